@@ -1,0 +1,369 @@
+"""Seeded synthetic inputs for the ORB hot path (datasets are absent: SURVEY.md F7, §8(d)).
+
+Pure numpy, deterministic per seed.  Used by tests/, bench.py and __graft_entry__.smoke().
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# reference configs (Examples/RGB-D/TUM1.yaml, Examples/Stereo/KITTI00-02.yaml, Examples/Stereo/EuRoC.yaml)
+CONFIGS = {
+    "tum": dict(w=640, h=480, nfeatures=1000, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, bf=40.0),
+    "kitti": dict(w=1241, h=376, nfeatures=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448),
+    "euroc": dict(w=752, h=480, nfeatures=1200, fx=435.2046959714599, fy=435.2046959714599, cx=367.4517211914062, cy=252.2008514404297, bf=47.90639384423901),
+}
+ORB_PARAMS = dict(scale_factor=1.2, nlevels=8, ini_th=20, min_th=7)
+
+
+def _value_noise(rng, h, w, cell, amp):
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.uniform(-amp, amp, size=(gh, gw)).astype(np.float32)
+    ys = (np.arange(h, dtype=np.float32) / cell)
+    xs = (np.arange(w, dtype=np.float32) / cell)
+    y0 = ys.astype(np.int32)
+    x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def synth_image(seed: int, w: int = 640, h: int = 480) -> np.ndarray:
+    """u8 grayscale test image: 3-octave value noise + rectangles (+ a low-contrast zone that
+    exercises the minThFAST fallback, src/ORBextractor.cc:812-816) + Gaussian pixel noise."""
+    rng = np.random.default_rng(np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(seed))
+    img = np.full((h, w), 118.0, dtype=np.float32)
+    img += _value_noise(rng, h, w, 64, 60)
+    img += _value_noise(rng, h, w, 16, 40)
+    img += _value_noise(rng, h, w, 4, 20)
+    n_rect = 400
+    cx = rng.integers(0, w, n_rect)
+    cy = rng.integers(0, h, n_rect)
+    sw = rng.integers(6, 61, n_rect)
+    sh = rng.integers(6, 61, n_rect)
+    val = rng.uniform(0, 255, n_rect).astype(np.float32)
+    rot = rng.uniform(0, np.pi, n_rect)
+    for i in range(n_rect):
+        x0, x1 = max(0, cx[i] - sw[i] // 2), min(w, cx[i] + sw[i] // 2)
+        y0, y1 = max(0, cy[i] - sh[i] // 2), min(h, cy[i] + sh[i] // 2)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        if i % 4 == 3:  # rotated rectangle
+            R = int(0.75 * max(sw[i], sh[i])) + 1
+            xa, xb = max(0, cx[i] - R), min(w, cx[i] + R)
+            ya, yb = max(0, cy[i] - R), min(h, cy[i] + R)
+            yy, xx = np.mgrid[ya:yb, xa:xb]
+            c, s = np.cos(rot[i]), np.sin(rot[i])
+            u = (xx - cx[i]) * c + (yy - cy[i]) * s
+            v = -(xx - cx[i]) * s + (yy - cy[i]) * c
+            m = (np.abs(u) <= sw[i] / 2) & (np.abs(v) <= sh[i] / 2)
+            img[ya:yb, xa:xb][m] = val[i]
+        else:
+            img[y0:y1, x0:x1] = val[i]
+    # low-contrast zone: smooth background + faint rectangles (contrast 9..18)
+    zx0, zx1, zy0, zy1 = 0, w // 3, (2 * h) // 3, h
+    zone = np.full((zy1 - zy0, zx1 - zx0), 100.0, dtype=np.float32)
+    for _ in range(30):
+        a = rng.integers(0, zx1 - zx0 - 8)
+        b = rng.integers(0, zy1 - zy0 - 8)
+        ww = rng.integers(6, 40)
+        hh = rng.integers(6, 40)
+        zone[b:b + hh, a:a + ww] += rng.uniform(9, 18) * rng.choice([-1.0, 1.0])
+    img[zy0:zy1, zx0:zx1] = zone
+    # one totally flat block (no corners at any threshold)
+    img[0:h // 6, (5 * w) // 6:w] = 77.0
+    noise = rng.normal(0.0, 3.0, size=(h, w)).astype(np.float32)
+    noise[zy0:zy1, zx0:zx1] *= 0.3
+    noise[0:h // 6, (5 * w) // 6:w] = 0.0
+    img += noise
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_batch(seed0: int, n: int, w: int = 640, h: int = 480) -> np.ndarray:
+    return np.stack([synth_image(seed0 + i, w, h) for i in range(n)], axis=0)
+
+
+# ----------------------------------------------------------------------------- matching
+def synth_descriptors(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def flip_bits(rng, desc, p=0.08):
+    """copy + flip each bit with probability p"""
+    bits = np.unpackbits(desc, axis=1)
+    flips = rng.random(bits.shape) < p
+    return np.packbits(bits ^ flips.astype(np.uint8), axis=1)
+
+
+def synth_bow_problem(seed: int, n_kf: int = 1000, n_f: int = 1000, n_nodes: int = 100,
+                      nnratio: float = 0.7, check_orientation: bool = True):
+    """Two descriptor sets with planted matches + FeatureVectors."""
+    rng = np.random.default_rng(1000 + seed)
+    desc_kf = synth_descriptors(rng, n_kf)
+    desc_f = synth_descriptors(rng, n_f)
+    node_kf = rng.integers(0, n_nodes, n_kf)
+    node_f = rng.integers(0, n_nodes, n_f)
+    angle_kf = rng.uniform(0, 360, n_kf).astype(np.float32)
+    angle_f = rng.uniform(0, 360, n_f).astype(np.float32)
+    n_pl = int(0.6 * min(n_kf, n_f))
+    src = rng.permutation(n_kf)[:n_pl]
+    dst = rng.permutation(n_f)[:n_pl]
+    desc_f[dst] = flip_bits(rng, desc_kf[src], 0.08)
+    same = rng.random(n_pl) < 0.9
+    node_f[dst[same]] = node_kf[src[same]]
+    dang = rng.normal(35.0, 5.0, n_pl).astype(np.float32)
+    angle_f[dst] = np.mod(angle_kf[src] - dang, 360.0).astype(np.float32)
+    kf_has_mp = (rng.random(n_kf) < 0.8).astype(np.uint8)
+
+    def fv(nodes):
+        order = np.argsort(nodes, kind="stable")
+        ids, counts = np.unique(nodes[order], return_counts=True)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        return ids.astype(np.int32), off, order.astype(np.int32)
+
+    id_kf, off_kf, idx_kf = fv(node_kf)
+    id_f, off_f, idx_f = fv(node_f)
+    return dict(desc_kf=desc_kf, desc_f=desc_f, kf_has_mp=kf_has_mp, angle_kf=angle_kf,
+                angle_f=angle_f, node_id_kf=id_kf, node_off_kf=off_kf, node_idx_kf=idx_kf,
+                node_id_f=id_f, node_off_f=off_f, node_idx_f=idx_f, nnratio=np.float32(nnratio),
+                check_orientation=int(check_orientation))
+
+
+GRID_COLS, GRID_ROWS = 64, 48  # include/Frame.h:37-38
+
+
+def build_grid(kp_x, kp_y, min_x, min_y, max_x, max_y):
+    """Frame::AssignFeaturesToGrid (src/Frame.cc:259-274) as CSR, cell = ix*48+iy."""
+    gw_inv = np.float32(GRID_COLS) / np.float32(max_x - min_x)
+    gh_inv = np.float32(GRID_ROWS) / np.float32(max_y - min_y)
+    px = np.round((kp_x - np.float32(min_x)) * gw_inv).astype(np.int64)   # round half away (x>=0)
+    py = np.round((kp_y - np.float32(min_y)) * gh_inv).astype(np.int64)
+    # C round() is half-away-from-zero; numpy rounds half to even -> redo exactly
+    fxv = (kp_x - np.float32(min_x)) * gw_inv
+    fyv = (kp_y - np.float32(min_y)) * gh_inv
+    px = np.where(fxv >= 0, np.floor(fxv + np.float32(0.5)), np.ceil(fxv - np.float32(0.5))).astype(np.int64)
+    py = np.where(fyv >= 0, np.floor(fyv + np.float32(0.5)), np.ceil(fyv - np.float32(0.5))).astype(np.int64)
+    ok = (px >= 0) & (px < GRID_COLS) & (py >= 0) & (py < GRID_ROWS)
+    cell = px * GRID_ROWS + py
+    idx = np.nonzero(ok)[0]
+    order = np.argsort(cell[idx], kind="stable")
+    idx = idx[order]
+    counts = np.bincount(cell[idx], minlength=GRID_COLS * GRID_ROWS)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return off, idx.astype(np.int32), np.float32(gw_inv), np.float32(gh_inv)
+
+
+def synth_frame_view(rng, n_f, w, h, n_levels=8, stereo=True, frac_with_obs=0.1):
+    kp_x = rng.uniform(20, w - 20, n_f).astype(np.float32)
+    kp_y = rng.uniform(20, h - 20, n_f).astype(np.float32)
+    octave = np.minimum(rng.geometric(0.35, n_f) - 1, n_levels - 1).astype(np.int32)
+    angle = rng.uniform(0, 360, n_f).astype(np.float32)
+    u_right = np.where(rng.random(n_f) < (0.7 if stereo else 0.0), kp_x - rng.uniform(2, 40, n_f), -1.0).astype(np.float32)
+    sf = (np.float32(1.2) ** np.arange(n_levels)).astype(np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(n_levels - 1, np.float32(1.2), np.float32)])).astype(np.float32)
+    min_x, min_y, max_x, max_y = np.float32(0), np.float32(0), np.float32(w), np.float32(h)
+    off, idx, gwi, ghi = build_grid(kp_x, kp_y, min_x, min_y, max_x, max_y)
+    state = rng.choice([0, 1, 2], size=n_f, p=[1 - frac_with_obs - 0.05, 0.05, frac_with_obs]).astype(np.uint8)
+    desc = synth_descriptors(rng, n_f)
+    return dict(n_f=n_f, desc_f=desc, kp_x=kp_x, kp_y=kp_y, kp_octave=octave, kp_angle=angle,
+                u_right=u_right, scale_factors=sf, n_levels=n_levels, min_x=min_x, min_y=min_y,
+                max_x=max_x, max_y=max_y, grid_w_inv=gwi, grid_h_inv=ghi, grid_off=off,
+                grid_idx=idx, f_mp_state=state)
+
+
+def synth_proj_mp_problem(seed: int, n_f: int = 1000, n_mp: int = 1500, w: int = 640, h: int = 480,
+                          th: float = 3.0, nnratio: float = 0.8):
+    """Frame + local map points with planted projections (SearchByProjection(F, vpMP, th))."""
+    rng = np.random.default_rng(2000 + seed)
+    f = synth_frame_view(rng, n_f, w, h)
+    tgt = rng.integers(0, n_f, n_mp)
+    proj_x = (f["kp_x"][tgt] + rng.normal(0, 1.5, n_mp)).astype(np.float32)
+    proj_y = (f["kp_y"][tgt] + rng.normal(0, 1.5, n_mp)).astype(np.float32)
+    ur = f["u_right"][tgt]
+    proj_xr = np.where(ur > 0, ur + rng.normal(0, 1.0, n_mp), proj_x - 10).astype(np.float32)
+    pred_level = np.clip(f["kp_octave"][tgt] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    desc = flip_bits(rng, f["desc_f"][tgt], 0.1)
+    rnd = rng.random(n_mp) < 0.25
+    desc[rnd] = synth_descriptors(rng, int(rnd.sum()))
+    mp = dict(n_mp=n_mp, track_in_view=(rng.random(n_mp) < 0.85).astype(np.uint8),
+              pred_level=pred_level, view_cos=rng.uniform(0.9, 1.0, n_mp).astype(np.float32),
+              proj_x=proj_x, proj_y=proj_y, proj_xr=proj_xr, desc=desc,
+              has_obs=(rng.random(n_mp) < 0.9).astype(np.uint8), th=np.float32(th),
+              nnratio=np.float32(nnratio))
+    return f, mp
+
+
+def synth_proj_last_problem(seed: int, n: int = 1000, w: int = 640, h: int = 480, cfg: str = "tum",
+                            th: float = 7.0, mono: bool = False, check_orientation: bool = True):
+    """Current frame + last frame map points (SearchByProjection(Cur, Last, th, bMono))."""
+    rng = np.random.default_rng(3000 + seed)
+    c = CONFIGS[cfg]
+    cur = synth_frame_view(rng, n, w, h)
+    fx, fy, cx, cy, bf = (np.float32(c[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
+    # current pose: small rotation + translation; last pose: identity-ish
+    def pose(rv, t):
+        th_ = np.linalg.norm(rv)
+        K = np.array([[0, -rv[2], rv[1]], [rv[2], 0, -rv[0]], [-rv[1], rv[0], 0]])
+        R = np.eye(3) + np.sin(th_) / th_ * K + (1 - np.cos(th_)) / th_ ** 2 * K @ K
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = t
+        return T.astype(np.float32)
+    fwd = [0.0, 0.0, -0.3, 0.3, 0.02][seed % 5]
+    Tcw = pose(np.array([0.01, -0.02, 0.015]), np.array([0.05, -0.02, fwd]))
+    Tlw = pose(np.array([0.001, 0.002, -0.001]), np.array([0.0, 0.0, 0.0]))
+    # world points that project onto current keypoints (+ jitter)
+    tgt = rng.integers(0, n, n)
+    z = rng.uniform(1.0, 12.0, n)
+    u = cur["kp_x"][tgt] + rng.normal(0, 2.0, n)
+    v = cur["kp_y"][tgt] + rng.normal(0, 2.0, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], axis=1)
+    R, t = Tcw[:3, :3].astype(np.float64), Tcw[:3, 3].astype(np.float64)
+    Xw = (Xc - t) @ R  # R^T (Xc - t)
+    behind = rng.random(n) < 0.03
+    Xw[behind] *= -1
+    desc = flip_bits(rng, cur["desc_f"][tgt], 0.1)
+    rnd = rng.random(n) < 0.2
+    desc[rnd] = synth_descriptors(rng, int(rnd.sum()))
+    last_angle = np.mod(cur["kp_angle"][tgt] + rng.normal(20, 6, n), 360).astype(np.float32)
+    p = dict(n_last=n, last_valid=(rng.random(n) < 0.8).astype(np.uint8),
+             world_pos=Xw.astype(np.float32), desc=desc,
+             last_octave=np.clip(cur["kp_octave"][tgt] + rng.integers(-1, 2, n), 0, 7).astype(np.int32),
+             last_angle=last_angle, has_obs=(rng.random(n) < 0.9).astype(np.uint8),
+             Tcw=Tcw.reshape(-1), Tlw=Tlw.reshape(-1), fx=fx, fy=fy, cx=cx, cy=cy,
+             mb=np.float32(bf / fx), mbf=bf, th=np.float32(th), mono=int(mono),
+             check_orientation=int(check_orientation))
+    return cur, p
+
+
+# ----------------------------------------------------------------------------- local BA
+def _rot_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        q = np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = np.zeros(4)
+        q[i] = 0.5 * s
+        s = 0.5 / s
+        q[3] = (R[k, j] - R[j, k]) * s
+        q[j] = (R[j, i] + R[i, j]) * s
+        q[k] = (R[k, i] + R[i, k]) * s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def synth_lba_problem(seed: int, n_local: int = 20, n_fixed: int = 30, n_points: int = 4000,
+                      obs_per_point: int = 6, cfg: str = "kitti", stereo_frac: float = 1.0,
+                      outlier_frac: float = 0.05, include_kf0: bool = False):
+    """Keyframes on an arc looking forward, points in a box ahead; float32 inputs like the reference
+    (KeyFrame::GetPose / MapPoint::GetWorldPos are float32 cv::Mat).  SURVEY §8(d)."""
+    rng = np.random.default_rng(4000 + seed)
+    c = CONFIGS[cfg]
+    fx, fy, cx, cy, bf = c["fx"], c["fy"], c["cx"], c["cy"], c["bf"]
+    W, H = c["w"], c["h"]
+    n_poses = n_local + n_fixed
+    Twc_true = []
+    for i in range(n_poses):
+        s = i / max(n_poses - 1, 1)
+        ang = 0.6 * s  # arc
+        Rwc = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        twc = np.array([40.0 * np.sin(ang) * 0.8, 0.05 * np.sin(7 * s), 40.0 * s * 0.8])
+        Twc_true.append((Rwc, twc))
+    # points: sample in front of random keyframes
+    pts = np.zeros((n_points, 3))
+    for j in range(n_points):
+        k = rng.integers(0, n_poses)
+        Rwc, twc = Twc_true[k]
+        z = rng.uniform(4.0, 40.0)
+        u = rng.uniform(0, W)
+        v = rng.uniform(0, H)
+        Xc = np.array([(u - cx) / fx * z, (v - cy) / fy * z, z])
+        pts[j] = Rwc @ Xc + twc
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    inv_sigma2_lv = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    # order poses: local first then fixed (local = the last n_local keyframes, like a sliding window)
+    order = list(range(n_fixed, n_poses)) + list(range(0, n_fixed))
+    pose_id = np.array(order, dtype=np.int64) + (0 if include_kf0 else 1)
+    pose_fixed = np.array([0] * n_local + [1] * n_fixed, dtype=np.uint8)
+    if include_kf0:
+        pose_fixed[pose_id == 0] = 1
+    edge_pose, edge_point, edge_obs, edge_stereo, edge_is2 = [], [], [], [], []
+    used_pts = []
+    for j in range(n_points):
+        vis = []
+        for slot, k in enumerate(order):
+            Rwc, twc = Twc_true[k]
+            Xc = Rwc.T @ (pts[j] - twc)
+            if Xc[2] < 1.0:
+                continue
+            u = fx * Xc[0] / Xc[2] + cx
+            v = fy * Xc[1] / Xc[2] + cy
+            if 0 <= u < W and 0 <= v < H:
+                vis.append((slot, u, v, Xc[2]))
+        if len(vis) < 2:
+            continue
+        sel = rng.permutation(len(vis))[:obs_per_point]
+        sel.sort()
+        if not any(vis[s][0] < n_local for s in sel):
+            continue  # a local map point must be seen by a local keyframe
+        pj = len(used_pts)
+        used_pts.append(j)
+        for s in sel:
+            slot, u, v, z = vis[s]
+            lvl = int(min(7, rng.geometric(0.4) - 1))
+            sig = float(sf[lvl])
+            out = rng.random() < outlier_frac
+            du, dv = rng.normal(0, sig, 2)
+            if out:
+                du += rng.uniform(20, 80) * rng.choice([-1, 1])
+                dv += rng.uniform(20, 80) * rng.choice([-1, 1])
+            is_st = rng.random() < stereo_frac
+            ur = (u + du) - bf / z + rng.normal(0, sig) if is_st else -1.0
+            edge_pose.append(slot)
+            edge_point.append(pj)
+            edge_obs.append((np.float32(u + du), np.float32(v + dv), np.float32(ur)))
+            edge_stereo.append(1 if is_st else 0)
+            edge_is2.append(inv_sigma2_lv[lvl])
+    used = np.array(used_pts, dtype=np.int64)
+    P = pts[used]
+    # perturb and convert to float32 inputs
+    Tcw = np.zeros((n_poses, 4, 4), dtype=np.float32)
+    for slot, k in enumerate(order):
+        Rwc, twc = Twc_true[k]
+        Rcw, tcw = Rwc.T, -Rwc.T @ twc
+        if not pose_fixed[slot]:
+            rv = rng.normal(0, 0.02 / np.sqrt(3), 3)
+            th_ = np.linalg.norm(rv)
+            K = np.array([[0, -rv[2], rv[1]], [rv[2], 0, -rv[0]], [-rv[1], rv[0], 0]])
+            dR = np.eye(3) + np.sin(th_) / th_ * K + (1 - np.cos(th_)) / th_ ** 2 * K @ K
+            Rcw = dR @ Rcw
+            tcw = tcw + rng.normal(0, 0.1 / np.sqrt(3), 3)
+        Tcw[slot, :3, :3] = Rcw
+        Tcw[slot, :3, 3] = tcw
+        Tcw[slot, 3, 3] = 1
+    Pn = (P + rng.normal(0, 0.05, P.shape)).astype(np.float32)
+    return dict(n_poses=n_poses, n_points=len(used), n_edges=len(edge_pose),
+                pose_Tcw=Tcw.reshape(n_poses, 16), pose_fixed=pose_fixed, pose_id=pose_id,
+                point_xyz=Pn, point_id=np.arange(len(used), dtype=np.int64) * 3 + 7,
+                edge_pose=np.array(edge_pose, np.int32), edge_point=np.array(edge_point, np.int32),
+                edge_obs=np.array(edge_obs, np.float32).reshape(-1, 3),
+                edge_stereo=np.array(edge_stereo, np.uint8),
+                edge_inv_sigma2=np.array(edge_is2, np.float32),
+                fx=fx, fy=fy, cx=cx, cy=cy, bf=bf)
+
+
+def tcw_to_qt(Tcw16):
+    """Converter::toSE3Quat (src/Converter.cc:37-47): float32 4x4 -> (qx qy qz qw tx ty tz) double."""
+    T = np.asarray(Tcw16, dtype=np.float32).reshape(4, 4).astype(np.float64)
+    q = _rot_to_quat(T[:3, :3])
+    return np.concatenate([q, T[:3, 3]])

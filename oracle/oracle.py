@@ -1,0 +1,419 @@
+"""ctypes binding of the ORACLE library (test infrastructure only; PARITY UNPINNED).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborb_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        for name in ("scale_factors", "inv_scale_factors", "sigma2", "inv_sigma2"):
+            f = getattr(L, "orc_extractor_" + name)
+            f.restype = C.POINTER(C.c_float)
+            f.argtypes = [C.c_void_p]
+        for name in ("features_per_level", "umax"):
+            f = getattr(L, "orc_extractor_" + name)
+            f.restype = C.POINTER(C.c_int)
+            f.argtypes = [C.c_void_p]
+        L.orc_extractor_levels.argtypes = [C.c_void_p]
+        L.orc_extractor_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_extractor_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_extractor_level_plane.restype = C.c_void_p
+        L.orc_extractor_level_plane.argtypes = [C.c_void_p, C.c_int]
+        L.orc_extractor_level_blurred.restype = C.c_void_p
+        L.orc_extractor_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.orc_extractor_level_candidates.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+                                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.orc_extractor_level_nkeys.argtypes = [C.c_void_p, C.c_int]
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_fast_corner_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_copy_make_border_reflect101.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_mp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_se3_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_quat_from_rot.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_rot_from_quat.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pose_from_Tcw_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pose_to_Tcw_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_edge_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_void_p] * 3
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """ORBextractor restatement (reference src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.orc_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_extractor_destroy(self.h)
+            self.h = None
+
+    def _farr(self, name, n, ct=np.float32):
+        ptr = getattr(self.L, "orc_extractor_" + name)(self.h)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(ct).copy()
+
+    @property
+    def scale_factors(self):
+        return self._farr("scale_factors", self.nlevels)
+
+    @property
+    def inv_scale_factors(self):
+        return self._farr("inv_scale_factors", self.nlevels)
+
+    @property
+    def sigma2(self):
+        return self._farr("sigma2", self.nlevels)
+
+    @property
+    def inv_sigma2(self):
+        return self._farr("inv_sigma2", self.nlevels)
+
+    @property
+    def features_per_level(self):
+        return self._farr("features_per_level", self.nlevels, np.int32)
+
+    @property
+    def umax(self):
+        return self._farr("umax", 16, np.int32)
+
+    def extract(self, img: np.ndarray, cap: int | None = None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = cap or (self.nfeatures * 2 + 64)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        st = self.L.orc_extractor_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap, C.byref(n))
+        if st != 0:
+            raise RuntimeError(f"oracle extract failed: {st}")
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        pitch = self.L.orc_extractor_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value, pitch
+
+    def level_plane(self, level):
+        w, h, pitch = self.level_size(level)
+        ptr = self.L.orc_extractor_level_plane(self.h, level)
+        buf = (C.c_uint8 * (pitch * h)).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.uint8, count=pitch * (h - 1) + w)
+        return np.lib.stride_tricks.as_strided(a, shape=(h, w), strides=(pitch, 1)).copy()
+
+    def level_blurred(self, level):
+        w, h, _ = self.level_size(level)
+        ptr = self.L.orc_extractor_level_blurred(self.h, level)
+        buf = (C.c_uint8 * (w * h)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h, w).copy()
+
+    def level_candidates(self, level):
+        xs, ys, sc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = self.L.orc_extractor_level_candidates(self.h, level, C.byref(xs), C.byref(ys), C.byref(sc))
+        if n <= 0:
+            return (np.zeros(0, np.int16),) * 2 + (np.zeros(0, np.uint8),)
+        x = np.frombuffer((C.c_int16 * n).from_address(xs.value), dtype=np.int16).copy()
+        y = np.frombuffer((C.c_int16 * n).from_address(ys.value), dtype=np.int16).copy()
+        s = np.frombuffer((C.c_uint8 * n).from_address(sc.value), dtype=np.uint8).copy()
+        return x, y, s
+
+    def level_nkeys(self, level):
+        return self.L.orc_extractor_level_nkeys(self.h, level)
+
+
+def fast9_16(img, threshold):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xs = np.zeros(cap, np.int16)
+    ys = np.zeros(cap, np.int16)
+    sc = np.zeros(cap, np.uint8)
+    n = lib().orc_fast9_16(_p(img), w, h, img.strides[0], threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_corner_score(img, x, y, threshold):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    addr = img.ctypes.data + y * img.strides[0] + x
+    return lib().orc_fast_corner_score(C.c_void_p(addr), img.strides[0], threshold)
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(float(y), float(x)))
+
+
+def cv_round(v):
+    return int(lib().orc_cv_round_f(float(v)))
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), sw, sh, src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_u8(_p(src), w, h, src.strides[0], _p(dst), w)
+    return dst
+
+
+def copy_make_border(src, border=19):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().orc_copy_make_border_reflect101(_p(src), w, h, src.strides[0], _p(dst), border, w + 2 * border)
+    return dst
+
+
+def distribute_octree(xs, ys, resp, minX, maxX, minY, maxY, N):
+    xs = np.ascontiguousarray(xs, np.float32)
+    ys = np.ascontiguousarray(ys, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    n = len(xs)
+    out = np.zeros(max(n, 1), np.int32)
+    k = lib().orc_distribute_octree(_p(xs), _p(ys), _p(resp), n, minX, maxX, minY, maxY, N, _p(out), len(out))
+    return out[:k].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+# ---------------------------------------------------------------------------- matcher structs
+class _BowProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int), ("n_f", C.c_int), ("desc_kf", C.c_void_p), ("desc_f", C.c_void_p),
+                ("kf_has_mp", C.c_void_p), ("angle_kf", C.c_void_p), ("angle_f", C.c_void_p),
+                ("n_nodes_kf", C.c_int), ("n_nodes_f", C.c_int),
+                ("node_id_kf", C.c_void_p), ("node_off_kf", C.c_void_p), ("node_idx_kf", C.c_void_p),
+                ("node_id_f", C.c_void_p), ("node_off_f", C.c_void_p), ("node_idx_f", C.c_void_p),
+                ("nnratio", C.c_float), ("check_orientation", C.c_int)]
+
+
+class _FrameView(C.Structure):
+    _fields_ = [("n_f", C.c_int), ("desc_f", C.c_void_p), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p),
+                ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p), ("u_right", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("n_levels", C.c_int),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float),
+                ("grid_off", C.c_void_p), ("grid_idx", C.c_void_p), ("f_mp_state", C.c_void_p)]
+
+
+class _ProjMp(C.Structure):
+    _fields_ = [("n_mp", C.c_int), ("track_in_view", C.c_void_p), ("pred_level", C.c_void_p),
+                ("view_cos", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p),
+                ("proj_xr", C.c_void_p), ("desc", C.c_void_p), ("has_obs", C.c_void_p),
+                ("th", C.c_float), ("nnratio", C.c_float)]
+
+
+class _ProjLast(C.Structure):
+    _fields_ = [("n_last", C.c_int), ("last_valid", C.c_void_p), ("world_pos", C.c_void_p),
+                ("desc", C.c_void_p), ("last_octave", C.c_void_p), ("last_angle", C.c_void_p),
+                ("has_obs", C.c_void_p), ("Tcw", C.c_float * 16), ("Tlw", C.c_float * 16),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mb", C.c_float), ("mbf", C.c_float), ("th", C.c_float),
+                ("mono", C.c_int), ("check_orientation", C.c_int)]
+
+
+def _fill(struct, d, keep):
+    for name, ct in struct._fields_:
+        if name not in d:
+            continue
+        v = d[name]
+        if isinstance(v, np.ndarray) and ct is C.c_void_p:
+            v = np.ascontiguousarray(v)
+            keep.append(v)
+            setattr(struct, name, v.ctypes.data)
+        elif isinstance(v, np.ndarray):
+            arr = (C.c_float * 16)(*[float(x) for x in v.reshape(-1)])
+            setattr(struct, name, arr)
+        else:
+            setattr(struct, name, v.item() if hasattr(v, "item") else v)
+
+
+def search_by_bow(p: dict):
+    keep = []
+    s = _BowProblem()
+    d = dict(p)
+    d["n_kf"] = len(p["desc_kf"])
+    d["n_f"] = len(p["desc_f"])
+    d["n_nodes_kf"] = len(p["node_id_kf"])
+    d["n_nodes_f"] = len(p["node_id_f"])
+    _fill(s, d, keep)
+    match = np.zeros(d["n_f"], np.int32)
+    n = lib().orc_search_by_bow(C.byref(s), _p(match))
+    return n, match
+
+
+def _frame_view(f: dict, keep):
+    s = _FrameView()
+    _fill(s, f, keep)
+    return s
+
+
+def search_by_projection_mp(f: dict, mp: dict):
+    keep = []
+    fv = _frame_view(f, keep)
+    s = _ProjMp()
+    _fill(s, mp, keep)
+    match = np.zeros(f["n_f"], np.int32)
+    n = lib().orc_search_by_projection_mp(C.byref(fv), C.byref(s), _p(match))
+    return n, match
+
+
+def search_by_projection_last(cur: dict, p: dict):
+    keep = []
+    fv = _frame_view(cur, keep)
+    s = _ProjLast()
+    _fill(s, p, keep)
+    match = np.zeros(cur["n_f"], np.int32)
+    n = lib().orc_search_by_projection_last(C.byref(fv), C.byref(s), _p(match))
+    return n, match
+
+
+# ---------------------------------------------------------------------------- local BA
+class _LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("pose_qt", C.c_void_p), ("pose_fixed", C.c_void_p), ("pose_id", C.c_void_p),
+                ("point_xyz", C.c_void_p), ("point_id", C.c_void_p),
+                ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p),
+                ("edge_stereo", C.c_void_p), ("edge_inv_sigma2", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("bf", C.c_double), ("stop_flag", C.c_void_p), ("iters1", C.c_int), ("iters2", C.c_int)]
+
+
+class _LbaResult(C.Structure):
+    _fields_ = [("edge_chi2", C.c_void_p), ("edge_depth_pos", C.c_void_p), ("edge_outlier", C.c_void_p),
+                ("edge_level1", C.c_void_p), ("lambda_trace", C.c_double * 64),
+                ("chi2_trace", C.c_double * 64), ("n_trace", C.c_int),
+                ("iters_done1", C.c_int), ("iters_done2", C.c_int)]
+
+
+def pose_from_Tcw(T16):
+    T = np.ascontiguousarray(T16, np.float32).reshape(16)
+    qt = np.zeros(7, np.float64)
+    lib().orc_pose_from_Tcw_f32(_p(T), _p(qt))
+    return qt
+
+
+def pose_to_Tcw(qt):
+    qt = np.ascontiguousarray(qt, np.float64)
+    T = np.zeros(16, np.float32)
+    lib().orc_pose_to_Tcw_f32(_p(qt), _p(T))
+    return T
+
+
+def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
+    """Runs the LocalBA numerical core on a synth_lba_problem()-style dict with float32 inputs.
+    Returns dict with float32 write-back poses/points like Optimizer.cc:763-778."""
+    n_poses, n_points, n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
+    qt = np.stack([pose_from_Tcw(prob["pose_Tcw"][i]) for i in range(n_poses)]).astype(np.float64)
+    pts = np.ascontiguousarray(prob["point_xyz"], np.float32).astype(np.float64)  # Converter::toVector3d
+    obs = np.ascontiguousarray(prob["edge_obs"], np.float32).astype(np.float64)
+    keep = [qt, pts, obs]
+    s = _LbaProblem()
+    s.n_poses, s.n_points, s.n_edges = n_poses, n_points, n_edges
+    s.pose_qt = qt.ctypes.data
+    s.point_xyz = pts.ctypes.data
+    s.edge_obs = obs.ctypes.data
+    for name, dt in (("pose_fixed", np.uint8), ("pose_id", np.int64), ("point_id", np.int64),
+                     ("edge_pose", np.int32), ("edge_point", np.int32), ("edge_stereo", np.uint8),
+                     ("edge_inv_sigma2", np.float32)):
+        a = np.ascontiguousarray(prob[name], dt)
+        keep.append(a)
+        setattr(s, name, a.ctypes.data)
+    s.fx, s.fy, s.cx, s.cy, s.bf = (float(prob[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
+    if stop_flag is not None:
+        keep.append(stop_flag)
+        s.stop_flag = stop_flag.ctypes.data
+    s.iters1, s.iters2 = iters1, iters2
+    r = _LbaResult()
+    chi2 = np.zeros(n_edges, np.float64)
+    dpos = np.zeros(n_edges, np.uint8)
+    outl = np.zeros(n_edges, np.uint8)
+    lvl1 = np.zeros(n_edges, np.uint8)
+    r.edge_chi2, r.edge_depth_pos, r.edge_outlier, r.edge_level1 = (a.ctypes.data for a in (chi2, dpos, outl, lvl1))
+    st = lib().orc_lba_solve(C.byref(s), C.byref(r))
+    Tout = np.stack([pose_to_Tcw(qt[i]) for i in range(n_poses)])
+    return dict(status=st, pose_qt=qt, pose_Tcw=Tout, point_xyz=pts.astype(np.float32), point_xyz64=pts,
+                edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier=outl, edge_level1=lvl1,
+                lambda_trace=np.array(r.lambda_trace[: r.n_trace]), chi2_trace=np.array(r.chi2_trace[: r.n_trace]),
+                iters=(r.iters_done1, r.iters_done2))
+
+
+def se3_exp(upd):
+    upd = np.ascontiguousarray(upd, np.float64)
+    out = np.zeros(7)
+    lib().orc_se3_exp(_p(upd), _p(out))
+    return out
+
+
+def se3_mul(a, b):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    out = np.zeros(7)
+    lib().orc_se3_mul(_p(a), _p(b), _p(out))
+    return out
+
+
+def edge_linearize(qt, xyz, obs, stereo, fx, fy, cx, cy, bf):
+    qt = np.ascontiguousarray(qt, np.float64)
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    err, Ji, Jj = np.zeros(3), np.zeros(9), np.zeros(18)
+    lib().orc_edge_linearize(_p(qt), _p(xyz), _p(obs), int(stereo), fx, fy, cx, cy, bf, _p(err), _p(Ji), _p(Jj))
+    return err, Ji.reshape(3, 3), Jj.reshape(3, 6)

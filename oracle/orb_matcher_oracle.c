@@ -1,0 +1,327 @@
+/*
+ * ORACLE (test infrastructure only; PARITY UNPINNED, see orb_oracle.h).
+ *
+ * CPU restatement of the ORBmatcher hot-path methods (reference src/ORBmatcher.cc) over plain
+ * SoA snapshots of the Frame/KeyFrame/MapPoint fields they read.
+ * Build with -ffp-contract=off.
+ */
+#include "orb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TH_HIGH 100      /* src/ORBmatcher.cc:37 */
+#define TH_LOW 50        /* :38 */
+#define HISTO_LENGTH 30  /* :39 */
+#define FRAME_GRID_ROWS 48 /* include/Frame.h:37 */
+#define FRAME_GRID_COLS 64 /* include/Frame.h:38 */
+
+/* DescriptorDistance :1647-1663 */
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* rotation histogram as growable int vectors */
+typedef struct { int *v; int n, cap; } ivec_t;
+static void iv_push(ivec_t *a, int x)
+{
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 64;
+        a->v = (int *)realloc(a->v, sizeof(int) * a->cap);
+    }
+    a->v[a->n++] = x;
+}
+
+/* ComputeThreeMaxima :1601-1642 */
+static void compute_three_maxima(const ivec_t *histo, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i].n;
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            *ind3 = *ind2; *ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            *ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        *ind2 = -1;
+        *ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        *ind3 = -1;
+    }
+}
+
+static int rot_bin(float rot)
+{
+    const float factor = 1.0f / HISTO_LENGTH; /* quirk kept: :172 */
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+/* SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) :159-288 */
+int orc_search_by_bow(const orc_bow_problem_t *p, int32_t *match_f)
+{
+    for (int i = 0; i < p->n_f; ++i) match_f[i] = -1;
+    int nmatches = 0;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    int ik = 0, jf = 0;
+    while (ik < p->n_nodes_kf && jf < p->n_nodes_f) {
+        int idk = p->node_id_kf[ik], idf = p->node_id_f[jf];
+        if (idk == idf) {
+            for (int a = p->node_off_kf[ik]; a < p->node_off_kf[ik + 1]; ++a) {
+                const int realIdxKF = p->node_idx_kf[a];
+                if (!p->kf_has_mp[realIdxKF]) continue;
+                const uint8_t *dKF = p->desc_kf + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int b = p->node_off_f[jf]; b < p->node_off_f[jf + 1]; ++b) {
+                    const int realIdxF = p->node_idx_f[b];
+                    if (match_f[realIdxF] >= 0) continue;
+                    const int dist = orc_descriptor_distance(dKF, p->desc_f + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < p->nnratio * (float)bestDist2) {
+                        match_f[bestIdxF] = realIdxKF;
+                        if (p->check_orientation) {
+                            float rot = p->angle_kf[realIdxKF] - p->angle_f[bestIdxF];
+                            iv_push(&rotHist[rot_bin(rot)], bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            ik++;
+            jf++;
+        } else if (idk < idf) {
+            while (ik < p->n_nodes_kf && p->node_id_kf[ik] < idf) ik++; /* lower_bound */
+        } else {
+            while (jf < p->n_nodes_f && p->node_id_f[jf] < idk) jf++;
+        }
+    }
+    if (p->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) {
+                match_f[rotHist[i].v[j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    return nmatches;
+}
+
+/* Frame::GetFeaturesInArea src/Frame.cc:356-409 ; returns count into out */
+static int features_in_area(const orc_frame_view_t *f, float x, float y, float r, int minLevel,
+                            int maxLevel, int *out)
+{
+    int n = 0;
+    const int nMinCellX0 = (int)floorf((x - f->min_x - r) * f->grid_w_inv);
+    const int nMinCellX = nMinCellX0 > 0 ? nMinCellX0 : 0;
+    if (nMinCellX >= FRAME_GRID_COLS) return 0;
+    const int nMaxCellX0 = (int)ceilf((x - f->min_x + r) * f->grid_w_inv);
+    const int nMaxCellX = nMaxCellX0 < FRAME_GRID_COLS - 1 ? nMaxCellX0 : FRAME_GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    const int nMinCellY0 = (int)floorf((y - f->min_y - r) * f->grid_h_inv);
+    const int nMinCellY = nMinCellY0 > 0 ? nMinCellY0 : 0;
+    if (nMinCellY >= FRAME_GRID_ROWS) return 0;
+    const int nMaxCellY0 = (int)ceilf((y - f->min_y + r) * f->grid_h_inv);
+    const int nMaxCellY = nMaxCellY0 < FRAME_GRID_ROWS - 1 ? nMaxCellY0 : FRAME_GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            int c = ix * FRAME_GRID_ROWS + iy;
+            for (int j = f->grid_off[c]; j < f->grid_off[c + 1]; ++j) {
+                int idx = f->grid_idx[j];
+                if (bCheckLevels) {
+                    if (f->kp_octave[idx] < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (f->kp_octave[idx] > maxLevel) continue;
+                }
+                const float distx = f->kp_x[idx] - x;
+                const float disty = f->kp_y[idx] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) out[n++] = idx;
+            }
+        }
+    }
+    return n;
+}
+
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th) :45-129 */
+int orc_search_by_projection_mp(const orc_frame_view_t *f, const orc_proj_mp_problem_t *p,
+                                int32_t *match_f)
+{
+    int nmatches = 0;
+    const int bFactor = p->th != 1.0;
+    uint8_t *state = (uint8_t *)malloc(f->n_f ? f->n_f : 1);
+    memcpy(state, f->f_mp_state, f->n_f);
+    for (int i = 0; i < f->n_f; ++i) match_f[i] = -1;
+    int *vIndices = (int *)malloc(sizeof(int) * (f->n_f ? f->n_f : 1));
+    for (int iMP = 0; iMP < p->n_mp; iMP++) {
+        if (!p->track_in_view[iMP]) continue;
+        const int nPredictedLevel = p->pred_level[iMP];
+        float r = p->view_cos[iMP] > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos :131-137 */
+        if (bFactor) r *= p->th;
+        const int nInd = features_in_area(f, p->proj_x[iMP], p->proj_y[iMP],
+                                          r * f->scale_factors[nPredictedLevel],
+                                          nPredictedLevel - 1, nPredictedLevel, vIndices);
+        if (nInd == 0) continue;
+        const uint8_t *MPdescriptor = p->desc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int idx = vIndices[k];
+            if (state[idx] == 2) continue;
+            if (f->u_right[idx] > 0) {
+                const float er = fabsf(p->proj_xr[iMP] - f->u_right[idx]);
+                if (er > r * f->scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = orc_descriptor_distance(MPdescriptor, f->desc_f + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = f->kp_octave[idx];
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = f->kp_octave[idx];
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > p->nnratio * bestDist2) continue;
+            match_f[bestIdx] = iMP;
+            state[bestIdx] = p->has_obs[iMP] ? 2 : 1;
+            nmatches++;
+        }
+    }
+    free(state);
+    free(vIndices);
+    return nmatches;
+}
+
+/* SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) :1328-1470 */
+int orc_search_by_projection_last(const orc_frame_view_t *cur, const orc_proj_last_problem_t *p,
+                                  int32_t *match_f)
+{
+    int nmatches = 0;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    const float *T = p->Tcw, *Tl = p->Tlw;
+    /* twc = -Rcw^T * tcw ; tlc = Rlw*twc + tlw  (cv::Mat float arithmetic, :1339-1346) */
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; ++i) {
+        /* cv::gemm general path (GEMM_1_T, alpha=-1): double accumulation, then cast */
+        double s = (double)T[0 * 4 + i] * (double)T[3] + (double)T[1 * 4 + i] * (double)T[7] +
+                   (double)T[2 * 4 + i] * (double)T[11];
+        twc[i] = (float)(s * -1.0);
+    }
+    for (int i = 0; i < 3; ++i) {
+        float s = Tl[i * 4 + 0] * twc[0] + Tl[i * 4 + 1] * twc[1] + Tl[i * 4 + 2] * twc[2];
+        tlc[i] = s + Tl[i * 4 + 3];
+    }
+    const int bForward = tlc[2] > p->mb && !p->mono;
+    const int bBackward = -tlc[2] > p->mb && !p->mono;
+
+    uint8_t *state = (uint8_t *)malloc(cur->n_f ? cur->n_f : 1);
+    memcpy(state, cur->f_mp_state, cur->n_f);
+    for (int i = 0; i < cur->n_f; ++i) match_f[i] = -1;
+    int *vIndices2 = (int *)malloc(sizeof(int) * (cur->n_f ? cur->n_f : 1));
+
+    for (int i = 0; i < p->n_last; i++) {
+        if (!p->last_valid[i]) continue;
+        const float *X = p->world_pos + 3 * (size_t)i;
+        float x3Dc[3];
+        for (int r = 0; r < 3; ++r) {
+            float s = T[r * 4 + 0] * X[0] + T[r * 4 + 1] * X[1] + T[r * 4 + 2] * X[2];
+            x3Dc[r] = s + T[r * 4 + 3];
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (invzc < 0) continue;
+        float u = p->fx * xc * invzc + p->cx;
+        float v = p->fy * yc * invzc + p->cy;
+        if (u < cur->min_x || u > cur->max_x) continue;
+        if (v < cur->min_y || v > cur->max_y) continue;
+        int nLastOctave = p->last_octave[i];
+        float radius = p->th * cur->scale_factors[nLastOctave];
+        int nInd;
+        if (bForward)
+            nInd = features_in_area(cur, u, v, radius, nLastOctave, -1, vIndices2);
+        else if (bBackward)
+            nInd = features_in_area(cur, u, v, radius, 0, nLastOctave, vIndices2);
+        else
+            nInd = features_in_area(cur, u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices2);
+        if (nInd == 0) continue;
+        const uint8_t *dMP = p->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int i2 = vIndices2[k];
+            if (state[i2] == 2) continue;
+            if (cur->u_right[i2] > 0) {
+                const float ur = u - p->mbf * invzc;
+                const float er = fabsf(ur - cur->u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(dMP, cur->desc_f + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            match_f[bestIdx2] = i;
+            state[bestIdx2] = p->has_obs[i] ? 2 : 1;
+            nmatches++;
+            if (p->check_orientation) {
+                float rot = p->last_angle[i] - cur->kp_angle[bestIdx2];
+                iv_push(&rotHist[rot_bin(rot)], bestIdx2);
+            }
+        }
+    }
+    if (p->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (int j = 0; j < rotHist[i].n; j++) {
+                    match_f[rotHist[i].v[j]] = -2; /* set to NULL by the cull (:1459) */
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    free(state);
+    free(vIndices2);
+    return nmatches;
+}
