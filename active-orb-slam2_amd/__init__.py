@@ -1,0 +1,7 @@
+"""MI355X-native ORB front-end + LocalBA hot path of Active-ORB-SLAM2 (C-ABI HIP library + bindings).
+
+The directory name contains '-', so import it through `__graft_entry__.load_package()` (or
+importlib) under the module name `active_orb_slam2_amd`.
+"""
+from . import capi, synth  # noqa: F401
+from .capi import (Extractor, Matcher, LocalBA, LibraryMissing, AosError, device_count, lib_path)  # noqa: F401

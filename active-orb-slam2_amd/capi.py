@@ -1,0 +1,257 @@
+"""ctypes binding of the C ABI declared in include/aos2.h (lib/libaos2.so, built by csrc/Makefile).
+
+This is plumbing: numpy arrays in, numpy arrays out, every call goes through the extern "C" entry
+points a C++/cgo/JNI caller would use.  There is no Python or CPU fallback: a missing library
+raises LibraryMissing, a missing GPU surfaces as AosError(AOS2_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+AOS2_OK = 0
+AOS2_ERR_ARG, AOS2_ERR_CAPACITY, AOS2_ERR_TOO_SMALL, AOS2_ERR_HIP, AOS2_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+AOS2_ERR_STOPPED = 1
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class AosError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"aos2 error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libaos2.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise LibraryMissing(f"{p} not found: build it with `make -C {_HERE}/csrc` "
+                                 "(__graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(p)
+        L.aos2_last_error.restype = C.c_char_p
+        L.aos2_version.restype = C.c_char_p
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        L.aos2_extractor_create.argtypes = [ci, cf, ci, ci, ci, ci, C.POINTER(vp)]
+        L.aos2_extractor_destroy.argtypes = [vp]
+        L.aos2_extractor_levels.argtypes = [vp]
+        L.aos2_extractor_scale_factor.argtypes = [vp]
+        L.aos2_extractor_scale_factor.restype = cf
+        for n in ("scale_factors", "inv_scale_factors", "sigma2", "inv_sigma2"):
+            f = getattr(L, "aos2_extractor_" + n)
+            f.argtypes = [vp]
+            f.restype = C.POINTER(cf)
+        for n in ("features_per_level", "umax"):
+            f = getattr(L, "aos2_extractor_" + n)
+            f.argtypes = [vp]
+            f.restype = C.POINTER(ci)
+        L.aos2_extractor_max_keypoints.argtypes = [vp]
+        L.aos2_extractor_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, C.POINTER(ci)]
+        L.aos2_extractor_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+        L.aos2_extractor_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+        L.aos2_extractor_pyramid_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.aos2_extractor_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
+        L.aos2_extractor_debug_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(ci)]
+        L.aos2_extractor_last_timing.argtypes = [vp, vp, ci]
+        L.aos2_extractor_bench_fast.argtypes = [vp, ci, C.POINTER(cf)]
+        L.aos2_extractor_bench_describe.argtypes = [vp, ci, C.POINTER(cf)]
+        L.aos2_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
+        L.aos2_debug_sincos_host.argtypes = [cf, C.POINTER(cf), C.POINTER(cf)]
+        L.aos2_debug_sincos_device.argtypes = [vp, ci, vp, vp, ci]
+        if hasattr(L, "aos2_matcher_create"):
+            L.aos2_matcher_create.argtypes = [cf, ci, ci, C.POINTER(vp)]
+            L.aos2_matcher_destroy.argtypes = [vp]
+            L.aos2_descriptor_distance.argtypes = [vp, vp]
+            L.aos2_matcher_hamming_best2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
+            L.aos2_matcher_hamming_best2_device.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, C.POINTER(cf)]
+            L.aos2_matcher_search_by_bow.argtypes = [vp, vp, ci, vp, vp]
+            L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
+            L.aos2_matcher_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, vp, vp]
+        if hasattr(L, "aos2_lba_create"):
+            L.aos2_lba_create.argtypes = [ci, C.POINTER(vp)]
+            L.aos2_lba_destroy.argtypes = [vp]
+            L.aos2_lba_solve.argtypes = [vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def _check(st, ok=(AOS2_OK,)):
+    if st not in ok:
+        raise AosError(st, lib().aos2_last_error().decode(errors="replace"))
+    return st
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().aos2_device_count()
+
+
+class Extractor:
+    """Mirror of ORBextractor (include/ORBextractor.h:45-111): ctor args, operator(), getters."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.aos2_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th, device, C.byref(h)))
+        self.h = h
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aos2_extractor_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _arr(self, name, n, dt):
+        ptr = getattr(self.L, "aos2_extractor_" + name)(self.h)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy()
+
+    # GetLevels / GetScaleFactor(s) / ... (include/ORBextractor.h:58-83)
+    def GetLevels(self):
+        return self.L.aos2_extractor_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.aos2_extractor_scale_factor(self.h)
+
+    def GetScaleFactors(self):
+        return self._arr("scale_factors", self.nlevels, np.float32)
+
+    def GetInverseScaleFactors(self):
+        return self._arr("inv_scale_factors", self.nlevels, np.float32)
+
+    def GetScaleSigmaSquares(self):
+        return self._arr("sigma2", self.nlevels, np.float32)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._arr("inv_sigma2", self.nlevels, np.float32)
+
+    @property
+    def features_per_level(self):
+        return self._arr("features_per_level", self.nlevels, np.int32)
+
+    @property
+    def umax(self):
+        return self._arr("umax", 16, np.int32)
+
+    @property
+    def max_keypoints(self):
+        return self.L.aos2_extractor_max_keypoints(self.h)
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors): returns (keypoints[KP_DTYPE], desc[n,32])."""
+        if image is None or image.size == 0:
+            n = C.c_int(-1)
+            _check(self.L.aos2_extractor_extract(self.h, None, 0, 0, 0, None, None, 0, C.byref(n)))
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise AssertionError("image.type() == CV_8UC1")  # src/ORBextractor.cc:1050
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.aos2_extractor_extract(self.h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, images):
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, h, w = images.shape
+        cap = self.max_keypoints
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        _check(self.L.aos2_extractor_extract_batch(self.h, _p(images), B, w, h, w, w * h, _p(kps), _p(desc), cap, _p(n)))
+        return [(kps[b, : n[b]].copy(), desc[b, : n[b]].copy()) for b in range(B)]
+
+    def extract_batch_device(self, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_nout):
+        """raw device pointers (ints)"""
+        _check(self.L.aos2_extractor_extract_batch_device(self.h, C.c_void_p(d_imgs), batch, w, h, stride, image_stride,
+                                                          C.c_void_p(d_kps), C.c_void_p(d_desc), cap, C.c_void_p(d_nout)))
+
+    def pyramid_level(self, level, image=0, border=0):
+        """mvImagePyramid[level] (include/ORBextractor.h:85)"""
+        w, h = C.c_int(), C.c_int()
+        _check(self.L.aos2_extractor_pyramid_level_size(self.h, level, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value + 2 * border, w.value + 2 * border), np.uint8)
+        _check(self.L.aos2_extractor_pyramid_level(self.h, image, level, border, _p(out), out.strides[0]))
+        return out
+
+    def debug_candidates(self, level, image=0):
+        n = C.c_int(0)
+        _check(self.L.aos2_extractor_debug_candidates(self.h, image, level, None, None, None, 0, C.byref(n)))
+        xs = np.zeros(max(n.value, 1), np.int16)
+        ys = np.zeros(max(n.value, 1), np.int16)
+        sc = np.zeros(max(n.value, 1), np.uint8)
+        _check(self.L.aos2_extractor_debug_candidates(self.h, image, level, _p(xs), _p(ys), _p(sc), len(xs), C.byref(n)))
+        return xs[: n.value], ys[: n.value], sc[: n.value]
+
+    def last_timing(self):
+        t = np.zeros(8, np.float32)
+        _check(self.L.aos2_extractor_last_timing(self.h, _p(t), 8))
+        return dict(pyramid=float(t[0]), fast=float(t[1]), compact=float(t[2]), octree=float(t[3]),
+                    describe=float(t[4]), total_wall=float(t[5]))
+
+    def bench_fast(self, iters=20):
+        ms = C.c_float(0)
+        _check(self.L.aos2_extractor_bench_fast(self.h, iters, C.byref(ms)))
+        return ms.value
+
+    def bench_describe(self, iters=20):
+        ms = C.c_float(0)
+        _check(self.L.aos2_extractor_bench_describe(self.h, iters, C.byref(ms)))
+        return ms.value
+
+
+def debug_octree_host(xs, ys, score, minX, maxX, minY, maxY, N):
+    xs = np.ascontiguousarray(xs, np.int16)
+    ys = np.ascontiguousarray(ys, np.int16)
+    score = np.ascontiguousarray(score, np.uint8)
+    out = np.zeros(max(len(xs), 1), np.int32)
+    k = lib().aos2_debug_octree_host(_p(xs), _p(ys), _p(score), len(xs), minX, maxX, minY, maxY, N, _p(out), len(out))
+    if k < 0:
+        raise AosError(k, "octree scratch exhausted")
+    return out[:k].copy()
+
+
+def debug_sincos_host(angle_rad):
+    s, c = C.c_float(), C.c_float()
+    lib().aos2_debug_sincos_host(float(angle_rad), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def debug_sincos_device(angles, device=0):
+    a = np.ascontiguousarray(angles, np.float32)
+    s = np.zeros_like(a)
+    c = np.zeros_like(a)
+    _check(lib().aos2_debug_sincos_device(_p(a), len(a), _p(s), _p(c), device))
+    return s, c
+
+
+class Matcher:  # filled in below
+    pass
+
+
+class LocalBA:
+    pass

@@ -1,0 +1,754 @@
+// Host side of the ORB extractor: plan construction (level sizes, grid cells, resize tables),
+// device buffers, stage orchestration on one HIP stream, and the C ABI of include/aos2.h.
+// Reference: src/ORBextractor.cc (ctor :410-470, operator() :1043-1105, ComputePyramid :1107-1132,
+// ComputeKeyPointsOctTree :765-853).
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "aos2_common.h"
+#include "extractor_kernels.h"
+#include "octree.h"
+
+namespace aos2 {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int bind_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return AOS2_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("HIP device %d out of range (0..%d)", device, n - 1);
+        return AOS2_ERR_NO_DEVICE;
+    }
+    AOS2_HIP_CHECK(hipSetDevice(device));
+    return AOS2_OK;
+}
+
+static const int8_t k_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+constexpr int kEdge = 19;       // EDGE_THRESHOLD src/ORBextractor.cc:74
+constexpr int kPatch = 31;      // PATCH_SIZE :72
+constexpr int kHalfPatch = 15;  // HALF_PATCH_SIZE :73
+constexpr int kMaxLevels = 16;
+
+struct Plan {
+    int w = 0, h = 0;
+    std::vector<LevelDev> levels;
+    std::vector<CellDev> cells;
+    std::vector<int> level_cell_begin;
+    std::vector<int> xofs, xab, yofs, yab;
+    size_t pyr_bytes = 0;      // one image's pyramid block
+    size_t slot_total = 0;     // candidate slots per image
+    int max_cw = 0, max_ch = 0;
+    int TP = 0, TH = 0, SP = 0;
+    size_t fast_lds = 0;
+    // device copies
+    DevBuf<LevelDev> d_levels;
+    DevBuf<CellDev> d_cells;
+    DevBuf<int> d_level_cell_begin, d_xofs, d_xab, d_yofs, d_yab;
+    void release_device()
+    {
+        d_levels.release(); d_cells.release(); d_level_cell_begin.release();
+        d_xofs.release(); d_xab.release(); d_yofs.release(); d_yab.release();
+    }
+};
+
+}  // namespace aos2
+
+using namespace aos2;
+
+struct aos2_extractor {
+    int nfeatures, nlevels, iniTh, minTh, device;
+    float scaleFactor;
+    float mvScaleFactor[kMaxLevels], mvInvScaleFactor[kMaxLevels];
+    float mvLevelSigma2[kMaxLevels], mvInvLevelSigma2[kMaxLevels];
+    int mnFeaturesPerLevel[kMaxLevels];
+    int umax[16];
+    int gauss7[7];
+    int cap_level = 0, max_kp = 0;
+    bool host_octree = false;
+    int host_threads = 8;
+    int max_cand = 16384;
+
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    Plan plan;
+    int batch_cap = 0;
+    int last_batch = 0;
+    DevBuf<uint8_t> d_pyr, d_in, d_desc;
+    DevBuf<uint32_t> d_slots, d_dense, d_sel;
+    DevBuf<int32_t> d_cell_cnt, d_level_off, d_sel_cnt, d_nout;
+    DevBuf<aos2_keypoint_t> d_kps;
+    int out_cap = 0;
+    // device octree scratch
+    DevBuf<int16_t> o_xs, o_ys;
+    DevBuf<uint8_t> o_sc;
+    DevBuf<int32_t> o_perm, o_tmp, o_pairs, o_idx;
+    DevBuf<OctNode> o_nodes;
+    int o_max_nodes = 0;
+    // host mirrors
+    PinnedBuf<int32_t> h_level_off, h_sel_cnt, h_nout;
+    PinnedBuf<uint32_t> h_dense, h_sel;
+    float timing[8] = {};
+};
+
+namespace aos2 {
+
+static int cv_round_f(float v) { return (int)lrintf(v); }
+
+static void build_host_tables(aos2_extractor *e)
+{
+    // scale tables :415-432
+    e->mvScaleFactor[0] = 1.0f;
+    e->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < e->nlevels; i++) {
+        e->mvScaleFactor[i] = e->mvScaleFactor[i - 1] * e->scaleFactor;
+        e->mvLevelSigma2[i] = e->mvScaleFactor[i] * e->mvScaleFactor[i];
+    }
+    for (int i = 0; i < e->nlevels; i++) {
+        e->mvInvScaleFactor[i] = 1.0f / e->mvScaleFactor[i];
+        e->mvInvLevelSigma2[i] = 1.0f / e->mvLevelSigma2[i];
+    }
+    // per-level quotas :436-448
+    const float factor = 1.0f / e->scaleFactor;
+    float nDesired = e->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)e->nlevels));
+    int sum = 0;
+    for (int level = 0; level < e->nlevels - 1; level++) {
+        e->mnFeaturesPerLevel[level] = cv_round_f(nDesired);
+        sum += e->mnFeaturesPerLevel[level];
+        nDesired *= factor;
+    }
+    e->mnFeaturesPerLevel[e->nlevels - 1] = std::max(e->nfeatures - sum, 0);
+    // circular patch extents :454-470
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; ++v) e->umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+    // cv::getGaussianKernel(7, 2, CV_32F) -> 8 fractional bits (createSeparableLinearFilter 8U path)
+    {
+        float cf[7];
+        double s = 0;
+        for (int i = 0; i < 7; ++i) {
+            const double x = i - 3.0;
+            cf[i] = (float)std::exp(-0.5 / 4.0 * x * x);
+            s += cf[i];
+        }
+        s = 1. / s;
+        for (int i = 0; i < 7; ++i) {
+            cf[i] = (float)(cf[i] * s);
+            e->gauss7[i] = (int)lrint((double)cf[i] * 256.0);
+        }
+    }
+    int cl = 0, tot = 0;
+    for (int l = 0; l < e->nlevels; ++l) {
+        cl = std::max(cl, e->mnFeaturesPerLevel[l] + 4);
+        tot += e->mnFeaturesPerLevel[l] + 3;
+    }
+    e->cap_level = cl;
+    e->max_kp = tot;
+}
+
+static short sat_short(float v)
+{
+    int i = (int)lrintf(v);
+    return (short)std::min(32767, std::max(-32768, i));
+}
+
+// cv::resize() coefficient tables for src -> dst (INTER_LINEAR, 8U fixed point)
+static void resize_tables(int sw, int sh, int dw, int dh, std::vector<int> &xofs, std::vector<int> &xab,
+                          std::vector<int> &yofs, std::vector<int> &yab)
+{
+    const double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+    const double scale_x = 1. / inv_sx, scale_y = 1. / inv_sy;
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const short a0 = sat_short((1.f - fx) * 2048), a1 = sat_short(fx * 2048);
+        xofs.push_back(sx);
+        xab.push_back((int)((uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16)));
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        const short b0 = sat_short((1.f - fy) * 2048), b1 = sat_short(fy * 2048);
+        yofs.push_back(sy);
+        yab.push_back((int)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16)));
+    }
+}
+
+static int build_plan(aos2_extractor *e, int w, int h)
+{
+    Plan &P = e->plan;
+    if (P.w == w && P.h == h) return AOS2_OK;
+    // smallest level must admit at least one 30-px cell in both directions (:783-786)
+    {
+        const float s = e->mvInvScaleFactor[e->nlevels - 1];
+        const int lw = cv_round_f((float)w * s), lh = cv_round_f((float)h * s);
+        if (lw - 32 < 30 || lh - 32 < 30) {
+            set_error("image %dx%d too small for %d pyramid levels", w, h, e->nlevels);
+            return AOS2_ERR_TOO_SMALL;
+        }
+        if (w > 4000 || h > 4000) {
+            set_error("image %dx%d exceeds the 12-bit candidate packing", w, h);
+            return AOS2_ERR_ARG;
+        }
+    }
+    P.release_device();
+    P = Plan();
+    P.w = w;
+    P.h = h;
+    size_t off = 0, slot = 0;
+    for (int l = 0; l < e->nlevels; ++l) {
+        LevelDev L{};
+        const float s = e->mvInvScaleFactor[l];
+        L.w = cv_round_f((float)w * s);   // :1112
+        L.h = cv_round_f((float)h * s);
+        L.pitch = (L.w + 4 + 15) & ~15;   // >= w+4 so 32-bit tile loads may overrun a row end
+        L.off = off;
+        off += ((size_t)L.pitch * (L.h + 1) + 255) & ~(size_t)255;
+        L.nfeat = e->mnFeaturesPerLevel[l];
+        L.scaled_patch = (int)(kPatch * e->mvScaleFactor[l]);
+        L.scale = e->mvScaleFactor[l];
+        L.tab_x = (int)P.xofs.size();
+        L.tab_y = (int)P.yofs.size();
+        if (l > 0)
+            resize_tables(P.levels[l - 1].w, P.levels[l - 1].h, L.w, L.h, P.xofs, P.xab, P.yofs, P.yab);
+        P.levels.push_back(L);
+        // grid cells :768-806
+        const int minBorderX = kEdge - 3, minBorderY = minBorderX;
+        const int maxBorderX = L.w - kEdge + 3, maxBorderY = L.h - kEdge + 3;
+        const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+        P.level_cell_begin.push_back((int)P.cells.size());
+        for (int i = 0; i < nRows; i++) {
+            const int iniY = minBorderY + i * hCell;
+            int maxY = iniY + hCell + 6;
+            if (iniY >= maxBorderY - 3) continue;
+            if (maxY > maxBorderY) maxY = maxBorderY;
+            for (int j = 0; j < nCols; j++) {
+                const int iniX = minBorderX + j * wCell;
+                int maxX = iniX + wCell + 6;
+                if (iniX >= maxBorderX - 6) continue;
+                if (maxX > maxBorderX) maxX = maxBorderX;
+                CellDev c{};
+                c.level = (int16_t)l;
+                c.vx0 = (int16_t)(iniX + 3);
+                c.vy0 = (int16_t)(iniY + 3);
+                c.cw = (int16_t)(maxX - iniX - 6);
+                c.ch = (int16_t)(maxY - iniY - 6);
+                if (c.cw <= 0 || c.ch <= 0) continue;  // sub-image < 7 px: cv::FAST evaluates nothing
+                if (c.cw > 64) {
+                    set_error("cell width %d > 64 unsupported", (int)c.cw);
+                    return AOS2_ERR_ARG;
+                }
+                c.slot_off = (int32_t)slot;
+                slot += (size_t)((c.cw + 1) / 2) * ((c.ch + 1) / 2);
+                P.max_cw = std::max<int>(P.max_cw, c.cw);
+                P.max_ch = std::max<int>(P.max_ch, c.ch);
+                P.cells.push_back(c);
+            }
+        }
+    }
+    P.pyr_bytes = off;
+    P.slot_total = (slot + 63) & ~(size_t)63;
+    P.TP = (P.max_cw + 12 + 3) & ~3;
+    P.TH = P.max_ch + 6;
+    P.SP = P.max_cw + 2;
+    P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (size_t)P.SP * (P.max_ch + 2) + 16;
+    // upload
+    int st;
+    if ((st = P.d_levels.alloc(P.levels.size()))) return st;
+    if ((st = P.d_cells.alloc(P.cells.size()))) return st;
+    if ((st = P.d_level_cell_begin.alloc(P.level_cell_begin.size()))) return st;
+    if ((st = P.d_xofs.alloc(P.xofs.size()))) return st;
+    if ((st = P.d_xab.alloc(P.xab.size()))) return st;
+    if ((st = P.d_yofs.alloc(P.yofs.size()))) return st;
+    if ((st = P.d_yab.alloc(P.yab.size()))) return st;
+    AOS2_HIP_CHECK(hipMemcpy(P.d_levels.p, P.levels.data(), P.levels.size() * sizeof(LevelDev), hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(P.d_cells.p, P.cells.data(), P.cells.size() * sizeof(CellDev), hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(P.d_level_cell_begin.p, P.level_cell_begin.data(), P.level_cell_begin.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!P.xofs.empty()) {
+        AOS2_HIP_CHECK(hipMemcpy(P.d_xofs.p, P.xofs.data(), P.xofs.size() * sizeof(int), hipMemcpyHostToDevice));
+        AOS2_HIP_CHECK(hipMemcpy(P.d_xab.p, P.xab.data(), P.xab.size() * sizeof(int), hipMemcpyHostToDevice));
+        AOS2_HIP_CHECK(hipMemcpy(P.d_yofs.p, P.yofs.data(), P.yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+        AOS2_HIP_CHECK(hipMemcpy(P.d_yab.p, P.yab.data(), P.yab.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    e->batch_cap = 0;  // buffers depend on the plan
+    return AOS2_OK;
+}
+
+static int init_device(aos2_extractor *e)
+{
+    int st = bind_device(e->device);
+    if (st) return st;
+    if (e->dev_ready) return AOS2_OK;
+    AOS2_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &ev : e->ev) AOS2_HIP_CHECK(hipEventCreate(&ev));
+    int r = upload_constants(k_pattern, e->umax, e->gauss7, e->stream);
+    if (r != 0) {
+        set_error("constant upload failed: %s", hipGetErrorString((hipError_t)r));
+        return AOS2_ERR_HIP;
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->dev_ready = true;
+    return AOS2_OK;
+}
+
+static int ensure_batch(aos2_extractor *e, int batch)
+{
+    if (batch <= e->batch_cap) return AOS2_OK;
+    Plan &P = e->plan;
+    const int L = e->nlevels;
+    const size_t nc = P.cells.size();
+    int st;
+    if ((st = e->d_pyr.alloc(P.pyr_bytes * batch + 256))) return st;
+    if ((st = e->d_slots.alloc(P.slot_total * batch))) return st;
+    if ((st = e->d_dense.alloc(P.slot_total * batch))) return st;
+    if ((st = e->d_cell_cnt.alloc(nc * batch))) return st;
+    if ((st = e->d_level_off.alloc((size_t)(L + 1) * batch))) return st;
+    if ((st = e->d_sel.alloc((size_t)L * e->cap_level * batch))) return st;
+    if ((st = e->d_sel_cnt.alloc((size_t)L * batch))) return st;
+    if ((st = e->h_level_off.alloc((size_t)(L + 1) * batch))) return st;
+    if ((st = e->h_sel_cnt.alloc((size_t)L * batch))) return st;
+    if ((st = e->h_nout.alloc(batch))) return st;
+    if (!e->host_octree) {
+        const size_t jobs = (size_t)L * batch;
+        e->o_max_nodes = oct_max_nodes(e->max_cand, e->cap_level);
+        if ((st = e->o_xs.alloc(jobs * e->max_cand))) return st;
+        if ((st = e->o_ys.alloc(jobs * e->max_cand))) return st;
+        if ((st = e->o_sc.alloc(jobs * e->max_cand))) return st;
+        if ((st = e->o_perm.alloc(jobs * e->max_cand))) return st;
+        if ((st = e->o_tmp.alloc(jobs * e->max_cand))) return st;
+        if ((st = e->o_pairs.alloc(jobs * 4 * e->o_max_nodes))) return st;
+        if ((st = e->o_idx.alloc(jobs * e->cap_level))) return st;
+        if ((st = e->o_nodes.alloc(jobs * e->o_max_nodes))) return st;
+    } else {
+        if ((st = e->h_sel.alloc((size_t)L * e->cap_level * batch))) return st;
+    }
+    // row h of every plane (1 guard row) and pitch padding are read by 32-bit tile loads: keep
+    // them defined
+    AOS2_HIP_CHECK(hipMemsetAsync(e->d_pyr.p, 0, P.pyr_bytes * batch + 256, e->stream));
+    e->batch_cap = batch;
+    return AOS2_OK;
+}
+
+static int ensure_out(aos2_extractor *e, int batch, int cap)
+{
+    int st;
+    if ((st = e->d_kps.alloc((size_t)batch * cap))) return st;
+    if ((st = e->d_desc.alloc((size_t)batch * cap * 32))) return st;
+    if ((st = e->d_nout.alloc(batch))) return st;
+    return AOS2_OK;
+}
+
+// host octree stage (optional): D2H candidates, std::thread pool, H2D selection
+static int octree_on_host(aos2_extractor *e, int batch)
+{
+    Plan &P = e->plan;
+    const int L = e->nlevels;
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->h_level_off.p, e->d_level_off.p, sizeof(int32_t) * (L + 1) * batch,
+                                  hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    int maxn = 0;
+    for (int b = 0; b < batch; ++b) maxn = std::max(maxn, e->h_level_off.p[(size_t)b * (L + 1) + L]);
+    if (maxn == 0) maxn = 1;
+    int st;
+    if ((st = e->h_dense.alloc((size_t)maxn * batch))) return st;
+    AOS2_HIP_CHECK(hipMemcpy2DAsync(e->h_dense.p, (size_t)maxn * 4, e->d_dense.p, P.slot_total * 4, (size_t)maxn * 4,
+                                    batch, hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    std::atomic<int> next{0}, fail{0};
+    const int jobs = batch * L;
+    auto worker = [&]() {
+        std::vector<int16_t> xs, ys;
+        std::vector<uint8_t> sc;
+        std::vector<int32_t> perm, tmp, pairs, idx(e->cap_level);
+        std::vector<OctNode> nodes;
+        for (;;) {
+            const int job = next.fetch_add(1);
+            if (job >= jobs) break;
+            const int b = job / L, l = job % L;
+            const int32_t *lo = e->h_level_off.p + (size_t)b * (L + 1);
+            const int beg = lo[l], n = lo[l + 1] - lo[l];
+            const uint32_t *cand = e->h_dense.p + (size_t)b * maxn + beg;
+            int nk = 0;
+            if (n > 0) {
+                xs.resize(n); ys.resize(n); sc.resize(n); perm.resize(n); tmp.resize(n);
+                for (int i = 0; i < n; ++i) {
+                    xs[i] = (int16_t)(cand[i] & 0xfff);
+                    ys[i] = (int16_t)((cand[i] >> 12) & 0xfff);
+                    sc[i] = (uint8_t)(cand[i] >> 24);
+                }
+                const int mn = oct_max_nodes(n, P.levels[l].nfeat);
+                nodes.resize(mn);
+                pairs.resize((size_t)4 * mn);
+                OctScratch S{nodes.data(), perm.data(), tmp.data(), pairs.data(), pairs.data() + 2 * mn, mn};
+                nk = distribute_octree(xs.data(), ys.data(), sc.data(), n, 16, P.levels[l].w - 16, 16,
+                                       P.levels[l].h - 16, P.levels[l].nfeat, S, idx.data(), e->cap_level);
+                if (nk < 0) fail.store(nk);
+                uint32_t *out = e->h_sel.p + ((size_t)b * L + l) * e->cap_level;
+                for (int k = 0; k < nk; ++k) out[k] = cand[idx[k]];
+            }
+            e->h_sel_cnt.p[(size_t)b * L + l] = nk;
+        }
+    };
+    const int nt = std::max(1, std::min(e->host_threads, jobs));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    if (fail.load() < 0) {
+        set_error("host octree scratch exhausted (%d)", fail.load());
+        return AOS2_ERR_CAPACITY;
+    }
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->d_sel.p, e->h_sel.p, sizeof(uint32_t) * L * e->cap_level * batch,
+                                  hipMemcpyHostToDevice, e->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->d_sel_cnt.p, e->h_sel_cnt.p, sizeof(int32_t) * L * batch, hipMemcpyHostToDevice, e->stream));
+    return AOS2_OK;
+}
+
+static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
+                      size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    int st;
+    if ((st = init_device(e))) return st;
+    if ((st = build_plan(e, w, h))) return st;
+    if ((st = ensure_batch(e, batch))) return st;
+    Plan &P = e->plan;
+    const int L = e->nlevels;
+    hipStream_t s = e->stream;
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[0], s));
+    launch_copy_level0(d_imgs, w, h, stride, image_stride, e->d_pyr.p, P.pyr_bytes, P.levels[0].pitch, batch, s);
+    for (int l = 1; l < L; ++l)
+        launch_resize(e->d_pyr.p, P.pyr_bytes, P.levels[l - 1], P.levels[l], P.d_xofs.p, P.d_xab.p, P.d_yofs.p,
+                      P.d_yab.p, batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[1], s));
+    launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
+                P.TH, P.SP, P.fast_lds, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[2], s));
+    launch_compact(P.d_cells.p, (int)P.cells.size(), L, P.d_level_cell_begin.p, e->d_slots.p, P.slot_total,
+                   e->d_cell_cnt.p, e->d_dense.p, P.slot_total, e->d_level_off.p, batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[3], s));
+    if (e->host_octree) {
+        if ((st = octree_on_host(e, batch))) return st;
+    } else {
+        OctDevScratch scr{e->o_xs.p, e->o_ys.p, e->o_sc.p, e->o_perm.p, e->o_tmp.p, e->o_pairs.p, e->o_idx.p,
+                          e->o_nodes.p, e->max_cand, e->o_max_nodes};
+        launch_octree(e->d_dense.p, P.slot_total, e->d_level_off.p, P.d_levels.p, L, batch, scr, e->d_sel.p,
+                      (size_t)L * e->cap_level, e->d_sel_cnt.p, e->cap_level, s);
+    }
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
+    launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
+                    e->d_sel_cnt.p, d_kps, d_desc, cap, d_nout, batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p, e->d_sel_cnt.p, sizeof(int32_t) * L * batch, hipMemcpyDeviceToHost, s));
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->h_nout.p, d_nout, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    AOS2_HIP_CHECK(hipStreamSynchronize(s));
+    AOS2_HIP_CHECK(hipGetLastError());
+    e->last_batch = batch;
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&e->timing[i], e->ev[i], e->ev[i + 1]);
+    e->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < L * batch; ++i) {
+        if (e->h_sel_cnt.p[i] < 0) {
+            set_error("octree stage failed for image %d level %d (code %d: %s)", i / L, i % L, e->h_sel_cnt.p[i],
+                      e->h_sel_cnt.p[i] == -4 ? "more FAST candidates than AOS2_MAX_CAND" : "scratch exhausted");
+            return AOS2_ERR_CAPACITY;
+        }
+    }
+    for (int b = 0; b < batch; ++b)
+        if (e->h_nout.p[b] > cap) {
+            set_error("image %d has %d keypoints, capacity %d", b, e->h_nout.p[b], cap);
+            return AOS2_ERR_CAPACITY;
+        }
+    return AOS2_OK;
+}
+
+}  // namespace aos2
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char *aos2_last_error(void) { return g_err.c_str(); }
+const char *aos2_version(void) { return "aos2 0.1 (gfx950, HIP)"; }
+
+int aos2_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                          int device, aos2_extractor_t **out)
+{
+    if (!out) return AOS2_ERR_ARG;
+    *out = nullptr;
+    if (nfeatures <= 0 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th_fast < 1 ||
+        min_th_fast < 1 || min_th_fast > ini_th_fast || ini_th_fast > 255) {
+        set_error("bad extractor parameters");
+        return AOS2_ERR_ARG;
+    }
+    aos2_extractor *e = new aos2_extractor();
+    e->nfeatures = nfeatures;
+    e->nlevels = nlevels;
+    e->iniTh = ini_th_fast;
+    e->minTh = min_th_fast;
+    e->scaleFactor = scale_factor;
+    e->device = device;
+    build_host_tables(e);
+    if (const char *v = getenv("AOS2_OCTREE")) e->host_octree = (strcmp(v, "host") == 0);
+    const unsigned hc = std::thread::hardware_concurrency();
+    e->host_threads = (int)std::min(32u, std::max(1u, hc));
+    if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));
+    if (const char *v = getenv("AOS2_MAX_CAND")) e->max_cand = std::max(1024, atoi(v));
+    *out = e;
+    return AOS2_OK;
+}
+
+void aos2_extractor_destroy(aos2_extractor_t *e)
+{
+    if (!e) return;
+    if (e->dev_ready) {
+        (void)hipSetDevice(e->device);
+        (void)hipStreamSynchronize(e->stream);
+        e->plan.release_device();
+        e->d_pyr.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
+        e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_sel_cnt.release();
+        e->d_nout.release(); e->d_kps.release();
+        e->o_xs.release(); e->o_ys.release(); e->o_sc.release(); e->o_perm.release(); e->o_tmp.release();
+        e->o_pairs.release(); e->o_idx.release(); e->o_nodes.release();
+        e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_dense.release(); e->h_sel.release();
+        for (auto &ev : e->ev) (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+int aos2_extractor_levels(const aos2_extractor_t *e) { return e->nlevels; }
+float aos2_extractor_scale_factor(const aos2_extractor_t *e) { return e->scaleFactor; }
+const float *aos2_extractor_scale_factors(const aos2_extractor_t *e) { return e->mvScaleFactor; }
+const float *aos2_extractor_inv_scale_factors(const aos2_extractor_t *e) { return e->mvInvScaleFactor; }
+const float *aos2_extractor_sigma2(const aos2_extractor_t *e) { return e->mvLevelSigma2; }
+const float *aos2_extractor_inv_sigma2(const aos2_extractor_t *e) { return e->mvInvLevelSigma2; }
+const int *aos2_extractor_features_per_level(const aos2_extractor_t *e) { return e->mnFeaturesPerLevel; }
+const int *aos2_extractor_umax(const aos2_extractor_t *e) { return e->umax; }
+int aos2_extractor_max_keypoints(const aos2_extractor_t *e) { return e->max_kp; }
+
+int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_imgs, int batch, int w, int h,
+                                        int stride, size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc,
+                                        int cap, int32_t *d_n_out)
+{
+    if (!e || !d_imgs || !d_kps || !d_desc || !d_n_out || batch <= 0 || w <= 0 || h <= 0 || stride < w || cap <= 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    return run_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
+}
+
+int aos2_extractor_extract_batch(aos2_extractor_t *e, const uint8_t *imgs, int batch, int w, int h, int stride,
+                                 size_t image_stride, aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out)
+{
+    if (!e || batch <= 0 || !n_out) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (!imgs || w <= 0 || h <= 0) {  // empty image: silent return (:1046)
+        for (int b = 0; b < batch; ++b) n_out[b] = 0;
+        return AOS2_OK;
+    }
+    if (stride < w || cap <= 0 || !kps || !desc) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = init_device(e))) return st;
+    if ((st = e->d_in.alloc((size_t)batch * w * h))) return st;
+    if ((st = ensure_out(e, batch, cap))) return st;
+    e->out_cap = cap;
+    AOS2_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p, (size_t)w, imgs, (size_t)stride, (size_t)w, (size_t)h * 1, hipMemcpyHostToDevice, e->stream));
+    for (int b = 1; b < batch; ++b)
+        AOS2_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p + (size_t)b * w * h, (size_t)w, imgs + (size_t)b * image_stride,
+                                        (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, e->stream));
+    st = run_device(e, e->d_in.p, batch, w, h, w, (size_t)w * h, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p);
+    if (st == AOS2_OK || st == AOS2_ERR_CAPACITY) {
+        for (int b = 0; b < batch; ++b) n_out[b] = e->h_nout.p[b];
+    }
+    if (st) return st;
+    AOS2_HIP_CHECK(hipMemcpyAsync(kps, e->d_kps.p, sizeof(aos2_keypoint_t) * (size_t)batch * cap, hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(desc, e->d_desc.p, (size_t)batch * cap * 32, hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return AOS2_OK;
+}
+
+int aos2_extractor_extract(aos2_extractor_t *e, const uint8_t *img, int w, int h, int stride, aos2_keypoint_t *kps,
+                           uint8_t *desc, int cap, int *n_out)
+{
+    int32_t n = 0;
+    const int st = aos2_extractor_extract_batch(e, img, 1, w, h, stride, (size_t)stride * (h > 0 ? h : 0), kps, desc,
+                                                cap, &n);
+    if (n_out) *n_out = n;
+    return st;
+}
+
+int aos2_extractor_pyramid_level_size(const aos2_extractor_t *e, int level, int *w, int *h)
+{
+    if (!e || level < 0 || level >= e->nlevels || e->plan.levels.empty()) {
+        set_error("no pyramid available");
+        return AOS2_ERR_ARG;
+    }
+    if (w) *w = e->plan.levels[level].w;
+    if (h) *h = e->plan.levels[level].h;
+    return AOS2_OK;
+}
+
+int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int border, uint8_t *dst, int dst_stride)
+{
+    if (!e || !dst || level < 0 || level >= e->nlevels || e->plan.levels.empty() || image < 0 ||
+        image >= e->last_batch || border < 0 || border > 64) {
+        set_error("bad argument / no pyramid available");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = bind_device(e->device))) return st;
+    const LevelDev &L = e->plan.levels[level];
+    if (dst_stride < L.w + 2 * border) return AOS2_ERR_ARG;
+    uint8_t *interior = dst + (size_t)border * dst_stride + border;
+    AOS2_HIP_CHECK(hipMemcpy2DAsync(interior, (size_t)dst_stride, e->d_pyr.p + (size_t)image * e->plan.pyr_bytes + L.off,
+                                    (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (border > 0) {  // cv::copyMakeBorder(BORDER_REFLECT_101), :1122-1128
+        auto refl = [](int p, int n) {
+            while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+            return p;
+        };
+        for (int y = -border; y < L.h + border; ++y) {
+            const uint8_t *srow = interior + (ptrdiff_t)refl(y, L.h) * dst_stride;
+            uint8_t *drow = interior + (ptrdiff_t)y * dst_stride;
+            for (int x = -border; x < L.w + border; ++x) {
+                if (y >= 0 && y < L.h && x >= 0 && x < L.w) continue;
+                drow[x] = srow[refl(x, L.w)];
+            }
+        }
+    }
+    return AOS2_OK;
+}
+
+int aos2_extractor_debug_candidates(aos2_extractor_t *e, int image, int level, int16_t *xs, int16_t *ys,
+                                    uint8_t *score, int cap, int *n)
+{
+    if (!e || !n || level < 0 || level >= e->nlevels || image < 0 || image >= e->last_batch) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = bind_device(e->device))) return st;
+    const int L = e->nlevels;
+    int32_t lo[2];
+    AOS2_HIP_CHECK(hipMemcpy(lo, e->d_level_off.p + (size_t)image * (L + 1) + level, sizeof(lo), hipMemcpyDeviceToHost));
+    const int cnt = lo[1] - lo[0];
+    *n = cnt;
+    if (!xs || !ys || !score) return AOS2_OK;
+    if (cnt > cap) return AOS2_ERR_CAPACITY;
+    std::vector<uint32_t> tmp(cnt > 0 ? cnt : 1);
+    if (cnt > 0)
+        AOS2_HIP_CHECK(hipMemcpy(tmp.data(), e->d_dense.p + (size_t)image * e->plan.slot_total + lo[0],
+                                 sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; ++i) {
+        xs[i] = (int16_t)(tmp[i] & 0xfff);
+        ys[i] = (int16_t)((tmp[i] >> 12) & 0xfff);
+        score[i] = (uint8_t)(tmp[i] >> 24);
+    }
+    return AOS2_OK;
+}
+
+int aos2_extractor_last_timing(const aos2_extractor_t *e, float *ms, int n)
+{
+    if (!e || !ms) return AOS2_ERR_ARG;
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = e->timing[i];
+    return AOS2_OK;
+}
+
+int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms)
+{
+    if (!e || !avg_ms || iters <= 0 || e->last_batch <= 0) {
+        set_error("bench_fast needs a previous batch");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = bind_device(e->device))) return st;
+    Plan &P = e->plan;
+    hipStream_t s = e->stream;
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
+    for (int i = 0; i < iters; ++i)
+        launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
+                    P.TH, P.SP, P.fast_lds, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, e->last_batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
+    AOS2_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    AOS2_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[6], e->ev[7]));
+    *avg_ms = ms / iters;
+    return AOS2_OK;
+}
+
+int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms)
+{
+    if (!e || !avg_ms || iters <= 0 || e->last_batch <= 0 || !e->d_kps.p || e->out_cap <= 0) {
+        set_error("bench_describe needs a previous host-API batch");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = bind_device(e->device))) return st;
+    Plan &P = e->plan;
+    const int L = e->nlevels;
+    hipStream_t s = e->stream;
+    const int cap = e->out_cap;
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
+    for (int i = 0; i < iters; ++i)
+        launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
+                        e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, s);
+    AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
+    AOS2_HIP_CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    AOS2_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[6], e->ev[7]));
+    *avg_ms = ms / iters;
+    return AOS2_OK;
+}
+
+}  // extern "C"

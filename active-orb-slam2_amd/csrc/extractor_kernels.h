@@ -1,0 +1,55 @@
+// Device-side descriptors and kernel launchers of the ORB extractor (extractor_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aos2.h"
+
+namespace aos2 {
+
+struct OctNode;
+
+struct LevelDev {
+    int w, h, pitch;      // interior size, row pitch (multiple of 16) of the plane
+    size_t off;           // byte offset of the plane inside one image's pyramid block
+    int tab_x, tab_y;     // offsets of this level's resize tables (destination side)
+    int nfeat;            // mnFeaturesPerLevel[level]
+    int scaled_patch;     // (int)(31 * scale[level])
+    float scale;          // mvScaleFactor[level]
+};
+
+struct CellDev {
+    int16_t level;
+    int16_t vx0, vy0;     // first evaluated pixel of the cell (level interior coordinates)
+    int16_t cw, ch;       // evaluated columns / rows
+    int16_t pad;
+    int32_t slot_off;     // offset of the cell's candidate slots inside one image's slot block
+};
+
+struct OctDevScratch {
+    int16_t *xs, *ys;
+    uint8_t *sc;
+    int32_t *perm, *tmp, *pairs, *out_idx;
+    OctNode *nodes;
+    int max_cand, max_nodes;
+};
+
+int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st);
+void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t simg_stride, uint8_t *pyr,
+                        size_t pyr_stride, int dpitch, int batch, hipStream_t st);
+void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const LevelDev &dst, const int *xofs,
+                   const int *xab, const int *yofs, const int *yab, int batch, hipStream_t st);
+void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
+                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, uint32_t *slots,
+                 size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st);
+void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,
+                    const uint32_t *slots, size_t slot_stride, const int32_t *cell_cnt, uint32_t *dense,
+                    size_t dense_stride, int32_t *level_off, int batch, hipStream_t st);
+void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+                   int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                   int32_t *sel_level_cnt, int cap_level, hipStream_t st);
+void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
+                     const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
+                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, hipStream_t st);
+
+}  // namespace aos2

@@ -1,0 +1,558 @@
+// HIP kernels of the ORB extractor for gfx950 (wave64).  Integer/byte work, HBM/LDS bound:
+// no MFMA here by design.  Reference semantics: src/ORBextractor.cc (see each kernel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "extractor_kernels.h"
+#include "octree.h"
+#include "sincos_exact.h"
+
+namespace aos2 {
+
+__constant__ int8_t c_pattern[1024];   // rBRIEF test locations (src/ORBextractor.cc:150-408)
+__constant__ int c_umax[16];           // circular patch row extents (:454-470)
+__constant__ int c_gauss[8];           // 7-tap Gaussian, 8 fractional bits {18,34,49,55,49,34,18}
+
+int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st)
+{
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pattern), pattern, 1024, 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_umax), umax, 16 * sizeof(int), 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    int g[8] = {gauss7[0], gauss7[1], gauss7[2], gauss7[3], gauss7[4], gauss7[5], gauss7[6], 0};
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_gauss), g, sizeof(g), 0, hipMemcpyHostToDevice, st);
+    return (int)e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level 0: copy the caller's image (arbitrary stride) into the pitched pyramid plane.
+// (ComputePyramid, src/ORBextractor.cc:1107-1132; the 19-px REFLECT_101 frame the reference keeps
+// around each level is never read by the extractor and is synthesised on demand for
+// mvImagePyramid readers, see aos2_extractor_pyramid_level.)
+// ---------------------------------------------------------------------------------------------
+__global__ void copy_level0_kernel(const uint8_t *__restrict__ src, int w, int h, int sstride,
+                                   size_t simg_stride, uint8_t *__restrict__ pyr, size_t pyr_stride,
+                                   int dpitch)
+{
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x4 >= w) return;
+    const uint8_t *s = src + (size_t)b * simg_stride + (size_t)y * sstride + x4;
+    uint8_t *d = pyr + (size_t)b * pyr_stride + (size_t)y * dpitch + x4;
+    uint32_t v = 0;
+    if (x4 + 3 < w) {
+        v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    } else {
+        for (int k = 0; k < 4 && x4 + k < w; ++k) v |= (uint32_t)s[k] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(d) = v;  // dpitch % 4 == 0, plane base 256-aligned
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR) 8UC1, level L-1 -> L (src/ORBextractor.cc:1120).  Fixed point,
+// 11-bit coefficients; the coefficient tables are built on the host exactly like OpenCV's
+// resize() does (float fx, two separately rounded shorts), so host and device cannot disagree.
+// One thread = 4 horizontally adjacent output pixels (one aligned 32-bit store).
+// ---------------------------------------------------------------------------------------------
+__global__ void resize_level_kernel(uint8_t *__restrict__ pyr, size_t pyr_stride, LevelDev src,
+                                    LevelDev dst, const int *__restrict__ xofs,
+                                    const int *__restrict__ xab, const int *__restrict__ yofs,
+                                    const int *__restrict__ yab)
+{
+    const int b = blockIdx.z;
+    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (dy >= dst.h || dx0 >= dst.w) return;
+    const uint8_t *sp = pyr + (size_t)b * pyr_stride + src.off;
+    uint8_t *dp = pyr + (size_t)b * pyr_stride + dst.off;
+    int sy0 = yofs[dst.tab_y + dy], sy1 = sy0 + 1;
+    sy0 = min(max(sy0, 0), src.h - 1);
+    sy1 = min(max(sy1, 0), src.h - 1);
+    const int bb = yab[dst.tab_y + dy];
+    const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)(bb >> 16);
+    const uint8_t *S0 = sp + (size_t)sy0 * src.pitch, *S1 = sp + (size_t)sy1 * src.pitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < dst.w) {
+            const int sx = xofs[dst.tab_x + dx];
+            const int sx1 = sx + 1 < src.w ? sx + 1 : sx;
+            const int aa = xab[dst.tab_x + dx];
+            const int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)(aa >> 16);
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            out |= (uint32_t)v << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(dp + (size_t)dy * dst.pitch + dx0) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 score + 3x3 non-max suppression + threshold fallback, one workgroup per
+// (grid cell, image).  cv::FAST(cell, kps, iniThFAST, true) with the minThFAST retry of
+// src/ORBextractor.cc:809-816, cell geometry of :775-806.
+//
+// Closed form used here (equivalent to OpenCV's cornerScore<16>, DESIGN.md "FAST score"):
+//   with ring pixels x[0..15] around centre v,
+//     A = v - min_s max(x[s..s+8]),  B' = max_s min(x[s..s+8]) - v,   S = max(A, B') - 1
+//   pixel is a corner at threshold t  <=>  S >= t,  and its score is S for every t <= S.
+// NMS only looks at neighbours inside the same cell's evaluated region (scores outside are 0),
+// so no halo beyond the 3-px ring is needed and cells are independent.
+// The tile (cell + 3-px ring halo) is staged in LDS with coalesced 32-bit loads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
+{
+    // t points at the centre pixel inside the LDS tile
+    int x[16];
+    x[0] = t[3 * TP];      x[1] = t[3 * TP + 1];   x[2] = t[2 * TP + 2];   x[3] = t[TP + 3];
+    x[4] = t[3];           x[5] = t[-TP + 3];      x[6] = t[-2 * TP + 2];  x[7] = t[-3 * TP + 1];
+    x[8] = t[-3 * TP];     x[9] = t[-3 * TP - 1];  x[10] = t[-2 * TP - 2]; x[11] = t[-TP - 3];
+    x[12] = t[-3];         x[13] = t[TP - 3];      x[14] = t[2 * TP - 2];  x[15] = t[3 * TP - 1];
+    int mx1[16], mn1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        mx1[i] = max(x[i], x[(i + 1) & 15]);
+        mn1[i] = min(x[i], x[(i + 1) & 15]);
+    }
+    int mx2[16], mn2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        mx2[i] = max(mx1[i], mx1[(i + 2) & 15]);
+        mn2[i] = min(mn1[i], mn1[(i + 2) & 15]);
+    }
+    int minmax = 255, maxmin = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m8x = max(mx2[i], mx2[(i + 4) & 15]);
+        const int m8n = min(mn2[i], mn2[(i + 4) & 15]);
+        const int m9x = max(m8x, x[(i + 8) & 15]);
+        const int m9n = min(m8n, x[(i + 8) & 15]);
+        minmax = min(minmax, m9x);
+        maxmin = max(maxmin, m9n);
+    }
+    const int v = t[0];
+    return max(v - minmax, maxmin - v) - 1;
+}
+
+__global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restrict__ pyr,
+                                                         size_t pyr_stride,
+                                                         const LevelDev *__restrict__ levels,
+                                                         const CellDev *__restrict__ cells,
+                                                         int n_cells, int ini_th, int min_th,
+                                                         int TP, int TH, int SP,
+                                                         uint32_t *__restrict__ slots,
+                                                         size_t slot_stride,
+                                                         int32_t *__restrict__ cell_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tile = smem;                                  // TH x TP
+    uint8_t *smap = smem + ((TP * TH + 15) & ~15);         // (SH) x SP, 1-px zero border
+    __shared__ int wtot[4];
+
+    const int b = blockIdx.y;
+    const CellDev cell = cells[blockIdx.x];
+    const LevelDev lv = levels[cell.level];
+    const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    const int cw = cell.cw, ch = cell.ch;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage tile: rows vy0-3 .. vy0+ch+2, cols vx0-3 .. vx0+cw+2 (always inside the level)
+    {
+        const int tx0 = cell.vx0 - 3, ty0 = cell.vy0 - 3;
+        const int tw = cw + 6, th = ch + 6;
+        const int ax0 = tx0 & ~3;             // aligned start column in the plane
+        const int shift = tx0 - ax0;          // 0..3
+        const int ndw = (shift + tw + 3) >> 2; // dwords per row
+        // LDS rows hold the aligned dwords; tile origin is offset by `shift`
+        for (int i = tid; i < th * ndw; i += 256) {
+            const int r = i / ndw, c = i - r * ndw;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (size_t)(ty0 + r) * lv.pitch + ax0 + 4 * c);
+            *reinterpret_cast<uint32_t *>(tile + r * TP + 4 * c) = v;
+        }
+        tile += shift;
+    }
+    const int SH = ch + 2;
+    const int rps = 64 / cw;                 // rows per wave step (cw <= 64)
+    const int lrow = lane / cw;
+    const int px = lane - lrow * cw;
+    const bool lane_ok = lrow < rps;
+    const int rows_per_step = 4 * rps;
+    const int n_steps = (ch + rows_per_step - 1) / rows_per_step;
+    uint32_t *my_slots = slots + (size_t)b * slot_stride + cell.slot_off;
+
+    int th = ini_th;
+    int total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = tid; i < SH * SP; i += 256) smap[i] = 0;
+        __syncthreads();
+        // ---- scores
+        for (int s = 0; s < n_steps; ++s) {
+            const int py = s * rows_per_step + wave * rps + lrow;
+            if (lane_ok && py < ch) {
+                const uint8_t *t = tile + (py + 3) * TP + px + 3;
+                const int v = t[0];
+                // necessary condition: a 9-arc contains >= 2 of the 4 compass pixels
+                const int c0 = t[3 * TP], c4 = t[3], c8 = t[-3 * TP], c12 = t[-3];
+                const int hi = v + th, lo = v - th;
+                const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
+                const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
+                if (nb >= 2 || nd >= 2) {
+                    const int S = fast_score_full(t, TP);
+                    if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- NMS + ordered compaction (row-major inside the cell)
+        total = 0;
+        for (int s = 0; s < n_steps; ++s) {
+            const int py = s * rows_per_step + wave * rps + lrow;
+            int sc = 0;
+            bool keep = false;
+            if (lane_ok && py < ch) {
+                const uint8_t *m = smap + (py + 1) * SP + px + 1;
+                sc = m[0];
+                keep = sc > 0 && sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] &&
+                       sc > m[-SP + 1] && sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (lane == 0) wtot[wave] = __popcll(bal);
+            __syncthreads();
+            int base = total;
+            for (int w = 0; w < wave; ++w) base += wtot[w];
+            if (keep) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const uint32_t xr = (uint32_t)(cell.vx0 - 16 + px), yr = (uint32_t)(cell.vy0 - 16 + py);
+                my_slots[pos] = xr | (yr << 12) | ((uint32_t)sc << 24);
+            }
+            total += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            __syncthreads();
+        }
+        if (total > 0 || th == min_th) break;
+        th = min_th;  // vKeysCell.empty() -> retry with minThFAST (:812-816)
+    }
+    if (tid == 0) cell_cnt[(size_t)b * n_cells + blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per image: exclusive scan of the cell counts in the reference's emission order (levels, then
+// cells row-major) and gather of the per-cell slots into one dense list per image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_candidates_kernel(const CellDev *__restrict__ cells,
+                                                                 int n_cells, int n_levels,
+                                                                 const int *__restrict__ level_cell_begin,
+                                                                 const uint32_t *__restrict__ slots,
+                                                                 size_t slot_stride,
+                                                                 const int32_t *__restrict__ cell_cnt,
+                                                                 uint32_t *__restrict__ dense,
+                                                                 size_t dense_stride,
+                                                                 int32_t *__restrict__ level_off)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    __shared__ int cell_off_sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t *cnt = cell_cnt + (size_t)b * n_cells;
+    const uint32_t *sl = slots + (size_t)b * slot_stride;
+    uint32_t *out = dense + (size_t)b * dense_stride;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_cells; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = c < n_cells ? cnt[c] : 0;
+        // wave inclusive scan
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int excl = carry + woff + x - v;
+        cell_off_sh[tid] = excl;
+        // level boundaries
+        if (c < n_cells) {
+            for (int l = 0; l < n_levels; ++l)
+                if (level_cell_begin[l] == c) level_off[(size_t)b * (n_levels + 1) + l] = excl;
+            const uint32_t *src = sl + cells[c].slot_off;
+            for (int i = 0; i < v; ++i) out[excl + i] = src[i];
+        }
+        __syncthreads();
+        if (tid == 255) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) level_off[(size_t)b * (n_levels + 1) + n_levels] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DistributeOctTree on the device: one lane per (image, level) running the shared serial
+// routine of octree.h over global scratch.  Latency-bound by construction (pointer-chasing
+// control flow of src/ORBextractor.cc:539-763); it exists to keep the candidates on the device.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
+                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+                              int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
+                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level)
+{
+    // one wave per job; candidate unpacking is wave-parallel, the tree itself runs on lane 0
+    const int job = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int b = job / n_levels, l = job - b * n_levels;
+    const int32_t *lo = level_off + (size_t)b * (n_levels + 1);
+    const int beg = lo[l], n = lo[l + 1] - lo[l];
+    const uint32_t *cand = dense + (size_t)b * dense_stride + beg;
+    int16_t *xs = scr.xs + (size_t)job * scr.max_cand;
+    int16_t *ys = scr.ys + (size_t)job * scr.max_cand;
+    uint8_t *sc = scr.sc + (size_t)job * scr.max_cand;
+    uint32_t *out = sel + (size_t)b * sel_stride + (size_t)l * cap_level;
+    if (n > scr.max_cand) {
+        if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = -4;
+        return;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t c = cand[i];
+        xs[i] = (int16_t)(c & 0xfff);
+        ys[i] = (int16_t)((c >> 12) & 0xfff);
+        sc[i] = (uint8_t)(c >> 24);
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    int nk = 0;
+    if (n > 0) {
+        OctScratch S;
+        S.nodes = scr.nodes + (size_t)job * scr.max_nodes;
+        S.perm = scr.perm + (size_t)job * scr.max_cand;
+        S.tmp = scr.tmp + (size_t)job * scr.max_cand;
+        S.pairs_a = scr.pairs + (size_t)job * 4 * scr.max_nodes;
+        S.pairs_b = S.pairs_a + 2 * scr.max_nodes;
+        S.max_nodes = scr.max_nodes;
+        int32_t *idx = scr.out_idx + (size_t)job * cap_level;
+        const LevelDev lv = levels[l];
+        nk = distribute_octree(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
+        for (int k = 0; k < nk; ++k) out[k] = cand[idx[k]];
+    }
+    sel_level_cnt[(size_t)b * n_levels + l] = nk;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orientation (IC_Angle, :77-104) + 7x7 Gaussian blur (cv::GaussianBlur sigma 2, :1085-1086)
+// + steered rBRIEF (computeOrbDescriptor, :108-147), one wave per keypoint.
+//
+// The 43x43 unblurred patch around the keypoint is staged in LDS once (BORDER_REFLECT_101 at the
+// level's edges, exactly what blurring the cloned interior sees).  From it:
+//   * integer moments over the circular r=15 patch -> fastAtan2 polynomial (float, no FMA);
+//   * horizontal 7-tap pass into a u16 LDS tile (43 rows x 37 cols; max 255*257 fits 16 bits);
+//   * the 512 rotated sample positions take the vertical 7-tap on demand, (sum+2^15)>>16.
+// This fuses the reference's full-level blur into the consumer: only the <= 37x37 footprint a
+// descriptor can touch (pattern reach +-13 rotated => +-18) is ever blurred, and the blurred
+// pyramid never goes to HBM.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+constexpr int PR = 21;            // patch radius staged (18 sample reach + 3 blur taps)
+constexpr int PW = 2 * PR + 1;    // 43
+constexpr int PP = 44;            // LDS pitch of the u8 patch
+constexpr int HR = 18;            // horizontal-blur tile radius in x
+constexpr int HW = 2 * HR + 1;    // 37
+constexpr int HP = 38;            // LDS pitch (u16) of the h-blur tile
+constexpr int KP_PER_BLOCK = 4;
+
+__global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ pyr,
+                                                       size_t pyr_stride,
+                                                       const LevelDev *__restrict__ levels,
+                                                       int n_levels, const uint32_t *__restrict__ sel,
+                                                       size_t sel_stride, int cap_level,
+                                                       const int32_t *__restrict__ sel_level_cnt,
+                                                       aos2_keypoint_t *__restrict__ kps,
+                                                       uint8_t *__restrict__ desc, int cap,
+                                                       int32_t *__restrict__ n_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t patch_s[KP_PER_BLOCK][PW * PP];
+    __shared__ __attribute__((aligned(16))) uint16_t hb_s[KP_PER_BLOCK][PW * HP];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * KP_PER_BLOCK + wave;  // output slot in the image
+    // locate level and index inside the level (levels are concatenated level-major, :1060-1104)
+    const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
+    int level = -1, kin = k, total = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int c = cnt[l] > 0 ? cnt[l] : 0;
+        if (level < 0 && kin < c) level = l;
+        if (level < 0) kin -= c;
+        total += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[b] = total;
+    const bool valid = level >= 0 && k < cap;
+    uint8_t *patch = patch_s[wave];
+    uint16_t *hb = hb_s[wave];
+    int kx = 0, ky = 0, score = 0;
+    LevelDev lv = levels[valid ? level : 0];
+    if (valid) {
+        const uint32_t c = sel[(size_t)b * sel_stride + (size_t)level * cap_level + kin];
+        kx = (int)(c & 0xfff) + 16;           // + minBorderX (:842)
+        ky = (int)((c >> 12) & 0xfff) + 16;
+        score = (int)(c >> 24);
+        const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+        for (int i = lane; i < PW * PW; i += 64) {
+            const int r = i / PW, cc = i - r * PW;
+            const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + cc, lv.w);
+            patch[r * PP + cc] = plane[(size_t)yy * lv.pitch + xx];
+        }
+    }
+    __syncthreads();
+    float angle = 0.f;
+    if (valid) {
+        // ---- IC_Angle
+        int m10 = 0, m01 = 0;
+        for (int i = lane; i < 31 * 31; i += 64) {
+            const int r = i / 31, cc = i - r * 31;
+            const int v = r - 15, u = cc - 15;
+            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+            if (au <= c_umax[av]) {
+                const int I = patch[(PR + v) * PP + PR + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            m10 += __shfl_xor(m10, d);
+            m01 += __shfl_xor(m01, d);
+        }
+        angle = fast_atan2_deg((float)m01, (float)m10);
+        // ---- horizontal blur pass
+        for (int i = lane; i < PW * HW; i += 64) {
+            const int r = i / HW, cc = i - r * HW;
+            const uint8_t *p = patch + r * PP + (PR - HR) + cc;  // centre column
+            const int s = c_gauss[0] * (p[-3] + p[3]) + c_gauss[1] * (p[-2] + p[2]) +
+                          c_gauss[2] * (p[-1] + p[1]) + c_gauss[3] * p[0];
+            hb[r * HP + cc] = (uint16_t)s;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float ang = __fmul_rn(angle, factorPI);
+        float a, bb;
+        sincos_exact(ang, &bb, &a);
+        unsigned long long words[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pair = r * 64 + lane;
+            int val[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float px = (float)c_pattern[4 * pair + 2 * q], py = (float)c_pattern[4 * pair + 2 * q + 1];
+                const int iy = __float2int_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)));
+                const int ix = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)));
+                const uint16_t *h = hb + (PR + iy) * HP + HR + ix;
+                const int s = c_gauss[0] * (h[-3 * HP] + h[3 * HP]) + c_gauss[1] * (h[-2 * HP] + h[2 * HP]) +
+                              c_gauss[2] * (h[-HP] + h[HP]) + c_gauss[3] * h[0];
+                int v = (s + (1 << 15)) >> 16;
+                val[q] = v > 255 ? 255 : v;
+            }
+            words[r] = __ballot(val[0] < val[1]);
+        }
+        if (lane == 0) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
+            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+            aos2_keypoint_t kp;
+            const float scale = lv.scale;
+            kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
+            kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
+            kp.size = (float)lv.scaled_patch;
+            kp.angle = angle;
+            kp.response = (float)score;
+            kp.octave = level;
+            kp.class_id = -1;
+            kps[(size_t)b * cap + k] = kp;
+        }
+    }
+}
+
+// host launchers -------------------------------------------------------------------------------
+void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t simg_stride, uint8_t *pyr,
+                        size_t pyr_stride, int dpitch, int batch, hipStream_t st)
+{
+    dim3 blk(64), grd((w / 4 + 64) / 64, h, batch);
+    hipLaunchKernelGGL(copy_level0_kernel, grd, blk, 0, st, d_src, w, h, sstride, simg_stride, pyr, pyr_stride, dpitch);
+}
+
+void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const LevelDev &dst, const int *xofs,
+                   const int *xab, const int *yofs, const int *yab, int batch, hipStream_t st)
+{
+    dim3 blk(64, 4), grd((dst.w + 255) / 256, (dst.h + 3) / 4, batch);
+    hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, pyr, pyr_stride, src, dst, xofs, xab, yofs, yab);
+}
+
+void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
+                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, uint32_t *slots,
+                 size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
+{
+    dim3 blk(256), grd(n_cells, batch);
+    hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, pyr, pyr_stride, levels, cells, n_cells, ini_th,
+                       min_th, TP, TH, SP, slots, slot_stride, cell_cnt);
+}
+
+void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,
+                    const uint32_t *slots, size_t slot_stride, const int32_t *cell_cnt, uint32_t *dense,
+                    size_t dense_stride, int32_t *level_off, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(compact_candidates_kernel, dim3(batch), dim3(256), 0, st, cells, n_cells, n_levels,
+                       level_cell_begin, slots, slot_stride, cell_cnt, dense, dense_stride, level_off);
+}
+
+void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+                   int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                   int32_t *sel_level_cnt, int cap_level, hipStream_t st)
+{
+    const int jobs = batch * n_levels;
+    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), 0, st, dense, dense_stride, level_off,
+                       levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level);
+}
+
+void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
+                     const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
+                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, hipStream_t st)
+{
+    dim3 blk(256), grd((cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch);
+    hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
+                       cap_level, sel_level_cnt, kps, desc, cap, n_out);
+}
+
+}  // namespace aos2

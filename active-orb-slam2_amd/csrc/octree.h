@@ -1,0 +1,322 @@
+// Quad-tree keypoint distribution (ORBextractor::DistributeOctTree + ExtractorNode::DivideNode,
+// reference src/ORBextractor.cc:481-763) as an allocation-free routine over caller-provided
+// scratch, written so the same source runs on the host (thread per (image, level)) and inside a
+// HIP kernel (one lane per (image, level)).
+//
+// Formulation differences from the reference (results are identical):
+//  * a node is an axis-aligned rectangle [x0,x1) x [y0,y1) (the reference stores 4 corners that
+//    always form one);
+//  * a node's keys are a contiguous segment of one permutation array; DivideNode is a stable
+//    4-way partition of that segment (the reference copies KeyPoints into 4 new vectors);
+//  * std::list<ExtractorNode> is an index-linked list over a node arena;
+//  * the (size, pointer) sort of :684 uses the arena index as the pointer stand-in (creation
+//    order; later-created = larger), DESIGN.md parity convention 1.
+// Candidate coordinates are integer pixel positions relative to (minBorderX, minBorderY).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AOS2_OCT_HD __host__ __device__ inline
+#else
+#define AOS2_OCT_HD inline
+#endif
+
+namespace aos2 {
+
+struct OctNode {
+    int16_t x0, y0, x1, y1;
+    int32_t beg, cnt;
+    int32_t prev, next;
+    int32_t no_more;
+};
+
+// scratch requirements for n candidates and target N:
+//   nodes: arena of at most oct_max_nodes(n, N) OctNode
+//   perm, tmp: n int32 each; pairs: 2 * oct_max_nodes int32
+AOS2_OCT_HD int oct_max_nodes(int n, int N)
+{
+    // every split allocates <= 4 nodes and the list never exceeds min(n, N+3) live leaves; the
+    // number of splits is bounded by the number of nodes ever created.  A node is split at most
+    // once, and each split either increases the live count or keeps it (degenerate), the latter
+    // ends the pass.  Conservative bound used for sizing:
+    // Productive splits <= live leaves; degenerate splits (all keys fall into one child) form
+    // chains no longer than the box-halving depth (<= 12 for 4096-px levels).
+    int live = (n < N + 3 ? n : N + 3) + 8;
+    return 48 * live + 64;
+}
+
+struct OctScratch {
+    OctNode *nodes;
+    int32_t *perm;
+    int32_t *tmp;
+    int32_t *pairs_a;  // (size,node) pairs of the current pass
+    int32_t *pairs_b;  // previous pass (sorted)
+    int max_nodes;
+};
+
+namespace octdetail {
+
+struct List {
+    OctNode *nodes;
+    int n_alloc, head, tail, size, cap;
+};
+
+AOS2_OCT_HD int new_node(List &L)
+{
+    if (L.n_alloc >= L.cap) return -1;
+    OctNode &n = L.nodes[L.n_alloc];
+    n.prev = n.next = -1;
+    n.no_more = 0;
+    n.cnt = 0;
+    n.beg = 0;
+    return L.n_alloc++;
+}
+AOS2_OCT_HD void push_back(List &L, int id)
+{
+    OctNode &n = L.nodes[id];
+    n.prev = L.tail;
+    n.next = -1;
+    if (L.tail >= 0) L.nodes[L.tail].next = id; else L.head = id;
+    L.tail = id;
+    L.size++;
+}
+AOS2_OCT_HD void push_front(List &L, int id)
+{
+    OctNode &n = L.nodes[id];
+    n.next = L.head;
+    n.prev = -1;
+    if (L.head >= 0) L.nodes[L.head].prev = id; else L.tail = id;
+    L.head = id;
+    L.size++;
+}
+AOS2_OCT_HD int erase(List &L, int id)
+{
+    OctNode &n = L.nodes[id];
+    int nx = n.next;
+    if (n.prev >= 0) L.nodes[n.prev].next = n.next; else L.head = n.next;
+    if (n.next >= 0) L.nodes[n.next].prev = n.prev; else L.tail = n.prev;
+    L.size--;
+    return nx;
+}
+
+// DivideNode: stable 4-way partition of the parent's segment; children c[0..3] = n1..n4
+// (UL, UR, BL, BR quadrants).  Returns false if the arena is exhausted.
+AOS2_OCT_HD bool divide(List &L, int id, int c[4], const int16_t *xs, const int16_t *ys,
+                        int32_t *perm, int32_t *tmp)
+{
+    const OctNode p = L.nodes[id];
+    const int hx = (p.x1 - p.x0 + 1) / 2;  // ceil(float(x1-x0)/2)
+    const int hy = (p.y1 - p.y0 + 1) / 2;
+    const int mx = p.x0 + hx, my = p.y0 + hy;
+    for (int i = 0; i < 4; ++i) {
+        c[i] = new_node(L);
+        if (c[i] < 0) return false;
+    }
+    OctNode &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
+    n1.x0 = p.x0; n1.y0 = p.y0; n1.x1 = (int16_t)mx; n1.y1 = (int16_t)my;
+    n2.x0 = (int16_t)mx; n2.y0 = p.y0; n2.x1 = p.x1; n2.y1 = (int16_t)my;
+    n3.x0 = p.x0; n3.y0 = (int16_t)my; n3.x1 = (int16_t)mx; n3.y1 = p.y1;
+    n4.x0 = (int16_t)mx; n4.y0 = (int16_t)my; n4.x1 = p.x1; n4.y1 = p.y1;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < p.cnt; ++i) {
+        const int k = perm[p.beg + i];
+        const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
+        cnt[q]++;
+    }
+    int off[4];
+    off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+    int fill[4] = {off[0], off[1], off[2], off[3]};
+    for (int i = 0; i < p.cnt; ++i) {
+        const int k = perm[p.beg + i];
+        const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
+        tmp[fill[q]++] = k;
+    }
+    for (int i = 0; i < p.cnt; ++i) perm[p.beg + i] = tmp[i];
+    for (int q = 0; q < 4; ++q) {
+        OctNode &n = L.nodes[c[q]];
+        n.beg = p.beg + off[q];
+        n.cnt = cnt[q];
+        n.no_more = (cnt[q] == 1);
+    }
+    return true;
+}
+
+// ascending (size, node) -- heap sort, in place, no recursion (device friendly)
+AOS2_OCT_HD bool pair_less(const int32_t *a, int i, int j)
+{
+    if (a[2 * i] != a[2 * j]) return a[2 * i] < a[2 * j];
+    return a[2 * i + 1] < a[2 * j + 1];
+}
+AOS2_OCT_HD void pair_swap(int32_t *a, int i, int j)
+{
+    int32_t t0 = a[2 * i], t1 = a[2 * i + 1];
+    a[2 * i] = a[2 * j]; a[2 * i + 1] = a[2 * j + 1];
+    a[2 * j] = t0; a[2 * j + 1] = t1;
+}
+AOS2_OCT_HD void sift_down(int32_t *a, int start, int end)
+{
+    int root = start;
+    while (2 * root + 1 <= end) {
+        int child = 2 * root + 1, sw = root;
+        if (pair_less(a, sw, child)) sw = child;
+        if (child + 1 <= end && pair_less(a, sw, child + 1)) sw = child + 1;
+        if (sw == root) return;
+        pair_swap(a, root, sw);
+        root = sw;
+    }
+}
+AOS2_OCT_HD void pair_sort(int32_t *a, int n)
+{
+    for (int start = (n - 2) / 2; start >= 0; --start) sift_down(a, start, n - 1);
+    for (int end = n - 1; end > 0; --end) {
+        pair_swap(a, 0, end);
+        sift_down(a, 0, end - 1);
+    }
+}
+
+}  // namespace octdetail
+
+// xs, ys, score: n candidates in the reference's emission order.  [minX,maxX) x [minY,maxY) is
+// the level's search box (16 .. w-16).  Writes the kept candidate indices in list order to
+// out_idx (capacity cap) and returns their number; <0 if scratch is exhausted / cap too small.
+AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const uint8_t *score, int n,
+                                  int minX, int maxX, int minY, int maxY, int N, OctScratch &S,
+                                  int32_t *out_idx, int cap)
+{
+    using namespace octdetail;
+    if (n <= 0) return 0;
+    List L;
+    L.nodes = S.nodes;
+    L.n_alloc = 0;
+    L.head = L.tail = -1;
+    L.size = 0;
+    L.cap = S.max_nodes;
+    int32_t *perm = S.perm, *tmp = S.tmp;
+
+    // roots :541-585
+    const float ratio = (float)(maxX - minX) / (float)(maxY - minY);
+    // round(): half away from zero; ratio > 0 and (ratio - floor) is exact in float
+    const float fl = (float)(int)ratio;
+    const int nIni = (int)fl + ((ratio - fl) >= 0.5f ? 1 : 0);
+    if (nIni < 1) return -1;  // reference divides by zero here (tall images): unsupported
+    const float hX = (float)(maxX - minX) / (float)nIni;
+    // count per root, then stable bucket the candidates
+    for (int i = 0; i < nIni; ++i) {
+        int id = new_node(L);
+        if (id < 0) return -2;
+        OctNode &r = L.nodes[id];
+        r.x0 = (int16_t)(int)(hX * (float)i);
+        r.x1 = (int16_t)(int)(hX * (float)(i + 1));
+        r.y0 = 0;
+        r.y1 = (int16_t)(maxY - minY);
+        push_back(L, id);
+    }
+    for (int i = 0; i < n; ++i) {
+        int r = (int)((float)xs[i] / hX);
+        if (r >= nIni) r = nIni - 1;  // cannot happen for x < maxX-minX; guards the arena
+        L.nodes[r].cnt++;
+    }
+    {
+        int acc = 0;
+        for (int i = 0; i < nIni; ++i) {
+            L.nodes[i].beg = acc;
+            acc += L.nodes[i].cnt;
+            L.nodes[i].cnt = 0;
+        }
+        for (int i = 0; i < n; ++i) {
+            int r = (int)((float)xs[i] / hX);
+            if (r >= nIni) r = nIni - 1;
+            perm[L.nodes[r].beg + L.nodes[r].cnt++] = i;
+        }
+    }
+    for (int lit = L.head; lit >= 0;) {
+        OctNode &nd = L.nodes[lit];
+        if (nd.cnt == 1) {
+            nd.no_more = 1;
+            lit = nd.next;
+        } else if (nd.cnt == 0)
+            lit = erase(L, lit);
+        else
+            lit = nd.next;
+    }
+
+    bool finish = false;
+    int32_t *cur = S.pairs_a, *prv = S.pairs_b;
+    int ncur = 0;
+    while (!finish) {
+        const int prevSize = L.size;
+        int nToExpand = 0;
+        ncur = 0;
+        for (int lit = L.head; lit >= 0;) {
+            if (L.nodes[lit].no_more) {
+                lit = L.nodes[lit].next;
+                continue;
+            }
+            int c[4];
+            if (!divide(L, lit, c, xs, ys, perm, tmp)) return -2;
+            for (int q = 0; q < 4; ++q) {
+                const int cn = L.nodes[c[q]].cnt;
+                if (cn > 0) {
+                    push_front(L, c[q]);
+                    if (cn > 1) {
+                        nToExpand++;
+                        cur[2 * ncur] = cn;
+                        cur[2 * ncur + 1] = c[q];
+                        ncur++;
+                    }
+                }
+            }
+            lit = erase(L, lit);
+        }
+        if (L.size >= N || L.size == prevSize) {
+            finish = true;
+        } else if (L.size + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prevSize2 = L.size;
+                // swap buffers: prv = recorded pairs, cur = empty
+                int32_t *t = prv; prv = cur; cur = t;
+                const int nprev = ncur;
+                ncur = 0;
+                pair_sort(prv, nprev);
+                for (int j = nprev - 1; j >= 0; --j) {
+                    const int id = prv[2 * j + 1];
+                    int c[4];
+                    if (!divide(L, id, c, xs, ys, perm, tmp)) return -2;
+                    for (int q = 0; q < 4; ++q) {
+                        const int cn = L.nodes[c[q]].cnt;
+                        if (cn > 0) {
+                            push_front(L, c[q]);
+                            if (cn > 1) {
+                                cur[2 * ncur] = cn;
+                                cur[2 * ncur + 1] = c[q];
+                                ncur++;
+                            }
+                        }
+                    }
+                    erase(L, id);
+                    if (L.size >= N) break;
+                }
+                if (L.size >= N || L.size == prevSize2) finish = true;
+            }
+        }
+    }
+    // best response per node, first wins ties :741-762
+    int nout = 0;
+    for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
+        const OctNode &nd = L.nodes[lit];
+        int best = perm[nd.beg];
+        int maxResponse = score[best];
+        for (int k = 1; k < nd.cnt; ++k) {
+            const int idx = perm[nd.beg + k];
+            if (score[idx] > maxResponse) {
+                best = idx;
+                maxResponse = score[idx];
+            }
+        }
+        if (nout >= cap) return -3;
+        out_idx[nout++] = best;
+    }
+    return nout;
+}
+
+}  // namespace aos2

@@ -1,0 +1,295 @@
+/*
+ * aos2.h -- C ABI of the MI355X-native ORB front-end + LocalBA hot path.
+ *
+ * This is the drop-in boundary under the reference's three C++ class surfaces
+ * (SURVEY.md section 8(b)); every entry point names the reference interface it replaces
+ * (path:line relative to the Active-ORB-SLAM2 checkout).  Plain C, POD arguments, caller-allocated
+ * buffers, int status (0 = ok, <0 = error, see AOS2_ERR_*).  No torch / OpenCV / Eigen types.
+ *
+ * Threading: a handle is NOT re-entrant (like an ORBextractor instance, which owns a mutable
+ * mvImagePyramid); different handles may be used concurrently from different threads (the stereo
+ * path runs one extractor per eye, src/Frame.cc:103-106).  Each handle owns one HIP stream.
+ *
+ * There is no CPU fallback: every compute entry point returns AOS2_ERR_NO_DEVICE when no HIP
+ * device is present.
+ */
+#ifndef AOS2_H
+#define AOS2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOS2_OK 0
+#define AOS2_ERR_ARG (-1)        /* bad argument (NULL, non-positive size, unsupported layout) */
+#define AOS2_ERR_CAPACITY (-2)   /* output buffer too small; *n_out still holds the needed count */
+#define AOS2_ERR_TOO_SMALL (-3)  /* image too small for the pyramid (reference would divide by 0) */
+#define AOS2_ERR_HIP (-4)        /* HIP runtime error, see aos2_last_error() */
+#define AOS2_ERR_NO_DEVICE (-5)  /* no HIP device / device index out of range */
+#define AOS2_ERR_STOPPED (1)     /* LocalBA: stop flag was set before optimisation started */
+
+/* last error text of the calling thread */
+const char *aos2_last_error(void);
+/* number of HIP devices visible (0 when none; never fails) */
+int aos2_device_count(void);
+const char *aos2_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ORBextractor  (include/ORBextractor.h:45-111, src/ORBextractor.cc)
+ * ------------------------------------------------------------------------------------------ */
+
+/* bit-compatible with cv::KeyPoint (28 bytes) */
+typedef struct {
+    float x, y;      /* pt, level-0 pixel units */
+    float size;      /* 31 * scale[octave], truncated (src/ORBextractor.cc:837,846) */
+    float angle;     /* degrees [0,360) */
+    float response;  /* FAST-9/16 corner score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} aos2_keypoint_t;
+
+typedef struct aos2_extractor aos2_extractor_t;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * src/ORBextractor.cc:410-470.  device = HIP device index.  Creation only builds the host-side
+ * tables (no HIP call), so it succeeds without a GPU; the first extract binds the device. */
+int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                          int min_th_fast, int device, aos2_extractor_t **out);
+void aos2_extractor_destroy(aos2_extractor_t *e);
+
+/* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:58-83).  Arrays have nlevels entries and
+ * live as long as the handle. */
+int aos2_extractor_levels(const aos2_extractor_t *e);
+float aos2_extractor_scale_factor(const aos2_extractor_t *e);
+const float *aos2_extractor_scale_factors(const aos2_extractor_t *e);
+const float *aos2_extractor_inv_scale_factors(const aos2_extractor_t *e);
+const float *aos2_extractor_sigma2(const aos2_extractor_t *e);
+const float *aos2_extractor_inv_sigma2(const aos2_extractor_t *e);
+/* mnFeaturesPerLevel (include/ORBextractor.h:101) and umax (:103) -- exposed for tests */
+const int *aos2_extractor_features_per_level(const aos2_extractor_t *e);
+const int *aos2_extractor_umax(const aos2_extractor_t *e);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors)  src/ORBextractor.cc:1043-1105.
+ * img: 8-bit single channel, host memory, `stride` bytes per row (the CV_8UC1 assert of :1050 is
+ * the caller's contract).  mask is ignored by the reference and has no parameter here.
+ * kps[cap], desc[cap*32] are caller-allocated (host).  *n_out = number of keypoints.
+ * Empty image (img==NULL or w<=0 or h<=0) -> AOS2_OK with *n_out = 0 (silent return, :1046).
+ * The result can exceed nfeatures by a few keypoints (octree overshoot);
+ * cap >= aos2_extractor_max_keypoints() always suffices. */
+int aos2_extractor_extract(aos2_extractor_t *e, const uint8_t *img, int w, int h, int stride,
+                           aos2_keypoint_t *kps, uint8_t *desc, int cap, int *n_out);
+int aos2_extractor_max_keypoints(const aos2_extractor_t *e);
+
+/* Batched form for frame-parallel throughput: `batch` images of identical size, host memory,
+ * image b at imgs + b*image_stride.  Outputs are [batch][cap] / [batch][cap][32] / [batch]. */
+int aos2_extractor_extract_batch(aos2_extractor_t *e, const uint8_t *imgs, int batch, int w, int h,
+                                 int stride, size_t image_stride, aos2_keypoint_t *kps,
+                                 uint8_t *desc, int cap, int32_t *n_out);
+
+/* Same with inputs and outputs resident in device memory (HBM).  d_* are device pointers owned
+ * by the caller; the call is synchronous on the handle's stream (returns when results are in
+ * d_kps / d_desc / d_n_out). */
+int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_imgs, int batch,
+                                        int w, int h, int stride, size_t image_stride,
+                                        aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap,
+                                        int32_t *d_n_out);
+
+/* mvImagePyramid[level] (include/ORBextractor.h:85; read by Frame::ComputeStereoMatches,
+ * src/Frame.cc:502,592,609) of image `image` of the last extract on this handle.
+ * Copies the level to host memory `dst` with row pitch dst_stride.  border = 0 gives the w x h
+ * interior (the ROI the reference exposes); border = 19 gives the (w+38) x (h+38) buffer with the
+ * BORDER_REFLECT_101 frame the reference keeps around it (:1113-1128). */
+int aos2_extractor_pyramid_level_size(const aos2_extractor_t *e, int level, int *w, int *h);
+int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int border,
+                                 uint8_t *dst, int dst_stride);
+
+/* Stage taps for parity tests (no reference equivalent): FAST candidates handed to
+ * DistributeOctTree for (image, level) of the last extract, in the reference's emission order
+ * (cells row-major, pixels row-major inside a cell); coordinates relative to (minBorderX,
+ * minBorderY) like src/ORBextractor.cc:822-823. Returns count via *n (arrays may be NULL). */
+int aos2_extractor_debug_candidates(aos2_extractor_t *e, int image, int level, int16_t *xs,
+                                    int16_t *ys, uint8_t *score, int cap, int *n);
+
+/* Timing of the last batch, milliseconds, measured with HIP events on the handle's stream:
+ * [0] pyramid kernels, [1] FAST+NMS kernel, [2] candidate compaction, [3] octree stage
+ * (device kernel, or D2H + host + H2D when the host octree is selected), [4] orientation +
+ * blur + rBRIEF kernel, [5] whole call (host wall clock).  n <= 8 values are written. */
+int aos2_extractor_last_timing(const aos2_extractor_t *e, float *ms, int n);
+
+/* Launches only the FAST+NMS kernel `iters` times on the pyramid of the last batch and returns
+ * the average kernel time in ms (HIP events on the handle's stream) -- roofline measurement. */
+int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms);
+int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms);
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher  (include/ORBmatcher.h:37-102, src/ORBmatcher.cc)
+ * The C++ shim snapshots the Frame / KeyFrame / MapPoint fields each method reads into the SoA
+ * views below and maps the returned indices back to MapPoint*.
+ * ------------------------------------------------------------------------------------------ */
+#define AOS2_TH_HIGH 100     /* ORBmatcher::TH_HIGH  src/ORBmatcher.cc:37 */
+#define AOS2_TH_LOW 50       /* ORBmatcher::TH_LOW   :38 */
+#define AOS2_HISTO_LENGTH 30 /* ORBmatcher::HISTO_LENGTH :39 */
+#define AOS2_GRID_COLS 64    /* FRAME_GRID_COLS include/Frame.h:38 */
+#define AOS2_GRID_ROWS 48    /* FRAME_GRID_ROWS include/Frame.h:37 */
+
+typedef struct aos2_matcher aos2_matcher_t;
+
+/* ORBmatcher::ORBmatcher(float nnratio=0.6, bool checkOri=true)  src/ORBmatcher.cc:41-43 */
+int aos2_matcher_create(float nnratio, int check_orientation, int device, aos2_matcher_t **out);
+void aos2_matcher_destroy(aos2_matcher_t *m);
+
+/* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)  :1647-1663.
+ * Host scalar helper (pure); the device kernels use xor + popcount of the same 256 bits. */
+int aos2_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+/* Brute-force Hamming: for every query descriptor the best and second best train descriptor.
+ * q[nq][32], t[nt][32] host memory.  best_idx/best_dist/second_dist: nq entries.
+ * Ties: lowest train index wins (strict '<' update order of the reference loops). */
+int aos2_matcher_hamming_best2(aos2_matcher_t *m, const uint8_t *q, int nq, const uint8_t *t,
+                               int nt, int32_t *best_idx, int32_t *best_dist,
+                               int32_t *second_dist);
+/* device-resident variant + kernel timing (ms, HIP events) for the roofline/throughput report */
+int aos2_matcher_hamming_best2_device(aos2_matcher_t *m, const uint8_t *d_q, int nq,
+                                      const uint8_t *d_t, int nt, int32_t *d_best_idx,
+                                      int32_t *d_best_dist, int32_t *d_second_dist, int iters,
+                                      float *avg_ms);
+
+typedef struct {
+    int32_t n_kf, n_f;
+    const uint8_t *desc_kf;    /* pKF->mDescriptors, n_kf x 32 */
+    const uint8_t *desc_f;     /* F.mDescriptors, n_f x 32 */
+    const uint8_t *kf_has_mp;  /* n_kf: vpMapPointsKF[i] != NULL && !isBad() (:194-198) */
+    const float *angle_kf;     /* pKF->mvKeysUn[i].angle */
+    const float *angle_f;      /* F.mvKeys[j].angle */
+    /* DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) flattened to CSR with node ids
+     * ascending: Thirdparty/DBoW2/DBoW2/FeatureVector.h:21-22 */
+    int32_t n_nodes_kf, n_nodes_f;
+    const int32_t *node_id_kf, *node_off_kf, *node_idx_kf;
+    const int32_t *node_id_f, *node_off_f, *node_idx_f;
+} aos2_bow_pair_t;
+
+/* int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  src/ORBmatcher.cc:159-288.
+ * `n_pairs` independent (KF, F) pairs are matched in one launch (one workgroup per pair).
+ * match_f[p] (n_f entries): index of the KF feature whose MapPoint is assigned to frame feature j,
+ * or -1 (NULL).  nmatches[p] = return value. */
+int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs,
+                               int32_t *const *match_f, int32_t *nmatches);
+
+typedef struct {
+    int32_t n_f;
+    const uint8_t *desc_f;      /* F.mDescriptors */
+    const float *kp_x, *kp_y;   /* F.mvKeysUn[i].pt */
+    const int32_t *kp_octave;   /* F.mvKeysUn[i].octave */
+    const float *kp_angle;      /* F.mvKeysUn[i].angle */
+    const float *u_right;       /* F.mvuRight */
+    const float *scale_factors; /* F.mvScaleFactors */
+    int32_t n_levels;
+    float min_x, min_y, max_x, max_y; /* F.mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float grid_w_inv, grid_h_inv;     /* F.mfGridElementWidthInv / HeightInv */
+    /* F.mGrid[64][48] as CSR, cell = ix*48 + iy (src/Frame.cc:259-274) */
+    const int32_t *grid_off, *grid_idx;
+    /* per feature: 0 = mvpMapPoints[i]==NULL, 1 = map point with Observations()==0,
+     * 2 = map point with Observations()>0 (the skip test of :87-89 / :1403-1405) */
+    const uint8_t *f_mp_state;
+} aos2_frame_view_t;
+
+typedef struct {
+    int32_t n_mp;
+    const uint8_t *track_in_view; /* pMP->mbTrackInView && !pMP->isBad() (:52-56) */
+    const int32_t *pred_level;    /* mnTrackScaleLevel */
+    const float *view_cos;        /* mTrackViewCos */
+    const float *proj_x, *proj_y, *proj_xr; /* mTrackProjX / Y / XR */
+    const uint8_t *desc;          /* pMP->GetDescriptor(), n_mp x 32 */
+    const uint8_t *has_obs;       /* pMP->Observations() > 0 */
+} aos2_proj_mp_t;
+
+/* int ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, const float th)
+ * src/ORBmatcher.cc:45-129.  match_f[n_f]: index into the map point list newly assigned to
+ * F.mvpMapPoints[j], or -1 = entry unchanged. */
+int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t *f,
+                                      const aos2_proj_mp_t *p, float th, int32_t *match_f,
+                                      int32_t *nmatches);
+
+typedef struct {
+    int32_t n_last;
+    const uint8_t *last_valid;  /* LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] */
+    const float *world_pos;     /* pMP->GetWorldPos(), n_last x 3 float32 */
+    const uint8_t *desc;        /* pMP->GetDescriptor(), n_last x 32 */
+    const int32_t *last_octave; /* LastFrame.mvKeys[i].octave */
+    const float *last_angle;    /* LastFrame.mvKeysUn[i].angle */
+    const uint8_t *has_obs;     /* pMP->Observations() > 0 */
+    float Tcw[16], Tlw[16];     /* CurrentFrame.mTcw, LastFrame.mTcw: row-major 4x4 float32 */
+    float fx, fy, cx, cy, mb, mbf;
+} aos2_proj_last_t;
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th,
+ * const bool bMono)  src/ORBmatcher.cc:1328-1470.  match_f[n_f]: last-frame feature index whose
+ * MapPoint is assigned, -1 = unchanged, -2 = reset to NULL by the rotation-histogram cull. */
+int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_view_t *cur,
+                                           const aos2_proj_last_t *p, float th, int mono,
+                                           int32_t *match_f, int32_t *nmatches);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer::LocalBundleAdjustment  (include/Optimizer.h:45, src/Optimizer.cc:454-779)
+ * The C++ shim gathers the local window from the KeyFrame/MapPoint pointer graph (:457-505)
+ * and emits vertices/edges in the reference's order; this call runs :507-744 (g2o graph,
+ * 5 + 10 Levenberg-Marquardt iterations with the outlier pass in between) on the device and
+ * returns poses/points in the float32 form the reference writes back (:763-778).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_poses;   /* local keyframes first or in any order; fixed flag decides */
+    int32_t n_points;
+    int32_t n_edges;
+    const float *pose_Tcw;      /* n_poses x 16: KeyFrame::GetPose() row-major float32 4x4 */
+    const uint8_t *pose_fixed;  /* n_poses: fixed camera, or mnId==0 (:530,:543) */
+    const int64_t *pose_id;     /* KeyFrame::mnId (Hessian ordering) */
+    const float *point_xyz;     /* n_points x 3: MapPoint::GetWorldPos() float32 */
+    const int64_t *point_id;    /* MapPoint::mnId */
+    const int32_t *edge_pose;   /* n_edges: index into poses */
+    const int32_t *edge_point;  /* n_edges: index into points */
+    const float *edge_obs;      /* n_edges x 3: kpUn.pt.x, kpUn.pt.y, mvuRight (ignored for mono) */
+    const uint8_t *edge_stereo; /* n_edges: mvuRight >= 0 (:595) */
+    const float *edge_inv_sigma2; /* n_edges: pKFi->mvInvLevelSigma2[kpUn.octave] */
+    float fx, fy, cx, cy, bf;   /* pKFi->fx ... pKFi->mbf (float members of KeyFrame) */
+    const volatile uint8_t *stop_flag; /* bool* pbStopFlag, may be NULL; polled between iterations */
+    int32_t iters_first, iters_second; /* 5 and 10 (:661,:708) */
+} aos2_lba_problem_t;
+
+typedef struct {
+    float *pose_Tcw;         /* n_poses x 16 out: Converter::toCvMat(SE3Quat) (:767) */
+    float *point_xyz;        /* n_points x 3 out (:776) */
+    uint8_t *edge_outlier;   /* n_edges out: observation to erase (:712-744) */
+    double *edge_chi2;       /* n_edges out (may be NULL): e->chi2() at the end */
+    int32_t iters_done_first, iters_done_second;
+    double final_chi2;       /* robust chi2 of the active edges after the last accepted step */
+    double final_lambda;
+    float ms_device;         /* device time of the whole solve (HIP events) */
+} aos2_lba_result_t;
+
+typedef struct aos2_lba aos2_lba_t;
+int aos2_lba_create(int device, aos2_lba_t **out);
+void aos2_lba_destroy(aos2_lba_t *s);
+/* void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*)  numerical part.
+ * Returns AOS2_OK, AOS2_ERR_STOPPED if *stop_flag was set on entry (early return, :656-658;
+ * outputs then equal inputs), or an error. */
+int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r);
+
+/* ------------------------------------------------------------------------------------------
+ * Test taps (no reference equivalent): shared primitives run in isolation.
+ * ------------------------------------------------------------------------------------------ */
+/* DistributeOctTree (src/ORBextractor.cc:539-763) on the HOST with the routine the device kernel
+ * also runs (csrc/octree.h).  Returns the number of kept candidates (indices in out_idx) or <0. */
+int aos2_debug_octree_host(const int16_t *xs, const int16_t *ys, const uint8_t *score, int n,
+                           int minX, int maxX, int minY, int maxY, int N, int32_t *out_idx, int cap);
+/* rBRIEF steering sin/cos (csrc/sincos_exact.h) evaluated on the host / on the device */
+void aos2_debug_sincos_host(float angle_rad, float *s, float *c);
+int aos2_debug_sincos_device(const float *angles, int n, float *s, float *c, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOS2_H */

@@ -743,13 +743,60 @@ static float ic_angle(const uint8_t *image, int step, float ptx, float pty, cons
     return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
+/* Steering a = cos(angle), b = sin(angle) (:112-113).  The reference calls libm cosf/sinf through
+ * the std:: float overloads; their last bit depends on the glibc version (glibc 2.35 differs from
+ * the correctly rounded value for ~2.6% of angles).  Parity convention 3: a and b are
+ * the correctly rounded float cosine/sine, obtained from a fixed IEEE-double polynomial (same
+ * operation sequence as the device).  orc_set_trig_mode(1) switches to libm for measuring the
+ * effect of that choice. */
+static int g_trig_libm = 0;
+void orc_set_trig_mode(int use_libm) { g_trig_libm = use_libm; }
+
+void orc_sincos_exact(float angle_rad, float *s_out, float *c_out)
+{
+    const double x = (double)angle_rad;
+    const int k = (int)(x * 6.36619772367581382433e-01 + 0.5);
+    const double fk = (double)k;
+    double r = x - fk * 1.57079632673412561417e+00;
+    r = r - fk * 6.07710050650619224932e-11;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = ps * z + -2.50507602534068634195e-08;
+    ps = ps * z + 2.75573137070700676789e-06;
+    ps = ps * z + -1.98412698298579493134e-04;
+    ps = ps * z + 8.33333333332248946124e-03;
+    ps = ps * z + -1.66666666666666324348e-01;
+    const double sn = r + (r * z) * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = pc * z + 2.08757232129817482790e-09;
+    pc = pc * z + -2.75573143513906633035e-07;
+    pc = pc * z + 2.48015872894767294178e-05;
+    pc = pc * z + -1.38888888888741095749e-03;
+    pc = pc * z + 4.16666666666666019037e-02;
+    const double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    double sv, cv;
+    switch (k & 3) {
+        case 0: sv = sn; cv = cs; break;
+        case 1: sv = cs; cv = -sn; break;
+        case 2: sv = -sn; cv = -cs; break;
+        default: sv = -cs; cv = sn; break;
+    }
+    *s_out = (float)sv;
+    *c_out = (float)cv;
+}
+
 /* computeOrbDescriptor :108-147 */
 static void compute_orb_descriptor(const orc_keypoint_t *kpt, const uint8_t *img, int step,
                                    const int8_t *pattern, uint8_t *desc)
 {
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float angle = (float)kpt->angle * factorPI;
-    float a = (float)cosf(angle), b = (float)sinf(angle);
+    float a, b;
+    if (g_trig_libm) {
+        a = (float)cosf(angle);
+        b = (float)sinf(angle);
+    } else
+        orc_sincos_exact(angle, &b, &a);
     const uint8_t *center = img + (size_t)orc_cv_round_f(kpt->y) * step + orc_cv_round_f(kpt->x);
 #define GET_VALUE(idx)                                                                        \
     center[orc_cv_round_f((float)pattern[2 * (idx)] * b + (float)pattern[2 * (idx) + 1] * a) * step + \

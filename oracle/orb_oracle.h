@@ -65,6 +65,9 @@ int orc_fast9_16(const uint8_t *img, int w, int h, int stride, int threshold, in
 /* corner score of one pixel (ring must be inside the image) */
 int orc_fast_corner_score(const uint8_t *center, int stride, int threshold);
 float orc_fast_atan2(float y, float x);
+/* rBRIEF steering trig: 0 = correctly rounded (default, parity convention 3), 1 = libm cosf/sinf */
+void orc_set_trig_mode(int use_libm);
+void orc_sincos_exact(float angle_rad, float *s_out, float *c_out);
 int orc_cv_round_f(float v);
 /* cv::resize INTER_LINEAR 8UC1 */
 void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw,
