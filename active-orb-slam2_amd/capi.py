@@ -249,9 +249,199 @@ def debug_sincos_device(angles, device=0):
     return s, c
 
 
-class Matcher:  # filled in below
-    pass
+# ------------------------------------------------------------------------------------------ matcher
+class _BowPair(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_f", C.c_int32), ("desc_kf", C.c_void_p), ("desc_f", C.c_void_p),
+                ("kf_has_mp", C.c_void_p), ("angle_kf", C.c_void_p), ("angle_f", C.c_void_p),
+                ("n_nodes_kf", C.c_int32), ("n_nodes_f", C.c_int32),
+                ("node_id_kf", C.c_void_p), ("node_off_kf", C.c_void_p), ("node_idx_kf", C.c_void_p),
+                ("node_id_f", C.c_void_p), ("node_off_f", C.c_void_p), ("node_idx_f", C.c_void_p)]
+
+
+class _FrameView(C.Structure):
+    _fields_ = [("n_f", C.c_int32), ("desc_f", C.c_void_p), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p),
+                ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p), ("u_right", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("n_levels", C.c_int32),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_w_inv", C.c_float), ("grid_h_inv", C.c_float),
+                ("grid_off", C.c_void_p), ("grid_idx", C.c_void_p), ("f_mp_state", C.c_void_p)]
+
+
+class _ProjMp(C.Structure):
+    _fields_ = [("n_mp", C.c_int32), ("track_in_view", C.c_void_p), ("pred_level", C.c_void_p),
+                ("view_cos", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p),
+                ("proj_xr", C.c_void_p), ("desc", C.c_void_p), ("has_obs", C.c_void_p)]
+
+
+class _ProjLast(C.Structure):
+    _fields_ = [("n_last", C.c_int32), ("last_valid", C.c_void_p), ("world_pos", C.c_void_p),
+                ("desc", C.c_void_p), ("last_octave", C.c_void_p), ("last_angle", C.c_void_p),
+                ("has_obs", C.c_void_p), ("Tcw", C.c_float * 16), ("Tlw", C.c_float * 16),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mb", C.c_float), ("mbf", C.c_float)]
+
+
+_DTYPES = dict(desc_kf=np.uint8, desc_f=np.uint8, kf_has_mp=np.uint8, angle_kf=np.float32, angle_f=np.float32,
+               node_id_kf=np.int32, node_off_kf=np.int32, node_idx_kf=np.int32, node_id_f=np.int32,
+               node_off_f=np.int32, node_idx_f=np.int32, kp_x=np.float32, kp_y=np.float32, kp_octave=np.int32,
+               kp_angle=np.float32, u_right=np.float32, scale_factors=np.float32, grid_off=np.int32,
+               grid_idx=np.int32, f_mp_state=np.uint8, track_in_view=np.uint8, pred_level=np.int32,
+               view_cos=np.float32, proj_x=np.float32, proj_y=np.float32, proj_xr=np.float32, desc=np.uint8,
+               has_obs=np.uint8, last_valid=np.uint8, world_pos=np.float32, last_octave=np.int32,
+               last_angle=np.float32)
+
+
+def _fill_struct(st, d, keep):
+    for name, ct in st._fields_:
+        if name not in d:
+            continue
+        v = d[name]
+        if ct is C.c_void_p:
+            a = np.ascontiguousarray(v, _DTYPES[name])
+            keep.append(a)
+            setattr(st, name, a.ctypes.data)
+        elif isinstance(v, np.ndarray) and v.size == 16:
+            setattr(st, name, (C.c_float * 16)(*[float(x) for x in v.reshape(-1)]))
+        else:
+            setattr(st, name, v.item() if hasattr(v, "item") else v)
+    return st
+
+
+class Matcher:
+    """Mirror of ORBmatcher (include/ORBmatcher.h:37-102) over SoA snapshots."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, check_orientation=True, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.aos2_matcher_create(float(nnratio), int(bool(check_orientation)), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aos2_matcher_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return lib().aos2_descriptor_distance(_p(a), _p(b))
+
+    def hamming_best2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        bi = np.zeros(len(q), np.int32)
+        bd = np.zeros(len(q), np.int32)
+        sd = np.zeros(len(q), np.int32)
+        _check(self.L.aos2_matcher_hamming_best2(self.h, _p(q), len(q), _p(t), len(t), _p(bi), _p(bd), _p(sd)))
+        return bi, bd, sd
+
+    def hamming_best2_device(self, d_q, nq, d_t, nt, d_bi, d_bd, d_sd, iters=1):
+        ms = C.c_float(0)
+        _check(self.L.aos2_matcher_hamming_best2_device(self.h, C.c_void_p(d_q), nq, C.c_void_p(d_t), nt,
+                                                        C.c_void_p(d_bi), C.c_void_p(d_bd), C.c_void_p(d_sd),
+                                                        iters, C.byref(ms)))
+        return ms.value
+
+    def SearchByBoW(self, problems):
+        """problems: list of synth_bow_problem()-style dicts (or one dict). Returns [(nmatches, match_f)]."""
+        single = isinstance(problems, dict)
+        if single:
+            problems = [problems]
+        keep = []
+        arr = (_BowPair * len(problems))()
+        outs = []
+        for i, p in enumerate(problems):
+            d = dict(p)
+            d["n_kf"], d["n_f"] = len(p["desc_kf"]), len(p["desc_f"])
+            d["n_nodes_kf"], d["n_nodes_f"] = len(p["node_id_kf"]), len(p["node_id_f"])
+            _fill_struct(arr[i], d, keep)
+            outs.append(np.zeros(max(d["n_f"], 1), np.int32))
+        ptrs = (C.c_void_p * len(problems))(*[o.ctypes.data for o in outs])
+        nm = np.zeros(len(problems), np.int32)
+        _check(self.L.aos2_matcher_search_by_bow(self.h, C.byref(arr), len(problems), ptrs, _p(nm)))
+        res = [(int(nm[i]), outs[i][: len(problems[i]["desc_f"])]) for i in range(len(problems))]
+        return res[0] if single else res
+
+    def SearchByProjection(self, f, mp, th=3.0):
+        keep = []
+        fv = _fill_struct(_FrameView(), f, keep)
+        pm = _fill_struct(_ProjMp(), mp, keep)
+        match = np.zeros(max(f["n_f"], 1), np.int32)
+        n = np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_by_projection(self.h, C.byref(fv), C.byref(pm), float(th), _p(match), _p(n)))
+        return int(n[0]), match[: f["n_f"]]
+
+    def SearchByProjectionLast(self, cur, last, th, mono):
+        keep = []
+        fv = _fill_struct(_FrameView(), cur, keep)
+        pl = _fill_struct(_ProjLast(), last, keep)
+        match = np.zeros(max(cur["n_f"], 1), np.int32)
+        n = np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_by_projection_last(self.h, C.byref(fv), C.byref(pl), float(th), int(mono),
+                                                             _p(match), _p(n)))
+        return int(n[0]), match[: cur["n_f"]]
+
+
+# ------------------------------------------------------------------------------------------ local BA
+class _LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_Tcw", C.c_void_p), ("pose_fixed", C.c_void_p), ("pose_id", C.c_void_p),
+                ("point_xyz", C.c_void_p), ("point_id", C.c_void_p), ("edge_pose", C.c_void_p),
+                ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p), ("edge_stereo", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("stop_flag", C.c_void_p), ("iters_first", C.c_int32), ("iters_second", C.c_int32)]
+
+
+class _LbaResult(C.Structure):
+    _fields_ = [("pose_Tcw", C.c_void_p), ("point_xyz", C.c_void_p), ("edge_outlier", C.c_void_p),
+                ("edge_chi2", C.c_void_p), ("iters_done_first", C.c_int32), ("iters_done_second", C.c_int32),
+                ("final_chi2", C.c_double), ("final_lambda", C.c_double), ("ms_device", C.c_float)]
 
 
 class LocalBA:
-    pass
+    """Optimizer::LocalBundleAdjustment numerical part (include/Optimizer.h:45, src/Optimizer.cc:454-779)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.aos2_lba_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aos2_lba_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def LocalBundleAdjustment(self, prob, stop_flag=None, iters=(5, 10)):
+        keep = []
+        s = _LbaProblem()
+        s.n_poses, s.n_points, s.n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
+        for name, dt in (("pose_Tcw", np.float32), ("pose_fixed", np.uint8), ("pose_id", np.int64),
+                         ("point_xyz", np.float32), ("point_id", np.int64), ("edge_pose", np.int32),
+                         ("edge_point", np.int32), ("edge_obs", np.float32), ("edge_stereo", np.uint8),
+                         ("edge_inv_sigma2", np.float32)):
+            a = np.ascontiguousarray(prob[name], dt)
+            keep.append(a)
+            setattr(s, name, a.ctypes.data)
+        s.fx, s.fy, s.cx, s.cy, s.bf = (float(np.float32(prob[k])) for k in ("fx", "fy", "cx", "cy", "bf"))
+        if stop_flag is not None:
+            keep.append(stop_flag)
+            s.stop_flag = stop_flag.ctypes.data
+        s.iters_first, s.iters_second = iters
+        r = _LbaResult()
+        Tout = np.zeros((s.n_poses, 16), np.float32)
+        Pout = np.zeros((s.n_points, 3), np.float32)
+        outl = np.zeros(s.n_edges, np.uint8)
+        chi2 = np.zeros(s.n_edges, np.float64)
+        r.pose_Tcw, r.point_xyz, r.edge_outlier, r.edge_chi2 = Tout.ctypes.data, Pout.ctypes.data, outl.ctypes.data, chi2.ctypes.data
+        st = _check(self.L.aos2_lba_solve(self.h, C.byref(s), C.byref(r)), ok=(AOS2_OK, AOS2_ERR_STOPPED))
+        return dict(status=st, pose_Tcw=Tout, point_xyz=Pout, edge_outlier=outl, edge_chi2=chi2,
+                    iters=(r.iters_done_first, r.iters_done_second), final_chi2=r.final_chi2,
+                    final_lambda=r.final_lambda, ms_device=r.ms_device)

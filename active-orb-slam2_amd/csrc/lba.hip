@@ -1,2 +1,983 @@
-// placeholder, replaced below
+// Optimizer::LocalBundleAdjustment numerical core on gfx950 (reference src/Optimizer.cc:507-744 and
+// the vendored g2o it drives: optimization_algorithm_levenberg.cpp:61-164, block_solver.hpp:367-604,
+// base_binary_edge.hpp:55-120, robust_kernel_impl.cpp:78-91, types_six_dof_expmap.{h,cpp},
+// se3quat.h).  All arithmetic is IEEE double like g2o (one float reciprocal in the stereo
+// projection, types_six_dof_expmap.cpp:151).
+//
+// Device layout: SoA doubles for poses (qx qy qz qw tx ty tz), points, edges; the active set of a
+// pass is a list of edge "slots" with three CSR views (by point, by free pose, by point restricted
+// to free poses sorted by pose = the Hpl column of block_solver.hpp:398).  The host runs the
+// Levenberg-Marquardt control flow and reads two scalars per trial step.
+//
+// Kernels: residual+Huber, Jacobian/quadratic-form fill (per-edge, no atomics), deterministic
+// per-vertex gathers for Hll/Hpp/b, per-landmark Schur complement (3x3 inverse, 6x3.3x3.3x6 block
+// products, f64 atomics into the dense reduced system), dense LDL^T of the <= (6 Np)^2 system in
+// one workgroup, back-substitution + manifold update.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
 #include "aos2_common.h"
+
+namespace aos2 {
+
+// ------------------------------------------------------------------------------------------ math
+__host__ __device__ inline void quat_from_rot(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+
+__host__ __device__ inline void rot_from_quat(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__host__ __device__ inline void quat_normalize_rot(double q[4])
+{
+    if (q[3] < 0)
+        for (int i = 0; i < 4; ++i) q[i] *= -1;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+
+__host__ __device__ inline void quat_rotate(const double q[4], const double v[3], double out[3])
+{
+    double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+    for (int i = 0; i < 3; ++i) out[i] = v[i] + q[3] * uv[i] + c[i];
+}
+
+__host__ __device__ inline void se3_map(const double qt[7], const double X[3], double out[3])
+{
+    double r[3];
+    quat_rotate(qt, X, r);
+    for (int i = 0; i < 3; ++i) out[i] = r[i] + qt[4 + i];
+}
+
+// T <- exp(upd) * T  (VertexSE3Expmap::oplusImpl, SE3Quat::exp se3quat.h:223-257, operator* :104-110)
+__device__ inline void se3_oplus(const double upd[6], double T[7])
+{
+    const double *omega = upd, *ups = upd + 3;
+    const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+    const double Om[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+    double Om2[9], R[9], V[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Om2[i * 3 + j] = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) {
+            R[i] = I[i] + Om[i] + Om2[i];
+            V[i] = R[i];
+        }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
+        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; ++i) {
+            R[i] = I[i] + a * Om[i] + b * Om2[i];
+            V[i] = I[i] + b * Om[i] + c * Om2[i];
+        }
+    }
+    double e[7];
+    quat_from_rot(R, e);
+    quat_normalize_rot(e);
+    for (int i = 0; i < 3; ++i) e[4 + i] = V[i * 3] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
+    // e * T
+    double rt[3], q[4];
+    quat_rotate(e, T + 4, rt);
+    q[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
+    q[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
+    q[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
+    q[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
+    quat_normalize_rot(q);
+    for (int i = 0; i < 4; ++i) T[i] = q[i];
+    for (int i = 0; i < 3; ++i) T[4 + i] = e[4 + i] + rt[i];
+}
+
+__device__ inline void mat3_inverse(const double m[9], double inv[9])
+{
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c10 = m[5] * m[6] - m[3] * m[8];
+    const double c20 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c10 + m[2] * c20;
+    const double id = 1.0 / det;
+    inv[0] = c00 * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c10 * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c20 * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+struct Cam {
+    double fx, fy, cx, cy, bf;
+    float bf_f;  // cam_project takes bf as `const float&` (types_six_dof_expmap.cpp:150)
+    double delta_mono, delta_stereo;  // Huber deltas (float sqrt -> double, Optimizer.cc:570-571)
+};
+
+// device-side problem view
+struct LbaDev {
+    int n_poses, n_points, n_edges;
+    double *pose, *point;            // estimates
+    const int32_t *e_pose, *e_point;
+    const double *e_obs, *e_w;
+    const uint8_t *e_stereo;
+    uint8_t *e_robust, *e_level1;
+    double *err;                      // n_edges x 3, last computed _error
+    Cam cam;
+};
+
+// active structure of one optimisation pass
+struct LbaAct {
+    int ka, np, nl;                  // active slots, free poses, active points
+    const int32_t *act;              // slot -> edge
+    const int32_t *k_ph, *k_lh;      // slot -> pose hidx (-1 fixed) / point hidx
+    const int32_t *hpose, *hpoint;   // hidx -> pose / point index
+    const int32_t *pt_off, *pt_k;    // slots by point (active order)
+    const int32_t *ps_off, *ps_k;    // slots by free pose (active order)
+    const int32_t *pl_off, *pl_k;    // free-pose slots by point, ascending pose hidx
+    double *JA, *JB, *Wr, *wo, *Hpl; // per slot: 9, 18, 3, 1, 18
+    double *Hpp, *Hll, *b, *x, *Hs, *bs, *coeff, *Dinv;
+    double *tmp;                     // reduction scratch (>= max(ka, 6np+3nl))
+    double *scal;                    // [0] chi2, [1] scale, [2] max diag, [3] solve ok
+};
+
+__device__ inline double edge_chi2(const double *er, double w, int D)
+{
+    double s = 0;
+    for (int i = 0; i < D; ++i) s += er[i] * (w * er[i]);
+    return s;
+}
+
+__device__ inline void robustify(double e, double delta, double rho[2])
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) {
+        rho[0] = e;
+        rho[1] = 1.;
+    } else {
+        const double sqrte = sqrt(e);
+        rho[0] = 2 * sqrte * delta - dsqr;
+        rho[1] = delta / sqrte;
+    }
+}
+
+// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114)
+__global__ void k_errors(LbaDev P, LbaAct A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.ka) return;
+    const int e = A.act[k];
+    const double *T = P.pose + 7 * (size_t)P.e_pose[e];
+    const double *X = P.point + 3 * (size_t)P.e_point[e];
+    const double *obs = P.e_obs + 3 * (size_t)e;
+    double p[3], er[3];
+    se3_map(T, X, p);
+    const int stereo = P.e_stereo[e];
+    if (!stereo) {
+        const double u = p[0] / p[2], v = p[1] / p[2];
+        er[0] = obs[0] - (u * P.cam.fx + P.cam.cx);
+        er[1] = obs[1] - (v * P.cam.fy + P.cam.cy);
+        er[2] = 0;
+    } else {
+        const float invz = (float)(1.0 / p[2]);
+        const double r0 = p[0] * invz * P.cam.fx + P.cam.cx;
+        const double r1 = p[1] * invz * P.cam.fy + P.cam.cy;
+        const double r2 = r0 - (double)__fmul_rn(P.cam.bf_f, invz);
+        er[0] = obs[0] - r0;
+        er[1] = obs[1] - r1;
+        er[2] = obs[2] - r2;
+    }
+    double *dst = P.err + 3 * (size_t)e;
+    dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+    double c = edge_chi2(er, P.e_w[e], stereo ? 3 : 2);
+    if (P.e_robust[e]) {
+        double rho[2];
+        robustify(c, stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
+        c = rho[0];
+    }
+    A.tmp[k] = c;
+}
+
+// deterministic sum / max of n doubles by one workgroup -> out[0]
+template <bool kMax>
+__global__ __launch_bounds__(1024) void k_reduce(const double *v, int n, double *out)
+{
+    __shared__ double sh[1024];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc = kMax ? fmax(acc, fabs(v[i])) : acc + v[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = kMax ? fmax(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// linearizeOplus + the per-edge part of constructQuadraticForm
+__global__ void k_linearize(LbaDev P, LbaAct A)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.ka) return;
+    const int e = A.act[k];
+    const double *T = P.pose + 7 * (size_t)P.e_pose[e];
+    const double *X = P.point + 3 * (size_t)P.e_point[e];
+    const int stereo = P.e_stereo[e];
+    const int D = stereo ? 3 : 2;
+    const double fx = P.cam.fx, fy = P.cam.fy, bf = P.cam.bf;
+    double p[3], R[9];
+    se3_map(T, X, p);
+    rot_from_quat(T, R);
+    const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+    double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Jb[18];
+    for (int i = 0; i < 18; ++i) Jb[i] = 0;
+    if (!stereo) {
+        const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        const double s = -1. / z;
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) {
+                const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
+                Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
+            }
+    } else {
+        for (int c = 0; c < 3; ++c) {
+            Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+            Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+            Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
+        }
+    }
+    Jb[0] = x * y / z_2 * fx;
+    Jb[1] = -(1 + (x * x / z_2)) * fx;
+    Jb[2] = y / z * fx;
+    Jb[3] = -1. / z * fx;
+    Jb[4] = 0;
+    Jb[5] = x / z_2 * fx;
+    Jb[6] = (1 + y * y / z_2) * fy;
+    Jb[7] = -x * y / z_2 * fy;
+    Jb[8] = -x / z * fy;
+    Jb[9] = 0;
+    Jb[10] = -1. / z * fy;
+    Jb[11] = y / z_2 * fy;
+    if (stereo) {
+        Jb[12] = Jb[0] - bf * y / z_2;
+        Jb[13] = Jb[1] + bf * x / z_2;
+        Jb[14] = Jb[2];
+        Jb[15] = Jb[3];
+        Jb[16] = 0;
+        Jb[17] = Jb[5] - bf / z_2;
+    }
+    const double *er = P.err + 3 * (size_t)e;
+    const double w = P.e_w[e];
+    double omr[3] = {0, 0, 0};
+    for (int i = 0; i < D; ++i) omr[i] = -(w * er[i]);
+    double wo = w;
+    if (P.e_robust[e]) {
+        double rho[2];
+        robustify(edge_chi2(er, w, D), stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
+        wo = rho[1] * w;
+        for (int i = 0; i < D; ++i) omr[i] *= rho[1];
+    }
+    double *ja = A.JA + 9 * (size_t)k, *jb = A.JB + 18 * (size_t)k;
+    for (int i = 0; i < 9; ++i) ja[i] = Ja[i];
+    for (int i = 0; i < 18; ++i) jb[i] = Jb[i];
+    A.Wr[3 * (size_t)k] = omr[0]; A.Wr[3 * (size_t)k + 1] = omr[1]; A.Wr[3 * (size_t)k + 2] = omr[2];
+    A.wo[k] = wo;
+    if (A.k_ph[k] >= 0) {
+        double *h = A.Hpl + 18 * (size_t)k;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double t = 0;
+                for (int d = 0; d < D; ++d) t += Jb[d * 6 + r] * wo * Ja[d * 3 + c];
+                h[r * 3 + c] = t;
+            }
+    }
+}
+
+// Hll, b_l: one thread per active point, edges in active (insertion) order like g2o
+__global__ void k_accum_points(LbaAct A)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= A.nl) return;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    for (int a = A.pt_off[l]; a < A.pt_off[l + 1]; ++a) {
+        const int k = A.pt_k[a];
+        const double *ja = A.JA + 9 * (size_t)k, *wr = A.Wr + 3 * (size_t)k;
+        const double wo = A.wo[k];
+        for (int r = 0; r < 3; ++r) {
+            bl[r] += ja[r] * wr[0] + ja[3 + r] * wr[1] + ja[6 + r] * wr[2];
+            for (int c = 0; c < 3; ++c) H[r * 3 + c] += ja[r] * wo * ja[c] + ja[3 + r] * wo * ja[3 + c] + ja[6 + r] * wo * ja[6 + c];
+        }
+    }
+    for (int i = 0; i < 9; ++i) A.Hll[9 * (size_t)l + i] = H[i];
+    for (int i = 0; i < 3; ++i) A.b[6 * (size_t)A.np + 3 * (size_t)l + i] = bl[i];
+}
+
+// Hpp, b_p: one workgroup per free pose; strided partial sums + fixed-order tree reduction
+__global__ __launch_bounds__(256) void k_accum_poses(LbaAct A)
+{
+    __shared__ double sh[256][43];
+    const int p = blockIdx.x;
+    double acc[42];
+    for (int i = 0; i < 42; ++i) acc[i] = 0;
+    for (int a = A.ps_off[p] + threadIdx.x; a < A.ps_off[p + 1]; a += 256) {
+        const int k = A.ps_k[a];
+        const double *jb = A.JB + 18 * (size_t)k, *wr = A.Wr + 3 * (size_t)k;
+        const double wo = A.wo[k];
+        for (int r = 0; r < 6; ++r) {
+            acc[36 + r] += jb[r] * wr[0] + jb[6 + r] * wr[1] + jb[12 + r] * wr[2];
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += jb[r] * wo * jb[c] + jb[6 + r] * wo * jb[6 + c] + jb[12 + r] * wo * jb[12 + c];
+        }
+    }
+    for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x < 36) A.Hpp[36 * (size_t)p + threadIdx.x] = sh[0][threadIdx.x];
+    if (threadIdx.x < 6) A.b[6 * (size_t)p + threadIdx.x] = sh[0][36 + threadIdx.x];
+}
+
+// |H_jj| of every free vertex -> tmp (computeLambdaInit, levenberg.cpp:166-180)
+__global__ void k_diag(LbaAct A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n6 = 6 * A.np, n = n6 + 3 * A.nl;
+    if (i >= n) return;
+    double v;
+    if (i < n6)
+        v = A.Hpp[36 * (size_t)(i / 6) + (i % 6) * 7];
+    else {
+        const int j = i - n6;
+        v = A.Hll[9 * (size_t)(j / 3) + (j % 3) * 4];
+    }
+    A.tmp[i] = v;
+}
+
+// _Hschur = _Hpp (+ lambda on the diagonal), coefficients = 0
+__global__ void k_schur_init(LbaAct A, double lambda)
+{
+    const int n6 = 6 * A.np;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n6 * n6) return;
+    const int r = i / n6, c = i - r * n6;
+    double v = 0;
+    if (r / 6 == c / 6) {
+        v = A.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + (c % 6)];
+        if (r == c) v += lambda;
+    }
+    A.Hs[i] = v;
+    if (i < n6) A.coeff[i] = 0;
+}
+
+// per landmark: Dinv = (Hll + lambda I)^-1, db, coefficients, Hschur(i1,i2) -= B_i1 Dinv B_i2^T
+// one wave per landmark; lanes enumerate the (a <= b) pairs of its free-pose column
+__global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
+{
+    const int l = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n6 = 6 * A.np;
+    double D[9], Dinv[9];
+    for (int i = 0; i < 9; ++i) D[i] = A.Hll[9 * (size_t)l + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    mat3_inverse(D, Dinv);
+    const double *bl = A.b + n6 + 3 * (size_t)l;
+    double db[3];
+    for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) A.Dinv[9 * (size_t)l + i] = Dinv[i];
+    const int c0 = A.pl_off[l], m = A.pl_off[l + 1] - c0;
+    // coefficients
+    for (int a = lane; a < m; a += 64) {
+        const int ka = A.pl_k[c0 + a];
+        const int i1 = A.k_ph[ka];
+        const double *Bi = A.Hpl + 18 * (size_t)ka;
+        for (int r = 0; r < 6; ++r)
+            atomicAdd(&A.coeff[6 * i1 + r], Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2]);
+    }
+    const int npairs = m * (m + 1) / 2;
+    for (int t = lane; t < npairs; t += 64) {
+        // t -> (a, b) with a <= b, row-major over the upper triangle
+        int a = 0, rem = t;
+        while (rem >= m - a) {
+            rem -= m - a;
+            ++a;
+        }
+        const int b = a + rem;
+        const int ka = A.pl_k[c0 + a], kb = A.pl_k[c0 + b];
+        const int i1 = A.k_ph[ka], i2 = A.k_ph[kb];
+        const double *Bi = A.Hpl + 18 * (size_t)ka, *Bj = A.Hpl + 18 * (size_t)kb;
+        double BD[18];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                const double v = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
+                atomicAdd(&A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c], -v);
+            }
+    }
+}
+
+// bschur = b_p - coefficients ; mirror the upper block triangle into the lower one
+__global__ void k_schur_finish(LbaAct A)
+{
+    const int n6 = 6 * A.np;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n6 * n6) return;
+    const int r = i / n6, c = i - r * n6;
+    if (c > r) A.Hs[(size_t)c * n6 + r] = A.Hs[i];
+    if (i < n6) A.bs[i] = A.b[i] - A.coeff[i];
+}
+
+// dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve, one
+// workgroup.  Works in place on the lower triangle of Hs (L2/LDS resident: (6 Np)^2 doubles).
+__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A)
+{
+    extern __shared__ double col[];  // n doubles: column j before scaling ; then d[] (n)
+    const int n = 6 * A.np;
+    double *M = A.Hs;
+    double *d = col + n;
+    __shared__ int fail;
+    if (threadIdx.x == 0) fail = 0;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double dj = M[(size_t)j * n + j];
+        if (dj == 0.0 || dj != dj) {
+            if (threadIdx.x == 0) fail = 1;
+            __syncthreads();
+            break;
+        }
+        for (int i = j + 1 + threadIdx.x; i < n; i += 256) {
+            const double c = M[(size_t)i * n + j];
+            col[i] = c;
+            M[(size_t)i * n + j] = c / dj;
+        }
+        if (threadIdx.x == 0) d[j] = dj;
+        __syncthreads();
+        // trailing update of the lower triangle: M[i][k] -= L[i][j] * col[k], j < k <= i
+        const int m = n - j - 1;
+        const int total = m * (m + 1) / 2;
+        for (int t = threadIdx.x; t < total; t += 256) {
+            // t -> (ii, kk) with kk <= ii (row-major lower triangle)
+            int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+            while (ii * (ii + 1) / 2 > t) --ii;
+            const int kk = t - ii * (ii + 1) / 2;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            M[(size_t)i * n + k] -= M[(size_t)i * n + j] * col[k];
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        if (threadIdx.x == 0) A.scal[3] = 0.0;
+        return;
+    }
+    // forward substitution L y = b (column oriented), y in x[0..n)
+    double *xv = A.x;
+    for (int i = threadIdx.x; i < n; i += 256) xv[i] = A.bs[i];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const double yk = xv[k];
+        for (int i = k + 1 + threadIdx.x; i < n; i += 256) xv[i] -= M[(size_t)i * n + k] * yk;
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 256) xv[i] /= d[i];
+    __syncthreads();
+    for (int k = n - 1; k >= 0; --k) {
+        const double xk = xv[k];
+        for (int i = threadIdx.x; i < k; i += 256) xv[i] -= M[(size_t)k * n + i] * xk;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.scal[3] = 1.0;
+}
+
+// xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j) -> tmp
+__global__ void k_backsub_points(LbaDev P, LbaAct A, double lambda)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= A.nl) return;
+    const int n6 = 6 * A.np;
+    double cl[3] = {A.b[n6 + 3 * l], A.b[n6 + 3 * l + 1], A.b[n6 + 3 * l + 2]};
+    for (int a = A.pl_off[l]; a < A.pl_off[l + 1]; ++a) {
+        const int ka = A.pl_k[a];
+        const int i1 = A.k_ph[ka];
+        const double *Bi = A.Hpl + 18 * (size_t)ka;
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-A.x[6 * i1 + r]);
+    }
+    const double *Dinv = A.Dinv + 9 * (size_t)l;
+    double *X = P.point + 3 * (size_t)A.hpoint[l];
+    for (int r = 0; r < 3; ++r) {
+        const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
+        A.x[n6 + 3 * l + r] = xl;
+        X[r] += xl;
+        A.tmp[n6 + 3 * l + r] = xl * (lambda * xl + A.b[n6 + 3 * l + r]);
+    }
+}
+
+__global__ void k_update_poses(LbaDev P, LbaAct A, double lambda)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.np) return;
+    double upd[6];
+    for (int i = 0; i < 6; ++i) {
+        upd[i] = A.x[6 * p + i];
+        A.tmp[6 * p + i] = upd[i] * (lambda * upd[i] + A.b[6 * p + i]);
+    }
+    se3_oplus(upd, P.pose + 7 * (size_t)A.hpose[p]);
+}
+
+// outlier pass between the two optimisations (Optimizer.cc:672-703) and the final check (:712-744)
+__global__ void k_edge_check(LbaDev P, int mark_level1, double *chi2_out, uint8_t *outlier_out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_edges) return;
+    const int stereo = P.e_stereo[e];
+    const double c = edge_chi2(P.err + 3 * (size_t)e, P.e_w[e], stereo ? 3 : 2);
+    double p[3];
+    se3_map(P.pose + 7 * (size_t)P.e_pose[e], P.point + 3 * (size_t)P.e_point[e], p);
+    const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
+    if (mark_level1) {
+        if (bad) P.e_level1[e] = 1;
+        P.e_robust[e] = 0;
+    }
+    if (chi2_out) chi2_out[e] = c;
+    if (outlier_out) outlier_out[e] = bad ? 1 : 0;
+}
+
+}  // namespace aos2
+
+using namespace aos2;
+
+struct aos2_lba {
+    int device;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {};
+    DevBuf<uint8_t> arena;
+    PinnedBuf<double> h_scal;
+};
+
+namespace aos2 {
+
+struct HostArena {
+    std::vector<uint8_t> host;
+    size_t push(const void *src, size_t bytes)
+    {
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes);
+        if (src && bytes) memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+};
+
+static int lba_init(aos2_lba *s)
+{
+    int st = bind_device(s->device);
+    if (st) return st;
+    if (s->dev_ready) return AOS2_OK;
+    AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
+    if ((st = s->h_scal.alloc(8))) return st;
+    s->dev_ready = true;
+    return AOS2_OK;
+}
+
+static void pose_from_Tcw(const float *T, double qt[7])  // Converter::toSE3Quat, Converter.cc:37-47
+{
+    double R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i * 3 + j] = (double)T[i * 4 + j];
+    quat_from_rot(R, qt);
+    quat_normalize_rot(qt);
+    for (int i = 0; i < 3; ++i) qt[4 + i] = (double)T[i * 4 + 3];
+}
+
+static void pose_to_Tcw(const double qt[7], float *T)  // Converter::toCvMat(SE3Quat), Converter.cc:49-71
+{
+    double R[9];
+    rot_from_quat(qt, R);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
+        T[i * 4 + 3] = (float)qt[4 + i];
+    }
+    T[12] = T[13] = T[14] = 0.f;
+    T[15] = 1.f;
+}
+
+static bool stop_requested(const aos2_lba_problem_t *p) { return p->stop_flag && *p->stop_flag != 0; }
+
+struct Pass {
+    std::vector<int32_t> act, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
+    int ka = 0, np = 0, nl = 0;
+};
+
+// initializeOptimization(level 0) + buildIndexMapping + the symbolic part of buildStructure
+static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &level1, Pass &S)
+{
+    S = Pass();
+    std::vector<uint8_t> pose_act(p->n_poses, 0), point_act(p->n_points, 0);
+    for (int e = 0; e < p->n_edges; ++e) {
+        if (level1[e]) continue;
+        S.act.push_back(e);
+        pose_act[p->edge_pose[e]] = 1;
+        point_act[p->edge_point[e]] = 1;
+    }
+    S.ka = (int)S.act.size();
+    if (S.ka == 0) return false;
+    std::vector<int32_t> pose_h(p->n_poses, -1), point_h(p->n_points, -1);
+    for (int i = 0; i < p->n_poses; ++i)
+        if (pose_act[i] && !p->pose_fixed[i]) S.hpose.push_back(i);
+    std::stable_sort(S.hpose.begin(), S.hpose.end(), [&](int a, int b) { return p->pose_id[a] < p->pose_id[b]; });
+    for (int i = 0; i < p->n_points; ++i)
+        if (point_act[i]) S.hpoint.push_back(i);
+    std::stable_sort(S.hpoint.begin(), S.hpoint.end(), [&](int a, int b) { return p->point_id[a] < p->point_id[b]; });
+    S.np = (int)S.hpose.size();
+    S.nl = (int)S.hpoint.size();
+    for (int i = 0; i < S.np; ++i) pose_h[S.hpose[i]] = i;
+    for (int i = 0; i < S.nl; ++i) point_h[S.hpoint[i]] = i;
+    S.k_ph.resize(S.ka);
+    S.k_lh.resize(S.ka);
+    S.pt_off.assign(S.nl + 1, 0);
+    S.ps_off.assign(S.np + 1, 0);
+    S.pl_off.assign(S.nl + 1, 0);
+    for (int k = 0; k < S.ka; ++k) {
+        const int e = S.act[k];
+        S.k_ph[k] = pose_h[p->edge_pose[e]];
+        S.k_lh[k] = point_h[p->edge_point[e]];
+        S.pt_off[S.k_lh[k] + 1]++;
+        if (S.k_ph[k] >= 0) {
+            S.ps_off[S.k_ph[k] + 1]++;
+            S.pl_off[S.k_lh[k] + 1]++;
+        }
+    }
+    for (int i = 0; i < S.nl; ++i) {
+        S.pt_off[i + 1] += S.pt_off[i];
+        S.pl_off[i + 1] += S.pl_off[i];
+    }
+    for (int i = 0; i < S.np; ++i) S.ps_off[i + 1] += S.ps_off[i];
+    S.pt_k.resize(S.pt_off[S.nl]);
+    S.ps_k.resize(S.ps_off[S.np]);
+    S.pl_k.resize(S.pl_off[S.nl]);
+    std::vector<int> f1(S.nl, 0), f2(S.np, 0), f3(S.nl, 0);
+    for (int k = 0; k < S.ka; ++k) {
+        const int l = S.k_lh[k], ph = S.k_ph[k];
+        S.pt_k[S.pt_off[l] + f1[l]++] = k;
+        if (ph >= 0) {
+            S.ps_k[S.ps_off[ph] + f2[ph]++] = k;
+            S.pl_k[S.pl_off[l] + f3[l]++] = k;
+        }
+    }
+    for (int l = 0; l < S.nl; ++l)
+        std::stable_sort(S.pl_k.begin() + S.pl_off[l], S.pl_k.begin() + S.pl_off[l + 1],
+                         [&](int a, int b) { return S.k_ph[a] < S.k_ph[b]; });
+    return true;
+}
+
+}  // namespace aos2
+
+extern "C" {
+
+int aos2_lba_create(int device, aos2_lba_t **out)
+{
+    if (!out) return AOS2_ERR_ARG;
+    aos2_lba *s = new aos2_lba();
+    s->device = device;
+    *out = s;
+    return AOS2_OK;
+}
+
+void aos2_lba_destroy(aos2_lba_t *s)
+{
+    if (!s) return;
+    if (s->dev_ready) {
+        (void)hipSetDevice(s->device);
+        (void)hipStreamSynchronize(s->stream);
+        s->arena.release();
+        s->h_scal.release();
+        for (auto &e : s->ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(s->stream);
+    }
+    delete s;
+}
+
+int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r)
+{
+    if (!s || !p || !r || p->n_poses <= 0 || p->n_points <= 0 || p->n_edges <= 0 || !p->pose_Tcw || !p->pose_fixed ||
+        !p->pose_id || !p->point_xyz || !p->point_id || !p->edge_pose || !p->edge_point || !p->edge_obs ||
+        !p->edge_stereo || !p->edge_inv_sigma2 || !r->pose_Tcw || !r->point_xyz) {
+        set_error("bad LocalBA problem");
+        return AOS2_ERR_ARG;
+    }
+    for (int e = 0; e < p->n_edges; ++e)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+            set_error("edge %d references a vertex out of range", e);
+            return AOS2_ERR_ARG;
+        }
+    r->iters_done_first = r->iters_done_second = 0;
+    r->final_chi2 = 0;
+    r->final_lambda = 0;
+    r->ms_device = 0;
+    if (stop_requested(p)) {  // Optimizer.cc:656-658: return before optimising, nothing is written back
+        memcpy(r->pose_Tcw, p->pose_Tcw, sizeof(float) * 16 * p->n_poses);
+        memcpy(r->point_xyz, p->point_xyz, sizeof(float) * 3 * p->n_points);
+        if (r->edge_outlier) memset(r->edge_outlier, 0, p->n_edges);
+        return AOS2_ERR_STOPPED;
+    }
+    int st = lba_init(s);
+    if (st) return st;
+    const int NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+    // ---- host-side conversion (Converter.cc) and upload
+    std::vector<double> pose(7 * (size_t)NP), point(3 * (size_t)NL), obs(3 * (size_t)E), w(E);
+    for (int i = 0; i < NP; ++i) pose_from_Tcw(p->pose_Tcw + 16 * (size_t)i, &pose[7 * (size_t)i]);
+    for (size_t i = 0; i < 3 * (size_t)NL; ++i) point[i] = (double)p->point_xyz[i];
+    for (size_t i = 0; i < 3 * (size_t)E; ++i) obs[i] = (double)p->edge_obs[i];
+    for (int e = 0; e < E; ++e) w[e] = (double)p->edge_inv_sigma2[e];
+    std::vector<uint8_t> level1(E, 0), robust(E, 1);
+
+    HostArena H;
+    const size_t o_pose = H.push(pose.data(), pose.size() * 8), o_point = H.push(point.data(), point.size() * 8);
+    const size_t o_bkpose = H.push(nullptr, pose.size() * 8), o_bkpoint = H.push(nullptr, point.size() * 8);
+    const size_t o_epose = H.push(p->edge_pose, (size_t)E * 4), o_epoint = H.push(p->edge_point, (size_t)E * 4);
+    const size_t o_obs = H.push(obs.data(), obs.size() * 8), o_w = H.push(w.data(), w.size() * 8);
+    const size_t o_st = H.push(p->edge_stereo, E), o_rb = H.push(robust.data(), E), o_l1 = H.push(level1.data(), E);
+    const size_t o_err = H.push(nullptr, (size_t)E * 3 * 8);
+    const size_t o_chi = H.push(nullptr, (size_t)E * 8), o_out = H.push(nullptr, E);
+    // per-pass structure + system (sized for the first pass, which is the largest)
+    int n_free = 0;
+    for (int i = 0; i < NP; ++i) n_free += p->pose_fixed[i] ? 0 : 1;
+    const size_t n6max = 6 * (size_t)n_free, dimmax = n6max + 3 * (size_t)NL;
+    const size_t o_act = H.push(nullptr, (size_t)E * 4), o_kph = H.push(nullptr, (size_t)E * 4), o_klh = H.push(nullptr, (size_t)E * 4);
+    const size_t o_hpose = H.push(nullptr, (size_t)NP * 4 + 4), o_hpoint = H.push(nullptr, (size_t)NL * 4 + 4);
+    const size_t o_ptoff = H.push(nullptr, (size_t)(NL + 1) * 4), o_ptk = H.push(nullptr, (size_t)E * 4);
+    const size_t o_psoff = H.push(nullptr, (size_t)(NP + 1) * 4), o_psk = H.push(nullptr, (size_t)E * 4);
+    const size_t o_ploff = H.push(nullptr, (size_t)(NL + 1) * 4), o_plk = H.push(nullptr, (size_t)E * 4);
+    const size_t o_JA = H.push(nullptr, (size_t)E * 9 * 8), o_JB = H.push(nullptr, (size_t)E * 18 * 8);
+    const size_t o_Wr = H.push(nullptr, (size_t)E * 3 * 8), o_wo = H.push(nullptr, (size_t)E * 8);
+    const size_t o_Hpl = H.push(nullptr, (size_t)E * 18 * 8);
+    const size_t o_Hpp = H.push(nullptr, (size_t)n_free * 36 * 8 + 8), o_Hll = H.push(nullptr, (size_t)NL * 9 * 8);
+    const size_t o_b = H.push(nullptr, dimmax * 8 + 8), o_x = H.push(nullptr, dimmax * 8 + 8);
+    const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
+    const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
+    const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, 64);
+    if ((st = s->arena.alloc(H.host.size() + 256))) return st;
+    uint8_t *base = s->arena.p;
+    hipStream_t q = s->stream;
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), o_err, hipMemcpyHostToDevice, q));  // inputs only
+    AOS2_HIP_CHECK(hipMemsetAsync(base + o_err, 0, (size_t)E * 3 * 8, q));
+    AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
+
+    LbaDev D{};
+    D.n_poses = NP; D.n_points = NL; D.n_edges = E;
+    D.pose = (double *)(base + o_pose); D.point = (double *)(base + o_point);
+    D.e_pose = (int32_t *)(base + o_epose); D.e_point = (int32_t *)(base + o_epoint);
+    D.e_obs = (double *)(base + o_obs); D.e_w = (double *)(base + o_w);
+    D.e_stereo = base + o_st; D.e_robust = base + o_rb; D.e_level1 = base + o_l1;
+    D.err = (double *)(base + o_err);
+    D.cam.fx = (double)p->fx; D.cam.fy = (double)p->fy; D.cam.cx = (double)p->cx; D.cam.cy = (double)p->cy;
+    D.cam.bf = (double)p->bf; D.cam.bf_f = p->bf;
+    D.cam.delta_mono = (double)(float)std::sqrt(5.991);
+    D.cam.delta_stereo = (double)(float)std::sqrt(7.815);
+    double *d_bkpose = (double *)(base + o_bkpose), *d_bkpoint = (double *)(base + o_bkpoint);
+    double *d_scal = (double *)(base + o_scal);
+    double *hs = s->h_scal.p;
+
+    LbaAct A{};
+    A.act = (int32_t *)(base + o_act); A.k_ph = (int32_t *)(base + o_kph); A.k_lh = (int32_t *)(base + o_klh);
+    A.hpose = (int32_t *)(base + o_hpose); A.hpoint = (int32_t *)(base + o_hpoint);
+    A.pt_off = (int32_t *)(base + o_ptoff); A.pt_k = (int32_t *)(base + o_ptk);
+    A.ps_off = (int32_t *)(base + o_psoff); A.ps_k = (int32_t *)(base + o_psk);
+    A.pl_off = (int32_t *)(base + o_ploff); A.pl_k = (int32_t *)(base + o_plk);
+    A.JA = (double *)(base + o_JA); A.JB = (double *)(base + o_JB); A.Wr = (double *)(base + o_Wr);
+    A.wo = (double *)(base + o_wo); A.Hpl = (double *)(base + o_Hpl); A.Hpp = (double *)(base + o_Hpp);
+    A.Hll = (double *)(base + o_Hll); A.b = (double *)(base + o_b); A.x = (double *)(base + o_x);
+    A.Hs = (double *)(base + o_Hs); A.bs = (double *)(base + o_bs); A.coeff = (double *)(base + o_coeff);
+    A.Dinv = (double *)(base + o_Dinv); A.tmp = (double *)(base + o_tmp); A.scal = d_scal;
+
+    auto upload_pass = [&](const Pass &S) -> int {
+        A.ka = S.ka; A.np = S.np; A.nl = S.nl;
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.act, S.act.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_ph, S.k_ph.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_lh, S.k_lh.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
+        if (S.np) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.hpose, S.hpose.data(), (size_t)S.np * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.hpoint, S.hpoint.data(), (size_t)S.nl * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pt_off, S.pt_off.data(), (size_t)(S.nl + 1) * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pt_k, S.pt_k.data(), S.pt_k.size() * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.ps_off, S.ps_off.data(), (size_t)(S.np + 1) * 4, hipMemcpyHostToDevice, q));
+        if (!S.ps_k.empty()) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.ps_k, S.ps_k.data(), S.ps_k.size() * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pl_off, S.pl_off.data(), (size_t)(S.nl + 1) * 4, hipMemcpyHostToDevice, q));
+        if (!S.pl_k.empty()) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pl_k, S.pl_k.data(), S.pl_k.size() * 4, hipMemcpyHostToDevice, q));
+        AOS2_HIP_CHECK(hipStreamSynchronize(q));  // the host vectors may go out of scope
+        return AOS2_OK;
+    };
+    auto blocks = [](int n, int t) { return dim3((unsigned)((n + t - 1) / t)); };
+    auto errors_chi2 = [&](double *out_host) -> int {
+        hipLaunchKernelGGL(k_errors, blocks(A.ka, 256), dim3(256), 0, q, D, A);
+        hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, q, A.tmp, A.ka, d_scal + 0);
+        if (out_host) {
+            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, q));
+            AOS2_HIP_CHECK(hipStreamSynchronize(q));
+            *out_host = hs[0];
+        }
+        return AOS2_OK;
+    };
+
+    double lambda = 0, ni = 2, last_chi = 0;
+    int nBad = 0;
+    // OptimizationAlgorithmLevenberg::solve (levenberg.cpp:61-164)
+    auto lm_solve = [&](int iteration, int &result) -> int {
+        double currentChi = 0;
+        int rc = errors_chi2(&currentChi);
+        if (rc) return rc;
+        double tempChi = currentChi;
+        const double iniChi = currentChi;
+        const int dim = 6 * A.np + 3 * A.nl, n6 = 6 * A.np;
+        hipLaunchKernelGGL(k_linearize, blocks(A.ka, 128), dim3(128), 0, q, D, A);
+        hipLaunchKernelGGL(k_accum_points, blocks(A.nl, 128), dim3(128), 0, q, A);
+        if (A.np) hipLaunchKernelGGL(k_accum_poses, dim3(A.np), dim3(256), 0, q, A);
+        if (iteration == 0) {
+            hipLaunchKernelGGL(k_diag, blocks(dim, 256), dim3(256), 0, q, A);
+            hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(1024), 0, q, A.tmp, dim, d_scal + 2);
+            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, q));
+            AOS2_HIP_CHECK(hipStreamSynchronize(q));
+            lambda = 1e-5 * hs[2];
+            ni = 2;
+            nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        const int maxTrials = 10;
+        do {
+            // push
+            AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpose, D.pose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
+            AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpoint, D.point, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
+            // setLambda + Schur solve (the diagonal is never modified in place: lambda is added
+            // where Hpp / Hll are consumed, which is what restoreDiagonal undoes in g2o)
+            if (n6 > 0) {
+                hipLaunchKernelGGL(k_schur_init, blocks(n6 * n6, 256), dim3(256), 0, q, A, lambda);
+                hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);
+                hipLaunchKernelGGL(k_schur_finish, blocks(n6 * n6, 256), dim3(256), 0, q, A);
+                hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), (size_t)2 * n6 * sizeof(double), q, A);
+                hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
+            } else {
+                hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);  // Dinv only
+                AOS2_HIP_CHECK(hipMemsetAsync(d_scal + 3, 0, sizeof(double), q));
+            }
+            hipLaunchKernelGGL(k_backsub_points, blocks(A.nl, 128), dim3(128), 0, q, D, A, lambda);
+            hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, q, A.tmp, dim, d_scal + 1);
+            rc = errors_chi2(&tempChi);  // also fetches scale and the solver flag
+            if (rc) return rc;
+            const bool ok2 = (n6 == 0) || hs[3] != 0.0;
+            if (!ok2) tempChi = 1.7976931348623157e308;
+            rho = (currentChi - tempChi);
+            double scale = hs[1];
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                const double scaleFactor = std::max(1. / 3., alpha);
+                lambda *= scaleFactor;
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                // pop
+                AOS2_HIP_CHECK(hipMemcpyAsync(D.pose, d_bkpose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
+                AOS2_HIP_CHECK(hipMemcpyAsync(D.point, d_bkpoint, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
+            }
+            qmax++;
+        } while (rho < 0 && qmax < maxTrials && !stop_requested(p));
+        last_chi = currentChi;
+        if (qmax == maxTrials || rho == 0) {
+            result = 1;  // Terminate
+            return AOS2_OK;
+        }
+        if ((iniChi - currentChi) * 1e3 < iniChi)
+            nBad++;
+        else
+            nBad = 0;
+        result = nBad >= 3 ? 1 : 0;
+        return AOS2_OK;
+    };
+    auto optimize = [&](int iterations, int &done) -> int {
+        done = 0;
+        bool ok = true;
+        for (int i = 0; i < iterations && !stop_requested(p) && ok; ++i) {
+            int result = 0;
+            const int rc = lm_solve(i, result);
+            if (rc) return rc;
+            ok = (result == 0);
+            ++done;
+        }
+        return AOS2_OK;
+    };
+
+    Pass S;
+    if (build_pass(p, level1, S)) {
+        if ((st = upload_pass(S))) return st;
+        if ((st = optimize(p->iters_first, r->iters_done_first))) return st;
+    }
+    if (!stop_requested(p)) {  // bDoMore, Optimizer.cc:663-710
+        hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 1, (double *)nullptr, (uint8_t *)nullptr);
+        AOS2_HIP_CHECK(hipMemcpyAsync(level1.data(), D.e_level1, E, hipMemcpyDeviceToHost, q));
+        AOS2_HIP_CHECK(hipStreamSynchronize(q));
+        if (build_pass(p, level1, S)) {
+            if ((st = upload_pass(S))) return st;
+            if ((st = optimize(p->iters_second, r->iters_done_second))) return st;
+        }
+    }
+    // final inlier check + write-back (Optimizer.cc:712-778)
+    hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 0, (double *)(base + o_chi), base + o_out);
+    AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
+    AOS2_HIP_CHECK(hipMemcpyAsync(pose.data(), D.pose, pose.size() * 8, hipMemcpyDeviceToHost, q));
+    AOS2_HIP_CHECK(hipMemcpyAsync(point.data(), D.point, point.size() * 8, hipMemcpyDeviceToHost, q));
+    std::vector<uint8_t> outl(E);
+    AOS2_HIP_CHECK(hipMemcpyAsync(outl.data(), base + o_out, E, hipMemcpyDeviceToHost, q));
+    if (r->edge_chi2) AOS2_HIP_CHECK(hipMemcpyAsync(r->edge_chi2, base + o_chi, (size_t)E * 8, hipMemcpyDeviceToHost, q));
+    AOS2_HIP_CHECK(hipStreamSynchronize(q));
+    AOS2_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < NP; ++i) pose_to_Tcw(&pose[7 * (size_t)i], r->pose_Tcw + 16 * (size_t)i);
+    for (size_t i = 0; i < 3 * (size_t)NL; ++i) r->point_xyz[i] = (float)point[i];
+    if (r->edge_outlier) memcpy(r->edge_outlier, outl.data(), E);
+    r->final_chi2 = last_chi;
+    r->final_lambda = lambda;
+    (void)hipEventElapsedTime(&r->ms_device, s->ev[0], s->ev[1]);
+    return AOS2_OK;
+}
+
+}  // extern "C"

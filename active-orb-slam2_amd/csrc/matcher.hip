@@ -1,2 +1,881 @@
-// placeholder, replaced below
+// ORBmatcher hot path on gfx950: 256-bit Hamming (xor + popcount) brute force, SearchByBoW and the
+// two SearchByProjection variants (reference src/ORBmatcher.cc:45-129, 159-288, 1328-1470,
+// DescriptorDistance :1647-1663).  Integer VALU work; descriptors stay L2/LDS resident.
+//
+// The reference loops are sequential over the query set (a later query sees the features an
+// earlier one took, :87-89, :209, :1403-1405).  Each problem therefore runs on ONE wave: the
+// 64 lanes share the candidate set of the current query (Hamming distances + a two-smallest
+// reduction with the reference's first-wins tie-break), while the greedy bookkeeping is
+// wave-uniform.  Independent problems ((KF,F) pairs) are spread over the grid.
+#include <vector>
+
 #include "aos2_common.h"
+
+namespace aos2 {
+
+constexpr int TH_HIGH = AOS2_TH_HIGH;
+constexpr int TH_LOW = AOS2_TH_LOW;
+constexpr int HISTO = AOS2_HISTO_LENGTH;
+constexpr int GRID_COLS = AOS2_GRID_COLS;
+constexpr int GRID_ROWS = AOS2_GRID_ROWS;
+constexpr uint32_t KEY_NONE = 0xffffffffu;
+
+struct Desc {
+    uint32_t w[8];
+};
+
+__device__ __forceinline__ Desc load_desc(const uint8_t *p)
+{
+    Desc d;
+    const uint4 a = *reinterpret_cast<const uint4 *>(p);
+    const uint4 b = *reinterpret_cast<const uint4 *>(p + 16);
+    d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w;
+    d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+    return d;
+}
+
+__device__ __forceinline__ int hamming(const Desc &a, const Desc &b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += __popc(a.w[i] ^ b.w[i]);
+    return d;
+}
+
+// merge two (smallest, second smallest) pairs
+__device__ __forceinline__ void merge2(uint32_t &k1, uint32_t &k2, uint32_t o1, uint32_t o2)
+{
+    const uint32_t lo = min(k1, o1), hi = max(k1, o1);
+    k2 = min(hi, min(k2, o2));
+    k1 = lo;
+}
+
+__device__ __forceinline__ void wave_min2(uint32_t &k1, uint32_t &k2)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
+        merge2(k1, k2, o1, o2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brute force: best and second best train descriptor per query.  Block = 256 threads = 256
+// queries; the train set is streamed through LDS in 256-descriptor tiles (8 KB), every lane
+// reads the same train word (LDS broadcast).  grid.y splits the train set; partial results are
+// merged by a second tiny kernel.  key = dist << 20 | train index  (first index wins ties).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hamming_best2_kernel(const uint8_t *__restrict__ q, int nq,
+                                                            const uint8_t *__restrict__ t, int nt,
+                                                            int t_per_split, uint32_t *__restrict__ part1,
+                                                            uint32_t *__restrict__ part2)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[256 * 8];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * t_per_split, t1 = min(nt, t0 + t_per_split);
+    Desc dq{};
+    if (qi < nq) dq = load_desc(q + (size_t)qi * 32);
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int base = t0; base < t1; base += 256) {
+        const int cnt = min(256, t1 - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * 2; i += 256)
+            reinterpret_cast<uint4 *>(tile)[i] = reinterpret_cast<const uint4 *>(t + (size_t)base * 32)[i];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const uint4 a = reinterpret_cast<const uint4 *>(tile)[2 * j];
+            const uint4 b = reinterpret_cast<const uint4 *>(tile)[2 * j + 1];
+            int d = __popc(dq.w[0] ^ a.x) + __popc(dq.w[1] ^ a.y) + __popc(dq.w[2] ^ a.z) + __popc(dq.w[3] ^ a.w) +
+                    __popc(dq.w[4] ^ b.x) + __popc(dq.w[5] ^ b.y) + __popc(dq.w[6] ^ b.z) + __popc(dq.w[7] ^ b.w);
+            const uint32_t key = ((uint32_t)d << 20) | (uint32_t)(base + j);
+            if (key < k1) {
+                k2 = k1;
+                k1 = key;
+            } else if (key < k2)
+                k2 = key;
+        }
+    }
+    if (qi < nq) {
+        part1[(size_t)blockIdx.y * nq + qi] = k1;
+        part2[(size_t)blockIdx.y * nq + qi] = k2;
+    }
+}
+
+__global__ void hamming_merge_kernel(const uint32_t *__restrict__ part1, const uint32_t *__restrict__ part2,
+                                     int nq, int splits, int32_t *__restrict__ best_idx,
+                                     int32_t *__restrict__ best_dist, int32_t *__restrict__ second_dist)
+{
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int s = 0; s < splits; ++s) merge2(k1, k2, part1[(size_t)s * nq + qi], part2[(size_t)s * nq + qi]);
+    best_idx[qi] = k1 == KEY_NONE ? -1 : (int32_t)(k1 & 0xfffff);
+    best_dist[qi] = k1 == KEY_NONE ? 256 : (int32_t)(k1 >> 20);
+    second_dist[qi] = k2 == KEY_NONE ? 256 : (int32_t)(k2 >> 20);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotation histogram helpers (ComputeThreeMaxima :1601-1642, bin quirk factor = 1/30 kept, :172)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int rot_bin(float rot)
+{
+    const float factor = 1.0f / HISTO;
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == HISTO) bin = 0;
+    return bin;
+}
+
+__device__ __forceinline__ void three_maxima(const int *histo, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < HISTO; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+        ind3 = -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  :159-288 -- one wave per (KF, F) pair.
+// ---------------------------------------------------------------------------------------------
+struct BowPairDev {
+    int n_kf, n_f, n_nodes_kf, n_nodes_f;
+    const uint8_t *desc_kf, *desc_f, *kf_has_mp;
+    const float *angle_kf, *angle_f;
+    const int32_t *node_id_kf, *node_off_kf, *node_idx_kf;
+    const int32_t *node_id_f, *node_off_f, *node_idx_f;
+    int32_t *match_f;   // n_f
+    uint32_t *bin_f;    // n_f scratch: bit b set = pushed into rotHist[b]
+    int32_t *nmatches;  // 1
+};
+
+__global__ __launch_bounds__(64) void search_by_bow_kernel(const BowPairDev *__restrict__ pairs, float nnratio,
+                                                           int check_ori)
+{
+    extern __shared__ uint8_t taken[];  // vpMapPointMatches[j] != NULL
+    __shared__ int histo[HISTO];
+    const BowPairDev P = pairs[blockIdx.x];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < P.n_f; i += 64) {
+        P.match_f[i] = -1;
+        P.bin_f[i] = 0;
+        taken[i] = 0;
+    }
+    if (lane < HISTO) histo[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    int ik = 0, jf = 0;
+    while (ik < P.n_nodes_kf && jf < P.n_nodes_f) {
+        const int idk = P.node_id_kf[ik], idf = P.node_id_f[jf];
+        if (idk == idf) {
+            const int a0 = P.node_off_kf[ik], a1 = P.node_off_kf[ik + 1];
+            const int b0 = P.node_off_f[jf], b1 = P.node_off_f[jf + 1];
+            for (int a = a0; a < a1; ++a) {
+                const int realIdxKF = P.node_idx_kf[a];
+                if (!P.kf_has_mp[realIdxKF]) continue;
+                const Desc dKF = load_desc(P.desc_kf + (size_t)realIdxKF * 32);
+                uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+                for (int b = b0 + lane; b < b1; b += 64) {
+                    const int realIdxF = P.node_idx_f[b];
+                    if (taken[realIdxF]) continue;  // vpMapPointMatches[realIdxF] (:209)
+                    const int dist = hamming(dKF, load_desc(P.desc_f + (size_t)realIdxF * 32));
+                    const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(b - b0);
+                    if (key < k1) {
+                        k2 = k1;
+                        k1 = key;
+                    } else if (key < k2)
+                        k2 = key;
+                }
+                wave_min2(k1, k2);
+                const int bestDist1 = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
+                const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+                    const int bestIdxF = P.node_idx_f[b0 + (int)(k1 & 0xfffff)];
+                    if (lane == 0) {
+                        P.match_f[bestIdxF] = realIdxKF;
+                        taken[bestIdxF] = 1;
+                        if (check_ori) {
+                            const int bin = rot_bin(__fsub_rn(P.angle_kf[realIdxKF], P.angle_f[bestIdxF]));
+                            P.bin_f[bestIdxF] |= 1u << bin;
+                            histo[bin]++;
+                        }
+                    }
+                    nmatches++;
+                    __syncthreads();  // single wave: lane 0's LDS/global writes before the next reads
+                }
+            }
+            ik++;
+            jf++;
+        } else if (idk < idf) {
+            while (ik < P.n_nodes_kf && P.node_id_kf[ik] < idf) ik++;
+        } else {
+            while (jf < P.n_nodes_f && P.node_id_f[jf] < idk) jf++;
+        }
+    }
+    __syncthreads();
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        uint32_t culled = 0;
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) {
+                culled |= 1u << i;
+                nmatches -= histo[i];  // one decrement per pushed entry (:281)
+            }
+        for (int i = lane; i < P.n_f; i += 64)
+            if (P.bin_f[i] & culled) P.match_f[i] = -1;
+    }
+    if (lane == 0) *P.nmatches = nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frame::GetFeaturesInArea (src/Frame.cc:356-409) candidate walk shared by both projection
+// searches.  Lanes take grid cells of the window (ix-major, iy-minor like the reference loops);
+// a wave prefix sum over the cell populations gives every candidate its position in the
+// reference's visiting order, which is the tie-break of the strict '<' updates.
+// ---------------------------------------------------------------------------------------------
+struct FrameDev {
+    int n_f, n_levels;
+    const uint8_t *desc_f;
+    const float *kp_x, *kp_y, *kp_angle, *u_right, *scale_factors;
+    const int32_t *kp_octave;
+    float min_x, min_y, max_x, max_y, grid_w_inv, grid_h_inv;
+    const int32_t *grid_off, *grid_idx;
+    const uint8_t *f_mp_state;
+};
+
+struct Best2 {
+    uint32_t k1, k2;      // dist << 20 | position
+    int idx1, oct1, oct2; // payload of the lane-local entries
+};
+
+template <bool kUseRightGate>
+__device__ __forceinline__ void scan_window(const FrameDev &F, const uint8_t *state, const Desc &dq, float x,
+                                            float y, float r, int minLevel, int maxLevel, float xr_proj,
+                                            float xr_tol, int lane, Best2 &B, bool &any)
+{
+    B.k1 = B.k2 = KEY_NONE;
+    B.idx1 = -1;
+    B.oct1 = B.oct2 = -1;
+    any = false;
+    const int nMinCellX0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv));
+    const int nMinCellX = max(0, nMinCellX0);
+    if (nMinCellX >= GRID_COLS) return;
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv)));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv));
+    const int nMinCellY = max(0, nMinCellY0);
+    if (nMinCellY >= GRID_ROWS) return;
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv)));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int ny = nMaxCellY - nMinCellY + 1;
+    const int ncell = (nMaxCellX - nMinCellX + 1) * ny;
+    int base = 0;
+    bool found = false;
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        int beg = 0, cnt = 0;
+        if (c < ncell) {
+            const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;
+            const int cell = ix * GRID_ROWS + iy;
+            beg = F.grid_off[cell];
+            cnt = F.grid_off[cell + 1] - beg;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int yv = __shfl_up(incl, d);
+            if (lane >= d) incl += yv;
+        }
+        const int pos0 = base + incl - cnt;
+        for (int j = 0; j < cnt; ++j) {
+            const int idx = F.grid_idx[beg + j];
+            const int oct = F.kp_octave[idx];
+            if (bCheckLevels) {
+                if (oct < minLevel) continue;
+                if (maxLevel >= 0 && oct > maxLevel) continue;
+            }
+            const float distx = __fsub_rn(F.kp_x[idx], x), disty = __fsub_rn(F.kp_y[idx], y);
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            found = true;  // vIndices non-empty
+            if (state[idx] == 2) continue;  // mvpMapPoints[idx]->Observations() > 0
+            if (kUseRightGate) {
+                const float ur = F.u_right[idx];
+                if (ur > 0) {
+                    const float er = fabsf(__fsub_rn(xr_proj, ur));
+                    if (er > xr_tol) continue;
+                }
+            }
+            const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+            const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
+            if (key < B.k1) {
+                B.k2 = B.k1;
+                B.oct2 = B.oct1;
+                B.k1 = key;
+                B.idx1 = idx;
+                B.oct1 = oct;
+            } else if (key < B.k2) {
+                B.k2 = key;
+                B.oct2 = oct;
+            }
+        }
+        base += __shfl(incl, 63);
+    }
+    any = __any(found);
+}
+
+// wave reduction of Best2 keeping payloads: returns uniform results
+__device__ __forceinline__ void reduce_best2(const Best2 &B, int lane, uint32_t &k1, uint32_t &k2, int &idx1,
+                                             int &oct1, int &oct2)
+{
+    k1 = B.k1;
+    k2 = B.k2;
+    wave_min2(k1, k2);
+    // owners: keys are unique (position is unique per candidate)
+    const unsigned long long own1 = __ballot(B.k1 == k1 && k1 != KEY_NONE);
+    idx1 = -1;
+    oct1 = -1;
+    oct2 = -1;
+    if (own1) {
+        const int src = __ffsll((long long)own1) - 1;
+        idx1 = __shfl(B.idx1, src);
+        oct1 = __shfl(B.oct1, src);
+    }
+    if (k2 != KEY_NONE) {
+        const unsigned long long o2a = __ballot(B.k1 == k2);
+        const unsigned long long o2b = __ballot(B.k2 == k2);
+        if (o2a) {
+            const int src = __ffsll((long long)o2a) - 1;
+            oct2 = __shfl(B.oct1, src);
+        } else if (o2b) {
+            const int src = __ffsll((long long)o2b) - 1;
+            oct2 = __shfl(B.oct2, src);
+        }
+    }
+}
+
+struct ProjMpDev {
+    int n_mp;
+    const uint8_t *track_in_view, *desc, *has_obs;
+    const int32_t *pred_level;
+    const float *view_cos, *proj_x, *proj_y, *proj_xr;
+};
+
+// SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129
+__global__ __launch_bounds__(64) void search_by_projection_mp_kernel(FrameDev F, ProjMpDev P, float th,
+                                                                     float nnratio, int32_t *match_f,
+                                                                     int32_t *nmatches_out)
+{
+    extern __shared__ uint8_t state[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < F.n_f; i += 64) {
+        state[i] = F.f_mp_state[i];
+        match_f[i] = -1;
+    }
+    __syncthreads();
+    const bool bFactor = th != 1.0f;
+    int nmatches = 0;
+    for (int iMP = 0; iMP < P.n_mp; iMP++) {
+        if (!P.track_in_view[iMP]) continue;
+        const int nPredictedLevel = P.pred_level[iMP];
+        float r = (double)P.view_cos[iMP] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos :131-137
+        if (bFactor) r = __fmul_rn(r, th);
+        const float rs = __fmul_rn(r, F.scale_factors[nPredictedLevel]);
+        const Desc dq = load_desc(P.desc + (size_t)iMP * 32);
+        Best2 B;
+        bool any;
+        scan_window<true>(F, state, dq, P.proj_x[iMP], P.proj_y[iMP], rs, nPredictedLevel - 1, nPredictedLevel,
+                          P.proj_xr[iMP], rs, lane, B, any);
+        if (!any) continue;
+        uint32_t k1, k2;
+        int bestIdx, bestLevel, bestLevel2;
+        reduce_best2(B, lane, k1, k2, bestIdx, bestLevel, bestLevel2);
+        const int bestDist = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
+        const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
+            if (lane == 0) {
+                match_f[bestIdx] = iMP;
+                state[bestIdx] = P.has_obs[iMP] ? 2 : 1;
+            }
+            nmatches++;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) *nmatches_out = nmatches;
+}
+
+struct ProjLastDev {
+    int n_last;
+    const uint8_t *last_valid, *desc, *has_obs;
+    const float *world_pos, *last_angle;
+    const int32_t *last_octave;
+    float Tcw[16], Tlw[16];
+    float fx, fy, cx, cy, mb, mbf;
+};
+
+// SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  :1328-1470
+__global__ __launch_bounds__(64) void search_by_projection_last_kernel(FrameDev F, ProjLastDev P, float th,
+                                                                       int mono, int check_ori,
+                                                                       int32_t *match_f, uint32_t *bin_f,
+                                                                       int32_t *nmatches_out)
+{
+    extern __shared__ uint8_t state[];
+    __shared__ int histo[HISTO];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < F.n_f; i += 64) {
+        state[i] = F.f_mp_state[i];
+        match_f[i] = -1;
+        bin_f[i] = 0;
+    }
+    if (lane < HISTO) histo[lane] = 0;
+    __syncthreads();
+    const float *T = P.Tcw, *Tl = P.Tlw;
+    // twc = -Rcw^T tcw (cv::gemm general path: double accumulation) ; tlc = Rlw twc + tlw (:1339-1346)
+    float twc[3], tlc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double s = __dadd_rn(__dadd_rn(__dmul_rn((double)T[i], (double)T[3]), __dmul_rn((double)T[4 + i], (double)T[7])),
+                                   __dmul_rn((double)T[8 + i], (double)T[11]));
+        twc[i] = (float)__dmul_rn(s, -1.0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s = __fadd_rn(__fadd_rn(__fmul_rn(Tl[i * 4], twc[0]), __fmul_rn(Tl[i * 4 + 1], twc[1])),
+                                  __fmul_rn(Tl[i * 4 + 2], twc[2]));
+        tlc[i] = __fadd_rn(s, Tl[i * 4 + 3]);
+    }
+    const bool bForward = tlc[2] > P.mb && !mono;
+    const bool bBackward = -tlc[2] > P.mb && !mono;
+    int nmatches = 0;
+    for (int i = 0; i < P.n_last; i++) {
+        if (!P.last_valid[i]) continue;
+        const float X0 = P.world_pos[3 * i], X1 = P.world_pos[3 * i + 1], X2 = P.world_pos[3 * i + 2];
+        float x3Dc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float s = __fadd_rn(__fadd_rn(__fmul_rn(T[r * 4], X0), __fmul_rn(T[r * 4 + 1], X1)), __fmul_rn(T[r * 4 + 2], X2));
+            x3Dc[r] = __fadd_rn(s, T[r * 4 + 3]);
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)__ddiv_rn(1.0, (double)x3Dc[2]);
+        if (invzc < 0) continue;
+        const float u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, xc), invzc), P.cx);
+        const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, yc), invzc), P.cy);
+        if (u < F.min_x || u > F.max_x) continue;
+        if (v < F.min_y || v > F.max_y) continue;
+        const int nLastOctave = P.last_octave[i];
+        const float radius = __fmul_rn(th, F.scale_factors[nLastOctave]);
+        int minL, maxL;
+        if (bForward) {
+            minL = nLastOctave;
+            maxL = -1;
+        } else if (bBackward) {
+            minL = 0;
+            maxL = nLastOctave;
+        } else {
+            minL = nLastOctave - 1;
+            maxL = nLastOctave + 1;
+        }
+        const Desc dq = load_desc(P.desc + (size_t)i * 32);
+        const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
+        Best2 B;
+        bool any;
+        scan_window<true>(F, state, dq, u, v, radius, minL, maxL, ur, radius, lane, B, any);
+        if (!any) continue;
+        uint32_t k1, k2;
+        int bestIdx2, o1, o2;
+        reduce_best2(B, lane, k1, k2, bestIdx2, o1, o2);
+        const int bestDist = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
+        if (bestDist <= TH_HIGH) {
+            if (lane == 0) {
+                match_f[bestIdx2] = i;
+                state[bestIdx2] = P.has_obs[i] ? 2 : 1;
+                if (check_ori) {
+                    const int bin = rot_bin(__fsub_rn(P.last_angle[i], F.kp_angle[bestIdx2]));
+                    // a feature can be pushed several times when a zero-observation point is
+                    // overwritten (:1432): it is reset if ANY of its bins is culled, and nmatches
+                    // drops once per pushed entry (:1459-1460)
+                    histo[bin]++;
+                    bin_f[bestIdx2] |= 1u << bin;
+                }
+            }
+            nmatches++;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        uint32_t culled = 0;
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) {
+                culled |= 1u << i;
+                nmatches -= histo[i];
+            }
+        for (int i = lane; i < F.n_f; i += 64)
+            if (bin_f[i] & culled) match_f[i] = -2;  // set to NULL (:1459)
+    }
+    if (lane == 0) *nmatches_out = nmatches;
+}
+
+}  // namespace aos2
+
+using namespace aos2;
+
+struct aos2_matcher {
+    float nnratio;
+    int check_ori;
+    int device;
+    bool dev_ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {};
+    DevBuf<uint8_t> arena;     // staging arena for problem snapshots
+    DevBuf<uint32_t> part;     // hamming partials
+};
+
+namespace aos2 {
+
+static int matcher_init(aos2_matcher *m)
+{
+    int st = bind_device(m->device);
+    if (st) return st;
+    if (m->dev_ready) return AOS2_OK;
+    AOS2_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    for (auto &e : m->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
+    m->dev_ready = true;
+    return AOS2_OK;
+}
+
+// bump allocator over one device arena: uploads host arrays, returns device pointers
+struct Arena {
+    aos2_matcher *m;
+    std::vector<uint8_t> host;
+    size_t used = 0;
+    size_t push(const void *src, size_t bytes)
+    {
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes);
+        if (src && bytes) memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes) { return push(nullptr, bytes); }
+    int upload()
+    {
+        int st = m->arena.alloc(host.size() + 256);
+        if (st) return st;
+        AOS2_HIP_CHECK(hipMemcpyAsync(m->arena.p, host.data(), host.size(), hipMemcpyHostToDevice, m->stream));
+        return AOS2_OK;
+    }
+    template <typename T>
+    T *dev(size_t off) const { return reinterpret_cast<T *>(m->arena.p + off); }
+};
+
+static void fill_frame(Arena &A, const aos2_frame_view_t *f, size_t off[12])
+{
+    const size_t n = (size_t)f->n_f;
+    off[0] = A.push(f->desc_f, n * 32);
+    off[1] = A.push(f->kp_x, n * 4);
+    off[2] = A.push(f->kp_y, n * 4);
+    off[3] = A.push(f->kp_angle, n * 4);
+    off[4] = A.push(f->u_right, n * 4);
+    off[5] = A.push(f->scale_factors, (size_t)f->n_levels * 4);
+    off[6] = A.push(f->kp_octave, n * 4);
+    off[7] = A.push(f->grid_off, (size_t)(GRID_COLS * GRID_ROWS + 1) * 4);
+    off[8] = A.push(f->grid_idx, (size_t)f->grid_off[GRID_COLS * GRID_ROWS] * 4);
+    off[9] = A.push(f->f_mp_state, n);
+}
+
+static FrameDev frame_dev(const Arena &A, const aos2_frame_view_t *f, const size_t off[12])
+{
+    FrameDev F{};
+    F.n_f = f->n_f;
+    F.n_levels = f->n_levels;
+    F.desc_f = A.dev<uint8_t>(off[0]);
+    F.kp_x = A.dev<float>(off[1]);
+    F.kp_y = A.dev<float>(off[2]);
+    F.kp_angle = A.dev<float>(off[3]);
+    F.u_right = A.dev<float>(off[4]);
+    F.scale_factors = A.dev<float>(off[5]);
+    F.kp_octave = A.dev<int32_t>(off[6]);
+    F.grid_off = A.dev<int32_t>(off[7]);
+    F.grid_idx = A.dev<int32_t>(off[8]);
+    F.f_mp_state = A.dev<uint8_t>(off[9]);
+    F.min_x = f->min_x; F.min_y = f->min_y; F.max_x = f->max_x; F.max_y = f->max_y;
+    F.grid_w_inv = f->grid_w_inv; F.grid_h_inv = f->grid_h_inv;
+    return F;
+}
+
+static int check_frame(const aos2_frame_view_t *f)
+{
+    if (!f || f->n_f < 0 || !f->grid_off || (f->n_f > 0 && (!f->desc_f || !f->kp_x || !f->kp_y || !f->kp_octave ||
+        !f->kp_angle || !f->u_right || !f->f_mp_state)) || !f->scale_factors || f->n_levels <= 0) {
+        set_error("bad frame view");
+        return AOS2_ERR_ARG;
+    }
+    if (f->n_f > 60000) {
+        set_error("n_f %d exceeds the LDS state table (60000)", f->n_f);
+        return AOS2_ERR_ARG;
+    }
+    return AOS2_OK;
+}
+
+}  // namespace aos2
+
+extern "C" {
+
+int aos2_matcher_create(float nnratio, int check_orientation, int device, aos2_matcher_t **out)
+{
+    if (!out) return AOS2_ERR_ARG;
+    aos2_matcher *m = new aos2_matcher();
+    m->nnratio = nnratio;
+    m->check_ori = check_orientation ? 1 : 0;
+    m->device = device;
+    *out = m;
+    return AOS2_OK;
+}
+
+void aos2_matcher_destroy(aos2_matcher_t *m)
+{
+    if (!m) return;
+    if (m->dev_ready) {
+        (void)hipSetDevice(m->device);
+        (void)hipStreamSynchronize(m->stream);
+        m->arena.release();
+        m->part.release();
+        for (auto &e : m->ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(m->stream);
+    }
+    delete m;
+}
+
+int aos2_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        dist += __builtin_popcountll(x ^ y);
+    }
+    return dist;
+}
+
+static int hamming_run(aos2_matcher *m, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int32_t *d_bi,
+                       int32_t *d_bd, int32_t *d_sd, int iters, float *avg_ms)
+{
+    const int splits = std::max(1, std::min(64, (nt + 255) / 256));
+    const int t_per_split = (((nt + splits - 1) / splits) + 255) & ~255;
+    const int eff_splits = (nt + t_per_split - 1) / t_per_split;
+    int st = m->part.alloc((size_t)2 * eff_splits * nq);
+    if (st) return st;
+    uint32_t *p1 = m->part.p, *p2 = m->part.p + (size_t)eff_splits * nq;
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(hamming_best2_kernel, dim3((nq + 255) / 256, eff_splits), dim3(256), 0, m->stream, d_q, nq,
+                           d_t, nt, t_per_split, p1, p2);
+        hipLaunchKernelGGL(hamming_merge_kernel, dim3((nq + 255) / 256), dim3(256), 0, m->stream, p1, p2, nq,
+                           eff_splits, d_bi, d_bd, d_sd);
+    }
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    if (avg_ms) {
+        float ms = 0;
+        AOS2_HIP_CHECK(hipEventElapsedTime(&ms, m->ev[0], m->ev[1]));
+        *avg_ms = ms / iters;
+    }
+    return AOS2_OK;
+}
+
+int aos2_matcher_hamming_best2_device(aos2_matcher_t *m, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt,
+                                      int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist, int iters,
+                                      float *avg_ms)
+{
+    if (!m || !d_q || !d_t || nq <= 0 || nt <= 0 || nt >= (1 << 20) || !d_best_idx || !d_best_dist || !d_second_dist ||
+        iters <= 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    return hamming_run(m, d_q, nq, d_t, nt, d_best_idx, d_best_dist, d_second_dist, iters, avg_ms);
+}
+
+int aos2_matcher_hamming_best2(aos2_matcher_t *m, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                               int32_t *best_idx, int32_t *best_dist, int32_t *second_dist)
+{
+    if (!m || !q || !t || nq <= 0 || nt <= 0 || nt >= (1 << 20) || !best_idx || !best_dist || !second_dist) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    Arena A{m};
+    const size_t oq = A.push(q, (size_t)nq * 32), ot = A.push(t, (size_t)nt * 32);
+    const size_t o1 = A.reserve((size_t)nq * 4), o2 = A.reserve((size_t)nq * 4), o3 = A.reserve((size_t)nq * 4);
+    if ((st = A.upload())) return st;
+    st = hamming_run(m, A.dev<uint8_t>(oq), nq, A.dev<uint8_t>(ot), nt, A.dev<int32_t>(o1), A.dev<int32_t>(o2),
+                     A.dev<int32_t>(o3), 1, nullptr);
+    if (st) return st;
+    AOS2_HIP_CHECK(hipMemcpy(best_idx, A.dev<int32_t>(o1), (size_t)nq * 4, hipMemcpyDeviceToHost));
+    AOS2_HIP_CHECK(hipMemcpy(best_dist, A.dev<int32_t>(o2), (size_t)nq * 4, hipMemcpyDeviceToHost));
+    AOS2_HIP_CHECK(hipMemcpy(second_dist, A.dev<int32_t>(o3), (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs, int32_t *const *match_f,
+                               int32_t *nmatches)
+{
+    if (!m || !pairs || n_pairs <= 0 || !match_f || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    Arena A{m};
+    struct Off { size_t o[16]; };
+    std::vector<Off> offs(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const aos2_bow_pair_t &P = pairs[p];
+        if (P.n_kf < 0 || P.n_f < 0 || P.n_nodes_kf < 0 || P.n_nodes_f < 0 || !match_f[p]) {
+            set_error("bad BoW pair %d", p);
+            return AOS2_ERR_ARG;
+        }
+        Off &o = offs[p];
+        o.o[0] = A.push(P.desc_kf, (size_t)P.n_kf * 32);
+        o.o[1] = A.push(P.desc_f, (size_t)P.n_f * 32);
+        o.o[2] = A.push(P.kf_has_mp, (size_t)P.n_kf);
+        o.o[3] = A.push(P.angle_kf, (size_t)P.n_kf * 4);
+        o.o[4] = A.push(P.angle_f, (size_t)P.n_f * 4);
+        o.o[5] = A.push(P.node_id_kf, (size_t)P.n_nodes_kf * 4);
+        o.o[6] = A.push(P.node_off_kf, (size_t)(P.n_nodes_kf + 1) * 4);
+        o.o[7] = A.push(P.node_idx_kf, (size_t)(P.n_nodes_kf ? P.node_off_kf[P.n_nodes_kf] : 0) * 4);
+        o.o[8] = A.push(P.node_id_f, (size_t)P.n_nodes_f * 4);
+        o.o[9] = A.push(P.node_off_f, (size_t)(P.n_nodes_f + 1) * 4);
+        o.o[10] = A.push(P.node_idx_f, (size_t)(P.n_nodes_f ? P.node_off_f[P.n_nodes_f] : 0) * 4);
+        o.o[11] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
+        o.o[12] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
+        o.o[13] = A.reserve(4);                      // nmatches
+    }
+    const size_t opairs = A.reserve(sizeof(BowPairDev) * n_pairs);
+    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    std::vector<BowPairDev> dev(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const aos2_bow_pair_t &P = pairs[p];
+        const Off &o = offs[p];
+        BowPairDev &D = dev[p];
+        D.n_kf = P.n_kf; D.n_f = P.n_f; D.n_nodes_kf = P.n_nodes_kf; D.n_nodes_f = P.n_nodes_f;
+        D.desc_kf = A.dev<uint8_t>(o.o[0]); D.desc_f = A.dev<uint8_t>(o.o[1]); D.kf_has_mp = A.dev<uint8_t>(o.o[2]);
+        D.angle_kf = A.dev<float>(o.o[3]); D.angle_f = A.dev<float>(o.o[4]);
+        D.node_id_kf = A.dev<int32_t>(o.o[5]); D.node_off_kf = A.dev<int32_t>(o.o[6]); D.node_idx_kf = A.dev<int32_t>(o.o[7]);
+        D.node_id_f = A.dev<int32_t>(o.o[8]); D.node_off_f = A.dev<int32_t>(o.o[9]); D.node_idx_f = A.dev<int32_t>(o.o[10]);
+        D.match_f = A.dev<int32_t>(o.o[11]); D.bin_f = A.dev<uint32_t>(o.o[12]); D.nmatches = A.dev<int32_t>(o.o[13]);
+    }
+    memcpy(A.host.data() + opairs, dev.data(), sizeof(BowPairDev) * n_pairs);
+    if ((st = A.upload())) return st;
+    int max_nf = 0;
+    for (int p = 0; p < n_pairs; ++p) max_nf = std::max(max_nf, pairs[p].n_f);
+    if (max_nf > 60000) {
+        set_error("n_f %d exceeds the LDS flag table (60000)", max_nf);
+        return AOS2_ERR_ARG;
+    }
+    hipLaunchKernelGGL(search_by_bow_kernel, dim3(n_pairs), dim3(64), (size_t)max_nf + 16, m->stream,
+                       A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
+    for (int p = 0; p < n_pairs; ++p) {
+        AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_f, (size_t)pairs[p].n_f * 4, hipMemcpyDeviceToHost, m->stream));
+        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t *f, const aos2_proj_mp_t *p, float th,
+                                      int32_t *match_f, int32_t *nmatches)
+{
+    if (!m || !p || !match_f || !nmatches || p->n_mp < 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = check_frame(f);
+    if (st) return st;
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t fo[12];
+    fill_frame(A, f, fo);
+    const size_t n = (size_t)p->n_mp;
+    const size_t o0 = A.push(p->track_in_view, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
+    const size_t o3 = A.push(p->pred_level, n * 4), o4 = A.push(p->view_cos, n * 4), o5 = A.push(p->proj_x, n * 4);
+    const size_t o6 = A.push(p->proj_y, n * 4), o7 = A.push(p->proj_xr, n * 4);
+    const size_t om = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(4);
+    if ((st = A.upload())) return st;
+    FrameDev F = frame_dev(A, f, fo);
+    ProjMpDev P{};
+    P.n_mp = p->n_mp;
+    P.track_in_view = A.dev<uint8_t>(o0); P.desc = A.dev<uint8_t>(o1); P.has_obs = A.dev<uint8_t>(o2);
+    P.pred_level = A.dev<int32_t>(o3); P.view_cos = A.dev<float>(o4); P.proj_x = A.dev<float>(o5);
+    P.proj_y = A.dev<float>(o6); P.proj_xr = A.dev<float>(o7);
+    hipLaunchKernelGGL(search_by_projection_mp_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, th,
+                       m->nnratio, A.dev<int32_t>(om), A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_view_t *cur, const aos2_proj_last_t *p,
+                                           float th, int mono, int32_t *match_f, int32_t *nmatches)
+{
+    if (!m || !p || !match_f || !nmatches || p->n_last < 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = check_frame(cur);
+    if (st) return st;
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t fo[12];
+    fill_frame(A, cur, fo);
+    const size_t n = (size_t)p->n_last;
+    const size_t o0 = A.push(p->last_valid, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
+    const size_t o3 = A.push(p->world_pos, n * 12), o4 = A.push(p->last_angle, n * 4), o5 = A.push(p->last_octave, n * 4);
+    const size_t om = A.reserve((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve(4);
+    if ((st = A.upload())) return st;
+    FrameDev F = frame_dev(A, cur, fo);
+    ProjLastDev P{};
+    P.n_last = p->n_last;
+    P.last_valid = A.dev<uint8_t>(o0); P.desc = A.dev<uint8_t>(o1); P.has_obs = A.dev<uint8_t>(o2);
+    P.world_pos = A.dev<float>(o3); P.last_angle = A.dev<float>(o4); P.last_octave = A.dev<int32_t>(o5);
+    memcpy(P.Tcw, p->Tcw, sizeof(P.Tcw));
+    memcpy(P.Tlw, p->Tlw, sizeof(P.Tlw));
+    P.fx = p->fx; P.fy = p->fy; P.cx = p->cx; P.cy = p->cy; P.mb = p->mb; P.mbf = p->mbf;
+    hipLaunchKernelGGL(search_by_projection_last_kernel, dim3(1), dim3(64), (size_t)cur->n_f + 16, m->stream, F, P, th,
+                       mono ? 1 : 0, m->check_ori, A.dev<int32_t>(om), A.dev<uint32_t>(ob), A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)cur->n_f * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    return AOS2_OK;
+}
+
+}  // extern "C"

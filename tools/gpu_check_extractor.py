@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle()
-cfgs = [("tum", 640, 480, 1000), ("kitti", 1241, 376, 2000), ("small", 200, 160, 300)]
+cfgs = [("tum", 640, 480, 1000), ("kitti", 1241, 376, 2000), ("small", 320, 240, 300)]
 for name, w, h, nf in cfgs:
     img = pkg.synth.synth_image(1, w, h)
     ex = pkg.Extractor(nfeatures=nf); oe = O.Extractor(nfeatures=nf)
@@ -43,3 +43,15 @@ a = np.linspace(0, 6.2832, 100000).astype(np.float32)
 s, c = pkg.capi.debug_sincos_device(a)
 hs = np.array([pkg.capi.debug_sincos_host(v) for v in a[:20000]], np.float32)
 print("sincos device==host:", (s[:20000] == hs[:, 0]).all() and (c[:20000] == hs[:, 1]).all())
+for B in (64, 256):
+    imgs = pkg.synth.synth_batch(1000, B)
+    ex = pkg.Extractor()
+    res = ex.extract_batch(imgs)
+    t = time.time(); res = ex.extract_batch(imgs); dt = time.time() - t
+    print("batch", B, "wall %.1f ms -> %.0f fps" % (dt * 1e3, B / dt), ex.last_timing(), "fast ms", ex.bench_fast(10), "describe ms", ex.bench_describe(10))
+os.environ["AOS2_OCTREE"] = "host"
+ex = pkg.Extractor()
+res = ex.extract_batch(imgs)
+t = time.time(); res2 = ex.extract_batch(imgs); dt = time.time() - t
+print("host-octree batch", len(imgs), "wall %.1f ms -> %.0f fps" % (dt * 1e3, len(imgs) / dt), ex.last_timing(), "nproc", os.cpu_count())
+print("host==device octree:", all((a[0].tobytes() == b[0].tobytes()) and (a[1] == b[1]).all() for a, b in zip(res, res2)))
