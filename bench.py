@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Benchmark of the ORB hot path on MI355X (contract: one JSON line on rank 0).
+
+step      = one pass of ORBextractor::operator() over one batch of synthetic 640x480 frames per GPU
+            (BASELINE.json configs[1]: "TUM fr1_desk 640x480 ORBextractor-only on 1 MI355X"),
+            inputs resident in HBM before the timed region, keypoints/descriptors left in HBM.
+value     = frames/s over all ranks (weak scaling: every rank extracts its own batch; frames are
+            independent, no data-path collective).  After the timed region one RCCL gather of the
+            keypoint slots to rank 0 exercises the only exchange step of the path (reported, untimed).
+roofline  = FAST+NMS kernel (the dominant HBM consumer named by north_star): algorithmic bytes P per
+            image / kernel time from HIP events on the library's stream.
+cpu_baseline = the ORACLE restatement (C, 1 core) on a bounded sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: the library then binds to the same HIP runtime as torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pkg = g.load_package()
+    cfg = pkg.synth.CONFIGS["tum"]
+    W, H, NF = cfg["w"], cfg["h"], cfg["nfeatures"]
+    B = args.batch
+
+    # synthetic frames: 32 distinct seeded images per rank, tiled to the batch, resident in HBM
+    n_unique = min(B, 32)
+    base = pkg.synth.synth_batch(10_000 + 1000 * rank, n_unique, W, H)
+    reps = -(-B // n_unique)
+    frames = np.concatenate([base] * reps, axis=0)[:B]
+    d_img = torch.from_numpy(frames).to(dev)
+    ex = pkg.Extractor(nfeatures=NF, device=local_rank)
+    cap = ex.max_keypoints
+    d_kps = torch.empty((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def step():
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stage = ex.last_timing()
+    fast_ms = ex.bench_fast(20)
+
+    # the one exchange step of the path: keypoint/descriptor slots of 8 frames per rank -> rank 0 (RCCL)
+    gather_ms = None
+    n_kp = d_n.cpu().numpy()
+    if world > 1:
+        sh = pkg.sharding
+        k = min(8, B)
+        slot = torch.zeros((k, sh.slot_bytes(cap)), dtype=torch.uint8, device=dev)
+        slot[:, 16:16 + 28 * cap] = d_kps[:k].view(torch.uint8).reshape(k, -1)
+        slot[:, 16 + 28 * cap:16 + 60 * cap] = d_desc[:k].reshape(k, -1)
+        slot[:, :4] = d_n[:k].view(torch.uint8).reshape(k, 4)
+        bufs = [torch.empty_like(slot) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        dist.gather(slot, bufs, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank == 0:
+        P = 950_532  # sum of level pixels for 640x480
+        fast_bytes = P * B
+        achieved = fast_bytes / (fast_ms * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec (extract) TUM 640x480",
+            "value": world * B * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "TUM 640x480 ORBextractor-only, 1000 features, 8 levels, scale 1.2, FAST 20/7 (BASELINE configs[1])",
+                       "frames_per_gpu_per_step": B, "octree": os.environ.get("AOS2_OCTREE", "device"),
+                       "keypoints_per_frame_mean": float(n_kp.mean())},
+            "stage_ms": stage,
+            "roofline": {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": fast_bytes, "kernel_ms": fast_ms},
+        }
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+        if not args.no_cpu_baseline:
+            O = g.load_oracle()
+            oe = O.Extractor(nfeatures=NF)
+            n_cpu = args.cpu_frames or 32
+            oe.extract(base[0])
+            tc = time.perf_counter()
+            done = 0
+            for i in range(n_cpu):
+                oe.extract(base[i % n_unique])
+                done += 1
+                if time.perf_counter() - tc > 20.0:
+                    break
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": done / tc, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{done} of the same 640x480 frames, oracle C restatement (-O3, 1 thread), host has {os.cpu_count()} cores"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -274,6 +274,8 @@ def _fill(struct, d, keep):
         if name not in d:
             continue
         v = d[name]
+        if isinstance(v, np.ndarray) and v.ndim == 0:
+            v = v.item()
         if isinstance(v, np.ndarray) and ct is C.c_void_p:
             v = np.ascontiguousarray(v)
             keep.append(v)
@@ -376,7 +378,8 @@ def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
         a = np.ascontiguousarray(prob[name], dt)
         keep.append(a)
         setattr(s, name, a.ctypes.data)
-    s.fx, s.fy, s.cx, s.cy, s.bf = (float(prob[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
+    # KeyFrame::fx..mbf are float members copied into the edges' double fields (Optimizer.cc:613-616,642-646)
+    s.fx, s.fy, s.cx, s.cy, s.bf = (float(np.float32(prob[k])) for k in ("fx", "fy", "cx", "cy", "bf"))
     if stop_flag is not None:
         keep.append(stop_flag)
         s.stop_flag = stop_flag.ctypes.data

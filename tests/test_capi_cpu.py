@@ -1,0 +1,140 @@
+"""Host-side checks of the product that need no GPU: the C-ABI library loads and exports every
+symbol include/aos2.h declares, host tables equal the oracle's, the shared octree routine (host
+execution) equals the oracle's DistributeOctTree, error behaviour without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "aos2.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(aos2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.capi.lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert b"gfx950" in L.aos2_version()
+
+
+def test_library_contains_gfx950_code_object(pkg):
+    data = open(pkg.lib_path(), "rb").read()
+    assert b"gfx950" in data and b"fast_cells_kernel" in data and b"describe_kernel" in data
+
+
+def test_host_tables_match_oracle(pkg, oracle):
+    for nf, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (1200, 1.2, 8), (500, 1.5, 4), (3000, 1.1, 12)):
+        a = pkg.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+        b = oracle.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+        assert a.GetLevels() == nl and a.GetScaleFactor() == np.float32(sf)
+        assert (a.GetScaleFactors() == b.scale_factors).all()
+        assert (a.GetInverseScaleFactors() == b.inv_scale_factors).all()
+        assert (a.GetScaleSigmaSquares() == b.sigma2).all()
+        assert (a.GetInverseScaleSigmaSquares() == b.inv_sigma2).all()
+        assert (a.features_per_level == b.features_per_level).all()
+        assert (a.umax == b.umax).all()
+        assert a.max_keypoints >= nf
+
+
+def test_bad_arguments_and_missing_device(pkg):
+    capi = pkg.capi
+    with pytest.raises(capi.AosError) as e:
+        pkg.Extractor(nfeatures=0)
+    assert e.value.code == capi.AOS2_ERR_ARG
+    with pytest.raises(capi.AosError):
+        pkg.Extractor(nlevels=40)
+    ex = pkg.Extractor()
+    # empty image: silent return like src/ORBextractor.cc:1046 (no device needed)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    with pytest.raises(AssertionError):
+        ex(np.zeros((480, 640), np.float32))
+    if pkg.device_count() == 0:
+        with pytest.raises(capi.AosError) as e:
+            ex(np.zeros((480, 640), np.uint8))
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE  # loud failure, no CPU fallback
+        with pytest.raises(capi.AosError) as e:
+            pkg.Matcher().hamming_best2(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE
+        prob = pkg.synth.synth_lba_problem(1, n_local=2, n_fixed=1, n_points=20)
+        with pytest.raises(capi.AosError) as e:
+            pkg.LocalBA().LocalBundleAdjustment(prob)
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE
+
+
+def test_descriptor_distance_host(pkg, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert pkg.Matcher.DescriptorDistance(a, b) == oracle.descriptor_distance(a, b)
+    assert pkg.Matcher.TH_LOW == 50 and pkg.Matcher.TH_HIGH == 100 and pkg.Matcher.HISTO_LENGTH == 30
+
+
+def test_octree_routine_matches_oracle_on_extractor_candidates(pkg, oracle):
+    for seed, (w, h, nf) in enumerate([(640, 480, 1000), (1241, 376, 2000), (752, 480, 1200)]):
+        img = pkg.synth.synth_image(20 + seed, w, h)
+        oe = oracle.Extractor(nfeatures=nf)
+        oe.extract(img)
+        for l in range(8):
+            x, y, s = oe.level_candidates(l)
+            lw, lh, _ = oe.level_size(l)
+            N = int(oe.features_per_level[l])
+            a = oracle.distribute_octree(x, y, s, 16, lw - 16, 16, lh - 16, N)
+            b = pkg.capi.debug_octree_host(x, y, s, 16, lw - 16, 16, lh - 16, N)
+            assert len(a) == len(b) == oe.level_nkeys(l) and (a == b).all()
+
+
+def test_octree_routine_ties_and_degenerate_inputs(pkg, oracle):
+    rng = np.random.default_rng(3)
+    for case in range(60):
+        W, H = int(rng.integers(40, 1300)), int(rng.integers(40, 500))
+        if W < H * 0.5:
+            W = H  # nIni would be 0 (the reference divides by zero on tall boxes)
+        n = int(rng.integers(1, 3000))
+        N = int(rng.integers(1, 500))
+        pts = np.unique(np.stack([rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)], 1), axis=0)
+        rng.shuffle(pts)
+        x, y = pts[:, 0].astype(np.int16), pts[:, 1].astype(np.int16)
+        if case % 3 == 0:
+            s = np.full(len(x), 50, np.uint8)            # all responses tie
+        elif case % 3 == 1:
+            s = rng.integers(7, 12, len(x)).astype(np.uint8)  # many ties
+        else:
+            s = rng.integers(7, 255, len(x)).astype(np.uint8)
+        if case % 5 == 0:  # clustered points: deep, degenerate splits
+            x = (x // 8 + 5).astype(np.int16)
+            y = (y // 8 + 5).astype(np.int16)
+            u = np.unique(np.stack([x, y], 1), axis=0)
+            x, y, s = u[:, 0].astype(np.int16), u[:, 1].astype(np.int16), s[: len(u)]
+        a = oracle.distribute_octree(x, y, s, 0, W, 0, H, N)
+        b = pkg.capi.debug_octree_host(x, y, s, 0, W, 0, H, N)
+        assert len(a) == len(b) and (a == b).all(), case
+        assert len(set(a.tolist())) == len(a)
+        assert len(a) <= min(len(x), N + 3)
+
+
+def test_sincos_host_tap_equals_oracle(pkg, oracle):
+    L = oracle.lib()
+    L.orc_sincos_exact.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for a in np.linspace(0, 6.2832, 5000).astype(np.float32):
+        s, c = C.c_float(), C.c_float()
+        L.orc_sincos_exact(float(a), C.byref(s), C.byref(c))
+        assert pkg.capi.debug_sincos_host(a) == (s.value, c.value)
+
+
+def test_synth_is_seeded(pkg):
+    a, b = pkg.synth.synth_image(3), pkg.synth.synth_image(3)
+    assert (a == b).all() and a.dtype == np.uint8 and a.shape == (480, 640)
+    assert (pkg.synth.synth_image(4) != a).any()
+    off, idx, gwi, ghi = pkg.synth.build_grid(np.array([0.0, 639.9, 320.0], np.float32), np.array([0.0, 479.9, 240.0], np.float32), 0, 0, 640, 480)
+    assert off[-1] == 2 and len(off) == 64 * 48 + 1  # the point at the max border falls outside (posX == 64)

@@ -1,0 +1,121 @@
+"""Parity of the HIP ORBextractor path (through the C ABI) against the oracle and the committed
+golden fixtures.  Integer / index / byte work: everything is compared bit for bit."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def same(a, b):
+    return len(a[0]) == len(b[0]) and a[0].tobytes() == b[0].tobytes() and (a[1] == b[1]).all()
+
+
+@pytest.mark.parametrize("cfg", ["tum", "kitti", "euroc"])
+def test_extract_bit_exact_vs_oracle_reference_configs(pkg, oracle, gpu, cfg):
+    c = pkg.synth.CONFIGS[cfg]
+    ex = pkg.Extractor(nfeatures=c["nfeatures"])
+    oe = oracle.Extractor(nfeatures=c["nfeatures"])
+    for seed in (1, 2):
+        img = pkg.synth.synth_image(seed, c["w"], c["h"])
+        got = ex(img)
+        want = oe.extract(img)
+        assert same(got, want)
+        for l in range(8):
+            assert (ex.pyramid_level(l) == oe.level_plane(l)).all()
+            gx, gy, gs = ex.debug_candidates(l)
+            ox, oy, os_ = oe.level_candidates(l)
+            assert len(gx) == len(ox) and (gx == ox).all() and (gy == oy).all() and (gs == os_).all()
+        # mvImagePyramid with the 19-px BORDER_REFLECT_101 frame (src/ORBextractor.cc:1113-1128)
+        assert (ex.pyramid_level(3, border=19) == oracle.copy_make_border(oe.level_plane(3))).all()
+
+
+@pytest.mark.parametrize("name", ["extract_320x240_L8", "extract_160x120_L4", "extract_tum", "extract_kitti"])
+def test_extract_matches_golden_fixture(pkg, gpu, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    if "img" in g.files:
+        img, nl = g["img"], int(g["nlevels"])
+    else:
+        img, nl = pkg.synth.synth_image(int(g["seed"]), int(g["w"]), int(g["h"])), 8
+        if zlib.crc32(img.tobytes()) != int(g["img_crc"]):
+            pytest.skip("synthetic image generator is not bit-reproducible on this numpy build")
+    kps, desc = pkg.Extractor(nfeatures=int(g["nfeatures"]), nlevels=nl)(img)
+    assert kps.tobytes() == g["kps"].tobytes() and (desc == g["desc"]).all()
+
+
+def test_edge_cases(pkg, oracle, gpu):
+    capi = pkg.capi
+    ex = pkg.Extractor()
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0
+    with pytest.raises(capi.AosError) as e:
+        ex(np.zeros((100, 100), np.uint8))           # nCols/nRows would be 0 in the reference
+    assert e.value.code == capi.AOS2_ERR_TOO_SMALL
+    flat = np.full((480, 640), 90, np.uint8)          # no corner at any threshold
+    k, d = ex(flat)
+    assert len(k) == 0 and d.shape == (0, 32)
+    low = pkg.synth.synth_image(9)
+    low = (low.astype(np.int32) // 6 + 100).astype(np.uint8)   # low contrast: minThFAST path everywhere
+    assert same(ex(low), oracle.Extractor().extract(low))
+    sat = np.where(pkg.synth.synth_image(10) > 128, 255, 0).astype(np.uint8)  # saturated scores
+    assert same(ex(sat), oracle.Extractor().extract(sat))
+    # non-contiguous rows (stride > width) and odd sizes
+    big = np.zeros((333, 700), np.uint8)
+    big[:, :517] = pkg.synth.synth_image(11, 517, 333)
+    view = big[:, :517]
+    ex2, oe2 = pkg.Extractor(nfeatures=700), oracle.Extractor(nfeatures=700)
+    assert same(ex2(view), oe2.extract(np.ascontiguousarray(view)))
+    # other pyramid parameters
+    ex3 = pkg.Extractor(nfeatures=800, scale_factor=1.5, nlevels=4, ini_th=30, min_th=10)
+    oe3 = oracle.Extractor(nfeatures=800, scale_factor=1.5, nlevels=4, ini_th=30, min_th=10)
+    img = pkg.synth.synth_image(12)
+    assert same(ex3(img), oe3.extract(img))
+
+
+def test_batch_equals_single_and_idempotent(pkg, oracle, gpu):
+    imgs = pkg.synth.synth_batch(40, 12)
+    ex = pkg.Extractor()
+    res = ex.extract_batch(imgs)
+    oe = oracle.Extractor()
+    for b in range(len(imgs)):
+        assert same(res[b], oe.extract(imgs[b]))
+    again = ex.extract_batch(imgs)
+    assert all(same(a, b) for a, b in zip(res, again))
+    single = pkg.Extractor()
+    assert same(single(imgs[5]), res[5])
+    t = ex.last_timing()
+    assert t["fast"] > 0 and t["describe"] > 0
+
+
+def test_host_octree_path_equals_device_octree(pkg, gpu, monkeypatch):
+    imgs = pkg.synth.synth_batch(60, 6)
+    dev = pkg.Extractor().extract_batch(imgs)
+    monkeypatch.setenv("AOS2_OCTREE", "host")
+    host = pkg.Extractor().extract_batch(imgs)
+    assert all(same(a, b) for a, b in zip(dev, host))
+
+
+def test_full_batch_properties(pkg, oracle, gpu):
+    """BASELINE-size batch (256 x 640x480): size-independent properties + sampled exact parity."""
+    B = 256
+    imgs = pkg.synth.synth_batch(5000, 8)
+    imgs = np.concatenate([imgs] * (B // 8), axis=0)   # replicas: equal inputs must give equal outputs
+    ex = pkg.Extractor()
+    res = ex.extract_batch(imgs)
+    oe = oracle.Extractor()
+    for b in range(8):
+        want = oe.extract(imgs[b])
+        for r in range(b, B, 8):
+            assert same(res[r], want)
+    crc = [zlib.crc32(res[b][0].tobytes() + res[b][1].tobytes()) for b in range(B)]
+    assert zlib.crc32(np.array(crc, np.uint32).tobytes()) == zlib.crc32(np.array(crc[:8] * (B // 8), np.uint32).tobytes())
+
+
+def test_sincos_device_equals_host(pkg, gpu):
+    a = (np.linspace(0, 360, 200001).astype(np.float32) * np.float32(np.pi / 180.0)).astype(np.float32)
+    s, c = pkg.capi.debug_sincos_device(a)
+    hs = np.array([pkg.capi.debug_sincos_host(v) for v in a[::10]], np.float32)
+    assert (s[::10] == hs[:, 0]).all() and (c[::10] == hs[:, 1]).all()

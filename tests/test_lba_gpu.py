@@ -1,0 +1,64 @@
+"""HIP LocalBundleAdjustment vs the oracle.  Floating point (IEEE double inside, float32 at the
+boundary like the reference): tolerance 1e-5 absolute on the float32 poses/points written back
+(north_star), checked on top of the float32 quantisation of the stored value."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    # 1e-5 absolute, plus one float32 ulp of the magnitude (values ~40 m have ulp 3.8e-6)
+    return (np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 2 * np.spacing(np.abs(b).astype(np.float32))).all()
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=1, n_local=3, n_fixed=2, n_points=60, stereo_frac=0.5),
+                                 dict(seed=2, n_local=6, n_fixed=4, n_points=400, stereo_frac=0.0),
+                                 dict(seed=4, n_local=5, n_fixed=0, n_points=300, include_kf0=True),
+                                 dict(seed=0), dict(seed=3, include_kf0=True, outlier_frac=0.15)])
+def test_lba_vs_oracle(pkg, oracle, gpu, cfg):
+    prob = pkg.synth.synth_lba_problem(**cfg)
+    want = oracle.lba_solve(prob)
+    got = pkg.LocalBA().LocalBundleAdjustment(prob)
+    assert got["status"] == 0 and got["iters"] == want["iters"]
+    assert close(got["pose_Tcw"], want["pose_Tcw"])
+    assert close(got["point_xyz"], want["point_xyz"])
+    assert (got["edge_outlier"] == want["edge_outlier"]).all()
+    assert abs(got["final_chi2"] - want["chi2_trace"][-1]) <= 1e-6 * want["chi2_trace"][-1]
+    assert np.allclose(got["edge_chi2"], want["edge_chi2"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["lba_3kf", "lba_14kf"])
+def test_lba_golden(pkg, gpu, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    prob = {k: g[k] for k in g.files if not k.startswith("out_")}
+    for k in ("n_poses", "n_points", "n_edges"):
+        prob[k] = int(prob[k])
+    got = pkg.LocalBA().LocalBundleAdjustment(prob)
+    assert close(got["pose_Tcw"], g["out_pose_Tcw"]) and close(got["point_xyz"], g["out_point_xyz"])
+    assert (got["edge_outlier"] == g["out_outlier"]).all()
+
+
+def test_lba_stop_flag_and_properties(pkg, oracle, gpu):
+    prob = pkg.synth.synth_lba_problem(5, n_local=4, n_fixed=3, n_points=200)
+    ba = pkg.LocalBA()
+    flag = np.ones(1, np.uint8)
+    r = ba.LocalBundleAdjustment(prob, stop_flag=flag)
+    assert r["status"] == pkg.capi.AOS2_ERR_STOPPED and r["iters"] == (0, 0)
+    assert (r["pose_Tcw"] == prob["pose_Tcw"]).all() and (r["point_xyz"] == prob["point_xyz"]).all()
+    r = ba.LocalBundleAdjustment(prob)
+    fixed = prob["pose_fixed"].astype(bool)
+    assert np.abs(r["pose_Tcw"][fixed] - prob["pose_Tcw"][fixed]).max() < 1e-6   # fixed cameras do not move
+    # a solved problem stays solved (idempotence up to the LM stop rule)
+    p2 = dict(prob)
+    p2["pose_Tcw"], p2["point_xyz"] = r["pose_Tcw"], r["point_xyz"]
+    r2 = ba.LocalBundleAdjustment(p2)
+    assert np.abs(r2["pose_Tcw"] - r["pose_Tcw"]).max() < 5e-3
+    # iteration counts: only the first pass
+    r3 = ba.LocalBundleAdjustment(prob, iters=(5, 0))
+    w3 = oracle.lba_solve(prob, iters1=5, iters2=0)
+    assert close(r3["pose_Tcw"], w3["pose_Tcw"]) and close(r3["point_xyz"], w3["point_xyz"])

@@ -1,0 +1,96 @@
+"""Parity of the HIP ORBmatcher path against the oracle / golden fixtures (indices and counts are
+compared exactly)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_hamming_best2_vs_bruteforce(pkg, gpu):
+    rng = np.random.default_rng(0)
+    S = pkg.synth
+    m = pkg.Matcher()
+    for nq, nt in ((1, 1), (7, 300), (2000, 2000), (513, 4099)):
+        q, t = S.synth_descriptors(rng, nq), S.synth_descriptors(rng, nt)
+        if nt > 10:
+            t[: min(nq, nt) // 2] = S.flip_bits(rng, q[: min(nq, nt) // 2], 0.05)
+            t[5] = t[3]  # exact tie: lowest index must win
+        bi, bd, sd = m.hamming_best2(q, t)
+        D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+        assert (bi == D.argmin(axis=1)).all() and (bd == D.min(axis=1)).all()
+        if nt > 1:
+            assert (sd == np.sort(D, axis=1)[:, 1]).all()
+        else:
+            assert (sd == 256).all()
+    z = np.zeros((2, 32), np.uint8)
+    o = np.full((3, 32), 255, np.uint8)
+    bi, bd, sd = m.hamming_best2(z, o)
+    assert (bd == 256).all() and (bi == 0).all()
+
+
+def test_search_by_bow_vs_oracle(pkg, oracle, gpu):
+    S = pkg.synth
+    for ratio, ori in ((0.7, True), (0.6, False), (0.9, True)):
+        m = pkg.Matcher(ratio, ori)
+        probs = [S.synth_bow_problem(s, 900 + 50 * s, 1000 - 30 * s, n_nodes=60 + 10 * s, nnratio=ratio, check_orientation=ori) for s in range(6)]
+        res = m.SearchByBoW(probs)
+        for p, (n, match) in zip(probs, res):
+            on, om = oracle.search_by_bow(p)
+            assert n == on and (match == om).all()
+    # KITTI-size pair and a big vocabulary bucket (> 64 candidates per node)
+    m = pkg.Matcher(0.7, True)
+    for p in (S.synth_bow_problem(50, 2000, 2000), S.synth_bow_problem(51, 1500, 1500, n_nodes=6)):
+        n, match = m.SearchByBoW(p)
+        on, om = oracle.search_by_bow(p)
+        assert n == on and (match == om).all()
+    g = np.load(os.path.join(GOLD, "bow_300.npz"))
+    p = {k: g[k] for k in g.files if k not in ("nmatches", "match")}
+    n, match = pkg.Matcher(float(g["nnratio"]), bool(g["check_orientation"])).SearchByBoW(p)
+    assert n == int(g["nmatches"]) and (match == g["match"]).all()
+
+
+def test_search_by_projection_vs_oracle(pkg, oracle, gpu):
+    S = pkg.synth
+    for seed in range(6):
+        f, mp = S.synth_proj_mp_problem(seed, n_f=1000 + 100 * seed, n_mp=1500, th=3.0 if seed % 2 else 1.0)
+        on, om = oracle.search_by_projection_mp(f, mp)
+        m = pkg.Matcher(float(mp["nnratio"]), True)
+        n, match = m.SearchByProjection(f, mp, th=float(mp["th"]))
+        assert n == on and (match == om).all()
+    f, mp = S.synth_proj_mp_problem(7, n_f=2000, n_mp=3000, w=1241, h=376)
+    on, om = oracle.search_by_projection_mp(f, mp)
+    n, match = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+    assert n == on and (match == om).all()
+
+
+def test_search_by_projection_last_vs_oracle(pkg, oracle, gpu):
+    S = pkg.synth
+    for seed in range(10):
+        cur, p = S.synth_proj_last_problem(seed, n=1000 + 100 * (seed % 3), mono=(seed % 5 == 4), th=7.0 if seed % 2 else 15.0,
+                                           check_orientation=(seed != 3))
+        on, om = oracle.search_by_projection_last(cur, p)
+        m = pkg.Matcher(0.9, bool(p["check_orientation"]))
+        n, match = m.SearchByProjectionLast(cur, p, float(p["th"]), int(p["mono"]))
+        assert n == on and (match == om).all()
+    g = np.load(os.path.join(GOLD, "proj_last_300.npz"))
+    f = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    pl = {k[3:]: g[k] for k in g.files if k.startswith("pl_")}
+    f["n_f"], f["n_levels"] = int(f["n_f"]), int(f["n_levels"])
+    n, match = pkg.Matcher(0.9, bool(pl["check_orientation"])).SearchByProjectionLast(f, pl, float(pl["th"]), int(pl["mono"]))
+    assert n == int(g["nmatches"]) and (match == g["match"]).all()
+
+
+def test_match_on_extracted_frames(pkg, oracle, gpu):
+    """extract -> brute-force match of a frame against a shifted copy: most keypoints re-match."""
+    img = pkg.synth.synth_image(77)
+    ex = pkg.Extractor()
+    k0, d0 = ex(img)
+    k1, d1 = ex(np.roll(img, 3, axis=1))
+    bi, bd, sd = pkg.Matcher().hamming_best2(d0, d1)
+    good = bd <= 50
+    assert good.mean() > 0.5
+    dx = k1["x"][bi[good]] - k0["x"][good]
+    assert np.median(np.abs(dx - 3 * 1.0)) < 4.0
