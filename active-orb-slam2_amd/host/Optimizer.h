@@ -1,0 +1,28 @@
+// ORB_SLAM2::Optimizer::LocalBundleAdjustment surface (include/Optimizer.h:45) over a POD problem.
+// The real Optimizer.cc keeps `void static LocalBundleAdjustment(KeyFrame*, bool*, Map*)`: its
+// window gathering (:457-505) fills aos2_lba_problem_t, this call replaces :507-744, and its
+// write-back (:746-778) consumes aos2_lba_result_t.
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "aos2_types.h"
+
+namespace ORB_SLAM2 {
+
+class Optimizer {
+public:
+    // returns false when *pbStopFlag was already set (the reference returns before optimising)
+    bool static LocalBundleAdjustment(const aos2_lba_problem_t &problem, aos2_lba_result_t &result, int device = 0)
+    {
+        aos2_lba_t *s = nullptr;
+        if (aos2_lba_create(device, &s) != AOS2_OK) throw std::runtime_error(aos2_last_error());
+        const int st = aos2_lba_solve(s, &problem, &result);
+        aos2_lba_destroy(s);
+        if (st == AOS2_ERR_STOPPED) return false;
+        if (st != AOS2_OK) throw std::runtime_error(std::string("LocalBundleAdjustment: ") + aos2_last_error());
+        return true;
+    }
+};
+
+}  // namespace ORB_SLAM2
