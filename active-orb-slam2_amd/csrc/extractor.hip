@@ -63,6 +63,7 @@ struct Plan {
     size_t slot_total = 0;     // candidate slots per image
     int max_cw = 0, max_ch = 0;
     int TP = 0, TH = 0, SP = 0;
+    int list_cap = 0, keep_cap = 0;
     size_t fast_lds = 0;
     // device copies
     DevBuf<LevelDev> d_levels;
@@ -284,10 +285,14 @@ static int build_plan(aos2_extractor *e, int w, int h)
     }
     P.pyr_bytes = off;
     P.slot_total = (slot + 63) & ~(size_t)63;
-    P.TP = (P.max_cw + 12 + 3) & ~3;
+    // LDS tile: [4-byte left halo | nq quads | 4-byte right halo] per row, evaluated column 0 at byte 4
+    P.TP = 4 * ((P.max_cw + 3) / 4) + 8;
     P.TH = P.max_ch + 6;
-    P.SP = P.max_cw + 2;
-    P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (size_t)P.SP * (P.max_ch + 2) + 16;
+    P.SP = (P.max_cw + 2 + 3) & ~3;
+    P.list_cap = (P.max_cw * P.max_ch + 7) & ~7;                       // every pixel may survive the pre-test
+    P.keep_cap = ((P.max_cw + 1) / 2) * ((P.max_ch + 1) / 2);          // NMS survivors are >= 2 px apart
+    P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (((size_t)P.SP * (P.TH - 4) + 15) & ~(size_t)15) +
+                 (size_t)P.list_cap * 2 * 2 + (size_t)P.keep_cap * 4 + 16;
     // upload
     int st;
     if ((st = P.d_levels.alloc(P.levels.size()))) return st;
@@ -458,7 +463,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
                       P.d_yab.p, batch, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[1], s));
     launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
-                P.TH, P.SP, P.fast_lds, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, batch, s);
+                P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, batch, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[2], s));
     launch_compact(P.d_cells.p, (int)P.cells.size(), L, P.d_level_cell_begin.p, e->d_slots.p, P.slot_total,
                    e->d_cell_cnt.p, e->d_dense.p, P.slot_total, e->d_level_off.p, batch, s);
@@ -718,7 +723,7 @@ int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms)
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
     for (int i = 0; i < iters; ++i)
         launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
-                    P.TH, P.SP, P.fast_lds, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, e->last_batch, s);
+                    P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, e->last_batch, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
     AOS2_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;

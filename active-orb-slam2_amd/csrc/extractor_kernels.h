@@ -40,8 +40,8 @@ void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t 
 void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const LevelDev &dst, const int *xofs,
                    const int *xab, const int *yofs, const int *yab, int batch, hipStream_t st);
 void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
-                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, uint32_t *slots,
-                 size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st);
+                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
+                 uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st);
 void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,
                     const uint32_t *slots, size_t slot_stride, const int32_t *cell_cnt, uint32_t *dense,
                     size_t dense_stride, int32_t *level_off, int batch, hipStream_t st);

@@ -138,6 +138,34 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
     return max(v - minmax, maxmin - v) - 1;
 }
 
+// wave-aggregated append to an LDS list: returns this lane's slot (valid where pred)
+__device__ __forceinline__ int lds_append(bool pred, int *counter, int lane)
+{
+    const unsigned long long bal = __ballot(pred);
+    int base = 0;
+    if (bal) {
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(counter, __popcll(bal));
+        base = __shfl(base, leader);
+    }
+    return base + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// Phases per workgroup (one grid cell of one image):
+//   0. stage the cell + ring halo in LDS (32-bit loads), evaluated column 0 on a dword boundary
+//   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords;
+//      survivors are appended to an LDS list (wave-aggregated)            -> dense work from here
+//   2. exact score for the survivors; corners (S >= th) go to the score map and a second list
+//   3. NMS of the corners against the score map; kept ones to a third list
+//   4. empty after NMS and th == iniThFAST -> repeat 1-3 with minThFAST (:812-816)
+//   5. rank sort of the kept list by (row, col) = cv::FAST's emission order, write the cell's slots
 __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restrict__ pyr,
                                                          size_t pyr_stride,
                                                          const LevelDev *__restrict__ levels,
@@ -146,96 +174,124 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restri
                                                          int TP, int TH, int SP,
                                                          uint32_t *__restrict__ slots,
                                                          size_t slot_stride,
-                                                         int32_t *__restrict__ cell_cnt)
+                                                         int32_t *__restrict__ cell_cnt,
+                                                         int list_cap, int keep_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *tile = smem;                                  // TH x TP
-    uint8_t *smap = smem + ((TP * TH + 15) & ~15);         // (SH) x SP, 1-px zero border
-    __shared__ int wtot[4];
+    __shared__ int cnt[4];  // [0] survivors, [1] corners, [2] kept
+    const int tile_bytes = (TP * TH + 15) & ~15;
+    const int smap_bytes = (SP * (TH - 4) + 15) & ~15;  // (ch+2) rows
+    uint8_t *tile = smem;                                      // TH x TP
+    uint8_t *smap = smem + tile_bytes;                         // (ch+2) x SP, 1-px zero border
+    uint16_t *list1 = reinterpret_cast<uint16_t *>(smap + smap_bytes);   // survivors  (py<<6 | px)
+    uint16_t *list2 = list1 + list_cap;                                  // corners
+    uint32_t *list3 = reinterpret_cast<uint32_t *>(list2 + list_cap);    // kept: (py<<6|px)<<8 | score
 
     const int b = blockIdx.y;
     const CellDev cell = cells[blockIdx.x];
     const LevelDev lv = levels[cell.level];
     const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
     const int cw = cell.cw, ch = cell.ch;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nq = (cw + 3) >> 2;           // 4-pixel groups per row
+    const int ndw = nq + 2;                 // dwords staged per row: [halo | nq quads | halo]
 
-    // ---- stage tile: rows vy0-3 .. vy0+ch+2, cols vx0-3 .. vx0+cw+2 (always inside the level)
+    // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c
     {
-        const int tx0 = cell.vx0 - 3, ty0 = cell.vy0 - 3;
-        const int tw = cw + 6, th = ch + 6;
-        const int ax0 = tx0 & ~3;             // aligned start column in the plane
-        const int shift = tx0 - ax0;          // 0..3
-        const int ndw = (shift + tw + 3) >> 2; // dwords per row
-        // LDS rows hold the aligned dwords; tile origin is offset by `shift`
-        for (int i = tid; i < th * ndw; i += 256) {
+        const uint8_t *src = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);
+        const int th_rows = ch + 6;
+        for (int i = tid; i < th_rows * ndw; i += 256) {
             const int r = i / ndw, c = i - r * ndw;
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (size_t)(ty0 + r) * lv.pitch + ax0 + 4 * c);
-            *reinterpret_cast<uint32_t *>(tile + r * TP + 4 * c) = v;
+            *reinterpret_cast<uint32_t *>(tile + r * TP + 4 * c) = load_u32_unaligned(src + (size_t)r * lv.pitch + 4 * c);
         }
-        tile += shift;
     }
     const int SH = ch + 2;
-    const int rps = 64 / cw;                 // rows per wave step (cw <= 64)
-    const int lrow = lane / cw;
-    const int px = lane - lrow * cw;
-    const bool lane_ok = lrow < rps;
-    const int rows_per_step = 4 * rps;
-    const int n_steps = (ch + rows_per_step - 1) / rows_per_step;
     uint32_t *my_slots = slots + (size_t)b * slot_stride + cell.slot_off;
-
     int th = ini_th;
-    int total = 0;
+    int nkept = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        for (int i = tid; i < SH * SP; i += 256) smap[i] = 0;
+        for (int i = tid; i < (SH * SP + 3) >> 2; i += 256) reinterpret_cast<uint32_t *>(smap)[i] = 0;
+        if (tid < 3) cnt[tid] = 0;
         __syncthreads();
-        // ---- scores
-        for (int s = 0; s < n_steps; ++s) {
-            const int py = s * rows_per_step + wave * rps + lrow;
-            if (lane_ok && py < ch) {
-                const uint8_t *t = tile + (py + 3) * TP + px + 3;
-                const int v = t[0];
-                // necessary condition: a 9-arc contains >= 2 of the 4 compass pixels
-                const int c0 = t[3 * TP], c4 = t[3], c8 = t[-3 * TP], c12 = t[-3];
+        // ---- 1. compass pre-test (a 9-arc contains >= 2 of the 4 compass pixels)
+        for (int g = tid; g < nq * ch; g += 256) {
+            const int py = g / nq, qd = g - py * nq;
+            const uint8_t *row = tile + (py + 3) * TP + 4 + 4 * qd;
+            const uint32_t C = *reinterpret_cast<const uint32_t *>(row);
+            const uint32_t Wd = *reinterpret_cast<const uint32_t *>(row - 4);
+            const uint32_t Ed = *reinterpret_cast<const uint32_t *>(row + 4);
+            const uint32_t N = *reinterpret_cast<const uint32_t *>(row - 3 * TP);   // ring pixel 8 (dy=-3)
+            const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * TP);   // ring pixel 0 (dy=+3)
+            const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
+            const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
+            bool p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = (C >> (8 * k)) & 255;
+                const int c0 = (S >> (8 * k)) & 255, c4 = (Eq >> (8 * k)) & 255;
+                const int c8 = (N >> (8 * k)) & 255, c12 = (Wq >> (8 * k)) & 255;
                 const int hi = v + th, lo = v - th;
                 const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
                 const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
-                if (nb >= 2 || nd >= 2) {
-                    const int S = fast_score_full(t, TP);
-                    if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
-                }
+                p[k] = (nb >= 2 || nd >= 2) && (4 * qd + k < cw);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int slot = lds_append(p[k], &cnt[0], lane);
+                if (p[k]) list1[slot] = (uint16_t)((py << 6) | (4 * qd + k));
             }
         }
         __syncthreads();
-        // ---- NMS + ordered compaction (row-major inside the cell)
-        total = 0;
-        for (int s = 0; s < n_steps; ++s) {
-            const int py = s * rows_per_step + wave * rps + lrow;
-            int sc = 0;
+        // ---- 2. exact scores of the survivors
+        const int n1 = cnt[0];
+        for (int i0 = 0; i0 < n1; i0 += 256) {
+            const int i = i0 + tid;
+            bool corner = false;
+            int pos = 0, S = 0;
+            if (i < n1) {
+                pos = list1[i];
+                const int py = pos >> 6, px = pos & 63;
+                S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+                corner = S >= th;
+                if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+            }
+            const int slot = lds_append(corner, &cnt[1], lane);
+            if (corner) list2[slot] = (uint16_t)pos;
+        }
+        __syncthreads();
+        // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell)
+        const int n2 = cnt[1];
+        for (int i0 = 0; i0 < n2; i0 += 256) {
+            const int i = i0 + tid;
             bool keep = false;
-            if (lane_ok && py < ch) {
+            int pos = 0, sc = 0;
+            if (i < n2) {
+                pos = list2[i];
+                const int py = pos >> 6, px = pos & 63;
                 const uint8_t *m = smap + (py + 1) * SP + px + 1;
                 sc = m[0];
-                keep = sc > 0 && sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] &&
-                       sc > m[-SP + 1] && sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
+                keep = sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] && sc > m[-SP + 1] &&
+                       sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
             }
-            const unsigned long long bal = __ballot(keep);
-            if (lane == 0) wtot[wave] = __popcll(bal);
-            __syncthreads();
-            int base = total;
-            for (int w = 0; w < wave; ++w) base += wtot[w];
-            if (keep) {
-                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                const uint32_t xr = (uint32_t)(cell.vx0 - 16 + px), yr = (uint32_t)(cell.vy0 - 16 + py);
-                my_slots[pos] = xr | (yr << 12) | ((uint32_t)sc << 24);
-            }
-            total += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-            __syncthreads();
+            const int slot = lds_append(keep, &cnt[2], lane);
+            if (keep && slot < keep_cap) list3[slot] = ((uint32_t)pos << 8) | (uint32_t)sc;
         }
-        if (total > 0 || th == min_th) break;
+        __syncthreads();
+        nkept = cnt[2];
+        if (nkept > 0 || th == min_th) break;
         th = min_th;  // vKeysCell.empty() -> retry with minThFAST (:812-816)
+        __syncthreads();
     }
-    if (tid == 0) cell_cnt[(size_t)b * n_cells + blockIdx.x] = total;
+    // ---- 5. emission order: rank by position (keys are unique)
+    for (int i = tid; i < nkept; i += 256) {
+        const uint32_t key = list3[i];
+        int rank = 0;
+        for (int j = 0; j < nkept; ++j) rank += list3[j] < key;
+        const uint32_t pos = key >> 8;
+        const uint32_t xr = (uint32_t)(cell.vx0 - 16) + (pos & 63), yr = (uint32_t)(cell.vy0 - 16) + (pos >> 6);
+        my_slots[rank] = xr | (yr << 12) | ((key & 255u) << 24);
+    }
+    if (tid == 0) cell_cnt[(size_t)b * n_cells + blockIdx.x] = nkept;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -301,7 +357,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
                               int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
                               size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level)
 {
-    // one wave per job; candidate unpacking is wave-parallel, the tree itself runs on lane 0
+    // one wave per job: the tree/list control flow is wave-uniform, the key loops are wave-parallel
     const int job = blockIdx.x;
     const int lane = threadIdx.x;
     const int b = job / n_levels, l = job - b * n_levels;
@@ -323,7 +379,6 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
         sc[i] = (uint8_t)(c >> 24);
     }
     __syncthreads();
-    if (lane != 0) return;
     int nk = 0;
     if (n > 0) {
         OctScratch S;
@@ -335,10 +390,10 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
         S.max_nodes = scr.max_nodes;
         int32_t *idx = scr.out_idx + (size_t)job * cap_level;
         const LevelDev lv = levels[l];
-        nk = distribute_octree(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
-        for (int k = 0; k < nk; ++k) out[k] = cand[idx[k]];
+        nk = distribute_octree<WaveCoop>(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
+        for (int k = lane; k < nk; k += 64) out[k] = cand[idx[k]];
     }
-    sel_level_cnt[(size_t)b * n_levels + l] = nk;
+    if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = nk;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,12 +576,12 @@ void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const L
 }
 
 void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
-                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, uint32_t *slots,
-                 size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
+                 int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
+                 uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
 {
     dim3 blk(256), grd(n_cells, batch);
     hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, pyr, pyr_stride, levels, cells, n_cells, ini_th,
-                       min_th, TP, TH, SP, slots, slot_stride, cell_cnt);
+                       min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap);
 }
 
 void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,

@@ -54,7 +54,33 @@ struct OctScratch {
     int max_nodes;
 };
 
+// Execution policy of the O(n) inner loops (stable partitions, per-node maxima):
+//   SerialCoop -- one thread does everything (host threads; also what the CPU tests run)
+//   WaveCoop   -- device: all 64 lanes of ONE wave run the list/tree control flow redundantly on
+//                 wave-uniform data (same loads, same stores), and share the key loops through
+//                 ballots; the results are identical because a stable partition is unique.
+struct SerialCoop {
+    static constexpr bool kWave = false;
+};
+#if defined(__HIPCC__)
+struct WaveCoop {
+    static constexpr bool kWave = true;
+};
+#endif
+
 namespace octdetail {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int coop_lane() { return (int)(threadIdx.x & 63); }
+__device__ inline void coop_sync() { __syncthreads(); }  // single-wave workgroup: waitcnt + barrier
+__device__ inline unsigned long long coop_ballot(bool p) { return __ballot(p); }
+__device__ inline int coop_popc(unsigned long long m) { return __popcll(m); }
+#else
+inline int coop_lane() { return 0; }
+inline void coop_sync() {}
+inline unsigned long long coop_ballot(bool p) { return p ? 1ull : 0ull; }
+inline int coop_popc(unsigned long long m) { return __builtin_popcountll(m); }
+#endif
 
 struct List {
     OctNode *nodes;
@@ -101,6 +127,7 @@ AOS2_OCT_HD int erase(List &L, int id)
 
 // DivideNode: stable 4-way partition of the parent's segment; children c[0..3] = n1..n4
 // (UL, UR, BL, BR quadrants).  Returns false if the arena is exhausted.
+template <class Coop>
 AOS2_OCT_HD bool divide(List &L, int id, int c[4], const int16_t *xs, const int16_t *ys,
                         int32_t *perm, int32_t *tmp)
 {
@@ -112,26 +139,78 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], const int16_t *xs, const int1
         c[i] = new_node(L);
         if (c[i] < 0) return false;
     }
-    OctNode &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
-    n1.x0 = p.x0; n1.y0 = p.y0; n1.x1 = (int16_t)mx; n1.y1 = (int16_t)my;
-    n2.x0 = (int16_t)mx; n2.y0 = p.y0; n2.x1 = p.x1; n2.y1 = (int16_t)my;
-    n3.x0 = p.x0; n3.y0 = (int16_t)my; n3.x1 = (int16_t)mx; n3.y1 = p.y1;
-    n4.x0 = (int16_t)mx; n4.y0 = (int16_t)my; n4.x1 = p.x1; n4.y1 = p.y1;
+    {
+        OctNode &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
+        n1.x0 = p.x0; n1.y0 = p.y0; n1.x1 = (int16_t)mx; n1.y1 = (int16_t)my;
+        n2.x0 = (int16_t)mx; n2.y0 = p.y0; n2.x1 = p.x1; n2.y1 = (int16_t)my;
+        n3.x0 = p.x0; n3.y0 = (int16_t)my; n3.x1 = (int16_t)mx; n3.y1 = p.y1;
+        n4.x0 = (int16_t)mx; n4.y0 = (int16_t)my; n4.x1 = p.x1; n4.y1 = p.y1;
+    }
     int cnt[4] = {0, 0, 0, 0};
-    for (int i = 0; i < p.cnt; ++i) {
-        const int k = perm[p.beg + i];
-        const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
-        cnt[q]++;
-    }
     int off[4];
-    off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
-    int fill[4] = {off[0], off[1], off[2], off[3]};
-    for (int i = 0; i < p.cnt; ++i) {
-        const int k = perm[p.beg + i];
-        const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
-        tmp[fill[q]++] = k;
+    if (!Coop::kWave) {
+        for (int i = 0; i < p.cnt; ++i) {
+            const int k = perm[p.beg + i];
+            const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
+            cnt[q]++;
+        }
+        off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+        int fill[4] = {off[0], off[1], off[2], off[3]};
+        for (int i = 0; i < p.cnt; ++i) {
+            const int k = perm[p.beg + i];
+            const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
+            tmp[fill[q]++] = k;
+        }
+        for (int i = 0; i < p.cnt; ++i) perm[p.beg + i] = tmp[i];
+    } else {
+        const int lane = coop_lane();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (p.cnt <= 64) {
+            // whole segment in registers: read, barrier, scatter in place
+            const bool valid = lane < p.cnt;
+            const int k = valid ? perm[p.beg + lane] : 0;
+            const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+            const unsigned long long b0 = coop_ballot(q == 0), b1 = coop_ballot(q == 1);
+            const unsigned long long b2 = coop_ballot(q == 2), b3 = coop_ballot(q == 3);
+            cnt[0] = coop_popc(b0); cnt[1] = coop_popc(b1); cnt[2] = coop_popc(b2); cnt[3] = coop_popc(b3);
+            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+            coop_sync();
+            if (valid) {
+                const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                perm[p.beg + off[q] + coop_popc(bq & lt)] = k;
+            }
+            coop_sync();
+        } else {
+            for (int base = 0; base < p.cnt; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < p.cnt;
+                const int k = valid ? perm[p.beg + i] : 0;
+                const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+                cnt[0] += coop_popc(coop_ballot(q == 0));
+                cnt[1] += coop_popc(coop_ballot(q == 1));
+                cnt[2] += coop_popc(coop_ballot(q == 2));
+                cnt[3] += coop_popc(coop_ballot(q == 3));
+            }
+            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+            int run[4] = {off[0], off[1], off[2], off[3]};
+            for (int base = 0; base < p.cnt; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < p.cnt;
+                const int k = valid ? perm[p.beg + i] : 0;
+                const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+                const unsigned long long b0 = coop_ballot(q == 0), b1 = coop_ballot(q == 1);
+                const unsigned long long b2 = coop_ballot(q == 2), b3 = coop_ballot(q == 3);
+                if (valid) {
+                    const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+                    tmp[run[q] + coop_popc(bq & lt)] = k;
+                }
+                run[0] += coop_popc(b0); run[1] += coop_popc(b1); run[2] += coop_popc(b2); run[3] += coop_popc(b3);
+            }
+            coop_sync();
+            for (int i = lane; i < p.cnt; i += 64) perm[p.beg + i] = tmp[i];
+            coop_sync();
+        }
     }
-    for (int i = 0; i < p.cnt; ++i) perm[p.beg + i] = tmp[i];
     for (int q = 0; q < 4; ++q) {
         OctNode &n = L.nodes[c[q]];
         n.beg = p.beg + off[q];
@@ -179,6 +258,7 @@ AOS2_OCT_HD void pair_sort(int32_t *a, int n)
 // xs, ys, score: n candidates in the reference's emission order.  [minX,maxX) x [minY,maxY) is
 // the level's search box (16 .. w-16).  Writes the kept candidate indices in list order to
 // out_idx (capacity cap) and returns their number; <0 if scratch is exhausted / cap too small.
+template <class Coop = SerialCoop>
 AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const uint8_t *score, int n,
                                   int minX, int maxX, int minY, int maxY, int N, OctScratch &S,
                                   int32_t *out_idx, int cap)
@@ -211,12 +291,12 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
         r.y1 = (int16_t)(maxY - minY);
         push_back(L, id);
     }
-    for (int i = 0; i < n; ++i) {
-        int r = (int)((float)xs[i] / hX);
-        if (r >= nIni) r = nIni - 1;  // cannot happen for x < maxX-minX; guards the arena
-        L.nodes[r].cnt++;
-    }
-    {
+    if (!Coop::kWave) {
+        for (int i = 0; i < n; ++i) {
+            int r = (int)((float)xs[i] / hX);
+            if (r >= nIni) r = nIni - 1;  // cannot happen for x < maxX-minX; guards the arena
+            L.nodes[r].cnt++;
+        }
         int acc = 0;
         for (int i = 0; i < nIni; ++i) {
             L.nodes[i].beg = acc;
@@ -228,6 +308,29 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
             if (r >= nIni) r = nIni - 1;
             perm[L.nodes[r].beg + L.nodes[r].cnt++] = i;
         }
+    } else {
+        // stable bucketing by root, one ballot per root and 64-key chunk
+        const int lane = coop_lane();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int acc = 0;
+        for (int r = 0; r < nIni; ++r) {
+            int c = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                int rr = -1;
+                if (i < n) {
+                    rr = (int)((float)xs[i] / hX);
+                    if (rr >= nIni) rr = nIni - 1;
+                }
+                const unsigned long long bal = coop_ballot(rr == r);
+                if (rr == r) perm[acc + c + coop_popc(bal & lt)] = i;
+                c += coop_popc(bal);
+            }
+            L.nodes[r].beg = acc;
+            L.nodes[r].cnt = c;
+            acc += c;
+        }
+        coop_sync();
     }
     for (int lit = L.head; lit >= 0;) {
         OctNode &nd = L.nodes[lit];
@@ -253,7 +356,7 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 continue;
             }
             int c[4];
-            if (!divide(L, lit, c, xs, ys, perm, tmp)) return -2;
+            if (!divide<Coop>(L, lit, c, xs, ys, perm, tmp)) return -2;
             for (int q = 0; q < 4; ++q) {
                 const int cn = L.nodes[c[q]].cnt;
                 if (cn > 0) {
@@ -281,7 +384,7 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 for (int j = nprev - 1; j >= 0; --j) {
                     const int id = prv[2 * j + 1];
                     int c[4];
-                    if (!divide(L, id, c, xs, ys, perm, tmp)) return -2;
+                    if (!divide<Coop>(L, id, c, xs, ys, perm, tmp)) return -2;
                     for (int q = 0; q < 4; ++q) {
                         const int cn = L.nodes[c[q]].cnt;
                         if (cn > 0) {
@@ -302,19 +405,43 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
     }
     // best response per node, first wins ties :741-762
     int nout = 0;
-    for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
-        const OctNode &nd = L.nodes[lit];
-        int best = perm[nd.beg];
-        int maxResponse = score[best];
-        for (int k = 1; k < nd.cnt; ++k) {
-            const int idx = perm[nd.beg + k];
-            if (score[idx] > maxResponse) {
-                best = idx;
-                maxResponse = score[idx];
+    if (!Coop::kWave) {
+        for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
+            const OctNode &nd = L.nodes[lit];
+            int best = perm[nd.beg];
+            int maxResponse = score[best];
+            for (int k = 1; k < nd.cnt; ++k) {
+                const int idx = perm[nd.beg + k];
+                if (score[idx] > maxResponse) {
+                    best = idx;
+                    maxResponse = score[idx];
+                }
             }
+            if (nout >= cap) return -3;
+            out_idx[nout++] = best;
         }
-        if (nout >= cap) return -3;
-        out_idx[nout++] = best;
+    } else {
+        // list order -> array (uniform walk), then one lane per node
+        int32_t *order = S.pairs_a;  // free at this point
+        for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
+            if (nout >= cap) return -3;
+            order[nout++] = lit;
+        }
+        coop_sync();
+        for (int j = coop_lane(); j < nout; j += 64) {
+            const OctNode nd = L.nodes[order[j]];
+            int best = perm[nd.beg];
+            int maxResponse = score[best];
+            for (int k = 1; k < nd.cnt; ++k) {
+                const int idx = perm[nd.beg + k];
+                if (score[idx] > maxResponse) {
+                    best = idx;
+                    maxResponse = score[idx];
+                }
+            }
+            out_idx[j] = best;
+        }
+        coop_sync();
     }
     return nout;
 }
