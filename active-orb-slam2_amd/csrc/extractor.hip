@@ -89,6 +89,7 @@ struct aos2_extractor {
     int umax[16];
     int gauss7[7];
     int cap_level = 0, max_kp = 0;
+    unsigned long long umax_nibbles = 0;
     bool host_octree = false;
     int host_threads = 8;
     int max_cand = 16384;
@@ -175,6 +176,8 @@ static void build_host_tables(aos2_extractor *e)
     }
     e->cap_level = cl;
     e->max_kp = tot;
+    e->umax_nibbles = 0;
+    for (int v = 0; v < 16; ++v) e->umax_nibbles |= (unsigned long long)(e->umax[v] & 15) << (4 * v);
 }
 
 static short sat_short(float v)
@@ -478,7 +481,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
     }
     AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
     launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
-                    e->d_sel_cnt.p, d_kps, d_desc, cap, d_nout, batch, s);
+                    e->d_sel_cnt.p, d_kps, d_desc, cap, d_nout, batch, e->umax_nibbles, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
     AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p, e->d_sel_cnt.p, sizeof(int32_t) * L * batch, hipMemcpyDeviceToHost, s));
     AOS2_HIP_CHECK(hipMemcpyAsync(e->h_nout.p, d_nout, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
@@ -747,7 +750,7 @@ int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms)
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
     for (int i = 0; i < iters; ++i)
         launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
-                        e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, s);
+                        e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, e->umax_nibbles, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
     AOS2_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;

@@ -50,6 +50,7 @@ void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *le
                    int32_t *sel_level_cnt, int cap_level, hipStream_t st);
 void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
-                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, hipStream_t st);
+                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
+                     unsigned long long umax_nibbles, hipStream_t st);
 
 }  // namespace aos2

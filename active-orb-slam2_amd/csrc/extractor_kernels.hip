@@ -9,7 +9,7 @@
 
 namespace aos2 {
 
-__constant__ int8_t c_pattern[1024];   // rBRIEF test locations (src/ORBextractor.cc:150-408)
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024];   // rBRIEF test locations (src/ORBextractor.cc:150-408)
 __constant__ int c_umax[16];           // circular patch row extents (:454-470)
 __constant__ int c_gauss[8];           // 7-tap Gaussian, 8 fractional bits {18,34,49,55,49,34,18}
 
@@ -440,28 +440,29 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 constexpr int PR = 21;            // patch radius staged (18 sample reach + 3 blur taps)
-constexpr int PW = 2 * PR + 1;    // 43
-constexpr int PP = 44;            // LDS pitch of the u8 patch
+constexpr int PW = 2 * PR + 1;    // 43 rows / columns
+constexpr int PD = 12;            // LDS dwords per patch row (48 bytes, 44 used)
 constexpr int HR = 18;            // horizontal-blur tile radius in x
-constexpr int HW = 2 * HR + 1;    // 37
-constexpr int HP = 38;            // LDS pitch (u16) of the h-blur tile
-constexpr int KP_PER_BLOCK = 4;
+constexpr int HD = 20;            // LDS dwords per h-blur row (40 u16, 37 used)
+constexpr int HP = 2 * HD;        // u16 pitch of the h-blur tile
 
-__global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ pyr,
-                                                       size_t pyr_stride,
-                                                       const LevelDev *__restrict__ levels,
-                                                       int n_levels, const uint32_t *__restrict__ sel,
-                                                       size_t sel_stride, int cap_level,
-                                                       const int32_t *__restrict__ sel_level_cnt,
-                                                       aos2_keypoint_t *__restrict__ kps,
-                                                       uint8_t *__restrict__ desc, int cap,
-                                                       int32_t *__restrict__ n_out)
+// One wave (= one 64-thread workgroup) per keypoint.
+__global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict__ pyr,
+                                                      size_t pyr_stride,
+                                                      const LevelDev *__restrict__ levels,
+                                                      int n_levels, const uint32_t *__restrict__ sel,
+                                                      size_t sel_stride, int cap_level,
+                                                      const int32_t *__restrict__ sel_level_cnt,
+                                                      aos2_keypoint_t *__restrict__ kps,
+                                                      uint8_t *__restrict__ desc, int cap,
+                                                      int32_t *__restrict__ n_out,
+                                                      unsigned long long umax_nibbles)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch_s[KP_PER_BLOCK][PW * PP];
-    __shared__ __attribute__((aligned(16))) uint16_t hb_s[KP_PER_BLOCK][PW * HP];
+    __shared__ __attribute__((aligned(16))) uint32_t patch32[PW * PD];
+    __shared__ __attribute__((aligned(16))) uint32_t hb32[PW * HD];
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * KP_PER_BLOCK + wave;  // output slot in the image
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x;  // output slot in the image
     // locate level and index inside the level (levels are concatenated level-major, :1060-1104)
     const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
     int level = -1, kin = k, total = 0;
@@ -471,92 +472,113 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict
         if (level < 0) kin -= c;
         total += c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_out[b] = total;
-    const bool valid = level >= 0 && k < cap;
-    uint8_t *patch = patch_s[wave];
-    uint16_t *hb = hb_s[wave];
-    int kx = 0, ky = 0, score = 0;
-    LevelDev lv = levels[valid ? level : 0];
-    if (valid) {
-        const uint32_t c = sel[(size_t)b * sel_stride + (size_t)level * cap_level + kin];
-        kx = (int)(c & 0xfff) + 16;           // + minBorderX (:842)
-        ky = (int)((c >> 12) & 0xfff) + 16;
-        score = (int)(c >> 24);
-        const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    if (k == 0 && lane == 0) n_out[b] = total;
+    if (level < 0 || k >= cap) return;  // wave-uniform
+    const LevelDev lv = levels[level];
+    const uint32_t csel = sel[(size_t)b * sel_stride + (size_t)level * cap_level + kin];
+    const int kx = (int)(csel & 0xfff) + 16;           // + minBorderX (:842)
+    const int ky = (int)((csel >> 12) & 0xfff) + 16;
+    const int score = (int)(csel >> 24);
+    const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
+    // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
+    if (kx - PR >= 0 && kx + PR + 1 < lv.w && ky - PR >= 0 && ky + PR < lv.h) {
+        const uint8_t *src = plane + (size_t)(ky - PR) * lv.pitch + (kx - PR);
+        for (int i = lane; i < PW * 11; i += 64) {
+            const int r = i / 11, c = i - r * 11;
+            patch32[r * PD + c] = load_u32_unaligned(src + (size_t)r * lv.pitch + 4 * c);
+        }
+    } else {
         for (int i = lane; i < PW * PW; i += 64) {
             const int r = i / PW, cc = i - r * PW;
             const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + cc, lv.w);
-            patch[r * PP + cc] = plane[(size_t)yy * lv.pitch + xx];
+            patch[r * (4 * PD) + cc] = plane[(size_t)yy * lv.pitch + xx];
         }
     }
     __syncthreads();
-    float angle = 0.f;
-    if (valid) {
-        // ---- IC_Angle
-        int m10 = 0, m01 = 0;
-        for (int i = lane; i < 31 * 31; i += 64) {
-            const int r = i / 31, cc = i - r * 31;
-            const int v = r - 15, u = cc - 15;
-            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-            if (au <= c_umax[av]) {
-                const int I = patch[(PR + v) * PP + PR + u];
-                m10 += u * I;
-                m01 += v * I;
-            }
-        }
+    // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 9; i += 64) {
+        const int vr = i / 9, dj = i - vr * 9 + 1;     // patch dwords 1..9 cover columns 4..39
+        const int v = vr - 15;
+        const int av = v < 0 ? -v : v;
+        const int um = (int)((umax_nibbles >> (4 * av)) & 15ull);
+        const uint32_t d = patch32[(PR + v) * PD + dj];
+        int rowsum = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m10 += __shfl_xor(m10, d);
-            m01 += __shfl_xor(m01, d);
+        for (int kk = 0; kk < 4; ++kk) {
+            const int u = 4 * dj + kk - PR;
+            const int au = u < 0 ? -u : u;
+            const int I = au <= um ? (int)((d >> (8 * kk)) & 255u) : 0;
+            m10 += u * I;
+            rowsum += I;
         }
-        angle = fast_atan2_deg((float)m01, (float)m10);
-        // ---- horizontal blur pass
-        for (int i = lane; i < PW * HW; i += 64) {
-            const int r = i / HW, cc = i - r * HW;
-            const uint8_t *p = patch + r * PP + (PR - HR) + cc;  // centre column
-            const int s = c_gauss[0] * (p[-3] + p[3]) + c_gauss[1] * (p[-2] + p[2]) +
-                          c_gauss[2] * (p[-1] + p[1]) + c_gauss[3] * p[0];
-            hb[r * HP + cc] = (uint16_t)s;
+        m01 += v * rowsum;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d);
+        m01 += __shfl_xor(m01, d);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ---- horizontal 7-tap pass: output column cc (0..36) <-> patch column cc+3; 4 outputs per item
+    {
+        const uint32_t W0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
+        const uint32_t W1 = (uint32_t)c_gauss[4] | ((uint32_t)c_gauss[5] << 8) | ((uint32_t)c_gauss[6] << 16);
+        for (int i = lane; i < PW * 10; i += 64) {
+            const int r = i / 10, j = i - r * 10;
+            const uint32_t D0 = patch32[r * PD + j], D1 = patch32[r * PD + j + 1], D2 = patch32[r * PD + j + 2];
+            uint32_t o[4];
+            o[0] = __builtin_amdgcn_udot4(D0, W0, __builtin_amdgcn_udot4(D1, W1, 0u, false), false);
+            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), W0,
+                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), W1, 0u, false), false);
+            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), W0,
+                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), W1, 0u, false), false);
+            o[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), W0,
+                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), W1, 0u, false), false);
+            hb32[r * HD + 2 * j] = o[0] | (o[1] << 16);       // each <= 255*257 = 65535
+            hb32[r * HD + 2 * j + 1] = o[2] | (o[3] << 16);
         }
     }
     __syncthreads();
-    if (valid) {
-        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-        const float ang = __fmul_rn(angle, factorPI);
-        float a, bb;
-        sincos_exact(ang, &bb, &a);
-        unsigned long long words[4];
+    // ---- steered rBRIEF: vertical 7-tap on demand at the 512 rotated sample positions
+    const uint16_t *hb = reinterpret_cast<const uint16_t *>(hb32);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = __fmul_rn(angle, factorPI);
+    float a, bb;
+    sincos_exact(ang, &bb, &a);
+    const int g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+    unsigned long long words[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pair = r * 64 + lane;
-            int val[2];
+    for (int r = 0; r < 4; ++r) {
+        const int pair = r * 64 + lane;
+        const uint32_t pat = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * pair]);
+        int val[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float px = (float)c_pattern[4 * pair + 2 * q], py = (float)c_pattern[4 * pair + 2 * q + 1];
-                const int iy = __float2int_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)));
-                const int ix = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)));
-                const uint16_t *h = hb + (PR + iy) * HP + HR + ix;
-                const int s = c_gauss[0] * (h[-3 * HP] + h[3 * HP]) + c_gauss[1] * (h[-2 * HP] + h[2 * HP]) +
-                              c_gauss[2] * (h[-HP] + h[HP]) + c_gauss[3] * h[0];
-                int v = (s + (1 << 15)) >> 16;
-                val[q] = v > 255 ? 255 : v;
-            }
-            words[r] = __ballot(val[0] < val[1]);
+        for (int q = 0; q < 2; ++q) {
+            const float px = (float)(int8_t)(pat >> (16 * q)), py = (float)(int8_t)(pat >> (16 * q + 8));
+            const int iy = __float2int_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)));
+            const int ix = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)));
+            const uint16_t *h = hb + (PR + iy) * HP + HR + ix;
+            const int s = g0 * (h[-3 * HP] + h[3 * HP]) + g1 * (h[-2 * HP] + h[2 * HP]) + g2 * (h[-HP] + h[HP]) + g3 * h[0];
+            const int v = (s + (1 << 15)) >> 16;
+            val[q] = v > 255 ? 255 : v;
         }
-        if (lane == 0) {
-            unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
-            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
-            aos2_keypoint_t kp;
-            const float scale = lv.scale;
-            kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
-            kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
-            kp.size = (float)lv.scaled_patch;
-            kp.angle = angle;
-            kp.response = (float)score;
-            kp.octave = level;
-            kp.class_id = -1;
-            kps[(size_t)b * cap + k] = kp;
-        }
+        words[r] = __ballot(val[0] < val[1]);
+    }
+    if (lane == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
+        d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+        aos2_keypoint_t kp;
+        const float scale = lv.scale;
+        kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
+        kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
+        kp.size = (float)lv.scaled_patch;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[(size_t)b * cap + k] = kp;
     }
 }
 
@@ -603,11 +625,12 @@ void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *le
 
 void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
-                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, hipStream_t st)
+                     aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
+                     unsigned long long umax_nibbles, hipStream_t st)
 {
-    dim3 blk(256), grd((cap + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch);
+    dim3 blk(64), grd(cap, batch);
     hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
-                       cap_level, sel_level_cnt, kps, desc, cap, n_out);
+                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles);
 }
 
 }  // namespace aos2
