@@ -100,6 +100,9 @@ struct aos2_extractor {
     Plan plan;
     int batch_cap = 0;
     int last_batch = 0;
+    const uint8_t *img0 = nullptr;  // level 0 of the last batch = the caller's (device) images
+    size_t img0_stride = 0;
+    int pitch0 = 0;
     DevBuf<uint8_t> d_pyr, d_in, d_desc;
     DevBuf<uint32_t> d_slots, d_dense, d_sel;
     DevBuf<int32_t> d_cell_cnt, d_level_off, d_sel_cnt, d_nout;
@@ -209,6 +212,15 @@ static void resize_tables(int sw, int sh, int dw, int dh, std::vector<int> &xofs
         const short b0 = sat_short((1.f - fy) * 2048), b1 = sat_short(fy * 2048);
         yofs.push_back(sy);
         yab.push_back((int)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16)));
+    }
+    // the kernel reads x tables as int4: pad every level's table to a multiple of 4 entries
+    while (xofs.size() % 4) {
+        xofs.push_back(xofs.back());
+        xab.push_back(xab.back());
+    }
+    while (yofs.size() % 4) {
+        yofs.push_back(yofs.back());
+        yab.push_back(yab.back());
     }
 }
 
@@ -460,13 +472,19 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
     const int L = e->nlevels;
     hipStream_t s = e->stream;
     AOS2_HIP_CHECK(hipEventRecord(e->ev[0], s));
-    launch_copy_level0(d_imgs, w, h, stride, image_stride, e->d_pyr.p, P.pyr_bytes, P.levels[0].pitch, batch, s);
-    for (int l = 1; l < L; ++l)
-        launch_resize(e->d_pyr.p, P.pyr_bytes, P.levels[l - 1], P.levels[l], P.d_xofs.p, P.d_xab.p, P.d_yofs.p,
-                      P.d_yab.p, batch, s);
+    // level 0 is the caller's image (no copy); levels >= 1 live in the pyramid block
+    e->img0 = d_imgs;
+    e->img0_stride = image_stride;
+    e->pitch0 = stride;
+    for (int l = 1; l < L; ++l) {
+        const bool from0 = (l == 1);
+        launch_resize(from0 ? d_imgs : e->d_pyr.p + P.levels[l - 1].off, from0 ? image_stride : P.pyr_bytes,
+                      from0 ? stride : P.levels[l - 1].pitch, e->d_pyr.p, P.pyr_bytes, P.levels[l - 1], P.levels[l],
+                      P.d_xofs.p, P.d_xab.p, P.d_yofs.p, P.d_yab.p, batch, s);
+    }
     AOS2_HIP_CHECK(hipEventRecord(e->ev[1], s));
-    launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
-                P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, batch, s);
+    launch_fast(e->img0, e->img0_stride, e->pitch0, e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p,
+                (int)P.cells.size(), e->iniTh, e->minTh, P.TP, P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, batch, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[2], s));
     launch_compact(P.d_cells.p, (int)P.cells.size(), L, P.d_level_cell_begin.p, e->d_slots.p, P.slot_total,
                    e->d_cell_cnt.p, e->d_dense.p, P.slot_total, e->d_level_off.p, batch, s);
@@ -480,7 +498,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
                       (size_t)L * e->cap_level, e->d_sel_cnt.p, e->cap_level, s);
     }
     AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
-    launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
+    launch_describe(e->img0, e->img0_stride, e->pitch0, e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
                     e->d_sel_cnt.p, d_kps, d_desc, cap, d_nout, batch, e->umax_nibbles, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
     AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p, e->d_sel_cnt.p, sizeof(int32_t) * L * batch, hipMemcpyDeviceToHost, s));
@@ -531,6 +549,10 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     if (nfeatures <= 0 || nlevels < 1 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || ini_th_fast < 1 ||
         min_th_fast < 1 || min_th_fast > ini_th_fast || ini_th_fast > 255) {
         set_error("bad extractor parameters");
+        return AOS2_ERR_ARG;
+    }
+    if (scale_factor > 2.0f) {  // the resize kernel stages <= 2.5x source windows in LDS
+        set_error("scale factor %.3f > 2.0 is not supported", scale_factor);
         return AOS2_ERR_ARG;
     }
     aos2_extractor *e = new aos2_extractor();
@@ -658,8 +680,11 @@ int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int 
     const LevelDev &L = e->plan.levels[level];
     if (dst_stride < L.w + 2 * border) return AOS2_ERR_ARG;
     uint8_t *interior = dst + (size_t)border * dst_stride + border;
-    AOS2_HIP_CHECK(hipMemcpy2DAsync(interior, (size_t)dst_stride, e->d_pyr.p + (size_t)image * e->plan.pyr_bytes + L.off,
-                                    (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost, e->stream));
+    const uint8_t *srcp = level == 0 ? e->img0 + (size_t)image * e->img0_stride
+                                     : e->d_pyr.p + (size_t)image * e->plan.pyr_bytes + L.off;
+    const size_t srcpitch = level == 0 ? (size_t)e->pitch0 : (size_t)L.pitch;
+    AOS2_HIP_CHECK(hipMemcpy2DAsync(interior, (size_t)dst_stride, srcp, srcpitch, (size_t)L.w, (size_t)L.h,
+                                    hipMemcpyDeviceToHost, e->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
     if (border > 0) {  // cv::copyMakeBorder(BORDER_REFLECT_101), :1122-1128
         auto refl = [](int p, int n) {
@@ -725,8 +750,8 @@ int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms)
     hipStream_t s = e->stream;
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
     for (int i = 0; i < iters; ++i)
-        launch_fast(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p, (int)P.cells.size(), e->iniTh, e->minTh, P.TP,
-                    P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, e->last_batch, s);
+        launch_fast(e->img0, e->img0_stride, e->pitch0, e->d_pyr.p, P.pyr_bytes, P.d_levels.p, P.d_cells.p,
+                    (int)P.cells.size(), e->iniTh, e->minTh, P.TP, P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, e->d_slots.p, P.slot_total, e->d_cell_cnt.p, e->last_batch, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
     AOS2_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;
@@ -749,7 +774,7 @@ int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms)
     const int cap = e->out_cap;
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
     for (int i = 0; i < iters; ++i)
-        launch_describe(e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
+        launch_describe(e->img0, e->img0_stride, e->pitch0, e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
                         e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, e->umax_nibbles, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
     AOS2_HIP_CHECK(hipStreamSynchronize(s));

@@ -37,9 +37,11 @@ struct OctDevScratch {
 int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st);
 void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t simg_stride, uint8_t *pyr,
                         size_t pyr_stride, int dpitch, int batch, hipStream_t st);
-void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const LevelDev &dst, const int *xofs,
-                   const int *xab, const int *yofs, const int *yab, int batch, hipStream_t st);
-void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
+void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
+                   const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
+                   const int *yab, int batch, hipStream_t st);
+void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                 const LevelDev *levels, const CellDev *cells, int n_cells,
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
                  uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st);
 void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,
@@ -48,7 +50,8 @@ void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *
 void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
                    int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                    int32_t *sel_level_cnt, int cap_level, hipStream_t st);
-void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
+void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                     const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, hipStream_t st);

@@ -24,6 +24,13 @@ int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, 
     return (int)e;
 }
 
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Level 0: copy the caller's image (arbitrary stride) into the pitched pyramid plane.
 // (ComputePyramid, src/ORBextractor.cc:1107-1132; the 19-px REFLECT_101 frame the reference keeps
@@ -55,32 +62,59 @@ __global__ void copy_level0_kernel(const uint8_t *__restrict__ src, int w, int h
 // resize() does (float fx, two separately rounded shorts), so host and device cannot disagree.
 // One thread = 4 horizontally adjacent output pixels (one aligned 32-bit store).
 // ---------------------------------------------------------------------------------------------
-__global__ void resize_level_kernel(uint8_t *__restrict__ pyr, size_t pyr_stride, LevelDev src,
-                                    LevelDev dst, const int *__restrict__ xofs,
-                                    const int *__restrict__ xab, const int *__restrict__ yofs,
-                                    const int *__restrict__ yab)
+constexpr int RS_ROWS = 12;     // max source rows per 4-row output tile (scale <= 2.5)
+constexpr int RS_PITCH = 672;   // max staged source bytes per row (256 outputs * scale 2.5 + slack)
+
+__global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__restrict__ src_base,
+                                                           size_t src_img_stride, int src_pitch,
+                                                           uint8_t *__restrict__ pyr, size_t pyr_stride,
+                                                           LevelDev src, LevelDev dst,
+                                                           const int *__restrict__ xofs,
+                                                           const int *__restrict__ xab,
+                                                           const int *__restrict__ yofs,
+                                                           const int *__restrict__ yab)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[RS_ROWS * RS_PITCH];
     const int b = blockIdx.z;
-    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
-    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (dy >= dst.h || dx0 >= dst.w) return;
-    const uint8_t *sp = pyr + (size_t)b * pyr_stride + src.off;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int dy0 = blockIdx.y * 4, dxb = blockIdx.x * 256;
+    const int dy = dy0 + threadIdx.y;
+    const int dx0 = dxb + threadIdx.x * 4;
+    const uint8_t *sp = src_base + (size_t)b * src_img_stride;
     uint8_t *dp = pyr + (size_t)b * pyr_stride + dst.off;
+    // source window of this output tile
+    const int dx_last = min(dxb + 255, dst.w - 1), dy_last = min(dy0 + 3, dst.h - 1);
+    const int sx_min = xofs[dst.tab_x + dxb] & ~3;
+    const int sx_max = min(xofs[dst.tab_x + dx_last] + 1, src.w - 1);
+    const int sy_min = min(max(yofs[dst.tab_y + dy0], 0), src.h - 1);
+    const int sy_max = min(max(yofs[dst.tab_y + dy_last] + 1, 0), src.h - 1);
+    const int ndw = (sx_max - sx_min + 4) >> 2;
+    const int nrow = sy_max - sy_min + 1;
+    for (int i = tid; i < nrow * ndw; i += 256) {
+        const int r = i / ndw, c = i - r * ndw;
+        *reinterpret_cast<uint32_t *>(tile + r * RS_PITCH + 4 * c) =
+            load_u32_unaligned(sp + (size_t)(sy_min + r) * src_pitch + sx_min + 4 * c);
+    }
+    __syncthreads();
+    if (dy >= dst.h || dx0 >= dst.w) return;
     int sy0 = yofs[dst.tab_y + dy], sy1 = sy0 + 1;
-    sy0 = min(max(sy0, 0), src.h - 1);
-    sy1 = min(max(sy1, 0), src.h - 1);
+    sy0 = min(max(sy0, 0), src.h - 1) - sy_min;
+    sy1 = min(max(sy1, 0), src.h - 1) - sy_min;
     const int bb = yab[dst.tab_y + dy];
     const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)(bb >> 16);
-    const uint8_t *S0 = sp + (size_t)sy0 * src.pitch, *S1 = sp + (size_t)sy1 * src.pitch;
+    const uint8_t *S0 = tile + sy0 * RS_PITCH - sx_min, *S1 = tile + sy1 * RS_PITCH - sx_min;
+    const int4 xo = *reinterpret_cast<const int4 *>(xofs + dst.tab_x + dx0);   // tables are padded to x4
+    const int4 xa = *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0);
+    const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
+    const int aas[4] = {xa.x, xa.y, xa.z, xa.w};
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int dx = dx0 + k;
         if (dx < dst.w) {
-            const int sx = xofs[dst.tab_x + dx];
+            const int sx = sxs[k];
             const int sx1 = sx + 1 < src.w ? sx + 1 : sx;
-            const int aa = xab[dst.tab_x + dx];
-            const int a0 = (int)(short)(aa & 0xffff), a1 = (int)(short)(aa >> 16);
+            const int a0 = (int)(short)(aas[k] & 0xffff), a1 = (int)(short)(aas[k] >> 16);
             const int r0 = S0[sx] * a0 + S0[sx1] * a1;
             const int r1 = S1[sx] * a0 + S1[sx1] * a1;
             int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
@@ -151,13 +185,6 @@ __device__ __forceinline__ int lds_append(bool pred, int *counter, int lane)
     return base + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
-__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
-{
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-
 // Phases per workgroup (one grid cell of one image):
 //   0. stage the cell + ring halo in LDS (32-bit loads), evaluated column 0 on a dword boundary
 //   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords;
@@ -166,7 +193,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 //   3. NMS of the corners against the score map; kept ones to a third list
 //   4. empty after NMS and th == iniThFAST -> repeat 1-3 with minThFAST (:812-816)
 //   5. rank sort of the kept list by (row, col) = cv::FAST's emission order, write the cell's slots
-__global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restrict__ pyr,
+__global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restrict__ img0,
+                                                         size_t img0_stride, int pitch0,
+                                                         const uint8_t *__restrict__ pyr,
                                                          size_t pyr_stride,
                                                          const LevelDev *__restrict__ levels,
                                                          const CellDev *__restrict__ cells,
@@ -189,8 +218,12 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restri
 
     const int b = blockIdx.y;
     const CellDev cell = cells[blockIdx.x];
-    const LevelDev lv = levels[cell.level];
+    LevelDev lv = levels[cell.level];
     const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    if (cell.level == 0) {  // level 0 is the caller's image itself (no copy)
+        plane = img0 + (size_t)b * img0_stride;
+        lv.pitch = pitch0;
+    }
     const int cw = cell.cw, ch = cell.ch;
     const int tid = threadIdx.x, lane = tid & 63;
     const int nq = (cw + 3) >> 2;           // 4-pixel groups per row
@@ -447,7 +480,9 @@ constexpr int HD = 20;            // LDS dwords per h-blur row (40 u16, 37 used)
 constexpr int HP = 2 * HD;        // u16 pitch of the h-blur tile
 
 // One wave (= one 64-thread workgroup) per keypoint.
-__global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict__ pyr,
+__global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict__ img0,
+                                                      size_t img0_stride, int pitch0,
+                                                      const uint8_t *__restrict__ pyr,
                                                       size_t pyr_stride,
                                                       const LevelDev *__restrict__ levels,
                                                       int n_levels, const uint32_t *__restrict__ sel,
@@ -474,12 +509,16 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
     }
     if (k == 0 && lane == 0) n_out[b] = total;
     if (level < 0 || k >= cap) return;  // wave-uniform
-    const LevelDev lv = levels[level];
+    LevelDev lv = levels[level];
     const uint32_t csel = sel[(size_t)b * sel_stride + (size_t)level * cap_level + kin];
     const int kx = (int)(csel & 0xfff) + 16;           // + minBorderX (:842)
     const int ky = (int)((csel >> 12) & 0xfff) + 16;
     const int score = (int)(csel >> 24);
     const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    if (level == 0) {
+        plane = img0 + (size_t)b * img0_stride;
+        lv.pitch = pitch0;
+    }
     uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
     // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
     if (kx - PR >= 0 && kx + PR + 1 < lv.w && ky - PR >= 0 && ky + PR < lv.h) {
@@ -590,19 +629,22 @@ void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t 
     hipLaunchKernelGGL(copy_level0_kernel, grd, blk, 0, st, d_src, w, h, sstride, simg_stride, pyr, pyr_stride, dpitch);
 }
 
-void launch_resize(uint8_t *pyr, size_t pyr_stride, const LevelDev &src, const LevelDev &dst, const int *xofs,
-                   const int *xab, const int *yofs, const int *yab, int batch, hipStream_t st)
+void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
+                   const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
+                   const int *yab, int batch, hipStream_t st)
 {
     dim3 blk(64, 4), grd((dst.w + 255) / 256, (dst.h + 3) / 4, batch);
-    hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, pyr, pyr_stride, src, dst, xofs, xab, yofs, yab);
+    hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
+                       dst, xofs, xab, yofs, yab);
 }
 
-void launch_fast(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, const CellDev *cells, int n_cells,
+void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                 const LevelDev *levels, const CellDev *cells, int n_cells,
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
                  uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
 {
     dim3 blk(256), grd(n_cells, batch);
-    hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, pyr, pyr_stride, levels, cells, n_cells, ini_th,
+    hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, cells, n_cells, ini_th,
                        min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap);
 }
 
@@ -623,13 +665,14 @@ void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *le
                        levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level);
 }
 
-void launch_describe(const uint8_t *pyr, size_t pyr_stride, const LevelDev *levels, int n_levels,
+void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                     const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, hipStream_t st)
 {
     dim3 blk(64), grd(cap, batch);
-    hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
+    hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
                        cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles);
 }
 
