@@ -291,6 +291,11 @@ static int build_plan(aos2_extractor *e, int w, int h)
                     return AOS2_ERR_ARG;
                 }
                 c.slot_off = (int32_t)slot;
+                {
+                    const uint32_t nq = (uint32_t)(c.cw + 3) / 4;
+                    c.inv_nq = 65536u / nq + 1;
+                    c.inv_ndw = 65536u / (nq + 2) + 1;
+                }
                 slot += (size_t)((c.cw + 1) / 2) * ((c.ch + 1) / 2);
                 P.max_cw = std::max<int>(P.max_cw, c.cw);
                 P.max_ch = std::max<int>(P.max_ch, c.ch);
@@ -307,7 +312,7 @@ static int build_plan(aos2_extractor *e, int w, int h)
     P.list_cap = (P.max_cw * P.max_ch + 7) & ~7;                       // every pixel may survive the pre-test
     P.keep_cap = ((P.max_cw + 1) / 2) * ((P.max_ch + 1) / 2);          // NMS survivors are >= 2 px apart
     P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (((size_t)P.SP * (P.TH - 4) + 15) & ~(size_t)15) +
-                 (size_t)P.list_cap * 2 * 2 + (size_t)P.keep_cap * 4 + 16;
+                 (size_t)P.list_cap * 2 + (size_t)P.keep_cap * 4 + 16;
     // upload
     int st;
     if ((st = P.d_levels.alloc(P.levels.size()))) return st;

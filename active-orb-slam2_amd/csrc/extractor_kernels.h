@@ -24,6 +24,8 @@ struct CellDev {
     int16_t cw, ch;       // evaluated columns / rows
     int16_t pad;
     int32_t slot_off;     // offset of the cell's candidate slots inside one image's slot block
+    uint32_t inv_ndw;     // 65536 / (quads per row + 2) + 1: exact i / ndw for i < 4096 by mul-shift
+    uint32_t inv_nq;      // 65536 / quads per row + 1
 };
 
 struct OctDevScratch {

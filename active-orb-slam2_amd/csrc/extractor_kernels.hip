@@ -172,49 +172,54 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
     return max(v - minmax, maxmin - v) - 1;
 }
 
-// wave-aggregated append to an LDS list: returns this lane's slot (valid where pred)
-__device__ __forceinline__ int lds_append(bool pred, int *counter, int lane)
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2_t as_us2(uint32_t x) { return __builtin_bit_cast(us2_t, x); }
+__device__ __forceinline__ uint32_t as_u32(us2_t x) { return __builtin_bit_cast(uint32_t, x); }
+
+// compass pre-test on two pixels at once (packed u16 lanes): non-zero lane <=> at least two of the
+// four compass pixels are brighter than v+t, or at least two are darker than v-t
+// (= the second largest exceeds v+t, or the second smallest is below v-t)
+__device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c, us2_t d, us2_t T)
 {
-    const unsigned long long bal = __ballot(pred);
-    int base = 0;
-    if (bal) {
-        const int leader = __ffsll((long long)bal) - 1;
-        if (lane == leader) base = atomicAdd(counter, __popcll(bal));
-        base = __shfl(base, leader);
-    }
-    return base + __popcll(bal & ((1ull << lane) - 1ull));
+    const us2_t h1 = __builtin_elementwise_max(a, b), l1 = __builtin_elementwise_min(a, b);
+    const us2_t h2 = __builtin_elementwise_max(c, d), l2 = __builtin_elementwise_min(c, d);
+    const us2_t m1 = __builtin_elementwise_min(h1, h2), m2 = __builtin_elementwise_max(l1, l2);
+    const us2_t sec_hi = __builtin_elementwise_max(m1, m2);   // second largest of a,b,c,d
+    const us2_t sec_lo = __builtin_elementwise_min(m1, m2);   // second smallest
+    const us2_t bright = __builtin_elementwise_sub_sat(sec_hi, (us2_t)(v + T));
+    const us2_t dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, T), sec_lo);
+    return as_u32(bright) | as_u32(dark);
 }
 
-// Phases per workgroup (one grid cell of one image):
+// Phases per wave (one grid cell of one image, 64-thread workgroup = one wave, so list counters are
+// wave-uniform registers and no LDS atomics or multi-wave barriers are needed):
 //   0. stage the cell + ring halo in LDS (32-bit loads), evaluated column 0 on a dword boundary
-//   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords;
-//      survivors are appended to an LDS list (wave-aggregated)            -> dense work from here
-//   2. exact score for the survivors; corners (S >= th) go to the score map and a second list
-//   3. NMS of the corners against the score map; kept ones to a third list
+//   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords,
+//      two pixels per packed-u16 op; survivors are ballot-compacted into an LDS list
+//   2. exact score for the survivors (dense lanes); corners (S >= th) go to the score map
+//   3. NMS of the corners against the score map; kept ones to a second list
 //   4. empty after NMS and th == iniThFAST -> repeat 1-3 with minThFAST (:812-816)
 //   5. rank sort of the kept list by (row, col) = cv::FAST's emission order, write the cell's slots
-__global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restrict__ img0,
-                                                         size_t img0_stride, int pitch0,
-                                                         const uint8_t *__restrict__ pyr,
-                                                         size_t pyr_stride,
-                                                         const LevelDev *__restrict__ levels,
-                                                         const CellDev *__restrict__ cells,
-                                                         int n_cells, int ini_th, int min_th,
-                                                         int TP, int TH, int SP,
-                                                         uint32_t *__restrict__ slots,
-                                                         size_t slot_stride,
-                                                         int32_t *__restrict__ cell_cnt,
-                                                         int list_cap, int keep_cap)
+__global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restrict__ img0,
+                                                        size_t img0_stride, int pitch0,
+                                                        const uint8_t *__restrict__ pyr,
+                                                        size_t pyr_stride,
+                                                        const LevelDev *__restrict__ levels,
+                                                        const CellDev *__restrict__ cells,
+                                                        int n_cells, int ini_th, int min_th,
+                                                        int TP, int TH, int SP,
+                                                        uint32_t *__restrict__ slots,
+                                                        size_t slot_stride,
+                                                        int32_t *__restrict__ cell_cnt,
+                                                        int list_cap, int keep_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int cnt[4];  // [0] survivors, [1] corners, [2] kept
     const int tile_bytes = (TP * TH + 15) & ~15;
     const int smap_bytes = (SP * (TH - 4) + 15) & ~15;  // (ch+2) rows
     uint8_t *tile = smem;                                      // TH x TP
     uint8_t *smap = smem + tile_bytes;                         // (ch+2) x SP, 1-px zero border
     uint16_t *list1 = reinterpret_cast<uint16_t *>(smap + smap_bytes);   // survivors  (py<<6 | px)
-    uint16_t *list2 = list1 + list_cap;                                  // corners
-    uint32_t *list3 = reinterpret_cast<uint32_t *>(list2 + list_cap);    // kept: (py<<6|px)<<8 | score
+    uint32_t *list3 = reinterpret_cast<uint32_t *>(list1 + list_cap);    // kept: (py<<6|px)<<8 | score
 
     const int b = blockIdx.y;
     const CellDev cell = cells[blockIdx.x];
@@ -225,16 +230,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restri
         lv.pitch = pitch0;
     }
     const int cw = cell.cw, ch = cell.ch;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int nq = (cw + 3) >> 2;           // 4-pixel groups per row
     const int ndw = nq + 2;                 // dwords staged per row: [halo | nq quads | halo]
 
     // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c
     {
         const uint8_t *src = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);
-        const int th_rows = ch + 6;
-        for (int i = tid; i < th_rows * ndw; i += 256) {
-            const int r = i / ndw, c = i - r * ndw;
+        const int total = (ch + 6) * ndw;
+        for (int i = lane; i < total; i += 64) {
+            const int r = (int)(((uint32_t)i * cell.inv_ndw) >> 16), c = i - r * ndw;
             *reinterpret_cast<uint32_t *>(tile + r * TP + 4 * c) = load_u32_unaligned(src + (size_t)r * lv.pitch + 4 * c);
         }
     }
@@ -243,80 +249,82 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restri
     int th = ini_th;
     int nkept = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        for (int i = tid; i < (SH * SP + 3) >> 2; i += 256) reinterpret_cast<uint32_t *>(smap)[i] = 0;
-        if (tid < 3) cnt[tid] = 0;
+        for (int i = lane; i < (SH * SP + 3) >> 2; i += 64) reinterpret_cast<uint32_t *>(smap)[i] = 0;
         __syncthreads();
         // ---- 1. compass pre-test (a 9-arc contains >= 2 of the 4 compass pixels)
-        for (int g = tid; g < nq * ch; g += 256) {
-            const int py = g / nq, qd = g - py * nq;
-            const uint8_t *row = tile + (py + 3) * TP + 4 + 4 * qd;
-            const uint32_t C = *reinterpret_cast<const uint32_t *>(row);
-            const uint32_t Wd = *reinterpret_cast<const uint32_t *>(row - 4);
-            const uint32_t Ed = *reinterpret_cast<const uint32_t *>(row + 4);
-            const uint32_t N = *reinterpret_cast<const uint32_t *>(row - 3 * TP);   // ring pixel 8 (dy=-3)
-            const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * TP);   // ring pixel 0 (dy=+3)
-            const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
-            const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
-            bool p[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int v = (C >> (8 * k)) & 255;
-                const int c0 = (S >> (8 * k)) & 255, c4 = (Eq >> (8 * k)) & 255;
-                const int c8 = (N >> (8 * k)) & 255, c12 = (Wq >> (8 * k)) & 255;
-                const int hi = v + th, lo = v - th;
-                const int nb = (c0 > hi) + (c4 > hi) + (c8 > hi) + (c12 > hi);
-                const int nd = (c0 < lo) + (c4 < lo) + (c8 < lo) + (c12 < lo);
-                p[k] = (nb >= 2 || nd >= 2) && (4 * qd + k < cw);
+        int n1 = 0;
+        const us2_t T = {(unsigned short)th, (unsigned short)th};
+        const int nitems = nq * ch;
+        for (int g0 = 0; g0 < nitems; g0 += 64) {
+            const int g = g0 + lane;
+            uint32_t f_lo = 0, f_hi = 0;
+            int py = 0, qd = 0;
+            if (g < nitems) {
+                py = (int)(((uint32_t)g * cell.inv_nq) >> 16);
+                qd = g - py * nq;
+                const uint8_t *row = tile + (py + 3) * TP + 4 + 4 * qd;
+                const uint32_t C = *reinterpret_cast<const uint32_t *>(row);
+                const uint32_t Wd = *reinterpret_cast<const uint32_t *>(row - 4);
+                const uint32_t Ed = *reinterpret_cast<const uint32_t *>(row + 4);
+                const uint32_t N = *reinterpret_cast<const uint32_t *>(row - 3 * TP);   // ring pixel 8 (dy=-3)
+                const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * TP);   // ring pixel 0 (dy=+3)
+                const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
+                const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
+                const uint32_t M = 0x00ff00ffu;
+                f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(Eq & M), as_us2(N & M), as_us2(Wq & M), T);
+                f_hi = compass2(as_us2((C >> 8) & M), as_us2((S >> 8) & M), as_us2((Eq >> 8) & M), as_us2((N >> 8) & M),
+                                as_us2((Wq >> 8) & M), T);
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int slot = lds_append(p[k], &cnt[0], lane);
-                if (p[k]) list1[slot] = (uint16_t)((py << 6) | (4 * qd + k));
-            }
+            const int x0 = 4 * qd;
+            const bool p0 = (f_lo & 0xffffu) != 0 && x0 < cw, p1 = (f_hi & 0xffffu) != 0 && x0 + 1 < cw;
+            const bool p2 = (f_lo >> 16) != 0 && x0 + 2 < cw, p3 = (f_hi >> 16) != 0 && x0 + 3 < cw;
+            const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
+            if ((b0 | b1 | b2 | b3) == 0ull) continue;
+            const int base = (py << 6) | x0;
+            if (p0) list1[n1 + __popcll(b0 & lt)] = (uint16_t)base;
+            n1 += __popcll(b0);
+            if (p1) list1[n1 + __popcll(b1 & lt)] = (uint16_t)(base + 1);
+            n1 += __popcll(b1);
+            if (p2) list1[n1 + __popcll(b2 & lt)] = (uint16_t)(base + 2);
+            n1 += __popcll(b2);
+            if (p3) list1[n1 + __popcll(b3 & lt)] = (uint16_t)(base + 3);
+            n1 += __popcll(b3);
         }
         __syncthreads();
         // ---- 2. exact scores of the survivors
-        const int n1 = cnt[0];
-        for (int i0 = 0; i0 < n1; i0 += 256) {
-            const int i = i0 + tid;
-            bool corner = false;
-            int pos = 0, S = 0;
-            if (i < n1) {
-                pos = list1[i];
-                const int py = pos >> 6, px = pos & 63;
-                S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
-                corner = S >= th;
-                if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
-            }
-            const int slot = lds_append(corner, &cnt[1], lane);
-            if (corner) list2[slot] = (uint16_t)pos;
+        for (int i = lane; i < n1; i += 64) {
+            const int pos = list1[i];
+            const int py = pos >> 6, px = pos & 63;
+            const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+            if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
         }
         __syncthreads();
         // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell)
-        const int n2 = cnt[1];
-        for (int i0 = 0; i0 < n2; i0 += 256) {
-            const int i = i0 + tid;
+        nkept = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
             bool keep = false;
             int pos = 0, sc = 0;
-            if (i < n2) {
-                pos = list2[i];
+            if (i < n1) {
+                pos = list1[i];
                 const int py = pos >> 6, px = pos & 63;
                 const uint8_t *m = smap + (py + 1) * SP + px + 1;
                 sc = m[0];
-                keep = sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] && sc > m[-SP + 1] &&
-                       sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
+                if (sc > 0)
+                    keep = sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] && sc > m[-SP + 1] &&
+                           sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
             }
-            const int slot = lds_append(keep, &cnt[2], lane);
-            if (keep && slot < keep_cap) list3[slot] = ((uint32_t)pos << 8) | (uint32_t)sc;
+            const unsigned long long bk = __ballot(keep);
+            if (keep) list3[nkept + __popcll(bk & lt)] = ((uint32_t)pos << 8) | (uint32_t)sc;
+            nkept += __popcll(bk);
         }
-        __syncthreads();
-        nkept = cnt[2];
         if (nkept > 0 || th == min_th) break;
         th = min_th;  // vKeysCell.empty() -> retry with minThFAST (:812-816)
         __syncthreads();
     }
+    __syncthreads();
     // ---- 5. emission order: rank by position (keys are unique)
-    for (int i = tid; i < nkept; i += 256) {
+    for (int i = lane; i < nkept; i += 64) {
         const uint32_t key = list3[i];
         int rank = 0;
         for (int j = 0; j < nkept; ++j) rank += list3[j] < key;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const uint8_t *__restri
         const uint32_t xr = (uint32_t)(cell.vx0 - 16) + (pos & 63), yr = (uint32_t)(cell.vy0 - 16) + (pos >> 6);
         my_slots[rank] = xr | (yr << 12) | ((key & 255u) << 24);
     }
-    if (tid == 0) cell_cnt[(size_t)b * n_cells + blockIdx.x] = nkept;
+    if (lane == 0) cell_cnt[(size_t)b * n_cells + blockIdx.x] = nkept;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -643,7 +651,7 @@ void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
                  uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
 {
-    dim3 blk(256), grd(n_cells, batch);
+    dim3 blk(64), grd(n_cells, batch);
     hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, cells, n_cells, ini_th,
                        min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap);
 }
