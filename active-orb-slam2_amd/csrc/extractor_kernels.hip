@@ -238,10 +238,10 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c
     {
         const uint8_t *src = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);
-        const int total = (ch + 6) * ndw;
-        for (int i = lane; i < total; i += 64) {
-            const int r = (int)(((uint32_t)i * cell.inv_ndw) >> 16), c = i - r * ndw;
-            *reinterpret_cast<uint32_t *>(tile + r * TP + 4 * c) = load_u32_unaligned(src + (size_t)r * lv.pitch + 4 * c);
+        const uint32_t total = (uint32_t)((ch + 6) * ndw), pitch = (uint32_t)lv.pitch;
+        for (uint32_t i = lane; i < total; i += 64) {
+            const uint32_t r = (i * cell.inv_ndw) >> 16, c = i - r * (uint32_t)ndw;
+            *reinterpret_cast<uint32_t *>(tile + r * (uint32_t)TP + 4 * c) = load_u32_unaligned(src + (r * pitch + 4 * c));
         }
     }
     const int SH = ch + 2;
@@ -275,9 +275,10 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 f_hi = compass2(as_us2((C >> 8) & M), as_us2((S >> 8) & M), as_us2((Eq >> 8) & M), as_us2((N >> 8) & M),
                                 as_us2((Wq >> 8) & M), T);
             }
+            // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
-            const bool p0 = (f_lo & 0xffffu) != 0 && x0 < cw, p1 = (f_hi & 0xffffu) != 0 && x0 + 1 < cw;
-            const bool p2 = (f_lo >> 16) != 0 && x0 + 2 < cw, p3 = (f_hi >> 16) != 0 && x0 + 3 < cw;
+            const bool p0 = (f_lo & 0xffffu) != 0, p1 = (f_hi & 0xffffu) != 0;
+            const bool p2 = (f_lo >> 16) != 0, p3 = (f_hi >> 16) != 0;
             const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
             if ((b0 | b1 | b2 | b3) == 0ull) continue;
             const int base = (py << 6) | x0;
@@ -295,8 +296,10 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         for (int i = lane; i < n1; i += 64) {
             const int pos = list1[i];
             const int py = pos >> 6, px = pos & 63;
-            const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
-            if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+            if (px < cw) {
+                const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+                if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+            }
         }
         __syncthreads();
         // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell)

@@ -128,10 +128,11 @@ AOS2_OCT_HD int erase(List &L, int id)
 // DivideNode: stable 4-way partition of the parent's segment; children c[0..3] = n1..n4
 // (UL, UR, BL, BR quadrants).  Returns false if the arena is exhausted.
 template <class Coop>
-AOS2_OCT_HD bool divide(List &L, int id, int c[4], const int16_t *xs, const int16_t *ys,
-                        int32_t *perm, int32_t *tmp)
+AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id, const int16_t *xs,
+                        const int16_t *ys, int32_t *perm, int32_t *tmp)
 {
     const OctNode p = L.nodes[id];
+    next_of_id = p.next;
     const int hx = (p.x1 - p.x0 + 1) / 2;  // ceil(float(x1-x0)/2)
     const int hy = (p.y1 - p.y0 + 1) / 2;
     const int mx = p.x0 + hx, my = p.y0 + hy;
@@ -216,7 +217,14 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], const int16_t *xs, const int1
         n.beg = p.beg + off[q];
         n.cnt = cnt[q];
         n.no_more = (cnt[q] == 1);
+        ccnt[q] = cnt[q];
     }
+    // unlink the parent here (its prev/next are already in registers); children are pushed to the
+    // front by the caller, which never touches the parent's neighbours, so the order of the two
+    // operations does not matter
+    if (p.prev >= 0) L.nodes[p.prev].next = p.next; else L.head = p.next;
+    if (p.next >= 0) L.nodes[p.next].prev = p.prev; else L.tail = p.prev;
+    L.size--;
     return true;
 }
 
@@ -355,10 +363,10 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 lit = L.nodes[lit].next;
                 continue;
             }
-            int c[4];
-            if (!divide<Coop>(L, lit, c, xs, ys, perm, tmp)) return -2;
+            int c[4], ccnt[4], nxt;
+            if (!divide<Coop>(L, lit, c, ccnt, nxt, xs, ys, perm, tmp)) return -2;
             for (int q = 0; q < 4; ++q) {
-                const int cn = L.nodes[c[q]].cnt;
+                const int cn = ccnt[q];
                 if (cn > 0) {
                     push_front(L, c[q]);
                     if (cn > 1) {
@@ -369,7 +377,7 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                     }
                 }
             }
-            lit = erase(L, lit);
+            lit = nxt;
         }
         if (L.size >= N || L.size == prevSize) {
             finish = true;
@@ -383,10 +391,10 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 pair_sort(prv, nprev);
                 for (int j = nprev - 1; j >= 0; --j) {
                     const int id = prv[2 * j + 1];
-                    int c[4];
-                    if (!divide<Coop>(L, id, c, xs, ys, perm, tmp)) return -2;
+                    int c[4], ccnt[4], nxt;
+                    if (!divide<Coop>(L, id, c, ccnt, nxt, xs, ys, perm, tmp)) return -2;
                     for (int q = 0; q < 4; ++q) {
-                        const int cn = L.nodes[c[q]].cnt;
+                        const int cn = ccnt[q];
                         if (cn > 0) {
                             push_front(L, c[q]);
                             if (cn > 1) {
@@ -396,7 +404,6 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                             }
                         }
                     }
-                    erase(L, id);
                     if (L.size >= N) break;
                 }
                 if (L.size >= N || L.size == prevSize2) finish = true;
