@@ -462,66 +462,151 @@ __global__ void k_schur_finish(LbaAct A)
     if (i < n6) A.bs[i] = A.b[i] - A.coeff[i];
 }
 
-// dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve, one
-// workgroup.  Works in place on the lower triangle of Hs (L2/LDS resident: (6 Np)^2 doubles).
-__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A)
+// Dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve of the reduced
+// camera system, one workgroup of 4 waves.  Blocked right-looking factorisation, block 16:
+//   (1) 16x16 diagonal block: unblocked LDL^T by wave 0 (wave-synchronous, no workgroup barrier)
+//   (2) panel: one thread per row below the block, 16-column forward substitution, W = L * D kept
+//   (3) trailing update A[I][J] -= W[I] * L[J]^T on 16x16 tiles with v_mfma_f64_16x16x4_f64
+//       (the only GEMM-shaped piece of the path; tiles round-robin over the 4 waves)
+// then forward / diagonal / backward substitution by wave 0 with the vector in registers.
+// The matrix is padded to a multiple of 16 with an identity tail and lives in LDS when
+// npad^2 * 8 B fits (npad <= 128, i.e. <= 21 free keyframes), otherwise in a global scratch.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_lds, double *gscratch)
 {
-    extern __shared__ double col[];  // n doubles: column j before scaling ; then d[] (n)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = 6 * A.np;
-    double *M = A.Hs;
-    double *d = col + n;
-    __shared__ int fail;
-    if (threadIdx.x == 0) fail = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *M = use_lds ? sm : gscratch;                 // npad x npad (lower triangle is used)
+    double *W = use_lds ? sm + (size_t)npad * npad : gscratch + (size_t)npad * npad;   // npad x 16
+    double *dvec = W + (size_t)npad * 16;                // npad
+    double *ccol = dvec + npad;                          // 16
+    volatile int *failp = reinterpret_cast<volatile int *>(ccol + 16);  // kept in the dynamic region (LDS base alignment)
+    if (tid == 0) *failp = 0;
+    for (int idx = tid; idx < npad * npad; idx += 256) {
+        const int r = idx / npad, c = idx - r * npad;
+        M[idx] = (r < n && c < n) ? A.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+    }
     __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        const double dj = M[(size_t)j * n + j];
-        if (dj == 0.0 || dj != dj) {
-            if (threadIdx.x == 0) fail = 1;
-            __syncthreads();
-            break;
+    const int nb = npad >> 4;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int k0 = kb << 4;
+        // ---- (1) diagonal block, wave 0
+        if (wave == 0) {
+            for (int j = 0; j < 16; ++j) {
+                const double dj = M[(size_t)(k0 + j) * npad + k0 + j];
+                if (dj == 0.0 || dj != dj) {
+                    if (lane == 0) *failp = 1;
+                    break;
+                }
+                if (lane < 16 && lane > j) {
+                    const double c = M[(size_t)(k0 + lane) * npad + k0 + j];
+                    ccol[lane] = c;
+                    M[(size_t)(k0 + lane) * npad + k0 + j] = c / dj;
+                }
+                if (lane == 0) dvec[k0 + j] = dj;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int idx = lane; idx < 256; idx += 64) {
+                    const int i = idx >> 4, k = idx & 15;
+                    if (k > j && k <= i) M[(size_t)(k0 + i) * npad + k0 + k] -= M[(size_t)(k0 + i) * npad + k0 + j] * ccol[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        for (int i = j + 1 + threadIdx.x; i < n; i += 256) {
-            const double c = M[(size_t)i * n + j];
-            col[i] = c;
-            M[(size_t)i * n + j] = c / dj;
-        }
-        if (threadIdx.x == 0) d[j] = dj;
         __syncthreads();
-        // trailing update of the lower triangle: M[i][k] -= L[i][j] * col[k], j < k <= i
-        const int m = n - j - 1;
-        const int total = m * (m + 1) / 2;
-        for (int t = threadIdx.x; t < total; t += 256) {
-            // t -> (ii, kk) with kk <= ii (row-major lower triangle)
-            int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-            while (ii * (ii + 1) / 2 > t) --ii;
-            const int kk = t - ii * (ii + 1) / 2;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            M[(size_t)i * n + k] -= M[(size_t)i * n + j] * col[k];
+        if (*failp) break;
+        // ---- (2) panel below the block
+        for (int i = k0 + 16 + tid; i < npad; i += 256) {
+            double w[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double sacc = M[(size_t)i * npad + k0 + c];
+#pragma unroll
+                for (int m = 0; m < c; ++m) sacc -= w[m] * M[(size_t)(k0 + c) * npad + k0 + m];
+                w[c] = sacc;
+                M[(size_t)i * npad + k0 + c] = sacc / dvec[k0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) W[(size_t)i * 16 + c] = w[c];
+        }
+        __syncthreads();
+        // ---- (3) trailing update with f64 MFMA, lower-triangle tiles (I >= J > kb)
+        const int m = nb - kb - 1;
+        const int ntiles = m * (m + 1) / 2;
+        for (int t = wave; t < ntiles; t += 4) {
+            int ii = 0, rem = t;
+            while (rem > ii) {  // row-major lower triangle: row ii holds ii+1 tiles
+                rem -= ii + 1;
+                ++ii;
+            }
+            const int I0 = (kb + 1 + ii) << 4, J0 = (kb + 1 + rem) << 4;
+            double4_t acc;
+            const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * npad + J0 + col];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double av = -W[(size_t)(I0 + col) * 16 + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
+                const double bv = M[(size_t)(J0 + col) * npad + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * npad + J0 + col] = acc[r];
         }
         __syncthreads();
     }
-    if (fail) {
-        if (threadIdx.x == 0) A.scal[3] = 0.0;
+    if (*failp) {
+        if (tid == 0) A.scal[3] = 0.0;
         return;
     }
-    // forward substitution L y = b (column oriented), y in x[0..n)
-    double *xv = A.x;
-    for (int i = threadIdx.x; i < n; i += 256) xv[i] = A.bs[i];
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        const double yk = xv[k];
-        for (int i = k + 1 + threadIdx.x; i < n; i += 256) xv[i] -= M[(size_t)i * n + k] * yk;
-        __syncthreads();
+    // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 256)
+    if (wave == 0) {
+        double xv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = lane + 64 * s;
+            xv[s] = i < n ? A.bs[i] : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // forward: y_i -= L[i][k] y_k
+            for (int kl = 0; kl < 64 && ks * 64 + kl < npad; ++kl) {
+                const int k = ks * 64 + kl;
+                const double yk = __shfl(xv[ks], kl);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i > k && i < npad) xv[s] -= M[(size_t)i * npad + k] * yk;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = lane + 64 * s;
+            if (i < npad) xv[s] /= dvec[i];
+        }
+#pragma unroll
+        for (int ks = 3; ks >= 0; --ks) {  // backward: x_i -= L[k][i] x_k
+            for (int kl = 63; kl >= 0; --kl) {
+                const int k = ks * 64 + kl;
+                if (k >= npad) continue;
+                const double xk = __shfl(xv[ks], kl);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i < k) xv[s] -= M[(size_t)k * npad + i] * xk;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = lane + 64 * s;
+            if (i < n) A.x[i] = xv[s];
+        }
+        if (lane == 0) A.scal[3] = 1.0;
     }
-    for (int i = threadIdx.x; i < n; i += 256) xv[i] /= d[i];
-    __syncthreads();
-    for (int k = n - 1; k >= 0; --k) {
-        const double xk = xv[k];
-        for (int i = threadIdx.x; i < k; i += 256) xv[i] -= M[(size_t)k * n + i] * xk;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) A.scal[3] = 1.0;
 }
 
 // xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j) -> tmp
@@ -612,6 +697,8 @@ static int lba_init(aos2_lba *s)
     AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     if ((st = s->h_scal.alloc(8))) return st;
+    // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -793,6 +880,8 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
     const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
     const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, 64);
+    const size_t npad_max = (n6max + 15) & ~(size_t)15;
+    const size_t o_ldlt = H.push(nullptr, (npad_max * npad_max + npad_max * 16 + npad_max + 64) * 8);
     if ((st = s->arena.alloc(H.host.size() + 256))) return st;
     uint8_t *base = s->arena.p;
     hipStream_t q = s->stream;
@@ -890,7 +979,17 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
                 hipLaunchKernelGGL(k_schur_init, blocks(n6 * n6, 256), dim3(256), 0, q, A, lambda);
                 hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);
                 hipLaunchKernelGGL(k_schur_finish, blocks(n6 * n6, 256), dim3(256), 0, q, A);
-                hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), (size_t)2 * n6 * sizeof(double), q, A);
+                {
+                    const int npad = (n6 + 15) & ~15;
+                    if (npad > 256) {
+                        set_error("reduced camera system of dimension %d exceeds 256 (more than 42 free keyframes)", n6);
+                        return AOS2_ERR_ARG;
+                    }
+                    const size_t need = ((size_t)npad * npad + (size_t)npad * 16 + npad + 64) * sizeof(double);
+                    const int use_lds = need <= 150 * 1024 ? 1 : 0;
+                    hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), use_lds ? need : 0, q, A, npad, use_lds,
+                                       (double *)(base + o_ldlt));
+                }
                 hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
             } else {
                 hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);  // Dinv only
