@@ -77,6 +77,8 @@ def lib():
             L.aos2_matcher_create.argtypes = [cf, ci, ci, C.POINTER(vp)]
             L.aos2_matcher_destroy.argtypes = [vp]
             L.aos2_descriptor_distance.argtypes = [vp, vp]
+            L.aos2_matcher_last_device_ms.argtypes = [vp]
+            L.aos2_matcher_last_device_ms.restype = cf
             L.aos2_matcher_hamming_best2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
             L.aos2_matcher_hamming_best2_device.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, C.POINTER(cf)]
             L.aos2_matcher_search_by_bow.argtypes = [vp, vp, ci, vp, vp]
@@ -323,6 +325,9 @@ class Matcher:
             self.h = None
 
     __del__ = close
+
+    def last_device_ms(self):
+        return float(self.L.aos2_matcher_last_device_ms(self.h))
 
     @staticmethod
     def DescriptorDistance(a, b):

@@ -50,13 +50,39 @@ __device__ __forceinline__ void merge2(uint32_t &k1, uint32_t &k2, uint32_t o1, 
     k1 = lo;
 }
 
+// Two smallest keys of the wave, result uniform.  The serial matcher loops sit on this latency, so
+// no LDS crossbar (ds_bpermute) is used: four DPP butterfly steps reduce each 16-lane row at VALU
+// speed (every step merges two disjoint lane sets), then the four row results are read into SGPRs.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ void wave_min2(uint32_t &k1, uint32_t &k2)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
-        merge2(k1, k2, o1, o2);
-    }
+    merge2(k1, k2, dpp_mov<0xB1>(k1), dpp_mov<0xB1>(k2));    // quad_perm [1,0,3,2]
+    merge2(k1, k2, dpp_mov<0x4E>(k1), dpp_mov<0x4E>(k2));    // quad_perm [2,3,0,1]
+    merge2(k1, k2, dpp_mov<0x141>(k1), dpp_mov<0x141>(k2));  // row_half_mirror
+    merge2(k1, k2, dpp_mov<0x140>(k1), dpp_mov<0x140>(k2));  // row_mirror
+    uint32_t a1 = __builtin_amdgcn_readlane(k1, 0), a2 = __builtin_amdgcn_readlane(k2, 0);
+    merge2(a1, a2, __builtin_amdgcn_readlane(k1, 16), __builtin_amdgcn_readlane(k2, 16));
+    merge2(a1, a2, __builtin_amdgcn_readlane(k1, 32), __builtin_amdgcn_readlane(k2, 32));
+    merge2(a1, a2, __builtin_amdgcn_readlane(k1, 48), __builtin_amdgcn_readlane(k2, 48));
+    k1 = a1;
+    k2 = a2;
+}
+
+// Single-wave kernels: lane 0's LDS write (taken/state flags) must be visible to the other lanes'
+// later LDS reads.  LDS operations of one wave execute in order, so only the compiler has to be
+// kept from reordering; a full __syncthreads() would also drain the prefetched global loads
+// (vmcnt(0)) and put their latency back on the serial chain.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// value of `v` in the (unique) lane selected by a ballot mask, uniform result
+__device__ __forceinline__ uint32_t read_owner(uint32_t v, unsigned long long mask)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __ffsll((long long)mask) - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -152,21 +178,61 @@ __device__ __forceinline__ void three_maxima(const int *histo, int &ind1, int &i
 }
 
 // ---------------------------------------------------------------------------------------------
-// SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  :159-288 -- one wave per (KF, F) pair.
+// Two-stage structure of the three search methods (SURVEY.md App. E option (a)):
+//   stage A (parallel, one wave per query): enumerate the query's candidates in the reference's
+//           visiting order and compute the Hamming distances -> entries {key, payload},
+//           key = dist << 20 | visiting position (KEY_NONE for candidates the static gates reject);
+//   stage B (sequential, one wave per problem): the reference's greedy loop over the queries;
+//           per query one coalesced read of its entries (prefetched one query ahead), the
+//           "already taken" mask applied from LDS, a two-smallest wave reduction, the accept
+//           test, and the state update.  (best, second) of the strict '<' loops = the two
+//           smallest keys, so ties resolve exactly like the reference.
 // ---------------------------------------------------------------------------------------------
+struct Entry {
+    uint32_t key;      // dist << 20 | position, KEY_NONE = rejected before the distance test
+    uint32_t payload;  // feature index | octave << 24
+};
+
+// SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  :159-288
+struct BowQuery {
+    int32_t kf_idx;   // realIdxKF
+    int32_t f_beg;    // start of the frame's bucket in node_idx_f
+    int32_t f_cnt;    // bucket size
+    int32_t ent_off;  // offset of this query's entries
+};
+
 struct BowPairDev {
-    int n_kf, n_f, n_nodes_kf, n_nodes_f;
-    const uint8_t *desc_kf, *desc_f, *kf_has_mp;
+    int n_kf, n_f, n_queries;
+    const uint8_t *desc_kf, *desc_f;
     const float *angle_kf, *angle_f;
-    const int32_t *node_id_kf, *node_off_kf, *node_idx_kf;
-    const int32_t *node_id_f, *node_off_f, *node_idx_f;
+    const int32_t *node_idx_f;
+    const BowQuery *queries;  // in the reference's visiting order (common nodes ascending, KF features in node order)
+    Entry *entries;
     int32_t *match_f;   // n_f
     uint32_t *bin_f;    // n_f scratch: bit b set = pushed into rotHist[b]
     int32_t *nmatches;  // 1
 };
 
-__global__ __launch_bounds__(64) void search_by_bow_kernel(const BowPairDev *__restrict__ pairs, float nnratio,
-                                                           int check_ori)
+// stage A: grid = (max queries, pairs); one wave per query
+__global__ __launch_bounds__(64) void bow_distances_kernel(const BowPairDev *__restrict__ pairs)
+{
+    const BowPairDev P = pairs[blockIdx.y];
+    if ((int)blockIdx.x >= P.n_queries) return;
+    const BowQuery q = P.queries[blockIdx.x];
+    const Desc dKF = load_desc(P.desc_kf + (size_t)q.kf_idx * 32);
+    for (int j = threadIdx.x; j < q.f_cnt; j += 64) {
+        const int realIdxF = P.node_idx_f[q.f_beg + j];
+        const int dist = hamming(dKF, load_desc(P.desc_f + (size_t)realIdxF * 32));
+        Entry e;
+        e.key = ((uint32_t)dist << 20) | (uint32_t)j;
+        e.payload = (uint32_t)realIdxF;
+        P.entries[q.ent_off + j] = e;
+    }
+}
+
+// stage B: one wave per pair
+__global__ __launch_bounds__(64) void bow_resolve_kernel(const BowPairDev *__restrict__ pairs, float nnratio,
+                                                         int check_ori)
 {
     extern __shared__ uint8_t taken[];  // vpMapPointMatches[j] != NULL
     __shared__ int histo[HISTO];
@@ -180,52 +246,77 @@ __global__ __launch_bounds__(64) void search_by_bow_kernel(const BowPairDev *__r
     if (lane < HISTO) histo[lane] = 0;
     __syncthreads();
     int nmatches = 0;
-    int ik = 0, jf = 0;
-    while (ik < P.n_nodes_kf && jf < P.n_nodes_f) {
-        const int idk = P.node_id_kf[ik], idf = P.node_id_f[jf];
-        if (idk == idf) {
-            const int a0 = P.node_off_kf[ik], a1 = P.node_off_kf[ik + 1];
-            const int b0 = P.node_off_f[jf], b1 = P.node_off_f[jf + 1];
-            for (int a = a0; a < a1; ++a) {
-                const int realIdxKF = P.node_idx_kf[a];
-                if (!P.kf_has_mp[realIdxKF]) continue;
-                const Desc dKF = load_desc(P.desc_kf + (size_t)realIdxKF * 32);
-                uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
-                for (int b = b0 + lane; b < b1; b += 64) {
-                    const int realIdxF = P.node_idx_f[b];
-                    if (taken[realIdxF]) continue;  // vpMapPointMatches[realIdxF] (:209)
-                    const int dist = hamming(dKF, load_desc(P.desc_f + (size_t)realIdxF * 32));
-                    const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(b - b0);
-                    if (key < k1) {
-                        k2 = k1;
-                        k1 = key;
-                    } else if (key < k2)
-                        k2 = key;
-                }
-                wave_min2(k1, k2);
-                const int bestDist1 = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
-                const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
-                if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
-                    const int bestIdxF = P.node_idx_f[b0 + (int)(k1 & 0xfffff)];
-                    if (lane == 0) {
-                        P.match_f[bestIdxF] = realIdxKF;
-                        taken[bestIdxF] = 1;
-                        if (check_ori) {
-                            const int bin = rot_bin(__fsub_rn(P.angle_kf[realIdxKF], P.angle_f[bestIdxF]));
-                            P.bin_f[bestIdxF] |= 1u << bin;
-                            histo[bin]++;
-                        }
-                    }
-                    nmatches++;
-                    __syncthreads();  // single wave: lane 0's LDS/global writes before the next reads
+    // queries are read 64 at a time (one per lane) and broadcast with shuffles; the entries of
+    // the next two queries are prefetched, so no global-memory latency sits on the serial chain
+    BowQuery qreg{0, 0, 0, 0};
+    auto query_at = [&](int qi) {
+        BowQuery r;
+        const int src = qi & 63;
+        r.kf_idx = __shfl(qreg.kf_idx, src);
+        r.f_beg = __shfl(qreg.f_beg, src);
+        r.f_cnt = __shfl(qreg.f_cnt, src);
+        r.ent_off = __shfl(qreg.ent_off, src);
+        return r;
+    };
+    auto fetch = [&](const BowQuery &qq) {
+        Entry r{KEY_NONE, 0};
+        if (lane < qq.f_cnt) r = P.entries[qq.ent_off + lane];
+        return r;
+    };
+    Entry e1{KEY_NONE, 0}, e2{KEY_NONE, 0};
+    BowQuery q1{0, 0, 0, 0}, q2{0, 0, 0, 0};
+    if (P.n_queries > 0) {
+        if (lane < P.n_queries) qreg = P.queries[lane];
+        q1 = query_at(0);
+        e1 = fetch(q1);
+        if (P.n_queries > 1) {
+            q2 = query_at(1);
+            e2 = fetch(q2);
+        }
+    }
+    for (int qi = 0; qi < P.n_queries; ++qi) {
+        const BowQuery q = q1;
+        Entry e = e1;
+        q1 = q2;
+        e1 = e2;
+        if (qi + 2 < P.n_queries) {
+            if (((qi + 2) & 63) == 0) {  // next chunk of queries (uniform branch)
+                qreg = BowQuery{0, 0, 0, 0};
+                if (qi + 2 + lane < P.n_queries) qreg = P.queries[qi + 2 + lane];
+            }
+            q2 = query_at(qi + 2);
+            e2 = fetch(q2);
+        }
+        uint32_t k1 = KEY_NONE, k2 = KEY_NONE, p1 = 0;
+        for (int j0 = 0; j0 < q.f_cnt; j0 += 64) {
+            if (j0 > 0) e = (j0 + lane < q.f_cnt) ? P.entries[q.ent_off + j0 + lane] : Entry{KEY_NONE, 0};
+            if (j0 + lane < q.f_cnt && !taken[e.payload]) {  // vpMapPointMatches[realIdxF] (:209)
+                if (e.key < k1) {
+                    k2 = k1;
+                    k1 = e.key;
+                    p1 = e.payload;
+                } else if (e.key < k2)
+                    k2 = e.key;
+            }
+        }
+        const uint32_t my1 = k1;
+        wave_min2(k1, k2);
+        const int bestDist1 = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
+        const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
+        if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+            const unsigned long long own = __ballot(my1 == k1);
+            const int bestIdxF = (int)read_owner(p1, own);
+            if (lane == 0) {
+                P.match_f[bestIdxF] = q.kf_idx;
+                taken[bestIdxF] = 1;
+                if (check_ori) {
+                    const int bin = rot_bin(__fsub_rn(P.angle_kf[q.kf_idx], P.angle_f[bestIdxF]));
+                    P.bin_f[bestIdxF] |= 1u << bin;
+                    histo[bin]++;
                 }
             }
-            ik++;
-            jf++;
-        } else if (idk < idf) {
-            while (ik < P.n_nodes_kf && P.node_id_kf[ik] < idf) ik++;
-        } else {
-            while (jf < P.n_nodes_f && P.node_id_f[jf] < idk) jf++;
+            nmatches++;
+            lds_fence();
         }
     }
     __syncthreads();
@@ -260,41 +351,54 @@ struct FrameDev {
     const uint8_t *f_mp_state;
 };
 
-struct Best2 {
-    uint32_t k1, k2;      // dist << 20 | position
-    int idx1, oct1, oct2; // payload of the lane-local entries
+struct Window {
+    int x0, x1, y0, y1;  // cell range, valid iff ok
+    bool ok;
 };
 
-template <bool kUseRightGate>
-__device__ __forceinline__ void scan_window(const FrameDev &F, const uint8_t *state, const Desc &dq, float x,
-                                            float y, float r, int minLevel, int maxLevel, float xr_proj,
-                                            float xr_tol, int lane, Best2 &B, bool &any)
+__device__ __forceinline__ Window window_cells(const FrameDev &F, float x, float y, float r)
 {
-    B.k1 = B.k2 = KEY_NONE;
-    B.idx1 = -1;
-    B.oct1 = B.oct2 = -1;
-    any = false;
-    const int nMinCellX0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv));
-    const int nMinCellX = max(0, nMinCellX0);
-    if (nMinCellX >= GRID_COLS) return;
-    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv)));
-    if (nMaxCellX < 0) return;
-    const int nMinCellY0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv));
-    const int nMinCellY = max(0, nMinCellY0);
-    if (nMinCellY >= GRID_ROWS) return;
-    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv)));
-    if (nMaxCellY < 0) return;
+    Window w;
+    w.ok = false;
+    w.x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv)));
+    if (w.x0 >= GRID_COLS) return w;
+    w.x1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F.min_x), r), F.grid_w_inv)));
+    if (w.x1 < 0) return w;
+    w.y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv)));
+    if (w.y0 >= GRID_ROWS) return w;
+    w.y1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F.min_y), r), F.grid_h_inv)));
+    if (w.y1 < 0) return w;
+    w.ok = true;
+    return w;
+}
+
+// population of the window (all features of its cells, before any gate); wave-uniform result
+__device__ __forceinline__ int window_population(const FrameDev &F, const Window &w, int lane)
+{
+    const int ny = w.y1 - w.y0 + 1, ncell = (w.x1 - w.x0 + 1) * ny;
+    int total = 0;
+    for (int c = lane; c < ncell; c += 64) {
+        const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
+        total += F.grid_off[cell + 1] - F.grid_off[cell];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    return total;
+}
+
+// stage A body: writes one entry per feature of the window at out[position]
+__device__ __forceinline__ void window_entries(const FrameDev &F, const Window &w, const Desc &dq, float x, float y,
+                                               float r, int minLevel, int maxLevel, float xr_proj, float xr_tol,
+                                               int lane, Entry *out)
+{
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    const int ny = nMaxCellY - nMinCellY + 1;
-    const int ncell = (nMaxCellX - nMinCellX + 1) * ny;
+    const int ny = w.y1 - w.y0 + 1, ncell = (w.x1 - w.x0 + 1) * ny;
     int base = 0;
-    bool found = false;
     for (int c0 = 0; c0 < ncell; c0 += 64) {
         const int c = c0 + lane;
         int beg = 0, cnt = 0;
         if (c < ncell) {
-            const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;
-            const int cell = ix * GRID_ROWS + iy;
+            const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
             beg = F.grid_off[cell];
             cnt = F.grid_off[cell + 1] - beg;
         }
@@ -308,68 +412,137 @@ __device__ __forceinline__ void scan_window(const FrameDev &F, const uint8_t *st
         for (int j = 0; j < cnt; ++j) {
             const int idx = F.grid_idx[beg + j];
             const int oct = F.kp_octave[idx];
+            Entry e;
+            e.key = KEY_NONE;
+            e.payload = (uint32_t)idx | ((uint32_t)oct << 24);
+            bool pass = true;
             if (bCheckLevels) {
-                if (oct < minLevel) continue;
-                if (maxLevel >= 0 && oct > maxLevel) continue;
+                if (oct < minLevel) pass = false;
+                if (maxLevel >= 0 && oct > maxLevel) pass = false;
             }
-            const float distx = __fsub_rn(F.kp_x[idx], x), disty = __fsub_rn(F.kp_y[idx], y);
-            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            found = true;  // vIndices non-empty
-            if (state[idx] == 2) continue;  // mvpMapPoints[idx]->Observations() > 0
-            if (kUseRightGate) {
+            if (pass) {
+                const float distx = __fsub_rn(F.kp_x[idx], x), disty = __fsub_rn(F.kp_y[idx], y);
+                pass = fabsf(distx) < r && fabsf(disty) < r;
+            }
+            if (pass) {
                 const float ur = F.u_right[idx];
                 if (ur > 0) {
                     const float er = fabsf(__fsub_rn(xr_proj, ur));
-                    if (er > xr_tol) continue;
+                    if (er > xr_tol) pass = false;
                 }
             }
-            const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
-            const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
-            if (key < B.k1) {
-                B.k2 = B.k1;
-                B.oct2 = B.oct1;
-                B.k1 = key;
-                B.idx1 = idx;
-                B.oct1 = oct;
-            } else if (key < B.k2) {
-                B.k2 = key;
-                B.oct2 = oct;
+            if (pass) {
+                const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+                e.key = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
             }
+            out[pos0 + j] = e;
         }
         base += __shfl(incl, 63);
     }
-    any = __any(found);
 }
 
-// wave reduction of Best2 keeping payloads: returns uniform results
-__device__ __forceinline__ void reduce_best2(const Best2 &B, int lane, uint32_t &k1, uint32_t &k2, int &idx1,
-                                             int &oct1, int &oct2)
+struct QuerySlot {
+    int32_t cnt;      // window population (0 = query skipped / empty window)
+    int32_t ent_off;  // offset of its entries in the pool
+};
+
+// best / second of one query in stage B; e = entries of the first 64 candidates (prefetched)
+struct Pick {
+    uint32_t k1, k2;
+    int idx1, oct1, oct2;
+};
+
+__device__ __forceinline__ Pick pick_best2(const Entry *__restrict__ ent, int cnt, Entry e, const uint8_t *state,
+                                           int lane)
 {
-    k1 = B.k1;
-    k2 = B.k2;
-    wave_min2(k1, k2);
-    // owners: keys are unique (position is unique per candidate)
-    const unsigned long long own1 = __ballot(B.k1 == k1 && k1 != KEY_NONE);
-    idx1 = -1;
-    oct1 = -1;
-    oct2 = -1;
-    if (own1) {
-        const int src = __ffsll((long long)own1) - 1;
-        idx1 = __shfl(B.idx1, src);
-        oct1 = __shfl(B.oct1, src);
-    }
-    if (k2 != KEY_NONE) {
-        const unsigned long long o2a = __ballot(B.k1 == k2);
-        const unsigned long long o2b = __ballot(B.k2 == k2);
-        if (o2a) {
-            const int src = __ffsll((long long)o2a) - 1;
-            oct2 = __shfl(B.oct1, src);
-        } else if (o2b) {
-            const int src = __ffsll((long long)o2b) - 1;
-            oct2 = __shfl(B.oct2, src);
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE, p1 = 0, p2 = 0;
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+        if (j0 > 0) e = (j0 + lane < cnt) ? ent[j0 + lane] : Entry{KEY_NONE, 0};
+        if (j0 + lane < cnt && e.key != KEY_NONE && state[e.payload & 0xffffffu] != 2) {  // Observations()>0 skip
+            if (e.key < k1) {
+                k2 = k1; p2 = p1;
+                k1 = e.key; p1 = e.payload;
+            } else if (e.key < k2) {
+                k2 = e.key; p2 = e.payload;
+            }
         }
     }
+    Pick r;
+    r.k1 = k1;
+    r.k2 = k2;
+    wave_min2(r.k1, r.k2);
+    r.idx1 = -1;
+    r.oct1 = r.oct2 = -1;
+    // keys are unique (unique position): find the owners' payloads
+    const unsigned long long own1 = __ballot(k1 == r.k1 && r.k1 != KEY_NONE);
+    if (own1) {
+        const uint32_t pl = read_owner(p1, own1);
+        r.idx1 = (int)(pl & 0xffffffu);
+        r.oct1 = (int)(pl >> 24);
+    }
+    if (r.k2 != KEY_NONE) {
+        const unsigned long long o2a = __ballot(k1 == r.k2), o2b = __ballot(k2 == r.k2);
+        if (o2a)
+            r.oct2 = (int)(read_owner(p1, o2a) >> 24);
+        else if (o2b)
+            r.oct2 = (int)(read_owner(p2, o2b) >> 24);
+    }
+    return r;
 }
+
+// stage-B query stream: slots are read 64 at a time (one per lane) and broadcast with shuffles, the
+// entries of the next two queries are prefetched
+struct SlotStream {
+    const QuerySlot *slots;
+    const Entry *pool;
+    int n, lane;
+    QuerySlot sreg, s1, s2;
+    Entry e1, e2;
+    __device__ __forceinline__ QuerySlot at(int i) const
+    {
+        QuerySlot r;
+        r.cnt = __shfl(sreg.cnt, i & 63);
+        r.ent_off = __shfl(sreg.ent_off, i & 63);
+        return r;
+    }
+    __device__ __forceinline__ Entry fetch(const QuerySlot &q) const
+    {
+        Entry r{KEY_NONE, 0};
+        if (lane < q.cnt) r = pool[q.ent_off + lane];
+        return r;
+    }
+    __device__ __forceinline__ void init(const QuerySlot *sl, const Entry *pl, int n_, int lane_)
+    {
+        slots = sl; pool = pl; n = n_; lane = lane_;
+        sreg = s1 = s2 = QuerySlot{0, 0};
+        e1 = e2 = Entry{KEY_NONE, 0};
+        if (n > 0) {
+            if (lane < n) sreg = slots[lane];
+            s1 = at(0);
+            e1 = fetch(s1);
+            if (n > 1) {
+                s2 = at(1);
+                e2 = fetch(s2);
+            }
+        }
+    }
+    // returns query i (slot + first 64 entries) and advances the prefetch window
+    __device__ __forceinline__ void next(int i, QuerySlot &s, Entry &e)
+    {
+        s = s1;
+        e = e1;
+        s1 = s2;
+        e1 = e2;
+        if (i + 2 < n) {
+            if (((i + 2) & 63) == 0) {
+                sreg = QuerySlot{0, 0};
+                if (i + 2 + lane < n) sreg = slots[i + 2 + lane];
+            }
+            s2 = at(i + 2);
+            e2 = fetch(s2);
+        }
+    }
+};
 
 struct ProjMpDev {
     int n_mp;
@@ -378,10 +551,47 @@ struct ProjMpDev {
     const float *view_cos, *proj_x, *proj_y, *proj_xr;
 };
 
-// SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129
-__global__ __launch_bounds__(64) void search_by_projection_mp_kernel(FrameDev F, ProjMpDev P, float th,
-                                                                     float nnratio, int32_t *match_f,
-                                                                     int32_t *nmatches_out)
+__device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P, int i, float th)
+{
+    float r = (double)P.view_cos[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos :131-137
+    if (th != 1.0f) r = __fmul_rn(r, th);
+    return __fmul_rn(r, F.scale_factors[P.pred_level[i]]);
+}
+
+// SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129, stage A: one wave per map point
+__global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpDev P, float th, QuerySlot *slots,
+                                                             Entry *pool, int32_t *pool_used, int pool_cap)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    QuerySlot s{0, 0};
+    if (P.track_in_view[i]) {
+        const float rs = mp_radius(F, P, i, th);
+        const Window w = window_cells(F, P.proj_x[i], P.proj_y[i], rs);
+        if (w.ok) {
+            const int pop = window_population(F, w, lane);
+            if (pop > 0) {
+                int off = 0;
+                if (lane == 0) off = atomicAdd(pool_used, pop);
+                off = __shfl(off, 0);
+                if (off + pop <= pool_cap) {
+                    const int lvl = P.pred_level[i];
+                    window_entries(F, w, load_desc(P.desc + (size_t)i * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
+                                   P.proj_xr[i], rs, lane, pool + off);
+                    s.cnt = pop;
+                    s.ent_off = off;
+                } else
+                    s.cnt = -1;  // pool exhausted (cannot happen: the pool holds n_mp * n_f entries)
+            }
+        }
+    }
+    if (lane == 0) slots[i] = s;
+}
+
+// stage B
+__global__ __launch_bounds__(64) void proj_mp_resolve_kernel(FrameDev F, ProjMpDev P, float nnratio,
+                                                             const QuerySlot *__restrict__ slots,
+                                                             const Entry *__restrict__ pool, int32_t *match_f,
+                                                             int32_t *nmatches_out)
 {
     extern __shared__ uint8_t state[];
     const int lane = threadIdx.x;
@@ -390,33 +600,25 @@ __global__ __launch_bounds__(64) void search_by_projection_mp_kernel(FrameDev F,
         match_f[i] = -1;
     }
     __syncthreads();
-    const bool bFactor = th != 1.0f;
     int nmatches = 0;
+    SlotStream Q;
+    Q.init(slots, pool, P.n_mp, lane);
     for (int iMP = 0; iMP < P.n_mp; iMP++) {
-        if (!P.track_in_view[iMP]) continue;
-        const int nPredictedLevel = P.pred_level[iMP];
-        float r = (double)P.view_cos[iMP] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos :131-137
-        if (bFactor) r = __fmul_rn(r, th);
-        const float rs = __fmul_rn(r, F.scale_factors[nPredictedLevel]);
-        const Desc dq = load_desc(P.desc + (size_t)iMP * 32);
-        Best2 B;
-        bool any;
-        scan_window<true>(F, state, dq, P.proj_x[iMP], P.proj_y[iMP], rs, nPredictedLevel - 1, nPredictedLevel,
-                          P.proj_xr[iMP], rs, lane, B, any);
-        if (!any) continue;
-        uint32_t k1, k2;
-        int bestIdx, bestLevel, bestLevel2;
-        reduce_best2(B, lane, k1, k2, bestIdx, bestLevel, bestLevel2);
-        const int bestDist = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
-        const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
+        QuerySlot s;
+        Entry e;
+        Q.next(iMP, s, e);
+        if (s.cnt <= 0) continue;  // not in view, empty window (vIndices.empty()) -- nothing to do
+        const Pick b = pick_best2(pool + s.ent_off, s.cnt, e, state, lane);
+        const int bestDist = b.k1 == KEY_NONE ? 256 : (int)(b.k1 >> 20);
+        const int bestDist2 = b.k2 == KEY_NONE ? 256 : (int)(b.k2 >> 20);
         if (bestDist <= TH_HIGH) {
-            if (bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
+            if (b.oct1 == b.oct2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)) continue;
             if (lane == 0) {
-                match_f[bestIdx] = iMP;
-                state[bestIdx] = P.has_obs[iMP] ? 2 : 1;
+                match_f[b.idx1] = iMP;
+                state[b.idx1] = P.has_obs[iMP] ? 2 : 1;
             }
             nmatches++;
-            __syncthreads();
+            lds_fence();
         }
     }
     if (lane == 0) *nmatches_out = nmatches;
@@ -432,10 +634,77 @@ struct ProjLastDev {
 };
 
 // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  :1328-1470
-__global__ __launch_bounds__(64) void search_by_projection_last_kernel(FrameDev F, ProjLastDev P, float th,
-                                                                       int mono, int check_ori,
-                                                                       int32_t *match_f, uint32_t *bin_f,
-                                                                       int32_t *nmatches_out)
+// stage A: one wave per last-frame feature: project, window, distances
+__global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjLastDev P, float th, int mono,
+                                                               QuerySlot *slots, Entry *pool, int32_t *pool_used,
+                                                               int pool_cap)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    QuerySlot s{0, 0};
+    const float *T = P.Tcw, *Tl = P.Tlw;
+    if (P.last_valid[i]) {
+        // twc = -Rcw^T tcw (cv::gemm general path: double accumulation) ; tlc = Rlw twc + tlw (:1339-1346)
+        float twc[3], tlc2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double sacc = __dadd_rn(__dadd_rn(__dmul_rn((double)T[k], (double)T[3]), __dmul_rn((double)T[4 + k], (double)T[7])),
+                                          __dmul_rn((double)T[8 + k], (double)T[11]));
+            twc[k] = (float)__dmul_rn(sacc, -1.0);
+        }
+        tlc2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Tl[8], twc[0]), __fmul_rn(Tl[9], twc[1])), __fmul_rn(Tl[10], twc[2])), Tl[11]);
+        const bool bForward = tlc2 > P.mb && !mono;
+        const bool bBackward = -tlc2 > P.mb && !mono;
+        const float X0 = P.world_pos[3 * i], X1 = P.world_pos[3 * i + 1], X2 = P.world_pos[3 * i + 2];
+        float x3Dc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float sacc = __fadd_rn(__fadd_rn(__fmul_rn(T[r * 4], X0), __fmul_rn(T[r * 4 + 1], X1)), __fmul_rn(T[r * 4 + 2], X2));
+            x3Dc[r] = __fadd_rn(sacc, T[r * 4 + 3]);
+        }
+        const float invzc = (float)__ddiv_rn(1.0, (double)x3Dc[2]);
+        const float u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, x3Dc[0]), invzc), P.cx);
+        const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, x3Dc[1]), invzc), P.cy);
+        const bool inside = !(invzc < 0) && !(u < F.min_x || u > F.max_x) && !(v < F.min_y || v > F.max_y);
+        if (inside) {
+            const int nLastOctave = P.last_octave[i];
+            const float radius = __fmul_rn(th, F.scale_factors[nLastOctave]);
+            int minL, maxL;
+            if (bForward) {
+                minL = nLastOctave;
+                maxL = -1;
+            } else if (bBackward) {
+                minL = 0;
+                maxL = nLastOctave;
+            } else {
+                minL = nLastOctave - 1;
+                maxL = nLastOctave + 1;
+            }
+            const Window w = window_cells(F, u, v, radius);
+            if (w.ok) {
+                const int pop = window_population(F, w, lane);
+                if (pop > 0) {
+                    int off = 0;
+                    if (lane == 0) off = atomicAdd(pool_used, pop);
+                    off = __shfl(off, 0);
+                    if (off + pop <= pool_cap) {
+                        const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
+                        window_entries(F, w, load_desc(P.desc + (size_t)i * 32), u, v, radius, minL, maxL, ur, radius, lane,
+                                       pool + off);
+                        s.cnt = pop;
+                        s.ent_off = off;
+                    } else
+                        s.cnt = -1;
+                }
+            }
+        }
+    }
+    if (lane == 0) slots[i] = s;
+}
+
+__global__ __launch_bounds__(64) void proj_last_resolve_kernel(FrameDev F, ProjLastDev P, int check_ori,
+                                                               const QuerySlot *__restrict__ slots,
+                                                               const Entry *__restrict__ pool, int32_t *match_f,
+                                                               uint32_t *bin_f, int32_t *nmatches_out)
 {
     extern __shared__ uint8_t state[];
     __shared__ int histo[HISTO];
@@ -447,78 +716,31 @@ __global__ __launch_bounds__(64) void search_by_projection_last_kernel(FrameDev 
     }
     if (lane < HISTO) histo[lane] = 0;
     __syncthreads();
-    const float *T = P.Tcw, *Tl = P.Tlw;
-    // twc = -Rcw^T tcw (cv::gemm general path: double accumulation) ; tlc = Rlw twc + tlw (:1339-1346)
-    float twc[3], tlc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double s = __dadd_rn(__dadd_rn(__dmul_rn((double)T[i], (double)T[3]), __dmul_rn((double)T[4 + i], (double)T[7])),
-                                   __dmul_rn((double)T[8 + i], (double)T[11]));
-        twc[i] = (float)__dmul_rn(s, -1.0);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float s = __fadd_rn(__fadd_rn(__fmul_rn(Tl[i * 4], twc[0]), __fmul_rn(Tl[i * 4 + 1], twc[1])),
-                                  __fmul_rn(Tl[i * 4 + 2], twc[2]));
-        tlc[i] = __fadd_rn(s, Tl[i * 4 + 3]);
-    }
-    const bool bForward = tlc[2] > P.mb && !mono;
-    const bool bBackward = -tlc[2] > P.mb && !mono;
     int nmatches = 0;
+    SlotStream Q;
+    Q.init(slots, pool, P.n_last, lane);
     for (int i = 0; i < P.n_last; i++) {
-        if (!P.last_valid[i]) continue;
-        const float X0 = P.world_pos[3 * i], X1 = P.world_pos[3 * i + 1], X2 = P.world_pos[3 * i + 2];
-        float x3Dc[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float s = __fadd_rn(__fadd_rn(__fmul_rn(T[r * 4], X0), __fmul_rn(T[r * 4 + 1], X1)), __fmul_rn(T[r * 4 + 2], X2));
-            x3Dc[r] = __fadd_rn(s, T[r * 4 + 3]);
-        }
-        const float xc = x3Dc[0], yc = x3Dc[1];
-        const float invzc = (float)__ddiv_rn(1.0, (double)x3Dc[2]);
-        if (invzc < 0) continue;
-        const float u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, xc), invzc), P.cx);
-        const float v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, yc), invzc), P.cy);
-        if (u < F.min_x || u > F.max_x) continue;
-        if (v < F.min_y || v > F.max_y) continue;
-        const int nLastOctave = P.last_octave[i];
-        const float radius = __fmul_rn(th, F.scale_factors[nLastOctave]);
-        int minL, maxL;
-        if (bForward) {
-            minL = nLastOctave;
-            maxL = -1;
-        } else if (bBackward) {
-            minL = 0;
-            maxL = nLastOctave;
-        } else {
-            minL = nLastOctave - 1;
-            maxL = nLastOctave + 1;
-        }
-        const Desc dq = load_desc(P.desc + (size_t)i * 32);
-        const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
-        Best2 B;
-        bool any;
-        scan_window<true>(F, state, dq, u, v, radius, minL, maxL, ur, radius, lane, B, any);
-        if (!any) continue;
-        uint32_t k1, k2;
-        int bestIdx2, o1, o2;
-        reduce_best2(B, lane, k1, k2, bestIdx2, o1, o2);
-        const int bestDist = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
+        QuerySlot s;
+        Entry e;
+        Q.next(i, s, e);
+        if (s.cnt <= 0) continue;
+        const Pick b = pick_best2(pool + s.ent_off, s.cnt, e, state, lane);
+        const int bestDist = b.k1 == KEY_NONE ? 256 : (int)(b.k1 >> 20);
         if (bestDist <= TH_HIGH) {
             if (lane == 0) {
-                match_f[bestIdx2] = i;
-                state[bestIdx2] = P.has_obs[i] ? 2 : 1;
+                match_f[b.idx1] = i;
+                state[b.idx1] = P.has_obs[i] ? 2 : 1;
                 if (check_ori) {
-                    const int bin = rot_bin(__fsub_rn(P.last_angle[i], F.kp_angle[bestIdx2]));
+                    const int bin = rot_bin(__fsub_rn(P.last_angle[i], F.kp_angle[b.idx1]));
                     // a feature can be pushed several times when a zero-observation point is
                     // overwritten (:1432): it is reset if ANY of its bins is culled, and nmatches
                     // drops once per pushed entry (:1459-1460)
                     histo[bin]++;
-                    bin_f[bestIdx2] |= 1u << bin;
+                    bin_f[b.idx1] |= 1u << bin;
                 }
             }
             nmatches++;
-            __syncthreads();
+            lds_fence();
         }
     }
     __syncthreads();
@@ -550,6 +772,8 @@ struct aos2_matcher {
     hipEvent_t ev[2] = {};
     DevBuf<uint8_t> arena;     // staging arena for problem snapshots
     DevBuf<uint32_t> part;     // hamming partials
+    DevBuf<uint64_t> pool;     // candidate entries of the projection searches (8 B each)
+    float last_ms = 0;         // device time of the kernels of the last search call
 };
 
 namespace aos2 {
@@ -661,11 +885,14 @@ void aos2_matcher_destroy(aos2_matcher_t *m)
         (void)hipStreamSynchronize(m->stream);
         m->arena.release();
         m->part.release();
+        m->pool.release();
         for (auto &e : m->ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(m->stream);
     }
     delete m;
 }
+
+float aos2_matcher_last_device_ms(const aos2_matcher_t *m) { return m ? m->last_ms : 0.f; }
 
 int aos2_descriptor_distance(const uint8_t *a, const uint8_t *b)
 {
@@ -752,29 +979,65 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
     int st = matcher_init(m);
     if (st) return st;
     Arena A{m};
-    struct Off { size_t o[16]; };
+    struct Off { size_t o[12]; int nq; };
     std::vector<Off> offs(n_pairs);
+    std::vector<BowQuery> queries;
+    int max_nf = 0, max_q = 0;
     for (int p = 0; p < n_pairs; ++p) {
         const aos2_bow_pair_t &P = pairs[p];
         if (P.n_kf < 0 || P.n_f < 0 || P.n_nodes_kf < 0 || P.n_nodes_f < 0 || !match_f[p]) {
             set_error("bad BoW pair %d", p);
             return AOS2_ERR_ARG;
         }
+        // merge-join of the two FeatureVectors (:181-258) on the host: the visiting order of the
+        // KF features and the bucket each one is compared against
+        queries.clear();
+        size_t ent = 0;
+        int ik = 0, jf = 0;
+        while (ik < P.n_nodes_kf && jf < P.n_nodes_f) {
+            const int idk = P.node_id_kf[ik], idf = P.node_id_f[jf];
+            if (idk == idf) {
+                const int b0 = P.node_off_f[jf], bc = P.node_off_f[jf + 1] - b0;
+                for (int a = P.node_off_kf[ik]; a < P.node_off_kf[ik + 1]; ++a) {
+                    const int kf = P.node_idx_kf[a];
+                    if (kf < 0 || kf >= P.n_kf) {
+                        set_error("BoW pair %d: feature index out of range", p);
+                        return AOS2_ERR_ARG;
+                    }
+                    if (!P.kf_has_mp[kf]) continue;  // no map point / bad (:194-198)
+                    queries.push_back(BowQuery{kf, b0, bc, (int32_t)ent});
+                    ent += (size_t)bc;
+                }
+                ik++;
+                jf++;
+            } else if (idk < idf) {
+                while (ik < P.n_nodes_kf && P.node_id_kf[ik] < idf) ik++;  // lower_bound
+            } else {
+                while (jf < P.n_nodes_f && P.node_id_f[jf] < idk) jf++;
+            }
+        }
+        if (ent > (size_t)1 << 28) {
+            set_error("BoW pair %d needs %zu distance entries", p, ent);
+            return AOS2_ERR_ARG;
+        }
         Off &o = offs[p];
+        o.nq = (int)queries.size();
         o.o[0] = A.push(P.desc_kf, (size_t)P.n_kf * 32);
         o.o[1] = A.push(P.desc_f, (size_t)P.n_f * 32);
-        o.o[2] = A.push(P.kf_has_mp, (size_t)P.n_kf);
-        o.o[3] = A.push(P.angle_kf, (size_t)P.n_kf * 4);
-        o.o[4] = A.push(P.angle_f, (size_t)P.n_f * 4);
-        o.o[5] = A.push(P.node_id_kf, (size_t)P.n_nodes_kf * 4);
-        o.o[6] = A.push(P.node_off_kf, (size_t)(P.n_nodes_kf + 1) * 4);
-        o.o[7] = A.push(P.node_idx_kf, (size_t)(P.n_nodes_kf ? P.node_off_kf[P.n_nodes_kf] : 0) * 4);
-        o.o[8] = A.push(P.node_id_f, (size_t)P.n_nodes_f * 4);
-        o.o[9] = A.push(P.node_off_f, (size_t)(P.n_nodes_f + 1) * 4);
-        o.o[10] = A.push(P.node_idx_f, (size_t)(P.n_nodes_f ? P.node_off_f[P.n_nodes_f] : 0) * 4);
-        o.o[11] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
-        o.o[12] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
-        o.o[13] = A.reserve(4);                      // nmatches
+        o.o[2] = A.push(P.angle_kf, (size_t)P.n_kf * 4);
+        o.o[3] = A.push(P.angle_f, (size_t)P.n_f * 4);
+        o.o[4] = A.push(P.node_idx_f, (size_t)(P.n_nodes_f ? P.node_off_f[P.n_nodes_f] : 0) * 4);
+        o.o[5] = A.push(queries.data(), queries.size() * sizeof(BowQuery));
+        o.o[6] = A.reserve(ent * sizeof(Entry) + 8);
+        o.o[7] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
+        o.o[8] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
+        o.o[9] = A.reserve(4);                      // nmatches
+        max_nf = std::max(max_nf, P.n_f);
+        max_q = std::max(max_q, o.nq);
+    }
+    if (max_nf > 60000) {
+        set_error("n_f %d exceeds the LDS flag table (60000)", max_nf);
+        return AOS2_ERR_ARG;
     }
     const size_t opairs = A.reserve(sizeof(BowPairDev) * n_pairs);
     if ((st = m->arena.alloc(A.host.size() + 256))) return st;
@@ -783,29 +1046,27 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
         const aos2_bow_pair_t &P = pairs[p];
         const Off &o = offs[p];
         BowPairDev &D = dev[p];
-        D.n_kf = P.n_kf; D.n_f = P.n_f; D.n_nodes_kf = P.n_nodes_kf; D.n_nodes_f = P.n_nodes_f;
-        D.desc_kf = A.dev<uint8_t>(o.o[0]); D.desc_f = A.dev<uint8_t>(o.o[1]); D.kf_has_mp = A.dev<uint8_t>(o.o[2]);
-        D.angle_kf = A.dev<float>(o.o[3]); D.angle_f = A.dev<float>(o.o[4]);
-        D.node_id_kf = A.dev<int32_t>(o.o[5]); D.node_off_kf = A.dev<int32_t>(o.o[6]); D.node_idx_kf = A.dev<int32_t>(o.o[7]);
-        D.node_id_f = A.dev<int32_t>(o.o[8]); D.node_off_f = A.dev<int32_t>(o.o[9]); D.node_idx_f = A.dev<int32_t>(o.o[10]);
-        D.match_f = A.dev<int32_t>(o.o[11]); D.bin_f = A.dev<uint32_t>(o.o[12]); D.nmatches = A.dev<int32_t>(o.o[13]);
+        D.n_kf = P.n_kf; D.n_f = P.n_f; D.n_queries = o.nq;
+        D.desc_kf = A.dev<uint8_t>(o.o[0]); D.desc_f = A.dev<uint8_t>(o.o[1]);
+        D.angle_kf = A.dev<float>(o.o[2]); D.angle_f = A.dev<float>(o.o[3]);
+        D.node_idx_f = A.dev<int32_t>(o.o[4]); D.queries = A.dev<BowQuery>(o.o[5]); D.entries = A.dev<Entry>(o.o[6]);
+        D.match_f = A.dev<int32_t>(o.o[7]); D.bin_f = A.dev<uint32_t>(o.o[8]); D.nmatches = A.dev<int32_t>(o.o[9]);
     }
     memcpy(A.host.data() + opairs, dev.data(), sizeof(BowPairDev) * n_pairs);
     if ((st = A.upload())) return st;
-    int max_nf = 0;
-    for (int p = 0; p < n_pairs; ++p) max_nf = std::max(max_nf, pairs[p].n_f);
-    if (max_nf > 60000) {
-        set_error("n_f %d exceeds the LDS flag table (60000)", max_nf);
-        return AOS2_ERR_ARG;
-    }
-    hipLaunchKernelGGL(search_by_bow_kernel, dim3(n_pairs), dim3(64), (size_t)max_nf + 16, m->stream,
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (max_q > 0)
+        hipLaunchKernelGGL(bow_distances_kernel, dim3(max_q, n_pairs), dim3(64), 0, m->stream, A.dev<BowPairDev>(opairs));
+    hipLaunchKernelGGL(bow_resolve_kernel, dim3(n_pairs), dim3(64), (size_t)max_nf + 16, m->stream,
                        A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     for (int p = 0; p < n_pairs; ++p) {
         AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_f, (size_t)pairs[p].n_f * 4, hipMemcpyDeviceToHost, m->stream));
         AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
     }
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
 
@@ -826,7 +1087,14 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     const size_t o0 = A.push(p->track_in_view, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
     const size_t o3 = A.push(p->pred_level, n * 4), o4 = A.push(p->view_cos, n * 4), o5 = A.push(p->proj_x, n * 4);
     const size_t o6 = A.push(p->proj_y, n * 4), o7 = A.push(p->proj_xr, n * 4);
-    const size_t om = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(4);
+    const size_t om = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(8);
+    const size_t oslots = A.reserve((size_t)(p->n_mp + 1) * sizeof(QuerySlot));
+    const size_t pool_cap = (size_t)p->n_mp * (size_t)f->n_f;   // a window holds at most every feature
+    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
+        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_mp, f->n_f);
+        return AOS2_ERR_ARG;
+    }
+    if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = A.upload())) return st;
     FrameDev F = frame_dev(A, f, fo);
     ProjMpDev P{};
@@ -834,12 +1102,21 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     P.track_in_view = A.dev<uint8_t>(o0); P.desc = A.dev<uint8_t>(o1); P.has_obs = A.dev<uint8_t>(o2);
     P.pred_level = A.dev<int32_t>(o3); P.view_cos = A.dev<float>(o4); P.proj_x = A.dev<float>(o5);
     P.proj_y = A.dev<float>(o6); P.proj_xr = A.dev<float>(o7);
-    hipLaunchKernelGGL(search_by_projection_mp_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, th,
-                       m->nnratio, A.dev<int32_t>(om), A.dev<int32_t>(on));
+    int32_t *d_used = A.dev<int32_t>(on) + 1;
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (p->n_mp > 0)
+        hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th,
+                           A.dev<QuerySlot>(oslots), reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+    hipLaunchKernelGGL(proj_mp_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, m->nnratio,
+                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                       A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
 
@@ -859,7 +1136,14 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     const size_t n = (size_t)p->n_last;
     const size_t o0 = A.push(p->last_valid, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
     const size_t o3 = A.push(p->world_pos, n * 12), o4 = A.push(p->last_angle, n * 4), o5 = A.push(p->last_octave, n * 4);
-    const size_t om = A.reserve((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve(4);
+    const size_t om = A.reserve((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve(8);
+    const size_t oslots = A.reserve((size_t)(p->n_last + 1) * sizeof(QuerySlot));
+    const size_t pool_cap = (size_t)p->n_last * (size_t)cur->n_f;
+    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
+        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_last, cur->n_f);
+        return AOS2_ERR_ARG;
+    }
+    if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = A.upload())) return st;
     FrameDev F = frame_dev(A, cur, fo);
     ProjLastDev P{};
@@ -869,12 +1153,21 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     memcpy(P.Tcw, p->Tcw, sizeof(P.Tcw));
     memcpy(P.Tlw, p->Tlw, sizeof(P.Tlw));
     P.fx = p->fx; P.fy = p->fy; P.cx = p->cx; P.cy = p->cy; P.mb = p->mb; P.mbf = p->mbf;
-    hipLaunchKernelGGL(search_by_projection_last_kernel, dim3(1), dim3(64), (size_t)cur->n_f + 16, m->stream, F, P, th,
-                       mono ? 1 : 0, m->check_ori, A.dev<int32_t>(om), A.dev<uint32_t>(ob), A.dev<int32_t>(on));
+    int32_t *d_used = A.dev<int32_t>(on) + 1;
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (p->n_last > 0)
+        hipLaunchKernelGGL(proj_last_entries_kernel, dim3(p->n_last), dim3(64), 0, m->stream, F, P, th, mono ? 1 : 0,
+                           A.dev<QuerySlot>(oslots), reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+    hipLaunchKernelGGL(proj_last_resolve_kernel, dim3(1), dim3(64), (size_t)cur->n_f + 16, m->stream, F, P, m->check_ori,
+                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                       A.dev<uint32_t>(ob), A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)cur->n_f * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
 

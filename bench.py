@@ -126,12 +126,14 @@ def main():
             tb = time.perf_counter()
             m.SearchByBoW(probs)
             extra["search_by_bow_64pairs_wall_ms"] = (time.perf_counter() - tb) * 1e3
+            extra["search_by_bow_64pairs_device_ms"] = m.last_device_ms()
             f, mp = S.synth_proj_mp_problem(0)
             m2 = pkg.Matcher(0.8, True, device=local_rank)
             m2.SearchByProjection(f, mp, th=3.0)
             tb = time.perf_counter()
             m2.SearchByProjection(f, mp, th=3.0)
             extra["search_by_projection_1500mp_wall_ms"] = (time.perf_counter() - tb) * 1e3
+            extra["search_by_projection_1500mp_device_ms"] = m2.last_device_ms()
             prob = S.synth_lba_problem(0)
             ba = pkg.LocalBA(device=local_rank)
             ba.LocalBundleAdjustment(prob)

@@ -142,6 +142,9 @@ typedef struct aos2_matcher aos2_matcher_t;
 int aos2_matcher_create(float nnratio, int check_orientation, int device, aos2_matcher_t **out);
 void aos2_matcher_destroy(aos2_matcher_t *m);
 
+/* device time (ms, HIP events) of the kernels of the last search_* call on this handle */
+float aos2_matcher_last_device_ms(const aos2_matcher_t *m);
+
 /* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)  :1647-1663.
  * Host scalar helper (pure); the device kernels use xor + popcount of the same 256 bits. */
 int aos2_descriptor_distance(const uint8_t *a, const uint8_t *b);
