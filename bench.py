@@ -40,13 +40,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (never set by the driver): run the N>1 code path on a box with fewer GPUs
+    backend = os.environ.get("AOS2_BENCH_BACKEND", "nccl")
+    if os.environ.get("AOS2_BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     pkg = g.load_package()
     cfg = pkg.synth.CONFIGS["tum"]
     W, H, NF = cfg["w"], cfg["h"], cfg["nfeatures"]
@@ -82,7 +89,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stage = ex.last_timing()
@@ -98,6 +105,7 @@ def main():
         slot[:, 16:16 + 28 * cap] = d_kps[:k].view(torch.uint8).reshape(k, -1)
         slot[:, 16 + 28 * cap:16 + 60 * cap] = d_desc[:k].reshape(k, -1)
         slot[:, :4] = d_n[:k].view(torch.uint8).reshape(k, 4)
+        slot = slot.to(cdev)
         bufs = [torch.empty_like(slot) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         dist.barrier()
@@ -105,6 +113,10 @@ def main():
         dist.gather(slot, bufs, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:  # the gathered slots must carry every rank's keypoint counts
+            for r_ in range(world):
+                got = bufs[r_][:, :4].contiguous().cpu().view(torch.int32).reshape(-1)
+                assert (got > 0).all() and (got <= cap).all(), "gathered slot header corrupt"
 
     # secondary measurements of the other hot-path rows (reported, not part of `value`)
     extra = {}
