@@ -33,7 +33,7 @@ class AosError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libaos2.so")
+    return os.environ.get("AOS2_LIB") or os.path.join(_HERE, "lib", "libaos2.so")
 
 
 def lib():
@@ -68,6 +68,8 @@ def lib():
         L.aos2_extractor_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
         L.aos2_extractor_debug_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(ci)]
         L.aos2_extractor_last_timing.argtypes = [vp, vp, ci]
+        if hasattr(L, "aos2_extractor_set_chunks"):
+            L.aos2_extractor_set_chunks.argtypes = [vp, ci]
         L.aos2_extractor_bench_fast.argtypes = [vp, ci, C.POINTER(cf)]
         L.aos2_extractor_bench_describe.argtypes = [vp, ci, C.POINTER(cf)]
         L.aos2_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
@@ -77,8 +79,9 @@ def lib():
             L.aos2_matcher_create.argtypes = [cf, ci, ci, C.POINTER(vp)]
             L.aos2_matcher_destroy.argtypes = [vp]
             L.aos2_descriptor_distance.argtypes = [vp, vp]
-            L.aos2_matcher_last_device_ms.argtypes = [vp]
-            L.aos2_matcher_last_device_ms.restype = cf
+            if hasattr(L, "aos2_matcher_last_device_ms"):
+                L.aos2_matcher_last_device_ms.argtypes = [vp]
+                L.aos2_matcher_last_device_ms.restype = cf
             L.aos2_matcher_hamming_best2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
             L.aos2_matcher_hamming_best2_device.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, C.POINTER(cf)]
             L.aos2_matcher_search_by_bow.argtypes = [vp, vp, ci, vp, vp]
@@ -209,11 +212,14 @@ class Extractor:
         _check(self.L.aos2_extractor_debug_candidates(self.h, image, level, _p(xs), _p(ys), _p(sc), len(xs), C.byref(n)))
         return xs[: n.value], ys[: n.value], sc[: n.value]
 
+    def set_chunks(self, n):
+        _check(self.L.aos2_extractor_set_chunks(self.h, n))
+
     def last_timing(self):
         t = np.zeros(8, np.float32)
         _check(self.L.aos2_extractor_last_timing(self.h, _p(t), 8))
         return dict(pyramid=float(t[0]), fast=float(t[1]), compact=float(t[2]), octree=float(t[3]),
-                    describe=float(t[4]), total_wall=float(t[5]))
+                    describe=float(t[4]), total_wall=float(t[5]), chunks=int(t[6]))
 
     def bench_fast(self, iters=20):
         ms = C.c_float(0)

@@ -92,7 +92,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-stage device times of one un-chunked (single-stream) pass; `value` above is measured with the
+    # default multi-stream chunking
+    ex.set_chunks(1)
+    step()
     stage = ex.last_timing()
+    ex.set_chunks(0)
     fast_ms = ex.bench_fast(20)
 
     # the one exchange step of the path: keypoint/descriptor slots of 8 frames per rank -> rank 0 (RCCL)

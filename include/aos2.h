@@ -114,6 +114,12 @@ int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int 
 int aos2_extractor_debug_candidates(aos2_extractor_t *e, int image, int level, int16_t *xs,
                                     int16_t *ys, uint8_t *score, int cap, int *n);
 
+/* A batch is cut into `chunks` sub-batches that run on separate HIP streams so that the
+ * latency-bound octree kernel of one overlaps the streaming kernels of the others.
+ * 0 = automatic (2 for batch >= 64, else 1); 1 = one stream (stage timing below is
+ * only meaningful then); at most 4. */
+int aos2_extractor_set_chunks(aos2_extractor_t *e, int chunks);
+
 /* Timing of the last batch, milliseconds, measured with HIP events on the handle's stream:
  * [0] pyramid kernels, [1] FAST+NMS kernel, [2] candidate compaction, [3] octree stage
  * (device kernel, or D2H + host + H2D when the host octree is selected), [4] orientation +
