@@ -614,6 +614,7 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     e->host_threads = (int)std::min(32u, std::max(1u, hc));
     if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));
     if (const char *v = getenv("AOS2_MAX_CAND")) e->max_cand = std::max(1024, atoi(v));
+    if (const char *v = getenv("AOS2_CHUNKS")) e->chunks = std::max(0, std::min(kMaxStreams, atoi(v)));
     *out = e;
     return AOS2_OK;
 }

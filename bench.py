@@ -97,7 +97,7 @@ def main():
     ex.set_chunks(1)
     step()
     stage = ex.last_timing()
-    ex.set_chunks(0)
+    ex.set_chunks(int(os.environ.get("AOS2_CHUNKS", "0")))
     fast_ms = ex.bench_fast(20)
 
     # the one exchange step of the path: keypoint/descriptor slots of 8 frames per rank -> rank 0 (RCCL)
