@@ -313,7 +313,9 @@ static int build_plan(aos2_extractor *e, int w, int h)
     P.TP = 4 * ((P.max_cw + 3) / 4) + 8;
     P.TH = P.max_ch + 6;
     P.SP = (P.max_cw + 2 + 3) & ~3;
-    P.list_cap = (P.max_cw * P.max_ch + 7) & ~7;                       // every pixel may survive the pre-test
+    // every pixel of every 4-px group may survive the pre-test (columns >= cw of the last group are
+    // only dropped in phase 2), so size the list for whole groups
+    P.list_cap = (4 * ((P.max_cw + 3) / 4) * P.max_ch + 7) & ~7;
     P.keep_cap = ((P.max_cw + 1) / 2) * ((P.max_ch + 1) / 2);          // NMS survivors are >= 2 px apart
     P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (((size_t)P.SP * (P.TH - 4) + 15) & ~(size_t)15) +
                  (size_t)P.list_cap * 2 + (size_t)P.keep_cap * 4 + 16;

@@ -37,8 +37,6 @@ struct OctDevScratch {
 };
 
 int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st);
-void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t simg_stride, uint8_t *pyr,
-                        size_t pyr_stride, int dpitch, int batch, hipStream_t st);
 void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
                    const int *yab, int batch, hipStream_t st);

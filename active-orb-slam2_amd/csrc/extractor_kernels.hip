@@ -32,30 +32,10 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Level 0: copy the caller's image (arbitrary stride) into the pitched pyramid plane.
-// (ComputePyramid, src/ORBextractor.cc:1107-1132; the 19-px REFLECT_101 frame the reference keeps
-// around each level is never read by the extractor and is synthesised on demand for
-// mvImagePyramid readers, see aos2_extractor_pyramid_level.)
-// ---------------------------------------------------------------------------------------------
-__global__ void copy_level0_kernel(const uint8_t *__restrict__ src, int w, int h, int sstride,
-                                   size_t simg_stride, uint8_t *__restrict__ pyr, size_t pyr_stride,
-                                   int dpitch)
-{
-    const int b = blockIdx.z;
-    const int y = blockIdx.y;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (x4 >= w) return;
-    const uint8_t *s = src + (size_t)b * simg_stride + (size_t)y * sstride + x4;
-    uint8_t *d = pyr + (size_t)b * pyr_stride + (size_t)y * dpitch + x4;
-    uint32_t v = 0;
-    if (x4 + 3 < w) {
-        v = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    } else {
-        for (int k = 0; k < 4 && x4 + k < w; ++k) v |= (uint32_t)s[k] << (8 * k);
-    }
-    *reinterpret_cast<uint32_t *>(d) = v;  // dpitch % 4 == 0, plane base 256-aligned
-}
-
+// Level 0 of the pyramid (ComputePyramid, src/ORBextractor.cc:1107-1132) is the caller's image
+// itself: nothing is copied.  The 19-px REFLECT_101 frame the reference keeps around each level is
+// never read by the extractor and is synthesised on demand for mvImagePyramid readers
+// (aos2_extractor_pyramid_level).
 // ---------------------------------------------------------------------------------------------
 // cv::resize(INTER_LINEAR) 8UC1, level L-1 -> L (src/ORBextractor.cc:1120).  Fixed point,
 // 11-bit coefficients; the coefficient tables are built on the host exactly like OpenCV's
@@ -90,10 +70,15 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
     const int sy_max = min(max(yofs[dst.tab_y + dy_last] + 1, 0), src.h - 1);
     const int ndw = (sx_max - sx_min + 4) >> 2;
     const int nrow = sy_max - sy_min + 1;
-    for (int i = tid; i < nrow * ndw; i += 256) {
-        const int r = i / ndw, c = i - r * ndw;
-        *reinterpret_cast<uint32_t *>(tile + r * RS_PITCH + 4 * c) =
-            load_u32_unaligned(sp + (size_t)(sy_min + r) * src_pitch + sx_min + 4 * c);
+    {
+        // linear item -> (row, dword) by an exact multiply-high division; 32-bit offsets
+        const uint8_t *win = sp + (size_t)sy_min * src_pitch + sx_min;
+        const uint32_t magic = 0xFFFFFFFFu / (uint32_t)ndw + 1u;  // exact for items < 2^16
+        const uint32_t total = (uint32_t)(nrow * ndw);
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint32_t r = __umulhi(i, magic), c = i - r * (uint32_t)ndw;
+            *reinterpret_cast<uint32_t *>(tile + r * RS_PITCH + 4 * c) = load_u32_unaligned(win + (r * (uint32_t)src_pitch + 4u * c));
+        }
     }
     __syncthreads();
     if (dy >= dst.h || dx0 >= dst.w) return;
@@ -638,13 +623,6 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
 }
 
 // host launchers -------------------------------------------------------------------------------
-void launch_copy_level0(const uint8_t *d_src, int w, int h, int sstride, size_t simg_stride, uint8_t *pyr,
-                        size_t pyr_stride, int dpitch, int batch, hipStream_t st)
-{
-    dim3 blk(64), grd((w / 4 + 64) / 64, h, batch);
-    hipLaunchKernelGGL(copy_level0_kernel, grd, blk, 0, st, d_src, w, h, sstride, simg_stride, pyr, pyr_stride, dpitch);
-}
-
 void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
                    const int *yab, int batch, hipStream_t st)
