@@ -61,6 +61,7 @@ struct Plan {
     std::vector<int> level_cell_begin;
     std::vector<int> xofs, xab, yofs, yab;
     size_t pyr_bytes = 0;      // one image's pyramid block
+    size_t oct_cand_total = 0, oct_node_total = 0;  // octree scratch per image
     size_t slot_total = 0;     // candidate slots per image
     int max_cw = 0, max_ch = 0;
     int TP = 0, TH = 0, SP = 0;
@@ -93,7 +94,6 @@ struct aos2_extractor {
     unsigned long long umax_nibbles = 0;
     bool host_octree = false;
     int host_threads = 8;
-    int max_cand = 16384;
 
     bool dev_ready = false;
     hipStream_t stream = nullptr;       // = streams[0]
@@ -117,7 +117,6 @@ struct aos2_extractor {
     DevBuf<uint8_t> o_sc;
     DevBuf<int32_t> o_perm, o_tmp, o_pairs, o_idx;
     DevBuf<OctNode> o_nodes;
-    int o_max_nodes = 0;
     // host mirrors
     PinnedBuf<int32_t> h_level_off, h_sel_cnt, h_nout;
     PinnedBuf<uint32_t> h_dense, h_sel;
@@ -309,6 +308,18 @@ static int build_plan(aos2_extractor *e, int w, int h)
     }
     P.pyr_bytes = off;
     P.slot_total = (slot + 63) & ~(size_t)63;
+    for (int l = 0; l < e->nlevels; ++l) {
+        LevelDev &L = P.levels[l];
+        size_t cap = 0;
+        const int c1 = l + 1 < e->nlevels ? P.level_cell_begin[l + 1] : (int)P.cells.size();
+        for (int c = P.level_cell_begin[l]; c < c1; ++c) cap += (size_t)((P.cells[c].cw + 1) / 2) * ((P.cells[c].ch + 1) / 2);
+        L.oct_cand_off = (int)P.oct_cand_total;
+        L.oct_cand_cap = (int)cap;
+        P.oct_cand_total += (cap + 63) & ~(size_t)63;
+        L.oct_node_off = (int)P.oct_node_total;
+        L.oct_node_cap = oct_max_nodes((int)cap, L.nfeat);
+        P.oct_node_total += (size_t)L.oct_node_cap;
+    }
     // LDS tile: [4-byte left halo | nq quads | 4-byte right halo] per row, evaluated column 0 at byte 4
     P.TP = 4 * ((P.max_cw + 3) / 4) + 8;
     P.TH = P.max_ch + 6;
@@ -388,15 +399,14 @@ static int ensure_batch(aos2_extractor *e, int batch)
     if ((st = e->h_nout.alloc(batch))) return st;
     if (!e->host_octree) {
         const size_t jobs = (size_t)L * batch;
-        e->o_max_nodes = oct_max_nodes(e->max_cand, e->cap_level);
-        if ((st = e->o_xs.alloc(jobs * e->max_cand))) return st;
-        if ((st = e->o_ys.alloc(jobs * e->max_cand))) return st;
-        if ((st = e->o_sc.alloc(jobs * e->max_cand))) return st;
-        if ((st = e->o_perm.alloc(jobs * e->max_cand))) return st;
-        if ((st = e->o_tmp.alloc(jobs * e->max_cand))) return st;
-        if ((st = e->o_pairs.alloc(jobs * 4 * e->o_max_nodes))) return st;
+        if ((st = e->o_xs.alloc(P.oct_cand_total * batch))) return st;
+        if ((st = e->o_ys.alloc(P.oct_cand_total * batch))) return st;
+        if ((st = e->o_sc.alloc(P.oct_cand_total * batch))) return st;
+        if ((st = e->o_perm.alloc(P.oct_cand_total * batch))) return st;
+        if ((st = e->o_tmp.alloc(P.oct_cand_total * batch))) return st;
+        if ((st = e->o_pairs.alloc(P.oct_node_total * 4 * batch))) return st;
         if ((st = e->o_idx.alloc(jobs * e->cap_level))) return st;
-        if ((st = e->o_nodes.alloc(jobs * e->o_max_nodes))) return st;
+        if ((st = e->o_nodes.alloc(P.oct_node_total * batch))) return st;
     } else {
         if ((st = e->h_sel.alloc((size_t)L * e->cap_level * batch))) return st;
     }
@@ -529,11 +539,10 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
             int st2 = octree_on_host(e, nb);
             if (st2) return st2;
         } else {
-            const size_t j0 = (size_t)b0 * L;
-            OctDevScratch scr{e->o_xs.p + j0 * e->max_cand, e->o_ys.p + j0 * e->max_cand, e->o_sc.p + j0 * e->max_cand,
-                              e->o_perm.p + j0 * e->max_cand, e->o_tmp.p + j0 * e->max_cand,
-                              e->o_pairs.p + j0 * 4 * e->o_max_nodes, e->o_idx.p + j0 * e->cap_level,
-                              e->o_nodes.p + j0 * e->o_max_nodes, e->max_cand, e->o_max_nodes};
+            const size_t j0 = (size_t)b0 * L, c0 = (size_t)b0 * P.oct_cand_total, n0 = (size_t)b0 * P.oct_node_total;
+            OctDevScratch scr{e->o_xs.p + c0, e->o_ys.p + c0, e->o_sc.p + c0, e->o_perm.p + c0, e->o_tmp.p + c0,
+                              e->o_pairs.p + 4 * n0, e->o_idx.p + j0 * e->cap_level, e->o_nodes.p + n0,
+                              P.oct_cand_total, P.oct_node_total};
             launch_octree(dense, P.slot_total, level_off, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level, sel_cnt,
                           e->cap_level, s);
         }
@@ -559,7 +568,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
     for (int i = 0; i < L * batch; ++i) {
         if (e->h_sel_cnt.p[i] < 0) {
             set_error("octree stage failed for image %d level %d (code %d: %s)", i / L, i % L, e->h_sel_cnt.p[i],
-                      e->h_sel_cnt.p[i] == -4 ? "more FAST candidates than AOS2_MAX_CAND" : "scratch exhausted");
+                      e->h_sel_cnt.p[i] == -4 ? "candidate capacity exceeded" : "node arena exhausted");
             return AOS2_ERR_CAPACITY;
         }
     }
@@ -615,7 +624,6 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     const unsigned hc = std::thread::hardware_concurrency();
     e->host_threads = (int)std::min(32u, std::max(1u, hc));
     if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));
-    if (const char *v = getenv("AOS2_MAX_CAND")) e->max_cand = std::max(1024, atoi(v));
     if (const char *v = getenv("AOS2_CHUNKS")) e->chunks = std::max(0, std::min(kMaxStreams, atoi(v)));
     *out = e;
     return AOS2_OK;

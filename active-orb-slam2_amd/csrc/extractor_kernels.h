@@ -16,6 +16,10 @@ struct LevelDev {
     int nfeat;            // mnFeaturesPerLevel[level]
     int scaled_patch;     // (int)(31 * scale[level])
     float scale;          // mvScaleFactor[level]
+    // octree scratch of this level inside one image's scratch block (sized for the theoretical
+    // maximum of NMS survivors, so no input can overflow it)
+    int oct_cand_off, oct_cand_cap;   // in candidates
+    int oct_node_off, oct_node_cap;   // in OctNode
 };
 
 struct CellDev {
@@ -33,7 +37,7 @@ struct OctDevScratch {
     uint8_t *sc;
     int32_t *perm, *tmp, *pairs, *out_idx;
     OctNode *nodes;
-    int max_cand, max_nodes;
+    size_t cand_stride, node_stride;  // per image
 };
 
 int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st);

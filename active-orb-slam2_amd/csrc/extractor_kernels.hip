@@ -398,11 +398,13 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
     const int32_t *lo = level_off + (size_t)b * (n_levels + 1);
     const int beg = lo[l], n = lo[l + 1] - lo[l];
     const uint32_t *cand = dense + (size_t)b * dense_stride + beg;
-    int16_t *xs = scr.xs + (size_t)job * scr.max_cand;
-    int16_t *ys = scr.ys + (size_t)job * scr.max_cand;
-    uint8_t *sc = scr.sc + (size_t)job * scr.max_cand;
+    const LevelDev lv = levels[l];
+    const size_t co = (size_t)b * scr.cand_stride + lv.oct_cand_off, no = (size_t)b * scr.node_stride + lv.oct_node_off;
+    int16_t *xs = scr.xs + co;
+    int16_t *ys = scr.ys + co;
+    uint8_t *sc = scr.sc + co;
     uint32_t *out = sel + (size_t)b * sel_stride + (size_t)l * cap_level;
-    if (n > scr.max_cand) {
+    if (n > lv.oct_cand_cap) {  // cannot happen: the capacity is the geometric maximum of NMS survivors
         if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = -4;
         return;
     }
@@ -416,14 +418,13 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
     int nk = 0;
     if (n > 0) {
         OctScratch S;
-        S.nodes = scr.nodes + (size_t)job * scr.max_nodes;
-        S.perm = scr.perm + (size_t)job * scr.max_cand;
-        S.tmp = scr.tmp + (size_t)job * scr.max_cand;
-        S.pairs_a = scr.pairs + (size_t)job * 4 * scr.max_nodes;
-        S.pairs_b = S.pairs_a + 2 * scr.max_nodes;
-        S.max_nodes = scr.max_nodes;
+        S.nodes = scr.nodes + no;
+        S.perm = scr.perm + co;
+        S.tmp = scr.tmp + co;
+        S.pairs_a = scr.pairs + 4 * no;
+        S.pairs_b = S.pairs_a + 2 * (size_t)lv.oct_node_cap;
+        S.max_nodes = lv.oct_node_cap;
         int32_t *idx = scr.out_idx + (size_t)job * cap_level;
-        const LevelDev lv = levels[l];
         nk = distribute_octree<WaveCoop>(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
         for (int k = lane; k < nk; k += 64) out[k] = cand[idx[k]];
     }

@@ -62,6 +62,14 @@ def test_edge_cases(pkg, oracle, gpu):
     assert same(ex(low), oracle.Extractor().extract(low))
     sat = np.where(pkg.synth.synth_image(10) > 128, 255, 0).astype(np.uint8)  # saturated scores
     assert same(ex(sat), oracle.Extractor().extract(sat))
+    # maximum-density inputs: far more FAST candidates than a natural image (scratch is sized for the
+    # geometric maximum, nothing may overflow)
+    rng = np.random.default_rng(7)
+    noise = (rng.integers(0, 2, (480, 640)) * 255).astype(np.uint8)
+    assert same(ex(noise), oracle.Extractor().extract(noise))
+    yy, xx = np.mgrid[0:480, 0:640]
+    checker = (((xx // 3) + (yy // 3)) % 2 * 200 + 20).astype(np.uint8)
+    assert same(ex(checker), oracle.Extractor().extract(checker))
     # non-contiguous rows (stride > width) and odd sizes
     big = np.zeros((333, 700), np.uint8)
     big[:, :517] = pkg.synth.synth_image(11, 517, 333)
