@@ -404,12 +404,14 @@ __global__ void k_schur_init(LbaAct A, double lambda)
 }
 
 // per landmark: Dinv = (Hll + lambda I)^-1, db, coefficients, Hschur(i1,i2) -= B_i1 Dinv B_i2^T
-// one wave per landmark; lanes enumerate the (a <= b) pairs of its free-pose column
-__global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
+// (block_solver.hpp:379-432).  Each single-wave workgroup owns a private copy of the reduced system
+// in LDS and folds a fixed, strided subset of the landmarks into it: the lanes of one instruction
+// touch distinct (i1,i2) blocks (a landmark is seen once per keyframe), so plain LDS
+// read-modify-writes suffice -- no atomics, and the summation order is fixed (bit-reproducible).
+// The partial matrices are then summed in a fixed order by k_schur_reduce.
+__device__ __forceinline__ void schur_point(const LbaAct &A, int l, double lambda, int n6, int lane, double *Msh,
+                                            double *csh, bool to_lds)
 {
-    const int l = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int n6 = 6 * A.np;
     double D[9], Dinv[9];
     for (int i = 0; i < 9; ++i) D[i] = A.Hll[9 * (size_t)l + i];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
@@ -420,19 +422,22 @@ __global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
     if (lane == 0)
         for (int i = 0; i < 9; ++i) A.Dinv[9 * (size_t)l + i] = Dinv[i];
     const int c0 = A.pl_off[l], m = A.pl_off[l + 1] - c0;
-    // coefficients
     for (int a = lane; a < m; a += 64) {
         const int ka = A.pl_k[c0 + a];
         const int i1 = A.k_ph[ka];
         const double *Bi = A.Hpl + 18 * (size_t)ka;
-        for (int r = 0; r < 6; ++r)
-            atomicAdd(&A.coeff[6 * i1 + r], Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2]);
+        for (int r = 0; r < 6; ++r) {
+            const double v = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+            if (to_lds)
+                csh[6 * i1 + r] += v;
+            else
+                atomicAdd(&A.coeff[6 * i1 + r], v);
+        }
     }
     const int npairs = m * (m + 1) / 2;
     for (int t = lane; t < npairs; t += 64) {
-        // t -> (a, b) with a <= b, row-major over the upper triangle
         int a = 0, rem = t;
-        while (rem >= m - a) {
+        while (rem >= m - a) {  // t -> (a, b) with a <= b, row-major over the upper triangle
             rem -= m - a;
             ++a;
         }
@@ -446,9 +451,69 @@ __global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
         for (int r = 0; r < 6; ++r)
             for (int c = 0; c < 6; ++c) {
                 const double v = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
-                atomicAdd(&A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c], -v);
+                if (to_lds)
+                    Msh[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] -= v;
+                else
+                    atomicAdd(&A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c], -v);
             }
     }
+}
+
+// LDS variant: grid = G single-wave workgroups, partial[g] = contribution of landmarks g, g+G, ...
+__global__ __launch_bounds__(64) void k_schur_partial(LbaAct A, double lambda, double *partial, int G)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n6 = 6 * A.np, lane = threadIdx.x;
+    const int tot = n6 * n6 + n6;
+    for (int i = lane; i < tot; i += 64) sm[i] = 0.0;
+    __syncthreads();
+    for (int l = blockIdx.x; l < A.nl; l += G) {
+        schur_point(A, l, lambda, n6, lane, sm, sm + (size_t)n6 * n6, true);
+        __syncthreads();
+    }
+    double *out = partial + (size_t)blockIdx.x * tot;
+    for (int i = lane; i < tot; i += 64) out[i] = sm[i];
+}
+
+// Hschur = Hpp (+lambda) + sum_g partial[g] (upper block triangle, mirrored); bschur = b - sum_g coeff[g]
+// 32 elements x 8 partial-sum slices per workgroup, fixed summation order (bit-reproducible)
+__global__ __launch_bounds__(256) void k_schur_reduce(LbaAct A, double lambda, const double *partial, int G)
+{
+    __shared__ double sh[8][33];
+    const int n6 = 6 * A.np, tot = n6 * n6 + n6;
+    const int el = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + el;
+    double acc = 0;
+    if (i < tot) {
+        const int gper = (G + 7) >> 3;
+        const int g0 = part * gper, g1 = min(G, g0 + gper);
+        for (int g = g0; g < g1; ++g) acc += partial[(size_t)g * tot + i];
+    }
+    sh[part][el] = acc;
+    __syncthreads();
+    if (part != 0 || i >= tot) return;
+    double v = sh[0][el];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v += sh[p][el];
+    if (i < n6 * n6) {
+        const int r = i / n6, c = i - r * n6;
+        if (c / 6 < r / 6) return;  // lower block triangle is the mirror image
+        if (r / 6 == c / 6) {
+            v += A.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + (c % 6)];
+            if (r == c) v += lambda;
+        }
+        A.Hs[i] = v;
+        if (c > r) A.Hs[(size_t)c * n6 + r] = v;
+    } else {
+        const int j = i - n6 * n6;
+        A.bs[j] = A.b[j] - v;
+    }
+}
+
+// fallback for reduced systems too large for LDS (> 22 free keyframes): f64 atomics in global memory
+__global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
+{
+    schur_point(A, blockIdx.x, lambda, 6 * A.np, threadIdx.x, nullptr, nullptr, false);
 }
 
 // bschur = b_p - coefficients ; mirror the upper block triangle into the lower one
@@ -473,47 +538,80 @@ __global__ void k_schur_finish(LbaAct A)
 // npad^2 * 8 B fits (npad <= 128, i.e. <= 21 free keyframes), otherwise in a global scratch.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_lds, double *gscratch)
+// value of `v` in lane `src` (wave-uniform index), uniform result
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *gscratch)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = 6 * A.np;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *M = use_lds ? sm : gscratch;                 // npad x npad (lower triangle is used)
-    double *W = use_lds ? sm + (size_t)npad * npad : gscratch + (size_t)npad * npad;   // npad x 16
-    double *dvec = W + (size_t)npad * 16;                // npad
+    // odd leading dimensions: column-direction accesses (panel rows, MFMA operands, substitution)
+    // then fall on distinct LDS banks instead of one
+    const int ld = npad + 1, lw = 17;
+    // kLds: the pointers below derive from the LDS array only, so the compiler emits ds_* accesses
+    // (a runtime-selected pointer would turn every access into a slow flat_* instruction)
+    double *M = kLds ? sm : gscratch;                    // npad x ld (lower triangle is used)
+    double *W = M + (size_t)npad * ld;                   // npad x lw
+    double *dvec = W + (size_t)npad * lw;                // npad
     double *ccol = dvec + npad;                          // 16
     volatile int *failp = reinterpret_cast<volatile int *>(ccol + 16);  // kept in the dynamic region (LDS base alignment)
     if (tid == 0) *failp = 0;
-    for (int idx = tid; idx < npad * npad; idx += 256) {
-        const int r = idx / npad, c = idx - r * npad;
-        M[idx] = (r < n && c < n) ? A.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+    // load (identity-padded): 8 independent global loads in flight per thread before the LDS stores
+    for (int r0 = tid >> 5; r0 < npad; r0 += 64) {
+        for (int c = tid & 31; c < npad; c += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 8 * u;
+                v[u] = (r < n && c < n) ? A.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 8 * u;
+                if (r < npad) M[(size_t)r * ld + c] = v[u];
+            }
+        }
     }
     __syncthreads();
     const int nb = npad >> 4;
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb << 4;
-        // ---- (1) diagonal block, wave 0
+        // ---- (1) diagonal block, wave 0: lane i < 16 keeps row i of the block in registers; the
+        // pivot and the column entries travel through v_readlane (SGPR broadcast), no LDS round trips
         if (wave == 0) {
+            double row[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = lane < 16 ? M[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
+            bool bad = false;
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double dj = M[(size_t)(k0 + j) * npad + k0 + j];
-                if (dj == 0.0 || dj != dj) {
-                    if (lane == 0) *failp = 1;
-                    break;
+                const double dj = readlane_f64(row[j], j);
+                if (dj == 0.0 || dj != dj) bad = true;
+                if (!bad) {
+                    const double ci = row[j];
+                    const double lij = ci / dj;
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) {
+                        const double ck = readlane_f64(ci, k);
+                        if (lane > j && k <= lane) row[k] -= lij * ck;
+                    }
+                    if (lane > j) row[j] = lij;
+                    if (lane == 0) dvec[k0 + j] = dj;
                 }
-                if (lane < 16 && lane > j) {
-                    const double c = M[(size_t)(k0 + lane) * npad + k0 + j];
-                    ccol[lane] = c;
-                    M[(size_t)(k0 + lane) * npad + k0 + j] = c / dj;
-                }
-                if (lane == 0) dvec[k0 + j] = dj;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                for (int idx = lane; idx < 256; idx += 64) {
-                    const int i = idx >> 4, k = idx & 15;
-                    if (k > j && k <= i) M[(size_t)(k0 + i) * npad + k0 + k] -= M[(size_t)(k0 + i) * npad + k0 + j] * ccol[k];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            }
+            if (bad && lane == 0) *failp = 1;
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= lane) M[(size_t)(k0 + lane) * ld + k0 + c] = row[c];
             }
         }
         __syncthreads();
@@ -523,14 +621,14 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_
             double w[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                double sacc = M[(size_t)i * npad + k0 + c];
+                double sacc = M[(size_t)i * ld + k0 + c];
 #pragma unroll
-                for (int m = 0; m < c; ++m) sacc -= w[m] * M[(size_t)(k0 + c) * npad + k0 + m];
+                for (int m = 0; m < c; ++m) sacc -= w[m] * M[(size_t)(k0 + c) * ld + k0 + m];
                 w[c] = sacc;
-                M[(size_t)i * npad + k0 + c] = sacc / dvec[k0 + c];
+                M[(size_t)i * ld + k0 + c] = sacc / dvec[k0 + c];
             }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) W[(size_t)i * 16 + c] = w[c];
+            for (int c = 0; c < 16; ++c) W[(size_t)i * lw + c] = w[c];
         }
         __syncthreads();
         // ---- (3) trailing update with f64 MFMA, lower-triangle tiles (I >= J > kb)
@@ -546,15 +644,15 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_
             double4_t acc;
             const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * npad + J0 + col];
+            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const double av = -W[(size_t)(I0 + col) * 16 + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
-                const double bv = M[(size_t)(J0 + col) * npad + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
+                const double av = -W[(size_t)(I0 + col) * lw + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
+                const double bv = M[(size_t)(J0 + col) * ld + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * npad + J0 + col] = acc[r];
+            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
         }
         __syncthreads();
     }
@@ -574,11 +672,11 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_
         for (int ks = 0; ks < 4; ++ks) {  // forward: y_i -= L[i][k] y_k
             for (int kl = 0; kl < 64 && ks * 64 + kl < npad; ++kl) {
                 const int k = ks * 64 + kl;
-                const double yk = __shfl(xv[ks], kl);
+                const double yk = readlane_f64(xv[ks], kl);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int i = lane + 64 * s;
-                    if (i > k && i < npad) xv[s] -= M[(size_t)i * npad + k] * yk;
+                    if (i > k && i < npad) xv[s] -= M[(size_t)i * ld + k] * yk;
                 }
             }
         }
@@ -592,11 +690,11 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, int use_
             for (int kl = 63; kl >= 0; --kl) {
                 const int k = ks * 64 + kl;
                 if (k >= npad) continue;
-                const double xk = __shfl(xv[ks], kl);
+                const double xk = readlane_f64(xv[ks], kl);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int i = lane + 64 * s;
-                    if (i < k) xv[s] -= M[(size_t)k * npad + i] * xk;
+                    if (i < k) xv[s] -= M[(size_t)k * ld + i] * xk;
                 }
             }
         }
@@ -678,13 +776,19 @@ struct aos2_lba {
 
 namespace aos2 {
 
+constexpr int kSchurGroups = 256;  // single-wave workgroups folding landmarks into private LDS copies
+
 struct HostArena {
-    std::vector<uint8_t> host;
+    std::vector<uint8_t> host;  // staged inputs (a prefix of the arena)
+    size_t size = 0;            // total arena size including device-only scratch
     size_t push(const void *src, size_t bytes)
     {
-        const size_t off = (host.size() + 255) & ~(size_t)255;
-        host.resize(off + bytes);
-        if (src && bytes) memcpy(host.data() + off, src, bytes);
+        const size_t off = (size + 255) & ~(size_t)255;
+        size = off + bytes;
+        if (src && bytes) {  // inputs are pushed before any scratch, so `host` stays a prefix
+            host.resize(size);
+            memcpy(host.data() + off, src, bytes);
+        }
         return off;
     }
 };
@@ -698,7 +802,8 @@ static int lba_init(aos2_lba *s)
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     if ((st = s->h_scal.alloc(8))) return st;
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_partial, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -880,12 +985,13 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
     const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
     const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, 64);
+    const size_t o_partial = H.push(nullptr, (size_t)kSchurGroups * (n6max * n6max + n6max) * 8 + 8);
     const size_t npad_max = (n6max + 15) & ~(size_t)15;
-    const size_t o_ldlt = H.push(nullptr, (npad_max * npad_max + npad_max * 16 + npad_max + 64) * 8);
-    if ((st = s->arena.alloc(H.host.size() + 256))) return st;
+    const size_t o_ldlt = H.push(nullptr, (npad_max * (npad_max + 1) + npad_max * 17 + npad_max + 64) * 8);
+    if ((st = s->arena.alloc(H.size + 256))) return st;
     uint8_t *base = s->arena.p;
     hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), o_err, hipMemcpyHostToDevice, q));  // inputs only
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), std::min(H.host.size(), o_err), hipMemcpyHostToDevice, q));  // inputs only
     AOS2_HIP_CHECK(hipMemsetAsync(base + o_err, 0, (size_t)E * 3 * 8, q));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
 
@@ -902,6 +1008,7 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     D.cam.delta_stereo = (double)(float)std::sqrt(7.815);
     double *d_bkpose = (double *)(base + o_bkpose), *d_bkpoint = (double *)(base + o_bkpoint);
     double *d_scal = (double *)(base + o_scal);
+    double *d_partial = (double *)(base + o_partial);
     double *hs = s->h_scal.p;
 
     LbaAct A{};
@@ -947,10 +1054,16 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     double lambda = 0, ni = 2, last_chi = 0;
     int nBad = 0;
     // OptimizationAlgorithmLevenberg::solve (levenberg.cpp:61-164)
+    bool errors_fresh = false;  // err[] and last_chi belong to the current estimates
     auto lm_solve = [&](int iteration, int &result) -> int {
-        double currentChi = 0;
-        int rc = errors_chi2(&currentChi);
-        if (rc) return rc;
+        double currentChi = last_chi;
+        int rc = AOS2_OK;
+        // computeActiveErrors at the top of solve() (levenberg.cpp:75): recomputing at unchanged
+        // estimates reproduces the values of the accepted trial bit for bit, so it is skipped then
+        if (!errors_fresh || iteration == 0) {
+            rc = errors_chi2(&currentChi);
+            if (rc) return rc;
+        }
         double tempChi = currentChi;
         const double iniChi = currentChi;
         const int dim = 6 * A.np + 3 * A.nl, n6 = 6 * A.np;
@@ -976,19 +1089,28 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
             // setLambda + Schur solve (the diagonal is never modified in place: lambda is added
             // where Hpp / Hll are consumed, which is what restoreDiagonal undoes in g2o)
             if (n6 > 0) {
-                hipLaunchKernelGGL(k_schur_init, blocks(n6 * n6, 256), dim3(256), 0, q, A, lambda);
-                hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);
-                hipLaunchKernelGGL(k_schur_finish, blocks(n6 * n6, 256), dim3(256), 0, q, A);
+                const size_t sch_lds = ((size_t)n6 * n6 + n6) * sizeof(double);
+                if (sch_lds <= 150 * 1024) {
+                    const int G = std::min(kSchurGroups, A.nl);
+                    hipLaunchKernelGGL(k_schur_partial, dim3(G), dim3(64), sch_lds, q, A, lambda, d_partial, G);
+                    hipLaunchKernelGGL(k_schur_reduce, blocks(n6 * n6 + n6, 32), dim3(256), 0, q, A, lambda, d_partial, G);
+                } else {
+                    hipLaunchKernelGGL(k_schur_init, blocks(n6 * n6, 256), dim3(256), 0, q, A, lambda);
+                    hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);
+                    hipLaunchKernelGGL(k_schur_finish, blocks(n6 * n6, 256), dim3(256), 0, q, A);
+                }
                 {
                     const int npad = (n6 + 15) & ~15;
                     if (npad > 256) {
                         set_error("reduced camera system of dimension %d exceeds 256 (more than 42 free keyframes)", n6);
                         return AOS2_ERR_ARG;
                     }
-                    const size_t need = ((size_t)npad * npad + (size_t)npad * 16 + npad + 64) * sizeof(double);
-                    const int use_lds = need <= 150 * 1024 ? 1 : 0;
-                    hipLaunchKernelGGL(k_ldlt_solve, dim3(1), dim3(256), use_lds ? need : 0, q, A, npad, use_lds,
-                                       (double *)(base + o_ldlt));
+                    const size_t need = ((size_t)npad * (npad + 1) + (size_t)npad * 17 + npad + 64) * sizeof(double);
+                    const int use_lds = need <= 160 * 1024 ? 1 : 0;
+                    if (use_lds)
+                        hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(1), dim3(256), need, q, A, npad, (double *)(base + o_ldlt));
+                    else
+                        hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(1), dim3(256), 0, q, A, npad, (double *)(base + o_ldlt));
                 }
                 hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
             } else {
@@ -1012,7 +1134,9 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
                 lambda *= scaleFactor;
                 ni = 2;
                 currentChi = tempChi;
+                errors_fresh = true;
             } else {
+                errors_fresh = false;
                 lambda *= ni;
                 ni *= 2;
                 // pop
