@@ -91,6 +91,10 @@ def lib():
             L.aos2_lba_create.argtypes = [ci, C.POINTER(vp)]
             L.aos2_lba_destroy.argtypes = [vp]
             L.aos2_lba_solve.argtypes = [vp, vp, vp]
+            if hasattr(L, "aos2_pose_optimization"):
+                L.aos2_pose_optimization.argtypes = [vp, vp, vp, ci]
+                L.aos2_pose_optimization_last_device_ms.argtypes = [vp]
+                L.aos2_pose_optimization_last_device_ms.restype = cf
         _LIB = L
     return _LIB
 
@@ -414,6 +418,16 @@ class _LbaResult(C.Structure):
                 ("final_chi2", C.c_double), ("final_lambda", C.c_double), ("ms_device", C.c_float)]
 
 
+class _PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("stereo", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("bf", C.c_float), ("Tcw", C.c_float * 16)]
+
+
+class _PoseResult(C.Structure):
+    _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_bad", C.c_int32), ("n_inliers", C.c_int32)]
+
+
 class LocalBA:
     """Optimizer::LocalBundleAdjustment numerical part (include/Optimizer.h:45, src/Optimizer.cc:454-779)."""
 
@@ -456,3 +470,33 @@ class LocalBA:
         return dict(status=st, pose_Tcw=Tout, point_xyz=Pout, edge_outlier=outl, edge_chi2=chi2,
                     iters=(r.iters_done_first, r.iters_done_second), final_chi2=r.final_chi2,
                     final_lambda=r.final_lambda, ms_device=r.ms_device)
+
+
+    def PoseOptimization(self, problems):
+        """int Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:239-452) for one dict or a list of
+        synth_pose_problem()-style dicts (one workgroup per frame, one launch)."""
+        single = isinstance(problems, dict)
+        if single:
+            problems = [problems]
+        keep = []
+        P = (_PoseProblem * len(problems))()
+        R = (_PoseResult * len(problems))()
+        outs = []
+        for i, p in enumerate(problems):
+            P[i].n = int(p["n"])
+            for name, dt in (("Xw", np.float32), ("obs", np.float32), ("stereo", np.uint8), ("inv_sigma2", np.float32)):
+                a = np.ascontiguousarray(p[name], dt)
+                keep.append(a)
+                setattr(P[i], name, a.ctypes.data)
+            P[i].fx, P[i].fy, P[i].cx, P[i].cy, P[i].bf = (float(np.float32(p[k])) for k in ("fx", "fy", "cx", "cy", "bf"))
+            P[i].Tcw = (C.c_float * 16)(*[float(x) for x in np.asarray(p["Tcw"], np.float32).reshape(-1)])
+            o = np.zeros(max(P[i].n, 1), np.uint8)
+            outs.append(o)
+            R[i].outlier = o.ctypes.data
+        _check(self.L.aos2_pose_optimization(self.h, C.byref(P), C.byref(R), len(problems)))
+        res = [dict(n_inliers=R[i].n_inliers, n_bad=R[i].n_bad, outlier=outs[i][: P[i].n].copy(),
+                    Tcw=np.array(list(R[i].Tcw), np.float32)) for i in range(len(problems))]
+        return res[0] if single else res
+
+    def pose_last_device_ms(self):
+        return float(self.L.aos2_pose_optimization_last_device_ms(self.h))

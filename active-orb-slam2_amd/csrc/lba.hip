@@ -761,6 +761,302 @@ __global__ void k_edge_check(LbaDev P, int mark_level1, double *chi2_out, uint8_
     if (outlier_out) outlier_out[e] = bad ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization (src/Optimizer.cc:239-452): one workgroup per frame, the complete
+// procedure on the device (no host round trips): residuals + Huber, EdgeSE3ProjectXYZOnlyPose /
+// EdgeStereoSE3ProjectXYZOnlyPose Jacobians (types_six_dof_expmap.cpp:266-364), 6x6 normal
+// equations by a fixed-order workgroup reduction, Cholesky, exp-map update, the Levenberg
+// accept/reject logic (levenberg.cpp:61-164) and the outlier reclassification of :371-430.
+// ---------------------------------------------------------------------------------------------
+struct PoseProbDev {
+    int n;
+    const double *Xw, *obs;       // n x 3
+    const double *w;              // n
+    const uint8_t *stereo;        // n
+    double *err;                  // n x 3 scratch
+    uint8_t *level1, *robust;     // n scratch
+    uint8_t *outlier;             // n out
+    double fx, fy, cx, cy, bf;
+    double pose_in[7];
+    double *pose_out;             // 7
+    int32_t *counts;              // [0] n_bad, [1] n_inliers
+};
+
+__device__ __forceinline__ void po_edge_error(const double *qt, const double *X, const double *obs, int stereo,
+                                              const PoseProbDev &P, double er[3])
+{
+    double p[3];
+    se3_map(qt, X, p);
+    if (!stereo) {
+        const double u = p[0] / p[2], v = p[1] / p[2];
+        er[0] = obs[0] - (u * P.fx + P.cx);
+        er[1] = obs[1] - (v * P.fy + P.cy);
+        er[2] = 0;
+    } else {
+        const float invz = (float)(1.0 / p[2]);
+        const double r0 = p[0] * invz * P.fx + P.cx;
+        const double r1 = p[1] * invz * P.fy + P.cy;
+        const double r2 = r0 - P.bf * invz;
+        er[0] = obs[0] - r0;
+        er[1] = obs[1] - r1;
+        er[2] = obs[2] - r2;
+    }
+}
+
+// fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) */, double *out)
+{
+    const int tid = threadIdx.x;
+    for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] = v[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+            for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] += sh[(tid + s) * (K + 1) + i];
+        __syncthreads();
+    }
+    for (int i = 0; i < K; ++i) out[i] = sh[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28
+    __shared__ double qt[7], bk[7], xs[6];
+    __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
+    __shared__ int s_flag;
+    const PoseProbDev P = probs[blockIdx.x];
+    const int tid = threadIdx.x, n = P.n;
+    for (int e = tid; e < n; e += 256) {
+        P.level1[e] = 0;
+        P.robust[e] = 1;
+        P.outlier[e] = 0;
+        P.err[3 * e] = P.err[3 * e + 1] = P.err[3 * e + 2] = 0;
+    }
+    if (tid < 7) qt[tid] = P.pose_in[tid];
+    __syncthreads();
+    if (n < 3) {  // nInitialCorrespondences < 3 (:355-356)
+        if (tid < 7) P.pose_out[tid] = P.pose_in[tid];
+        if (tid == 0) { P.counts[0] = 0; P.counts[1] = 0; }
+        return;
+    }
+    const double delta_m = (double)(float)sqrt(5.991), delta_s = (double)(float)sqrt(7.815);
+    int nBad = 0;
+    // residuals of the active edges + robust chi2 (computeActiveErrors + activeRobustChi2)
+    auto errors_chi2 = [&](double &chi_out) {
+        double acc[1] = {0};
+        for (int e = tid; e < n; e += 256) {
+            if (P.level1[e]) continue;
+            double er[3];
+            const int st = P.stereo[e];
+            po_edge_error(qt, P.Xw + 3 * e, P.obs + 3 * e, st, P, er);
+            P.err[3 * e] = er[0]; P.err[3 * e + 1] = er[1]; P.err[3 * e + 2] = er[2];
+            double c = edge_chi2(er, P.w[e], st ? 3 : 2);
+            if (P.robust[e]) {
+                double rho[2];
+                robustify(c, st ? delta_s : delta_m, rho);
+                c = rho[0];
+            }
+            acc[0] += c;
+        }
+        double out[1];
+        block_sum<1>(acc, sh, out);
+        chi_out = out[0];
+    };
+    for (int it = 0; it < 4; ++it) {
+        if (tid < 7) qt[tid] = P.pose_in[tid];  // every round restarts from pFrame->mTcw (:368)
+        __syncthreads();
+        int n_active = 0;
+        {
+            double cnt[1] = {0}, out[1];
+            for (int e = tid; e < n; e += 256) cnt[0] += P.level1[e] ? 0.0 : 1.0;
+            block_sum<1>(cnt, sh, out);
+            n_active = (int)out[0];
+        }
+        if (n_active > 0) {
+            int nBadLM = 0;
+            bool ok = true;
+            for (int i = 0; i < 10 && ok; ++i) {
+                double currentChi;
+                errors_chi2(currentChi);
+                const double iniChi = currentChi;
+                // buildSystem: H (upper triangle, 21) + b (6)
+                double acc[27];
+                for (int k = 0; k < 27; ++k) acc[k] = 0;
+                for (int e = tid; e < n; e += 256) {
+                    if (P.level1[e]) continue;
+                    const int st = P.stereo[e], D = st ? 3 : 2;
+                    double p[3];
+                    se3_map(qt, P.Xw + 3 * e, p);
+                    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+                    double J[18];
+                    J[0] = x * y * invz_2 * P.fx;
+                    J[1] = -(1 + (x * x * invz_2)) * P.fx;
+                    J[2] = y * invz * P.fx;
+                    J[3] = -invz * P.fx;
+                    J[4] = 0;
+                    J[5] = x * invz_2 * P.fx;
+                    J[6] = (1 + y * y * invz_2) * P.fy;
+                    J[7] = -x * y * invz_2 * P.fy;
+                    J[8] = -x * invz * P.fy;
+                    J[9] = 0;
+                    J[10] = -invz * P.fy;
+                    J[11] = y * invz_2 * P.fy;
+                    J[12] = J[0] - P.bf * y * invz_2;
+                    J[13] = J[1] + P.bf * x * invz_2;
+                    J[14] = J[2];
+                    J[15] = J[3];
+                    J[16] = 0;
+                    J[17] = J[5] - P.bf * invz_2;
+                    const double *er = P.err + 3 * e;
+                    const double w = P.w[e];
+                    double wo = w, r1 = 1.0;
+                    if (P.robust[e]) {
+                        double rho[2];
+                        robustify(edge_chi2(er, w, D), st ? delta_s : delta_m, rho);
+                        r1 = rho[1];
+                        wo = rho[1] * w;
+                    }
+                    int k = 0;
+                    for (int r = 0; r < 6; ++r) {
+                        double sacc = 0;
+                        for (int d = 0; d < D; ++d) sacc += J[d * 6 + r] * (w * er[d]);
+                        acc[21 + r] -= r1 * sacc;
+                        for (int c = r; c < 6; ++c, ++k) {
+                            double t = 0;
+                            for (int d = 0; d < D; ++d) t += J[d * 6 + r] * wo * J[d * 6 + c];
+                            acc[k] += t;
+                        }
+                    }
+                }
+                double Hb[27];
+                block_sum<27>(acc, sh, Hb);
+                if (tid == 0) {
+                    if (i == 0) {
+                        double maxDiagonal = 0.;
+                        const int di[6] = {0, 6, 11, 15, 18, 20};
+                        for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
+                        s_lambda = 1e-5 * maxDiagonal;
+                        s_ni = 2;
+                    }
+                    s_currentChi = currentChi;
+                }
+                if (i == 0) nBadLM = 0;
+                __syncthreads();
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    if (tid == 0) {
+                        for (int k = 0; k < 7; ++k) bk[k] = qt[k];
+                        // (H + lambda I) x = b by Cholesky; "not positive" -> the step is rejected
+                        double L[36];
+                        int k = 0;
+                        for (int r = 0; r < 6; ++r)
+                            for (int c = r; c < 6; ++c, ++k) L[c * 6 + r] = L[r * 6 + c] = Hb[k];
+                        for (int d = 0; d < 6; ++d) L[d * 7] += s_lambda;
+                        bool pos = true;
+                        for (int j = 0; j < 6 && pos; ++j) {
+                            double dd = L[j * 6 + j];
+                            for (int m = 0; m < j; ++m) dd -= L[j * 6 + m] * L[j * 6 + m];
+                            if (!(dd > 0)) { pos = false; break; }
+                            dd = sqrt(dd);
+                            L[j * 6 + j] = dd;
+                            for (int r = j + 1; r < 6; ++r) {
+                                double sacc = L[r * 6 + j];
+                                for (int m = 0; m < j; ++m) sacc -= L[r * 6 + m] * L[j * 6 + m];
+                                L[r * 6 + j] = sacc / dd;
+                            }
+                        }
+                        if (pos) {
+                            double yv[6];
+                            for (int r = 0; r < 6; ++r) {
+                                double sacc = Hb[21 + r];
+                                for (int m = 0; m < r; ++m) sacc -= L[r * 6 + m] * yv[m];
+                                yv[r] = sacc / L[r * 6 + r];
+                            }
+                            for (int r = 5; r >= 0; --r) {
+                                double sacc = yv[r];
+                                for (int m = r + 1; m < 6; ++m) sacc -= L[m * 6 + r] * xs[m];
+                                xs[r] = sacc / L[r * 6 + r];
+                            }
+                        }
+                        s_flag = pos ? 1 : 0;
+                        double upd[6], T[7];
+                        for (int k2 = 0; k2 < 6; ++k2) upd[k2] = xs[k2];
+                        for (int k2 = 0; k2 < 7; ++k2) T[k2] = qt[k2];
+                        se3_oplus(upd, T);
+                        for (int k2 = 0; k2 < 7; ++k2) qt[k2] = T[k2];
+                    }
+                    __syncthreads();
+                    double tempChi;
+                    errors_chi2(tempChi);
+                    if (tid == 0) {
+                        if (!s_flag) tempChi = 1.7976931348623157e308;
+                        double r = s_currentChi - tempChi;
+                        double scale = 0.;
+                        for (int j = 0; j < 6; ++j) scale += xs[j] * (s_lambda * xs[j] + Hb[21 + j]);
+                        scale += 1e-3;
+                        r /= scale;
+                        if (r > 0 && isfinite(tempChi)) {
+                            double alpha = 1. - pow((2 * r - 1), 3.0);
+                            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
+                            s_lambda *= scaleFactor;
+                            s_ni = 2;
+                            s_currentChi = tempChi;
+                        } else {
+                            s_lambda *= s_ni;
+                            s_ni *= 2;
+                            for (int k = 0; k < 7; ++k) qt[k] = bk[k];
+                        }
+                        s_rho = r;
+                    }
+                    __syncthreads();
+                    rho = s_rho;
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                const double curChi = s_currentChi;
+                if (qmax == 10 || rho == 0) {
+                    ok = false;
+                } else {
+                    if ((iniChi - curChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                    if (nBadLM >= 3) ok = false;
+                }
+                __syncthreads();
+            }
+        }
+        // outlier reclassification (:371-430)
+        double bad[1] = {0}, outb[1];
+        for (int e = tid; e < n; e += 256) {
+            const int st = P.stereo[e];
+            if (P.outlier[e]) {
+                double er[3];
+                po_edge_error(qt, P.Xw + 3 * e, P.obs + 3 * e, st, P, er);
+                P.err[3 * e] = er[0]; P.err[3 * e + 1] = er[1]; P.err[3 * e + 2] = er[2];
+            }
+            const float chi2 = (float)edge_chi2(P.err + 3 * e, P.w[e], st ? 3 : 2);
+            if (chi2 > (st ? 7.815f : 5.991f)) {
+                P.outlier[e] = 1;
+                P.level1[e] = 1;
+                bad[0] += 1.0;
+            } else {
+                P.outlier[e] = 0;
+                P.level1[e] = 0;
+            }
+            if (it == 2) P.robust[e] = 0;
+        }
+        block_sum<1>(bad, sh, outb);
+        nBad = (int)outb[0];
+        if (n < 10) break;  // optimizer.edges().size() < 10
+    }
+    if (tid < 7) P.pose_out[tid] = qt[tid];
+    if (tid == 0) {
+        P.counts[0] = nBad;
+        P.counts[1] = n - nBad;
+    }
+}
+
 }  // namespace aos2
 
 using namespace aos2;
@@ -772,6 +1068,7 @@ struct aos2_lba {
     hipEvent_t ev[2] = {};
     DevBuf<uint8_t> arena;
     PinnedBuf<double> h_scal;
+    float last_pose_ms = 0;
 };
 
 namespace aos2 {
@@ -1202,5 +1499,88 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     (void)hipEventElapsedTime(&r->ms_device, s->ev[0], s->ev[1]);
     return AOS2_OK;
 }
+
+int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, aos2_pose_result_t *results, int n_problems)
+{
+    if (!s || !problems || !results || n_problems <= 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    for (int i = 0; i < n_problems; ++i)
+        if (problems[i].n < 0 || (problems[i].n > 0 && (!problems[i].Xw || !problems[i].obs || !problems[i].stereo ||
+                                                        !problems[i].inv_sigma2 || !results[i].outlier))) {
+            set_error("bad pose problem %d", i);
+            return AOS2_ERR_ARG;
+        }
+    int st = lba_init(s);
+    if (st) return st;
+    HostArena H;
+    struct Off { size_t xw, obs, w, st, err, l1, rb, out, pose, cnt; };
+    std::vector<Off> offs(n_problems);
+    std::vector<double> tmp;
+    for (int i = 0; i < n_problems; ++i) {
+        const aos2_pose_problem_t &p = problems[i];
+        const size_t n = (size_t)p.n;
+        tmp.resize(3 * n + 1);
+        for (size_t k = 0; k < 3 * n; ++k) tmp[k] = (double)p.Xw[k];
+        offs[i].xw = H.push(tmp.data(), (3 * n + 1) * 8);
+        for (size_t k = 0; k < 3 * n; ++k) tmp[k] = (double)p.obs[k];
+        offs[i].obs = H.push(tmp.data(), (3 * n + 1) * 8);
+        for (size_t k = 0; k < n; ++k) tmp[k] = (double)p.inv_sigma2[k];
+        offs[i].w = H.push(tmp.data(), (n + 1) * 8);
+        static const uint8_t zero = 0;
+        offs[i].st = H.push(n ? p.stereo : &zero, n + 1);
+    }
+    const size_t o_probs = H.push(nullptr, sizeof(PoseProbDev) * n_problems);  // filled below (needs device base)
+    for (int i = 0; i < n_problems; ++i) {
+        const size_t n = (size_t)problems[i].n;
+        offs[i].err = H.push(nullptr, (3 * n + 1) * 8);
+        offs[i].l1 = H.push(nullptr, n + 1);
+        offs[i].rb = H.push(nullptr, n + 1);
+        offs[i].out = H.push(nullptr, n + 1);
+        offs[i].pose = H.push(nullptr, 7 * 8);
+        offs[i].cnt = H.push(nullptr, 8);
+    }
+    if ((st = s->arena.alloc(H.size + 256))) return st;
+    uint8_t *base = s->arena.p;
+    std::vector<PoseProbDev> dev(n_problems);
+    for (int i = 0; i < n_problems; ++i) {
+        const aos2_pose_problem_t &p = problems[i];
+        PoseProbDev &D = dev[i];
+        D.n = p.n;
+        D.Xw = (const double *)(base + offs[i].xw); D.obs = (const double *)(base + offs[i].obs);
+        D.w = (const double *)(base + offs[i].w); D.stereo = base + offs[i].st;
+        D.err = (double *)(base + offs[i].err); D.level1 = base + offs[i].l1; D.robust = base + offs[i].rb;
+        D.outlier = base + offs[i].out; D.pose_out = (double *)(base + offs[i].pose); D.counts = (int32_t *)(base + offs[i].cnt);
+        D.fx = (double)p.fx; D.fy = (double)p.fy; D.cx = (double)p.cx; D.cy = (double)p.cy; D.bf = (double)p.bf;
+        pose_from_Tcw(p.Tcw, D.pose_in);
+    }
+    hipStream_t q = s->stream;
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), H.host.size(), hipMemcpyHostToDevice, q));
+    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_probs, dev.data(), sizeof(PoseProbDev) * n_problems, hipMemcpyHostToDevice, q));
+    AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
+    hipLaunchKernelGGL(pose_optimization_kernel, dim3(n_problems), dim3(256), 256 * 28 * sizeof(double), q,
+                       (const PoseProbDev *)(base + o_probs));
+    AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
+    std::vector<double> poses(7 * (size_t)n_problems);
+    std::vector<int32_t> cnts(2 * (size_t)n_problems);
+    for (int i = 0; i < n_problems; ++i) {
+        AOS2_HIP_CHECK(hipMemcpyAsync(&poses[7 * (size_t)i], base + offs[i].pose, 56, hipMemcpyDeviceToHost, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync(&cnts[2 * (size_t)i], base + offs[i].cnt, 8, hipMemcpyDeviceToHost, q));
+        if (problems[i].n > 0)
+            AOS2_HIP_CHECK(hipMemcpyAsync(results[i].outlier, base + offs[i].out, (size_t)problems[i].n, hipMemcpyDeviceToHost, q));
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(q));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&s->last_pose_ms, s->ev[0], s->ev[1]);
+    for (int i = 0; i < n_problems; ++i) {
+        pose_to_Tcw(&poses[7 * (size_t)i], results[i].Tcw);
+        results[i].n_bad = cnts[2 * (size_t)i];
+        results[i].n_inliers = cnts[2 * (size_t)i + 1];
+    }
+    return AOS2_OK;
+}
+
+float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s) { return s ? s->last_pose_ms : 0.f; }
 
 }  // extern "C"

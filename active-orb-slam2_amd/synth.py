@@ -367,3 +367,40 @@ def tcw_to_qt(Tcw16):
     T = np.asarray(Tcw16, dtype=np.float32).reshape(4, 4).astype(np.float64)
     q = _rot_to_quat(T[:3, :3])
     return np.concatenate([q, T[:3, 3]])
+
+
+def synth_pose_problem(seed: int, n: int = 800, cfg: str = "kitti", stereo_frac: float = 0.8,
+                       outlier_frac: float = 0.1, rot_err: float = 0.01, trans_err: float = 0.05):
+    """Frame with n map-point matches for Optimizer::PoseOptimization (src/Optimizer.cc:239-452)."""
+    rng = np.random.default_rng(5000 + seed)
+    c = CONFIGS[cfg]
+    fx, fy, cx, cy, bf = c["fx"], c["fy"], c["cx"], c["cy"], c["bf"]
+    W, H = c["w"], c["h"]
+    ang = rng.uniform(-0.3, 0.3)
+    Rcw = np.array([[np.cos(ang), 0, -np.sin(ang)], [0, 1, 0], [np.sin(ang), 0, np.cos(ang)]])
+    tcw = rng.uniform(-1, 1, 3)
+    z = rng.uniform(3.0, 40.0, n)
+    u = rng.uniform(20, W - 20, n)
+    v = rng.uniform(20, H - 20, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], axis=1)
+    Xw = (Xc - tcw) @ Rcw  # Rcw^T (Xc - tcw)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    lvl = np.minimum(rng.geometric(0.4, n) - 1, 7)
+    sig = sf[lvl].astype(np.float64)
+    du, dv, dr = rng.normal(0, 1, n) * sig, rng.normal(0, 1, n) * sig, rng.normal(0, 1, n) * sig
+    out = rng.random(n) < outlier_frac
+    du[out] += rng.uniform(15, 60, int(out.sum())) * rng.choice([-1, 1], int(out.sum()))
+    dv[out] += rng.uniform(15, 60, int(out.sum())) * rng.choice([-1, 1], int(out.sum()))
+    stereo = (rng.random(n) < stereo_frac)
+    ur = np.where(stereo, u + du - bf / z + dr, -1.0)
+    obs = np.stack([u + du, v + dv, ur], axis=1).astype(np.float32)
+    rv = rng.normal(0, rot_err / np.sqrt(3), 3)
+    th_ = np.linalg.norm(rv)
+    K = np.array([[0, -rv[2], rv[1]], [rv[2], 0, -rv[0]], [-rv[1], rv[0], 0]])
+    dR = np.eye(3) + np.sin(th_) / th_ * K + (1 - np.cos(th_)) / th_ ** 2 * K @ K
+    T = np.eye(4)
+    T[:3, :3] = dR @ Rcw
+    T[:3, 3] = tcw + rng.normal(0, trans_err / np.sqrt(3), 3)
+    return dict(n=n, Xw=Xw.astype(np.float32), obs=obs, stereo=stereo.astype(np.uint8),
+                inv_sigma2=(np.float32(1.0) / (sf[lvl] * sf[lvl])).astype(np.float32),
+                fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, Tcw=T.astype(np.float32).reshape(16))

@@ -288,6 +288,36 @@ void aos2_lba_destroy(aos2_lba_t *s);
 int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r);
 
 /* ------------------------------------------------------------------------------------------
+ * Optimizer::PoseOptimization  (include/Optimizer.h:47, src/Optimizer.cc:239-452) -- SURVEY §8(f)
+ * rank 1, called 1-3 times per frame right after each matcher call (Tracking.cc:870,994,1039).
+ * One workgroup per frame runs the whole procedure on the device (4 rounds of up to 10
+ * Levenberg-Marquardt iterations on the 6x6 system, outlier reclassification in between);
+ * `n_problems` independent frames are solved in one launch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n;                  /* features with a map point (nInitialCorrespondences) */
+    const float *Xw;            /* n x 3: pMP->GetWorldPos() */
+    const float *obs;           /* n x 3: mvKeysUn[i].pt.x, .pt.y, mvuRight[i] */
+    const uint8_t *stereo;      /* n: mvuRight[i] >= 0 */
+    const float *inv_sigma2;    /* n: mvInvLevelSigma2[octave] */
+    float fx, fy, cx, cy, bf;   /* pFrame->fx .. pFrame->mbf */
+    float Tcw[16];              /* pFrame->mTcw, row-major float32 4x4 */
+} aos2_pose_problem_t;
+
+typedef struct {
+    float Tcw[16];              /* out: pose written by pFrame->SetPose (:446) */
+    uint8_t *outlier;           /* out, n entries, caller-allocated: pFrame->mvbOutlier of the features */
+    int32_t n_bad;              /* pFrame->nBadPoseOpt */
+    int32_t n_inliers;          /* return value: nInitialCorrespondences - nBad (0 if n < 3) */
+} aos2_pose_result_t;
+
+/* int Optimizer::PoseOptimization(Frame *pFrame) for a batch of frames; `s` provides device + stream */
+int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, aos2_pose_result_t *results,
+                           int n_problems);
+/* device time (ms, HIP events) of the kernel of the last aos2_pose_optimization call */
+float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s);
+
+/* ------------------------------------------------------------------------------------------
  * Test taps (no reference equivalent): shared primitives run in isolation.
  * ------------------------------------------------------------------------------------------ */
 /* DistributeOctTree (src/ORBextractor.cc:539-763) on the HOST with the routine the device kernel

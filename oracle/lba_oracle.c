@@ -785,3 +785,265 @@ void orc_pose_to_Tcw_f32(const double qt[7], float T[16])
     T[12] = T[13] = T[14] = 0.f;
     T[15] = 1.f;
 }
+
+/* ------------------------------------------------------------------ Optimizer::PoseOptimization
+ * src/Optimizer.cc:239-452 with EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose
+ * (types_six_dof_expmap.h:143-205, .cpp:266-364), BaseUnaryEdge::constructQuadraticForm
+ * (core/base_unary_edge.hpp:43-72), BlockSolver without Schur + LinearSolverDense
+ * (solvers/linear_solver_dense.h:64-110; Eigen's pivoted LDLT restated as an unpivoted Cholesky
+ * with the same "positive" acceptance test) and the same Levenberg loop as LocalBA. */
+static void pose_edge_error(const double qt[7], const double Xw[3], const double obs[3], int stereo, double fx,
+                            double fy, double cx, double cy, double bf, double err[3])
+{
+    double p[3];
+    se3_map(qt, Xw, p);
+    if (!stereo) {
+        double u = p[0] / p[2], v = p[1] / p[2];
+        err[0] = obs[0] - (u * fx + cx);
+        err[1] = obs[1] - (v * fy + cy);
+        err[2] = 0;
+    } else {
+        const float invz = (float)(1.0f / p[2]);
+        double r0 = p[0] * invz * fx + cx;
+        double r1 = p[1] * invz * fy + cy;
+        double r2 = r0 - bf * invz; /* member bf is double here (.cpp:304) */
+        err[0] = obs[0] - r0;
+        err[1] = obs[1] - r1;
+        err[2] = obs[2] - r2;
+    }
+}
+
+static void pose_edge_jacobian(const double qt[7], const double Xw[3], int stereo, double fx, double fy, double bf,
+                               double J[18])
+{
+    double p[3];
+    se3_map(qt, Xw, p);
+    double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+    memset(J, 0, sizeof(double) * 18);
+    J[0] = x * y * invz_2 * fx;
+    J[1] = -(1 + (x * x * invz_2)) * fx;
+    J[2] = y * invz * fx;
+    J[3] = -invz * fx;
+    J[4] = 0;
+    J[5] = x * invz_2 * fx;
+    J[6] = (1 + y * y * invz_2) * fy;
+    J[7] = -x * y * invz_2 * fy;
+    J[8] = -x * invz * fy;
+    J[9] = 0;
+    J[10] = -invz * fy;
+    J[11] = y * invz_2 * fy;
+    if (stereo) {
+        J[12] = J[0] - bf * y * invz_2;
+        J[13] = J[1] + bf * x * invz_2;
+        J[14] = J[2];
+        J[15] = J[3];
+        J[16] = 0;
+        J[17] = J[5] - bf * invz_2;
+    }
+}
+
+typedef struct {
+    const orc_pose_problem_t *p;
+    double qt[7];
+    double *err;      /* n x 3 */
+    uint8_t *level1;  /* n */
+    uint8_t *robust;  /* n */
+    double H[36], b[6], x[6];
+} po_t;
+
+static double po_chi2(const po_t *S, int e)
+{
+    const double *er = S->err + 3 * (size_t)e;
+    double w = (double)S->p->inv_sigma2[e];
+    int D = S->p->stereo[e] ? 3 : 2;
+    double s = 0;
+    for (int i = 0; i < D; ++i) s += er[i] * (w * er[i]);
+    return s;
+}
+static void po_errors(po_t *S)
+{
+    const orc_pose_problem_t *p = S->p;
+    for (int e = 0; e < p->n; ++e)
+        if (!S->level1[e])
+            pose_edge_error(S->qt, p->Xw + 3 * (size_t)e, p->obs + 3 * (size_t)e, p->stereo[e], p->fx, p->fy, p->cx, p->cy, p->bf,
+                            S->err + 3 * (size_t)e);
+}
+static double po_robust_chi2(const po_t *S)
+{
+    double chi = 0;
+    for (int e = 0; e < S->p->n; ++e) {
+        if (S->level1[e]) continue;
+        double c = po_chi2(S, e);
+        if (S->robust[e]) {
+            double rho[3];
+            robustify(c, huber_delta(S->p->stereo[e]), rho);
+            chi += rho[0];
+        } else
+            chi += c;
+    }
+    return chi;
+}
+static void po_build(po_t *S)
+{
+    const orc_pose_problem_t *p = S->p;
+    memset(S->H, 0, sizeof(S->H));
+    memset(S->b, 0, sizeof(S->b));
+    for (int e = 0; e < p->n; ++e) {
+        if (S->level1[e]) continue;
+        int D = p->stereo[e] ? 3 : 2;
+        double J[18];
+        pose_edge_jacobian(S->qt, p->Xw + 3 * (size_t)e, p->stereo[e], p->fx, p->fy, p->bf, J);
+        const double *er = S->err + 3 * (size_t)e;
+        double w = (double)p->inv_sigma2[e], wo = w, r1 = 1.0;
+        if (S->robust[e]) {
+            double rho[3];
+            robustify(po_chi2(S, e), huber_delta(p->stereo[e]), rho);
+            r1 = rho[1];
+            wo = rho[1] * w;
+        }
+        for (int r = 0; r < 6; ++r) {
+            double s = 0;
+            for (int d = 0; d < D; ++d) s += J[d * 6 + r] * (w * er[d]);
+            S->b[r] -= r1 * s;
+            for (int c = 0; c < 6; ++c) {
+                double t = 0;
+                for (int d = 0; d < D; ++d) t += J[d * 6 + r] * wo * J[d * 6 + c];
+                S->H[r * 6 + c] += t;
+            }
+        }
+    }
+}
+/* Cholesky solve of (H + lambda I) x = b; returns 0 if not positive definite */
+static int po_solve(const po_t *S, double lambda, double x[6])
+{
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = S->H[i];
+    for (int i = 0; i < 6; ++i) L[i * 7] += lambda;
+    for (int j = 0; j < 6; ++j) {
+        double d = L[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d);
+        L[j * 6 + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = L[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = s / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = S->b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return 1;
+}
+
+int orc_pose_optimization(const orc_pose_problem_t *p, const double pose_in[7], double pose_out[7], uint8_t *outlier,
+                          int *n_bad_out)
+{
+    po_t S;
+    memset(&S, 0, sizeof(S));
+    S.p = p;
+    S.err = (double *)calloc((size_t)p->n * 3 + 1, sizeof(double));
+    S.level1 = (uint8_t *)calloc(p->n + 1, 1);
+    S.robust = (uint8_t *)malloc(p->n + 1);
+    memset(S.robust, 1, p->n + 1);
+    memcpy(S.qt, pose_in, sizeof(S.qt));
+    for (int e = 0; e < p->n; ++e) outlier[e] = 0;
+    int nBad = 0;
+    if (p->n < 3) { /* nInitialCorrespondences < 3 -> return 0 (:355-356) */
+        memcpy(pose_out, pose_in, sizeof(double) * 7);
+        *n_bad_out = 0;
+        free(S.err); free(S.level1); free(S.robust);
+        return 0;
+    }
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    for (int it = 0; it < 4; ++it) {
+        memcpy(S.qt, pose_in, sizeof(S.qt)); /* vSE3->setEstimate(toSE3Quat(pFrame->mTcw)) :368 */
+        int n_active = 0;
+        for (int e = 0; e < p->n; ++e) n_active += !S.level1[e];
+        if (n_active > 0) {
+            double lambda = 0, ni = 2;
+            int nBadLM = 0, ok = 1;
+            for (int i = 0; i < 10 && ok; ++i) { /* optimize(10) */
+                po_errors(&S);
+                double currentChi = po_robust_chi2(&S), tempChi = currentChi;
+                const double iniChi = currentChi;
+                po_build(&S);
+                if (i == 0) {
+                    double maxDiagonal = 0.;
+                    for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(S.H[d * 7]), maxDiagonal);
+                    lambda = 1e-5 * maxDiagonal;
+                    ni = 2;
+                    nBadLM = 0;
+                }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    double bk[7];
+                    memcpy(bk, S.qt, sizeof(bk));
+                    int ok2 = po_solve(&S, lambda, S.x);
+                    double ex[7], out[7];
+                    orc_se3_exp(S.x, ex);
+                    orc_se3_mul(ex, S.qt, out);
+                    memcpy(S.qt, out, sizeof(out));
+                    po_errors(&S);
+                    tempChi = po_robust_chi2(&S);
+                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    rho = (currentChi - tempChi);
+                    double scale = 0.;
+                    for (int j = 0; j < 6; ++j) scale += S.x[j] * (lambda * S.x[j] + S.b[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3);
+                        alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                        double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
+                        lambda *= scaleFactor;
+                        ni = 2;
+                        currentChi = tempChi;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                        memcpy(S.qt, bk, sizeof(bk));
+                    }
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                if (qmax == 10 || rho == 0) {
+                    ok = 0;
+                } else {
+                    if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                    if (nBadLM >= 3) ok = 0;
+                }
+            }
+        }
+        nBad = 0;
+        for (int e = 0; e < p->n; ++e) { /* :371-430 (mono and stereo loops have the same body) */
+            if (outlier[e])
+                pose_edge_error(S.qt, p->Xw + 3 * (size_t)e, p->obs + 3 * (size_t)e, p->stereo[e], p->fx, p->fy, p->cx, p->cy,
+                                p->bf, S.err + 3 * (size_t)e);
+            const float chi2 = (float)po_chi2(&S, e);
+            if (chi2 > (p->stereo[e] ? chi2Stereo : chi2Mono)) {
+                outlier[e] = 1;
+                S.level1[e] = 1;
+                nBad++;
+            } else {
+                outlier[e] = 0;
+                S.level1[e] = 0;
+            }
+            if (it == 2) S.robust[e] = 0;
+        }
+        if (p->n < 10) break; /* optimizer.edges().size() < 10 */
+    }
+    memcpy(pose_out, S.qt, sizeof(double) * 7);
+    *n_bad_out = nBad;
+    free(S.err); free(S.level1); free(S.robust);
+    return p->n - nBad;
+}

@@ -398,6 +398,32 @@ def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
                 iters=(r.iters_done1, r.iters_done2))
 
 
+class _PoseProblem(C.Structure):
+    _fields_ = [("n", C.c_int), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("stereo", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("bf", C.c_double)]
+
+
+def pose_optimization(prob: dict):
+    """Optimizer::PoseOptimization on a synth_pose_problem()-style dict; float32 boundary like the reference."""
+    L = lib()
+    L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    n = int(prob["n"])
+    Xw = np.ascontiguousarray(prob["Xw"], np.float32).astype(np.float64)
+    obs = np.ascontiguousarray(prob["obs"], np.float32).astype(np.float64)
+    st = np.ascontiguousarray(prob["stereo"], np.uint8)
+    w = np.ascontiguousarray(prob["inv_sigma2"], np.float32)
+    s = _PoseProblem()
+    s.n, s.Xw, s.obs, s.stereo, s.inv_sigma2 = n, Xw.ctypes.data, obs.ctypes.data, st.ctypes.data, w.ctypes.data
+    s.fx, s.fy, s.cx, s.cy, s.bf = (float(np.float32(prob[k])) for k in ("fx", "fy", "cx", "cy", "bf"))
+    qin = pose_from_Tcw(prob["Tcw"])
+    qout = np.zeros(7)
+    outl = np.zeros(max(n, 1), np.uint8)
+    nbad = C.c_int(0)
+    ninl = L.orc_pose_optimization(C.byref(s), _p(qin), _p(qout), _p(outl), C.byref(nbad))
+    return dict(n_inliers=ninl, n_bad=nbad.value, outlier=outl[:n].copy(), pose_qt=qout, Tcw=pose_to_Tcw(qout))
+
+
 def se3_exp(upd):
     upd = np.ascontiguousarray(upd, np.float64)
     out = np.zeros(7)

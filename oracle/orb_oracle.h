@@ -185,6 +185,19 @@ typedef struct {
 } orc_lba_result_t;
 int orc_lba_solve(orc_lba_problem_t *p, orc_lba_result_t *r);
 
+/* ---- Optimizer::PoseOptimization src/Optimizer.cc:239-452 ---- */
+typedef struct {
+    int n;                     /* features with a map point (nInitialCorrespondences) */
+    const double *Xw;          /* n x 3: MapPoint::GetWorldPos() (float32 widened) */
+    const double *obs;         /* n x 3: kpUn.pt.x, kpUn.pt.y, mvuRight */
+    const uint8_t *stereo;     /* n: mvuRight >= 0 */
+    const float *inv_sigma2;   /* n: mvInvLevelSigma2[octave] */
+    double fx, fy, cx, cy, bf;
+} orc_pose_problem_t;
+/* returns nInitialCorrespondences - nBad; outlier[n] = pFrame->mvbOutlier */
+int orc_pose_optimization(const orc_pose_problem_t *p, const double pose_in[7], double pose_out[7],
+                          uint8_t *outlier, int *n_bad_out);
+
 /* Converter.cc:37-71 boundary conversions */
 void orc_pose_from_Tcw_f32(const float T[16], double qt[7]);
 void orc_pose_to_Tcw_f32(const double qt[7], float T[16]);

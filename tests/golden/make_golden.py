@@ -66,3 +66,9 @@ r = O.lba_solve(prob)
 np.savez_compressed(os.path.join(OUT, "lba_14kf.npz"), out_pose_Tcw=r["pose_Tcw"], out_point_xyz=r["point_xyz"],
                     out_outlier=r["edge_outlier"], out_lambda=r["lambda_trace"], out_chi2=r["chi2_trace"], **prob)
 print("done")
+# pose optimisation
+prob = S.synth_pose_problem(41, n=500)
+r = O.pose_optimization(prob)
+np.savez_compressed(os.path.join(OUT, "pose_500.npz"), out_Tcw=r["Tcw"], out_outlier=r["outlier"],
+                    out_n_inliers=r["n_inliers"], out_n_bad=r["n_bad"], **prob)
+print("pose", r["n_inliers"])

@@ -62,3 +62,32 @@ def test_lba_stop_flag_and_properties(pkg, oracle, gpu):
     r3 = ba.LocalBundleAdjustment(prob, iters=(5, 0))
     w3 = oracle.lba_solve(prob, iters1=5, iters2=0)
     assert close(r3["pose_Tcw"], w3["pose_Tcw"]) and close(r3["point_xyz"], w3["point_xyz"])
+
+
+# ---- Optimizer::PoseOptimization -----------------------------------------
+@pytest.mark.parametrize("cfg", [dict(seed=0), dict(seed=1, stereo_frac=0.0, cfg="tum"), dict(seed=2, n=300, outlier_frac=0.3),
+                                 dict(seed=3, n=2000), dict(seed=4, n=8), dict(seed=5, n=2), dict(seed=6, n=40, rot_err=0.05)])
+def test_pose_optimization_vs_oracle(pkg, oracle, gpu, cfg):
+    prob = pkg.synth.synth_pose_problem(**cfg)
+    want = oracle.pose_optimization(prob)
+    got = pkg.LocalBA().PoseOptimization(prob)
+    assert got["n_inliers"] == want["n_inliers"] and got["n_bad"] == want["n_bad"]
+    assert (got["outlier"] == want["outlier"]).all()
+    assert close(got["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16))
+
+
+def test_pose_optimization_batch_and_golden(pkg, oracle, gpu):
+    probs = [pkg.synth.synth_pose_problem(100 + i, n=600 + 37 * i) for i in range(24)]
+    ba = pkg.LocalBA()
+    res = ba.PoseOptimization(probs)
+    for p, r in zip(probs, res):
+        w = oracle.pose_optimization(p)
+        assert r["n_inliers"] == w["n_inliers"] and (r["outlier"] == w["outlier"]).all()
+        assert close(r["Tcw"].reshape(1, 16), w["Tcw"].reshape(1, 16))
+    assert ba.pose_last_device_ms() > 0
+    g = np.load(os.path.join(GOLD, "pose_500.npz"))
+    prob = {k: g[k] for k in g.files if not k.startswith("out_")}
+    prob["n"] = int(prob["n"])
+    r = ba.PoseOptimization(prob)
+    assert r["n_inliers"] == int(g["out_n_inliers"]) and (r["outlier"] == g["out_outlier"]).all()
+    assert close(r["Tcw"].reshape(1, 16), g["out_Tcw"].reshape(1, 16))

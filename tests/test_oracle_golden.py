@@ -192,3 +192,21 @@ def test_lba_stop_flag_early_return(oracle, pkg):
     r = oracle.lba_solve(prob, stop_flag=flag)
     assert r["status"] == 1 and r["iters"] == (0, 0)
     assert np.abs(r["pose_Tcw"] - prob["pose_Tcw"]).max() < 1e-6
+
+
+def test_pose_optimization_golden_and_properties(oracle, pkg):
+    g = load("pose_500")
+    prob = {k: g[k] for k in g.files if not k.startswith("out_")}
+    prob["n"] = int(prob["n"])
+    r = oracle.pose_optimization(prob)
+    assert r["n_inliers"] == int(g["out_n_inliers"]) and r["n_bad"] == int(g["out_n_bad"])
+    assert (r["outlier"] == g["out_outlier"]).all() and np.abs(r["Tcw"] - g["out_Tcw"]).max() < 1e-6
+    assert r["n_inliers"] + r["n_bad"] == prob["n"] and int(r["outlier"].sum()) == r["n_bad"]
+    # fewer than 3 correspondences: returns 0, pose untouched (src/Optimizer.cc:355-356)
+    small = pkg.synth.synth_pose_problem(1, n=2)
+    rs = oracle.pose_optimization(small)
+    assert rs["n_inliers"] == 0 and np.abs(rs["Tcw"] - small["Tcw"]).max() < 1e-6
+    # a clean problem started near the truth converges to sub-pixel residuals and keeps every point
+    clean = pkg.synth.synth_pose_problem(2, n=400, outlier_frac=0.0, rot_err=0.002, trans_err=0.01)
+    rc = oracle.pose_optimization(clean)
+    assert rc["n_inliers"] >= 0.8 * clean["n"]  # (the synthetic uR noise is correlated with u: heavier tail)
