@@ -804,25 +804,34 @@ __device__ __forceinline__ void po_edge_error(const double *qt, const double *X,
     }
 }
 
-// fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return
+// fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return.
+// Two barriers per call: thread k < K adds the 256 partials of component k in thread order (8 slices
+// of 32 by 8 threads for latency), instead of a log-depth tree with a barrier per level.
 template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) */, double *out)
+__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) + 8 x K */, double *out)
 {
     const int tid = threadIdx.x;
     for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] = v[i];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s)
-            for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] += sh[(tid + s) * (K + 1) + i];
-        __syncthreads();
+    double *part = sh + 256 * (K + 1);
+    if (tid < 8 * K) {
+        const int k = tid % K, slice = tid / K;
+        double acc = 0;
+        for (int t = 32 * slice; t < 32 * slice + 32; ++t) acc += sh[t * (K + 1) + k];
+        part[slice * K + k] = acc;
     }
-    for (int i = 0; i < K; ++i) out[i] = sh[i];
+    __syncthreads();
+    for (int i = 0; i < K; ++i) {
+        double acc = part[i];
+        for (int sl = 1; sl < 8; ++sl) acc += part[sl * K + i];
+        out[i] = acc;
+    }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28
+    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 8 x 27
     __shared__ double qt[7], bk[7], xs[6];
     __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
     __shared__ int s_flag;
@@ -1559,7 +1568,7 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), H.host.size(), hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipMemcpyAsync(base + o_probs, dev.data(), sizeof(PoseProbDev) * n_problems, hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
-    hipLaunchKernelGGL(pose_optimization_kernel, dim3(n_problems), dim3(256), 256 * 28 * sizeof(double), q,
+    hipLaunchKernelGGL(pose_optimization_kernel, dim3(n_problems), dim3(256), (256 * 28 + 8 * 27) * sizeof(double), q,
                        (const PoseProbDev *)(base + o_probs));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
     std::vector<double> poses(7 * (size_t)n_problems);

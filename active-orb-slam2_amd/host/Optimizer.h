@@ -23,6 +23,19 @@ public:
         if (st != AOS2_OK) throw std::runtime_error(std::string("LocalBundleAdjustment: ") + aos2_last_error());
         return true;
     }
+
+    // int Optimizer::PoseOptimization(Frame *pFrame) (include/Optimizer.h:47, src/Optimizer.cc:239-452):
+    // returns nInitialCorrespondences - nBad; result.Tcw / result.outlier are what the reference writes
+    // into pFrame->mTcw / pFrame->mvbOutlier for the features that have a map point
+    int static PoseOptimization(const aos2_pose_problem_t &frame, aos2_pose_result_t &result, int device = 0)
+    {
+        aos2_lba_t *s = nullptr;
+        if (aos2_lba_create(device, &s) != AOS2_OK) throw std::runtime_error(aos2_last_error());
+        const int st = aos2_pose_optimization(s, &frame, &result, 1);
+        aos2_lba_destroy(s);
+        if (st != AOS2_OK) throw std::runtime_error(std::string("PoseOptimization: ") + aos2_last_error());
+        return result.n_inliers;
+    }
 };
 
 }  // namespace ORB_SLAM2
