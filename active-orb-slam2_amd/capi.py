@@ -72,6 +72,11 @@ def lib():
             L.aos2_extractor_set_chunks.argtypes = [vp, ci]
         L.aos2_extractor_bench_fast.argtypes = [vp, ci, C.POINTER(cf)]
         L.aos2_extractor_bench_describe.argtypes = [vp, ci, C.POINTER(cf)]
+        if hasattr(L, "aos2_compute_stereo_matches"):
+            L.aos2_compute_stereo_matches.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+            L.aos2_compute_stereo_matches_device.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
+            L.aos2_compute_stereo_matches_last_device_ms.restype = cf
+            L.aos2_compute_stereo_matches_last_device_ms.argtypes = [vp]
         L.aos2_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
         L.aos2_debug_sincos_host.argtypes = [cf, C.POINTER(cf), C.POINTER(cf)]
         L.aos2_debug_sincos_device.argtypes = [vp, ci, vp, vp, ci]
@@ -234,6 +239,29 @@ class Extractor:
         ms = C.c_float(0)
         _check(self.L.aos2_extractor_bench_describe(self.h, iters, C.byref(ms)))
         return ms.value
+
+
+def ComputeStereoMatches(left: Extractor, right: Extractor, kps_l, desc_l, kps_r, desc_r, mb, mbf, image=0):
+    """Frame::ComputeStereoMatches (src/Frame.cc:495-669) on the pyramids `left` / `right` hold from their
+    last extract.  Returns (mvuRight, mvDepth) float32 arrays, -1 = no match."""
+    kps_l = np.ascontiguousarray(kps_l, KP_DTYPE)
+    kps_r = np.ascontiguousarray(kps_r, KP_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8)
+    desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    ur = np.full(len(kps_l), -1.0, np.float32)
+    dp = np.full(len(kps_l), -1.0, np.float32)
+    _check(left.L.aos2_compute_stereo_matches(left.h, right.h, image, _p(kps_l), _p(desc_l), len(kps_l), _p(kps_r),
+                                              _p(desc_r), len(kps_r), mb, mbf, _p(ur), _p(dp)))
+    return ur, dp
+
+
+def compute_stereo_matches_device(left: Extractor, right: Extractor, batch, d_kpl, d_dl, d_nl, d_kpr, d_dr, d_nr, cap,
+                                  mb, mbf, d_ur, d_depth):
+    """raw device pointers (ints); arrays as written by extract_batch_device for the two eyes"""
+    V = C.c_void_p
+    _check(left.L.aos2_compute_stereo_matches_device(left.h, right.h, batch, V(d_kpl), V(d_dl), V(d_nl), V(d_kpr),
+                                                     V(d_dr), V(d_nr), cap, mb, mbf, V(d_ur), V(d_depth)))
+    return float(left.L.aos2_compute_stereo_matches_last_device_ms(left.h))
 
 
 def debug_octree_host(xs, ys, score, minX, maxX, minY, maxY, N):

@@ -12,6 +12,7 @@
 #include "aos2_common.h"
 #include "extractor_kernels.h"
 #include "octree.h"
+#include "stereo.h"
 
 namespace aos2 {
 
@@ -112,6 +113,11 @@ struct aos2_extractor {
     DevBuf<int32_t> d_cell_cnt, d_level_off, d_sel_cnt, d_nout;
     DevBuf<aos2_keypoint_t> d_kps;
     int out_cap = 0;
+    // ComputeStereoMatches scratch (this handle = the left eye)
+    DevBuf<int32_t> st_sad;
+    DevBuf<uint8_t> st_io;
+    PinnedBuf<uint8_t> st_host;
+    float stereo_ms = 0;
     // device octree scratch
     DevBuf<int16_t> o_xs, o_ys;
     DevBuf<uint8_t> o_sc;
@@ -639,6 +645,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         e->d_pyr.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
         e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_sel_cnt.release();
         e->d_nout.release(); e->d_kps.release();
+        e->st_sad.release(); e->st_io.release(); e->st_host.release();
         e->o_xs.release(); e->o_ys.release(); e->o_sc.release(); e->o_perm.release(); e->o_tmp.release();
         e->o_pairs.release(); e->o_idx.release(); e->o_nodes.release();
         e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_dense.release(); e->h_sel.release();
@@ -713,6 +720,125 @@ int aos2_extractor_extract(aos2_extractor_t *e, const uint8_t *img, int w, int h
     if (n_out) *n_out = n;
     return st;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (src/Frame.cc:495-669): the two extractors keep mvImagePyramid of the
+// last call in HBM; kernels are in stereo.hip.
+static void fill_view(const aos2_extractor *e, PyrView &v)
+{
+    v.img0 = e->img0;
+    v.img0_stride = e->img0_stride;
+    v.pitch0 = e->pitch0;
+    v.pyr = e->d_pyr.p;
+    v.pyr_bytes = e->plan.pyr_bytes;
+    v.nlevels = e->nlevels;
+    for (int l = 0; l < e->nlevels; ++l) {
+        const LevelDev &L = e->plan.levels[l];
+        v.w[l] = L.w; v.h[l] = L.h; v.pitch[l] = L.pitch; v.off[l] = L.off;
+        v.scale[l] = e->mvScaleFactor[l];
+        v.inv_scale[l] = e->mvInvScaleFactor[l];
+    }
+}
+
+static int stereo_check(const aos2_extractor *l, const aos2_extractor *r)
+{
+    if (!l || !r || l->plan.levels.empty() || r->plan.levels.empty() || l->last_batch <= 0 || r->last_batch <= 0) {
+        set_error("ComputeStereoMatches: both extractors must hold the pyramids of an extract call");
+        return AOS2_ERR_ARG;
+    }
+    if (l->device != r->device || l->nlevels != r->nlevels || l->nlevels > kStereoMaxLevels ||
+        l->scaleFactor != r->scaleFactor || l->plan.w != r->plan.w || l->plan.h != r->plan.h) {
+        set_error("ComputeStereoMatches: left/right extractors differ (device, levels, scale or image size)");
+        return AOS2_ERR_ARG;
+    }
+    return AOS2_OK;
+}
+
+static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int batch, const aos2_keypoint_t *d_kpl,
+                      const uint8_t *d_dl, const int32_t *d_nl, const aos2_keypoint_t *d_kpr, const uint8_t *d_dr,
+                      const int32_t *d_nr, int cap, int max_n_left, float mb, float mbf, float *d_ur, float *d_depth)
+{
+    int st;
+    if ((st = l->st_sad.alloc((size_t)batch * cap))) return st;
+    StereoArgs a;
+    fill_view(l, a.L);
+    fill_view(r, a.R);
+    a.first_image_l = a.first_image_r = first_image;
+    a.kp_l = d_kpl; a.kp_r = d_kpr; a.desc_l = d_dl; a.desc_r = d_dr; a.n_l = d_nl; a.n_r = d_nr;
+    a.cap = cap; a.batch = batch; a.mb = mb; a.mbf = mbf;
+    a.u_right = d_ur; a.depth = d_depth; a.sad = l->st_sad.p;
+    AOS2_HIP_CHECK(hipEventRecord(l->ev[0], l->stream));
+    if ((st = launch_stereo(a, max_n_left, l->stream))) return st;
+    AOS2_HIP_CHECK(hipEventRecord(l->ev[1], l->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(l->stream));
+    float ms = 0;
+    AOS2_HIP_CHECK(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
+    l->stereo_ms = ms;
+    return AOS2_OK;
+}
+
+int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t *right, int batch,
+                                       const aos2_keypoint_t *d_kp_left, const uint8_t *d_desc_left,
+                                       const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
+                                       const uint8_t *d_desc_right, const int32_t *d_n_right, int cap, float mb,
+                                       float mbf, float *d_u_right, float *d_depth)
+{
+    int st;
+    if ((st = stereo_check(left, right))) return st;
+    if (!d_kp_left || !d_desc_left || !d_n_left || !d_kp_right || !d_desc_right || !d_n_right || !d_u_right ||
+        !d_depth || cap <= 0 || batch <= 0 || batch > left->last_batch || batch > right->last_batch || !(mb > 0)) {
+        set_error("ComputeStereoMatches: bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if ((st = bind_device(left->device))) return st;
+    return stereo_run(left, right, 0, batch, d_kp_left, d_desc_left, d_n_left, d_kp_right, d_desc_right, d_n_right, cap,
+                      cap, mb, mbf, d_u_right, d_depth);
+}
+
+int aos2_compute_stereo_matches(aos2_extractor_t *left, aos2_extractor_t *right, int image,
+                                const aos2_keypoint_t *kp_left, const uint8_t *desc_left, int n_left,
+                                const aos2_keypoint_t *kp_right, const uint8_t *desc_right, int n_right, float mb,
+                                float mbf, float *u_right, float *depth)
+{
+    int st;
+    if ((st = stereo_check(left, right))) return st;
+    if (n_left < 0 || n_right < 0 || image < 0 || image >= left->last_batch || image >= right->last_batch ||
+        !(mb > 0) || (n_left > 0 && (!kp_left || !desc_left || !u_right || !depth)) ||
+        (n_right > 0 && (!kp_right || !desc_right))) {
+        set_error("ComputeStereoMatches: bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (n_left == 0) return AOS2_OK;
+    if ((st = bind_device(left->device))) return st;
+    aos2_extractor *e = left;
+    const int cap = ((n_left > n_right ? n_left : n_right) + 3) & ~3;  // keeps the descriptor blocks 16-byte aligned
+    const size_t kb = sizeof(aos2_keypoint_t) * (size_t)cap, db = (size_t)cap * 32;
+    // one upload block: kpL | kpR | descL | descR | nL nR ; one download block: uRight | depth
+    const size_t o_kr = kb, o_dl = 2 * kb, o_dr = 2 * kb + db, o_n = 2 * kb + 2 * db, o_out = o_n + 16;
+    const size_t total = o_out + 2 * sizeof(float) * (size_t)cap;
+    if ((st = e->st_io.alloc(total))) return st;
+    if ((st = e->st_host.alloc(total))) return st;
+    uint8_t *hp = e->st_host.p;
+    memcpy(hp, kp_left, sizeof(aos2_keypoint_t) * (size_t)n_left);
+    if (n_right) memcpy(hp + o_kr, kp_right, sizeof(aos2_keypoint_t) * (size_t)n_right);
+    memcpy(hp + o_dl, desc_left, (size_t)n_left * 32);
+    if (n_right) memcpy(hp + o_dr, desc_right, (size_t)n_right * 32);
+    int32_t nn[2] = {n_left, n_right};
+    memcpy(hp + o_n, nn, sizeof(nn));
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->st_io.p, hp, o_out, hipMemcpyHostToDevice, e->stream));
+    uint8_t *dp = e->st_io.p;
+    st = stereo_run(left, right, image, 1, (const aos2_keypoint_t *)dp, dp + o_dl, (const int32_t *)(dp + o_n),
+                    (const aos2_keypoint_t *)(dp + o_kr), dp + o_dr, (const int32_t *)(dp + o_n) + 1, cap, n_left, mb,
+                    mbf, (float *)(dp + o_out), (float *)(dp + o_out) + cap);
+    if (st) return st;
+    AOS2_HIP_CHECK(hipMemcpyAsync(hp + o_out, dp + o_out, 2 * sizeof(float) * (size_t)cap, hipMemcpyDeviceToHost, e->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    memcpy(u_right, hp + o_out, sizeof(float) * (size_t)n_left);
+    memcpy(depth, hp + o_out + sizeof(float) * (size_t)cap, sizeof(float) * (size_t)n_left);
+    return AOS2_OK;
+}
+
+float aos2_compute_stereo_matches_last_device_ms(const aos2_extractor_t *left) { return left ? left->stereo_ms : 0.0f; }
 
 int aos2_extractor_pyramid_level_size(const aos2_extractor_t *e, int level, int *w, int *h)
 {

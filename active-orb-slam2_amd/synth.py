@@ -87,6 +87,27 @@ def synth_batch(seed0: int, n: int, w: int = 640, h: int = 480) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- matching
+def synth_stereo_pair(seed: int, w: int = 640, h: int = 480, max_disp: int = 48):
+    """Rectified stereo pair: the right image is the left one resampled by a per-row-band fractional
+    disparity (right(x) = left(x + d)), plus independent pixel noise.  Returns (left, right, disp_rows)."""
+    wide = synth_image(seed, w + max_disp + 2, h).astype(np.float32)
+    rng = np.random.default_rng(np.uint64(0xD1B54A32D192ED03) ^ np.uint64(seed))
+    band = 32
+    nb = (h + band - 1) // band
+    dband = rng.uniform(3.0, max_disp - 1.0, nb).astype(np.float32)
+    disp = np.repeat(dband, band)[:h]
+    left = wide[:, :w]
+    right = np.empty((h, w), np.float32)
+    xs = np.arange(w)
+    for y in range(h):
+        d0 = int(np.floor(disp[y]))
+        f = disp[y] - d0
+        right[y] = (1 - f) * wide[y, xs + d0] + f * wide[y, xs + d0 + 1]
+    right += rng.normal(0, 1.5, size=(h, w)).astype(np.float32)
+    return (np.clip(np.rint(left), 0, 255).astype(np.uint8), np.clip(np.rint(right), 0, 255).astype(np.uint8),
+            disp)
+
+
 def synth_descriptors(rng, n):
     return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
 

@@ -107,6 +107,31 @@ int aos2_extractor_pyramid_level_size(const aos2_extractor_t *e, int level, int 
 int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int border,
                                  uint8_t *dst, int dst_stride);
 
+/* Frame::ComputeStereoMatches()  src/Frame.cc:495-669  (SURVEY.md §8(f) rank 2).
+ * `left` / `right` are the two ORBextractor handles of the stereo Frame (mpORBextractorLeft / Right,
+ * include/Frame.h:108); both must still hold the device pyramids of their last extract*() call
+ * (mvImagePyramid, read at :502,592,609) and `image` selects the image of that batch.
+ * kp_* / desc_* = mvKeys / mvKeysRight and mDescriptors / mDescriptorsRight (host memory).
+ * mb = baseline in metres (minZ, :526), mbf = baseline * fx (:527).
+ * Outputs mvuRight[n_left], mvDepth[n_left]; -1 = no stereo match (:498).
+ * When no left keypoint passes the SAD stage the reference reads vDistIdx[0] of an empty vector
+ * (:655); here that case leaves every output at -1. */
+int aos2_compute_stereo_matches(aos2_extractor_t *left, aos2_extractor_t *right, int image,
+                                const aos2_keypoint_t *kp_left, const uint8_t *desc_left, int n_left,
+                                const aos2_keypoint_t *kp_right, const uint8_t *desc_right,
+                                int n_right, float mb, float mbf, float *u_right, float *depth);
+/* Batched, fully device-resident form: the arrays are exactly what
+ * aos2_extractor_extract_batch_device() wrote for the two eyes ([batch][cap] keypoints,
+ * [batch][cap][32] descriptors, [batch] counts; descriptor blocks 16-byte aligned); image b of the
+ * call = image b of both extractors' last batch.  d_u_right / d_depth are [batch][cap]. */
+int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t *right, int batch,
+                                       const aos2_keypoint_t *d_kp_left, const uint8_t *d_desc_left,
+                                       const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
+                                       const uint8_t *d_desc_right, const int32_t *d_n_right,
+                                       int cap, float mb, float mbf, float *d_u_right, float *d_depth);
+/* device time (ms) of the kernels of the last ComputeStereoMatches call on `left` */
+float aos2_compute_stereo_matches_last_device_ms(const aos2_extractor_t *left);
+
 /* Stage taps for parity tests (no reference equivalent): FAST candidates handed to
  * DistributeOctTree for (image, level) of the last extract, in the reference's emission order
  * (cells row-major, pixels row-major inside a cell); coordinates relative to (minBorderX,

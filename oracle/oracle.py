@@ -66,6 +66,7 @@ def lib():
         L.orc_search_by_projection_mp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_se3_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quat_from_rot.argtypes = [C.c_void_p, C.c_void_p]
@@ -328,6 +329,44 @@ def search_by_projection_last(cur: dict, p: dict):
 
 
 # ---------------------------------------------------------------------------- local BA
+class _StereoProblem(C.Structure):
+    _fields_ = [("n_left", C.c_int), ("n_right", C.c_int), ("kp_left", C.c_void_p), ("kp_right", C.c_void_p),
+                ("desc_left", C.c_void_p), ("desc_right", C.c_void_p), ("n_levels", C.c_int),
+                ("scale_factors", C.c_void_p), ("inv_scale_factors", C.c_void_p),
+                ("left_planes", C.c_void_p), ("right_planes", C.c_void_p),
+                ("left_pitch", C.c_void_p), ("right_pitch", C.c_void_p), ("level_w", C.c_void_p),
+                ("level_h", C.c_void_p), ("mb", C.c_float), ("mbf", C.c_float)]
+
+
+def compute_stereo_matches(ext_left: "Extractor", ext_right: "Extractor", kps_l, desc_l, kps_r, desc_r,
+                           mb: float, mbf: float):
+    """Frame::ComputeStereoMatches (src/Frame.cc:495-669) on the pyramids the two oracle extractors hold
+    from their last extract().  Returns (mvuRight, mvDepth, n_before_cull)."""
+    L = lib()
+    nl = ext_left.nlevels
+    kps_l = np.ascontiguousarray(kps_l, dtype=KP_DTYPE)
+    kps_r = np.ascontiguousarray(kps_r, dtype=KP_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, dtype=np.uint8)
+    desc_r = np.ascontiguousarray(desc_r, dtype=np.uint8)
+    sf = ext_left.scale_factors
+    isf = ext_left.inv_scale_factors
+    pl = (C.c_void_p * nl)(*[L.orc_extractor_level_plane(ext_left.h, l) for l in range(nl)])
+    pr = (C.c_void_p * nl)(*[L.orc_extractor_level_plane(ext_right.h, l) for l in range(nl)])
+    szl = [ext_left.level_size(l) for l in range(nl)]
+    szr = [ext_right.level_size(l) for l in range(nl)]
+    lw = np.array([s[0] for s in szl], np.int32)
+    lh = np.array([s[1] for s in szl], np.int32)
+    lp = np.array([s[2] for s in szl], np.int32)
+    rp = np.array([s[2] for s in szr], np.int32)
+    P = _StereoProblem(len(kps_l), len(kps_r), _p(kps_l).value, _p(kps_r).value, _p(desc_l).value, _p(desc_r).value,
+                       nl, _p(sf).value, _p(isf).value, C.cast(pl, C.c_void_p).value, C.cast(pr, C.c_void_p).value,
+                       _p(lp).value, _p(rp).value, _p(lw).value, _p(lh).value, np.float32(mb), np.float32(mbf))
+    ur = np.zeros(len(kps_l), np.float32)
+    dp = np.zeros(len(kps_l), np.float32)
+    n = L.orc_compute_stereo_matches(C.byref(P), _p(ur), _p(dp))
+    return ur, dp, n
+
+
 class _LbaProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
                 ("pose_qt", C.c_void_p), ("pose_fixed", C.c_void_p), ("pose_id", C.c_void_p),

@@ -325,3 +325,133 @@ int orc_search_by_projection_last(const orc_frame_view_t *cur, const orc_proj_la
     free(vIndices2);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------ Frame::ComputeStereoMatches
+ * src/Frame.cc:495-669.  Pyramid levels are passed as interior planes
+ * (the reference reads mvImagePyramid[level] ROIs; the accessed windows never leave the interior,
+ * see DESIGN.md).  cv::norm(IL, IR, NORM_L1) of integer-valued float patches is an exact integer. */
+int orc_compute_stereo_matches(const orc_stereo_problem_t *p, float *u_right, float *depth)
+{
+    const int N = p->n_left, Nr = p->n_right;
+    for (int i = 0; i < N; ++i) u_right[i] = depth[i] = -1.0f;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = p->level_h[0];
+    /* row table :505-523 */
+    ivec_t *rows = (ivec_t *)calloc(nRows, sizeof(ivec_t));
+    for (int iR = 0; iR < Nr; iR++) {
+        const float kpY = p->kp_right[iR].y;
+        const float r = 2.0f * p->scale_factors[p->kp_right[iR].octave];
+        const int maxr = (int)ceilf(kpY + r);
+        const int minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) iv_push(&rows[yi], iR); /* the reference has no guard; keypoints keep yi inside */
+    }
+    const float minZ = p->mb, minD = 0, maxD = p->mbf / minZ;
+    int *vdist = (int *)malloc(sizeof(int) * (N ? N : 1)), *vidx = (int *)malloc(sizeof(int) * (N ? N : 1));
+    int nv = 0;
+    for (int iL = 0; iL < N; iL++) {
+        const orc_keypoint_t *kpL = &p->kp_left[iL];
+        const int levelL = kpL->octave;
+        const float vL = kpL->y, uL = kpL->x;
+        const int row = (int)vL;
+        if (row < 0 || row >= nRows) continue;
+        const ivec_t *cand = &rows[row];
+        if (cand->n == 0) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        const uint8_t *dL = p->desc_left + (size_t)iL * 32;
+        for (int iC = 0; iC < cand->n; iC++) {
+            const int iR = cand->v[iC];
+            const orc_keypoint_t *kpR = &p->kp_right[iR];
+            if (kpR->octave < levelL - 1 || kpR->octave > levelL + 1) continue;
+            const float uR = kpR->x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_descriptor_distance(dL, p->desc_right + (size_t)iR * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = p->kp_right[bestIdxR].x;
+            const float scaleFactor = p->inv_scale_factors[kpL->octave];
+            const float scaleduL = roundf(kpL->x * scaleFactor);
+            const float scaledvL = roundf(kpL->y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const uint8_t *PL = p->left_planes[kpL->octave], *PR = p->right_planes[kpL->octave];
+            const int pitchL = p->left_pitch[kpL->octave], pitchR = p->right_pitch[kpL->octave];
+            const int cols = p->level_w[kpL->octave];
+            const int cuL = (int)scaleduL, cvL = (int)scaledvL, cuR0 = (int)scaleduR0;
+            float IL[11][11];
+            const float cL = (float)PL[(size_t)cvL * pitchL + cuL];
+            for (int dy = -w; dy <= w; ++dy)
+                for (int dx = -w; dx <= w; ++dx) IL[dy + w][dx + w] = (float)PL[(size_t)(cvL + dy) * pitchL + cuL + dx] - cL;
+            int bestDistS = 2147483647, bestincR = 0;
+            float vDists[11];
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= cols) continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                const float cR = (float)PR[(size_t)cvL * pitchR + cuR0 + incR];
+                double acc = 0;
+                for (int dy = -w; dy <= w; ++dy)
+                    for (int dx = -w; dx <= w; ++dx) {
+                        const float ir = (float)PR[(size_t)(cvL + dy) * pitchR + cuR0 + incR + dx] - cR;
+                        acc += fabs((double)IL[dy + w][dx + w] - (double)ir);
+                    }
+                const float dist = (float)acc;
+                if (dist < bestDistS) {
+                    bestDistS = (int)dist;
+                    bestincR = incR;
+                }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = p->scale_factors[kpL->octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = uL - 0.01f;
+                }
+                depth[iL] = p->mbf / disparity;
+                u_right[iL] = bestuR;
+                vdist[nv] = bestDistS;
+                vidx[nv] = iL;
+                nv++;
+            }
+        }
+    }
+    if (nv > 0) { /* :654-668 (the reference reads vDistIdx[0] of an empty vector when nothing matched) */
+        /* sort (dist, iL) ascending -> median = element nv/2 */
+        int *order = (int *)malloc(sizeof(int) * nv);
+        for (int i = 0; i < nv; ++i) order[i] = i;
+        for (int i = 1; i < nv; ++i) { /* insertion sort, stable on (dist, iL) since iL ascends */
+            int o = order[i], j = i - 1;
+            while (j >= 0 && (vdist[order[j]] > vdist[o] || (vdist[order[j]] == vdist[o] && vidx[order[j]] > vidx[o]))) {
+                order[j + 1] = order[j];
+                --j;
+            }
+            order[j + 1] = o;
+        }
+        const float median = (float)vdist[order[nv / 2]];
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; i--) {
+            if ((float)vdist[order[i]] < thDist) break;
+            u_right[vidx[order[i]]] = -1;
+            depth[vidx[order[i]]] = -1;
+        }
+        free(order);
+    }
+    for (int i = 0; i < nRows; ++i) free(rows[i].v);
+    free(rows);
+    free(vdist);
+    free(vidx);
+    return nv;
+}

@@ -154,6 +154,21 @@ typedef struct {
 int orc_search_by_projection_last(const orc_frame_view_t *cur, const orc_proj_last_problem_t *p,
                                   int32_t *match_f);
 
+/* ---- Frame::ComputeStereoMatches src/Frame.cc:495-669 ---- */
+typedef struct {
+    int n_left, n_right;
+    const orc_keypoint_t *kp_left, *kp_right;   /* mvKeys / mvKeysRight (level-0 pixel units) */
+    const uint8_t *desc_left, *desc_right;      /* mDescriptors / mDescriptorsRight */
+    int n_levels;
+    const float *scale_factors, *inv_scale_factors;
+    const uint8_t *const *left_planes;          /* mpORBextractorLeft->mvImagePyramid[l] interior */
+    const uint8_t *const *right_planes;
+    const int *left_pitch, *right_pitch, *level_w, *level_h;
+    float mb, mbf;
+} orc_stereo_problem_t;
+/* fills mvuRight / mvDepth (-1 = no match); returns the number of matches before the median cull */
+int orc_compute_stereo_matches(const orc_stereo_problem_t *p, float *u_right, float *depth);
+
 /* ---- local BA: src/Optimizer.cc:454-779 + vendored g2o ---- */
 typedef struct {
     int n_poses;               /* local + fixed keyframes */

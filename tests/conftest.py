@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+try:  # torch ships its own libamdhip64: it has to be the first HIP runtime the process loads, or a
+    import torch  # noqa: F401  later torch.cuda init finds "no HIP GPUs" (tests that hand torch tensors to the C ABI)
+except ImportError:  # pragma: no cover
+    pass
+
 import __graft_entry__ as graft  # noqa: E402
 
 

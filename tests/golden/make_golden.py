@@ -72,3 +72,16 @@ r = O.pose_optimization(prob)
 np.savez_compressed(os.path.join(OUT, "pose_500.npz"), out_Tcw=r["Tcw"], out_outlier=r["outlier"],
                     out_n_inliers=r["n_inliers"], out_n_bad=r["n_bad"], **prob)
 print("pose", r["n_inliers"])
+# Frame::ComputeStereoMatches: inputs are regenerated from the seed
+seed, w, h, nf = 61, 752, 480, 1200
+left, right, disp = S.synth_stereo_pair(seed, w, h)
+eL, eR = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+kl, dl = eL.extract(left)
+kr, dr = eR.extract(right)
+mbf = np.float32(S.CONFIGS["euroc"]["bf"])
+mb = np.float32(mbf / np.float32(S.CONFIGS["euroc"]["fx"]))
+ur, dp, n = O.compute_stereo_matches(eL, eR, kl, dl, kr, dr, mb, mbf)
+np.savez_compressed(os.path.join(OUT, "stereo_euroc.npz"), seed=seed, w=w, h=h, nfeatures=nf, mb=mb, mbf=mbf,
+                    left_crc=np.uint32(zlib.crc32(left.tobytes())), right_crc=np.uint32(zlib.crc32(right.tobytes())),
+                    n_left=len(kl), n_right=len(kr), u_right=ur, depth=dp, n_before_cull=n)
+print("stereo", n, int((ur >= 0).sum()))

@@ -210,3 +210,58 @@ def test_pose_optimization_golden_and_properties(oracle, pkg):
     clean = pkg.synth.synth_pose_problem(2, n=400, outlier_frac=0.0, rot_err=0.002, trans_err=0.01)
     rc = oracle.pose_optimization(clean)
     assert rc["n_inliers"] >= 0.8 * clean["n"]  # (the synthetic uR noise is correlated with u: heavier tail)
+
+
+def _stereo_case(oracle, pkg, seed, w, h, nf, cfg):
+    S = pkg.synth
+    left, right, disp = S.synth_stereo_pair(seed, w, h)
+    eL, eR = oracle.Extractor(nfeatures=nf), oracle.Extractor(nfeatures=nf)
+    kl, dl = eL.extract(left)
+    kr, dr = eR.extract(right)
+    mbf = np.float32(S.CONFIGS[cfg]["bf"])
+    mb = np.float32(mbf / np.float32(S.CONFIGS[cfg]["fx"]))
+    ur, dp, n = oracle.compute_stereo_matches(eL, eR, kl, dl, kr, dr, mb, mbf)
+    return left, right, disp, kl, kr, ur, dp, n, mb, mbf
+
+
+def test_compute_stereo_matches_golden_and_known_answer(oracle, pkg):
+    """Frame::ComputeStereoMatches restatement (src/Frame.cc:495-669): golden regression + the planted
+    per-row disparity of the synthetic pair is recovered (an answer the oracle did not produce itself)."""
+    g = np.load(os.path.join(GOLD, "stereo_euroc.npz"))
+    left, right, disp, kl, kr, ur, dp, n, mb, mbf = _stereo_case(oracle, pkg, int(g["seed"]), int(g["w"]), int(g["h"]),
+                                                                  int(g["nfeatures"]), "euroc")
+    assert np.uint32(zlib.crc32(left.tobytes())) == g["left_crc"] and np.uint32(zlib.crc32(right.tobytes())) == g["right_crc"]
+    assert len(kl) == int(g["n_left"]) and len(kr) == int(g["n_right"]) and n == int(g["n_before_cull"])
+    assert ur.tobytes() == g["u_right"].tobytes() and dp.tobytes() == g["depth"].tobytes()
+    m = ur >= 0
+    assert m.sum() > 300 and ((dp > 0) == m).all()
+    # known answer: uL - uR = planted disparity of the keypoint's row (sub-pixel at level 0, coarser above)
+    err = np.abs((kl["x"][m] - ur[m]) - disp[kl["y"][m].astype(int)])
+    assert np.median(err) < 0.75 and (err < 2.5 * 1.2 ** kl["octave"][m]).mean() > 0.9
+    # depth = mbf / disparity (:644), uR <= uL, disparity < mbf/mb
+    d = kl["x"][m] - ur[m]
+    assert (d > 0).all() and (d < mbf / mb).all()
+    assert np.allclose(dp[m], mbf / d, rtol=1e-5)
+
+
+def test_compute_stereo_matches_edge_cases(oracle, pkg):
+    S = pkg.synth
+    left, right, disp, kl, kr, ur, dp, n, mb, mbf = _stereo_case(oracle, pkg, 5, 320, 240, 500, "tum")
+    eL, eR = oracle.Extractor(nfeatures=500), oracle.Extractor(nfeatures=500)
+    kl, dl = eL.extract(left)
+    kr, dr = eR.extract(right)
+    # no right keypoints / no left keypoints
+    u0, d0, n0 = oracle.compute_stereo_matches(eL, eR, kl, dl, kr[:0], dr[:0], mb, mbf)
+    assert n0 == 0 and (u0 == -1).all() and (d0 == -1).all()
+    u1, d1, n1 = oracle.compute_stereo_matches(eL, eR, kl[:0], dl[:0], kr, dr, mb, mbf)
+    assert n1 == 0 and len(u1) == 0
+    # unrelated right image: (almost) nothing survives the Hamming + SAD gates
+    other = S.synth_image(99, 320, 240)
+    ko, do = eR.extract(other)
+    u2, d2, n2 = oracle.compute_stereo_matches(eL, eR, kl, dl, ko, do, mb, mbf)
+    assert n2 < 0.1 * max(1, n)
+    # identical images: every SAD is 0, so median = 0, thDist = 0 and the cull loop (:660-668) removes
+    # every match (no entry is < 0) -- the reference's behaviour, kept
+    eR.extract(left)
+    u3, d3, n3 = oracle.compute_stereo_matches(eL, eR, kl, dl, kl, dl, mb, mbf)
+    assert n3 > 100 and (u3 == -1).all() and (d3 == -1).all()
