@@ -168,6 +168,41 @@ def main():
             extra["local_ba"] = {"edges": prob["n_edges"], "keyframes": prob["n_poses"], "points": prob["n_points"],
                                  "wall_ms": lba_wall, "device_ms": r["ms_device"],
                                  "bound": "latency (LM control loop, ~25 launches per iteration)"}
+            # stereo front-end (EuRoC 752x480, 1200 features/eye): both eyes + Frame::ComputeStereoMatches,
+            # everything device-resident
+            c = S.CONFIGS["euroc"]
+            sb, uniq = 64, 4
+            prs = [S.synth_stereo_pair(300 + i, c["w"], c["h"]) for i in range(uniq)]
+            dl_ = torch.from_numpy(np.stack([prs[i % uniq][0] for i in range(sb)])).to(dev)
+            dr_ = torch.from_numpy(np.stack([prs[i % uniq][1] for i in range(sb)])).to(dev)
+            xl = pkg.Extractor(nfeatures=c["nfeatures"], device=local_rank)
+            xr = pkg.Extractor(nfeatures=c["nfeatures"], device=local_rank)
+            scap = xl.max_keypoints
+            so = [(torch.empty((sb, scap, 7), dtype=torch.float32, device=dev),
+                   torch.empty((sb, scap, 32), dtype=torch.uint8, device=dev),
+                   torch.empty((sb,), dtype=torch.int32, device=dev)) for _ in range(2)]
+            s_ur = torch.empty((sb, scap), dtype=torch.float32, device=dev)
+            s_dp = torch.empty((sb, scap), dtype=torch.float32, device=dev)
+            mbf = np.float32(c["bf"])
+            mb = np.float32(mbf / np.float32(c["fx"]))
+
+            def stereo_step():
+                for x_, im, o in ((xl, dl_, so[0]), (xr, dr_, so[1])):
+                    x_.extract_batch_device(im.data_ptr(), sb, c["w"], c["h"], c["w"], c["w"] * c["h"], o[0].data_ptr(),
+                                            o[1].data_ptr(), scap, o[2].data_ptr())
+                return pkg.capi.compute_stereo_matches_device(xl, xr, sb, so[0][0].data_ptr(), so[0][1].data_ptr(),
+                                                              so[0][2].data_ptr(), so[1][0].data_ptr(), so[1][1].data_ptr(),
+                                                              so[1][2].data_ptr(), scap, mb, mbf, s_ur.data_ptr(),
+                                                              s_dp.data_ptr())
+            stereo_step()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            sms = [stereo_step() for _ in range(5)]
+            torch.cuda.synchronize()
+            swall = (time.perf_counter() - tb) / 5
+            extra["stereo_frontend_euroc_64pairs"] = {
+                "pairs_per_s": sb / swall, "wall_ms": swall * 1e3, "compute_stereo_matches_device_ms": float(np.mean(sms)),
+                "matches_per_pair": float((s_dp > 0).sum().item()) / sb}
         except Exception as exc:  # secondary numbers must never break the contract line
             extra["error"] = repr(exc)
 

@@ -6,6 +6,7 @@
 #include <fstream>
 #include <vector>
 
+#include "../../active-orb-slam2_amd/host/Frame.h"
 #include "../../active-orb-slam2_amd/host/ORBextractor.h"
 #include "../../active-orb-slam2_amd/host/ORBmatcher.h"
 #include "../../active-orb-slam2_amd/host/Optimizer.h"
@@ -35,6 +36,17 @@ int main(int argc, char **argv)
     if (*(p0.data - p0.step - 1) != p0.data[p0.step + 1]) return 5;
     if (p0.data[5 * p0.step + 7] != buf[5 * (size_t)w + 7]) return 6;
     if (!kps.empty() && ORB_SLAM2::ORBmatcher::DescriptorDistance(desc.roi(0, 0, 32, 1), desc.roi(0, 0, 32, 1)) != 0) return 7;
+    {   // stereo Frame with two identical eyes: matches exist but the median cull (thDist = 0) drops them all
+        ORB_SLAM2::ORBextractor exR(nf, 1.2f, 8, 20, 7, 0, false);
+        std::vector<aos2::KeyPoint> kr;
+        aos2::Mat8 dr;
+        exR(image, mask, kr, dr);
+        std::vector<float> uR, depth;
+        ORB_SLAM2::ComputeStereoMatches(&ex, &exR, kps, kr, desc, dr, 0.0773f, 40.0f, uR, depth);
+        if (uR.size() != kps.size() || depth.size() != kps.size()) return 8;
+        for (float v : uR)
+            if (v != -1.0f) return 9;
+    }
     if (argc > 5) {
         std::ofstream o(argv[5], std::ios::binary);
         o.write(reinterpret_cast<const char *>(kps.data()), kps.size() * sizeof(aos2::KeyPoint));
