@@ -23,7 +23,7 @@ int aos2_debug_octree_host(const int16_t *xs, const int16_t *ys, const uint8_t *
     const int mn = oct_max_nodes(n, N);
     std::vector<OctNode> nodes(mn);
     std::vector<int32_t> perm(n), tmp(n), pairs((size_t)4 * mn);
-    OctScratch S{nodes.data(), perm.data(), tmp.data(), pairs.data(), pairs.data() + 2 * mn, mn};
+    OctScratch S{nodes.data(), perm.data(), tmp.data(), pairs.data(), pairs.data() + 2 * mn, mn, mn};
     return distribute_octree(xs, ys, score, n, minX, maxX, minY, maxY, N, S, out_idx, cap);
 }
 

@@ -94,6 +94,7 @@ struct aos2_extractor {
     int cap_level = 0, max_kp = 0;
     unsigned long long umax_nibbles = 0;
     bool host_octree = false;
+    int oct_lds = 0;                     // LDS bytes per octree job (0 = global-scratch path only)
     int host_threads = 8;
 
     bool dev_ready = false;
@@ -473,7 +474,7 @@ static int octree_on_host(aos2_extractor *e, int batch)
                 const int mn = oct_max_nodes(n, P.levels[l].nfeat);
                 nodes.resize(mn);
                 pairs.resize((size_t)4 * mn);
-                OctScratch S{nodes.data(), perm.data(), tmp.data(), pairs.data(), pairs.data() + 2 * mn, mn};
+                OctScratch S{nodes.data(), perm.data(), tmp.data(), pairs.data(), pairs.data() + 2 * mn, mn, mn};
                 nk = distribute_octree(xs.data(), ys.data(), sc.data(), n, 16, P.levels[l].w - 16, 16,
                                        P.levels[l].h - 16, P.levels[l].nfeat, S, idx.data(), e->cap_level);
                 if (nk < 0) fail.store(nk);
@@ -550,7 +551,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
                               e->o_pairs.p + 4 * n0, e->o_idx.p + j0 * e->cap_level, e->o_nodes.p + n0,
                               P.oct_cand_total, P.oct_node_total};
             launch_octree(dense, P.slot_total, level_off, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level, sel_cnt,
-                          e->cap_level, s);
+                          e->cap_level, e->oct_lds, s);
         }
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
         launch_describe(img, image_stride, stride, pyr, P.pyr_bytes, P.d_levels.p, L, sel, (size_t)L * e->cap_level,
@@ -627,6 +628,16 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     e->device = device;
     build_host_tables(e);
     if (const char *v = getenv("AOS2_OCTREE")) e->host_octree = (strcmp(v, "host") == 0);
+    {
+        // LDS budget of an octree job: sized for ~8 candidates per requested feature on level 0 (the
+        // busiest level), capped at the 64 KB a workgroup may take without opt-in; jobs that need more
+        // run over global scratch.  AOS2_OCT_LDS=0 forces the global path (tests).
+        const int n0 = e->mnFeaturesPerLevel[0];
+        size_t want = oct_lds_bytes(8 * n0 + 256, n0);
+        if (want > 65536) want = 65536;
+        e->oct_lds = (int)want;
+        if (const char *v = getenv("AOS2_OCT_LDS")) e->oct_lds = std::max(0, std::min(65536, atoi(v)));
+    }
     const unsigned hc = std::thread::hardware_concurrency();
     e->host_threads = (int)std::min(32u, std::max(1u, hc));
     if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));

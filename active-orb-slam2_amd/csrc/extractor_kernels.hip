@@ -386,37 +386,72 @@ __global__ __launch_bounds__(256) void compact_candidates_kernel(const CellDev *
 // routine of octree.h over global scratch.  Latency-bound by construction (pointer-chasing
 // control flow of src/ORBextractor.cc:539-763); it exists to keep the candidates on the device.
 // ---------------------------------------------------------------------------------------------
+#if defined(AOS2_OCT_PROF)
+}  // namespace aos2
+__device__ long long g_oct_prof[16];
+extern "C" int aos2_debug_oct_prof(long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_prof), sizeof(long long) * 16) != hipSuccess) return -4;
+    if (reset) {
+        long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_oct_prof), z, sizeof(z)) != hipSuccess) return -4;
+    }
+    return 0;
+}
+namespace aos2 {
+#endif
+static_assert(sizeof(OctNode16) == 16, "oct_lds_bytes() assumes 16-byte compact nodes");
+
 __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
                               const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
                               int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
-                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level)
+                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes)
 {
-    // one wave per job: the tree/list control flow is wave-uniform, the key loops are wave-parallel
+    // one wave per job: the tree/list control flow is wave-uniform, the key loops are wave-parallel.
+    // Jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones fill in.
+    extern __shared__ uint32_t oct_lds[];
     const int job = blockIdx.x;
     const int lane = threadIdx.x;
-    const int b = job / n_levels, l = job - b * n_levels;
+    const int l = job / batch, b = job - l * batch;
     const int32_t *lo = level_off + (size_t)b * (n_levels + 1);
     const int beg = lo[l], n = lo[l + 1] - lo[l];
     const uint32_t *cand = dense + (size_t)b * dense_stride + beg;
     const LevelDev lv = levels[l];
-    const size_t co = (size_t)b * scr.cand_stride + lv.oct_cand_off, no = (size_t)b * scr.node_stride + lv.oct_node_off;
-    int16_t *xs = scr.xs + co;
-    int16_t *ys = scr.ys + co;
-    uint8_t *sc = scr.sc + co;
     uint32_t *out = sel + (size_t)b * sel_stride + (size_t)l * cap_level;
+    int32_t *idx = scr.out_idx + ((size_t)b * n_levels + l) * cap_level;
     if (n > lv.oct_cand_cap) {  // cannot happen: the capacity is the geometric maximum of NMS survivors
         if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = -4;
         return;
     }
-    for (int i = lane; i < n; i += 64) {
-        const uint32_t c = cand[i];
-        xs[i] = (int16_t)(c & 0xfff);
-        ys[i] = (int16_t)((c >> 12) & 0xfff);
-        sc[i] = (uint8_t)(c >> 24);
+    int nk = -2;
+    if (n > 0 && n < 32768 && oct_lds_bytes(n, lv.nfeat) <= (size_t)lds_bytes) {
+        // working set in LDS: packed candidates | perm | tmp | node arena | pairs
+        const int ncand = (n + 3) & ~3;
+        uint32_t *c_l = oct_lds;
+        int16_t *perm_l = reinterpret_cast<int16_t *>(c_l + ncand);
+        int16_t *tmp_l = perm_l + ncand;
+        OctNode16 *nodes_l = reinterpret_cast<OctNode16 *>(tmp_l + ncand);
+        const int mn = oct_lds_nodes(lv.nfeat), mp = oct_lds_pairs(lv.nfeat);
+        int32_t *pairs_l = reinterpret_cast<int32_t *>(nodes_l + mn);
+        for (int i = lane; i < n; i += 64) c_l[i] = cand[i];
+        __syncthreads();
+        const OctCandsPacked C{c_l};
+        const OctScratchT<OctCompact> S{nodes_l, perm_l, tmp_l, pairs_l, pairs_l + 2 * mp, mn, mp};
+        nk = distribute_octree<WaveCoop, OctCompact>(C, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
     }
-    __syncthreads();
-    int nk = 0;
-    if (n > 0) {
+    if (n > 0 && nk == -2) {
+        // general path over global scratch (jobs that do not fit the LDS budget, or exhausted its arena)
+        const size_t co = (size_t)b * scr.cand_stride + lv.oct_cand_off, no = (size_t)b * scr.node_stride + lv.oct_node_off;
+        int16_t *xs = scr.xs + co;
+        int16_t *ys = scr.ys + co;
+        uint8_t *sc = scr.sc + co;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t c = cand[i];
+            xs[i] = (int16_t)(c & 0xfff);
+            ys[i] = (int16_t)((c >> 12) & 0xfff);
+            sc[i] = (uint8_t)(c >> 24);
+        }
+        __syncthreads();
         OctScratch S;
         S.nodes = scr.nodes + no;
         S.perm = scr.perm + co;
@@ -424,10 +459,11 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
         S.pairs_a = scr.pairs + 4 * no;
         S.pairs_b = S.pairs_a + 2 * (size_t)lv.oct_node_cap;
         S.max_nodes = lv.oct_node_cap;
-        int32_t *idx = scr.out_idx + (size_t)job * cap_level;
+        S.max_pairs = lv.oct_node_cap;
         nk = distribute_octree<WaveCoop>(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
-        for (int k = lane; k < nk; k += 64) out[k] = cand[idx[k]];
     }
+    if (n <= 0) nk = 0;
+    for (int k = lane; k < nk; k += 64) out[k] = cand[idx[k]];
     if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = nk;
 }
 
@@ -653,11 +689,11 @@ void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *
 
 void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
                    int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
-                   int32_t *sel_level_cnt, int cap_level, hipStream_t st)
+                   int32_t *sel_level_cnt, int cap_level, int lds_bytes, hipStream_t st)
 {
     const int jobs = batch * n_levels;
-    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), 0, st, dense, dense_stride, level_off,
-                       levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level);
+    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), (size_t)lds_bytes, st, dense, dense_stride, level_off,
+                       levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lds_bytes);
 }
 
 void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

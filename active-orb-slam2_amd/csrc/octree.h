@@ -16,18 +16,71 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define AOS2_OCT_HD __host__ __device__ inline
+// always inlined on the device: the LDS instantiation relies on address-space inference (ds_*
+// instead of flat_* accesses), which stops at call boundaries
+#define AOS2_OCT_HD __host__ __device__ __forceinline__
 #else
 #define AOS2_OCT_HD inline
 #endif
 
+#if defined(AOS2_OCT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ long long g_oct_prof[16];
+#define OCT_T0() long long t_prof = wall_clock64()
+#define OCT_TICK(i)                                                                  \
+    do {                                                                             \
+        long long t_now = wall_clock64();                                            \
+        if (prof_on && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_oct_prof[i], (unsigned long long)(t_now - t_prof)); \
+        t_prof = t_now;                                                              \
+    } while (0)
+#define OCT_COUNT(i, v)                                                              \
+    do {                                                                             \
+        if (prof_on && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&g_oct_prof[i], (unsigned long long)(v)); \
+    } while (0)
+#else
+#define OCT_T0()
+#define OCT_TICK(i)
+#define OCT_COUNT(i, v)
+#endif
+
 namespace aos2 {
 
+// bNoMore of the reference (:1012-1019, :573) is exactly "holds one key", so it is not stored.
 struct OctNode {
     int16_t x0, y0, x1, y1;
     int32_t beg, cnt;
     int32_t prev, next;
-    int32_t no_more;
+};
+// compact node for LDS-resident jobs (n and the arena both < 32768)
+struct OctNode16 {
+    int16_t x0, y0, x1, y1;
+    int16_t beg, cnt;
+    int16_t prev, next;
+};
+
+// candidate access: split arrays (host, debug tap, device fallback) or the packed words the FAST
+// kernel emits (x | y << 12 | score << 24)
+struct OctCandsSplit {
+    const int16_t *xs, *ys;
+    const uint8_t *sc;
+    AOS2_OCT_HD int x(int k) const { return xs[k]; }
+    AOS2_OCT_HD int y(int k) const { return ys[k]; }
+    AOS2_OCT_HD int score(int k) const { return sc[k]; }
+};
+struct OctCandsPacked {
+    const uint32_t *c;
+    AOS2_OCT_HD int x(int k) const { return (int)(c[k] & 0xfffu); }
+    AOS2_OCT_HD int y(int k) const { return (int)((c[k] >> 12) & 0xfffu); }
+    AOS2_OCT_HD int score(int k) const { return (int)(c[k] >> 24); }
+};
+struct OctWide {
+    using Node = OctNode;
+    using Idx = int32_t;
+    using Cands = OctCandsSplit;
+};
+struct OctCompact {
+    using Node = OctNode16;
+    using Idx = int16_t;
+    using Cands = OctCandsPacked;
 };
 
 // scratch requirements for n candidates and target N:
@@ -45,14 +98,17 @@ AOS2_OCT_HD int oct_max_nodes(int n, int N)
     return 48 * live + 64;
 }
 
-struct OctScratch {
-    OctNode *nodes;
-    int32_t *perm;
-    int32_t *tmp;
+template <class Tr>
+struct OctScratchT {
+    typename Tr::Node *nodes;
+    typename Tr::Idx *perm;
+    typename Tr::Idx *tmp;
     int32_t *pairs_a;  // (size,node) pairs of the current pass
     int32_t *pairs_b;  // previous pass (sorted)
     int max_nodes;
+    int max_pairs;     // capacity of each pairs array, in pairs
 };
+using OctScratch = OctScratchT<OctWide>;
 
 // Execution policy of the O(n) inner loops (stable partitions, per-node maxima):
 //   SerialCoop -- one thread does everything (host threads; also what the CPU tests run)
@@ -82,42 +138,46 @@ inline unsigned long long coop_ballot(bool p) { return p ? 1ull : 0ull; }
 inline int coop_popc(unsigned long long m) { return __builtin_popcountll(m); }
 #endif
 
+template <class Node>
 struct List {
-    OctNode *nodes;
+    Node *nodes;
     int n_alloc, head, tail, size, cap;
 };
 
-AOS2_OCT_HD int new_node(List &L)
+template <class Node>
+AOS2_OCT_HD int new_node(List<Node> &L)
 {
     if (L.n_alloc >= L.cap) return -1;
-    OctNode &n = L.nodes[L.n_alloc];
+    Node &n = L.nodes[L.n_alloc];
     n.prev = n.next = -1;
-    n.no_more = 0;
     n.cnt = 0;
     n.beg = 0;
     return L.n_alloc++;
 }
-AOS2_OCT_HD void push_back(List &L, int id)
+template <class Node>
+AOS2_OCT_HD void push_back(List<Node> &L, int id)
 {
-    OctNode &n = L.nodes[id];
-    n.prev = L.tail;
+    Node &n = L.nodes[id];
+    n.prev = (decltype(n.prev))L.tail;
     n.next = -1;
-    if (L.tail >= 0) L.nodes[L.tail].next = id; else L.head = id;
+    if (L.tail >= 0) L.nodes[L.tail].next = (decltype(n.next))id; else L.head = id;
     L.tail = id;
     L.size++;
 }
-AOS2_OCT_HD void push_front(List &L, int id)
+template <class Node>
+AOS2_OCT_HD void push_front(List<Node> &L, int id)
 {
-    OctNode &n = L.nodes[id];
-    n.next = L.head;
+    Node &n = L.nodes[id];
+    n.next = (decltype(n.next))L.head;
     n.prev = -1;
-    if (L.head >= 0) L.nodes[L.head].prev = id; else L.tail = id;
+    if (L.head >= 0) L.nodes[L.head].prev = (decltype(n.prev))id; else L.tail = id;
     L.head = id;
     L.size++;
 }
-AOS2_OCT_HD int erase(List &L, int id)
+template <class Node>
+AOS2_OCT_HD int erase(List<Node> &L, int id)
 {
-    OctNode &n = L.nodes[id];
+    Node &n = L.nodes[id];
     int nx = n.next;
     if (n.prev >= 0) L.nodes[n.prev].next = n.next; else L.head = n.next;
     if (n.next >= 0) L.nodes[n.next].prev = n.prev; else L.tail = n.prev;
@@ -127,11 +187,13 @@ AOS2_OCT_HD int erase(List &L, int id)
 
 // DivideNode: stable 4-way partition of the parent's segment; children c[0..3] = n1..n4
 // (UL, UR, BL, BR quadrants).  Returns false if the arena is exhausted.
-template <class Coop>
-AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id, const int16_t *xs,
-                        const int16_t *ys, int32_t *perm, int32_t *tmp)
+template <class Coop, class Tr>
+AOS2_OCT_HD bool divide(List<typename Tr::Node> &L, int id, int c[4], int ccnt[4], int &next_of_id,
+                        const typename Tr::Cands &C, typename Tr::Idx *perm, typename Tr::Idx *tmp)
 {
-    const OctNode p = L.nodes[id];
+    using Node = typename Tr::Node;
+    using Idx = typename Tr::Idx;
+    const Node p = L.nodes[id];
     next_of_id = p.next;
     const int hx = (p.x1 - p.x0 + 1) / 2;  // ceil(float(x1-x0)/2)
     const int hy = (p.y1 - p.y0 + 1) / 2;
@@ -141,7 +203,7 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
         if (c[i] < 0) return false;
     }
     {
-        OctNode &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
+        Node &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
         n1.x0 = p.x0; n1.y0 = p.y0; n1.x1 = (int16_t)mx; n1.y1 = (int16_t)my;
         n2.x0 = (int16_t)mx; n2.y0 = p.y0; n2.x1 = p.x1; n2.y1 = (int16_t)my;
         n3.x0 = p.x0; n3.y0 = (int16_t)my; n3.x1 = (int16_t)mx; n3.y1 = p.y1;
@@ -152,15 +214,15 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
     if (!Coop::kWave) {
         for (int i = 0; i < p.cnt; ++i) {
             const int k = perm[p.beg + i];
-            const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
+            const int q = (C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2);
             cnt[q]++;
         }
         off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
         int fill[4] = {off[0], off[1], off[2], off[3]};
         for (int i = 0; i < p.cnt; ++i) {
             const int k = perm[p.beg + i];
-            const int q = (xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2);
-            tmp[fill[q]++] = k;
+            const int q = (C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2);
+            tmp[fill[q]++] = (Idx)k;
         }
         for (int i = 0; i < p.cnt; ++i) perm[p.beg + i] = tmp[i];
     } else {
@@ -170,7 +232,7 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
             // whole segment in registers: read, barrier, scatter in place
             const bool valid = lane < p.cnt;
             const int k = valid ? perm[p.beg + lane] : 0;
-            const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+            const int q = valid ? ((C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2)) : -1;
             const unsigned long long b0 = coop_ballot(q == 0), b1 = coop_ballot(q == 1);
             const unsigned long long b2 = coop_ballot(q == 2), b3 = coop_ballot(q == 3);
             cnt[0] = coop_popc(b0); cnt[1] = coop_popc(b1); cnt[2] = coop_popc(b2); cnt[3] = coop_popc(b3);
@@ -178,7 +240,7 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
             coop_sync();
             if (valid) {
                 const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
-                perm[p.beg + off[q] + coop_popc(bq & lt)] = k;
+                perm[p.beg + off[q] + coop_popc(bq & lt)] = (Idx)k;
             }
             coop_sync();
         } else {
@@ -186,7 +248,7 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
                 const int i = base + lane;
                 const bool valid = i < p.cnt;
                 const int k = valid ? perm[p.beg + i] : 0;
-                const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+                const int q = valid ? ((C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2)) : -1;
                 cnt[0] += coop_popc(coop_ballot(q == 0));
                 cnt[1] += coop_popc(coop_ballot(q == 1));
                 cnt[2] += coop_popc(coop_ballot(q == 2));
@@ -198,12 +260,12 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
                 const int i = base + lane;
                 const bool valid = i < p.cnt;
                 const int k = valid ? perm[p.beg + i] : 0;
-                const int q = valid ? ((xs[k] < mx ? 0 : 1) + (ys[k] < my ? 0 : 2)) : -1;
+                const int q = valid ? ((C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2)) : -1;
                 const unsigned long long b0 = coop_ballot(q == 0), b1 = coop_ballot(q == 1);
                 const unsigned long long b2 = coop_ballot(q == 2), b3 = coop_ballot(q == 3);
                 if (valid) {
                     const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
-                    tmp[run[q] + coop_popc(bq & lt)] = k;
+                    tmp[run[q] + coop_popc(bq & lt)] = (Idx)k;
                 }
                 run[0] += coop_popc(b0); run[1] += coop_popc(b1); run[2] += coop_popc(b2); run[3] += coop_popc(b3);
             }
@@ -213,10 +275,9 @@ AOS2_OCT_HD bool divide(List &L, int id, int c[4], int ccnt[4], int &next_of_id,
         }
     }
     for (int q = 0; q < 4; ++q) {
-        OctNode &n = L.nodes[c[q]];
-        n.beg = p.beg + off[q];
-        n.cnt = cnt[q];
-        n.no_more = (cnt[q] == 1);
+        Node &n = L.nodes[c[q]];
+        n.beg = (decltype(n.beg))(p.beg + off[q]);
+        n.cnt = (decltype(n.cnt))cnt[q];
         ccnt[q] = cnt[q];
     }
     // unlink the parent here (its prev/next are already in registers); children are pushed to the
@@ -261,25 +322,53 @@ AOS2_OCT_HD void pair_sort(int32_t *a, int n)
     }
 }
 
+// same order as pair_sort, out of place, one element per lane and round (keys are unique: the
+// node index is part of the key)
+template <class Coop>
+AOS2_OCT_HD void pair_sort_to(const int32_t *src, int n, int32_t *dst)
+{
+    if (!Coop::kWave) {
+        for (int i = 0; i < 2 * n; ++i) dst[i] = src[i];
+        pair_sort(dst, n);
+    } else {
+        for (int i = coop_lane(); i < n; i += 64) {
+            const int32_t a0 = src[2 * i], a1 = src[2 * i + 1];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const int32_t b0 = src[2 * j], b1 = src[2 * j + 1];
+                rank += (b0 < a0 || (b0 == a0 && b1 < a1)) ? 1 : 0;
+            }
+            dst[2 * rank] = a0;
+            dst[2 * rank + 1] = a1;
+        }
+        coop_sync();
+    }
+}
+
 }  // namespace octdetail
 
 // xs, ys, score: n candidates in the reference's emission order.  [minX,maxX) x [minY,maxY) is
 // the level's search box (16 .. w-16).  Writes the kept candidate indices in list order to
 // out_idx (capacity cap) and returns their number; <0 if scratch is exhausted / cap too small.
-template <class Coop = SerialCoop>
-AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const uint8_t *score, int n,
-                                  int minX, int maxX, int minY, int maxY, int N, OctScratch &S,
-                                  int32_t *out_idx, int cap)
+template <class Coop = SerialCoop, class Tr = OctWide>
+AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, int maxX, int minY, int maxY, int N,
+                                  const OctScratchT<Tr> &S, int32_t *out_idx, int cap)
 {
     using namespace octdetail;
+    using Node = typename Tr::Node;
+    using Idx = typename Tr::Idx;
     if (n <= 0) return 0;
-    List L;
+#if defined(AOS2_OCT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const bool prof_on = N > 200;  // level 0 only
+#endif
+    OCT_T0();
+    List<Node> L;
     L.nodes = S.nodes;
     L.n_alloc = 0;
     L.head = L.tail = -1;
     L.size = 0;
     L.cap = S.max_nodes;
-    int32_t *perm = S.perm, *tmp = S.tmp;
+    Idx *perm = S.perm, *tmp = S.tmp;
 
     // roots :541-585
     const float ratio = (float)(maxX - minX) / (float)(maxY - minY);
@@ -292,7 +381,7 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
     for (int i = 0; i < nIni; ++i) {
         int id = new_node(L);
         if (id < 0) return -2;
-        OctNode &r = L.nodes[id];
+        Node &r = L.nodes[id];
         r.x0 = (int16_t)(int)(hX * (float)i);
         r.x1 = (int16_t)(int)(hX * (float)(i + 1));
         r.y0 = 0;
@@ -301,7 +390,7 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
     }
     if (!Coop::kWave) {
         for (int i = 0; i < n; ++i) {
-            int r = (int)((float)xs[i] / hX);
+            int r = (int)((float)C.x(i) / hX);
             if (r >= nIni) r = nIni - 1;  // cannot happen for x < maxX-minX; guards the arena
             L.nodes[r].cnt++;
         }
@@ -312,9 +401,9 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
             L.nodes[i].cnt = 0;
         }
         for (int i = 0; i < n; ++i) {
-            int r = (int)((float)xs[i] / hX);
+            int r = (int)((float)C.x(i) / hX);
             if (r >= nIni) r = nIni - 1;
-            perm[L.nodes[r].beg + L.nodes[r].cnt++] = i;
+            perm[L.nodes[r].beg + L.nodes[r].cnt++] = (Idx)i;
         }
     } else {
         // stable bucketing by root, one ballot per root and 64-key chunk
@@ -327,30 +416,28 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 const int i = base + lane;
                 int rr = -1;
                 if (i < n) {
-                    rr = (int)((float)xs[i] / hX);
+                    rr = (int)((float)C.x(i) / hX);
                     if (rr >= nIni) rr = nIni - 1;
                 }
                 const unsigned long long bal = coop_ballot(rr == r);
-                if (rr == r) perm[acc + c + coop_popc(bal & lt)] = i;
+                if (rr == r) perm[acc + c + coop_popc(bal & lt)] = (Idx)i;
                 c += coop_popc(bal);
             }
-            L.nodes[r].beg = acc;
-            L.nodes[r].cnt = c;
+            L.nodes[r].beg = (decltype(L.nodes[r].beg))acc;
+            L.nodes[r].cnt = (decltype(L.nodes[r].cnt))c;
             acc += c;
         }
         coop_sync();
     }
     for (int lit = L.head; lit >= 0;) {
-        OctNode &nd = L.nodes[lit];
-        if (nd.cnt == 1) {
-            nd.no_more = 1;
-            lit = nd.next;
-        } else if (nd.cnt == 0)
+        Node &nd = L.nodes[lit];
+        if (nd.cnt == 0)
             lit = erase(L, lit);
         else
             lit = nd.next;
     }
 
+    OCT_TICK(0);  // roots + bucketing
     bool finish = false;
     int32_t *cur = S.pairs_a, *prv = S.pairs_b;
     int ncur = 0;
@@ -359,12 +446,13 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
         int nToExpand = 0;
         ncur = 0;
         for (int lit = L.head; lit >= 0;) {
-            if (L.nodes[lit].no_more) {
+            if (L.nodes[lit].cnt == 1) {  // bNoMore
                 lit = L.nodes[lit].next;
                 continue;
             }
             int c[4], ccnt[4], nxt;
-            if (!divide<Coop>(L, lit, c, ccnt, nxt, xs, ys, perm, tmp)) return -2;
+            if (!divide<Coop, Tr>(L, lit, c, ccnt, nxt, C, perm, tmp)) return -2;
+            if (ncur + 4 > S.max_pairs) return -2;
             for (int q = 0; q < 4; ++q) {
                 const int cn = ccnt[q];
                 if (cn > 0) {
@@ -378,21 +466,26 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                 }
             }
             lit = nxt;
+            OCT_COUNT(8, 1);
         }
+        OCT_TICK(1);  // main passes
+        OCT_COUNT(9, 1);
         if (L.size >= N || L.size == prevSize) {
             finish = true;
         } else if (L.size + nToExpand * 3 > N) {
             while (!finish) {
                 const int prevSize2 = L.size;
-                // swap buffers: prv = recorded pairs, cur = empty
-                int32_t *t = prv; prv = cur; cur = t;
+                // sort the recorded pairs into prv; cur is then free for this round's records
                 const int nprev = ncur;
                 ncur = 0;
-                pair_sort(prv, nprev);
+                pair_sort_to<Coop>(cur, nprev, prv);
+                OCT_TICK(2);  // sort
+                OCT_COUNT(10, nprev);
                 for (int j = nprev - 1; j >= 0; --j) {
                     const int id = prv[2 * j + 1];
                     int c[4], ccnt[4], nxt;
-                    if (!divide<Coop>(L, id, c, ccnt, nxt, xs, ys, perm, tmp)) return -2;
+                    if (!divide<Coop, Tr>(L, id, c, ccnt, nxt, C, perm, tmp)) return -2;
+                    if (ncur + 4 > S.max_pairs) return -2;
                     for (int q = 0; q < 4; ++q) {
                         const int cn = ccnt[q];
                         if (cn > 0) {
@@ -404,8 +497,10 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
                             }
                         }
                     }
+                    OCT_COUNT(11, 1);
                     if (L.size >= N) break;
                 }
+                OCT_TICK(3);  // final-phase divides
                 if (L.size >= N || L.size == prevSize2) finish = true;
             }
         }
@@ -414,14 +509,14 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
     int nout = 0;
     if (!Coop::kWave) {
         for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
-            const OctNode &nd = L.nodes[lit];
+            const Node &nd = L.nodes[lit];
             int best = perm[nd.beg];
-            int maxResponse = score[best];
+            int maxResponse = C.score(best);
             for (int k = 1; k < nd.cnt; ++k) {
                 const int idx = perm[nd.beg + k];
-                if (score[idx] > maxResponse) {
+                if (C.score(idx) > maxResponse) {
                     best = idx;
-                    maxResponse = score[idx];
+                    maxResponse = C.score(idx);
                 }
             }
             if (nout >= cap) return -3;
@@ -431,26 +526,38 @@ AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const ui
         // list order -> array (uniform walk), then one lane per node
         int32_t *order = S.pairs_a;  // free at this point
         for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
-            if (nout >= cap) return -3;
+            if (nout >= cap || nout >= 2 * S.max_pairs) return -3;
             order[nout++] = lit;
         }
         coop_sync();
         for (int j = coop_lane(); j < nout; j += 64) {
-            const OctNode nd = L.nodes[order[j]];
+            const Node nd = L.nodes[order[j]];
             int best = perm[nd.beg];
-            int maxResponse = score[best];
+            int maxResponse = C.score(best);
             for (int k = 1; k < nd.cnt; ++k) {
                 const int idx = perm[nd.beg + k];
-                if (score[idx] > maxResponse) {
+                if (C.score(idx) > maxResponse) {
                     best = idx;
-                    maxResponse = score[idx];
+                    maxResponse = C.score(idx);
                 }
             }
             out_idx[j] = best;
         }
         coop_sync();
     }
+    OCT_TICK(4);  // best response
+    OCT_COUNT(12, 1);
+    OCT_COUNT(13, L.n_alloc);
     return nout;
+}
+
+// split-array form used by the host paths
+template <class Coop = SerialCoop>
+AOS2_OCT_HD int distribute_octree(const int16_t *xs, const int16_t *ys, const uint8_t *score, int n, int minX, int maxX,
+                                  int minY, int maxY, int N, const OctScratch &S, int32_t *out_idx, int cap)
+{
+    const OctCandsSplit C{xs, ys, score};
+    return distribute_octree<Coop, OctWide>(C, n, minX, maxX, minY, maxY, N, S, out_idx, cap);
 }
 
 }  // namespace aos2
