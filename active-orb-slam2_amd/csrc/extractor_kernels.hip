@@ -42,8 +42,9 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 // resize() does (float fx, two separately rounded shorts), so host and device cannot disagree.
 // One thread = 4 horizontally adjacent output pixels (one aligned 32-bit store).
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_ROWS = 12;     // max source rows per 4-row output tile (scale <= 2.5)
-constexpr int RS_PITCH = 672;   // max staged source bytes per row (256 outputs * scale 2.5 + slack)
+constexpr int RS_TILE_H = 16;                 // output rows per workgroup (4 per thread)
+constexpr int RS_ROWS = 2 * RS_TILE_H + 3;    // max source rows of a tile (scale <= 2.0)
+constexpr int RS_PITCH = 544;                 // max staged source bytes per row (256 outputs * scale 2.0 + slack)
 
 __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__restrict__ src_base,
                                                            size_t src_img_stride, int src_pitch,
@@ -57,19 +58,29 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
     __shared__ __attribute__((aligned(16))) uint8_t tile[RS_ROWS * RS_PITCH];
     const int b = blockIdx.z;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int dy0 = blockIdx.y * 4, dxb = blockIdx.x * 256;
-    const int dy = dy0 + threadIdx.y;
+    const int dy0 = blockIdx.y * RS_TILE_H, dxb = blockIdx.x * 256;
     const int dx0 = dxb + threadIdx.x * 4;
     const uint8_t *sp = src_base + (size_t)b * src_img_stride;
     uint8_t *dp = pyr + (size_t)b * pyr_stride + dst.off;
     // source window of this output tile
-    const int dx_last = min(dxb + 255, dst.w - 1), dy_last = min(dy0 + 3, dst.h - 1);
+    const int dx_last = min(dxb + 255, dst.w - 1), dy_last = min(dy0 + RS_TILE_H - 1, dst.h - 1);
     const int sx_min = xofs[dst.tab_x + dxb] & ~3;
     const int sx_max = min(xofs[dst.tab_x + dx_last] + 1, src.w - 1);
     const int sy_min = min(max(yofs[dst.tab_y + dy0], 0), src.h - 1);
     const int sy_max = min(max(yofs[dst.tab_y + dy_last] + 1, 0), src.h - 1);
     const int ndw = (sx_max - sx_min + 4) >> 2;
     const int nrow = sy_max - sy_min + 1;
+    // per-thread tables: issued before the staging loop so their latency overlaps it (tables are padded to x4)
+    const bool col_ok = dx0 < dst.w;
+    const int4 xo = col_ok ? *reinterpret_cast<const int4 *>(xofs + dst.tab_x + dx0) : make_int4(0, 0, 0, 0);
+    const int4 xa = col_ok ? *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0) : make_int4(0, 0, 0, 0);
+    int ysrc[4], ycoef[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dy = min(dy0 + threadIdx.y + 4 * j, dst.h - 1);
+        ysrc[j] = yofs[dst.tab_y + dy];
+        ycoef[j] = yab[dst.tab_y + dy];
+    }
     {
         // linear item -> (row, dword) by an exact multiply-high division; 32-bit offsets
         const uint8_t *win = sp + (size_t)sy_min * src_pitch + sx_min;
@@ -81,33 +92,34 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
         }
     }
     __syncthreads();
-    if (dy >= dst.h || dx0 >= dst.w) return;
-    int sy0 = yofs[dst.tab_y + dy], sy1 = sy0 + 1;
-    sy0 = min(max(sy0, 0), src.h - 1) - sy_min;
-    sy1 = min(max(sy1, 0), src.h - 1) - sy_min;
-    const int bb = yab[dst.tab_y + dy];
-    const int b0 = (int)(short)(bb & 0xffff), b1 = (int)(short)(bb >> 16);
-    const uint8_t *S0 = tile + sy0 * RS_PITCH - sx_min, *S1 = tile + sy1 * RS_PITCH - sx_min;
-    const int4 xo = *reinterpret_cast<const int4 *>(xofs + dst.tab_x + dx0);   // tables are padded to x4
-    const int4 xa = *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0);
+    if (!col_ok) return;
     const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
     const int aas[4] = {xa.x, xa.y, xa.z, xa.w};
-    uint32_t out = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int dx = dx0 + k;
-        if (dx < dst.w) {
-            const int sx = sxs[k];
-            const int sx1 = sx + 1 < src.w ? sx + 1 : sx;
-            const int a0 = (int)(short)(aas[k] & 0xffff), a1 = (int)(short)(aas[k] >> 16);
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            out |= (uint32_t)v << (8 * k);
+    for (int j = 0; j < 4; ++j) {
+        const int dy = dy0 + threadIdx.y + 4 * j;
+        if (dy >= dst.h) break;
+        const int sy0 = min(max(ysrc[j], 0), src.h - 1) - sy_min;
+        const int sy1 = min(max(ysrc[j] + 1, 0), src.h - 1) - sy_min;
+        const int b0 = (int)(short)(ycoef[j] & 0xffff), b1 = (int)(short)(ycoef[j] >> 16);
+        const uint8_t *S0 = tile + sy0 * RS_PITCH - sx_min, *S1 = tile + sy1 * RS_PITCH - sx_min;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = dx0 + k;
+            if (dx < dst.w) {
+                const int sx = sxs[k];
+                const int sx1 = sx + 1 < src.w ? sx + 1 : sx;
+                const int a0 = (int)(short)(aas[k] & 0xffff), a1 = (int)(short)(aas[k] >> 16);
+                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                out |= (uint32_t)v << (8 * k);
+            }
         }
+        *reinterpret_cast<uint32_t *>(dp + (size_t)dy * dst.pitch + dx0) = out;
     }
-    *reinterpret_cast<uint32_t *>(dp + (size_t)dy * dst.pitch + dx0) = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,7 +676,7 @@ void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
                    const int *yab, int batch, hipStream_t st)
 {
-    dim3 blk(64, 4), grd((dst.w + 255) / 256, (dst.h + 3) / 4, batch);
+    dim3 blk(64, 4), grd((dst.w + 255) / 256, (dst.h + RS_TILE_H - 1) / RS_TILE_H, batch);
     hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
                        dst, xofs, xab, yofs, yab);
 }
