@@ -77,6 +77,22 @@ def lib():
             L.aos2_compute_stereo_matches_device.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
             L.aos2_compute_stereo_matches_last_device_ms.restype = cf
             L.aos2_compute_stereo_matches_last_device_ms.argtypes = [vp]
+        if hasattr(L, "aos2_vocabulary_create"):
+            L.aos2_vocabulary_create.argtypes = [ci, C.POINTER(vp)]
+            L.aos2_vocabulary_destroy.argtypes = [vp]
+            L.aos2_vocabulary_load_binary.argtypes = [vp, C.c_char_p]
+            L.aos2_vocabulary_load_text.argtypes = [vp, C.c_char_p]
+            L.aos2_vocabulary_save_binary.argtypes = [vp, C.c_char_p]
+            L.aos2_vocabulary_set_nodes.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+            for nm in ("k", "levels", "scoring", "weighting", "nodes", "empty"):
+                getattr(L, "aos2_vocabulary_" + nm).argtypes = [vp]
+            L.aos2_vocabulary_size.argtypes = [vp]
+            L.aos2_vocabulary_size.restype = C.c_uint
+            L.aos2_vocabulary_transform.argtypes = [vp, vp, ci, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp, vp]
+            L.aos2_vocabulary_transform_device.argtypes = [vp, ci, vp, vp, ci, ci] + [vp] * 9
+            L.aos2_vocabulary_last_device_ms.restype = cf
+            L.aos2_vocabulary_last_device_ms.argtypes = [vp]
+            L.aos2_vocabulary_score.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.POINTER(C.c_double)]
         L.aos2_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
         L.aos2_debug_sincos_host.argtypes = [cf, C.POINTER(cf), C.POINTER(cf)]
         L.aos2_debug_sincos_device.argtypes = [vp, ci, vp, vp, ci]
@@ -239,6 +255,78 @@ class Extractor:
         ms = C.c_float(0)
         _check(self.L.aos2_extractor_bench_describe(self.h, iters, C.byref(ms)))
         return ms.value
+
+
+class Vocabulary:
+    """ORBVocabulary (include/ORBVocabulary.h:31-32): loaders, transform(), score()."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.aos2_vocabulary_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aos2_vocabulary_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def loadFromBinaryFile(self, path):
+        return self.L.aos2_vocabulary_load_binary(self.h, str(path).encode()) == AOS2_OK
+
+    def loadFromTextFile(self, path):
+        return self.L.aos2_vocabulary_load_text(self.h, str(path).encode()) == AOS2_OK
+
+    def saveToBinaryFile(self, path):
+        _check(self.L.aos2_vocabulary_save_binary(self.h, str(path).encode()))
+
+    def set_nodes(self, k, L, scoring, weighting, parent, desc, weight, is_leaf):
+        parent = np.ascontiguousarray(parent, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        _check(self.L.aos2_vocabulary_set_nodes(self.h, k, L, scoring, weighting, len(parent), _p(parent), _p(desc),
+                                                _p(weight), _p(is_leaf)))
+
+    def info(self):
+        g = lambda n: getattr(self.L, "aos2_vocabulary_" + n)(self.h)  # noqa: E731
+        return dict(k=g("k"), L=g("levels"), scoring=g("scoring"), weighting=g("weighting"), nodes=g("nodes"),
+                    words=int(g("size")))
+
+    def empty(self):
+        return bool(self.L.aos2_vocabulary_empty(self.h))
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(bow_word, bow_value, fv_node, fv_off, fv_idx, word_of, node_of)"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        bw, bv = np.zeros(m, np.uint32), np.zeros(m, np.float64)
+        fn, fo, fi = np.zeros(m, np.int32), np.zeros(n + 2, np.int32), np.zeros(m, np.int32)
+        wo, no = np.zeros(m, np.uint32), np.zeros(m, np.uint32)
+        nb, nf = C.c_int(0), C.c_int(0)
+        _check(self.L.aos2_vocabulary_transform(self.h, _p(desc), n, levelsup, _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fo),
+                                                _p(fi), C.byref(nf), _p(wo), _p(no)))
+        nb, nf = nb.value, nf.value
+        return dict(bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=fn[:nf].copy(), fv_off=fo[: nf + 1].copy(),
+                    fv_idx=fi[: fo[nf]].copy(), word_of=wo[:n].copy(), node_of=no[:n].copy())
+
+    def transform_device(self, batch, d_desc, d_n, cap, levelsup, d_bw, d_bv, d_nb, d_fn, d_fo, d_fi, d_nf, d_wo=0, d_no=0):
+        """raw device pointers (ints); returns the device time in ms"""
+        V = C.c_void_p
+        _check(self.L.aos2_vocabulary_transform_device(self.h, batch, V(d_desc), V(d_n), cap, levelsup, V(d_bw), V(d_bv),
+                                                       V(d_nb), V(d_fn), V(d_fo), V(d_fi), V(d_nf), V(d_wo or None),
+                                                       V(d_no or None)))
+        return float(self.L.aos2_vocabulary_last_device_ms(self.h))
+
+    def score(self, a, b):
+        w1, v1 = np.ascontiguousarray(a["bow_word"], np.uint32), np.ascontiguousarray(a["bow_value"], np.float64)
+        w2, v2 = np.ascontiguousarray(b["bow_word"], np.uint32), np.ascontiguousarray(b["bow_value"], np.float64)
+        s = C.c_double(0)
+        _check(self.L.aos2_vocabulary_score(self.h, _p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2), C.byref(s)))
+        return s.value
 
 
 def ComputeStereoMatches(left: Extractor, right: Extractor, kps_l, desc_l, kps_r, desc_r, mb, mbf, image=0):

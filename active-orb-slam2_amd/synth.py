@@ -108,6 +108,56 @@ def synth_stereo_pair(seed: int, w: int = 640, h: int = 480, max_disp: int = 48)
             disp)
 
 
+def synth_vocabulary(seed: int, k: int = 10, L: int = 3, stop_frac: float = 0.02, ragged: bool = False):
+    """Hierarchical binary vocabulary in the reference's node order (DBoW2 saves nodes depth-first as k-means
+    created them; here level by level -- both satisfy "parents precede children").  Each child descriptor is
+    its parent's with bits flipped (fewer flips deeper), leaf weights are idf-like positives, a fraction of
+    the words is stopped (weight 0, TemplatedVocabulary.h:1176).  ragged=True removes some subtrees so that
+    leaves appear above level L.  Returns dict(k, L, scoring=0 (L1_NORM), weighting=0 (TF_IDF), parent, desc,
+    weight, is_leaf) for nodes 1..n (node 0 is the root)."""
+    rng = np.random.default_rng(np.uint64(0xA0761D6478BD642F) ^ np.uint64(seed))
+    nid = 1
+    prev_ids = np.array([0])
+    prev_desc = rng.integers(0, 256, size=(1, 32), dtype=np.uint8)
+    all_parent, all_desc, all_leaf = [], [], []
+    for lev in range(1, L + 1):
+        if ragged and lev > 1 and len(prev_ids) > 2:  # some nodes of the previous level stay childless (= leaves)
+            keep = rng.random(len(prev_ids)) > 0.15
+            keep[0] = True
+            all_leaf[-1][~keep] = 1
+            prev_ids, prev_desc = prev_ids[keep], prev_desc[keep]
+        n_par = len(prev_ids)
+        # bit flips: p = 1/2 below the root, then 1/8, 1/16, ... (AND of independent random bytes)
+        flips = rng.integers(0, 256, size=(n_par, k, 32), dtype=np.uint8)
+        for _ in range(0 if lev == 1 else min(lev, 4)):
+            flips &= rng.integers(0, 256, size=(n_par, k, 32), dtype=np.uint8)
+        d = prev_desc[:, None, :] ^ flips
+        ids = nid + np.arange(n_par * k)
+        all_parent.append(np.repeat(prev_ids, k).astype(np.int32))
+        all_desc.append(d.reshape(-1, 32))
+        all_leaf.append(np.full(n_par * k, 1 if lev == L else 0, np.uint8))
+        prev_ids, prev_desc = ids, d.reshape(-1, 32)
+        nid += n_par * k
+    parent = np.concatenate(all_parent)
+    desc = np.concatenate(all_desc)
+    is_leaf = np.concatenate(all_leaf)
+    weight = np.where(is_leaf > 0, rng.uniform(0.5, 12.0, len(parent)), 0.0)
+    weight = weight.astype(np.float32).astype(np.float64)  # what the binary file format can hold
+    stop = (rng.random(len(parent)) < stop_frac) & (is_leaf > 0)
+    weight[stop] = 0.0
+    return dict(k=k, L=L, scoring=0, weighting=0, parent=parent, desc=desc, weight=weight, is_leaf=is_leaf)
+
+
+def vocab_descriptors(rng, voc, n, p=0.04):
+    """n query descriptors: random leaves of the vocabulary with bit noise (plus 10 % unrelated ones)"""
+    leaves = np.flatnonzero(voc["is_leaf"])
+    pick = rng.choice(leaves, n)
+    d = flip_bits(rng, voc["desc"][pick], p)
+    r = rng.random(n) < 0.1
+    d[r] = rng.integers(0, 256, size=(int(r.sum()), 32), dtype=np.uint8)
+    return d
+
+
 def synth_descriptors(rng, n):
     return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
 

@@ -157,6 +157,73 @@ int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms);
 int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms);
 
 /* ------------------------------------------------------------------------------------------
+ * ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>   
+ * (include/ORBVocabulary.h:31-32, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct aos2_vocabulary aos2_vocabulary_t;
+
+/* DBoW2 enums (Thirdparty/DBoW2/DBoW2/BowVector.h:36-53) */
+#define AOS2_WEIGHT_TF_IDF 0
+#define AOS2_WEIGHT_TF 1
+#define AOS2_WEIGHT_IDF 2
+#define AOS2_WEIGHT_BINARY 3
+#define AOS2_SCORING_L1_NORM 0
+#define AOS2_SCORING_L2_NORM 1
+#define AOS2_SCORING_CHI_SQUARE 2
+#define AOS2_SCORING_KL 3
+#define AOS2_SCORING_BHATTACHARYYA 4
+#define AOS2_SCORING_DOT_PRODUCT 5
+
+int aos2_vocabulary_create(int device, aos2_vocabulary_t **out);
+void aos2_vocabulary_destroy(aos2_vocabulary_t *v);
+/* bool loadFromBinaryFile(filename) :1456-1496 / loadFromTextFile :1351-1431 (src/System.cc:89-92),
+ * saveToBinaryFile :1500-1521.  Both loaders reproduce the reference's `while(!f.eof())` tail
+ * (binary: the last record is appended twice; text: a final newline yields one more, childless,
+ * zero-weight child of the root) -- see DESIGN.md §5.5. */
+int aos2_vocabulary_load_binary(aos2_vocabulary_t *v, const char *filename);
+int aos2_vocabulary_load_text(aos2_vocabulary_t *v, const char *filename);
+int aos2_vocabulary_save_binary(const aos2_vocabulary_t *v, const char *filename);
+/* Programmatic construction (no reference equivalent; the vocabulary file is absent):
+ * record i describes node i+1 exactly like one record of the binary file (parent id, 32-byte
+ * descriptor, weight, leaf flag); parents must precede their children. */
+int aos2_vocabulary_set_nodes(aos2_vocabulary_t *v, int k, int L, int scoring, int weighting,
+                              int n_nodes, const int32_t *parent, const uint8_t *desc,
+                              const double *weight, const uint8_t *is_leaf);
+int aos2_vocabulary_k(const aos2_vocabulary_t *v);          /* getBranchingFactor() */
+int aos2_vocabulary_levels(const aos2_vocabulary_t *v);     /* getDepthLevels() */
+int aos2_vocabulary_scoring(const aos2_vocabulary_t *v);    /* getScoringType() */
+int aos2_vocabulary_weighting(const aos2_vocabulary_t *v);  /* getWeightingType() */
+int aos2_vocabulary_nodes(const aos2_vocabulary_t *v);      /* m_nodes.size() */
+unsigned aos2_vocabulary_size(const aos2_vocabulary_t *v);  /* size() = number of words */
+int aos2_vocabulary_empty(const aos2_vocabulary_t *v);      /* empty() */
+
+/* void transform(const vector<TDescriptor>& features, BowVector&, FeatureVector&, int levelsup)
+ * :1140-1187 (Frame::ComputeBoW src/Frame.cc:424-431 and KeyFrame::ComputeBoW call it with
+ * levelsup = 4).  desc: n x 32 bytes, host.  The two std::maps are returned as key-ascending arrays:
+ *   BowVector     bow_word[*n_bow], bow_value[*n_bow]                       (capacity n each)
+ *   FeatureVector fv_node[*n_fv], fv_off[*n_fv + 1], fv_idx[fv_off[*n_fv]]  (capacity n, n+1, n)
+ * -- the CSR layout aos2_bow_pair_t takes.  word_of / node_of (optional, n each): per-feature word id
+ * and node id at level L - levelsup (transform(feature, id, weight, &nid, levelsup) :1215-1260).
+ * An empty vocabulary clears both outputs and returns AOS2_OK (:1147-1150). */
+int aos2_vocabulary_transform(aos2_vocabulary_t *v, const uint8_t *desc, int n, int levelsup,
+                              uint32_t *bow_word, double *bow_value, int *n_bow, int32_t *fv_node,
+                              int32_t *fv_off, int32_t *fv_idx, int *n_fv, uint32_t *word_of,
+                              uint32_t *node_of);
+/* Batched device-resident form: d_desc [batch][cap][32] and d_n [batch] as written by
+ * aos2_extractor_extract_batch_device; outputs [batch][cap] (d_fv_off: [batch][cap + 1]),
+ * counts [batch].  d_word_of / d_node_of may be NULL.  cap <= 8192. */
+int aos2_vocabulary_transform_device(aos2_vocabulary_t *v, int batch, const uint8_t *d_desc,
+                                     const int32_t *d_n, int cap, int levelsup,
+                                     uint32_t *d_bow_word, double *d_bow_value, int32_t *d_n_bow,
+                                     int32_t *d_fv_node, int32_t *d_fv_off, int32_t *d_fv_idx,
+                                     int32_t *d_n_fv, uint32_t *d_word_of, uint32_t *d_node_of);
+float aos2_vocabulary_last_device_ms(const aos2_vocabulary_t *v);
+/* double score(const BowVector&, const BowVector&) :1191-1195 for L1_NORM
+ * (L1Scoring::score, Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-72); host scalar helper. */
+int aos2_vocabulary_score(const aos2_vocabulary_t *v, const uint32_t *w1, const double *v1, int n1,
+                          const uint32_t *w2, const double *v2, int n2, double *score);
+
+/* ------------------------------------------------------------------------------------------
  * ORBmatcher  (include/ORBmatcher.h:37-102, src/ORBmatcher.cc)
  * The C++ shim snapshots the Frame / KeyFrame / MapPoint fields each method reads into the SoA
  * views below and maps the returned indices back to MapPoint*.

@@ -66,6 +66,17 @@ def lib():
         L.orc_search_by_projection_mp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_vocab_create.restype = C.c_void_p
+        L.orc_vocab_destroy.argtypes = [C.c_void_p]
+        for name in ("k", "L", "scoring", "weighting", "nodes", "size"):
+            getattr(L, "orc_vocab_" + name).argtypes = [C.c_void_p]
+        L.orc_vocab_set_nodes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.orc_vocab_load_binary.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_vocab_save_binary.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_vocab_load_text.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_vocab_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9
+        L.orc_vocab_score_l1.restype = C.c_double
+        L.orc_vocab_score_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_se3_mul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -365,6 +376,69 @@ def compute_stereo_matches(ext_left: "Extractor", ext_right: "Extractor", kps_l,
     dp = np.zeros(len(kps_l), np.float32)
     n = L.orc_compute_stereo_matches(C.byref(P), _p(ur), _p(dp))
     return ur, dp, n
+
+
+class Vocabulary:
+    """ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> restatement (dbow_oracle.c)."""
+
+    def __init__(self):
+        self.L_ = lib()
+        self.h = self.L_.orc_vocab_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L_.orc_vocab_destroy(self.h)
+            self.h = None
+
+    def set_nodes(self, k, L, scoring, weighting, parent, desc, weight, is_leaf):
+        parent = np.ascontiguousarray(parent, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        st = self.L_.orc_vocab_set_nodes(self.h, k, L, scoring, weighting, len(parent), _p(parent), _p(desc), _p(weight),
+                                         _p(is_leaf))
+        if st:
+            raise ValueError(f"set_nodes failed: {st}")
+
+    def load_binary(self, path):
+        return self.L_.orc_vocab_load_binary(self.h, str(path).encode()) == 0
+
+    def save_binary(self, path):
+        return self.L_.orc_vocab_save_binary(self.h, str(path).encode()) == 0
+
+    def load_text(self, path):
+        return self.L_.orc_vocab_load_text(self.h, str(path).encode()) == 0
+
+    def info(self):
+        g = lambda n: getattr(self.L_, "orc_vocab_" + n)(self.h)  # noqa: E731
+        return dict(k=g("k"), L=g("L"), scoring=g("scoring"), weighting=g("weighting"), nodes=g("nodes"), words=g("size"))
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(bow_word, bow_value, fv_node, fv_off, fv_idx, word_of, node_of) or None if the vocabulary is empty"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        bw = np.zeros(max(n, 1), np.uint32)
+        bv = np.zeros(max(n, 1), np.float64)
+        fn = np.zeros(max(n, 1), np.int32)
+        fo = np.zeros(n + 2, np.int32)
+        fi = np.zeros(max(n, 1), np.int32)
+        wo = np.zeros(max(n, 1), np.uint32)
+        no = np.zeros(max(n, 1), np.uint32)
+        nb, nf = C.c_int(0), C.c_int(0)
+        st = self.L_.orc_vocab_transform(self.h, _p(desc), n, levelsup, _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(fi),
+                                         C.byref(nf), _p(wo), _p(no))
+        if st:
+            return None
+        nb, nf = nb.value, nf.value
+        return dict(bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=fn[:nf].copy(), fv_off=fo[: nf + 1].copy(),
+                    fv_idx=fi[: fo[nf]].copy(), word_of=wo[:n].copy(), node_of=no[:n].copy())
+
+
+def vocab_score_l1(a, b):
+    L = lib()
+    w1, v1 = np.ascontiguousarray(a["bow_word"], np.uint32), np.ascontiguousarray(a["bow_value"], np.float64)
+    w2, v2 = np.ascontiguousarray(b["bow_word"], np.uint32), np.ascontiguousarray(b["bow_value"], np.float64)
+    return L.orc_vocab_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
 
 
 class _LbaProblem(C.Structure):

@@ -169,6 +169,26 @@ typedef struct {
 /* fills mvuRight / mvDepth (-1 = no match); returns the number of matches before the median cull */
 int orc_compute_stereo_matches(const orc_stereo_problem_t *p, float *u_right, float *depth);
 
+/* ---- DBoW2 vocabulary (ORBVocabulary), SURVEY §8(f) rank 3: dbow_oracle.c ---- */
+typedef struct orc_vocab orc_vocab_t;
+orc_vocab_t *orc_vocab_create(void);
+void orc_vocab_destroy(orc_vocab_t *v);
+int orc_vocab_k(const orc_vocab_t *v);
+int orc_vocab_L(const orc_vocab_t *v);
+int orc_vocab_scoring(const orc_vocab_t *v);
+int orc_vocab_weighting(const orc_vocab_t *v);
+int orc_vocab_nodes(const orc_vocab_t *v); /* m_nodes.size() (root included) */
+int orc_vocab_size(const orc_vocab_t *v);  /* size() = number of words */
+int orc_vocab_set_nodes(orc_vocab_t *v, int k, int L, int scoring, int weighting, int n, const int32_t *parent,
+                        const uint8_t *desc, const double *weight, const uint8_t *is_leaf);
+int orc_vocab_load_binary(orc_vocab_t *v, const char *path);
+int orc_vocab_save_binary(const orc_vocab_t *v, const char *path);
+int orc_vocab_load_text(orc_vocab_t *v, const char *path);
+int orc_vocab_transform(const orc_vocab_t *v, const uint8_t *desc, int n, int levelsup, uint32_t *bow_word,
+                        double *bow_value, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx,
+                        int *n_fv, uint32_t *word_of, uint32_t *node_of);
+double orc_vocab_score_l1(const uint32_t *w1, const double *v1, int n1, const uint32_t *w2, const double *v2, int n2);
+
 /* ---- local BA: src/Optimizer.cc:454-779 + vendored g2o ---- */
 typedef struct {
     int n_poses;               /* local + fixed keyframes */

@@ -85,3 +85,10 @@ np.savez_compressed(os.path.join(OUT, "stereo_euroc.npz"), seed=seed, w=w, h=h, 
                     left_crc=np.uint32(zlib.crc32(left.tobytes())), right_crc=np.uint32(zlib.crc32(right.tobytes())),
                     n_left=len(kl), n_right=len(kr), u_right=ur, depth=dp, n_before_cull=n)
 print("stereo", n, int((ur >= 0).sum()))
+# ORBVocabulary::transform: vocabulary regenerated from the seed
+seed, k, L, lu = 51, 10, 3, 2
+voc = S.synth_vocabulary(seed, k, L)
+V = O.Vocabulary()
+V.set_nodes(k, L, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+d = S.vocab_descriptors(np.random.default_rng(52), voc, 600)
+np.savez_compressed(os.path.join(OUT, "vocab_k10_L3.npz"), seed=seed, k=k, L=L, levelsup=lu, desc=d, **V.transform(d, lu))

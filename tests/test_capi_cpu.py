@@ -138,3 +138,32 @@ def test_synth_is_seeded(pkg):
     assert (pkg.synth.synth_image(4) != a).any()
     off, idx, gwi, ghi = pkg.synth.build_grid(np.array([0.0, 639.9, 320.0], np.float32), np.array([0.0, 479.9, 240.0], np.float32), 0, 0, 640, 480)
     assert off[-1] == 2 and len(off) == 64 * 48 + 1  # the point at the max border falls outside (posX == 64)
+
+
+def test_vocabulary_host_side_without_gpu(pkg, oracle, tmp_path):
+    """Loaders, getters, saveToBinaryFile and score() are host code: same results as the oracle, no device."""
+    S = pkg.synth
+    voc = S.synth_vocabulary(5, 10, 3)
+    V, O = pkg.Vocabulary(), oracle.Vocabulary()
+    assert V.empty() and V.info()["nodes"] == 0
+    V.set_nodes(10, 3, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    O.set_nodes(10, 3, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    assert V.info() == O.info() == dict(k=10, L=3, scoring=0, weighting=0, nodes=1111, words=1000)
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    V.saveToBinaryFile(a)
+    assert O.save_binary(b) and a.read_bytes() == b.read_bytes()
+    V2 = pkg.Vocabulary()
+    assert V2.loadFromBinaryFile(a) and V2.info()["nodes"] == 1112 and V2.info()["words"] == 1001   # eof quirk
+    assert not V2.loadFromBinaryFile(tmp_path / "missing.bin") and not V2.loadFromTextFile(tmp_path / "missing.txt")
+    bad = tmp_path / "bad.txt"
+    bad.write_text("99 3 0 0\n")
+    assert not V2.loadFromTextFile(bad)
+    with pytest.raises(pkg.AosError):
+        V2.set_nodes(10, 3, 0, 0, [0, 5], voc["desc"][:2], voc["weight"][:2], voc["is_leaf"][:2])  # parent after child
+    assert V2.empty()
+    rng = np.random.default_rng(1)
+    r1, r2 = O.transform(S.vocab_descriptors(rng, voc, 400), 2), O.transform(S.vocab_descriptors(rng, voc, 400), 2)
+    assert V.score(r1, r2) == oracle.vocab_score_l1(r1, r2) and abs(V.score(r1, r1) - 1.0) < 1e-12
+    if pkg.device_count() == 0:  # transform needs the device: loud failure, no CPU fallback
+        with pytest.raises(pkg.AosError):
+            V.transform(voc["desc"][:10], 2)

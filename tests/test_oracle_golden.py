@@ -265,3 +265,80 @@ def test_compute_stereo_matches_edge_cases(oracle, pkg):
     eR.extract(left)
     u3, d3, n3 = oracle.compute_stereo_matches(eL, eR, kl, dl, kl, dl, mb, mbf)
     assert n3 > 100 and (u3 == -1).all() and (d3 == -1).all()
+
+
+def test_vocabulary_transform_handmade_known_answer(oracle):
+    """k=2, L=2 tree worked out by hand (DBoW2 TemplatedVocabulary.h:1140-1260, BowVector.cpp:30-82)."""
+    Z, F = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    h = np.zeros(32, np.uint8)
+    h[:16] = 255
+    q = np.zeros(32, np.uint8)
+    q[:8] = 255
+    # nodes: 1 = Z, 2 = F (children of the root); 3 = Z, 4 = q (children of 1); 5 = h, 6 = F (children of 2)
+    parent = [0, 0, 1, 1, 2, 2]
+    desc = np.stack([Z, F, Z, q, h, F])
+    weight = [0, 0, 2.0, 0.5, 1.0, 0.0]  # word 3 (node 6) is stopped
+    leaf = [0, 0, 1, 1, 1, 1]
+    V = oracle.Vocabulary()
+    V.set_nodes(2, 2, 0, 0, parent, desc, weight, leaf)
+    assert V.info() == dict(k=2, L=2, scoring=0, weighting=0, nodes=7, words=4)
+    feats = np.stack([Z, q, q, F, h, Z])  # words 0, 1, 1, 3(stopped), tie h: d(h,Z)=d(h,F)=128 -> first child (node 1) -> d(h,Z)=128 > d(h,q)=64 -> word 1; word 0
+    r = V.transform(feats, 1)   # nid level = L - 1 = 1 -> nodes 1 / 2
+    assert r["word_of"].tolist() == [0, 1, 1, 3, 1, 0]
+    assert r["node_of"].tolist() == [1, 1, 1, 2, 1, 1]
+    # TF-IDF: word 0: 2+2 = 4, word 1: 0.5*3 = 1.5; L1 norm 5.5
+    assert r["bow_word"].tolist() == [0, 1] and r["bow_value"].tolist() == [4 / 5.5, 1.5 / 5.5]
+    assert r["fv_node"].tolist() == [1] and r["fv_off"].tolist() == [0, 5] and r["fv_idx"].tolist() == [0, 1, 2, 4, 5]
+    r0 = V.transform(feats, 0)  # nid level 2 = the leaves themselves
+    assert r0["fv_node"].tolist() == [3, 4] and r0["fv_idx"].tolist() == [0, 5, 1, 2, 4] and r0["fv_off"].tolist() == [0, 2, 5]
+    r2 = V.transform(feats, 2)  # nid level 0 -> root
+    assert r2["fv_node"].tolist() == [0] and r2["node_of"].tolist() == [0] * 6
+    # BINARY weighting + L2: values 2 and .5 once each, / sqrt(4.25)
+    V.set_nodes(2, 2, 1, 3, parent, desc, weight, leaf)
+    rb = V.transform(feats, 1)
+    assert rb["bow_value"].tolist() == [2.0 / np.sqrt(4.25), 0.5 / np.sqrt(4.25)]
+    # L1 score: identical vectors -> 1; disjoint -> 0
+    a = dict(bow_word=np.array([1, 5], np.uint32), bow_value=np.array([0.25, 0.75]))
+    b = dict(bow_word=np.array([2, 7], np.uint32), bow_value=np.array([0.5, 0.5]))
+    assert oracle.vocab_score_l1(a, a) == 1.0 and oracle.vocab_score_l1(a, b) == 0.0
+    c = dict(bow_word=np.array([1, 7], np.uint32), bow_value=np.array([0.5, 0.5]))
+    assert oracle.vocab_score_l1(a, c) == -((abs(0.25 - 0.5) - 0.25 - 0.5)) / 2
+
+
+def test_vocabulary_golden_and_loader_quirks(oracle, pkg, tmp_path):
+    g = np.load(os.path.join(GOLD, "vocab_k10_L3.npz"))
+    S = pkg.synth
+    voc = S.synth_vocabulary(int(g["seed"]), int(g["k"]), int(g["L"]))
+    V = oracle.Vocabulary()
+    V.set_nodes(voc["k"], voc["L"], 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    r = V.transform(g["desc"], int(g["levelsup"]))
+    for k in ("bow_word", "bow_value", "fv_node", "fv_off", "fv_idx", "word_of", "node_of"):
+        assert r[k].tobytes() == g[k].tobytes(), k
+    # independent check of the descent with numpy: greedy argmin (first wins) per level
+    d = g["desc"]
+    bits = lambda a: np.unpackbits(a, axis=-1)  # noqa: E731
+    kk, L = voc["k"], voc["L"]
+    node = np.zeros(len(d), np.int64)  # current node id
+    child0 = {0: 1}
+    first_child = np.full(len(voc["parent"]) + 1, -1, np.int64)
+    for i, p in enumerate(voc["parent"]):
+        if first_child[p] < 0:
+            first_child[p] = i + 1
+    for lev in range(L):
+        fc = first_child[node]
+        cd = voc["desc"][(fc[:, None] + np.arange(kk)[None, :]) - 1]
+        dist = (bits(cd) != bits(d)[:, None, :]).sum(-1)
+        node = fc + dist.argmin(1)
+    leaves = np.flatnonzero(voc["is_leaf"]) + 1
+    assert (np.searchsorted(leaves, node) == r["word_of"]).all()
+    # binary file: saved bytes have the documented layout; loading appends the last record twice (eof quirk)
+    p = tmp_path / "v.bin"
+    assert V.save_binary(p)
+    raw = p.read_bytes()
+    n = len(voc["parent"])
+    assert len(raw) == 24 + 41 * n and np.frombuffer(raw[:24], np.int32).tolist() == [n + 1, 41, 10, 3, 0, 0]
+    W = oracle.Vocabulary()
+    assert W.load_binary(p) and W.info()["nodes"] == n + 2 and W.info()["words"] == V.info()["words"] + 1
+    rw = W.transform(d, int(g["levelsup"]))
+    assert rw["bow_value"].tobytes() == r["bow_value"].tobytes() and rw["fv_idx"].tobytes() == r["fv_idx"].tobytes()
+    assert not W.load_binary(tmp_path / "nope.bin")
