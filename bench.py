@@ -203,6 +203,28 @@ def main():
             extra["stereo_frontend_euroc_64pairs"] = {
                 "pairs_per_s": sb / swall, "wall_ms": swall * 1e3, "compute_stereo_matches_device_ms": float(np.mean(sms)),
                 "matches_per_pair": float((s_dp > 0).sum().item()) / sb}
+            # ORBVocabulary::transform with a vocabulary of the real ORBvoc shape (k=10, L=6: 1.1 M nodes),
+            # 64 frames x 1000 descriptors, device-resident
+            voc = S.synth_vocabulary(400, 10, 6)
+            vv = pkg.Vocabulary(device=local_rank)
+            vv.set_nodes(10, 6, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+            vb, vcap = 64, 1000
+            vd = torch.from_numpy(np.stack([S.vocab_descriptors(rng, voc, vcap) for _ in range(4)] * (vb // 4))).to(dev)
+            vn = torch.full((vb,), vcap, dtype=torch.int32, device=dev)
+            v_bw = torch.empty((vb, vcap), dtype=torch.int32, device=dev)
+            v_bv = torch.empty((vb, vcap), dtype=torch.float64, device=dev)
+            v_fn = torch.empty((vb, vcap), dtype=torch.int32, device=dev)
+            v_fo = torch.empty((vb, vcap + 1), dtype=torch.int32, device=dev)
+            v_fi = torch.empty((vb, vcap), dtype=torch.int32, device=dev)
+            v_nb = torch.empty((vb,), dtype=torch.int32, device=dev)
+            v_nf = torch.empty((vb,), dtype=torch.int32, device=dev)
+            vargs = (vb, vd.data_ptr(), vn.data_ptr(), vcap, 4, v_bw.data_ptr(), v_bv.data_ptr(), v_nb.data_ptr(),
+                     v_fn.data_ptr(), v_fo.data_ptr(), v_fi.data_ptr(), v_nf.data_ptr())
+            vv.transform_device(*vargs)
+            vms = float(np.mean([vv.transform_device(*vargs) for _ in range(5)]))
+            extra["vocabulary_transform_64frames_1000desc_k10L6"] = {
+                "device_ms": vms, "descriptors_per_s": vb * vcap / (vms * 1e-3), "nodes": len(voc["parent"]) + 1,
+                "words_per_frame": float(v_nb.float().mean().item())}
         except Exception as exc:  # secondary numbers must never break the contract line
             extra["error"] = repr(exc)
 

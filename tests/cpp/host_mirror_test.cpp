@@ -9,6 +9,7 @@
 #include "../../active-orb-slam2_amd/host/Frame.h"
 #include "../../active-orb-slam2_amd/host/ORBextractor.h"
 #include "../../active-orb-slam2_amd/host/ORBmatcher.h"
+#include "../../active-orb-slam2_amd/host/ORBVocabulary.h"
 #include "../../active-orb-slam2_amd/host/Optimizer.h"
 
 int main(int argc, char **argv)
@@ -19,6 +20,31 @@ int main(int argc, char **argv)
     std::vector<float> sf = ex.GetScaleFactors(), isig = ex.GetInverseScaleSigmaSquares();
     printf("levels %d scale %.3f sf7 %.6f isig7 %.6f\n", ex.GetLevels(), ex.GetScaleFactor(), sf[7], isig[7]);
     if (ORB_SLAM2::ORBmatcher::TH_LOW != 50 || ORB_SLAM2::ORBmatcher::TH_HIGH != 100 || ORB_SLAM2::ORBmatcher::HISTO_LENGTH != 30) return 4;
+    {   // vocabulary host side: 2 words under the root, save / load (eof quirk: one more node and word)
+        ORB_SLAM2::ORBVocabulary voc;
+        if (!voc.empty()) return 10;
+        const int32_t parent[2] = {0, 0};
+        uint8_t vd[64] = {};
+        for (int i = 32; i < 64; ++i) vd[i] = 255;
+        const double vw[2] = {1.0, 3.0};
+        const uint8_t leaf[2] = {1, 1};
+        if (aos2_vocabulary_set_nodes(voc.handle(), 2, 1, 0, 0, 2, parent, vd, vw, leaf) != AOS2_OK || voc.size() != 2) return 11;
+        if (argc > 5) {
+            const std::string vp = std::string(argv[5]) + ".voc";
+            voc.saveToBinaryFile(vp);
+            ORB_SLAM2::ORBVocabulary v2;
+            if (!v2.loadFromBinaryFile(vp) || v2.size() != 3 || v2.getBranchingFactor() != 2 || v2.getDepthLevels() != 1) return 12;
+            if (aos2_device_count() >= 1) {
+                std::vector<uint8_t> q(3 * 32, 0);
+                for (int i = 64; i < 96; ++i) q[i] = 255;  // features: word 0, word 0, word 1
+                DBoW2::BowVector bv;
+                DBoW2::FeatureVector fv;
+                v2.transform(q.data(), 3, bv, fv, 1);
+                if (bv.size() != 2 || bv[0] != 2.0 / 5.0 || bv[1] != 3.0 / 5.0 || fv.size() != 1 || fv[0].size() != 3) return 13;
+                if (v2.score(bv, bv) != 1.0) return 14;
+            }
+        }
+    }
     if (aos2_device_count() < 1) {
         printf("no device\n");
         return 3;
