@@ -106,6 +106,10 @@ def lib():
             L.aos2_matcher_hamming_best2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
             L.aos2_matcher_hamming_best2_device.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, C.POINTER(cf)]
             L.aos2_matcher_search_by_bow.argtypes = [vp, vp, ci, vp, vp]
+            if hasattr(L, "aos2_matcher_search_by_bow_kf"):
+                L.aos2_matcher_search_by_bow_kf.argtypes = [vp, vp, ci, vp, vp]
+                L.aos2_matcher_search_for_triangulation.argtypes = [vp, vp, ci, ci, vp, vp]
+                L.aos2_compute_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp]
             L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
             L.aos2_matcher_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, vp, vp]
         if hasattr(L, "aos2_lba_create"):
@@ -386,6 +390,26 @@ class _BowPair(C.Structure):
                 ("node_id_f", C.c_void_p), ("node_off_f", C.c_void_p), ("node_idx_f", C.c_void_p)]
 
 
+class _BowKfPair(C.Structure):
+    _fields_ = [("n1", C.c_int32), ("n2", C.c_int32), ("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),
+                ("n_nodes1", C.c_int32), ("n_nodes2", C.c_int32),
+                ("node_id1", C.c_void_p), ("node_off1", C.c_void_p), ("node_idx1", C.c_void_p),
+                ("node_id2", C.c_void_p), ("node_off2", C.c_void_p), ("node_idx2", C.c_void_p)]
+
+
+class _TriangPair(C.Structure):
+    _fields_ = [("n1", C.c_int32), ("n2", C.c_int32), ("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
+                ("x1", C.c_void_p), ("y1", C.c_void_p), ("angle1", C.c_void_p), ("u_right1", C.c_void_p),
+                ("x2", C.c_void_p), ("y2", C.c_void_p), ("angle2", C.c_void_p), ("u_right2", C.c_void_p),
+                ("octave2", C.c_void_p), ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p),
+                ("n_levels2", C.c_int32), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("n_nodes1", C.c_int32), ("n_nodes2", C.c_int32),
+                ("node_id1", C.c_void_p), ("node_off1", C.c_void_p), ("node_idx1", C.c_void_p),
+                ("node_id2", C.c_void_p), ("node_off2", C.c_void_p), ("node_idx2", C.c_void_p)]
+
+
 class _FrameView(C.Structure):
     _fields_ = [("n_f", C.c_int32), ("desc_f", C.c_void_p), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p),
                 ("kp_octave", C.c_void_p), ("kp_angle", C.c_void_p), ("u_right", C.c_void_p),
@@ -416,7 +440,11 @@ _DTYPES = dict(desc_kf=np.uint8, desc_f=np.uint8, kf_has_mp=np.uint8, angle_kf=n
                grid_idx=np.int32, f_mp_state=np.uint8, track_in_view=np.uint8, pred_level=np.int32,
                view_cos=np.float32, proj_x=np.float32, proj_y=np.float32, proj_xr=np.float32, desc=np.uint8,
                has_obs=np.uint8, last_valid=np.uint8, world_pos=np.float32, last_octave=np.int32,
-               last_angle=np.float32)
+               last_angle=np.float32, desc1=np.uint8, desc2=np.uint8, has_mp1=np.uint8, has_mp2=np.uint8,
+               angle1=np.float32, angle2=np.float32, node_id1=np.int32, node_off1=np.int32, node_idx1=np.int32,
+               node_id2=np.int32, node_off2=np.int32, node_idx2=np.int32, x1=np.float32, y1=np.float32, x2=np.float32,
+               y2=np.float32, u_right1=np.float32, u_right2=np.float32, octave2=np.int32, scale_factors2=np.float32,
+               level_sigma2_2=np.float32)
 
 
 def _fill_struct(st, d, keep):
@@ -428,8 +456,8 @@ def _fill_struct(st, d, keep):
             a = np.ascontiguousarray(v, _DTYPES[name])
             keep.append(a)
             setattr(st, name, a.ctypes.data)
-        elif isinstance(v, np.ndarray) and v.size == 16:
-            setattr(st, name, (C.c_float * 16)(*[float(x) for x in v.reshape(-1)]))
+        elif isinstance(v, np.ndarray) and hasattr(ct, "_length_"):
+            setattr(st, name, ct(*[float(x) for x in v.reshape(-1)]))
         else:
             setattr(st, name, v.item() if hasattr(v, "item") else v)
     return st
@@ -496,6 +524,45 @@ class Matcher:
         _check(self.L.aos2_matcher_search_by_bow(self.h, C.byref(arr), len(problems), ptrs, _p(nm)))
         res = [(int(nm[i]), outs[i][: len(problems[i]["desc_f"])]) for i in range(len(problems))]
         return res[0] if single else res
+
+    def _kfkf(self, struct_t, fn, problems, *extra):
+        single = isinstance(problems, dict)
+        if single:
+            problems = [problems]
+        keep = []
+        arr = (struct_t * len(problems))()
+        outs = []
+        for i, p in enumerate(problems):
+            d = dict(p)
+            d["n1"], d["n2"] = len(p["desc1"]), len(p["desc2"])
+            d["n_nodes1"], d["n_nodes2"] = len(p["node_id1"]), len(p["node_id2"])
+            if "scale_factors2" in p:
+                d["n_levels2"] = len(p["scale_factors2"])
+            _fill_struct(arr[i], d, keep)
+            outs.append(np.zeros(max(d["n1"], 1), np.int32))
+        ptrs = (C.c_void_p * len(problems))(*[o.ctypes.data for o in outs])
+        nm = np.zeros(len(problems), np.int32)
+        _check(fn(self.h, C.byref(arr), len(problems), *extra, ptrs, _p(nm)))
+        res = [(int(nm[i]), outs[i][: len(problems[i]["desc1"])]) for i in range(len(problems))]
+        return res[0] if single else res
+
+    def SearchByBoWKF(self, problems):
+        """SearchByBoW(pKF1, pKF2, vpMatches12) src/ORBmatcher.cc:522-655; synth_bow_kf_problem()-style dicts.
+        Returns (nmatches, match12) per problem."""
+        return self._kfkf(_BowKfPair, self.L.aos2_matcher_search_by_bow_kf, problems)
+
+    def SearchForTriangulation(self, problems, only_stereo=False):
+        """src/ORBmatcher.cc:657-823; synth_triang_problem()-style dicts. Returns (nmatches, vMatches12)."""
+        return self._kfkf(_TriangPair, self.L.aos2_matcher_search_for_triangulation, problems, int(only_stereo))
+
+    def ComputeDistinctiveDescriptors(self, off, desc):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:275-340) for a CSR batch of map points."""
+        off = np.ascontiguousarray(off, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(off) - 1
+        best = np.zeros(max(n, 1), np.int32)
+        _check(self.L.aos2_compute_distinctive_descriptors(self.h, n, _p(off), _p(desc), _p(best)))
+        return best[:n]
 
     def SearchByProjection(self, f, mp, th=3.0):
         keep = []

@@ -211,6 +211,11 @@ struct BowPairDev {
     int32_t *match_f;   // n_f
     uint32_t *bin_f;    // n_f scratch: bit b set = pushed into rotHist[b]
     int32_t *nmatches;  // 1
+    // SearchByBoW(KF1, KF2) :522-655 (kf_kf != 0): "kf" = KF1, "f" = KF2
+    int kf_kf;
+    const uint8_t *f_has_mp;  // vpMapPoints2[idx2] && !isBad(); candidates without one are skipped (:572-577)
+    int32_t *match_1;         // n_kf: vpMatches12 as KF2 feature indices
+    int32_t *bin_1;           // n_kf scratch: rotHist bin + 1 of a matched KF1 feature
 };
 
 // stage A: grid = (max queries, pairs); one wave per query
@@ -238,10 +243,18 @@ __global__ __launch_bounds__(64) void bow_resolve_kernel(const BowPairDev *__res
     __shared__ int histo[HISTO];
     const BowPairDev P = pairs[blockIdx.x];
     const int lane = threadIdx.x;
-    for (int i = lane; i < P.n_f; i += 64) {
-        P.match_f[i] = -1;
-        P.bin_f[i] = 0;
-        taken[i] = 0;
+    if (!P.kf_kf) {
+        for (int i = lane; i < P.n_f; i += 64) {
+            P.match_f[i] = -1;
+            P.bin_f[i] = 0;
+            taken[i] = 0;
+        }
+    } else {
+        for (int i = lane; i < P.n_f; i += 64) taken[i] = P.f_has_mp[i] ? 0 : 1;  // vbMatched2 || !pMP2 || isBad
+        for (int i = lane; i < P.n_kf; i += 64) {
+            P.match_1[i] = -1;
+            P.bin_1[i] = 0;
+        }
     }
     if (lane < HISTO) histo[lane] = 0;
     __syncthreads();
@@ -303,16 +316,24 @@ __global__ __launch_bounds__(64) void bow_resolve_kernel(const BowPairDev *__res
         wave_min2(k1, k2);
         const int bestDist1 = k1 == KEY_NONE ? 256 : (int)(k1 >> 20);
         const int bestDist2 = k2 == KEY_NONE ? 256 : (int)(k2 >> 20);
-        if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+        // (KF, F): bestDist1 <= TH_LOW (:237); (KF, KF): bestDist1 < TH_LOW (:599)
+        const bool low = P.kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;
+        if (low && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
             const unsigned long long own = __ballot(my1 == k1);
             const int bestIdxF = (int)read_owner(p1, own);
             if (lane == 0) {
-                P.match_f[bestIdxF] = q.kf_idx;
                 taken[bestIdxF] = 1;
+                int bin = 0;
                 if (check_ori) {
-                    const int bin = rot_bin(__fsub_rn(P.angle_kf[q.kf_idx], P.angle_f[bestIdxF]));
-                    P.bin_f[bestIdxF] |= 1u << bin;
+                    bin = rot_bin(__fsub_rn(P.angle_kf[q.kf_idx], P.angle_f[bestIdxF]));
                     histo[bin]++;
+                }
+                if (!P.kf_kf) {
+                    P.match_f[bestIdxF] = q.kf_idx;
+                    if (check_ori) P.bin_f[bestIdxF] |= 1u << bin;
+                } else {
+                    P.match_1[q.kf_idx] = bestIdxF;
+                    P.bin_1[q.kf_idx] = bin + 1;
                 }
             }
             nmatches++;
@@ -327,12 +348,162 @@ __global__ __launch_bounds__(64) void bow_resolve_kernel(const BowPairDev *__res
         for (int i = 0; i < HISTO; ++i)
             if (i != i1 && i != i2 && i != i3) {
                 culled |= 1u << i;
-                nmatches -= histo[i];  // one decrement per pushed entry (:281)
+                nmatches -= histo[i];  // one decrement per pushed entry (:281, :650)
             }
-        for (int i = lane; i < P.n_f; i += 64)
-            if (P.bin_f[i] & culled) P.match_f[i] = -1;
+        if (!P.kf_kf) {
+            for (int i = lane; i < P.n_f; i += 64)
+                if (P.bin_f[i] & culled) P.match_f[i] = -1;
+        } else {
+            for (int i = lane; i < P.n_kf; i += 64) {
+                const int bn = P.bin_1[i];
+                if (bn > 0 && ((culled >> (bn - 1)) & 1u)) P.match_1[i] = -1;
+            }
+        }
     }
     if (lane == 0) *P.nmatches = nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  :657-823.
+// vbMatched2 is declared but never set by the reference, so the KF1 features are independent: one
+// wave per query, lanes over the KF2 bucket.  The sequential rule "dist <= bestDist and the geometry
+// holds -> take it" (:728, :741-745) selects the smallest distance and, among equals, the LAST
+// candidate visited: key = dist << 20 | (0xFFFFF - position).
+// ---------------------------------------------------------------------------------------------
+struct TriQuery {
+    int32_t idx1, f_beg, f_cnt;
+};
+
+struct TriPairDev {
+    int n1, n2, n_queries, only_stereo;
+    const uint8_t *desc1, *desc2, *has_mp2;
+    const float *x1, *y1, *angle1, *u_right1, *x2, *y2, *angle2, *u_right2;
+    const int32_t *octave2;
+    const float *scale_factors2, *level_sigma2_2;
+    float F12[9], ex, ey;
+    const int32_t *node_idx2;
+    const TriQuery *queries;
+    int32_t *match12;   // n1
+    int32_t *nmatches;
+};
+
+__global__ __launch_bounds__(64) void triang_match_kernel(const TriPairDev *__restrict__ pairs)
+{
+    const TriPairDev &P = pairs[blockIdx.y];
+    if ((int)blockIdx.x >= P.n_queries) return;
+    const TriQuery q = P.queries[blockIdx.x];
+    const int lane = threadIdx.x;
+    const Desc d1 = load_desc(P.desc1 + (size_t)q.idx1 * 32);
+    const float kx = P.x1[q.idx1], ky = P.y1[q.idx1];
+    const bool bStereo1 = P.u_right1[q.idx1] >= 0;
+    // epipolar line l = x1' F12 (:142-144)
+    const float a = __fadd_rn(__fadd_rn(__fmul_rn(kx, P.F12[0]), __fmul_rn(ky, P.F12[3])), P.F12[6]);
+    const float b = __fadd_rn(__fadd_rn(__fmul_rn(kx, P.F12[1]), __fmul_rn(ky, P.F12[4])), P.F12[7]);
+    const float c = __fadd_rn(__fadd_rn(__fmul_rn(kx, P.F12[2]), __fmul_rn(ky, P.F12[5])), P.F12[8]);
+    const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    uint32_t key = KEY_NONE, pay = 0;
+    for (int j = lane; j < q.f_cnt; j += 64) {
+        const int idx2 = P.node_idx2[q.f_beg + j];
+        if (P.has_mp2[idx2]) continue;                       // :723
+        const bool bStereo2 = P.u_right2[idx2] >= 0;
+        if (P.only_stereo && !bStereo2) continue;
+        const int dist = hamming(d1, load_desc(P.desc2 + (size_t)idx2 * 32));
+        if (dist > TH_LOW) continue;                         // :734 (bestDist never exceeds TH_LOW)
+        const float x2 = P.x2[idx2], y2 = P.y2[idx2];
+        const int oct = P.octave2[idx2];
+        if (!bStereo1 && !bStereo2) {                        // too close to the epipole (:739-745)
+            const float dx = __fsub_rn(P.ex, x2), dy = __fsub_rn(P.ey, y2);
+            if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.0f, P.scale_factors2[oct])) continue;
+        }
+        // CheckDistEpipolarLine :139-157
+        const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, x2), __fmul_rn(b, y2)), c);
+        if (den == 0.0f) continue;
+        const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+        if (!((double)dsqr < __dmul_rn(3.84, (double)P.level_sigma2_2[oct]))) continue;
+        const uint32_t k = ((uint32_t)dist << 20) | (0xFFFFFu - (uint32_t)j);
+        if (k < key) {
+            key = k;
+            pay = (uint32_t)idx2;
+        }
+    }
+    uint32_t k1 = key, k2 = KEY_NONE;
+    wave_min2(k1, k2);
+    if (k1 != KEY_NONE) {
+        const unsigned long long own = __ballot(key == k1);
+        const int best = (int)read_owner(pay, own);
+        if (lane == 0) P.match12[q.idx1] = best;
+    }
+}
+
+// rotation consistency (:776-808) + count, one wave per pair
+__global__ __launch_bounds__(64) void triang_finish_kernel(const TriPairDev *__restrict__ pairs, int check_ori)
+{
+    __shared__ int histo[HISTO];
+    const TriPairDev &P = pairs[blockIdx.x];
+    const int lane = threadIdx.x;
+    if (lane < HISTO) histo[lane] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = lane; i < P.n1; i += 64) {
+        const int m2 = P.match12[i];
+        if (m2 >= 0) {
+            cnt++;
+            if (check_ori) atomicAdd(&histo[rot_bin(__fsub_rn(P.angle1[i], P.angle2[m2]))], 1);
+        }
+    }
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        for (int i = lane; i < P.n1; i += 64) {
+            const int m2 = P.match12[i];
+            if (m2 >= 0) {
+                const int bin = rot_bin(__fsub_rn(P.angle1[i], P.angle2[m2]));
+                if (bin != i1 && bin != i2 && bin != i3) P.match12[i] = -1;
+            }
+        }
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) cnt -= histo[i];
+    }
+    if (lane == 0) *P.nmatches = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors  src/MapPoint.cc:275-340, batched over map points: one wave
+// per point, lane = row of the N x N distance matrix.  The row median vDists[0.5*(N-1)] is found by
+// bisection on the value (distances are 0..256) instead of sorting; the first row with the smallest
+// median wins (strict '<', :326-330).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void distinctive_kernel(int n_points, const int32_t *__restrict__ off,
+                                                         const uint8_t *__restrict__ desc, int32_t *__restrict__ best)
+{
+    const int p = blockIdx.x;
+    if (p >= n_points) return;
+    const int lane = threadIdx.x;
+    const int beg = off[p], N = off[p + 1] - off[p];
+    if (N <= 0) {
+        if (lane == 0) best[p] = -1;
+        return;
+    }
+    const uint8_t *d = desc + (size_t)beg * 32;
+    const int kth = (N - 1) / 2;  // (int)(0.5 * (N - 1))
+    uint32_t key = KEY_NONE;
+    for (int i = lane; i < N; i += 64) {
+        const Desc di = load_desc(d + (size_t)i * 32);
+        int lo = 0, hi = 256;
+        while (lo < hi) {  // smallest v with #{j : dist(i, j) <= v} >= kth + 1
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < N; ++j) c += (j == i ? 0 : hamming(di, load_desc(d + (size_t)j * 32))) <= mid;
+            if (c >= kth + 1) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t k = ((uint32_t)lo << 20) | (uint32_t)i;
+        key = min(key, k);
+    }
+    uint32_t k1 = key, k2 = KEY_NONE;
+    wave_min2(k1, k2);
+    if (lane == 0) best[p] = (int32_t)(k1 & 0xFFFFFu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,13 +1140,11 @@ int aos2_matcher_hamming_best2(aos2_matcher_t *m, const uint8_t *q, int nq, cons
     return AOS2_OK;
 }
 
-int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs, int32_t *const *match_f,
-                               int32_t *nmatches)
+// shared by SearchByBoW(KF, F) (kf_kf = 0, match_out[p] has n_f entries) and SearchByBoW(KF1, KF2)
+// (kf_kf = 1, f_has_mp[p] = has_mp2, match_out[p] has n_kf entries)
+static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_t *const *f_has_mp, int n_pairs, int kf_kf,
+                   int32_t *const *match_f, int32_t *nmatches)
 {
-    if (!m || !pairs || n_pairs <= 0 || !match_f || !nmatches) {
-        set_error("bad argument");
-        return AOS2_ERR_ARG;
-    }
     int st = matcher_init(m);
     if (st) return st;
     Arena A{m};
@@ -1032,6 +1201,10 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
         o.o[7] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
         o.o[8] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
         o.o[9] = A.reserve(4);                      // nmatches
+        if (kf_kf) {
+            o.o[10] = A.push(f_has_mp[p], (size_t)P.n_f);
+            o.o[11] = A.reserve((size_t)P.n_kf * 8 + 8);  // match_1 | bin_1
+        }
         max_nf = std::max(max_nf, P.n_f);
         max_q = std::max(max_q, o.nq);
     }
@@ -1051,6 +1224,13 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
         D.angle_kf = A.dev<float>(o.o[2]); D.angle_f = A.dev<float>(o.o[3]);
         D.node_idx_f = A.dev<int32_t>(o.o[4]); D.queries = A.dev<BowQuery>(o.o[5]); D.entries = A.dev<Entry>(o.o[6]);
         D.match_f = A.dev<int32_t>(o.o[7]); D.bin_f = A.dev<uint32_t>(o.o[8]); D.nmatches = A.dev<int32_t>(o.o[9]);
+        D.kf_kf = kf_kf;
+        D.f_has_mp = nullptr; D.match_1 = nullptr; D.bin_1 = nullptr;
+        if (kf_kf) {
+            D.f_has_mp = A.dev<uint8_t>(o.o[10]);
+            D.match_1 = A.dev<int32_t>(o.o[11]);
+            D.bin_1 = D.match_1 + P.n_kf;
+        }
     }
     memcpy(A.host.data() + opairs, dev.data(), sizeof(BowPairDev) * n_pairs);
     if ((st = A.upload())) return st;
@@ -1061,9 +1241,180 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
                        A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     for (int p = 0; p < n_pairs; ++p) {
-        AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_f, (size_t)pairs[p].n_f * 4, hipMemcpyDeviceToHost, m->stream));
+        if (!kf_kf)
+            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_f, (size_t)pairs[p].n_f * 4, hipMemcpyDeviceToHost, m->stream));
+        else if (pairs[p].n_kf > 0)
+            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_1, (size_t)pairs[p].n_kf * 4, hipMemcpyDeviceToHost, m->stream));
         AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
     }
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs, int32_t *const *match_f,
+                               int32_t *nmatches)
+{
+    if (!m || !pairs || n_pairs <= 0 || !match_f || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    return bow_run(m, pairs, nullptr, n_pairs, 0, match_f, nmatches);
+}
+
+int aos2_matcher_search_by_bow_kf(aos2_matcher_t *m, const aos2_bow_kf_pair_t *pairs, int n_pairs, int32_t *const *match12,
+                                  int32_t *nmatches)
+{
+    if (!m || !pairs || n_pairs <= 0 || !match12 || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    std::vector<aos2_bow_pair_t> v(n_pairs);
+    std::vector<const uint8_t *> hm2(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const aos2_bow_kf_pair_t &K = pairs[p];
+        if (K.n2 > 0 && !K.has_mp2) {
+            set_error("bad BoW pair %d", p);
+            return AOS2_ERR_ARG;
+        }
+        aos2_bow_pair_t &B = v[p];
+        B.n_kf = K.n1; B.n_f = K.n2;
+        B.desc_kf = K.desc1; B.desc_f = K.desc2;
+        B.kf_has_mp = K.has_mp1;
+        B.angle_kf = K.angle1; B.angle_f = K.angle2;
+        B.n_nodes_kf = K.n_nodes1; B.n_nodes_f = K.n_nodes2;
+        B.node_id_kf = K.node_id1; B.node_off_kf = K.node_off1; B.node_idx_kf = K.node_idx1;
+        B.node_id_f = K.node_id2; B.node_off_f = K.node_off2; B.node_idx_f = K.node_idx2;
+        hm2[p] = K.has_mp2;
+    }
+    return bow_run(m, v.data(), hm2.data(), n_pairs, 1, match12, nmatches);
+}
+
+int aos2_matcher_search_for_triangulation(aos2_matcher_t *m, const aos2_triang_pair_t *pairs, int n_pairs, int only_stereo,
+                                          int32_t *const *match12, int32_t *nmatches)
+{
+    if (!m || !pairs || n_pairs <= 0 || !match12 || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    Arena A{m};
+    struct Off { size_t o[20]; int nq; };
+    std::vector<Off> offs(n_pairs);
+    std::vector<TriQuery> queries;
+    int max_q = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const aos2_triang_pair_t &P = pairs[p];
+        if (P.n1 < 0 || P.n2 < 0 || P.n_nodes1 < 0 || P.n_nodes2 < 0 || !match12[p] || P.n_levels2 <= 0) {
+            set_error("bad triangulation pair %d", p);
+            return AOS2_ERR_ARG;
+        }
+        queries.clear();
+        int i1 = 0, i2 = 0;
+        while (i1 < P.n_nodes1 && i2 < P.n_nodes2) {  // merge-join of the FeatureVectors (:691-772)
+            const int a = P.node_id1[i1], b = P.node_id2[i2];
+            if (a == b) {
+                const int b0 = P.node_off2[i2], bc = P.node_off2[i2 + 1] - b0;
+                for (int k = P.node_off1[i1]; k < P.node_off1[i1 + 1]; ++k) {
+                    const int idx1 = P.node_idx1[k];
+                    if (idx1 < 0 || idx1 >= P.n1) {
+                        set_error("triangulation pair %d: feature index out of range", p);
+                        return AOS2_ERR_ARG;
+                    }
+                    if (P.has_mp1[idx1]) continue;                            // :700-703
+                    if (only_stereo && !(P.u_right1[idx1] >= 0)) continue;    // :705-709
+                    queries.push_back(TriQuery{idx1, b0, bc});
+                }
+                i1++;
+                i2++;
+            } else if (a < b) {
+                while (i1 < P.n_nodes1 && P.node_id1[i1] < b) i1++;
+            } else {
+                while (i2 < P.n_nodes2 && P.node_id2[i2] < a) i2++;
+            }
+        }
+        Off &o = offs[p];
+        o.nq = (int)queries.size();
+        const size_t n1 = (size_t)P.n1, n2 = (size_t)P.n2;
+        o.o[0] = A.push(P.desc1, n1 * 32); o.o[1] = A.push(P.desc2, n2 * 32); o.o[2] = A.push(P.has_mp2, n2);
+        o.o[3] = A.push(P.x1, n1 * 4); o.o[4] = A.push(P.y1, n1 * 4); o.o[5] = A.push(P.angle1, n1 * 4);
+        o.o[6] = A.push(P.u_right1, n1 * 4);
+        o.o[7] = A.push(P.x2, n2 * 4); o.o[8] = A.push(P.y2, n2 * 4); o.o[9] = A.push(P.angle2, n2 * 4);
+        o.o[10] = A.push(P.u_right2, n2 * 4); o.o[11] = A.push(P.octave2, n2 * 4);
+        o.o[12] = A.push(P.scale_factors2, (size_t)P.n_levels2 * 4);
+        o.o[13] = A.push(P.level_sigma2_2, (size_t)P.n_levels2 * 4);
+        o.o[14] = A.push(P.node_idx2, (size_t)(P.n_nodes2 ? P.node_off2[P.n_nodes2] : 0) * 4);
+        o.o[15] = A.push(queries.data(), queries.size() * sizeof(TriQuery));
+        std::vector<int32_t> init(n1 + 1, -1);
+        o.o[16] = A.push(init.data(), (n1 + 1) * 4);  // match12 = -1 (:681)
+        o.o[17] = A.reserve(8);
+        max_q = std::max(max_q, o.nq);
+    }
+    const size_t opairs = A.reserve(sizeof(TriPairDev) * n_pairs);
+    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    std::vector<TriPairDev> dev(n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        const aos2_triang_pair_t &P = pairs[p];
+        const Off &o = offs[p];
+        TriPairDev &D = dev[p];
+        D.n1 = P.n1; D.n2 = P.n2; D.n_queries = o.nq; D.only_stereo = only_stereo;
+        D.desc1 = A.dev<uint8_t>(o.o[0]); D.desc2 = A.dev<uint8_t>(o.o[1]); D.has_mp2 = A.dev<uint8_t>(o.o[2]);
+        D.x1 = A.dev<float>(o.o[3]); D.y1 = A.dev<float>(o.o[4]); D.angle1 = A.dev<float>(o.o[5]); D.u_right1 = A.dev<float>(o.o[6]);
+        D.x2 = A.dev<float>(o.o[7]); D.y2 = A.dev<float>(o.o[8]); D.angle2 = A.dev<float>(o.o[9]); D.u_right2 = A.dev<float>(o.o[10]);
+        D.octave2 = A.dev<int32_t>(o.o[11]); D.scale_factors2 = A.dev<float>(o.o[12]); D.level_sigma2_2 = A.dev<float>(o.o[13]);
+        memcpy(D.F12, P.F12, sizeof(D.F12));
+        D.ex = P.ex; D.ey = P.ey;
+        D.node_idx2 = A.dev<int32_t>(o.o[14]); D.queries = A.dev<TriQuery>(o.o[15]);
+        D.match12 = A.dev<int32_t>(o.o[16]); D.nmatches = A.dev<int32_t>(o.o[17]);
+    }
+    memcpy(A.host.data() + opairs, dev.data(), sizeof(TriPairDev) * n_pairs);
+    if ((st = A.upload())) return st;
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (max_q > 0)
+        hipLaunchKernelGGL(triang_match_kernel, dim3(max_q, n_pairs), dim3(64), 0, m->stream, A.dev<TriPairDev>(opairs));
+    hipLaunchKernelGGL(triang_finish_kernel, dim3(n_pairs), dim3(64), 0, m->stream, A.dev<TriPairDev>(opairs), m->check_ori);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    for (int p = 0; p < n_pairs; ++p) {
+        if (pairs[p].n1 > 0)
+            AOS2_HIP_CHECK(hipMemcpyAsync(match12[p], dev[p].match12, (size_t)pairs[p].n1 * 4, hipMemcpyDeviceToHost, m->stream));
+        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_compute_distinctive_descriptors(aos2_matcher_t *m, int n_points, const int32_t *off, const uint8_t *desc,
+                                         int32_t *best_idx)
+{
+    if (!m || n_points < 0 || (n_points > 0 && (!off || !best_idx))) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (n_points == 0) return AOS2_OK;
+    for (int p = 0; p < n_points; ++p)
+        if (off[p + 1] < off[p] || off[0] != 0) {
+            set_error("observation offsets must start at 0 and ascend");
+            return AOS2_ERR_ARG;
+        }
+    const size_t total = (size_t)off[n_points];
+    if (total > 0 && !desc) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    Arena A{m};
+    const size_t o0 = A.push(off, (size_t)(n_points + 1) * 4), o1 = A.push(desc, total * 32), o2 = A.reserve((size_t)n_points * 4);
+    if ((st = A.upload())) return st;
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(distinctive_kernel, dim3(n_points), dim3(64), 0, m->stream, n_points, A.dev<int32_t>(o0),
+                       A.dev<uint8_t>(o1), A.dev<int32_t>(o2));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(best_idx, A.dev<int32_t>(o2), (size_t)n_points * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);

@@ -206,6 +206,94 @@ def synth_bow_problem(seed: int, n_kf: int = 1000, n_f: int = 1000, n_nodes: int
 GRID_COLS, GRID_ROWS = 64, 48  # include/Frame.h:37-38
 
 
+def _feature_vector(nodes):
+    order = np.argsort(nodes, kind="stable")
+    ids, counts = np.unique(nodes[order], return_counts=True)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return ids.astype(np.int32), off, order.astype(np.int32)
+
+
+def synth_bow_kf_problem(seed: int, n1: int = 1000, n2: int = 1000, n_nodes: int = 100, nnratio: float = 0.75,
+                         check_orientation: bool = True):
+    """Two keyframes with map points for SearchByBoW(KF, KF) (src/ORBmatcher.cc:522-655)."""
+    b = synth_bow_problem(seed + 7000, n1, n2, n_nodes, nnratio, check_orientation)
+    rng = np.random.default_rng(7100 + seed)
+    return dict(desc1=b["desc_kf"], desc2=b["desc_f"], has_mp1=b["kf_has_mp"],
+                has_mp2=(rng.random(n2) < 0.8).astype(np.uint8), angle1=b["angle_kf"], angle2=b["angle_f"],
+                node_id1=b["node_id_kf"], node_off1=b["node_off_kf"], node_idx1=b["node_idx_kf"],
+                node_id2=b["node_id_f"], node_off2=b["node_off_f"], node_idx2=b["node_idx_f"],
+                nnratio=np.float32(nnratio), check_orientation=int(check_orientation))
+
+
+def synth_triang_problem(seed: int, n1: int = 1000, n2: int = 1000, n_nodes: int = 100, cfg: str = "kitti",
+                         only_stereo: bool = False, check_orientation: bool = True, mono: bool = False):
+    """Two keyframes of a moving camera for SearchForTriangulation (src/ORBmatcher.cc:657-823): 60 % of the
+    features are projections of common 3-D points (epipolar-consistent, similar descriptors, same vocabulary
+    node), the rest is clutter.  F12 = K^-T [t12]x R12 K^-1 as LocalMapping::ComputeF12 builds it."""
+    rng = np.random.default_rng(8000 + seed)
+    c = CONFIGS[cfg]
+    fx, fy, cx, cy, W, H = c["fx"], c["fy"], c["cx"], c["cy"], c["w"], c["h"]
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    ang = 0.03
+    R2w = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t2w = np.array([-0.6, 0.02, 0.15])                    # camera 1 = world
+    n_pl = int(0.6 * min(n1, n2))
+    X = np.stack([rng.uniform(-8, 8, n_pl), rng.uniform(-3, 3, n_pl), rng.uniform(4, 30, n_pl)], 1)
+    p1 = (K @ X.T).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    Xc2 = (R2w @ X.T).T + t2w
+    p2 = (K @ Xc2.T).T
+    p2 = p2[:, :2] / p2[:, 2:]
+    x1 = rng.uniform(0, W, n1).astype(np.float32)
+    y1 = rng.uniform(0, H, n1).astype(np.float32)
+    x2 = rng.uniform(0, W, n2).astype(np.float32)
+    y2 = rng.uniform(0, H, n2).astype(np.float32)
+    src, dst = rng.permutation(n1)[:n_pl], rng.permutation(n2)[:n_pl]
+    x1[src], y1[src] = p1[:, 0], p1[:, 1]
+    x2[dst], y2[dst] = p2[:, 0] + rng.normal(0, 0.4, n_pl), p2[:, 1] + rng.normal(0, 0.4, n_pl)
+    desc1, desc2 = synth_descriptors(rng, n1), synth_descriptors(rng, n2)
+    desc2[dst] = flip_bits(rng, desc1[src], 0.06)
+    extra = rng.permutation(n2)[: n2 // 10]               # decoys: similar descriptor, wrong place
+    desc2[extra] = flip_bits(rng, desc1[rng.integers(0, n1, len(extra))], 0.06)
+    node1, node2 = rng.integers(0, n_nodes, n1), rng.integers(0, n_nodes, n2)
+    node2[dst] = node1[src]
+    angle1 = rng.uniform(0, 360, n1).astype(np.float32)
+    angle2 = rng.uniform(0, 360, n2).astype(np.float32)
+    angle2[dst] = np.mod(angle1[src] - rng.normal(10.0, 4.0, n_pl), 360.0).astype(np.float32)
+    octave2 = rng.integers(0, 8, n2).astype(np.int32)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    ur1 = np.where(rng.random(n1) < (0.0 if mono else 0.6), x1 - 3.0, -1.0).astype(np.float32)
+    ur2 = np.where(rng.random(n2) < (0.0 if mono else 0.6), x2 - 3.0, -1.0).astype(np.float32)
+    # R12, t12 (camera 2 -> camera 1): R12 = R1w R2w^T, t12 = -R12 t2w (+ t1w = 0)
+    R12 = R2w.T
+    t12 = -R12 @ t2w
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F12 = np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)
+    C2 = t2w                                              # camera-1 centre (0) in camera 2
+    ex, ey = fx * C2[0] / C2[2] + cx, fy * C2[1] / C2[2] + cy
+    id1, off1, idx1 = _feature_vector(node1)
+    id2, off2, idx2 = _feature_vector(node2)
+    return dict(desc1=desc1, desc2=desc2, has_mp1=(rng.random(n1) < 0.4).astype(np.uint8),
+                has_mp2=(rng.random(n2) < 0.4).astype(np.uint8), x1=x1, y1=y1, angle1=angle1, u_right1=ur1,
+                x2=x2, y2=y2, angle2=angle2, u_right2=ur2, octave2=octave2, scale_factors2=sf,
+                level_sigma2_2=(sf * sf).astype(np.float32), F12=F12.astype(np.float32).reshape(9),
+                ex=np.float32(ex), ey=np.float32(ey), only_stereo=int(only_stereo),
+                check_orientation=int(check_orientation), node_id1=id1, node_off1=off1, node_idx1=idx1,
+                node_id2=id2, node_off2=off2, node_idx2=idx2)
+
+
+def synth_observations(seed: int, n_points: int = 2000, max_obs: int = 24):
+    """Observed descriptors of a batch of map points (CSR) for MapPoint::ComputeDistinctiveDescriptors."""
+    rng = np.random.default_rng(9000 + seed)
+    cnt = rng.integers(0, max_obs + 1, n_points)
+    cnt[rng.random(n_points) < 0.02] = max_obs * 4        # a few heavily observed points
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    base = synth_descriptors(rng, n_points)
+    desc = np.repeat(base, cnt, axis=0)
+    desc = flip_bits(rng, desc, 0.08) if len(desc) else desc
+    return off, desc
+
+
 def build_grid(kp_x, kp_y, min_x, min_y, max_x, max_y):
     """Frame::AssignFeaturesToGrid (src/Frame.cc:259-274) as CSR, cell = ix*48+iy."""
     gw_inv = np.float32(GRID_COLS) / np.float32(max_x - min_x)

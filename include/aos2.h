@@ -280,6 +280,55 @@ typedef struct {
 int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs,
                                int32_t *const *match_f, int32_t *nmatches);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)
+ * src/ORBmatcher.cc:522-655 (LoopClosing.cc:? / Tracking relocalisation candidates).
+ * has_mp*: GetMapPointMatches()[i] != NULL && !isBad().  match12[p] (n1 entries): index of the KF2
+ * feature whose MapPoint becomes vpMatches12[i], or -1 (NULL). */
+typedef struct {
+    int32_t n1, n2;
+    const uint8_t *desc1, *desc2;      /* mDescriptors */
+    const uint8_t *has_mp1, *has_mp2;
+    const float *angle1, *angle2;      /* mvKeysUn[i].angle */
+    int32_t n_nodes1, n_nodes2;        /* mFeatVec as CSR, node ids ascending */
+    const int32_t *node_id1, *node_off1, *node_idx1;
+    const int32_t *node_id2, *node_off2, *node_idx2;
+} aos2_bow_kf_pair_t;
+int aos2_matcher_search_by_bow_kf(aos2_matcher_t *m, const aos2_bow_kf_pair_t *pairs, int n_pairs,
+                                  int32_t *const *match12, int32_t *nmatches);
+
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+ *         vector<pair<size_t,size_t>> &vMatchedPairs, const bool bOnlyStereo)   src/ORBmatcher.cc:657-823
+ * (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:? calls it once per neighbour keyframe:
+ * `n_pairs` (pKF1, pKF2_k) problems go in one launch).  has_mp*: GetMapPoint(i) != NULL.
+ * F12: row-major 3x3 (LocalMapping::ComputeF12); ex, ey: the epipole of :664-670.
+ * match12[p] (n1 entries) = vMatches12 (KF2 feature index or -1); vMatchedPairs is its non-negative
+ * entries in ascending i (:811-820).  nmatches[p] = return value. */
+typedef struct {
+    int32_t n1, n2;
+    const uint8_t *desc1, *desc2;
+    const uint8_t *has_mp1, *has_mp2;
+    const float *x1, *y1, *angle1, *u_right1;   /* pKF1->mvKeysUn[i].pt / .angle, mvuRight */
+    const float *x2, *y2, *angle2, *u_right2;
+    const int32_t *octave2;                     /* pKF2->mvKeysUn[i].octave */
+    const float *scale_factors2, *level_sigma2_2;  /* pKF2->mvScaleFactors / mvLevelSigma2 */
+    int32_t n_levels2;
+    float F12[9];
+    float ex, ey;
+    int32_t n_nodes1, n_nodes2;                 /* mFeatVec as CSR */
+    const int32_t *node_id1, *node_off1, *node_idx1;
+    const int32_t *node_id2, *node_off2, *node_idx2;
+} aos2_triang_pair_t;
+int aos2_matcher_search_for_triangulation(aos2_matcher_t *m, const aos2_triang_pair_t *pairs,
+                                          int n_pairs, int only_stereo, int32_t *const *match12,
+                                          int32_t *nmatches);
+
+/* void MapPoint::ComputeDistinctiveDescriptors()  src/MapPoint.cc:275-340, for a batch of map points:
+ * the descriptors observed for point p (rows of the non-bad keyframes, in std::map order, :297-303) are
+ * desc[off[p] .. off[p+1]).  best_idx[p] = index inside that list of the descriptor with the least
+ * median distance to the others (first one on ties), -1 for an empty list. */
+int aos2_compute_distinctive_descriptors(aos2_matcher_t *m, int n_points, const int32_t *off,
+                                         const uint8_t *desc, int32_t *best_idx);
+
 typedef struct {
     int32_t n_f;
     const uint8_t *desc_f;      /* F.mDescriptors */

@@ -66,6 +66,10 @@ def lib():
         L.orc_search_by_projection_mp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_compute_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_compute_distinctive_descriptors.restype = None
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
         for name in ("k", "L", "scoring", "weighting", "nodes", "size"):
@@ -293,7 +297,7 @@ def _fill(struct, d, keep):
             keep.append(v)
             setattr(struct, name, v.ctypes.data)
         elif isinstance(v, np.ndarray):
-            arr = (C.c_float * 16)(*[float(x) for x in v.reshape(-1)])
+            arr = ct(*[float(x) for x in v.reshape(-1)]) if hasattr(ct, "_length_") else (C.c_float * 16)(*[float(x) for x in v.reshape(-1)])
             setattr(struct, name, arr)
         else:
             setattr(struct, name, v.item() if hasattr(v, "item") else v)
@@ -340,6 +344,59 @@ def search_by_projection_last(cur: dict, p: dict):
 
 
 # ---------------------------------------------------------------------------- local BA
+class _BowKfProblem(C.Structure):
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),
+                ("n_nodes1", C.c_int), ("n_nodes2", C.c_int),
+                ("node_id1", C.c_void_p), ("node_off1", C.c_void_p), ("node_idx1", C.c_void_p),
+                ("node_id2", C.c_void_p), ("node_off2", C.c_void_p), ("node_idx2", C.c_void_p),
+                ("nnratio", C.c_float), ("check_orientation", C.c_int)]
+
+
+class _TriangProblem(C.Structure):
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("desc1", C.c_void_p), ("desc2", C.c_void_p),
+                ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p),
+                ("x1", C.c_void_p), ("y1", C.c_void_p), ("angle1", C.c_void_p), ("u_right1", C.c_void_p),
+                ("x2", C.c_void_p), ("y2", C.c_void_p), ("angle2", C.c_void_p), ("u_right2", C.c_void_p),
+                ("octave2", C.c_void_p), ("scale_factors2", C.c_void_p), ("level_sigma2_2", C.c_void_p),
+                ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("only_stereo", C.c_int), ("check_orientation", C.c_int),
+                ("n_nodes1", C.c_int), ("n_nodes2", C.c_int),
+                ("node_id1", C.c_void_p), ("node_off1", C.c_void_p), ("node_idx1", C.c_void_p),
+                ("node_id2", C.c_void_p), ("node_off2", C.c_void_p), ("node_idx2", C.c_void_p)]
+
+
+def _kfkf(struct_t, fn, p):
+    keep = []
+    s = struct_t()
+    d = dict(p)
+    d["n1"], d["n2"] = len(p["desc1"]), len(p["desc2"])
+    d["n_nodes1"], d["n_nodes2"] = len(p["node_id1"]), len(p["node_id2"])
+    _fill(s, d, keep)
+    match = np.zeros(max(d["n1"], 1), np.int32)
+    n = fn(C.byref(s), _p(match))
+    return n, match[: d["n1"]]
+
+
+def search_by_bow_kf(p: dict):
+    """SearchByBoW(pKF1, pKF2, vpMatches12) src/ORBmatcher.cc:522-655 -> (nmatches, match12)"""
+    return _kfkf(_BowKfProblem, lib().orc_search_by_bow_kf, p)
+
+
+def search_for_triangulation(p: dict):
+    """SearchForTriangulation src/ORBmatcher.cc:657-823 -> (nmatches, vMatches12)"""
+    return _kfkf(_TriangProblem, lib().orc_search_for_triangulation, p)
+
+
+def compute_distinctive_descriptors(off, desc):
+    """MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:275-340 for a batch (CSR) -> best index per point"""
+    off = np.ascontiguousarray(off, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    best = np.zeros(max(len(off) - 1, 1), np.int32)
+    lib().orc_compute_distinctive_descriptors(len(off) - 1, _p(off), _p(desc), _p(best))
+    return best[: len(off) - 1]
+
+
 class _StereoProblem(C.Structure):
     _fields_ = [("n_left", C.c_int), ("n_right", C.c_int), ("kp_left", C.c_void_p), ("kp_right", C.c_void_p),
                 ("desc_left", C.c_void_p), ("desc_right", C.c_void_p), ("n_levels", C.c_int),

@@ -455,3 +455,180 @@ int orc_compute_stereo_matches(const orc_stereo_problem_t *p, float *u_right, fl
     free(vidx);
     return nv;
 }
+
+/* ------------------------------------------------------------------ SURVEY §8(f) rank 4 */
+/* SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) :522-655.
+ * match12[n1] = index of the KF2 feature whose MapPoint is assigned to KF1 feature i, or -1. */
+int orc_search_by_bow_kf(const orc_bow_kf_problem_t *p, int32_t *match12)
+{
+    for (int i = 0; i < p->n1; ++i) match12[i] = -1;
+    uint8_t *matched2 = (uint8_t *)calloc(p->n2 ? p->n2 : 1, 1);
+    int nmatches = 0;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    int i1n = 0, i2n = 0;
+    while (i1n < p->n_nodes1 && i2n < p->n_nodes2) {
+        const int id1 = p->node_id1[i1n], id2 = p->node_id2[i2n];
+        if (id1 == id2) {
+            for (int a = p->node_off1[i1n]; a < p->node_off1[i1n + 1]; ++a) {
+                const int idx1 = p->node_idx1[a];
+                if (!p->has_mp1[idx1]) continue;
+                const uint8_t *d1 = p->desc1 + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = p->node_off2[i2n]; b < p->node_off2[i2n + 1]; ++b) {
+                    const int idx2 = p->node_idx2[b];
+                    if (matched2[idx2] || !p->has_mp2[idx2]) continue;
+                    const int dist = orc_descriptor_distance(d1, p->desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < TH_LOW) {
+                    if ((float)bestDist1 < p->nnratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (p->check_orientation) {
+                            float rot = p->angle1[idx1] - p->angle2[bestIdx2];
+                            iv_push(&rotHist[rot_bin(rot)], idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            i1n++;
+            i2n++;
+        } else if (id1 < id2) {
+            while (i1n < p->n_nodes1 && p->node_id1[i1n] < id2) i1n++;
+        } else {
+            while (i2n < p->n_nodes2 && p->node_id2[i2n] < id1) i2n++;
+        }
+    }
+    if (p->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) {
+                match12[rotHist[i].v[j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    free(matched2);
+    return nmatches;
+}
+
+/* CheckDistEpipolarLine :139-157 */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12, float sigma2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+/* SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) :657-823.  ex, ey = the epipole of
+ * :664-670 (host arithmetic on the two poses, taken as input).  match12[n1] = vMatches12; the pair list of
+ * :811-820 is its non-negative entries in ascending i.  vbMatched2 is never set by the reference. */
+int orc_search_for_triangulation(const orc_triang_problem_t *p, int32_t *match12)
+{
+    for (int i = 0; i < p->n1; ++i) match12[i] = -1;
+    int nmatches = 0;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    int i1n = 0, i2n = 0;
+    while (i1n < p->n_nodes1 && i2n < p->n_nodes2) {
+        const int id1 = p->node_id1[i1n], id2 = p->node_id2[i2n];
+        if (id1 == id2) {
+            for (int a = p->node_off1[i1n]; a < p->node_off1[i1n + 1]; ++a) {
+                const int idx1 = p->node_idx1[a];
+                if (p->has_mp1[idx1]) continue; /* already a MapPoint */
+                const int bStereo1 = p->u_right1[idx1] >= 0;
+                if (p->only_stereo && !bStereo1) continue;
+                const uint8_t *d1 = p->desc1 + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int b = p->node_off2[i2n]; b < p->node_off2[i2n + 1]; ++b) {
+                    const int idx2 = p->node_idx2[b];
+                    if (p->has_mp2[idx2]) continue;
+                    const int bStereo2 = p->u_right2[idx2] >= 0;
+                    if (p->only_stereo && !bStereo2) continue;
+                    const int dist = orc_descriptor_distance(d1, p->desc2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = p->ex - p->x2[idx2];
+                        const float distey = p->ey - p->y2[idx2];
+                        if (distex * distex + distey * distey < 100 * p->scale_factors2[p->octave2[idx2]]) continue;
+                    }
+                    if (check_dist_epipolar_line(p->x1[idx1], p->y1[idx1], p->x2[idx2], p->y2[idx2], p->F12,
+                                                 p->level_sigma2_2[p->octave2[idx2]])) {
+                        bestIdx2 = idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (p->check_orientation) {
+                        float rot = p->angle1[idx1] - p->angle2[bestIdx2];
+                        iv_push(&rotHist[rot_bin(rot)], idx1);
+                    }
+                }
+            }
+            i1n++;
+            i2n++;
+        } else if (id1 < id2) {
+            while (i1n < p->n_nodes1 && p->node_id1[i1n] < id2) i1n++;
+        } else {
+            while (i2n < p->n_nodes2 && p->node_id2[i2n] < id1) i2n++;
+        }
+    }
+    if (p->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) {
+                match12[rotHist[i].v[j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    return nmatches;
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:275-340 for a batch of map points: the observed
+ * descriptors of point p are desc[off[p] .. off[p+1]); best[p] = index (inside the point's list) of the
+ * descriptor with the least median distance to the others, -1 for an empty list. */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+void orc_compute_distinctive_descriptors(int n_points, const int32_t *off, const uint8_t *desc, int32_t *best)
+{
+    for (int p = 0; p < n_points; ++p) {
+        const int N = off[p + 1] - off[p];
+        best[p] = -1;
+        if (N <= 0) continue;
+        const uint8_t *d = desc + (size_t)off[p] * 32;
+        int *row = (int *)malloc(sizeof(int) * N);
+        int BestMedian = 2147483647, BestIdx = 0;
+        for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < N; ++j) row[j] = i == j ? 0 : orc_descriptor_distance(d + (size_t)i * 32, d + (size_t)j * 32);
+            qsort(row, N, sizeof(int), cmp_int);
+            const int median = row[(int)(0.5 * (N - 1))];
+            if (median < BestMedian) {
+                BestMedian = median;
+                BestIdx = i;
+            }
+        }
+        best[p] = BestIdx;
+        free(row);
+    }
+}

@@ -154,6 +154,38 @@ typedef struct {
 int orc_search_by_projection_last(const orc_frame_view_t *cur, const orc_proj_last_problem_t *p,
                                   int32_t *match_f);
 
+/* ---- the remaining matcher methods ---- */
+typedef struct {
+    int n1, n2;
+    const uint8_t *desc1, *desc2;         /* pKF1/pKF2->mDescriptors */
+    const uint8_t *has_mp1, *has_mp2;     /* GetMapPointMatches()[i] != NULL && !isBad() */
+    const float *angle1, *angle2;         /* mvKeysUn[i].angle */
+    int n_nodes1, n_nodes2;               /* FeatureVectors as CSR */
+    const int32_t *node_id1, *node_off1, *node_idx1;
+    const int32_t *node_id2, *node_off2, *node_idx2;
+    float nnratio;
+    int check_orientation;
+} orc_bow_kf_problem_t;
+int orc_search_by_bow_kf(const orc_bow_kf_problem_t *p, int32_t *match12);
+
+typedef struct {
+    int n1, n2;
+    const uint8_t *desc1, *desc2;
+    const uint8_t *has_mp1, *has_mp2;     /* GetMapPoint(i) != NULL (no isBad test here, :700,:723) */
+    const float *x1, *y1, *angle1, *u_right1;      /* mvKeysUn / mvuRight of pKF1 */
+    const float *x2, *y2, *angle2, *u_right2;
+    const int32_t *octave2;
+    const float *scale_factors2, *level_sigma2_2;  /* pKF2->mvScaleFactors / mvLevelSigma2 */
+    float F12[9];                         /* row-major 3x3 */
+    float ex, ey;                         /* epipole in the second image (:664-670) */
+    int only_stereo, check_orientation;
+    int n_nodes1, n_nodes2;
+    const int32_t *node_id1, *node_off1, *node_idx1;
+    const int32_t *node_id2, *node_off2, *node_idx2;
+} orc_triang_problem_t;
+int orc_search_for_triangulation(const orc_triang_problem_t *p, int32_t *match12);
+void orc_compute_distinctive_descriptors(int n_points, const int32_t *off, const uint8_t *desc, int32_t *best);
+
 /* ---- Frame::ComputeStereoMatches src/Frame.cc:495-669 ---- */
 typedef struct {
     int n_left, n_right;

@@ -92,3 +92,12 @@ V = O.Vocabulary()
 V.set_nodes(k, L, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
 d = S.vocab_descriptors(np.random.default_rng(52), voc, 600)
 np.savez_compressed(os.path.join(OUT, "vocab_k10_L3.npz"), seed=seed, k=k, L=L, levelsup=lu, desc=d, **V.transform(d, lu))
+# remaining matcher methods
+p = S.synth_bow_kf_problem(24, 300, 320, n_nodes=20, nnratio=0.75)
+n, m = O.search_by_bow_kf(p)
+np.savez_compressed(os.path.join(OUT, "bow_kf_300.npz"), nmatches=n, match=m, **p)
+p = S.synth_triang_problem(25, 300, 320, n_nodes=20)
+n, m = O.search_for_triangulation(p)
+np.savez_compressed(os.path.join(OUT, "triang_300.npz"), nmatches=n, match=m, **p)
+off, desc = S.synth_observations(26, 200, 16)
+np.savez_compressed(os.path.join(OUT, "distinctive_200.npz"), off=off, desc=desc, best=O.compute_distinctive_descriptors(off, desc))

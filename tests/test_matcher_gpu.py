@@ -94,3 +94,74 @@ def test_match_on_extracted_frames(pkg, oracle, gpu):
     assert good.mean() > 0.5
     dx = k1["x"][bi[good]] - k0["x"][good]
     assert np.median(np.abs(dx - 3 * 1.0)) < 4.0
+
+
+def test_search_by_bow_kf_vs_oracle(pkg, oracle, gpu):
+    """SearchByBoW(KF, KF) src/ORBmatcher.cc:522-655"""
+    S = pkg.synth
+    for ratio, ori in ((0.75, True), (0.6, False), (0.9, True)):
+        m = pkg.Matcher(ratio, ori)
+        probs = [S.synth_bow_kf_problem(s, 900 + 40 * s, 1000 - 25 * s, n_nodes=50 + 10 * s, nnratio=ratio, check_orientation=ori)
+                 for s in range(6)]
+        for p, (n, match) in zip(probs, m.SearchByBoWKF(probs)):
+            on, om = oracle.search_by_bow_kf(p)
+            assert n == on and (match == om).all() and n > 100
+    # no map points on one side / empty keyframes
+    m = pkg.Matcher(0.75, True)
+    p = S.synth_bow_kf_problem(9, 300, 300)
+    p["has_mp2"] = np.zeros_like(p["has_mp2"])
+    n, match = m.SearchByBoWKF(p)
+    assert n == 0 and (match == -1).all() and oracle.search_by_bow_kf(p)[0] == 0
+    g = np.load(os.path.join(GOLD, "bow_kf_300.npz"))
+    p = {k: g[k] for k in g.files if k not in ("nmatches", "match")}
+    n, match = pkg.Matcher(float(g["nnratio"]), bool(g["check_orientation"])).SearchByBoWKF(p)
+    assert n == int(g["nmatches"]) and (match == g["match"]).all()
+
+
+def test_search_for_triangulation_vs_oracle(pkg, oracle, gpu):
+    """SearchForTriangulation src/ORBmatcher.cc:657-823: stereo, stereo-only and monocular keyframes"""
+    S = pkg.synth
+    for ori in (True, False):
+        m = pkg.Matcher(0.6, ori)
+        for kw in (dict(), dict(only_stereo=True), dict(mono=True), dict(cfg="tum")):
+            probs = [S.synth_triang_problem(s, 1000 + 50 * s, 1100 - 40 * s, n_nodes=40 + 15 * s, check_orientation=ori, **kw)
+                     for s in range(5)]
+            res = m.SearchForTriangulation(probs, only_stereo=kw.get("only_stereo", False))
+            for p, (n, match) in zip(probs, res):
+                on, om = oracle.search_for_triangulation(p)
+                assert n == on and (match == om).all()
+            assert sum(r[0] for r in res) > (50 if kw.get("only_stereo") else 300)
+    # equal distances: the LAST candidate of the bucket wins (dist > bestDist is the skip test, :734)
+    p = S.synth_triang_problem(77, 200, 200, n_nodes=1)
+    p["has_mp1"][:] = 0
+    p["has_mp2"][:] = 0
+    p["desc2"][:] = p["desc1"][0]
+    p["F12"] = np.zeros(9, np.float32)
+    p["F12"][6] = 1e-3  # a = 1e-3, b = 0: every point lies near the "line"
+    p["u_right1"][:] = 1.0
+    m = pkg.Matcher(0.6, False)
+    n, match = m.SearchForTriangulation(p)
+    on, om = oracle.search_for_triangulation(p)
+    assert n == on and (match == om).all()
+    g = np.load(os.path.join(GOLD, "triang_300.npz"))
+    p = {k: g[k] for k in g.files if k not in ("nmatches", "match")}
+    n, match = pkg.Matcher(0.6, bool(g["check_orientation"])).SearchForTriangulation(p, only_stereo=bool(g["only_stereo"]))
+    assert n == int(g["nmatches"]) and (match == g["match"]).all()
+
+
+def test_compute_distinctive_descriptors_vs_oracle(pkg, oracle, gpu):
+    """MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:275-340 (batched)"""
+    S = pkg.synth
+    m = pkg.Matcher()
+    for seed, n, mo in ((0, 3000, 24), (1, 500, 70), (2, 40, 3)):
+        off, desc = S.synth_observations(seed, n, mo)
+        best = m.ComputeDistinctiveDescriptors(off, desc)
+        assert (best == oracle.compute_distinctive_descriptors(off, desc)).all()
+        cnt = np.diff(off)
+        assert ((best == -1) == (cnt == 0)).all() and (best[cnt > 0] < cnt[cnt > 0]).all()
+    # ties: identical descriptors -> index 0; two descriptors -> median = row[0] = 0 for both -> index 0
+    off = np.array([0, 5, 7, 8, 8], np.int32)
+    desc = np.zeros((8, 32), np.uint8)
+    desc[5] = 255
+    assert m.ComputeDistinctiveDescriptors(off, desc).tolist() == [0, 0, 0, -1]
+    assert len(m.ComputeDistinctiveDescriptors(np.zeros(1, np.int32), np.zeros((0, 32), np.uint8))) == 0

@@ -342,3 +342,39 @@ def test_vocabulary_golden_and_loader_quirks(oracle, pkg, tmp_path):
     rw = W.transform(d, int(g["levelsup"]))
     assert rw["bow_value"].tobytes() == r["bow_value"].tobytes() and rw["fv_idx"].tobytes() == r["fv_idx"].tobytes()
     assert not W.load_binary(tmp_path / "nope.bin")
+
+
+def test_rank4_matcher_golden_and_known_answers(oracle, pkg):
+    """SearchByBoW(KF,KF) :522-655, SearchForTriangulation :657-823, ComputeDistinctiveDescriptors MapPoint.cc:275-340"""
+    g = np.load(os.path.join(GOLD, "bow_kf_300.npz"))
+    p = {k: g[k] for k in g.files if k not in ("nmatches", "match")}
+    n, m = oracle.search_by_bow_kf(p)
+    assert n == int(g["nmatches"]) and (m == g["match"]).all()
+    # every match joins two features with map points in the same vocabulary node, KF2 features used once
+    i1 = np.flatnonzero(m >= 0)
+    assert p["has_mp1"][i1].all() and p["has_mp2"][m[i1]].all() and len(set(m[i1].tolist())) == len(i1) == n
+    g = np.load(os.path.join(GOLD, "triang_300.npz"))
+    p = {k: g[k] for k in g.files if k not in ("nmatches", "match")}
+    n, m = oracle.search_for_triangulation(p)
+    assert n == int(g["nmatches"]) and (m == g["match"]).all() and n > 20
+    i1 = np.flatnonzero(m >= 0)
+    assert not p["has_mp1"][i1].any() and not p["has_mp2"][m[i1]].any()
+    # known answer: the matched pairs satisfy the epipolar constraint x2' F12' x1 ~ 0 (independent numpy check)
+    F = p["F12"].reshape(3, 3).astype(np.float64)
+    x1 = np.stack([p["x1"][i1], p["y1"][i1], np.ones(len(i1))], 1)
+    x2 = np.stack([p["x2"][m[i1]], p["y2"][m[i1]], np.ones(len(i1))], 1)
+    line = x1 @ F
+    d2 = (line * x2).sum(1) ** 2 / (line[:, 0] ** 2 + line[:, 1] ** 2)
+    assert (d2 < 3.84 * p["level_sigma2_2"][p["octave2"][m[i1]]] * (1 + 1e-4)).all()
+    g = np.load(os.path.join(GOLD, "distinctive_200.npz"))
+    best = oracle.compute_distinctive_descriptors(g["off"], g["desc"])
+    assert (best == g["best"]).all()
+    # brute-force numpy restatement of the median rule on a few points
+    for pt in range(0, 200, 17):
+        d = g["desc"][g["off"][pt]: g["off"][pt + 1]]
+        if len(d) == 0:
+            assert best[pt] == -1
+            continue
+        D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
+        med = np.sort(D, axis=1)[:, int(0.5 * (len(d) - 1))]
+        assert best[pt] == int(np.argmin(med))
