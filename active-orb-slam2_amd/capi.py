@@ -110,6 +110,11 @@ def lib():
                 L.aos2_matcher_search_by_bow_kf.argtypes = [vp, vp, ci, vp, vp]
                 L.aos2_matcher_search_for_triangulation.argtypes = [vp, vp, ci, ci, vp, vp]
                 L.aos2_compute_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp]
+            if hasattr(L, "aos2_matcher_fuse"):
+                L.aos2_matcher_fuse.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+                L.aos2_matcher_search_by_projection_kf.argtypes = [vp, vp, vp, vp, vp]
+                L.aos2_matcher_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+                L.aos2_matcher_search_by_projection_reloc.argtypes = [vp, vp, vp, ci, vp, vp]
             L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
             L.aos2_matcher_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, vp, vp]
         if hasattr(L, "aos2_lba_create"):
@@ -433,6 +438,14 @@ class _ProjLast(C.Structure):
                 ("mb", C.c_float), ("mbf", C.c_float)]
 
 
+class _ProjPoints(C.Structure):
+    _fields_ = [("n_pts", C.c_int32), ("valid", C.c_void_p), ("pos", C.c_void_p), ("max_dist", C.c_void_p),
+                ("min_dist", C.c_void_p), ("normal", C.c_void_p), ("desc", C.c_void_p), ("q_angle", C.c_void_p),
+                ("R", C.c_float * 9), ("t", C.c_float * 3), ("Ow", C.c_float * 3), ("R2", C.c_float * 9),
+                ("t2", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float), ("log_scale_factor", C.c_float), ("inv_level_sigma2", C.c_void_p), ("th", C.c_float)]
+
+
 _DTYPES = dict(desc_kf=np.uint8, desc_f=np.uint8, kf_has_mp=np.uint8, angle_kf=np.float32, angle_f=np.float32,
                node_id_kf=np.int32, node_off_kf=np.int32, node_idx_kf=np.int32, node_id_f=np.int32,
                node_off_f=np.int32, node_idx_f=np.int32, kp_x=np.float32, kp_y=np.float32, kp_octave=np.int32,
@@ -444,7 +457,8 @@ _DTYPES = dict(desc_kf=np.uint8, desc_f=np.uint8, kf_has_mp=np.uint8, angle_kf=n
                angle1=np.float32, angle2=np.float32, node_id1=np.int32, node_off1=np.int32, node_idx1=np.int32,
                node_id2=np.int32, node_off2=np.int32, node_idx2=np.int32, x1=np.float32, y1=np.float32, x2=np.float32,
                y2=np.float32, u_right1=np.float32, u_right2=np.float32, octave2=np.int32, scale_factors2=np.float32,
-               level_sigma2_2=np.float32)
+               level_sigma2_2=np.float32, valid=np.uint8, pos=np.float32, max_dist=np.float32, min_dist=np.float32,
+               normal=np.float32, q_angle=np.float32, inv_level_sigma2=np.float32)
 
 
 def _fill_struct(st, d, keep):
@@ -582,6 +596,45 @@ class Matcher:
         _check(self.L.aos2_matcher_search_by_projection_last(self.h, C.byref(fv), C.byref(pl), float(th), int(mono),
                                                              _p(match), _p(n)))
         return int(n[0]), match[: cur["n_f"]]
+
+
+    # ---- projection family; f / p: synth_proj_gen_problem()-style dicts
+    def Fuse(self, kf, p, sim3=False):
+        """search part of Fuse (src/ORBmatcher.cc:825-975, sim3: :977-1100) -> (nFused, best_idx, best_dist)"""
+        keep = []
+        fv = _fill_struct(_FrameView(), kf, keep)
+        pp = _fill_struct(_ProjPoints(), p, keep)
+        bi, bd = np.zeros(max(p["n_pts"], 1), np.int32), np.zeros(max(p["n_pts"], 1), np.int32)
+        n = np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_fuse(self.h, C.byref(fv), C.byref(pp), int(sim3), _p(bi), _p(bd), _p(n)))
+        return int(n[0]), bi[: p["n_pts"]], bd[: p["n_pts"]]
+
+    def SearchByProjectionKF(self, kf, p):
+        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) :290-403 -> (nmatches, match_f)"""
+        keep = []
+        fv = _fill_struct(_FrameView(), kf, keep)
+        pp = _fill_struct(_ProjPoints(), p, keep)
+        match, n = np.zeros(max(kf["n_f"], 1), np.int32), np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_by_projection_kf(self.h, C.byref(fv), C.byref(pp), _p(match), _p(n)))
+        return int(n[0]), match[: kf["n_f"]]
+
+    def SearchBySim3(self, kf1, kf2, p12, p21):
+        """SearchBySim3 :1102-1326 -> (nFound, match12)"""
+        keep = []
+        a, b = _fill_struct(_FrameView(), kf1, keep), _fill_struct(_FrameView(), kf2, keep)
+        c, d = _fill_struct(_ProjPoints(), p12, keep), _fill_struct(_ProjPoints(), p21, keep)
+        match, n = np.zeros(max(p12["n_pts"], 1), np.int32), np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_by_sim3(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), _p(match), _p(n)))
+        return int(n[0]), match[: p12["n_pts"]]
+
+    def SearchByProjectionReloc(self, frame, p, orb_dist=100):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) :1472-1599 -> (nmatches, match_f)"""
+        keep = []
+        fv = _fill_struct(_FrameView(), frame, keep)
+        pp = _fill_struct(_ProjPoints(), p, keep)
+        match, n = np.zeros(max(frame["n_f"], 1), np.int32), np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_by_projection_reloc(self.h, C.byref(fv), C.byref(pp), int(orb_dist), _p(match), _p(n)))
+        return int(n[0]), match[: frame["n_f"]]
 
 
 # ------------------------------------------------------------------------------------------ local BA

@@ -7,6 +7,7 @@
 // 64 lanes share the candidate set of the current query (Hamming distances + a two-smallest
 // reduction with the reference's first-wins tie-break), while the greedy bookkeeping is
 // wave-uniform.  Independent problems ((KF,F) pairs) are spread over the grid.
+#include <type_traits>
 #include <vector>
 
 #include "aos2_common.h"
@@ -624,12 +625,13 @@ struct Pick {
 };
 
 __device__ __forceinline__ Pick pick_best2(const Entry *__restrict__ ent, int cnt, Entry e, const uint8_t *state,
-                                           int lane)
+                                           int lane, bool skip_any = false)
 {
     uint32_t k1 = KEY_NONE, k2 = KEY_NONE, p1 = 0, p2 = 0;
     for (int j0 = 0; j0 < cnt; j0 += 64) {
         if (j0 > 0) e = (j0 + lane < cnt) ? ent[j0 + lane] : Entry{KEY_NONE, 0};
-        if (j0 + lane < cnt && e.key != KEY_NONE && state[e.payload & 0xffffffu] != 2) {  // Observations()>0 skip
+        const uint8_t stv = (j0 + lane < cnt && e.key != KEY_NONE) ? state[e.payload & 0xffffffu] : (uint8_t)2;
+        if (j0 + lane < cnt && e.key != KEY_NONE && (skip_any ? stv == 0 : stv != 2)) {  // Observations()>0 skip / any map point
             if (e.key < k1) {
                 k2 = k1; p2 = p1;
                 k1 = e.key; p1 = e.payload;
@@ -926,6 +928,286 @@ __global__ __launch_bounds__(64) void proj_last_resolve_kernel(FrameDev F, ProjL
             }
         for (int i = lane; i < F.n_f; i += 64)
             if (bin_f[i] & culled) match_f[i] = -2;  // set to NULL (:1459)
+    }
+    if (lane == 0) *nmatches_out = nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projection family: map points projected into a keyframe / frame and matched to
+// the most similar feature of a window.
+//   mode 0  Fuse(pKF, vpMapPoints, th)                         :825-975    independent points
+//   mode 1  Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)        :977-1100   independent points
+//   mode 2  SearchByProjection(pKF, Scw, vpPoints, vpMatched)   :290-403    greedy over vpMatched
+//   mode 3  one direction of SearchBySim3                       :1148-1303  independent points
+//   mode 4  SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) :1472-1599  greedy + rotation
+// cv::Mat arithmetic as the reference performs it (DESIGN.md conventions): R*p+t in float left to right,
+// cv::norm and Mat::dot with double accumulation, log() = correctly rounded float logarithm.
+// ---------------------------------------------------------------------------------------------
+struct ProjGenDev {
+    int n_pts, mode;
+    const uint8_t *valid, *desc;
+    const float *pos, *max_dist, *min_dist, *normal, *q_angle, *inv_level_sigma2;
+    float R[9], t[3], Ow[3], R2[9], t2[3];
+    float fx, fy, cx, cy, bf, log_scale_factor, th;
+};
+
+__device__ __forceinline__ void xform3(const float *R, const float *t, const float *p, float *o)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        o[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(R[3 * r], p[0]), __fmul_rn(R[3 * r + 1], p[1])), __fmul_rn(R[3 * r + 2], p[2])), t[r]);
+}
+__device__ __forceinline__ float norm3d(const float *v)
+{
+    const double s = __dadd_rn(__dadd_rn(__dmul_rn((double)v[0], (double)v[0]), __dmul_rn((double)v[1], (double)v[1])),
+                               __dmul_rn((double)v[2], (double)v[2]));
+    return (float)sqrt(s);
+}
+
+struct ProjSetup {
+    bool ok;
+    float u, v, ur, radius;
+    int level;
+};
+
+// everything before GetFeaturesInArea; wave-uniform
+__device__ __forceinline__ ProjSetup proj_gen_setup(const FrameDev &F, const ProjGenDev &P, int i)
+{
+    ProjSetup S;
+    S.ok = false;
+    S.u = S.v = S.ur = S.radius = 0.0f;
+    S.level = 0;
+    if (!P.valid[i]) return S;
+    const float pw[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+    float pc[3];
+    xform3(P.R, P.t, pw, pc);
+    if (P.mode == 3) {  // p3Dc2 = sR21 * p3Dc1 + t21 (:1163)
+        float c2[3];
+        xform3(P.R2, P.t2, pc, c2);
+        pc[0] = c2[0]; pc[1] = c2[1]; pc[2] = c2[2];
+    }
+    float u, v, invz;
+    if (P.mode == 4) {  // :1505-1516: no depth test, u = fx*xc*invzc + cx, closed bounds
+        invz = (float)__ddiv_rn(1.0, (double)pc[2]);
+        u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, pc[0]), invz), P.cx);
+        v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, pc[1]), invz), P.cy);
+        if (u < F.min_x || u > F.max_x) return S;
+        if (v < F.min_y || v > F.max_y) return S;
+    } else {
+        if (pc[2] < 0.0f) return S;
+        // `1/z` (float division) in :852 and :329, `1.0/z` (double division, then float) in :1026 and :1170
+        invz = (P.mode == 0 || P.mode == 2) ? __fdiv_rn(1.0f, pc[2]) : (float)__ddiv_rn(1.0, (double)pc[2]);
+        const float x = __fmul_rn(pc[0], invz), y = __fmul_rn(pc[1], invz);
+        u = __fadd_rn(__fmul_rn(P.fx, x), P.cx);
+        v = __fadd_rn(__fmul_rn(P.fy, y), P.cy);
+        if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) return S;  // KeyFrame::IsInImage
+    }
+    float dist3D;
+    if (P.mode == 3) {
+        dist3D = norm3d(pc);  // cv::norm(p3Dc2) :1185
+    } else {
+        const float PO[3] = {__fsub_rn(pw[0], P.Ow[0]), __fsub_rn(pw[1], P.Ow[1]), __fsub_rn(pw[2], P.Ow[2])};
+        dist3D = norm3d(PO);
+        if (P.mode != 4) {  // viewing angle below 60 deg: PO.dot(Pn) < 0.5*dist3D
+            const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)P.normal[3 * i]),
+                                                   __dmul_rn((double)PO[1], (double)P.normal[3 * i + 1])),
+                                         __dmul_rn((double)PO[2], (double)P.normal[3 * i + 2]));
+            if (dist3D < P.min_dist[i] || dist3D > P.max_dist[i]) return S;
+            if (dot < __dmul_rn(0.5, (double)dist3D)) return S;
+        }
+    }
+    const float maxd = P.max_dist[i];
+    if (dist3D < P.min_dist[i] || dist3D > maxd) return S;
+    // MapPoint::PredictScale (src/MapPoint.cc:427-459)
+    const float ratio = __fdiv_rn(maxd, dist3D);
+    const float lg = (float)log((double)ratio);
+    int nScale = (int)ceilf(__fdiv_rn(lg, P.log_scale_factor));
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= F.n_levels) nScale = F.n_levels - 1;
+    S.level = nScale;
+    S.radius = __fmul_rn(P.th, F.scale_factors[nScale]);
+    S.u = u;
+    S.v = v;
+    S.ur = __fsub_rn(u, __fmul_rn(P.bf, invz));
+    S.ok = true;
+    return S;
+}
+
+// best candidate of a window for the independent modes: min over (dist << 20 | visiting position)
+__device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGenDev &P, const Window &w, const Desc &dq,
+                                                const ProjSetup &S, int lane, uint32_t &payload)
+{
+    const int ny = w.y1 - w.y0 + 1, ncell = (w.x1 - w.x0 + 1) * ny;
+    int base = 0;
+    uint32_t key = KEY_NONE;
+    payload = 0;
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        int beg = 0, cnt = 0;
+        if (c < ncell) {
+            const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
+            beg = F.grid_off[cell];
+            cnt = F.grid_off[cell + 1] - beg;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int yv = __shfl_up(incl, d);
+            if (lane >= d) incl += yv;
+        }
+        const int pos0 = base + incl - cnt;
+        for (int j = 0; j < cnt; ++j) {
+            const int idx = F.grid_idx[beg + j];
+            const float kx = F.kp_x[idx], ky = F.kp_y[idx];
+            if (!(fabsf(__fsub_rn(kx, S.u)) < S.radius && fabsf(__fsub_rn(ky, S.v)) < S.radius)) continue;
+            const int oct = F.kp_octave[idx];
+            if (oct < S.level - 1 || oct > S.level) continue;
+            if (P.mode == 0) {  // reprojection error gates of Fuse (:911-935)
+                const float ex = __fsub_rn(S.u, kx), ey = __fsub_rn(S.v, ky);
+                const float kr = F.u_right[idx];
+                float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                double lim = 5.99;
+                if (kr >= 0) {
+                    const float er = __fsub_rn(S.ur, kr);
+                    e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                    lim = 7.8;
+                }
+                if ((double)__fmul_rn(e2, P.inv_level_sigma2[oct]) > lim) continue;
+            }
+            const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+            const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
+            if (k < key) {
+                key = k;
+                payload = (uint32_t)idx;
+            }
+        }
+        base += __shfl(incl, 63);
+    }
+    uint32_t k1 = key, k2 = KEY_NONE;
+    wave_min2(k1, k2);
+    if (k1 != KEY_NONE) payload = read_owner(payload, __ballot(key == k1));
+    return k1;
+}
+
+// modes 0, 1, 3: one wave per point, no shared state
+__global__ __launch_bounds__(64) void projgen_best_kernel(FrameDev F, ProjGenDev P, int thr, int32_t *best_idx,
+                                                          int32_t *best_dist)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    int bi = -1, bd = 256;
+    const ProjSetup S = proj_gen_setup(F, P, i);
+    if (S.ok) {
+        const Window w = window_cells(F, S.u, S.v, S.radius);
+        if (w.ok) {
+            uint32_t pay;
+            const uint32_t k = window_best(F, P, w, load_desc(P.desc + (size_t)i * 32), S, lane, pay);
+            if (k != KEY_NONE && (int)(k >> 20) <= thr) {
+                bi = (int)pay;
+                bd = (int)(k >> 20);
+            }
+        }
+    }
+    if (lane == 0) {
+        best_idx[i] = bi;
+        best_dist[i] = bd;
+    }
+}
+
+// SearchBySim3 agreement (:1306-1323)
+__global__ void sim3_agree_kernel(const int32_t *__restrict__ vn1, const int32_t *__restrict__ vn2, int n1, int n2,
+                                  int32_t *match12, int32_t *nfound)
+{
+    const int i1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i1 >= n1) return;
+    int m = -1;
+    const int idx2 = vn1[i1];
+    if (idx2 >= 0 && idx2 < n2 && vn2[idx2] == i1) m = idx2;
+    match12[i1] = m;
+    if (m >= 0) atomicAdd(nfound, 1);
+}
+
+// modes 2, 4 stage A: entries of the window into the pool
+__global__ __launch_bounds__(64) void projgen_entries_kernel(FrameDev F, ProjGenDev P, QuerySlot *slots, Entry *pool,
+                                                             int32_t *pool_used, int pool_cap)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    QuerySlot s{0, 0};
+    const ProjSetup S = proj_gen_setup(F, P, i);
+    if (S.ok) {
+        const Window w = window_cells(F, S.u, S.v, S.radius);
+        if (w.ok) {
+            const int pop = window_population(F, w, lane);
+            if (pop > 0) {
+                int off = 0;
+                if (lane == 0) off = atomicAdd(pool_used, pop);
+                off = __shfl(off, 0);
+                if (off + pop <= pool_cap) {
+                    // mode 2: levels [pred-1, pred] tested per candidate (:379-382) == the level filter of the
+                    // Frame version; mode 4: GetFeaturesInArea(u, v, radius, pred-1, pred+1) (:1537).  A level
+                    // window starting at 0 or below disables only the lower test, like bCheckLevels (Frame.cc:379).
+                    const int lo = S.level - 1, hi = P.mode == 4 ? S.level + 1 : S.level;
+                    window_entries(F, w, load_desc(P.desc + (size_t)i * 32), S.u, S.v, S.radius, lo, hi, 0.0f,
+                                   __builtin_huge_valf(), lane, pool + off);
+                    s.cnt = pop;
+                    s.ent_off = off;
+                } else
+                    s.cnt = -1;
+            }
+        }
+    }
+    if (lane == 0) slots[i] = s;
+}
+
+// modes 2, 4 stage B: the reference's greedy loop over the points
+__global__ __launch_bounds__(64) void projgen_resolve_kernel(FrameDev F, ProjGenDev P, int thr, int check_ori,
+                                                             const QuerySlot *__restrict__ slots,
+                                                             const Entry *__restrict__ pool, int32_t *match_f,
+                                                             int32_t *bin_f, int32_t *nmatches_out)
+{
+    extern __shared__ uint8_t state[];  // != 0: vpMatched[idx] / mvpMapPoints[idx] is set
+    __shared__ int histo[HISTO];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < F.n_f; i += 64) {
+        state[i] = F.f_mp_state[i] != 0;
+        match_f[i] = -1;
+        bin_f[i] = 0;
+    }
+    if (lane < HISTO) histo[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    SlotStream Q;
+    Q.init(slots, pool, P.n_pts, lane);
+    for (int i = 0; i < P.n_pts; i++) {
+        QuerySlot s;
+        Entry e;
+        Q.next(i, s, e);
+        if (s.cnt <= 0) continue;
+        const Pick b = pick_best2(pool + s.ent_off, s.cnt, e, state, lane, true);
+        const int bestDist = b.k1 == KEY_NONE ? 256 : (int)(b.k1 >> 20);
+        if (bestDist <= thr) {
+            if (lane == 0) {
+                match_f[b.idx1] = i;
+                state[b.idx1] = 1;
+                if (check_ori) {
+                    const int bin = rot_bin(__fsub_rn(P.q_angle[i], F.kp_angle[b.idx1]));
+                    histo[bin]++;
+                    bin_f[b.idx1] = bin + 1;
+                }
+            }
+            nmatches++;
+            lds_fence();
+        }
+    }
+    __syncthreads();
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) nmatches -= histo[i];
+        for (int i = lane; i < F.n_f; i += 64) {
+            const int bn = bin_f[i] - 1;
+            if (bn >= 0 && bn != i1 && bn != i2 && bn != i3) match_f[i] = -2;  // set to NULL (:1589)
+        }
     }
     if (lane == 0) *nmatches_out = nmatches;
 }
@@ -1520,6 +1802,199 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
+}
+
+// ---- projection family -------------------------------------------------
+static int check_points(const aos2_proj_points_t *p, int mode)
+{
+    if (!p || p->n_pts < 0 || (p->n_pts > 0 && (!p->valid || !p->pos || !p->max_dist || !p->min_dist || !p->desc)) ||
+        (p->n_pts > 0 && mode <= 2 && !p->normal) || (mode == 0 && !p->inv_level_sigma2) ||
+        (p->n_pts > 0 && mode == 4 && !p->q_angle) || !(p->log_scale_factor > 0)) {
+        set_error("bad point set");
+        return AOS2_ERR_ARG;
+    }
+    return AOS2_OK;
+}
+
+static ProjGenDev points_dev(Arena &A, const aos2_proj_points_t *p, int mode, int n_levels)
+{
+    const size_t n = (size_t)p->n_pts;
+    ProjGenDev P{};
+    P.n_pts = p->n_pts;
+    P.mode = mode;
+    const size_t o0 = A.push(p->valid, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->pos, n * 12);
+    const size_t o3 = A.push(p->max_dist, n * 4), o4 = A.push(p->min_dist, n * 4);
+    const size_t o5 = p->normal ? A.push(p->normal, n * 12) : 0, o6 = p->q_angle ? A.push(p->q_angle, n * 4) : 0;
+    const size_t o7 = p->inv_level_sigma2 ? A.push(p->inv_level_sigma2, (size_t)n_levels * 4) : 0;
+    // device pointers are resolved after the arena is uploaded: keep offsets in the pointer fields for now
+    P.valid = reinterpret_cast<const uint8_t *>(o0); P.desc = reinterpret_cast<const uint8_t *>(o1);
+    P.pos = reinterpret_cast<const float *>(o2); P.max_dist = reinterpret_cast<const float *>(o3);
+    P.min_dist = reinterpret_cast<const float *>(o4); P.normal = reinterpret_cast<const float *>(o5);
+    P.q_angle = reinterpret_cast<const float *>(o6); P.inv_level_sigma2 = reinterpret_cast<const float *>(o7);
+    memcpy(P.R, p->R, sizeof(P.R)); memcpy(P.t, p->t, sizeof(P.t)); memcpy(P.Ow, p->Ow, sizeof(P.Ow));
+    memcpy(P.R2, p->R2, sizeof(P.R2)); memcpy(P.t2, p->t2, sizeof(P.t2));
+    P.fx = p->fx; P.fy = p->fy; P.cx = p->cx; P.cy = p->cy; P.bf = p->bf;
+    P.log_scale_factor = p->log_scale_factor;
+    P.th = p->th;
+    return P;
+}
+
+static void points_resolve(const Arena &A, ProjGenDev &P)
+{
+    auto fix = [&](auto *&ptr) {
+        using T = std::remove_reference_t<decltype(ptr)>;
+        ptr = reinterpret_cast<T>(A.m->arena.p + reinterpret_cast<size_t>(ptr));
+    };
+    fix(P.valid); fix(P.desc); fix(P.pos); fix(P.max_dist); fix(P.min_dist); fix(P.normal); fix(P.q_angle);
+    fix(P.inv_level_sigma2);
+}
+
+// independent points: modes 0 (Fuse), 1 (Fuse with Scw)
+int aos2_matcher_fuse(aos2_matcher_t *m, const aos2_frame_view_t *kf, const aos2_proj_points_t *p, int sim3,
+                      int32_t *best_idx, int32_t *best_dist, int32_t *n_fused)
+{
+    const int mode = sim3 ? 1 : 0;
+    if (!m || !best_idx || !best_dist) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = check_frame(kf);
+    if (st) return st;
+    if ((st = check_points(p, mode))) return st;
+    if (n_fused) *n_fused = 0;
+    if (p->n_pts == 0) return AOS2_OK;
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t fo[12];
+    fill_frame(A, kf, fo);
+    ProjGenDev P = points_dev(A, p, mode, kf->n_levels);
+    const size_t ob = A.reserve((size_t)p->n_pts * 8 + 8);
+    if ((st = A.upload())) return st;
+    points_resolve(A, P);
+    FrameDev F = frame_dev(A, kf, fo);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(projgen_best_kernel, dim3(p->n_pts), dim3(64), 0, m->stream, F, P, TH_LOW, A.dev<int32_t>(ob),
+                       A.dev<int32_t>(ob) + p->n_pts);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(best_idx, A.dev<int32_t>(ob), (size_t)p->n_pts * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(best_dist, A.dev<int32_t>(ob) + p->n_pts, (size_t)p->n_pts * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    if (n_fused) {
+        int c = 0;
+        for (int i = 0; i < p->n_pts; ++i) c += best_idx[i] >= 0;
+        *n_fused = c;
+    }
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_sim3(aos2_matcher_t *m, const aos2_frame_view_t *kf1, const aos2_frame_view_t *kf2,
+                                const aos2_proj_points_t *p12, const aos2_proj_points_t *p21, int32_t *match12,
+                                int32_t *n_found)
+{
+    if (!m || !match12 || !n_found) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if ((st = check_frame(kf1)) || (st = check_frame(kf2)) || (st = check_points(p12, 3)) || (st = check_points(p21, 3))) return st;
+    if (p12->n_pts != kf1->n_f || p21->n_pts != kf2->n_f) {
+        set_error("SearchBySim3: one (possibly invalid) map point per keyframe feature is expected");
+        return AOS2_ERR_ARG;
+    }
+    *n_found = 0;
+    if (p12->n_pts == 0) return AOS2_OK;
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t f1o[12], f2o[12];
+    fill_frame(A, kf1, f1o);
+    fill_frame(A, kf2, f2o);
+    ProjGenDev P12 = points_dev(A, p12, 3, kf2->n_levels), P21 = points_dev(A, p21, 3, kf1->n_levels);
+    const size_t n1 = (size_t)p12->n_pts, n2 = (size_t)p21->n_pts;
+    const size_t o1 = A.reserve((n1 + 1) * 8), o2 = A.reserve((n2 + 1) * 8), om = A.reserve((n1 + 1) * 4), on = A.reserve(8);
+    if ((st = A.upload())) return st;
+    points_resolve(A, P12);
+    points_resolve(A, P21);
+    FrameDev F1 = frame_dev(A, kf1, f1o), F2 = frame_dev(A, kf2, f2o);
+    AOS2_HIP_CHECK(hipMemsetAsync(A.dev<int32_t>(on), 0, 8, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(projgen_best_kernel, dim3((unsigned)n1), dim3(64), 0, m->stream, F2, P12, TH_HIGH, A.dev<int32_t>(o1),
+                       A.dev<int32_t>(o1) + n1);
+    if (n2 > 0)
+        hipLaunchKernelGGL(projgen_best_kernel, dim3((unsigned)n2), dim3(64), 0, m->stream, F1, P21, TH_HIGH, A.dev<int32_t>(o2),
+                           A.dev<int32_t>(o2) + n2);
+    hipLaunchKernelGGL(sim3_agree_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream, A.dev<int32_t>(o1),
+                       A.dev<int32_t>(o2), (int)n1, (int)n2, A.dev<int32_t>(om), A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n1 * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(n_found, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+// greedy modes 2 (SearchByProjection(pKF, Scw, ...)) and 4 (SearchByProjection(CurrentFrame, pKF, ...))
+static int projgen_serial(aos2_matcher_t *m, const aos2_frame_view_t *f, const aos2_proj_points_t *p, int mode, int thr,
+                          int check_ori, int32_t *match_f, int32_t *nmatches)
+{
+    if (!m || !match_f || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = check_frame(f);
+    if (st) return st;
+    if ((st = check_points(p, mode))) return st;
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t fo[12];
+    fill_frame(A, f, fo);
+    ProjGenDev P = points_dev(A, p, mode, f->n_levels);
+    const size_t om = A.reserve((size_t)f->n_f * 4 + 4), ob = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(8);
+    const size_t oslots = A.reserve((size_t)(p->n_pts + 1) * sizeof(QuerySlot));
+    const size_t pool_cap = (size_t)p->n_pts * (size_t)f->n_f;
+    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
+        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_pts, f->n_f);
+        return AOS2_ERR_ARG;
+    }
+    if ((st = m->pool.alloc(pool_cap + 1))) return st;
+    if ((st = A.upload())) return st;
+    points_resolve(A, P);
+    FrameDev F = frame_dev(A, f, fo);
+    int32_t *d_used = A.dev<int32_t>(on) + 1;
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (p->n_pts > 0)
+        hipLaunchKernelGGL(projgen_entries_kernel, dim3(p->n_pts), dim3(64), 0, m->stream, F, P, A.dev<QuerySlot>(oslots),
+                           reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+    hipLaunchKernelGGL(projgen_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, thr, check_ori,
+                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                       A.dev<int32_t>(ob), A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    if (f->n_f > 0)
+        AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_projection_kf(aos2_matcher_t *m, const aos2_frame_view_t *kf, const aos2_proj_points_t *p,
+                                         int32_t *match_f, int32_t *nmatches)
+{
+    return projgen_serial(m, kf, p, 2, TH_LOW, 0, match_f, nmatches);
+}
+
+int aos2_matcher_search_by_projection_reloc(aos2_matcher_t *m, const aos2_frame_view_t *frame, const aos2_proj_points_t *p,
+                                            int orb_dist, int32_t *match_f, int32_t *nmatches)
+{
+    if (!m) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    return projgen_serial(m, frame, p, 4, orb_dist, m->check_ori, match_f, nmatches);
 }
 
 }  // extern "C"

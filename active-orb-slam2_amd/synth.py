@@ -333,6 +333,139 @@ def synth_frame_view(rng, n_f, w, h, n_levels=8, stereo=True, frac_with_obs=0.1)
                 grid_idx=idx, f_mp_state=state)
 
 
+def _view_from(rng, kp_x, kp_y, w, h, n_levels=8, stereo=True, frac_with_mp=0.15):
+    """frame / keyframe view around given keypoint positions (grid built from them)"""
+    n_f = len(kp_x)
+    kp_x, kp_y = kp_x.astype(np.float32), kp_y.astype(np.float32)
+    octave = np.minimum(rng.geometric(0.35, n_f) - 1, n_levels - 1).astype(np.int32)
+    angle = rng.uniform(0, 360, n_f).astype(np.float32)
+    u_right = np.where(rng.random(n_f) < (0.7 if stereo else 0.0), kp_x - rng.uniform(2, 40, n_f), -1.0).astype(np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(n_levels - 1, np.float32(1.2), np.float32)])).astype(np.float32)
+    min_x, min_y, max_x, max_y = np.float32(0), np.float32(0), np.float32(w), np.float32(h)
+    off, idx, gwi, ghi = build_grid(kp_x, kp_y, min_x, min_y, max_x, max_y)
+    state = (rng.random(n_f) < frac_with_mp).astype(np.uint8)
+    return dict(n_f=n_f, desc_f=synth_descriptors(rng, n_f), kp_x=kp_x, kp_y=kp_y, kp_octave=octave, kp_angle=angle,
+                u_right=u_right, scale_factors=sf, n_levels=n_levels, min_x=min_x, min_y=min_y, max_x=max_x, max_y=max_y,
+                grid_w_inv=gwi, grid_h_inv=ghi, grid_off=off, grid_idx=idx, f_mp_state=state)
+
+
+def _small_pose(rv, t):
+    th_ = np.linalg.norm(rv)
+    K = np.array([[0, -rv[2], rv[1]], [rv[2], 0, -rv[0]], [-rv[1], rv[0], 0]])
+    R = np.eye(3) + np.sin(th_) / th_ * K + (1 - np.cos(th_)) / th_ ** 2 * K @ K
+    return R, np.asarray(t, np.float64)
+
+
+def _points_for_view(rng, view, tgt, R, t, c, jitter=1.5):
+    """world points whose projection with (R, t) lands near the view's keypoints `tgt`, with scale-invariance
+    distances that predict the keypoint's octave (or one above), normals roughly facing the camera"""
+    n = len(tgt)
+    fx, fy, cx, cy = c["fx"], c["fy"], c["cx"], c["cy"]
+    z = rng.uniform(1.0, 15.0, n)
+    u = view["kp_x"][tgt] + rng.normal(0, jitter, n)
+    v = view["kp_y"][tgt] + rng.normal(0, jitter, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], axis=1)
+    Xw = (Xc - t) @ R
+    Ow = -R.T @ t
+    PO = Xw - Ow
+    dist = np.linalg.norm(PO, axis=1)
+    lvl = view["kp_octave"][tgt] + rng.uniform(-0.95, 0.95, n)
+    max_dist = dist * 1.2 ** lvl
+    min_dist = max_dist / 1.2 ** 7 * 0.8
+    far = rng.random(n) < 0.05
+    max_dist[far] *= 0.2                                   # out of the scale-invariance range
+    nrm = PO / dist[:, None] + rng.normal(0, 0.25, (n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    back = rng.random(n) < 0.08
+    nrm[back] *= -1                                        # viewed from behind (> 60 deg)
+    behind = rng.random(n) < 0.03
+    Xw[behind] = Ow + (Ow - Xw[behind])                    # negative depth
+    return Xw, max_dist, min_dist, nrm, Ow
+
+
+def synth_proj_gen_problem(seed: int, n_f: int = 1000, n_pts: int = 1500, cfg: str = "kitti", th: float = 3.0,
+                           stereo: bool = True):
+    """A keyframe / frame view + map points to project into it: the inputs of Fuse (src/ORBmatcher.cc:825-975,
+    :977-1100), SearchByProjection(KF, Scw) (:290-403) and SearchByProjection(F, KF) (:1472-1599)."""
+    rng = np.random.default_rng(11000 + seed)
+    c = CONFIGS[cfg]
+    w, h = c["w"], c["h"]
+    view = _view_from(rng, rng.uniform(20, w - 20, n_f), rng.uniform(20, h - 20, n_f), w, h, stereo=stereo)
+    R, t = _small_pose(np.array([0.02, -0.03, 0.01]), [0.3, -0.1, 0.2])
+    tgt = rng.integers(0, n_f, n_pts)
+    Xw, max_dist, min_dist, nrm, Ow = _points_for_view(rng, view, tgt, R, t, c)
+    desc = flip_bits(rng, view["desc_f"][tgt], 0.08)
+    rnd = rng.random(n_pts) < 0.2
+    desc[rnd] = synth_descriptors(rng, int(rnd.sum()))
+    q_angle = np.mod(view["kp_angle"][tgt] + rng.normal(15, 5, n_pts), 360).astype(np.float32)
+    odd = rng.random(n_pts) < 0.15
+    q_angle[odd] = rng.uniform(0, 360, int(odd.sum())).astype(np.float32)
+    sf = view["scale_factors"]
+    p = dict(n_pts=n_pts, valid=(rng.random(n_pts) < 0.85).astype(np.uint8), pos=Xw.astype(np.float32),
+             max_dist=max_dist.astype(np.float32), min_dist=min_dist.astype(np.float32), normal=nrm.astype(np.float32),
+             desc=desc, q_angle=q_angle, R=R.astype(np.float32).reshape(9), t=t.astype(np.float32),
+             Ow=Ow.astype(np.float32), R2=np.eye(3, dtype=np.float32).reshape(9), t2=np.zeros(3, np.float32),
+             fx=np.float32(c["fx"]), fy=np.float32(c["fy"]), cx=np.float32(c["cx"]), cy=np.float32(c["cy"]),
+             bf=np.float32(c["bf"]), log_scale_factor=np.float32(np.log(np.float32(1.2))),
+             inv_level_sigma2=(1.0 / (sf * sf)).astype(np.float32), th=np.float32(th))
+    return view, p
+
+
+def synth_sim3_problem(seed: int, n1: int = 1000, n2: int = 1000, cfg: str = "kitti", th: float = 7.5):
+    """Two keyframes related by a similarity for SearchBySim3 (src/ORBmatcher.cc:1102-1326): 50 % of the
+    features observe common 3-D points (so the two projections can agree), the rest is clutter."""
+    rng = np.random.default_rng(12000 + seed)
+    c = CONFIGS[cfg]
+    w, h, fx, fy, cx, cy = c["w"], c["h"], c["fx"], c["fy"], c["cx"], c["cy"]
+    R1w, t1w = _small_pose(np.array([0.01, 0.02, -0.01]), [0.1, 0.0, 0.05])
+    R2w, t2w = _small_pose(np.array([-0.02, 0.05, 0.01]), [-0.5, 0.05, 0.1])
+    s12 = 1.07
+    R12 = R1w @ R2w.T                                       # camera 2 -> camera 1 (up to the scale drift s12)
+    t12 = t1w - s12 * R12 @ t2w
+    sR12, sR21 = s12 * R12, (1.0 / s12) * R12.T
+    t21 = -sR21 @ t12
+    k = int(0.5 * min(n1, n2))
+    x1, y1 = rng.uniform(20, w - 20, n1), rng.uniform(20, h - 20, n1)
+    x2, y2 = rng.uniform(20, w - 20, n2), rng.uniform(20, h - 20, n2)
+    i1, i2 = rng.permutation(n1)[:k], rng.permutation(n2)[:k]
+    z = rng.uniform(3.0, 20.0, k)
+    c1 = np.stack([rng.uniform(-0.7, 0.7, k) * z, rng.uniform(-0.25, 0.25, k) * z, z], 1)   # camera-1 coordinates
+    c2 = (sR21 @ c1.T).T + t21
+    x1[i1], y1[i1] = fx * c1[:, 0] / c1[:, 2] + cx, fy * c1[:, 1] / c1[:, 2] + cy
+    x2[i2], y2[i2] = fx * c2[:, 0] / c2[:, 2] + cx, fy * c2[:, 1] / c2[:, 2] + cy
+    ok = (x1[i1] > 5) & (x1[i1] < w - 5) & (y1[i1] > 5) & (y1[i1] < h - 5) & (x2[i2] > 5) & (x2[i2] < w - 5) & \
+         (y2[i2] > 5) & (y2[i2] < h - 5) & (c2[:, 2] > 0.5)
+    x1[i1[~ok]], y1[i1[~ok]] = rng.uniform(20, w - 20, int((~ok).sum())), rng.uniform(20, h - 20, int((~ok).sum()))
+    x2[i2[~ok]], y2[i2[~ok]] = rng.uniform(20, w - 20, int((~ok).sum())), rng.uniform(20, h - 20, int((~ok).sum()))
+    f1, f2 = _view_from(rng, x1, y1, w, h), _view_from(rng, x2, y2, w, h)
+    f2["kp_octave"][i2] = f1["kp_octave"][i1]
+    lsf = np.float32(np.log(np.float32(1.2)))
+
+    def side(n, view, other_view, Rw, tw, R2_, t2_, mine, theirs, cam):
+        # map points of this keyframe: world position = back-projection of its own features
+        zz = rng.uniform(3.0, 20.0, n)
+        cc = np.stack([(view["kp_x"] - cx) / fx * zz, (view["kp_y"] - cy) / fy * zz, zz], 1)
+        cc[mine[ok]] = cam[ok]
+        Xw = (cc - tw) @ Rw
+        tgt_c = (R2_ @ cc.T).T + t2_                        # in the other camera
+        dist = np.linalg.norm(tgt_c, axis=1)
+        lvl = view["kp_octave"] + rng.uniform(-0.9, 0.9, n)
+        max_dist = dist * 1.2 ** lvl
+        desc = synth_descriptors(rng, n)
+        desc[mine[ok]] = flip_bits(rng, other_view["desc_f"][theirs[ok]], 0.07)
+        return dict(n_pts=n, valid=(rng.random(n) < 0.9).astype(np.uint8), pos=Xw.astype(np.float32),
+                    max_dist=max_dist.astype(np.float32), min_dist=(max_dist / 1.2 ** 7 * 0.8).astype(np.float32),
+                    normal=np.zeros((n, 3), np.float32), desc=desc, q_angle=np.zeros(n, np.float32),
+                    R=Rw.astype(np.float32).reshape(9), t=tw.astype(np.float32), Ow=np.zeros(3, np.float32),
+                    R2=R2_.astype(np.float32).reshape(9), t2=t2_.astype(np.float32), fx=np.float32(fx), fy=np.float32(fy),
+                    cx=np.float32(cx), cy=np.float32(cy), bf=np.float32(c["bf"]), log_scale_factor=lsf,
+                    inv_level_sigma2=(1.0 / (view["scale_factors"] ** 2)).astype(np.float32), th=np.float32(th))
+
+    p12 = side(n1, f1, f2, R1w, t1w, sR21, t21, i1, i2, c1)
+    p21 = side(n2, f2, f1, R2w, t2w, sR12, t12, i2, i1, c2)
+    return f1, f2, p12, p21
+
+
 def synth_proj_mp_problem(seed: int, n_f: int = 1000, n_mp: int = 1500, w: int = 640, h: int = 480,
                           th: float = 3.0, nnratio: float = 0.8):
     """Frame + local map points with planted projections (SearchByProjection(F, vpMP, th))."""

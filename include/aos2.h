@@ -383,6 +383,63 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
                                            const aos2_proj_last_t *p, float th, int mono,
                                            int32_t *match_f, int32_t *nmatches);
 
+/* Projection family: a set of map points projected into a keyframe / frame (aos2_frame_view_t; for a
+ * KeyFrame the view carries mvKeysUn, mvuRight, mDescriptors, mGrid, mnMin/Max*, mvScaleFactors; f_mp_state
+ * is used by the two greedy searches only).  Rotations are row-major 3x3.  The few cv::Mat lines that
+ * decompose Scw or build sR12 / sR21 / t21 (:299-304, :986-991, :1116-1120) stay in the caller: R, t, Ow
+ * (and R2, t2) are inputs, so no OpenCV rounding behaviour is guessed on the device. */
+typedef struct {
+    int32_t n_pts;
+    const uint8_t *valid;            /* the per-point gate of the reference loop head, see each function */
+    const float *pos;                /* 3 per point: GetWorldPos() */
+    const float *max_dist, *min_dist;   /* GetMax/MinDistanceInvariance() */
+    const float *normal;             /* 3 per point: GetNormal() (unused by SearchBySim3 and the reloc search) */
+    const uint8_t *desc;             /* 32 per point: GetDescriptor() */
+    const float *q_angle;            /* reloc search only: pKF->mvKeysUn[i].angle */
+    float R[9], t[3], Ow[3];         /* Rcw, tcw, camera centre */
+    float R2[9], t2[3];              /* SearchBySim3 only: sR21, t21 (KF1 -> KF2) or sR12, t12 */
+    float fx, fy, cx, cy, bf;        /* bf: Fuse(pKF, vpMapPoints) only (ur = u - bf*invz, :870) */
+    float log_scale_factor;          /* mfLogScaleFactor of the target (MapPoint::PredictScale) */
+    const float *inv_level_sigma2;   /* mvInvLevelSigma2 of the target, Fuse(pKF, vpMapPoints) only */
+    float th;
+} aos2_proj_points_t;
+
+/* The search part of int ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th)  :825-975  (sim3 = 0,
+ * valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF)) and of Fuse(KeyFrame*, cv::Mat Scw,
+ * vpPoints, th, vpReplacePoint)  :977-1100 (sim3 = 1, valid[i] = !isBad() && !spAlreadyFound.count(pMP)).
+ * best_idx[i] = the keyframe feature the point fuses with (bestDist <= TH_LOW), -1 otherwise;
+ * best_dist[i] its distance; *n_fused = the count.  The Replace / AddObservation / vpReplacePoint
+ * bookkeeping of :950-969 / :1079-1093 consumes best_idx on the host (it only reads map state). */
+int aos2_matcher_fuse(aos2_matcher_t *m, const aos2_frame_view_t *kf, const aos2_proj_points_t *p,
+                      int sim3, int32_t *best_idx, int32_t *best_dist, int32_t *n_fused);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*> &vpPoints,
+ *         vector<MapPoint*> &vpMatched, int th)  :290-403.  valid[i] = !isBad() && !spAlreadyFound.count;
+ * kf->f_mp_state[idx] != 0 <=> vpMatched[idx] != NULL on entry.  match_f[idx] = index of the point
+ * written to vpMatched[idx], -1 = unchanged. */
+int aos2_matcher_search_by_projection_kf(aos2_matcher_t *m, const aos2_frame_view_t *kf,
+                                         const aos2_proj_points_t *p, int32_t *match_f,
+                                         int32_t *nmatches);
+
+/* int ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  :1102-1326.
+ * p12: one entry per KF1 feature (valid = pMP && !vbAlreadyMatched1[i] && !isBad(); R, t = R1w, t1w;
+ * R2, t2 = sR21, t21), projected into kf2; p21 the converse (R2w, t2w; sR12, t12) into kf1.
+ * match12[i1] = KF2 feature index whose map point becomes vpMatches12[i1], -1 = unchanged. */
+int aos2_matcher_search_by_sim3(aos2_matcher_t *m, const aos2_frame_view_t *kf1,
+                                const aos2_frame_view_t *kf2, const aos2_proj_points_t *p12,
+                                const aos2_proj_points_t *p21, int32_t *match12, int32_t *n_found);
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*>
+ *         &sAlreadyFound, const float th, const int ORBdist)  :1472-1599 (relocalisation).
+ * Points = pKF->GetMapPointMatches() (valid = pMP && !isBad() && !sAlreadyFound.count(pMP));
+ * frame->f_mp_state[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL on entry.
+ * match_f[i2]: keyframe feature index whose map point is assigned, -1 unchanged, -2 reset to NULL by the
+ * rotation check. */
+int aos2_matcher_search_by_projection_reloc(aos2_matcher_t *m, const aos2_frame_view_t *frame,
+                                            const aos2_proj_points_t *p, int orb_dist,
+                                            int32_t *match_f, int32_t *nmatches);
+
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer::LocalBundleAdjustment  (include/Optimizer.h:45, src/Optimizer.cc:454-779)
  * The C++ shim gathers the local window from the KeyFrame/MapPoint pointer graph (:457-505)

@@ -67,6 +67,11 @@ def lib():
         L.orc_search_by_projection_last.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_fuse.argtypes = [C.c_void_p] * 4
+        L.orc_fuse_sim3.argtypes = [C.c_void_p] * 4
+        L.orc_search_by_projection_kf.argtypes = [C.c_void_p] * 3
+        L.orc_search_by_sim3.argtypes = [C.c_void_p] * 5
+        L.orc_search_by_projection_reloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_compute_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_compute_distinctive_descriptors.restype = None
@@ -344,6 +349,57 @@ def search_by_projection_last(cur: dict, p: dict):
 
 
 # ---------------------------------------------------------------------------- local BA
+class _ProjGen(C.Structure):
+    _fields_ = [("n_pts", C.c_int), ("valid", C.c_void_p), ("pos", C.c_void_p), ("max_dist", C.c_void_p),
+                ("min_dist", C.c_void_p), ("normal", C.c_void_p), ("desc", C.c_void_p), ("q_angle", C.c_void_p),
+                ("R", C.c_float * 9), ("t", C.c_float * 3), ("Ow", C.c_float * 3), ("R2", C.c_float * 9),
+                ("t2", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float), ("log_scale_factor", C.c_float), ("inv_level_sigma2", C.c_void_p), ("th", C.c_float)]
+
+
+def _proj_gen(p, keep):
+    s = _ProjGen()
+    _fill(s, p, keep)
+    return s
+
+
+def fuse(f: dict, p: dict, sim3=False):
+    """Fuse search part (src/ORBmatcher.cc:825-975; sim3=True: :977-1100) -> (nFused, best_idx, best_dist)"""
+    keep = []
+    fv, pg = _frame_view(f, keep), _proj_gen(p, keep)
+    bi, bd = np.zeros(max(p["n_pts"], 1), np.int32), np.zeros(max(p["n_pts"], 1), np.int32)
+    fn = lib().orc_fuse_sim3 if sim3 else lib().orc_fuse
+    n = fn(C.byref(fv), C.byref(pg), _p(bi), _p(bd))
+    return n, bi[: p["n_pts"]], bd[: p["n_pts"]]
+
+
+def search_by_projection_kf(f: dict, p: dict):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) src/ORBmatcher.cc:290-403 -> (nmatches, match_f)"""
+    keep = []
+    fv, pg = _frame_view(f, keep), _proj_gen(p, keep)
+    m = np.zeros(max(f["n_f"], 1), np.int32)
+    n = lib().orc_search_by_projection_kf(C.byref(fv), C.byref(pg), _p(m))
+    return n, m[: f["n_f"]]
+
+
+def search_by_sim3(f1: dict, f2: dict, p12: dict, p21: dict):
+    """SearchBySim3 src/ORBmatcher.cc:1102-1326 -> (nFound, match12)"""
+    keep = []
+    a, b, c, d = _frame_view(f1, keep), _frame_view(f2, keep), _proj_gen(p12, keep), _proj_gen(p21, keep)
+    m = np.zeros(max(p12["n_pts"], 1), np.int32)
+    n = lib().orc_search_by_sim3(C.byref(a), C.byref(b), C.byref(c), C.byref(d), _p(m))
+    return n, m[: p12["n_pts"]]
+
+
+def search_by_projection_reloc(f: dict, p: dict, orb_dist=100, check_orientation=True):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) src/ORBmatcher.cc:1472-1599"""
+    keep = []
+    fv, pg = _frame_view(f, keep), _proj_gen(p, keep)
+    m = np.zeros(max(f["n_f"], 1), np.int32)
+    n = lib().orc_search_by_projection_reloc(C.byref(fv), C.byref(pg), int(orb_dist), int(check_orientation), _p(m))
+    return n, m[: f["n_f"]]
+
+
 class _BowKfProblem(C.Structure):
     _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("desc1", C.c_void_p), ("desc2", C.c_void_p),
                 ("has_mp1", C.c_void_p), ("has_mp2", C.c_void_p), ("angle1", C.c_void_p), ("angle2", C.c_void_p),

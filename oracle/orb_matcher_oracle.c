@@ -632,3 +632,318 @@ void orc_compute_distinctive_descriptors(int n_points, const int32_t *off, const
         free(row);
     }
 }
+
+/* ------------------------------------------------------------------ projection family (rank 4)
+ * cv::Mat arithmetic conventions (OpenCV 3.2, non-IPP), same as the SearchByProjection restatement above:
+ *   R*p + t          3x3 * 3x1 CV_32F, no transpose flag: the small-matrix path, float products summed left
+ *                    to right in float, then a float add of t;
+ *   cv::norm(v)      sqrt of a double sum of (double)v_i^2, returned as double, stored in a float;
+ *   a.dot(b)         double sum of (double)a_i * (double)b_i;
+ *   log(ratio)       std::log(float); convention 4: the correctly rounded float logarithm,
+ *                    evaluated as (float)log((double)ratio). */
+static void xform(const float *R, const float *t, const float *p, float *out)
+{
+    for (int r = 0; r < 3; ++r) {
+        float s = R[r * 3 + 0] * p[0] + R[r * 3 + 1] * p[1] + R[r * 3 + 2] * p[2];
+        out[r] = s + t[r];
+    }
+}
+static float norm3(const float *v)
+{
+    double s = (double)v[0] * (double)v[0] + (double)v[1] * (double)v[1] + (double)v[2] * (double)v[2];
+    return (float)sqrt(s);
+}
+/* MapPoint::PredictScale(currentDist, pKF / pF) src/MapPoint.cc:427-459 */
+static int predict_scale(float max_dist, float dist, float log_scale_factor, int n_levels)
+{
+    const float ratio = max_dist / dist;
+    const float lg = (float)log((double)ratio);
+    int nScale = (int)ceilf(lg / log_scale_factor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= n_levels) nScale = n_levels - 1;
+    return nScale;
+}
+
+/* Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) :825-975, the search part: for every map
+ * point the KF feature it would be fused with (best_idx, -1 = none) and the distance.  valid[i] stands for
+ * `pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF)`; what happens to the pair (:950-969) is host state. */
+int orc_fuse(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *best_idx, int32_t *best_dist)
+{
+    int nFused = 0;
+    int *vIndices = (int *)malloc(sizeof(int) * (f->n_f ? f->n_f : 1));
+    for (int i = 0; i < p->n_pts; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!p->valid[i]) continue;
+        const float *p3Dw = p->pos + 3 * (size_t)i;
+        float p3Dc[3];
+        xform(p->R, p->t, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = p->fx * x + p->cx;
+        const float v = p->fy * y + p->cy;
+        if (!(u >= f->min_x && u < f->max_x && v >= f->min_y && v < f->max_y)) continue; /* KeyFrame::IsInImage */
+        const float ur = u - p->bf * invz;
+        float PO[3] = {p3Dw[0] - p->Ow[0], p3Dw[1] - p->Ow[1], p3Dw[2] - p->Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        const float *Pn = p->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
+        if (dot < 0.5 * dist3D) continue;
+        const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
+        const float radius = p->th * f->scale_factors[nPredictedLevel];
+        const int nInd = features_in_area(f, u, v, radius, -1, -1, vIndices);
+        if (nInd == 0) continue;
+        const uint8_t *dMP = p->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int idx = vIndices[k];
+            const int kpLevel = f->kp_octave[idx];
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (f->u_right[idx] >= 0) {
+                const float ex = u - f->kp_x[idx], ey = v - f->kp_y[idx], er = ur - f->u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * p->inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - f->kp_x[idx], ey = v - f->kp_y[idx];
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * p->inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(dMP, f->desc_f + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            best_idx[i] = bestIdx;
+            best_dist[i] = bestDist;
+            nFused++;
+        }
+    }
+    free(vIndices);
+    return nFused;
+}
+
+/* shared body of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) :977-1100 and
+ * SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) :290-403.  R, t, Ow = Rcw, tcw, Ow of :986-991 /
+ * :299-304 (host cv::Mat arithmetic on Scw, taken as input).  taken == NULL: the Fuse flavour (independent
+ * points, best_idx per point); taken != NULL: the SearchByProjection flavour (vpMatched, updated in place,
+ * match_f[idx] = point index). */
+static int proj_sim3_kf(const orc_frame_view_t *f, const orc_proj_gen_t *p, int invz_double, uint8_t *taken,
+                        int32_t *best_idx, int32_t *best_dist, int32_t *match_f)
+{
+    int n = 0;
+    int *vIndices = (int *)malloc(sizeof(int) * (f->n_f ? f->n_f : 1));
+    for (int i = 0; i < p->n_pts; i++) {
+        if (best_idx) {
+            best_idx[i] = -1;
+            best_dist[i] = 256;
+        }
+        if (!p->valid[i]) continue;
+        const float *p3Dw = p->pos + 3 * (size_t)i;
+        float p3Dc[3];
+        xform(p->R, p->t, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = invz_double ? (float)(1.0 / p3Dc[2]) : 1 / p3Dc[2]; /* :1026 `1.0/z`, :329 `1/z` */
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = p->fx * x + p->cx;
+        const float v = p->fy * y + p->cy;
+        if (!(u >= f->min_x && u < f->max_x && v >= f->min_y && v < f->max_y)) continue;
+        float PO[3] = {p3Dw[0] - p->Ow[0], p3Dw[1] - p->Ow[1], p3Dw[2] - p->Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        const float *Pn = p->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
+        if (dot < 0.5 * dist3D) continue;
+        const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
+        const float radius = p->th * f->scale_factors[nPredictedLevel];
+        const int nInd = features_in_area(f, u, v, radius, -1, -1, vIndices);
+        if (nInd == 0) continue;
+        const uint8_t *dMP = p->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1; /* :1063 starts at INT_MAX; no distance exceeds 256 */
+        for (int k = 0; k < nInd; ++k) {
+            const int idx = vIndices[k];
+            if (taken && taken[idx]) continue; /* vpMatched[idx] :374 */
+            const int kpLevel = f->kp_octave[idx];
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(dMP, f->desc_f + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (taken) {
+                taken[bestIdx] = 1;
+                match_f[bestIdx] = i;
+            } else {
+                best_idx[i] = bestIdx;
+                best_dist[i] = bestDist;
+            }
+            n++;
+        }
+    }
+    free(vIndices);
+    return n;
+}
+int orc_fuse_sim3(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *best_idx, int32_t *best_dist)
+{
+    return proj_sim3_kf(f, p, 1, NULL, best_idx, best_dist, NULL);
+}
+/* f->f_mp_state[idx] != 0 <=> vpMatched[idx] != NULL on entry; match_f[n_f] = index of the point newly
+ * written to vpMatched[idx], or -1 */
+int orc_search_by_projection_kf(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *match_f)
+{
+    uint8_t *taken = (uint8_t *)malloc(f->n_f ? f->n_f : 1);
+    for (int i = 0; i < f->n_f; ++i) {
+        taken[i] = f->f_mp_state[i] != 0;
+        match_f[i] = -1;
+    }
+    const int n = proj_sim3_kf(f, p, 0, taken, NULL, NULL, match_f);
+    free(taken);
+    return n;
+}
+
+/* one direction of SearchBySim3 (:1148-1225 / :1228-1303): points of one keyframe into the other.
+ * R, t = R1w, t1w (camera of the source keyframe from world); R2, t2 = sR21, t21 (or sR12, t12). */
+static void sim3_direction(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *vnMatch)
+{
+    int *vIndices = (int *)malloc(sizeof(int) * (f->n_f ? f->n_f : 1));
+    for (int i = 0; i < p->n_pts; i++) {
+        vnMatch[i] = -1;
+        if (!p->valid[i]) continue;
+        float c1[3], c2[3];
+        xform(p->R, p->t, p->pos + 3 * (size_t)i, c1);
+        xform(p->R2, p->t2, c1, c2);
+        if (c2[2] < 0.0f) continue;
+        const float invz = (float)(1.0 / c2[2]);
+        const float x = c2[0] * invz;
+        const float y = c2[1] * invz;
+        const float u = p->fx * x + p->cx;
+        const float v = p->fy * y + p->cy;
+        if (!(u >= f->min_x && u < f->max_x && v >= f->min_y && v < f->max_y)) continue;
+        const float dist3D = norm3(c2);
+        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
+        const float radius = p->th * f->scale_factors[nPredictedLevel];
+        const int nInd = features_in_area(f, u, v, radius, -1, -1, vIndices);
+        if (nInd == 0) continue;
+        const uint8_t *dMP = p->desc + (size_t)i * 32;
+        int bestDist = 2147483647, bestIdx = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int idx = vIndices[k];
+            if (f->kp_octave[idx] < nPredictedLevel - 1 || f->kp_octave[idx] > nPredictedLevel) continue;
+            const int dist = orc_descriptor_distance(dMP, f->desc_f + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+    }
+    free(vIndices);
+}
+/* SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) :1102-1326.  p12: the map points of KF1 (one per
+ * KF1 feature, valid = pMP && !vbAlreadyMatched1 && !isBad) projected into KF2 (view f2); p21 the converse.
+ * match12[n1] = index of the KF2 feature whose map point becomes vpMatches12[i1], or -1 (unchanged). */
+int orc_search_by_sim3(const orc_frame_view_t *f1, const orc_frame_view_t *f2, const orc_proj_gen_t *p12,
+                       const orc_proj_gen_t *p21, int32_t *match12)
+{
+    int32_t *vn1 = (int32_t *)malloc(sizeof(int32_t) * (p12->n_pts ? p12->n_pts : 1));
+    int32_t *vn2 = (int32_t *)malloc(sizeof(int32_t) * (p21->n_pts ? p21->n_pts : 1));
+    sim3_direction(f2, p12, vn1);
+    sim3_direction(f1, p21, vn2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < p12->n_pts; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vn1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vn2[idx2];
+            if (idx1 == i1) {
+                match12[i1] = idx2;
+                nFound++;
+            }
+        }
+    }
+    free(vn1);
+    free(vn2);
+    return nFound;
+}
+
+/* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) :1472-1599.
+ * points = pKF's map points (valid = pMP && !isBad && !sAlreadyFound.count), q_angle = pKF->mvKeysUn[i].angle;
+ * f_mp_state[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL on entry.
+ * match_f[n_f]: keyframe feature index newly assigned to frame feature i2, -1 unchanged, -2 reset to NULL by
+ * the rotation cull (:1583-1594, which also clears a slot that was already non-NULL? no: only pushed i2). */
+int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen_t *p, int orb_dist, int check_orientation,
+                                   int32_t *match_f)
+{
+    int nmatches = 0;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    uint8_t *taken = (uint8_t *)malloc(f->n_f ? f->n_f : 1);
+    for (int i = 0; i < f->n_f; ++i) {
+        taken[i] = f->f_mp_state[i] != 0;
+        match_f[i] = -1;
+    }
+    int *vIndices2 = (int *)malloc(sizeof(int) * (f->n_f ? f->n_f : 1));
+    for (int i = 0; i < p->n_pts; i++) {
+        if (!p->valid[i]) continue;
+        const float *x3Dw = p->pos + 3 * (size_t)i;
+        float x3Dc[3];
+        xform(p->R, p->t, x3Dw, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        const float u = p->fx * xc * invzc + p->cx;
+        const float v = p->fy * yc * invzc + p->cy;
+        if (u < f->min_x || u > f->max_x) continue;
+        if (v < f->min_y || v > f->max_y) continue;
+        float PO[3] = {x3Dw[0] - p->Ow[0], x3Dw[1] - p->Ow[1], x3Dw[2] - p->Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
+        const float radius = p->th * f->scale_factors[nPredictedLevel];
+        const int nInd = features_in_area(f, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+        if (nInd == 0) continue;
+        const uint8_t *dMP = p->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int i2 = vIndices2[k];
+            if (taken[i2]) continue;
+            const int dist = orc_descriptor_distance(dMP, f->desc_f + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= orb_dist) {
+            taken[bestIdx2] = 1;
+            match_f[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = p->q_angle[i] - f->kp_angle[bestIdx2];
+                iv_push(&rotHist[rot_bin(rot)], bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (int j = 0; j < rotHist[i].n; j++) {
+                    match_f[rotHist[i].v[j]] = -2;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    free(taken);
+    free(vIndices2);
+    return nmatches;
+}

@@ -186,6 +186,30 @@ typedef struct {
 int orc_search_for_triangulation(const orc_triang_problem_t *p, int32_t *match12);
 void orc_compute_distinctive_descriptors(int n_points, const int32_t *off, const uint8_t *desc, int32_t *best);
 
+/* projection family: a set of map points projected into a keyframe / frame (orc_frame_view_t) */
+typedef struct {
+    int n_pts;
+    const uint8_t *valid;          /* per-point static gate, see each function */
+    const float *pos;              /* 3 per point: GetWorldPos() */
+    const float *max_dist, *min_dist;  /* GetMax/MinDistanceInvariance() */
+    const float *normal;           /* 3 per point: GetNormal() (Fuse, SearchByProjection(KF,Scw)) */
+    const uint8_t *desc;           /* 32 per point: GetDescriptor() */
+    const float *q_angle;          /* SearchByProjection(F,KF): pKF->mvKeysUn[i].angle */
+    float R[9], t[3], Ow[3];       /* camera rotation / translation (row-major) and centre */
+    float R2[9], t2[3];            /* SearchBySim3: sR21, t21 (or sR12, t12) */
+    float fx, fy, cx, cy, bf;
+    float log_scale_factor;        /* mfLogScaleFactor of the target */
+    const float *inv_level_sigma2; /* mvInvLevelSigma2 of the target (Fuse) */
+    float th;
+} orc_proj_gen_t;
+int orc_fuse(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *best_idx, int32_t *best_dist);
+int orc_fuse_sim3(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *best_idx, int32_t *best_dist);
+int orc_search_by_projection_kf(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *match_f);
+int orc_search_by_sim3(const orc_frame_view_t *f1, const orc_frame_view_t *f2, const orc_proj_gen_t *p12,
+                       const orc_proj_gen_t *p21, int32_t *match12);
+int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen_t *p, int orb_dist,
+                                   int check_orientation, int32_t *match_f);
+
 /* ---- Frame::ComputeStereoMatches src/Frame.cc:495-669 ---- */
 typedef struct {
     int n_left, n_right;

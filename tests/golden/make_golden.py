@@ -101,3 +101,10 @@ n, m = O.search_for_triangulation(p)
 np.savez_compressed(os.path.join(OUT, "triang_300.npz"), nmatches=n, match=m, **p)
 off, desc = S.synth_observations(26, 200, 16)
 np.savez_compressed(os.path.join(OUT, "distinctive_200.npz"), off=off, desc=desc, best=O.compute_distinctive_descriptors(off, desc))
+f, p = S.synth_proj_gen_problem(41, n_f=400, n_pts=500)
+n, bi, bd = O.fuse(f, p)
+np.savez_compressed(os.path.join(OUT, "fuse_400.npz"), n=n, best_idx=bi, best_dist=bd, **{"f_" + k: v for k, v in f.items()},
+                    **{"p_" + k: v for k, v in p.items()})
+n, m = O.search_by_projection_reloc(f, p, 100, True)
+np.savez_compressed(os.path.join(OUT, "reloc_400.npz"), n=n, match=m, **{"f_" + k: v for k, v in f.items()},
+                    **{"p_" + k: v for k, v in p.items()})

@@ -165,3 +165,70 @@ def test_compute_distinctive_descriptors_vs_oracle(pkg, oracle, gpu):
     desc[5] = 255
     assert m.ComputeDistinctiveDescriptors(off, desc).tolist() == [0, 0, 0, -1]
     assert len(m.ComputeDistinctiveDescriptors(np.zeros(1, np.int32), np.zeros((0, 32), np.uint8))) == 0
+
+
+def test_fuse_vs_oracle(pkg, oracle, gpu):
+    """search part of Fuse(pKF, vpMapPoints, th) :825-975 and Fuse(pKF, Scw, ...) :977-1100"""
+    S = pkg.synth
+    m = pkg.Matcher()
+    tot = 0
+    for seed, cfg, th, stereo in ((0, "kitti", 3.0, True), (1, "tum", 3.0, True), (2, "euroc", 4.0, False), (3, "kitti", 2.5, True)):
+        f, p = S.synth_proj_gen_problem(seed, n_f=1000 + 200 * seed, n_pts=1500 + 300 * seed, cfg=cfg, th=th, stereo=stereo)
+        for sim3 in (False, True):
+            n, bi, bd = m.Fuse(f, p, sim3=sim3)
+            on, obi, obd = oracle.fuse(f, p, sim3=sim3)
+            assert n == on and (bi == obi).all() and (bd == obd).all()
+            tot += n
+            # every fused pair respects the gates: TH_LOW, level window
+            k = np.flatnonzero(bi >= 0)
+            assert (bd[k] <= 50).all() and p["valid"][k].all()
+    assert tot > 1000
+    f, p = S.synth_proj_gen_problem(9, n_f=300, n_pts=0)
+    assert m.Fuse(f, p)[0] == 0
+    g = np.load(os.path.join(GOLD, "fuse_400.npz"))
+    f = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    p = {k[2:]: g[k] for k in g.files if k.startswith("p_")}
+    f["n_f"], f["n_levels"], p["n_pts"] = int(f["n_f"]), int(f["n_levels"]), int(p["n_pts"])
+    n, bi, bd = m.Fuse(f, p)
+    assert n == int(g["n"]) and (bi == g["best_idx"]).all() and (bd == g["best_dist"]).all()
+
+
+def test_search_by_projection_kf_and_reloc_vs_oracle(pkg, oracle, gpu):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) :290-403 and the relocalisation search :1472-1599"""
+    S = pkg.synth
+    for seed in range(5):
+        f, p = S.synth_proj_gen_problem(20 + seed, n_f=900 + 150 * seed, n_pts=1400, cfg=("kitti", "tum")[seed % 2], th=[10, 4, 7][seed % 3])
+        m = pkg.Matcher()
+        n, match = m.SearchByProjectionKF(f, p)
+        on, om = oracle.search_by_projection_kf(f, p)
+        assert n == on and (match == om).all() and n > 200
+        assert not f["f_mp_state"][match >= 0].any()       # slots that were taken on entry stay untouched
+        for ori in (True, False):
+            for orb_dist in (100, 64):
+                mm = pkg.Matcher(0.9, ori)
+                n, match = mm.SearchByProjectionReloc(f, p, orb_dist)
+                on, om = oracle.search_by_projection_reloc(f, p, orb_dist, ori)
+                assert n == on and (match == om).all()
+                assert n == (match >= 0).sum() and (ori or (match != -2).all())
+    g = np.load(os.path.join(GOLD, "reloc_400.npz"))
+    f = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    p = {k[2:]: g[k] for k in g.files if k.startswith("p_")}
+    f["n_f"], f["n_levels"], p["n_pts"] = int(f["n_f"]), int(f["n_levels"]), int(p["n_pts"])
+    n, match = pkg.Matcher(0.9, True).SearchByProjectionReloc(f, p, 100)
+    assert n == int(g["n"]) and (match == g["match"]).all()
+
+
+def test_search_by_sim3_vs_oracle(pkg, oracle, gpu):
+    """SearchBySim3 :1102-1326"""
+    S = pkg.synth
+    m = pkg.Matcher()
+    tot = 0
+    for seed in range(5):
+        f1, f2, p12, p21 = S.synth_sim3_problem(seed, 900 + 100 * seed, 1000 - 50 * seed, cfg=("kitti", "euroc")[seed % 2])
+        n, match = m.SearchBySim3(f1, f2, p12, p21)
+        on, om = oracle.search_by_sim3(f1, f2, p12, p21)
+        assert n == on and (match == om).all() and n == (match >= 0).sum()
+        tot += n
+        k = np.flatnonzero(match >= 0)
+        assert len(set(match[k].tolist())) == len(k)       # mutual agreement makes the assignment injective
+    assert tot > 500

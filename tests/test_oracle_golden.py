@@ -378,3 +378,63 @@ def test_rank4_matcher_golden_and_known_answers(oracle, pkg):
         D = np.unpackbits(d[:, None, :] ^ d[None, :, :], axis=2).sum(2)
         med = np.sort(D, axis=1)[:, int(0.5 * (len(d) - 1))]
         assert best[pt] == int(np.argmin(med))
+
+
+def _gold_fp(name):
+    g = np.load(os.path.join(GOLD, name))
+    f = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    p = {k[2:]: g[k] for k in g.files if k.startswith("p_")}
+    f["n_f"], f["n_levels"], p["n_pts"] = int(f["n_f"]), int(f["n_levels"]), int(p["n_pts"])
+    return g, f, p
+
+
+def test_projection_family_golden_and_numpy_restatement(oracle, pkg):
+    """Fuse :825-975 / :977-1100, SearchByProjection(KF,Scw) :290-403, reloc search :1472-1599, SearchBySim3 :1102-1326"""
+    g, f, p = _gold_fp("fuse_400.npz")
+    n, bi, bd = oracle.fuse(f, p)
+    assert n == int(g["n"]) and (bi == g["best_idx"]).all() and (bd == g["best_dist"]).all()
+    g2, f2, p2 = _gold_fp("reloc_400.npz")
+    n2, m2 = oracle.search_by_projection_reloc(f2, p2, 100, True)
+    assert n2 == int(g2["n"]) and (m2 == g2["match"]).all() and (m2 == -2).sum() > 0
+    # independent float64 numpy restatement of Fuse's per-point search (agreement except at float boundaries)
+    R, t, Ow = p["R"].reshape(3, 3).astype(np.float64), p["t"].astype(np.float64), p["Ow"].astype(np.float64)
+    sf, isig = f["scale_factors"].astype(np.float64), p["inv_level_sigma2"].astype(np.float64)
+    bits_f = np.unpackbits(f["desc_f"], axis=1)
+    agree = 0
+    for i in range(p["n_pts"]):
+        exp = -1
+        X = p["pos"][i].astype(np.float64)
+        pc = R @ X + t
+        if p["valid"][i] and pc[2] >= 0:
+            u, v = p["fx"] * pc[0] / pc[2] + p["cx"], p["fy"] * pc[1] / pc[2] + p["cy"]
+            ur = u - p["bf"] / pc[2]
+            PO = X - Ow
+            d = np.linalg.norm(PO)
+            if (f["min_x"] <= u < f["max_x"] and f["min_y"] <= v < f["max_y"] and p["min_dist"][i] <= d <= p["max_dist"][i]
+                    and PO @ p["normal"][i] >= 0.5 * d):
+                lvl = int(min(max(np.ceil(np.log(p["max_dist"][i] / d) / p["log_scale_factor"]), 0), f["n_levels"] - 1))
+                r = p["th"] * sf[lvl]
+                cand = np.flatnonzero((np.abs(f["kp_x"] - u) < r) & (np.abs(f["kp_y"] - v) < r) &
+                                      (f["kp_octave"] >= lvl - 1) & (f["kp_octave"] <= lvl))
+                e2 = (u - f["kp_x"][cand]) ** 2 + (v - f["kp_y"][cand]) ** 2
+                st = f["u_right"][cand] >= 0
+                e2 = e2 + np.where(st, (ur - f["u_right"][cand]) ** 2, 0.0)
+                cand = cand[e2 * isig[f["kp_octave"][cand]] <= np.where(st, 7.8, 5.99)]
+                if len(cand):
+                    dist = (bits_f[cand] != np.unpackbits(p["desc"][i])[None, :]).sum(1)
+                    if dist.min() <= 50:
+                        exp = -2 if (dist == dist.min()).sum() > 1 else int(cand[dist.argmin()])   # ties: order-dependent
+        agree += exp == -2 or exp == bi[i]
+    assert agree >= 0.99 * p["n_pts"]
+    # the Sim3 flavour drops the chi2 gates: a superset of fusions; the greedy KF search respects vpMatched
+    ns, bis, _ = oracle.fuse(f, p, sim3=True)
+    assert ns >= n
+    nk, mk = oracle.search_by_projection_kf(f, p)
+    assert nk == (mk >= 0).sum() and not f["f_mp_state"][mk >= 0].any()
+    f1, f2_, p12, p21 = pkg.synth.synth_sim3_problem(3, 400, 420)
+    n3, m3 = oracle.search_by_sim3(f1, f2_, p12, p21)
+    k = np.flatnonzero(m3 >= 0)
+    assert n3 == len(k) > 50 and len(set(m3[k].tolist())) == len(k)
+    # planted correspondences dominate: the matched KF2 feature's descriptor is close to the KF1 point's
+    d = np.unpackbits(p12["desc"][k] ^ f2_["desc_f"][m3[k]], axis=1).sum(1)
+    assert (d <= 100).all() and np.median(d) < 40
