@@ -6,6 +6,7 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "aos2_types.h"
@@ -63,6 +64,89 @@ public:
         check(aos2_matcher_search_by_bow(h_, &pair, 1, &out, &n));
         vpMapPointMatches.resize(pair.n_f);
         return n;
+    }
+
+    // SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12)  (:522-655)
+    // vpMatches12[i] = index of the KF2 feature whose MapPoint is matched to KF1 feature i, or -1
+    int SearchByBoW(const aos2_bow_kf_pair_t &pair, std::vector<int32_t> &vpMatches12)
+    {
+        vpMatches12.assign(pair.n1 > 0 ? pair.n1 : 1, -1);
+        int32_t n = 0;
+        int32_t *out = vpMatches12.data();
+        check(aos2_matcher_search_by_bow_kf(h_, &pair, 1, &out, &n));
+        vpMatches12.resize(pair.n1);
+        return n;
+    }
+
+    // SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  (:657-823); F12 and the epipole
+    // travel inside `pair`
+    int SearchForTriangulation(const aos2_triang_pair_t &pair, std::vector<std::pair<size_t, size_t>> &vMatchedPairs,
+                               const bool bOnlyStereo)
+    {
+        std::vector<int32_t> m12(pair.n1 > 0 ? pair.n1 : 1, -1);
+        int32_t n = 0;
+        int32_t *out = m12.data();
+        check(aos2_matcher_search_for_triangulation(h_, &pair, 1, bOnlyStereo ? 1 : 0, &out, &n));
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(n > 0 ? n : 0);
+        for (int i = 0; i < pair.n1; ++i)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));  // :811-820
+        return n;
+    }
+
+    // search part of Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) (:825-975, sim3 = false) and of
+    // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:977-1100, sim3 = true): bestIdx[i] = feature to fuse with or -1
+    int Fuse(const aos2_frame_view_t &pKF, const aos2_proj_points_t &vpMapPoints, std::vector<int32_t> &bestIdx,
+             std::vector<int32_t> &bestDist, bool sim3 = false)
+    {
+        bestIdx.assign(vpMapPoints.n_pts > 0 ? vpMapPoints.n_pts : 1, -1);
+        bestDist.assign(bestIdx.size(), 256);
+        int32_t n = 0;
+        check(aos2_matcher_fuse(h_, &pKF, &vpMapPoints, sim3 ? 1 : 0, bestIdx.data(), bestDist.data(), &n));
+        bestIdx.resize(vpMapPoints.n_pts);
+        bestDist.resize(vpMapPoints.n_pts);
+        return n;
+    }
+
+    // SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th)  (:290-403)
+    int SearchByProjection(const aos2_frame_view_t &pKF, const aos2_proj_points_t &vpPoints, std::vector<int32_t> &vpMatched)
+    {
+        vpMatched.assign(pKF.n_f > 0 ? pKF.n_f : 1, -1);
+        int32_t n = 0;
+        check(aos2_matcher_search_by_projection_kf(h_, &pKF, &vpPoints, vpMatched.data(), &n));
+        vpMatched.resize(pKF.n_f);
+        return n;
+    }
+
+    // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)  (:1472-1599)
+    int SearchByProjection(const aos2_frame_view_t &CurrentFrame, const aos2_proj_points_t &pKFpoints,
+                           std::vector<int32_t> &match, const int ORBdist)
+    {
+        match.assign(CurrentFrame.n_f > 0 ? CurrentFrame.n_f : 1, -1);
+        int32_t n = 0;
+        check(aos2_matcher_search_by_projection_reloc(h_, &CurrentFrame, &pKFpoints, ORBdist, match.data(), &n));
+        match.resize(CurrentFrame.n_f);
+        return n;
+    }
+
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  (:1102-1326)
+    int SearchBySim3(const aos2_frame_view_t &pKF1, const aos2_frame_view_t &pKF2, const aos2_proj_points_t &p12,
+                     const aos2_proj_points_t &p21, std::vector<int32_t> &vpMatches12)
+    {
+        vpMatches12.assign(p12.n_pts > 0 ? p12.n_pts : 1, -1);
+        int32_t n = 0;
+        check(aos2_matcher_search_by_sim3(h_, &pKF1, &pKF2, &p12, &p21, vpMatches12.data(), &n));
+        vpMatches12.resize(p12.n_pts);
+        return n;
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:275-340) for a batch of map points (CSR)
+    void ComputeDistinctiveDescriptors(const std::vector<int32_t> &off, const uint8_t *desc, std::vector<int32_t> &best)
+    {
+        const int n = (int)off.size() - 1;
+        best.assign(n > 0 ? n : 1, -1);
+        check(aos2_compute_distinctive_descriptors(h_, n > 0 ? n : 0, off.data(), desc, best.data()));
+        best.resize(n > 0 ? n : 0);
     }
 
     aos2_matcher_t *handle() { return h_; }
