@@ -205,6 +205,36 @@ def main():
             extra["stereo_frontend_640x480"] = {
                 "pairs_per_step": B, "pairs_per_s": B / swall, "wall_ms": swall * 1e3,
                 "compute_stereo_matches_device_ms": float(np.mean(sms)), "matches_per_pair": float((s_dp > 0).sum().item()) / B}
+            # rank-4 matcher rows (device time of the kernels, one call each)
+            r4 = {}
+            mt = pkg.Matcher(0.6, True, device=local_rank)
+            tp = [S.synth_triang_problem(500 + i, 2000, 2000, n_nodes=100) for i in range(20)]
+            mt.SearchForTriangulation(tp)
+            mt.SearchForTriangulation(tp)
+            r4["search_for_triangulation_20pairs_2000feat_ms"] = mt.last_device_ms()
+            kp = [S.synth_bow_kf_problem(520 + i, 2000, 2000) for i in range(20)]
+            mk = pkg.Matcher(0.75, True, device=local_rank)
+            mk.SearchByBoWKF(kp)
+            mk.SearchByBoWKF(kp)
+            r4["search_by_bow_kf_20pairs_2000feat_ms"] = mk.last_device_ms()
+            fz, pz = S.synth_proj_gen_problem(530, n_f=2000, n_pts=3000)
+            mt.Fuse(fz, pz)
+            mt.Fuse(fz, pz)
+            r4["fuse_3000pts_2000feat_ms"] = mt.last_device_ms()
+            mt.SearchByProjectionKF(fz, pz)
+            mt.SearchByProjectionKF(fz, pz)
+            r4["search_by_projection_kf_3000pts_ms"] = mt.last_device_ms()
+            mt.SearchByProjectionReloc(fz, pz, 100)
+            r4["search_by_projection_reloc_3000pts_ms"] = mt.last_device_ms()
+            s1, s2, q12, q21 = S.synth_sim3_problem(540, 2000, 2000)
+            mt.SearchBySim3(s1, s2, q12, q21)
+            mt.SearchBySim3(s1, s2, q12, q21)
+            r4["search_by_sim3_2000x2000_ms"] = mt.last_device_ms()
+            oo, od = S.synth_observations(550, 4000, 24)
+            mt.ComputeDistinctiveDescriptors(oo, od)
+            mt.ComputeDistinctiveDescriptors(oo, od)
+            r4["compute_distinctive_descriptors_4000pts_ms"] = mt.last_device_ms()
+            extra["rank4_matcher"] = r4
             # ORBVocabulary::transform with a vocabulary of the real ORBvoc shape (k=10, L=6: 1.1 M nodes),
             # 64 frames x 1000 descriptors, device-resident
             voc = S.synth_vocabulary(400, 10, 6)
