@@ -115,6 +115,8 @@ def lib():
                 L.aos2_matcher_search_by_projection_kf.argtypes = [vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_projection_reloc.argtypes = [vp, vp, vp, ci, vp, vp]
+            if hasattr(L, "aos2_matcher_search_for_initialization"):
+                L.aos2_matcher_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
             L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
             L.aos2_matcher_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, vp, vp]
         if hasattr(L, "aos2_lba_create"):
@@ -626,6 +628,19 @@ class Matcher:
         match, n = np.zeros(max(p12["n_pts"], 1), np.int32), np.zeros(1, np.int32)
         _check(self.L.aos2_matcher_search_by_sim3(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), _p(match), _p(n)))
         return int(n[0]), match[: p12["n_pts"]]
+
+    def SearchForInitialization(self, f2, q, window_size=100):
+        """SearchForInitialization :405-520; q = dict(desc1, octave1, angle1, prev_xy) -> (nmatches, vnMatches12)"""
+        keep = []
+        fv = _fill_struct(_FrameView(), f2, keep)
+        d1 = np.ascontiguousarray(q["desc1"], np.uint8)
+        o1 = np.ascontiguousarray(q["octave1"], np.int32)
+        a1 = np.ascontiguousarray(q["angle1"], np.float32)
+        pv = np.ascontiguousarray(q["prev_xy"], np.float32)
+        match, n = np.zeros(max(len(d1), 1), np.int32), np.zeros(1, np.int32)
+        _check(self.L.aos2_matcher_search_for_initialization(self.h, C.byref(fv), len(d1), _p(d1), _p(o1), _p(a1), _p(pv),
+                                                             int(window_size), _p(match), _p(n)))
+        return int(n[0]), match[: len(d1)]
 
     def SearchByProjectionReloc(self, frame, p, orb_dist=100):
         """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) :1472-1599 -> (nmatches, match_f)"""

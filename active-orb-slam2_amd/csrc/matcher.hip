@@ -1212,6 +1212,134 @@ __global__ __launch_bounds__(64) void projgen_resolve_kernel(FrameDev F, ProjGen
     if (lane == 0) *nmatches_out = nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  :405-520 (monocular bootstrap).
+// Stage A: one wave per level-0 F1 feature, window of F2 around vbPrevMatched[i1] restricted to level 0.
+// Stage B: the greedy loop with its two per-F2 tables in LDS: vMatchedDistance (a candidate is skipped
+// while an earlier match holds it with a distance <= ours, :443) and vnMatches21 (a better later match
+// steals the F2 feature and un-matches its previous owner, :462-466).
+// ---------------------------------------------------------------------------------------------
+struct InitDev {
+    int n1;
+    const uint8_t *desc1;
+    const int32_t *octave1;
+    const float *angle1, *prev_xy;
+    float window;
+};
+
+__global__ __launch_bounds__(64) void init_entries_kernel(FrameDev F2, InitDev P, QuerySlot *slots, Entry *pool,
+                                                          int32_t *pool_used, int pool_cap)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    QuerySlot s{0, 0};
+    if (P.octave1[i] <= 0) {  // level1 > 0 -> continue (:421-423)
+        const float x = P.prev_xy[2 * i], y = P.prev_xy[2 * i + 1];
+        const Window w = window_cells(F2, x, y, P.window);
+        if (w.ok) {
+            const int pop = window_population(F2, w, lane);
+            if (pop > 0) {
+                int off = 0;
+                if (lane == 0) off = atomicAdd(pool_used, pop);
+                off = __shfl(off, 0);
+                if (off + pop <= pool_cap) {
+                    const int lvl = P.octave1[i];
+                    window_entries(F2, w, load_desc(P.desc1 + (size_t)i * 32), x, y, P.window, lvl, lvl, 0.0f,
+                                   __builtin_huge_valf(), lane, pool + off);
+                    s.cnt = pop;
+                    s.ent_off = off;
+                } else
+                    s.cnt = -1;
+            }
+        }
+    }
+    if (lane == 0) slots[i] = s;
+}
+
+__global__ __launch_bounds__(64) void init_resolve_kernel(FrameDev F2, InitDev P, float nnratio, int check_ori,
+                                                          const QuerySlot *__restrict__ slots,
+                                                          const Entry *__restrict__ pool, int32_t *match12,
+                                                          int32_t *bin_1, int32_t *nmatches_out)
+{
+    extern __shared__ uint16_t init_lds[];
+    uint16_t *md = init_lds;               // vMatchedDistance (0xFFFF = INT_MAX)
+    uint16_t *m21 = init_lds + F2.n_f;     // vnMatches21 + 1 (0 = -1)
+    __shared__ int histo[HISTO];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < F2.n_f; i += 64) {
+        md[i] = 0xFFFFu;
+        m21[i] = 0;
+    }
+    for (int i = lane; i < P.n1; i += 64) {
+        match12[i] = -1;
+        bin_1[i] = 0;
+    }
+    if (lane < HISTO) histo[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    SlotStream Q;
+    Q.init(slots, pool, P.n1, lane);
+    for (int i1 = 0; i1 < P.n1; i1++) {
+        QuerySlot s;
+        Entry e;
+        Q.next(i1, s, e);
+        if (s.cnt <= 0) continue;
+        uint32_t k1 = KEY_NONE, k2 = KEY_NONE, p1 = 0;
+        for (int j0 = 0; j0 < s.cnt; j0 += 64) {
+            if (j0 > 0) e = (j0 + lane < s.cnt) ? pool[s.ent_off + j0 + lane] : Entry{KEY_NONE, 0};
+            if (j0 + lane < s.cnt && e.key != KEY_NONE) {
+                const uint32_t dist = e.key >> 20;
+                if ((uint32_t)md[e.payload & 0xffffffu] > dist) {  // !(vMatchedDistance[i2] <= dist)
+                    if (e.key < k1) {
+                        k2 = k1;
+                        k1 = e.key;
+                        p1 = e.payload;
+                    } else if (e.key < k2)
+                        k2 = e.key;
+                }
+            }
+        }
+        const uint32_t my1 = k1;
+        wave_min2(k1, k2);
+        if (k1 == KEY_NONE) continue;
+        const int bestDist = (int)(k1 >> 20);
+        const float second = k2 == KEY_NONE ? 2147483648.0f : (float)(int)(k2 >> 20);  // (float)INT_MAX
+        if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(second, nnratio)) {
+            const int bestIdx2 = (int)(read_owner(p1, __ballot(my1 == k1)) & 0xffffffu);
+            const int prev = (int)m21[bestIdx2];
+            if (lane == 0) {
+                if (prev > 0) match12[prev - 1] = -1;
+                match12[i1] = bestIdx2;
+                m21[bestIdx2] = (uint16_t)(i1 + 1);
+                md[bestIdx2] = (uint16_t)bestDist;
+                if (check_ori) {
+                    const int bin = rot_bin(__fsub_rn(P.angle1[i1], F2.kp_angle[bestIdx2]));
+                    histo[bin]++;
+                    bin_1[i1] = bin + 1;
+                }
+            }
+            nmatches += prev > 0 ? 0 : 1;  // nmatches-- for the stolen match, nmatches++ for the new one
+            lds_fence();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (check_ori) {
+        int i1m, i2m, i3m;
+        three_maxima(histo, i1m, i2m, i3m);
+        int drop = 0;
+        for (int i = lane; i < P.n1; i += 64) {
+            const int bn = bin_1[i] - 1;
+            if (bn >= 0 && bn != i1m && bn != i2m && bn != i3m && match12[i] >= 0) {  // :497-501
+                match12[i] = -1;
+                drop++;
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1) drop += __shfl_xor(drop, d);
+        nmatches -= drop;
+    }
+    if (lane == 0) *nmatches_out = nmatches;
+}
+
 }  // namespace aos2
 
 using namespace aos2;
@@ -1995,6 +2123,59 @@ int aos2_matcher_search_by_projection_reloc(aos2_matcher_t *m, const aos2_frame_
         return AOS2_ERR_ARG;
     }
     return projgen_serial(m, frame, p, 4, orb_dist, m->check_ori, match_f, nmatches);
+}
+
+int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_view_t *f2, int n1, const uint8_t *desc1,
+                                           const int32_t *octave1, const float *angle1, const float *prev_xy,
+                                           int window_size, int32_t *match12, int32_t *nmatches)
+{
+    if (!m || n1 < 0 || !nmatches || (n1 > 0 && (!desc1 || !octave1 || !angle1 || !prev_xy || !match12))) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = check_frame(f2);
+    if (st) return st;
+    *nmatches = 0;
+    if (n1 == 0) return AOS2_OK;
+    if (n1 >= 65535 || f2->n_f > 15000) {
+        set_error("SearchForInitialization: %d x %d features exceed the LDS match tables (65534 / 15000)", n1, f2->n_f);
+        return AOS2_ERR_CAPACITY;
+    }
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    size_t fo[12];
+    fill_frame(A, f2, fo);
+    const size_t n = (size_t)n1;
+    const size_t o0 = A.push(desc1, n * 32), o1 = A.push(octave1, n * 4), o2 = A.push(angle1, n * 4), o3 = A.push(prev_xy, n * 8);
+    const size_t om = A.reserve(n * 8 + 8), on = A.reserve(8);
+    const size_t oslots = A.reserve((n + 1) * sizeof(QuerySlot));
+    const size_t pool_cap = n * (size_t)f2->n_f;
+    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
+        set_error("initialization search of %d x %d features exceeds the 1 GiB entry pool", n1, f2->n_f);
+        return AOS2_ERR_ARG;
+    }
+    if ((st = m->pool.alloc(pool_cap + 1))) return st;
+    if ((st = A.upload())) return st;
+    FrameDev F = frame_dev(A, f2, fo);
+    InitDev P{};
+    P.n1 = n1;
+    P.desc1 = A.dev<uint8_t>(o0); P.octave1 = A.dev<int32_t>(o1); P.angle1 = A.dev<float>(o2); P.prev_xy = A.dev<float>(o3);
+    P.window = (float)window_size;
+    int32_t *d_used = A.dev<int32_t>(on) + 1;
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(init_entries_kernel, dim3(n1), dim3(64), 0, m->stream, F, P, A.dev<QuerySlot>(oslots),
+                       reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+    hipLaunchKernelGGL(init_resolve_kernel, dim3(1), dim3(64), (size_t)f2->n_f * 4 + 16, m->stream, F, P, m->nnratio,
+                       m->check_ori, A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                       A.dev<int32_t>(om) + n1, A.dev<int32_t>(on));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
 }
 
 }  // extern "C"

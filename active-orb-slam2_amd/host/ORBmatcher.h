@@ -129,6 +129,26 @@ public:
         return n;
     }
 
+    // SearchForInitialization(Frame &F1, Frame &F2, vbPrevMatched, vnMatches12, windowSize=10)  (:405-520)
+    // F1 enters through its descriptor rows, octaves and angles; vbPrevMatched (2 floats per F1 feature) is updated
+    // like :512-515
+    int SearchForInitialization(int n1, const uint8_t *desc1, const int32_t *octave1, const float *angle1,
+                                const aos2_frame_view_t &F2, std::vector<float> &vbPrevMatched, std::vector<int> &vnMatches12,
+                                int windowSize = 10)
+    {
+        vnMatches12.assign(n1 > 0 ? n1 : 1, -1);
+        int32_t n = 0;
+        check(aos2_matcher_search_for_initialization(h_, &F2, n1, desc1, octave1, angle1, vbPrevMatched.data(), windowSize,
+                                                     vnMatches12.data(), &n));
+        vnMatches12.resize(n1);
+        for (int i1 = 0; i1 < n1; ++i1)
+            if (vnMatches12[i1] >= 0) {
+                vbPrevMatched[2 * i1] = F2.kp_x[vnMatches12[i1]];
+                vbPrevMatched[2 * i1 + 1] = F2.kp_y[vnMatches12[i1]];
+            }
+        return n;
+    }
+
     // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)  (:1102-1326)
     int SearchBySim3(const aos2_frame_view_t &pKF1, const aos2_frame_view_t &pKF2, const aos2_proj_points_t &p12,
                      const aos2_proj_points_t &p21, std::vector<int32_t> &vpMatches12)

@@ -466,6 +466,33 @@ def synth_sim3_problem(seed: int, n1: int = 1000, n2: int = 1000, cfg: str = "ki
     return f1, f2, p12, p21
 
 
+def synth_init_problem(seed: int, n1: int = 1500, n2: int = 1500, w: int = 640, h: int = 480):
+    """Two monocular frames a small motion apart for SearchForInitialization (src/ORBmatcher.cc:405-520):
+    60 % of F1's features reappear in F2 displaced by a smooth flow; several F1 features compete for the
+    same F2 feature (the vMatchedDistance / vnMatches21 stealing logic)."""
+    rng = np.random.default_rng(13000 + seed)
+    x1, y1 = rng.uniform(20, w - 20, n1), rng.uniform(20, h - 20, n1)
+    x2, y2 = rng.uniform(20, w - 20, n2), rng.uniform(20, h - 20, n2)
+    k = int(0.6 * min(n1, n2))
+    i1, i2 = rng.permutation(n1)[:k], rng.permutation(n2)[:k]
+    x2[i2] = np.clip(x1[i1] + 12 + 0.02 * (y1[i1] - h / 2) + rng.normal(0, 1.0, k), 1, w - 1)
+    y2[i2] = np.clip(y1[i1] - 5 + rng.normal(0, 1.0, k), 1, h - 1)
+    f2 = _view_from(rng, x2, y2, w, h, stereo=False)
+    octave1 = np.minimum(rng.geometric(0.5, n1) - 1, 7).astype(np.int32)
+    f2["kp_octave"][i2] = octave1[i1]
+    desc1 = synth_descriptors(rng, n1)
+    desc1[i1] = flip_bits(rng, f2["desc_f"][i2], 0.06)
+    rivals = rng.permutation(n1)[: n1 // 8]                 # near-duplicates that fight for the same F2 feature
+    src = rng.choice(i1, len(rivals))
+    desc1[rivals] = flip_bits(rng, desc1[src], 0.03)
+    x1[rivals], y1[rivals] = x1[src] + rng.normal(0, 3, len(rivals)), y1[src] + rng.normal(0, 3, len(rivals))
+    octave1[rivals] = octave1[src]
+    angle1 = rng.uniform(0, 360, n1).astype(np.float32)
+    angle1[i1] = np.mod(f2["kp_angle"][i2] + rng.normal(8, 4, k), 360).astype(np.float32)
+    prev = np.stack([x1, y1], 1).astype(np.float32)         # vbPrevMatched starts as F1's own keypoints
+    return f2, dict(desc1=desc1, octave1=octave1, angle1=angle1, prev_xy=prev)
+
+
 def synth_proj_mp_problem(seed: int, n_f: int = 1000, n_mp: int = 1500, w: int = 640, h: int = 480,
                           th: float = 3.0, nnratio: float = 0.8):
     """Frame + local map points with planted projections (SearchByProjection(F, vpMP, th))."""

@@ -439,6 +439,18 @@ int aos2_matcher_search_by_projection_reloc(aos2_matcher_t *m, const aos2_frame_
                                             const aos2_proj_points_t *p, int orb_dist,
                                             int32_t *match_f, int32_t *nmatches);
 
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
+ *         vector<int> &vnMatches12, int windowSize=10)  src/ORBmatcher.cc:405-520 (monocular bootstrap,
+ * Tracking::MonocularInitialization).  f2 = view of F2 (grid, mvKeysUn, descriptors); F1 enters through
+ * desc1 / octave1 / angle1 (mvKeysUn[i].octave / .angle) and prev_xy = vbPrevMatched (2 floats per F1
+ * feature).  match12[n1] = vnMatches12.  The update of :512-515 (vbPrevMatched[i1] = F2 keypoint of the
+ * match) is one line in the caller.  n1 < 65535, f2->n_f <= 15000. */
+int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_view_t *f2, int n1,
+                                           const uint8_t *desc1, const int32_t *octave1,
+                                           const float *angle1, const float *prev_xy,
+                                           int window_size, int32_t *match12, int32_t *nmatches);
+
+
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer::LocalBundleAdjustment  (include/Optimizer.h:45, src/Optimizer.cc:454-779)

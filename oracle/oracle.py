@@ -68,6 +68,8 @@ def lib():
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_fuse.argtypes = [C.c_void_p] * 4
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_float, C.c_int, C.c_void_p]
         L.orc_fuse_sim3.argtypes = [C.c_void_p] * 4
         L.orc_search_by_projection_kf.argtypes = [C.c_void_p] * 3
         L.orc_search_by_sim3.argtypes = [C.c_void_p] * 5
@@ -398,6 +400,20 @@ def search_by_projection_reloc(f: dict, p: dict, orb_dist=100, check_orientation
     m = np.zeros(max(f["n_f"], 1), np.int32)
     n = lib().orc_search_by_projection_reloc(C.byref(fv), C.byref(pg), int(orb_dist), int(check_orientation), _p(m))
     return n, m[: f["n_f"]]
+
+
+def search_for_initialization(f2: dict, q: dict, window_size=100, nnratio=0.9, check_orientation=True):
+    """SearchForInitialization src/ORBmatcher.cc:405-520 -> (nmatches, vnMatches12)"""
+    keep = []
+    fv = _frame_view(f2, keep)
+    d1 = np.ascontiguousarray(q["desc1"], np.uint8)
+    o1 = np.ascontiguousarray(q["octave1"], np.int32)
+    a1 = np.ascontiguousarray(q["angle1"], np.float32)
+    pv = np.ascontiguousarray(q["prev_xy"], np.float32)
+    m = np.zeros(max(len(d1), 1), np.int32)
+    n = lib().orc_search_for_initialization(C.byref(fv), len(d1), _p(d1), _p(o1), _p(a1), _p(pv), int(window_size),
+                                            np.float32(nnratio), int(check_orientation), _p(m))
+    return n, m[: len(d1)]
 
 
 class _BowKfProblem(C.Structure):

@@ -947,3 +947,80 @@ int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen
     free(vIndices2);
     return nmatches;
 }
+
+/* SearchForInitialization(Frame &F1, Frame &F2, vbPrevMatched, vnMatches12, windowSize) :405-520.
+ * f2 = view of F2; F1 enters through its arrays.  prev_xy (2 per F1 feature) = vbPrevMatched on entry; the
+ * update of :512-515 is `prev_xy[i1] = f2 keypoint of match12[i1]` and is left to the caller.
+ * match12[n1] = vnMatches12. */
+int orc_search_for_initialization(const orc_frame_view_t *f2, int n1, const uint8_t *desc1, const int32_t *octave1,
+                                  const float *angle1, const float *prev_xy, int window_size, float nnratio,
+                                  int check_orientation, int32_t *match12)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) match12[i] = -1;
+    ivec_t rotHist[HISTO_LENGTH];
+    memset(rotHist, 0, sizeof(rotHist));
+    const int n2 = f2->n_f;
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (n2 ? n2 : 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (n2 ? n2 : 1));
+    int *vIndices2 = (int *)malloc(sizeof(int) * (n2 ? n2 : 1));
+    for (int i = 0; i < n2; ++i) {
+        vMatchedDistance[i] = 2147483647;
+        vnMatches21[i] = -1;
+    }
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = octave1[i1];
+        if (level1 > 0) continue;
+        const int nInd = features_in_area(f2, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window_size, level1, level1, vIndices2);
+        if (nInd == 0) continue;
+        const uint8_t *d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int k = 0; k < nInd; ++k) {
+            const int i2 = vIndices2[k];
+            const int dist = orc_descriptor_distance(d1, f2->desc_f + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    match12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                match12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = angle1[i1] - f2->kp_angle[bestIdx2];
+                    iv_push(&rotHist[rot_bin(rot)], i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotHist[i].n; j++) {
+                const int idx1 = rotHist[i].v[j];
+                if (match12[idx1] >= 0) {
+                    match12[idx1] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i].v);
+    free(vMatchedDistance);
+    free(vnMatches21);
+    free(vIndices2);
+    return nmatches;
+}

@@ -108,3 +108,7 @@ np.savez_compressed(os.path.join(OUT, "fuse_400.npz"), n=n, best_idx=bi, best_di
 n, m = O.search_by_projection_reloc(f, p, 100, True)
 np.savez_compressed(os.path.join(OUT, "reloc_400.npz"), n=n, match=m, **{"f_" + k: v for k, v in f.items()},
                     **{"p_" + k: v for k, v in p.items()})
+f2, q = S.synth_init_problem(42, 500, 520)
+n, m = O.search_for_initialization(f2, q, 100, 0.9, True)
+np.savez_compressed(os.path.join(OUT, "init_500.npz"), n=n, match=m, **{"f_" + k: v for k, v in f2.items()},
+                    **{"q_" + k: v for k, v in q.items()})

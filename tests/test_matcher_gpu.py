@@ -232,3 +232,28 @@ def test_search_by_sim3_vs_oracle(pkg, oracle, gpu):
         k = np.flatnonzero(match >= 0)
         assert len(set(match[k].tolist())) == len(k)       # mutual agreement makes the assignment injective
     assert tot > 500
+
+
+def test_search_for_initialization_vs_oracle(pkg, oracle, gpu):
+    """SearchForInitialization :405-520 (vMatchedDistance gate, match stealing, rotation check)"""
+    S = pkg.synth
+    tot = 0
+    for seed in range(5):
+        f2, q = S.synth_init_problem(seed, 1200 + 200 * seed, 1500 - 100 * seed)
+        for ratio, ori, ws in ((0.9, True, 100), (0.7, False, 30), (0.9, True, 10)):
+            n, match = pkg.Matcher(ratio, ori).SearchForInitialization(f2, q, ws)
+            on, om = oracle.search_for_initialization(f2, q, ws, ratio, ori)
+            assert n == on and (match == om).all() and n == (match >= 0).sum()
+            k = np.flatnonzero(match >= 0)
+            assert len(set(match[k].tolist())) == len(k) and (q["octave1"][k] == 0).all() and (f2["kp_octave"][match[k]] == 0).all()
+            tot += n
+    assert tot > 1500
+    f2, q = S.synth_init_problem(9, 50, 60)
+    q0 = {k: v[:0] for k, v in q.items()}
+    assert pkg.Matcher().SearchForInitialization(f2, q0)[0] == 0
+    g = np.load(os.path.join(GOLD, "init_500.npz"))
+    f2 = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    q = {k[2:]: g[k] for k in g.files if k.startswith("q_")}
+    f2["n_f"], f2["n_levels"] = int(f2["n_f"]), int(f2["n_levels"])
+    n, match = pkg.Matcher(0.9, True).SearchForInitialization(f2, q, 100)
+    assert n == int(g["n"]) and (match == g["match"]).all()

@@ -438,3 +438,29 @@ def test_projection_family_golden_and_numpy_restatement(oracle, pkg):
     # planted correspondences dominate: the matched KF2 feature's descriptor is close to the KF1 point's
     d = np.unpackbits(p12["desc"][k] ^ f2_["desc_f"][m3[k]], axis=1).sum(1)
     assert (d <= 100).all() and np.median(d) < 40
+
+
+def test_search_for_initialization_golden_and_stealing(oracle, pkg):
+    """SearchForInitialization :405-520"""
+    g = np.load(os.path.join(GOLD, "init_500.npz"))
+    f2 = {k[2:]: g[k] for k in g.files if k.startswith("f_")}
+    q = {k[2:]: g[k] for k in g.files if k.startswith("q_")}
+    f2["n_f"], f2["n_levels"] = int(f2["n_f"]), int(f2["n_levels"])
+    n, m = oracle.search_for_initialization(f2, q, 100, 0.9, True)
+    assert n == int(g["n"]) and (m == g["match"]).all() and n > 50
+    # hand-made stealing case: two identical F1 features near one F2 feature; the second, equal distance, is
+    # blocked by vMatchedDistance[i2] <= dist (:443); a strictly better third one steals it (:462-466)
+    S = pkg.synth
+    rng = np.random.default_rng(0)
+    v = S._view_from(rng, np.array([100.0, 400.0]), np.array([100.0, 300.0]), 640, 480, stereo=False)
+    v["kp_octave"][:] = 0
+    d = v["desc_f"][0].copy()
+    worse = d.copy()
+    worse[0] ^= 0x0F                      # 4 bits away
+    q = dict(desc1=np.stack([worse, worse, d]), octave1=np.zeros(3, np.int32), angle1=np.full(3, 10, np.float32),
+             prev_xy=np.array([[101, 100], [99, 101], [100, 99]], np.float32))
+    n, m = oracle.search_for_initialization(v, q, 20, 0.9, False)
+    assert n == 1 and m.tolist() == [-1, -1, 0]
+    n, m = oracle.search_for_initialization(v, dict(q, desc1=q["desc1"][:2], octave1=q["octave1"][:2], angle1=q["angle1"][:2],
+                                                    prev_xy=q["prev_xy"][:2]), 20, 0.9, False)
+    assert n == 1 and m.tolist() == [0, -1]
