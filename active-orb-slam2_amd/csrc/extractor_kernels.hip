@@ -12,6 +12,9 @@ namespace aos2 {
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024];   // rBRIEF test locations (src/ORBextractor.cc:150-408)
 __constant__ int c_umax[16];           // circular patch row extents (:454-470)
 __constant__ int c_gauss[8];           // 7-tap Gaussian, 8 fractional bits {18,34,49,55,49,34,18}
+// IC_Angle: byte masks of the circular patch, [31 rows v = -15..15][9 dwords covering patch columns 4..39]:
+// byte k of dword dj (column 4*dj + k, u = column - 21) is inside iff |u| <= umax[|v|] (:88-101)
+__constant__ uint32_t c_icmask[31 * 9 + 1];
 
 int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st)
 {
@@ -21,6 +24,20 @@ int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, 
     if (e != hipSuccess) return (int)e;
     int g[8] = {gauss7[0], gauss7[1], gauss7[2], gauss7[3], gauss7[4], gauss7[5], gauss7[6], 0};
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_gauss), g, sizeof(g), 0, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    uint32_t icm[31 * 9 + 1] = {};
+    for (int vr = 0; vr < 31; ++vr) {
+        const int v = vr - 15, um = umax[v < 0 ? -v : v];
+        for (int dj = 1; dj <= 9; ++dj) {
+            uint32_t m = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int u = 4 * dj + k - 21;
+                if ((u < 0 ? -u : u) <= um) m |= 0xffu << (8 * k);
+            }
+            icm[vr * 9 + dj - 1] = m;
+        }
+    }
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_icmask), icm, sizeof(icm), 0, hipMemcpyHostToDevice, st);
     return (int)e;
 }
 
@@ -572,10 +589,13 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
     uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
     // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
     if (kx - PR >= 0 && kx + PR + 1 < lv.w && ky - PR >= 0 && ky + PR < lv.h) {
-        const uint8_t *src = plane + (size_t)(ky - PR) * lv.pitch + (kx - PR);
-        for (int i = lane; i < PW * 11; i += 64) {
-            const int r = i / 11, c = i - r * 11;
-            patch32[r * PD + c] = load_u32_unaligned(src + (size_t)r * lv.pitch + 4 * c);
+        // 5 rows x 11 dwords per step (55 lanes): the (row, dword) split is done once per lane
+        const int rs = (lane * 373) >> 12, c = lane - 11 * rs;   // lane / 11 for lane < 64
+        if (rs < 5) {
+            const uint8_t *src = plane + (size_t)(ky - PR + rs) * lv.pitch + (kx - PR) + 4 * c;
+            const size_t step = (size_t)5 * lv.pitch;
+            uint32_t *dst = patch32 + rs * PD + c;
+            for (int r = rs; r < PW; r += 5, src += step, dst += 5 * PD) *dst = load_u32_unaligned(src);
         }
     } else {
         for (int i = lane; i < PW * PW; i += 64) {
@@ -587,22 +607,20 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
     __syncthreads();
     // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 9; i += 64) {
-        const int vr = i / 9, dj = i - vr * 9 + 1;     // patch dwords 1..9 cover columns 4..39
-        const int v = vr - 15;
-        const int av = v < 0 ? -v : v;
-        const int um = (int)((umax_nibbles >> (4 * av)) & 15ull);
-        const uint32_t d = patch32[(PR + v) * PD + dj];
-        int rowsum = 0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int u = 4 * dj + kk - PR;
-            const int au = u < 0 ? -u : u;
-            const int I = au <= um ? (int)((d >> (8 * kk)) & 255u) : 0;
-            m10 += u * I;
-            rowsum += I;
+    {
+        // 7 rows x 9 dwords per step (63 lanes); patch dwords 1..9 cover columns 4..39.  With the precomputed
+        // byte mask: sum(u*I) over the dword = (4*dj - 21) * S + T, S = sum of the kept bytes, T = sum of k * byte_k
+        const int rs = (lane * 57) >> 9, dj = lane - 9 * rs + 1;   // lane / 9 for lane < 64
+        if (rs < 7) {
+            const int c0 = 4 * dj - PR;
+            for (int vr = rs; vr < 31; vr += 7) {
+                const uint32_t d = patch32[(PR - 15 + vr) * PD + dj] & c_icmask[vr * 9 + dj - 1];
+                const int S = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
+                const int T = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
+                m10 += c0 * S + T;
+                m01 += (vr - 15) * S;
+            }
         }
-        m01 += v * rowsum;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -614,8 +632,9 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
     {
         const uint32_t W0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
         const uint32_t W1 = (uint32_t)c_gauss[4] | ((uint32_t)c_gauss[5] << 8) | ((uint32_t)c_gauss[6] << 16);
-        for (int i = lane; i < PW * 10; i += 64) {
-            const int r = i / 10, j = i - r * 10;
+        // 6 rows x 10 output quads per step (60 lanes)
+        const int rs = (lane * 205) >> 11, j = lane - 10 * rs;   // lane / 10 for lane < 64
+        for (int r = rs; r < PW && rs < 6; r += 6) {
             const uint32_t D0 = patch32[r * PD + j], D1 = patch32[r * PD + j + 1], D2 = patch32[r * PD + j + 2];
             uint32_t o[4];
             o[0] = __builtin_amdgcn_udot4(D0, W0, __builtin_amdgcn_udot4(D1, W1, 0u, false), false);
