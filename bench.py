@@ -284,7 +284,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": fast_bytes, "kernel_ms": fast_ms,
-                         "note": "VALU-issue bound in practice (profiles/README.md): ~1040 VALU instr per 1.2k-px cell-wave = 2.17e8 per launch x 4 cycles / 1024 SIMDs = 0.353 ms at 2.4 GHz, i.e. ~91 % of the VALU issue rate"},
+                         "note": "instruction-issue bound, not bandwidth bound (profiles/README.md): ~1040 VALU + 450 SALU + 130 LDS instructions per 1.2k-px cell-wave; VALU ~46 % busy at 2 cycles per wave64 instruction, 4 waves/SIMD (LDS-limited)"},
             "extra": extra,
         }
         # HBM-side bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes
