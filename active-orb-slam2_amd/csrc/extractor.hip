@@ -335,8 +335,14 @@ static int build_plan(aos2_extractor *e, int w, int h)
     // only dropped in phase 2), so size the list for whole groups
     P.list_cap = (4 * ((P.max_cw + 3) / 4) * P.max_ch + 7) & ~7;
     P.keep_cap = ((P.max_cw + 1) / 2) * ((P.max_ch + 1) / 2);          // NMS survivors are >= 2 px apart
+    // The survivor list is bounded (typical cells produce 100-200 survivors); a cell that produces more is
+    // scored in instalments.  The smaller LDS footprint doubles the waves per SIMD.  AOS2_FAST_LIST overrides
+    // the bound (tests force the instalment path with a small value).
+    int l1 = 768;
+    if (const char *v = getenv("AOS2_FAST_LIST")) l1 = std::max(264, atoi(v));
+    P.list_cap = std::min(P.list_cap, (l1 + 7) & ~7);
     P.fast_lds = (((size_t)P.TP * P.TH + 15) & ~(size_t)15) + (((size_t)P.SP * (P.TH - 4) + 15) & ~(size_t)15) +
-                 (size_t)P.list_cap * 2 + (size_t)P.keep_cap * 4 + 16;
+                 (size_t)P.list_cap * 2 + 16;
     // upload
     int st;
     if ((st = P.d_levels.alloc(P.levels.size()))) return st;

@@ -232,8 +232,13 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     const int smap_bytes = (SP * (TH - 4) + 15) & ~15;  // (ch+2) rows
     uint8_t *tile = smem;                                      // TH x TP
     uint8_t *smap = smem + tile_bytes;                         // (ch+2) x SP, 1-px zero border
-    uint16_t *list1 = reinterpret_cast<uint16_t *>(smap + smap_bytes);   // survivors  (py<<6 | px)
-    uint32_t *list3 = reinterpret_cast<uint32_t *>(list1 + list_cap);    // kept: (py<<6|px)<<8 | score
+    // survivors (py<<6 | px): list_cap entries; a cell that produces more is scored in instalments (below)
+    uint16_t *list1 = reinterpret_cast<uint16_t *>(smap + smap_bytes);
+    // kept corners ((py<<6|px)<<8 | score) reuse the tile: NMS reads only the score map, and when the
+    // minThFAST pass needs the tile again the first pass has kept nothing, i.e. written nothing here.
+    // <= ceil(cw/2)*ceil(ch/2) entries (NMS survivors are >= 2 px apart) always fit (cw+8)*(ch+6) bytes.
+    uint32_t *list3 = reinterpret_cast<uint32_t *>(tile);
+    (void)keep_cap;
 
     const int b = blockIdx.y;
     // Cell order = dispatch order (round-robin over the 8 XCDs).  An XCD-banded order (each XCD a
@@ -270,11 +275,30 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = lane; i < (SH * SP + 3) >> 2; i += 64) reinterpret_cast<uint32_t *>(smap)[i] = 0;
         __syncthreads();
+        // ---- 2. exact scores of the survivors (called once per pass, or per instalment on overflow)
+        auto score_survivors = [&](int n) {
+            for (int i = lane; i < n; i += 64) {
+                const int pos = list1[i];
+                const int py = pos >> 6, px = pos & 63;
+                if (px < cw) {
+                    const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+                    if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+                }
+            }
+        };
         // ---- 1. compass pre-test (a 9-arc contains >= 2 of the 4 compass pixels)
         int n1 = 0;
+        bool overflowed = false;   // the survivor list was emptied at least once: NMS walks the score map instead
         const us2_t T = {(unsigned short)th, (unsigned short)th};
         const int nitems = nq * ch;
         for (int g0 = 0; g0 < nitems; g0 += 64) {
+            if (n1 > 0 && n1 + 256 > list_cap) {  // one iteration appends <= 256 entries (wave-uniform test)
+                __syncthreads();
+                score_survivors(n1);
+                __syncthreads();
+                n1 = 0;
+                overflowed = true;
+            }
             const int g = g0 + lane;
             uint32_t f_lo = 0, f_hi = 0;
             int py = 0, qd = 0;
@@ -311,24 +335,22 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             n1 += __popcll(b3);
         }
         __syncthreads();
-        // ---- 2. exact scores of the survivors
-        for (int i = lane; i < n1; i += 64) {
-            const int pos = list1[i];
-            const int py = pos >> 6, px = pos & 63;
-            if (px < cw) {
-                const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
-                if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
-            }
-        }
+        score_survivors(n1);
         __syncthreads();
         // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell)
         nkept = 0;
-        for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int n3 = overflowed ? cw * ch : n1;   // overflow: every pixel of the cell is a candidate position
+        for (int i0 = 0; i0 < n3; i0 += 64) {
             const int i = i0 + lane;
             bool keep = false;
             int pos = 0, sc = 0;
-            if (i < n1) {
-                pos = list1[i];
+            if (i < n3) {
+                if (!overflowed)
+                    pos = list1[i];
+                else {
+                    const int yy = i / cw;
+                    pos = (yy << 6) | (i - yy * cw);
+                }
                 const int py = pos >> 6, px = pos & 63;
                 const uint8_t *m = smap + (py + 1) * SP + px + 1;
                 sc = m[0];

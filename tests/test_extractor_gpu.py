@@ -106,6 +106,20 @@ def test_host_octree_path_equals_device_octree(pkg, gpu, monkeypatch):
     assert all(same(a, b) for a, b in zip(dev, host))
 
 
+def test_fallback_paths_equal_the_fast_paths(pkg, oracle, gpu, monkeypatch):
+    """The two capacity fallbacks give the same bits: FAST survivor list scored in instalments
+    (AOS2_FAST_LIST=264 forces it for every dense cell) and the octree over global scratch (AOS2_OCT_LDS=0)."""
+    rng = np.random.default_rng(5)
+    noise = (rng.integers(0, 2, (480, 640)) * 255).astype(np.uint8)   # every cell overflows a 264-entry list
+    imgs = [pkg.synth.synth_image(70), noise, pkg.synth.synth_image(71, 1241, 376)]
+    ref = [pkg.Extractor(nfeatures=2000)(im) for im in imgs]
+    assert same(ref[1], oracle.Extractor(nfeatures=2000).extract(noise))
+    monkeypatch.setenv("AOS2_FAST_LIST", "264")
+    monkeypatch.setenv("AOS2_OCT_LDS", "0")
+    alt = [pkg.Extractor(nfeatures=2000)(im) for im in imgs]
+    assert all(same(a, b) for a, b in zip(ref, alt))
+
+
 def test_full_batch_properties(pkg, oracle, gpu):
     """BASELINE-size batch (256 x 640x480): size-independent properties + sampled exact parity."""
     B = 256
