@@ -278,6 +278,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "TUM 640x480 ORBextractor-only, 1000 features, 8 levels, scale 1.2, FAST 20/7 (BASELINE configs[1])",
+                       "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
+                       "metric_scope": "BASELINE.json's metric is quoted on configs[1] = ORBextractor-only, so a step is "
+                                       "ORBextractor::operator() over the batch; the match and LocalBA rows of the same metric "
+                                       "are timed separately under `extra` (they do not shard by frames, DESIGN.md section 7)",
                        "frames_per_gpu_per_step": B, "octree": os.environ.get("AOS2_OCTREE", "device"),
                        "keypoints_per_frame_mean": float(n_kp.mean())},
             "stage_ms": stage,
