@@ -130,3 +130,47 @@ def test_stereo_batch_device_matches_host_api(pkg, oracle, gpu):
         assert nl[b] == len(kl)
         assert ur[b, : nl[b]].cpu().numpy().tobytes() == our.tobytes()
         assert dp[b, : nl[b]].cpu().numpy().tobytes() == odp.tobytes()
+
+
+def test_front_end_chain_extract_stereo_bow_match(pkg, oracle, gpu):
+    """The rows compose: ORBextractor (both eyes) -> ComputeStereoMatches -> ORBVocabulary::transform ->
+    SearchByBoW, with every intermediate in the format the next stage takes; the device chain equals the
+    oracle chain bit for bit."""
+    S = pkg.synth
+    c = S.CONFIGS["euroc"]
+    mb, mbf = _params(S, "euroc")
+    left, right, _ = S.synth_stereo_pair(7, c["w"], c["h"])
+    nxt = np.roll(left, 9, axis=1)                       # the "next frame": the left image panned by 9 px
+    voc = S.synth_vocabulary(3, 10, 4)
+    rng = np.random.default_rng(3)
+    # device chain
+    xl, xr, xn = (pkg.Extractor(nfeatures=c["nfeatures"]) for _ in range(3))
+    kl, dl = xl(left)
+    kr, dr = xr(right)
+    kn, dn = xn(nxt)
+    ur, dp = pkg.ComputeStereoMatches(xl, xr, kl, dl, kr, dr, mb, mbf)
+    V = pkg.Vocabulary()
+    V.set_nodes(voc["k"], voc["L"], 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    fa, fb = V.transform(dl, 4), V.transform(dn, 4)
+    has_mp = (dp > 0).astype(np.uint8)                   # map points exist where stereo depth was found
+
+    def pair(fa_, fb_, d1, d2, k1, k2, mp):
+        return dict(desc_kf=d1, desc_f=d2, kf_has_mp=mp, angle_kf=k1["angle"].copy(), angle_f=k2["angle"].copy(),
+                    node_id_kf=fa_["fv_node"], node_off_kf=fa_["fv_off"], node_idx_kf=fa_["fv_idx"],
+                    node_id_f=fb_["fv_node"], node_off_f=fb_["fv_off"], node_idx_f=fb_["fv_idx"],
+                    nnratio=np.float32(0.7), check_orientation=1)
+    n, match = pkg.Matcher(0.7, True).SearchByBoW(pair(fa, fb, dl, dn, kl, kn, has_mp))
+    # oracle chain
+    oL, oR, oN = (oracle.Extractor(nfeatures=c["nfeatures"]) for _ in range(3))
+    okl, odl = oL.extract(left)
+    okr, odr = oR.extract(right)
+    okn, odn = oN.extract(nxt)
+    our, odp, _ = oracle.compute_stereo_matches(oL, oR, okl, odl, okr, odr, mb, mbf)
+    OV = oracle.Vocabulary()
+    OV.set_nodes(voc["k"], voc["L"], 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    ofa, ofb = OV.transform(odl, 4), OV.transform(odn, 4)
+    on, omatch = oracle.search_by_bow(pair(ofa, ofb, odl, odn, okl, okn, (odp > 0).astype(np.uint8)))
+    assert dp.tobytes() == odp.tobytes() and fa["bow_value"].tobytes() == ofa["bow_value"].tobytes()
+    assert n == on and (match == omatch).all()
+    assert has_mp.sum() > 100                            # the chain is not vacuous
+    assert V.score(fa, fb) == oracle.vocab_score_l1(ofa, ofb)
