@@ -262,16 +262,20 @@ __global__ void k_linearize(LbaDev P, LbaAct A)
     rot_from_quat(T, R);
     const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
     double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Jb[18];
+#pragma unroll
     for (int i = 0; i < 18; ++i) Jb[i] = 0;
     if (!stereo) {
         const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
         const double s = -1. / z;
+#pragma unroll
         for (int r = 0; r < 2; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
                 Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
             }
     } else {
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
             Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
@@ -300,26 +304,33 @@ __global__ void k_linearize(LbaDev P, LbaAct A)
     }
     const double *er = P.err + 3 * (size_t)e;
     const double w = P.e_w[e];
-    double omr[3] = {0, 0, 0};
-    for (int i = 0; i < D; ++i) omr[i] = -(w * er[i]);
+    // static indices only (a runtime-length loop over D would put Ja/Jb/omr in scratch memory)
+    double omr[3] = {-(w * er[0]), -(w * er[1]), stereo ? -(w * er[2]) : 0.0};
     double wo = w;
     if (P.e_robust[e]) {
         double rho[2];
         robustify(edge_chi2(er, w, D), stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
         wo = rho[1] * w;
-        for (int i = 0; i < D; ++i) omr[i] *= rho[1];
+        omr[0] *= rho[1];
+        omr[1] *= rho[1];
+        if (stereo) omr[2] *= rho[1];
     }
     double *ja = A.JA + 9 * (size_t)k, *jb = A.JB + 18 * (size_t)k;
+#pragma unroll
     for (int i = 0; i < 9; ++i) ja[i] = Ja[i];
+#pragma unroll
     for (int i = 0; i < 18; ++i) jb[i] = Jb[i];
     A.Wr[3 * (size_t)k] = omr[0]; A.Wr[3 * (size_t)k + 1] = omr[1]; A.Wr[3 * (size_t)k + 2] = omr[2];
     A.wo[k] = wo;
     if (A.k_ph[k] >= 0) {
         double *h = A.Hpl + 18 * (size_t)k;
+#pragma unroll
         for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
-                double t = 0;
-                for (int d = 0; d < D; ++d) t += Jb[d * 6 + r] * wo * Ja[d * 3 + c];
+                double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
+                t += Jb[6 + r] * wo * Ja[3 + c];
+                if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
                 h[r * 3 + c] = t;
             }
     }
@@ -829,19 +840,47 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K
     __syncthreads();
 }
 
+// kEpt > 0: every thread keeps its (<= kEpt) edges -- map point, observation, weight, residual, flags -- in
+// registers for the whole procedure (n <= 256 * kEpt); the 40 LM iterations then touch no global memory.
+// kEpt == 0: edges stay in global memory (any n).  Same arithmetic, same per-thread edge order either way.
+template <int kEpt>
 __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
 {
+    constexpr int EPT = kEpt > 0 ? kEpt : 1;
+    constexpr bool kReg = kEpt > 0;
+    double Xr[EPT][3], Or[EPT][3], Wr[EPT], Er[EPT][3];
+    uint8_t Sr[EPT], L1r[EPT], Rbr[EPT], Outr[EPT];
     extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 8 x 27
     __shared__ double qt[7], bk[7], xs[6];
     __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
     __shared__ int s_flag;
     const PoseProbDev P = probs[blockIdx.x];
     const int tid = threadIdx.x, n = P.n;
-    for (int e = tid; e < n; e += 256) {
-        P.level1[e] = 0;
-        P.robust[e] = 1;
-        P.outlier[e] = 0;
-        P.err[3 * e] = P.err[3 * e + 1] = P.err[3 * e + 2] = 0;
+    // edge loop: thread tid owns edges tid, tid + 256, ... (slot j); accessors pick registers or global memory
+#define PO_FOR_EDGES(j, e) for (int j = 0, e = tid; e < n && (!kReg || j < EPT); ++j, e += 256)
+    auto Xp = [&](int j, int e) -> const double * { return kReg ? Xr[j] : P.Xw + 3 * e; };
+    auto Op = [&](int j, int e) -> const double * { return kReg ? Or[j] : P.obs + 3 * e; };
+    auto Ep = [&](int j, int e) -> double * { return kReg ? Er[j] : P.err + 3 * e; };
+    auto Wv = [&](int j, int e) -> double { return kReg ? Wr[j] : P.w[e]; };
+    auto Sv = [&](int j, int e) -> int { return kReg ? Sr[j] : P.stereo[e]; };
+    auto L1 = [&](int j, int e) -> uint8_t & { return kReg ? L1r[j] : P.level1[e]; };
+    auto Rb = [&](int j, int e) -> uint8_t & { return kReg ? Rbr[j] : P.robust[e]; };
+    auto Ou = [&](int j, int e) -> uint8_t & { return kReg ? Outr[j] : P.outlier[e]; };
+#pragma unroll EPT
+    PO_FOR_EDGES(j, e) {
+        if (kReg) {
+            for (int k = 0; k < 3; ++k) {
+                Xr[j][k] = P.Xw[3 * e + k];
+                Or[j][k] = P.obs[3 * e + k];
+            }
+            Wr[j] = P.w[e];
+            Sr[j] = P.stereo[e];
+        }
+        L1(j, e) = 0;
+        Rb(j, e) = 1;
+        Ou(j, e) = 0;
+        double *er0 = Ep(j, e);
+        er0[0] = er0[1] = er0[2] = 0;
     }
     if (tid < 7) qt[tid] = P.pose_in[tid];
     __syncthreads();
@@ -855,14 +894,16 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
     // residuals of the active edges + robust chi2 (computeActiveErrors + activeRobustChi2)
     auto errors_chi2 = [&](double &chi_out) {
         double acc[1] = {0};
-        for (int e = tid; e < n; e += 256) {
-            if (P.level1[e]) continue;
+#pragma unroll EPT
+        PO_FOR_EDGES(j, e) {
+            if (L1(j, e)) continue;
             double er[3];
-            const int st = P.stereo[e];
-            po_edge_error(qt, P.Xw + 3 * e, P.obs + 3 * e, st, P, er);
-            P.err[3 * e] = er[0]; P.err[3 * e + 1] = er[1]; P.err[3 * e + 2] = er[2];
-            double c = edge_chi2(er, P.w[e], st ? 3 : 2);
-            if (P.robust[e]) {
+            const int st = Sv(j, e);
+            po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
+            double *ee = Ep(j, e);
+            ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
+            double c = edge_chi2(er, Wv(j, e), st ? 3 : 2);
+            if (Rb(j, e)) {
                 double rho[2];
                 robustify(c, st ? delta_s : delta_m, rho);
                 c = rho[0];
@@ -879,7 +920,8 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
         int n_active = 0;
         {
             double cnt[1] = {0}, out[1];
-            for (int e = tid; e < n; e += 256) cnt[0] += P.level1[e] ? 0.0 : 1.0;
+#pragma unroll EPT
+            PO_FOR_EDGES(j, e) cnt[0] += L1(j, e) ? 0.0 : 1.0;
             block_sum<1>(cnt, sh, out);
             n_active = (int)out[0];
         }
@@ -892,12 +934,14 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                 const double iniChi = currentChi;
                 // buildSystem: H (upper triangle, 21) + b (6)
                 double acc[27];
+#pragma unroll
                 for (int k = 0; k < 27; ++k) acc[k] = 0;
-                for (int e = tid; e < n; e += 256) {
-                    if (P.level1[e]) continue;
-                    const int st = P.stereo[e], D = st ? 3 : 2;
+#pragma unroll EPT
+                PO_FOR_EDGES(j, e) {
+                    if (L1(j, e)) continue;
+                    const int st = Sv(j, e), D = st ? 3 : 2;
                     double p[3];
-                    se3_map(qt, P.Xw + 3 * e, p);
+                    se3_map(qt, Xp(j, e), p);
                     const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
                     double J[18];
                     J[0] = x * y * invz_2 * P.fx;
@@ -918,23 +962,30 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                     J[15] = J[3];
                     J[16] = 0;
                     J[17] = J[5] - P.bf * invz_2;
-                    const double *er = P.err + 3 * e;
-                    const double w = P.w[e];
+                    const double *er = Ep(j, e);
+                    const double w = Wv(j, e);
                     double wo = w, r1 = 1.0;
-                    if (P.robust[e]) {
+                    if (Rb(j, e)) {
                         double rho[2];
                         robustify(edge_chi2(er, w, D), st ? delta_s : delta_m, rho);
                         r1 = rho[1];
                         wo = rho[1] * w;
                     }
+                    // static indices only (registers): the third row joins for stereo edges; 0 + a == a, so the
+                    // sums equal the d-loops of the reference order
+                    const bool st3 = D == 3;
                     int k = 0;
+#pragma unroll
                     for (int r = 0; r < 6; ++r) {
-                        double sacc = 0;
-                        for (int d = 0; d < D; ++d) sacc += J[d * 6 + r] * (w * er[d]);
+                        double sacc = J[r] * (w * er[0]);
+                        sacc += J[6 + r] * (w * er[1]);
+                        if (st3) sacc += J[12 + r] * (w * er[2]);
                         acc[21 + r] -= r1 * sacc;
+#pragma unroll
                         for (int c = r; c < 6; ++c, ++k) {
-                            double t = 0;
-                            for (int d = 0; d < D; ++d) t += J[d * 6 + r] * wo * J[d * 6 + c];
+                            double t = J[r] * wo * J[c];
+                            t += J[6 + r] * wo * J[6 + c];
+                            if (st3) t += J[12 + r] * wo * J[12 + c];
                             acc[k] += t;
                         }
                     }
@@ -944,7 +995,8 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                 if (tid == 0) {
                     if (i == 0) {
                         double maxDiagonal = 0.;
-                        const int di[6] = {0, 6, 11, 15, 18, 20};
+                        constexpr int di[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
                         for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
                         s_lambda = 1e-5 * maxDiagonal;
                         s_ni = 2;
@@ -958,37 +1010,55 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                 do {
                     if (tid == 0) {
                         for (int k = 0; k < 7; ++k) bk[k] = qt[k];
-                        // (H + lambda I) x = b by Cholesky; "not positive" -> the step is rejected
+                        // (H + lambda I) x = b by Cholesky; "not positive" -> the step is rejected.  All loops have
+                        // constant bounds and are unrolled so that L, y stay in registers (dynamic indexing would put
+                        // them in scratch memory, on the serial path of every LM step); after a non-positive pivot
+                        // the remaining arithmetic runs on but its result is discarded (pos = false).
                         double L[36];
-                        int k = 0;
-                        for (int r = 0; r < 6; ++r)
-                            for (int c = r; c < 6; ++c, ++k) L[c * 6 + r] = L[r * 6 + c] = Hb[k];
+                        {
+                            int k = 0;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                                for (int c = r; c < 6; ++c, ++k) L[c * 6 + r] = L[r * 6 + c] = Hb[k];
+                        }
+#pragma unroll
                         for (int d = 0; d < 6; ++d) L[d * 7] += s_lambda;
                         bool pos = true;
-                        for (int j = 0; j < 6 && pos; ++j) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
                             double dd = L[j * 6 + j];
+#pragma unroll
                             for (int m = 0; m < j; ++m) dd -= L[j * 6 + m] * L[j * 6 + m];
-                            if (!(dd > 0)) { pos = false; break; }
+                            if (!(dd > 0)) pos = false;
                             dd = sqrt(dd);
                             L[j * 6 + j] = dd;
+#pragma unroll
                             for (int r = j + 1; r < 6; ++r) {
                                 double sacc = L[r * 6 + j];
+#pragma unroll
                                 for (int m = 0; m < j; ++m) sacc -= L[r * 6 + m] * L[j * 6 + m];
                                 L[r * 6 + j] = sacc / dd;
                             }
                         }
                         if (pos) {
-                            double yv[6];
+                            double yv[6], xv[6];
+#pragma unroll
                             for (int r = 0; r < 6; ++r) {
                                 double sacc = Hb[21 + r];
+#pragma unroll
                                 for (int m = 0; m < r; ++m) sacc -= L[r * 6 + m] * yv[m];
                                 yv[r] = sacc / L[r * 6 + r];
                             }
+#pragma unroll
                             for (int r = 5; r >= 0; --r) {
                                 double sacc = yv[r];
-                                for (int m = r + 1; m < 6; ++m) sacc -= L[m * 6 + r] * xs[m];
-                                xs[r] = sacc / L[r * 6 + r];
+#pragma unroll
+                                for (int m = r + 1; m < 6; ++m) sacc -= L[m * 6 + r] * xv[m];
+                                xv[r] = sacc / L[r * 6 + r];
                             }
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) xs[r] = xv[r];
                         }
                         s_flag = pos ? 1 : 0;
                         double upd[6], T[7];
@@ -1004,6 +1074,7 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                         if (!s_flag) tempChi = 1.7976931348623157e308;
                         double r = s_currentChi - tempChi;
                         double scale = 0.;
+#pragma unroll
                         for (int j = 0; j < 6; ++j) scale += xs[j] * (s_lambda * xs[j] + Hb[21 + j]);
                         scale += 1e-3;
                         r /= scale;
@@ -1037,33 +1108,40 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
         }
         // outlier reclassification (:371-430)
         double bad[1] = {0}, outb[1];
-        for (int e = tid; e < n; e += 256) {
-            const int st = P.stereo[e];
-            if (P.outlier[e]) {
+#pragma unroll EPT
+        PO_FOR_EDGES(j, e) {
+            const int st = Sv(j, e);
+            if (Ou(j, e)) {
                 double er[3];
-                po_edge_error(qt, P.Xw + 3 * e, P.obs + 3 * e, st, P, er);
-                P.err[3 * e] = er[0]; P.err[3 * e + 1] = er[1]; P.err[3 * e + 2] = er[2];
+                po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
+                double *ee = Ep(j, e);
+                ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
             }
-            const float chi2 = (float)edge_chi2(P.err + 3 * e, P.w[e], st ? 3 : 2);
+            const float chi2 = (float)edge_chi2(Ep(j, e), Wv(j, e), st ? 3 : 2);
             if (chi2 > (st ? 7.815f : 5.991f)) {
-                P.outlier[e] = 1;
-                P.level1[e] = 1;
+                Ou(j, e) = 1;
+                L1(j, e) = 1;
                 bad[0] += 1.0;
             } else {
-                P.outlier[e] = 0;
-                P.level1[e] = 0;
+                Ou(j, e) = 0;
+                L1(j, e) = 0;
             }
-            if (it == 2) P.robust[e] = 0;
+            if (it == 2) Rb(j, e) = 0;
         }
         block_sum<1>(bad, sh, outb);
         nBad = (int)outb[0];
         if (n < 10) break;  // optimizer.edges().size() < 10
+    }
+    if (kReg) {
+#pragma unroll EPT
+        PO_FOR_EDGES(j, e) P.outlier[e] = Outr[j];
     }
     if (tid < 7) P.pose_out[tid] = qt[tid];
     if (tid == 0) {
         P.counts[0] = nBad;
         P.counts[1] = n - nBad;
     }
+#undef PO_FOR_EDGES
 }
 
 }  // namespace aos2
@@ -1568,8 +1646,13 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), H.host.size(), hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipMemcpyAsync(base + o_probs, dev.data(), sizeof(PoseProbDev) * n_problems, hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
-    hipLaunchKernelGGL(pose_optimization_kernel, dim3(n_problems), dim3(256), (256 * 28 + 8 * 27) * sizeof(double), q,
-                       (const PoseProbDev *)(base + o_probs));
+    int max_n = 0;
+    for (int i = 0; i < n_problems; ++i) max_n = std::max(max_n, problems[i].n);
+    const size_t po_lds = (256 * 28 + 8 * 27) * sizeof(double);
+    if (max_n <= 256 * 4)   // the usual case (a frame has <= ~1000 map-point matches): edges live in registers
+        hipLaunchKernelGGL(pose_optimization_kernel<4>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
+    else
+        hipLaunchKernelGGL(pose_optimization_kernel<0>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
     std::vector<double> poses(7 * (size_t)n_problems);
     std::vector<int32_t> cnts(2 * (size_t)n_problems);
