@@ -663,20 +663,18 @@ __device__ __forceinline__ Pick pick_best2(const Entry *__restrict__ ent, int cn
     return r;
 }
 
-// stage-B query stream: slots are read 64 at a time (one per lane) and broadcast with shuffles, the
-// entries of the next two queries are prefetched
+// stage-B query stream: the slot of query i + 2 is fetched with a wave-uniform (scalar) load and its first 64
+// entries with one vector load, two queries ahead of their use, so neither latency sits on the serial chain
 struct SlotStream {
     const QuerySlot *slots;
     const Entry *pool;
     int n, lane;
-    QuerySlot sreg, s1, s2;
+    QuerySlot s1, s2;
     Entry e1, e2;
     __device__ __forceinline__ QuerySlot at(int i) const
     {
-        QuerySlot r;
-        r.cnt = __shfl(sreg.cnt, i & 63);
-        r.ent_off = __shfl(sreg.ent_off, i & 63);
-        return r;
+        const int iu = __builtin_amdgcn_readfirstlane(i);  // tell the compiler the index is uniform
+        return slots[iu];
     }
     __device__ __forceinline__ Entry fetch(const QuerySlot &q) const
     {
@@ -687,10 +685,9 @@ struct SlotStream {
     __device__ __forceinline__ void init(const QuerySlot *sl, const Entry *pl, int n_, int lane_)
     {
         slots = sl; pool = pl; n = n_; lane = lane_;
-        sreg = s1 = s2 = QuerySlot{0, 0};
+        s1 = s2 = QuerySlot{0, 0};
         e1 = e2 = Entry{KEY_NONE, 0};
         if (n > 0) {
-            if (lane < n) sreg = slots[lane];
             s1 = at(0);
             e1 = fetch(s1);
             if (n > 1) {
@@ -707,10 +704,6 @@ struct SlotStream {
         s1 = s2;
         e1 = e2;
         if (i + 2 < n) {
-            if (((i + 2) & 63) == 0) {
-                sreg = QuerySlot{0, 0};
-                if (i + 2 + lane < n) sreg = slots[i + 2 + lane];
-            }
             s2 = at(i + 2);
             e2 = fetch(s2);
         }
