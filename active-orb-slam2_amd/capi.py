@@ -115,6 +115,8 @@ def lib():
                 L.aos2_matcher_search_by_projection_kf.argtypes = [vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_projection_reloc.argtypes = [vp, vp, vp, ci, vp, vp]
+            if hasattr(L, "aos2_frame_is_in_frustum"):
+                L.aos2_frame_is_in_frustum.argtypes = [vp, vp, cf, cf, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
             if hasattr(L, "aos2_matcher_search_for_initialization"):
                 L.aos2_matcher_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
             L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
@@ -628,6 +630,19 @@ class Matcher:
         match, n = np.zeros(max(p12["n_pts"], 1), np.int32), np.zeros(1, np.int32)
         _check(self.L.aos2_matcher_search_by_sim3(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), _p(match), _p(n)))
         return int(n[0]), match[: p12["n_pts"]]
+
+    def isInFrustum(self, frame, p, viewing_cos_limit=0.5):
+        """Frame::isInFrustum (src/Frame.cc:298-354) for all points of p -> dict with the aos2_proj_mp_t arrays"""
+        keep = []
+        pp = _fill_struct(_ProjPoints(), p, keep)
+        n = p["n_pts"]
+        iv = np.zeros(max(n, 1), np.uint8)
+        px, py, pr, vc = (np.zeros(max(n, 1), np.float32) for _ in range(4))
+        lv = np.zeros(max(n, 1), np.int32)
+        _check(self.L.aos2_frame_is_in_frustum(self.h, C.byref(pp), float(frame["min_x"]), float(frame["max_x"]),
+                                               float(frame["min_y"]), float(frame["max_y"]), int(frame["n_levels"]),
+                                               float(viewing_cos_limit), _p(iv), _p(px), _p(py), _p(pr), _p(lv), _p(vc)))
+        return dict(track_in_view=iv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pr[:n], pred_level=lv[:n], view_cos=vc[:n])
 
     def SearchForInitialization(self, f2, q, window_size=100):
         """SearchForInitialization :405-520; q = dict(desc1, octave1, angle1, prev_xy) -> (nmatches, vnMatches12)"""

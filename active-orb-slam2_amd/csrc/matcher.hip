@@ -1026,6 +1026,55 @@ __device__ __forceinline__ ProjSetup proj_gen_setup(const FrameDev &F, const Pro
     return S;
 }
 
+// Frame::isInFrustum (src/Frame.cc:298-354) for a batch of map points: one thread per point
+__global__ void is_in_frustum_kernel(ProjGenDev P, float min_x, float max_x, float min_y, float max_y, int n_levels,
+                                     float cos_limit, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr,
+                                     int32_t *pred_level, float *view_cos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_pts) return;
+    uint8_t ok = 0;
+    float u = 0, v = 0, ur = 0, vc = 0;
+    int lvl = 0;
+    const float pw[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+    float pc[3];
+    xform3(P.R, P.t, pw, pc);
+    if (!(pc[2] < 0.0f)) {
+        const float invz = __fdiv_rn(1.0f, pc[2]);
+        const float uu = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, pc[0]), invz), P.cx);
+        const float vv = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, pc[1]), invz), P.cy);
+        if (!(uu < min_x || uu > max_x) && !(vv < min_y || vv > max_y)) {
+            const float PO[3] = {__fsub_rn(pw[0], P.Ow[0]), __fsub_rn(pw[1], P.Ow[1]), __fsub_rn(pw[2], P.Ow[2])};
+            const float dist = norm3d(PO);
+            if (!(dist < P.min_dist[i] || dist > P.max_dist[i])) {
+                const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)P.normal[3 * i]),
+                                                       __dmul_rn((double)PO[1], (double)P.normal[3 * i + 1])),
+                                             __dmul_rn((double)PO[2], (double)P.normal[3 * i + 2]));
+                const float viewCos = (float)__ddiv_rn(dot, (double)dist);
+                if (!(viewCos < cos_limit)) {
+                    const float ratio = __fdiv_rn(P.max_dist[i], dist);
+                    const float lg = (float)log((double)ratio);
+                    int nScale = (int)ceilf(__fdiv_rn(lg, P.log_scale_factor));
+                    if (nScale < 0) nScale = 0;
+                    else if (nScale >= n_levels) nScale = n_levels - 1;
+                    ok = 1;
+                    u = uu;
+                    v = vv;
+                    ur = __fsub_rn(uu, __fmul_rn(P.bf, invz));
+                    lvl = nScale;
+                    vc = viewCos;
+                }
+            }
+        }
+    }
+    in_view[i] = ok;
+    proj_x[i] = u;
+    proj_y[i] = v;
+    proj_xr[i] = ur;
+    pred_level[i] = lvl;
+    view_cos[i] = vc;
+}
+
 // best candidate of a window for the independent modes: min over (dist << 20 | visiting position)
 __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGenDev &P, const Window &w, const Desc &dq,
                                                 const ProjSetup &S, int lane, uint32_t &payload)
@@ -2050,6 +2099,66 @@ int aos2_matcher_search_by_sim3(aos2_matcher_t *m, const aos2_frame_view_t *kf1,
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n1 * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(n_found, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_frame_is_in_frustum(aos2_matcher_t *m, const aos2_proj_points_t *p, float min_x, float max_x, float min_y,
+                             float max_y, int n_levels, float viewing_cos_limit, uint8_t *track_in_view, float *proj_x,
+                             float *proj_y, float *proj_xr, int32_t *pred_level, float *view_cos)
+{
+    if (!m || n_levels <= 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (!p || p->n_pts < 0 || (p->n_pts > 0 && (!p->pos || !p->max_dist || !p->min_dist || !p->normal)) ||
+        !(p->log_scale_factor > 0)) {
+        set_error("bad point set");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    if (p->n_pts == 0) return AOS2_OK;
+    if (!track_in_view || !proj_x || !proj_y || !proj_xr || !pred_level || !view_cos) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    const size_t n = (size_t)p->n_pts;
+    ProjGenDev P{};
+    {
+        P.n_pts = p->n_pts;
+        P.mode = 5;
+        const size_t o2 = A.push(p->pos, n * 12), o3 = A.push(p->max_dist, n * 4), o4 = A.push(p->min_dist, n * 4),
+                     o5 = A.push(p->normal, n * 12);
+        P.pos = reinterpret_cast<const float *>(o2); P.max_dist = reinterpret_cast<const float *>(o3);
+        P.min_dist = reinterpret_cast<const float *>(o4); P.normal = reinterpret_cast<const float *>(o5);
+        memcpy(P.R, p->R, sizeof(P.R)); memcpy(P.t, p->t, sizeof(P.t)); memcpy(P.Ow, p->Ow, sizeof(P.Ow));
+        P.fx = p->fx; P.fy = p->fy; P.cx = p->cx; P.cy = p->cy; P.bf = p->bf;
+        P.log_scale_factor = p->log_scale_factor;
+    }
+    const size_t oo = A.reserve(n * 24 + 64);
+    if ((st = A.upload())) return st;
+    uint8_t *base = m->arena.p;
+    P.pos = reinterpret_cast<const float *>(base + reinterpret_cast<size_t>(P.pos));
+    P.max_dist = reinterpret_cast<const float *>(base + reinterpret_cast<size_t>(P.max_dist));
+    P.min_dist = reinterpret_cast<const float *>(base + reinterpret_cast<size_t>(P.min_dist));
+    P.normal = reinterpret_cast<const float *>(base + reinterpret_cast<size_t>(P.normal));
+    float *d_px = A.dev<float>(oo), *d_py = d_px + n, *d_pr = d_py + n, *d_vc = d_pr + n;
+    int32_t *d_lv = reinterpret_cast<int32_t *>(d_vc + n);
+    uint8_t *d_iv = reinterpret_cast<uint8_t *>(d_lv + n);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(is_in_frustum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, P, min_x, max_x, min_y,
+                       max_y, n_levels, viewing_cos_limit, d_iv, d_px, d_py, d_pr, d_lv, d_vc);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(proj_x, d_px, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(proj_y, d_py, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(proj_xr, d_pr, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(view_cos, d_vc, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(pred_level, d_lv, n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(track_in_view, d_iv, n, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);

@@ -439,6 +439,16 @@ int aos2_matcher_search_by_projection_reloc(aos2_matcher_t *m, const aos2_frame_
                                             const aos2_proj_points_t *p, int orb_dist,
                                             int32_t *match_f, int32_t *nmatches);
 
+/* bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit)  src/Frame.cc:298-354, for all the local map
+ * points of Tracking::SearchLocalPoints in one call.  p: pos / max_dist / min_dist / normal per point (valid,
+ * desc, q_angle unused), R, t, Ow = mRcw, mtcw, mOw, bf = mbf; bounds = mnMinX.. (closed, :319-322).
+ * Outputs are the members the search reads: mbTrackInView, mTrackProjX, mTrackProjY, mTrackProjXR,
+ * mnTrackScaleLevel, mTrackViewCos -- i.e. the arrays of aos2_proj_mp_t. */
+int aos2_frame_is_in_frustum(aos2_matcher_t *m, const aos2_proj_points_t *p, float min_x, float max_x,
+                             float min_y, float max_y, int n_levels, float viewing_cos_limit,
+                             uint8_t *track_in_view, float *proj_x, float *proj_y, float *proj_xr,
+                             int32_t *pred_level, float *view_cos);
+
 /* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
  *         vector<int> &vnMatches12, int windowSize=10)  src/ORBmatcher.cc:405-520 (monocular bootstrap,
  * Tracking::MonocularInitialization).  f2 = view of F2 (grid, mvKeysUn, descriptors); F1 enters through

@@ -68,6 +68,8 @@ def lib():
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_fuse.argtypes = [C.c_void_p] * 4
+        L.orc_is_in_frustum.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float] + [C.c_void_p] * 6
+        L.orc_is_in_frustum.restype = None
         L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                     C.c_float, C.c_int, C.c_void_p]
         L.orc_fuse_sim3.argtypes = [C.c_void_p] * 4
@@ -400,6 +402,20 @@ def search_by_projection_reloc(f: dict, p: dict, orb_dist=100, check_orientation
     m = np.zeros(max(f["n_f"], 1), np.int32)
     n = lib().orc_search_by_projection_reloc(C.byref(fv), C.byref(pg), int(orb_dist), int(check_orientation), _p(m))
     return n, m[: f["n_f"]]
+
+
+def is_in_frustum(f: dict, p: dict, viewing_cos_limit=0.5):
+    """Frame::isInFrustum (src/Frame.cc:298-354) for all points of p against frame view f -> dict of the track members"""
+    keep = []
+    pg = _proj_gen(p, keep)
+    n = p["n_pts"]
+    iv = np.zeros(max(n, 1), np.uint8)
+    px, py, pr, vc = (np.zeros(max(n, 1), np.float32) for _ in range(4))
+    lv = np.zeros(max(n, 1), np.int32)
+    lib().orc_is_in_frustum(C.byref(pg), np.float32(f["min_x"]), np.float32(f["max_x"]), np.float32(f["min_y"]),
+                            np.float32(f["max_y"]), int(f["n_levels"]), np.float32(viewing_cos_limit), _p(iv), _p(px), _p(py),
+                            _p(pr), _p(lv), _p(vc))
+    return dict(track_in_view=iv[:n], proj_x=px[:n], proj_y=py[:n], proj_xr=pr[:n], pred_level=lv[:n], view_cos=vc[:n])
 
 
 def search_for_initialization(f2: dict, q: dict, window_size=100, nnratio=0.9, check_orientation=True):

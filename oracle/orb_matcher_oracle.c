@@ -1024,3 +1024,39 @@ int orc_search_for_initialization(const orc_frame_view_t *f2, int n1, const uint
     free(vIndices2);
     return nmatches;
 }
+
+/* Frame::isInFrustum(MapPoint*, viewingCosLimit) src/Frame.cc:298-354 for a batch of map points (the loop of
+ * Tracking::SearchLocalPoints).  R, t, Ow = mRcw, mtcw, mOw; bf = mbf.  Outputs = the mbTrackInView /
+ * mTrackProj* / mnTrackScaleLevel / mTrackViewCos members the search reads (SURVEY a12 inputs). */
+void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float min_y, float max_y, int n_levels,
+                       float viewing_cos_limit, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr,
+                       int32_t *pred_level, float *view_cos)
+{
+    for (int i = 0; i < p->n_pts; ++i) {
+        in_view[i] = 0;
+        proj_x[i] = proj_y[i] = proj_xr[i] = view_cos[i] = 0;
+        pred_level[i] = 0;
+        const float *P = p->pos + 3 * (size_t)i;
+        float Pc[3];
+        xform(p->R, p->t, P, Pc);
+        if (Pc[2] < 0.0f) continue;
+        const float invz = 1.0f / Pc[2];
+        const float u = p->fx * Pc[0] * invz + p->cx;
+        const float v = p->fy * Pc[1] * invz + p->cy;
+        if (u < min_x || u > max_x) continue;
+        if (v < min_y || v > max_y) continue;
+        float PO[3] = {P[0] - p->Ow[0], P[1] - p->Ow[1], P[2] - p->Ow[2]};
+        const float dist = norm3(PO);
+        if (dist < p->min_dist[i] || dist > p->max_dist[i]) continue;
+        const float *Pn = p->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
+        const float viewCos = (float)(dot / dist);
+        if (viewCos < viewing_cos_limit) continue;
+        in_view[i] = 1;
+        proj_x[i] = u;
+        proj_xr[i] = u - p->bf * invz;
+        proj_y[i] = v;
+        pred_level[i] = predict_scale(p->max_dist[i], dist, p->log_scale_factor, n_levels);
+        view_cos[i] = viewCos;
+    }
+}

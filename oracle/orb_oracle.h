@@ -210,6 +210,9 @@ int orc_search_by_sim3(const orc_frame_view_t *f1, const orc_frame_view_t *f2, c
 int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen_t *p, int orb_dist,
                                    int check_orientation, int32_t *match_f);
 
+void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float min_y, float max_y, int n_levels,
+                       float viewing_cos_limit, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr,
+                       int32_t *pred_level, float *view_cos);
 int orc_search_for_initialization(const orc_frame_view_t *f2, int n1, const uint8_t *desc1, const int32_t *octave1,
                                   const float *angle1, const float *prev_xy, int window_size, float nnratio,
                                   int check_orientation, int32_t *match12);

@@ -257,3 +257,33 @@ def test_search_for_initialization_vs_oracle(pkg, oracle, gpu):
     f2["n_f"], f2["n_levels"] = int(f2["n_f"]), int(f2["n_levels"])
     n, match = pkg.Matcher(0.9, True).SearchForInitialization(f2, q, 100)
     assert n == int(g["n"]) and (match == g["match"]).all()
+
+
+def test_is_in_frustum_feeds_search_local_points(pkg, oracle, gpu):
+    """Frame::isInFrustum (src/Frame.cc:298-354) on the device, and its outputs driving SearchByProjection(F, vpMP):
+    the Tracking::SearchLocalPoints chain equals the oracle chain."""
+    S = pkg.synth
+    m = pkg.Matcher(0.8, True)
+    seen = 0
+    for seed, cfg in ((0, "kitti"), (1, "tum"), (2, "euroc")):
+        f, p = S.synth_proj_gen_problem(60 + seed, n_f=1200, n_pts=2500, cfg=cfg)
+        for lim in (0.5, 0.9):
+            a, b = m.isInFrustum(f, p, lim), oracle.is_in_frustum(f, p, lim)
+            for k in a:
+                assert a[k].tobytes() == b[k].tobytes(), k
+            seen += int(a["track_in_view"].sum())
+        a = m.isInFrustum(f, p, 0.5)
+        # gates visible in the outputs: closed image bounds, cosine limit, level range
+        iv = a["track_in_view"] > 0
+        assert (a["view_cos"][iv] >= 0.5).all() and (a["pred_level"][iv] >= 0).all() and (a["pred_level"][iv] < f["n_levels"]).all()
+        assert (a["proj_x"][iv] >= f["min_x"]).all() and (a["proj_x"][iv] <= f["max_x"]).all()
+        mp = dict(n_mp=p["n_pts"], track_in_view=a["track_in_view"], pred_level=a["pred_level"], view_cos=a["view_cos"],
+                  proj_x=a["proj_x"], proj_y=a["proj_y"], proj_xr=a["proj_xr"], desc=p["desc"],
+                  has_obs=np.ones(p["n_pts"], np.uint8), th=np.float32(3.0), nnratio=np.float32(0.8))
+        n, match = m.SearchByProjection(f, mp, th=3.0)
+        on, om = oracle.search_by_projection_mp(f, mp)
+        assert n == on and (match == om).all() and n > 100
+    assert seen > 3000
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == p["n_pts"] else v) for k, v in p.items()}
+    empty["n_pts"] = 0
+    assert len(m.isInFrustum(f, empty)["proj_x"]) == 0

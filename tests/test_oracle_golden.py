@@ -464,3 +464,25 @@ def test_search_for_initialization_golden_and_stealing(oracle, pkg):
     n, m = oracle.search_for_initialization(v, dict(q, desc1=q["desc1"][:2], octave1=q["octave1"][:2], angle1=q["angle1"][:2],
                                                     prev_xy=q["prev_xy"][:2]), 20, 0.9, False)
     assert n == 1 and m.tolist() == [0, -1]
+
+
+def test_is_in_frustum_numpy_restatement(oracle, pkg):
+    """Frame::isInFrustum src/Frame.cc:298-354 against a float64 numpy restatement (agreement except at float boundaries)"""
+    f, p = pkg.synth.synth_proj_gen_problem(5, n_f=600, n_pts=1500)
+    r = oracle.is_in_frustum(f, p, 0.5)
+    R, t, Ow = p["R"].reshape(3, 3).astype(np.float64), p["t"].astype(np.float64), p["Ow"].astype(np.float64)
+    X = p["pos"].astype(np.float64)
+    pc = X @ R.T + t
+    u = p["fx"] * pc[:, 0] / pc[:, 2] + p["cx"]
+    v = p["fy"] * pc[:, 1] / pc[:, 2] + p["cy"]
+    PO = X - Ow
+    d = np.linalg.norm(PO, axis=1)
+    cosv = (PO * p["normal"]).sum(1) / d
+    ok = (pc[:, 2] >= 0) & (u >= f["min_x"]) & (u <= f["max_x"]) & (v >= f["min_y"]) & (v <= f["max_y"]) & \
+         (d >= p["min_dist"]) & (d <= p["max_dist"]) & (cosv >= 0.5)
+    assert (ok == (r["track_in_view"] > 0)).mean() > 0.998 and ok.sum() > 500
+    both = ok & (r["track_in_view"] > 0)
+    assert np.allclose(r["proj_x"][both], u[both], atol=2e-3) and np.allclose(r["view_cos"][both], cosv[both], atol=1e-5)
+    lvl = np.clip(np.ceil(np.log(p["max_dist"] / d) / p["log_scale_factor"]), 0, f["n_levels"] - 1)
+    assert (r["pred_level"][both] == lvl[both]).mean() > 0.998
+    assert np.allclose(r["proj_xr"][both], u[both] - p["bf"] / pc[both, 2], atol=2e-3)
