@@ -115,6 +115,9 @@ def lib():
                 L.aos2_matcher_search_by_projection_kf.argtypes = [vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp]
                 L.aos2_matcher_search_by_projection_reloc.argtypes = [vp, vp, vp, ci, vp, vp]
+            if hasattr(L, "aos2_frame_assign_features_to_grid"):
+                L.aos2_frame_assign_features_to_grid.argtypes = [vp, ci, vp, vp, cf, cf, cf, cf, vp, vp, C.POINTER(C.c_int32)]
+                L.aos2_frame_stereo_from_rgbd.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, cf, vp, vp]
             if hasattr(L, "aos2_frame_is_in_frustum"):
                 L.aos2_frame_is_in_frustum.argtypes = [vp, vp, cf, cf, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
             if hasattr(L, "aos2_matcher_search_for_initialization"):
@@ -630,6 +633,26 @@ class Matcher:
         match, n = np.zeros(max(p12["n_pts"], 1), np.int32), np.zeros(1, np.int32)
         _check(self.L.aos2_matcher_search_by_sim3(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), _p(match), _p(n)))
         return int(n[0]), match[: p12["n_pts"]]
+
+    def AssignFeaturesToGrid(self, kp_x, kp_y, min_x, min_y, grid_w_inv, grid_h_inv):
+        """Frame::AssignFeaturesToGrid (src/Frame.cc:259-274) -> (grid_off[3073], grid_idx)"""
+        kp_x, kp_y = np.ascontiguousarray(kp_x, np.float32), np.ascontiguousarray(kp_y, np.float32)
+        off = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(max(len(kp_x), 1), np.int32)
+        n = C.c_int32(0)
+        _check(self.L.aos2_frame_assign_features_to_grid(self.h, len(kp_x), _p(kp_x), _p(kp_y), float(min_x), float(min_y),
+                                                         float(grid_w_inv), float(grid_h_inv), _p(off), _p(idx), C.byref(n)))
+        return off, idx[: n.value]
+
+    def ComputeStereoFromRGBD(self, kp_x, kp_y, kpun_x, depth_img, mbf):
+        """Frame::ComputeStereoFromRGBD (src/Frame.cc:672-693) -> (mvuRight, mvDepth)"""
+        kp_x, kp_y, kpun_x = (np.ascontiguousarray(a, np.float32) for a in (kp_x, kp_y, kpun_x))
+        depth_img = np.ascontiguousarray(depth_img, np.float32)
+        ur, dp = np.zeros(max(len(kp_x), 1), np.float32), np.zeros(max(len(kp_x), 1), np.float32)
+        _check(self.L.aos2_frame_stereo_from_rgbd(self.h, len(kp_x), _p(kp_x), _p(kp_y), _p(kpun_x), _p(depth_img),
+                                                  depth_img.shape[1], depth_img.shape[0], depth_img.shape[1], float(mbf),
+                                                  _p(ur), _p(dp)))
+        return ur[: len(kp_x)], dp[: len(kp_x)]
 
     def isInFrustum(self, frame, p, viewing_cos_limit=0.5):
         """Frame::isInFrustum (src/Frame.cc:298-354) for all points of p -> dict with the aos2_proj_mp_t arrays"""

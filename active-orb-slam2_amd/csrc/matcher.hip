@@ -1026,6 +1026,81 @@ __device__ __forceinline__ ProjSetup proj_gen_setup(const FrameDev &F, const Pro
     return S;
 }
 
+// Frame::AssignFeaturesToGrid (src/Frame.cc:259-274, PosInGrid :411-424): one workgroup; cell of every feature,
+// per-cell counts by LDS atomics, exclusive scan, and a stable fill (rank of a feature inside its cell = number of
+// earlier features of the same cell, which is the push_back order of the reference)
+__global__ __launch_bounds__(256) void assign_grid_kernel(int n, const float *__restrict__ kp_x, const float *__restrict__ kp_y,
+                                                          float min_x, float min_y, float gwi, float ghi,
+                                                          int32_t *__restrict__ grid_off, int32_t *__restrict__ grid_idx)
+{
+    extern __shared__ int32_t gsh[];
+    constexpr int NC = GRID_COLS * GRID_ROWS;
+    int32_t *cnt = gsh;                                  // NC + 1
+    int16_t *cell = reinterpret_cast<int16_t *>(gsh + NC + 1);   // n
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c <= NC; c += 256) cnt[c] = 0;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp_x[i], min_x), gwi));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp_y[i], min_y), ghi));
+        const int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+        cell[i] = (int16_t)c;
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the NC counts, 256 at a time
+    for (int c0 = 0; c0 < NC; c0 += 256) {
+        const int c = c0 + tid;
+        const int v = c < NC ? cnt[c] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int excl = carry + woff + x - v;
+        if (c < NC) {
+            cnt[c] = excl;
+            grid_off[c] = excl;
+        }
+        __syncthreads();
+        if (tid == 255) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) grid_off[NC] = carry;
+    for (int i = tid; i < n; i += 256) {
+        const int c = cell[i];
+        if (c < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < i; ++j) rank += cell[j] == c;
+        grid_idx[cnt[c] + rank] = i;
+    }
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:672-693)
+__global__ void stereo_from_rgbd_kernel(int n, const float *__restrict__ kp_x, const float *__restrict__ kp_y,
+                                        const float *__restrict__ kpun_x, const float *__restrict__ depth_img, int stride,
+                                        float mbf, float *__restrict__ u_right, float *__restrict__ depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = depth_img[(size_t)(int)kp_y[i] * stride + (int)kp_x[i]];   // imDepth.at<float>(v, u): indices truncate
+    float ur = -1.0f, dp = -1.0f;
+    if (d > 0) {
+        dp = d;
+        ur = __fsub_rn(kpun_x[i], __fdiv_rn(mbf, d));
+    }
+    u_right[i] = ur;
+    depth[i] = dp;
+}
+
 // Frame::isInFrustum (src/Frame.cc:298-354) for a batch of map points: one thread per point
 __global__ void is_in_frustum_kernel(ProjGenDev P, float min_x, float max_x, float min_y, float max_y, int n_levels,
                                      float cos_limit, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr,
@@ -2099,6 +2174,71 @@ int aos2_matcher_search_by_sim3(aos2_matcher_t *m, const aos2_frame_view_t *kf1,
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n1 * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(n_found, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_frame_assign_features_to_grid(aos2_matcher_t *m, int n, const float *kp_x, const float *kp_y, float min_x,
+                                       float min_y, float grid_w_inv, float grid_h_inv, int32_t *grid_off, int32_t *grid_idx,
+                                       int32_t *n_in_grid)
+{
+    if (!m || n < 0 || !grid_off || (n > 0 && (!kp_x || !kp_y || !grid_idx))) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (n > 32000) {
+        set_error("AssignFeaturesToGrid: more than 32000 features");
+        return AOS2_ERR_CAPACITY;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    constexpr int NC = GRID_COLS * GRID_ROWS;
+    Arena A{m};
+    const size_t ox = A.push(kp_x, (size_t)n * 4), oy = A.push(kp_y, (size_t)n * 4);
+    const size_t oo = A.reserve((size_t)(NC + 1) * 4), oi = A.reserve((size_t)n * 4 + 4);
+    if ((st = A.upload())) return st;
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(assign_grid_kernel, dim3(1), dim3(256), (size_t)(NC + 1) * 4 + (size_t)n * 2 + 16, m->stream, n,
+                       A.dev<float>(ox), A.dev<float>(oy), min_x, min_y, grid_w_inv, grid_h_inv, A.dev<int32_t>(oo),
+                       A.dev<int32_t>(oi));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(grid_off, A.dev<int32_t>(oo), (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, m->stream));
+    if (n > 0) AOS2_HIP_CHECK(hipMemcpyAsync(grid_idx, A.dev<int32_t>(oi), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    if (n_in_grid) *n_in_grid = grid_off[NC];
+    return AOS2_OK;
+}
+
+int aos2_frame_stereo_from_rgbd(aos2_matcher_t *m, int n, const float *kp_x, const float *kp_y, const float *kpun_x,
+                                const float *depth_img, int w, int h, int stride, float mbf, float *u_right, float *depth)
+{
+    if (!m || n < 0 || (n > 0 && (!kp_x || !kp_y || !kpun_x || !depth_img || !u_right || !depth)) || w <= 0 || h <= 0 ||
+        stride < w) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (n == 0) return AOS2_OK;
+    for (int i = 0; i < n; ++i)
+        if (!((int)kp_x[i] >= 0 && (int)kp_x[i] < w && (int)kp_y[i] >= 0 && (int)kp_y[i] < h)) {
+            set_error("ComputeStereoFromRGBD: keypoint %d (%g, %g) outside the depth image", i, kp_x[i], kp_y[i]);
+            return AOS2_ERR_ARG;
+        }
+    int st = matcher_init(m);
+    if (st) return st;
+    Arena A{m};
+    const size_t ox = A.push(kp_x, (size_t)n * 4), oy = A.push(kp_y, (size_t)n * 4), ou = A.push(kpun_x, (size_t)n * 4);
+    const size_t od = A.push(depth_img, (size_t)stride * h * 4), oo = A.reserve((size_t)n * 8 + 8);
+    if ((st = A.upload())) return st;
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    hipLaunchKernelGGL(stereo_from_rgbd_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, n, A.dev<float>(ox),
+                       A.dev<float>(oy), A.dev<float>(ou), A.dev<float>(od), stride, mbf, A.dev<float>(oo), A.dev<float>(oo) + n);
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(u_right, A.dev<float>(oo), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    AOS2_HIP_CHECK(hipMemcpyAsync(depth, A.dev<float>(oo) + n, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);

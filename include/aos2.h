@@ -449,6 +449,20 @@ int aos2_frame_is_in_frustum(aos2_matcher_t *m, const aos2_proj_points_t *p, flo
                              uint8_t *track_in_view, float *proj_x, float *proj_y, float *proj_xr,
                              int32_t *pred_level, float *view_cos);
 
+/* void Frame::AssignFeaturesToGrid()  src/Frame.cc:259-274 (+ PosInGrid :411-424): mGrid[64][48] as CSR,
+ * cell = ix * 48 + iy, features of a cell in ascending index (= push_back order) -- the grid_off / grid_idx
+ * arrays of aos2_frame_view_t.  kp_x / kp_y = mvKeysUn[i].pt.  *n_in_grid = features that fall inside the grid. */
+int aos2_frame_assign_features_to_grid(aos2_matcher_t *m, int n, const float *kp_x, const float *kp_y,
+                                       float min_x, float min_y, float grid_w_inv, float grid_h_inv,
+                                       int32_t *grid_off, int32_t *grid_idx, int32_t *n_in_grid);
+
+/* void Frame::ComputeStereoFromRGBD(const cv::Mat &imDepth)  src/Frame.cc:672-693 (the RGB-D configs, e.g.
+ * TUM).  kp_x / kp_y = mvKeys[i].pt (distorted, index the depth image by truncation), kpun_x = mvKeysUn[i].pt.x,
+ * depth_img: CV_32F, `stride` floats per row.  Outputs mvuRight / mvDepth (-1 where the depth is not positive). */
+int aos2_frame_stereo_from_rgbd(aos2_matcher_t *m, int n, const float *kp_x, const float *kp_y,
+                                const float *kpun_x, const float *depth_img, int w, int h, int stride,
+                                float mbf, float *u_right, float *depth);
+
 /* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
  *         vector<int> &vnMatches12, int windowSize=10)  src/ORBmatcher.cc:405-520 (monocular bootstrap,
  * Tracking::MonocularInitialization).  f2 = view of F2 (grid, mvKeysUn, descriptors); F1 enters through

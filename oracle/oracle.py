@@ -68,6 +68,9 @@ def lib():
         L.orc_lba_solve.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_fuse.argtypes = [C.c_void_p] * 4
+        L.orc_assign_features_to_grid.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_stereo_from_rgbd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_stereo_from_rgbd.restype = None
         L.orc_is_in_frustum.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float] + [C.c_void_p] * 6
         L.orc_is_in_frustum.restype = None
         L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -402,6 +405,26 @@ def search_by_projection_reloc(f: dict, p: dict, orb_dist=100, check_orientation
     m = np.zeros(max(f["n_f"], 1), np.int32)
     n = lib().orc_search_by_projection_reloc(C.byref(fv), C.byref(pg), int(orb_dist), int(check_orientation), _p(m))
     return n, m[: f["n_f"]]
+
+
+def assign_features_to_grid(kp_x, kp_y, min_x, min_y, grid_w_inv, grid_h_inv):
+    """Frame::AssignFeaturesToGrid src/Frame.cc:259-274 -> (grid_off[3073], grid_idx)"""
+    kp_x, kp_y = np.ascontiguousarray(kp_x, np.float32), np.ascontiguousarray(kp_y, np.float32)
+    off = np.zeros(64 * 48 + 1, np.int32)
+    idx = np.zeros(max(len(kp_x), 1), np.int32)
+    n = lib().orc_assign_features_to_grid(len(kp_x), _p(kp_x), _p(kp_y), np.float32(min_x), np.float32(min_y),
+                                          np.float32(grid_w_inv), np.float32(grid_h_inv), _p(off), _p(idx))
+    return off, idx[:n]
+
+
+def stereo_from_rgbd(kp_x, kp_y, kpun_x, depth_img, mbf):
+    """Frame::ComputeStereoFromRGBD src/Frame.cc:672-693 -> (mvuRight, mvDepth)"""
+    kp_x, kp_y, kpun_x = (np.ascontiguousarray(a, np.float32) for a in (kp_x, kp_y, kpun_x))
+    depth_img = np.ascontiguousarray(depth_img, np.float32)
+    ur, dp = np.zeros(max(len(kp_x), 1), np.float32), np.zeros(max(len(kp_x), 1), np.float32)
+    lib().orc_stereo_from_rgbd(len(kp_x), _p(kp_x), _p(kp_y), _p(kpun_x), _p(depth_img), depth_img.shape[1], np.float32(mbf),
+                               _p(ur), _p(dp))
+    return ur[: len(kp_x)], dp[: len(kp_x)]
 
 
 def is_in_frustum(f: dict, p: dict, viewing_cos_limit=0.5):

@@ -1060,3 +1060,41 @@ void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float 
         view_cos[i] = viewCos;
     }
 }
+
+/* Frame::AssignFeaturesToGrid src/Frame.cc:259-274 with PosInGrid :411-424: mGrid as CSR (cell = ix*48+iy,
+ * features of a cell in ascending index = push_back order).  Returns the number of features inside the grid. */
+int orc_assign_features_to_grid(int n, const float *kp_x, const float *kp_y, float min_x, float min_y, float grid_w_inv,
+                                float grid_h_inv, int32_t *grid_off, int32_t *grid_idx)
+{
+    const int NC = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    int *cell = (int *)malloc(sizeof(int) * (n ? n : 1));
+    for (int c = 0; c <= NC; ++c) grid_off[c] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int posX = (int)roundf((kp_x[i] - min_x) * grid_w_inv);
+        const int posY = (int)roundf((kp_y[i] - min_y) * grid_h_inv);
+        cell[i] = (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) ? -1 : posX * FRAME_GRID_ROWS + posY;
+        if (cell[i] >= 0) grid_off[cell[i] + 1]++;
+    }
+    for (int c = 0; c < NC; ++c) grid_off[c + 1] += grid_off[c];
+    int *fill = (int *)calloc(NC, sizeof(int));
+    for (int i = 0; i < n; ++i)
+        if (cell[i] >= 0) grid_idx[grid_off[cell[i]] + fill[cell[i]]++] = i;
+    free(fill);
+    free(cell);
+    return grid_off[NC];
+}
+
+/* Frame::ComputeStereoFromRGBD src/Frame.cc:672-693: depth image CV_32F (stride in floats) */
+void orc_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x, const float *depth_img,
+                          int stride, float mbf, float *u_right, float *depth)
+{
+    for (int i = 0; i < n; ++i) {
+        u_right[i] = depth[i] = -1;
+        const float v = kp_y[i], u = kp_x[i];
+        const float d = depth_img[(size_t)(int)v * stride + (int)u];
+        if (d > 0) {
+            depth[i] = d;
+            u_right[i] = kpun_x[i] - mbf / d;
+        }
+    }
+}

@@ -210,6 +210,10 @@ int orc_search_by_sim3(const orc_frame_view_t *f1, const orc_frame_view_t *f2, c
 int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen_t *p, int orb_dist,
                                    int check_orientation, int32_t *match_f);
 
+int orc_assign_features_to_grid(int n, const float *kp_x, const float *kp_y, float min_x, float min_y, float grid_w_inv,
+                                float grid_h_inv, int32_t *grid_off, int32_t *grid_idx);
+void orc_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x, const float *depth_img,
+                          int stride, float mbf, float *u_right, float *depth);
 void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float min_y, float max_y, int n_levels,
                        float viewing_cos_limit, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr,
                        int32_t *pred_level, float *view_cos);

@@ -287,3 +287,36 @@ def test_is_in_frustum_feeds_search_local_points(pkg, oracle, gpu):
     empty = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == p["n_pts"] else v) for k, v in p.items()}
     empty["n_pts"] = 0
     assert len(m.isInFrustum(f, empty)["proj_x"]) == 0
+
+
+def test_frame_grid_and_rgbd_depth_vs_oracle(pkg, oracle, gpu):
+    """Frame::AssignFeaturesToGrid (src/Frame.cc:259-274) and Frame::ComputeStereoFromRGBD (:672-693)"""
+    S = pkg.synth
+    m = pkg.Matcher()
+    rng = np.random.default_rng(4)
+    for n, (w, h) in ((1000, (640, 480)), (2000, (1241, 376)), (1, (640, 480)), (0, (640, 480)), (5000, (752, 480))):
+        x = rng.uniform(-3, w + 3, n).astype(np.float32)      # undistorted keypoints can leave the image (:417)
+        y = rng.uniform(-3, h + 3, n).astype(np.float32)
+        if n > 10:
+            x[:5], y[:5] = x[5], y[5]                        # several features in one cell keep their index order
+        gwi, ghi = np.float32(64.0 / w), np.float32(48.0 / h)
+        off, idx = m.AssignFeaturesToGrid(x, y, 0.0, 0.0, gwi, ghi)
+        ooff, oidx = oracle.assign_features_to_grid(x, y, 0.0, 0.0, gwi, ghi)
+        assert (off == ooff).all() and (idx == oidx).all() and off[-1] == len(idx) <= n
+        # identical to the python builder the other tests use, on in-image points
+        if n >= 1000:
+            xi, yi = np.clip(x, 1, w - 1), np.clip(y, 1, h - 1)
+            o2, i2, _, _ = S.build_grid(xi, yi, np.float32(0), np.float32(0), np.float32(w), np.float32(h))
+            o3, i3 = m.AssignFeaturesToGrid(xi, yi, 0.0, 0.0, gwi, ghi)
+            assert (o2 == o3).all() and (i2 == i3).all()
+    depth = rng.uniform(0.3, 8.0, (480, 640)).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.2] = 0.0               # missing depth
+    kx = rng.uniform(0, 639.9, 1500).astype(np.float32)
+    ky = rng.uniform(0, 479.9, 1500).astype(np.float32)
+    kux = (kx + rng.normal(0, 0.3, 1500)).astype(np.float32)
+    ur, dp = m.ComputeStereoFromRGBD(kx, ky, kux, depth, 40.0)
+    our, odp = oracle.stereo_from_rgbd(kx, ky, kux, depth, 40.0)
+    assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
+    assert ((dp > 0) == (depth[ky.astype(int), kx.astype(int)] > 0)).all() and (ur[dp < 0] == -1).all()
+    with pytest.raises(pkg.AosError):
+        m.ComputeStereoFromRGBD(np.array([700.0], np.float32), np.array([10.0], np.float32), np.array([700.0], np.float32), depth, 40.0)
