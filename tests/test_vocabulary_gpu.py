@@ -38,7 +38,7 @@ def test_transform_golden(pkg, gpu):
 
 
 @pytest.mark.parametrize("k,L,levelsup,n", [(10, 3, 1, 1000), (10, 4, 2, 2000), (10, 5, 4, 1500), (4, 6, 4, 700), (18, 3, 2, 300),
-                                            (10, 3, 4, 500)])
+                                            (10, 3, 4, 500), (10, 6, 4, 2000)])  # the last one has ORBvoc's shape: 1 111 110 nodes
 def test_transform_vs_oracle(pkg, oracle, gpu, k, L, levelsup, n):
     S = pkg.synth
     voc = S.synth_vocabulary(100 + k + L, k, L)
