@@ -122,6 +122,8 @@ def lib():
                 L.aos2_frame_is_in_frustum.argtypes = [vp, vp, cf, cf, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
             if hasattr(L, "aos2_matcher_search_for_initialization"):
                 L.aos2_matcher_search_for_initialization.argtypes = [vp, vp, ci, vp, vp, vp, vp, ci, vp, vp]
+            if hasattr(L, "aos2_matcher_search_by_projection_batch"):
+                L.aos2_matcher_search_by_projection_batch.argtypes = [vp, vp, vp, ci, cf, vp, vp]
             L.aos2_matcher_search_by_projection.argtypes = [vp, vp, vp, cf, vp, vp]
             L.aos2_matcher_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, vp, vp]
         if hasattr(L, "aos2_lba_create"):
@@ -593,6 +595,21 @@ class Matcher:
         n = np.zeros(1, np.int32)
         _check(self.L.aos2_matcher_search_by_projection(self.h, C.byref(fv), C.byref(pm), float(th), _p(match), _p(n)))
         return int(n[0]), match[: f["n_f"]]
+
+    def SearchByProjectionBatch(self, frames, mps, th=3.0):
+        """n independent SearchByProjection(F, vpMapPoints, th) problems in one launch -> [(nmatches, match_f)]"""
+        keep = []
+        n = len(frames)
+        fa, pa = (_FrameView * n)(), (_ProjMp * n)()
+        outs = []
+        for i in range(n):
+            _fill_struct(fa[i], frames[i], keep)
+            _fill_struct(pa[i], mps[i], keep)
+            outs.append(np.zeros(max(frames[i]["n_f"], 1), np.int32))
+        ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        nm = np.zeros(n, np.int32)
+        _check(self.L.aos2_matcher_search_by_projection_batch(self.h, C.byref(fa), C.byref(pa), n, float(th), ptrs, _p(nm)))
+        return [(int(nm[i]), outs[i][: frames[i]["n_f"]]) for i in range(n)]
 
     def SearchByProjectionLast(self, cur, last, th, mono):
         keep = []

@@ -725,10 +725,10 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 }
 
 // SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129, stage A: one wave per map point
-__global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpDev P, float th, QuerySlot *slots,
-                                                             Entry *pool, int32_t *pool_used, int pool_cap)
+__device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
+                                                     Entry *pool, int32_t *pool_used, int pool_cap, int i)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     QuerySlot s{0, 0};
     if (P.track_in_view[i]) {
         const float rs = mp_radius(F, P, i, th);
@@ -753,11 +753,16 @@ __global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpD
     if (lane == 0) slots[i] = s;
 }
 
+__global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpDev P, float th, QuerySlot *slots,
+                                                             Entry *pool, int32_t *pool_used, int pool_cap)
+{
+    proj_mp_entries_body(F, P, th, slots, pool, pool_used, pool_cap, blockIdx.x);
+}
+
 // stage B
-__global__ __launch_bounds__(64) void proj_mp_resolve_kernel(FrameDev F, ProjMpDev P, float nnratio,
-                                                             const QuerySlot *__restrict__ slots,
-                                                             const Entry *__restrict__ pool, int32_t *match_f,
-                                                             int32_t *nmatches_out)
+__device__ __forceinline__ void proj_mp_resolve_body(const FrameDev &F, const ProjMpDev &P, float nnratio,
+                                                     const QuerySlot *__restrict__ slots, const Entry *__restrict__ pool,
+                                                     int32_t *match_f, int32_t *nmatches_out)
 {
     extern __shared__ uint8_t state[];
     const int lane = threadIdx.x;
@@ -788,6 +793,35 @@ __global__ __launch_bounds__(64) void proj_mp_resolve_kernel(FrameDev F, ProjMpD
         }
     }
     if (lane == 0) *nmatches_out = nmatches;
+}
+
+__global__ __launch_bounds__(64) void proj_mp_resolve_kernel(FrameDev F, ProjMpDev P, float nnratio,
+                                                             const QuerySlot *__restrict__ slots,
+                                                             const Entry *__restrict__ pool, int32_t *match_f,
+                                                             int32_t *nmatches_out)
+{
+    proj_mp_resolve_body(F, P, nnratio, slots, pool, match_f, nmatches_out);
+}
+
+// batched form: problem = blockIdx.y (stage A) / blockIdx.x (stage B); one entry pool shared through pool_used
+struct ProjMpItem {
+    FrameDev F;
+    ProjMpDev P;
+    QuerySlot *slots;
+    int32_t *match_f, *nmatches;
+};
+__global__ __launch_bounds__(64) void proj_mp_entries_batch_kernel(const ProjMpItem *__restrict__ items, float th, Entry *pool,
+                                                                   int32_t *pool_used, int pool_cap)
+{
+    const ProjMpItem &it = items[blockIdx.y];
+    if ((int)blockIdx.x >= it.P.n_mp) return;
+    proj_mp_entries_body(it.F, it.P, th, it.slots, pool, pool_used, pool_cap, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void proj_mp_resolve_batch_kernel(const ProjMpItem *__restrict__ items, float nnratio,
+                                                                   const Entry *__restrict__ pool)
+{
+    const ProjMpItem &it = items[blockIdx.x];
+    proj_mp_resolve_body(it.F, it.P, nnratio, it.slots, pool, it.match_f, it.nmatches);
 }
 
 struct ProjLastDev {
@@ -1995,6 +2029,95 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    return AOS2_OK;
+}
+
+int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_view_t *frames, const aos2_proj_mp_t *problems,
+                                            int n_problems, float th, int32_t *const *match_f, int32_t *nmatches)
+{
+    if (!m || !frames || !problems || n_problems <= 0 || !match_f || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st;
+    size_t pool_cap = 0;
+    int max_mp = 0, max_nf = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        if ((st = check_frame(&frames[i]))) return st;
+        if (problems[i].n_mp < 0 || !match_f[i]) {
+            set_error("bad projection problem %d", i);
+            return AOS2_ERR_ARG;
+        }
+        // entry budget: a search window rarely holds more than a few dozen features; 512 per map point (or the
+        // whole frame if smaller) is the bound here -- AOS2_ERR_CAPACITY if a problem ever needs more
+        pool_cap += (size_t)problems[i].n_mp * (size_t)std::min(frames[i].n_f, 512);
+        max_mp = std::max(max_mp, problems[i].n_mp);
+        max_nf = std::max(max_nf, frames[i].n_f);
+    }
+    if (pool_cap * sizeof(Entry) > ((size_t)1 << 31)) {
+        set_error("batched projection search needs a %zu-entry pool (> 2 GiB)", pool_cap);
+        return AOS2_ERR_ARG;
+    }
+    if ((st = matcher_init(m))) return st;
+    Arena A{m};
+    struct Off { size_t fo[12], o[8], om, on, oslots; };
+    std::vector<Off> offs(n_problems);
+    for (int i = 0; i < n_problems; ++i) {
+        const aos2_proj_mp_t *p = &problems[i];
+        Off &o = offs[i];
+        fill_frame(A, &frames[i], o.fo);
+        const size_t n = (size_t)p->n_mp;
+        o.o[0] = A.push(p->track_in_view, n); o.o[1] = A.push(p->desc, n * 32); o.o[2] = A.push(p->has_obs, n);
+        o.o[3] = A.push(p->pred_level, n * 4); o.o[4] = A.push(p->view_cos, n * 4); o.o[5] = A.push(p->proj_x, n * 4);
+        o.o[6] = A.push(p->proj_y, n * 4); o.o[7] = A.push(p->proj_xr, n * 4);
+        o.om = A.reserve((size_t)frames[i].n_f * 4 + 4);
+        o.on = A.reserve(8);
+        o.oslots = A.reserve((n + 1) * sizeof(QuerySlot));
+    }
+    const size_t oitems = A.reserve(sizeof(ProjMpItem) * (size_t)n_problems), oused = A.reserve(8);
+    if ((st = m->pool.alloc(pool_cap + 1))) return st;
+    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    std::vector<ProjMpItem> items(n_problems);
+    for (int i = 0; i < n_problems; ++i) {
+        const aos2_proj_mp_t *p = &problems[i];
+        const Off &o = offs[i];
+        ProjMpItem &it = items[i];
+        it.F = frame_dev(A, &frames[i], o.fo);
+        it.P = ProjMpDev{};
+        it.P.n_mp = p->n_mp;
+        it.P.track_in_view = A.dev<uint8_t>(o.o[0]); it.P.desc = A.dev<uint8_t>(o.o[1]); it.P.has_obs = A.dev<uint8_t>(o.o[2]);
+        it.P.pred_level = A.dev<int32_t>(o.o[3]); it.P.view_cos = A.dev<float>(o.o[4]); it.P.proj_x = A.dev<float>(o.o[5]);
+        it.P.proj_y = A.dev<float>(o.o[6]); it.P.proj_xr = A.dev<float>(o.o[7]);
+        it.slots = A.dev<QuerySlot>(o.oslots);
+        it.match_f = A.dev<int32_t>(o.om);
+        it.nmatches = A.dev<int32_t>(o.on);
+    }
+    memcpy(A.host.data() + oitems, items.data(), sizeof(ProjMpItem) * (size_t)n_problems);
+    if ((st = A.upload())) return st;
+    int32_t *d_used = A.dev<int32_t>(oused);
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+    if (max_mp > 0)
+        hipLaunchKernelGGL(proj_mp_entries_batch_kernel, dim3(max_mp, n_problems), dim3(64), 0, m->stream,
+                           A.dev<ProjMpItem>(oitems), th, reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+    hipLaunchKernelGGL(proj_mp_resolve_batch_kernel, dim3(n_problems), dim3(64), (size_t)max_nf + 16, m->stream,
+                       A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
+    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+    std::vector<int32_t> used(1);
+    AOS2_HIP_CHECK(hipMemcpyAsync(used.data(), d_used, 4, hipMemcpyDeviceToHost, m->stream));
+    for (int i = 0; i < n_problems; ++i) {
+        if (frames[i].n_f > 0)
+            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[i], items[i].match_f, (size_t)frames[i].n_f * 4, hipMemcpyDeviceToHost, m->stream));
+        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[i], items[i].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+    AOS2_HIP_CHECK(hipGetLastError());
+    (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
+    if ((size_t)used[0] > pool_cap) {
+        set_error("batched projection search: the search windows hold %d entries, more than the %zu budgeted; "
+                  "use aos2_matcher_search_by_projection per frame", used[0], pool_cap);
+        return AOS2_ERR_CAPACITY;
+    }
     return AOS2_OK;
 }
 

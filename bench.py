@@ -151,6 +151,10 @@ def main():
             m2.SearchByProjection(f, mp, th=3.0)
             extra["search_by_projection_1500mp_wall_ms"] = (time.perf_counter() - tb) * 1e3
             extra["search_by_projection_1500mp_device_ms"] = m2.last_device_ms()
+            pb = [S.synth_proj_mp_problem(700 + i) for i in range(64)]
+            m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
+            m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
+            extra["search_by_projection_64frames_1500mp_device_ms"] = m2.last_device_ms()
             prob = S.synth_lba_problem(0)
             ba = pkg.LocalBA(device=local_rank)
             ba.LocalBundleAdjustment(prob)

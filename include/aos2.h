@@ -364,6 +364,14 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
                                       const aos2_proj_mp_t *p, float th, int32_t *match_f,
                                       int32_t *nmatches);
 
+/* The same search for `n_problems` independent (frame, local map points) problems in one launch (one
+ * greedy-resolve wave per frame, all frames in flight together): replaying or relocalising many frames.
+ * match_f[i] has frames[i].n_f entries.  The candidate-entry pool is budgeted at 512 features per search
+ * window; AOS2_ERR_CAPACITY if the windows of a batch hold more (then call the per-frame entry point). */
+int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_view_t *frames,
+                                            const aos2_proj_mp_t *problems, int n_problems, float th,
+                                            int32_t *const *match_f, int32_t *nmatches);
+
 typedef struct {
     int32_t n_last;
     const uint8_t *last_valid;  /* LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] */

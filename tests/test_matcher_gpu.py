@@ -320,3 +320,19 @@ def test_frame_grid_and_rgbd_depth_vs_oracle(pkg, oracle, gpu):
     assert ((dp > 0) == (depth[ky.astype(int), kx.astype(int)] > 0)).all() and (ur[dp < 0] == -1).all()
     with pytest.raises(pkg.AosError):
         m.ComputeStereoFromRGBD(np.array([700.0], np.float32), np.array([10.0], np.float32), np.array([700.0], np.float32), depth, 40.0)
+
+
+def test_search_by_projection_batch_equals_single(pkg, oracle, gpu):
+    """n frames in one launch give exactly the per-frame results (and the oracle's)"""
+    S = pkg.synth
+    probs = [S.synth_proj_mp_problem(200 + s, n_f=900 + 37 * s, n_mp=1200 + 50 * s, th=3.0) for s in range(12)]
+    frames, mps = [p[0] for p in probs], [p[1] for p in probs]
+    m = pkg.Matcher(float(mps[0]["nnratio"]), True)
+    res = m.SearchByProjectionBatch(frames, mps, th=3.0)
+    ms_batch = m.last_device_ms()
+    for (f, mp), (n, match) in zip(probs, res):
+        on, om = oracle.search_by_projection_mp(f, mp)
+        assert n == on and (match == om).all()
+    n1, m1 = m.SearchByProjection(frames[0], mps[0], th=3.0)
+    assert n1 == res[0][0] and (m1 == res[0][1]).all()
+    assert ms_batch < 6 * m.last_device_ms()        # 12 frames cost far less than 12 single calls
