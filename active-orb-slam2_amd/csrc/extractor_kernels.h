@@ -53,14 +53,23 @@ void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *
                     size_t dense_stride, int32_t *level_off, int batch, hipStream_t st);
 // LDS working set of one octree job with n candidates and target N (OctCompact layout in
 // octree_kernel: packed candidates | perm | tmp | 16-byte node arena | two pairs arrays)
-__host__ __device__ inline int oct_lds_nodes(int N) { return 3 * N + 96; }
-__host__ __device__ inline int oct_lds_pairs(int N) { return N + 64; }
+__host__ __device__ inline int oct_lds_nodes(int N) { return 2 * N + 96; }   // ~1.4 N nodes are created in practice
+__host__ __device__ inline int oct_lds_pairs(int N) { return N + 32; }
 __host__ __device__ inline size_t oct_lds_bytes(int n, int N)
 {
     const size_t ncand = (size_t)((n + 3) & ~3);
     return ncand * 8 + (size_t)oct_lds_nodes(N) * 16 + (size_t)oct_lds_pairs(N) * 16;
 }
 
+// LDS slices of the one-workgroup-per-image octree kernel (one wave per level)
+struct OctImageLayout {
+    int off[16], bytes[16];
+    int total;
+};
+int prepare_octree_image_kernel(int total_lds);
+void launch_octree_image(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+                         int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                         int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st);
 void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
                    int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                    int32_t *sel_level_cnt, int cap_level, int lds_bytes, hipStream_t st);

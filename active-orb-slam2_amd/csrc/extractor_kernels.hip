@@ -453,17 +453,14 @@ namespace aos2 {
 #endif
 static_assert(sizeof(OctNode16) == 16, "oct_lds_bytes() assumes 16-byte compact nodes");
 
-__global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
-                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
-                              int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
-                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes)
+// one (image, level) job, executed by ONE wave (lane = threadIdx.x & 63) over the LDS slice [lds, lds + lds_bytes)
+__device__ __forceinline__ void octree_job(int b, int l, const uint32_t *__restrict__ dense, size_t dense_stride,
+                                           const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+                                           int n_levels, const OctDevScratch &scr, uint32_t *__restrict__ sel,
+                                           size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level,
+                                           uint32_t *oct_lds, int lds_bytes)
 {
-    // one wave per job: the tree/list control flow is wave-uniform, the key loops are wave-parallel.
-    // Jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones fill in.
-    extern __shared__ uint32_t oct_lds[];
-    const int job = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int l = job / batch, b = job - l * batch;
+    const int lane = threadIdx.x & 63;
     const int32_t *lo = level_off + (size_t)b * (n_levels + 1);
     const int beg = lo[l], n = lo[l + 1] - lo[l];
     const uint32_t *cand = dense + (size_t)b * dense_stride + beg;
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
         const int mn = oct_lds_nodes(lv.nfeat), mp = oct_lds_pairs(lv.nfeat);
         int32_t *pairs_l = reinterpret_cast<int32_t *>(nodes_l + mn);
         for (int i = lane; i < n; i += 64) c_l[i] = cand[i];
-        __syncthreads();
+        octdetail::coop_sync();
         const OctCandsPacked C{c_l};
         const OctScratchT<OctCompact> S{nodes_l, perm_l, tmp_l, pairs_l, pairs_l + 2 * mp, mn, mp};
         nk = distribute_octree<WaveCoop, OctCompact>(C, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
@@ -502,7 +499,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
             ys[i] = (int16_t)((c >> 12) & 0xfff);
             sc[i] = (uint8_t)(c >> 24);
         }
-        __syncthreads();
+        octdetail::coop_sync();
         OctScratch S;
         S.nodes = scr.nodes + no;
         S.perm = scr.perm + co;
@@ -514,8 +511,39 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
         nk = distribute_octree<WaveCoop>(xs, ys, sc, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
     }
     if (n <= 0) nk = 0;
+    octdetail::coop_sync();
     for (int k = lane; k < nk; k += 64) out[k] = cand[idx[k]];
     if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = nk;
+}
+
+// one wave per job; jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones
+// fill in.  Every workgroup reserves the level-0 working set.
+__global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
+                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+                              int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
+                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes)
+{
+    extern __shared__ uint32_t oct_lds[];
+    const int job = blockIdx.x;
+    const int l = job / batch, b = job - l * batch;
+    octree_job(b, l, dense, dense_stride, level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, oct_lds,
+               lds_bytes);
+}
+
+// one workgroup per image, one wave per level, each with its own LDS slice sized for that level: the LDS
+// reservation matches the jobs (the per-job kernel reserves the level-0 size for every level, which halves the
+// number of resident jobs), so all (image, level) jobs of a 256-image batch are resident at once.  The waves are
+// independent (wave-local fences only).
+__global__ __launch_bounds__(1024) void octree_image_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
+                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+                              int n_levels, OctDevScratch scr, uint32_t *__restrict__ sel, size_t sel_stride,
+                              int32_t *__restrict__ sel_level_cnt, int cap_level, OctImageLayout lay)
+{
+    extern __shared__ uint32_t oct_lds[];
+    const int l = threadIdx.x >> 6;
+    if (l >= n_levels) return;
+    octree_job(blockIdx.x, l, dense, dense_stride, level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
+               oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,6 +775,19 @@ void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *le
     const int jobs = batch * n_levels;
     hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), (size_t)lds_bytes, st, dense, dense_stride, level_off,
                        levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lds_bytes);
+}
+
+int prepare_octree_image_kernel(int total_lds)
+{
+    return (int)hipFuncSetAttribute((const void *)octree_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, total_lds);
+}
+
+void launch_octree_image(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+                         int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                         int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st)
+{
+    hipLaunchKernelGGL(octree_image_kernel, dim3(batch), dim3(64 * n_levels), (size_t)lay.total, st, dense, dense_stride,
+                       level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
 }
 
 void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

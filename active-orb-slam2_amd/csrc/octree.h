@@ -128,11 +128,37 @@ namespace octdetail {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline int coop_lane() { return (int)(threadIdx.x & 63); }
-__device__ inline void coop_sync() { __syncthreads(); }  // single-wave workgroup: waitcnt + barrier
+// wave-local fence: the memory operations of one wave complete in order, so waiting for them (and keeping the
+// compiler from reordering) is all a one-wave job needs; no workgroup barrier, so several independent jobs can
+// share a workgroup
+__device__ inline void coop_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 __device__ inline unsigned long long coop_ballot(bool p) { return __ballot(p); }
 __device__ inline int coop_popc(unsigned long long m) { return __popcll(m); }
+__device__ inline int coop_shfl(int v, int src) { return __shfl(v, src); }
+__device__ inline int coop_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ inline int coop_excl_scan(int v)  // exclusive prefix sum over the lanes
+{
+    const int lane = coop_lane();
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    return x - v;
+}
+__device__ inline int coop_ffs(unsigned long long m) { return __ffsll((long long)m) - 1; }
 #else
 inline int coop_lane() { return 0; }
+inline int coop_ffs(unsigned long long m) { return __builtin_ffsll((long long)m) - 1; }
+inline int coop_shfl(int v, int) { return v; }
+inline int coop_sum(int v) { return v; }
+inline int coop_excl_scan(int) { return 0; }
 inline void coop_sync() {}
 inline unsigned long long coop_ballot(bool p) { return p ? 1ull : 0ull; }
 inline int coop_popc(unsigned long long m) { return __builtin_popcountll(m); }
@@ -481,7 +507,139 @@ AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, 
                 pair_sort_to<Coop>(cur, nprev, prv);
                 OCT_TICK(2);  // sort
                 OCT_COUNT(10, nprev);
-                for (int j = nprev - 1; j >= 0; --j) {
+                int j_start = nprev - 1;
+                if (Coop::kWave) {
+                    // Device: the divides of this round are independent except for the stop test "size >= N after a
+                    // divide".  Up to 64 nodes of the sorted order are taken together, ONE NODE PER LANE: every lane
+                    // counts the quadrants of its node's <= 64 keys; a prefix sum of the leaf increments (non-empty
+                    // children - 1) in processing order gives the exact node at which the sequential loop would
+                    // break; the lanes up to it then do the stable partition, the four child records, the list
+                    // links and the pair records, all placed by prefix sums in the order the sequential loop would
+                    // have produced.  A divided parent is not unlinked but marked dead (cnt = -1); the final walk
+                    // skips it.
+                    const int lane = coop_lane();
+                    while (j_start >= 12 && L.size < N) {   // a batch costs about as much as a dozen one-at-a-time divides
+                        const int K0 = j_start + 1 < 64 ? j_start + 1 : 64;
+                        const bool cand = lane < K0;
+                        const int id = cand ? prv[2 * (j_start - lane) + 1] : 0;
+                        const Node p = L.nodes[id];
+                        const int pcnt = cand ? (int)p.cnt : 0;
+                        if (coop_ballot(pcnt > 64) != 0ull) break;  // a crowded node: the one-at-a-time loop below takes over
+                        const int hx = (p.x1 - p.x0 + 1) / 2, hy = (p.y1 - p.y0 + 1) / 2;
+                        const int mx = p.x0 + hx, my = p.y0 + hy;
+                        int cq[4] = {0, 0, 0, 0};
+                        unsigned long long qbits_lo = 0, qbits_hi = 0;   // quadrant of key i in bits 2i, 2i+1 (i < 64)
+                        for (int i = 0; i < pcnt; i += 4) {               // 4 keys per step: independent LDS reads
+                            int kk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) kk[u] = i + u < pcnt ? (int)perm[p.beg + i + u] : -1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (kk[u] < 0) continue;
+                                const int q = (C.x(kk[u]) < mx ? 0 : 1) + (C.y(kk[u]) < my ? 0 : 2);
+                                cq[0] += q == 0; cq[1] += q == 1; cq[2] += q == 2; cq[3] += q == 3;
+                                const int ii = i + u;
+                                if (ii < 32) qbits_lo |= (unsigned long long)q << (2 * ii); else qbits_hi |= (unsigned long long)q << (2 * (ii - 32));
+                            }
+                        }
+                        const int grow = cand ? (cq[0] > 0) + (cq[1] > 0) + (cq[2] > 0) + (cq[3] > 0) - 1 : 0;
+                        const int incl = coop_excl_scan(grow) + grow;
+                        // first lane after whose divide the list holds >= N leaves: the sequential loop breaks there
+                        const unsigned long long hit = coop_ballot(cand && L.size + incl >= N);
+                        const int K = hit ? (int)coop_ffs(hit) + 1 : K0;
+                        const bool act = lane < K;
+                        if (L.n_alloc + 4 * K > L.cap || ncur + 4 * K > S.max_pairs) return -2;
+                        const int pn = act ? pcnt : 0;
+                        int w0 = p.beg, w1 = w0 + cq[0], w2 = w1 + cq[1], w3 = w2 + cq[2];
+                        const int b0 = w0, b1 = w1, b2 = w2, b3 = w3;
+                        for (int i = 0; i < pn; i += 4) {   // the quadrants are remembered: only the keys are re-read
+                            int kk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) kk[u] = i + u < pn ? (int)perm[p.beg + i + u] : -1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (kk[u] < 0) continue;
+                                const int ii = i + u;
+                                const int q = (int)((ii < 32 ? qbits_lo >> (2 * ii) : qbits_hi >> (2 * (ii - 32))) & 3ull);
+                                const int w = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : w3;
+                                tmp[w] = (Idx)kk[u];
+                                w0 += q == 0; w1 += q == 1; w2 += q == 2; w3 += q == 3;
+                            }
+                        }
+                        coop_sync();
+                        for (int i = 0; i < pn; i += 4) {
+                            int kk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) kk[u] = i + u < pn ? (int)tmp[p.beg + i + u] : 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (i + u < pn) perm[p.beg + i + u] = (Idx)kk[u];
+                        }
+                        // children: arena slots in creation order (4 per divide, n1..n4)
+                        const int base = L.n_alloc + 4 * lane;
+                        const int cb[4] = {b0, b1, b2, b3};
+                        // list: push_front of the non-empty children in the order n1..n4.  first = first pushed
+                        // (deepest of the group), last = last pushed (front of the group)
+                        int first = -1, last = -1, npush = 0;
+                        for (int q = 0; q < 4; ++q)
+                            if (act && cq[q] > 0) {
+                                if (first < 0) first = base + q;
+                                last = base + q;
+                                npush++;
+                            }
+                        const int below = coop_shfl(last, lane > 0 ? lane - 1 : 0);    // front of the previous lane's group
+                        const int above = coop_shfl(first, lane + 1 < 64 ? lane + 1 : 63);  // bottom of the next lane's group
+                        const int old_head = L.head;
+                        if (act) {
+                            int prev_pushed = -1;  // the child pushed just before (it sits right behind in the list)
+                            for (int q = 0; q < 4; ++q) {
+                                Node &n = L.nodes[base + q];
+                                n.x0 = (q & 1) ? (int16_t)mx : p.x0;
+                                n.x1 = (q & 1) ? p.x1 : (int16_t)mx;
+                                n.y0 = (q & 2) ? (int16_t)my : p.y0;
+                                n.y1 = (q & 2) ? p.y1 : (int16_t)my;
+                                n.beg = (decltype(n.beg))cb[q];
+                                n.cnt = (decltype(n.cnt))cq[q];
+                                n.prev = n.next = -1;
+                                if (cq[q] > 0) {
+                                    // next (towards the tail): the previously pushed child, or for the first pushed one the
+                                    // front of the earlier lane's group / the old head
+                                    const int nx = prev_pushed >= 0 ? prev_pushed : (lane > 0 ? below : old_head);
+                                    n.next = (decltype(n.next))nx;
+                                    if (prev_pushed >= 0) L.nodes[prev_pushed].prev = (decltype(n.prev))(base + q);
+                                    prev_pushed = base + q;
+                                }
+                            }
+                            // front of my group: its prev is the bottom of the next lane's group (or -1 at the new head)
+                            L.nodes[last].prev = (decltype(p.prev))(lane + 1 < K ? above : -1);
+                            if (lane == 0 && old_head >= 0) L.nodes[old_head].prev = (decltype(p.prev))first;
+                            L.nodes[id].cnt = -1;  // dead parent
+                        }
+                        if (old_head < 0) L.tail = coop_shfl(first, 0);  // (cannot happen: the list is never empty here)
+                        // pair records of children with more than one key, in divide order then n1..n4
+                        int r = 0;
+                        for (int q = 0; q < 4; ++q) r += act && cq[q] > 1;
+                        const int eoff = ncur + coop_excl_scan(r);
+                        if (act) {
+                            int e = eoff;
+                            for (int q = 0; q < 4; ++q)
+                                if (cq[q] > 1) {
+                                    cur[2 * e] = cq[q];
+                                    cur[2 * e + 1] = base + q;
+                                    e++;
+                                }
+                        }
+                        ncur += coop_sum(r);
+                        L.head = coop_shfl(last, K - 1);
+                        L.size += coop_sum(act ? npush - 1 : 0);
+                        L.n_alloc += 4 * K;
+                        j_start -= K;
+                        OCT_COUNT(11, K);
+                        coop_sync();
+                    }
+                }
+                for (int j = j_start; j >= 0; --j) {
+                    if (L.size >= N) break;
                     const int id = prv[2 * j + 1];
                     int c[4], ccnt[4], nxt;
                     if (!divide<Coop, Tr>(L, id, c, ccnt, nxt, C, perm, tmp)) return -2;
@@ -525,10 +683,17 @@ AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, 
     } else {
         // list order -> array (uniform walk), then one lane per node
         int32_t *order = S.pairs_a;  // free at this point
-        for (int lit = L.head; lit >= 0; lit = L.nodes[lit].next) {
+        for (int lit = L.head; lit >= 0;) {
             if (nout >= cap || nout >= 2 * S.max_pairs) return -3;
-            order[nout++] = lit;
+            // branch-free on the node's state: only the `next` load sits on the pointer-chasing chain; a dead parent
+            // (cnt < 0, divided by a lane-parallel batch) is overwritten by the next live node
+            const int nx = L.nodes[lit].next;
+            const int live = L.nodes[lit].cnt >= 0;
+            order[nout] = lit;
+            nout += live;
+            lit = nx;
         }
+        OCT_TICK(5);  // list walk
         coop_sync();
         for (int j = coop_lane(); j < nout; j += 64) {
             const Node nd = L.nodes[order[j]];

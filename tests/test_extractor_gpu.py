@@ -118,6 +118,13 @@ def test_fallback_paths_equal_the_fast_paths(pkg, oracle, gpu, monkeypatch):
     monkeypatch.setenv("AOS2_OCT_LDS", "0")
     alt = [pkg.Extractor(nfeatures=2000)(im) for im in imgs]
     assert all(same(a, b) for a, b in zip(ref, alt))
+    # the one-workgroup-per-image octree kernel (opt-in) gives the same bits as the one-wave-per-job kernel
+    monkeypatch.delenv("AOS2_FAST_LIST")
+    monkeypatch.delenv("AOS2_OCT_LDS")
+    monkeypatch.setenv("AOS2_OCT_IMAGE", "1")
+    ex = pkg.Extractor(nfeatures=1000)
+    batch = pkg.synth.synth_batch(80, 6)
+    assert all(same(a, b) for a, b in zip(ex.extract_batch(batch), [pkg.Extractor(nfeatures=1000)(im) for im in batch]))
 
 
 def test_full_batch_properties(pkg, oracle, gpu):

@@ -18,7 +18,7 @@ v = np.array(out[:], dtype=np.float64)
 jobs = v[12]
 print("timing", {k: round(x, 3) for k, x in ex.last_timing().items()})
 print("level-0 jobs", jobs)
-names = ["roots+bucket", "main passes", "sort", "final divides", "best response"]
+names = ["roots+bucket", "main passes", "sort", "final divides", "best response", "list walk"]
 for i, nm in enumerate(names):
     print(f"  {nm:14s} {v[i] / jobs / 100.0:8.2f} us/job")   # wall_clock64 = 100 MHz
-print(f"  main divides/job {v[8]/jobs:.1f}  passes/job {v[9]/jobs:.2f}  sorted pairs/job {v[10]/jobs:.1f}  final divides/job {v[11]/jobs:.1f}  nodes/job {v[13]/jobs:.1f}")
+print(f"  main divides/job {v[8]/jobs:.1f}  passes/job {v[9]/jobs:.2f}  sorted pairs/job {v[10]/jobs:.1f}  final divides/job {v[11]/jobs:.1f}  nodes/job {v[13]/jobs:.1f}  walk steps/job {v[14]/jobs:.1f}")
