@@ -48,6 +48,12 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
     return v;
 }
 
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Level 0 of the pyramid (ComputePyramid, src/ORBextractor.cc:1107-1132) is the caller's image
 // itself: nothing is copied.  The 19-px REFLECT_101 frame the reference keeps around each level is
@@ -57,11 +63,20 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p)
 // cv::resize(INTER_LINEAR) 8UC1, level L-1 -> L (src/ORBextractor.cc:1120).  Fixed point,
 // 11-bit coefficients; the coefficient tables are built on the host exactly like OpenCV's
 // resize() does (float fx, two separately rounded shorts), so host and device cannot disagree.
-// One thread = 4 horizontally adjacent output pixels (one aligned 32-bit store).
+//
+// The kernel is integer-VALU bound (4 cycles per wave64 instruction for everything but add / logic / shift,
+// tools/microbench/valu_rate.hip), so it is organised around the instruction count per output pixel:
+//   * one lane = 4 horizontally adjacent output pixels (one aligned 32-bit store) x RS_BAND output rows;
+//   * the <= 8 source bytes the 4 outputs of a row need (scale <= 2) are ONE unaligned 64-bit load straight
+//     from L2 -- no LDS staging; all source rows of the band are requested before the first is used;
+//   * horizontal pass per source row: v_perm_b32 (pair of neighbours -> u16x2) + v_dot2_u32_u16 with the packed
+//     (a0, a1) table entry, 2 instructions per value, and each source row is evaluated once although two output
+//     rows use it; vertical pass: two v_mul_hi_u32 per value ((b << 16) * (r >> 4) >> 32 == (b * (r >> 4)) >> 16);
+//   * every lane of a wave works on the SAME band of rows (items are flattened over (image, column quad)), so
+//     the row bookkeeping is scalar and a level's ragged right edge costs no idle lanes.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_TILE_H = 16;                 // output rows per workgroup (4 per thread)
-constexpr int RS_ROWS = 2 * RS_TILE_H + 3;    // max source rows of a tile (scale <= 2.0)
-constexpr int RS_PITCH = 544;                 // max staged source bytes per row (256 outputs * scale 2.0 + slack)
+constexpr int RS_BAND = 8;    // output rows per lane
+constexpr int RS_NR = 16;     // max source rows of a band: ceil(7 * scale) + 2, scale <= 2.0
 
 __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__restrict__ src_base,
                                                            size_t src_img_stride, int src_pitch,
@@ -70,72 +85,84 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
                                                            const int *__restrict__ xofs,
                                                            const int *__restrict__ xab,
                                                            const int *__restrict__ yofs,
-                                                           const int *__restrict__ yab)
+                                                           const int *__restrict__ yab,
+                                                           int batch, int nquads, uint32_t inv_nquads)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[RS_ROWS * RS_PITCH];
-    const int b = blockIdx.z;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int dy0 = blockIdx.y * RS_TILE_H, dxb = blockIdx.x * 256;
-    const int dx0 = dxb + threadIdx.x * 4;
-    const uint8_t *sp = src_base + (size_t)b * src_img_stride;
-    uint8_t *dp = pyr + (size_t)b * pyr_stride + dst.off;
-    // source window of this output tile
-    const int dx_last = min(dxb + 255, dst.w - 1), dy_last = min(dy0 + RS_TILE_H - 1, dst.h - 1);
-    const int sx_min = xofs[dst.tab_x + dxb] & ~3;
-    const int sx_max = min(xofs[dst.tab_x + dx_last] + 1, src.w - 1);
-    const int sy_min = min(max(yofs[dst.tab_y + dy0], 0), src.h - 1);
-    const int sy_max = min(max(yofs[dst.tab_y + dy_last] + 1, 0), src.h - 1);
-    const int ndw = (sx_max - sx_min + 4) >> 2;
-    const int nrow = sy_max - sy_min + 1;
-    // per-thread tables: issued before the staging loop so their latency overlaps it (tables are padded to x4)
-    const bool col_ok = dx0 < dst.w;
-    const int4 xo = col_ok ? *reinterpret_cast<const int4 *>(xofs + dst.tab_x + dx0) : make_int4(0, 0, 0, 0);
-    const int4 xa = col_ok ? *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0) : make_int4(0, 0, 0, 0);
-    int ysrc[4], ycoef[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int dy = min(dy0 + threadIdx.y + 4 * j, dst.h - 1);
-        ysrc[j] = yofs[dst.tab_y + dy];
-        ycoef[j] = yab[dst.tab_y + dy];
+    const int lane = threadIdx.x & 63;
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const int dy0 = blockIdx.y * RS_BAND;
+    const int nout = min(RS_BAND, dst.h - dy0);   // >= 1
+    // lane l < nout keeps the y-table entries of output row dy0 + l (read back with v_readlane)
+    int ty = 0, tc = 0;
+    if (lane < nout) {
+        ty = yofs[dst.tab_y + dy0 + lane];
+        tc = yab[dst.tab_y + dy0 + lane];
     }
-    {
-        // linear item -> (row, dword) by an exact multiply-high division; 32-bit offsets
-        const uint8_t *win = sp + (size_t)sy_min * src_pitch + sx_min;
-        const uint32_t magic = 0xFFFFFFFFu / (uint32_t)ndw + 1u;  // exact for items < 2^16
-        const uint32_t total = (uint32_t)(nrow * ndw);
-        for (uint32_t i = tid; i < total; i += 256) {
-            const uint32_t r = __umulhi(i, magic), c = i - r * (uint32_t)ndw;
-            *reinterpret_cast<uint32_t *>(tile + r * RS_PITCH + 4 * c) = load_u32_unaligned(win + (r * (uint32_t)src_pitch + 4u * c));
-        }
-    }
-    __syncthreads();
-    if (!col_ok) return;
+    if (id >= (uint32_t)nquads * (uint32_t)batch) return;
+    const uint32_t img = __umulhi(id, inv_nquads);   // id / nquads, exact for id < 2^32 / nquads
+    const int dx0 = 4 * (int)(id - img * (uint32_t)nquads);
+    // x tables are padded to a multiple of 4 entries per level
+    const int4 xo = *reinterpret_cast<const int4 *>(xofs + dst.tab_x + dx0);
+    const int4 xa = *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0);
     const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
-    const int aas[4] = {xa.x, xa.y, xa.z, xa.w};
+    const uint32_t aas[4] = {(uint32_t)xa.x, (uint32_t)xa.y, (uint32_t)xa.z, (uint32_t)xa.w};
+    // 8-byte source window [start, start + 8) holds sx_k and sx_k + 1 of the 4 outputs; at the right edge the
+    // window is pulled inside the row and the neighbour selector repeats sx (its weight a1 is 0 there)
+    const int start = max(min(sxs[0], src.w - 8), 0);
+    uint32_t sel[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int dy = dy0 + threadIdx.y + 4 * j;
-        if (dy >= dst.h) break;
-        const int sy0 = min(max(ysrc[j], 0), src.h - 1) - sy_min;
-        const int sy1 = min(max(ysrc[j] + 1, 0), src.h - 1) - sy_min;
-        const int b0 = (int)(short)(ycoef[j] & 0xffff), b1 = (int)(short)(ycoef[j] >> 16);
-        const uint8_t *S0 = tile + sy0 * RS_PITCH - sx_min, *S1 = tile + sy1 * RS_PITCH - sx_min;
-        uint32_t out = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = (uint32_t)(sxs[k] - start), hi = sxs[k] + 1 < src.w ? lo + 1 : lo;
+        sel[k] = lo | (hi << 16) | 0x0c000c00u;   // v_perm_b32: byte 0 <- window[lo], byte 2 <- window[hi], bytes 1,3 <- 0
+    }
+    const uint8_t *sp = src_base + (size_t)img * src_img_stride + start;
+    uint8_t *dp = pyr + (size_t)img * pyr_stride + dst.off + dx0;
+    const uint32_t keep = dx0 + 4 <= dst.w ? 0xffffffffu : (1u << (8 * (dst.w - dx0))) - 1u;   // padding columns stay 0
+    // source rows of the band: every row of [r_first, r_last] is used (scale <= 2)
+    const int hmax = src.h - 1;
+    const int t_first = __builtin_amdgcn_readlane(ty, 0), t_last = __builtin_amdgcn_readlane(ty, nout - 1);
+    const int r_first = min(max(t_first, 0), hmax);
+    const int nrows = min(max(t_last + 1, 0), hmax) - r_first + 1;
+    uint2 win[RS_NR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int dx = dx0 + k;
-            if (dx < dst.w) {
-                const int sx = sxs[k];
-                const int sx1 = sx + 1 < src.w ? sx + 1 : sx;
-                const int a0 = (int)(short)(aas[k] & 0xffff), a1 = (int)(short)(aas[k] >> 16);
-                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                v = min(max(v, 0), 255);
-                out |= (uint32_t)v << (8 * k);
+    for (int c = 0; c < RS_NR / 4; ++c) {
+        if (4 * c < nrows) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = min(r_first + 4 * c + t, hmax);
+                __builtin_memcpy(&win[4 * c + t], sp + (size_t)((uint32_t)r * (uint32_t)src_pitch), 8);
             }
         }
-        *reinterpret_cast<uint32_t *>(dp + (size_t)dy * dst.pitch + dx0) = out;
+    }
+    uint32_t prev[4] = {0u, 0u, 0u, 0u}, cur[4] = {0u, 0u, 0u, 0u};
+    int j = 0;
+    int sy0 = 0, sy1 = min(max(t_first + 1, 0), hmax) - r_first, coef = __builtin_amdgcn_readlane(tc, 0);
+#pragma unroll
+    for (int i = 0; i < RS_NR; ++i) {
+        if (i >= nrows) continue;   // (uniform) not `break`: the loop must unroll completely, win[] is a register array
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            prev[k] = cur[k];
+            cur[k] = udot2_u16(__builtin_amdgcn_perm(win[i].y, win[i].x, sel[k]), aas[k], 0u) >> 4;
+        }
+        while (j < nout && sy1 == i) {
+            const uint32_t b0s = (uint32_t)coef << 16, b1s = (uint32_t)coef & 0xffff0000u;
+            const bool same = sy0 == i;   // bottom edge: both rows clamp to the last one
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t v = (__umulhi(b0s, same ? cur[k] : prev[k]) + __umulhi(b1s, cur[k]) + 2u) >> 2;   // <= 255
+                out |= v << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(dp + (uint32_t)(dy0 + j) * (uint32_t)dst.pitch) = out & keep;
+            ++j;
+            if (j < nout) {
+                const int t = __builtin_amdgcn_readlane(ty, j);
+                sy0 = min(max(t, 0), hmax) - r_first;
+                sy1 = min(max(t + 1, 0), hmax) - r_first;
+                coef = __builtin_amdgcn_readlane(tc, j);
+            }
+        }
     }
 }
 
@@ -152,6 +179,22 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
 // so no halo beyond the 3-px ring is needed and cells are independent.
 // The tile (cell + 3-px ring halo) is staged in LDS with coalesced 32-bit loads.
 // ---------------------------------------------------------------------------------------------
+// gfx950's packed 3-input IEEE maximum / minimum on f16 pairs, used on integers: a byte v is carried as the f16
+// bit pattern 0x0400 | v (exponent 1, mantissa v: a positive normal number, monotonic in v), so maximum3 / minimum3
+// of such patterns are the patterns of the integer max / min (checked exhaustively by tools/microbench/valu_rate.hip).
+__device__ __forceinline__ uint32_t pk_max3_h(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min3_h(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
 {
     // t points at the centre pixel inside the LDS tile
@@ -160,28 +203,23 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
     x[4] = t[3];           x[5] = t[-TP + 3];      x[6] = t[-2 * TP + 2];  x[7] = t[-3 * TP + 1];
     x[8] = t[-3 * TP];     x[9] = t[-3 * TP - 1];  x[10] = t[-2 * TP - 2]; x[11] = t[-TP - 3];
     x[12] = t[-3];         x[13] = t[TP - 3];      x[14] = t[2 * TP - 2];  x[15] = t[3 * TP - 1];
-    int mx1[16], mn1[16];
+    // Both polarities in one chain: low half carries x, high half 255 - x, so a packed max over an arc gives
+    // (max x, 255 - min x).  One v_mad_i32_i24 per ring pixel builds the pair: x * (1 - 65536) + 0x04FF0400.
+    uint32_t P[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        mx1[i] = max(x[i], x[(i + 1) & 15]);
-        mn1[i] = min(x[i], x[(i + 1) & 15]);
-    }
-    int mx2[16], mn2[16];
+    for (int i = 0; i < 16; ++i) P[i] = (uint32_t)(__mul24(x[i], -65535) + 0x04FF0400);
+    uint32_t M3[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        mx2[i] = max(mx1[i], mx1[(i + 2) & 15]);
-        mn2[i] = min(mn1[i], mn1[(i + 2) & 15]);
-    }
-    int minmax = 255, maxmin = 0;
+    for (int i = 0; i < 16; ++i) M3[i] = pk_max3_h(P[i], P[(i + 1) & 15], P[(i + 2) & 15]);
+    uint32_t M9[16];   // arc i .. i+8
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m8x = max(mx2[i], mx2[(i + 4) & 15]);
-        const int m8n = min(mn2[i], mn2[(i + 4) & 15]);
-        const int m9x = max(m8x, x[(i + 8) & 15]);
-        const int m9n = min(m8n, x[(i + 8) & 15]);
-        minmax = min(minmax, m9x);
-        maxmin = max(maxmin, m9n);
-    }
+    for (int i = 0; i < 16; ++i) M9[i] = pk_max3_h(M3[i], M3[(i + 3) & 15], M3[(i + 6) & 15]);
+    const uint32_t a0 = pk_min3_h(M9[0], M9[1], M9[2]), a1 = pk_min3_h(M9[3], M9[4], M9[5]), a2 = pk_min3_h(M9[6], M9[7], M9[8]);
+    const uint32_t a3 = pk_min3_h(M9[9], M9[10], M9[11]), a4 = pk_min3_h(M9[12], M9[13], M9[14]);
+    const uint32_t b0 = pk_min3_h(a0, a1, a2), b1 = pk_min3_h(a3, a4, M9[15]);
+    const uint32_t R = pk_min3_h(b0, b1, b1);
+    const int minmax = (int)(R & 0xffu);                  // min over arcs of the arc's max
+    const int maxmin = 255 - (int)((R >> 16) & 0xffu);    // max over arcs of the arc's min
     const int v = t[0];
     return max(v - minmax, maxmin - v) - 1;
 }
@@ -592,12 +630,31 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 constexpr int PR = 21;            // patch radius staged (18 sample reach + 3 blur taps)
 constexpr int PW = 2 * PR + 1;    // 43 rows / columns
 constexpr int PD = 12;            // LDS dwords per patch row (48 bytes, 44 used)
-constexpr int HR = 18;            // horizontal-blur tile radius in x
-constexpr int HD = 20;            // LDS dwords per h-blur row (40 u16, 37 used)
-constexpr int HP = 2 * HD;        // u16 pitch of the h-blur tile
+constexpr int HR = 18;            // blurred-tile radius (reach of the rotated pattern: |(13,13)| = 18.4)
+constexpr int BW = 2 * HR + 1;    // 37 blurred rows / columns
+constexpr int HTP = 23;           // row-PAIR pitch (dwords) of the transposed h-blur tile; odd: column walks hit 32 banks
+constexpr int HTC = 40;           // columns of the h-blur tile (10 quads, 37 used)
+constexpr int VBP = 44;           // byte pitch of the blurred tile, stored transposed ([x][y]); 11 dwords (odd)
 
-// One wave (= one 64-thread workgroup) per keypoint.
-__global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict__ img0,
+#ifndef AOS2_DESC_KPW
+#define AOS2_DESC_KPW 4
+#endif
+constexpr int DK = AOS2_DESC_KPW;   // keypoints per wave
+
+// LDS traffic of ONE wave is processed in issue order, so a write by one lane is visible to a later read by
+// another lane of the same wave; this only stops the compiler from moving LDS accesses across the phase boundary
+// (and, unlike __syncthreads(), leaves the global prefetch of the next keypoint in flight).
+__device__ __forceinline__ void wave_lds_phase() { asm volatile("" ::: "memory"); }
+
+// One wave (= one 64-thread workgroup) per DK consecutive output slots of one image.  The 43x43 patch of slot
+// i+1 is fetched into registers while slot i is processed out of LDS, so the L2/HBM latency of the staging
+// phase is covered by the wave's own arithmetic instead of by occupancy.
+#ifdef AOS2_DESC_WPE
+#define DESC_ATTR __attribute__((amdgpu_waves_per_eu(AOS2_DESC_WPE, 8)))
+#else
+#define DESC_ATTR
+#endif
+__global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *__restrict__ img0,
                                                       size_t img0_stride, int pitch0,
                                                       const uint8_t *__restrict__ pyr,
                                                       size_t pyr_stride,
@@ -610,133 +667,213 @@ __global__ __launch_bounds__(64) void describe_kernel(const uint8_t *__restrict_
                                                       int32_t *__restrict__ n_out,
                                                       unsigned long long umax_nibbles)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t patch32[PW * PD];
-    __shared__ __attribute__((aligned(16))) uint32_t hb32[PW * HD];
+    // raw patch, 43 rows (+1 so that the last row pair can be read); once the h-pass is done the same bytes hold the
+    // blurred tile (37 x VBP = 1628 B)
+    __shared__ __attribute__((aligned(16))) uint32_t patch32[(PW + 1) * PD];
+    __shared__ __attribute__((aligned(16))) uint32_t hbT[HTC * HTP];   // h-pass sums, [column][row pair] u16x2
     const int b = blockIdx.y;
     const int lane = threadIdx.x;
-    const int k = blockIdx.x;  // output slot in the image
-    // locate level and index inside the level (levels are concatenated level-major, :1060-1104)
+    const int k0 = blockIdx.x * DK;  // first output slot of this wave
+    // lane l < n_levels keeps level l's geometry; lane i < DK locates slot k0 + i (levels are concatenated
+    // level-major, :1060-1104).  Both loads are independent of each other.
+    int lv_w = 0, lv_h = 0, lv_pitch = 0, lv_sp = 0;
+    uint32_t lv_off = 0;
+    float lv_scale = 0.f;
+    if (lane < n_levels) {
+        const LevelDev &L = levels[lane];
+        lv_w = L.w; lv_h = L.h; lv_pitch = lane == 0 ? pitch0 : L.pitch; lv_off = (uint32_t)L.off;
+        lv_sp = L.scaled_patch; lv_scale = L.scale;
+    }
     const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
-    int level = -1, kin = k, total = 0;
+    int my_level = -1, my_kin = k0 + lane, total = 0;
     for (int l = 0; l < n_levels; ++l) {
         const int c = cnt[l] > 0 ? cnt[l] : 0;
-        if (level < 0 && kin < c) level = l;
-        if (level < 0) kin -= c;
+        if (my_level < 0 && my_kin < c) my_level = l;
+        if (my_level < 0) my_kin -= c;
         total += c;
     }
-    if (k == 0 && lane == 0) n_out[b] = total;
-    if (level < 0 || k >= cap) return;  // wave-uniform
-    LevelDev lv = levels[level];
-    const uint32_t csel = sel[(size_t)b * sel_stride + (size_t)level * cap_level + kin];
-    const int kx = (int)(csel & 0xfff) + 16;           // + minBorderX (:842)
-    const int ky = (int)((csel >> 12) & 0xfff) + 16;
-    const int score = (int)(csel >> 24);
-    const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
-    if (level == 0) {
-        plane = img0 + (size_t)b * img0_stride;
-        lv.pitch = pitch0;
-    }
+    if (k0 == 0 && lane == 0) n_out[b] = total;
+    const int nk = min(DK, min(total, cap) - k0);
+    if (nk <= 0) return;  // wave-uniform
+    uint32_t my_sel = 0;
+    if (lane < nk) my_sel = sel[(size_t)b * sel_stride + (size_t)my_level * cap_level + my_kin];
+    const uint8_t *img_pyr = pyr + (size_t)b * pyr_stride;
+    const uint8_t *img_l0 = img0 + (size_t)b * img0_stride;
     uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
-    // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
-    if (kx - PR >= 0 && kx + PR + 1 < lv.w && ky - PR >= 0 && ky + PR < lv.h) {
-        // 5 rows x 11 dwords per step (55 lanes): the (row, dword) split is done once per lane
-        const int rs = (lane * 373) >> 12, c = lane - 11 * rs;   // lane / 11 for lane < 64
-        if (rs < 5) {
-            const uint8_t *src = plane + (size_t)(ky - PR + rs) * lv.pitch + (kx - PR) + 4 * c;
-            const size_t step = (size_t)5 * lv.pitch;
-            uint32_t *dst = patch32 + rs * PD + c;
-            for (int r = rs; r < PW; r += 5, src += step, dst += 5 * PD) *dst = load_u32_unaligned(src);
+    // per-lane constants of the three lane grids (each split done once)
+    const int st_rs = (lane * 373) >> 12, st_c = lane - 11 * st_rs;   // staging: 5 rows x 11 dwords
+    const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1; // IC_Angle: 7 rows x 9 dwords
+    // Gaussian weights (8 fractional bits, sum 257): bytes for the h-pass dot4, u16 pairs for the v-pass dot2
+    const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+    const uint32_t W0 = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), W1 = g2 | (g1 << 8) | (g0 << 16);
+    const uint32_t WE0 = g0 | (g1 << 16), WE1 = g2 | (g3 << 16), WE2 = g2 | (g1 << 16), WE3 = g0;   // even output row
+    const uint32_t WO0 = g0 << 16, WO1 = g1 | (g2 << 16), WO2 = g3 | (g2 << 16), WO3 = g1 | (g0 << 16);   // odd
+    uint32_t pats[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pats[r] = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * (r * 64 + lane)]);
+
+    struct Slot {
+        int level, kx, ky, score, w, h, pitch;
+        const uint8_t *plane;
+        bool interior;
+    };
+    auto locate = [&](int i) {
+        Slot s;
+        s.level = __builtin_amdgcn_readlane(my_level, i);
+        const uint32_t csel = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, i);
+        s.kx = (int)(csel & 0xfff) + 16;           // + minBorderX (:842)
+        s.ky = (int)((csel >> 12) & 0xfff) + 16;
+        s.score = (int)(csel >> 24);
+        s.w = __builtin_amdgcn_readlane(lv_w, s.level);
+        s.h = __builtin_amdgcn_readlane(lv_h, s.level);
+        s.pitch = __builtin_amdgcn_readlane(lv_pitch, s.level);
+        s.plane = s.level == 0 ? img_l0 : img_pyr + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, s.level);
+        s.interior = s.kx - PR >= 0 && s.kx + PR + 1 < s.w && s.ky - PR >= 0 && s.ky + PR < s.h;
+        return s;
+    };
+    uint32_t pre[9];
+    auto prefetch = [&](const Slot &s) {
+        if (s.interior && st_rs < 5) {
+            const uint8_t *src = s.plane + (size_t)(s.ky - PR + st_rs) * s.pitch + (s.kx - PR) + 4 * st_c;
+            const size_t step = (size_t)5 * s.pitch;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (t < 8 || st_rs < 3) pre[t] = load_u32_unaligned(src + t * step);
         }
-    } else {
-        for (int i = lane; i < PW * PW; i += 64) {
-            const int r = i / PW, cc = i - r * PW;
-            const int yy = reflect101(ky - PR + r, lv.h), xx = reflect101(kx - PR + cc, lv.w);
-            patch[r * (4 * PD) + cc] = plane[(size_t)yy * lv.pitch + xx];
+    };
+    Slot cur = locate(0);
+    prefetch(cur);
+    for (int i = 0; i < nk; ++i) {
+        const int k = k0 + i;
+        // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
+        if (cur.interior) {
+            if (st_rs < 5) {
+                uint32_t *dst = patch32 + st_rs * PD + st_c;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if (t < 8 || st_rs < 3) dst[t * 5 * PD] = pre[t];
+            }
+        } else {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)   // rare path: keep it out of the register budget
+            for (int q = lane; q < PW * PW; q += 64) {
+                const int r = q / PW, cc = q - r * PW;
+                const int yy = reflect101(cur.ky - PR + r, cur.h), xx = reflect101(cur.kx - PR + cc, cur.w);
+                patch[r * (4 * PD) + cc] = cur.plane[(size_t)yy * cur.pitch + xx];
+            }
         }
-    }
-    __syncthreads();
-    // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
-    int m10 = 0, m01 = 0;
-    {
-        // 7 rows x 9 dwords per step (63 lanes); patch dwords 1..9 cover columns 4..39.  With the precomputed
-        // byte mask: sum(u*I) over the dword = (4*dj - 21) * S + T, S = sum of the kept bytes, T = sum of k * byte_k
-        const int rs = (lane * 57) >> 9, dj = lane - 9 * rs + 1;   // lane / 9 for lane < 64
-        if (rs < 7) {
-            const int c0 = 4 * dj - PR;
-            for (int vr = rs; vr < 31; vr += 7) {
-                const uint32_t d = patch32[(PR - 15 + vr) * PD + dj] & c_icmask[vr * 9 + dj - 1];
+        Slot nxt = cur;
+        if (i + 1 < nk) {
+            nxt = locate(i + 1);
+            prefetch(nxt);
+        }
+        wave_lds_phase();
+        // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
+        int m10 = 0, m01 = 0;
+        if (ic_rs < 7) {
+            // patch dwords 1..9 cover columns 4..39.  With the precomputed byte mask: sum(u*I) over the dword
+            // = (4*dj - 21) * S + T, S = sum of the kept bytes, T = sum of k * byte_k
+            const int c0 = 4 * ic_dj - PR;
+            for (int vr = ic_rs; vr < 31; vr += 7) {
+                const uint32_t d = patch32[(PR - 15 + vr) * PD + ic_dj] & c_icmask[vr * 9 + ic_dj - 1];
                 const int S = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
                 const int T = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
                 m10 += c0 * S + T;
                 m01 += (vr - 15) * S;
             }
         }
-    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d);
-        m01 += __shfl_xor(m01, d);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // ---- horizontal 7-tap pass: output column cc (0..36) <-> patch column cc+3; 4 outputs per item
-    {
-        const uint32_t W0 = (uint32_t)c_gauss[0] | ((uint32_t)c_gauss[1] << 8) | ((uint32_t)c_gauss[2] << 16) | ((uint32_t)c_gauss[3] << 24);
-        const uint32_t W1 = (uint32_t)c_gauss[4] | ((uint32_t)c_gauss[5] << 8) | ((uint32_t)c_gauss[6] << 16);
-        // 6 rows x 10 output quads per step (60 lanes)
-        const int rs = (lane * 205) >> 11, j = lane - 10 * rs;   // lane / 10 for lane < 64
-        for (int r = rs; r < PW && rs < 6; r += 6) {
-            const uint32_t D0 = patch32[r * PD + j], D1 = patch32[r * PD + j + 1], D2 = patch32[r * PD + j + 2];
-            uint32_t o[4];
-            o[0] = __builtin_amdgcn_udot4(D0, W0, __builtin_amdgcn_udot4(D1, W1, 0u, false), false);
-            o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), W0,
-                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), W1, 0u, false), false);
-            o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), W0,
-                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), W1, 0u, false), false);
-            o[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), W0,
-                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), W1, 0u, false), false);
-            hb32[r * HD + 2 * j] = o[0] | (o[1] << 16);       // each <= 255*257 = 65535
-            hb32[r * HD + 2 * j + 1] = o[2] | (o[3] << 16);
+        for (int d = 32; d >= 1; d >>= 1) {
+            m10 += __shfl_xor(m10, d);
+            m01 += __shfl_xor(m01, d);
         }
-    }
-    __syncthreads();
-    // ---- steered rBRIEF: vertical 7-tap on demand at the 512 rotated sample positions
-    const uint16_t *hb = reinterpret_cast<const uint16_t *>(hb32);
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float ang = __fmul_rn(angle, factorPI);
-    float a, bb;
-    sincos_exact(ang, &bb, &a);
-    const int g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
-    unsigned long long words[4];
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        // ---- horizontal 7-tap pass (exact 16-bit sums): item = (row pair m, output quad j); output column cc
+        // (0..36) <-> patch column cc+3.  Stored transposed, rows 2m / 2m+1 packed in one dword, for the v-pass dot2.
+        for (int id = lane; id < 22 * 10; id += 64) {
+            const int m = (id * 205) >> 11, j = id - 10 * m;   // id / 10
+            const uint32_t *src = patch32 + 2 * m * PD + j;
+            uint32_t o[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pair = r * 64 + lane;
-        const uint32_t pat = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * pair]);
-        int val[2];
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t D0 = src[h * PD], D1 = src[h * PD + 1], D2 = src[h * PD + 2];
+                o[h][0] = __builtin_amdgcn_udot4(D0, W0, __builtin_amdgcn_udot4(D1, W1, 0u, false), false);
+                o[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), W0,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), W1, 0u, false), false);
+                o[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), W0,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), W1, 0u, false), false);
+                o[h][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), W0,
+                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), W1, 0u, false), false);
+            }
+            uint32_t *dst = hbT + 4 * j * HTP + m;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float px = (float)(int8_t)(pat >> (16 * q)), py = (float)(int8_t)(pat >> (16 * q + 8));
-            const int iy = __float2int_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)));
-            const int ix = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)));
-            const uint16_t *h = hb + (PR + iy) * HP + HR + ix;
-            const int s = g0 * (h[-3 * HP] + h[3 * HP]) + g1 * (h[-2 * HP] + h[2 * HP]) + g2 * (h[-HP] + h[HP]) + g3 * h[0];
-            const int v = (s + (1 << 15)) >> 16;
-            val[q] = v > 255 ? 255 : v;
+            for (int q = 0; q < 4; ++q) dst[q * HTP] = o[0][q] | (o[1][q] << 16);   // each <= 255*257 = 65535
         }
-        words[r] = __ballot(val[0] < val[1]);
-    }
-    if (lane == 0) {
-        unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
-        d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
-        aos2_keypoint_t kp;
-        const float scale = lv.scale;
-        kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
-        kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
-        kp.size = (float)lv.scaled_patch;
-        kp.angle = angle;
-        kp.response = (float)score;
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[(size_t)b * cap + k] = kp;
+        wave_lds_phase();
+        // ---- vertical 7-tap pass over the whole 37x37 tile: item = (column x, 8 output rows); two taps per dot2
+        {
+            uint8_t *vb = patch;   // the raw patch is dead
+            for (int id = lane; id < BW * 5; id += 64) {
+                const int seg = (id * 1772) >> 16, x = id - BW * seg;   // id / 37
+                const uint32_t *src = hbT + x * HTP + 4 * seg;
+                uint32_t P[7];
+#pragma unroll
+                for (int t = 0; t < 7; ++t) P[t] = src[t];
+                uint32_t w[2] = {0u, 0u};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t e = udot2_u16(P[t], WE0, 1u << 15), od = udot2_u16(P[t], WO0, 1u << 15);
+                    e = udot2_u16(P[t + 1], WE1, e); od = udot2_u16(P[t + 1], WO1, od);
+                    e = udot2_u16(P[t + 2], WE2, e); od = udot2_u16(P[t + 2], WO2, od);
+                    e = udot2_u16(P[t + 3], WE3, e); od = udot2_u16(P[t + 3], WO3, od);
+                    e = min(e >> 16, 255u); od = min(od >> 16, 255u);
+                    w[t >> 1] |= (e | (od << 8)) << (16 * (t & 1));
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(vb + x * VBP) + 2 * seg;
+                dst[0] = w[0]; dst[1] = w[1];
+            }
+        }
+        wave_lds_phase();
+        // ---- steered rBRIEF on the blurred tile: one LDS byte per sample
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float ang = __fmul_rn(angle, factorPI);
+        float a, bb;
+        sincos_exact(ang, &bb, &a);
+        unsigned long long words[4];
+        // cvRound by the 1.5 * 2^23 trick: the low bits of (f + MAGIC) are 0x4B400000 + rint(f) for |f| < 2^22, with the
+        // FPU's round-to-nearest-even = cvRound's rounding; the constant parts of both coordinates fold into K.
+        const float MAGIC = 12582912.f;
+        const uint32_t K = 0x400000u * (uint32_t)VBP + 0x4B400000u - (uint32_t)(HR * VBP + HR);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t pat = pats[r];
+            int val[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float px = (float)(int8_t)(pat >> (16 * q)), py = (float)(int8_t)(pat >> (16 * q + 8));
+                const float fy = __fadd_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)), MAGIC);
+                const float fx = __fadd_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)), MAGIC);
+                const uint32_t off = (uint32_t)(__mul24(__builtin_bit_cast(int, fx), VBP) + __builtin_bit_cast(int, fy)) - K;
+                val[q] = patch[off];
+            }
+            words[r] = __ballot(val[0] < val[1]);
+        }
+        wave_lds_phase();
+        if (lane == 0) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
+            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+            aos2_keypoint_t kp;
+            const int level = cur.level;
+            const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv_scale), level));
+            kp.x = level != 0 ? __fmul_rn((float)cur.kx, scale) : (float)cur.kx;
+            kp.y = level != 0 ? __fmul_rn((float)cur.ky, scale) : (float)cur.ky;
+            kp.size = (float)__builtin_amdgcn_readlane(lv_sp, level);
+            kp.angle = angle;
+            kp.response = (float)cur.score;
+            kp.octave = level;
+            kp.class_id = -1;
+            kps[(size_t)b * cap + k] = kp;
+        }
+        cur = nxt;
     }
 }
 
@@ -745,9 +882,12 @@ void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
                    const int *yab, int batch, hipStream_t st)
 {
-    dim3 blk(64, 4), grd((dst.w + 255) / 256, (dst.h + RS_TILE_H - 1) / RS_TILE_H, batch);
+    const int nquads = (dst.w + 3) / 4;
+    const uint32_t inv_nquads = 0xFFFFFFFFu / (uint32_t)nquads + 1u;
+    const uint32_t items = (uint32_t)nquads * (uint32_t)batch;   // < 2^32 / nquads (checked by the caller's plan)
+    dim3 blk(256), grd((items + 255) / 256, (dst.h + RS_BAND - 1) / RS_BAND);
     hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
-                       dst, xofs, xab, yofs, yab);
+                       dst, xofs, xab, yofs, yab, batch, nquads, inv_nquads);
 }
 
 void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
@@ -796,7 +936,7 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, hipStream_t st)
 {
-    dim3 blk(64), grd(cap, batch);
+    dim3 blk(64), grd((cap + DK - 1) / DK, batch);
     hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
                        cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles);
 }
