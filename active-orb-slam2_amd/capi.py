@@ -64,6 +64,8 @@ def lib():
         L.aos2_extractor_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, C.POINTER(ci)]
         L.aos2_extractor_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
         L.aos2_extractor_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+        L.aos2_extractor_extract_batch_device_async.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+        L.aos2_extractor_wait.argtypes = [vp]
         L.aos2_extractor_pyramid_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
         L.aos2_extractor_pyramid_level.argtypes = [vp, ci, ci, ci, vp, ci]
         L.aos2_extractor_debug_candidates.argtypes = [vp, ci, ci, vp, vp, vp, ci, C.POINTER(ci)]
@@ -237,6 +239,15 @@ class Extractor:
         """raw device pointers (ints)"""
         _check(self.L.aos2_extractor_extract_batch_device(self.h, C.c_void_p(d_imgs), batch, w, h, stride, image_stride,
                                                           C.c_void_p(d_kps), C.c_void_p(d_desc), cap, C.c_void_p(d_nout)))
+
+    def extract_batch_device_async(self, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_nout):
+        """enqueue only (raw device pointers); results and errors are complete after wait()"""
+        _check(self.L.aos2_extractor_extract_batch_device_async(self.h, C.c_void_p(d_imgs), batch, w, h, stride, image_stride,
+                                                                C.c_void_p(d_kps), C.c_void_p(d_desc), cap, C.c_void_p(d_nout)))
+
+    def wait(self):
+        """complete every batch enqueued with extract_batch_device_async"""
+        _check(self.L.aos2_extractor_wait(self.h))
 
     def pyramid_level(self, level, image=0, border=0):
         """mvImagePyramid[level] (include/ORBextractor.h:85)"""

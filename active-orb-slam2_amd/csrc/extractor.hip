@@ -53,7 +53,7 @@ constexpr int kEdge = 19;       // EDGE_THRESHOLD src/ORBextractor.cc:74
 constexpr int kPatch = 31;      // PATCH_SIZE :72
 constexpr int kHalfPatch = 15;  // HALF_PATCH_SIZE :73
 constexpr int kMaxLevels = 16;
-constexpr int kMaxStreams = 4;
+constexpr int kMaxStreams = 8;
 
 struct Plan {
     int w = 0, h = 0;
@@ -100,13 +100,17 @@ struct aos2_extractor {
 
     bool dev_ready = false;
     hipStream_t stream = nullptr;       // = streams[0]
-    hipStream_t streams[4] = {};
+    hipStream_t streams[kMaxStreams] = {};
     int chunks = 0;                      // 0 = automatic
     int n_streams = 0;
     hipEvent_t ev[8] = {};
     Plan plan;
     int batch_cap = 0;
     int last_batch = 0;
+    // asynchronous batches (aos2_extractor_extract_batch_device_async): enqueued, not yet waited for
+    int in_flight = 0, flight_cap = 0;
+    std::chrono::steady_clock::time_point t_enqueue;
+    DevBuf<int32_t> d_status;   // sticky [lowest octree failure code, largest n_out] of the batches in flight
     const uint8_t *img0 = nullptr;  // level 0 of the last batch = the caller's (device) images
     size_t img0_stride = 0;
     int pitch0 = 0;
@@ -393,6 +397,8 @@ static int init_device(aos2_extractor *e)
         set_error("constant upload failed: %s", hipGetErrorString((hipError_t)r));
         return AOS2_ERR_HIP;
     }
+    if ((st = e->d_status.alloc(2))) return st;
+    AOS2_HIP_CHECK(hipMemsetAsync(e->d_status.p, 0, 2 * sizeof(int32_t), e->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->dev_ready = true;
     return AOS2_OK;
@@ -510,12 +516,20 @@ static int octree_on_host(aos2_extractor *e, int batch)
     return AOS2_OK;
 }
 
-static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
-                      size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
+static int finish_device(aos2_extractor *e);
+
+// Enqueues one batch on the handle's streams and returns; finish_device() completes it.  Chunk c of every batch
+// uses stream c and the scratch of its own image range, so consecutive batches are ordered per stream and may be
+// in flight together: a chunk's latency-bound octree then overlaps the next batch's kernels on the other streams.
+static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
+                          size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
 {
-    const auto t0 = std::chrono::steady_clock::now();
+    e->t_enqueue = std::chrono::steady_clock::now();
     int st;
     if ((st = init_device(e))) return st;
+    if (e->in_flight > 0 && (w != e->plan.w || h != e->plan.h || batch > e->batch_cap || cap != e->flight_cap)) {
+        if ((st = finish_device(e))) return st;   // geometry change: scratch is rebuilt, nothing may be in flight
+    }
     if ((st = build_plan(e, w, h))) return st;
     if ((st = ensure_batch(e, batch))) return st;
     Plan &P = e->plan;
@@ -526,10 +540,13 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
     e->img0_stride = image_stride;
     e->pitch0 = stride;
     // The batch is cut into chunks that run on separate streams: the octree kernel is
-    // latency-bound (one wave per (image, level), ~0.5 ms whatever the batch size) and leaves
-    // the CUs idle, so a chunk's octree overlaps the streaming kernels of the other chunks.
-    // measured at B=256 (tools/gpu_chunk_sweep.py): 1 chunk 1.80 ms, 2 chunks 1.61 ms, 3: 1.62, 4: 2.19
-    int chunks = e->chunks > 0 ? e->chunks : (batch >= 64 ? 2 : 1);
+    // latency-bound (one wave per (image, level), ~0.15 ms whatever the batch size) and leaves
+    // the CUs idle, so a chunk's octree overlaps the VALU-bound kernels of the other chunks (and, with the
+    // asynchronous call, of the next batch).  Measured at B=256, K steps in flight / synchronous call:
+    // 2 chunks 0.933 / 0.964 ms, 3 chunks 0.855 / 0.967, 4 chunks 0.852 / 0.971 (needs GPU_MAX_HW_QUEUES=8: the
+    // runtime's default of 4 hardware queues puts two of the 4 streams on one queue, 1.16 ms), 6: 1.08, 8: 1.28
+    // (~13 launches per chunk: the host's launch rate becomes the limit).
+    int chunks = e->chunks > 0 ? e->chunks : (batch >= 96 ? 3 : batch >= 64 ? 2 : 1);
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
     auto enqueue = [&](int b0, int nb, hipStream_t s, bool timed) -> int {
@@ -571,7 +588,7 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
         launch_describe(img, image_stride, stride, pyr, P.pyr_bytes, P.d_levels.p, L, sel, (size_t)L * e->cap_level,
                         e->cap_level, sel_cnt, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32, cap, d_nout + b0, nb,
-                        e->umax_nibbles, s);
+                        e->umax_nibbles, e->d_status.p, s);
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
         AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p + (size_t)b0 * L, sel_cnt, sizeof(int32_t) * L * nb, hipMemcpyDeviceToHost, s));
         AOS2_HIP_CHECK(hipMemcpyAsync(e->h_nout.p + b0, d_nout + b0, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
@@ -581,12 +598,26 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
         const int b0 = (int)((long long)batch * c / chunks), b1 = (int)((long long)batch * (c + 1) / chunks);
         if (b1 > b0 && (st = enqueue(b0, b1 - b0, e->streams[c], c == 0))) return st;
     }
-    for (int c = 0; c < chunks; ++c) AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[c]));
     e->timing[6] = (float)chunks;
-    AOS2_HIP_CHECK(hipGetLastError());
     e->last_batch = batch;
+    e->flight_cap = cap;
+    ++e->in_flight;
+    return AOS2_OK;
+}
+
+// Waits for every batch in flight; reports the sticky device status of all of them and, in detail, the last one.
+static int finish_device(aos2_extractor *e)
+{
+    if (e->in_flight == 0) return AOS2_OK;
+    const int L = e->nlevels, batch = e->last_batch, cap = e->flight_cap;
+    int32_t status[2] = {0, 0};
+    for (int c = 0; c < kMaxStreams; ++c) AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[c]));
+    AOS2_HIP_CHECK(hipMemcpy(status, e->d_status.p, sizeof(status), hipMemcpyDeviceToHost));
+    e->in_flight = 0;
+    AOS2_HIP_CHECK(hipGetLastError());
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&e->timing[i], e->ev[i], e->ev[i + 1]);
-    e->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    e->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e->t_enqueue).count();
+    if (status[0] != 0 || status[1] != 0) AOS2_HIP_CHECK(hipMemset(e->d_status.p, 0, sizeof(status)));
     for (int i = 0; i < L * batch; ++i) {
         if (e->h_sel_cnt.p[i] < 0) {
             set_error("octree stage failed for image %d level %d (code %d: %s)", i / L, i % L, e->h_sel_cnt.p[i],
@@ -599,7 +630,26 @@ static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w
             set_error("image %d has %d keypoints, capacity %d", b, e->h_nout.p[b], cap);
             return AOS2_ERR_CAPACITY;
         }
+    // earlier batches of the same flight (their per-image counts are gone; the sticky words are not)
+    if (status[0] < 0) {
+        set_error("octree stage failed in an earlier batch of this flight (code %d: %s)", status[0],
+                  status[0] == -4 ? "candidate capacity exceeded" : "node arena exhausted");
+        return AOS2_ERR_CAPACITY;
+    }
+    if (status[1] > cap) {
+        set_error("an earlier batch of this flight produced %d keypoints for one image, capacity %d", status[1], cap);
+        return AOS2_ERR_CAPACITY;
+    }
     return AOS2_OK;
+}
+
+static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
+                      size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
+{
+    int st;
+    if (e->in_flight > 0 && (st = finish_device(e))) return st;
+    if ((st = enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_nout))) return st;
+    return finish_device(e);
 }
 
 }  // namespace aos2
@@ -718,6 +768,32 @@ int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_im
     return run_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
 }
 
+int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t *d_imgs, int batch, int w, int h,
+                                              int stride, size_t image_stride, aos2_keypoint_t *d_kps,
+                                              uint8_t *d_desc, int cap, int32_t *d_n_out)
+{
+    if (!e || !d_imgs || !d_kps || !d_desc || !d_n_out || batch <= 0 || w <= 0 || h <= 0 || stride < w || cap <= 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (e->host_octree) {   // the host octree path synchronises inside the batch: run it synchronously
+        return run_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
+    }
+    return enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
+}
+
+int aos2_extractor_wait(aos2_extractor_t *e)
+{
+    if (!e) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (!e->dev_ready) return AOS2_OK;
+    int st = bind_device(e->device);
+    if (st) return st;
+    return finish_device(e);
+}
+
 int aos2_extractor_extract_batch(aos2_extractor_t *e, const uint8_t *imgs, int batch, int w, int h, int stride,
                                  size_t image_stride, aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out)
 {
@@ -833,6 +909,7 @@ int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t 
         return AOS2_ERR_ARG;
     }
     if ((st = bind_device(left->device))) return st;
+    if ((st = finish_device(left)) || (st = finish_device(right))) return st;
     return stereo_run(left, right, 0, batch, d_kp_left, d_desc_left, d_n_left, d_kp_right, d_desc_right, d_n_right, cap,
                       cap, mb, mbf, d_u_right, d_depth);
 }
@@ -852,6 +929,7 @@ int aos2_compute_stereo_matches(aos2_extractor_t *left, aos2_extractor_t *right,
     }
     if (n_left == 0) return AOS2_OK;
     if ((st = bind_device(left->device))) return st;
+    if ((st = finish_device(left)) || (st = finish_device(right))) return st;
     aos2_extractor *e = left;
     const int cap = ((n_left > n_right ? n_left : n_right) + 3) & ~3;  // keeps the descriptor blocks 16-byte aligned
     const size_t kb = sizeof(aos2_keypoint_t) * (size_t)cap, db = (size_t)cap * 32;
@@ -902,6 +980,7 @@ int aos2_extractor_pyramid_level(aos2_extractor_t *e, int image, int level, int 
     }
     int st;
     if ((st = bind_device(e->device))) return st;
+    if ((st = finish_device(e))) return st;   // batches enqueued asynchronously
     const LevelDev &L = e->plan.levels[level];
     if (dst_stride < L.w + 2 * border) return AOS2_ERR_ARG;
     uint8_t *interior = dst + (size_t)border * dst_stride + border;
@@ -937,6 +1016,7 @@ int aos2_extractor_debug_candidates(aos2_extractor_t *e, int image, int level, i
     }
     int st;
     if ((st = bind_device(e->device))) return st;
+    if ((st = finish_device(e))) return st;   // batches enqueued asynchronously
     const int L = e->nlevels;
     int32_t lo[2];
     AOS2_HIP_CHECK(hipMemcpy(lo, e->d_level_off.p + (size_t)image * (L + 1) + level, sizeof(lo), hipMemcpyDeviceToHost));
@@ -978,6 +1058,7 @@ int aos2_extractor_bench_fast(aos2_extractor_t *e, int iters, float *avg_ms)
     }
     int st;
     if ((st = bind_device(e->device))) return st;
+    if ((st = finish_device(e))) return st;   // batches enqueued asynchronously
     Plan &P = e->plan;
     hipStream_t s = e->stream;
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
@@ -1000,6 +1081,7 @@ int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms)
     }
     int st;
     if ((st = bind_device(e->device))) return st;
+    if ((st = finish_device(e))) return st;   // batches enqueued asynchronously
     Plan &P = e->plan;
     const int L = e->nlevels;
     hipStream_t s = e->stream;
@@ -1007,7 +1089,7 @@ int aos2_extractor_bench_describe(aos2_extractor_t *e, int iters, float *avg_ms)
     AOS2_HIP_CHECK(hipEventRecord(e->ev[6], s));
     for (int i = 0; i < iters; ++i)
         launch_describe(e->img0, e->img0_stride, e->pitch0, e->d_pyr.p, P.pyr_bytes, P.d_levels.p, L, e->d_sel.p, (size_t)L * e->cap_level, e->cap_level,
-                        e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, e->umax_nibbles, s);
+                        e->d_sel_cnt.p, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, e->last_batch, e->umax_nibbles, e->d_status.p, s);
     AOS2_HIP_CHECK(hipEventRecord(e->ev[7], s));
     AOS2_HIP_CHECK(hipStreamSynchronize(s));
     float ms = 0;

@@ -77,6 +77,6 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
-                     unsigned long long umax_nibbles, hipStream_t st);
+                     unsigned long long umax_nibbles, int32_t *status, hipStream_t st);
 
 }  // namespace aos2

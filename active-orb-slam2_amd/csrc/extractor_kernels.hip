@@ -2,6 +2,8 @@
 // no MFMA here by design.  Reference semantics: src/ORBextractor.cc (see each kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include <cmath>
 
 #include "extractor_kernels.h"
 #include "octree.h"
@@ -16,8 +18,37 @@ __constant__ int c_gauss[8];           // 7-tap Gaussian, 8 fractional bits {18,
 // byte k of dword dj (column 4*dj + k, u = column - 21) is inside iff |u| <= umax[|v|] (:88-101)
 __constant__ uint32_t c_icmask[31 * 9 + 1];
 
+// describe_kernel's horizontal blur works on items (row pair m, output quad j) of the 43 x 37 tile; only the items a
+// rotated pattern point can reach (disc of radius max|pattern| + rounding, +-3 rows of vertical taps) are listed:
+// 189 of 220 for the ORB pattern, i.e. 3 rounds of 64 lanes instead of 4.  Entry = m << 8 | j, 0xffff = none.
+__constant__ uint16_t c_hitems[256];
+__constant__ int c_hrounds;
+
 int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, hipStream_t st)
 {
+    {
+        double rmax = 0;
+        for (int i = 0; i < 512; ++i) rmax = std::max(rmax, std::hypot((double)pattern[2 * i], (double)pattern[2 * i + 1]));
+        // a sample is (round(x'), round(y')) of a point at distance <= rmax * |(cos, sin)|_float from the centre
+        const double R = rmax * (1.0 + 1e-6) + 0.70711, R2 = R * R;
+        bool need[22][10] = {};
+        for (int ix = -18; ix <= 18; ++ix)
+            for (int iy = -18; iy <= 18; ++iy) {
+                if ((double)(ix * ix + iy * iy) > R2) continue;
+                for (int dy = iy - 3; dy <= iy + 3; ++dy) need[(dy + 21) / 2][(ix + 18) / 4] = true;
+            }
+        uint16_t items[256];
+        int n = 0;
+        for (int m = 0; m < 22; ++m)
+            for (int j = 0; j < 10; ++j)
+                if (need[m][j]) items[n++] = (uint16_t)(m << 8 | j);
+        const int rounds = (n + 63) / 64;
+        for (; n < 256; ++n) items[n] = 0xffff;
+        hipError_t eh = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hitems), items, sizeof(items), 0, hipMemcpyHostToDevice, st);
+        if (eh != hipSuccess) return (int)eh;
+        eh = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hrounds), &rounds, sizeof(int), 0, hipMemcpyHostToDevice, st);
+        if (eh != hipSuccess) return (int)eh;
+    }
     hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pattern), pattern, 1024, 0, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_umax), umax, 16 * sizeof(int), 0, hipMemcpyHostToDevice, st);
@@ -641,6 +672,18 @@ constexpr int VBP = 44;           // byte pitch of the blurred tile, stored tran
 #endif
 constexpr int DK = AOS2_DESC_KPW;   // keypoints per wave
 
+// Sum over the 64 lanes, result wave-uniform: 4 DPP adds inside each row of 16 lanes (every lane of a row ends with the
+// row's sum) + 4 v_readlane.  (__shfl_xor compiles to ds_bpermute_b32: 6 dependent LDS round trips per value.)
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
 // LDS traffic of ONE wave is processed in issue order, so a write by one lane is visible to a later read by
 // another lane of the same wave; this only stops the compiler from moving LDS accesses across the phase boundary
 // (and, unlike __syncthreads(), leaves the global prefetch of the next keypoint in flight).
@@ -665,7 +708,8 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                                                       aos2_keypoint_t *__restrict__ kps,
                                                       uint8_t *__restrict__ desc, int cap,
                                                       int32_t *__restrict__ n_out,
-                                                      unsigned long long umax_nibbles)
+                                                      unsigned long long umax_nibbles,
+                                                      int32_t *__restrict__ status)
 {
     // raw patch, 43 rows (+1 so that the last row pair can be read); once the h-pass is done the same bytes hold the
     // blurred tile (37 x VBP = 1628 B)
@@ -685,14 +729,20 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         lv_sp = L.scaled_patch; lv_scale = L.scale;
     }
     const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
-    int my_level = -1, my_kin = k0 + lane, total = 0;
+    int my_level = -1, my_kin = k0 + lane, total = 0, worst = 0;
     for (int l = 0; l < n_levels; ++l) {
         const int c = cnt[l] > 0 ? cnt[l] : 0;
+        worst = min(worst, cnt[l]);   // negative = the octree stage's failure code for this (image, level)
         if (my_level < 0 && my_kin < c) my_level = l;
         if (my_level < 0) my_kin -= c;
         total += c;
     }
-    if (k0 == 0 && lane == 0) n_out[b] = total;
+    if (k0 == 0 && lane == 0) {
+        n_out[b] = total;
+        // sticky per-handle status, read by aos2_extractor_wait(): [0] = lowest failure code, [1] = largest n_out
+        if (worst < 0) atomicMin(status, worst);
+        if (total > cap) atomicMax(status + 1, total);
+    }
     const int nk = min(DK, min(total, cap) - k0);
     if (nk <= 0) return;  // wave-uniform
     uint32_t my_sel = 0;
@@ -705,7 +755,21 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1; // IC_Angle: 7 rows x 9 dwords
     // Gaussian weights (8 fractional bits, sum 257): bytes for the h-pass dot4, u16 pairs for the v-pass dot2
     const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
-    const uint32_t W0 = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), W1 = g2 | (g1 << 8) | (g0 << 16);
+    // h-pass: the 4 outputs of a quad read the same 3 dwords; the taps are shifted in the WEIGHTS (10 dot4, no
+    // byte realignment of the data).  Byte k of a weight dword multiplies pixel k of the data dword.
+    const uint32_t g[7] = {g0, g1, g2, g3, g2, g1, g0};
+    auto wq = [&](int first) {   // weights of taps first .. first+3 (taps outside 0..6 are 0)
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k)
+            if (first + k >= 0 && first + k < 7) w |= g[first + k] << (8 * k);
+        return w;
+    };
+    const uint32_t WA0 = wq(0), WA1 = wq(4), WB0 = wq(-1), WB1 = wq(3), WC0 = wq(-2), WC1 = wq(2), WC2 = wq(6);
+    const uint32_t WD0 = wq(-3), WD1 = wq(1), WD2 = wq(5);
+    uint32_t hit2[2];   // this lane's item of rounds (0,1) and (2,3), two u16 per register
+#pragma unroll
+    for (int t = 0; t < 2; ++t) hit2[t] = (uint32_t)c_hitems[lane + 128 * t] | ((uint32_t)c_hitems[lane + 128 * t + 64] << 16);
+    const int hrounds = c_hrounds;
     const uint32_t WE0 = g0 | (g1 << 16), WE1 = g2 | (g3 << 16), WE2 = g2 | (g1 << 16), WE3 = g0;   // even output row
     const uint32_t WO0 = g0 << 16, WO1 = g1 | (g2 << 16), WO2 = g3 | (g2 << 16), WO3 = g1 | (g0 << 16);   // odd
     uint32_t pats[4];
@@ -781,32 +845,34 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                 m01 += (vr - 15) * S;
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m10 += __shfl_xor(m10, d);
-            m01 += __shfl_xor(m01, d);
-        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
         const float angle = fast_atan2_deg((float)m01, (float)m10);
-        // ---- horizontal 7-tap pass (exact 16-bit sums): item = (row pair m, output quad j); output column cc
-        // (0..36) <-> patch column cc+3.  Stored transposed, rows 2m / 2m+1 packed in one dword, for the v-pass dot2.
-        for (int id = lane; id < 22 * 10; id += 64) {
-            const int m = (id * 205) >> 11, j = id - 10 * m;   // id / 10
-            const uint32_t *src = patch32 + 2 * m * PD + j;
-            uint32_t o[2][4];
+        // ---- horizontal 7-tap pass (exact 16-bit sums): item = (row pair m, output quad j) from c_hitems; output
+        // column cc (0..36) <-> patch column cc+3.  Stored transposed, rows 2m / 2m+1 packed in one dword, for the
+        // v-pass dot2.
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t D0 = src[h * PD], D1 = src[h * PD + 1], D2 = src[h * PD + 2];
-                o[h][0] = __builtin_amdgcn_udot4(D0, W0, __builtin_amdgcn_udot4(D1, W1, 0u, false), false);
-                o[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 1), W0,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 1), W1, 0u, false), false);
-                o[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 2), W0,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 2), W1, 0u, false), false);
-                o[h][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D1, D0, 3), W0,
-                                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(D2, D1, 3), W1, 0u, false), false);
+        for (int t = 0; t < 4; ++t) {
+            if (t >= hrounds) continue;   // uniform
+            // (the per-round addresses are loop-invariant and stay in registers: 76 VGPRs = 6 waves/SIMD measured
+            // faster, 0.313 ms, than recomputing them per slot at 7 waves, 0.328 ms -- the kernel is VALU-bound)
+            const uint32_t it = (hit2[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+            if (it != 0xffffu) {
+                const int m = it >> 8, j = it & 255;
+                const uint32_t *src = patch32 + 2 * m * PD + j;
+                uint32_t o[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t D0 = src[h * PD], D1 = src[h * PD + 1], D2 = src[h * PD + 2];
+                    o[h][0] = __builtin_amdgcn_udot4(D0, WA0, __builtin_amdgcn_udot4(D1, WA1, 0u, false), false);
+                    o[h][1] = __builtin_amdgcn_udot4(D0, WB0, __builtin_amdgcn_udot4(D1, WB1, 0u, false), false);
+                    o[h][2] = __builtin_amdgcn_udot4(D0, WC0, __builtin_amdgcn_udot4(D1, WC1, __builtin_amdgcn_udot4(D2, WC2, 0u, false), false), false);
+                    o[h][3] = __builtin_amdgcn_udot4(D0, WD0, __builtin_amdgcn_udot4(D1, WD1, __builtin_amdgcn_udot4(D2, WD2, 0u, false), false), false);
+                }
+                uint32_t *dst = hbT + 4 * j * HTP + m;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q * HTP] = o[0][q] | (o[1][q] << 16);   // each <= 255*257 = 65535
             }
-            uint32_t *dst = hbT + 4 * j * HTP + m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q * HTP] = o[0][q] | (o[1][q] << 16);   // each <= 255*257 = 65535
         }
         wave_lds_phase();
         // ---- vertical 7-tap pass over the whole 37x37 tile: item = (column x, 8 output rows); two taps per dot2
@@ -934,11 +1000,11 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      const LevelDev *levels, int n_levels,
                      const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
-                     unsigned long long umax_nibbles, hipStream_t st)
+                     unsigned long long umax_nibbles, int32_t *status, hipStream_t st)
 {
     dim3 blk(64), grd((cap + DK - 1) / DK, batch);
     hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
-                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles);
+                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status);
 }
 
 }  // namespace aos2

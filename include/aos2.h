@@ -98,6 +98,19 @@ int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_im
                                         aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap,
                                         int32_t *d_n_out);
 
+/* Asynchronous form of the above: enqueues the batch on the handle's HIP streams and returns; the outputs are
+ * complete, and errors (octree capacity, more keypoints than `cap`) reported, by aos2_extractor_wait().
+ * Several batches may be enqueued before one wait: chunk c of every batch runs on stream c with its own scratch,
+ * so the latency-bound octree stage of one batch overlaps the FAST / descriptor kernels of the next (the
+ * frame-parallel pipeline of SURVEY.md section 8(e)).  The caller must not reuse the input or output buffers of a
+ * batch that is still in flight, and all batches of one flight share (w, h, cap); a change of geometry waits
+ * for the flight first.  Every other call on the handle waits for the flight implicitly. */
+int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t *d_imgs, int batch,
+                                              int w, int h, int stride, size_t image_stride,
+                                              aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap,
+                                              int32_t *d_n_out);
+int aos2_extractor_wait(aos2_extractor_t *e);
+
 /* mvImagePyramid[level] (include/ORBextractor.h:85; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:502,592,609) of image `image` of the last extract on this handle.
  * Copies the level to host memory `dst` with row pitch dst_stride.  border = 0 gives the w x h

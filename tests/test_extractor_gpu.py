@@ -143,6 +143,65 @@ def test_full_batch_properties(pkg, oracle, gpu):
     assert zlib.crc32(np.array(crc, np.uint32).tobytes()) == zlib.crc32(np.array(crc[:8] * (B // 8), np.uint32).tobytes())
 
 
+def test_async_flight_equals_synchronous_batches(pkg, oracle, gpu):
+    """aos2_extractor_extract_batch_device_async: three different batches in flight on one handle (chunked over
+    two streams) + one wait == the synchronous call on each batch, bit for bit; wait() reports a capacity error of
+    an EARLIER batch of the flight; a geometry change and other calls on the handle wait implicitly."""
+    import torch
+    dev = torch.device("cuda:0")
+    B, w, h = 64, 640, 480     # >= 64 images: two chunks on two streams
+    ex = pkg.Extractor()
+    cap = ex.max_keypoints
+    batches = [torch.from_numpy(np.concatenate([pkg.synth.synth_batch(9000 + 10 * i, 8)] * (B // 8))).to(dev) for i in range(3)]
+
+    def outs():
+        return (torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                torch.zeros(B, dtype=torch.int32, device=dev))
+
+    sync_out = []
+    for d in batches:
+        o = outs()
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, o[0].data_ptr(), o[1].data_ptr(), cap, o[2].data_ptr())
+        sync_out.append(o)
+    async_out = [outs() for _ in batches]
+    for rep in range(2):       # twice: the second flight starts while nothing of the first is pending
+        for d, o in zip(batches, async_out):
+            ex.extract_batch_device_async(d.data_ptr(), B, w, h, w, w * h, o[0].data_ptr(), o[1].data_ptr(), cap, o[2].data_ptr())
+        ex.wait()
+        torch.cuda.synchronize()
+        for a, b_ in zip(async_out, sync_out):
+            n = b_[2].cpu().numpy()
+            assert (a[2].cpu().numpy() == n).all() and n.min() > 0
+            ka, kb, da, db = a[0].cpu().numpy(), b_[0].cpu().numpy(), a[1].cpu().numpy(), b_[1].cpu().numpy()
+            for b in range(B):
+                assert (ka[b, : n[b]] == kb[b, : n[b]]).all() and (da[b, : n[b]] == db[b, : n[b]]).all()
+    # sampled exact parity of the asynchronous results with the oracle
+    oe = oracle.Extractor()
+    kps = async_out[1][0].cpu().numpy().view(pkg.capi.KP_DTYPE).reshape(B, cap)
+    want = oe.extract(batches[1][3].cpu().numpy())
+    n3 = int(async_out[1][2][3])
+    assert n3 == len(want[0]) and (async_out[1][1][3, :n3].cpu().numpy() == want[1]).all()
+    assert (kps[3, :n3]["x"] == want[0]["x"]).all() and (kps[3, :n3]["angle"] == want[0]["angle"]).all()
+    # an earlier batch of a flight overflows the caller's capacity -> the wait fails, the handle stays usable
+    small = 300
+    o_small = (torch.zeros((B, small, 28), dtype=torch.uint8, device=dev), torch.zeros((B, small, 32), dtype=torch.uint8, device=dev),
+               torch.zeros(B, dtype=torch.int32, device=dev))
+    flat = torch.full((B, h, w), 128, dtype=torch.uint8, device=dev)      # no corners at all: n_out = 0, fits
+    ex.extract_batch_device_async(batches[0].data_ptr(), B, w, h, w, w * h, o_small[0].data_ptr(), o_small[1].data_ptr(), small, o_small[2].data_ptr())
+    ex.extract_batch_device_async(flat.data_ptr(), B, w, h, w, w * h, o_small[0].data_ptr(), o_small[1].data_ptr(), small, o_small[2].data_ptr())
+    with pytest.raises(pkg.AosError):
+        ex.wait()
+    ex.wait()                  # nothing in flight: no error left behind
+    # another call on the handle completes the flight first
+    o = outs()
+    ex.extract_batch_device_async(batches[2].data_ptr(), B, w, h, w, w * h, o[0].data_ptr(), o[1].data_ptr(), cap, o[2].data_ptr())
+    lvl = ex.pyramid_level(1, image=5)
+    ex2 = pkg.Extractor()
+    ex2.extract_batch(batches[2][:6].cpu().numpy())
+    assert (lvl == ex2.pyramid_level(1, image=5)).all()
+    assert (o[2].cpu().numpy() == sync_out[2][2].cpu().numpy()).all()
+
+
 def test_sincos_device_equals_host(pkg, gpu):
     a = (np.linspace(0, 360, 200001).astype(np.float32) * np.float32(np.pi / 180.0)).astype(np.float32)
     s, c = pkg.capi.debug_sincos_device(a)
