@@ -116,7 +116,7 @@ struct aos2_extractor {
     int pitch0 = 0;
     DevBuf<uint8_t> d_pyr, d_in, d_desc;
     DevBuf<uint32_t> d_slots, d_dense, d_sel;
-    DevBuf<int32_t> d_cell_cnt, d_level_off, d_sel_cnt, d_nout;
+    DevBuf<int32_t> d_cell_cnt, d_level_off, d_level_cnt, d_sel_cnt, d_nout;
     DevBuf<aos2_keypoint_t> d_kps;
     int out_cap = 0;
     // ComputeStereoMatches scratch (this handle = the left eye)
@@ -416,6 +416,7 @@ static int ensure_batch(aos2_extractor *e, int batch)
     if ((st = e->d_dense.alloc(P.slot_total * batch))) return st;
     if ((st = e->d_cell_cnt.alloc(nc * batch))) return st;
     if ((st = e->d_level_off.alloc((size_t)(L + 1) * batch))) return st;
+    if ((st = e->d_level_cnt.alloc((size_t)L * batch))) return st;
     if ((st = e->d_sel.alloc((size_t)L * e->cap_level * batch))) return st;
     if ((st = e->d_sel_cnt.alloc((size_t)L * batch))) return st;
     if ((st = e->h_level_off.alloc((size_t)(L + 1) * batch))) return st;
@@ -567,8 +568,12 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
         launch_fast(img, image_stride, stride, pyr, P.pyr_bytes, P.d_levels.p, P.d_cells.p, NC, e->iniTh, e->minTh, P.TP,
                     P.TH, P.SP, P.fast_lds, P.list_cap, P.keep_cap, slots, P.slot_total, cell_cnt, nb, s);
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[2], s));
-        launch_compact(P.d_cells.p, NC, L, P.d_level_cell_begin.p, slots, P.slot_total, cell_cnt, dense, P.slot_total,
-                       level_off, nb, s);
+        // device octree: every (image, level) job gathers its own candidates from the cell slots; the separate
+        // compaction kernel (one latency-bound workgroup per image on the critical path of the chunk, 31 us at
+        // B=256) only feeds the host octree path
+        if (e->host_octree)
+            launch_compact(P.d_cells.p, NC, L, P.d_level_cell_begin.p, slots, P.slot_total, cell_cnt, dense, P.slot_total,
+                           level_off, nb, s);
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[3], s));
         if (e->host_octree) {
             int st2 = octree_on_host(e, nb);
@@ -578,11 +583,13 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
             OctDevScratch scr{e->o_xs.p + c0, e->o_ys.p + c0, e->o_sc.p + c0, e->o_perm.p + c0, e->o_tmp.p + c0,
                               e->o_pairs.p + 4 * n0, e->o_idx.p + j0 * e->cap_level, e->o_nodes.p + n0,
                               P.oct_cand_total, P.oct_node_total};
+            const OctGather gather{P.d_cells.p, P.d_level_cell_begin.p, slots, P.slot_total, cell_cnt, NC,
+                                   e->d_level_cnt.p + (size_t)b0 * L};
             if (e->oct_image.total > 0)
-                launch_octree_image(dense, P.slot_total, level_off, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
+                launch_octree_image(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
                                     sel_cnt, e->cap_level, e->oct_image, s);
             else
-                launch_octree(dense, P.slot_total, level_off, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level, sel_cnt,
+                launch_octree(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level, sel_cnt,
                               e->cap_level, e->oct_lds, s);
         }
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
@@ -735,7 +742,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         for (auto &sx : e->streams) (void)hipStreamSynchronize(sx);
         e->plan.release_device();
         e->d_pyr.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
-        e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_sel_cnt.release();
+        e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_level_cnt.release(); e->d_sel_cnt.release();
         e->d_nout.release(); e->d_kps.release();
         e->st_sad.release(); e->st_io.release(); e->st_host.release();
         e->o_xs.release(); e->o_ys.release(); e->o_sc.release(); e->o_perm.release(); e->o_tmp.release();
@@ -1019,7 +1026,14 @@ int aos2_extractor_debug_candidates(aos2_extractor_t *e, int image, int level, i
     if ((st = finish_device(e))) return st;   // batches enqueued asynchronously
     const int L = e->nlevels;
     int32_t lo[2];
-    AOS2_HIP_CHECK(hipMemcpy(lo, e->d_level_off.p + (size_t)image * (L + 1) + level, sizeof(lo), hipMemcpyDeviceToHost));
+    if (e->host_octree) {   // dense list of the whole image, written by the compaction kernel
+        AOS2_HIP_CHECK(hipMemcpy(lo, e->d_level_off.p + (size_t)image * (L + 1) + level, sizeof(lo), hipMemcpyDeviceToHost));
+    } else {                // per-level lists, written by the octree jobs at the level's first slot
+        int32_t n_l = 0;
+        AOS2_HIP_CHECK(hipMemcpy(&n_l, e->d_level_cnt.p + (size_t)image * L + level, sizeof(n_l), hipMemcpyDeviceToHost));
+        lo[0] = e->plan.cells[e->plan.level_cell_begin[level]].slot_off;
+        lo[1] = lo[0] + n_l;
+    }
     const int cnt = lo[1] - lo[0];
     *n = cnt;
     if (!xs || !ys || !score) return AOS2_OK;

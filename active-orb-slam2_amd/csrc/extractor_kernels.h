@@ -32,6 +32,17 @@ struct CellDev {
     uint32_t inv_nq;      // 65536 / quads per row + 1
 };
 
+// inputs of the octree jobs' candidate gather (FAST's per-cell slots) and the per-(image, level) candidate count
+struct OctGather {
+    const CellDev *cells;
+    const int *level_cell_begin;   // [n_levels]
+    const uint32_t *slots;         // [batch][slot_stride]
+    size_t slot_stride;
+    const int32_t *cell_cnt;       // [batch][n_cells]
+    int n_cells;
+    int32_t *level_cnt;            // out [batch][n_levels]
+};
+
 struct OctDevScratch {
     int16_t *xs, *ys;
     uint8_t *sc;
@@ -67,10 +78,10 @@ struct OctImageLayout {
     int total;
 };
 int prepare_octree_image_kernel(int total_lds);
-void launch_octree_image(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+void launch_octree_image(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
                          int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                          int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st);
-void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+void launch_octree(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
                    int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                    int32_t *sel_level_cnt, int cap_level, int lds_bytes, hipStream_t st);
 void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

@@ -523,16 +523,55 @@ namespace aos2 {
 static_assert(sizeof(OctNode16) == 16, "oct_lds_bytes() assumes 16-byte compact nodes");
 
 // one (image, level) job, executed by ONE wave (lane = threadIdx.x & 63) over the LDS slice [lds, lds + lds_bytes)
-__device__ __forceinline__ void octree_job(int b, int l, const uint32_t *__restrict__ dense, size_t dense_stride,
-                                           const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+__device__ __forceinline__ void octree_job(int b, int l, uint32_t *__restrict__ dense, size_t dense_stride,
+                                           const OctGather &G, const LevelDev *__restrict__ levels,
                                            int n_levels, const OctDevScratch &scr, uint32_t *__restrict__ sel,
                                            size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level,
                                            uint32_t *oct_lds, int lds_bytes)
 {
     const int lane = threadIdx.x & 63;
-    const int32_t *lo = level_off + (size_t)b * (n_levels + 1);
-    const int beg = lo[l], n = lo[l + 1] - lo[l];
-    const uint32_t *cand = dense + (size_t)b * dense_stride + beg;
+    // ---- candidates of this (image, level) in the reference's order (:775-846: cells row-major, cv::FAST's
+    // emission order inside a cell): exclusive scan of the level's cell counts, each lane copies its cells' slots.
+    // The dense list of a level starts at the level's first slot, so no job depends on another level's counts.
+    const int cb = G.level_cell_begin[l], ce = l + 1 < n_levels ? G.level_cell_begin[l + 1] : G.n_cells;
+    uint32_t *cand = dense + (size_t)b * dense_stride + G.cells[cb].slot_off;
+    int n = 0;
+    {
+        const int32_t *cc = G.cell_cnt + (size_t)b * G.n_cells;
+        const uint32_t *sl = G.slots + (size_t)b * G.slot_stride;
+        // This runs on the job's critical path, so the memory round trips are batched: the counts (and slot
+        // offsets) of 8 rounds of 64 cells are requested together, and a cell's slots are moved 16 at a time
+        // (16 predicated loads in flight, then 16 stores) instead of one dependent load -> store per element.
+        for (int c0 = cb; c0 < ce; c0 += 8 * 64) {
+            int v[8], so[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = c0 + 64 * r + lane;
+                v[r] = c < ce ? cc[c] : 0;
+                so[r] = c < ce ? G.cells[c].slot_off : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (c0 + 64 * r >= ce) continue;   // uniform
+                const int excl = octdetail::coop_excl_scan(v[r]);
+                const uint32_t *src = sl + so[r];
+                uint32_t *dst = cand + n + excl;
+                const int vmax = octdetail::coop_max(v[r]);
+                for (int i0 = 0; i0 < vmax; i0 += 16) {
+                    uint32_t t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (i0 + u < v[r]) t[u] = src[i0 + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (i0 + u < v[r]) dst[i0 + u] = t[u];
+                }
+                n += octdetail::coop_shfl(excl + v[r], 63);
+            }
+        }
+        if (lane == 0) G.level_cnt[(size_t)b * n_levels + l] = n;
+        octdetail::coop_sync();
+    }
     const LevelDev lv = levels[l];
     uint32_t *out = sel + (size_t)b * sel_stride + (size_t)l * cap_level;
     int32_t *idx = scr.out_idx + ((size_t)b * n_levels + l) * cap_level;
@@ -587,15 +626,18 @@ __device__ __forceinline__ void octree_job(int b, int l, const uint32_t *__restr
 
 // one wave per job; jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones
 // fill in.  Every workgroup reserves the level-0 working set.
-__global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
-                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+__global__ __launch_bounds__(64) void octree_kernel(uint32_t *__restrict__ dense, size_t dense_stride,
+                              OctGather gather, const LevelDev *__restrict__ levels,
                               int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
                               size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes)
 {
     extern __shared__ uint32_t oct_lds[];
+    // the jobs are few, long and serial: let them issue ahead of the VALU-bound waves of other streams' kernels that
+    // share the SIMD (without this the kernel stretches from 0.19 to 0.27 ms when it overlaps FAST / describe)
+    __builtin_amdgcn_s_setprio(3);
     const int job = blockIdx.x;
     const int l = job / batch, b = job - l * batch;
-    octree_job(b, l, dense, dense_stride, level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, oct_lds,
+    octree_job(b, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, oct_lds,
                lds_bytes);
 }
 
@@ -603,15 +645,15 @@ __global__ __launch_bounds__(64) void octree_kernel(const uint32_t *__restrict__
 // reservation matches the jobs (the per-job kernel reserves the level-0 size for every level, which halves the
 // number of resident jobs), so all (image, level) jobs of a 256-image batch are resident at once.  The waves are
 // independent (wave-local fences only).
-__global__ __launch_bounds__(1024) void octree_image_kernel(const uint32_t *__restrict__ dense, size_t dense_stride,
-                              const int32_t *__restrict__ level_off, const LevelDev *__restrict__ levels,
+__global__ __launch_bounds__(1024) void octree_image_kernel(uint32_t *__restrict__ dense, size_t dense_stride,
+                              OctGather gather, const LevelDev *__restrict__ levels,
                               int n_levels, OctDevScratch scr, uint32_t *__restrict__ sel, size_t sel_stride,
                               int32_t *__restrict__ sel_level_cnt, int cap_level, OctImageLayout lay)
 {
     extern __shared__ uint32_t oct_lds[];
     const int l = threadIdx.x >> 6;
     if (l >= n_levels) return;
-    octree_job(blockIdx.x, l, dense, dense_stride, level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
+    octree_job(blockIdx.x, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
                oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
 }
 
@@ -974,12 +1016,12 @@ void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *
                        level_cell_begin, slots, slot_stride, cell_cnt, dense, dense_stride, level_off);
 }
 
-void launch_octree(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+void launch_octree(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
                    int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                    int32_t *sel_level_cnt, int cap_level, int lds_bytes, hipStream_t st)
 {
     const int jobs = batch * n_levels;
-    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), (size_t)lds_bytes, st, dense, dense_stride, level_off,
+    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), (size_t)lds_bytes, st, dense, dense_stride, gather,
                        levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lds_bytes);
 }
 
@@ -988,12 +1030,12 @@ int prepare_octree_image_kernel(int total_lds)
     return (int)hipFuncSetAttribute((const void *)octree_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, total_lds);
 }
 
-void launch_octree_image(const uint32_t *dense, size_t dense_stride, const int32_t *level_off, const LevelDev *levels,
+void launch_octree_image(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
                          int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                          int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st)
 {
     hipLaunchKernelGGL(octree_image_kernel, dim3(batch), dim3(64 * n_levels), (size_t)lay.total, st, dense, dense_stride,
-                       level_off, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
+                       gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
 }
 
 void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

@@ -134,22 +134,41 @@ __device__ inline int coop_lane() { return (int)(threadIdx.x & 63); }
 __device__ inline void coop_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 __device__ inline unsigned long long coop_ballot(bool p) { return __ballot(p); }
 __device__ inline int coop_popc(unsigned long long m) { return __popcll(m); }
-__device__ inline int coop_shfl(int v, int src) { return __shfl(v, src); }
+__device__ inline int coop_shfl(int v, int src) { return __shfl(v, src); }   // lane-varying source: ds_bpermute_b32
+// Wave reductions / scans on DPP (4 + 2 row-level steps, no LDS round trips; __shfl_xor / __shfl_up compile to
+// ds_bpermute_b32, i.e. 6 dependent LDS accesses per call -- these helpers sit on the jobs' serial path).
+__device__ inline int coop_row_reduce_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return v;   // every lane: the sum of its row of 16
+}
 __device__ inline int coop_sum(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    v = coop_row_reduce_add(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ inline int coop_max(int v)   // v >= 0
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ inline int coop_excl_scan(int v)  // exclusive prefix sum over the lanes
 {
-    const int lane = coop_lane();
     int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8  -> inclusive scan inside each row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return x - v;
 }
 __device__ inline int coop_ffs(unsigned long long m) { return __ffsll((long long)m) - 1; }
@@ -158,6 +177,7 @@ inline int coop_lane() { return 0; }
 inline int coop_ffs(unsigned long long m) { return __builtin_ffsll((long long)m) - 1; }
 inline int coop_shfl(int v, int) { return v; }
 inline int coop_sum(int v) { return v; }
+inline int coop_max(int v) { return v; }
 inline int coop_excl_scan(int) { return 0; }
 inline void coop_sync() {}
 inline unsigned long long coop_ballot(bool p) { return p ? 1ull : 0ull; }
