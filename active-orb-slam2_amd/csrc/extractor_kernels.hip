@@ -255,6 +255,13 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int TP)
     return max(v - minmax, maxmin - v) - 1;
 }
 
+// number of set bits of a ballot below this lane: v_mbcnt_lo + v_mbcnt_hi (instead of masking with (1 << lane) - 1 and
+// two v_bcnt)
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2_t as_us2(uint32_t x) { return __builtin_bit_cast(us2_t, x); }
 __device__ __forceinline__ uint32_t as_u32(us2_t x) { return __builtin_bit_cast(uint32_t, x); }
@@ -324,17 +331,28 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     }
     const int cw = cell.cw, ch = cell.ch;
     const int lane = threadIdx.x;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const int nq = (cw + 3) >> 2;           // 4-pixel groups per row
     const int ndw = nq + 2;                 // dwords staged per row: [halo | nq quads | halo]
 
-    // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c
+    // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c.  Lane grid (rows x ndw dwords) fixed once per wave;
+    // up to 8 row steps are requested together before the first LDS write.
     {
-        const uint8_t *src = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);
-        const uint32_t total = (uint32_t)((ch + 6) * ndw), pitch = (uint32_t)lv.pitch;
-        for (uint32_t i = lane; i < total; i += 64) {
-            const uint32_t r = (i * cell.inv_ndw) >> 16, c = i - r * (uint32_t)ndw;
-            *reinterpret_cast<uint32_t *>(tile + r * (uint32_t)TP + 4 * c) = load_u32_unaligned(src + (r * pitch + 4 * c));
+        const int nrs = max(1, (int)((64u * cell.inv_ndw) >> 16));      // rows per step = 64 / ndw (cells are < 64 px wide: ndw <= 18)
+        const int rs = (int)(((uint32_t)lane * cell.inv_ndw) >> 16), c = lane - rs * ndw;
+        const int nrows = ch + 6;
+        if (rs < nrs) {
+            const uint8_t *src = plane + (size_t)(cell.vy0 - 3 + rs) * lv.pitch + (cell.vx0 - 4) + 4 * c;
+            uint8_t *dst = tile + rs * TP + 4 * c;
+            const uint32_t sstep = (uint32_t)(nrs * lv.pitch), dstep = (uint32_t)(nrs * TP);
+            for (int r0 = rs; r0 < nrows; r0 += 8 * nrs, src += 8 * (size_t)sstep, dst += 8 * dstep) {
+                uint32_t t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u * nrs < nrows) t[u] = load_u32_unaligned(src + u * sstep);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + u * nrs < nrows) *reinterpret_cast<uint32_t *>(dst + u * dstep) = t[u];
+            }
         }
     }
     const int SH = ch + 2;
@@ -394,13 +412,13 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
             if ((b0 | b1 | b2 | b3) == 0ull) continue;
             const int base = (py << 6) | x0;
-            if (p0) list1[n1 + __popcll(b0 & lt)] = (uint16_t)base;
+            if (p0) list1[n1 + lanes_below(b0)] = (uint16_t)base;
             n1 += __popcll(b0);
-            if (p1) list1[n1 + __popcll(b1 & lt)] = (uint16_t)(base + 1);
+            if (p1) list1[n1 + lanes_below(b1)] = (uint16_t)(base + 1);
             n1 += __popcll(b1);
-            if (p2) list1[n1 + __popcll(b2 & lt)] = (uint16_t)(base + 2);
+            if (p2) list1[n1 + lanes_below(b2)] = (uint16_t)(base + 2);
             n1 += __popcll(b2);
-            if (p3) list1[n1 + __popcll(b3 & lt)] = (uint16_t)(base + 3);
+            if (p3) list1[n1 + lanes_below(b3)] = (uint16_t)(base + 3);
             n1 += __popcll(b3);
         }
         __syncthreads();
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                            sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
             }
             const unsigned long long bk = __ballot(keep);
-            if (keep) list3[nkept + __popcll(bk & lt)] = ((uint32_t)pos << 8) | (uint32_t)sc;
+            if (keep) list3[nkept + lanes_below(bk)] = ((uint32_t)pos << 8) | (uint32_t)sc;
             nkept += __popcll(bk);
         }
         if (nkept > 0 || th == min_th) break;

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed `extra` rows (matcher / BA / stereo / vocabulary): used for the rocprofv3 summaries, whose per-kernel averages should cover the timed workload only")
     args = ap.parse_args()
 
     import torch  # first: the library then binds to the same HIP runtime as torch
@@ -139,7 +140,7 @@ def main():
     extra = {"synchronous_call_ms_per_step": dt_sync / args.steps * 1e3,
              "synchronous_call_note": "aos2_extractor_extract_batch_device (host waits for every step); `value` enqueues the K steps with "
                                       "aos2_extractor_extract_batch_device_async and waits once"}
-    if rank == 0:
+    if rank == 0 and not args.no_extra:
         try:
             S = pkg.synth
             rng = np.random.default_rng(0)
@@ -306,9 +307,28 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": fast_bytes, "kernel_ms": fast_ms,
-                         "note": "instruction-issue bound, not bandwidth bound (profiles/README.md): ~1040 VALU + 450 SALU + 130 LDS instructions per 1.2k-px cell-wave; VALU ~46 % busy at 2 cycles per wave64 instruction, 4 waves/SIMD (LDS-limited)"},
+                         "note": "integer-VALU bound, not bandwidth bound: the kernel keeps the vector ALUs ~92 % busy (VALUBusy = "
+                                 "4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE, profiles/r01_pmc_sq_busy.csv) at the issue rates "
+                                 "measured on this chip (tools/microbench/valu_rate.hip -> profiles/r01_valu_rate.txt: 4 cycles per "
+                                 "wave64 instruction for packed-16 / min / max / compare / dot / perm / mad, 2 for add / sub / logic / "
+                                 "mov / f32); ~810 VALU instructions per 1.2k-pixel cell-wave, so the HBM fraction can only rise by "
+                                 "removing instructions (profiles/README.md has the history: 1040 -> 810 per cell-wave this round)"},
             "extra": extra,
         }
+        # the other two streaming kernels of the step, from the un-chunked stage times (HIP events of the library)
+        out["roofline_other"] = [
+            {"kernel": "describe_kernel", "bound": "hbm", "kernel_ms": stage["describe"],
+             "algorithmic_bytes_per_launch": float(n_kp.sum()) * (749 + 512 + 60),
+             "achieved": float(n_kp.sum()) * (749 + 512 + 60) / (stage["describe"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+             "frac": float(n_kp.sum()) * (749 + 512 + 60) / (stage["describe"] * 1e-3) / 1e9 / 8000.0,
+             "note": "integer-VALU bound as well (VALUBusy ~84 %, profiles/r01_pmc_sq_busy.csv): ~585 VALU instructions per keypoint "
+                     "(7x7 blur of the 43x37 patch = 55 %, 512 steered samples = 20 %, IC_Angle + exact sin/cos = 20 %)"},
+            {"kernel": "resize_level_kernel x7", "bound": "hbm", "kernel_ms": stage["pyramid"],
+             "algorithmic_bytes_per_launch": 1.57e6 * B,
+             "achieved": 1.57e6 * B / (stage["pyramid"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+             "frac": 1.57e6 * B / (stage["pyramid"] * 1e-3) / 1e9 / 8000.0,
+             "note": "seven dependent launches (level k is resized from level k-1); the large levels run at 3.2-3.5 TB/s, the small "
+                     "ones are launch / tail bound; VALUBusy 35 %"}]
         # HBM-side bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes
         try:
             import csv
