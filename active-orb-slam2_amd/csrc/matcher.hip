@@ -194,6 +194,80 @@ struct Entry {
     uint32_t payload;  // feature index | octave << 24
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Stage B without the serial chain (the greedy searches).  The reference's loops are greedy assignments: query q
+// (a map point / keyframe feature, visited in a fixed order) sees feature f as taken iff an EARLIER query that
+// "blocks" chose f, or f was taken before the call.  Let B[f] = the smallest such q (-1: before the call, INT_MAX:
+// never).  Then every query can decide on its own ("f is blocked for q iff B[f] < q") and B follows from the
+// decisions: a fixed point that is unique and equal to the sequential result (induction over q: the decision of q
+// only reads B restricted to queries < q).  Iterating "all decisions from the previous B, in parallel -> next B"
+// makes at least one more leading query final per pass and in practice converges in a handful of passes, because
+// conflicts between search windows are rare.  One workgroup per problem, B double-buffered in LDS, the decisions
+// (choice[q] = feature or -1) in global scratch; the caller turns the final decisions into the method's outputs.
+// ---------------------------------------------------------------------------------------------
+struct Best2 {
+    uint32_t k1, k2, p1, p2;   // smallest / second smallest key among the free candidates and their payloads
+};
+
+__device__ __forceinline__ Best2 scan_best2_free(const Entry *__restrict__ ent, int cnt, const int32_t *B, int q, uint32_t idx_mask)
+{
+    Best2 r{KEY_NONE, KEY_NONE, 0u, 0u};
+    for (int j0 = 0; j0 < cnt; j0 += 8) {   // 8 entries per memory round trip (a window / bucket rarely holds more)
+        Entry eb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) eb[u] = j0 + u < cnt ? ent[j0 + u] : Entry{KEY_NONE, 0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const Entry e = eb[u];
+            if (e.key == KEY_NONE || B[e.payload & idx_mask] < q) continue;
+            if (e.key < r.k1) {
+                r.k2 = r.k1; r.p2 = r.p1;
+                r.k1 = e.key; r.p1 = e.payload;
+            } else if (e.key < r.k2) {
+                r.k2 = e.key; r.p2 = e.payload;
+            }
+        }
+    }
+    return r;
+}
+
+// initB(f) -> -1 (taken before the call) or INT_MAX; ent_of(q, cnt) -> the query's entries; accept(q, Best2) -> chosen
+// feature or -1; blocks(q) -> whether a choice of q hides the feature from later queries.  All NT threads call it.
+template <int NT, class InitB, class EntOf, class Accept, class Blocks>
+__device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds, int32_t *choice, uint32_t idx_mask,
+                                                 InitB initB, EntOf ent_of, Accept accept, Blocks blocks)
+{
+    __shared__ int changed;
+    const int tid = threadIdx.x;
+    int32_t *Bc = lds, *Bn = lds + n_f;
+    for (int i = tid; i < n_f; i += NT) Bc[i] = initB(i);
+    for (int q = tid; q < n_q; q += NT) choice[q] = -2;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) changed = 0;
+        for (int i = tid; i < n_f; i += NT) Bn[i] = initB(i);
+        __syncthreads();
+        bool ch = false;
+        for (int q = tid; q < n_q; q += NT) {
+            int cnt = 0;
+            const Entry *ent = ent_of(q, cnt);
+            int c = -1;
+            if (cnt > 0) c = accept(q, scan_best2_free(ent, cnt, Bc, q, idx_mask));
+            if (c != choice[q]) {
+                ch = true;
+                choice[q] = c;
+            }
+            if (c >= 0 && blocks(q)) atomicMin(&Bn[c], q);
+        }
+        if (ch) changed = 1;
+        __syncthreads();
+        if (!changed) break;   // the decisions reproduced themselves: B is the fixed point
+        int32_t *t = Bc; Bc = Bn; Bn = t;
+        __syncthreads();
+    }
+}
+
 // SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  :159-288
 struct BowQuery {
     int32_t kf_idx;   // realIdxKF
@@ -217,6 +291,7 @@ struct BowPairDev {
     const uint8_t *f_has_mp;  // vpMapPoints2[idx2] && !isBad(); candidates without one are skipped (:572-577)
     int32_t *match_1;         // n_kf: vpMatches12 as KF2 feature indices
     int32_t *bin_1;           // n_kf scratch: rotHist bin + 1 of a matched KF1 feature
+    int32_t *choice;          // n_queries scratch of the parallel stage B
 };
 
 // stage A: grid = (max queries, pairs); one wave per query
@@ -362,6 +437,88 @@ __global__ __launch_bounds__(64) void bow_resolve_kernel(const BowPairDev *__res
         }
     }
     if (lane == 0) *P.nmatches = nmatches;
+}
+
+// parallel stage B of both SearchByBoW forms (resolve_fixpoint): every match hides its frame feature (:209, :577)
+__global__ __launch_bounds__(512) void bow_resolve_fix_kernel(const BowPairDev *__restrict__ pairs, float nnratio, int check_ori)
+{
+    constexpr int NT = 512;
+    extern __shared__ int32_t fix_lds[];
+    __shared__ int histo[HISTO];
+    __shared__ int total;
+    const BowPairDev P = pairs[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (!P.kf_kf) {
+        for (int i = tid; i < P.n_f; i += NT) {
+            P.match_f[i] = -1;
+            P.bin_f[i] = 0;
+        }
+    } else {
+        for (int i = tid; i < P.n_kf; i += NT) {
+            P.match_1[i] = -1;
+            P.bin_1[i] = 0;
+        }
+    }
+    if (tid < HISTO) histo[tid] = 0;
+    if (tid == 0) total = 0;
+    resolve_fixpoint<NT>(
+        P.n_f, P.n_queries, fix_lds, P.choice, 0xffffffffu,
+        [&](int i) { return (P.kf_kf && !P.f_has_mp[i]) ? -1 : INT_MAX; },   // vbMatched2 || !pMP2 || isBad (:572-577)
+        [&](int q, int &cnt) {
+            const BowQuery bq = P.queries[q];
+            cnt = bq.f_cnt;
+            return (const Entry *)(P.entries + bq.ent_off);
+        },
+        [&](int, const Best2 &b) {
+            const int bestDist1 = b.k1 == KEY_NONE ? 256 : (int)(b.k1 >> 20);
+            const int bestDist2 = b.k2 == KEY_NONE ? 256 : (int)(b.k2 >> 20);
+            // (KF, F): bestDist1 <= TH_LOW (:237); (KF, KF): bestDist1 < TH_LOW (:599)
+            const bool low = P.kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;
+            return (low && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) ? (int)b.p1 : -1;
+        },
+        [&](int) { return true; });
+    int cnt = 0;
+    for (int q = tid; q < P.n_queries; q += NT) {
+        const int c = P.choice[q];
+        if (c < 0) continue;
+        const int kf = P.queries[q].kf_idx;
+        int bin = 0;
+        if (check_ori) {
+            bin = rot_bin(__fsub_rn(P.angle_kf[kf], P.angle_f[c]));
+            atomicAdd(&histo[bin], 1);
+        }
+        if (!P.kf_kf) {   // a frame feature is chosen by at most one query
+            P.match_f[c] = kf;
+            if (check_ori) P.bin_f[c] = 1u << bin;
+        } else {
+            P.match_1[kf] = c;
+            P.bin_1[kf] = bin + 1;
+        }
+        ++cnt;
+    }
+    if (cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    int nmatches = total;
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        uint32_t culled = 0;
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) {
+                culled |= 1u << i;
+                nmatches -= histo[i];  // one decrement per pushed entry (:281, :650)
+            }
+        if (!P.kf_kf) {
+            for (int i = tid; i < P.n_f; i += NT)
+                if (P.bin_f[i] & culled) P.match_f[i] = -1;
+        } else {
+            for (int i = tid; i < P.n_kf; i += NT) {
+                const int bn = P.bin_1[i];
+                if (bn > 0 && ((culled >> (bn - 1)) & 1u)) P.match_1[i] = -1;
+            }
+        }
+    }
+    if (tid == 0) *P.nmatches = nmatches;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -803,12 +960,61 @@ __global__ __launch_bounds__(64) void proj_mp_resolve_kernel(FrameDev F, ProjMpD
     proj_mp_resolve_body(F, P, nnratio, slots, pool, match_f, nmatches_out);
 }
 
+// parallel stage B of SearchByProjection(F, vpMapPoints, th) (resolve_fixpoint above): a map point WITH observations
+// hides its feature from later map points (:62-64); match_f[f] = the LAST map point that chose f (:94 overwrites)
+template <int NT>
+__device__ __forceinline__ void proj_mp_resolve_fix_body(const FrameDev &F, const ProjMpDev &P, float nnratio,
+                                                         const QuerySlot *__restrict__ slots, const Entry *__restrict__ pool,
+                                                         int32_t *match_f, int32_t *nmatches_out, int32_t *choice)
+{
+    extern __shared__ int32_t fix_lds[];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < F.n_f; i += NT) match_f[i] = -1;
+    if (tid == 0) total = 0;
+    resolve_fixpoint<NT>(
+        F.n_f, P.n_mp, fix_lds, choice, 0xffffffu, [&](int i) { return F.f_mp_state[i] == 2 ? -1 : INT_MAX; },
+        [&](int q, int &cnt) {
+            const QuerySlot s = slots[q];
+            cnt = s.cnt;
+            return pool + s.ent_off;
+        },
+        [&](int, const Best2 &b) {
+            const int bestDist = b.k1 == KEY_NONE ? 256 : (int)(b.k1 >> 20);
+            const int bestDist2 = b.k2 == KEY_NONE ? 256 : (int)(b.k2 >> 20);
+            const int oct1 = b.k1 == KEY_NONE ? -1 : (int)(b.p1 >> 24), oct2 = b.k2 == KEY_NONE ? -1 : (int)(b.p2 >> 24);
+            if (bestDist <= TH_HIGH && !(oct1 == oct2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2)))
+                return (int)(b.p1 & 0xffffffu);
+            return -1;
+        },
+        [&](int q) { return P.has_obs[q] != 0; });
+    int cnt = 0;
+    for (int q = tid; q < P.n_mp; q += NT) {
+        const int c = choice[q];
+        if (c >= 0) {
+            atomicMax(&match_f[c], q);
+            ++cnt;
+        }
+    }
+    if (cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    if (tid == 0) *nmatches_out = total;
+}
+
+__global__ __launch_bounds__(1024) void proj_mp_resolve_fix_kernel(FrameDev F, ProjMpDev P, float nnratio,
+                                                                   const QuerySlot *__restrict__ slots,
+                                                                   const Entry *__restrict__ pool, int32_t *match_f,
+                                                                   int32_t *nmatches_out, int32_t *choice)
+{
+    proj_mp_resolve_fix_body<1024>(F, P, nnratio, slots, pool, match_f, nmatches_out, choice);
+}
+
 // batched form: problem = blockIdx.y (stage A) / blockIdx.x (stage B); one entry pool shared through pool_used
 struct ProjMpItem {
     FrameDev F;
     ProjMpDev P;
     QuerySlot *slots;
-    int32_t *match_f, *nmatches;
+    int32_t *match_f, *nmatches, *choice;
 };
 __global__ __launch_bounds__(64) void proj_mp_entries_batch_kernel(const ProjMpItem *__restrict__ items, float th, Entry *pool,
                                                                    int32_t *pool_used, int pool_cap)
@@ -822,6 +1028,13 @@ __global__ __launch_bounds__(64) void proj_mp_resolve_batch_kernel(const ProjMpI
 {
     const ProjMpItem &it = items[blockIdx.x];
     proj_mp_resolve_body(it.F, it.P, nnratio, it.slots, pool, it.match_f, it.nmatches);
+}
+
+__global__ __launch_bounds__(256) void proj_mp_resolve_fix_batch_kernel(const ProjMpItem *__restrict__ items, float nnratio,
+                                                                        const Entry *__restrict__ pool)
+{
+    const ProjMpItem &it = items[blockIdx.x];
+    proj_mp_resolve_fix_body<256>(it.F, it.P, nnratio, it.slots, pool, it.match_f, it.nmatches, it.choice);
 }
 
 struct ProjLastDev {
@@ -957,6 +1170,65 @@ __global__ __launch_bounds__(64) void proj_last_resolve_kernel(FrameDev F, ProjL
             if (bin_f[i] & culled) match_f[i] = -2;  // set to NULL (:1459)
     }
     if (lane == 0) *nmatches_out = nmatches;
+}
+
+// parallel stage B of SearchByProjection(CurrentFrame, LastFrame, th, bMono) (resolve_fixpoint)
+__global__ __launch_bounds__(1024) void proj_last_resolve_fix_kernel(FrameDev F, ProjLastDev P, int check_ori,
+                                                                     const QuerySlot *__restrict__ slots,
+                                                                     const Entry *__restrict__ pool, int32_t *match_f,
+                                                                     uint32_t *bin_f, int32_t *nmatches_out, int32_t *choice)
+{
+    constexpr int NT = 1024;
+    extern __shared__ int32_t fix_lds[];
+    __shared__ int histo[HISTO];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < F.n_f; i += NT) {
+        match_f[i] = -1;
+        bin_f[i] = 0;
+    }
+    if (tid < HISTO) histo[tid] = 0;
+    if (tid == 0) total = 0;
+    resolve_fixpoint<NT>(
+        F.n_f, P.n_last, fix_lds, choice, 0xffffffu, [&](int i) { return F.f_mp_state[i] == 2 ? -1 : INT_MAX; },
+        [&](int q, int &cnt) {
+            const QuerySlot s = slots[q];
+            cnt = s.cnt;
+            return pool + s.ent_off;
+        },
+        [&](int, const Best2 &b) { return (b.k1 != KEY_NONE && (int)(b.k1 >> 20) <= TH_HIGH) ? (int)(b.p1 & 0xffffffu) : -1; },
+        [&](int q) { return P.has_obs[q] != 0; });
+    int cnt = 0;
+    for (int q = tid; q < P.n_last; q += NT) {
+        const int c = choice[q];
+        if (c >= 0) {
+            atomicMax(&match_f[c], q);
+            if (check_ori) {
+                // a feature can be pushed several times when a zero-observation point is overwritten (:1432): it is
+                // reset if ANY of its bins is culled, and nmatches drops once per pushed entry (:1459-1460)
+                const int bin = rot_bin(__fsub_rn(P.last_angle[q], F.kp_angle[c]));
+                atomicAdd(&histo[bin], 1);
+                atomicOr(&bin_f[c], 1u << bin);
+            }
+            ++cnt;
+        }
+    }
+    if (cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    int nmatches = total;
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        uint32_t culled = 0;
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) {
+                culled |= 1u << i;
+                nmatches -= histo[i];
+            }
+        for (int i = tid; i < F.n_f; i += NT)
+            if (bin_f[i] & culled) match_f[i] = -2;  // set to NULL (:1459)
+    }
+    if (tid == 0) *nmatches_out = nmatches;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1363,6 +1635,60 @@ __global__ __launch_bounds__(64) void projgen_resolve_kernel(FrameDev F, ProjGen
     if (lane == 0) *nmatches_out = nmatches;
 }
 
+// modes 2, 4 parallel stage B (resolve_fixpoint): every match hides its feature, so a feature has one owner
+__global__ __launch_bounds__(1024) void projgen_resolve_fix_kernel(FrameDev F, ProjGenDev P, int thr, int check_ori,
+                                                                   const QuerySlot *__restrict__ slots,
+                                                                   const Entry *__restrict__ pool, int32_t *match_f,
+                                                                   int32_t *bin_f, int32_t *nmatches_out, int32_t *choice)
+{
+    constexpr int NT = 1024;
+    extern __shared__ int32_t fix_lds[];
+    __shared__ int histo[HISTO];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < F.n_f; i += NT) {
+        match_f[i] = -1;
+        bin_f[i] = 0;
+    }
+    if (tid < HISTO) histo[tid] = 0;
+    if (tid == 0) total = 0;
+    resolve_fixpoint<NT>(
+        F.n_f, P.n_pts, fix_lds, choice, 0xffffffu, [&](int i) { return F.f_mp_state[i] != 0 ? -1 : INT_MAX; },
+        [&](int q, int &cnt) {
+            const QuerySlot s = slots[q];
+            cnt = s.cnt;
+            return pool + s.ent_off;
+        },
+        [&](int, const Best2 &b) { return (b.k1 != KEY_NONE && (int)(b.k1 >> 20) <= thr) ? (int)(b.p1 & 0xffffffu) : -1; },
+        [&](int) { return true; });
+    int cnt = 0;
+    for (int q = tid; q < P.n_pts; q += NT) {
+        const int c = choice[q];
+        if (c < 0) continue;
+        match_f[c] = q;
+        if (check_ori) {
+            const int bin = rot_bin(__fsub_rn(P.q_angle[q], F.kp_angle[c]));
+            atomicAdd(&histo[bin], 1);
+            bin_f[c] = bin + 1;
+        }
+        ++cnt;
+    }
+    if (cnt) atomicAdd(&total, cnt);
+    __syncthreads();
+    int nmatches = total;
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(histo, i1, i2, i3);
+        for (int i = 0; i < HISTO; ++i)
+            if (i != i1 && i != i2 && i != i3) nmatches -= histo[i];
+        for (int i = tid; i < F.n_f; i += NT) {
+            const int bn = bin_f[i] - 1;
+            if (bn >= 0 && bn != i1 && bn != i2 && bn != i3) match_f[i] = -2;  // set to NULL (:1589)
+        }
+    }
+    if (tid == 0) *nmatches_out = nmatches;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  :405-520 (monocular bootstrap).
 // Stage A: one wave per level-0 F1 feature, window of F2 around vbPrevMatched[i1] restricted to level 0.
@@ -1495,6 +1821,9 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameDev F2, InitDev P
 
 using namespace aos2;
 
+// LDS budget of the fixed-point resolve kernels (two int32 copies of B[n_f]): default dynamic-LDS limit
+constexpr size_t kFixLdsBytes = 60 * 1024;
+
 struct aos2_matcher {
     float nnratio;
     int check_ori;
@@ -1506,6 +1835,7 @@ struct aos2_matcher {
     DevBuf<uint32_t> part;     // hamming partials
     DevBuf<uint64_t> pool;     // candidate entries of the projection searches (8 B each)
     float last_ms = 0;         // device time of the kernels of the last search call
+    bool serial_resolve = false;   // AOS2_SERIAL_RESOLVE=1: the one-wave sequential stage B (tests compare both)
 };
 
 namespace aos2 {
@@ -1517,6 +1847,10 @@ static int matcher_init(aos2_matcher *m)
     if (m->dev_ready) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     for (auto &e : m->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
+    {
+        const char *v = getenv("AOS2_SERIAL_RESOLVE");
+        m->serial_resolve = v && atoi(v) != 0;
+    }
     m->dev_ready = true;
     return AOS2_OK;
 }
@@ -1709,7 +2043,7 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
     int st = matcher_init(m);
     if (st) return st;
     Arena A{m};
-    struct Off { size_t o[12]; int nq; };
+    struct Off { size_t o[13]; int nq; };
     std::vector<Off> offs(n_pairs);
     std::vector<BowQuery> queries;
     int max_nf = 0, max_q = 0;
@@ -1762,6 +2096,7 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         o.o[7] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
         o.o[8] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
         o.o[9] = A.reserve(4);                      // nmatches
+        o.o[12] = A.reserve(queries.size() * 4 + 4);  // choice (parallel stage B)
         if (kf_kf) {
             o.o[10] = A.push(f_has_mp[p], (size_t)P.n_f);
             o.o[11] = A.reserve((size_t)P.n_kf * 8 + 8);  // match_1 | bin_1
@@ -1786,6 +2121,7 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         D.node_idx_f = A.dev<int32_t>(o.o[4]); D.queries = A.dev<BowQuery>(o.o[5]); D.entries = A.dev<Entry>(o.o[6]);
         D.match_f = A.dev<int32_t>(o.o[7]); D.bin_f = A.dev<uint32_t>(o.o[8]); D.nmatches = A.dev<int32_t>(o.o[9]);
         D.kf_kf = kf_kf;
+        D.choice = A.dev<int32_t>(o.o[12]);
         D.f_has_mp = nullptr; D.match_1 = nullptr; D.bin_1 = nullptr;
         if (kf_kf) {
             D.f_has_mp = A.dev<uint8_t>(o.o[10]);
@@ -1798,8 +2134,12 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
     AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
     if (max_q > 0)
         hipLaunchKernelGGL(bow_distances_kernel, dim3(max_q, n_pairs), dim3(64), 0, m->stream, A.dev<BowPairDev>(opairs));
-    hipLaunchKernelGGL(bow_resolve_kernel, dim3(n_pairs), dim3(64), (size_t)max_nf + 16, m->stream,
-                       A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
+    if ((size_t)max_nf * 8 <= kFixLdsBytes && !m->serial_resolve)
+        hipLaunchKernelGGL(bow_resolve_fix_kernel, dim3(n_pairs), dim3(512), (size_t)max_nf * 8 + 16, m->stream,
+                           A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
+    else
+        hipLaunchKernelGGL(bow_resolve_kernel, dim3(n_pairs), dim3(64), (size_t)max_nf + 16, m->stream,
+                           A.dev<BowPairDev>(opairs), m->nnratio, m->check_ori);
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     for (int p = 0; p < n_pairs; ++p) {
         if (!kf_kf)
@@ -2001,6 +2341,7 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     const size_t o6 = A.push(p->proj_y, n * 4), o7 = A.push(p->proj_xr, n * 4);
     const size_t om = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(8);
     const size_t oslots = A.reserve((size_t)(p->n_mp + 1) * sizeof(QuerySlot));
+    const size_t ochoice = A.reserve((size_t)(p->n_mp + 1) * 4);
     const size_t pool_cap = (size_t)p->n_mp * (size_t)f->n_f;   // a window holds at most every feature
     if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
         set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_mp, f->n_f);
@@ -2020,9 +2361,14 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     if (p->n_mp > 0)
         hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th,
                            A.dev<QuerySlot>(oslots), reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
-    hipLaunchKernelGGL(proj_mp_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, m->nnratio,
-                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
-                       A.dev<int32_t>(on));
+    if ((size_t)f->n_f * 8 <= kFixLdsBytes && !m->serial_resolve)
+        hipLaunchKernelGGL(proj_mp_resolve_fix_kernel, dim3(1), dim3(1024), (size_t)f->n_f * 8 + 16, m->stream, F, P, m->nnratio,
+                           A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                           A.dev<int32_t>(on), A.dev<int32_t>(ochoice));
+    else   // the one-wave sequential loop: frames with more features than the LDS copy of B holds, or AOS2_SERIAL_RESOLVE=1
+        hipLaunchKernelGGL(proj_mp_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, m->nnratio,
+                           A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                           A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
@@ -2060,7 +2406,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     }
     if ((st = matcher_init(m))) return st;
     Arena A{m};
-    struct Off { size_t fo[12], o[8], om, on, oslots; };
+    struct Off { size_t fo[12], o[8], om, on, oslots, ochoice; };
     std::vector<Off> offs(n_problems);
     for (int i = 0; i < n_problems; ++i) {
         const aos2_proj_mp_t *p = &problems[i];
@@ -2073,6 +2419,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         o.om = A.reserve((size_t)frames[i].n_f * 4 + 4);
         o.on = A.reserve(8);
         o.oslots = A.reserve((n + 1) * sizeof(QuerySlot));
+        o.ochoice = A.reserve((n + 1) * 4);
     }
     const size_t oitems = A.reserve(sizeof(ProjMpItem) * (size_t)n_problems), oused = A.reserve(8);
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
@@ -2091,6 +2438,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         it.slots = A.dev<QuerySlot>(o.oslots);
         it.match_f = A.dev<int32_t>(o.om);
         it.nmatches = A.dev<int32_t>(o.on);
+        it.choice = A.dev<int32_t>(o.ochoice);
     }
     memcpy(A.host.data() + oitems, items.data(), sizeof(ProjMpItem) * (size_t)n_problems);
     if ((st = A.upload())) return st;
@@ -2100,8 +2448,12 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     if (max_mp > 0)
         hipLaunchKernelGGL(proj_mp_entries_batch_kernel, dim3(max_mp, n_problems), dim3(64), 0, m->stream,
                            A.dev<ProjMpItem>(oitems), th, reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
-    hipLaunchKernelGGL(proj_mp_resolve_batch_kernel, dim3(n_problems), dim3(64), (size_t)max_nf + 16, m->stream,
-                       A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
+    if ((size_t)max_nf * 8 <= kFixLdsBytes && !m->serial_resolve)
+        hipLaunchKernelGGL(proj_mp_resolve_fix_batch_kernel, dim3(n_problems), dim3(256), (size_t)max_nf * 8 + 16, m->stream,
+                           A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
+    else
+        hipLaunchKernelGGL(proj_mp_resolve_batch_kernel, dim3(n_problems), dim3(64), (size_t)max_nf + 16, m->stream,
+                           A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     std::vector<int32_t> used(1);
     AOS2_HIP_CHECK(hipMemcpyAsync(used.data(), d_used, 4, hipMemcpyDeviceToHost, m->stream));
@@ -2139,6 +2491,7 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     const size_t o3 = A.push(p->world_pos, n * 12), o4 = A.push(p->last_angle, n * 4), o5 = A.push(p->last_octave, n * 4);
     const size_t om = A.reserve((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve(8);
     const size_t oslots = A.reserve((size_t)(p->n_last + 1) * sizeof(QuerySlot));
+    const size_t ochoice = A.reserve((size_t)(p->n_last + 1) * 4);
     const size_t pool_cap = (size_t)p->n_last * (size_t)cur->n_f;
     if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
         set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_last, cur->n_f);
@@ -2160,9 +2513,14 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     if (p->n_last > 0)
         hipLaunchKernelGGL(proj_last_entries_kernel, dim3(p->n_last), dim3(64), 0, m->stream, F, P, th, mono ? 1 : 0,
                            A.dev<QuerySlot>(oslots), reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
-    hipLaunchKernelGGL(proj_last_resolve_kernel, dim3(1), dim3(64), (size_t)cur->n_f + 16, m->stream, F, P, m->check_ori,
-                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
-                       A.dev<uint32_t>(ob), A.dev<int32_t>(on));
+    if ((size_t)cur->n_f * 8 <= kFixLdsBytes && !m->serial_resolve)
+        hipLaunchKernelGGL(proj_last_resolve_fix_kernel, dim3(1), dim3(1024), (size_t)cur->n_f * 8 + 16, m->stream, F, P,
+                           m->check_ori, A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p),
+                           A.dev<int32_t>(om), A.dev<uint32_t>(ob), A.dev<int32_t>(on), A.dev<int32_t>(ochoice));
+    else
+        hipLaunchKernelGGL(proj_last_resolve_kernel, dim3(1), dim3(64), (size_t)cur->n_f + 16, m->stream, F, P, m->check_ori,
+                           A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                           A.dev<uint32_t>(ob), A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)cur->n_f * 4, hipMemcpyDeviceToHost, m->stream));
     AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
@@ -2446,6 +2804,7 @@ static int projgen_serial(aos2_matcher_t *m, const aos2_frame_view_t *f, const a
     ProjGenDev P = points_dev(A, p, mode, f->n_levels);
     const size_t om = A.reserve((size_t)f->n_f * 4 + 4), ob = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(8);
     const size_t oslots = A.reserve((size_t)(p->n_pts + 1) * sizeof(QuerySlot));
+    const size_t ochoice = A.reserve((size_t)(p->n_pts + 1) * 4);
     const size_t pool_cap = (size_t)p->n_pts * (size_t)f->n_f;
     if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
         set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_pts, f->n_f);
@@ -2461,7 +2820,12 @@ static int projgen_serial(aos2_matcher_t *m, const aos2_frame_view_t *f, const a
     if (p->n_pts > 0)
         hipLaunchKernelGGL(projgen_entries_kernel, dim3(p->n_pts), dim3(64), 0, m->stream, F, P, A.dev<QuerySlot>(oslots),
                            reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
-    hipLaunchKernelGGL(projgen_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, thr, check_ori,
+    if ((size_t)f->n_f * 8 <= kFixLdsBytes && !m->serial_resolve)
+        hipLaunchKernelGGL(projgen_resolve_fix_kernel, dim3(1), dim3(1024), (size_t)f->n_f * 8 + 16, m->stream, F, P, thr, check_ori,
+                       A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
+                       A.dev<int32_t>(ob), A.dev<int32_t>(on), A.dev<int32_t>(ochoice));
+    else
+        hipLaunchKernelGGL(projgen_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, thr, check_ori,
                        A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
                        A.dev<int32_t>(ob), A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));

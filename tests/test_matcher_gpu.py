@@ -66,6 +66,64 @@ def test_search_by_projection_vs_oracle(pkg, oracle, gpu):
     assert n == on and (match == om).all()
 
 
+def test_search_by_projection_parallel_resolve_equals_sequential(pkg, oracle, gpu, monkeypatch):
+    """the fixed-point stage B (all map points decide in parallel from B[f] = first earlier taker, iterated until the
+    decisions reproduce themselves) == the one-wave sequential loop (AOS2_SERIAL_RESOLVE=1) == the oracle, also when
+    almost every map point competes for the same few features (long dependency chains, many passes)."""
+    S = pkg.synth
+    cases = [S.synth_proj_mp_problem(40, n_f=1200, n_mp=1500, th=3.0),
+             S.synth_proj_mp_problem(41, n_f=60, n_mp=2500, th=12.0),          # ~40 map points per feature
+             S.synth_proj_mp_problem(42, n_f=8, n_mp=900, th=40.0, w=160, h=120)]  # every window holds every feature
+    for f, mp in cases:
+        mp["has_obs"] = (np.arange(len(mp["has_obs"])) % 3 != 0).astype(np.uint8)   # mixes blocking / non-blocking takers
+        on, om = oracle.search_by_projection_mp(f, mp)
+        n, match = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+        assert n == on and (match == om).all()
+        monkeypatch.setenv("AOS2_SERIAL_RESOLVE", "1")
+        n2, match2 = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+        monkeypatch.delenv("AOS2_SERIAL_RESOLVE")
+        assert n2 == on and (match2 == om).all()
+    assert on > 0
+
+
+def test_greedy_searches_parallel_resolve_equals_sequential(pkg, oracle, gpu, monkeypatch):
+    """SearchByBoW (KF,F) / (KF,KF), SearchByProjection(Current, Last), SearchByProjection(pKF, Scw) and the
+    relocalisation search: fixed-point stage B == the one-wave
+    sequential stage B (AOS2_SERIAL_RESOLVE=1) == the oracle, including tiny vocabularies (every keyframe feature
+    competes for the same frame features)."""
+    S = pkg.synth
+    bow = [S.synth_bow_problem(60, 1000, 900, n_nodes=80), S.synth_bow_problem(61, 1200, 300, n_nodes=3),
+           S.synth_bow_problem(62, 800, 40, n_nodes=1, nnratio=0.95)]
+    bowkf = [S.synth_bow_kf_problem(63, 900, 900, n_nodes=60), S.synth_bow_kf_problem(64, 1000, 200, n_nodes=2, nnratio=0.95)]
+    last = [S.synth_proj_last_problem(70, n=1000, th=7.0), S.synth_proj_last_problem(71, n=1200, th=15.0, mono=True)]
+    gen = [S.synth_proj_gen_problem(80, n_f=1000, n_pts=1400, cfg="tum", th=10),
+           S.synth_proj_gen_problem(81, n_f=120, n_pts=2500, cfg="kitti", th=25)]      # ~20 points per feature
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("AOS2_SERIAL_RESOLVE", "1")
+        for p in bow:
+            n, match = pkg.Matcher(float(p["nnratio"]), bool(p["check_orientation"])).SearchByBoW(p)
+            on, om = oracle.search_by_bow(p)
+            assert n == on and (match == om).all()
+        for p in bowkf:
+            n, match = pkg.Matcher(float(p["nnratio"]), bool(p["check_orientation"])).SearchByBoWKF(p)
+            on, om = oracle.search_by_bow_kf(p)
+            assert n == on and (match == om).all()
+        for cur, p in last:
+            n, match = pkg.Matcher(0.9, bool(p["check_orientation"])).SearchByProjectionLast(cur, p, float(p["th"]), int(p["mono"]))
+            on, om = oracle.search_by_projection_last(cur, p)
+            assert n == on and (match == om).all()
+        for f, p in gen:        # SearchByProjection(pKF, Scw, ...) and the relocalisation search
+            n, match = pkg.Matcher().SearchByProjectionKF(f, p)
+            on, om = oracle.search_by_projection_kf(f, p)
+            assert n == on and (match == om).all()
+            for ori in (True, False):
+                n, match = pkg.Matcher(0.9, ori).SearchByProjectionReloc(f, p, 100)
+                on, om = oracle.search_by_projection_reloc(f, p, 100, ori)
+                assert n == on and (match == om).all()
+    monkeypatch.delenv("AOS2_SERIAL_RESOLVE")
+
+
 def test_search_by_projection_last_vs_oracle(pkg, oracle, gpu):
     S = pkg.synth
     for seed in range(10):
