@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                                                         uint32_t *__restrict__ slots,
                                                         size_t slot_stride,
                                                         int32_t *__restrict__ cell_cnt,
-                                                        int list_cap, int keep_cap)
+                                                        int list_cap, int keep_cap, int batch)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tile_bytes = (TP * TH + 15) & ~15;
@@ -316,12 +316,14 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     uint32_t *list3 = reinterpret_cast<uint32_t *>(tile);
     (void)keep_cap;
 
-    const int b = blockIdx.y;
-    // Cell order = dispatch order (round-robin over the 8 XCDs).  An XCD-banded order (each XCD a
-    // contiguous band of the cell list, to share halo lines in one L2) was measured 40 % SLOWER
-    // (0.42 -> 0.60 ms at B=256): the kernel is VALU-issue bound, not fetch bound, and banding
-    // unbalances the XCDs because corner density differs between pyramid levels.
-    const int cell_id = (int)blockIdx.x;
+    // Image = blockIdx.x (fastest in dispatch order, padded to a multiple of 8), cell = blockIdx.y: consecutive
+    // workgroups go round-robin to the 8 XCDs, so image b always lands on XCD b % 8 and the halo columns / rows that
+    // neighbouring cells of an image share are served by that XCD's L2 instead of being fetched by up to 8 L2s.
+    // (An XCD-banded CELL order was measured 40 % slower earlier: it unbalances the XCDs because corner density
+    // differs between pyramid levels; an image-to-XCD affinity has no such effect.)
+    const int b = blockIdx.x;
+    if (b >= batch) return;
+    const int cell_id = (int)blockIdx.y;
     const CellDev cell = cells[cell_id];
     LevelDev lv = levels[cell.level];
     const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
@@ -769,15 +771,17 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                                                       uint8_t *__restrict__ desc, int cap,
                                                       int32_t *__restrict__ n_out,
                                                       unsigned long long umax_nibbles,
-                                                      int32_t *__restrict__ status)
+                                                      int32_t *__restrict__ status, int batch)
 {
     // raw patch, 43 rows (+1 so that the last row pair can be read); once the h-pass is done the same bytes hold the
     // blurred tile (37 x VBP = 1628 B)
     __shared__ __attribute__((aligned(16))) uint32_t patch32[(PW + 1) * PD];
     __shared__ __attribute__((aligned(16))) uint32_t hbT[HTC * HTP];   // h-pass sums, [column][row pair] u16x2
-    const int b = blockIdx.y;
+    // image = blockIdx.x (padded to a multiple of 8): image b -> XCD b % 8, whose L2 then holds that image's pyramid
+    const int b = blockIdx.x;
+    if (b >= batch) return;
     const int lane = threadIdx.x;
-    const int k0 = blockIdx.x * DK;  // first output slot of this wave
+    const int k0 = blockIdx.y * DK;  // first output slot of this wave
     // lane l < n_levels keeps level l's geometry; lane i < DK locates slot k0 + i (levels are concatenated
     // level-major, :1060-1104).  Both loads are independent of each other.
     int lv_w = 0, lv_h = 0, lv_pitch = 0, lv_sp = 0;
@@ -1021,9 +1025,9 @@ void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
                  uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
 {
-    dim3 blk(64), grd(n_cells, batch);
+    dim3 blk(64), grd((batch + 7) & ~7, n_cells);
     hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, cells, n_cells, ini_th,
-                       min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap);
+                       min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap, batch);
 }
 
 void launch_compact(const CellDev *cells, int n_cells, int n_levels, const int *level_cell_begin,
@@ -1062,9 +1066,9 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, int32_t *status, hipStream_t st)
 {
-    dim3 blk(64), grd((cap + DK - 1) / DK, batch);
+    dim3 blk(64), grd((batch + 7) & ~7, (cap + DK - 1) / DK);
     hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
-                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status);
+                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status, batch);
 }
 
 }  // namespace aos2

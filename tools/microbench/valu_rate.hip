@@ -138,6 +138,27 @@ KERNEL(rndne_f32, F_RNDNE, 1)
 KERNEL(cvt_i32_f32, F_CVTI, 1)
 KERNEL(dot2_u32_u16, F_DOT2, 1)
 
+#define OP8D(fmt) \
+    asm volatile(fmt("%0") "\n" fmt("%1") "\n" fmt("%2") "\n" fmt("%3") "\n" fmt("%4") "\n" fmt("%5") "\n" fmt("%6") "\n" fmt("%7") \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c))
+#define F_FMA64(r) "v_fma_f64 " r ", " r ", %8, %9"
+#define F_MUL64(r) "v_mul_f64 " r ", " r ", %8"
+#define F_ADD64(r) "v_add_f64 " r ", " r ", %8"
+#define KERNELD(NAME, FMT)                                                              \
+    __global__ __launch_bounds__(64) void k_##NAME(uint32_t *out, uint32_t bi, uint32_t ci) \
+    {                                                                                     \
+        double b = 1.0 + bi * 1e-9, c = ci * 1e-12;                                        \
+        double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        for (int i = 0; i < ITERS; ++i) {                                                 \
+            _Pragma("unroll") for (int u = 0; u < UNR; ++u) OP8D(FMT);                     \
+        }                                                                                 \
+        out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+    }                                                                                     \
+    static const int per_##NAME = 1;
+KERNELD(fma_f64, F_FMA64)
+KERNELD(mul_f64, F_MUL64)
+KERNELD(add_f64, F_ADD64)
+
 // LDS: conflict-free b32 reads, byte reads, and 64-lane random u16 gathers
 template <int MODE>
 __global__ __launch_bounds__(64) void k_lds(uint32_t *out, uint32_t b, uint32_t c)
@@ -200,7 +221,7 @@ int main()
         C(cndmask) C(sad_u8) C(bcnt) C(mov_dpp_quad) C(add_dpp_row_shr) C(cvt_f32_u32)
         C(pk_maximum3_f16) C(pk_minimum3_f16) C(bitop3_b32) C(min3_u32) C(mul_hi_u32) C(mad_i32_i24) C(or_b32) C(lshlrev_b32)
         C(lshl_or_b32) C(and_or_b32) C(sub_u32) C(cvt_f32_ubyte0) C(mul_f32) C(add_f32) C(mbcnt_lo) C(mov_b32) C(max_u16)
-        C(add_u16) C(rndne_f32) C(cvt_i32_f32) C(dot2_u32_u16)
+        C(add_u16) C(rndne_f32) C(cvt_i32_f32) C(dot2_u32_u16) C(fma_f64) C(mul_f64) C(add_f64)
         {"ds_read_b32 (no conflict)", k_lds<0>, 1, 64}, {"ds_read_u8 (no conflict)", k_lds<1>, 1, 64},
         {"ds_read_u16 (random gather)", k_lds<2>, 1, 64},
     };
