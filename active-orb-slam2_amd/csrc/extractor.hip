@@ -120,7 +120,7 @@ struct aos2_extractor {
     DevBuf<aos2_keypoint_t> d_kps;
     int out_cap = 0;
     // ComputeStereoMatches scratch (this handle = the left eye)
-    DevBuf<int32_t> st_sad;
+    DevBuf<int32_t> st_sad, st_rows;
     DevBuf<uint8_t> st_io;
     PinnedBuf<uint8_t> st_host;
     float stereo_ms = 0;
@@ -744,7 +744,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         e->d_pyr.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
         e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_level_cnt.release(); e->d_sel_cnt.release();
         e->d_nout.release(); e->d_kps.release();
-        e->st_sad.release(); e->st_io.release(); e->st_host.release();
+        e->st_sad.release(); e->st_rows.release(); e->st_io.release(); e->st_host.release();
         e->o_xs.release(); e->o_ys.release(); e->o_sc.release(); e->o_perm.release(); e->o_tmp.release();
         e->o_pairs.release(); e->o_idx.release(); e->o_nodes.release();
         e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_dense.release(); e->h_sel.release();
@@ -892,6 +892,11 @@ static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int
     a.kp_l = d_kpl; a.kp_r = d_kpr; a.desc_l = d_dl; a.desc_r = d_dr; a.n_l = d_nl; a.n_r = d_nr;
     a.cap = cap; a.batch = batch; a.mb = mb; a.mbf = mbf;
     a.u_right = d_ur; a.depth = d_depth; a.sad = l->st_sad.p;
+    a.rows = a.L.h[0];
+    a.row_cap = cap * stereo_row_span(a.L);
+    if ((st = l->st_rows.alloc((size_t)batch * ((size_t)a.rows + 1 + (size_t)a.row_cap)))) return st;
+    a.row_off = l->st_rows.p;
+    a.row_idx = l->st_rows.p + (size_t)batch * ((size_t)a.rows + 1);
     AOS2_HIP_CHECK(hipEventRecord(l->ev[0], l->stream));
     if ((st = launch_stereo(a, max_n_left, l->stream))) return st;
     AOS2_HIP_CHECK(hipEventRecord(l->ev[1], l->stream));

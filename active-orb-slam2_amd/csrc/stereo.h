@@ -35,7 +35,14 @@ struct StereoArgs {
     float mb, mbf;
     float *u_right, *depth;              // [batch][cap]
     int32_t *sad;                        // scratch [batch][cap]
+    // vRowIndices (:503-522): for every image row the right keypoints whose band [floor(y - r), ceil(y + r)] covers it
+    int rows, row_cap;                   // rows = mvImagePyramid[0].rows; row_cap = entries reserved per image
+    int32_t *row_off;                    // scratch [batch][rows + 1]
+    int32_t *row_idx;                    // scratch [batch][row_cap]
 };
+
+// entries one right keypoint can add to the row table: 2 * ceil(2 * max scale factor) + 3
+int stereo_row_span(const PyrView &v);
 
 // enqueue match + cull kernels on `stream`; max_n_left = upper bound of n_l[] (grid size)
 int launch_stereo(const StereoArgs &a, int max_n_left, hipStream_t stream);

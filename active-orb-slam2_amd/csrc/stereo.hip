@@ -62,12 +62,76 @@ constexpr int kW = 5, kL = 5;            // :587-588
 constexpr int kWin = 2 * (kW + kL) + 1;  // 21 columns of the right window
 constexpr int kWinPitch = 24;
 
+// vRowIndices (:503-522), one workgroup per image: rows -> right keypoints whose vertical band covers the row.
+// (the reference appends in iR order; the order inside a row is irrelevant here because the best candidate is the
+// minimum of dist << 20 | iR)
+__global__ __launch_bounds__(256) void stereo_rows_kernel(const StereoArgs A)
+{
+    extern __shared__ int rcnt[];   // rows counters, then cursors
+    __shared__ int part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nR = A.n_r[b], rows = A.rows;
+    const size_t base = (size_t)b * A.cap;
+    for (int y = tid; y < rows; y += 256) rcnt[y] = 0;
+    __syncthreads();
+    auto band = [&](int i, int &minr, int &maxr) {
+        const aos2_keypoint_t *kr = A.kp_r + base + i;
+        const float kpY = kr->y;
+        const float r = __fmul_rn(2.0f, A.L.scale[kr->octave]);  // :512 (mvScaleFactors = the left extractor's)
+        maxr = min((int)ceilf(__fadd_rn(kpY, r)), rows - 1);
+        minr = max((int)floorf(__fsub_rn(kpY, r)), 0);
+    };
+    for (int i = tid; i < nR; i += 256) {
+        int minr, maxr;
+        band(i, minr, maxr);
+        for (int y = minr; y <= maxr; ++y) atomicAdd(&rcnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the rows: per-thread segment sums, block scan of the 256 partial sums
+    const int seg = (rows + 255) / 256, y0 = tid * seg, y1 = min(y0 + seg, rows);
+    int ssum = 0;
+    for (int y = y0; y < y1; ++y) ssum += rcnt[y];
+    part[tid] = ssum;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int v = part[t];
+            part[t] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    int32_t *ro = A.row_off + (size_t)b * (rows + 1);
+    int acc = part[tid];
+    for (int y = y0; y < y1; ++y) {
+        const int v = rcnt[y];
+        ro[y] = acc;
+        rcnt[y] = acc;   // cursor
+        acc += v;
+    }
+    if (y1 == rows && y0 < rows) ro[rows] = acc;
+    if (rows == 0 && tid == 0) ro[0] = 0;
+    __syncthreads();
+    int32_t *ri = A.row_idx + (size_t)b * A.row_cap;
+    for (int i = tid; i < nR; i += 256) {
+        int minr, maxr;
+        band(i, minr, maxr);
+        for (int y = minr; y <= maxr; ++y) {
+            const int pos = atomicAdd(&rcnt[y], 1);
+            if (pos < A.row_cap) ri[pos] = i;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void stereo_match_kernel(const StereoArgs A)
 {
     __shared__ uint8_t win[4][(2 * kW + 1) * kWinPitch];
-    const int b = blockIdx.y;
+    // image pair = blockIdx.x (padded to a multiple of 8): pair b runs on XCD b % 8, whose L2 keeps both pyramids
+    const int b = blockIdx.x;
+    if (b >= A.batch) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + wave;
+    const int iL = blockIdx.y * 4 + wave;
     const int nL = A.n_l[b], nR = A.n_r[b];
     if (iL >= nL) return;
     const size_t base = (size_t)b * A.cap;
@@ -84,17 +148,18 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const StereoArgs A)
     if (!(maxU < 0.0f)) {
         const uint4 *dl = reinterpret_cast<const uint4 *>(A.desc_l + (base + iL) * 32);
         const uint4 a0 = dl[0], a1 = dl[1];
-        for (int i = lane; i < nR; i += 64) {
+        // candidates = vRowIndices[(int)vL] (:546-548); the row test itself is the table's construction
+        const int32_t *ro = A.row_off + (size_t)b * (A.rows + 1);
+        const int rowc = min(max(row, 0), A.rows - 1);
+        const int cbeg = ro[rowc], cend = min(ro[rowc + 1], A.row_cap);
+        const int32_t *ri = A.row_idx + (size_t)b * A.row_cap;
+        for (int c = cbeg + lane; c < cend; c += 64) {
+            const int i = ri[c];
             const aos2_keypoint_t *kr = A.kp_r + base + i;
             const int oct = kr->octave;
             if (oct < levelL - 1 || oct > levelL + 1) continue;  // :557
             const float uR = kr->x;
             if (!(uR >= minU && uR <= maxU)) continue;  // :562
-            const float kpY = kr->y;
-            const float r = __fmul_rn(2.0f, A.L.scale[oct]);  // :512 (mvScaleFactors = the left extractor's)
-            const int maxr = (int)ceilf(__fadd_rn(kpY, r));
-            const int minr = (int)floorf(__fsub_rn(kpY, r));
-            if (row < minr || row > maxr) continue;
             const uint4 *dr = reinterpret_cast<const uint4 *>(A.desc_r + (base + i) * 32);
             const uint4 b0 = dr[0], b1 = dr[1];
             const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
@@ -235,14 +300,27 @@ __global__ __launch_bounds__(256) void stereo_cull_kernel(const StereoArgs A)
 
 }  // namespace
 
+int stereo_row_span(const PyrView &v)
+{
+    float smax = 1.0f;
+    for (int l = 0; l < v.nlevels; ++l) smax = v.scale[l] > smax ? v.scale[l] : smax;
+    return 2 * (int)ceilf(2.0f * smax) + 3;
+}
+
 int launch_stereo(const StereoArgs &a, int max_n_left, hipStream_t stream)
 {
+    if (a.rows > 12000) {  // row counters live in LDS
+        set_error("ComputeStereoMatches: images with more than 12000 rows");
+        return AOS2_ERR_CAPACITY;
+    }
     if (max_n_left <= 0 || a.batch <= 0) return AOS2_OK;
     if (max_n_left > 15360) {  // cull kernel keeps one int per left keypoint in LDS
         set_error("ComputeStereoMatches: more than 15360 left keypoints per image");
         return AOS2_ERR_CAPACITY;
     }
-    hipLaunchKernelGGL(stereo_match_kernel, dim3((max_n_left + 3) / 4, a.batch), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(stereo_rows_kernel, dim3(a.batch), dim3(256), sizeof(int) * (size_t)(a.rows + 1), stream, a);
+    AOS2_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((a.batch + 7) & ~7, (max_n_left + 3) / 4), dim3(256), 0, stream, a);
     AOS2_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(stereo_cull_kernel, dim3(a.batch), dim3(256), sizeof(int) * (size_t)max_n_left, stream, a);
     AOS2_HIP_CHECK(hipGetLastError());
