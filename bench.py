@@ -321,7 +321,7 @@ def main():
              "algorithmic_bytes_per_launch": float(n_kp.sum()) * (749 + 512 + 60),
              "achieved": float(n_kp.sum()) * (749 + 512 + 60) / (stage["describe"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
              "frac": float(n_kp.sum()) * (749 + 512 + 60) / (stage["describe"] * 1e-3) / 1e9 / 8000.0,
-             "note": "integer-VALU bound as well (VALUBusy ~84 %, profiles/r01_pmc_sq_busy.csv): ~585 VALU instructions per keypoint "
+             "note": "integer-VALU bound as well (VALUBusy ~87 %, profiles/r01_pmc_sq_busy.csv): ~585 VALU instructions per keypoint "
                      "(7x7 blur of the 43x37 patch = 55 %, 512 steered samples = 20 %, IC_Angle + exact sin/cos = 20 %)"},
             {"kernel": "resize_level_kernel x7", "bound": "hbm", "kernel_ms": stage["pyramid"],
              "algorithmic_bytes_per_launch": 1.57e6 * B,
