@@ -8,6 +8,7 @@
 #include "extractor_kernels.h"
 #include "octree.h"
 #include "sincos_exact.h"
+#include "wave_ops.h"
 
 namespace aos2 {
 
@@ -733,18 +734,6 @@ constexpr int VBP = 44;           // byte pitch of the blurred tile, stored tran
 #define AOS2_DESC_KPW 4
 #endif
 constexpr int DK = AOS2_DESC_KPW;   // keypoints per wave
-
-// Sum over the 64 lanes, result wave-uniform: 4 DPP adds inside each row of 16 lanes (every lane of a row ends with the
-// row's sum) + 4 v_readlane.  (__shfl_xor compiles to ds_bpermute_b32: 6 dependent LDS round trips per value.)
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
-}
 
 // LDS traffic of ONE wave is processed in issue order, so a write by one lane is visible to a later read by
 // another lane of the same wave; this only stops the compiler from moving LDS accesses across the phase boundary

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "aos2_common.h"
+#include "wave_ops.h"
 
 namespace aos2 {
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(64) void triang_finish_kernel(const TriPairDev *__r
         }
     }
     __syncthreads();
-    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    cnt = wave_sum_i32(cnt);
     if (check_ori) {
         int i1, i2, i3;
         three_maxima(histo, i1, i2, i3);
@@ -710,9 +711,7 @@ __device__ __forceinline__ int window_population(const FrameDev &F, const Window
         const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
         total += F.grid_off[cell + 1] - F.grid_off[cell];
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
-    return total;
+    return wave_sum_i32(total);
 }
 
 // stage A body: writes one entry per feature of the window at out[position]
@@ -731,12 +730,7 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
             beg = F.grid_off[cell];
             cnt = F.grid_off[cell + 1] - beg;
         }
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int yv = __shfl_up(incl, d);
-            if (lane >= d) incl += yv;
-        }
+        const int incl = wave_incl_scan_i32(cnt);
         const int pos0 = base + incl - cnt;
         for (int j = 0; j < cnt; ++j) {
             const int idx = F.grid_idx[beg + j];
@@ -766,7 +760,7 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
             }
             out[pos0 + j] = e;
         }
-        base += __shfl(incl, 63);
+        base += __builtin_amdgcn_readlane(incl, 63);
     }
 }
 
@@ -895,7 +889,7 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
             if (pop > 0) {
                 int off = 0;
                 if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __shfl(off, 0);
+                off = __builtin_amdgcn_readfirstlane(off);
                 if (off + pop <= pool_cap) {
                     const int lvl = P.pred_level[i];
                     window_entries(F, w, load_desc(P.desc + (size_t)i * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
@@ -1098,7 +1092,7 @@ __global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjL
                 if (pop > 0) {
                     int off = 0;
                     if (lane == 0) off = atomicAdd(pool_used, pop);
-                    off = __shfl(off, 0);
+                    off = __builtin_amdgcn_readfirstlane(off);
                     if (off + pop <= pool_cap) {
                         const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
                         window_entries(F, w, load_desc(P.desc + (size_t)i * 32), u, v, radius, minL, maxL, ur, radius, lane,
@@ -1472,12 +1466,7 @@ __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGen
             beg = F.grid_off[cell];
             cnt = F.grid_off[cell + 1] - beg;
         }
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int yv = __shfl_up(incl, d);
-            if (lane >= d) incl += yv;
-        }
+        const int incl = wave_incl_scan_i32(cnt);
         const int pos0 = base + incl - cnt;
         for (int j = 0; j < cnt; ++j) {
             const int idx = F.grid_idx[beg + j];
@@ -1504,7 +1493,7 @@ __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGen
                 payload = (uint32_t)idx;
             }
         }
-        base += __shfl(incl, 63);
+        base += __builtin_amdgcn_readlane(incl, 63);
     }
     uint32_t k1 = key, k2 = KEY_NONE;
     wave_min2(k1, k2);
@@ -1563,7 +1552,7 @@ __global__ __launch_bounds__(64) void projgen_entries_kernel(FrameDev F, ProjGen
             if (pop > 0) {
                 int off = 0;
                 if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __shfl(off, 0);
+                off = __builtin_amdgcn_readfirstlane(off);
                 if (off + pop <= pool_cap) {
                     // mode 2: levels [pred-1, pred] tested per candidate (:379-382) == the level filter of the
                     // Frame version; mode 4: GetFeaturesInArea(u, v, radius, pred-1, pred+1) (:1537).  A level
@@ -1717,7 +1706,7 @@ __global__ __launch_bounds__(64) void init_entries_kernel(FrameDev F2, InitDev P
             if (pop > 0) {
                 int off = 0;
                 if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __shfl(off, 0);
+                off = __builtin_amdgcn_readfirstlane(off);
                 if (off + pop <= pool_cap) {
                     const int lvl = P.octave1[i];
                     window_entries(F2, w, load_desc(P.desc1 + (size_t)i * 32), x, y, P.window, lvl, lvl, 0.0f,
@@ -1811,7 +1800,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameDev F2, InitDev P
                 drop++;
             }
         }
-        for (int d = 32; d >= 1; d >>= 1) drop += __shfl_xor(drop, d);
+        drop = wave_sum_i32(drop);
         nmatches -= drop;
     }
     if (lane == 0) *nmatches_out = nmatches;
