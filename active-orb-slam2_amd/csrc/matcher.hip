@@ -204,7 +204,7 @@ struct Entry {
 // decisions: a fixed point that is unique and equal to the sequential result (induction over q: the decision of q
 // only reads B restricted to queries < q).  Iterating "all decisions from the previous B, in parallel -> next B"
 // makes at least one more leading query final per pass and in practice converges in a handful of passes, because
-// conflicts between search windows are rare.  One workgroup per problem, B double-buffered in LDS, the decisions
+// conflicts between search windows are rare (2-3 passes on the bench problems: 1500-3000 queries, 1000-2000 features).  One workgroup per problem, B double-buffered in LDS, the decisions
 // (choice[q] = feature or -1) in global scratch; the caller turns the final decisions into the method's outputs.
 // ---------------------------------------------------------------------------------------------
 struct Best2 {
@@ -243,29 +243,104 @@ __device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds,
     const int tid = threadIdx.x;
     int32_t *Bc = lds, *Bn = lds + n_f;
     for (int i = tid; i < n_f; i += NT) Bc[i] = initB(i);
-    for (int q = tid; q < n_q; q += NT) choice[q] = -2;
+    // Up to QPT queries per thread keep their slot, their first 8 entries, their blocking flag and their current
+    // decision in registers: a pass then touches only LDS (B) -- no global round trips on the pass loop.
+    constexpr int QPT = 4;
+    const bool cached = n_q <= NT * QPT;
+    Entry ce[QPT][8];
+    const Entry *cent[QPT];
+    int ccnt[QPT], cchoice[QPT];
+    bool cblk[QPT];
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int q = tid + NT * j;
+            ccnt[j] = 0;
+            cent[j] = nullptr;
+            cchoice[j] = -2;
+            cblk[j] = false;
+            if (q < n_q) {
+                cent[j] = ent_of(q, ccnt[j]);
+                cblk[j] = blocks(q);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ce[j][u] = u < ccnt[j] ? cent[j][u] : Entry{KEY_NONE, 0};
+        }
+    } else {
+        for (int q = tid; q < n_q; q += NT) choice[q] = -2;
+    }
     __syncthreads();
     for (;;) {
         if (tid == 0) changed = 0;
         for (int i = tid; i < n_f; i += NT) Bn[i] = initB(i);
         __syncthreads();
         bool ch = false;
-        for (int q = tid; q < n_q; q += NT) {
-            int cnt = 0;
-            const Entry *ent = ent_of(q, cnt);
-            int c = -1;
-            if (cnt > 0) c = accept(q, scan_best2_free(ent, cnt, Bc, q, idx_mask));
-            if (c != choice[q]) {
-                ch = true;
-                choice[q] = c;
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < QPT; ++j) {
+                const int q = tid + NT * j;
+                if (q >= n_q) continue;
+                int c = -1;
+                if (ccnt[j] > 0) {
+                    Best2 r{KEY_NONE, KEY_NONE, 0u, 0u};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const Entry e = ce[j][u];
+                        if (e.key == KEY_NONE || Bc[e.payload & idx_mask] < q) continue;
+                        if (e.key < r.k1) {
+                            r.k2 = r.k1; r.p2 = r.p1;
+                            r.k1 = e.key; r.p1 = e.payload;
+                        } else if (e.key < r.k2) {
+                            r.k2 = e.key; r.p2 = e.payload;
+                        }
+                    }
+                    if (ccnt[j] > 8) {   // rare: the rest of a large window / bucket comes from memory
+                        const Best2 t = scan_best2_free(cent[j] + 8, ccnt[j] - 8, Bc, q, idx_mask);
+                        const uint32_t tk[2] = {t.k1, t.k2}, tp[2] = {t.p1, t.p2};
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (tk[u] < r.k1) {
+                                r.k2 = r.k1; r.p2 = r.p1;
+                                r.k1 = tk[u]; r.p1 = tp[u];
+                            } else if (tk[u] < r.k2) {
+                                r.k2 = tk[u]; r.p2 = tp[u];
+                            }
+                        }
+                    }
+                    c = accept(q, r);
+                }
+                if (c != cchoice[j]) {
+                    ch = true;
+                    cchoice[j] = c;
+                }
+                if (c >= 0 && cblk[j]) atomicMin(&Bn[c], q);
             }
-            if (c >= 0 && blocks(q)) atomicMin(&Bn[c], q);
+        } else {
+            for (int q = tid; q < n_q; q += NT) {
+                int cnt = 0;
+                const Entry *ent = ent_of(q, cnt);
+                int c = -1;
+                if (cnt > 0) c = accept(q, scan_best2_free(ent, cnt, Bc, q, idx_mask));
+                if (c != choice[q]) {
+                    ch = true;
+                    choice[q] = c;
+                }
+                if (c >= 0 && blocks(q)) atomicMin(&Bn[c], q);
+            }
         }
         if (ch) changed = 1;
         __syncthreads();
         if (!changed) break;   // the decisions reproduced themselves: B is the fixed point
         int32_t *t = Bc; Bc = Bn; Bn = t;
         __syncthreads();
+    }
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int q = tid + NT * j;
+            if (q < n_q) choice[q] = cchoice[j];
+        }
+        __syncthreads();   // the callers read choice[] with a different thread -> query mapping
     }
 }
 
