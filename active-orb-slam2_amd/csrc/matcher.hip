@@ -207,51 +207,63 @@ struct Entry {
 // conflicts between search windows are rare (2-3 passes on the bench problems: 1500-3000 queries, 1000-2000 features).  One workgroup per problem, B double-buffered in LDS, the decisions
 // (choice[q] = feature or -1) in global scratch; the caller turns the final decisions into the method's outputs.
 // ---------------------------------------------------------------------------------------------
+constexpr int kFixQpt = 3;   // queries per thread whose candidates stay in registers over the passes (VGPR budget of a 1024-thread workgroup)
+
 struct Best2 {
     uint32_t k1, k2, p1, p2;   // smallest / second smallest key among the free candidates and their payloads
 };
 
-__device__ __forceinline__ Best2 scan_best2_free(const Entry *__restrict__ ent, int cnt, const int32_t *B, int q, uint32_t idx_mask)
+// (key, payload) pairs ordered by key (keys are unique: they carry the visiting position): branch-free insert of a
+// candidate into the running (smallest, second smallest) pair
+__device__ __forceinline__ void best2_insert(unsigned long long &b1, unsigned long long &b2, unsigned long long kk)
 {
-    Best2 r{KEY_NONE, KEY_NONE, 0u, 0u};
-    for (int j0 = 0; j0 < cnt; j0 += 8) {   // 8 entries per memory round trip (a window / bucket rarely holds more)
+    const unsigned long long lo = kk < b1 ? kk : b1, hi = kk < b1 ? b1 : kk;
+    b1 = lo;
+    b2 = hi < b2 ? hi : b2;
+}
+
+__device__ __forceinline__ Best2 best2_unpack(unsigned long long b1, unsigned long long b2)
+{
+    return Best2{(uint32_t)(b1 >> 32), (uint32_t)(b2 >> 32), (uint32_t)b1, (uint32_t)b2};
+}
+
+// 8 entries per memory round trip (a window / bucket rarely holds more); all B reads are issued together
+__device__ __forceinline__ void scan_best2_free(const Entry *__restrict__ ent, int cnt, const int32_t *B, int q,
+                                                uint32_t idx_mask, unsigned long long &b1, unsigned long long &b2)
+{
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
         Entry eb[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) eb[u] = j0 + u < cnt ? ent[j0 + u] : Entry{KEY_NONE, 0};
+        int bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = eb[u].key != KEY_NONE ? B[eb[u].payload & idx_mask] : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const Entry e = eb[u];
-            if (e.key == KEY_NONE || B[e.payload & idx_mask] < q) continue;
-            if (e.key < r.k1) {
-                r.k2 = r.k1; r.p2 = r.p1;
-                r.k1 = e.key; r.p1 = e.payload;
-            } else if (e.key < r.k2) {
-                r.k2 = e.key; r.p2 = e.payload;
-            }
+            const bool free_ = eb[u].key != KEY_NONE && bv[u] >= q;
+            best2_insert(b1, b2, free_ ? ((unsigned long long)eb[u].key << 32) | eb[u].payload : ~0ull);
         }
     }
-    return r;
 }
 
 // initB(f) -> -1 (taken before the call) or INT_MAX; ent_of(q, cnt) -> the query's entries; accept(q, Best2) -> chosen
 // feature or -1; blocks(q) -> whether a choice of q hides the feature from later queries.  All NT threads call it.
-template <int NT, class InitB, class EntOf, class Accept, class Blocks>
-__device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds, int32_t *choice, uint32_t idx_mask,
-                                                 InitB initB, EntOf ent_of, Accept accept, Blocks blocks)
+// CACHED (n_q <= kFixQpt * NT): up to kFixQpt queries per thread keep their (up to 8) valid entries, their blocking flag and their current
+// decision in registers, so a pass touches only LDS (B) -- no global round trips on the pass loop.
+template <int NT, bool CACHED, class InitB, class EntOf, class Accept, class Blocks>
+__device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t *lds, int32_t *choice, uint32_t idx_mask,
+                                                      InitB initB, EntOf ent_of, Accept accept, Blocks blocks)
 {
     __shared__ int changed;
     const int tid = threadIdx.x;
     int32_t *Bc = lds, *Bn = lds + n_f;
     for (int i = tid; i < n_f; i += NT) Bc[i] = initB(i);
-    // Up to QPT queries per thread keep their slot, their first 8 entries, their blocking flag and their current
-    // decision in registers: a pass then touches only LDS (B) -- no global round trips on the pass loop.
-    constexpr int QPT = 4;
-    const bool cached = n_q <= NT * QPT;
+    constexpr int QPT = CACHED ? kFixQpt : 1;
     Entry ce[QPT][8];
     const Entry *cent[QPT];
     int ccnt[QPT], cchoice[QPT];
-    bool cblk[QPT];
-    if (cached) {
+    bool cblk[QPT], covf[QPT];
+    if (CACHED) {
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int q = tid + NT * j;
@@ -259,12 +271,31 @@ __device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds,
             cent[j] = nullptr;
             cchoice[j] = -2;
             cblk[j] = false;
+            covf[j] = false;
             if (q < n_q) {
                 cent[j] = ent_of(q, ccnt[j]);
                 cblk[j] = blocks(q);
             }
+            // keep the VALID entries (a window's population is mostly features rejected by the level / radius tests
+            // before the distance, key == KEY_NONE): a shift register, so the array is only indexed statically.  More
+            // than 8 valid ones (rare): the query rescans its entries from memory in every pass.
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ce[j][u] = u < ccnt[j] ? cent[j][u] : Entry{KEY_NONE, 0};
+            for (int u = 0; u < 8; ++u) ce[j][u] = Entry{KEY_NONE, 0};
+            int nvalid = 0;
+            for (int j0 = 0; j0 < ccnt[j]; j0 += 8) {
+                Entry eb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) eb[u] = j0 + u < ccnt[j] ? cent[j][j0 + u] : Entry{KEY_NONE, 0};
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (eb[u].key != KEY_NONE) {
+#pragma unroll
+                        for (int w = 7; w > 0; --w) ce[j][w] = ce[j][w - 1];
+                        ce[j][0] = eb[u];
+                        ++nvalid;
+                    }
+            }
+            covf[j] = nvalid > 8;
         }
     } else {
         for (int q = tid; q < n_q; q += NT) choice[q] = -2;
@@ -275,52 +306,35 @@ __device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds,
         for (int i = tid; i < n_f; i += NT) Bn[i] = initB(i);
         __syncthreads();
         bool ch = false;
-        if (cached) {
+        if (CACHED) {
 #pragma unroll
             for (int j = 0; j < QPT; ++j) {
                 const int q = tid + NT * j;
-                if (q >= n_q) continue;
-                int c = -1;
-                if (ccnt[j] > 0) {
-                    Best2 r{KEY_NONE, KEY_NONE, 0u, 0u};
+                int bv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const Entry e = ce[j][u];
-                        if (e.key == KEY_NONE || Bc[e.payload & idx_mask] < q) continue;
-                        if (e.key < r.k1) {
-                            r.k2 = r.k1; r.p2 = r.p1;
-                            r.k1 = e.key; r.p1 = e.payload;
-                        } else if (e.key < r.k2) {
-                            r.k2 = e.key; r.p2 = e.payload;
-                        }
-                    }
-                    if (ccnt[j] > 8) {   // rare: the rest of a large window / bucket comes from memory
-                        const Best2 t = scan_best2_free(cent[j] + 8, ccnt[j] - 8, Bc, q, idx_mask);
-                        const uint32_t tk[2] = {t.k1, t.k2}, tp[2] = {t.p1, t.p2};
+                for (int u = 0; u < 8; ++u) bv[u] = ce[j][u].key != KEY_NONE ? Bc[ce[j][u].payload & idx_mask] : -1;
+                unsigned long long b1 = ~0ull, b2 = ~0ull;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            if (tk[u] < r.k1) {
-                                r.k2 = r.k1; r.p2 = r.p1;
-                                r.k1 = tk[u]; r.p1 = tp[u];
-                            } else if (tk[u] < r.k2) {
-                                r.k2 = tk[u]; r.p2 = tp[u];
-                            }
-                        }
-                    }
-                    c = accept(q, r);
+                for (int u = 0; u < 8; ++u) {
+                    const bool free_ = ce[j][u].key != KEY_NONE && bv[u] >= q;
+                    best2_insert(b1, b2, free_ ? ((unsigned long long)ce[j][u].key << 32) | ce[j][u].payload : ~0ull);
                 }
-                if (c != cchoice[j]) {
-                    ch = true;
-                    cchoice[j] = c;
+                if (covf[j]) {   // rare: more than 8 valid candidates
+                    b1 = b2 = ~0ull;
+                    scan_best2_free(cent[j], ccnt[j], Bc, q, idx_mask, b1, b2);
                 }
+                const int c = ccnt[j] > 0 ? accept(q, best2_unpack(b1, b2)) : -1;   // (q >= n_q: ccnt = 0)
+                ch |= c != cchoice[j];
+                cchoice[j] = c;
                 if (c >= 0 && cblk[j]) atomicMin(&Bn[c], q);
             }
         } else {
             for (int q = tid; q < n_q; q += NT) {
                 int cnt = 0;
                 const Entry *ent = ent_of(q, cnt);
-                int c = -1;
-                if (cnt > 0) c = accept(q, scan_best2_free(ent, cnt, Bc, q, idx_mask));
+                unsigned long long b1 = ~0ull, b2 = ~0ull;
+                scan_best2_free(ent, cnt, Bc, q, idx_mask, b1, b2);
+                const int c = cnt > 0 ? accept(q, best2_unpack(b1, b2)) : -1;
                 if (c != choice[q]) {
                     ch = true;
                     choice[q] = c;
@@ -334,7 +348,7 @@ __device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds,
         int32_t *t = Bc; Bc = Bn; Bn = t;
         __syncthreads();
     }
-    if (cached) {
+    if (CACHED) {
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int q = tid + NT * j;
@@ -342,6 +356,16 @@ __device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds,
         }
         __syncthreads();   // the callers read choice[] with a different thread -> query mapping
     }
+}
+
+template <int NT, class InitB, class EntOf, class Accept, class Blocks>
+__device__ __forceinline__ void resolve_fixpoint(int n_f, int n_q, int32_t *lds, int32_t *choice, uint32_t idx_mask,
+                                                 InitB initB, EntOf ent_of, Accept accept, Blocks blocks)
+{
+    if (n_q <= kFixQpt * NT)   // uniform
+        resolve_fixpoint_impl<NT, true>(n_f, n_q, lds, choice, idx_mask, initB, ent_of, accept, blocks);
+    else
+        resolve_fixpoint_impl<NT, false>(n_f, n_q, lds, choice, idx_mask, initB, ent_of, accept, blocks);
 }
 
 // SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  :159-288
@@ -951,8 +975,10 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 }
 
 // SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129, stage A: one wave per map point
+// pool_base / pool_cap: this problem's region of the entry pool; pool_used: its own counter (one counter shared by all
+// problems of a batch serialises ~100 k same-address atomics in one L2 channel: 0.94 ms for 64 frames, 0.39 for 12)
 __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
-                                                     Entry *pool, int32_t *pool_used, int pool_cap, int i)
+                                                     Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0)
 {
     const int lane = threadIdx.x;
     QuerySlot s{0, 0};
@@ -967,6 +993,7 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
                 off = __builtin_amdgcn_readfirstlane(off);
                 if (off + pop <= pool_cap) {
                     const int lvl = P.pred_level[i];
+                    off += pool_base;
                     window_entries(F, w, load_desc(P.desc + (size_t)i * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
                                    P.proj_xr[i], rs, lane, pool + off);
                     s.cnt = pop;
@@ -1084,13 +1111,14 @@ struct ProjMpItem {
     ProjMpDev P;
     QuerySlot *slots;
     int32_t *match_f, *nmatches, *choice;
+    int32_t *pool_used;        // this problem's entry counter
+    int32_t pool_base, pool_cap;
 };
-__global__ __launch_bounds__(64) void proj_mp_entries_batch_kernel(const ProjMpItem *__restrict__ items, float th, Entry *pool,
-                                                                   int32_t *pool_used, int pool_cap)
+__global__ __launch_bounds__(64) void proj_mp_entries_batch_kernel(const ProjMpItem *__restrict__ items, float th, Entry *pool)
 {
     const ProjMpItem &it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.P.n_mp) return;
-    proj_mp_entries_body(it.F, it.P, th, it.slots, pool, pool_used, pool_cap, blockIdx.x);
+    proj_mp_entries_body(it.F, it.P, th, it.slots, pool, it.pool_used, it.pool_cap, blockIdx.x, it.pool_base);
 }
 __global__ __launch_bounds__(64) void proj_mp_resolve_batch_kernel(const ProjMpItem *__restrict__ items, float nnratio,
                                                                    const Entry *__restrict__ pool)
@@ -2485,10 +2513,12 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         o.oslots = A.reserve((n + 1) * sizeof(QuerySlot));
         o.ochoice = A.reserve((n + 1) * 4);
     }
-    const size_t oitems = A.reserve(sizeof(ProjMpItem) * (size_t)n_problems), oused = A.reserve(8);
+    const size_t oitems = A.reserve(sizeof(ProjMpItem) * (size_t)n_problems);
+    const size_t oused = A.reserve((size_t)n_problems * 256 + 8);   // one counter per problem, 256 B apart
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = m->arena.alloc(A.host.size() + 256))) return st;
     std::vector<ProjMpItem> items(n_problems);
+    size_t pool_next = 0;
     for (int i = 0; i < n_problems; ++i) {
         const aos2_proj_mp_t *p = &problems[i];
         const Off &o = offs[i];
@@ -2503,15 +2533,19 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         it.match_f = A.dev<int32_t>(o.om);
         it.nmatches = A.dev<int32_t>(o.on);
         it.choice = A.dev<int32_t>(o.ochoice);
+        it.pool_used = A.dev<int32_t>(oused) + 64 * (size_t)i;
+        it.pool_cap = (int32_t)((size_t)p->n_mp * (size_t)std::min(frames[i].n_f, 512));
+        it.pool_base = (int32_t)pool_next;
+        pool_next += (size_t)it.pool_cap;
     }
     memcpy(A.host.data() + oitems, items.data(), sizeof(ProjMpItem) * (size_t)n_problems);
     if ((st = A.upload())) return st;
     int32_t *d_used = A.dev<int32_t>(oused);
-    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, (size_t)n_problems * 256, m->stream));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
     if (max_mp > 0)
         hipLaunchKernelGGL(proj_mp_entries_batch_kernel, dim3(max_mp, n_problems), dim3(64), 0, m->stream,
-                           A.dev<ProjMpItem>(oitems), th, reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
+                           A.dev<ProjMpItem>(oitems), th, reinterpret_cast<Entry *>(m->pool.p));
     if ((size_t)max_nf * 8 <= kFixLdsBytes && !m->serial_resolve)
         hipLaunchKernelGGL(proj_mp_resolve_fix_batch_kernel, dim3(n_problems), dim3(256), (size_t)max_nf * 8 + 16, m->stream,
                            A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
@@ -2519,8 +2553,8 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         hipLaunchKernelGGL(proj_mp_resolve_batch_kernel, dim3(n_problems), dim3(64), (size_t)max_nf + 16, m->stream,
                            A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    std::vector<int32_t> used(1);
-    AOS2_HIP_CHECK(hipMemcpyAsync(used.data(), d_used, 4, hipMemcpyDeviceToHost, m->stream));
+    std::vector<int32_t> used((size_t)n_problems * 64);
+    AOS2_HIP_CHECK(hipMemcpyAsync(used.data(), d_used, (size_t)n_problems * 256, hipMemcpyDeviceToHost, m->stream));
     for (int i = 0; i < n_problems; ++i) {
         if (frames[i].n_f > 0)
             AOS2_HIP_CHECK(hipMemcpyAsync(match_f[i], items[i].match_f, (size_t)frames[i].n_f * 4, hipMemcpyDeviceToHost, m->stream));
@@ -2529,11 +2563,12 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
-    if ((size_t)used[0] > pool_cap) {
-        set_error("batched projection search: the search windows hold %d entries, more than the %zu budgeted; "
-                  "use aos2_matcher_search_by_projection per frame", used[0], pool_cap);
-        return AOS2_ERR_CAPACITY;
-    }
+    for (int i = 0; i < n_problems; ++i)
+        if (used[(size_t)i * 64] > items[i].pool_cap) {
+            set_error("batched projection search: the search windows of problem %d hold %d entries, more than the %d "
+                      "budgeted; use aos2_matcher_search_by_projection per frame", i, used[(size_t)i * 64], items[i].pool_cap);
+            return AOS2_ERR_CAPACITY;
+        }
     return AOS2_OK;
 }
 
