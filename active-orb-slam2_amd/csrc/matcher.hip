@@ -975,8 +975,9 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 }
 
 // SearchByProjection(Frame&, const vector<MapPoint*>&, th)  :45-129, stage A: one wave per map point
-// pool_base / pool_cap: this problem's region of the entry pool; pool_used: its own counter (one counter shared by all
-// problems of a batch serialises ~100 k same-address atomics in one L2 channel: 0.94 ms for 64 frames, 0.39 for 12)
+// pool_base / pool_cap: this problem's region of the entry pool, cut into one fixed slice per map point (a counter
+// shared by all waves serialised ~100 k same-address atomics in one L2 channel: 0.94 ms for 64 frames); pool_used is
+// only an overflow flag
 __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
                                                      Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0)
 {
@@ -988,10 +989,11 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
         if (w.ok) {
             const int pop = window_population(F, w, lane);
             if (pop > 0) {
-                int off = 0;
-                if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __builtin_amdgcn_readfirstlane(off);
-                if (off + pop <= pool_cap) {
+                // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
+                const int stride = pool_cap / max(P.n_mp, 1);
+                int off = i * stride;
+                if (pop > stride && lane == 0) atomicMax(pool_used, pop);   // overflow flag for the host (batched form)
+                if (pop <= stride) {
                     const int lvl = P.pred_level[i];
                     off += pool_base;
                     window_entries(F, w, load_desc(P.desc + (size_t)i * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
@@ -1193,10 +1195,10 @@ __global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjL
             if (w.ok) {
                 const int pop = window_population(F, w, lane);
                 if (pop > 0) {
-                    int off = 0;
-                    if (lane == 0) off = atomicAdd(pool_used, pop);
-                    off = __builtin_amdgcn_readfirstlane(off);
-                    if (off + pop <= pool_cap) {
+                    const int stride = pool_cap / max(P.n_last, 1);
+                    const int off = i * stride;
+                    if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                    if (pop <= stride) {
                         const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
                         window_entries(F, w, load_desc(P.desc + (size_t)i * 32), u, v, radius, minL, maxL, ur, radius, lane,
                                        pool + off);
@@ -1653,10 +1655,10 @@ __global__ __launch_bounds__(64) void projgen_entries_kernel(FrameDev F, ProjGen
         if (w.ok) {
             const int pop = window_population(F, w, lane);
             if (pop > 0) {
-                int off = 0;
-                if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __builtin_amdgcn_readfirstlane(off);
-                if (off + pop <= pool_cap) {
+                const int stride = pool_cap / max(P.n_pts, 1);   // query i owns pool[i * stride ..): no shared counter
+                const int off = i * stride;
+                if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                if (pop <= stride) {
                     // mode 2: levels [pred-1, pred] tested per candidate (:379-382) == the level filter of the
                     // Frame version; mode 4: GetFeaturesInArea(u, v, radius, pred-1, pred+1) (:1537).  A level
                     // window starting at 0 or below disables only the lower test, like bCheckLevels (Frame.cc:379).
@@ -1807,10 +1809,10 @@ __global__ __launch_bounds__(64) void init_entries_kernel(FrameDev F2, InitDev P
         if (w.ok) {
             const int pop = window_population(F2, w, lane);
             if (pop > 0) {
-                int off = 0;
-                if (lane == 0) off = atomicAdd(pool_used, pop);
-                off = __builtin_amdgcn_readfirstlane(off);
-                if (off + pop <= pool_cap) {
+                const int stride = pool_cap / max(P.n1, 1);
+                const int off = i * stride;
+                if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                if (pop <= stride) {
                     const int lvl = P.octave1[i];
                     window_entries(F2, w, load_desc(P.desc1 + (size_t)i * 32), x, y, P.window, lvl, lvl, 0.0f,
                                    __builtin_huge_valf(), lane, pool + off);
@@ -2564,9 +2566,10 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     for (int i = 0; i < n_problems; ++i)
-        if (used[(size_t)i * 64] > items[i].pool_cap) {
-            set_error("batched projection search: the search windows of problem %d hold %d entries, more than the %d "
-                      "budgeted; use aos2_matcher_search_by_projection per frame", i, used[(size_t)i * 64], items[i].pool_cap);
+        if (used[(size_t)i * 64] > 0) {   // overflow flag = largest window population that did not fit its slice
+            set_error("batched projection search: a search window of problem %d holds %d features, more than the %d "
+                      "budgeted per map point; use aos2_matcher_search_by_projection per frame", i, used[(size_t)i * 64],
+                      std::min(frames[i].n_f, 512));
             return AOS2_ERR_CAPACITY;
         }
     return AOS2_OK;
