@@ -61,6 +61,7 @@ def lib():
             f.argtypes = [vp]
             f.restype = C.POINTER(ci)
         L.aos2_extractor_max_keypoints.argtypes = [vp]
+        L.aos2_extractor_max_keypoints_for.argtypes = [vp, ci, ci]
         L.aos2_extractor_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, C.POINTER(ci)]
         L.aos2_extractor_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
         L.aos2_extractor_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
@@ -207,6 +208,10 @@ class Extractor:
     def max_keypoints(self):
         return self.L.aos2_extractor_max_keypoints(self.h)
 
+    def max_keypoints_for(self, w, h):
+        """capacity that always suffices for w x h images (wide images can exceed nfeatures + 3 per level)"""
+        return self.L.aos2_extractor_max_keypoints_for(self.h, int(w), int(h))
+
     def __call__(self, image, mask=None):
         """operator()(image, mask, keypoints, descriptors): returns (keypoints[KP_DTYPE], desc[n,32])."""
         if image is None or image.size == 0:
@@ -218,7 +223,7 @@ class Extractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        cap = self.max_keypoints
+        cap = self.max_keypoints_for(w, h)
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
@@ -228,7 +233,7 @@ class Extractor:
     def extract_batch(self, images):
         images = np.ascontiguousarray(images, dtype=np.uint8)
         B, h, w = images.shape
-        cap = self.max_keypoints
+        cap = self.max_keypoints_for(w, h)
         kps = np.zeros((B, cap), KP_DTYPE)
         desc = np.zeros((B, cap, 32), np.uint8)
         n = np.zeros(B, np.int32)

@@ -187,15 +187,42 @@ static void build_host_tables(aos2_extractor *e)
             e->gauss7[i] = (int)lrint((double)cf[i] * 256.0);
         }
     }
-    int cl = 0, tot = 0;
-    for (int l = 0; l < e->nlevels; ++l) {
-        cl = std::max(cl, e->mnFeaturesPerLevel[l] + 4);
-        tot += e->mnFeaturesPerLevel[l] + 3;
+    // capacities for a "normal" aspect ratio; build_plan() raises them for the actual image size (keypoint_bounds)
+    {
+        int cl = 0, tot = 0;
+        for (int l = 0; l < e->nlevels; ++l) {
+            cl = std::max(cl, e->mnFeaturesPerLevel[l] + 4);
+            tot += e->mnFeaturesPerLevel[l] + 3;
+        }
+        e->cap_level = cl;
+        e->max_kp = tot;
     }
-    e->cap_level = cl;
-    e->max_kp = tot;
     e->umax_nibbles = 0;
     for (int v = 0; v < 16; ++v) e->umax_nibbles |= (unsigned long long)(e->umax[v] & 15) << (4 * v);
+}
+
+// Upper bound of DistributeOctTree's output per level for a w x h image (:539-763): the loop stops at >= N leaves with at
+// most 3 extra from the last divide, EXCEPT that its first pass divides all nIni = round(W / H) root nodes unconditionally
+// (:549-590), which alone can leave 4 * nIni leaves -- more than N + 3 for wide images with few features
+// (found by tools/gpu_fuzz_extractor.py: 838 x 118, nfeatures 100 -> 123 keypoints).
+static void keypoint_bounds(const aos2_extractor *e, int w, int h, int *cap_level, int *max_kp)
+{
+    int cl = 0, tot = 0;
+    for (int l = 0; l < e->nlevels; ++l) {
+        int b = e->mnFeaturesPerLevel[l] + 3;
+        if (w > 0 && h > 0) {
+            const float s = e->mvInvScaleFactor[l];
+            const int lw = (int)lrintf((float)w * s), lh = (int)lrintf((float)h * s);
+            if (lh - 32 > 0 && lw - 32 > 0) {
+                const int nIni = (int)roundf((float)(lw - 32) / (float)(lh - 32));   // round(): half away from zero (:545)
+                b = std::max(b, 4 * nIni);
+            }
+        }
+        cl = std::max(cl, b + 1);
+        tot += b;
+    }
+    *cap_level = cl;
+    *max_kp = tot;
 }
 
 static short sat_short(float v)
@@ -260,6 +287,7 @@ static int build_plan(aos2_extractor *e, int w, int h)
     P = Plan();
     P.w = w;
     P.h = h;
+    keypoint_bounds(e, w, h, &e->cap_level, &e->max_kp);
     size_t off = 0, slot = 0;
     for (int l = 0; l < e->nlevels; ++l) {
         LevelDev L{};
@@ -628,7 +656,10 @@ static int finish_device(aos2_extractor *e)
     for (int i = 0; i < L * batch; ++i) {
         if (e->h_sel_cnt.p[i] < 0) {
             set_error("octree stage failed for image %d level %d (code %d: %s)", i / L, i % L, e->h_sel_cnt.p[i],
-                      e->h_sel_cnt.p[i] == -4 ? "candidate capacity exceeded" : "node arena exhausted");
+                      e->h_sel_cnt.p[i] == -4   ? "candidate capacity exceeded"
+                      : e->h_sel_cnt.p[i] == -1 ? "level more than twice as tall as wide: round(width / height) == 0, the reference's "
+                                                  "DistributeOctTree divides by zero (src/ORBextractor.cc:545)"
+                                                : "node arena exhausted");
             return AOS2_ERR_CAPACITY;
         }
     }
@@ -640,7 +671,7 @@ static int finish_device(aos2_extractor *e)
     // earlier batches of the same flight (their per-image counts are gone; the sticky words are not)
     if (status[0] < 0) {
         set_error("octree stage failed in an earlier batch of this flight (code %d: %s)", status[0],
-                  status[0] == -4 ? "candidate capacity exceeded" : "node arena exhausted");
+                  status[0] == -4 ? "candidate capacity exceeded" : status[0] == -1 ? "level more than twice as tall as wide" : "node arena exhausted");
         return AOS2_ERR_CAPACITY;
     }
     if (status[1] > cap) {
@@ -763,6 +794,13 @@ const float *aos2_extractor_inv_sigma2(const aos2_extractor_t *e) { return e->mv
 const int *aos2_extractor_features_per_level(const aos2_extractor_t *e) { return e->mnFeaturesPerLevel; }
 const int *aos2_extractor_umax(const aos2_extractor_t *e) { return e->umax; }
 int aos2_extractor_max_keypoints(const aos2_extractor_t *e) { return e->max_kp; }
+int aos2_extractor_max_keypoints_for(const aos2_extractor_t *e, int w, int h)
+{
+    if (!e) return 0;
+    int cl = 0, tot = 0;
+    keypoint_bounds(e, w, h, &cl, &tot);
+    return tot;
+}
 
 int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_imgs, int batch, int w, int h,
                                         int stride, size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc,

@@ -107,9 +107,13 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 //   * every lane of a wave works on the SAME band of rows (items are flattened over (image, column quad)), so
 //     the row bookkeeping is scalar and a level's ragged right edge costs no idle lanes.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_BAND = 8;    // output rows per lane
-constexpr int RS_NR = 16;     // max source rows of a band: ceil(7 * scale) + 2, scale <= 2.0
+constexpr int RS_BAND = 8;    // output rows per lane (4 when the level's vertical ratio exceeds 2: see launch_resize)
+constexpr int RS_NR = 16;     // source rows of a band kept in registers: ceil((band - 1) * ratio) + 2 <= 16
 
+// WIDE = false: one 8-byte window holds sx_0 .. sx_3 + 1 (horizontal ratio <= 2.0); WIDE = true: one window per output
+// PAIR (any ratio <= 6).  A level's ratio src / dst can exceed the extractor's scale factor slightly because the level
+// sizes are rounded (cvRound(165 / 2.0) = 82 -> 2.012), so scaleFactor = 2.0 needs the wide form and 4-row bands.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__restrict__ src_base,
                                                            size_t src_img_stride, int src_pitch,
                                                            uint8_t *__restrict__ pyr, size_t pyr_stride,
@@ -118,12 +122,12 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
                                                            const int *__restrict__ xab,
                                                            const int *__restrict__ yofs,
                                                            const int *__restrict__ yab,
-                                                           int batch, int nquads, uint32_t inv_nquads)
+                                                           int batch, int nquads, uint32_t inv_nquads, int band)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    const int dy0 = blockIdx.y * RS_BAND;
-    const int nout = min(RS_BAND, dst.h - dy0);   // >= 1
+    const int dy0 = blockIdx.y * band;
+    const int nout = min(band, dst.h - dy0);   // >= 1
     // lane l < nout keeps the y-table entries of output row dy0 + l (read back with v_readlane)
     int ty = 0, tc = 0;
     if (lane < nout) {
@@ -138,31 +142,36 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
     const int4 xa = *reinterpret_cast<const int4 *>(xab + dst.tab_x + dx0);
     const int sxs[4] = {xo.x, xo.y, xo.z, xo.w};
     const uint32_t aas[4] = {(uint32_t)xa.x, (uint32_t)xa.y, (uint32_t)xa.z, (uint32_t)xa.w};
-    // 8-byte source window [start, start + 8) holds sx_k and sx_k + 1 of the 4 outputs; at the right edge the
-    // window is pulled inside the row and the neighbour selector repeats sx (its weight a1 is 0 there)
-    const int start = max(min(sxs[0], src.w - 8), 0);
+    // 8-byte source window [start, start + 8) holds sx_k and sx_k + 1 of its outputs; at the right edge the window is
+    // pulled inside the row and the neighbour selector repeats sx (its weight a1 is 0 there)
+    constexpr int NW = WIDE ? 2 : 1;
+    int start[NW];
+#pragma unroll
+    for (int v = 0; v < NW; ++v) start[v] = max(min(sxs[2 * v], src.w - 8), 0);
     uint32_t sel[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t lo = (uint32_t)(sxs[k] - start), hi = sxs[k] + 1 < src.w ? lo + 1 : lo;
+        const uint32_t lo = (uint32_t)(sxs[k] - start[WIDE ? k >> 1 : 0]), hi = sxs[k] + 1 < src.w ? lo + 1 : lo;
         sel[k] = lo | (hi << 16) | 0x0c000c00u;   // v_perm_b32: byte 0 <- window[lo], byte 2 <- window[hi], bytes 1,3 <- 0
     }
-    const uint8_t *sp = src_base + (size_t)img * src_img_stride + start;
+    const uint8_t *sp = src_base + (size_t)img * src_img_stride;
     uint8_t *dp = pyr + (size_t)img * pyr_stride + dst.off + dx0;
     const uint32_t keep = dx0 + 4 <= dst.w ? 0xffffffffu : (1u << (8 * (dst.w - dx0))) - 1u;   // padding columns stay 0
-    // source rows of the band: every row of [r_first, r_last] is used (scale <= 2)
+    // source rows of the band: every row of [r_first, r_last] is used
     const int hmax = src.h - 1;
     const int t_first = __builtin_amdgcn_readlane(ty, 0), t_last = __builtin_amdgcn_readlane(ty, nout - 1);
     const int r_first = min(max(t_first, 0), hmax);
-    const int nrows = min(max(t_last + 1, 0), hmax) - r_first + 1;
-    uint2 win[RS_NR];
+    const int nrows = min(min(max(t_last + 1, 0), hmax) - r_first + 1, RS_NR);
+    uint2 win[NW][RS_NR];
 #pragma unroll
     for (int c = 0; c < RS_NR / 4; ++c) {
         if (4 * c < nrows) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int r = min(r_first + 4 * c + t, hmax);
-                __builtin_memcpy(&win[4 * c + t], sp + (size_t)((uint32_t)r * (uint32_t)src_pitch), 8);
+#pragma unroll
+                for (int v = 0; v < NW; ++v)
+                    __builtin_memcpy(&win[v][4 * c + t], sp + (size_t)((uint32_t)r * (uint32_t)src_pitch) + start[v], 8);
             }
         }
     }
@@ -174,8 +183,9 @@ __global__ __launch_bounds__(256) void resize_level_kernel(const uint8_t *__rest
         if (i >= nrows) continue;   // (uniform) not `break`: the loop must unroll completely, win[] is a register array
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            const uint2 wk = win[WIDE ? k >> 1 : 0][i];
             prev[k] = cur[k];
-            cur[k] = udot2_u16(__builtin_amdgcn_perm(win[i].y, win[i].x, sel[k]), aas[k], 0u) >> 4;
+            cur[k] = udot2_u16(__builtin_amdgcn_perm(wk.y, wk.x, sel[k]), aas[k], 0u) >> 4;
         }
         while (j < nout && sy1 == i) {
             const uint32_t b0s = (uint32_t)coef << 16, b1s = (uint32_t)coef & 0xffff0000u;
@@ -1004,9 +1014,17 @@ void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch
     const int nquads = (dst.w + 3) / 4;
     const uint32_t inv_nquads = 0xFFFFFFFFu / (uint32_t)nquads + 1u;
     const uint32_t items = (uint32_t)nquads * (uint32_t)batch;   // < 2^32 / nquads (checked by the caller's plan)
-    dim3 blk(256), grd((items + 255) / 256, (dst.h + RS_BAND - 1) / RS_BAND);
-    hipLaunchKernelGGL(resize_level_kernel, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
-                       dst, xofs, xab, yofs, yab, batch, nquads, inv_nquads);
+    // actual ratios of this level pair (level sizes are rounded, so they can exceed the scale factor a little)
+    const double rx = (double)src.w / dst.w, ry = (double)src.h / dst.h;
+    const int band = (int)std::ceil((RS_BAND - 1) * ry) + 2 <= RS_NR ? RS_BAND : 4;   // 4 rows: ratios up to 4.6
+    const bool wide = (int)std::ceil(3.0 * rx) + 1 > 7;
+    dim3 blk(256), grd((items + 255) / 256, (dst.h + band - 1) / band);
+    if (wide)
+        hipLaunchKernelGGL(resize_level_kernel<true>, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
+                           dst, xofs, xab, yofs, yab, batch, nquads, inv_nquads, band);
+    else
+        hipLaunchKernelGGL(resize_level_kernel<false>, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
+                           dst, xofs, xab, yofs, yab, batch, nquads, inv_nquads, band);
 }
 
 void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

@@ -39,7 +39,7 @@ public:
                     aos2::Mat8 &descriptors)
     {
         if (image.empty()) return;  // src/ORBextractor.cc:1046
-        const int cap = aos2_extractor_max_keypoints(h_);
+        const int cap = aos2_extractor_max_keypoints_for(h_, image.cols, image.rows);
         keypoints.resize(cap);
         scratch_.resize((size_t)cap * 32);
         int n = 0;

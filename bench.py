@@ -210,8 +210,8 @@ def main():
             mb = np.float32(mbf / np.float32(517.306408))
 
             def stereo_step():
-                step()
-                xr.extract_batch_device(d_right.data_ptr(), B, W, H, W, W * H, r_kps.data_ptr(), r_desc.data_ptr(), cap, r_n.data_ptr())
+                step()       # both eyes are enqueued on their own handles' streams; the stereo call waits for both
+                xr.extract_batch_device_async(d_right.data_ptr(), B, W, H, W, W * H, r_kps.data_ptr(), r_desc.data_ptr(), cap, r_n.data_ptr())
                 return pkg.capi.compute_stereo_matches_device(ex, xr, B, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
                                                               r_kps.data_ptr(), r_desc.data_ptr(), r_n.data_ptr(), cap, mb, mbf,
                                                               s_ur.data_ptr(), s_dp.data_ptr())

@@ -83,6 +83,10 @@ const int *aos2_extractor_umax(const aos2_extractor_t *e);
 int aos2_extractor_extract(aos2_extractor_t *e, const uint8_t *img, int w, int h, int stride,
                            aos2_keypoint_t *kps, uint8_t *desc, int cap, int *n_out);
 int aos2_extractor_max_keypoints(const aos2_extractor_t *e);
+/* The same bound for a given image size, before any image was seen: DistributeOctTree's first pass divides all
+ * round(W / H) root nodes (src/ORBextractor.cc:549-590), so a wide image with few features per level can return more
+ * than nfeatures-per-level + 3 keypoints (4 * round(W / H) per level). */
+int aos2_extractor_max_keypoints_for(const aos2_extractor_t *e, int w, int h);
 
 /* Batched form for frame-parallel throughput: `batch` images of identical size, host memory,
  * image b at imgs + b*image_stride.  Outputs are [batch][cap] / [batch][cap][32] / [batch]. */

@@ -143,6 +143,32 @@ def test_full_batch_properties(pkg, oracle, gpu):
     assert zlib.crc32(np.array(crc, np.uint32).tobytes()) == zlib.crc32(np.array(crc[:8] * (B // 8), np.uint32).tobytes())
 
 
+def test_level_ratio_above_scale_factor(pkg, oracle, gpu):
+    """scaleFactor 2.0: the level sizes are rounded (cvRound(165 / 2) = 82), so a level pair's real ratio exceeds 2
+    (2.012): the resize kernel then needs its wide windows / 4-row bands.  Found by tools/gpu_fuzz_extractor.py."""
+    for (w, h, nf, nl) in ((859, 165, 100, 2), (217, 212, 1000, 2), (640, 481, 1000, 3), (333, 205, 500, 2)):
+        img = pkg.synth.synth_image(4242 + w, w, h)
+        ex = pkg.Extractor(nfeatures=nf, scale_factor=2.0, nlevels=nl)
+        oe = oracle.Extractor(nfeatures=nf, scale_factor=2.0, nlevels=nl)
+        got, want = ex(img), oe.extract(img)
+        for l in range(nl):
+            assert (ex.pyramid_level(l) == oe.level_plane(l)).all()
+        assert same(got, want)
+
+
+def test_wide_images_exceed_the_per_level_quota(pkg, oracle, gpu):
+    """DistributeOctTree divides all round(W / H) root nodes in its first pass (:549-590): a wide image with few features
+    returns more than nfeatures-per-level + 3 keypoints; the capacity getters account for it (tools/gpu_fuzz_extractor.py)."""
+    for (w, h, nf, sf, nl) in ((838, 118, 100, 1.2, 3), (1001, 245, 100, 1.1, 8), (1271, 196, 100, 1.5, 3), (1183, 263, 100, 1.2, 7)):
+        img = pkg.synth.synth_image(900 + w, w, h)
+        ex = pkg.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+        assert ex.max_keypoints_for(w, h) >= ex.max_keypoints
+        got, want = ex(img), oracle.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl).extract(img)
+        assert same(got, want) and len(got[0]) <= ex.max_keypoints_for(w, h)
+        assert ex.max_keypoints == ex.max_keypoints_for(w, h)          # after the first image of that size
+    assert len(got[0]) > 100 + 3 * 3
+
+
 def test_async_flight_equals_synchronous_batches(pkg, oracle, gpu):
     """aos2_extractor_extract_batch_device_async: three different batches in flight on one handle (chunked over
     two streams) + one wait == the synchronous call on each batch, bit for bit; wait() reports a capacity error of
