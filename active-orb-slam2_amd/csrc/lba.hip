@@ -884,7 +884,8 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
     }
     if (tid < 7) qt[tid] = P.pose_in[tid];
     __syncthreads();
-    if (n < 3) {  // nInitialCorrespondences < 3 (:355-356)
+    if (n < 3) {  // nInitialCorrespondences < 3 (:355-356): the pose stays, mvbOutlier was already reset (:283, :320)
+        for (int e = tid; e < n; e += 256) P.outlier[e] = 0;   // (the register copies above never reach memory here)
         if (tid < 7) P.pose_out[tid] = P.pose_in[tid];
         if (tid == 0) { P.counts[0] = 0; P.counts[1] = 0; }
         return;
@@ -1666,7 +1667,10 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     AOS2_HIP_CHECK(hipGetLastError());
     (void)hipEventElapsedTime(&s->last_pose_ms, s->ev[0], s->ev[1]);
     for (int i = 0; i < n_problems; ++i) {
-        pose_to_Tcw(&poses[7 * (size_t)i], results[i].Tcw);
+        if (problems[i].n < 3)   // the reference returns before touching mTcw (:355-356): keep the caller's matrix bit for bit
+            memcpy(results[i].Tcw, problems[i].Tcw, sizeof(float) * 16);
+        else
+            pose_to_Tcw(&poses[7 * (size_t)i], results[i].Tcw);
         results[i].n_bad = cnts[2 * (size_t)i];
         results[i].n_inliers = cnts[2 * (size_t)i + 1];
     }

@@ -459,6 +459,7 @@ int orc_distribute_octree(const float *xs, const float *ys, const float *resp, i
     memset(&L, 0, sizeof(L));
     L.head = L.tail = -1;
     const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (nIni < 1) return -1; /* the reference divides by zero here (:545-547, levels more than twice as tall as wide) */
     const float hX = (float)(maxX - minX) / nIni;
     int *ini = (int *)malloc(sizeof(int) * (nIni > 0 ? nIni : 1));
     for (int i = 0; i < nIni; ++i) {
@@ -918,6 +919,12 @@ int orc_extractor_extract(orc_extractor_t *e, const uint8_t *img, int w, int h, 
         float s = e->mvInvScaleFactor[e->nlevels - 1];
         int lw = orc_cv_round_f((float)w * s), lh = orc_cv_round_f((float)h * s);
         if (lw - 2 * EDGE_THRESHOLD + 6 < 30 || lh - 2 * EDGE_THRESHOLD + 6 < 30) return -3;
+        /* DistributeOctTree: nIni = round(width / height) == 0 -> the reference divides by zero (:545-547) */
+        for (int level = 0; level < e->nlevels; ++level) {
+            float sl = e->mvInvScaleFactor[level];
+            int wl = orc_cv_round_f((float)w * sl), hl = orc_cv_round_f((float)h * sl);
+            if ((int)roundf((float)(wl - 2 * EDGE_THRESHOLD + 6) / (float)(hl - 2 * EDGE_THRESHOLD + 6)) < 1) return -4;
+        }
     }
     compute_pyramid(e, img, w, h, stride);
     compute_keypoints_octree(e);

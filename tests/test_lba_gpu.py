@@ -76,6 +76,21 @@ def test_pose_optimization_vs_oracle(pkg, oracle, gpu, cfg):
     assert close(got["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16))
 
 
+def test_pose_optimization_fewer_than_three_correspondences(pkg, oracle, gpu):
+    """nInitialCorrespondences < 3 (:355-356): pose unchanged, 0 inliers, and mvbOutlier all false -- also right after a
+    call on the same handle that left outlier flags in the device arena (found by tools/gpu_fuzz_rest.py)."""
+    ba = pkg.LocalBA()
+    big = pkg.synth.synth_pose_problem(1, n=900, outlier_frac=0.5)
+    assert ba.PoseOptimization(big)["outlier"].any()
+    for seed in range(700, 720):
+        for n in (1, 2):
+            p = pkg.synth.synth_pose_problem(seed, n=n, stereo_frac=0.5)
+            got, want = ba.PoseOptimization(p), oracle.pose_optimization(p)
+            assert got["n_inliers"] == want["n_inliers"] == 0 and not got["outlier"].any() and not want["outlier"].any()
+            assert got["Tcw"].tobytes() == p["Tcw"].astype(np.float32).tobytes()
+        ba.PoseOptimization(big)
+
+
 def test_pose_optimization_batch_and_golden(pkg, oracle, gpu):
     probs = [pkg.synth.synth_pose_problem(100 + i, n=600 + 37 * i) for i in range(24)]
     ba = pkg.LocalBA()
