@@ -816,27 +816,38 @@ __device__ __forceinline__ void po_edge_error(const double *qt, const double *X,
 }
 
 // fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return.
-// Two barriers per call: thread k < K adds the 256 partials of component k in thread order (8 slices
-// of 32 by 8 threads for latency), instead of a log-depth tree with a barrier per level.
+// The 256 partials of component k are added in thread order (8 slices of 32, then the 8 slice sums), instead of a
+// log-depth tree with a barrier per level.
 template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) + 8 x K */, double *out)
+__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) + 9 x K */, double *out)
 {
+    // fixed summation order (bit-reproducible): 8 slices of 32 threads, each summed in thread order, then the 8 slice
+    // sums in slice order.  The 32 operands of a slice are fetched together before the dependent adds, and the 8-term
+    // final sums are formed once (K threads) and broadcast, instead of every thread re-adding 8 x K partials.
     const int tid = threadIdx.x;
     for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] = v[i];
     __syncthreads();
-    double *part = sh + 256 * (K + 1);
+    double *part = sh + 256 * (K + 1), *fin = part + 8 * K;
     if (tid < 8 * K) {
         const int k = tid % K, slice = tid / K;
+        double x[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) x[t] = sh[(32 * slice + t) * (K + 1) + k];
         double acc = 0;
-        for (int t = 32 * slice; t < 32 * slice + 32; ++t) acc += sh[t * (K + 1) + k];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) acc += x[t];
         part[slice * K + k] = acc;
     }
     __syncthreads();
-    for (int i = 0; i < K; ++i) {
-        double acc = part[i];
-        for (int sl = 1; sl < 8; ++sl) acc += part[sl * K + i];
-        out[i] = acc;
+    if (tid < K) {
+        double acc = part[tid];
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) acc += part[sl * K + tid];
+        fin[tid] = acc;
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K; ++i) out[i] = fin[i];
     __syncthreads();
 }
 
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
     constexpr bool kReg = kEpt > 0;
     double Xr[EPT][3], Or[EPT][3], Wr[EPT], Er[EPT][3];
     uint8_t Sr[EPT], L1r[EPT], Rbr[EPT], Outr[EPT];
-    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 8 x 27
+    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 9 x 27
     __shared__ double qt[7], bk[7], xs[6];
     __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
     __shared__ int s_flag;
@@ -1649,7 +1660,7 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     int max_n = 0;
     for (int i = 0; i < n_problems; ++i) max_n = std::max(max_n, problems[i].n);
-    const size_t po_lds = (256 * 28 + 8 * 27) * sizeof(double);
+    const size_t po_lds = (256 * 28 + 9 * 27) * sizeof(double);
     if (max_n <= 256 * 4)   // the usual case (a frame has <= ~1000 map-point matches): edges live in registers
         hipLaunchKernelGGL(pose_optimization_kernel<4>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
     else
