@@ -671,7 +671,12 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
         if (tid == 0) A.scal[3] = 0.0;
         return;
     }
-    // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 256)
+    // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 256).
+    // Blocked by the 16-column panels: the 16 x 16 triangle of a panel is solved among its 16 lanes with v_readlane
+    // broadcasts (its L entries fetched once), then every other row takes its 16-term update from 16 independent LDS
+    // reads.  Per element the subtractions happen in the same order as the column-by-column loop (k ascending forward,
+    // descending backward), so the result is bit-identical to it; the serial chain shrinks from npad dependent LDS
+    // round trips to npad / 16 (27 -> ~6 us at npad = 128).
     if (wave == 0) {
         double xv[4];
 #pragma unroll
@@ -679,15 +684,34 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
             const int i = lane + 64 * s;
             xv[s] = i < n ? A.bs[i] : 0.0;
         }
+        auto get_slot = [&](int slot) { return slot == 0 ? xv[0] : slot == 1 ? xv[1] : slot == 2 ? xv[2] : xv[3]; };
+        auto set_slot = [&](int slot, double v) {
+            if (slot == 0) xv[0] = v; else if (slot == 1) xv[1] = v; else if (slot == 2) xv[2] = v; else xv[3] = v;
+        };
+        for (int kb = 0; kb < nb; ++kb) {  // forward: y_i -= L[i][k] y_k, k ascending
+            const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
+            const bool in_blk = li >= 0 && li < 16;
+            double lrow[16];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {  // forward: y_i -= L[i][k] y_k
-            for (int kl = 0; kl < 64 && ks * 64 + kl < npad; ++kl) {
-                const int k = ks * 64 + kl;
-                const double yk = readlane_f64(xv[ks], kl);
+            for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < li) ? M[(size_t)(k0 + li) * ld + k0 + c] : 0.0;
+            double cur = get_slot(slot), yb[16];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int i = lane + 64 * s;
-                    if (i > k && i < npad) xv[s] -= M[(size_t)i * ld + k] * yk;
+            for (int j = 0; j < 16; ++j) {
+                yb[j] = readlane_f64(cur, lane0 + j);
+                if (in_blk && li > j) cur -= lrow[j] * yb[j];
+            }
+            set_slot(slot, cur);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = lane + 64 * s;
+                if (i >= k0 + 16 && i < npad) {
+                    double l[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) l[j] = M[(size_t)i * ld + k0 + j];
+                    double acc = xv[s];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc -= l[j] * yb[j];
+                    xv[s] = acc;
                 }
             }
         }
@@ -696,16 +720,30 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
             const int i = lane + 64 * s;
             if (i < npad) xv[s] /= dvec[i];
         }
+        for (int kb = nb - 1; kb >= 0; --kb) {  // backward: x_i -= L[k][i] x_k, k descending
+            const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
+            const bool in_blk = li >= 0 && li < 16;
+            double lcol[16];
 #pragma unroll
-        for (int ks = 3; ks >= 0; --ks) {  // backward: x_i -= L[k][i] x_k
-            for (int kl = 63; kl >= 0; --kl) {
-                const int k = ks * 64 + kl;
-                if (k >= npad) continue;
-                const double xk = readlane_f64(xv[ks], kl);
+            for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > li) ? M[(size_t)(k0 + j) * ld + k0 + li] : 0.0;
+            double cur = get_slot(slot), xb[16];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int i = lane + 64 * s;
-                    if (i < k) xv[s] -= M[(size_t)k * ld + i] * xk;
+            for (int j = 15; j >= 0; --j) {
+                xb[j] = readlane_f64(cur, lane0 + j);
+                if (in_blk && li < j) cur -= lcol[j] * xb[j];
+            }
+            set_slot(slot, cur);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = lane + 64 * s;
+                if (i < k0) {
+                    double l[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) l[j] = M[(size_t)(k0 + j) * ld + i];
+                    double acc = xv[s];
+#pragma unroll
+                    for (int j = 15; j >= 0; --j) acc -= l[j] * xb[j];
+                    xv[s] = acc;
                 }
             }
         }
