@@ -109,6 +109,7 @@ struct aos2_extractor {
     int last_batch = 0;
     // asynchronous batches (aos2_extractor_extract_batch_device_async): enqueued, not yet waited for
     int in_flight = 0, flight_cap = 0;
+    const int32_t *flight_nout = nullptr;   // d_n_out of the last enqueued batch
     std::chrono::steady_clock::time_point t_enqueue;
     DevBuf<int32_t> d_status;   // sticky [lowest octree failure code, largest n_out] of the batches in flight
     const uint8_t *img0 = nullptr;  // level 0 of the last batch = the caller's (device) images
@@ -130,7 +131,7 @@ struct aos2_extractor {
     DevBuf<int32_t> o_perm, o_tmp, o_pairs, o_idx;
     DevBuf<OctNode> o_nodes;
     // host mirrors
-    PinnedBuf<int32_t> h_level_off, h_sel_cnt, h_nout;
+    PinnedBuf<int32_t> h_level_off, h_sel_cnt, h_nout, h_status;
     PinnedBuf<uint32_t> h_dense, h_sel;
     float timing[8] = {};
 };
@@ -426,6 +427,7 @@ static int init_device(aos2_extractor *e)
         return AOS2_ERR_HIP;
     }
     if ((st = e->d_status.alloc(2))) return st;
+    if ((st = e->h_status.alloc(2))) return st;
     AOS2_HIP_CHECK(hipMemsetAsync(e->d_status.p, 0, 2 * sizeof(int32_t), e->stream));
     AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->dev_ready = true;
@@ -625,8 +627,8 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
                         e->cap_level, sel_cnt, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32, cap, d_nout + b0, nb,
                         e->umax_nibbles, e->d_status.p, s);
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
-        AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p + (size_t)b0 * L, sel_cnt, sizeof(int32_t) * L * nb, hipMemcpyDeviceToHost, s));
-        AOS2_HIP_CHECK(hipMemcpyAsync(e->h_nout.p + b0, d_nout + b0, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
+        // (the per-level and per-image counts of the LAST batch of a flight are fetched once by finish_device(); errors of
+        // earlier batches travel in the sticky status words -- no blit kernels between the chunks' launches)
         return AOS2_OK;
     };
     for (int c = 0; c < chunks; ++c) {
@@ -636,6 +638,7 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     e->timing[6] = (float)chunks;
     e->last_batch = batch;
     e->flight_cap = cap;
+    e->flight_nout = d_nout;
     ++e->in_flight;
     return AOS2_OK;
 }
@@ -646,8 +649,15 @@ static int finish_device(aos2_extractor *e)
     if (e->in_flight == 0) return AOS2_OK;
     const int L = e->nlevels, batch = e->last_batch, cap = e->flight_cap;
     int32_t status[2] = {0, 0};
-    for (int c = 0; c < kMaxStreams; ++c) AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[c]));
-    AOS2_HIP_CHECK(hipMemcpy(status, e->d_status.p, sizeof(status), hipMemcpyDeviceToHost));
+    for (int c = 1; c < kMaxStreams; ++c) AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[c]));
+    // status words + the counts of the last batch: three small copies behind the last chunk of stream 0, one wait
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->h_status.p, e->d_status.p, sizeof(status), hipMemcpyDeviceToHost, e->streams[0]));
+    if (!e->host_octree)
+        AOS2_HIP_CHECK(hipMemcpyAsync(e->h_sel_cnt.p, e->d_sel_cnt.p, sizeof(int32_t) * (size_t)L * batch, hipMemcpyDeviceToHost, e->streams[0]));
+    AOS2_HIP_CHECK(hipMemcpyAsync(e->h_nout.p, e->flight_nout, sizeof(int32_t) * (size_t)batch, hipMemcpyDeviceToHost, e->streams[0]));
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[0]));
+    status[0] = e->h_status.p[0];
+    status[1] = e->h_status.p[1];
     e->in_flight = 0;
     AOS2_HIP_CHECK(hipGetLastError());
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&e->timing[i], e->ev[i], e->ev[i + 1]);
@@ -778,7 +788,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         e->st_sad.release(); e->st_rows.release(); e->st_io.release(); e->st_host.release();
         e->o_xs.release(); e->o_ys.release(); e->o_sc.release(); e->o_perm.release(); e->o_tmp.release();
         e->o_pairs.release(); e->o_idx.release(); e->o_nodes.release();
-        e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_dense.release(); e->h_sel.release();
+        e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_status.release(); e->h_dense.release(); e->h_sel.release();
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
         for (int i = 0; i < e->n_streams; ++i) (void)hipStreamDestroy(e->streams[i]);
     }
