@@ -690,13 +690,15 @@ __global__ __launch_bounds__(1024) void octree_image_kernel(uint32_t *__restrict
 
 // ---------------------------------------------------------------------------------------------
 // Orientation (IC_Angle, :77-104) + 7x7 Gaussian blur (cv::GaussianBlur sigma 2, :1085-1086)
-// + steered rBRIEF (computeOrbDescriptor, :108-147), one wave per keypoint.
+// + steered rBRIEF (computeOrbDescriptor, :108-147), one wave per DK consecutive keypoints.
 //
 // The 43x43 unblurred patch around the keypoint is staged in LDS once (BORDER_REFLECT_101 at the
 // level's edges, exactly what blurring the cloned interior sees).  From it:
 //   * integer moments over the circular r=15 patch -> fastAtan2 polynomial (float, no FMA);
-//   * horizontal 7-tap pass into a u16 LDS tile (43 rows x 37 cols; max 255*257 fits 16 bits);
-//   * the 512 rotated sample positions take the vertical 7-tap on demand, (sum+2^15)>>16.
+//   * horizontal 7-tap pass (exact 16-bit sums, max 255*257) over the (row pair, quad) items a rotated
+//     pattern point can reach, stored transposed with two rows per dword;
+//   * vertical 7-tap pass over the 37x37 tile, (sum + 2^15) >> 16 -> bytes; the 512 rotated sample
+//     positions then read one LDS byte each.
 // This fuses the reference's full-level blur into the consumer: only the <= 37x37 footprint a
 // descriptor can touch (pattern reach +-13 rotated => +-18) is ever blurred, and the blurred
 // pyramid never goes to HBM.
