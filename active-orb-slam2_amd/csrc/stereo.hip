@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const StereoArgs A)
     if (b >= A.batch) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int iL = blockIdx.y * 4 + wave;
-    const int nL = A.n_l[b], nR = A.n_r[b];
+    const int nL = A.n_l[b];
     if (iL >= nL) return;
     const size_t base = (size_t)b * A.cap;
     float out_u = -1.0f, out_d = -1.0f;
