@@ -244,17 +244,11 @@ AOS2_OCT_HD bool divide(List<typename Tr::Node> &L, int id, int c[4], int ccnt[4
     const int hx = (p.x1 - p.x0 + 1) / 2;  // ceil(float(x1-x0)/2)
     const int hy = (p.y1 - p.y0 + 1) / 2;
     const int mx = p.x0 + hx, my = p.y0 + hy;
-    for (int i = 0; i < 4; ++i) {
-        c[i] = new_node(L);
-        if (c[i] < 0) return false;
-    }
-    {
-        Node &n1 = L.nodes[c[0]], &n2 = L.nodes[c[1]], &n3 = L.nodes[c[2]], &n4 = L.nodes[c[3]];
-        n1.x0 = p.x0; n1.y0 = p.y0; n1.x1 = (int16_t)mx; n1.y1 = (int16_t)my;
-        n2.x0 = (int16_t)mx; n2.y0 = p.y0; n2.x1 = p.x1; n2.y1 = (int16_t)my;
-        n3.x0 = p.x0; n3.y0 = (int16_t)my; n3.x1 = (int16_t)mx; n3.y1 = p.y1;
-        n4.x0 = (int16_t)mx; n4.y0 = (int16_t)my; n4.x1 = p.x1; n4.y1 = p.y1;
-    }
+    // four arena slots in creation order n1..n4 (the creation index is the tie-break of the size sort, :681-685); the
+    // records are built in registers and stored ONCE each, fully linked, after the partition (below)
+    if (L.n_alloc + 4 > L.cap) return false;
+    for (int i = 0; i < 4; ++i) c[i] = L.n_alloc + i;
+    L.n_alloc += 4;
     int cnt[4] = {0, 0, 0, 0};
     int off[4];
     if (!Coop::kWave) {
@@ -320,18 +314,36 @@ AOS2_OCT_HD bool divide(List<typename Tr::Node> &L, int id, int c[4], int ccnt[4
             coop_sync();
         }
     }
-    for (int q = 0; q < 4; ++q) {
-        Node &n = L.nodes[c[q]];
-        n.beg = (decltype(n.beg))(p.beg + off[q]);
-        n.cnt = (decltype(n.cnt))cnt[q];
-        ccnt[q] = cnt[q];
-    }
-    // unlink the parent here (its prev/next are already in registers); children are pushed to the
-    // front by the caller, which never touches the parent's neighbours, so the order of the two
-    // operations does not matter
+    // unlink the parent (its prev / next are in registers), then push the non-empty children to the front in the
+    // order n1..n4 (:1000-1040 push_front): the links are resolved in registers, so a child costs one record store
     if (p.prev >= 0) L.nodes[p.prev].next = p.next; else L.head = p.next;
     if (p.next >= 0) L.nodes[p.next].prev = p.prev; else L.tail = p.prev;
     L.size--;
+    int nx[4] = {-1, -1, -1, -1}, pv[4] = {-1, -1, -1, -1};
+    int head = L.head, head_q = -1;   // head_q >= 0: the current head is child head_q (still in registers)
+    for (int q = 0; q < 4; ++q) {
+        ccnt[q] = cnt[q];
+        if (cnt[q] <= 0) continue;
+        nx[q] = head;
+        if (head_q >= 0) pv[head_q] = c[q];
+        else if (head >= 0) L.nodes[head].prev = (decltype(p.prev))c[q];
+        else L.tail = c[q];
+        head = c[q];
+        head_q = q;
+        L.size++;
+    }
+    L.head = head;
+    const int bx0[4] = {p.x0, mx, p.x0, mx}, by0[4] = {p.y0, p.y0, my, my};
+    const int bx1[4] = {mx, p.x1, mx, p.x1}, by1[4] = {my, my, p.y1, p.y1};
+    for (int q = 0; q < 4; ++q) {
+        Node n;
+        n.x0 = (int16_t)bx0[q]; n.y0 = (int16_t)by0[q]; n.x1 = (int16_t)bx1[q]; n.y1 = (int16_t)by1[q];
+        n.beg = (decltype(n.beg))(p.beg + off[q]);
+        n.cnt = (decltype(n.cnt))cnt[q];
+        n.prev = (decltype(n.prev))pv[q];
+        n.next = (decltype(n.next))nx[q];
+        L.nodes[c[q]] = n;
+    }
     return true;
 }
 
@@ -501,14 +513,11 @@ AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, 
             if (ncur + 4 > S.max_pairs) return -2;
             for (int q = 0; q < 4; ++q) {
                 const int cn = ccnt[q];
-                if (cn > 0) {
-                    push_front(L, c[q]);
-                    if (cn > 1) {
-                        nToExpand++;
-                        cur[2 * ncur] = cn;
-                        cur[2 * ncur + 1] = c[q];
-                        ncur++;
-                    }
+                if (cn > 1) {   // (divide() has pushed the non-empty children to the front)
+                    nToExpand++;
+                    cur[2 * ncur] = cn;
+                    cur[2 * ncur + 1] = c[q];
+                    ncur++;
                 }
             }
             lit = nxt;
@@ -666,13 +675,10 @@ AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, 
                     if (ncur + 4 > S.max_pairs) return -2;
                     for (int q = 0; q < 4; ++q) {
                         const int cn = ccnt[q];
-                        if (cn > 0) {
-                            push_front(L, c[q]);
-                            if (cn > 1) {
-                                cur[2 * ncur] = cn;
-                                cur[2 * ncur + 1] = c[q];
-                                ncur++;
-                            }
+                        if (cn > 1) {
+                            cur[2 * ncur] = cn;
+                            cur[2 * ncur + 1] = c[q];
+                            ncur++;
                         }
                     }
                     OCT_COUNT(11, 1);
