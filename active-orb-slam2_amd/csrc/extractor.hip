@@ -576,7 +576,7 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     // asynchronous call, of the next batch).  Measured at B=256, K steps in flight / synchronous call:
     // 2 chunks 0.933 / 0.964 ms, 3 chunks 0.855 / 0.967, 4 chunks 0.852 / 0.971 (needs GPU_MAX_HW_QUEUES=8: the
     // runtime's default of 4 hardware queues puts two of the 4 streams on one queue, 1.16 ms), 6: 1.08, 8: 1.28
-    // (~13 launches per chunk: the host's launch rate becomes the limit).
+    // (smaller chunks lose to kernel tails and queue sharing; replaying each chunk as one hipGraph changed nothing).
     int chunks = e->chunks > 0 ? e->chunks : (batch >= 96 ? 3 : batch >= 64 ? 2 : 1);
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
