@@ -45,6 +45,33 @@ def test_host_tables_match_oracle(pkg, oracle):
         assert a.max_keypoints >= nf
 
 
+def test_keypoint_capacity_bound_covers_the_octree(pkg, oracle):
+    """aos2_extractor_max_keypoints_for(w, h) (host arithmetic, no device): per level max(N + 3, 4 * round(W / H)) --
+    DistributeOctTree's first pass divides all round(W / H) root nodes unconditionally (src/ORBextractor.cc:549-590).
+    Checked against the formula and against what the oracle's octree actually returns on crowded wide levels."""
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        w, h = int(rng.integers(120, 2000)), int(rng.integers(100, 700))
+        nf, sf, nl = int(rng.choice([50, 100, 1000])), float(rng.choice([1.1, 1.2, 1.5])), int(rng.integers(1, 9))
+        ex = pkg.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+        inv = ex.GetInverseScaleFactors()
+        want = 0
+        for l, n_l in enumerate(ex.features_per_level):
+            lw, lh = int(np.rint(np.float32(w) * inv[l])), int(np.rint(np.float32(h) * inv[l]))
+            b = int(n_l) + 3
+            if lw > 32 and lh > 32:
+                r = np.float32(lw - 32) / np.float32(lh - 32)
+                b = max(b, 4 * int(np.floor(r + np.float32(0.5))))      # round(): half away from zero
+            want += b
+        assert ex.max_keypoints_for(w, h) == want >= ex.max_keypoints
+    # the bound is reached: 7 root nodes, every one crowded, N = 20 -> 28 leaves
+    W, H = 7 * 60, 60
+    xs, ys = np.meshgrid(np.arange(2, W - 2, 3, dtype=np.float32), np.arange(2, H - 2, 3, dtype=np.float32))
+    xs, ys = xs.ravel(), ys.ravel()
+    sel = oracle.distribute_octree(xs, ys, np.ones(len(xs), np.float32), 0, W, 0, H, 20)
+    assert len(sel) == 28 > 20 + 3
+
+
 def test_bad_arguments_and_missing_device(pkg):
     capi = pkg.capi
     with pytest.raises(capi.AosError) as e:
