@@ -64,6 +64,8 @@ def lib():
         L.aos2_extractor_max_keypoints_for.argtypes = [vp, ci, ci]
         L.aos2_extractor_extract.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, C.POINTER(ci)]
         L.aos2_extractor_extract_batch.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+        L.aos2_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+        L.aos2_host_free.argtypes = [vp]
         L.aos2_extractor_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
         L.aos2_extractor_extract_batch_device_async.argtypes = [vp, vp, ci, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
         L.aos2_extractor_wait.argtypes = [vp]
@@ -151,6 +153,31 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _HostBlock:
+    """page-locked host allocation (aos2_host_alloc), released with the last array that views it"""
+
+    def __init__(self, nbytes):
+        self.L = lib()
+        p = C.c_void_p()
+        _check(self.L.aos2_host_alloc(C.byref(p), max(int(nbytes), 1)))
+        self.p = p.value
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            self.L.aos2_host_free(C.c_void_p(self.p))
+            self.p = None
+
+
+def host_empty(shape, dtype=np.uint8):
+    """uninitialised numpy array in page-locked host memory (for Extractor.extract_batch inputs / outputs)"""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    blk = _HostBlock(n)
+    buf = (C.c_uint8 * max(n, 1)).from_address(blk.p)
+    buf._block = blk   # the ctypes view keeps the allocation alive; numpy keeps the view alive (.base)
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
 def device_count():
     return lib().aos2_device_count()
 
@@ -231,11 +258,15 @@ class Extractor:
         return kps[: n.value].copy(), desc[: n.value].copy()
 
     def extract_batch(self, images):
+        """host images [B, h, w] (any host memory; host_empty() arrays are uploaded by DMA) -> [(kps, desc)] * B"""
         images = np.ascontiguousarray(images, dtype=np.uint8)
         B, h, w = images.shape
         cap = self.max_keypoints_for(w, h)
-        kps = np.zeros((B, cap), KP_DTYPE)
-        desc = np.zeros((B, cap, 32), np.uint8)
+        if getattr(self, "_out_key", None) != (B, cap):   # page-locked result buffers, reused between calls
+            self._out_key, self._out = None, None
+            self._out = (host_empty((B, cap), KP_DTYPE), host_empty((B, cap, 32), np.uint8))
+            self._out_key = (B, cap)
+        kps, desc = self._out
         n = np.zeros(B, np.int32)
         _check(self.L.aos2_extractor_extract_batch(self.h, _p(images), B, w, h, w, w * h, _p(kps), _p(desc), cap, _p(n)))
         return [(kps[b, : n[b]].copy(), desc[b, : n[b]].copy()) for b in range(B)]

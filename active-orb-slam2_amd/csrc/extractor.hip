@@ -552,8 +552,20 @@ static int finish_device(aos2_extractor *e);
 // Enqueues one batch on the handle's streams and returns; finish_device() completes it.  Chunk c of every batch
 // uses stream c and the scratch of its own image range, so consecutive batches are ordered per stream and may be
 // in flight together: a chunk's latency-bound octree then overlaps the next batch's kernels on the other streams.
+// Host buffers of the host-pointer entry point: each chunk's images are uploaded on the chunk's stream in front of
+// its kernels and its results downloaded behind them, so the PCIe copies of one chunk overlap the kernels of the
+// others (DMA needs page-locked caller memory -- aos2_host_alloc; pageable memory is staged by the runtime).
+struct HostIO {
+    const uint8_t *imgs;
+    int stride;
+    size_t image_stride;
+    aos2_keypoint_t *kps;
+    uint8_t *desc;
+};
+
 static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
-                          size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
+                          size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout,
+                          const HostIO *io = nullptr)
 {
     e->t_enqueue = std::chrono::steady_clock::now();
     int st;
@@ -578,6 +590,7 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     // runtime's default of 4 hardware queues puts two of the 4 streams on one queue, 1.16 ms), 6: 1.08, 8: 1.28
     // (smaller chunks lose to kernel tails and queue sharing; replaying each chunk as one hipGraph changed nothing).
     int chunks = e->chunks > 0 ? e->chunks : (batch >= 96 ? 3 : batch >= 64 ? 2 : 1);
+    if (io && e->chunks <= 0 && batch >= 32) chunks = 4;   // copy / compute pipeline of the host-pointer call
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
     auto enqueue = [&](int b0, int nb, hipStream_t s, bool timed) -> int {
@@ -587,6 +600,16 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
         int32_t *cell_cnt = e->d_cell_cnt.p + (size_t)b0 * NC, *level_off = e->d_level_off.p + (size_t)b0 * (L + 1);
         uint32_t *sel = e->d_sel.p + (size_t)b0 * L * e->cap_level;
         int32_t *sel_cnt = e->d_sel_cnt.p + (size_t)b0 * L;
+        if (io) {
+            uint8_t *dst = const_cast<uint8_t *>(img);
+            const uint8_t *src = io->imgs + (size_t)b0 * io->image_stride;
+            if (io->stride == w && io->image_stride == (size_t)w * h)
+                AOS2_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nb * w * h, hipMemcpyHostToDevice, s));
+            else
+                for (int b = 0; b < nb; ++b)
+                    AOS2_HIP_CHECK(hipMemcpy2DAsync(dst + (size_t)b * image_stride, (size_t)stride, src + (size_t)b * io->image_stride,
+                                                    (size_t)io->stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, s));
+        }
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[0], s));
         for (int l = 1; l < L; ++l) {
             const bool from0 = (l == 1);
@@ -627,6 +650,12 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
                         e->cap_level, sel_cnt, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32, cap, d_nout + b0, nb,
                         e->umax_nibbles, e->d_status.p, s);
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[5], s));
+        if (io) {
+            AOS2_HIP_CHECK(hipMemcpyAsync(io->kps + (size_t)b0 * cap, d_kps + (size_t)b0 * cap, sizeof(aos2_keypoint_t) * (size_t)nb * cap,
+                                          hipMemcpyDeviceToHost, s));
+            AOS2_HIP_CHECK(hipMemcpyAsync(io->desc + (size_t)b0 * cap * 32, d_desc + (size_t)b0 * cap * 32, (size_t)nb * cap * 32,
+                                          hipMemcpyDeviceToHost, s));
+        }
         // (the per-level and per-image counts of the LAST batch of a flight are fetched once by finish_device(); errors of
         // earlier batches travel in the sticky status words -- no blit kernels between the chunks' launches)
         return AOS2_OK;
@@ -692,11 +721,12 @@ static int finish_device(aos2_extractor *e)
 }
 
 static int run_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
-                      size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout)
+                      size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout,
+                      const HostIO *io = nullptr)
 {
     int st;
     if (e->in_flight > 0 && (st = finish_device(e))) return st;
-    if ((st = enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_nout))) return st;
+    if ((st = enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_nout, io))) return st;
     return finish_device(e);
 }
 
@@ -869,18 +899,35 @@ int aos2_extractor_extract_batch(aos2_extractor_t *e, const uint8_t *imgs, int b
     if ((st = e->d_in.alloc((size_t)batch * w * h))) return st;
     if ((st = ensure_out(e, batch, cap))) return st;
     e->out_cap = cap;
-    AOS2_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p, (size_t)w, imgs, (size_t)stride, (size_t)w, (size_t)h * 1, hipMemcpyHostToDevice, e->stream));
-    for (int b = 1; b < batch; ++b)
-        AOS2_HIP_CHECK(hipMemcpy2DAsync(e->d_in.p + (size_t)b * w * h, (size_t)w, imgs + (size_t)b * image_stride,
-                                        (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, e->stream));
-    st = run_device(e, e->d_in.p, batch, w, h, w, (size_t)w * h, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p);
+    // uploads, kernels and downloads are pipelined per chunk on the chunk's stream (HostIO)
+    const HostIO io{imgs, stride, image_stride, kps, desc};
+    st = run_device(e, e->d_in.p, batch, w, h, w, (size_t)w * h, e->d_kps.p, e->d_desc.p, cap, e->d_nout.p, &io);
     if (st == AOS2_OK || st == AOS2_ERR_CAPACITY) {
         for (int b = 0; b < batch; ++b) n_out[b] = e->h_nout.p[b];
     }
-    if (st) return st;
-    AOS2_HIP_CHECK(hipMemcpyAsync(kps, e->d_kps.p, sizeof(aos2_keypoint_t) * (size_t)batch * cap, hipMemcpyDeviceToHost, e->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(desc, e->d_desc.p, (size_t)batch * cap * 32, hipMemcpyDeviceToHost, e->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return st;
+}
+
+int aos2_host_alloc(void **p, size_t bytes)
+{
+    if (!p || bytes == 0) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    *p = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device: page-locked host memory needs the GPU runtime");
+        return AOS2_ERR_NO_DEVICE;
+    }
+    AOS2_HIP_CHECK(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return AOS2_OK;
+}
+
+int aos2_host_free(void *p)
+{
+    if (!p) return AOS2_OK;
+    AOS2_HIP_CHECK(hipHostFree(p));
     return AOS2_OK;
 }
 

@@ -194,3 +194,16 @@ def test_vocabulary_host_side_without_gpu(pkg, oracle, tmp_path):
     if pkg.device_count() == 0:  # transform needs the device: loud failure, no CPU fallback
         with pytest.raises(pkg.AosError):
             V.transform(voc["desc"][:10], 2)
+
+
+def test_host_alloc_needs_the_gpu_runtime(pkg):
+    """aos2_host_alloc is page-locked memory from the HIP runtime: without a device it must say so, not hand out malloc"""
+    import ctypes as C
+    L = pkg.capi.lib()
+    p = C.c_void_p(123)
+    if pkg.device_count() > 0:
+        pytest.skip("GPU present")
+    assert L.aos2_host_alloc(C.byref(p), 4096) == -5 and not p.value
+    assert L.aos2_host_free(None) == 0
+    with pytest.raises(pkg.AosError):
+        pkg.host_empty((4, 4))

@@ -228,6 +228,43 @@ def test_async_flight_equals_synchronous_batches(pkg, oracle, gpu):
     assert (o[2].cpu().numpy() == sync_out[2][2].cpu().numpy()).all()
 
 
+def test_host_pointer_batch_pipeline(pkg, oracle, gpu):
+    """aos2_extractor_extract_batch with host pointers: uploads / kernels / downloads are pipelined per chunk.  Pageable,
+    page-locked (aos2_host_alloc) and row-padded inputs give the device-resident call's results bit for bit, and a
+    sampled image equals the oracle."""
+    import ctypes as C
+    import torch
+    B, w, h = 40, 640, 480           # >= 32 images: 4 chunks on 4 streams
+    imgs = pkg.synth.synth_batch(4200, B)
+    ex = pkg.Extractor()
+    ref = ex.extract_batch(imgs)                                      # pageable input
+    pin = pkg.host_empty(imgs.shape, np.uint8)
+    pin[...] = imgs
+    got = ex.extract_batch(pin)                                       # page-locked input
+    dev = torch.from_numpy(imgs).to("cuda:0")
+    cap = ex.max_keypoints_for(w, h)
+    dk = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda:0"); dd = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda:0")
+    dn = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    ex.extract_batch_device(dev.data_ptr(), B, w, h, w, w * h, dk.data_ptr(), dd.data_ptr(), cap, dn.data_ptr())
+    kd = dk.cpu().numpy().view(pkg.capi.KP_DTYPE).reshape(B, cap); ddh = dd.cpu().numpy(); n = dn.cpu().numpy()
+    for b in range(B):
+        for r in (ref, got):
+            assert len(r[b][0]) == n[b] and (r[b][0] == kd[b, : n[b]]).all() and (r[b][1] == ddh[b, : n[b]]).all()
+    # padded rows and padded images (stride > w, image_stride > stride * h): the per-image 2-D upload path
+    stride, istride = w + 24, (w + 24) * (h + 3)
+    padded = np.full((B, istride), 255, np.uint8)
+    for b in range(B):
+        padded[b, : stride * h].reshape(h, stride)[:, :w] = imgs[b]
+    kps = np.zeros((B, cap), pkg.capi.KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); nn = np.zeros(B, np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert ex.L.aos2_extractor_extract_batch(ex.h, vp(padded), B, w, h, stride, istride, vp(kps), vp(desc), cap, vp(nn)) == 0
+    assert (nn == n).all()
+    for b in range(B):
+        assert (kps[b, : n[b]] == kd[b, : n[b]]).all() and (desc[b, : n[b]] == ddh[b, : n[b]]).all()
+    want = oracle.Extractor().extract(imgs[17])
+    assert len(want[0]) == n[17] and (want[1] == got[17][1]).all() and (want[0]["x"] == got[17][0]["x"]).all()
+
+
 def test_sincos_device_equals_host(pkg, gpu):
     a = (np.linspace(0, 360, 200001).astype(np.float32) * np.float32(np.pi / 180.0)).astype(np.float32)
     s, c = pkg.capi.debug_sincos_device(a)
