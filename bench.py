@@ -187,6 +187,20 @@ def main():
             extra["local_ba"] = {"edges": prob["n_edges"], "keyframes": prob["n_poses"], "points": prob["n_points"],
                                  "wall_ms": lba_wall, "device_ms": r["ms_device"],
                                  "bound": "latency (LM control loop, ~25 launches per iteration)"}
+            # independent windows (several maps / offline windows, SURVEY 8(e): LocalBA = replicas only): one handle
+            # and one host thread per window; the latency-bound kernels of the windows overlap on the GPU
+            import threading
+            nwin = 8
+            bas = [pkg.LocalBA(device=local_rank) for _ in range(nwin)]
+            probs_w = [S.synth_lba_problem(i) for i in range(nwin)]
+            for b_, q_ in zip(bas, probs_w):
+                b_.LocalBundleAdjustment(q_)
+            tb = time.perf_counter()
+            ths = [threading.Thread(target=b_.LocalBundleAdjustment, args=(q_,)) for b_, q_ in zip(bas, probs_w)]
+            [t_.start() for t_ in ths]
+            [t_.join() for t_ in ths]
+            wall_w = (time.perf_counter() - tb) * 1e3
+            extra["local_ba"]["concurrent_windows"] = {"windows": nwin, "wall_ms": wall_w, "windows_per_s": nwin / wall_w * 1e3}
             # stereo front-end on the bench frames themselves (same launch shapes as the timed steps, so the
             # rocprofv3 averages of the extractor kernels stay comparable): right eye = left eye shifted by a
             # per-row-band disparity + noise; both eyes' operator() + Frame::ComputeStereoMatches, device-resident

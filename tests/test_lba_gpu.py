@@ -106,3 +106,25 @@ def test_pose_optimization_batch_and_golden(pkg, oracle, gpu):
     r = ba.PoseOptimization(prob)
     assert r["n_inliers"] == int(g["out_n_inliers"]) and (r["outlier"] == g["out_outlier"]).all()
     assert close(r["Tcw"].reshape(1, 16), g["out_Tcw"].reshape(1, 16))
+
+
+def test_lba_concurrent_windows_from_threads(pkg, gpu):
+    """Independent windows (one handle + one host thread each, SURVEY 8(e) "replicas only") solved at the same time
+    give exactly the results of solving them one after the other: handles share nothing but the device."""
+    import threading
+    probs = [pkg.synth.synth_lba_problem(30 + i, n_local=4 + i, n_fixed=3, n_points=150 + 40 * i) for i in range(6)]
+    serial = [pkg.LocalBA().LocalBundleAdjustment(q) for q in probs]
+    handles = [pkg.LocalBA() for _ in probs]
+    out = [None] * len(probs)
+
+    def work(i):
+        for _ in range(3):
+            out[i] = handles[i].LocalBundleAdjustment(probs[i])
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(probs))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for a, b in zip(out, serial):
+        assert a is not None and a["status"] == 0 and a["iters"] == b["iters"]
+        assert (a["pose_Tcw"] == b["pose_Tcw"]).all() and (a["point_xyz"] == b["point_xyz"]).all()
+        assert (a["edge_outlier"] == b["edge_outlier"]).all()
