@@ -15,6 +15,8 @@
 // one workgroup, back-substitution + manifold update.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -169,6 +171,11 @@ struct LbaAct {
     const int32_t *pl_off, *pl_k;    // free-pose slots by point, ascending pose hidx
     double *JA, *JB, *Wr, *wo, *Hpl; // per slot: 9, 18, 3, 1, 18
     double *Hpp, *Hll, *b, *x, *Hs, *bs, *coeff, *Dinv;
+    // Schur complement by items: item = (landmark, free-pose slots ka <= kb of it), ranked by (pose, pose) block in
+    // upper-triangular order, landmark order inside a block (host-built per pass, build_schur_items)
+    const int32_t *it_ka, *it_kb, *it_l, *blk_off;
+    int n_items;
+    double *W, *Wc;                  // W[36][n_items] (B_a Dinv B_b^T, element-major); per active slot: 6 (B_a Dinv b_l)
     double *tmp;                     // reduction scratch (>= max(ka, 6np+3nl))
     double *scal;                    // [0] chi2, [1] scale, [2] max diag, [3] solve ok
 };
@@ -521,6 +528,110 @@ __global__ __launch_bounds__(256) void k_schur_reduce(LbaAct A, double lambda, c
     }
 }
 
+// ---- Schur complement in two conflict-free phases (the default).  The host ranks the items -- (landmark, free-pose
+// slots ka <= kb of it) -- by their (pose, pose) block, landmark order inside a block (build_schur_items).  Phase A:
+// thread s computes item s's 6x6 contribution B_a Dinv B_b^T (block_solver.hpp:379-432) and stores its 36 elements
+// element-major, W[e][s], so a wave's stores are contiguous; the diagonal items also produce the coefficient
+// vector's terms B_a Dinv b_l.  Phase B: one workgroup per block; each wave adds whole rows W[e][o0 .. o0+n) (lanes
+// stride the items, then a fixed butterfly over the lanes): no atomics, bit-reproducible, and no dependent chain of
+// landmarks per wave (k_schur_partial folds 8 landmarks one after the other into a private LDS matrix: 42 + 12 us per
+// LM iteration at 2005 landmarks / 20 free keyframes).
+// The threads behind the last item take the LM trial's backup of the estimates (SparseOptimizer::push, :600-604):
+// bk_n doubles from bk_src to bk_dst, which saves the two device-to-device copies per trial.
+__global__ __launch_bounds__(128) void k_schur_items(LbaAct A, double lambda, const double *bk_src, double *bk_dst, int bk_n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.n_items) {
+        const int i = t - A.n_items;
+        if (i < bk_n) bk_dst[i] = bk_src[i];
+        return;
+    }
+    const int ka = A.it_ka[t], kb = A.it_kb[t], l = A.it_l[t];   // three independent loads, then one level of gathers
+    double D[9], Dinv[9];
+    for (int i = 0; i < 9; ++i) D[i] = A.Hll[9 * (size_t)l + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    mat3_inverse(D, Dinv);
+    const double *Bi = A.Hpl + 18 * (size_t)ka, *Bj = A.Hpl + 18 * (size_t)kb;
+    double BD[18];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
+    double *w = A.W + t;
+    const size_t ni = (size_t)A.n_items;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) w[(size_t)(r * 6 + c) * ni] = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
+    if (ka == kb) {
+        const double *bl = A.b + 6 * A.np + 3 * (size_t)l;
+        double db[3];
+        for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
+        for (int r = 0; r < 6; ++r) A.Wc[6 * (size_t)ka + r] = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+    }
+}
+
+// sum over the 64 lanes in a fixed order (xor butterfly)
+__device__ __forceinline__ double wave_sum_f64_fixed(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// grid = np (np + 1) / 2 block workgroups (upper block triangle, row-major) followed by np coefficient workgroups;
+// 8 waves per workgroup, wave w takes the elements e = w, w + 8, ...
+__global__ __launch_bounds__(512) void k_schur_blocks(LbaAct A, double lambda)
+{
+    const int np = A.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x;
+    if (blk >= nblk) {   // bschur = b_p - sum over the pose's slots of B Dinv b_l
+        const int i = blk - nblk;
+        if (wave >= 6) return;
+        const int c0 = A.ps_off[i], n = A.ps_off[i + 1] - c0;
+        double acc = 0;
+        for (int j = lane; j < n; j += 64) acc += A.Wc[6 * (size_t)A.ps_k[c0 + j] + wave];
+        acc = wave_sum_f64_fixed(acc);
+        if (lane == 0) A.bs[6 * i + wave] = A.b[6 * i + wave] - acc;
+        return;
+    }
+    // blk -> (i1 <= i2)
+    int i1 = 0, rem = blk;
+    while (rem >= np - i1) {
+        rem -= np - i1;
+        ++i1;
+    }
+    const int i2 = i1 + rem;
+    const int o0 = A.blk_off[blk], n = A.blk_off[blk + 1] - o0;
+    const size_t ni = (size_t)A.n_items;
+    // the wave's (up to) five rows are summed together: their loads are independent and stay in flight side by side
+    double acc[5] = {0, 0, 0, 0, 0};
+    const double *w = A.W + (size_t)wave * ni + o0;
+    const bool five = wave + 32 < 36;
+#pragma unroll 2
+    for (int j = lane; j < n; j += 64) {
+        const double v0 = w[j], v1 = w[8 * ni + j], v2 = w[16 * ni + j], v3 = w[24 * ni + j];
+        const double v4 = five ? w[32 * ni + j] : 0.0;
+        acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3; acc[4] += v4;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] += __shfl_xor(acc[q], m, 64);
+    }
+    if (lane != 0) return;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = wave + 8 * q;
+        if (e >= 36) break;
+        double v = -acc[q];
+        const int r = e / 6, c = e - 6 * r;
+        if (i1 == i2) {
+            v += A.Hpp[36 * (size_t)i1 + e];
+            if (r == c) v += lambda;
+        }
+        A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
+        if (i1 != i2) A.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+    }
+}
+
 // fallback for reduced systems too large for LDS (> 22 free keyframes): f64 atomics in global memory
 __global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
 {
@@ -558,8 +669,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// kLds: the solution stays in LDS and wave 0 applies it to the free poses straight away (VertexSE3Expmap::oplusImpl +
+// the scale terms of k_update_poses), which saves a launch per LM trial; the global-scratch variant is followed by
+// k_update_poses.
 template <bool kLds>
-__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *gscratch)
+__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *gscratch, double *poses, double lambda)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = 6 * A.np;
@@ -751,8 +865,22 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
         for (int s = 0; s < 4; ++s) {
             const int i = lane + 64 * s;
             if (i < n) A.x[i] = xv[s];
+            if (kLds && i < n) M[i] = xv[s];   // the factor is dead: its first row carries x to the pose update
         }
         if (lane == 0) A.scal[3] = 1.0;
+        if (kLds) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < A.np) {
+                double upd[6];
+                for (int i = 0; i < 6; ++i) {
+                    upd[i] = M[6 * lane + i];
+                    A.tmp[6 * lane + i] = upd[i] * (lambda * upd[i] + A.b[6 * lane + i]);
+                }
+                se3_oplus(upd, poses + 7 * (size_t)A.hpose[lane]);
+            }
+        }
     }
 }
 
@@ -770,7 +898,12 @@ __global__ void k_backsub_points(LbaDev P, LbaAct A, double lambda)
         for (int c = 0; c < 3; ++c)
             for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-A.x[6 * i1 + r]);
     }
-    const double *Dinv = A.Dinv + 9 * (size_t)l;
+    // (Hll + lambda I)^-1 again, the same operations as in the Schur kernels (so the same bits): landmarks seen by
+    // fixed keyframes only have no Schur item that could have stored it
+    double Dm[9], Dinv[9];
+    for (int i = 0; i < 9; ++i) Dm[i] = A.Hll[9 * (size_t)l + i];
+    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+    mat3_inverse(Dm, Dinv);
     double *X = P.point + 3 * (size_t)A.hpoint[l];
     for (int r = 0; r < 3; ++r) {
         const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
@@ -1268,6 +1401,7 @@ static bool stop_requested(const aos2_lba_problem_t *p) { return p->stop_flag &&
 
 struct Pass {
     std::vector<int32_t> act, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
+    std::vector<int32_t> it_ka, it_kb, it_l, blk_off;   // Schur items (k_schur_items / k_schur_blocks)
     int ka = 0, np = 0, nl = 0;
 };
 
@@ -1331,6 +1465,55 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
         std::stable_sort(S.pl_k.begin() + S.pl_off[l], S.pl_k.begin() + S.pl_off[l + 1],
                          [&](int a, int b) { return S.k_ph[a] < S.k_ph[b]; });
     return true;
+}
+
+// number of Schur items of a pass: sum over landmarks of m (m + 1) / 2, m = observations by free keyframes
+static size_t schur_item_count(const Pass &S)
+{
+    size_t n = 0;
+    for (int l = 0; l < S.nl; ++l) {
+        const size_t m = (size_t)(S.pl_off[l + 1] - S.pl_off[l]);
+        n += m * (m + 1) / 2;
+    }
+    return n;
+}
+
+// items ranked by (pose, pose) block -- upper block triangle, row-major -- and by landmark inside a block (counting
+// sort; this order is the summation order of k_schur_blocks)
+static void build_schur_items(Pass &S)
+{
+    const size_t n = schur_item_count(S);
+    const int np = S.np, nblk = np * (np + 1) / 2;
+    S.it_ka.resize(n); S.it_kb.resize(n); S.it_l.resize(n);
+    S.blk_off.assign((size_t)nblk + 1, 0);
+    // block of (i1 <= i2) = row_base[i1] + i2 (pl_k is sorted by pose, so a <= b gives i1 <= i2)
+    std::vector<int32_t> row_base(np > 0 ? np : 1), ph(S.pl_k.size());
+    for (int i = 0; i < np; ++i) row_base[i] = i * np - i * (i - 1) / 2 - i;
+    for (size_t i = 0; i < S.pl_k.size(); ++i) ph[i] = S.k_ph[S.pl_k[i]];
+    for (int l = 0; l < S.nl; ++l) {
+        const int32_t *q = ph.data() + S.pl_off[l];
+        const int m = S.pl_off[l + 1] - S.pl_off[l];
+        for (int a = 0; a < m; ++a) {
+            int32_t *cnt = S.blk_off.data() + row_base[q[a]] + 1;
+            for (int b = a; b < m; ++b) cnt[q[b]]++;
+        }
+    }
+    for (int i = 0; i < nblk; ++i) S.blk_off[i + 1] += S.blk_off[i];
+    std::vector<int32_t> fill(S.blk_off.begin(), S.blk_off.end() - 1);
+    for (int l = 0; l < S.nl; ++l) {
+        const int c0 = S.pl_off[l], m = S.pl_off[l + 1] - c0;
+        const int32_t *q = ph.data() + c0, *k = S.pl_k.data() + c0;
+        for (int a = 0; a < m; ++a) {
+            int32_t *f = fill.data() + row_base[q[a]];
+            const int32_t ka = k[a];
+            for (int b = a; b < m; ++b) {
+                const int slot = f[q[b]]++;
+                S.it_ka[slot] = ka;
+                S.it_kb[slot] = k[b];
+                S.it_l[slot] = l;
+            }
+        }
+    }
 }
 
 }  // namespace aos2
@@ -1397,6 +1580,10 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     HostArena H;
     const size_t o_pose = H.push(pose.data(), pose.size() * 8), o_point = H.push(point.data(), point.size() * 8);
     const size_t o_bkpose = H.push(nullptr, pose.size() * 8), o_bkpoint = H.push(nullptr, point.size() * 8);
+    if (o_bkpoint - o_bkpose != o_point - o_pose) {   // the LM backup copies [poses | points] as one span
+        set_error("internal: arena layout");
+        return AOS2_ERR_ARG;
+    }
     const size_t o_epose = H.push(p->edge_pose, (size_t)E * 4), o_epoint = H.push(p->edge_point, (size_t)E * 4);
     const size_t o_obs = H.push(obs.data(), obs.size() * 8), o_w = H.push(w.data(), w.size() * 8);
     const size_t o_st = H.push(p->edge_stereo, E), o_rb = H.push(robust.data(), E), o_l1 = H.push(level1.data(), E);
@@ -1419,7 +1606,24 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
     const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
     const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, 64);
-    const size_t o_partial = H.push(nullptr, (size_t)kSchurGroups * (n6max * n6max + n6max) * 8 + 8);
+    // Schur items (first pass = all edges = the largest): sum over points of m (m + 1) / 2, m = edges to free keyframes
+    size_t n_items_max = 0;
+    {
+        std::vector<int32_t> m(NL, 0);
+        for (int e = 0; e < E; ++e)
+            if (!p->pose_fixed[p->edge_pose[e]]) m[p->edge_point[e]]++;
+        for (int l = 0; l < NL; ++l) n_items_max += (size_t)m[l] * (m[l] + 1) / 2;
+    }
+    // AOS2_SCHUR=partial selects the former per-wave LDS accumulation (kept for reduced systems whose items would
+    // not fit: W is 288 B per item); the tests run both
+    const char *schur_env = getenv("AOS2_SCHUR");
+    const bool schur_items = !(schur_env && strcmp(schur_env, "partial") == 0) && n_items_max * 288 <= ((size_t)1 << 30) &&
+                             n_items_max < ((size_t)1 << 30);
+    const size_t o_partial = H.push(nullptr, schur_items ? 8 : (size_t)kSchurGroups * (n6max * n6max + n6max) * 8 + 8);
+    const size_t n_it = schur_items ? n_items_max : 0, nblk_max = (size_t)n_free * (n_free + 1) / 2;
+    const size_t o_itka = H.push(nullptr, n_it * 4 + 4), o_itkb = H.push(nullptr, n_it * 4 + 4), o_itl = H.push(nullptr, n_it * 4 + 4);
+    const size_t o_blkoff = H.push(nullptr, (nblk_max + 1) * 4), o_W = H.push(nullptr, n_it * 288 + 8);
+    const size_t o_Wc = H.push(nullptr, schur_items ? (size_t)E * 48 + 8 : 8);
     const size_t npad_max = (n6max + 15) & ~(size_t)15;
     const size_t o_ldlt = H.push(nullptr, (npad_max * (npad_max + 1) + npad_max * 17 + npad_max + 64) * 8);
     if ((st = s->arena.alloc(H.size + 256))) return st;
@@ -1456,9 +1660,26 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     A.Hll = (double *)(base + o_Hll); A.b = (double *)(base + o_b); A.x = (double *)(base + o_x);
     A.Hs = (double *)(base + o_Hs); A.bs = (double *)(base + o_bs); A.coeff = (double *)(base + o_coeff);
     A.Dinv = (double *)(base + o_Dinv); A.tmp = (double *)(base + o_tmp); A.scal = d_scal;
+    A.it_ka = (int32_t *)(base + o_itka); A.it_kb = (int32_t *)(base + o_itkb); A.it_l = (int32_t *)(base + o_itl);
+    A.blk_off = (int32_t *)(base + o_blkoff); A.W = (double *)(base + o_W); A.Wc = (double *)(base + o_Wc);
 
-    auto upload_pass = [&](const Pass &S) -> int {
+    auto upload_pass = [&](Pass &S) -> int {
         A.ka = S.ka; A.np = S.np; A.nl = S.nl;
+        A.n_items = 0;
+        if (schur_items && S.np > 0) {
+            build_schur_items(S);
+            A.n_items = (int)S.it_ka.size();
+            if (S.it_ka.size() > n_items_max) {   // cannot happen: a pass is a subset of the edges
+                set_error("internal: Schur item count grew");
+                return AOS2_ERR_ARG;
+            }
+            if (A.n_items) {
+                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_ka, S.it_ka.data(), S.it_ka.size() * 4, hipMemcpyHostToDevice, q));
+                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_kb, S.it_kb.data(), S.it_kb.size() * 4, hipMemcpyHostToDevice, q));
+                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_l, S.it_l.data(), S.it_l.size() * 4, hipMemcpyHostToDevice, q));
+            }
+            AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.blk_off, S.blk_off.data(), S.blk_off.size() * 4, hipMemcpyHostToDevice, q));
+        }
         AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.act, S.act.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
         AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_ph, S.k_ph.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
         AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_lh, S.k_lh.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
@@ -1518,13 +1739,22 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         const int maxTrials = 10;
         do {
             // push
-            AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpose, D.pose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
-            AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpoint, D.point, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
+            // (poses and points are neighbours in the arena, and so are their backups: one span; the item kernel of
+            // the Schur complement copies it with its spare threads)
+            const int bk_n = (int)((o_point - o_pose) / 8 + 3 * (size_t)NL);
+            const bool push_in_items = schur_items && n6 > 0;
+            if (!push_in_items) {
+                AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpose, D.pose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
+                AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpoint, D.point, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
+            }
             // setLambda + Schur solve (the diagonal is never modified in place: lambda is added
             // where Hpp / Hll are consumed, which is what restoreDiagonal undoes in g2o)
             if (n6 > 0) {
                 const size_t sch_lds = ((size_t)n6 * n6 + n6) * sizeof(double);
-                if (sch_lds <= 150 * 1024) {
+                if (schur_items) {
+                    hipLaunchKernelGGL(k_schur_items, blocks(A.n_items + bk_n, 128), dim3(128), 0, q, A, lambda, D.pose, d_bkpose, bk_n);
+                    hipLaunchKernelGGL(k_schur_blocks, dim3(A.np * (A.np + 1) / 2 + A.np), dim3(512), 0, q, A, lambda);
+                } else if (sch_lds <= 150 * 1024) {
                     const int G = std::min(kSchurGroups, A.nl);
                     hipLaunchKernelGGL(k_schur_partial, dim3(G), dim3(64), sch_lds, q, A, lambda, d_partial, G);
                     hipLaunchKernelGGL(k_schur_reduce, blocks(n6 * n6 + n6, 32), dim3(256), 0, q, A, lambda, d_partial, G);
@@ -1542,13 +1772,13 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
                     const size_t need = ((size_t)npad * (npad + 1) + (size_t)npad * 17 + npad + 64) * sizeof(double);
                     const int use_lds = need <= 160 * 1024 ? 1 : 0;
                     if (use_lds)
-                        hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(1), dim3(256), need, q, A, npad, (double *)(base + o_ldlt));
-                    else
-                        hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(1), dim3(256), 0, q, A, npad, (double *)(base + o_ldlt));
+                        hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(1), dim3(256), need, q, A, npad, (double *)(base + o_ldlt), D.pose, lambda);
+                    else {
+                        hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(1), dim3(256), 0, q, A, npad, (double *)(base + o_ldlt), D.pose, lambda);
+                        hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
+                    }
                 }
-                hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
             } else {
-                hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);  // Dinv only
                 AOS2_HIP_CHECK(hipMemsetAsync(d_scal + 3, 0, sizeof(double), q));
             }
             hipLaunchKernelGGL(k_backsub_points, blocks(A.nl, 128), dim3(128), 0, q, D, A, lambda);

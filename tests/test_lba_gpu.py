@@ -128,3 +128,24 @@ def test_lba_concurrent_windows_from_threads(pkg, gpu):
         assert a is not None and a["status"] == 0 and a["iters"] == b["iters"]
         assert (a["pose_Tcw"] == b["pose_Tcw"]).all() and (a["point_xyz"] == b["point_xyz"]).all()
         assert (a["edge_outlier"] == b["edge_outlier"]).all()
+
+
+def test_lba_schur_by_items_equals_lds_accumulation(pkg, oracle, gpu, monkeypatch):
+    """The default Schur complement (one thread per (landmark, pose pair) item + one workgroup per block) and the former
+    per-wave LDS accumulation (AOS2_SCHUR=partial) differ only in the summation order of f64 terms: same iterations,
+    same outlier set, float32 results within the north_star tolerance of each other and of the oracle.  Includes a
+    problem whose landmarks are partly seen by fixed keyframes only (no item stores their Dinv)."""
+    for cfg in (dict(seed=11, n_local=7, n_fixed=5, n_points=500, stereo_frac=0.4), dict(seed=12, n_local=2, n_fixed=9, n_points=300),
+                dict(seed=0)):
+        prob = pkg.synth.synth_lba_problem(**cfg)
+        monkeypatch.delenv("AOS2_SCHUR", raising=False)
+        a = pkg.LocalBA().LocalBundleAdjustment(prob)
+        monkeypatch.setenv("AOS2_SCHUR", "partial")
+        b = pkg.LocalBA().LocalBundleAdjustment(prob)
+        monkeypatch.delenv("AOS2_SCHUR", raising=False)
+        want = oracle.lba_solve(prob)
+        for got in (a, b):
+            assert got["status"] == 0 and got["iters"] == want["iters"]
+            assert close(got["pose_Tcw"], want["pose_Tcw"]) and close(got["point_xyz"], want["point_xyz"])
+            assert (got["edge_outlier"] == want["edge_outlier"]).all()
+        assert close(a["pose_Tcw"], b["pose_Tcw"]) and close(a["point_xyz"], b["point_xyz"])
