@@ -200,11 +200,31 @@ __device__ inline void robustify(double e, double delta, double rho[2])
     }
 }
 
-// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114)
-__global__ void k_errors(LbaDev P, LbaAct A)
+// Sum of one value per thread of an N-thread workgroup (binary tree in LDS, fixed order) -> out[blockIdx.x].  The
+// host adds the few per-workgroup sums in order after the copy it makes anyway: no separate reduction launch, and no
+// device-scope fence (a "last workgroup adds everything" tail was measured SLOWER, 3.14 -> 3.55 ms: its
+// __threadfence() writes back the whole L2, including the 12 MB of Schur items).
+template <int N>
+__device__ __forceinline__ void workgroup_sum(double v, double *out)
+{
+    __shared__ double sh[N];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = N / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114); 1024-thread workgroups, the chi2 terms of
+// workgroup g are added into part[g]
+__global__ __launch_bounds__(1024) void k_errors(LbaDev P, LbaAct A, double *part)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.ka) return;
+    double c = 0;
+    if (k < A.ka) {
     const int e = A.act[k];
     const double *T = P.pose + 7 * (size_t)P.e_pose[e];
     const double *X = P.point + 3 * (size_t)P.e_point[e];
@@ -228,13 +248,14 @@ __global__ void k_errors(LbaDev P, LbaAct A)
     }
     double *dst = P.err + 3 * (size_t)e;
     dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-    double c = edge_chi2(er, P.e_w[e], stereo ? 3 : 2);
+    c = edge_chi2(er, P.e_w[e], stereo ? 3 : 2);
     if (P.e_robust[e]) {
         double rho[2];
         robustify(c, stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
         c = rho[0];
     }
-    A.tmp[k] = c;
+    }
+    workgroup_sum<1024>(c, part);
 }
 
 // deterministic sum / max of n doubles by one workgroup -> out[0]
@@ -885,11 +906,18 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
 }
 
 // xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j) -> tmp
-__global__ void k_backsub_points(LbaDev P, LbaAct A, double lambda)
+// 128-thread workgroups; the scale terms of workgroup g's points -> part[g], workgroup 0 adds those of the poses
+// (tmp[0 .. 6 np), written by the kernel before; two per thread)
+__global__ __launch_bounds__(128) void k_backsub_points(LbaDev P, LbaAct A, double lambda, double *part)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= A.nl) return;
     const int n6 = 6 * A.np;
+    double sc = 0;
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < n6) sc = A.tmp[threadIdx.x];
+        if ((int)threadIdx.x + 128 < n6) sc += A.tmp[threadIdx.x + 128];
+    }
+    if (l < A.nl) {
     double cl[3] = {A.b[n6 + 3 * l], A.b[n6 + 3 * l + 1], A.b[n6 + 3 * l + 2]};
     for (int a = A.pl_off[l]; a < A.pl_off[l + 1]; ++a) {
         const int ka = A.pl_k[a];
@@ -909,8 +937,10 @@ __global__ void k_backsub_points(LbaDev P, LbaAct A, double lambda)
         const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
         A.x[n6 + 3 * l + r] = xl;
         X[r] += xl;
-        A.tmp[n6 + 3 * l + r] = xl * (lambda * xl + A.b[n6 + 3 * l + r]);
+        sc += xl * (lambda * xl + A.b[n6 + 3 * l + r]);
     }
+    }
+    workgroup_sum<128>(sc, part);
 }
 
 __global__ void k_update_poses(LbaDev P, LbaAct A, double lambda)
@@ -1335,7 +1365,7 @@ struct aos2_lba {
     int device;
     bool dev_ready = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2] = {};
+    hipEvent_t ev[3] = {};   // [0], [1]: device time of a solve; [2]: the LM loop's scalar copy
     DevBuf<uint8_t> arena;
     PinnedBuf<double> h_scal;
     float last_pose_ms = 0;
@@ -1605,7 +1635,9 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     const size_t o_b = H.push(nullptr, dimmax * 8 + 8), o_x = H.push(nullptr, dimmax * 8 + 8);
     const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
     const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
-    const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, 64);
+    // scalars [0..3] (chi2 and scale are unused now), then the per-workgroup sums of k_errors and k_backsub_points
+    const int n_part_e = (E + 1023) / 1024, n_part = n_part_e + (NL + 127) / 128;
+    const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, (4 + (size_t)n_part) * 8 + 64);
     // Schur items (first pass = all edges = the largest): sum over points of m (m + 1) / 2, m = edges to free keyframes
     size_t n_items_max = 0;
     {
@@ -1647,6 +1679,7 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     double *d_bkpose = (double *)(base + o_bkpose), *d_bkpoint = (double *)(base + o_bkpoint);
     double *d_scal = (double *)(base + o_scal);
     double *d_partial = (double *)(base + o_partial);
+    if ((st = s->h_scal.alloc(8 + (size_t)n_part))) return st;
     double *hs = s->h_scal.p;
 
     LbaAct A{};
@@ -1663,8 +1696,10 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     A.it_ka = (int32_t *)(base + o_itka); A.it_kb = (int32_t *)(base + o_itkb); A.it_l = (int32_t *)(base + o_itl);
     A.blk_off = (int32_t *)(base + o_blkoff); A.W = (double *)(base + o_W); A.Wc = (double *)(base + o_Wc);
 
+    bool lin_ready = false;   // the system on the device was linearised at the current estimates
     auto upload_pass = [&](Pass &S) -> int {
         A.ka = S.ka; A.np = S.np; A.nl = S.nl;
+        lin_ready = false;
         A.n_items = 0;
         if (schur_items && S.np > 0) {
             build_schur_items(S);
@@ -1695,13 +1730,26 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         return AOS2_OK;
     };
     auto blocks = [](int n, int t) { return dim3((unsigned)((n + t - 1) / t)); };
-    auto errors_chi2 = [&](double *out_host) -> int {
-        hipLaunchKernelGGL(k_errors, blocks(A.ka, 256), dim3(256), 0, q, D, A);
-        hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, q, A.tmp, A.ka, d_scal + 0);
+    // linearizeOplus + constructQuadraticForm of all active edges (JA, JB, Hpl, Hll, Hpp, b) at the current estimates
+    auto linearize_all = [&]() {
+        hipLaunchKernelGGL(k_linearize, blocks(A.ka, 128), dim3(128), 0, q, D, A);
+        hipLaunchKernelGGL(k_accum_points, blocks(A.nl, 128), dim3(128), 0, q, A);
+        if (A.np) hipLaunchKernelGGL(k_accum_poses, dim3(A.np), dim3(256), 0, q, A);
+    };
+    // `speculate`: the linearisation at the estimates just evaluated is enqueued behind the scalar copy and runs
+    // while the host waits for the copy (an event, not the stream) and takes the LM decision: after an accepted step --
+    // the usual case -- the next iteration finds its system built and the GPU never waits for the host round trip.
+    auto errors_chi2 = [&](double *out_host, bool speculate = false) -> int {
+        const int ne = (A.ka + 1023) / 1024;
+        hipLaunchKernelGGL(k_errors, dim3(ne), dim3(1024), 0, q, D, A, d_scal + 4);
         if (out_host) {
-            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, q));
-            AOS2_HIP_CHECK(hipStreamSynchronize(q));
-            *out_host = hs[0];
+            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, (4 + (size_t)n_part) * sizeof(double), hipMemcpyDeviceToHost, q));
+            AOS2_HIP_CHECK(hipEventRecord(s->ev[2], q));
+            if (speculate) linearize_all();
+            AOS2_HIP_CHECK(hipEventSynchronize(s->ev[2]));
+            double c = 0;
+            for (int g = 0; g < ne; ++g) c += hs[4 + g];
+            *out_host = c;
         }
         return AOS2_OK;
     };
@@ -1722,9 +1770,8 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         double tempChi = currentChi;
         const double iniChi = currentChi;
         const int dim = 6 * A.np + 3 * A.nl, n6 = 6 * A.np;
-        hipLaunchKernelGGL(k_linearize, blocks(A.ka, 128), dim3(128), 0, q, D, A);
-        hipLaunchKernelGGL(k_accum_points, blocks(A.nl, 128), dim3(128), 0, q, A);
-        if (A.np) hipLaunchKernelGGL(k_accum_poses, dim3(A.np), dim3(256), 0, q, A);
+        if (!lin_ready || iteration == 0) linearize_all();
+        lin_ready = false;   // consumed by this iteration's trials
         if (iteration == 0) {
             hipLaunchKernelGGL(k_diag, blocks(dim, 256), dim3(256), 0, q, A);
             hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(1024), 0, q, A.tmp, dim, d_scal + 2);
@@ -1781,14 +1828,15 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
             } else {
                 AOS2_HIP_CHECK(hipMemsetAsync(d_scal + 3, 0, sizeof(double), q));
             }
-            hipLaunchKernelGGL(k_backsub_points, blocks(A.nl, 128), dim3(128), 0, q, D, A, lambda);
-            hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, q, A.tmp, dim, d_scal + 1);
-            rc = errors_chi2(&tempChi);  // also fetches scale and the solver flag
+            const int ns = (A.nl + 127) / 128;
+            hipLaunchKernelGGL(k_backsub_points, dim3(ns), dim3(128), 0, q, D, A, lambda, d_scal + 4 + n_part_e);
+            rc = errors_chi2(&tempChi, true);  // also fetches the scale terms and the solver flag; linearises ahead
             if (rc) return rc;
             const bool ok2 = (n6 == 0) || hs[3] != 0.0;
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = (currentChi - tempChi);
-            double scale = hs[1];
+            double scale = 0;   // sum of x_j (lambda x_j + b_j): the per-workgroup sums of k_backsub_points
+            for (int g = 0; g < ns; ++g) scale += hs[4 + n_part_e + g];
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
@@ -1799,13 +1847,19 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
                 ni = 2;
                 currentChi = tempChi;
                 errors_fresh = true;
+                lin_ready = true;   // the speculative linearisation was made at the accepted estimates
             } else {
-                errors_fresh = false;
                 lambda *= ni;
                 ni *= 2;
-                // pop
+                // pop; the residuals and the system of the restored estimates are rebuilt (the speculative
+                // linearisation belongs to the rejected step): the same inputs give the same bits as before the trial
                 AOS2_HIP_CHECK(hipMemcpyAsync(D.pose, d_bkpose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
                 AOS2_HIP_CHECK(hipMemcpyAsync(D.point, d_bkpoint, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
+                rc = errors_chi2(nullptr);
+                if (rc) return rc;
+                linearize_all();
+                errors_fresh = true;
+                lin_ready = true;
             }
             qmax++;
         } while (rho < 0 && qmax < maxTrials && !stop_requested(p));

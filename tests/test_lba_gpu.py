@@ -149,3 +149,41 @@ def test_lba_schur_by_items_equals_lds_accumulation(pkg, oracle, gpu, monkeypatc
             assert close(got["pose_Tcw"], want["pose_Tcw"]) and close(got["point_xyz"], want["point_xyz"])
             assert (got["edge_outlier"] == want["edge_outlier"]).all()
         assert close(a["pose_Tcw"], b["pose_Tcw"]) and close(a["point_xyz"], b["point_xyz"])
+
+
+def _hard_problem(pkg, seed, rot_sigma, trans_sigma, point_sigma):
+    """a small window whose free keyframes and points start far from the optimum, so that Levenberg-Marquardt rejects
+    steps (lambda grows, estimates are restored) and, for some seeds, gives up after ten failed trials"""
+    def rot(axis, a):
+        axis = axis / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    prob = pkg.synth.synth_lba_problem(seed, n_local=5, n_fixed=3, n_points=250, stereo_frac=0.3)
+    rng = np.random.default_rng(seed)
+    T = prob["pose_Tcw"].copy().reshape(-1, 4, 4)
+    for i in range(len(T)):
+        if not prob["pose_fixed"][i]:
+            R = rot(rng.normal(size=3), rot_sigma * rng.normal())
+            T[i, :3, :3] = (R @ T[i, :3, :3]).astype(np.float32)
+            T[i, :3, 3] += rng.normal(size=3).astype(np.float32) * trans_sigma
+    prob["pose_Tcw"] = T.reshape(prob["pose_Tcw"].shape).astype(np.float32)
+    prob["point_xyz"] = (prob["point_xyz"] + rng.normal(size=prob["point_xyz"].shape) * point_sigma).astype(np.float32)
+    return prob
+
+
+@pytest.mark.parametrize("cfg", [(42, 0.5, 3, 2), (43, 0.5, 3, 2), (43, 1.0, 6, 4), (42, 0.3, 10, 8), (44, 0.5, 3, 2)])
+def test_lba_rejected_trials_and_early_termination(pkg, oracle, gpu, cfg):
+    """LM trials that fail (rho <= 0): estimates restored from the backup the Schur item kernel made, residuals and
+    the speculatively rebuilt system recomputed at the restored estimates, lambda *= nu; ten failures end the
+    optimisation (levenberg.cpp:118-150).  Same iteration counts, lambda and outlier sets as the oracle."""
+    prob = _hard_problem(pkg, *cfg)
+    want = oracle.lba_solve(prob)
+    lt, n1 = want["lambda_trace"], want["iters"][0]
+    got = pkg.LocalBA().LocalBundleAdjustment(prob)
+    assert got["status"] == 0 and got["iters"] == want["iters"]
+    assert (got["edge_outlier"] == want["edge_outlier"]).all()
+    assert abs(got["final_chi2"] - want["chi2_trace"][-1]) <= 1e-6 * want["chi2_trace"][-1] + 1e-9   # (one case ends at chi2 ~ 1e-27)
+    assert close(got["pose_Tcw"], want["pose_Tcw"], 1e-4) and close(got["point_xyz"], want["point_xyz"], 1e-4)
+    if cfg[0] != 44:   # these problems do contain rejected trials (lambda grows inside a pass)
+        grow = [lt[i + 1] > lt[i] for i in range(len(lt) - 1) if i + 1 != n1]
+        assert any(grow)
