@@ -14,7 +14,9 @@
 // products, f64 atomics into the dense reduced system), dense LDL^T of the <= (6 Np)^2 system in
 // one workgroup, back-substitution + manifold update.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -1368,6 +1370,8 @@ struct aos2_lba {
     hipEvent_t ev[3] = {};   // [0], [1]: device time of a solve; [2]: the LM loop's scalar copy
     DevBuf<uint8_t> arena;
     PinnedBuf<double> h_scal;
+    PinnedBuf<uint8_t> h_stage;   // a pass's index arrays on their way to the arena
+    PinnedBuf<uint8_t> h_in;      // converted inputs (the arena's prefix) / results on their way back
     float last_pose_ms = 0;
 };
 
@@ -1376,17 +1380,34 @@ namespace aos2 {
 constexpr int kSchurGroups = 256;  // single-wave workgroups folding landmarks into private LDS copies
 
 struct HostArena {
-    std::vector<uint8_t> host;  // staged inputs (a prefix of the arena)
+    // staged inputs (a prefix of the arena): page-locked memory of the handle (host, host_cap), else an own vector
+    uint8_t *host = nullptr;
+    size_t host_cap = 0, host_size = 0;
+    std::vector<uint8_t> own;
     size_t size = 0;            // total arena size including device-only scratch
+    const uint8_t *data() const { return host ? host : own.data(); }
     size_t push(const void *src, size_t bytes)
     {
         const size_t off = (size + 255) & ~(size_t)255;
         size = off + bytes;
-        if (src && bytes) {  // inputs are pushed before any scratch, so `host` stays a prefix
-            host.resize(size);
-            memcpy(host.data() + off, src, bytes);
+        if (src && bytes) {  // inputs are pushed before any scratch, so the staged part stays a prefix
+            if (!host) {
+                own.resize(size);
+                memcpy(own.data() + off, src, bytes);
+            } else if (size <= host_cap)
+                memcpy(host + off, src, bytes);
+            host_size = size;
         }
         return off;
+    }
+    // input produced in place (conversions): returns where to write it
+    template <class T>
+    T *push_fill(size_t count, size_t &off)
+    {
+        off = (size + 255) & ~(size_t)255;
+        size = off + count * sizeof(T);
+        host_size = size;
+        return size <= host_cap ? reinterpret_cast<T *>(host + off) : nullptr;
     }
 };
 
@@ -1440,6 +1461,7 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
 {
     S = Pass();
     std::vector<uint8_t> pose_act(p->n_poses, 0), point_act(p->n_points, 0);
+    S.act.reserve(p->n_edges);
     for (int e = 0; e < p->n_edges; ++e) {
         if (level1[e]) continue;
         S.act.push_back(e);
@@ -1451,10 +1473,12 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
     std::vector<int32_t> pose_h(p->n_poses, -1), point_h(p->n_points, -1);
     for (int i = 0; i < p->n_poses; ++i)
         if (pose_act[i] && !p->pose_fixed[i]) S.hpose.push_back(i);
-    std::stable_sort(S.hpose.begin(), S.hpose.end(), [&](int a, int b) { return p->pose_id[a] < p->pose_id[b]; });
+    auto by_pose_id = [&](int a, int b) { return p->pose_id[a] < p->pose_id[b]; };
+    if (!std::is_sorted(S.hpose.begin(), S.hpose.end(), by_pose_id)) std::stable_sort(S.hpose.begin(), S.hpose.end(), by_pose_id);
     for (int i = 0; i < p->n_points; ++i)
         if (point_act[i]) S.hpoint.push_back(i);
-    std::stable_sort(S.hpoint.begin(), S.hpoint.end(), [&](int a, int b) { return p->point_id[a] < p->point_id[b]; });
+    auto by_point_id = [&](int a, int b) { return p->point_id[a] < p->point_id[b]; };
+    if (!std::is_sorted(S.hpoint.begin(), S.hpoint.end(), by_point_id)) std::stable_sort(S.hpoint.begin(), S.hpoint.end(), by_point_id);
     S.np = (int)S.hpose.size();
     S.nl = (int)S.hpoint.size();
     for (int i = 0; i < S.np; ++i) pose_h[S.hpose[i]] = i;
@@ -1491,9 +1515,18 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
             S.pl_k[S.pl_off[l] + f3[l]++] = k;
         }
     }
-    for (int l = 0; l < S.nl; ++l)
-        std::stable_sort(S.pl_k.begin() + S.pl_off[l], S.pl_k.begin() + S.pl_off[l + 1],
-                         [&](int a, int b) { return S.k_ph[a] < S.k_ph[b]; });
+    // per landmark: ascending pose index, ties in slot order (a stable insertion sort: the runs are a handful of
+    // slots long, and std::stable_sort would allocate a buffer for each of the thousands of runs)
+    for (int l = 0; l < S.nl; ++l) {
+        int32_t *q = S.pl_k.data() + S.pl_off[l];
+        const int m = S.pl_off[l + 1] - S.pl_off[l];
+        for (int i = 1; i < m; ++i) {
+            const int32_t v = q[i], key = S.k_ph[v];
+            int j = i - 1;
+            for (; j >= 0 && S.k_ph[q[j]] > key; --j) q[j + 1] = q[j];
+            q[j + 1] = v;
+        }
+    }
     return true;
 }
 
@@ -1567,6 +1600,8 @@ void aos2_lba_destroy(aos2_lba_t *s)
         (void)hipStreamSynchronize(s->stream);
         s->arena.release();
         s->h_scal.release();
+        s->h_stage.release();
+        s->h_in.release();
         for (auto &e : s->ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(s->stream);
     }
@@ -1596,26 +1631,37 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         if (r->edge_outlier) memset(r->edge_outlier, 0, p->n_edges);
         return AOS2_ERR_STOPPED;
     }
+    const auto t_call = std::chrono::steady_clock::now();
     int st = lba_init(s);
     if (st) return st;
     const int NP = p->n_poses, NL = p->n_points, E = p->n_edges;
     // ---- host-side conversion (Converter.cc) and upload
-    std::vector<double> pose(7 * (size_t)NP), point(3 * (size_t)NL), obs(3 * (size_t)E), w(E);
-    for (int i = 0; i < NP; ++i) pose_from_Tcw(p->pose_Tcw + 16 * (size_t)i, &pose[7 * (size_t)i]);
-    for (size_t i = 0; i < 3 * (size_t)NL; ++i) point[i] = (double)p->point_xyz[i];
-    for (size_t i = 0; i < 3 * (size_t)E; ++i) obs[i] = (double)p->edge_obs[i];
-    for (int e = 0; e < E; ++e) w[e] = (double)p->edge_inv_sigma2[e];
+    // (converted straight into the handle's page-locked input staging buffer: one asynchronous upload, no bounce)
+    std::vector<double> pose(7 * (size_t)NP), point(3 * (size_t)NL);
     std::vector<uint8_t> level1(E, 0), robust(E, 1);
-
     HostArena H;
-    const size_t o_pose = H.push(pose.data(), pose.size() * 8), o_point = H.push(point.data(), point.size() * 8);
+    // (the estimates' backup copies lie between the inputs, so the staged prefix spans them as well)
+    const size_t in_cap = 2 * (56 * (size_t)NP + 24 * (size_t)NL) + (size_t)E * (4 + 4 + 24 + 8 + 3) + 16 * 256;
+    if (int st0 = s->h_in.alloc(in_cap)) return st0;
+    H.host = s->h_in.p;
+    H.host_cap = in_cap;
+    size_t o_pose, o_point, o_obs, o_w;
+    double *h_pose = H.push_fill<double>(7 * (size_t)NP, o_pose), *h_point = H.push_fill<double>(3 * (size_t)NL, o_point);
     const size_t o_bkpose = H.push(nullptr, pose.size() * 8), o_bkpoint = H.push(nullptr, point.size() * 8);
     if (o_bkpoint - o_bkpose != o_point - o_pose) {   // the LM backup copies [poses | points] as one span
         set_error("internal: arena layout");
         return AOS2_ERR_ARG;
     }
     const size_t o_epose = H.push(p->edge_pose, (size_t)E * 4), o_epoint = H.push(p->edge_point, (size_t)E * 4);
-    const size_t o_obs = H.push(obs.data(), obs.size() * 8), o_w = H.push(w.data(), w.size() * 8);
+    double *h_obs = H.push_fill<double>(3 * (size_t)E, o_obs), *h_w = H.push_fill<double>((size_t)E, o_w);
+    if (!h_pose || !h_point || !h_obs || !h_w) {
+        set_error("internal: LocalBA input staging");
+        return AOS2_ERR_ARG;
+    }
+    for (int i = 0; i < NP; ++i) pose_from_Tcw(p->pose_Tcw + 16 * (size_t)i, h_pose + 7 * (size_t)i);
+    for (size_t i = 0; i < 3 * (size_t)NL; ++i) h_point[i] = (double)p->point_xyz[i];
+    for (size_t i = 0; i < 3 * (size_t)E; ++i) h_obs[i] = (double)p->edge_obs[i];
+    for (int e = 0; e < E; ++e) h_w[e] = (double)p->edge_inv_sigma2[e];
     const size_t o_st = H.push(p->edge_stereo, E), o_rb = H.push(robust.data(), E), o_l1 = H.push(level1.data(), E);
     const size_t o_err = H.push(nullptr, (size_t)E * 3 * 8);
     const size_t o_chi = H.push(nullptr, (size_t)E * 8), o_out = H.push(nullptr, E);
@@ -1661,7 +1707,11 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     if ((st = s->arena.alloc(H.size + 256))) return st;
     uint8_t *base = s->arena.p;
     hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), std::min(H.host.size(), o_err), hipMemcpyHostToDevice, q));  // inputs only
+    if (H.host_size > in_cap) {
+        set_error("internal: LocalBA input staging");
+        return AOS2_ERR_ARG;
+    }
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host, std::min(H.host_size, o_err), hipMemcpyHostToDevice, q));  // inputs only
     AOS2_HIP_CHECK(hipMemsetAsync(base + o_err, 0, (size_t)E * 3 * 8, q));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
 
@@ -1680,6 +1730,8 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
     double *d_scal = (double *)(base + o_scal);
     double *d_partial = (double *)(base + o_partial);
     if ((st = s->h_scal.alloc(8 + (size_t)n_part))) return st;
+    const size_t span1 = o_plk + (size_t)E * 4 - o_act, span2 = o_blkoff + (nblk_max + 1) * 4 - o_itka;
+    if ((st = s->h_stage.alloc(span1 + span2 + 64))) return st;
     double *hs = s->h_scal.p;
 
     LbaAct A{};
@@ -1701,6 +1753,15 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         A.ka = S.ka; A.np = S.np; A.nl = S.nl;
         lin_ready = false;
         A.n_items = 0;
+        // The pass's index arrays are neighbours in the arena ([o_act, end of pl_k) and [o_itka, end of blk_off)): they
+        // are laid out the same way in a page-locked staging buffer of the handle and go up as two asynchronous
+        // copies (instead of fourteen staged ones and a wait).  The staging buffer is rewritten by the next pass only,
+        // long after the LM loop has waited for results that follow these copies in the stream.
+        uint8_t *stg = s->h_stage.p;
+        auto put = [&](size_t off, size_t origin, const std::vector<int32_t> &v, size_t count) {
+            if (count) memcpy(stg + (off - origin), v.data(), count * 4);
+        };
+        uint8_t *stg2 = stg + span1;
         if (schur_items && S.np > 0) {
             build_schur_items(S);
             A.n_items = (int)S.it_ka.size();
@@ -1708,25 +1769,26 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
                 set_error("internal: Schur item count grew");
                 return AOS2_ERR_ARG;
             }
-            if (A.n_items) {
-                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_ka, S.it_ka.data(), S.it_ka.size() * 4, hipMemcpyHostToDevice, q));
-                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_kb, S.it_kb.data(), S.it_kb.size() * 4, hipMemcpyHostToDevice, q));
-                AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.it_l, S.it_l.data(), S.it_l.size() * 4, hipMemcpyHostToDevice, q));
-            }
-            AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.blk_off, S.blk_off.data(), S.blk_off.size() * 4, hipMemcpyHostToDevice, q));
+            stg = stg2;
+            put(o_itka, o_itka, S.it_ka, S.it_ka.size());
+            put(o_itkb, o_itka, S.it_kb, S.it_kb.size());
+            put(o_itl, o_itka, S.it_l, S.it_l.size());
+            put(o_blkoff, o_itka, S.blk_off, S.blk_off.size());
+            stg = s->h_stage.p;
+            AOS2_HIP_CHECK(hipMemcpyAsync(base + o_itka, stg2, o_blkoff + S.blk_off.size() * 4 - o_itka, hipMemcpyHostToDevice, q));
         }
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.act, S.act.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_ph, S.k_ph.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.k_lh, S.k_lh.data(), (size_t)S.ka * 4, hipMemcpyHostToDevice, q));
-        if (S.np) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.hpose, S.hpose.data(), (size_t)S.np * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.hpoint, S.hpoint.data(), (size_t)S.nl * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pt_off, S.pt_off.data(), (size_t)(S.nl + 1) * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pt_k, S.pt_k.data(), S.pt_k.size() * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.ps_off, S.ps_off.data(), (size_t)(S.np + 1) * 4, hipMemcpyHostToDevice, q));
-        if (!S.ps_k.empty()) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.ps_k, S.ps_k.data(), S.ps_k.size() * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pl_off, S.pl_off.data(), (size_t)(S.nl + 1) * 4, hipMemcpyHostToDevice, q));
-        if (!S.pl_k.empty()) AOS2_HIP_CHECK(hipMemcpyAsync((void *)A.pl_k, S.pl_k.data(), S.pl_k.size() * 4, hipMemcpyHostToDevice, q));
-        AOS2_HIP_CHECK(hipStreamSynchronize(q));  // the host vectors may go out of scope
+        put(o_act, o_act, S.act, (size_t)S.ka);
+        put(o_kph, o_act, S.k_ph, (size_t)S.ka);
+        put(o_klh, o_act, S.k_lh, (size_t)S.ka);
+        put(o_hpose, o_act, S.hpose, (size_t)S.np);
+        put(o_hpoint, o_act, S.hpoint, (size_t)S.nl);
+        put(o_ptoff, o_act, S.pt_off, (size_t)S.nl + 1);
+        put(o_ptk, o_act, S.pt_k, S.pt_k.size());
+        put(o_psoff, o_act, S.ps_off, (size_t)S.np + 1);
+        put(o_psk, o_act, S.ps_k, S.ps_k.size());
+        put(o_ploff, o_act, S.pl_off, (size_t)S.nl + 1);
+        put(o_plk, o_act, S.pl_k, S.pl_k.size());
+        AOS2_HIP_CHECK(hipMemcpyAsync(base + o_act, stg, span1, hipMemcpyHostToDevice, q));
         return AOS2_OK;
     };
     auto blocks = [](int n, int t) { return dim3((unsigned)((n + t - 1) / t)); };
@@ -1888,36 +1950,64 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
         return AOS2_OK;
     };
 
+    // AOS2_LBA_PROF=1: host-side phase times of this call on stderr (tools/gpu_lba_profile.py)
+    const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = t_call;
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const auto t = tnow();
+        fprintf(stderr, "[lba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+        t_prev = t;
+    };
+    lap("convert + arena + upload");
     Pass S;
     if (build_pass(p, level1, S)) {
+        lap("build_pass 1");
         if ((st = upload_pass(S))) return st;
+        lap("items + upload_pass 1");
         if ((st = optimize(p->iters_first, r->iters_done_first))) return st;
+        lap("optimize 1");
     }
     if (!stop_requested(p)) {  // bDoMore, Optimizer.cc:663-710
         hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 1, (double *)nullptr, (uint8_t *)nullptr);
         AOS2_HIP_CHECK(hipMemcpyAsync(level1.data(), D.e_level1, E, hipMemcpyDeviceToHost, q));
         AOS2_HIP_CHECK(hipStreamSynchronize(q));
+        lap("edge check");
         if (build_pass(p, level1, S)) {
+            lap("build_pass 2");
             if ((st = upload_pass(S))) return st;
+            lap("items + upload_pass 2");
             if ((st = optimize(p->iters_second, r->iters_done_second))) return st;
+            lap("optimize 2");
         }
     }
     // final inlier check + write-back (Optimizer.cc:712-778)
     hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 0, (double *)(base + o_chi), base + o_out);
     AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
-    AOS2_HIP_CHECK(hipMemcpyAsync(pose.data(), D.pose, pose.size() * 8, hipMemcpyDeviceToHost, q));
-    AOS2_HIP_CHECK(hipMemcpyAsync(point.data(), D.point, point.size() * 8, hipMemcpyDeviceToHost, q));
-    std::vector<uint8_t> outl(E);
-    AOS2_HIP_CHECK(hipMemcpyAsync(outl.data(), base + o_out, E, hipMemcpyDeviceToHost, q));
-    if (r->edge_chi2) AOS2_HIP_CHECK(hipMemcpyAsync(r->edge_chi2, base + o_chi, (size_t)E * 8, hipMemcpyDeviceToHost, q));
-    AOS2_HIP_CHECK(hipStreamSynchronize(q));
-    AOS2_HIP_CHECK(hipGetLastError());
-    for (int i = 0; i < NP; ++i) pose_to_Tcw(&pose[7 * (size_t)i], r->pose_Tcw + 16 * (size_t)i);
-    for (size_t i = 0; i < 3 * (size_t)NL; ++i) r->point_xyz[i] = (float)point[i];
-    if (r->edge_outlier) memcpy(r->edge_outlier, outl.data(), E);
+    // results come back through the page-locked staging buffer as two spans: [poses | points] and [chi2 | outlier]
+    {
+        const size_t spanA = (o_point - o_pose) + point.size() * 8, spanB = (o_out - o_chi) + (size_t)E;
+        uint8_t *hb = s->h_in.p;
+        const size_t offB = (spanA + 255) & ~(size_t)255;
+        if (offB + spanB > in_cap) {
+            set_error("internal: LocalBA result staging");
+            return AOS2_ERR_ARG;
+        }
+        AOS2_HIP_CHECK(hipMemcpyAsync(hb, base + o_pose, spanA, hipMemcpyDeviceToHost, q));
+        AOS2_HIP_CHECK(hipMemcpyAsync(hb + offB, base + o_chi, spanB, hipMemcpyDeviceToHost, q));
+        AOS2_HIP_CHECK(hipStreamSynchronize(q));
+        AOS2_HIP_CHECK(hipGetLastError());
+        const double *rp = reinterpret_cast<const double *>(hb), *rx = reinterpret_cast<const double *>(hb + (o_point - o_pose));
+        for (int i = 0; i < NP; ++i) pose_to_Tcw(rp + 7 * (size_t)i, r->pose_Tcw + 16 * (size_t)i);
+        for (size_t i = 0; i < 3 * (size_t)NL; ++i) r->point_xyz[i] = (float)rx[i];
+        if (r->edge_chi2) memcpy(r->edge_chi2, hb + offB, (size_t)E * 8);
+        if (r->edge_outlier) memcpy(r->edge_outlier, hb + offB + (o_out - o_chi), E);
+    }
     r->final_chi2 = last_chi;
     r->final_lambda = lambda;
     (void)hipEventElapsedTime(&r->ms_device, s->ev[0], s->ev[1]);
+    lap("final check + write-back");
     return AOS2_OK;
 }
 
@@ -1977,7 +2067,7 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
         pose_from_Tcw(p.Tcw, D.pose_in);
     }
     hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host.data(), H.host.size(), hipMemcpyHostToDevice, q));
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.data(), H.host_size, hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipMemcpyAsync(base + o_probs, dev.data(), sizeof(PoseProbDev) * n_problems, hipMemcpyHostToDevice, q));
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     int max_n = 0;
