@@ -1925,7 +1925,9 @@ struct aos2_matcher {
     bool dev_ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {};
-    DevBuf<uint8_t> arena;     // staging arena for problem snapshots
+    DevBuf<uint8_t> arena;     // one call's inputs | scratch | results (struct Arena)
+    PinnedBuf<uint8_t> h_in;   // page-locked: the inputs on their way up
+    PinnedBuf<uint8_t> h_out;  // page-locked: the results on their way back
     DevBuf<uint32_t> part;     // hamming partials
     DevBuf<uint64_t> pool;     // candidate entries of the projection searches (8 B each)
     float last_ms = 0;         // device time of the kernels of the last search call
@@ -1950,27 +1952,114 @@ static int matcher_init(aos2_matcher *m)
 }
 
 // bump allocator over one device arena: uploads host arrays, returns device pointers
+// One call's memory: three regions of the handle's device arena.
+//   inputs  (push / push_hole): assembled in the handle's page-locked host buffer and uploaded with ONE asynchronous
+//           copy; the buffer persists between calls, so after the first calls nothing is allocated;
+//   scratch (reserve): device only, zeroed by a device memset (never travels);
+//   results (reserve_out): device only, zeroed; fetch() + finish() bring ALL results back with one copy into a
+//           page-locked bounce buffer and scatter them to the caller's arrays.
+// (Earlier the whole arena, scratch included, was staged in a pageable vector and uploaded, and every result array
+// was a pageable copy of its own: 6.9 ms of host time around 0.06 ms of kernels for 64 SearchByBoW pairs.)
+// Offsets carry their region in the top bits; dev<T>() resolves them once every region's size is known, so all
+// push / reserve calls of a function come before its first dev<T>() / upload().
 struct Arena {
     aos2_matcher *m;
-    std::vector<uint8_t> host;
-    size_t used = 0;
+    static constexpr size_t kScr = (size_t)1 << 62, kOut = (size_t)1 << 61, kMask = kOut - 1;
+    size_t in_size = 0, scr_size = 0, out_size = 0;
+    mutable bool frozen = false;
+    int err = AOS2_OK;
+    struct Fetch { void *dst; size_t off, bytes; };
+    std::vector<Fetch> fetches;
+    static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+    void late(const char *what) const
+    {
+        if (!frozen) return;
+        fprintf(stderr, "aos2 matcher arena: %s after the layout was fixed\n", what);
+        abort();
+    }
     size_t push(const void *src, size_t bytes)
     {
-        const size_t off = (host.size() + 255) & ~(size_t)255;
-        host.resize(off + bytes);
-        if (src && bytes) memcpy(host.data() + off, src, bytes);
+        late("push");
+        const size_t off = up(in_size);
+        if (off + bytes > m->h_in.n) {   // grow the page-locked buffer (kept by the handle), contents preserved
+            PinnedBuf<uint8_t> nb;
+            const int st = nb.alloc(std::max((off + bytes) * 2, (size_t)1 << 20));
+            if (st) {
+                err = st;
+                return 0;
+            }
+            if (in_size) memcpy(nb.p, m->h_in.p, in_size);
+            m->h_in.release();
+            m->h_in = nb;
+            nb.p = nullptr;
+            nb.n = 0;
+        }
+        if (off > in_size) memset(m->h_in.p + in_size, 0, off - in_size);
+        if (bytes) {
+            if (src) memcpy(m->h_in.p + off, src, bytes);
+            else memset(m->h_in.p + off, 0, bytes);
+        }
+        in_size = off + bytes;
         return off;
     }
-    size_t reserve(size_t bytes) { return push(nullptr, bytes); }
+    size_t push_hole(size_t bytes) { return push(nullptr, bytes); }   // input the host fills through hostptr()
+    uint8_t *hostptr(size_t off) const { return m->h_in.p + off; }
+    size_t reserve(size_t bytes)
+    {
+        late("reserve");
+        const size_t off = up(scr_size);
+        scr_size = off + bytes;
+        return kScr | off;
+    }
+    size_t reserve_out(size_t bytes)
+    {
+        late("reserve_out");
+        const size_t off = up(out_size);
+        out_size = off + bytes;
+        return kOut | off;
+    }
+    size_t scr_base() const { return up(in_size); }
+    size_t out_base() const { return scr_base() + up(scr_size); }
+    size_t total() const { return out_base() + up(out_size); }
+    int alloc()
+    {
+        frozen = true;
+        if (err) return err;
+        return m->arena.alloc(total() + 256);
+    }
     int upload()
     {
-        int st = m->arena.alloc(host.size() + 256);
+        int st = alloc();
         if (st) return st;
-        AOS2_HIP_CHECK(hipMemcpyAsync(m->arena.p, host.data(), host.size(), hipMemcpyHostToDevice, m->stream));
+        if (in_size) AOS2_HIP_CHECK(hipMemcpyAsync(m->arena.p, m->h_in.p, in_size, hipMemcpyHostToDevice, m->stream));
+        if (total() > scr_base()) AOS2_HIP_CHECK(hipMemsetAsync(m->arena.p + scr_base(), 0, total() - scr_base(), m->stream));
         return AOS2_OK;
     }
     template <typename T>
-    T *dev(size_t off) const { return reinterpret_cast<T *>(m->arena.p + off); }
+    T *dev(size_t off) const
+    {
+        frozen = true;
+        const size_t base = (off & kScr) ? scr_base() : (off & kOut) ? out_base() : 0;
+        return reinterpret_cast<T *>(m->arena.p + base + (off & kMask));
+    }
+    // result `off` (from reserve_out) -> dst, delivered by finish()
+    void fetch(void *dst, size_t off, size_t bytes)
+    {
+        if (bytes) fetches.push_back(Fetch{dst, off & kMask, bytes});
+    }
+    // one device-to-host copy of the result region, a wait for the stream, then the scatter to the caller's arrays
+    int finish()
+    {
+        size_t span = 0;
+        for (const Fetch &f : fetches) span = std::max(span, f.off + f.bytes);
+        int st = m->h_out.alloc(span + 64);
+        if (st) return st;
+        if (span) AOS2_HIP_CHECK(hipMemcpyAsync(m->h_out.p, m->arena.p + out_base(), span, hipMemcpyDeviceToHost, m->stream));
+        AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
+        AOS2_HIP_CHECK(hipGetLastError());
+        for (const Fetch &f : fetches) memcpy(f.dst, m->h_out.p + f.off, f.bytes);
+        return AOS2_OK;
+    }
 };
 
 static void fill_frame(Arena &A, const aos2_frame_view_t *f, size_t off[12])
@@ -2044,6 +2133,8 @@ void aos2_matcher_destroy(aos2_matcher_t *m)
         (void)hipSetDevice(m->device);
         (void)hipStreamSynchronize(m->stream);
         m->arena.release();
+        m->h_in.release();
+        m->h_out.release();
         m->part.release();
         m->pool.release();
         for (auto &e : m->ev) (void)hipEventDestroy(e);
@@ -2187,13 +2278,13 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         o.o[4] = A.push(P.node_idx_f, (size_t)(P.n_nodes_f ? P.node_off_f[P.n_nodes_f] : 0) * 4);
         o.o[5] = A.push(queries.data(), queries.size() * sizeof(BowQuery));
         o.o[6] = A.reserve(ent * sizeof(Entry) + 8);
-        o.o[7] = A.reserve((size_t)P.n_f * 4 + 4);  // match_f
+        o.o[7] = A.reserve_out((size_t)P.n_f * 4 + 4);  // match_f
         o.o[8] = A.reserve((size_t)P.n_f * 4 + 4);  // bin_f
-        o.o[9] = A.reserve(4);                      // nmatches
+        o.o[9] = A.reserve_out(4);                      // nmatches
         o.o[12] = A.reserve(queries.size() * 4 + 4);  // choice (parallel stage B)
         if (kf_kf) {
             o.o[10] = A.push(f_has_mp[p], (size_t)P.n_f);
-            o.o[11] = A.reserve((size_t)P.n_kf * 8 + 8);  // match_1 | bin_1
+            o.o[11] = A.reserve_out((size_t)P.n_kf * 8 + 8);  // match_1 | bin_1
         }
         max_nf = std::max(max_nf, P.n_f);
         max_q = std::max(max_q, o.nq);
@@ -2202,8 +2293,8 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         set_error("n_f %d exceeds the LDS flag table (60000)", max_nf);
         return AOS2_ERR_ARG;
     }
-    const size_t opairs = A.reserve(sizeof(BowPairDev) * n_pairs);
-    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    const size_t opairs = A.push_hole(sizeof(BowPairDev) * n_pairs);
+    if ((st = A.alloc())) return st;
     std::vector<BowPairDev> dev(n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
         const aos2_bow_pair_t &P = pairs[p];
@@ -2223,7 +2314,7 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
             D.bin_1 = D.match_1 + P.n_kf;
         }
     }
-    memcpy(A.host.data() + opairs, dev.data(), sizeof(BowPairDev) * n_pairs);
+    memcpy(A.hostptr(opairs), dev.data(), sizeof(BowPairDev) * n_pairs);
     if ((st = A.upload())) return st;
     AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
     if (max_q > 0)
@@ -2237,13 +2328,12 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     for (int p = 0; p < n_pairs; ++p) {
         if (!kf_kf)
-            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_f, (size_t)pairs[p].n_f * 4, hipMemcpyDeviceToHost, m->stream));
-        else if (pairs[p].n_kf > 0)
-            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[p], dev[p].match_1, (size_t)pairs[p].n_kf * 4, hipMemcpyDeviceToHost, m->stream));
-        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+            A.fetch(match_f[p], offs[p].o[7], (size_t)pairs[p].n_f * 4);
+        else
+            A.fetch(match_f[p], offs[p].o[11], (size_t)pairs[p].n_kf * 4);
+        A.fetch(&nmatches[p], offs[p].o[9], 4);
     }
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2347,8 +2437,8 @@ int aos2_matcher_search_for_triangulation(aos2_matcher_t *m, const aos2_triang_p
         o.o[17] = A.reserve(8);
         max_q = std::max(max_q, o.nq);
     }
-    const size_t opairs = A.reserve(sizeof(TriPairDev) * n_pairs);
-    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    const size_t opairs = A.push_hole(sizeof(TriPairDev) * n_pairs);
+    if ((st = A.alloc())) return st;
     std::vector<TriPairDev> dev(n_pairs);
     for (int p = 0; p < n_pairs; ++p) {
         const aos2_triang_pair_t &P = pairs[p];
@@ -2364,7 +2454,7 @@ int aos2_matcher_search_for_triangulation(aos2_matcher_t *m, const aos2_triang_p
         D.node_idx2 = A.dev<int32_t>(o.o[14]); D.queries = A.dev<TriQuery>(o.o[15]);
         D.match12 = A.dev<int32_t>(o.o[16]); D.nmatches = A.dev<int32_t>(o.o[17]);
     }
-    memcpy(A.host.data() + opairs, dev.data(), sizeof(TriPairDev) * n_pairs);
+    memcpy(A.hostptr(opairs), dev.data(), sizeof(TriPairDev) * n_pairs);
     if ((st = A.upload())) return st;
     AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
     if (max_q > 0)
@@ -2433,7 +2523,7 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     const size_t o0 = A.push(p->track_in_view, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
     const size_t o3 = A.push(p->pred_level, n * 4), o4 = A.push(p->view_cos, n * 4), o5 = A.push(p->proj_x, n * 4);
     const size_t o6 = A.push(p->proj_y, n * 4), o7 = A.push(p->proj_xr, n * 4);
-    const size_t om = A.reserve((size_t)f->n_f * 4 + 4), on = A.reserve(8);
+    const size_t om = A.reserve_out((size_t)f->n_f * 4 + 4), on = A.reserve_out(8);
     const size_t oslots = A.reserve((size_t)(p->n_mp + 1) * sizeof(QuerySlot));
     const size_t ochoice = A.reserve((size_t)(p->n_mp + 1) * 4);
     const size_t pool_cap = (size_t)p->n_mp * (size_t)f->n_f;   // a window holds at most every feature
@@ -2464,10 +2554,9 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
                            A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
                            A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch(match_f, om, (size_t)f->n_f * 4);
+    A.fetch(nmatches, on, 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2510,15 +2599,15 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         o.o[0] = A.push(p->track_in_view, n); o.o[1] = A.push(p->desc, n * 32); o.o[2] = A.push(p->has_obs, n);
         o.o[3] = A.push(p->pred_level, n * 4); o.o[4] = A.push(p->view_cos, n * 4); o.o[5] = A.push(p->proj_x, n * 4);
         o.o[6] = A.push(p->proj_y, n * 4); o.o[7] = A.push(p->proj_xr, n * 4);
-        o.om = A.reserve((size_t)frames[i].n_f * 4 + 4);
-        o.on = A.reserve(8);
+        o.om = A.reserve_out((size_t)frames[i].n_f * 4 + 4);
+        o.on = A.reserve_out(8);
         o.oslots = A.reserve((n + 1) * sizeof(QuerySlot));
         o.ochoice = A.reserve((n + 1) * 4);
     }
-    const size_t oitems = A.reserve(sizeof(ProjMpItem) * (size_t)n_problems);
-    const size_t oused = A.reserve((size_t)n_problems * 256 + 8);   // one counter per problem, 256 B apart
+    const size_t oitems = A.push_hole(sizeof(ProjMpItem) * (size_t)n_problems);
+    const size_t oused = A.reserve_out((size_t)n_problems * 256 + 8);   // one counter per problem, 256 B apart
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
-    if ((st = m->arena.alloc(A.host.size() + 256))) return st;
+    if ((st = A.alloc())) return st;
     std::vector<ProjMpItem> items(n_problems);
     size_t pool_next = 0;
     for (int i = 0; i < n_problems; ++i) {
@@ -2540,7 +2629,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         it.pool_base = (int32_t)pool_next;
         pool_next += (size_t)it.pool_cap;
     }
-    memcpy(A.host.data() + oitems, items.data(), sizeof(ProjMpItem) * (size_t)n_problems);
+    memcpy(A.hostptr(oitems), items.data(), sizeof(ProjMpItem) * (size_t)n_problems);
     if ((st = A.upload())) return st;
     int32_t *d_used = A.dev<int32_t>(oused);
     AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, (size_t)n_problems * 256, m->stream));
@@ -2556,14 +2645,12 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
                            A.dev<ProjMpItem>(oitems), m->nnratio, reinterpret_cast<const Entry *>(m->pool.p));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     std::vector<int32_t> used((size_t)n_problems * 64);
-    AOS2_HIP_CHECK(hipMemcpyAsync(used.data(), d_used, (size_t)n_problems * 256, hipMemcpyDeviceToHost, m->stream));
+    A.fetch(used.data(), oused, (size_t)n_problems * 256);
     for (int i = 0; i < n_problems; ++i) {
-        if (frames[i].n_f > 0)
-            AOS2_HIP_CHECK(hipMemcpyAsync(match_f[i], items[i].match_f, (size_t)frames[i].n_f * 4, hipMemcpyDeviceToHost, m->stream));
-        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[i], items[i].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+        A.fetch(match_f[i], offs[i].om, (size_t)frames[i].n_f * 4);
+        A.fetch(&nmatches[i], offs[i].on, 4);
     }
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     for (int i = 0; i < n_problems; ++i)
         if (used[(size_t)i * 64] > 0) {   // overflow flag = largest window population that did not fit its slice
@@ -2591,7 +2678,7 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     const size_t n = (size_t)p->n_last;
     const size_t o0 = A.push(p->last_valid, n), o1 = A.push(p->desc, n * 32), o2 = A.push(p->has_obs, n);
     const size_t o3 = A.push(p->world_pos, n * 12), o4 = A.push(p->last_angle, n * 4), o5 = A.push(p->last_octave, n * 4);
-    const size_t om = A.reserve((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve(8);
+    const size_t om = A.reserve_out((size_t)cur->n_f * 4 + 4), ob = A.reserve((size_t)cur->n_f * 4 + 4), on = A.reserve_out(8);
     const size_t oslots = A.reserve((size_t)(p->n_last + 1) * sizeof(QuerySlot));
     const size_t ochoice = A.reserve((size_t)(p->n_last + 1) * 4);
     const size_t pool_cap = (size_t)p->n_last * (size_t)cur->n_f;
@@ -2624,10 +2711,9 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
                            A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
                            A.dev<uint32_t>(ob), A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)cur->n_f * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch(match_f, om, (size_t)cur->n_f * 4);
+    A.fetch(nmatches, on, 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
