@@ -1968,7 +1968,7 @@ struct Arena {
     size_t in_size = 0, scr_size = 0, out_size = 0;
     mutable bool frozen = false;
     int err = AOS2_OK;
-    struct Fetch { void *dst; size_t off, bytes; };
+    struct Fetch { void *dst; const uint8_t *src; size_t bytes; };
     std::vector<Fetch> fetches;
     static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
     void late(const char *what) const
@@ -2042,22 +2042,46 @@ struct Arena {
         const size_t base = (off & kScr) ? scr_base() : (off & kOut) ? out_base() : 0;
         return reinterpret_cast<T *>(m->arena.p + base + (off & kMask));
     }
-    // result `off` (from reserve_out) -> dst, delivered by finish()
+    // result at `off` (normally from reserve_out, so that all results are neighbours) -> dst, delivered by finish()
     void fetch(void *dst, size_t off, size_t bytes)
     {
-        if (bytes) fetches.push_back(Fetch{dst, off & kMask, bytes});
+        if (bytes) fetches.push_back(Fetch{dst, dev<uint8_t>(off), bytes});
     }
-    // one device-to-host copy of the result region, a wait for the stream, then the scatter to the caller's arrays
+    void fetch_dev(void *dst, const void *d_src, size_t bytes)
+    {
+        if (bytes) fetches.push_back(Fetch{dst, static_cast<const uint8_t *>(d_src), bytes});
+    }
+    // one device-to-host copy of the span the results occupy (they are neighbours in the arena; if they are not, one
+    // copy each) into the page-locked bounce buffer, a wait for the stream, then the scatter to the caller's arrays
     int finish()
     {
-        size_t span = 0;
-        for (const Fetch &f : fetches) span = std::max(span, f.off + f.bytes);
-        int st = m->h_out.alloc(span + 64);
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        size_t sum = 0;
+        for (const Fetch &f : fetches) {
+            if (!lo || f.src < lo) lo = f.src;
+            if (!hi || f.src + f.bytes > hi) hi = f.src + f.bytes;
+            sum += (f.bytes + 15) & ~(size_t)15;
+        }
+        const size_t span = (size_t)(hi - lo);
+        const bool one = span <= 4 * sum + 65536;
+        int st = m->h_out.alloc((one ? span : sum) + 64);
         if (st) return st;
-        if (span) AOS2_HIP_CHECK(hipMemcpyAsync(m->h_out.p, m->arena.p + out_base(), span, hipMemcpyDeviceToHost, m->stream));
+        if (one) {
+            if (span) AOS2_HIP_CHECK(hipMemcpyAsync(m->h_out.p, lo, span, hipMemcpyDeviceToHost, m->stream));
+        } else {
+            size_t o = 0;
+            for (const Fetch &f : fetches) {
+                AOS2_HIP_CHECK(hipMemcpyAsync(m->h_out.p + o, f.src, f.bytes, hipMemcpyDeviceToHost, m->stream));
+                o += (f.bytes + 15) & ~(size_t)15;
+            }
+        }
         AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
         AOS2_HIP_CHECK(hipGetLastError());
-        for (const Fetch &f : fetches) memcpy(f.dst, m->h_out.p + f.off, f.bytes);
+        size_t o = 0;
+        for (const Fetch &f : fetches) {
+            memcpy(f.dst, one ? m->h_out.p + (f.src - lo) : m->h_out.p + o, f.bytes);
+            o += (f.bytes + 15) & ~(size_t)15;
+        }
         return AOS2_OK;
     }
 };
@@ -2214,9 +2238,10 @@ int aos2_matcher_hamming_best2(aos2_matcher_t *m, const uint8_t *q, int nq, cons
     st = hamming_run(m, A.dev<uint8_t>(oq), nq, A.dev<uint8_t>(ot), nt, A.dev<int32_t>(o1), A.dev<int32_t>(o2),
                      A.dev<int32_t>(o3), 1, nullptr);
     if (st) return st;
-    AOS2_HIP_CHECK(hipMemcpy(best_idx, A.dev<int32_t>(o1), (size_t)nq * 4, hipMemcpyDeviceToHost));
-    AOS2_HIP_CHECK(hipMemcpy(best_dist, A.dev<int32_t>(o2), (size_t)nq * 4, hipMemcpyDeviceToHost));
-    AOS2_HIP_CHECK(hipMemcpy(second_dist, A.dev<int32_t>(o3), (size_t)nq * 4, hipMemcpyDeviceToHost));
+    A.fetch(best_idx, o1, (size_t)nq * 4);
+    A.fetch(best_dist, o2, (size_t)nq * 4);
+    A.fetch(second_dist, o3, (size_t)nq * 4);
+    if ((st = A.finish())) return st;
     return AOS2_OK;
 }
 
@@ -2463,11 +2488,10 @@ int aos2_matcher_search_for_triangulation(aos2_matcher_t *m, const aos2_triang_p
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     for (int p = 0; p < n_pairs; ++p) {
         if (pairs[p].n1 > 0)
-            AOS2_HIP_CHECK(hipMemcpyAsync(match12[p], dev[p].match12, (size_t)pairs[p].n1 * 4, hipMemcpyDeviceToHost, m->stream));
-        AOS2_HIP_CHECK(hipMemcpyAsync(&nmatches[p], dev[p].nmatches, 4, hipMemcpyDeviceToHost, m->stream));
+            A.fetch_dev(match12[p], dev[p].match12, (size_t)pairs[p].n1 * 4);
+        A.fetch_dev(&nmatches[p], dev[p].nmatches, 4);
     }
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2499,9 +2523,8 @@ int aos2_compute_distinctive_descriptors(aos2_matcher_t *m, int n_points, const 
     hipLaunchKernelGGL(distinctive_kernel, dim3(n_points), dim3(64), 0, m->stream, n_points, A.dev<int32_t>(o0),
                        A.dev<uint8_t>(o1), A.dev<int32_t>(o2));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(best_idx, A.dev<int32_t>(o2), (size_t)n_points * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(best_idx, A.dev<int32_t>(o2), (size_t)n_points * 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2790,10 +2813,9 @@ int aos2_matcher_fuse(aos2_matcher_t *m, const aos2_frame_view_t *kf, const aos2
     hipLaunchKernelGGL(projgen_best_kernel, dim3(p->n_pts), dim3(64), 0, m->stream, F, P, TH_LOW, A.dev<int32_t>(ob),
                        A.dev<int32_t>(ob) + p->n_pts);
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(best_idx, A.dev<int32_t>(ob), (size_t)p->n_pts * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(best_dist, A.dev<int32_t>(ob) + p->n_pts, (size_t)p->n_pts * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(best_idx, A.dev<int32_t>(ob), (size_t)p->n_pts * 4);
+    A.fetch_dev(best_dist, A.dev<int32_t>(ob) + p->n_pts, (size_t)p->n_pts * 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     if (n_fused) {
         int c = 0;
@@ -2841,10 +2863,9 @@ int aos2_matcher_search_by_sim3(aos2_matcher_t *m, const aos2_frame_view_t *kf1,
     hipLaunchKernelGGL(sim3_agree_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, m->stream, A.dev<int32_t>(o1),
                        A.dev<int32_t>(o2), (int)n1, (int)n2, A.dev<int32_t>(om), A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n1 * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(n_found, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(match12, A.dev<int32_t>(om), n1 * 4);
+    A.fetch_dev(n_found, A.dev<int32_t>(on), 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2873,10 +2894,9 @@ int aos2_frame_assign_features_to_grid(aos2_matcher_t *m, int n, const float *kp
                        A.dev<float>(ox), A.dev<float>(oy), min_x, min_y, grid_w_inv, grid_h_inv, A.dev<int32_t>(oo),
                        A.dev<int32_t>(oi));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(grid_off, A.dev<int32_t>(oo), (size_t)(NC + 1) * 4, hipMemcpyDeviceToHost, m->stream));
-    if (n > 0) AOS2_HIP_CHECK(hipMemcpyAsync(grid_idx, A.dev<int32_t>(oi), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(grid_off, A.dev<int32_t>(oo), (size_t)(NC + 1) * 4);
+    if (n > 0) A.fetch_dev(grid_idx, A.dev<int32_t>(oi), (size_t)n * 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     if (n_in_grid) *n_in_grid = grid_off[NC];
     return AOS2_OK;
@@ -2906,10 +2926,9 @@ int aos2_frame_stereo_from_rgbd(aos2_matcher_t *m, int n, const float *kp_x, con
     hipLaunchKernelGGL(stereo_from_rgbd_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, n, A.dev<float>(ox),
                        A.dev<float>(oy), A.dev<float>(ou), A.dev<float>(od), stride, mbf, A.dev<float>(oo), A.dev<float>(oo) + n);
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(u_right, A.dev<float>(oo), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(depth, A.dev<float>(oo) + n, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(u_right, A.dev<float>(oo), (size_t)n * 4);
+    A.fetch_dev(depth, A.dev<float>(oo) + n, (size_t)n * 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -2962,14 +2981,13 @@ int aos2_frame_is_in_frustum(aos2_matcher_t *m, const aos2_proj_points_t *p, flo
     hipLaunchKernelGGL(is_in_frustum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, P, min_x, max_x, min_y,
                        max_y, n_levels, viewing_cos_limit, d_iv, d_px, d_py, d_pr, d_lv, d_vc);
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(proj_x, d_px, n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(proj_y, d_py, n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(proj_xr, d_pr, n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(view_cos, d_vc, n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(pred_level, d_lv, n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(track_in_view, d_iv, n, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(proj_x, d_px, n * 4);
+    A.fetch_dev(proj_y, d_py, n * 4);
+    A.fetch_dev(proj_xr, d_pr, n * 4);
+    A.fetch_dev(view_cos, d_vc, n * 4);
+    A.fetch_dev(pred_level, d_lv, n * 4);
+    A.fetch_dev(track_in_view, d_iv, n);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -3018,10 +3036,9 @@ static int projgen_serial(aos2_matcher_t *m, const aos2_frame_view_t *f, const a
                        A.dev<int32_t>(ob), A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
     if (f->n_f > 0)
-        AOS2_HIP_CHECK(hipMemcpyAsync(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+        A.fetch_dev(match_f, A.dev<int32_t>(om), (size_t)f->n_f * 4);
+    A.fetch_dev(nmatches, A.dev<int32_t>(on), 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
@@ -3087,10 +3104,9 @@ int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_v
                        m->check_ori, A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
                        A.dev<int32_t>(om) + n1, A.dev<int32_t>(on));
     AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(match12, A.dev<int32_t>(om), n * 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipMemcpyAsync(nmatches, A.dev<int32_t>(on), 4, hipMemcpyDeviceToHost, m->stream));
-    AOS2_HIP_CHECK(hipStreamSynchronize(m->stream));
-    AOS2_HIP_CHECK(hipGetLastError());
+    A.fetch_dev(match12, A.dev<int32_t>(om), n * 4);
+    A.fetch_dev(nmatches, A.dev<int32_t>(on), 4);
+    if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }
