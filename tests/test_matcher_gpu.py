@@ -394,3 +394,28 @@ def test_search_by_projection_batch_equals_single(pkg, oracle, gpu):
     n1, m1 = m.SearchByProjection(frames[0], mps[0], th=3.0)
     assert n1 == res[0][0] and (m1 == res[0][1]).all()
     assert ms_batch < 12 * m.last_device_ms()       # 12 frames in one call cost less than 12 single calls
+
+
+def test_one_handle_across_growing_and_shrinking_calls(pkg, oracle, gpu):
+    """The handle's page-locked input buffer and device arena persist between calls and grow on demand -- also in the
+    middle of a call (a 40-pair SearchByBoW pushes ~6 MB into a 1 MB buffer).  Small, large, small again, different entry
+    points interleaved: every result equals the oracle's."""
+    S = pkg.synth
+    f, mp = S.synth_proj_mp_problem(7, n_f=1000, n_mp=1500)
+    m = pkg.Matcher(float(mp["nnratio"]), True)
+    small = S.synth_bow_problem(70, 200, 220, n_nodes=20, nnratio=float(mp["nnratio"]), check_orientation=True)
+    big = [S.synth_bow_problem(100 + s, 1000, 1000, nnratio=float(mp["nnratio"]), check_orientation=True) for s in range(40)]
+    for round_ in range(2):
+        n, match = m.SearchByBoW(small)
+        on, om = oracle.search_by_bow(small)
+        assert n == on and (match == om).all()
+        res = m.SearchByBoW(big)
+        for p, (n, match) in list(zip(big, res))[::7]:
+            on, om = oracle.search_by_bow(p)
+            assert n == on and (match == om).all()
+        n, match = m.SearchByProjection(f, mp, th=float(mp["th"]))
+        on, om = oracle.search_by_projection_mp(f, mp)
+        assert n == on and (match == om).all()
+        n, match = m.SearchByBoW(small)
+        on, om = oracle.search_by_bow(small)
+        assert n == on and (match == om).all()
