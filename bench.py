@@ -140,7 +140,7 @@ def main():
     extra = {"synchronous_call_ms_per_step": dt_sync / args.steps * 1e3,
              "synchronous_call_note": "aos2_extractor_extract_batch_device (host waits for every step); `value` enqueues the K steps with "
                                       "aos2_extractor_extract_batch_device_async and waits once"}
-    if rank == 0 and not args.no_extra:
+    if rank == 0 and world == 1 and not args.no_extra:   # (N = 1 only: the other ranks would wait at the final barrier)
         try:
             S = pkg.synth
             rng = np.random.default_rng(0)
@@ -362,7 +362,7 @@ def main():
             pass
         if gather_ms is not None:
             out["gather_ms"] = gather_ms
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only
             O = g.load_oracle()
             oe = O.Extractor(nfeatures=NF)
             n_cpu = args.cpu_frames or 32
