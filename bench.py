@@ -186,7 +186,7 @@ def main():
             extra["pose_optimization_1frame_device_ms"] = ba.pose_last_device_ms()
             extra["local_ba"] = {"edges": prob["n_edges"], "keyframes": prob["n_poses"], "points": prob["n_points"],
                                  "wall_ms": lba_wall, "device_ms": r["ms_device"],
-                                 "bound": "latency (LM control loop, ~25 launches per iteration)"}
+                                 "bound": "latency (LM control loop: 10 dependent launches per iteration, half of the time in the serial pivot chain of the reduced-system LDL^T)"}
             # independent windows (several maps / offline windows, SURVEY 8(e): LocalBA = replicas only): one handle
             # and one host thread per window; the latency-bound kernels of the windows overlap on the GPU
             import threading
