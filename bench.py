@@ -166,6 +166,28 @@ def main():
             m2.SearchByProjection(f, mp, th=3.0)
             extra["search_by_projection_1500mp_wall_ms"] = (time.perf_counter() - tb) * 1e3
             extra["search_by_projection_1500mp_device_ms"] = m2.last_device_ms()
+            # the per-frame tracking chain of the reference (Tracking::TrackWithMotionModel, Tracking.cc:862-870): one frame
+            # at a time through the host-pointer calls -- operator(), SearchByProjection(Cur, Last), PoseOptimization --
+            # wall time of each call as a caller sees it (ctypes wrapper included), median of 20
+            ex1 = pkg.Extractor(nfeatures=NF, device=local_rank)
+            img1 = np.ascontiguousarray(base[0])
+            cur_l, pl_l = S.synth_proj_last_problem(5, n=1000)
+            m3 = pkg.Matcher(0.9, True, device=local_rank)
+            pp1 = S.synth_pose_problem(9, n=800)
+            ba1 = pkg.LocalBA(device=local_rank)
+            chain = {"extract": [], "search_by_projection_last": [], "pose_optimization": []}
+            for it_ in range(23):
+                t0_ = time.perf_counter(); ex1(img1)
+                t1_ = time.perf_counter(); m3.SearchByProjectionLast(cur_l, pl_l, float(pl_l["th"]), int(pl_l["mono"]))
+                t2_ = time.perf_counter(); ba1.PoseOptimization(pp1)
+                t3_ = time.perf_counter()
+                if it_ >= 3:
+                    chain["extract"].append(t1_ - t0_); chain["search_by_projection_last"].append(t2_ - t1_)
+                    chain["pose_optimization"].append(t3_ - t2_)
+            tf = {k: float(np.median(v)) * 1e3 for k, v in chain.items()}
+            tf["total_ms"] = sum(tf.values())
+            tf["note"] = "single 640x480 frame, 1000 features, 1000 last-frame points, 800 pose correspondences; host buffers in and out"
+            extra["tracking_frame_chain_wall_ms"] = tf
             pb = [S.synth_proj_mp_problem(700 + i) for i in range(64)]
             m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
             m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
