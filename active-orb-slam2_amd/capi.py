@@ -135,6 +135,8 @@ def lib():
             L.aos2_lba_create.argtypes = [ci, C.POINTER(vp)]
             L.aos2_lba_destroy.argtypes = [vp]
             L.aos2_lba_solve.argtypes = [vp, vp, vp]
+            L.aos2_lba_solve_batch.argtypes = [vp, vp, vp, ci]
+            L.aos2_lba_debug_stop_at_poll.argtypes = [vp, ci]
             if hasattr(L, "aos2_pose_optimization"):
                 L.aos2_pose_optimization.argtypes = [vp, vp, vp, ci]
                 L.aos2_pose_optimization_last_device_ms.argtypes = [vp]
@@ -768,7 +770,9 @@ class _LbaProblem(C.Structure):
 class _LbaResult(C.Structure):
     _fields_ = [("pose_Tcw", C.c_void_p), ("point_xyz", C.c_void_p), ("edge_outlier", C.c_void_p),
                 ("edge_chi2", C.c_void_p), ("iters_done_first", C.c_int32), ("iters_done_second", C.c_int32),
-                ("final_chi2", C.c_double), ("final_lambda", C.c_double), ("ms_device", C.c_float)]
+                ("final_chi2", C.c_double), ("final_lambda", C.c_double), ("ms_device", C.c_float),
+                ("status", C.c_int32), ("trials_first", C.c_int32), ("trials_second", C.c_int32),
+                ("polls", C.c_int32), ("stop_poll", C.c_int32)]
 
 
 class _PoseProblem(C.Structure):
@@ -797,9 +801,7 @@ class LocalBA:
 
     __del__ = close
 
-    def LocalBundleAdjustment(self, prob, stop_flag=None, iters=(5, 10)):
-        keep = []
-        s = _LbaProblem()
+    def _fill(self, s, r, prob, stop_flag, iters, keep):
         s.n_poses, s.n_points, s.n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
         for name, dt in (("pose_Tcw", np.float32), ("pose_fixed", np.uint8), ("pose_id", np.int64),
                          ("point_xyz", np.float32), ("point_id", np.int64), ("edge_pose", np.int32),
@@ -813,17 +815,39 @@ class LocalBA:
             keep.append(stop_flag)
             s.stop_flag = stop_flag.ctypes.data
         s.iters_first, s.iters_second = iters
-        r = _LbaResult()
         Tout = np.zeros((s.n_poses, 16), np.float32)
         Pout = np.zeros((s.n_points, 3), np.float32)
         outl = np.zeros(s.n_edges, np.uint8)
         chi2 = np.zeros(s.n_edges, np.float64)
         r.pose_Tcw, r.point_xyz, r.edge_outlier, r.edge_chi2 = Tout.ctypes.data, Pout.ctypes.data, outl.ctypes.data, chi2.ctypes.data
-        st = _check(self.L.aos2_lba_solve(self.h, C.byref(s), C.byref(r)), ok=(AOS2_OK, AOS2_ERR_STOPPED))
-        return dict(status=st, pose_Tcw=Tout, point_xyz=Pout, edge_outlier=outl, edge_chi2=chi2,
-                    iters=(r.iters_done_first, r.iters_done_second), final_chi2=r.final_chi2,
-                    final_lambda=r.final_lambda, ms_device=r.ms_device)
+        return Tout, Pout, outl, chi2
 
+    @staticmethod
+    def _result(r, arrs):
+        Tout, Pout, outl, chi2 = arrs
+        return dict(status=r.status, pose_Tcw=Tout, point_xyz=Pout, edge_outlier=outl, edge_chi2=chi2,
+                    iters=(r.iters_done_first, r.iters_done_second), trials=(r.trials_first, r.trials_second),
+                    final_chi2=r.final_chi2, final_lambda=r.final_lambda, ms_device=r.ms_device,
+                    polls=r.polls, stop_poll=r.stop_poll)
+
+    def LocalBundleAdjustment(self, prob, stop_flag=None, iters=(5, 10)):
+        keep = []
+        s, r = _LbaProblem(), _LbaResult()
+        arrs = self._fill(s, r, prob, stop_flag, iters, keep)
+        _check(self.L.aos2_lba_solve(self.h, C.byref(s), C.byref(r)), ok=(AOS2_OK, AOS2_ERR_STOPPED))
+        return self._result(r, arrs)
+
+    def LocalBundleAdjustmentBatch(self, probs, stop_flags=None, iters=(5, 10)):
+        """aos2_lba_solve_batch: independent windows in one call."""
+        n = len(probs)
+        keep = []
+        S, R = (_LbaProblem * n)(), (_LbaResult * n)()
+        arrs = [self._fill(S[i], R[i], probs[i], None if stop_flags is None else stop_flags[i], iters, keep) for i in range(n)]
+        _check(self.L.aos2_lba_solve_batch(self.h, C.byref(S), C.byref(R), n))
+        return [self._result(R[i], arrs[i]) for i in range(n)]
+
+    def debug_stop_at_poll(self, poll):
+        _check(self.L.aos2_lba_debug_stop_at_poll(self.h, int(poll)))
 
     def PoseOptimization(self, problems):
         """int Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:239-452) for one dict or a list of

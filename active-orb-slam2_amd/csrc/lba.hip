@@ -4,145 +4,33 @@
 // se3quat.h).  All arithmetic is IEEE double like g2o (one float reciprocal in the stereo
 // projection, types_six_dof_expmap.cpp:151).
 //
-// Device layout: SoA doubles for poses (qx qy qz qw tx ty tz), points, edges; the active set of a
-// pass is a list of edge "slots" with three CSR views (by point, by free pose, by point restricted
-// to free poses sorted by pose = the Hpl column of block_solver.hpp:398).  The host runs the
-// Levenberg-Marquardt control flow and reads two scalars per trial step.
+// One call solves a BATCH of independent windows (aos2_lba_solve_batch; aos2_lba_solve is a batch of one).
+// Every kernel takes the array of window descriptors and uses blockIdx.y as the window, so the latency-bound
+// Levenberg-Marquardt chains of all windows advance side by side on different compute units.
 //
-// Kernels: residual+Huber, Jacobian/quadratic-form fill (per-edge, no atomics), deterministic
-// per-vertex gathers for Hll/Hpp/b, per-landmark Schur complement (3x3 inverse, 6x3.3x3.3x6 block
-// products, f64 atomics into the dense reduced system), dense LDL^T of the <= (6 Np)^2 system in
-// one workgroup, back-substitution + manifold update.
-#include <algorithm>
+// The whole procedure of a window -- optimize(5), the outlier pass, optimize(10), the final inlier check -- is
+// enqueued as ONE program; the Levenberg-Marquardt control flow (rho, lambda, accept / restore, the three
+// termination rules, the iteration counters, the polls of pbStopFlag) lives in a small per-window state block on the
+// device (LmState), updated by k_decide after every trial; every other kernel is gated by that state.  The host only
+// looks at the states when the program has run: a window that needed more trials than were enqueued (steps rejected
+// by the gain ratio) gets another short program.  No host round trip per trial.
+//
+// Device layout: SoA doubles for poses (qx qy qz qw tx ty tz), points, edges.  The edge set of a window has three CSR
+// views (by point, by free pose, by point restricted to free poses sorted by pose = the Hpl column of
+// block_solver.hpp:398) built once per call.  The second optimisation (level-0 edges only, Optimizer.cc:672-708)
+// reuses them: an excluded edge is MASKED -- its Jacobians, weights and Hpl block are written as zeros, its residual
+// is left alone like g2o leaves the _error of an inactive edge -- so every sum it took part in receives +0.0, which
+// is the same as leaving it out; vertices that lose all their edges keep a lambda-only diagonal block, decoupled from
+// the rest, and receive a zero update (g2o drops them from the index mapping instead: same result for the others).
 #include <chrono>
-#include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <numeric>
-#include <vector>
+#include <thread>
 
-#include "aos2_common.h"
+#include "lba_math.h"
 
 namespace aos2 {
-
-// ------------------------------------------------------------------------------------------ math
-__host__ __device__ inline void quat_from_rot(const double m[9], double q[4])
-{
-    double t = m[0] + m[4] + m[8];
-    if (t > 0) {
-        t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[7] - m[5]) * t;
-        q[1] = (m[2] - m[6]) * t;
-        q[2] = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-    }
-}
-
-__host__ __device__ inline void rot_from_quat(const double q[4], double R[9])
-{
-    const double x = q[0], y = q[1], z = q[2], w = q[3];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-    const double twx = tx * w, twy = ty * w, twz = tz * w;
-    const double txx = tx * x, txy = ty * x, txz = tz * x;
-    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
-    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
-}
-
-__host__ __device__ inline void quat_normalize_rot(double q[4])
-{
-    if (q[3] < 0)
-        for (int i = 0; i < 4; ++i) q[i] *= -1;
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int i = 0; i < 4; ++i) q[i] /= n;
-}
-
-__host__ __device__ inline void quat_rotate(const double q[4], const double v[3], double out[3])
-{
-    double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
-    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
-    const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
-    for (int i = 0; i < 3; ++i) out[i] = v[i] + q[3] * uv[i] + c[i];
-}
-
-__host__ __device__ inline void se3_map(const double qt[7], const double X[3], double out[3])
-{
-    double r[3];
-    quat_rotate(qt, X, r);
-    for (int i = 0; i < 3; ++i) out[i] = r[i] + qt[4 + i];
-}
-
-// T <- exp(upd) * T  (VertexSE3Expmap::oplusImpl, SE3Quat::exp se3quat.h:223-257, operator* :104-110)
-__device__ inline void se3_oplus(const double upd[6], double T[7])
-{
-    const double *omega = upd, *ups = upd + 3;
-    const double theta = sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
-    const double Om[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
-    double Om2[9], R[9], V[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            Om2[i * 3 + j] = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
-    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (theta < 0.00001) {
-        for (int i = 0; i < 9; ++i) {
-            R[i] = I[i] + Om[i] + Om2[i];
-            V[i] = R[i];
-        }
-    } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
-        const double c = (theta - sin(theta)) / (theta * theta * theta);
-        for (int i = 0; i < 9; ++i) {
-            R[i] = I[i] + a * Om[i] + b * Om2[i];
-            V[i] = I[i] + b * Om[i] + c * Om2[i];
-        }
-    }
-    double e[7];
-    quat_from_rot(R, e);
-    quat_normalize_rot(e);
-    for (int i = 0; i < 3; ++i) e[4 + i] = V[i * 3] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
-    // e * T
-    double rt[3], q[4];
-    quat_rotate(e, T + 4, rt);
-    q[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
-    q[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
-    q[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
-    q[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
-    quat_normalize_rot(q);
-    for (int i = 0; i < 4; ++i) T[i] = q[i];
-    for (int i = 0; i < 3; ++i) T[4 + i] = e[4 + i] + rt[i];
-}
-
-__device__ inline void mat3_inverse(const double m[9], double inv[9])
-{
-    const double c00 = m[4] * m[8] - m[5] * m[7];
-    const double c10 = m[5] * m[6] - m[3] * m[8];
-    const double c20 = m[3] * m[7] - m[4] * m[6];
-    const double det = m[0] * c00 + m[1] * c10 + m[2] * c20;
-    const double id = 1.0 / det;
-    inv[0] = c00 * id;
-    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
-    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    inv[3] = c10 * id;
-    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
-    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    inv[6] = c20 * id;
-    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
-    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
 
 struct Cam {
     double fx, fy, cx, cy, bf;
@@ -150,62 +38,79 @@ struct Cam {
     double delta_mono, delta_stereo;  // Huber deltas (float sqrt -> double, Optimizer.cc:570-571)
 };
 
-// device-side problem view
-struct LbaDev {
-    int n_poses, n_points, n_edges;
-    double *pose, *point;            // estimates
+// Levenberg-Marquardt / SparseOptimizer::optimize state of one window (levenberg.cpp:61-164, sparse_optimizer.cpp:354-419)
+struct LmState {
+    double lambda, ni, currentChi, iniChi;
+    double final_chi2, final_lambda;
+    int32_t phase;      // 0: first optimize() running, 1: first finished, 2: second running, 3: finished
+    int32_t run;        // the trial kernels execute
+    int32_t lin;        // the system is (re)linearised at the current estimates (after an accepted step)
+    int32_t initp;      // start of an optimize() call: residuals, system, lambda init pending
+    int32_t xmark;      // transition: the outlier pass runs
+    int32_t it, qmax, nBad;
+    int32_t iters_max[2], iters_done[2], trials[2];
+    int32_t polls;      // evaluations of terminate() so far (the host's entry check is the first)
+    int32_t stop_poll;  // the poll at which the stop flag was first seen set (0 = never)
+    int32_t stop_at_poll;  // test hook: the flag counts as set from this poll on (0 = off)
+    int32_t n_active;   // level-0 edges of the second optimisation
+    int32_t solver_failed;  // trials whose reduced system hit a zero pivot
+    int32_t ntr;            // trials recorded below (AOS2_LBA_TRACE=1 prints them)
+    double tr_rho[48], tr_temp[48], tr_cur[48], tr_lambda[48];
+};
+
+// device-side view of one window
+struct LbaWin {
+    int n_poses, n_points, n_edges, np, nl, n_items;
+    int iters1, iters2;              // optimize(5), optimize(10) (Optimizer.cc:661, 708)
+    // raw float32 inputs as the reference holds them (staged), converted by k_prepare (Converter.cc:37-47, 83-90)
+    const float *in_Tcw, *in_xyz, *in_obs, *in_w;
+    double *pose, *point;            // estimates, contiguous [7 n_poses | 3 n_points]
+    double *bk;                      // SparseOptimizer::push backup of the same span
+    int est_n;
     const int32_t *e_pose, *e_point;
-    const double *e_obs, *e_w;
+    double *e_obs, *e_w;
     const uint8_t *e_stereo;
     uint8_t *e_robust, *e_level1;
-    double *err;                      // n_edges x 3, last computed _error
+    double *err;                     // n_edges x 3, last computed _error
     Cam cam;
-};
-
-// active structure of one optimisation pass
-struct LbaAct {
-    int ka, np, nl;                  // active slots, free poses, active points
-    const int32_t *act;              // slot -> edge
-    const int32_t *k_ph, *k_lh;      // slot -> pose hidx (-1 fixed) / point hidx
+    const int32_t *k_ph, *k_lh;      // edge -> pose hidx (-1 fixed) / point hidx
     const int32_t *hpose, *hpoint;   // hidx -> pose / point index
-    const int32_t *pt_off, *pt_k;    // slots by point (active order)
-    const int32_t *ps_off, *ps_k;    // slots by free pose (active order)
-    const int32_t *pl_off, *pl_k;    // free-pose slots by point, ascending pose hidx
-    double *JA, *JB, *Wr, *wo, *Hpl; // per slot: 9, 18, 3, 1, 18
-    double *Hpp, *Hll, *b, *x, *Hs, *bs, *coeff, *Dinv;
-    // Schur complement by items: item = (landmark, free-pose slots ka <= kb of it), ranked by (pose, pose) block in
-    // upper-triangular order, landmark order inside a block (host-built per pass, build_schur_items)
+    const int32_t *pt_off, *pt_k;    // edges by point (insertion order)
+    const int32_t *ps_off, *ps_k;    // edges by free pose
+    const int32_t *pl_off, *pl_k;    // free-pose edges by point, ascending pose hidx
+    // Schur complement by items: item = (landmark, free-pose edges ka <= kb of it), ranked by (pose, pose) block in
+    // upper-triangular order, landmark order inside a block (build_schur_items)
     const int32_t *it_ka, *it_kb, *it_l, *blk_off;
-    int n_items;
-    double *W, *Wc;                  // W[36][n_items] (B_a Dinv B_b^T, element-major); per active slot: 6 (B_a Dinv b_l)
-    double *tmp;                     // reduction scratch (>= max(ka, 6np+3nl))
-    double *scal;                    // [0] chi2, [1] scale, [2] max diag, [3] solve ok
+    double *JA, *JB, *Wr, *wo, *Hpl; // per edge: 9, 18, 3, 1, 18
+    double *Hpp, *Hll, *b, *x, *Hs, *bs;
+    double *W, *Wc;                  // W[36][n_items] (B_a Dinv B_b^T, element-major); per edge: 6 (B_a Dinv b_l)
+    double *tmp;                     // scale terms of the poses (6 np)
+    double *scal;                    // [2] max diag, [3] solve ok
+    double *part;                    // per-workgroup sums: n_part_e of k_errors, then n_part_s of k_backsub_points
+    int n_part_e, n_part_s;
+    double *ldlt;                    // factorisation scratch of the global-memory variant
+    int npad, ldlt_lds;
+    LmState *st;
+    const int32_t *abort_word;       // mapped host memory: the forwarded pbStopFlag
+    float *out_Tcw, *out_xyz;        // Converter::toCvMat / toCvMat(Vector3d) write-back (Optimizer.cc:763-778)
+    double *out_chi2;
+    uint8_t *out_outlier;
 };
 
-__device__ inline double edge_chi2(const double *er, double w, int D)
+// bool SparseOptimizer::terminate(): counts the evaluation, latches the flag
+__device__ inline bool lm_poll(LmState *st, const int32_t *abort_word)
 {
-    double s = 0;
-    for (int i = 0; i < D; ++i) s += er[i] * (w * er[i]);
-    return s;
-}
-
-__device__ inline void robustify(double e, double delta, double rho[2])
-{
-    const double dsqr = delta * delta;
-    if (e <= dsqr) {
-        rho[0] = e;
-        rho[1] = 1.;
-    } else {
-        const double sqrte = sqrt(e);
-        rho[0] = 2 * sqrte * delta - dsqr;
-        rho[1] = delta / sqrte;
+    st->polls++;
+    if (st->stop_poll > 0) return true;
+    const int a = abort_word ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+    if (a || (st->stop_at_poll > 0 && st->polls >= st->stop_at_poll)) {
+        st->stop_poll = st->polls;
+        return true;
     }
+    return false;
 }
 
-// Sum of one value per thread of an N-thread workgroup (binary tree in LDS, fixed order) -> out[blockIdx.x].  The
-// host adds the few per-workgroup sums in order after the copy it makes anyway: no separate reduction launch, and no
-// device-scope fence (a "last workgroup adds everything" tail was measured SLOWER, 3.14 -> 3.55 ms: its
-// __threadfence() writes back the whole L2, including the 12 MB of Schur items).
+// Sum of one value per thread of an N-thread workgroup (binary tree in LDS, fixed order) -> out[blockIdx.x]
 template <int N>
 __device__ __forceinline__ void workgroup_sum(double v, double *out)
 {
@@ -220,73 +125,117 @@ __device__ __forceinline__ void workgroup_sum(double v, double *out)
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
-// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114); 1024-thread workgroups, the chi2 terms of
-// workgroup g are added into part[g]
-__global__ __launch_bounds__(1024) void k_errors(LbaDev P, LbaAct A, double *part)
+// Converter::toSE3Quat / toVector3d and the float -> double copies of Optimizer.cc:523-525, 552-553, 597-606
+__global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins, int stop_at_poll)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    double c = 0;
-    if (k < A.ka) {
-    const int e = A.act[k];
-    const double *T = P.pose + 7 * (size_t)P.e_pose[e];
-    const double *X = P.point + 3 * (size_t)P.e_point[e];
-    const double *obs = P.e_obs + 3 * (size_t)e;
-    double p[3], er[3];
-    se3_map(T, X, p);
-    const int stereo = P.e_stereo[e];
-    if (!stereo) {
-        const double u = p[0] / p[2], v = p[1] / p[2];
-        er[0] = obs[0] - (u * P.cam.fx + P.cam.cx);
-        er[1] = obs[1] - (v * P.cam.fy + P.cam.cy);
-        er[2] = 0;
-    } else {
-        const float invz = (float)(1.0 / p[2]);
-        const double r0 = p[0] * invz * P.cam.fx + P.cam.cx;
-        const double r1 = p[1] * invz * P.cam.fy + P.cam.cy;
-        const double r2 = r0 - (double)__fmul_rn(P.cam.bf_f, invz);
-        er[0] = obs[0] - r0;
-        er[1] = obs[1] - r1;
-        er[2] = obs[2] - r2;
+    const LbaWin &W = wins[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < W.n_poses) pose_from_Tcw(W.in_Tcw + 16 * (size_t)i, W.pose + 7 * (size_t)i);
+    if (i < W.n_points)
+        for (int d = 0; d < 3; ++d) W.point[3 * (size_t)i + d] = (double)W.in_xyz[3 * (size_t)i + d];
+    if (i < W.n_edges) {
+        for (int d = 0; d < 3; ++d) {
+            W.e_obs[3 * (size_t)i + d] = (double)W.in_obs[3 * (size_t)i + d];
+            W.err[3 * (size_t)i + d] = 0.0;
+        }
+        W.e_w[i] = (double)W.in_w[i];
+        W.e_robust[i] = 1;
+        W.e_level1[i] = 0;
     }
-    double *dst = P.err + 3 * (size_t)e;
-    dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-    c = edge_chi2(er, P.e_w[e], stereo ? 3 : 2);
-    if (P.e_robust[e]) {
-        double rho[2];
-        robustify(c, stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
-        c = rho[0];
+    if (i == 0) {
+        LmState *st = W.st;
+        *st = LmState{};
+        st->iters_max[0] = W.iters1;
+        st->iters_max[1] = W.iters2;
+        st->polls = 1;   // the entry check of Optimizer.cc:656-658 was made on the host
+        st->stop_at_poll = stop_at_poll;
+        st->n_active = W.n_edges;
     }
-    }
-    workgroup_sum<1024>(c, part);
 }
 
-// deterministic sum / max of n doubles by one workgroup -> out[0]
-template <bool kMax>
-__global__ __launch_bounds__(1024) void k_reduce(const double *v, int n, double *out)
+// SparseOptimizer::optimize(iterations) entry, first call (sparse_optimizer.cpp:354-372): `i < iterations &&
+// !terminate() && ok` before the first iteration
+__global__ void k_begin(const LbaWin *__restrict__ wins)
 {
-    __shared__ double sh[1024];
-    double acc = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) acc = kMax ? fmax(acc, fabs(v[i])) : acc + v[i];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = kMax ? fmax(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
-        __syncthreads();
+    const LbaWin &W = wins[blockIdx.x];
+    LmState *st = W.st;
+    st->phase = 0;
+    st->it = 0;
+    if (st->iters_max[0] <= 0 || lm_poll(st, W.abort_word)) {
+        st->phase = 1;
+        st->iters_done[0] = 0;
+    } else
+        st->initp = 1;
+}
+
+// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114); 1024-thread workgroups, the chi2 terms of
+// workgroup g are added into part[g].  init != 0: the call at the top of solve() in iteration 0.
+__global__ __launch_bounds__(1024) void k_errors(const LbaWin *__restrict__ wins, int init)
+{
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(init ? W.st->initp : W.st->run) || (int)blockIdx.x >= W.n_part_e) return;
+    const int e = blockIdx.x * 1024 + threadIdx.x;
+    double c = 0;
+    if (e < W.n_edges && !W.e_level1[e]) {
+        const double *T = W.pose + 7 * (size_t)W.e_pose[e];
+        const double *X = W.point + 3 * (size_t)W.e_point[e];
+        const double *obs = W.e_obs + 3 * (size_t)e;
+        double p[3], er[3];
+        se3_map(T, X, p);
+        const int stereo = W.e_stereo[e];
+        if (!stereo) {
+            const double u = p[0] / p[2], v = p[1] / p[2];
+            er[0] = obs[0] - (u * W.cam.fx + W.cam.cx);
+            er[1] = obs[1] - (v * W.cam.fy + W.cam.cy);
+            er[2] = 0;
+        } else {
+            const float invz = (float)(1.0 / p[2]);
+            const double r0 = p[0] * invz * W.cam.fx + W.cam.cx;
+            const double r1 = p[1] * invz * W.cam.fy + W.cam.cy;
+            const double r2 = r0 - (double)__fmul_rn(W.cam.bf_f, invz);
+            er[0] = obs[0] - r0;
+            er[1] = obs[1] - r1;
+            er[2] = obs[2] - r2;
+        }
+        double *dst = W.err + 3 * (size_t)e;
+        dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+        c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
+        if (W.e_robust[e]) {
+            double rho[2];
+            robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+            c = rho[0];
+        }
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    workgroup_sum<1024>(c, W.part);
 }
 
 // linearizeOplus + the per-edge part of constructQuadraticForm
-__global__ void k_linearize(LbaDev P, LbaAct A)
+__global__ __launch_bounds__(128) void k_linearize(const LbaWin *__restrict__ wins, int init)
 {
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(init ? W.st->initp : W.st->lin)) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.ka) return;
-    const int e = A.act[k];
-    const double *T = P.pose + 7 * (size_t)P.e_pose[e];
-    const double *X = P.point + 3 * (size_t)P.e_point[e];
-    const int stereo = P.e_stereo[e];
+    if (k >= W.n_edges) return;
+    double *ja = W.JA + 9 * (size_t)k, *jb = W.JB + 18 * (size_t)k;
+    if (W.e_level1[k]) {   // masked: contributes +0.0 to every sum
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ja[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) jb[i] = 0;
+        W.Wr[3 * (size_t)k] = 0; W.Wr[3 * (size_t)k + 1] = 0; W.Wr[3 * (size_t)k + 2] = 0;
+        W.wo[k] = 0;
+        if (W.k_ph[k] >= 0) {
+            double *h = W.Hpl + 18 * (size_t)k;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) h[i] = 0;
+        }
+        return;
+    }
+    const double *T = W.pose + 7 * (size_t)W.e_pose[k];
+    const double *X = W.point + 3 * (size_t)W.e_point[k];
+    const int stereo = W.e_stereo[k];
     const int D = stereo ? 3 : 2;
-    const double fx = P.cam.fx, fy = P.cam.fy, bf = P.cam.bf;
+    const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
     double p[3], R[9];
     se3_map(T, X, p);
     rot_from_quat(T, R);
@@ -332,28 +281,27 @@ __global__ void k_linearize(LbaDev P, LbaAct A)
         Jb[16] = 0;
         Jb[17] = Jb[5] - bf / z_2;
     }
-    const double *er = P.err + 3 * (size_t)e;
-    const double w = P.e_w[e];
+    const double *er = W.err + 3 * (size_t)k;
+    const double w = W.e_w[k];
     // static indices only (a runtime-length loop over D would put Ja/Jb/omr in scratch memory)
     double omr[3] = {-(w * er[0]), -(w * er[1]), stereo ? -(w * er[2]) : 0.0};
     double wo = w;
-    if (P.e_robust[e]) {
+    if (W.e_robust[k]) {
         double rho[2];
-        robustify(edge_chi2(er, w, D), stereo ? P.cam.delta_stereo : P.cam.delta_mono, rho);
+        robustify(edge_chi2(er, w, D), stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
         wo = rho[1] * w;
         omr[0] *= rho[1];
         omr[1] *= rho[1];
         if (stereo) omr[2] *= rho[1];
     }
-    double *ja = A.JA + 9 * (size_t)k, *jb = A.JB + 18 * (size_t)k;
 #pragma unroll
     for (int i = 0; i < 9; ++i) ja[i] = Ja[i];
 #pragma unroll
     for (int i = 0; i < 18; ++i) jb[i] = Jb[i];
-    A.Wr[3 * (size_t)k] = omr[0]; A.Wr[3 * (size_t)k + 1] = omr[1]; A.Wr[3 * (size_t)k + 2] = omr[2];
-    A.wo[k] = wo;
-    if (A.k_ph[k] >= 0) {
-        double *h = A.Hpl + 18 * (size_t)k;
+    W.Wr[3 * (size_t)k] = omr[0]; W.Wr[3 * (size_t)k + 1] = omr[1]; W.Wr[3 * (size_t)k + 2] = omr[2];
+    W.wo[k] = wo;
+    if (W.k_ph[k] >= 0) {
+        double *h = W.Hpl + 18 * (size_t)k;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -366,36 +314,41 @@ __global__ void k_linearize(LbaDev P, LbaAct A)
     }
 }
 
-// Hll, b_l: one thread per active point, edges in active (insertion) order like g2o
-__global__ void k_accum_points(LbaAct A)
+// Hll, b_l: one thread per point, edges in insertion order like g2o
+__global__ __launch_bounds__(128) void k_accum_points(const LbaWin *__restrict__ wins, int init)
 {
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(init ? W.st->initp : W.st->lin)) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= A.nl) return;
+    if (l >= W.nl) return;
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int a = A.pt_off[l]; a < A.pt_off[l + 1]; ++a) {
-        const int k = A.pt_k[a];
-        const double *ja = A.JA + 9 * (size_t)k, *wr = A.Wr + 3 * (size_t)k;
-        const double wo = A.wo[k];
+    for (int a = W.pt_off[l]; a < W.pt_off[l + 1]; ++a) {
+        const int k = W.pt_k[a];
+        const double *ja = W.JA + 9 * (size_t)k, *wr = W.Wr + 3 * (size_t)k;
+        const double wo = W.wo[k];
         for (int r = 0; r < 3; ++r) {
             bl[r] += ja[r] * wr[0] + ja[3 + r] * wr[1] + ja[6 + r] * wr[2];
             for (int c = 0; c < 3; ++c) H[r * 3 + c] += ja[r] * wo * ja[c] + ja[3 + r] * wo * ja[3 + c] + ja[6 + r] * wo * ja[6 + c];
         }
     }
-    for (int i = 0; i < 9; ++i) A.Hll[9 * (size_t)l + i] = H[i];
-    for (int i = 0; i < 3; ++i) A.b[6 * (size_t)A.np + 3 * (size_t)l + i] = bl[i];
+    for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
+    for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
 }
 
 // Hpp, b_p: one workgroup per free pose; strided partial sums + fixed-order tree reduction
-__global__ __launch_bounds__(256) void k_accum_poses(LbaAct A)
+__global__ __launch_bounds__(256) void k_accum_poses(const LbaWin *__restrict__ wins, int init)
 {
     __shared__ double sh[256][43];
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(init ? W.st->initp : W.st->lin)) return;
     const int p = blockIdx.x;
+    if (p >= W.np) return;
     double acc[42];
     for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int a = A.ps_off[p] + threadIdx.x; a < A.ps_off[p + 1]; a += 256) {
-        const int k = A.ps_k[a];
-        const double *jb = A.JB + 18 * (size_t)k, *wr = A.Wr + 3 * (size_t)k;
-        const double wo = A.wo[k];
+    for (int a = W.ps_off[p] + threadIdx.x; a < W.ps_off[p + 1]; a += 256) {
+        const int k = W.ps_k[a];
+        const double *jb = W.JB + 18 * (size_t)k, *wr = W.Wr + 3 * (size_t)k;
+        const double wo = W.wo[k];
         for (int r = 0; r < 6; ++r) {
             acc[36 + r] += jb[r] * wr[0] + jb[6 + r] * wr[1] + jb[12 + r] * wr[2];
             for (int c = 0; c < 6; ++c) acc[r * 6 + c] += jb[r] * wo * jb[c] + jb[6 + r] * wo * jb[6 + c] + jb[12 + r] * wo * jb[12 + c];
@@ -408,185 +361,87 @@ __global__ __launch_bounds__(256) void k_accum_poses(LbaAct A)
             for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
         __syncthreads();
     }
-    if (threadIdx.x < 36) A.Hpp[36 * (size_t)p + threadIdx.x] = sh[0][threadIdx.x];
-    if (threadIdx.x < 6) A.b[6 * (size_t)p + threadIdx.x] = sh[0][36 + threadIdx.x];
+    if (threadIdx.x < 36) W.Hpp[36 * (size_t)p + threadIdx.x] = sh[0][threadIdx.x];
+    if (threadIdx.x < 6) W.b[6 * (size_t)p + threadIdx.x] = sh[0][36 + threadIdx.x];
 }
 
-// |H_jj| of every free vertex -> tmp (computeLambdaInit, levenberg.cpp:166-180)
-__global__ void k_diag(LbaAct A)
+// top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
+// (computeLambdaInit :166-180), ni = 2
+__global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ wins)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n6 = 6 * A.np, n = n6 + 3 * A.nl;
-    if (i >= n) return;
-    double v;
-    if (i < n6)
-        v = A.Hpp[36 * (size_t)(i / 6) + (i % 6) * 7];
-    else {
-        const int j = i - n6;
-        v = A.Hll[9 * (size_t)(j / 3) + (j % 3) * 4];
-    }
-    A.tmp[i] = v;
-}
-
-// _Hschur = _Hpp (+ lambda on the diagonal), coefficients = 0
-__global__ void k_schur_init(LbaAct A, double lambda)
-{
-    const int n6 = 6 * A.np;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n6 * n6) return;
-    const int r = i / n6, c = i - r * n6;
-    double v = 0;
-    if (r / 6 == c / 6) {
-        v = A.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + (c % 6)];
-        if (r == c) v += lambda;
-    }
-    A.Hs[i] = v;
-    if (i < n6) A.coeff[i] = 0;
-}
-
-// per landmark: Dinv = (Hll + lambda I)^-1, db, coefficients, Hschur(i1,i2) -= B_i1 Dinv B_i2^T
-// (block_solver.hpp:379-432).  Each single-wave workgroup owns a private copy of the reduced system
-// in LDS and folds a fixed, strided subset of the landmarks into it: the lanes of one instruction
-// touch distinct (i1,i2) blocks (a landmark is seen once per keyframe), so plain LDS
-// read-modify-writes suffice -- no atomics, and the summation order is fixed (bit-reproducible).
-// The partial matrices are then summed in a fixed order by k_schur_reduce.
-__device__ __forceinline__ void schur_point(const LbaAct &A, int l, double lambda, int n6, int lane, double *Msh,
-                                            double *csh, bool to_lds)
-{
-    double D[9], Dinv[9];
-    for (int i = 0; i < 9; ++i) D[i] = A.Hll[9 * (size_t)l + i];
-    D[0] += lambda; D[4] += lambda; D[8] += lambda;
-    mat3_inverse(D, Dinv);
-    const double *bl = A.b + n6 + 3 * (size_t)l;
-    double db[3];
-    for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
-    if (lane == 0)
-        for (int i = 0; i < 9; ++i) A.Dinv[9 * (size_t)l + i] = Dinv[i];
-    const int c0 = A.pl_off[l], m = A.pl_off[l + 1] - c0;
-    for (int a = lane; a < m; a += 64) {
-        const int ka = A.pl_k[c0 + a];
-        const int i1 = A.k_ph[ka];
-        const double *Bi = A.Hpl + 18 * (size_t)ka;
-        for (int r = 0; r < 6; ++r) {
-            const double v = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
-            if (to_lds)
-                csh[6 * i1 + r] += v;
-            else
-                atomicAdd(&A.coeff[6 * i1 + r], v);
+    __shared__ double sh[1024];
+    const LbaWin &W = wins[blockIdx.x];
+    LmState *st = W.st;
+    if (!st->initp) return;
+    const int n6 = 6 * W.np, n = n6 + 3 * W.nl;
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double v;
+        if (i < n6)
+            v = W.Hpp[36 * (size_t)(i / 6) + (i % 6) * 7];
+        else {
+            const int j = i - n6;
+            v = W.Hll[9 * (size_t)(j / 3) + (j % 3) * 4];
         }
+        acc = fmax(acc, fabs(v));
     }
-    const int npairs = m * (m + 1) / 2;
-    for (int t = lane; t < npairs; t += 64) {
-        int a = 0, rem = t;
-        while (rem >= m - a) {  // t -> (a, b) with a <= b, row-major over the upper triangle
-            rem -= m - a;
-            ++a;
-        }
-        const int b = a + rem;
-        const int ka = A.pl_k[c0 + a], kb = A.pl_k[c0 + b];
-        const int i1 = A.k_ph[ka], i2 = A.k_ph[kb];
-        const double *Bi = A.Hpl + 18 * (size_t)ka, *Bj = A.Hpl + 18 * (size_t)kb;
-        double BD[18];
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) {
-                const double v = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
-                if (to_lds)
-                    Msh[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] -= v;
-                else
-                    atomicAdd(&A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c], -v);
-            }
-    }
-}
-
-// LDS variant: grid = G single-wave workgroups, partial[g] = contribution of landmarks g, g+G, ...
-__global__ __launch_bounds__(64) void k_schur_partial(LbaAct A, double lambda, double *partial, int G)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n6 = 6 * A.np, lane = threadIdx.x;
-    const int tot = n6 * n6 + n6;
-    for (int i = lane; i < tot; i += 64) sm[i] = 0.0;
+    sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int l = blockIdx.x; l < A.nl; l += G) {
-        schur_point(A, l, lambda, n6, lane, sm, sm + (size_t)n6 * n6, true);
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    double *out = partial + (size_t)blockIdx.x * tot;
-    for (int i = lane; i < tot; i += 64) out[i] = sm[i];
-}
-
-// Hschur = Hpp (+lambda) + sum_g partial[g] (upper block triangle, mirrored); bschur = b - sum_g coeff[g]
-// 32 elements x 8 partial-sum slices per workgroup, fixed summation order (bit-reproducible)
-__global__ __launch_bounds__(256) void k_schur_reduce(LbaAct A, double lambda, const double *partial, int G)
-{
-    __shared__ double sh[8][33];
-    const int n6 = 6 * A.np, tot = n6 * n6 + n6;
-    const int el = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + el;
-    double acc = 0;
-    if (i < tot) {
-        const int gper = (G + 7) >> 3;
-        const int g0 = part * gper, g1 = min(G, g0 + gper);
-        for (int g = g0; g < g1; ++g) acc += partial[(size_t)g * tot + i];
-    }
-    sh[part][el] = acc;
-    __syncthreads();
-    if (part != 0 || i >= tot) return;
-    double v = sh[0][el];
-#pragma unroll
-    for (int p = 1; p < 8; ++p) v += sh[p][el];
-    if (i < n6 * n6) {
-        const int r = i / n6, c = i - r * n6;
-        if (c / 6 < r / 6) return;  // lower block triangle is the mirror image
-        if (r / 6 == c / 6) {
-            v += A.Hpp[36 * (size_t)(r / 6) + (r % 6) * 6 + (c % 6)];
-            if (r == c) v += lambda;
-        }
-        A.Hs[i] = v;
-        if (c > r) A.Hs[(size_t)c * n6 + r] = v;
-    } else {
-        const int j = i - n6 * n6;
-        A.bs[j] = A.b[j] - v;
+    if (threadIdx.x == 0) {
+        double chi = 0;
+        for (int g = 0; g < W.n_part_e; ++g) chi += W.part[g];
+        st->currentChi = st->iniChi = chi;
+        st->lambda = 1e-5 * sh[0];
+        st->ni = 2;
+        st->nBad = 0;
+        st->it = 0;
+        st->qmax = 0;
+        st->initp = 0;
+        st->lin = 0;
+        st->run = 1;
     }
 }
 
-// ---- Schur complement in two conflict-free phases (the default).  The host ranks the items -- (landmark, free-pose
-// slots ka <= kb of it) -- by their (pose, pose) block, landmark order inside a block (build_schur_items).  Phase A:
+// ---- Schur complement in two conflict-free phases.  The host ranks the items -- (landmark, free-pose edges
+// ka <= kb of it) -- by their (pose, pose) block, landmark order inside a block (build_schur_items).  Phase A:
 // thread s computes item s's 6x6 contribution B_a Dinv B_b^T (block_solver.hpp:379-432) and stores its 36 elements
 // element-major, W[e][s], so a wave's stores are contiguous; the diagonal items also produce the coefficient
 // vector's terms B_a Dinv b_l.  Phase B: one workgroup per block; each wave adds whole rows W[e][o0 .. o0+n) (lanes
-// stride the items, then a fixed butterfly over the lanes): no atomics, bit-reproducible, and no dependent chain of
-// landmarks per wave (k_schur_partial folds 8 landmarks one after the other into a private LDS matrix: 42 + 12 us per
-// LM iteration at 2005 landmarks / 20 free keyframes).
-// The threads behind the last item take the LM trial's backup of the estimates (SparseOptimizer::push, :600-604):
-// bk_n doubles from bk_src to bk_dst, which saves the two device-to-device copies per trial.
-__global__ __launch_bounds__(128) void k_schur_items(LbaAct A, double lambda, const double *bk_src, double *bk_dst, int bk_n)
+// stride the items, then a fixed butterfly over the lanes): no atomics, bit-reproducible.
+// The threads behind the last item take the LM trial's backup of the estimates (SparseOptimizer::push, :600-604).
+__global__ __launch_bounds__(128) void k_schur_items(const LbaWin *__restrict__ wins)
 {
+    const LbaWin &W = wins[blockIdx.y];
+    if (!W.st->run) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= A.n_items) {
-        const int i = t - A.n_items;
-        if (i < bk_n) bk_dst[i] = bk_src[i];
+    if (t >= W.n_items) {
+        const int i = t - W.n_items;
+        if (i < W.est_n) W.bk[i] = W.pose[i];
         return;
     }
-    const int ka = A.it_ka[t], kb = A.it_kb[t], l = A.it_l[t];   // three independent loads, then one level of gathers
+    const double lambda = W.st->lambda;
+    const int ka = W.it_ka[t], kb = W.it_kb[t], l = W.it_l[t];   // three independent loads, then one level of gathers
     double D[9], Dinv[9];
-    for (int i = 0; i < 9; ++i) D[i] = A.Hll[9 * (size_t)l + i];
+    for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     mat3_inverse(D, Dinv);
-    const double *Bi = A.Hpl + 18 * (size_t)ka, *Bj = A.Hpl + 18 * (size_t)kb;
+    const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
     double BD[18];
     for (int r = 0; r < 6; ++r)
         for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
-    double *w = A.W + t;
-    const size_t ni = (size_t)A.n_items;
+    double *w = W.W + t;
+    const size_t ni = (size_t)W.n_items;
     for (int r = 0; r < 6; ++r)
         for (int c = 0; c < 6; ++c) w[(size_t)(r * 6 + c) * ni] = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
     if (ka == kb) {
-        const double *bl = A.b + 6 * A.np + 3 * (size_t)l;
+        const double *bl = W.b + 6 * W.np + 3 * (size_t)l;
         double db[3];
         for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
-        for (int r = 0; r < 6; ++r) A.Wc[6 * (size_t)ka + r] = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+        for (int r = 0; r < 6; ++r) W.Wc[6 * (size_t)ka + r] = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
     }
 }
 
@@ -598,21 +453,25 @@ __device__ __forceinline__ double wave_sum_f64_fixed(double v)
     return v;
 }
 
-// grid = np (np + 1) / 2 block workgroups (upper block triangle, row-major) followed by np coefficient workgroups;
+// grid.x = np (np + 1) / 2 block workgroups (upper block triangle, row-major) followed by np coefficient workgroups;
 // 8 waves per workgroup, wave w takes the elements e = w, w + 8, ...
-__global__ __launch_bounds__(512) void k_schur_blocks(LbaAct A, double lambda)
+__global__ __launch_bounds__(512) void k_schur_blocks(const LbaWin *__restrict__ wins)
 {
-    const int np = A.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
+    const LbaWin &W = wins[blockIdx.y];
+    if (!W.st->run) return;
+    const int np = W.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = blockIdx.x;
-    if (blk >= nblk) {   // bschur = b_p - sum over the pose's slots of B Dinv b_l
+    if (blk >= nblk + np) return;
+    const double lambda = W.st->lambda;
+    if (blk >= nblk) {   // bschur = b_p - sum over the pose's edges of B Dinv b_l
         const int i = blk - nblk;
         if (wave >= 6) return;
-        const int c0 = A.ps_off[i], n = A.ps_off[i + 1] - c0;
+        const int c0 = W.ps_off[i], n = W.ps_off[i + 1] - c0;
         double acc = 0;
-        for (int j = lane; j < n; j += 64) acc += A.Wc[6 * (size_t)A.ps_k[c0 + j] + wave];
+        for (int j = lane; j < n; j += 64) acc += W.Wc[6 * (size_t)W.ps_k[c0 + j] + wave];
         acc = wave_sum_f64_fixed(acc);
-        if (lane == 0) A.bs[6 * i + wave] = A.b[6 * i + wave] - acc;
+        if (lane == 0) W.bs[6 * i + wave] = W.b[6 * i + wave] - acc;
         return;
     }
     // blk -> (i1 <= i2)
@@ -622,11 +481,11 @@ __global__ __launch_bounds__(512) void k_schur_blocks(LbaAct A, double lambda)
         ++i1;
     }
     const int i2 = i1 + rem;
-    const int o0 = A.blk_off[blk], n = A.blk_off[blk + 1] - o0;
-    const size_t ni = (size_t)A.n_items;
+    const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
+    const size_t ni = (size_t)W.n_items;
     // the wave's (up to) five rows are summed together: their loads are independent and stay in flight side by side
     double acc[5] = {0, 0, 0, 0, 0};
-    const double *w = A.W + (size_t)wave * ni + o0;
+    const double *w = W.W + (size_t)wave * ni + o0;
     const bool five = wave + 32 < 36;
 #pragma unroll 2
     for (int j = lane; j < n; j += 64) {
@@ -647,40 +506,24 @@ __global__ __launch_bounds__(512) void k_schur_blocks(LbaAct A, double lambda)
         double v = -acc[q];
         const int r = e / 6, c = e - 6 * r;
         if (i1 == i2) {
-            v += A.Hpp[36 * (size_t)i1 + e];
+            v += W.Hpp[36 * (size_t)i1 + e];
             if (r == c) v += lambda;
         }
-        A.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
-        if (i1 != i2) A.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+        W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
+        if (i1 != i2) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
     }
 }
 
-// fallback for reduced systems too large for LDS (> 22 free keyframes): f64 atomics in global memory
-__global__ __launch_bounds__(64) void k_schur_points(LbaAct A, double lambda)
-{
-    schur_point(A, blockIdx.x, lambda, 6 * A.np, threadIdx.x, nullptr, nullptr, false);
-}
-
-// bschur = b_p - coefficients ; mirror the upper block triangle into the lower one
-__global__ void k_schur_finish(LbaAct A)
-{
-    const int n6 = 6 * A.np;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n6 * n6) return;
-    const int r = i / n6, c = i - r * n6;
-    if (c > r) A.Hs[(size_t)c * n6 + r] = A.Hs[i];
-    if (i < n6) A.bs[i] = A.b[i] - A.coeff[i];
-}
-
 // Dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve of the reduced
-// camera system, one workgroup of 4 waves.  Blocked right-looking factorisation, block 16:
+// camera system, one workgroup per window.  Blocked right-looking factorisation, block 16:
 //   (1) 16x16 diagonal block: unblocked LDL^T by wave 0 (wave-synchronous, no workgroup barrier)
 //   (2) panel: one thread per row below the block, 16-column forward substitution, W = L * D kept
 //   (3) trailing update A[I][J] -= W[I] * L[J]^T on 16x16 tiles with v_mfma_f64_16x16x4_f64
-//       (the only GEMM-shaped piece of the path; tiles round-robin over the 4 waves)
-// then forward / diagonal / backward substitution by wave 0 with the vector in registers.
-// The matrix is padded to a multiple of 16 with an identity tail and lives in LDS when
-// npad^2 * 8 B fits (npad <= 128, i.e. <= 21 free keyframes), otherwise in a global scratch.
+//       (the only GEMM-shaped piece of the path; tiles round-robin over the waves)
+// then forward / diagonal / backward substitution.
+// The matrix is padded to a multiple of 16 with an identity tail.  kLds: it lives in LDS (npad <= 128, i.e. <= 21 free
+// keyframes; 4 waves; substitution by wave 0 with the vector in registers, which then applies the update to the
+// poses).  Otherwise (any size): in a global scratch, 16 waves, the vector in LDS, k_update_poses follows.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // value of `v` in lane `src` (wave-uniform index), uniform result
@@ -692,38 +535,38 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// kLds: the solution stays in LDS and wave 0 applies it to the free poses straight away (VertexSE3Expmap::oplusImpl +
-// the scale terms of k_update_poses), which saves a launch per LM trial; the global-scratch variant is followed by
-// k_update_poses.
 template <bool kLds>
-__global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *gscratch, double *poses, double lambda)
+__global__ __launch_bounds__(kLds ? 256 : 1024) void k_ldlt_solve(const LbaWin *__restrict__ wins)
 {
+    constexpr int NT = kLds ? 256 : 1024, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n = 6 * A.np;
+    const LbaWin &Wn = wins[blockIdx.x];
+    if (!Wn.st->run || Wn.np == 0 || (Wn.ldlt_lds != 0) != kLds) return;
+    const int n = 6 * Wn.np, npad = Wn.npad;
+    const double lambda = Wn.st->lambda;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // odd leading dimensions: column-direction accesses (panel rows, MFMA operands, substitution)
     // then fall on distinct LDS banks instead of one
     const int ld = npad + 1, lw = 17;
     // kLds: the pointers below derive from the LDS array only, so the compiler emits ds_* accesses
     // (a runtime-selected pointer would turn every access into a slow flat_* instruction)
-    double *M = kLds ? sm : gscratch;                    // npad x ld (lower triangle is used)
+    double *M = kLds ? sm : Wn.ldlt;                     // npad x ld (lower triangle is used)
     double *W = M + (size_t)npad * ld;                   // npad x lw
     double *dvec = W + (size_t)npad * lw;                // npad
-    double *ccol = dvec + npad;                          // 16
-    volatile int *failp = reinterpret_cast<volatile int *>(ccol + 16);  // kept in the dynamic region (LDS base alignment)
-    if (tid == 0) *failp = 0;
-    // load (identity-padded): 8 independent global loads in flight per thread before the LDS stores
-    for (int r0 = tid >> 5; r0 < npad; r0 += 64) {
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    // load (identity-padded): 8 independent global loads in flight per thread before the stores
+    for (int r0 = tid >> 5; r0 < npad; r0 += 8 * (NT / 32)) {
         for (int c = tid & 31; c < npad; c += 32) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = r0 + 8 * u;
-                v[u] = (r < n && c < n) ? A.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+                const int r = r0 + (NT / 32) * u;
+                v[u] = (r < n && c < n) ? Wn.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = r0 + 8 * u;
+                const int r = r0 + (NT / 32) * u;
                 if (r < npad) M[(size_t)r * ld + c] = v[u];
             }
         }
@@ -755,7 +598,7 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
                     if (lane == 0) dvec[k0 + j] = dj;
                 }
             }
-            if (bad && lane == 0) *failp = 1;
+            if (bad && lane == 0) s_fail = 1;
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
@@ -763,9 +606,9 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
             }
         }
         __syncthreads();
-        if (*failp) break;
+        if (s_fail) break;
         // ---- (2) panel below the block
-        for (int i = k0 + 16 + tid; i < npad; i += 256) {
+        for (int i = k0 + 16 + tid; i < npad; i += NT) {
             double w[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -782,7 +625,7 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
         // ---- (3) trailing update with f64 MFMA, lower-triangle tiles (I >= J > kb)
         const int m = nb - kb - 1;
         const int ntiles = m * (m + 1) / 2;
-        for (int t = wave; t < ntiles; t += 4) {
+        for (int t = wave; t < ntiles; t += NW) {
             int ii = 0, rem = t;
             while (rem > ii) {  // row-major lower triangle: row ii holds ii+1 tiles
                 rem -= ii + 1;
@@ -804,672 +647,401 @@ __global__ __launch_bounds__(256) void k_ldlt_solve(LbaAct A, int npad, double *
         }
         __syncthreads();
     }
-    if (*failp) {
-        if (tid == 0) A.scal[3] = 0.0;
+    if (s_fail) {
+        if (tid == 0) Wn.scal[3] = 0.0;
         return;
     }
-    // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 256).
-    // Blocked by the 16-column panels: the 16 x 16 triangle of a panel is solved among its 16 lanes with v_readlane
-    // broadcasts (its L entries fetched once), then every other row takes its 16-term update from 16 independent LDS
-    // reads.  Per element the subtractions happen in the same order as the column-by-column loop (k ascending forward,
-    // descending backward), so the result is bit-identical to it; the serial chain shrinks from npad dependent LDS
-    // round trips to npad / 16 (27 -> ~6 us at npad = 128).
-    if (wave == 0) {
-        double xv[4];
+    if (kLds) {
+        // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 128).
+        // Blocked by the 16-column panels: the 16 x 16 triangle of a panel is solved among its 16 lanes with v_readlane
+        // broadcasts (its L entries fetched once), then every other row takes its 16-term update from 16 independent
+        // LDS reads.  Per element the subtractions happen in the same order as the column-by-column loop (k ascending
+        // forward, descending backward), so the result is bit-identical to it.
+        if (wave == 0) {
+            double xv[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int i = lane + 64 * s;
-            xv[s] = i < n ? A.bs[i] : 0.0;
-        }
-        auto get_slot = [&](int slot) { return slot == 0 ? xv[0] : slot == 1 ? xv[1] : slot == 2 ? xv[2] : xv[3]; };
-        auto set_slot = [&](int slot, double v) {
-            if (slot == 0) xv[0] = v; else if (slot == 1) xv[1] = v; else if (slot == 2) xv[2] = v; else xv[3] = v;
-        };
-        for (int kb = 0; kb < nb; ++kb) {  // forward: y_i -= L[i][k] y_k, k ascending
-            const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
-            const bool in_blk = li >= 0 && li < 16;
-            double lrow[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < li) ? M[(size_t)(k0 + li) * ld + k0 + c] : 0.0;
-            double cur = get_slot(slot), yb[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                yb[j] = readlane_f64(cur, lane0 + j);
-                if (in_blk && li > j) cur -= lrow[j] * yb[j];
-            }
-            set_slot(slot, cur);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 2; ++s) {
                 const int i = lane + 64 * s;
-                if (i >= k0 + 16 && i < npad) {
-                    double l[16];
+                xv[s] = i < n ? Wn.bs[i] : 0.0;
+            }
+            for (int kb = 0; kb < nb; ++kb) {  // forward: y_i -= L[i][k] y_k, k ascending
+                const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
+                const bool in_blk = li >= 0 && li < 16;
+                double lrow[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) l[j] = M[(size_t)i * ld + k0 + j];
-                    double acc = xv[s];
+                for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < li) ? M[(size_t)(k0 + li) * ld + k0 + c] : 0.0;
+                double cur = slot == 0 ? xv[0] : xv[1], yb[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) acc -= l[j] * yb[j];
-                    xv[s] = acc;
+                for (int j = 0; j < 16; ++j) {
+                    yb[j] = readlane_f64(cur, lane0 + j);
+                    if (in_blk && li > j) cur -= lrow[j] * yb[j];
+                }
+                if (slot == 0) xv[0] = cur; else xv[1] = cur;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i >= k0 + 16 && i < npad) {
+                        double l[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) l[j] = M[(size_t)i * ld + k0 + j];
+                        double acc = xv[s];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc -= l[j] * yb[j];
+                        xv[s] = acc;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int i = lane + 64 * s;
-            if (i < npad) xv[s] /= dvec[i];
-        }
-        for (int kb = nb - 1; kb >= 0; --kb) {  // backward: x_i -= L[k][i] x_k, k descending
-            const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
-            const bool in_blk = li >= 0 && li < 16;
-            double lcol[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > li) ? M[(size_t)(k0 + j) * ld + k0 + li] : 0.0;
-            double cur = get_slot(slot), xb[16];
-#pragma unroll
-            for (int j = 15; j >= 0; --j) {
-                xb[j] = readlane_f64(cur, lane0 + j);
-                if (in_blk && li < j) cur -= lcol[j] * xb[j];
-            }
-            set_slot(slot, cur);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 2; ++s) {
                 const int i = lane + 64 * s;
-                if (i < k0) {
-                    double l[16];
+                if (i < npad) xv[s] /= dvec[i];
+            }
+            for (int kb = nb - 1; kb >= 0; --kb) {  // backward: x_i -= L[k][i] x_k, k descending
+                const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
+                const bool in_blk = li >= 0 && li < 16;
+                double lcol[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) l[j] = M[(size_t)(k0 + j) * ld + i];
-                    double acc = xv[s];
+                for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > li) ? M[(size_t)(k0 + j) * ld + k0 + li] : 0.0;
+                double cur = slot == 0 ? xv[0] : xv[1], xb[16];
 #pragma unroll
-                    for (int j = 15; j >= 0; --j) acc -= l[j] * xb[j];
-                    xv[s] = acc;
+                for (int j = 15; j >= 0; --j) {
+                    xb[j] = readlane_f64(cur, lane0 + j);
+                    if (in_blk && li < j) cur -= lcol[j] * xb[j];
+                }
+                if (slot == 0) xv[0] = cur; else xv[1] = cur;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i < k0) {
+                        double l[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) l[j] = M[(size_t)(k0 + j) * ld + i];
+                        double acc = xv[s];
+#pragma unroll
+                        for (int j = 15; j >= 0; --j) acc -= l[j] * xb[j];
+                        xv[s] = acc;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int i = lane + 64 * s;
-            if (i < n) A.x[i] = xv[s];
-            if (kLds && i < n) M[i] = xv[s];   // the factor is dead: its first row carries x to the pose update
-        }
-        if (lane == 0) A.scal[3] = 1.0;
-        if (kLds) {
+            for (int s = 0; s < 2; ++s) {
+                const int i = lane + 64 * s;
+                if (i < n) Wn.x[i] = xv[s];
+                if (i < n) M[i] = xv[s];   // the factor is dead: its first row carries x to the pose update
+            }
+            if (lane == 0) Wn.scal[3] = 1.0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < A.np) {
+            if (lane < Wn.np) {   // (np <= 21 here) VertexSE3Expmap::oplusImpl + the poses' scale terms
                 double upd[6];
                 for (int i = 0; i < 6; ++i) {
                     upd[i] = M[6 * lane + i];
-                    A.tmp[6 * lane + i] = upd[i] * (lambda * upd[i] + A.b[6 * lane + i]);
+                    Wn.tmp[6 * lane + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * lane + i]);
                 }
-                se3_oplus(upd, poses + 7 * (size_t)A.hpose[lane]);
+                se3_oplus(upd, Wn.pose + 7 * (size_t)Wn.hpose[lane]);
             }
         }
+    } else {
+        // any size: the vector lives in LDS (sm[npad]); per 16-column panel the triangle is solved by 16 lanes of wave 0,
+        // the remaining rows are updated by all threads (same per-element order of subtractions as above)
+        double *xs = sm;
+        for (int i = tid; i < npad; i += NT) xs[i] = i < n ? Wn.bs[i] : 0.0;
+        __syncthreads();
+        for (int kb = 0; kb < nb; ++kb) {
+            const int k0 = kb << 4;
+            if (wave == 0) {
+                const bool in_blk = lane < 16;
+                double lrow[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < lane) ? M[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
+                double cur = in_blk ? xs[k0 + lane] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double yj = readlane_f64(cur, j);
+                    if (in_blk && lane > j) cur -= lrow[j] * yj;
+                }
+                if (in_blk) xs[k0 + lane] = cur;
+            }
+            __syncthreads();
+            for (int i = k0 + 16 + tid; i < npad; i += NT) {
+                double acc = xs[i];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc -= M[(size_t)i * ld + k0 + j] * xs[k0 + j];
+                xs[i] = acc;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < npad; i += NT) xs[i] /= dvec[i];
+        __syncthreads();
+        for (int kb = nb - 1; kb >= 0; --kb) {
+            const int k0 = kb << 4;
+            if (wave == 0) {
+                const bool in_blk = lane < 16;
+                double lcol[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > lane) ? M[(size_t)(k0 + j) * ld + k0 + lane] : 0.0;
+                double cur = in_blk ? xs[k0 + lane] : 0.0;
+#pragma unroll
+                for (int j = 15; j >= 0; --j) {
+                    const double xj = readlane_f64(cur, j);
+                    if (in_blk && lane < j) cur -= lcol[j] * xj;
+                }
+                if (in_blk) xs[k0 + lane] = cur;
+            }
+            __syncthreads();
+            for (int i = tid; i < k0; i += NT) {
+                double acc = xs[i];
+#pragma unroll
+                for (int j = 15; j >= 0; --j) acc -= M[(size_t)(k0 + j) * ld + i] * xs[k0 + j];
+                xs[i] = acc;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += NT) Wn.x[i] = xs[i];
+        if (tid == 0) Wn.scal[3] = 1.0;
     }
 }
 
-// xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j) -> tmp
-// 128-thread workgroups; the scale terms of workgroup g's points -> part[g], workgroup 0 adds those of the poses
-// (tmp[0 .. 6 np), written by the kernel before; two per thread)
-__global__ __launch_bounds__(128) void k_backsub_points(LbaDev P, LbaAct A, double lambda, double *part)
+// global-memory variant only: VertexSE3Expmap::oplusImpl + the poses' scale terms
+__global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ wins)
 {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n6 = 6 * A.np;
-    double sc = 0;
-    if (blockIdx.x == 0) {
-        if ((int)threadIdx.x < n6) sc = A.tmp[threadIdx.x];
-        if ((int)threadIdx.x + 128 < n6) sc += A.tmp[threadIdx.x + 128];
-    }
-    if (l < A.nl) {
-    double cl[3] = {A.b[n6 + 3 * l], A.b[n6 + 3 * l + 1], A.b[n6 + 3 * l + 2]};
-    for (int a = A.pl_off[l]; a < A.pl_off[l + 1]; ++a) {
-        const int ka = A.pl_k[a];
-        const int i1 = A.k_ph[ka];
-        const double *Bi = A.Hpl + 18 * (size_t)ka;
-        for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-A.x[6 * i1 + r]);
-    }
-    // (Hll + lambda I)^-1 again, the same operations as in the Schur kernels (so the same bits): landmarks seen by
-    // fixed keyframes only have no Schur item that could have stored it
-    double Dm[9], Dinv[9];
-    for (int i = 0; i < 9; ++i) Dm[i] = A.Hll[9 * (size_t)l + i];
-    Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-    mat3_inverse(Dm, Dinv);
-    double *X = P.point + 3 * (size_t)A.hpoint[l];
-    for (int r = 0; r < 3; ++r) {
-        const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
-        A.x[n6 + 3 * l + r] = xl;
-        X[r] += xl;
-        sc += xl * (lambda * xl + A.b[n6 + 3 * l + r]);
-    }
-    }
-    workgroup_sum<128>(sc, part);
-}
-
-__global__ void k_update_poses(LbaDev P, LbaAct A, double lambda)
-{
+    const LbaWin &W = wins[blockIdx.y];
+    if (!W.st->run || W.ldlt_lds || W.scal[3] == 0.0) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.np) return;
+    if (p >= W.np) return;
+    const double lambda = W.st->lambda;
     double upd[6];
     for (int i = 0; i < 6; ++i) {
-        upd[i] = A.x[6 * p + i];
-        A.tmp[6 * p + i] = upd[i] * (lambda * upd[i] + A.b[6 * p + i]);
+        upd[i] = W.x[6 * p + i];
+        W.tmp[6 * p + i] = upd[i] * (lambda * upd[i] + W.b[6 * p + i]);
     }
-    se3_oplus(upd, P.pose + 7 * (size_t)A.hpose[p]);
+    se3_oplus(upd, W.pose + 7 * (size_t)W.hpose[p]);
 }
 
-// outlier pass between the two optimisations (Optimizer.cc:672-703) and the final check (:712-744)
-__global__ void k_edge_check(LbaDev P, int mark_level1, double *chi2_out, uint8_t *outlier_out)
+// xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j): 128-thread workgroups, the
+// terms of workgroup g's points -> part[n_part_e + g]; workgroup 0 adds those of the poses (tmp[0 .. 6 np))
+__global__ __launch_bounds__(128) void k_backsub_points(const LbaWin *__restrict__ wins)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.n_edges) return;
-    const int stereo = P.e_stereo[e];
-    const double c = edge_chi2(P.err + 3 * (size_t)e, P.e_w[e], stereo ? 3 : 2);
-    double p[3];
-    se3_map(P.pose + 7 * (size_t)P.e_pose[e], P.point + 3 * (size_t)P.e_point[e], p);
-    const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
-    if (mark_level1) {
-        if (bad) P.e_level1[e] = 1;
-        P.e_robust[e] = 0;
-    }
-    if (chi2_out) chi2_out[e] = c;
-    if (outlier_out) outlier_out[e] = bad ? 1 : 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Optimizer::PoseOptimization (src/Optimizer.cc:239-452): one workgroup per frame, the complete
-// procedure on the device (no host round trips): residuals + Huber, EdgeSE3ProjectXYZOnlyPose /
-// EdgeStereoSE3ProjectXYZOnlyPose Jacobians (types_six_dof_expmap.cpp:266-364), 6x6 normal
-// equations by a fixed-order workgroup reduction, Cholesky, exp-map update, the Levenberg
-// accept/reject logic (levenberg.cpp:61-164) and the outlier reclassification of :371-430.
-// ---------------------------------------------------------------------------------------------
-struct PoseProbDev {
-    int n;
-    const double *Xw, *obs;       // n x 3
-    const double *w;              // n
-    const uint8_t *stereo;        // n
-    double *err;                  // n x 3 scratch
-    uint8_t *level1, *robust;     // n scratch
-    uint8_t *outlier;             // n out
-    double fx, fy, cx, cy, bf;
-    double pose_in[7];
-    double *pose_out;             // 7
-    int32_t *counts;              // [0] n_bad, [1] n_inliers
-};
-
-__device__ __forceinline__ void po_edge_error(const double *qt, const double *X, const double *obs, int stereo,
-                                              const PoseProbDev &P, double er[3])
-{
-    double p[3];
-    se3_map(qt, X, p);
-    if (!stereo) {
-        const double u = p[0] / p[2], v = p[1] / p[2];
-        er[0] = obs[0] - (u * P.fx + P.cx);
-        er[1] = obs[1] - (v * P.fy + P.cy);
-        er[2] = 0;
-    } else {
-        const float invz = (float)(1.0 / p[2]);
-        const double r0 = p[0] * invz * P.fx + P.cx;
-        const double r1 = p[1] * invz * P.fy + P.cy;
-        const double r2 = r0 - P.bf * invz;
-        er[0] = obs[0] - r0;
-        er[1] = obs[1] - r1;
-        er[2] = obs[2] - r2;
-    }
-}
-
-// fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return.
-// The 256 partials of component k are added in thread order (8 slices of 32, then the 8 slice sums), instead of a
-// log-depth tree with a barrier per level.
-template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) + 9 x K */, double *out)
-{
-    // fixed summation order (bit-reproducible): 8 slices of 32 threads, each summed in thread order, then the 8 slice
-    // sums in slice order.  The 32 operands of a slice are fetched together before the dependent adds, and the 8-term
-    // final sums are formed once (K threads) and broadcast, instead of every thread re-adding 8 x K partials.
-    const int tid = threadIdx.x;
-    for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] = v[i];
-    __syncthreads();
-    double *part = sh + 256 * (K + 1), *fin = part + 8 * K;
-    if (tid < 8 * K) {
-        const int k = tid % K, slice = tid / K;
-        double x[32];
-#pragma unroll
-        for (int t = 0; t < 32; ++t) x[t] = sh[(32 * slice + t) * (K + 1) + k];
-        double acc = 0;
-#pragma unroll
-        for (int t = 0; t < 32; ++t) acc += x[t];
-        part[slice * K + k] = acc;
-    }
-    __syncthreads();
-    if (tid < K) {
-        double acc = part[tid];
-#pragma unroll
-        for (int sl = 1; sl < 8; ++sl) acc += part[sl * K + tid];
-        fin[tid] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < K; ++i) out[i] = fin[i];
-    __syncthreads();
-}
-
-// kEpt > 0: every thread keeps its (<= kEpt) edges -- map point, observation, weight, residual, flags -- in
-// registers for the whole procedure (n <= 256 * kEpt); the 40 LM iterations then touch no global memory.
-// kEpt == 0: edges stay in global memory (any n).  Same arithmetic, same per-thread edge order either way.
-template <int kEpt>
-__global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
-{
-    constexpr int EPT = kEpt > 0 ? kEpt : 1;
-    constexpr bool kReg = kEpt > 0;
-    double Xr[EPT][3], Or[EPT][3], Wr[EPT], Er[EPT][3];
-    uint8_t Sr[EPT], L1r[EPT], Rbr[EPT], Outr[EPT];
-    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 9 x 27
-    __shared__ double qt[7], bk[7], xs[6];
-    __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
-    __shared__ int s_flag;
-    const PoseProbDev P = probs[blockIdx.x];
-    const int tid = threadIdx.x, n = P.n;
-    // edge loop: thread tid owns edges tid, tid + 256, ... (slot j); accessors pick registers or global memory
-#define PO_FOR_EDGES(j, e) for (int j = 0, e = tid; e < n && (!kReg || j < EPT); ++j, e += 256)
-    auto Xp = [&](int j, int e) -> const double * { return kReg ? Xr[j] : P.Xw + 3 * e; };
-    auto Op = [&](int j, int e) -> const double * { return kReg ? Or[j] : P.obs + 3 * e; };
-    auto Ep = [&](int j, int e) -> double * { return kReg ? Er[j] : P.err + 3 * e; };
-    auto Wv = [&](int j, int e) -> double { return kReg ? Wr[j] : P.w[e]; };
-    auto Sv = [&](int j, int e) -> int { return kReg ? Sr[j] : P.stereo[e]; };
-    auto L1 = [&](int j, int e) -> uint8_t & { return kReg ? L1r[j] : P.level1[e]; };
-    auto Rb = [&](int j, int e) -> uint8_t & { return kReg ? Rbr[j] : P.robust[e]; };
-    auto Ou = [&](int j, int e) -> uint8_t & { return kReg ? Outr[j] : P.outlier[e]; };
-#pragma unroll EPT
-    PO_FOR_EDGES(j, e) {
-        if (kReg) {
-            for (int k = 0; k < 3; ++k) {
-                Xr[j][k] = P.Xw[3 * e + k];
-                Or[j][k] = P.obs[3 * e + k];
-            }
-            Wr[j] = P.w[e];
-            Sr[j] = P.stereo[e];
+    const LbaWin &W = wins[blockIdx.y];
+    if (!W.st->run || (int)blockIdx.x >= W.n_part_s) return;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n6 = 6 * W.np;
+    const double lambda = W.st->lambda;
+    double sc = 0;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n6; i += 128) sc += W.tmp[i];
+    if (l < W.nl) {
+        double cl[3] = {W.b[n6 + 3 * l], W.b[n6 + 3 * l + 1], W.b[n6 + 3 * l + 2]};
+        for (int a = W.pl_off[l]; a < W.pl_off[l + 1]; ++a) {
+            const int ka = W.pl_k[a];
+            const int i1 = W.k_ph[ka];
+            const double *Bi = W.Hpl + 18 * (size_t)ka;
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-W.x[6 * i1 + r]);
         }
-        L1(j, e) = 0;
-        Rb(j, e) = 1;
-        Ou(j, e) = 0;
-        double *er0 = Ep(j, e);
-        er0[0] = er0[1] = er0[2] = 0;
+        // (Hll + lambda I)^-1 again, the same operations as in the Schur kernel (so the same bits): landmarks seen by
+        // fixed keyframes only have no Schur item that could have stored it
+        double Dm[9], Dinv[9];
+        for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
+        Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+        mat3_inverse(Dm, Dinv);
+        double *X = W.point + 3 * (size_t)W.hpoint[l];
+        for (int r = 0; r < 3; ++r) {
+            const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
+            W.x[n6 + 3 * l + r] = xl;
+            X[r] += xl;
+            sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
+        }
     }
-    if (tid < 7) qt[tid] = P.pose_in[tid];
+    workgroup_sum<128>(sc, W.part + W.n_part_e);
+}
+
+// The decision of one Levenberg-Marquardt trial and everything that hangs on it (levenberg.cpp:99-164,
+// sparse_optimizer.cpp:372-414): gain ratio, lambda update or pop(), the `while (rho < 0 && qmax < maxTrials &&
+// !terminate())` condition, the three ways an iteration can end the optimisation, and the `for (i < iterations &&
+// !terminate() && ok)` condition of the next iteration.  One workgroup per window; thread 0 decides, all threads
+// restore the estimates after a rejected step.
+__global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins)
+{
+    __shared__ int s_restore;
+    const LbaWin &W = wins[blockIdx.x];
+    LmState *st = W.st;
+    if (!st->run) return;
+    if (threadIdx.x == 0) {
+        const int pass = st->phase == 0 ? 0 : 1;
+        double tempChi = 0, scale = 0;
+        for (int g = 0; g < W.n_part_e; ++g) tempChi += W.part[g];
+        for (int g = 0; g < W.n_part_s; ++g) scale += W.part[W.n_part_e + g];
+        const bool ok2 = W.np == 0 || W.scal[3] != 0.0;
+        if (!ok2) {
+            tempChi = 1.7976931348623157e308;
+            st->solver_failed++;
+        }
+        double rho = st->currentChi - tempChi;
+        scale += 1e-3;
+        rho /= scale;
+        if (!ok2) rho = -1.0;   // (currentChi - DBL_MAX) / scale: negative for the positive scale of an LM step
+        const bool accepted = rho > 0 && isfinite(tempChi);
+        if (st->ntr < 48) {
+            st->tr_rho[st->ntr] = rho; st->tr_temp[st->ntr] = tempChi; st->tr_cur[st->ntr] = st->currentChi;
+            st->tr_lambda[st->ntr] = st->lambda;
+            st->ntr++;
+        }
+        if (accepted) {
+            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
+            st->lambda *= scaleFactor;
+            st->ni = 2;
+            st->currentChi = tempChi;
+        } else {
+            st->lambda *= st->ni;
+            st->ni *= 2;
+        }
+        s_restore = accepted ? 0 : 1;
+        st->qmax++;
+        st->trials[pass]++;
+        int lin = 0;
+        const bool again = rho < 0 && st->qmax < 10 && !lm_poll(st, W.abort_word);
+        if (!again) {
+            bool term = st->qmax == 10 || rho == 0;
+            if (!term) {
+                if ((st->iniChi - st->currentChi) * 1e3 < st->iniChi)
+                    st->nBad++;
+                else
+                    st->nBad = 0;
+                term = st->nBad >= 3;
+            }
+            st->it++;
+            bool more = st->it < st->iters_max[pass];
+            if (more) more = !lm_poll(st, W.abort_word);   // evaluated before `ok`
+            if (more) more = !term;
+            if (more) {
+                st->qmax = 0;
+                st->iniChi = st->currentChi;
+                lin = accepted ? 1 : 0;   // (a step that was neither accepted nor repeated leaves the system as it is)
+            } else {
+                st->run = 0;
+                st->iters_done[pass] = st->it;
+                st->final_chi2 = st->currentChi;
+                st->final_lambda = st->lambda;
+                st->phase = pass == 0 ? 1 : 3;
+            }
+        }
+        st->lin = lin;
+    }
     __syncthreads();
-    if (n < 3) {  // nInitialCorrespondences < 3 (:355-356): the pose stays, mvbOutlier was already reset (:283, :320)
-        for (int e = tid; e < n; e += 256) P.outlier[e] = 0;   // (the register copies above never reach memory here)
-        if (tid < 7) P.pose_out[tid] = P.pose_in[tid];
-        if (tid == 0) { P.counts[0] = 0; P.counts[1] = 0; }
+    if (s_restore)   // SparseOptimizer::pop
+        for (int i = threadIdx.x; i < W.est_n; i += 1024) W.pose[i] = W.bk[i];
+}
+
+// Between the two optimisations (Optimizer.cc:663-710).  (a): bDoMore = !*pbStopFlag
+__global__ void k_trans_a(const LbaWin *__restrict__ wins)
+{
+    const LbaWin &W = wins[blockIdx.x];
+    LmState *st = W.st;
+    st->xmark = 0;
+    if (st->phase != 1) return;
+    if (lm_poll(st, W.abort_word)) {
+        st->phase = 3;
         return;
     }
-    const double delta_m = (double)(float)sqrt(5.991), delta_s = (double)(float)sqrt(7.815);
-    int nBad = 0;
-    // residuals of the active edges + robust chi2 (computeActiveErrors + activeRobustChi2)
-    auto errors_chi2 = [&](double &chi_out) {
-        double acc[1] = {0};
-#pragma unroll EPT
-        PO_FOR_EDGES(j, e) {
-            if (L1(j, e)) continue;
-            double er[3];
-            const int st = Sv(j, e);
-            po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
-            double *ee = Ep(j, e);
-            ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
-            double c = edge_chi2(er, Wv(j, e), st ? 3 : 2);
-            if (Rb(j, e)) {
-                double rho[2];
-                robustify(c, st ? delta_s : delta_m, rho);
-                c = rho[0];
-            }
-            acc[0] += c;
-        }
-        double out[1];
-        block_sum<1>(acc, sh, out);
-        chi_out = out[0];
-    };
-    for (int it = 0; it < 4; ++it) {
-        if (tid < 7) qt[tid] = P.pose_in[tid];  // every round restarts from pFrame->mTcw (:368)
-        __syncthreads();
-        int n_active = 0;
-        {
-            double cnt[1] = {0}, out[1];
-#pragma unroll EPT
-            PO_FOR_EDGES(j, e) cnt[0] += L1(j, e) ? 0.0 : 1.0;
-            block_sum<1>(cnt, sh, out);
-            n_active = (int)out[0];
-        }
-        if (n_active > 0) {
-            int nBadLM = 0;
-            bool ok = true;
-            for (int i = 0; i < 10 && ok; ++i) {
-                double currentChi;
-                errors_chi2(currentChi);
-                const double iniChi = currentChi;
-                // buildSystem: H (upper triangle, 21) + b (6)
-                double acc[27];
-#pragma unroll
-                for (int k = 0; k < 27; ++k) acc[k] = 0;
-#pragma unroll EPT
-                PO_FOR_EDGES(j, e) {
-                    if (L1(j, e)) continue;
-                    const int st = Sv(j, e), D = st ? 3 : 2;
-                    double p[3];
-                    se3_map(qt, Xp(j, e), p);
-                    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
-                    double J[18];
-                    J[0] = x * y * invz_2 * P.fx;
-                    J[1] = -(1 + (x * x * invz_2)) * P.fx;
-                    J[2] = y * invz * P.fx;
-                    J[3] = -invz * P.fx;
-                    J[4] = 0;
-                    J[5] = x * invz_2 * P.fx;
-                    J[6] = (1 + y * y * invz_2) * P.fy;
-                    J[7] = -x * y * invz_2 * P.fy;
-                    J[8] = -x * invz * P.fy;
-                    J[9] = 0;
-                    J[10] = -invz * P.fy;
-                    J[11] = y * invz_2 * P.fy;
-                    J[12] = J[0] - P.bf * y * invz_2;
-                    J[13] = J[1] + P.bf * x * invz_2;
-                    J[14] = J[2];
-                    J[15] = J[3];
-                    J[16] = 0;
-                    J[17] = J[5] - P.bf * invz_2;
-                    const double *er = Ep(j, e);
-                    const double w = Wv(j, e);
-                    double wo = w, r1 = 1.0;
-                    if (Rb(j, e)) {
-                        double rho[2];
-                        robustify(edge_chi2(er, w, D), st ? delta_s : delta_m, rho);
-                        r1 = rho[1];
-                        wo = rho[1] * w;
-                    }
-                    // static indices only (registers): the third row joins for stereo edges; 0 + a == a, so the
-                    // sums equal the d-loops of the reference order
-                    const bool st3 = D == 3;
-                    int k = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        double sacc = J[r] * (w * er[0]);
-                        sacc += J[6 + r] * (w * er[1]);
-                        if (st3) sacc += J[12 + r] * (w * er[2]);
-                        acc[21 + r] -= r1 * sacc;
-#pragma unroll
-                        for (int c = r; c < 6; ++c, ++k) {
-                            double t = J[r] * wo * J[c];
-                            t += J[6 + r] * wo * J[6 + c];
-                            if (st3) t += J[12 + r] * wo * J[12 + c];
-                            acc[k] += t;
-                        }
-                    }
-                }
-                double Hb[27];
-                block_sum<27>(acc, sh, Hb);
-                if (tid == 0) {
-                    if (i == 0) {
-                        double maxDiagonal = 0.;
-                        constexpr int di[6] = {0, 6, 11, 15, 18, 20};
-#pragma unroll
-                        for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
-                        s_lambda = 1e-5 * maxDiagonal;
-                        s_ni = 2;
-                    }
-                    s_currentChi = currentChi;
-                }
-                if (i == 0) nBadLM = 0;
-                __syncthreads();
-                double rho = 0;
-                int qmax = 0;
-                do {
-                    if (tid == 0) {
-                        for (int k = 0; k < 7; ++k) bk[k] = qt[k];
-                        // (H + lambda I) x = b by Cholesky; "not positive" -> the step is rejected.  All loops have
-                        // constant bounds and are unrolled so that L, y stay in registers (dynamic indexing would put
-                        // them in scratch memory, on the serial path of every LM step); after a non-positive pivot
-                        // the remaining arithmetic runs on but its result is discarded (pos = false).
-                        double L[36];
-                        {
-                            int k = 0;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                                for (int c = r; c < 6; ++c, ++k) L[c * 6 + r] = L[r * 6 + c] = Hb[k];
-                        }
-#pragma unroll
-                        for (int d = 0; d < 6; ++d) L[d * 7] += s_lambda;
-                        bool pos = true;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            double dd = L[j * 6 + j];
-#pragma unroll
-                            for (int m = 0; m < j; ++m) dd -= L[j * 6 + m] * L[j * 6 + m];
-                            if (!(dd > 0)) pos = false;
-                            dd = sqrt(dd);
-                            L[j * 6 + j] = dd;
-#pragma unroll
-                            for (int r = j + 1; r < 6; ++r) {
-                                double sacc = L[r * 6 + j];
-#pragma unroll
-                                for (int m = 0; m < j; ++m) sacc -= L[r * 6 + m] * L[j * 6 + m];
-                                L[r * 6 + j] = sacc / dd;
-                            }
-                        }
-                        if (pos) {
-                            double yv[6], xv[6];
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                double sacc = Hb[21 + r];
-#pragma unroll
-                                for (int m = 0; m < r; ++m) sacc -= L[r * 6 + m] * yv[m];
-                                yv[r] = sacc / L[r * 6 + r];
-                            }
-#pragma unroll
-                            for (int r = 5; r >= 0; --r) {
-                                double sacc = yv[r];
-#pragma unroll
-                                for (int m = r + 1; m < 6; ++m) sacc -= L[m * 6 + r] * xv[m];
-                                xv[r] = sacc / L[r * 6 + r];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) xs[r] = xv[r];
-                        }
-                        s_flag = pos ? 1 : 0;
-                        double upd[6], T[7];
-                        for (int k2 = 0; k2 < 6; ++k2) upd[k2] = xs[k2];
-                        for (int k2 = 0; k2 < 7; ++k2) T[k2] = qt[k2];
-                        se3_oplus(upd, T);
-                        for (int k2 = 0; k2 < 7; ++k2) qt[k2] = T[k2];
-                    }
-                    __syncthreads();
-                    double tempChi;
-                    errors_chi2(tempChi);
-                    if (tid == 0) {
-                        if (!s_flag) tempChi = 1.7976931348623157e308;
-                        double r = s_currentChi - tempChi;
-                        double scale = 0.;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) scale += xs[j] * (s_lambda * xs[j] + Hb[21 + j]);
-                        scale += 1e-3;
-                        r /= scale;
-                        if (r > 0 && isfinite(tempChi)) {
-                            double alpha = 1. - pow((2 * r - 1), 3.0);
-                            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
-                            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
-                            s_lambda *= scaleFactor;
-                            s_ni = 2;
-                            s_currentChi = tempChi;
-                        } else {
-                            s_lambda *= s_ni;
-                            s_ni *= 2;
-                            for (int k = 0; k < 7; ++k) qt[k] = bk[k];
-                        }
-                        s_rho = r;
-                    }
-                    __syncthreads();
-                    rho = s_rho;
-                    qmax++;
-                } while (rho < 0 && qmax < 10);
-                const double curChi = s_currentChi;
-                if (qmax == 10 || rho == 0) {
-                    ok = false;
-                } else {
-                    if ((iniChi - curChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
-                    if (nBadLM >= 3) ok = false;
-                }
-                __syncthreads();
-            }
-        }
-        // outlier reclassification (:371-430)
-        double bad[1] = {0}, outb[1];
-#pragma unroll EPT
-        PO_FOR_EDGES(j, e) {
-            const int st = Sv(j, e);
-            if (Ou(j, e)) {
-                double er[3];
-                po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
-                double *ee = Ep(j, e);
-                ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
-            }
-            const float chi2 = (float)edge_chi2(Ep(j, e), Wv(j, e), st ? 3 : 2);
-            if (chi2 > (st ? 7.815f : 5.991f)) {
-                Ou(j, e) = 1;
-                L1(j, e) = 1;
-                bad[0] += 1.0;
-            } else {
-                Ou(j, e) = 0;
-                L1(j, e) = 0;
-            }
-            if (it == 2) Rb(j, e) = 0;
-        }
-        block_sum<1>(bad, sh, outb);
-        nBad = (int)outb[0];
-        if (n < 10) break;  // optimizer.edges().size() < 10
-    }
-    if (kReg) {
-#pragma unroll EPT
-        PO_FOR_EDGES(j, e) P.outlier[e] = Outr[j];
-    }
-    if (tid < 7) P.pose_out[tid] = qt[tid];
-    if (tid == 0) {
-        P.counts[0] = nBad;
-        P.counts[1] = n - nBad;
-    }
-#undef PO_FOR_EDGES
+    st->xmark = 1;
+    st->n_active = 0;
 }
 
-}  // namespace aos2
-
-using namespace aos2;
-
-struct aos2_lba {
-    int device;
-    bool dev_ready = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {};   // [0], [1]: device time of a solve; [2]: the LM loop's scalar copy
-    DevBuf<uint8_t> arena;
-    PinnedBuf<double> h_scal;
-    PinnedBuf<uint8_t> h_stage;   // a pass's index arrays on their way to the arena
-    PinnedBuf<uint8_t> h_in;      // converted inputs (the arena's prefix) / results on their way back
-    float last_pose_ms = 0;
-};
-
-namespace aos2 {
-
-constexpr int kSchurGroups = 256;  // single-wave workgroups folding landmarks into private LDS copies
-
-struct HostArena {
-    // staged inputs (a prefix of the arena): page-locked memory of the handle (host, host_cap), else an own vector
-    uint8_t *host = nullptr;
-    size_t host_cap = 0, host_size = 0;
-    std::vector<uint8_t> own;
-    size_t size = 0;            // total arena size including device-only scratch
-    const uint8_t *data() const { return host ? host : own.data(); }
-    size_t push(const void *src, size_t bytes)
-    {
-        const size_t off = (size + 255) & ~(size_t)255;
-        size = off + bytes;
-        if (src && bytes) {  // inputs are pushed before any scratch, so the staged part stays a prefix
-            if (!host) {
-                own.resize(size);
-                memcpy(own.data() + off, src, bytes);
-            } else if (size <= host_cap)
-                memcpy(host + off, src, bytes);
-            host_size = size;
-        }
-        return off;
+// (b): edges with chi2 above the threshold or non-positive depth leave the optimisation (setLevel(1)), all edges drop
+// their robust kernel (:672-703)
+__global__ __launch_bounds__(256) void k_edge_mark(const LbaWin *__restrict__ wins)
+{
+    const LbaWin &W = wins[blockIdx.y];
+    if (!W.st->xmark) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int keep = 0;
+    if (e < W.n_edges) {
+        const int stereo = W.e_stereo[e];
+        const double c = edge_chi2(W.err + 3 * (size_t)e, W.e_w[e], stereo ? 3 : 2);
+        double p[3];
+        se3_map(W.pose + 7 * (size_t)W.e_pose[e], W.point + 3 * (size_t)W.e_point[e], p);
+        const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
+        if (bad) W.e_level1[e] = 1;
+        W.e_robust[e] = 0;
+        keep = bad ? 0 : 1;
     }
-    // input produced in place (conversions): returns where to write it
-    template <class T>
-    T *push_fill(size_t count, size_t &off)
-    {
-        off = (size + 255) & ~(size_t)255;
-        size = off + count * sizeof(T);
-        host_size = size;
-        return size <= host_cap ? reinterpret_cast<T *>(host + off) : nullptr;
-    }
-};
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&W.st->n_active, __popcll(m));
+}
 
-static int lba_init(aos2_lba *s)
+// (c): initializeOptimization(0) (fails without level-0 edges) and the entry of optimize(10)
+__global__ void k_trans_b(const LbaWin *__restrict__ wins)
+{
+    const LbaWin &W = wins[blockIdx.x];
+    LmState *st = W.st;
+    if (!st->xmark) return;
+    st->xmark = 0;
+    st->it = 0;
+    if (st->n_active == 0 || st->iters_max[1] <= 0 || lm_poll(st, W.abort_word)) {
+        st->phase = 3;
+        st->iters_done[1] = 0;
+    } else {
+        st->phase = 2;
+        st->initp = 1;
+    }
+}
+
+// final inlier check (:712-744) and the write-back conversions (:763-778)
+__global__ __launch_bounds__(256) void k_final(const LbaWin *__restrict__ wins)
+{
+    const LbaWin &W = wins[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W.n_edges) {
+        const int stereo = W.e_stereo[i];
+        const double c = edge_chi2(W.err + 3 * (size_t)i, W.e_w[i], stereo ? 3 : 2);
+        double p[3];
+        se3_map(W.pose + 7 * (size_t)W.e_pose[i], W.point + 3 * (size_t)W.e_point[i], p);
+        const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
+        if (W.out_chi2) W.out_chi2[i] = c;
+        W.out_outlier[i] = bad ? 1 : 0;
+    }
+    if (i < W.n_poses) pose_to_Tcw(W.pose + 7 * (size_t)i, W.out_Tcw + 16 * (size_t)i);
+    if (i < W.n_points)
+        for (int d = 0; d < 3; ++d) W.out_xyz[3 * (size_t)i + d] = (float)W.point[3 * (size_t)i + d];
+}
+
+// ---------------------------------------------------------------------------------------------------------- host
+int lba_handle_init(aos2_lba *s)
 {
     int st = bind_device(s->device);
     if (st) return st;
     if (s->dev_ready) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
-    if ((st = s->h_scal.alloc(8))) return st;
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_schur_partial, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
 
-static void pose_from_Tcw(const float *T, double qt[7])  // Converter::toSE3Quat, Converter.cc:37-47
-{
-    double R[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R[i * 3 + j] = (double)T[i * 4 + j];
-    quat_from_rot(R, qt);
-    quat_normalize_rot(qt);
-    for (int i = 0; i < 3; ++i) qt[4 + i] = (double)T[i * 4 + 3];
-}
-
-static void pose_to_Tcw(const double qt[7], float *T)  // Converter::toCvMat(SE3Quat), Converter.cc:49-71
-{
-    double R[9];
-    rot_from_quat(qt, R);
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
-        T[i * 4 + 3] = (float)qt[4 + i];
-    }
-    T[12] = T[13] = T[14] = 0.f;
-    T[15] = 1.f;
-}
-
 static bool stop_requested(const aos2_lba_problem_t *p) { return p->stop_flag && *p->stop_flag != 0; }
 
+// index mapping and edge lists of a window: initializeOptimization(level 0) + buildIndexMapping + the symbolic part of
+// buildStructure for ALL edges (the second optimisation masks edges instead of rebuilding)
 struct Pass {
-    std::vector<int32_t> act, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
+    std::vector<int32_t> k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
     std::vector<int32_t> it_ka, it_kb, it_l, blk_off;   // Schur items (k_schur_items / k_schur_blocks)
-    int ka = 0, np = 0, nl = 0;
+    int np = 0, nl = 0;
 };
 
-// initializeOptimization(level 0) + buildIndexMapping + the symbolic part of buildStructure
-static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &level1, Pass &S)
+static void build_pass(const aos2_lba_problem_t *p, Pass &S)
 {
     S = Pass();
+    const int E = p->n_edges;
     std::vector<uint8_t> pose_act(p->n_poses, 0), point_act(p->n_points, 0);
-    S.act.reserve(p->n_edges);
-    for (int e = 0; e < p->n_edges; ++e) {
-        if (level1[e]) continue;
-        S.act.push_back(e);
+    for (int e = 0; e < E; ++e) {
         pose_act[p->edge_pose[e]] = 1;
         point_act[p->edge_point[e]] = 1;
     }
-    S.ka = (int)S.act.size();
-    if (S.ka == 0) return false;
     std::vector<int32_t> pose_h(p->n_poses, -1), point_h(p->n_points, -1);
     for (int i = 0; i < p->n_poses; ++i)
         if (pose_act[i] && !p->pose_fixed[i]) S.hpose.push_back(i);
@@ -1483,15 +1055,14 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
     S.nl = (int)S.hpoint.size();
     for (int i = 0; i < S.np; ++i) pose_h[S.hpose[i]] = i;
     for (int i = 0; i < S.nl; ++i) point_h[S.hpoint[i]] = i;
-    S.k_ph.resize(S.ka);
-    S.k_lh.resize(S.ka);
+    S.k_ph.resize(E);
+    S.k_lh.resize(E);
     S.pt_off.assign(S.nl + 1, 0);
     S.ps_off.assign(S.np + 1, 0);
     S.pl_off.assign(S.nl + 1, 0);
-    for (int k = 0; k < S.ka; ++k) {
-        const int e = S.act[k];
-        S.k_ph[k] = pose_h[p->edge_pose[e]];
-        S.k_lh[k] = point_h[p->edge_point[e]];
+    for (int k = 0; k < E; ++k) {
+        S.k_ph[k] = pose_h[p->edge_pose[k]];
+        S.k_lh[k] = point_h[p->edge_point[k]];
         S.pt_off[S.k_lh[k] + 1]++;
         if (S.k_ph[k] >= 0) {
             S.ps_off[S.k_ph[k] + 1]++;
@@ -1507,7 +1078,7 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
     S.ps_k.resize(S.ps_off[S.np]);
     S.pl_k.resize(S.pl_off[S.nl]);
     std::vector<int> f1(S.nl, 0), f2(S.np, 0), f3(S.nl, 0);
-    for (int k = 0; k < S.ka; ++k) {
+    for (int k = 0; k < E; ++k) {
         const int l = S.k_lh[k], ph = S.k_ph[k];
         S.pt_k[S.pt_off[l] + f1[l]++] = k;
         if (ph >= 0) {
@@ -1515,8 +1086,8 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
             S.pl_k[S.pl_off[l] + f3[l]++] = k;
         }
     }
-    // per landmark: ascending pose index, ties in slot order (a stable insertion sort: the runs are a handful of
-    // slots long, and std::stable_sort would allocate a buffer for each of the thousands of runs)
+    // per landmark: ascending pose index, ties in edge order (a stable insertion sort: the runs are a handful of
+    // edges long, and std::stable_sort would allocate a buffer for each of the thousands of runs)
     for (int l = 0; l < S.nl; ++l) {
         int32_t *q = S.pl_k.data() + S.pl_off[l];
         const int m = S.pl_off[l + 1] - S.pl_off[l];
@@ -1527,28 +1098,21 @@ static bool build_pass(const aos2_lba_problem_t *p, const std::vector<uint8_t> &
             q[j + 1] = v;
         }
     }
-    return true;
-}
-
-// number of Schur items of a pass: sum over landmarks of m (m + 1) / 2, m = observations by free keyframes
-static size_t schur_item_count(const Pass &S)
-{
-    size_t n = 0;
-    for (int l = 0; l < S.nl; ++l) {
-        const size_t m = (size_t)(S.pl_off[l + 1] - S.pl_off[l]);
-        n += m * (m + 1) / 2;
-    }
-    return n;
 }
 
 // items ranked by (pose, pose) block -- upper block triangle, row-major -- and by landmark inside a block (counting
 // sort; this order is the summation order of k_schur_blocks)
 static void build_schur_items(Pass &S)
 {
-    const size_t n = schur_item_count(S);
-    const int np = S.np, nblk = np * (np + 1) / 2;
+    size_t n = 0;
+    for (int l = 0; l < S.nl; ++l) {
+        const size_t m = (size_t)(S.pl_off[l + 1] - S.pl_off[l]);
+        n += m * (m + 1) / 2;
+    }
+    const int np = S.np;
+    const size_t nblk = (size_t)np * (np + 1) / 2;
     S.it_ka.resize(n); S.it_kb.resize(n); S.it_l.resize(n);
-    S.blk_off.assign((size_t)nblk + 1, 0);
+    S.blk_off.assign(nblk + 1, 0);
     // block of (i1 <= i2) = row_base[i1] + i2 (pl_k is sorted by pose, so a <= b gives i1 <= i2)
     std::vector<int32_t> row_base(np > 0 ? np : 1), ph(S.pl_k.size());
     for (int i = 0; i < np; ++i) row_base[i] = i * np - i * (i - 1) / 2 - i;
@@ -1561,7 +1125,7 @@ static void build_schur_items(Pass &S)
             for (int b = a; b < m; ++b) cnt[q[b]]++;
         }
     }
-    for (int i = 0; i < nblk; ++i) S.blk_off[i + 1] += S.blk_off[i];
+    for (size_t i = 0; i < nblk; ++i) S.blk_off[i + 1] += S.blk_off[i];
     std::vector<int32_t> fill(S.blk_off.begin(), S.blk_off.end() - 1);
     for (int l = 0; l < S.nl; ++l) {
         const int c0 = S.pl_off[l], m = S.pl_off[l + 1] - c0;
@@ -1579,7 +1143,32 @@ static void build_schur_items(Pass &S)
     }
 }
 
+// byte offsets of one window's regions in the arena
+struct WinLayout {
+    // staged (uploaded)
+    size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
+        pl_off, pl_k, it_ka, it_kb, it_l, blk_off;
+    // device only
+    size_t est, bk, e_obs, e_w, robust, level1, err, JA, JB, Wr, wo, Hpl, Hpp, Hll, b, x, Hs, bs, W, Wc, tmp, scal, part, ldlt;
+    // results (downloaded)
+    size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
+    int n_part_e, n_part_s, npad, ldlt_lds;
+    size_t n_items;
+};
+
+struct Bump {
+    size_t size = 0;
+    size_t take(size_t bytes, size_t align = 256)
+    {
+        const size_t off = (size + align - 1) & ~(align - 1);
+        size = off + bytes;
+        return off;
+    }
+};
+
 }  // namespace aos2
+
+using namespace aos2;
 
 extern "C" {
 
@@ -1599,525 +1188,379 @@ void aos2_lba_destroy(aos2_lba_t *s)
         (void)hipSetDevice(s->device);
         (void)hipStreamSynchronize(s->stream);
         s->arena.release();
-        s->h_scal.release();
         s->h_stage.release();
         s->h_in.release();
+        s->h_abort.release();
         for (auto &e : s->ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(s->stream);
     }
     delete s;
 }
 
-int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r)
+int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll)
 {
-    if (!s || !p || !r || p->n_poses <= 0 || p->n_points <= 0 || p->n_edges <= 0 || !p->pose_Tcw || !p->pose_fixed ||
-        !p->pose_id || !p->point_xyz || !p->point_id || !p->edge_pose || !p->edge_point || !p->edge_obs ||
-        !p->edge_stereo || !p->edge_inv_sigma2 || !r->pose_Tcw || !r->point_xyz) {
-        set_error("bad LocalBA problem");
+    if (!s || poll < 0) return AOS2_ERR_ARG;
+    s->debug_stop_at_poll = poll;
+    return AOS2_OK;
+}
+
+int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2_lba_result_t *results, int n_problems)
+{
+    if (!s || !problems || !results || n_problems <= 0) {
+        set_error("bad LocalBA batch");
         return AOS2_ERR_ARG;
     }
-    for (int e = 0; e < p->n_edges; ++e)
-        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
-            set_error("edge %d references a vertex out of range", e);
+    bool want_chi2 = false;
+    for (int w = 0; w < n_problems; ++w) {
+        const aos2_lba_problem_t *p = problems + w;
+        aos2_lba_result_t *r = results + w;
+        if (p->n_poses <= 0 || p->n_points <= 0 || p->n_edges <= 0 || !p->pose_Tcw || !p->pose_fixed || !p->pose_id ||
+            !p->point_xyz || !p->point_id || !p->edge_pose || !p->edge_point || !p->edge_obs || !p->edge_stereo ||
+            !p->edge_inv_sigma2 || !r->pose_Tcw || !r->point_xyz) {
+            set_error("bad LocalBA problem %d", w);
             return AOS2_ERR_ARG;
         }
-    r->iters_done_first = r->iters_done_second = 0;
-    r->final_chi2 = 0;
-    r->final_lambda = 0;
-    r->ms_device = 0;
-    if (stop_requested(p)) {  // Optimizer.cc:656-658: return before optimising, nothing is written back
-        memcpy(r->pose_Tcw, p->pose_Tcw, sizeof(float) * 16 * p->n_poses);
-        memcpy(r->point_xyz, p->point_xyz, sizeof(float) * 3 * p->n_points);
-        if (r->edge_outlier) memset(r->edge_outlier, 0, p->n_edges);
-        return AOS2_ERR_STOPPED;
-    }
-    const auto t_call = std::chrono::steady_clock::now();
-    int st = lba_init(s);
-    if (st) return st;
-    const int NP = p->n_poses, NL = p->n_points, E = p->n_edges;
-    // ---- host-side conversion (Converter.cc) and upload
-    // (converted straight into the handle's page-locked input staging buffer: one asynchronous upload, no bounce)
-    std::vector<double> pose(7 * (size_t)NP), point(3 * (size_t)NL);
-    std::vector<uint8_t> level1(E, 0), robust(E, 1);
-    HostArena H;
-    // (the estimates' backup copies lie between the inputs, so the staged prefix spans them as well)
-    const size_t in_cap = 2 * (56 * (size_t)NP + 24 * (size_t)NL) + (size_t)E * (4 + 4 + 24 + 8 + 3) + 16 * 256;
-    if (int st0 = s->h_in.alloc(in_cap)) return st0;
-    H.host = s->h_in.p;
-    H.host_cap = in_cap;
-    size_t o_pose, o_point, o_obs, o_w;
-    double *h_pose = H.push_fill<double>(7 * (size_t)NP, o_pose), *h_point = H.push_fill<double>(3 * (size_t)NL, o_point);
-    const size_t o_bkpose = H.push(nullptr, pose.size() * 8), o_bkpoint = H.push(nullptr, point.size() * 8);
-    if (o_bkpoint - o_bkpose != o_point - o_pose) {   // the LM backup copies [poses | points] as one span
-        set_error("internal: arena layout");
-        return AOS2_ERR_ARG;
-    }
-    const size_t o_epose = H.push(p->edge_pose, (size_t)E * 4), o_epoint = H.push(p->edge_point, (size_t)E * 4);
-    double *h_obs = H.push_fill<double>(3 * (size_t)E, o_obs), *h_w = H.push_fill<double>((size_t)E, o_w);
-    if (!h_pose || !h_point || !h_obs || !h_w) {
-        set_error("internal: LocalBA input staging");
-        return AOS2_ERR_ARG;
-    }
-    for (int i = 0; i < NP; ++i) pose_from_Tcw(p->pose_Tcw + 16 * (size_t)i, h_pose + 7 * (size_t)i);
-    for (size_t i = 0; i < 3 * (size_t)NL; ++i) h_point[i] = (double)p->point_xyz[i];
-    for (size_t i = 0; i < 3 * (size_t)E; ++i) h_obs[i] = (double)p->edge_obs[i];
-    for (int e = 0; e < E; ++e) h_w[e] = (double)p->edge_inv_sigma2[e];
-    const size_t o_st = H.push(p->edge_stereo, E), o_rb = H.push(robust.data(), E), o_l1 = H.push(level1.data(), E);
-    const size_t o_err = H.push(nullptr, (size_t)E * 3 * 8);
-    const size_t o_chi = H.push(nullptr, (size_t)E * 8), o_out = H.push(nullptr, E);
-    // per-pass structure + system (sized for the first pass, which is the largest)
-    int n_free = 0;
-    for (int i = 0; i < NP; ++i) n_free += p->pose_fixed[i] ? 0 : 1;
-    const size_t n6max = 6 * (size_t)n_free, dimmax = n6max + 3 * (size_t)NL;
-    const size_t o_act = H.push(nullptr, (size_t)E * 4), o_kph = H.push(nullptr, (size_t)E * 4), o_klh = H.push(nullptr, (size_t)E * 4);
-    const size_t o_hpose = H.push(nullptr, (size_t)NP * 4 + 4), o_hpoint = H.push(nullptr, (size_t)NL * 4 + 4);
-    const size_t o_ptoff = H.push(nullptr, (size_t)(NL + 1) * 4), o_ptk = H.push(nullptr, (size_t)E * 4);
-    const size_t o_psoff = H.push(nullptr, (size_t)(NP + 1) * 4), o_psk = H.push(nullptr, (size_t)E * 4);
-    const size_t o_ploff = H.push(nullptr, (size_t)(NL + 1) * 4), o_plk = H.push(nullptr, (size_t)E * 4);
-    const size_t o_JA = H.push(nullptr, (size_t)E * 9 * 8), o_JB = H.push(nullptr, (size_t)E * 18 * 8);
-    const size_t o_Wr = H.push(nullptr, (size_t)E * 3 * 8), o_wo = H.push(nullptr, (size_t)E * 8);
-    const size_t o_Hpl = H.push(nullptr, (size_t)E * 18 * 8);
-    const size_t o_Hpp = H.push(nullptr, (size_t)n_free * 36 * 8 + 8), o_Hll = H.push(nullptr, (size_t)NL * 9 * 8);
-    const size_t o_b = H.push(nullptr, dimmax * 8 + 8), o_x = H.push(nullptr, dimmax * 8 + 8);
-    const size_t o_Hs = H.push(nullptr, n6max * n6max * 8 + 8), o_bs = H.push(nullptr, n6max * 8 + 8);
-    const size_t o_coeff = H.push(nullptr, n6max * 8 + 8), o_Dinv = H.push(nullptr, (size_t)NL * 9 * 8);
-    // scalars [0..3] (chi2 and scale are unused now), then the per-workgroup sums of k_errors and k_backsub_points
-    const int n_part_e = (E + 1023) / 1024, n_part = n_part_e + (NL + 127) / 128;
-    const size_t o_tmp = H.push(nullptr, std::max((size_t)E, dimmax) * 8 + 8), o_scal = H.push(nullptr, (4 + (size_t)n_part) * 8 + 64);
-    // Schur items (first pass = all edges = the largest): sum over points of m (m + 1) / 2, m = edges to free keyframes
-    size_t n_items_max = 0;
-    {
-        std::vector<int32_t> m(NL, 0);
-        for (int e = 0; e < E; ++e)
-            if (!p->pose_fixed[p->edge_pose[e]]) m[p->edge_point[e]]++;
-        for (int l = 0; l < NL; ++l) n_items_max += (size_t)m[l] * (m[l] + 1) / 2;
-    }
-    // AOS2_SCHUR=partial selects the former per-wave LDS accumulation (kept for reduced systems whose items would
-    // not fit: W is 288 B per item); the tests run both
-    const char *schur_env = getenv("AOS2_SCHUR");
-    const bool schur_items = !(schur_env && strcmp(schur_env, "partial") == 0) && n_items_max * 288 <= ((size_t)1 << 30) &&
-                             n_items_max < ((size_t)1 << 30);
-    const size_t o_partial = H.push(nullptr, schur_items ? 8 : (size_t)kSchurGroups * (n6max * n6max + n6max) * 8 + 8);
-    const size_t n_it = schur_items ? n_items_max : 0, nblk_max = (size_t)n_free * (n_free + 1) / 2;
-    const size_t o_itka = H.push(nullptr, n_it * 4 + 4), o_itkb = H.push(nullptr, n_it * 4 + 4), o_itl = H.push(nullptr, n_it * 4 + 4);
-    const size_t o_blkoff = H.push(nullptr, (nblk_max + 1) * 4), o_W = H.push(nullptr, n_it * 288 + 8);
-    const size_t o_Wc = H.push(nullptr, schur_items ? (size_t)E * 48 + 8 : 8);
-    const size_t npad_max = (n6max + 15) & ~(size_t)15;
-    const size_t o_ldlt = H.push(nullptr, (npad_max * (npad_max + 1) + npad_max * 17 + npad_max + 64) * 8);
-    if ((st = s->arena.alloc(H.size + 256))) return st;
-    uint8_t *base = s->arena.p;
-    hipStream_t q = s->stream;
-    if (H.host_size > in_cap) {
-        set_error("internal: LocalBA input staging");
-        return AOS2_ERR_ARG;
-    }
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.host, std::min(H.host_size, o_err), hipMemcpyHostToDevice, q));  // inputs only
-    AOS2_HIP_CHECK(hipMemsetAsync(base + o_err, 0, (size_t)E * 3 * 8, q));
-    AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
-
-    LbaDev D{};
-    D.n_poses = NP; D.n_points = NL; D.n_edges = E;
-    D.pose = (double *)(base + o_pose); D.point = (double *)(base + o_point);
-    D.e_pose = (int32_t *)(base + o_epose); D.e_point = (int32_t *)(base + o_epoint);
-    D.e_obs = (double *)(base + o_obs); D.e_w = (double *)(base + o_w);
-    D.e_stereo = base + o_st; D.e_robust = base + o_rb; D.e_level1 = base + o_l1;
-    D.err = (double *)(base + o_err);
-    D.cam.fx = (double)p->fx; D.cam.fy = (double)p->fy; D.cam.cx = (double)p->cx; D.cam.cy = (double)p->cy;
-    D.cam.bf = (double)p->bf; D.cam.bf_f = p->bf;
-    D.cam.delta_mono = (double)(float)std::sqrt(5.991);
-    D.cam.delta_stereo = (double)(float)std::sqrt(7.815);
-    double *d_bkpose = (double *)(base + o_bkpose), *d_bkpoint = (double *)(base + o_bkpoint);
-    double *d_scal = (double *)(base + o_scal);
-    double *d_partial = (double *)(base + o_partial);
-    if ((st = s->h_scal.alloc(8 + (size_t)n_part))) return st;
-    const size_t span1 = o_plk + (size_t)E * 4 - o_act, span2 = o_blkoff + (nblk_max + 1) * 4 - o_itka;
-    if ((st = s->h_stage.alloc(span1 + span2 + 64))) return st;
-    double *hs = s->h_scal.p;
-
-    LbaAct A{};
-    A.act = (int32_t *)(base + o_act); A.k_ph = (int32_t *)(base + o_kph); A.k_lh = (int32_t *)(base + o_klh);
-    A.hpose = (int32_t *)(base + o_hpose); A.hpoint = (int32_t *)(base + o_hpoint);
-    A.pt_off = (int32_t *)(base + o_ptoff); A.pt_k = (int32_t *)(base + o_ptk);
-    A.ps_off = (int32_t *)(base + o_psoff); A.ps_k = (int32_t *)(base + o_psk);
-    A.pl_off = (int32_t *)(base + o_ploff); A.pl_k = (int32_t *)(base + o_plk);
-    A.JA = (double *)(base + o_JA); A.JB = (double *)(base + o_JB); A.Wr = (double *)(base + o_Wr);
-    A.wo = (double *)(base + o_wo); A.Hpl = (double *)(base + o_Hpl); A.Hpp = (double *)(base + o_Hpp);
-    A.Hll = (double *)(base + o_Hll); A.b = (double *)(base + o_b); A.x = (double *)(base + o_x);
-    A.Hs = (double *)(base + o_Hs); A.bs = (double *)(base + o_bs); A.coeff = (double *)(base + o_coeff);
-    A.Dinv = (double *)(base + o_Dinv); A.tmp = (double *)(base + o_tmp); A.scal = d_scal;
-    A.it_ka = (int32_t *)(base + o_itka); A.it_kb = (int32_t *)(base + o_itkb); A.it_l = (int32_t *)(base + o_itl);
-    A.blk_off = (int32_t *)(base + o_blkoff); A.W = (double *)(base + o_W); A.Wc = (double *)(base + o_Wc);
-
-    bool lin_ready = false;   // the system on the device was linearised at the current estimates
-    auto upload_pass = [&](Pass &S) -> int {
-        A.ka = S.ka; A.np = S.np; A.nl = S.nl;
-        lin_ready = false;
-        A.n_items = 0;
-        // The pass's index arrays are neighbours in the arena ([o_act, end of pl_k) and [o_itka, end of blk_off)): they
-        // are laid out the same way in a page-locked staging buffer of the handle and go up as two asynchronous
-        // copies (instead of fourteen staged ones and a wait).  The staging buffer is rewritten by the next pass only,
-        // long after the LM loop has waited for results that follow these copies in the stream.
-        uint8_t *stg = s->h_stage.p;
-        auto put = [&](size_t off, size_t origin, const std::vector<int32_t> &v, size_t count) {
-            if (count) memcpy(stg + (off - origin), v.data(), count * 4);
-        };
-        uint8_t *stg2 = stg + span1;
-        if (schur_items && S.np > 0) {
-            build_schur_items(S);
-            A.n_items = (int)S.it_ka.size();
-            if (S.it_ka.size() > n_items_max) {   // cannot happen: a pass is a subset of the edges
-                set_error("internal: Schur item count grew");
+        for (int e = 0; e < p->n_edges; ++e)
+            if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+                set_error("problem %d: edge %d references a vertex out of range", w, e);
                 return AOS2_ERR_ARG;
             }
-            stg = stg2;
-            put(o_itka, o_itka, S.it_ka, S.it_ka.size());
-            put(o_itkb, o_itka, S.it_kb, S.it_kb.size());
-            put(o_itl, o_itka, S.it_l, S.it_l.size());
-            put(o_blkoff, o_itka, S.blk_off, S.blk_off.size());
-            stg = s->h_stage.p;
-            AOS2_HIP_CHECK(hipMemcpyAsync(base + o_itka, stg2, o_blkoff + S.blk_off.size() * 4 - o_itka, hipMemcpyHostToDevice, q));
-        }
-        put(o_act, o_act, S.act, (size_t)S.ka);
-        put(o_kph, o_act, S.k_ph, (size_t)S.ka);
-        put(o_klh, o_act, S.k_lh, (size_t)S.ka);
-        put(o_hpose, o_act, S.hpose, (size_t)S.np);
-        put(o_hpoint, o_act, S.hpoint, (size_t)S.nl);
-        put(o_ptoff, o_act, S.pt_off, (size_t)S.nl + 1);
-        put(o_ptk, o_act, S.pt_k, S.pt_k.size());
-        put(o_psoff, o_act, S.ps_off, (size_t)S.np + 1);
-        put(o_psk, o_act, S.ps_k, S.ps_k.size());
-        put(o_ploff, o_act, S.pl_off, (size_t)S.nl + 1);
-        put(o_plk, o_act, S.pl_k, S.pl_k.size());
-        AOS2_HIP_CHECK(hipMemcpyAsync(base + o_act, stg, span1, hipMemcpyHostToDevice, q));
-        return AOS2_OK;
-    };
-    auto blocks = [](int n, int t) { return dim3((unsigned)((n + t - 1) / t)); };
-    // linearizeOplus + constructQuadraticForm of all active edges (JA, JB, Hpl, Hll, Hpp, b) at the current estimates
-    auto linearize_all = [&]() {
-        hipLaunchKernelGGL(k_linearize, blocks(A.ka, 128), dim3(128), 0, q, D, A);
-        hipLaunchKernelGGL(k_accum_points, blocks(A.nl, 128), dim3(128), 0, q, A);
-        if (A.np) hipLaunchKernelGGL(k_accum_poses, dim3(A.np), dim3(256), 0, q, A);
-    };
-    // `speculate`: the linearisation at the estimates just evaluated is enqueued behind the scalar copy and runs
-    // while the host waits for the copy (an event, not the stream) and takes the LM decision: after an accepted step --
-    // the usual case -- the next iteration finds its system built and the GPU never waits for the host round trip.
-    auto errors_chi2 = [&](double *out_host, bool speculate = false) -> int {
-        const int ne = (A.ka + 1023) / 1024;
-        hipLaunchKernelGGL(k_errors, dim3(ne), dim3(1024), 0, q, D, A, d_scal + 4);
-        if (out_host) {
-            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, (4 + (size_t)n_part) * sizeof(double), hipMemcpyDeviceToHost, q));
-            AOS2_HIP_CHECK(hipEventRecord(s->ev[2], q));
-            if (speculate) linearize_all();
-            AOS2_HIP_CHECK(hipEventSynchronize(s->ev[2]));
-            double c = 0;
-            for (int g = 0; g < ne; ++g) c += hs[4 + g];
-            *out_host = c;
-        }
-        return AOS2_OK;
-    };
-
-    double lambda = 0, ni = 2, last_chi = 0;
-    int nBad = 0;
-    // OptimizationAlgorithmLevenberg::solve (levenberg.cpp:61-164)
-    bool errors_fresh = false;  // err[] and last_chi belong to the current estimates
-    auto lm_solve = [&](int iteration, int &result) -> int {
-        double currentChi = last_chi;
-        int rc = AOS2_OK;
-        // computeActiveErrors at the top of solve() (levenberg.cpp:75): recomputing at unchanged
-        // estimates reproduces the values of the accepted trial bit for bit, so it is skipped then
-        if (!errors_fresh || iteration == 0) {
-            rc = errors_chi2(&currentChi);
-            if (rc) return rc;
-        }
-        double tempChi = currentChi;
-        const double iniChi = currentChi;
-        const int dim = 6 * A.np + 3 * A.nl, n6 = 6 * A.np;
-        if (!lin_ready || iteration == 0) linearize_all();
-        lin_ready = false;   // consumed by this iteration's trials
-        if (iteration == 0) {
-            hipLaunchKernelGGL(k_diag, blocks(dim, 256), dim3(256), 0, q, A);
-            hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(1024), 0, q, A.tmp, dim, d_scal + 2);
-            AOS2_HIP_CHECK(hipMemcpyAsync(hs, d_scal, 4 * sizeof(double), hipMemcpyDeviceToHost, q));
-            AOS2_HIP_CHECK(hipStreamSynchronize(q));
-            lambda = 1e-5 * hs[2];
-            ni = 2;
-            nBad = 0;
-        }
-        double rho = 0;
-        int qmax = 0;
-        const int maxTrials = 10;
-        do {
-            // push
-            // (poses and points are neighbours in the arena, and so are their backups: one span; the item kernel of
-            // the Schur complement copies it with its spare threads)
-            const int bk_n = (int)((o_point - o_pose) / 8 + 3 * (size_t)NL);
-            const bool push_in_items = schur_items && n6 > 0;
-            if (!push_in_items) {
-                AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpose, D.pose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
-                AOS2_HIP_CHECK(hipMemcpyAsync(d_bkpoint, D.point, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
-            }
-            // setLambda + Schur solve (the diagonal is never modified in place: lambda is added
-            // where Hpp / Hll are consumed, which is what restoreDiagonal undoes in g2o)
-            if (n6 > 0) {
-                const size_t sch_lds = ((size_t)n6 * n6 + n6) * sizeof(double);
-                if (schur_items) {
-                    hipLaunchKernelGGL(k_schur_items, blocks(A.n_items + bk_n, 128), dim3(128), 0, q, A, lambda, D.pose, d_bkpose, bk_n);
-                    hipLaunchKernelGGL(k_schur_blocks, dim3(A.np * (A.np + 1) / 2 + A.np), dim3(512), 0, q, A, lambda);
-                } else if (sch_lds <= 150 * 1024) {
-                    const int G = std::min(kSchurGroups, A.nl);
-                    hipLaunchKernelGGL(k_schur_partial, dim3(G), dim3(64), sch_lds, q, A, lambda, d_partial, G);
-                    hipLaunchKernelGGL(k_schur_reduce, blocks(n6 * n6 + n6, 32), dim3(256), 0, q, A, lambda, d_partial, G);
-                } else {
-                    hipLaunchKernelGGL(k_schur_init, blocks(n6 * n6, 256), dim3(256), 0, q, A, lambda);
-                    hipLaunchKernelGGL(k_schur_points, dim3(A.nl), dim3(64), 0, q, A, lambda);
-                    hipLaunchKernelGGL(k_schur_finish, blocks(n6 * n6, 256), dim3(256), 0, q, A);
-                }
-                {
-                    const int npad = (n6 + 15) & ~15;
-                    if (npad > 256) {
-                        set_error("reduced camera system of dimension %d exceeds 256 (more than 42 free keyframes)", n6);
-                        return AOS2_ERR_ARG;
-                    }
-                    const size_t need = ((size_t)npad * (npad + 1) + (size_t)npad * 17 + npad + 64) * sizeof(double);
-                    const int use_lds = need <= 160 * 1024 ? 1 : 0;
-                    if (use_lds)
-                        hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(1), dim3(256), need, q, A, npad, (double *)(base + o_ldlt), D.pose, lambda);
-                    else {
-                        hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(1), dim3(256), 0, q, A, npad, (double *)(base + o_ldlt), D.pose, lambda);
-                        hipLaunchKernelGGL(k_update_poses, blocks(A.np, 64), dim3(64), 0, q, D, A, lambda);
-                    }
-                }
-            } else {
-                AOS2_HIP_CHECK(hipMemsetAsync(d_scal + 3, 0, sizeof(double), q));
-            }
-            const int ns = (A.nl + 127) / 128;
-            hipLaunchKernelGGL(k_backsub_points, dim3(ns), dim3(128), 0, q, D, A, lambda, d_scal + 4 + n_part_e);
-            rc = errors_chi2(&tempChi, true);  // also fetches the scale terms and the solver flag; linearises ahead
-            if (rc) return rc;
-            const bool ok2 = (n6 == 0) || hs[3] != 0.0;
-            if (!ok2) tempChi = 1.7976931348623157e308;
-            rho = (currentChi - tempChi);
-            double scale = 0;   // sum of x_j (lambda x_j + b_j): the per-workgroup sums of k_backsub_points
-            for (int g = 0; g < ns; ++g) scale += hs[4 + n_part_e + g];
-            scale += 1e-3;
-            rho /= scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                const double scaleFactor = std::max(1. / 3., alpha);
-                lambda *= scaleFactor;
-                ni = 2;
-                currentChi = tempChi;
-                errors_fresh = true;
-                lin_ready = true;   // the speculative linearisation was made at the accepted estimates
-            } else {
-                lambda *= ni;
-                ni *= 2;
-                // pop; the residuals and the system of the restored estimates are rebuilt (the speculative
-                // linearisation belongs to the rejected step): the same inputs give the same bits as before the trial
-                AOS2_HIP_CHECK(hipMemcpyAsync(D.pose, d_bkpose, sizeof(double) * 7 * NP, hipMemcpyDeviceToDevice, q));
-                AOS2_HIP_CHECK(hipMemcpyAsync(D.point, d_bkpoint, sizeof(double) * 3 * NL, hipMemcpyDeviceToDevice, q));
-                rc = errors_chi2(nullptr);
-                if (rc) return rc;
-                linearize_all();
-                errors_fresh = true;
-                lin_ready = true;
-            }
-            qmax++;
-        } while (rho < 0 && qmax < maxTrials && !stop_requested(p));
-        last_chi = currentChi;
-        if (qmax == maxTrials || rho == 0) {
-            result = 1;  // Terminate
-            return AOS2_OK;
-        }
-        if ((iniChi - currentChi) * 1e3 < iniChi)
-            nBad++;
-        else
-            nBad = 0;
-        result = nBad >= 3 ? 1 : 0;
-        return AOS2_OK;
-    };
-    auto optimize = [&](int iterations, int &done) -> int {
-        done = 0;
-        bool ok = true;
-        for (int i = 0; i < iterations && !stop_requested(p) && ok; ++i) {
-            int result = 0;
-            const int rc = lm_solve(i, result);
-            if (rc) return rc;
-            ok = (result == 0);
-            ++done;
-        }
-        return AOS2_OK;
-    };
-
-    // AOS2_LBA_PROF=1: host-side phase times of this call on stderr (tools/gpu_lba_profile.py)
+        want_chi2 |= r->edge_chi2 != nullptr;
+    }
+    // Optimizer.cc:656-658: return before optimising when the flag is already set; nothing is written back
+    std::vector<int> act;
+    for (int w = 0; w < n_problems; ++w) {
+        const aos2_lba_problem_t *p = problems + w;
+        aos2_lba_result_t *r = results + w;
+        r->iters_done_first = r->iters_done_second = 0;
+        r->trials_first = r->trials_second = 0;
+        r->final_chi2 = r->final_lambda = 0;
+        r->ms_device = 0;
+        r->polls = 1;
+        r->stop_poll = 0;
+        r->status = AOS2_OK;
+        if (stop_requested(p) || s->debug_stop_at_poll == 1) {
+            memcpy(r->pose_Tcw, p->pose_Tcw, sizeof(float) * 16 * p->n_poses);
+            memcpy(r->point_xyz, p->point_xyz, sizeof(float) * 3 * p->n_points);
+            if (r->edge_outlier) memset(r->edge_outlier, 0, p->n_edges);
+            r->status = AOS2_ERR_STOPPED;
+            r->stop_poll = 1;
+        } else
+            act.push_back(w);
+    }
+    const int nw = (int)act.size();
+    if (nw == 0) return AOS2_OK;
+    int st = lba_handle_init(s);
+    if (st) return st;
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto t_prev = t_call;
+    auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!prof) return;
-        const auto t = tnow();
+        const auto t = std::chrono::steady_clock::now();
         fprintf(stderr, "[lba] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
         t_prev = t;
     };
-    lap("convert + arena + upload");
-    Pass S;
-    if (build_pass(p, level1, S)) {
-        lap("build_pass 1");
-        if ((st = upload_pass(S))) return st;
-        lap("items + upload_pass 1");
-        if ((st = optimize(p->iters_first, r->iters_done_first))) return st;
-        lap("optimize 1");
-    }
-    if (!stop_requested(p)) {  // bDoMore, Optimizer.cc:663-710
-        hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 1, (double *)nullptr, (uint8_t *)nullptr);
-        AOS2_HIP_CHECK(hipMemcpyAsync(level1.data(), D.e_level1, E, hipMemcpyDeviceToHost, q));
-        AOS2_HIP_CHECK(hipStreamSynchronize(q));
-        lap("edge check");
-        if (build_pass(p, level1, S)) {
-            lap("build_pass 2");
-            if ((st = upload_pass(S))) return st;
-            lap("items + upload_pass 2");
-            if ((st = optimize(p->iters_second, r->iters_done_second))) return st;
-            lap("optimize 2");
+
+    // ---- per-window structure (host; windows in parallel when there are several)
+    std::vector<Pass> passes(nw);
+    auto for_windows = [&](auto &&fn) {
+        const int nthr = std::max(1, std::min({nw, (int)std::thread::hardware_concurrency(), 32}));
+        if (nthr <= 1) {
+            for (int i = 0; i < nw; ++i) fn(i);
+            return;
         }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; ++t)
+            th.emplace_back([&, t] {
+                for (int i = t; i < nw; i += nthr) fn(i);
+            });
+        for (auto &x : th) x.join();
+    };
+    for_windows([&](int i) {
+        build_pass(problems + act[i], passes[i]);
+        if (passes[i].np > 0) build_schur_items(passes[i]);
+    });
+    lap("build_pass + items");
+
+    // ---- arena layout: [staged inputs of all windows | descriptors][device-only scratch][results of all windows]
+    std::vector<WinLayout> L(nw);
+    Bump B;
+    for (int i = 0; i < nw; ++i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        const Pass &S = passes[i];
+        WinLayout &l = L[i];
+        const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+        l.in_Tcw = B.take(64 * NP); l.in_xyz = B.take(12 * NL); l.in_obs = B.take(12 * E); l.in_w = B.take(4 * E);
+        l.e_pose = B.take(4 * E); l.e_point = B.take(4 * E); l.e_stereo = B.take(E);
+        l.k_ph = B.take(4 * E); l.k_lh = B.take(4 * E);
+        l.hpose = B.take(4 * (size_t)S.np + 4); l.hpoint = B.take(4 * (size_t)S.nl + 4);
+        l.pt_off = B.take(4 * ((size_t)S.nl + 1)); l.pt_k = B.take(4 * S.pt_k.size() + 4);
+        l.ps_off = B.take(4 * ((size_t)S.np + 1)); l.ps_k = B.take(4 * S.ps_k.size() + 4);
+        l.pl_off = B.take(4 * ((size_t)S.nl + 1)); l.pl_k = B.take(4 * S.pl_k.size() + 4);
+        l.n_items = S.it_ka.size();
+        l.it_ka = B.take(4 * l.n_items + 4); l.it_kb = B.take(4 * l.n_items + 4); l.it_l = B.take(4 * l.n_items + 4);
+        l.blk_off = B.take(4 * S.blk_off.size() + 4);
     }
-    // final inlier check + write-back (Optimizer.cc:712-778)
-    hipLaunchKernelGGL(k_edge_check, blocks(E, 256), dim3(256), 0, q, D, 0, (double *)(base + o_chi), base + o_out);
-    AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
-    // results come back through the page-locked staging buffer as two spans: [poses | points] and [chi2 | outlier]
-    {
-        const size_t spanA = (o_point - o_pose) + point.size() * 8, spanB = (o_out - o_chi) + (size_t)E;
-        uint8_t *hb = s->h_in.p;
-        const size_t offB = (spanA + 255) & ~(size_t)255;
-        if (offB + spanB > in_cap) {
-            set_error("internal: LocalBA result staging");
-            return AOS2_ERR_ARG;
+    const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
+    const size_t staged_bytes = B.size;
+    for (int i = 0; i < nw; ++i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        const Pass &S = passes[i];
+        WinLayout &l = L[i];
+        const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+        const size_t n6 = 6 * (size_t)S.np, dim = n6 + 3 * (size_t)S.nl;
+        l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
+        l.e_obs = B.take(24 * E); l.e_w = B.take(8 * E); l.robust = B.take(E); l.level1 = B.take(E);
+        l.err = B.take(24 * E);
+        l.JA = B.take(72 * E); l.JB = B.take(144 * E); l.Wr = B.take(24 * E); l.wo = B.take(8 * E); l.Hpl = B.take(144 * E);
+        l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
+        l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
+        l.Hs = B.take(8 * n6 * n6 + 8); l.bs = B.take(8 * n6 + 8);
+        l.W = B.take(288 * l.n_items + 8); l.Wc = B.take(48 * E + 8);
+        l.tmp = B.take(8 * n6 + 8);
+        l.n_part_e = (int)((E + 1023) / 1024);
+        l.n_part_s = std::max(1, (int)((S.nl + 127) / 128));
+        l.scal = B.take(64); l.part = B.take(8 * ((size_t)l.n_part_e + l.n_part_s) + 8);
+        l.npad = (int)((n6 + 15) & ~(size_t)15);
+        const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + l.npad + 64) * 8;
+        l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
+        l.ldlt = B.take(l.ldlt_lds ? 8 : ldlt_bytes);
+    }
+    const size_t o_res = B.take(0);
+    for (int i = 0; i < nw; ++i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        WinLayout &l = L[i];
+        const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+        l.st = B.take(sizeof(LmState), 64);
+        l.out_Tcw = B.take(64 * NP, 64); l.out_xyz = B.take(12 * NL, 64); l.out_outlier = B.take(E, 64);
+        l.out_chi2 = want_chi2 ? B.take(8 * E, 64) : 0;
+    }
+    const size_t res_bytes = B.size - o_res;
+    if ((st = s->arena.alloc(B.size + 256))) return st;
+    if ((st = s->h_in.alloc(staged_bytes + 256))) return st;
+    if ((st = s->h_stage.alloc(res_bytes + 256))) return st;
+    if ((st = s->h_abort.alloc((size_t)nw + 1))) return st;
+    uint8_t *base = s->arena.p, *hin = s->h_in.p;
+    int32_t *d_abort = nullptr;
+    AOS2_HIP_CHECK(hipHostGetDevicePointer((void **)&d_abort, s->h_abort.p, 0));
+    bool any_flag = false;
+    for (int i = 0; i < nw; ++i) {
+        s->h_abort.p[i] = 0;
+        any_flag |= problems[act[i]].stop_flag != nullptr;
+    }
+    lap("layout + arena");
+
+    // ---- staging (parallel) + descriptors
+    LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
+    bool any_lds = false, any_glob = false;
+    int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part_e = 0, mx_part_s = 0, mx_npad_glob = 0, mx_npad_lds = 0;
+    size_t mx_items_bk = 0, mx_blk = 0;
+    for_windows([&](int i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        const Pass &S = passes[i];
+        const WinLayout &l = L[i];
+        const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+        memcpy(hin + l.in_Tcw, p->pose_Tcw, 64 * NP);
+        memcpy(hin + l.in_xyz, p->point_xyz, 12 * NL);
+        memcpy(hin + l.in_obs, p->edge_obs, 12 * E);
+        memcpy(hin + l.in_w, p->edge_inv_sigma2, 4 * E);
+        memcpy(hin + l.e_pose, p->edge_pose, 4 * E);
+        memcpy(hin + l.e_point, p->edge_point, 4 * E);
+        memcpy(hin + l.e_stereo, p->edge_stereo, E);
+        auto put = [&](size_t off, const std::vector<int32_t> &v) {
+            if (!v.empty()) memcpy(hin + off, v.data(), v.size() * 4);
+        };
+        put(l.k_ph, S.k_ph); put(l.k_lh, S.k_lh); put(l.hpose, S.hpose); put(l.hpoint, S.hpoint);
+        put(l.pt_off, S.pt_off); put(l.pt_k, S.pt_k); put(l.ps_off, S.ps_off); put(l.ps_k, S.ps_k);
+        put(l.pl_off, S.pl_off); put(l.pl_k, S.pl_k);
+        put(l.it_ka, S.it_ka); put(l.it_kb, S.it_kb); put(l.it_l, S.it_l); put(l.blk_off, S.blk_off);
+    });
+    for (int i = 0; i < nw; ++i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        const Pass &S = passes[i];
+        const WinLayout &l = L[i];
+        LbaWin &W = hw[i];
+        memset(&W, 0, sizeof(W));
+        W.n_poses = p->n_poses; W.n_points = p->n_points; W.n_edges = p->n_edges;
+        W.np = S.np; W.nl = S.nl; W.n_items = (int)l.n_items;
+        W.iters1 = p->iters_first; W.iters2 = p->iters_second;
+        W.in_Tcw = (const float *)(base + l.in_Tcw); W.in_xyz = (const float *)(base + l.in_xyz);
+        W.in_obs = (const float *)(base + l.in_obs); W.in_w = (const float *)(base + l.in_w);
+        W.pose = (double *)(base + l.est); W.point = W.pose + 7 * (size_t)p->n_poses;
+        W.bk = (double *)(base + l.bk);
+        W.est_n = 7 * p->n_poses + 3 * p->n_points;
+        W.e_pose = (const int32_t *)(base + l.e_pose); W.e_point = (const int32_t *)(base + l.e_point);
+        W.e_obs = (double *)(base + l.e_obs); W.e_w = (double *)(base + l.e_w);
+        W.e_stereo = base + l.e_stereo; W.e_robust = base + l.robust; W.e_level1 = base + l.level1;
+        W.err = (double *)(base + l.err);
+        W.cam.fx = (double)p->fx; W.cam.fy = (double)p->fy; W.cam.cx = (double)p->cx; W.cam.cy = (double)p->cy;
+        W.cam.bf = (double)p->bf; W.cam.bf_f = p->bf;
+        W.cam.delta_mono = (double)(float)std::sqrt(5.991);
+        W.cam.delta_stereo = (double)(float)std::sqrt(7.815);
+        W.k_ph = (const int32_t *)(base + l.k_ph); W.k_lh = (const int32_t *)(base + l.k_lh);
+        W.hpose = (const int32_t *)(base + l.hpose); W.hpoint = (const int32_t *)(base + l.hpoint);
+        W.pt_off = (const int32_t *)(base + l.pt_off); W.pt_k = (const int32_t *)(base + l.pt_k);
+        W.ps_off = (const int32_t *)(base + l.ps_off); W.ps_k = (const int32_t *)(base + l.ps_k);
+        W.pl_off = (const int32_t *)(base + l.pl_off); W.pl_k = (const int32_t *)(base + l.pl_k);
+        W.it_ka = (const int32_t *)(base + l.it_ka); W.it_kb = (const int32_t *)(base + l.it_kb);
+        W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
+        W.JA = (double *)(base + l.JA); W.JB = (double *)(base + l.JB); W.Wr = (double *)(base + l.Wr);
+        W.wo = (double *)(base + l.wo); W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
+        W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
+        W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
+        W.W = (double *)(base + l.W); W.Wc = (double *)(base + l.Wc);
+        W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
+        W.n_part_e = l.n_part_e; W.n_part_s = l.n_part_s;
+        W.ldlt = (double *)(base + l.ldlt); W.npad = l.npad; W.ldlt_lds = l.ldlt_lds;
+        W.st = (LmState *)(base + l.st);
+        W.abort_word = d_abort + i;
+        W.out_Tcw = (float *)(base + l.out_Tcw); W.out_xyz = (float *)(base + l.out_xyz);
+        W.out_outlier = base + l.out_outlier;
+        W.out_chi2 = want_chi2 ? (double *)(base + l.out_chi2) : nullptr;
+        if (S.np > 0) {
+            if (l.ldlt_lds) {
+                any_lds = true;
+                mx_npad_lds = std::max(mx_npad_lds, l.npad);
+            } else {
+                any_glob = true;
+                mx_npad_glob = std::max(mx_npad_glob, l.npad);
+            }
         }
-        AOS2_HIP_CHECK(hipMemcpyAsync(hb, base + o_pose, spanA, hipMemcpyDeviceToHost, q));
-        AOS2_HIP_CHECK(hipMemcpyAsync(hb + offB, base + o_chi, spanB, hipMemcpyDeviceToHost, q));
+        mx_E = std::max(mx_E, p->n_edges);
+        mx_np = std::max(mx_np, S.np);
+        mx_nl = std::max(mx_nl, S.nl);
+        mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
+        mx_part_e = std::max(mx_part_e, l.n_part_e);
+        mx_part_s = std::max(mx_part_s, l.n_part_s);
+        mx_items_bk = std::max(mx_items_bk, l.n_items + (size_t)W.est_n);
+        mx_blk = std::max(mx_blk, (size_t)S.np * (S.np + 1) / 2 + S.np);
+    }
+    lap("staging");
+    hipStream_t q = s->stream;
+    AOS2_HIP_CHECK(hipMemcpyAsync(base, hin, staged_bytes, hipMemcpyHostToDevice, q));
+    AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
+    const LbaWin *dw = (const LbaWin *)(base + o_wins);
+    auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
+    const dim3 g_edges128(blocks(mx_E, 128), nw), g_edges256(blocks(mx_E, 256), nw);
+    auto enqueue_init = [&]() {
+        hipLaunchKernelGGL(k_errors, dim3(mx_part_e, nw), dim3(1024), 0, q, dw, 1);
+        hipLaunchKernelGGL(k_linearize, g_edges128, dim3(128), 0, q, dw, 1);
+        hipLaunchKernelGGL(k_accum_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, 1);
+        if (mx_np) hipLaunchKernelGGL(k_accum_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, 1);
+        hipLaunchKernelGGL(k_lm_init, dim3(nw), dim3(1024), 0, q, dw);
+    };
+    auto enqueue_trial = [&]() {
+        hipLaunchKernelGGL(k_schur_items, dim3(blocks(mx_items_bk, 128), nw), dim3(128), 0, q, dw);
+        if (mx_np) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)mx_blk, nw), dim3(512), 0, q, dw);
+        if (any_lds) {
+            const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + mx_npad_lds + 64) * sizeof(double);
+            hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(nw), dim3(256), need, q, dw);
+        }
+        if (any_glob) {
+            hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(nw), dim3(1024), (size_t)mx_npad_glob * sizeof(double), q, dw);
+            hipLaunchKernelGGL(k_update_poses, dim3(blocks(mx_np, 64), nw), dim3(64), 0, q, dw);
+        }
+        hipLaunchKernelGGL(k_backsub_points, dim3(mx_part_s, nw), dim3(128), 0, q, dw);
+        hipLaunchKernelGGL(k_errors, dim3(mx_part_e, nw), dim3(1024), 0, q, dw, 0);
+        hipLaunchKernelGGL(k_decide, dim3(nw), dim3(1024), 0, q, dw);
+        hipLaunchKernelGGL(k_linearize, g_edges128, dim3(128), 0, q, dw, 0);
+        hipLaunchKernelGGL(k_accum_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, 0);
+        if (mx_np) hipLaunchKernelGGL(k_accum_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, 0);
+    };
+    auto enqueue_transition = [&]() {
+        hipLaunchKernelGGL(k_trans_a, dim3(nw), dim3(1), 0, q, dw);
+        hipLaunchKernelGGL(k_edge_mark, g_edges256, dim3(256), 0, q, dw);
+        hipLaunchKernelGGL(k_trans_b, dim3(nw), dim3(1), 0, q, dw);
+    };
+    // results (and states) come back as one copy; the host forwards pbStopFlag into the mapped abort words meanwhile
+    auto finish = [&]() -> int {
+        hipLaunchKernelGGL(k_final, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw);
+        AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
+        AOS2_HIP_CHECK(hipMemcpyAsync(s->h_stage.p, base + o_res, res_bytes, hipMemcpyDeviceToHost, q));
+        if (any_flag) {
+            AOS2_HIP_CHECK(hipEventRecord(s->ev[2], q));
+            while (hipEventQuery(s->ev[2]) == hipErrorNotReady)
+                for (int i = 0; i < nw; ++i)
+                    if (stop_requested(problems + act[i])) __atomic_store_n(&s->h_abort.p[i], 1, __ATOMIC_RELAXED);
+        }
         AOS2_HIP_CHECK(hipStreamSynchronize(q));
         AOS2_HIP_CHECK(hipGetLastError());
-        const double *rp = reinterpret_cast<const double *>(hb), *rx = reinterpret_cast<const double *>(hb + (o_point - o_pose));
-        for (int i = 0; i < NP; ++i) pose_to_Tcw(rp + 7 * (size_t)i, r->pose_Tcw + 16 * (size_t)i);
-        for (size_t i = 0; i < 3 * (size_t)NL; ++i) r->point_xyz[i] = (float)rx[i];
-        if (r->edge_chi2) memcpy(r->edge_chi2, hb + offB, (size_t)E * 8);
-        if (r->edge_outlier) memcpy(r->edge_outlier, hb + offB + (o_out - o_chi), E);
+        return AOS2_OK;
+    };
+    int max_i1 = 0, max_i2 = 0;
+    for (int i = 0; i < nw; ++i) {
+        max_i1 = std::max(max_i1, problems[act[i]].iters_first);
+        max_i2 = std::max(max_i2, problems[act[i]].iters_second);
     }
-    r->final_chi2 = last_chi;
-    r->final_lambda = lambda;
-    (void)hipEventElapsedTime(&r->ms_device, s->ev[0], s->ev[1]);
-    lap("final check + write-back");
+    // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
+    hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw, s->debug_stop_at_poll);
+    hipLaunchKernelGGL(k_begin, dim3(nw), dim3(1), 0, q, dw);
+    if (max_i1 > 0) {
+        enqueue_init();
+        for (int t = 0; t < max_i1 + 1; ++t) enqueue_trial();
+    }
+    enqueue_transition();
+    if (max_i2 > 0) {
+        enqueue_init();
+        for (int t = 0; t < max_i2 + 1; ++t) enqueue_trial();
+    }
+    if ((st = finish())) return st;
+    lap("program");
+    auto state_of = [&](int i) { return reinterpret_cast<const LmState *>(s->h_stage.p + (L[i].st - o_res)); };
+    for (int round = 0;; ++round) {
+        bool all = true;
+        for (int i = 0; i < nw; ++i) all &= state_of(i)->phase == 3;
+        if (all) break;
+        if (round > 64) {   // 2 x 10 iterations x 10 trials at most: cannot happen
+            set_error("internal: LocalBA program did not finish");
+            return AOS2_ERR_ARG;
+        }
+        enqueue_transition();
+        enqueue_init();
+        for (int t = 0; t < 4; ++t) enqueue_trial();
+        if ((st = finish())) return st;
+    }
+    lap("continuation");
+    if (getenv("AOS2_LBA_TRACE"))
+        for (int i = 0; i < nw; ++i) {
+            const LmState *ls = state_of(i);
+            for (int t = 0; t < ls->ntr; ++t)
+                fprintf(stderr, "[lba] win %d trial %2d lambda %.6e chi %.9e -> %.9e rho %.6e\n", i, t, ls->tr_lambda[t], ls->tr_cur[t], ls->tr_temp[t], ls->tr_rho[t]);
+        }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]);
+    for (int i = 0; i < nw; ++i) {
+        const aos2_lba_problem_t *p = problems + act[i];
+        aos2_lba_result_t *r = results + act[i];
+        const WinLayout &l = L[i];
+        const uint8_t *hb = s->h_stage.p;
+        const LmState *ls = state_of(i);
+        memcpy(r->pose_Tcw, hb + (l.out_Tcw - o_res), 64 * (size_t)p->n_poses);
+        memcpy(r->point_xyz, hb + (l.out_xyz - o_res), 12 * (size_t)p->n_points);
+        if (r->edge_outlier) memcpy(r->edge_outlier, hb + (l.out_outlier - o_res), (size_t)p->n_edges);
+        if (r->edge_chi2) memcpy(r->edge_chi2, hb + (l.out_chi2 - o_res), 8 * (size_t)p->n_edges);
+        r->iters_done_first = ls->iters_done[0];
+        r->iters_done_second = ls->iters_done[1];
+        r->trials_first = ls->trials[0];
+        r->trials_second = ls->trials[1];
+        r->final_chi2 = ls->final_chi2;
+        r->final_lambda = ls->final_lambda;
+        r->polls = ls->polls;
+        r->stop_poll = ls->stop_poll;
+        r->ms_device = ms;
+    }
+    lap("write-back");
     return AOS2_OK;
 }
 
-int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, aos2_pose_result_t *results, int n_problems)
+int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r)
 {
-    if (!s || !problems || !results || n_problems <= 0) {
-        set_error("bad argument");
+    if (!s || !p || !r) {
+        set_error("bad LocalBA problem");
         return AOS2_ERR_ARG;
     }
-    for (int i = 0; i < n_problems; ++i)
-        if (problems[i].n < 0 || (problems[i].n > 0 && (!problems[i].Xw || !problems[i].obs || !problems[i].stereo ||
-                                                        !problems[i].inv_sigma2 || !results[i].outlier))) {
-            set_error("bad pose problem %d", i);
-            return AOS2_ERR_ARG;
-        }
-    int st = lba_init(s);
-    if (st) return st;
-    // Inputs are converted in place into the handle's page-locked staging buffer (one asynchronous upload that
-    // also carries the problem descriptors); the results of all problems -- pose, counts, outlier flags -- are
-    // neighbours in the arena and come back as ONE copy (the former three small pageable copies per problem cost
-    // 2 ms of host time for 64 frames, against 0.55 ms of kernel).
-    HostArena H;
-    struct Off { size_t xw, obs, w, st, err, l1, rb, out, pose, cnt; };
-    std::vector<Off> offs(n_problems);
-    size_t in_cap = sizeof(PoseProbDev) * (size_t)n_problems + 512;
-    for (int i = 0; i < n_problems; ++i) in_cap += (size_t)problems[i].n * (24 + 24 + 8 + 1) + 4 * 256 + 32;
-    if ((st = s->h_in.alloc(in_cap))) return st;
-    H.host = s->h_in.p;
-    H.host_cap = in_cap;
-    for (int i = 0; i < n_problems; ++i) {
-        const aos2_pose_problem_t &p = problems[i];
-        const size_t n = (size_t)p.n;
-        double *xw = H.push_fill<double>(3 * n + 1, offs[i].xw), *ob = H.push_fill<double>(3 * n + 1, offs[i].obs);
-        double *w = H.push_fill<double>(n + 1, offs[i].w);
-        uint8_t *sv = H.push_fill<uint8_t>(n + 1, offs[i].st);
-        if (!xw || !ob || !w || !sv) {
-            set_error("internal: pose optimisation input staging");
-            return AOS2_ERR_ARG;
-        }
-        for (size_t k = 0; k < 3 * n; ++k) xw[k] = (double)p.Xw[k];
-        for (size_t k = 0; k < 3 * n; ++k) ob[k] = (double)p.obs[k];
-        for (size_t k = 0; k < n; ++k) w[k] = (double)p.inv_sigma2[k];
-        xw[3 * n] = ob[3 * n] = w[n] = 0.0;
-        if (n) memcpy(sv, p.stereo, n);
-        sv[n] = 0;
-    }
-    size_t o_probs;
-    PoseProbDev *dev = H.push_fill<PoseProbDev>((size_t)n_problems, o_probs);   // filled below (needs the device base)
-    if (!dev) {
-        set_error("internal: pose optimisation input staging");
-        return AOS2_ERR_ARG;
-    }
-    const size_t in_bytes = H.host_size;
-    for (int i = 0; i < n_problems; ++i) {
-        const size_t n = (size_t)problems[i].n;
-        offs[i].err = H.push(nullptr, (3 * n + 1) * 8);
-        offs[i].l1 = H.push(nullptr, n + 1);
-        offs[i].rb = H.push(nullptr, n + 1);
-    }
-    const size_t o_res = (H.size + 255) & ~(size_t)255;   // results of all problems from here on
-    for (int i = 0; i < n_problems; ++i) {
-        offs[i].pose = H.push(nullptr, 7 * 8);
-        offs[i].cnt = H.push(nullptr, 8);
-        offs[i].out = H.push(nullptr, (size_t)problems[i].n + 1);
-    }
-    const size_t res_bytes = H.size - o_res;
-    if ((st = s->arena.alloc(H.size + 256))) return st;
-    if ((st = s->h_stage.alloc(res_bytes + 64))) return st;
-    uint8_t *base = s->arena.p;
-    for (int i = 0; i < n_problems; ++i) {
-        const aos2_pose_problem_t &p = problems[i];
-        PoseProbDev &D = dev[i];
-        D.n = p.n;
-        D.Xw = (const double *)(base + offs[i].xw); D.obs = (const double *)(base + offs[i].obs);
-        D.w = (const double *)(base + offs[i].w); D.stereo = base + offs[i].st;
-        D.err = (double *)(base + offs[i].err); D.level1 = base + offs[i].l1; D.robust = base + offs[i].rb;
-        D.outlier = base + offs[i].out; D.pose_out = (double *)(base + offs[i].pose); D.counts = (int32_t *)(base + offs[i].cnt);
-        D.fx = (double)p.fx; D.fy = (double)p.fy; D.cx = (double)p.cx; D.cy = (double)p.cy; D.bf = (double)p.bf;
-        pose_from_Tcw(p.Tcw, D.pose_in);
-    }
-    hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, H.data(), in_bytes, hipMemcpyHostToDevice, q));
-    AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
-    int max_n = 0;
-    for (int i = 0; i < n_problems; ++i) max_n = std::max(max_n, problems[i].n);
-    const size_t po_lds = (256 * 28 + 9 * 27) * sizeof(double);
-    if (max_n <= 256 * 4)   // the usual case (a frame has <= ~1000 map-point matches): edges live in registers
-        hipLaunchKernelGGL(pose_optimization_kernel<4>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
-    else
-        hipLaunchKernelGGL(pose_optimization_kernel<0>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
-    AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
-    const uint8_t *res = s->h_stage.p;
-    AOS2_HIP_CHECK(hipMemcpyAsync(s->h_stage.p, base + o_res, res_bytes, hipMemcpyDeviceToHost, q));
-    AOS2_HIP_CHECK(hipStreamSynchronize(q));
-    AOS2_HIP_CHECK(hipGetLastError());
-    (void)hipEventElapsedTime(&s->last_pose_ms, s->ev[0], s->ev[1]);
-    for (int i = 0; i < n_problems; ++i) {
-        const double *pose = reinterpret_cast<const double *>(res + (offs[i].pose - o_res));
-        const int32_t *cnt = reinterpret_cast<const int32_t *>(res + (offs[i].cnt - o_res));
-        if (problems[i].n > 0) memcpy(results[i].outlier, res + (offs[i].out - o_res), (size_t)problems[i].n);
-        if (problems[i].n < 3)   // the reference returns before touching mTcw (:355-356): keep the caller's matrix bit for bit
-            memcpy(results[i].Tcw, problems[i].Tcw, sizeof(float) * 16);
-        else
-            pose_to_Tcw(pose, results[i].Tcw);
-        results[i].n_bad = cnt[0];
-        results[i].n_inliers = cnt[1];
-    }
-    return AOS2_OK;
+    const int st = aos2_lba_solve_batch(s, p, r, 1);
+    return st ? st : r->status;
 }
-
-float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s) { return s ? s->last_pose_ms : 0.f; }
 
 }  // extern "C"

@@ -540,10 +540,14 @@ typedef struct {
     float *point_xyz;        /* n_points x 3 out (:776) */
     uint8_t *edge_outlier;   /* n_edges out: observation to erase (:712-744) */
     double *edge_chi2;       /* n_edges out (may be NULL): e->chi2() at the end */
-    int32_t iters_done_first, iters_done_second;
+    int32_t iters_done_first, iters_done_second;  /* iterations SparseOptimizer::optimize() ran (its return value) */
     double final_chi2;       /* robust chi2 of the active edges after the last accepted step */
     double final_lambda;
-    float ms_device;         /* device time of the whole solve (HIP events) */
+    float ms_device;         /* device time of the whole call (HIP events; all windows of a batch) */
+    int32_t status;          /* AOS2_OK or AOS2_ERR_STOPPED (flag set on entry: outputs equal inputs) */
+    int32_t trials_first, trials_second;  /* Levenberg-Marquardt trial steps (solves) of the two optimisations */
+    int32_t polls;           /* evaluations of pbStopFlag (SparseOptimizer::terminate()), the entry check included */
+    int32_t stop_poll;       /* the evaluation that first saw the flag set, 0 = never */
 } aos2_lba_result_t;
 
 typedef struct aos2_lba aos2_lba_t;
@@ -551,8 +555,23 @@ int aos2_lba_create(int device, aos2_lba_t **out);
 void aos2_lba_destroy(aos2_lba_t *s);
 /* void Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*)  numerical part.
  * Returns AOS2_OK, AOS2_ERR_STOPPED if *stop_flag was set on entry (early return, :656-658;
- * outputs then equal inputs), or an error. */
+ * outputs then equal inputs), or an error.
+ * The whole procedure (both optimisations, the outlier pass, the inlier check) runs on the device without a host
+ * round trip per Levenberg-Marquardt trial; *stop_flag is forwarded to the device while the call waits and is
+ * evaluated exactly where g2o evaluates terminate() (optimization_algorithm_levenberg.cpp:149,
+ * sparse_optimizer.cpp:372) and where Optimizer.cc:663-666 reads it.  Any number of free keyframes: the reduced camera
+ * system is factorised in LDS up to 21 of them, in device memory beyond. */
 int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t *r);
+/* `n_problems` independent windows (several maps, or an offline pass over many windows; SURVEY.md section 8(e):
+ * LocalBA = replicas only) in one call: every kernel covers all windows, so their latency-bound Levenberg-Marquardt
+ * chains overlap on the device.  results[i].status carries the per-window AOS2_OK / AOS2_ERR_STOPPED; the return
+ * value is AOS2_OK unless an argument or HIP error occurred. */
+int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2_lba_result_t *results,
+                         int n_problems);
+/* Test hook (no reference equivalent): the stop flag counts as set from its `poll`-th evaluation on (1 = the entry
+ * check), as if another thread had set it at that moment; 0 switches the hook off.  Used with
+ * aos2_lba_result_t.stop_poll to reproduce an asynchronous abort deterministically. */
+int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization  (include/Optimizer.h:47, src/Optimizer.cc:239-452) -- SURVEY §8(f)

@@ -260,6 +260,7 @@ typedef struct {
     double *bk_pose, *bk_point, *bk_dpp, *bk_dll;
     double lambda, ni;
     int nBad;
+    int polls, stop_poll, trials; /* evaluations of terminate(); the one that first saw the flag; LM trial steps */
 } lba_t;
 
 static double edge_chi2(const lba_t *S, int e)
@@ -626,7 +627,19 @@ static void apply_update(lba_t *S)
     }
 }
 
-static int terminate_flag(const lba_t *S) { return S->p->stop_flag ? (*S->p->stop_flag != 0) : 0; }
+/* bool SparseOptimizer::terminate() (reads *_forceStopFlag).  Test hook: stop_at_poll > 0 makes the flag count as set
+ * from that evaluation on, as if another thread (LocalMapping::InterruptBA, src/LocalMapping.cc:118-123) had set it
+ * at that moment; the evaluations are counted so that an asynchronous abort of the device path can be replayed. */
+static int terminate_flag(lba_t *S)
+{
+    S->polls++;
+    int set = S->stop_poll > 0;
+    if (!set && ((S->p->stop_flag && *S->p->stop_flag != 0) || (S->p->stop_at_poll > 0 && S->polls >= S->p->stop_at_poll))) {
+        S->stop_poll = S->polls;
+        set = 1;
+    }
+    return set;
+}
 
 enum { LM_OK = 0, LM_TERMINATE = 1, LM_FAIL = -1 };
 
@@ -653,6 +666,7 @@ static int lm_solve(lba_t *S, int iteration, orc_lba_result_t *res)
     const int maxTrials = 10;
     size_t dim = 6 * (size_t)S->np + 3 * (size_t)S->nl;
     do {
+        S->trials++;
         push_state(S);
         set_lambda(S, S->lambda);
         int ok2 = solve_schur(S);
@@ -725,7 +739,7 @@ int orc_lba_solve(orc_lba_problem_t *p, orc_lba_result_t *r)
     memset(S.robust, 1, p->n_edges + 1);
     S.pose_hidx = (int *)malloc(sizeof(int) * (p->n_poses + 1));
     S.point_hidx = (int *)malloc(sizeof(int) * (p->n_points + 1));
-    if (r) { r->n_trace = 0; r->iters_done1 = r->iters_done2 = 0; }
+    if (r) { r->n_trace = 0; r->iters_done1 = r->iters_done2 = 0; r->polls = r->stop_poll = r->trials = 0; }
     int status = 0;
     if (terminate_flag(&S)) { status = 1; goto done; } /* :656-658 early return */
     if (initialize_optimization(&S) == 0) {
@@ -755,6 +769,7 @@ int orc_lba_solve(orc_lba_problem_t *p, orc_lba_result_t *r)
         }
     }
 done:
+    if (r) { r->polls = S.polls; r->stop_poll = S.stop_poll; r->trials = S.trials; }
     free_structure(&S);
     free(S.err); free(S.level1); free(S.robust); free(S.pose_hidx); free(S.point_hidx);
     return status;

@@ -616,14 +616,16 @@ class _LbaProblem(C.Structure):
                 ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_obs", C.c_void_p),
                 ("edge_stereo", C.c_void_p), ("edge_inv_sigma2", C.c_void_p),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("bf", C.c_double), ("stop_flag", C.c_void_p), ("iters1", C.c_int), ("iters2", C.c_int)]
+                ("bf", C.c_double), ("stop_flag", C.c_void_p), ("iters1", C.c_int), ("iters2", C.c_int),
+                ("stop_at_poll", C.c_int)]
 
 
 class _LbaResult(C.Structure):
     _fields_ = [("edge_chi2", C.c_void_p), ("edge_depth_pos", C.c_void_p), ("edge_outlier", C.c_void_p),
                 ("edge_level1", C.c_void_p), ("lambda_trace", C.c_double * 64),
                 ("chi2_trace", C.c_double * 64), ("n_trace", C.c_int),
-                ("iters_done1", C.c_int), ("iters_done2", C.c_int)]
+                ("iters_done1", C.c_int), ("iters_done2", C.c_int), ("polls", C.c_int), ("stop_poll", C.c_int),
+                ("trials", C.c_int)]
 
 
 def pose_from_Tcw(T16):
@@ -640,7 +642,7 @@ def pose_to_Tcw(qt):
     return T
 
 
-def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
+def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None, stop_at_poll=0):
     """Runs the LocalBA numerical core on a synth_lba_problem()-style dict with float32 inputs.
     Returns dict with float32 write-back poses/points like Optimizer.cc:763-778."""
     n_poses, n_points, n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
@@ -665,6 +667,7 @@ def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
         keep.append(stop_flag)
         s.stop_flag = stop_flag.ctypes.data
     s.iters1, s.iters2 = iters1, iters2
+    s.stop_at_poll = int(stop_at_poll)
     r = _LbaResult()
     chi2 = np.zeros(n_edges, np.float64)
     dpos = np.zeros(n_edges, np.uint8)
@@ -676,7 +679,7 @@ def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None):
     return dict(status=st, pose_qt=qt, pose_Tcw=Tout, point_xyz=pts.astype(np.float32), point_xyz64=pts,
                 edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier=outl, edge_level1=lvl1,
                 lambda_trace=np.array(r.lambda_trace[: r.n_trace]), chi2_trace=np.array(r.chi2_trace[: r.n_trace]),
-                iters=(r.iters_done1, r.iters_done2))
+                iters=(r.iters_done1, r.iters_done2), polls=r.polls, stop_poll=r.stop_poll, trials=r.trials)
 
 
 class _PoseProblem(C.Structure):

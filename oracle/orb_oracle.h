@@ -273,6 +273,7 @@ typedef struct {
     double fx, fy, cx, cy, bf;
     const volatile uint8_t *stop_flag; /* may be NULL */
     int iters1, iters2;        /* 5, 10 */
+    int stop_at_poll;          /* test hook, 0 = off: see terminate_flag() */
 } orc_lba_problem_t;
 
 typedef struct {
@@ -284,6 +285,7 @@ typedef struct {
     double chi2_trace[64];      /* robust chi2 after each outer iteration */
     int n_trace;
     int iters_done1, iters_done2;
+    int polls, stop_poll, trials; /* evaluations of terminate(), the first that saw the flag set (0 = none), LM trial steps */
 } orc_lba_result_t;
 int orc_lba_solve(orc_lba_problem_t *p, orc_lba_result_t *r);
 
