@@ -81,13 +81,12 @@ struct LbaWin {
     // Schur complement by items: item = (landmark, free-pose edges ka <= kb of it), ranked by (pose, pose) block in
     // upper-triangular order, landmark order inside a block (build_schur_items)
     const int32_t *it_ka, *it_kb, *it_l, *blk_off;
-    double *JA, *JB, *Wr, *wo, *Hpl; // per edge: 9, 18, 3, 1, 18
+    double *Hpl;                     // per edge: the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
-    double *W, *Wc;                  // W[36][n_items] (B_a Dinv B_b^T, element-major); per edge: 6 (B_a Dinv b_l)
     double *tmp;                     // scale terms of the poses (6 np)
-    double *scal;                    // [2] max diag, [3] solve ok
-    double *part;                    // per-workgroup sums: n_part_e of k_errors, then n_part_s of k_backsub_points
-    int n_part_e, n_part_s;
+    double *scal;                    // [3] solve ok
+    double *part;                    // per-workgroup sums of k_points: chi2 terms [0, n_part), scale terms [n_part, 2 n_part)
+    int n_part;
     double *ldlt;                    // factorisation scratch of the global-memory variant
     int npad, ldlt_lds;
     LmState *st;
@@ -110,19 +109,26 @@ __device__ inline bool lm_poll(LmState *st, const int32_t *abort_word)
     return false;
 }
 
-// Sum of one value per thread of an N-thread workgroup (binary tree in LDS, fixed order) -> out[blockIdx.x]
+// Sums of two values per thread of an N-thread workgroup (binary trees in LDS, fixed order) -> out0[blockIdx.x], out1[blockIdx.x]
 template <int N>
-__device__ __forceinline__ void workgroup_sum(double v, double *out)
+__device__ __forceinline__ void workgroup_sum2(double v0, double v1, double *out0, double *out1)
 {
-    __shared__ double sh[N];
-    sh[threadIdx.x] = v;
+    __shared__ double sh[2][N];
+    sh[0][threadIdx.x] = v0;
+    sh[1][threadIdx.x] = v1;
     __syncthreads();
 #pragma unroll
     for (int s = N / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + s];
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] = sh[0][threadIdx.x] + sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] = sh[1][threadIdx.x] + sh[1][threadIdx.x + s];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) {
+        out0[blockIdx.x] = sh[0][0];
+        out1[blockIdx.x] = sh[1][0];
+    }
 }
 
 // Converter::toSE3Quat / toVector3d and the float -> double copies of Optimizer.cc:523-525, 552-553, 597-606
@@ -168,99 +174,93 @@ __global__ void k_begin(const LbaWin *__restrict__ wins)
         st->initp = 1;
 }
 
-// computeActiveErrors + per-edge robust chi2 (sparse_optimizer.cpp:61-114); 1024-thread workgroups, the chi2 terms of
-// workgroup g are added into part[g].  init != 0: the call at the top of solve() in iteration 0.
-__global__ __launch_bounds__(1024) void k_errors(const LbaWin *__restrict__ wins, int init)
+// EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ::computeError (types_six_dof_expmap.h:80-141) with the camera point given
+__device__ __forceinline__ void edge_error(const Cam &cam, const double p[3], const double *obs, int stereo, double er[3])
 {
-    const LbaWin &W = wins[blockIdx.y];
-    if (!(init ? W.st->initp : W.st->run) || (int)blockIdx.x >= W.n_part_e) return;
-    const int e = blockIdx.x * 1024 + threadIdx.x;
-    double c = 0;
-    if (e < W.n_edges && !W.e_level1[e]) {
-        const double *T = W.pose + 7 * (size_t)W.e_pose[e];
-        const double *X = W.point + 3 * (size_t)W.e_point[e];
-        const double *obs = W.e_obs + 3 * (size_t)e;
-        double p[3], er[3];
-        se3_map(T, X, p);
-        const int stereo = W.e_stereo[e];
-        if (!stereo) {
-            const double u = p[0] / p[2], v = p[1] / p[2];
-            er[0] = obs[0] - (u * W.cam.fx + W.cam.cx);
-            er[1] = obs[1] - (v * W.cam.fy + W.cam.cy);
-            er[2] = 0;
-        } else {
-            const float invz = (float)(1.0 / p[2]);
-            const double r0 = p[0] * invz * W.cam.fx + W.cam.cx;
-            const double r1 = p[1] * invz * W.cam.fy + W.cam.cy;
-            const double r2 = r0 - (double)__fmul_rn(W.cam.bf_f, invz);
-            er[0] = obs[0] - r0;
-            er[1] = obs[1] - r1;
-            er[2] = obs[2] - r2;
-        }
-        double *dst = W.err + 3 * (size_t)e;
-        dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-        c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
-        if (W.e_robust[e]) {
-            double rho[2];
-            robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
-            c = rho[0];
-        }
+    if (!stereo) {
+        const double u = p[0] / p[2], v = p[1] / p[2];
+        er[0] = obs[0] - (u * cam.fx + cam.cx);
+        er[1] = obs[1] - (v * cam.fy + cam.cy);
+        er[2] = 0;
+    } else {
+        const float invz = (float)(1.0 / p[2]);
+        const double r0 = p[0] * invz * cam.fx + cam.cx;
+        const double r1 = p[1] * invz * cam.fy + cam.cy;
+        const double r2 = r0 - (double)__fmul_rn(cam.bf_f, invz);
+        er[0] = obs[0] - r0;
+        er[1] = obs[1] - r1;
+        er[2] = obs[2] - r2;
     }
-    workgroup_sum<1024>(c, W.part);
 }
 
-// linearizeOplus + the per-edge part of constructQuadraticForm
-__global__ __launch_bounds__(128) void k_linearize(const LbaWin *__restrict__ wins, int init)
+// One thread per landmark, 128-thread workgroups.  solve = 1 (a Levenberg-Marquardt trial): the landmark's part of
+// BlockSolver::solve -- xl = (Hll + lambda I)^-1 (bl - B^T xp), block_solver.hpp:455-480 -- and of
+// SparseOptimizer::update (X += xl), its scale terms x_j (lambda x_j + b_j), then computeActiveErrors +
+// activeRobustChi2 (sparse_optimizer.cpp:61-114) of the landmark's edges at the new estimates (the poses were
+// updated by the kernel before).  solve = 0 (top of solve() in iteration 0): the residuals only.
+// Workgroup g leaves its chi2 terms in part[g] and its scale terms in part[n_part + g]; workgroup 0 adds the scale
+// terms of the poses (tmp[0 .. 6 np)).
+__global__ __launch_bounds__(128) void k_points(const LbaWin *__restrict__ wins, int solve)
 {
     const LbaWin &W = wins[blockIdx.y];
-    if (!(init ? W.st->initp : W.st->lin)) return;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= W.n_edges) return;
-    double *ja = W.JA + 9 * (size_t)k, *jb = W.JB + 18 * (size_t)k;
-    if (W.e_level1[k]) {   // masked: contributes +0.0 to every sum
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ja[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) jb[i] = 0;
-        W.Wr[3 * (size_t)k] = 0; W.Wr[3 * (size_t)k + 1] = 0; W.Wr[3 * (size_t)k + 2] = 0;
-        W.wo[k] = 0;
-        if (W.k_ph[k] >= 0) {
-            double *h = W.Hpl + 18 * (size_t)k;
-#pragma unroll
-            for (int i = 0; i < 18; ++i) h[i] = 0;
-        }
-        return;
-    }
-    const double *T = W.pose + 7 * (size_t)W.e_pose[k];
-    const double *X = W.point + 3 * (size_t)W.e_point[k];
-    const int stereo = W.e_stereo[k];
-    const int D = stereo ? 3 : 2;
-    const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
-    double p[3], R[9];
-    se3_map(T, X, p);
-    rot_from_quat(T, R);
-    const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
-    double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Jb[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) Jb[i] = 0;
-    if (!stereo) {
-        const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-        const double s = -1. / z;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
-                Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
+    if (!(solve ? W.st->run : W.st->initp) || (int)blockIdx.x >= W.n_part) return;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n6 = 6 * W.np;
+    double sc = 0, chi = 0;
+    if (solve && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n6; i += 128) sc += W.tmp[i];
+    if (l < W.nl) {
+        double *X = W.point + 3 * (size_t)W.hpoint[l];
+        double Xv[3] = {X[0], X[1], X[2]};
+        if (solve) {
+            const double lambda = W.st->lambda;
+            double cl[3] = {W.b[n6 + 3 * l], W.b[n6 + 3 * l + 1], W.b[n6 + 3 * l + 2]};
+            for (int a = W.pl_off[l]; a < W.pl_off[l + 1]; ++a) {
+                const int ka = W.pl_k[a];
+                const int i1 = W.k_ph[ka];
+                const double *Bi = W.Hpl + 18 * (size_t)ka;
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-W.x[6 * i1 + r]);
             }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
-            Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
-            Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
+            // (Hll + lambda I)^-1: the same operations as in the Schur kernel, so the same bits
+            double Dm[9], Dinv[9];
+            for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
+            Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+            mat3_inverse(Dm, Dinv);
+            for (int r = 0; r < 3; ++r) {
+                const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
+                W.x[n6 + 3 * l + r] = xl;
+                Xv[r] += xl;
+                X[r] = Xv[r];
+                sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
+            }
+        }
+        for (int a = W.pt_off[l]; a < W.pt_off[l + 1]; ++a) {
+            const int e = W.pt_k[a];
+            if (W.e_level1[e]) continue;   // an inactive edge keeps its _error
+            double p[3], er[3];
+            se3_map(W.pose + 7 * (size_t)W.e_pose[e], Xv, p);
+            const int stereo = W.e_stereo[e];
+            edge_error(W.cam, p, W.e_obs + 3 * (size_t)e, stereo, er);
+            double *dst = W.err + 3 * (size_t)e;
+            dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+            double c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
+            if (W.e_robust[e]) {
+                double rho[2];
+                robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+                c = rho[0];
+            }
+            chi += c;
         }
     }
+    workgroup_sum2<128>(chi, sc, W.part, W.part + W.n_part);
+}
+
+// J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6
+__device__ __forceinline__ void jac_pose(const Cam &cam, const double p[3], int stereo, double Jb[18])
+{
+    const double fx = cam.fx, fy = cam.fy, bf = cam.bf;
+    const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
     Jb[0] = x * y / z_2 * fx;
     Jb[1] = -(1 + (x * x / z_2)) * fx;
     Jb[2] = y / z * fx;
@@ -273,6 +273,8 @@ __global__ __launch_bounds__(128) void k_linearize(const LbaWin *__restrict__ wi
     Jb[9] = 0;
     Jb[10] = -1. / z * fy;
     Jb[11] = y / z_2 * fy;
+#pragma unroll
+    for (int i = 12; i < 18; ++i) Jb[i] = 0;
     if (stereo) {
         Jb[12] = Jb[0] - bf * y / z_2;
         Jb[13] = Jb[1] + bf * x / z_2;
@@ -281,79 +283,131 @@ __global__ __launch_bounds__(128) void k_linearize(const LbaWin *__restrict__ wi
         Jb[16] = 0;
         Jb[17] = Jb[5] - bf / z_2;
     }
+}
+
+// robustified information of an edge (BaseBinaryEdge::constructQuadraticForm, base_binary_edge.hpp:55-120):
+// omr = -rho' Omega e, wo = rho' * w
+__device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo, double omr[3], double &wo)
+{
     const double *er = W.err + 3 * (size_t)k;
     const double w = W.e_w[k];
-    // static indices only (a runtime-length loop over D would put Ja/Jb/omr in scratch memory)
-    double omr[3] = {-(w * er[0]), -(w * er[1]), stereo ? -(w * er[2]) : 0.0};
-    double wo = w;
+    // static indices only (a runtime-length loop over D would put the arrays in scratch memory)
+    omr[0] = -(w * er[0]);
+    omr[1] = -(w * er[1]);
+    omr[2] = stereo ? -(w * er[2]) : 0.0;
+    wo = w;
     if (W.e_robust[k]) {
         double rho[2];
-        robustify(edge_chi2(er, w, D), stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+        robustify(edge_chi2(er, w, stereo ? 3 : 2), stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
         wo = rho[1] * w;
         omr[0] *= rho[1];
         omr[1] *= rho[1];
         if (stereo) omr[2] *= rho[1];
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ja[i] = Ja[i];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) jb[i] = Jb[i];
-    W.Wr[3 * (size_t)k] = omr[0]; W.Wr[3 * (size_t)k + 1] = omr[1]; W.Wr[3 * (size_t)k + 2] = omr[2];
-    W.wo[k] = wo;
-    if (W.k_ph[k] >= 0) {
-        double *h = W.Hpl + 18 * (size_t)k;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
-                t += Jb[6 + r] * wo * Ja[3 + c];
-                if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
-                h[r * 3 + c] = t;
-            }
-    }
 }
 
-// Hll, b_l: one thread per point, edges in insertion order like g2o
-__global__ __launch_bounds__(128) void k_accum_points(const LbaWin *__restrict__ wins, int init)
+// buildSystem, the landmarks' side (block_solver.hpp:502-560): one thread per landmark walks its edges in insertion
+// order like g2o: linearizeOplus, Hll += Ji^T Omega Ji, b_l += Ji^T omr, and the edge's Hpl block Jj^T Omega Ji.
+// A masked edge adds nothing (its Hpl block was zeroed when it was masked).
+__global__ __launch_bounds__(128) void k_lin_points(const LbaWin *__restrict__ wins, int init)
 {
     const LbaWin &W = wins[blockIdx.y];
     if (!(init ? W.st->initp : W.st->lin)) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= W.nl) return;
+    const double *X = W.point + 3 * (size_t)W.hpoint[l];
+    const double Xv[3] = {X[0], X[1], X[2]};
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
     for (int a = W.pt_off[l]; a < W.pt_off[l + 1]; ++a) {
         const int k = W.pt_k[a];
-        const double *ja = W.JA + 9 * (size_t)k, *wr = W.Wr + 3 * (size_t)k;
-        const double wo = W.wo[k];
+        if (W.e_level1[k]) continue;
+        const double *T = W.pose + 7 * (size_t)W.e_pose[k];
+        const int stereo = W.e_stereo[k];
+        const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
+        double p[3], R[9];
+        se3_map(T, Xv, p);
+        rot_from_quat(T, R);
+        const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+        double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!stereo) {
+            const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+            const double s = -1. / z;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
+                    Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+                Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+                Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
+            }
+        }
+        double omr[3], wo;
+        edge_weights(W, k, stereo, omr, wo);
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
-            bl[r] += ja[r] * wr[0] + ja[3 + r] * wr[1] + ja[6 + r] * wr[2];
-            for (int c = 0; c < 3; ++c) H[r * 3 + c] += ja[r] * wo * ja[c] + ja[3 + r] * wo * ja[3 + c] + ja[6 + r] * wo * ja[6 + c];
+            bl[r] += Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[r * 3 + c] += Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
+        }
+        if (W.k_ph[k] >= 0) {
+            double Jb[18];
+            jac_pose(W.cam, p, stereo, Jb);
+            double *h = W.Hpl + 18 * (size_t)k;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
+                    t += Jb[6 + r] * wo * Ja[3 + c];
+                    if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
+                    h[r * 3 + c] = t;
+                }
         }
     }
     for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
     for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
 }
 
-// Hpp, b_p: one workgroup per free pose; strided partial sums + fixed-order tree reduction
-__global__ __launch_bounds__(256) void k_accum_poses(const LbaWin *__restrict__ wins, int init)
+// buildSystem, the keyframes' side: Hpp += Jj^T Omega Jj, b_p += Jj^T omr.  One workgroup per free pose; strided
+// partial sums + fixed-order tree reduction; the Jacobian is recomputed from the estimates (no per-edge arrays).
+__global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
 {
     __shared__ double sh[256][43];
     const LbaWin &W = wins[blockIdx.y];
     if (!(init ? W.st->initp : W.st->lin)) return;
-    const int p = blockIdx.x;
-    if (p >= W.np) return;
+    const int ph = blockIdx.x;
+    if (ph >= W.np) return;
+    double T[7];
+    {
+        const double *Tp = W.pose + 7 * (size_t)W.hpose[ph];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) T[i] = Tp[i];
+    }
     double acc[42];
+#pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int a = W.ps_off[p] + threadIdx.x; a < W.ps_off[p + 1]; a += 256) {
+    for (int a = W.ps_off[ph] + threadIdx.x; a < W.ps_off[ph + 1]; a += 256) {
         const int k = W.ps_k[a];
-        const double *jb = W.JB + 18 * (size_t)k, *wr = W.Wr + 3 * (size_t)k;
-        const double wo = W.wo[k];
+        if (W.e_level1[k]) continue;
+        const int stereo = W.e_stereo[k];
+        double p[3], Jb[18], omr[3], wo;
+        se3_map(T, W.point + 3 * (size_t)W.e_point[k], p);
+        jac_pose(W.cam, p, stereo, Jb);
+        edge_weights(W, k, stereo, omr, wo);
+#pragma unroll
         for (int r = 0; r < 6; ++r) {
-            acc[36 + r] += jb[r] * wr[0] + jb[6 + r] * wr[1] + jb[12 + r] * wr[2];
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += jb[r] * wo * jb[c] + jb[6 + r] * wo * jb[6 + c] + jb[12 + r] * wo * jb[12 + c];
+            acc[36 + r] += Jb[r] * omr[0] + Jb[6 + r] * omr[1] + Jb[12 + r] * omr[2];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += Jb[r] * wo * Jb[c] + Jb[6 + r] * wo * Jb[6 + c] + Jb[12 + r] * wo * Jb[12 + c];
         }
     }
+#pragma unroll
     for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] = acc[i];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -361,12 +415,12 @@ __global__ __launch_bounds__(256) void k_accum_poses(const LbaWin *__restrict__ 
             for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
         __syncthreads();
     }
-    if (threadIdx.x < 36) W.Hpp[36 * (size_t)p + threadIdx.x] = sh[0][threadIdx.x];
-    if (threadIdx.x < 6) W.b[6 * (size_t)p + threadIdx.x] = sh[0][36 + threadIdx.x];
+    if (threadIdx.x < 36) W.Hpp[36 * (size_t)ph + threadIdx.x] = sh[0][threadIdx.x];
+    if (threadIdx.x < 6) W.b[6 * (size_t)ph + threadIdx.x] = sh[0][36 + threadIdx.x];
 }
 
 // top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
-// (computeLambdaInit :166-180), ni = 2
+// (computeLambdaInit :166-180), ni = 2; the first trial's push() (the backup of the estimates)
 __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ wins)
 {
     __shared__ double sh[1024];
@@ -391,9 +445,10 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
         if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
+    for (int i = threadIdx.x; i < W.est_n; i += 1024) W.bk[i] = W.pose[i];
     if (threadIdx.x == 0) {
         double chi = 0;
-        for (int g = 0; g < W.n_part_e; ++g) chi += W.part[g];
+        for (int g = 0; g < W.n_part; ++g) chi += W.part[g];
         st->currentChi = st->iniChi = chi;
         st->lambda = 1e-5 * sh[0];
         st->ni = 2;
@@ -406,74 +461,22 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
     }
 }
 
-// ---- Schur complement in two conflict-free phases.  The host ranks the items -- (landmark, free-pose edges
-// ka <= kb of it) -- by their (pose, pose) block, landmark order inside a block (build_schur_items).  Phase A:
-// thread s computes item s's 6x6 contribution B_a Dinv B_b^T (block_solver.hpp:379-432) and stores its 36 elements
-// element-major, W[e][s], so a wave's stores are contiguous; the diagonal items also produce the coefficient
-// vector's terms B_a Dinv b_l.  Phase B: one workgroup per block; each wave adds whole rows W[e][o0 .. o0+n) (lanes
-// stride the items, then a fixed butterfly over the lanes): no atomics, bit-reproducible.
-// The threads behind the last item take the LM trial's backup of the estimates (SparseOptimizer::push, :600-604).
-__global__ __launch_bounds__(128) void k_schur_items(const LbaWin *__restrict__ wins)
+// ---- Schur complement (block_solver.hpp:379-432), one wave per (pose, pose) block of the upper block triangle.  The
+// host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order inside a block
+// (build_schur_items).  Lane j of the block's wave takes the items j, j + 64, ...: (Hll + lambda I)^-1 of the landmark,
+// B_a Dinv B_b^T (and, on the diagonal blocks, the coefficient term B_a Dinv b_l), accumulated in registers; the 64
+// partial 6x6 sums are then transposed through LDS and added in lane order by 36 (42) lanes: no atomics, a fixed
+// order (bit-reproducible), and no per-item array in memory (a materialised item list cost 288 B written + read per
+// item: 0.31 ms per trial for 32 windows of 24 k edges).  Hschur = Hpp + lambda I - sum, bschur = b_p - sum.
+__global__ __launch_bounds__(64) void k_schur(const LbaWin *__restrict__ wins)
 {
-    const LbaWin &W = wins[blockIdx.y];
-    if (!W.st->run) return;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= W.n_items) {
-        const int i = t - W.n_items;
-        if (i < W.est_n) W.bk[i] = W.pose[i];
-        return;
-    }
-    const double lambda = W.st->lambda;
-    const int ka = W.it_ka[t], kb = W.it_kb[t], l = W.it_l[t];   // three independent loads, then one level of gathers
-    double D[9], Dinv[9];
-    for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
-    D[0] += lambda; D[4] += lambda; D[8] += lambda;
-    mat3_inverse(D, Dinv);
-    const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
-    double BD[18];
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
-    double *w = W.W + t;
-    const size_t ni = (size_t)W.n_items;
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) w[(size_t)(r * 6 + c) * ni] = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
-    if (ka == kb) {
-        const double *bl = W.b + 6 * W.np + 3 * (size_t)l;
-        double db[3];
-        for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
-        for (int r = 0; r < 6; ++r) W.Wc[6 * (size_t)ka + r] = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
-    }
-}
-
-// sum over the 64 lanes in a fixed order (xor butterfly)
-__device__ __forceinline__ double wave_sum_f64_fixed(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// grid.x = np (np + 1) / 2 block workgroups (upper block triangle, row-major) followed by np coefficient workgroups;
-// 8 waves per workgroup, wave w takes the elements e = w, w + 8, ...
-__global__ __launch_bounds__(512) void k_schur_blocks(const LbaWin *__restrict__ wins)
-{
+    __shared__ double red[42 * 65];
     const LbaWin &W = wins[blockIdx.y];
     if (!W.st->run) return;
     const int np = W.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = blockIdx.x;
-    if (blk >= nblk + np) return;
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= nblk) return;
     const double lambda = W.st->lambda;
-    if (blk >= nblk) {   // bschur = b_p - sum over the pose's edges of B Dinv b_l
-        const int i = blk - nblk;
-        if (wave >= 6) return;
-        const int c0 = W.ps_off[i], n = W.ps_off[i + 1] - c0;
-        double acc = 0;
-        for (int j = lane; j < n; j += 64) acc += W.Wc[6 * (size_t)W.ps_k[c0 + j] + wave];
-        acc = wave_sum_f64_fixed(acc);
-        if (lane == 0) W.bs[6 * i + wave] = W.b[6 * i + wave] - acc;
-        return;
-    }
     // blk -> (i1 <= i2)
     int i1 = 0, rem = blk;
     while (rem >= np - i1) {
@@ -481,36 +484,69 @@ __global__ __launch_bounds__(512) void k_schur_blocks(const LbaWin *__restrict__
         ++i1;
     }
     const int i2 = i1 + rem;
+    const bool diag = i1 == i2;
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
-    const size_t ni = (size_t)W.n_items;
-    // the wave's (up to) five rows are summed together: their loads are independent and stay in flight side by side
-    double acc[5] = {0, 0, 0, 0, 0};
-    const double *w = W.W + (size_t)wave * ni + o0;
-    const bool five = wave + 32 < 36;
-#pragma unroll 2
+    double acc[36], accb[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) accb[i] = 0;
     for (int j = lane; j < n; j += 64) {
-        const double v0 = w[j], v1 = w[8 * ni + j], v2 = w[16 * ni + j], v3 = w[24 * ni + j];
-        const double v4 = five ? w[32 * ni + j] : 0.0;
-        acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3; acc[4] += v4;
-    }
+        const int ka = W.it_ka[o0 + j], kb = W.it_kb[o0 + j], l = W.it_l[o0 + j];   // three independent loads, then one level of gathers
+        double D[9], Dinv[9];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+        for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        mat3_inverse(D, Dinv);
+        const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
+        double Bb[18], BD[18];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) acc[q] += __shfl_xor(acc[q], m, 64);
-    }
-    if (lane != 0) return;
+        for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int e = wave + 8 * q;
-        if (e >= 36) break;
-        double v = -acc[q];
-        const int r = e / 6, c = e - 6 * r;
-        if (i1 == i2) {
-            v += W.Hpp[36 * (size_t)i1 + e];
-            if (r == c) v += lambda;
+        for (int r = 0; r < 6; ++r) {
+            const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
         }
-        W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
-        if (i1 != i2) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
+        if (diag) {   // (ka == kb: one edge per (keyframe, landmark) pair)
+            const double *bl = W.b + n6 + 3 * (size_t)l;
+            double db[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) accb[r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) red[i * 65 + lane] = acc[i];
+    if (diag) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) red[(36 + i) * 65 + lane] = accb[i];
+    }
+    __syncthreads();
+    const int e = lane;
+    if (e < (diag ? 42 : 36)) {
+        double x[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) x[j] = red[e * 65 + j];
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) sum += x[j];
+        if (e < 36) {
+            double v = -sum;
+            const int r = e / 6, c = e - 6 * r;
+            if (diag) {
+                v += W.Hpp[36 * (size_t)i1 + e];
+                if (r == c) v += lambda;
+            }
+            W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
+            if (!diag) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+        } else
+            W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
     }
 }
 
@@ -819,49 +855,11 @@ __global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ 
     se3_oplus(upd, W.pose + 7 * (size_t)W.hpose[p]);
 }
 
-// xl = Dinv (bl - B^T xp), then oplus on points; scale terms x_j (lambda x_j + b_j): 128-thread workgroups, the
-// terms of workgroup g's points -> part[n_part_e + g]; workgroup 0 adds those of the poses (tmp[0 .. 6 np))
-__global__ __launch_bounds__(128) void k_backsub_points(const LbaWin *__restrict__ wins)
-{
-    const LbaWin &W = wins[blockIdx.y];
-    if (!W.st->run || (int)blockIdx.x >= W.n_part_s) return;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n6 = 6 * W.np;
-    const double lambda = W.st->lambda;
-    double sc = 0;
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < n6; i += 128) sc += W.tmp[i];
-    if (l < W.nl) {
-        double cl[3] = {W.b[n6 + 3 * l], W.b[n6 + 3 * l + 1], W.b[n6 + 3 * l + 2]};
-        for (int a = W.pl_off[l]; a < W.pl_off[l + 1]; ++a) {
-            const int ka = W.pl_k[a];
-            const int i1 = W.k_ph[ka];
-            const double *Bi = W.Hpl + 18 * (size_t)ka;
-            for (int c = 0; c < 3; ++c)
-                for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-W.x[6 * i1 + r]);
-        }
-        // (Hll + lambda I)^-1 again, the same operations as in the Schur kernel (so the same bits): landmarks seen by
-        // fixed keyframes only have no Schur item that could have stored it
-        double Dm[9], Dinv[9];
-        for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
-        Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-        mat3_inverse(Dm, Dinv);
-        double *X = W.point + 3 * (size_t)W.hpoint[l];
-        for (int r = 0; r < 3; ++r) {
-            const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
-            W.x[n6 + 3 * l + r] = xl;
-            X[r] += xl;
-            sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
-        }
-    }
-    workgroup_sum<128>(sc, W.part + W.n_part_e);
-}
-
 // The decision of one Levenberg-Marquardt trial and everything that hangs on it (levenberg.cpp:99-164,
 // sparse_optimizer.cpp:372-414): gain ratio, lambda update or pop(), the `while (rho < 0 && qmax < maxTrials &&
 // !terminate())` condition, the three ways an iteration can end the optimisation, and the `for (i < iterations &&
 // !terminate() && ok)` condition of the next iteration.  One workgroup per window; thread 0 decides, all threads
-// restore the estimates after a rejected step.
+// restore the estimates after a rejected step (or back up the accepted ones for the next trial).
 __global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins)
 {
     __shared__ int s_restore;
@@ -871,8 +869,8 @@ __global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins
     if (threadIdx.x == 0) {
         const int pass = st->phase == 0 ? 0 : 1;
         double tempChi = 0, scale = 0;
-        for (int g = 0; g < W.n_part_e; ++g) tempChi += W.part[g];
-        for (int g = 0; g < W.n_part_s; ++g) scale += W.part[W.n_part_e + g];
+        for (int g = 0; g < W.n_part; ++g) tempChi += W.part[g];
+        for (int g = 0; g < W.n_part; ++g) scale += W.part[W.n_part + g];
         const bool ok2 = W.np == 0 || W.scal[3] != 0.0;
         if (!ok2) {
             tempChi = 1.7976931348623157e308;
@@ -932,8 +930,12 @@ __global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins
         st->lin = lin;
     }
     __syncthreads();
-    if (s_restore)   // SparseOptimizer::pop
+    // the backup always holds the estimates a trial starts from: pop() after a rejected step, the next push() after an
+    // accepted one (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610)
+    if (s_restore)
         for (int i = threadIdx.x; i < W.est_n; i += 1024) W.pose[i] = W.bk[i];
+    else
+        for (int i = threadIdx.x; i < W.est_n; i += 1024) W.bk[i] = W.pose[i];
 }
 
 // Between the two optimisations (Optimizer.cc:663-710).  (a): bDoMore = !*pbStopFlag
@@ -965,7 +967,11 @@ __global__ __launch_bounds__(256) void k_edge_mark(const LbaWin *__restrict__ wi
         double p[3];
         se3_map(W.pose + 7 * (size_t)W.e_pose[e], W.point + 3 * (size_t)W.e_point[e], p);
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
-        if (bad) W.e_level1[e] = 1;
+        if (bad) {
+            W.e_level1[e] = 1;
+            if (W.k_ph[e] >= 0)
+                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)e + i] = 0.0;
+        }
         W.e_robust[e] = 0;
         keep = bad ? 0 : 1;
     }
@@ -1033,7 +1039,7 @@ struct Pass {
     int np = 0, nl = 0;
 };
 
-static void build_pass(const aos2_lba_problem_t *p, Pass &S)
+static bool build_pass(const aos2_lba_problem_t *p, Pass &S)
 {
     S = Pass();
     const int E = p->n_edges;
@@ -1097,7 +1103,10 @@ static void build_pass(const aos2_lba_problem_t *p, Pass &S)
             for (; j >= 0 && S.k_ph[q[j]] > key; --j) q[j + 1] = q[j];
             q[j + 1] = v;
         }
+        for (int i = 1; i < m; ++i)
+            if (S.k_ph[q[i]] == S.k_ph[q[i - 1]]) return false;   // two edges between one keyframe and one landmark
     }
+    return true;
 }
 
 // items ranked by (pose, pose) block -- upper block triangle, row-major -- and by landmark inside a block (counting
@@ -1149,10 +1158,10 @@ struct WinLayout {
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off;
     // device only
-    size_t est, bk, e_obs, e_w, robust, level1, err, JA, JB, Wr, wo, Hpl, Hpp, Hll, b, x, Hs, bs, W, Wc, tmp, scal, part, ldlt;
+    size_t est, bk, e_obs, e_w, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
     size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
-    int n_part_e, n_part_s, npad, ldlt_lds;
+    int n_part, npad, ldlt_lds;
     size_t n_items;
 };
 
@@ -1276,10 +1285,16 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             });
         for (auto &x : th) x.join();
     };
+    std::vector<uint8_t> pass_ok(nw, 1);
     for_windows([&](int i) {
-        build_pass(problems + act[i], passes[i]);
-        if (passes[i].np > 0) build_schur_items(passes[i]);
+        pass_ok[i] = build_pass(problems + act[i], passes[i]) ? 1 : 0;
+        if (pass_ok[i] && passes[i].np > 0) build_schur_items(passes[i]);
     });
+    for (int i = 0; i < nw; ++i)
+        if (!pass_ok[i]) {   // (cannot come from the reference: KeyFrame observations are a map MapPoint -> index)
+            set_error("problem %d: two edges connect the same keyframe and map point", act[i]);
+            return AOS2_ERR_ARG;
+        }
     lap("build_pass + items");
 
     // ---- arena layout: [staged inputs of all windows | descriptors][device-only scratch][results of all windows]
@@ -1312,15 +1327,13 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
         l.e_obs = B.take(24 * E); l.e_w = B.take(8 * E); l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
-        l.JA = B.take(72 * E); l.JB = B.take(144 * E); l.Wr = B.take(24 * E); l.wo = B.take(8 * E); l.Hpl = B.take(144 * E);
+        l.Hpl = B.take(144 * E);
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.Hs = B.take(8 * n6 * n6 + 8); l.bs = B.take(8 * n6 + 8);
-        l.W = B.take(288 * l.n_items + 8); l.Wc = B.take(48 * E + 8);
         l.tmp = B.take(8 * n6 + 8);
-        l.n_part_e = (int)((E + 1023) / 1024);
-        l.n_part_s = std::max(1, (int)((S.nl + 127) / 128));
-        l.scal = B.take(64); l.part = B.take(8 * ((size_t)l.n_part_e + l.n_part_s) + 8);
+        l.n_part = std::max(1, (int)((S.nl + 127) / 128));
+        l.scal = B.take(64); l.part = B.take(16 * (size_t)l.n_part + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
         const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + l.npad + 64) * 8;
         l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
@@ -1353,8 +1366,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // ---- staging (parallel) + descriptors
     LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
     bool any_lds = false, any_glob = false;
-    int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part_e = 0, mx_part_s = 0, mx_npad_glob = 0, mx_npad_lds = 0;
-    size_t mx_items_bk = 0, mx_blk = 0;
+    int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part = 0, mx_npad_glob = 0, mx_npad_lds = 0;
+    size_t mx_blk = 0;
     for_windows([&](int i) {
         const aos2_lba_problem_t *p = problems + act[i];
         const Pass &S = passes[i];
@@ -1404,13 +1417,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.pl_off = (const int32_t *)(base + l.pl_off); W.pl_k = (const int32_t *)(base + l.pl_k);
         W.it_ka = (const int32_t *)(base + l.it_ka); W.it_kb = (const int32_t *)(base + l.it_kb);
         W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
-        W.JA = (double *)(base + l.JA); W.JB = (double *)(base + l.JB); W.Wr = (double *)(base + l.Wr);
-        W.wo = (double *)(base + l.wo); W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
+        W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
         W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
         W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
-        W.W = (double *)(base + l.W); W.Wc = (double *)(base + l.Wc);
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
-        W.n_part_e = l.n_part_e; W.n_part_s = l.n_part_s;
+        W.n_part = l.n_part;
         W.ldlt = (double *)(base + l.ldlt); W.npad = l.npad; W.ldlt_lds = l.ldlt_lds;
         W.st = (LmState *)(base + l.st);
         W.abort_word = d_abort + i;
@@ -1430,10 +1441,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         mx_np = std::max(mx_np, S.np);
         mx_nl = std::max(mx_nl, S.nl);
         mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
-        mx_part_e = std::max(mx_part_e, l.n_part_e);
-        mx_part_s = std::max(mx_part_s, l.n_part_s);
-        mx_items_bk = std::max(mx_items_bk, l.n_items + (size_t)W.est_n);
-        mx_blk = std::max(mx_blk, (size_t)S.np * (S.np + 1) / 2 + S.np);
+        mx_part = std::max(mx_part, l.n_part);
+        mx_blk = std::max(mx_blk, (size_t)S.np * (S.np + 1) / 2);
     }
     lap("staging");
     hipStream_t q = s->stream;
@@ -1441,17 +1450,19 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
-    const dim3 g_edges128(blocks(mx_E, 128), nw), g_edges256(blocks(mx_E, 256), nw);
+    const dim3 g_edges256(blocks(mx_E, 256), nw), g_points(mx_part, nw);
+    auto enqueue_lin = [&](int init) {
+        hipLaunchKernelGGL(k_lin_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, init);
+        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, init);
+    };
     auto enqueue_init = [&]() {
-        hipLaunchKernelGGL(k_errors, dim3(mx_part_e, nw), dim3(1024), 0, q, dw, 1);
-        hipLaunchKernelGGL(k_linearize, g_edges128, dim3(128), 0, q, dw, 1);
-        hipLaunchKernelGGL(k_accum_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, 1);
-        if (mx_np) hipLaunchKernelGGL(k_accum_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, 1);
+        hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 0);
+        enqueue_lin(1);
         hipLaunchKernelGGL(k_lm_init, dim3(nw), dim3(1024), 0, q, dw);
     };
+    // one Levenberg-Marquardt trial: 6 launches (7 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        hipLaunchKernelGGL(k_schur_items, dim3(blocks(mx_items_bk, 128), nw), dim3(128), 0, q, dw);
-        if (mx_np) hipLaunchKernelGGL(k_schur_blocks, dim3((unsigned)mx_blk, nw), dim3(512), 0, q, dw);
+        if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(64), 0, q, dw);
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + mx_npad_lds + 64) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(nw), dim3(256), need, q, dw);
@@ -1460,12 +1471,9 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(nw), dim3(1024), (size_t)mx_npad_glob * sizeof(double), q, dw);
             hipLaunchKernelGGL(k_update_poses, dim3(blocks(mx_np, 64), nw), dim3(64), 0, q, dw);
         }
-        hipLaunchKernelGGL(k_backsub_points, dim3(mx_part_s, nw), dim3(128), 0, q, dw);
-        hipLaunchKernelGGL(k_errors, dim3(mx_part_e, nw), dim3(1024), 0, q, dw, 0);
+        hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 1);
         hipLaunchKernelGGL(k_decide, dim3(nw), dim3(1024), 0, q, dw);
-        hipLaunchKernelGGL(k_linearize, g_edges128, dim3(128), 0, q, dw, 0);
-        hipLaunchKernelGGL(k_accum_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, 0);
-        if (mx_np) hipLaunchKernelGGL(k_accum_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, 0);
+        enqueue_lin(0);
     };
     auto enqueue_transition = [&]() {
         hipLaunchKernelGGL(k_trans_a, dim3(nw), dim3(1), 0, q, dw);
