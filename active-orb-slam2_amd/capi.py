@@ -141,6 +141,21 @@ def lib():
                 L.aos2_pose_optimization.argtypes = [vp, vp, vp, ci]
                 L.aos2_pose_optimization_last_device_ms.argtypes = [vp]
                 L.aos2_pose_optimization_last_device_ms.restype = cf
+        if hasattr(L, "aos2_frames_create"):
+            L.aos2_frames_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+            L.aos2_frames_destroy.argtypes = [vp]
+            L.aos2_frames_stream.argtypes = [vp]
+            L.aos2_frames_stream.restype = vp
+            L.aos2_frames_wait.argtypes = [vp]
+            L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
+            L.aos2_frames_set_pose.argtypes = [vp, vp]
+            L.aos2_frames_set_map_points.argtypes = [vp, vp, vp, vp]
+            L.aos2_frames_get.argtypes = [vp, ci, vp, C.c_size_t]
+            L.aos2_frames_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, ci, vp]
+            L.aos2_frames_pose_optimization.argtypes = [vp, vp, vp]
+            L.aos2_frames_discard_outliers.argtypes = [vp]
+            L.aos2_frames_search_local_points.argtypes = [vp, vp, vp, ci, cf, cf, vp]
+            L.aos2_extractor_stream_wait.argtypes = [vp, vp]
         _LIB = L
     return _LIB
 
@@ -877,3 +892,75 @@ class LocalBA:
 
     def pose_last_device_ms(self):
         return float(self.L.aos2_pose_optimization_last_device_ms(self.h))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device-resident frame batches (include/aos2.h: aos2_frames_*).  Device arrays are passed as raw pointers (torch
+# tensors' data_ptr()); this wrapper owns nothing but the handle.
+class _MapPointsDev(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pos", C.c_void_p), ("desc", C.c_void_p), ("has_obs", C.c_void_p),
+                ("normal", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p)]
+
+
+def map_points_dev(n, pos, desc, has_obs, normal=0, min_dist=0, max_dist=0):
+    """aos2_map_points_dev_t from device pointers (ints)"""
+    t = _MapPointsDev()
+    t.n, t.pos, t.desc, t.has_obs, t.normal, t.min_dist, t.max_dist = int(n), pos, desc, has_obs, normal or None, min_dist or None, max_dist or None
+    return t
+
+
+class Frames:
+    MAP_POINTS, OUTLIER, TCW, U_RIGHT, DEPTH, GRID_OFF, GRID_IDX = range(7)
+
+    def __init__(self, batch, cap, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.aos2_frames_create(device, batch, cap, C.byref(h)))
+        self.h, self.batch, self.cap = h, batch, cap
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.aos2_frames_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def build(self, extractor, d_kps, d_desc, d_n, w, h, d_depth, fx, fy, cx, cy, mbf, depth_stride=None, depth_image_stride=None):
+        _check(self.L.aos2_frames_build(self.h, extractor.h, self.batch, d_kps, d_desc, d_n, self.cap, w, h, d_depth or None,
+                                        depth_stride or w, depth_image_stride or w * h, fx, fy, cx, cy, mbf))
+
+    def set_pose(self, d_Tcw):
+        _check(self.L.aos2_frames_set_pose(self.h, d_Tcw))
+
+    def set_map_points(self, mp, table, outlier=None):
+        mp = np.ascontiguousarray(mp, np.int32).reshape(self.batch, self.cap)
+        if outlier is not None:
+            outlier = np.ascontiguousarray(outlier, np.uint8).reshape(self.batch, self.cap)
+        _check(self.L.aos2_frames_set_map_points(self.h, _p(mp), None if outlier is None else _p(outlier), C.byref(table)))
+
+    def get(self, what):
+        B, cap = self.batch, self.cap
+        shape, dt = {0: ((B, cap), np.int32), 1: ((B, cap), np.uint8), 2: ((B, 16), np.float32), 3: ((B, cap), np.float32),
+                     4: ((B, cap), np.float32), 5: ((B, 64 * 48 + 1), np.int32), 6: ((B, cap), np.int32)}[what]
+        a = np.zeros(shape, dt)
+        _check(self.L.aos2_frames_get(self.h, what, _p(a), a.nbytes))
+        return a
+
+    def SearchByProjectionLast(self, last, table, th, mono=False, check_orientation=True, d_nmatches=0):
+        _check(self.L.aos2_frames_search_by_projection_last(self.h, last.h, C.byref(table), th, int(mono), int(check_orientation),
+                                                            d_nmatches or None))
+
+    def PoseOptimization(self, table, d_inliers=0):
+        _check(self.L.aos2_frames_pose_optimization(self.h, C.byref(table), d_inliers or None))
+
+    def discard_outliers(self):
+        _check(self.L.aos2_frames_discard_outliers(self.h))
+
+    def SearchLocalPoints(self, table, d_local, n_local, th, nnratio, d_nmatches=0):
+        _check(self.L.aos2_frames_search_local_points(self.h, C.byref(table), d_local, n_local, th, nnratio, d_nmatches or None))
+
+    def wait(self):
+        _check(self.L.aos2_frames_wait(self.h))
+
+    def stream(self):
+        return self.L.aos2_frames_stream(self.h)

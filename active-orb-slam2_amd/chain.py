@@ -1,0 +1,96 @@
+"""Harness (tests/, bench.py): the device-resident per-frame tracking chain over a scenario.tracking_scenario().
+
+    ORBextractor::operator() -> Frame::Frame -> SearchByProjection(Current, Last) -> PoseOptimization -> outlier discard
+    -> SearchLocalPoints -> PoseOptimization                       (Tracking.cc:862-870, 963-1027, 1302-1352, 1039)
+
+PyTorch is only the owner of the device buffers; every stage is one C-ABI call of include/aos2.h.  `step()` enqueues
+the whole chain for the batch and returns; `wait()` completes it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi, scenario
+
+
+class TrackingChain:
+    def __init__(self, scen: dict, device: int = 0, n_local: int = 1500, th_last: float = 15.0, th_local: float = 3.0,
+                 nnratio_local: float = 0.8):
+        import torch
+        self.torch = torch
+        self.scen, self.device = scen, device
+        self.dev = torch.device("cuda", device)
+        self.th_last, self.th_local, self.nnratio_local, self.n_local = th_last, th_local, nnratio_local, n_local
+        B, W, H = scen["batch"], scen["w"], scen["h"]
+        self.B, self.W, self.H = B, W, H
+        self.ex = capi.Extractor(nfeatures=scen["nfeatures"], device=device)
+        self.ex_setup = capi.Extractor(nfeatures=scen["nfeatures"], device=device)
+        self.cap = cap = self.ex.max_keypoints_for(W, H)
+        idx = scen["index"]
+        t = torch
+        self.d_cur = t.from_numpy(scen["cur"][idx]).to(self.dev)
+        self.d_depth = t.from_numpy(scen["depth_cur"][idx]).to(self.dev)
+        self.d_guess = t.from_numpy(np.ascontiguousarray(scen["Tcw_guess"][idx].reshape(B, 16))).to(self.dev)
+        self.d_kps = t.zeros((B, cap, 7), dtype=t.float32, device=self.dev)
+        self.d_desc = t.zeros((B, cap, 32), dtype=t.uint8, device=self.dev)
+        self.d_n = t.zeros((B,), dtype=t.int32, device=self.dev)
+        self.d_nm = t.zeros((4, B), dtype=t.int32, device=self.dev)   # nmatches last / inliers 1 / nmatches local / inliers 2
+        self.cur = capi.Frames(B, cap, device)
+        self._setup_last()
+
+    # ---- LastFrame batch, MapPoint table and local lists (setup, untimed): built from the extractor's keypoints
+    def _setup_last(self):
+        t, scen, B, cap = self.torch, self.scen, self.B, self.cap
+        nu, idx = scen["n_unique"], scen["index"]
+        lk = self.ex_setup.extract_batch(scen["last"])
+        ok = self.ex_setup.extract_batch(scen["old"])
+        self.host_last = lk
+        m = scenario.build_map(scen, [k for k, _ in lk], [d for _, d in lk], [k for k, _ in ok], [d for _, d in ok],
+                               self.ex.GetScaleFactors(), n_local=self.n_local)
+        self.map = m
+        tb = m["table"]
+        self.d_table = {k: t.from_numpy(np.ascontiguousarray(tb[k])).to(self.dev) for k in ("pos", "desc", "has_obs", "normal", "min_dist", "max_dist")}
+        self.table = capi.map_points_dev(tb["n"], *(self.d_table[k].data_ptr() for k in ("pos", "desc", "has_obs", "normal", "min_dist", "max_dist")))
+        # the LastFrame batch holds the last views' extraction (tiled like the current frames)
+        self.d_last_img = t.from_numpy(scen["last"][idx]).to(self.dev)
+        self.d_last_depth = t.from_numpy(scen["depth_last"][idx]).to(self.dev)
+        self.dl_kps = t.zeros((B, cap, 7), dtype=t.float32, device=self.dev)
+        self.dl_desc = t.zeros((B, cap, 32), dtype=t.uint8, device=self.dev)
+        self.dl_n = t.zeros((B,), dtype=t.int32, device=self.dev)
+        W, H = self.W, self.H
+        self.ex_setup.extract_batch_device(self.d_last_img.data_ptr(), B, W, H, W, W * H, self.dl_kps.data_ptr(), self.dl_desc.data_ptr(),
+                                           cap, self.dl_n.data_ptr())
+        self.last = capi.Frames(B, cap, self.device)
+        s = scen
+        self.last.build(self.ex_setup, self.dl_kps.data_ptr(), self.dl_desc.data_ptr(), self.dl_n.data_ptr(), W, H,
+                        self.d_last_depth.data_ptr(), float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+        self.d_Tlw = t.from_numpy(np.ascontiguousarray(scen["Tlw"][idx].reshape(B, 16))).to(self.dev)
+        self.last.set_pose(self.d_Tlw.data_ptr())
+        mp = np.full((B, cap), -1, np.int32)
+        w_ = m["mp_last"].shape[1]
+        mp[:, :w_] = m["mp_last"][idx]
+        self.last_outlier = np.zeros((B, cap), np.uint8)
+        self.last_outlier[:, :w_] = m["outlier_last"][idx]
+        self.last.set_map_points(mp, self.table, self.last_outlier)
+        self.last_mp = mp
+        self.d_local = t.from_numpy(np.ascontiguousarray(m["local"][idx])).to(self.dev)
+        self.last.wait()
+
+    def step(self):
+        """enqueue the chain for the batch"""
+        B, W, H, cap, s = self.B, self.W, self.H, self.cap, self.scen
+        self.ex.extract_batch_device_async(self.d_cur.data_ptr(), B, W, H, W, W * H, self.d_kps.data_ptr(), self.d_desc.data_ptr(), cap,
+                                           self.d_n.data_ptr())
+        c = self.cur
+        c.build(self.ex, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), W, H, self.d_depth.data_ptr(),
+                float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+        c.set_pose(self.d_guess.data_ptr())
+        c.SearchByProjectionLast(self.last, self.table, self.th_last, mono=False, check_orientation=True, d_nmatches=self.d_nm[0].data_ptr())
+        c.PoseOptimization(self.table, self.d_nm[1].data_ptr())
+        c.discard_outliers()
+        c.SearchLocalPoints(self.table, self.d_local.data_ptr(), self.n_local, self.th_local, self.nnratio_local, self.d_nm[2].data_ptr())
+        c.PoseOptimization(self.table, self.d_nm[3].data_ptr())
+
+    def wait(self):
+        self.cur.wait()
+        self.ex.wait()

@@ -104,6 +104,7 @@ struct aos2_extractor {
     int chunks = 0;                      // 0 = automatic
     int n_streams = 0;
     hipEvent_t ev[8] = {};
+    hipEvent_t order_ev[kMaxStreams] = {};   // aos2_extractor_stream_wait
     Plan plan;
     int batch_cap = 0;
     int last_batch = 0;
@@ -821,6 +822,8 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         e->h_level_off.release(); e->h_sel_cnt.release(); e->h_nout.release(); e->h_status.release(); e->h_dense.release(); e->h_sel.release();
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
         for (int i = 0; i < e->n_streams; ++i) (void)hipStreamDestroy(e->streams[i]);
+        for (auto &oe : e->order_ev)
+            if (oe) (void)hipEventDestroy(oe);
     }
     delete e;
 }
@@ -865,6 +868,24 @@ int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t
         return run_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
     }
     return enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
+}
+
+int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream)
+{
+    if (!e) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if (!e->dev_ready) return AOS2_OK;   // nothing was ever enqueued
+    int st = bind_device(e->device);
+    if (st) return st;
+    hipStream_t waiter = static_cast<hipStream_t>(hip_stream);
+    for (int i = 0; i < e->n_streams; ++i) {
+        if (!e->order_ev[i]) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->order_ev[i], hipEventDisableTiming));
+        AOS2_HIP_CHECK(hipEventRecord(e->order_ev[i], e->streams[i]));
+        AOS2_HIP_CHECK(hipStreamWaitEvent(waiter, e->order_ev[i], 0));
+    }
+    return AOS2_OK;
 }
 
 int aos2_extractor_wait(aos2_extractor_t *e)

@@ -965,6 +965,7 @@ struct ProjMpDev {
     const uint8_t *track_in_view, *desc, *has_obs;
     const int32_t *pred_level;
     const float *view_cos, *proj_x, *proj_y, *proj_xr;
+    const int32_t *desc_idx;   // optional: row of `desc` that holds query i's descriptor (a map-point table), else row i
 };
 
 __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P, int i, float th)
@@ -978,8 +979,11 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 // pool_base / pool_cap: this problem's region of the entry pool, cut into one fixed slice per map point (a counter
 // shared by all waves serialised ~100 k same-address atomics in one L2 channel: 0.94 ms for 64 frames); pool_used is
 // only an overflow flag
+// phase 0: the query's entries go to its fixed slice of the pool (below).  Two-pass form (device-resident frames):
+// phase 1 only counts the window populations (slots[i].cnt), a scan assigns slots[i].ent_off, phase 2 fills.
 __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
-                                                     Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0)
+                                                     Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0,
+                                                     int phase = 0)
 {
     const int lane = threadIdx.x;
     QuerySlot s{0, 0};
@@ -988,15 +992,18 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
         const Window w = window_cells(F, P.proj_x[i], P.proj_y[i], rs);
         if (w.ok) {
             const int pop = window_population(F, w, lane);
-            if (pop > 0) {
+            if (pop > 0 && phase == 1) {
+                s.cnt = pop;
+            } else if (pop > 0) {
                 // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
-                const int stride = pool_cap / max(P.n_mp, 1);
-                int off = i * stride;
+                const int stride = phase == 2 ? pop : pool_cap / max(P.n_mp, 1);
+                int off = phase == 2 ? slots[i].ent_off - pool_base : i * stride;
                 if (pop > stride && lane == 0) atomicMax(pool_used, pop);   // overflow flag for the host (batched form)
-                if (pop <= stride) {
+                if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                     const int lvl = P.pred_level[i];
                     off += pool_base;
-                    window_entries(F, w, load_desc(P.desc + (size_t)i * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
+                    const size_t drow = P.desc_idx ? (size_t)P.desc_idx[i] : (size_t)i;
+                    window_entries(F, w, load_desc(P.desc + drow * 32), P.proj_x[i], P.proj_y[i], rs, lvl - 1, lvl,
                                    P.proj_xr[i], rs, lane, pool + off);
                     s.cnt = pop;
                     s.ent_off = off;
@@ -1005,7 +1012,7 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
             }
         }
     }
-    if (lane == 0) slots[i] = s;
+    if (lane == 0 && phase != 2) slots[i] = s;
 }
 
 __global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpDev P, float th, QuerySlot *slots,
@@ -1143,18 +1150,36 @@ struct ProjLastDev {
     const int32_t *last_octave;
     float Tcw[16], Tlw[16];
     float fx, fy, cx, cy, mb, mbf;
+    // optional (device-resident frames): LastFrame.mvpMapPoints as rows of a map-point table (world_pos / desc / has_obs
+    // are then the table's arrays) and LastFrame.mvbOutlier; last_valid is unused
+    const int32_t *mp_idx;
+    const uint8_t *outlier;
 };
+
+__device__ __forceinline__ bool proj_last_blocks(const ProjLastDev &P, int q)
+{
+    if (!P.mp_idx) return P.has_obs[q] != 0;
+    const int row = P.mp_idx[q];
+    return row >= 0 && P.has_obs[row] != 0;
+}
 
 // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  :1328-1470
 // stage A: one wave per last-frame feature: project, window, distances
-__global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjLastDev P, float th, int mono,
-                                                               QuerySlot *slots, Entry *pool, int32_t *pool_used,
-                                                               int pool_cap)
+__device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const ProjLastDev &P, float th, int mono,
+                                                       QuerySlot *slots, Entry *pool, int32_t *pool_used, int pool_cap,
+                                                       int i, int pool_base = 0, int phase = 0)
 {
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     QuerySlot s{0, 0};
     const float *T = P.Tcw, *Tl = P.Tlw;
-    if (P.last_valid[i]) {
+    int row = i;
+    bool valid;
+    if (P.mp_idx) {
+        row = P.mp_idx[i];
+        valid = row >= 0 && !P.outlier[i];
+    } else
+        valid = P.last_valid[i] != 0;
+    if (valid) {
         // twc = -Rcw^T tcw (cv::gemm general path: double accumulation) ; tlc = Rlw twc + tlw (:1339-1346)
         float twc[3], tlc2;
 #pragma unroll
@@ -1166,7 +1191,7 @@ __global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjL
         tlc2 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Tl[8], twc[0]), __fmul_rn(Tl[9], twc[1])), __fmul_rn(Tl[10], twc[2])), Tl[11]);
         const bool bForward = tlc2 > P.mb && !mono;
         const bool bBackward = -tlc2 > P.mb && !mono;
-        const float X0 = P.world_pos[3 * i], X1 = P.world_pos[3 * i + 1], X2 = P.world_pos[3 * i + 2];
+        const float X0 = P.world_pos[3 * (size_t)row], X1 = P.world_pos[3 * (size_t)row + 1], X2 = P.world_pos[3 * (size_t)row + 2];
         float x3Dc[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1194,13 +1219,15 @@ __global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjL
             const Window w = window_cells(F, u, v, radius);
             if (w.ok) {
                 const int pop = window_population(F, w, lane);
-                if (pop > 0) {
-                    const int stride = pool_cap / max(P.n_last, 1);
-                    const int off = i * stride;
+                if (pop > 0 && phase == 1) {
+                    s.cnt = pop;
+                } else if (pop > 0) {
+                    const int stride = phase == 2 ? pop : pool_cap / max(P.n_last, 1);
+                    const int off = phase == 2 ? slots[i].ent_off : pool_base + i * stride;
                     if (pop > stride && lane == 0) atomicMax(pool_used, pop);
-                    if (pop <= stride) {
+                    if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                         const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
-                        window_entries(F, w, load_desc(P.desc + (size_t)i * 32), u, v, radius, minL, maxL, ur, radius, lane,
+                        window_entries(F, w, load_desc(P.desc + (size_t)row * 32), u, v, radius, minL, maxL, ur, radius, lane,
                                        pool + off);
                         s.cnt = pop;
                         s.ent_off = off;
@@ -1210,7 +1237,14 @@ __global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjL
             }
         }
     }
-    if (lane == 0) slots[i] = s;
+    if (lane == 0 && phase != 2) slots[i] = s;
+}
+
+__global__ __launch_bounds__(64) void proj_last_entries_kernel(FrameDev F, ProjLastDev P, float th, int mono,
+                                                               QuerySlot *slots, Entry *pool, int32_t *pool_used,
+                                                               int pool_cap)
+{
+    proj_last_entries_body(F, P, th, mono, slots, pool, pool_used, pool_cap, blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void proj_last_resolve_kernel(FrameDev F, ProjLastDev P, int check_ori,
@@ -1272,12 +1306,12 @@ __global__ __launch_bounds__(64) void proj_last_resolve_kernel(FrameDev F, ProjL
 }
 
 // parallel stage B of SearchByProjection(CurrentFrame, LastFrame, th, bMono) (resolve_fixpoint)
-__global__ __launch_bounds__(1024) void proj_last_resolve_fix_kernel(FrameDev F, ProjLastDev P, int check_ori,
-                                                                     const QuerySlot *__restrict__ slots,
-                                                                     const Entry *__restrict__ pool, int32_t *match_f,
-                                                                     uint32_t *bin_f, int32_t *nmatches_out, int32_t *choice)
+template <int NT>
+__device__ __forceinline__ void proj_last_resolve_fix_body(const FrameDev &F, const ProjLastDev &P, int check_ori,
+                                                           const QuerySlot *__restrict__ slots,
+                                                           const Entry *__restrict__ pool, int32_t *match_f,
+                                                           uint32_t *bin_f, int32_t *nmatches_out, int32_t *choice)
 {
-    constexpr int NT = 1024;
     extern __shared__ int32_t fix_lds[];
     __shared__ int histo[HISTO];
     __shared__ int total;
@@ -1296,7 +1330,7 @@ __global__ __launch_bounds__(1024) void proj_last_resolve_fix_kernel(FrameDev F,
             return pool + s.ent_off;
         },
         [&](int, const Best2 &b) { return (b.k1 != KEY_NONE && (int)(b.k1 >> 20) <= TH_HIGH) ? (int)(b.p1 & 0xffffffu) : -1; },
-        [&](int q) { return P.has_obs[q] != 0; });
+        [&](int q) { return proj_last_blocks(P, q); });
     int cnt = 0;
     for (int q = tid; q < P.n_last; q += NT) {
         const int c = choice[q];
@@ -1328,6 +1362,14 @@ __global__ __launch_bounds__(1024) void proj_last_resolve_fix_kernel(FrameDev F,
             if (bin_f[i] & culled) match_f[i] = -2;  // set to NULL (:1459)
     }
     if (tid == 0) *nmatches_out = nmatches;
+}
+
+__global__ __launch_bounds__(1024) void proj_last_resolve_fix_kernel(FrameDev F, ProjLastDev P, int check_ori,
+                                                                     const QuerySlot *__restrict__ slots,
+                                                                     const Entry *__restrict__ pool, int32_t *match_f,
+                                                                     uint32_t *bin_f, int32_t *nmatches_out, int32_t *choice)
+{
+    proj_last_resolve_fix_body<1024>(F, P, check_ori, slots, pool, match_f, bin_f, nmatches_out, choice);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1434,9 +1476,9 @@ __device__ __forceinline__ ProjSetup proj_gen_setup(const FrameDev &F, const Pro
 // Frame::AssignFeaturesToGrid (src/Frame.cc:259-274, PosInGrid :411-424): one workgroup; cell of every feature,
 // per-cell counts by LDS atomics, exclusive scan, and a stable fill (rank of a feature inside its cell = number of
 // earlier features of the same cell, which is the push_back order of the reference)
-__global__ __launch_bounds__(256) void assign_grid_kernel(int n, const float *__restrict__ kp_x, const float *__restrict__ kp_y,
-                                                          float min_x, float min_y, float gwi, float ghi,
-                                                          int32_t *__restrict__ grid_off, int32_t *__restrict__ grid_idx)
+__device__ __forceinline__ void assign_grid_body(int n, const float *__restrict__ kp_x, const float *__restrict__ kp_y,
+                                                 float min_x, float min_y, float gwi, float ghi,
+                                                 int32_t *__restrict__ grid_off, int32_t *__restrict__ grid_idx)
 {
     extern __shared__ int32_t gsh[];
     constexpr int NC = GRID_COLS * GRID_ROWS;
@@ -1487,6 +1529,13 @@ __global__ __launch_bounds__(256) void assign_grid_kernel(int n, const float *__
         for (int j = 0; j < i; ++j) rank += cell[j] == c;
         grid_idx[cnt[c] + rank] = i;
     }
+}
+
+__global__ __launch_bounds__(256) void assign_grid_kernel(int n, const float *__restrict__ kp_x, const float *__restrict__ kp_y,
+                                                          float min_x, float min_y, float gwi, float ghi,
+                                                          int32_t *__restrict__ grid_off, int32_t *__restrict__ grid_idx)
+{
+    assign_grid_body(n, kp_x, kp_y, min_x, min_y, gwi, ghi, grid_off, grid_idx);
 }
 
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:672-693)
@@ -3112,3 +3161,5 @@ int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_v
 }
 
 }  // extern "C"
+
+#include "frames_impl.inc"

@@ -507,3 +507,5 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
 float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s) { return s ? s->last_pose_ms : 0.f; }
 
 }  // extern "C"
+
+#include "frames_pose.inc"

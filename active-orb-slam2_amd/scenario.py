@@ -1,0 +1,139 @@
+"""Synthetic tracking scenario for the per-frame chain (tests/, bench.py): B independent (LastFrame, CurrentFrame) pairs.
+
+Datasets are absent, so a pair is a textured fronto-parallel plane seen by a translating RGB-D camera:
+the current image is the last one shifted by an integer number of pixels plus pixel noise, the depth image is the
+plane's depth with a few invalid holes, and a third ("older") view of the same plane provides local map points that
+are not in the last frame.  Everything the chain needs besides the images -- the MapPoint table, LastFrame's
+mvpMapPoints, the local map point lists, the motion-model pose guesses -- is derived once, from the keypoints the
+extractor finds in the last / older views, by `build_map()`.  Pure numpy; deterministic per seed.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import synth
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+
+def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10):
+    """Images, depth maps and poses of `batch` (LastFrame, CurrentFrame) pairs (`n_unique` distinct ones, tiled)."""
+    c = synth.CONFIGS[cfg]
+    W, H = c["w"], c["h"]
+    fx, fy, cx, cy, mbf = (np.float32(c[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
+    M = 2 * max_shift + 4
+    nu = min(batch, n_unique or batch)
+    rng = np.random.default_rng(77000 + seed)
+    last = np.zeros((nu, H, W), np.uint8)
+    cur = np.zeros((nu, H, W), np.uint8)
+    old = np.zeros((nu, H, W), np.uint8)
+    depth_cur = np.zeros((nu, H, W), np.float32)
+    depth_last = np.zeros((nu, H, W), np.float32)
+    shift = np.zeros((nu, 2), np.int32)
+    shift_old = np.zeros((nu, 2), np.int32)
+    Z = np.zeros(nu, np.float64)
+    Tlw = np.zeros((nu, 4, 4), np.float64)
+    Tcw = np.zeros((nu, 4, 4), np.float64)
+    Tguess = np.zeros((nu, 4, 4), np.float64)
+    for u in range(nu):
+        canvas = synth.synth_image(seed * 1000 + u, W + 2 * M, H + 2 * M).astype(np.float32)
+        dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+        ex, ey = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+        shift[u] = (dx, dy)
+        shift_old[u] = (ex, ey)
+        last[u] = canvas[M:M + H, M:M + W].astype(np.uint8)
+        cur[u] = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
+        old[u] = np.clip(np.rint(canvas[M + ey:M + ey + H, M + ex:M + ex + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
+        Z[u] = rng.uniform(1.5, 3.0)
+        for dimg in (depth_cur[u], depth_last[u]):
+            dimg[:] = np.float32(Z[u])
+            for _ in range(12):   # invalid-depth holes: monocular observations (mvuRight < 0)
+                x0, y0 = int(rng.integers(0, W - 40)), int(rng.integers(0, H - 40))
+                dimg[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(8, 40))] = 0.0
+        # world frame: an arbitrary rigid transform of the last camera frame
+        Rlw = _rot(rng.normal(size=3), rng.uniform(0, np.pi))
+        T = np.eye(4)
+        T[:3, :3] = Rlw
+        T[:3, 3] = rng.uniform(-5, 5, 3)
+        Tlw[u] = T
+        # the camera translates parallel to the image plane: a feature at u_l in the last image appears at u_l - dx
+        t_l = np.array([dx * Z[u] / float(fx), dy * Z[u] / float(fy), 0.0])
+        Tcl = np.eye(4)
+        Tcl[:3, 3] = -t_l
+        Tcw[u] = Tcl @ T
+        # motion-model guess (mVelocity * mLastFrame.mTcw): the true pose off by a fraction of a degree and ~2 px
+        E = np.eye(4)
+        E[:3, :3] = _rot(rng.normal(size=3), rng.normal(0, 0.002))
+        E[:3, 3] = rng.normal(0, 2.0 * Z[u] / float(fx), 3)
+        Tguess[u] = E @ Tcw[u]
+    idx = np.arange(batch) % nu
+    return dict(cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
+                last=last, cur=cur, old=old, depth_cur=depth_cur, depth_last=depth_last, shift=shift, shift_old=shift_old, Z=Z,
+                Tlw=Tlw.astype(np.float32), Tcw_true=Tcw.astype(np.float32), Tcw_guess=Tguess.astype(np.float32))
+
+
+def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors, n_local: int = 1500, seed: int = 0):
+    """MapPoint table + LastFrame members + local map point lists from the keypoints of the last / older views.
+
+    last_kps[u] / old_kps[u]: structured keypoint arrays (x, y, size, angle, response, octave, class_id) of unique pair u,
+    last_desc[u] / old_desc[u]: their descriptors.  Returns numpy arrays with one slice per UNIQUE pair; rows of the
+    table are global (pair u owns a contiguous range)."""
+    nu = scen["n_unique"]
+    fx, fy, cx, cy = (float(scen[k]) for k in ("fx", "fy", "cx", "cy"))
+    rng = np.random.default_rng(99000 + seed)
+    sf = np.asarray(scale_factors, np.float64)
+    pos, desc, has_obs, normal, mind, maxd = [], [], [], [], [], []
+    cap = max(max(len(k) for k in last_kps), 1)
+    mp_last = np.full((nu, cap), -1, np.int32)
+    outl_last = np.zeros((nu, cap), np.uint8)
+    local = np.full((nu, n_local), -1, np.int32)
+    row0 = 0
+    for u in range(nu):
+        Tlw = scen["Tlw"][u].astype(np.float64).reshape(4, 4)
+        Rwl, twl = Tlw[:3, :3].T, -Tlw[:3, :3].T @ Tlw[:3, 3]
+        Ow = twl   # centre of the last camera in world coordinates
+        Z = scen["Z"][u]
+        rows_last, rows_old = [], []
+
+        def add(x_l, y_l, octave, d, obs):
+            Xl = np.array([(x_l - cx) * Z / fx, (y_l - cy) * Z / fy, Z])
+            Xw = Rwl @ Xl + twl
+            n = Xw - Ow
+            dist = np.linalg.norm(n)
+            pos.append(Xw.astype(np.float32)); desc.append(d); has_obs.append(obs)
+            normal.append((n / dist).astype(np.float32))
+            mx = dist * sf[int(octave)]
+            maxd.append(np.float32(1.2 * mx)); mind.append(np.float32(0.8 * mx / sf[-1]))
+            return len(pos) - 1
+
+        dl = scen["depth_last"][u]
+        for i, k in enumerate(last_kps[u]):
+            if dl[int(k["y"]), int(k["x"])] <= 0 or rng.random() < 0.08:
+                continue   # no depth -> no map point was created for it; a few more stay NULL
+            mp_last[u, i] = add(float(k["x"]), float(k["y"]), k["octave"], last_desc[u][i], 1 if rng.random() < 0.9 else 0)
+            rows_last.append(mp_last[u, i])
+            if rng.random() < 0.03:
+                outl_last[u, i] = 1   # LastFrame.mvbOutlier
+        ex, ey = scen["shift_old"][u]
+        for i, k in enumerate(old_kps[u]):
+            if rng.random() < 0.5:
+                continue
+            rows_old.append(add(float(k["x"]) + ex, float(k["y"]) + ey, k["octave"], old_desc[u][i], 1))
+        junk = []
+        for _ in range(60):   # points behind the camera / far outside the image: rejected by isInFrustum
+            Xl = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-5, 0.5)])
+            Xw = Rwl @ Xl + twl
+            pos.append(Xw.astype(np.float32)); desc.append(rng.integers(0, 256, 32, dtype=np.uint8)); has_obs.append(1)
+            normal.append(np.array([0, 0, 1], np.float32)); maxd.append(np.float32(100)); mind.append(np.float32(0.1))
+            junk.append(len(pos) - 1)
+        lst = (rows_old + rows_last + junk)[:n_local]
+        local[u, :len(lst)] = lst
+        row0 = len(pos)
+    table = dict(n=len(pos), pos=np.stack(pos).astype(np.float32), desc=np.stack(desc).astype(np.uint8),
+                 has_obs=np.asarray(has_obs, np.uint8), normal=np.stack(normal).astype(np.float32),
+                 min_dist=np.asarray(mind, np.float32), max_dist=np.asarray(maxd, np.float32))
+    return dict(table=table, mp_last=mp_last, outlier_last=outl_last, local=local, n_local=n_local)

@@ -122,6 +122,10 @@ int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t
                                               aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap,
                                               int32_t *d_n_out);
 int aos2_extractor_wait(aos2_extractor_t *e);
+/* Device-side ordering instead of a host wait: everything enqueued on `hip_stream` (a hipStream_t of the caller, e.g.
+ * the stream of an aos2_frames_t, or 0 for the null stream) after this call runs after everything enqueued on the
+ * extractor's streams before it.  Errors of the batches in flight are still reported by aos2_extractor_wait(). */
+int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream);
 
 /* mvImagePyramid[level] (include/ORBextractor.h:85; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:502,592,609) of image `image` of the last extract on this handle.
@@ -602,6 +606,83 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
                            int n_problems);
 /* device time (ms, HIP events) of the kernel of the last aos2_pose_optimization call */
 float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident frame batches: the per-frame chain of Tracking::Track (src/Tracking.cc:862-870, 963-1027, 1302-1352)
+ *   ORBextractor::operator() -> Frame::Frame -> SearchByProjection(Current, Last) -> PoseOptimization
+ *   -> SearchLocalPoints (isInFrustum + SearchByProjection(F, vpMapPoints)) -> PoseOptimization
+ * with the Frame members and the MapPoint table kept in HBM between the calls, so that no
+ * keypoint, descriptor, match or pose crosses PCIe inside the chain.  A batch is B independent Frames (replaying
+ * or relocalising many frames, several cameras, or B (LastFrame, CurrentFrame) pairs); every call is enqueued on the
+ * batch's stream and returns without waiting; aos2_frames_wait() waits and reports errors.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct aos2_frames aos2_frames_t;
+
+/* the members of MapPoint the chain reads (include/MapPoint.h), as a table in device memory; Frames refer to its rows */
+typedef struct {
+    int32_t n;
+    const float *pos;        /* n x 3  GetWorldPos() */
+    const uint8_t *desc;     /* n x 32 GetDescriptor() */
+    const uint8_t *has_obs;  /* n      Observations() > 0 */
+    const float *normal;     /* n x 3  GetNormal()                       (SearchLocalPoints only) */
+    const float *min_dist;   /* n      GetMinDistanceInvariance()        (SearchLocalPoints only) */
+    const float *max_dist;   /* n      GetMaxDistanceInvariance()        (SearchLocalPoints only) */
+} aos2_map_points_dev_t;
+
+/* batch frames of at most cap (<= 7680) keypoints each */
+int aos2_frames_create(int device, int batch, int cap, aos2_frames_t **out);
+void aos2_frames_destroy(aos2_frames_t *f);
+void *aos2_frames_stream(aos2_frames_t *f);   /* the batch's hipStream_t */
+/* waits for everything enqueued on the batch; AOS2_ERR_CAPACITY if a frame's search windows did not fit the entry pool */
+int aos2_frames_wait(aos2_frames_t *f);
+
+/* Frame::Frame(imGray, imDepth, ...)  src/Frame.cc:116-170, the part after ExtractORB: N = mvKeys.size(),
+ * UndistortKeyPoints for a rectified / distortion-free camera (mvKeysUn = mvKeys, :436-442), ComputeStereoFromRGBD
+ * (:672-693), mvpMapPoints = NULL, mvbOutlier = false, AssignFeaturesToGrid (:259-274); scale tables copied from the
+ * extractor (:94-100).  d_kps / d_desc / d_n ([batch][cap], [batch][cap][32], [batch]) are the device outputs of `e`'s
+ * last batch, which may still be in flight: the call orders itself behind it on the device and keeps referring to
+ * these buffers (the caller keeps them alive and unchanged while the batch is used).
+ * d_depth: `batch` float images (imDepth after convertTo(CV_32F, mDepthMapFactor), Tracking.cc:226-227), depth_stride
+ * floats per row, depth_image_stride floats per image; NULL = monocular (mvuRight = mvDepth = -1). */
+int aos2_frames_build(aos2_frames_t *f, aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps,
+                      const uint8_t *d_desc, const int32_t *d_n, int cap, int w, int h, const float *d_depth,
+                      int depth_stride, size_t depth_image_stride, float fx, float fy, float cx, float cy, float mbf);
+/* Frame::SetPose for every frame: d_Tcw = [batch][16] float32 in device memory (mVelocity * mLastFrame.mTcw, Tracking.cc:975) */
+int aos2_frames_set_pose(aos2_frames_t *f, const float *d_Tcw);
+/* mvpMapPoints (and optionally mvbOutlier) from the host: mp = [batch][cap] rows of `table` (-1 = NULL), outlier =
+ * [batch][cap] or NULL (unchanged); for setting up a LastFrame batch and tests */
+int aos2_frames_set_map_points(aos2_frames_t *f, const int32_t *mp, const uint8_t *outlier,
+                               const aos2_map_points_dev_t *table);
+/* members back to the host (waits for the batch): */
+#define AOS2_FRAMES_MAP_POINTS 0 /* int32 [batch][cap]  mvpMapPoints as table rows */
+#define AOS2_FRAMES_OUTLIER 1    /* uint8 [batch][cap]  mvbOutlier */
+#define AOS2_FRAMES_TCW 2        /* float [batch][16]   mTcw */
+#define AOS2_FRAMES_U_RIGHT 3    /* float [batch][cap]  mvuRight */
+#define AOS2_FRAMES_DEPTH 4      /* float [batch][cap]  mvDepth */
+#define AOS2_FRAMES_GRID_OFF 5   /* int32 [batch][64 * 48 + 1]  mGrid as CSR */
+#define AOS2_FRAMES_GRID_IDX 6   /* int32 [batch][cap] */
+int aos2_frames_get(aos2_frames_t *f, int what, void *dst, size_t bytes);
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+ * src/ORBmatcher.cc:1328-1470 for the pairs (cur frame b, last frame b): reads last's mvpMapPoints / mvbOutlier /
+ * mvKeys / mTcw and the table, writes cur's mvpMapPoints (the caller has just filled them with NULL,
+ * Tracking.cc:977).  d_nmatches: [batch] return values in device memory, may be NULL.  The reference's retry with
+ * 2 * th when fewer than 20 matches were found (Tracking.cc:984-988) is the caller's decision. */
+int aos2_frames_search_by_projection_last(aos2_frames_t *cur, const aos2_frames_t *last,
+                                          const aos2_map_points_dev_t *mps, float th, int mono,
+                                          int check_orientation, int32_t *d_nmatches);
+/* int Optimizer::PoseOptimization(Frame *pFrame)  src/Optimizer.cc:239-452 for every frame: edges from the features
+ * that hold a map point (:260-350), result in mTcw and mvbOutlier; d_inliers [batch] (may be NULL) = return values */
+int aos2_frames_pose_optimization(aos2_frames_t *f, const aos2_map_points_dev_t *mps, int32_t *d_inliers);
+/* Tracking::TrackWithMotionModel :1008-1025 after PoseOptimization: a feature flagged as outlier loses its map point
+ * (mvpMapPoints[i] = NULL, mvbOutlier[i] = false; the point counts as seen in this frame) */
+int aos2_frames_discard_outliers(aos2_frames_t *f);
+/* void Tracking::SearchLocalPoints()  src/Tracking.cc:1302-1352: d_local = [batch][n_local] rows of the table (-1 =
+ * none) = mvpLocalMapPoints of every frame; points already in the frame are skipped (:1305-1328), the others go
+ * through Frame::isInFrustum(pMP, 0.5) (src/Frame.cc:298-354) and ORBmatcher(nnratio).SearchByProjection(F,
+ * vpMapPoints, th) (src/ORBmatcher.cc:45-129); writes mvpMapPoints.  At most 4096 features per frame. */
+int aos2_frames_search_local_points(aos2_frames_t *f, const aos2_map_points_dev_t *mps, const int32_t *d_local,
+                                    int n_local, float th, float nnratio, int32_t *d_nmatches);
 
 /* ------------------------------------------------------------------------------------------
  * Test taps (no reference equivalent): shared primitives run in isolation.

@@ -1,0 +1,121 @@
+"""Device-resident frame batches (aos2_frames_*): every stage of the per-frame tracking chain against the oracle's
+host chain (oracle/chain.py) on the same scenario: integer results (map point assignments, outlier flags, grids, match
+counts) bit-identical, mvuRight / mvDepth bit-identical, poses within 1e-5 (float32 write-back of an f64 solve)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    return (np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 2 * np.spacing(np.abs(b).astype(np.float32))).all()
+
+
+@pytest.fixture(scope="module")
+def ochain(oracle):
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import chain
+    return chain
+
+
+@pytest.mark.parametrize("seed,batch", [(1, 6), (2, 3)])
+def test_chain_stage_by_stage_vs_oracle(pkg, oracle, ochain, gpu, seed, batch):
+    import torch
+    scen = pkg.scenario.tracking_scenario(seed, batch, n_unique=batch)
+    tc = pkg.chain.TrackingChain(scen, n_local=1500)
+    B, W, H, cap = tc.B, tc.W, tc.H, tc.cap
+    F = pkg.capi.Frames
+    # --- extraction + Frame::Frame
+    tc.ex.extract_batch_device(tc.d_cur.data_ptr(), B, W, H, W, W * H, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), cap, tc.d_n.data_ptr())
+    c = tc.cur
+    s = scen
+    c.build(tc.ex, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), tc.d_n.data_ptr(), W, H, tc.d_depth.data_ptr(),
+            float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+    c.set_pose(tc.d_guess.data_ptr())
+    n = tc.d_n.cpu().numpy()
+    kps = tc.d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.capi.KP_DTYPE).reshape(B, cap)
+    desc = tc.d_desc.cpu().numpy()
+    oe = oracle.Extractor(nfeatures=scen["nfeatures"])
+    sf, isg = oe.scale_factors, oe.inv_sigma2
+    frames = []
+    ur, dp, goff, gidx = c.get(F.U_RIGHT), c.get(F.DEPTH), c.get(F.GRID_OFF), c.get(F.GRID_IDX)
+    for b in range(B):
+        okps, odesc = oe.extract(scen["cur"][b])
+        assert len(okps) == n[b] and okps.tobytes() == kps[b, :n[b]].tobytes() and (odesc == desc[b, :n[b]]).all()
+        f = ochain.frame_from_extraction(okps, odesc, scen["depth_cur"][b], scen, sf, isg)
+        frames.append(f)
+        assert ur[b, :n[b]].tobytes() == f["u_right"].tobytes() and dp[b, :n[b]].tobytes() == f["depth"].tobytes()
+        assert (goff[b] == f["grid_off"]).all() and (gidx[b, :goff[b, -1]] == f["grid_idx"][:goff[b, -1]]).all()
+        assert (f["u_right"] < 0).any() and (f["u_right"] >= 0).any()   # mono and stereo observations both occur
+    # LastFrame members of the oracle chain
+    last_h = []
+    for b in range(B):
+        lk, _ = tc.host_last[b]
+        nl = len(lk)
+        last_h.append(dict(mp=tc.last_mp[b, :nl], outlier=tc.last_outlier[b, :nl], kp_octave=lk["octave"], kp_angle=lk["angle"]))
+    table = tc.map["table"]
+    want = [ochain.track_frame(frames[b], last_h[b], table, tc.map["local"][b], scen["Tcw_guess"][b], scen["Tlw"][b], scen) for b in range(B)]
+    # --- SearchByProjection(CurrentFrame, LastFrame)
+    c.SearchByProjectionLast(tc.last, tc.table, tc.th_last, mono=False, check_orientation=True, d_nmatches=tc.d_nm[0].data_ptr())
+    mp = c.get(F.MAP_POINTS)
+    nm = tc.d_nm.cpu().numpy()
+    for b in range(B):
+        assert nm[0, b] == want[b]["nmatches_last"] and nm[0, b] > 100
+        assert (mp[b, :n[b]] == want[b]["mp_after_last"]).all() and (mp[b, n[b]:] == -1).all()
+    # --- PoseOptimization + discard
+    c.PoseOptimization(tc.table, tc.d_nm[1].data_ptr())
+    T1, o1 = c.get(F.TCW), c.get(F.OUTLIER)
+    nm = tc.d_nm.cpu().numpy()
+    for b in range(B):
+        assert nm[1, b] == want[b]["inliers_1"]
+        assert (o1[b, :n[b]] == want[b]["outlier_1"]).all()
+        assert close(T1[b], want[b]["Tcw_1"])
+        # the optimised pose is close to the true one (the scenario is consistent)
+        assert np.abs(T1[b].reshape(4, 4)[:3, 3] - scen["Tcw_true"][b][:3, 3]).max() < 0.02
+    c.discard_outliers()
+    mp = c.get(F.MAP_POINTS)
+    for b in range(B):
+        assert (mp[b, :n[b]] == want[b]["mp_after_discard"]).all()
+    # --- SearchLocalPoints
+    c.SearchLocalPoints(tc.table, tc.d_local.data_ptr(), tc.n_local, tc.th_local, tc.nnratio_local, tc.d_nm[2].data_ptr())
+    mp = c.get(F.MAP_POINTS)
+    nm = tc.d_nm.cpu().numpy()
+    for b in range(B):
+        assert nm[2, b] == want[b]["nmatches_local"] and nm[2, b] > 20
+        assert (mp[b, :n[b]] == want[b]["mp_after_local"]).all()
+    # --- PoseOptimization
+    c.PoseOptimization(tc.table, tc.d_nm[3].data_ptr())
+    T2, o2 = c.get(F.TCW), c.get(F.OUTLIER)
+    nm = tc.d_nm.cpu().numpy()
+    for b in range(B):
+        assert nm[3, b] == want[b]["inliers_2"]
+        assert (o2[b, :n[b]] == want[b]["outlier_2"]).all()
+        assert close(T2[b], want[b]["Tcw_2"])
+    c.wait()
+    # --- the same chain enqueued in one go (asynchronously behind the extractor) gives the same members
+    tc.step()
+    tc.wait()
+    assert (c.get(F.MAP_POINTS) == mp).all() and (c.get(F.OUTLIER) == o2).all() and c.get(F.TCW).tobytes() == T2.tobytes()
+    assert (tc.d_nm.cpu().numpy() == nm).all()
+
+
+def test_chain_tiled_batch_and_window_budget(pkg, gpu, monkeypatch):
+    """a tiled batch (frames repeat) gives repeated results; an entry pool that is too small is reported, not ignored"""
+    scen = pkg.scenario.tracking_scenario(3, 16, n_unique=4)
+    tc = pkg.chain.TrackingChain(scen, n_local=1200)
+    tc.step()
+    tc.wait()
+    F = pkg.capi.Frames
+    mp, T = tc.cur.get(F.MAP_POINTS), tc.cur.get(F.TCW)
+    for b in range(4, 16):
+        assert (mp[b] == mp[b % 4]).all() and T[b].tobytes() == T[b % 4].tobytes()
+    assert (tc.d_nm.cpu().numpy()[3] > 50).all()
+    monkeypatch.setenv("AOS2_FRAMES_WINDOW_BUDGET", "1")
+    tc2 = pkg.chain.TrackingChain(scen, n_local=1200)
+    tc2.step()
+    with pytest.raises(pkg.AosError):
+        tc2.wait()
