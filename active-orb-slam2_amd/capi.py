@@ -861,6 +861,21 @@ class LocalBA:
         _check(self.L.aos2_lba_solve_batch(self.h, C.byref(S), C.byref(R), n))
         return [self._result(R[i], arrs[i]) for i in range(n)]
 
+    def prepare_batch(self, probs, iters=(5, 10), want_chi2=False):
+        """ctypes problem / result arrays for repeated aos2_lba_solve_batch calls on the same inputs (bench harness)"""
+        n = len(probs)
+        keep = []
+        S, R = (_LbaProblem * n)(), (_LbaResult * n)()
+        arrs = [self._fill(S[i], R[i], probs[i], None, iters, keep) for i in range(n)]
+        if not want_chi2:
+            for i in range(n):
+                R[i].edge_chi2 = None
+        return dict(S=S, R=R, arrs=arrs, keep=keep, n=n)
+
+    def solve_prepared(self, prep):
+        _check(self.L.aos2_lba_solve_batch(self.h, C.byref(prep["S"]), C.byref(prep["R"]), prep["n"]))
+        return prep["R"]
+
     def debug_stop_at_poll(self, poll):
         _check(self.L.aos2_lba_debug_stop_at_poll(self.h, int(poll)))
 
