@@ -1,0 +1,105 @@
+"""The reference-signature shims (active-orb-slam2_amd/host/ref/ORBmatcher.h, Optimizer.h):
+    int  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)
+    int  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float)
+    int  ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)
+    int  Optimizer::PoseOptimization(Frame*)
+    void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*)
+compiled with g++ against minimal stand-ins of Frame / KeyFrame / MapPoint / Map (tests/cpp/refstub) and driven like
+Tracking.cc / LocalMapping.cc drive the reference: what they leave in the objects equals the ctypes path's results."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bundle_io  # noqa: E402
+
+
+def build(tmp_path, pkg):
+    exe = str(tmp_path / "ref_signature_test")
+    libdir = os.path.dirname(pkg.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "ref_signature_test.cpp"),
+                           "-o", exe, "-L" + libdir, "-laos2", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def make_bundle(pkg, seed=0, lba=None):
+    S = pkg.synth
+    bow = S.synth_bow_problem(40 + seed, 1000, 1000, nnratio=0.7)
+    f, mp = S.synth_proj_mp_problem(50 + seed)
+    cur, last = S.synth_proj_last_problem(60 + seed, n=1000)
+    po = S.synth_pose_problem(70 + seed, n=700)
+    ba = S.synth_lba_problem(**(lba or dict(seed=80 + seed, n_local=6, n_fixed=4, n_points=400, stereo_frac=0.6)))
+    # the reference tells a stereo observation by mvuRight >= 0 (Optimizer.cc:278, :595): a synthetic stereo observation
+    # whose right coordinate fell left of the image border is a monocular one for both paths
+    po["stereo"] = (po["stereo"].astype(bool) & (po["obs"][:, 2] >= 0)).astype(np.uint8)
+    ba["edge_stereo"] = (ba["edge_stereo"].astype(bool) & (ba["edge_obs"][:, 2] >= 0)).astype(np.uint8)
+    arrays = {}
+    for k, v in bow.items():
+        arrays["bow_" + k] = np.asarray(v)
+    for k, v in f.items():
+        arrays["pm_f_" + k] = np.asarray(v)
+    for k, v in mp.items():
+        arrays["pm_" + k] = np.asarray(v)
+    for k, v in cur.items():
+        arrays["pl_f_" + k] = np.asarray(v)
+    for k, v in last.items():
+        arrays["pl_" + k] = np.asarray(v)
+    for k, v in po.items():
+        arrays["po_" + k] = np.asarray(v)
+    for k, v in ba.items():
+        arrays["ba_" + k] = np.asarray(v)
+    for k, v in list(arrays.items()):   # scalars travel as float32 / int32
+        if v.ndim == 0:
+            arrays[k] = v.astype(np.float32) if v.dtype.kind == "f" else v.astype(np.int32)
+    return arrays, dict(bow=bow, f=f, mp=mp, cur=cur, last=last, po=po, ba=ba)
+
+
+def test_shims_compile_without_device(pkg, tmp_path):
+    exe = build(tmp_path, pkg)
+    arrays, _ = make_bundle(pkg)
+    bundle_io.save(tmp_path / "in.bundle", arrays)
+    r = subprocess.run([exe, str(tmp_path / "in.bundle"), str(tmp_path / "out.bundle")], capture_output=True, text=True)
+    assert r.returncode in (0, 3)
+    if pkg.device_count() == 0:
+        assert r.returncode == 3   # loud: no device, nothing computed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lba", [(0, None), (1, dict(seed=91, n_local=9, n_fixed=0, n_points=500, include_kf0=True, stereo_frac=0.3))])
+def test_shims_equal_ctypes_path(pkg, gpu, tmp_path, seed, lba):
+    exe = build(tmp_path, pkg)
+    arrays, P = make_bundle(pkg, seed, lba)
+    bundle_io.save(tmp_path / "in.bundle", arrays)
+    r = subprocess.run([exe, str(tmp_path / "in.bundle"), str(tmp_path / "out.bundle")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = bundle_io.load(tmp_path / "out.bundle")
+    # SearchByBoW
+    n, m = pkg.Matcher(float(P["bow"]["nnratio"]), True).SearchByBoW(P["bow"])
+    assert int(out["bow_n"][0]) == n and n > 100 and (out["bow_match"] == m).all()
+    # SearchByProjection(F, vpMapPoints, th)
+    n, m = pkg.Matcher(float(P["mp"]["nnratio"]), True).SearchByProjection(P["f"], P["mp"], float(P["mp"]["th"]))
+    assert int(out["pm_n"][0]) == n and n > 50 and (out["pm_match"] == m).all()
+    # SearchByProjection(Current, Last, th, bMono): the rotation check resets culled features to NULL
+    n, m = pkg.Matcher(0.9, bool(P["last"]["check_orientation"])).SearchByProjectionLast(P["cur"], P["last"], float(P["last"]["th"]), int(P["last"]["mono"]))
+    assert int(out["pl_n"][0]) == n and n > 50 and (out["pl_match"] == np.where(m == -2, -1, m)).all()
+    # PoseOptimization(Frame*)
+    r1 = pkg.LocalBA().PoseOptimization(P["po"])
+    assert tuple(out["po_n"]) == (r1["n_inliers"], r1["n_bad"]) and (out["po_outlier"] == r1["outlier"]).all()
+    assert out["po_Tcw"].tobytes() == r1["Tcw"].tobytes()
+    # LocalBundleAdjustment(KeyFrame*, bool*, Map*): the shim emits the points in the order it meets them in the local
+    # keyframes' feature lists (Optimizer.cc:471-488), so sums run in another order than for the synth arrays: 1e-5
+    r2 = pkg.LocalBA().LocalBundleAdjustment(P["ba"])
+    ba = P["ba"]
+    free = ba["pose_fixed"] == 0
+    assert np.abs(out["ba_pose_Tcw"].reshape(-1, 16) - r2["pose_Tcw"]).max() <= 1e-5 + 4e-6
+    assert np.abs(out["ba_point_xyz"].reshape(-1, 3) - r2["point_xyz"]).max() <= 1e-5 + 8e-6
+    assert (out["ba_pose_Tcw"].reshape(-1, 16)[~free] == ba["pose_Tcw"][~free]).all()   # fixed cameras are not written back
+    assert (out["ba_erased"] == r2["edge_outlier"]).all() and r2["edge_outlier"].sum() > 0
+    assert int(out["ba_n"][0]) == ba["n_points"]   # UpdateNormalAndDepth for every local map point
+    t = out["timing_us"].reshape(-1, 3)
+    print("\nshim timing (gather, C-ABI call, scatter) us:", dict(zip(["SearchByBoW", "SearchByProjection(F,MPs)", "SearchByProjection(Cur,Last)",
+                                                                        "PoseOptimization", "LocalBundleAdjustment"], t.round(1).tolist())))
