@@ -16,8 +16,12 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };  // include/ORBextractor.h:49 (unused by the reference too)
 
+    // exposePyramid: copy all bordered levels back after every operator() (the reference's mvImagePyramid is always
+    // there).  Off by default: its only reader, Frame::ComputeStereoMatches, runs on the device pyramids
+    // (host/Frame.h), so the copy (8 levels, ~1.4 MB for 640x480) would be paid by every frame for nothing; a caller
+    // that does read mvImagePyramid calls FillImagePyramid() after operator().
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0,
-                 bool exposePyramid = true)
+                 bool exposePyramid = false)
         : nlevels_(nlevels), exposePyramid_(exposePyramid)
     {
         if (aos2_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_) != AOS2_OK)
@@ -53,17 +57,21 @@ public:
             descriptors.create(n, 32);  // :1068
             std::copy(scratch_.begin(), scratch_.begin() + (size_t)n * 32, descriptors.data);
         }
-        if (exposePyramid_) {
-            // mvImagePyramid[level]: ROI (interior) of a buffer that carries the 19-px REFLECT_101 frame
-            for (int l = 0; l < nlevels_; ++l) {
-                int w = 0, h = 0;
-                aos2_extractor_pyramid_level_size(h_, l, &w, &h);
-                aos2::Mat8 full;
-                full.create(h + 38, w + 38);
-                if (aos2_extractor_pyramid_level(h_, 0, l, 19, full.data, (int)full.step) != AOS2_OK)
-                    throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
-                mvImagePyramid[l] = full.roi(19, 19, w, h);
-            }
+        if (exposePyramid_) FillImagePyramid();
+    }
+
+    // mvImagePyramid[level] of the last operator() call: ROI (interior) of a buffer that carries the 19-px
+    // REFLECT_101 frame (src/ORBextractor.cc:1113-1128)
+    void FillImagePyramid()
+    {
+        for (int l = 0; l < nlevels_; ++l) {
+            int w = 0, h = 0;
+            aos2_extractor_pyramid_level_size(h_, l, &w, &h);
+            aos2::Mat8 full;
+            full.create(h + 38, w + 38);
+            if (aos2_extractor_pyramid_level(h_, 0, l, 19, full.data, (int)full.step) != AOS2_OK)
+                throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
+            mvImagePyramid[l] = full.roi(19, 19, w, h);
         }
     }
 

@@ -1,4 +1,5 @@
-// ORB_SLAM2::Optimizer::LocalBundleAdjustment surface (include/Optimizer.h:45) over a POD problem.
+// ORB_SLAM2::Optimizer over POD problems (the SoA level under host/ref/Optimizer.h, which keeps the reference's
+// signatures and does the gathering).
 // The real Optimizer.cc keeps `void static LocalBundleAdjustment(KeyFrame*, bool*, Map*)`: its
 // window gathering (:457-505) fills aos2_lba_problem_t, this call replaces :507-744, and its
 // write-back (:746-778) consumes aos2_lba_result_t.
@@ -7,6 +8,7 @@
 #include <string>
 
 #include "aos2_types.h"
+#include "ref/aos2_handles.h"   // one persistent optimiser handle per calling thread
 
 namespace ORB_SLAM2 {
 
@@ -15,10 +17,8 @@ public:
     // returns false when *pbStopFlag was already set (the reference returns before optimising)
     bool static LocalBundleAdjustment(const aos2_lba_problem_t &problem, aos2_lba_result_t &result, int device = 0)
     {
-        aos2_lba_t *s = nullptr;
-        if (aos2_lba_create(device, &s) != AOS2_OK) throw std::runtime_error(aos2_last_error());
-        const int st = aos2_lba_solve(s, &problem, &result);
-        aos2_lba_destroy(s);
+        aos2::default_device() = device;
+        const int st = aos2_lba_solve(aos2::optimizer_handle(), &problem, &result);
         if (st == AOS2_ERR_STOPPED) return false;
         if (st != AOS2_OK) throw std::runtime_error(std::string("LocalBundleAdjustment: ") + aos2_last_error());
         return true;
@@ -29,10 +29,8 @@ public:
     // into pFrame->mTcw / pFrame->mvbOutlier for the features that have a map point
     int static PoseOptimization(const aos2_pose_problem_t &frame, aos2_pose_result_t &result, int device = 0)
     {
-        aos2_lba_t *s = nullptr;
-        if (aos2_lba_create(device, &s) != AOS2_OK) throw std::runtime_error(aos2_last_error());
-        const int st = aos2_pose_optimization(s, &frame, &result, 1);
-        aos2_lba_destroy(s);
+        aos2::default_device() = device;
+        const int st = aos2_pose_optimization(aos2::optimizer_handle(), &frame, &result, 1);
         if (st != AOS2_OK) throw std::runtime_error(std::string("PoseOptimization: ") + aos2_last_error());
         return result.n_inliers;
     }

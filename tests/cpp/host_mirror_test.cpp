@@ -55,6 +55,7 @@ int main(int argc, char **argv)
     aos2::Mat8 image(h, w, buf.data(), (size_t)w), mask, desc;
     std::vector<aos2::KeyPoint> kps;
     ex(image, mask, kps, desc);
+    ex.FillImagePyramid();   // (lazy: only a caller that reads mvImagePyramid pays for the copy)
     printf("n %zu desc %dx%d pyr0 %dx%d pyr7 %dx%d\n", kps.size(), desc.rows, desc.cols, ex.mvImagePyramid[0].cols,
            ex.mvImagePyramid[0].rows, ex.mvImagePyramid[7].cols, ex.mvImagePyramid[7].rows);
     // the ROI exposes the border like the reference: pixel (-1,-1) of level 0 is REFLECT_101 = (1,1)

@@ -91,6 +91,21 @@ def test_pose_optimization_fewer_than_three_correspondences(pkg, oracle, gpu):
         ba.PoseOptimization(big)
 
 
+def test_pose_optimization_three_to_seven_correspondences(pkg, oracle, gpu):
+    """The smallest systems PoseOptimization accepts (nInitialCorrespondences >= 3, :355-356), with outliers among them:
+    the 6x6 system is close to singular, and still the float32 pose is within 1e-5 of the oracle (fixed-order sums: for
+    n <= 32 the workgroup reduction adds the edges in g2o's insertion order)."""
+    ba = pkg.LocalBA()
+    rng = np.random.default_rng(5)
+    for n in (3, 4, 5, 6, 7):
+        for seed in range(60):
+            p = pkg.synth.synth_pose_problem(3000 + seed, n=n, stereo_frac=float(rng.choice([0.0, 0.5, 1.0])),
+                                             outlier_frac=float(rng.choice([0.0, 0.1, 0.4])), cfg=("kitti", "tum")[seed % 2])
+            want, got = oracle.pose_optimization(p), ba.PoseOptimization(p)
+            assert got["n_inliers"] == want["n_inliers"] and (got["outlier"] == want["outlier"]).all()
+            assert close(got["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16)), (n, seed)
+
+
 def test_pose_optimization_batch_and_golden(pkg, oracle, gpu):
     probs = [pkg.synth.synth_pose_problem(100 + i, n=600 + 37 * i) for i in range(24)]
     ba = pkg.LocalBA()

@@ -36,7 +36,7 @@ for c in range(n_cases):
         if "too small" not in repr(e) and "twice as tall" not in repr(e) and "failed: -3" not in repr(e) and "failed: -4" not in repr(e):
             bad += 1; print("ERROR stereo", c, (w, h, nf), repr(e))
     # ---- PoseOptimization
-    n = int(rng.choice([1, 2, 9, 64, 257, 800, 1025, 3000]))   # (n = 3..5 is ill-conditioned: 1e-5 cannot be expected)
+    n = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 64, 257, 800, 1025, 3000]))
     p = S.synth_pose_problem(700 + c, n=n, stereo_frac=float(rng.choice([0.0, 0.5, 1.0])), outlier_frac=float(rng.choice([0.0, 0.1, 0.4])),
                              cfg=("kitti", "tum")[c % 2])
     wv, gv = O.pose_optimization(p), pkg.LocalBA().PoseOptimization(p)
