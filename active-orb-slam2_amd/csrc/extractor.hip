@@ -571,8 +571,14 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     e->t_enqueue = std::chrono::steady_clock::now();
     int st;
     if ((st = init_device(e))) return st;
-    if (e->in_flight > 0 && (w != e->plan.w || h != e->plan.h || batch > e->batch_cap || cap != e->flight_cap)) {
-        if ((st = finish_device(e))) return st;   // geometry change: scratch is rebuilt, nothing may be in flight
+    // Batches of one flight share the scratch by absolute image index, chunk c of every batch on stream c.  That is
+    // only race-free while the chunk partition stays the same: another batch size cuts the images differently (256 ->
+    // [0,85) [85,170) [170,256); 100 -> [0,33) [33,66) [66,100)), and chunk 1 of the new batch (stream 1) would overwrite
+    // the scratch of images 33..66 that chunk 0 of the old one (stream 0) may still be reading.  So a change of batch
+    // size, like a change of geometry, waits for the flight first.
+    if (e->in_flight > 0 && (w != e->plan.w || h != e->plan.h || batch > e->batch_cap || cap != e->flight_cap ||
+                             batch != e->last_batch)) {
+        if ((st = finish_device(e))) return st;   // scratch is rebuilt / re-partitioned: nothing may be in flight
     }
     if ((st = build_plan(e, w, h))) return st;
     if ((st = ensure_batch(e, batch))) return st;

@@ -115,8 +115,8 @@ int aos2_extractor_extract_batch_device(aos2_extractor_t *e, const uint8_t *d_im
  * Several batches may be enqueued before one wait: chunk c of every batch runs on stream c with its own scratch,
  * so the latency-bound octree stage of one batch overlaps the FAST / descriptor kernels of the next (the
  * frame-parallel pipeline of SURVEY.md section 8(e)).  The caller must not reuse the input or output buffers of a
- * batch that is still in flight, and all batches of one flight share (w, h, cap); a change of geometry waits
- * for the flight first.  Every other call on the handle waits for the flight implicitly. */
+ * batch that is still in flight, and all batches of one flight share (w, h, cap, batch); a change of geometry or
+ * of batch size waits for the flight first.  Every other call on the handle waits for the flight implicitly. */
 int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t *d_imgs, int batch,
                                               int w, int h, int stride, size_t image_stride,
                                               aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap,

@@ -270,3 +270,39 @@ def test_sincos_device_equals_host(pkg, gpu):
     s, c = pkg.capi.debug_sincos_device(a)
     hs = np.array([pkg.capi.debug_sincos_host(v) for v in a[::10]], np.float32)
     assert (s[::10] == hs[:, 0]).all() and (c[::10] == hs[:, 1]).all()
+
+
+def test_async_flight_with_mixed_batch_sizes(pkg, gpu):
+    """Batches of different sizes enqueued back to back on one handle (256, 100, 256, 37 ... images: their chunk partitions
+    differ, so chunks of consecutive batches would share scratch across streams): the enqueue waits for the flight when
+    the batch size changes, and every batch equals the synchronous call."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 640, 480
+    ex = pkg.Extractor()
+    cap = ex.max_keypoints
+    base = pkg.synth.synth_batch(9500, 16)
+    sizes = [256, 100, 256, 37, 130, 130, 96]
+    ins = [torch.from_numpy(np.concatenate([np.roll(base, i, axis=0)] * ((B + 15) // 16))[:B]).to(dev) for i, B in enumerate(sizes)]
+
+    def outs(B):
+        return (torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                torch.zeros(B, dtype=torch.int32, device=dev))
+    ref = pkg.Extractor()
+    want = []
+    for d, B in zip(ins, sizes):
+        o = outs(B)
+        ref.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, o[0].data_ptr(), o[1].data_ptr(), cap, o[2].data_ptr())
+        want.append(o)
+    for rep in range(3):
+        got = [outs(B) for B in sizes]
+        for d, B, o in zip(ins, sizes, got):
+            ex.extract_batch_device_async(d.data_ptr(), B, w, h, w, w * h, o[0].data_ptr(), o[1].data_ptr(), cap, o[2].data_ptr())
+        ex.wait()
+        torch.cuda.synchronize()
+        for a, b_, B in zip(got, want, sizes):
+            n = b_[2].cpu().numpy()
+            assert (a[2].cpu().numpy() == n).all() and n.min() > 0
+            ka, kb, da, db = a[0].cpu().numpy(), b_[0].cpu().numpy(), a[1].cpu().numpy(), b_[1].cpu().numpy()
+            for b in range(B):
+                assert (ka[b, : n[b]] == kb[b, : n[b]]).all() and (da[b, : n[b]] == db[b, : n[b]]).all()
