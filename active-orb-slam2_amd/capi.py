@@ -156,6 +156,7 @@ def lib():
             L.aos2_frames_discard_outliers.argtypes = [vp]
             L.aos2_frames_search_local_points.argtypes = [vp, vp, vp, ci, cf, cf, vp]
             L.aos2_extractor_stream_wait.argtypes = [vp, vp]
+            L.aos2_extractor_pack_slots.argtypes = [vp, ci, vp, vp, vp, ci, vp, C.c_size_t, vp]
         _LIB = L
     return _LIB
 
@@ -297,6 +298,13 @@ class Extractor:
         """enqueue only (raw device pointers); results and errors are complete after wait()"""
         _check(self.L.aos2_extractor_extract_batch_device_async(self.h, C.c_void_p(d_imgs), batch, w, h, stride, image_stride,
                                                                 C.c_void_p(d_kps), C.c_void_p(d_desc), cap, C.c_void_p(d_nout)))
+
+    def pack_slots(self, batch, d_kps, d_desc, d_n, cap, d_slots, slot_bytes, stream=None):
+        """aos2_extractor_pack_slots: device outputs -> fixed-size per-frame slots (sharding.slot_bytes layout)"""
+        _check(self.L.aos2_extractor_pack_slots(self.h, batch, d_kps, d_desc, d_n, cap, d_slots, slot_bytes, stream))
+
+    def stream_wait(self, stream):
+        _check(self.L.aos2_extractor_stream_wait(self.h, stream))
 
     def wait(self):
         """complete every batch enqueued with extract_batch_device_async"""

@@ -876,6 +876,48 @@ int aos2_extractor_extract_batch_device_async(aos2_extractor_t *e, const uint8_t
     return enqueue_device(e, d_imgs, batch, w, h, stride, image_stride, d_kps, d_desc, cap, d_n_out);
 }
 
+// fixed-size per-frame slots for the one exchange step of the sharded path:
+// {int32 n; int32 pad[3]; KeyPoint[cap]; uint8 desc[cap][32]} rounded up to 16 B -- sharding.py's layout
+__global__ __launch_bounds__(256) void pack_slots_kernel(const aos2_keypoint_t *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                                         const int32_t *__restrict__ n_out, int cap, uint8_t *__restrict__ slots,
+                                                         size_t slot_bytes)
+{
+    const int b = blockIdx.y;
+    uint4 *dst = reinterpret_cast<uint4 *>(slots + (size_t)b * slot_bytes);
+    const int n = min(n_out[b], cap);
+    const size_t words = slot_bytes / 16;
+    const size_t kp_words = ((size_t)cap * 28) / 16;   // cap * 28 is a multiple of 16 for the capacities in use (checked by the host)
+    const uint4 *ksrc = reinterpret_cast<const uint4 *>(kps + (size_t)b * cap);
+    const uint4 *dsrc = reinterpret_cast<const uint4 *>(desc + (size_t)b * cap * 32);
+    const size_t kp_used = ((size_t)n * 28 + 15) / 16, d_used = (size_t)n * 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i == 0)
+            v.x = (uint32_t)n;
+        else if (i - 1 < kp_words) {
+            if (i - 1 < kp_used) v = ksrc[i - 1];
+        } else if (i - 1 - kp_words < d_used)
+            v = dsrc[i - 1 - kp_words];
+        dst[i] = v;
+    }
+}
+
+int aos2_extractor_pack_slots(aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps, const uint8_t *d_desc,
+                              const int32_t *d_n, int cap, uint8_t *d_slots, size_t slot_bytes, void *hip_stream)
+{
+    if (!e || batch <= 0 || !d_kps || !d_desc || !d_n || !d_slots || cap <= 0 || ((size_t)cap * 28) % 16 != 0 ||
+        slot_bytes % 16 != 0 || slot_bytes < 16 + (size_t)cap * 60) {
+        set_error("bad argument (cap must be a multiple of 4, slot_bytes >= 16 + 60 * cap and a multiple of 16)");
+        return AOS2_ERR_ARG;
+    }
+    int st = aos2_extractor_stream_wait(e, hip_stream);
+    if (st) return st;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(pack_slots_kernel, dim3(16, batch), dim3(256), 0, s, d_kps, d_desc, d_n, cap, d_slots, slot_bytes);
+    AOS2_HIP_CHECK(hipGetLastError());
+    return AOS2_OK;
+}
+
 int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream)
 {
     if (!e) {

@@ -34,6 +34,92 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend):
+    """BASELINE configs[4]: EuRoC 752x480 stereo, nfeatures 1200, 8 frames per step sharded over the ranks (strong scaling:
+    8 / N frames per rank), every step's slots gathered to rank 0 inside the timed region.  One step of a rank =
+    both eyes' ORBextractor::operator() + Frame::ComputeStereoMatches for its frames + pack + gather."""
+    cfg = pkg.synth.CONFIGS["euroc"]
+    W, H, NF = cfg["w"], cfg["h"], cfg["nfeatures"]
+    total = 8
+    if total % world:
+        raise SystemExit("euroc8: the number of ranks must divide 8")
+    B = total // world
+    lo = rank * B
+    pairs = [pkg.synth.synth_stereo_pair(500 + lo + i, W, H) for i in range(B)]
+    d_l = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    d_r = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    xl, xr = pkg.Extractor(nfeatures=NF, device=local_rank), pkg.Extractor(nfeatures=NF, device=local_rank)
+    cap = xl.max_keypoints_for(W, H)
+    cap = (cap + 3) // 4 * 4
+    mk = lambda: (torch.zeros((B, cap, 7), dtype=torch.float32, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.zeros((B,), dtype=torch.int32, device=dev))
+    lk, ld, ln = mk()
+    rk, rd, rn = mk()
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    mbf = np.float32(cfg["bf"])
+    mb = np.float32(mbf / np.float32(cfg["fx"]))
+    sb = pkg.sharding.slot_bytes(cap)
+    slot = [torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(2)]
+    bufs = [[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+    work = [None, None]
+
+    def step(s):
+        j = s % 2
+        if work[j] is not None:
+            work[j].wait()
+            work[j] = None
+        xl.extract_batch_device_async(d_l.data_ptr(), B, W, H, W, W * H, lk.data_ptr(), ld.data_ptr(), cap, ln.data_ptr())
+        xr.extract_batch_device_async(d_r.data_ptr(), B, W, H, W, W * H, rk.data_ptr(), rd.data_ptr(), cap, rn.data_ptr())
+        pkg.capi.compute_stereo_matches_device(xl, xr, B, lk.data_ptr(), ld.data_ptr(), ln.data_ptr(), rk.data_ptr(), rd.data_ptr(),
+                                               rn.data_ptr(), cap, mb, mbf, ur.data_ptr(), dp.data_ptr())
+        xl.pack_slots(B, lk.data_ptr(), ld.data_ptr(), ln.data_ptr(), cap, slot[j].data_ptr(), sb, None)   # the null stream
+        if world > 1:
+            if backend == "nccl":
+                work[j] = dist.gather(slot[j], bufs[j], dst=0, async_op=True)
+            else:
+                work[j] = dist.gather(slot[j].cpu(), bufs[j], dst=0, async_op=True)
+
+    def sync():
+        for j in range(2):
+            if work[j] is not None:
+                work[j].wait()
+                work[j] = None
+        xl.wait()
+        xr.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ok = None
+        if world > 1:
+            hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in bufs[(args.steps - 1) % 2]])
+            ok = bool(((hdr > 0) & (hdr <= cap)).all())
+        print(json.dumps({
+            "metric": "frames/sec (stereo extract + stereo match, 8 frames/step sharded, gathered) EuRoC 752x480",
+            "value": total * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: EuRoC 752x480 stereo, 1200 features, 8 frames per step sharded over the ranks "
+                                   "(%d per rank), slots gathered to rank 0 every step" % B,
+                       "frames_per_step": total, "frames_per_rank": B, "slot_bytes": sb, "backend": backend, "headers_ok": ok,
+                       "stereo_matches_per_frame": float((dp > 0).sum().item()) / B}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +127,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--frames-per-keyframe", type=int, default=8, help="one LocalBA window per this many frames")
+    ap.add_argument("--workload", default="tum", choices=["tum", "euroc8"],
+                    help="tum = the BASELINE composite (default); euroc8 = BASELINE configs[4]: 8 EuRoC stereo frames per step "
+                         "sharded over the ranks (strong scaling), gathered to rank 0 every step")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed `extra` rows (matcher / BA / stereo / vocabulary): used for the rocprofv3 summaries, whose per-kernel averages should cover the timed workload only")
@@ -68,6 +157,12 @@ def main():
             dist.init_process_group(backend)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     pkg = g.load_package()
+    if args.workload == "euroc8":
+        run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cfg = pkg.synth.CONFIGS["tum"]
     W, H, NF = cfg["w"], cfg["h"], cfg["nfeatures"]
     B = args.batch
@@ -92,14 +187,40 @@ def main():
     lba_prep = [h.prepare_batch(lba_probs) for h in lbas]
     pool = ThreadPoolExecutor(2)   # LocalMapping-side threads: one per LocalBA handle
     lba_jobs = [None, None]
+    # N > 1: the one exchange step of the path -- every step's keypoint / descriptor slots go to
+    # rank 0 in one gather (RCCL over xGMI), enqueued behind the step on the step's own stream and left in flight while
+    # the next step runs; packed by a device kernel (aos2_extractor_pack_slots)
+    sh = pkg.sharding
+    sb = sh.slot_bytes(cap)
+    gather = None
+    if world > 1:
+        gather = dict(slot=[torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(2)], work=[None, None],
+                      ext=[torch.cuda.ExternalStream(pp.cur.stream()) for pp in pipes],
+                      bufs=[[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(2)])
+
+    def gather_step(j):
+        p = pipes[j]
+        if gather["work"][j] is not None:
+            gather["work"][j].wait()
+        p.ex.pack_slots(B, p.d_kps.data_ptr(), p.d_desc.data_ptr(), p.d_n.data_ptr(), cap, gather["slot"][j].data_ptr(), sb, p.cur.stream())
+        with torch.cuda.stream(gather["ext"][j]):
+            if backend == "nccl":
+                gather["work"][j] = dist.gather(gather["slot"][j], gather["bufs"][j], dst=0, async_op=True)
+            else:   # gloo (tests): host tensors
+                gather["work"][j] = dist.gather(gather["slot"][j].cpu(), gather["bufs"][j], dst=0, async_op=True)
 
     def step(s):
         # pipeline s % 2: its previous step (s - 2) is complete before its buffers are reused
         p = pipes[s % 2]
         if lba_jobs[s % 2] is not None:
             lba_jobs[s % 2].result()
+        if gather is not None and gather["work"][s % 2] is not None:
+            gather["work"][s % 2].wait()
+            gather["work"][s % 2] = None
         p.wait()
         p.step()
+        if gather is not None:
+            gather_step(s % 2)
         lba_jobs[s % 2] = pool.submit(lbas[s % 2].solve_prepared, lba_prep[s % 2])
 
     def sync():
@@ -107,6 +228,9 @@ def main():
             if lba_jobs[j] is not None:
                 lba_jobs[j].result()
                 lba_jobs[j] = None
+            if gather is not None and gather["work"][j] is not None:
+                gather["work"][j].wait()
+                gather["work"][j] = None
             pipes[j].wait()
         torch.cuda.synchronize()
         if world > 1:
@@ -195,28 +319,12 @@ def main():
     ex.set_chunks(int(os.environ.get("AOS2_CHUNKS", "0")))
     fast_ms = ex.bench_fast(20)
 
-    # the one exchange step of the path: keypoint/descriptor slots of 8 frames per rank -> rank 0 (RCCL)
-    gather_ms = None
     n_kp = d_n.cpu().numpy()
-    if world > 1:
-        sh = pkg.sharding
-        k = min(8, B)
-        slot = torch.zeros((k, sh.slot_bytes(cap)), dtype=torch.uint8, device=dev)
-        slot[:, 16:16 + 28 * cap] = d_kps[:k].view(torch.uint8).reshape(k, -1)
-        slot[:, 16 + 28 * cap:16 + 60 * cap] = d_desc[:k].reshape(k, -1)
-        slot[:, :4] = d_n[:k].view(torch.uint8).reshape(k, 4)
-        slot = slot.to(cdev)
-        bufs = [torch.empty_like(slot) for _ in range(world)] if rank == 0 else None
-        torch.cuda.synchronize()
-        dist.barrier()
-        tg = time.perf_counter()
-        dist.gather(slot, bufs, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        if rank == 0:  # the gathered slots must carry every rank's keypoint counts
-            for r_ in range(world):
-                got = bufs[r_][:, :4].contiguous().cpu().view(torch.int32).reshape(-1)
-                assert (got > 0).all() and (got <= cap).all(), "gathered slot header corrupt"
+    gather_ok = None
+    if world > 1 and rank == 0:   # the slots gathered in the last step carry every rank's keypoint counts
+        hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in gather["bufs"][(args.steps - 1) % 2]])
+        gather_ok = bool(((hdr > 0) & (hdr <= cap)).all())
+        assert gather_ok, "gathered slot headers corrupt"
 
     # secondary measurements of the other hot-path rows (reported, not part of `value`)
     extra = {"extract_only": {
@@ -476,8 +584,10 @@ def main():
                     out["roofline"]["traffic_source"] = "profiles/r01_pmc_{fetch,write}.csv (rocprofv3 --pmc, same command, B=256; uncorrected TCC_EA counters)"
         except Exception:
             pass
-        if gather_ms is not None:
-            out["gather_ms"] = gather_ms
+        if world > 1:
+            out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
+                                           "timed region, in flight while the next step runs" % (B, sb),
+                               "bytes_to_rank0_per_step": (world - 1) * B * sb, "backend": backend, "headers_ok": gather_ok}
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only
             # the SAME composite through the oracle (C restatement, one core): per frame extraction + Frame members +
             # the tracking chain (oracle/chain.py), per `fpk` frames one LocalBA window (oracle lba_solve)

@@ -126,6 +126,12 @@ int aos2_extractor_wait(aos2_extractor_t *e);
  * the stream of an aos2_frames_t, or 0 for the null stream) after this call runs after everything enqueued on the
  * extractor's streams before it.  Errors of the batches in flight are still reported by aos2_extractor_wait(). */
 int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream);
+/* The exchange step of the frame-sharded path: packs the device outputs of a batch into fixed-size
+ * per-frame slots {int32 n; int32 pad[3]; KeyPoint[cap]; uint8 desc[cap][32]} (slot_bytes each, a multiple of 16, unused
+ * tail zeroed) that one collective (RCCL gather over xGMI) moves to rank 0.  Enqueued on `hip_stream` behind the
+ * extractor's pending work; cap must be a multiple of 4. */
+int aos2_extractor_pack_slots(aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps, const uint8_t *d_desc,
+                              const int32_t *d_n, int cap, uint8_t *d_slots, size_t slot_bytes, void *hip_stream);
 
 /* mvImagePyramid[level] (include/ORBextractor.h:85; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:502,592,609) of image `image` of the last extract on this handle.

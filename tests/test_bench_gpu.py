@@ -1,0 +1,56 @@
+"""bench.py itself: the JSON contract at N = 1 and the N > 1 code path (two ranks sharing the box's one GPU over gloo:
+AOS2_BENCH_BACKEND / AOS2_BENCH_SHARE_GPU are test hooks; the driver's multi-GPU runs use RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(cmd, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu(gpu):
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "32", "--cpu-frames", "8", "--no-extra"])
+    assert d["metric"] == "frames/sec (extract+match+localBA) TUM 640x480" and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert set(d["cpu_baseline"]["ms_per_frame"]) >= {"extract", "search_by_projection_last", "pose_optimization", "search_local_points", "local_ba"}
+    m = d["config"]["matches_per_frame_mean"]
+    assert m["search_by_projection_last"] > 100 and m["inliers_2"] > 100 and d["config"]["local_ba_iterations"][0] > 0
+
+
+@pytest.mark.parametrize("workload", ["tum", "euroc8"])
+def test_bench_two_ranks_share_the_gpu(gpu, workload):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16",
+           "--no-extra", "--no-cpu-baseline", "--workload", workload]
+    d = _run(cmd, {"AOS2_BENCH_BACKEND": "gloo", "AOS2_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    if workload == "tum":
+        assert d["scaling"] == "weak" and d["exchange"]["headers_ok"] is True and d["exchange"]["bytes_to_rank0_per_step"] > 0
+        assert abs(d["value"] - 2 * 16 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    else:
+        assert d["scaling"] == "strong" and d["config"]["headers_ok"] is True and d["config"]["frames_per_rank"] == 4
