@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <thread>
+#include <type_traits>
 
 #include "lba_math.h"
 
@@ -56,6 +57,7 @@ struct LmState {
     int32_t solver_failed;  // trials whose reduced system hit a zero pivot
     int32_t ntr;            // trials recorded below (AOS2_LBA_TRACE=1 prints them)
     double tr_rho[48], tr_temp[48], tr_cur[48], tr_lambda[48];
+    long long dbg[16];      // cycle counters of the last reduced-system kernel (AOS2_LBA_TRACE=1)
 };
 
 // device-side view of one window
@@ -374,14 +376,16 @@ __global__ __launch_bounds__(128) void k_lin_points(const LbaWin *__restrict__ w
     for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
 }
 
-// buildSystem, the keyframes' side: Hpp += Jj^T Omega Jj, b_p += Jj^T omr.  One workgroup per free pose; strided
-// partial sums + fixed-order tree reduction; the Jacobian is recomputed from the estimates (no per-edge arrays).
-__global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
+// buildSystem, the keyframes' side: Hpp += Jj^T Omega Jj, b_p += Jj^T omr.  One wave per free pose: lane j takes the
+// pose's edges j, j + 64, ... (the Jacobian is recomputed from the estimates: no per-edge arrays), the 64 partial sums
+// are transposed through LDS and added in lane order by 42 lanes (fixed order: bit-reproducible).  (A 256-thread
+// workgroup with a 256 x 43 tree in LDS held 88 KB per pose -- one workgroup per compute unit.)
+__global__ __launch_bounds__(64) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
 {
-    __shared__ double sh[256][43];
+    __shared__ double red[42 * 65];
     const LbaWin &W = wins[blockIdx.y];
     if (!(init ? W.st->initp : W.st->lin)) return;
-    const int ph = blockIdx.x;
+    const int ph = blockIdx.x, lane = threadIdx.x;
     if (ph >= W.np) return;
     double T[7];
     {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wi
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int a = W.ps_off[ph] + threadIdx.x; a < W.ps_off[ph + 1]; a += 256) {
+    for (int a = W.ps_off[ph] + lane; a < W.ps_off[ph + 1]; a += 64) {
         const int k = W.ps_k[a];
         if (W.e_level1[k]) continue;
         const int stereo = W.e_stereo[k];
@@ -408,15 +412,20 @@ __global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wi
         }
     }
 #pragma unroll
-    for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] = acc[i];
+    for (int i = 0; i < 42; ++i) red[i * 65 + lane] = acc[i];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int i = 0; i < 42; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
-        __syncthreads();
+    if (lane < 42) {
+        double x[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) x[j] = red[lane * 65 + j];
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) sum += x[j];
+        if (lane < 36)
+            W.Hpp[36 * (size_t)ph + lane] = sum;
+        else
+            W.b[6 * (size_t)ph + (lane - 36)] = sum;
     }
-    if (threadIdx.x < 36) W.Hpp[36 * (size_t)ph + threadIdx.x] = sh[0][threadIdx.x];
-    if (threadIdx.x < 6) W.b[6 * (size_t)ph + threadIdx.x] = sh[0][36 + threadIdx.x];
 }
 
 // top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
@@ -569,6 +578,313 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
     const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
     const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// ---- LDS variant (npad <= 128): 8 waves, per 16-column panel k
+//   D_k  the 16x16 diagonal block by wave 0: unblocked LDL^T with row i of the block in the registers of lane i (pivot
+//        and column entries travel through v_readlane; no predication: the upper halves of the rows are scratch), the
+//        reciprocal pivots, then T_k = L_kk^-1 (lane c owns column c), stored in the unused UPPER triangle of the
+//        block, and the block's part of the forward substitution y_k = T_k r_k
+//   P_k  panel below the block as a GEMM: W_I = A_Ik T_k^T on 16x16 tiles with v_mfma_f64_16x16x4_f64, L_Ik = W_I D^-1;
+//        the rows' share of the forward substitution r_i -= L_ik y_k (so L y = b is solved while the matrix is
+//        factorised)
+//   U_k  trailing update A[I][J] -= W[I] L[J]^T on 16x16 tiles (MFMA); wave 0 takes the tile (k+1, k+1) and goes
+//        straight on to D_{k+1} (look-ahead) while the other seven waves update the rest
+// Two workgroup barriers per panel.  The backward substitution x = L^-T D^-1 y walks the panels the other way round
+// with the same look-ahead (x_k = T_k^T s_k, one barrier per panel); finally the first np threads apply the update to
+// the poses.  (The former version -- 4 waves, panel by per-row substitution with 16 divisions per row, predicated
+// pivot updates, separate forward / backward passes by one wave -- took 76 us at 20 free keyframes.)
+// cycle counters of the phases (s_memtime) for tools: compile with -DAOS2_LDLT_TIMING; off by default (every timestamp waits
+// for the wave's outstanding LDS traffic)
+#ifdef AOS2_LDLT_TIMING
+#define LDLT_T(...) __VA_ARGS__
+#else
+#define LDLT_T(...)
+#endif
+__global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ wins)
+{
+    constexpr int NT = 512, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_fail;
+    const LbaWin &Wn = wins[blockIdx.x];
+    if (!Wn.st->run || Wn.np == 0 || !Wn.ldlt_lds) return;
+    const int n = 6 * Wn.np, npad = Wn.npad;
+    const double lambda = Wn.st->lambda;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // odd leading dimensions: column-direction accesses (MFMA operands, substitution) fall on distinct banks
+    const int ld = npad + 1, lw = 17;
+    double *M = sm;                              // npad x ld: lower triangle = the matrix, then L; upper triangle of the diagonal blocks = T
+    double *W = M + (size_t)npad * ld;           // npad x lw: L * D of the current panel
+    double *dvec = W + (size_t)npad * lw;        // npad: D
+    double *rdv = dvec + npad;                   // npad: 1 / D
+    double *rv = rdv + npad;                     // npad: residual of the forward substitution, then y, then D^-1 y, then s
+    double *xs = rv + npad;                      // npad: solution
+    double *Tb = xs + npad;                      // 2 x 16 x 17: T_k^T of the current / next panel
+    LDLT_T(long long tD = 0, tP = 0, tU = 0, t_a = 0; const long long t_begin = __builtin_amdgcn_s_memtime();)
+    if (tid == 0) s_fail = 0;
+    // load (identity-padded): element pairs (n is even, rows are 16-byte aligned), 8 independent 16-byte global loads in
+    // flight per thread before the stores
+    {
+        const int hp = npad >> 1, npairs = npad * hp;
+        for (int p0 = tid; p0 < npairs; p0 += 8 * NT) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = p0 + u * NT;
+                const int r = q / hp, c = (q - r * hp) << 1;
+                if (q < npairs && r < n && c < n)
+                    v[u] = *reinterpret_cast<const double2 *>(Wn.Hs + (size_t)r * n + c);
+                else
+                    v[u] = double2{r == c ? 1.0 : 0.0, r == c + 1 ? 1.0 : 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = p0 + u * NT;
+                const int r = q / hp, c = (q - r * hp) << 1;
+                if (q < npairs) {
+                    M[(size_t)r * ld + c] = v[u].x;
+                    M[(size_t)r * ld + c + 1] = v[u].y;
+                }
+            }
+        }
+    }
+    for (int i = tid; i < npad; i += NT) rv[i] = i < n ? Wn.bs[i] : 0.0;
+    __syncthreads();
+    LDLT_T(const long long t_loaded = __builtin_amdgcn_s_memtime();)
+    auto wave_sync = [] {   // LDS writes of this wave visible to its other lanes (one wave: LDS operations execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // D_k (wave 0 only; lanes >= 16 mirror lanes 0..15, their results are not stored).  Measured single-wave latencies
+    // (tools/microbench/f64_latency.hip): dependent f64 FMA 9 cycles, IEEE division 67, v_rcp_f64 + 2 Newton steps 34,
+    // a v_readlane pair 13, LDS write -> broadcast read 77.  So per pivot: the pivot itself comes by v_readlane and its
+    // reciprocal by rcp + Newton (within 1 ulp), the column's other entries by ONE LDS write + broadcast reads that fly
+    // while the reciprocal is refined (30 v_readlane would cost 200 cycles of issue), and nothing is predicated: the
+    // upper halves of the rows are scratch.  T = L_kk^-1 is built on the way -- lane c owns column c,
+    // T <- (I - l_j e_j^T) T needs only column j of L, which every lane has just read -- and so is y_k = L_kk^-1 r_k.
+    LDLT_T(long long dt1 = 0, dt2 = 0, dt3 = 0, dt4 = 0;)
+    auto rcp_newton = [](double d) {   // 1 / d within 1 ulp: v_rcp_f64 + two Newton steps (34 cycles; the IEEE division takes 67)
+        double rd = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, rd, 1.0);
+        rd = __builtin_fma(rd, e, rd);
+        e = __builtin_fma(-d, rd, 1.0);
+        return __builtin_fma(rd, e, rd);
+    };
+    auto diag_block = [&](int k0) {
+        LDLT_T(const long long q0 = __builtin_amdgcn_s_memtime();)
+        const int li = lane & 15;
+        double *colbuf = xs;   // 16 doubles of scratch (xs is unused until the backward pass)
+        double *Tk = Tb + ((k0 >> 4) & 1) * (16 * 17);
+        double row[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[c] = M[(size_t)(k0 + li) * ld + k0 + c];
+        double cur = rv[k0 + li];
+        bool bad = false;
+        __builtin_amdgcn_sched_barrier(0);
+        LDLT_T(const long long q1 = __builtin_amdgcn_s_memtime(); dt1 += q1 - q0;)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double ci = row[j];
+            if (j < 15) colbuf[li] = ci;
+            const double dj = readlane_f64(ci, j);
+            if (dj == 0.0 || dj != dj) bad = true;
+            double ck[16];
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) ck[k] = colbuf[k];
+            const double rd = rcp_newton(dj);
+            const double lij = ci * rd;
+            const double yj = readlane_f64(cur, j);
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) row[k] = __builtin_fma(-lij, ck[k], row[k]);
+            // row i > j: its entry of column j becomes L[i][j]; row j keeps the pivot; rows above hold scratch there
+            row[j] = li == j ? ci : lij;
+            cur = li > j ? __builtin_fma(-lij, yj, cur) : cur;   // forward substitution inside the block
+            __builtin_amdgcn_sched_barrier(0);   // keep the pivots apart (hoisting the later pivots' reads only costs spills)
+        }
+        LDLT_T(const long long q2 = __builtin_amdgcn_s_memtime(); dt2 += q2 - q1;)
+        if (bad) {
+            if (lane == 0) s_fail = 1;
+            return;
+        }
+        // rows of the block back to LDS, whole rows without predication: the diagonal carries D, the entries right of it
+        // are scratch that nothing reads (lanes >= 16 store the same values to the same places)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) M[(size_t)(k0 + li) * ld + k0 + c] = row[c];
+        rv[k0 + li] = cur;   // y of this block
+        wave_sync();
+        {
+            const double d = M[(size_t)(k0 + li) * ld + k0 + li];
+            dvec[k0 + li] = d;
+            rdv[k0 + li] = rcp_newton(d);   // (the same operations as in the loop: the same bits)
+        }
+        LDLT_T(const long long q3 = __builtin_amdgcn_s_memtime(); dt3 += q3 - q2;)
+        // T = L_kk^-1 (unit lower triangular), lane c owns column c: T <- (I - l_j e_j^T) T for j = 0 .. 14, i.e.
+        // t[k] -= L[k][j] t[j] (k > j).  The entries of L come as broadcast reads, three batches of columns ahead of use.
+        {
+            double t[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t[c] = c == li ? 1.0 : 0.0;
+            auto sweep = [&](auto lo_c, auto hi_c) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                double lb[(HI - LO) * 16];
+#pragma unroll
+                for (int j = LO; j < HI; ++j)
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) lb[(j - LO) * 16 + k] = M[(size_t)(k0 + k) * ld + k0 + j];
+#pragma unroll
+                for (int j = LO; j < HI; ++j) {
+                    const double tj = t[j];
+#pragma unroll
+                    for (int k = j + 1; k < 16; ++k) t[k] = __builtin_fma(-lb[(j - LO) * 16 + k], tj, t[k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 9>{});
+            sweep(std::integral_constant<int, 9>{}, std::integral_constant<int, 15>{});
+            // column c of T as row c of the panel's T^T buffer (dense: zeros above the diagonal, ones on it)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Tk[li * 17 + i] = t[i];
+        }
+        LDLT_T(dt4 += __builtin_amdgcn_s_memtime() - q3;)
+    };
+    if (wave == 0) diag_block(0);
+    __syncthreads();
+    LDLT_T(const long long t_d0 = __builtin_amdgcn_s_memtime();)
+    const int nb = npad >> 4;
+    const int col = lane & 15, rq = lane >> 4;
+    for (int kb = 0; kb < nb && !s_fail; ++kb) {
+        const int k0 = kb << 4;
+        const int m = nb - kb - 1;
+        LDLT_T(t_a = __builtin_amdgcn_s_memtime();)
+        // ---- P_k: W_I = A_Ik T^T (one 16-row tile per wave turn), L_Ik = W_I D^-1
+        for (int ti = wave; ti < m; ti += NW) {
+            const int I0 = (kb + 1 + ti) << 4;
+            double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int c = 4 * kk + rq;
+                const double av = M[(size_t)(I0 + col) * ld + k0 + c];                                  // A[i = col][c]
+                const double tv = Tb[(kb & 1) * (16 * 17) + c * 17 + col];                                // B[c][j = col] = T[j][c]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tv, acc, 0, 0, 0);
+            }
+            const double rd = rdv[k0 + col];
+            // the tile's A entries were all read by the MFMAs above (this wave only): overwrite them with L
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                W[(size_t)(I0 + rq + 4 * r) * lw + col] = acc[r];
+                M[(size_t)(I0 + rq + 4 * r) * ld + k0 + col] = acc[r] * rd;
+            }
+        }
+        __syncthreads();
+        // forward substitution of the rows below: r_i -= sum_c L[i][k0 + c] y_c (c ascending)
+        for (int i = k0 + 16 + tid; i < npad; i += NT) {
+            double l[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) l[c] = M[(size_t)i * ld + k0 + c];
+            double ri = rv[i];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) ri -= l[c] * rv[k0 + c];
+            rv[i] = ri;
+        }
+        LDLT_T(tP += __builtin_amdgcn_s_memtime() - t_a; t_a = __builtin_amdgcn_s_memtime();)
+        // ---- U_k: trailing update with f64 MFMA on the lower-triangle tiles (I >= J > kb); tile 0 = (kb+1, kb+1) goes
+        // to wave 0, which then factorises that block while the other waves finish the update
+        const int ntiles = m * (m + 1) / 2;
+        auto tile = [&](int t) {
+            int ii = 0, rem = t;
+            while (rem > ii) {  // row-major lower triangle: row ii holds ii+1 tiles
+                rem -= ii + 1;
+                ++ii;
+            }
+            const int I0 = (kb + 1 + ii) << 4, J0 = (kb + 1 + rem) << 4;
+            double4_t acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double av = -W[(size_t)(I0 + col) * lw + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
+                const double bv = M[(size_t)(J0 + col) * ld + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
+        };
+        if (wave == 0) {
+            if (ntiles > 0) {
+                // (the rows k0+16 .. k0+31 of the forward substitution above belong to threads 0..15 = this wave)
+                wave_sync();
+                tile(0);
+                wave_sync();
+                LDLT_T(const long long t_d = __builtin_amdgcn_s_memtime();)
+                diag_block(k0 + 16);
+                LDLT_T(tD += __builtin_amdgcn_s_memtime() - t_d;)
+            }
+        } else {
+            for (int t = wave; t < ntiles; t += NW - 1) tile(t);
+        }
+        __syncthreads();
+        LDLT_T(tU += __builtin_amdgcn_s_memtime() - t_a;)
+    }
+    LDLT_T(const long long t_fact = __builtin_amdgcn_s_memtime();)
+    if (s_fail) {
+        if (tid == 0) Wn.scal[3] = 0.0;
+        return;
+    }
+    // ---- backward substitution: x = L^-T D^-1 y; per block x_k = T_k^T s_k, then the rows above take L_k^T x_k
+    for (int i = tid; i < npad; i += NT) rv[i] = rv[i] * rdv[i];
+    __syncthreads();
+    auto back_block = [&](int k0) {   // wave 0: L_kk^T x_k = s_k, k descending inside the block
+        const int li = lane & 15;
+        double lcol[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lcol[j] = M[(size_t)(k0 + j) * ld + k0 + li];   // L[j][i] for j > i (the rest is unused)
+        double cur = rv[k0 + li];
+#pragma unroll
+        for (int j = 15; j >= 1; --j) {
+            const double xj = readlane_f64(cur, j);
+            cur = li < j ? __builtin_fma(-lcol[j], xj, cur) : cur;
+        }
+        xs[k0 + li] = cur;
+    };
+    if (wave == 0) back_block((nb - 1) << 4);
+    __syncthreads();
+    for (int kb = nb - 1; kb > 0; --kb) {
+        const int k0 = kb << 4;
+        // rows above the block take its contribution; wave 0 does the rows of the next block first and solves it
+        auto update_row = [&](int i) {
+            double l[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) l[j] = M[(size_t)(k0 + j) * ld + i];
+            double acc = rv[i];
+#pragma unroll
+            for (int j = 15; j >= 0; --j) acc -= l[j] * xs[k0 + j];
+            rv[i] = acc;
+        };
+        if (wave == 0) {
+            if (lane < 16) update_row(k0 - 16 + lane);
+            wave_sync();
+            back_block(k0 - 16);
+        } else {
+            for (int i = tid - 64; i < k0 - 16; i += NT - 64) update_row(i);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) Wn.x[i] = xs[i];
+    if (tid == 0) {
+        Wn.scal[3] = 1.0;
+        LDLT_T(long long *g = Wn.st->dbg; g[0] = t_loaded - t_begin; g[1] = t_d0 - t_loaded; g[2] = tP; g[3] = tU; g[4] = tD;
+               g[5] = t_fact - t_d0; g[6] = __builtin_amdgcn_s_memtime() - t_fact; g[8] = dt1; g[9] = dt2; g[10] = dt3; g[11] = dt4;)
+    }
+    if (tid < Wn.np) {   // VertexSE3Expmap::oplusImpl + the poses' scale terms
+        double upd[6];
+        for (int i = 0; i < 6; ++i) {
+            upd[i] = xs[6 * tid + i];
+            Wn.tmp[6 * tid + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * tid + i]);
+        }
+        se3_oplus(upd, Wn.pose + 7 * (size_t)Wn.hpose[tid]);
+    }
 }
 
 template <bool kLds>
@@ -1024,7 +1340,7 @@ int lba_handle_init(aos2_lba *s)
     AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -1335,7 +1651,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.n_part = std::max(1, (int)((S.nl + 127) / 128));
         l.scal = B.take(64); l.part = B.take(16 * (size_t)l.n_part + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
-        const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + l.npad + 64) * 8;
+        const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + 4 * (size_t)l.npad + 2 * 16 * 17 + 16) * 8;
         l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
         l.ldlt = B.take(l.ldlt_lds ? 8 : ldlt_bytes);
     }
@@ -1453,7 +1769,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     const dim3 g_edges256(blocks(mx_E, 256), nw), g_points(mx_part, nw);
     auto enqueue_lin = [&](int init) {
         hipLaunchKernelGGL(k_lin_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, init);
-        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, init);
+        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(64), 0, q, dw, init);
     };
     auto enqueue_init = [&]() {
         hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 0);
@@ -1464,8 +1780,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     auto enqueue_trial = [&]() {
         if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(64), 0, q, dw);
         if (any_lds) {
-            const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + mx_npad_lds + 64) * sizeof(double);
-            hipLaunchKernelGGL(k_ldlt_solve<true>, dim3(nw), dim3(256), need, q, dw);
+            const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
+            hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
         }
         if (any_glob) {
             hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(nw), dim3(1024), (size_t)mx_npad_glob * sizeof(double), q, dw);
@@ -1532,6 +1848,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     if (getenv("AOS2_LBA_TRACE"))
         for (int i = 0; i < nw; ++i) {
             const LmState *ls = state_of(i);
+#ifdef AOS2_LDLT_TIMING
+            fprintf(stderr, "[lba] win %d reduced-system kernel cycles: load %lld, D0 %lld, P %lld, U(+lookahead D) %lld, D inside U %lld, factor %lld, backward %lld\n", i,
+                    ls->dbg[0], ls->dbg[1], ls->dbg[2], ls->dbg[3], ls->dbg[4], ls->dbg[5], ls->dbg[6]);
+            fprintf(stderr, "[lba]   diagonal blocks (8 of them): load %lld, pivots %lld, store %lld, T %lld\n", ls->dbg[8], ls->dbg[9], ls->dbg[10], ls->dbg[11]);
+#endif
             for (int t = 0; t < ls->ntr; ++t)
                 fprintf(stderr, "[lba] win %d trial %2d lambda %.6e chi %.9e -> %.9e rho %.6e\n", i, t, ls->tr_lambda[t], ls->tr_cur[t], ls->tr_temp[t], ls->tr_rho[t]);
         }

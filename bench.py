@@ -174,7 +174,8 @@ def main():
     scen = pkg.scenario.tracking_scenario(100 + rank, B, cfg="tum", n_unique=n_unique)
     base = scen["cur"]
     N_LOCAL = 1500
-    pipes = [pkg.chain.TrackingChain(scen, device=local_rank, n_local=N_LOCAL) for _ in range(2)]   # two steps in flight
+    NPIPE = max(1, int(os.environ.get("AOS2_BENCH_INFLIGHT", "2")))   # steps in flight (each with its own buffers)
+    pipes = [pkg.chain.TrackingChain(scen, device=local_rank, n_local=N_LOCAL) for _ in range(NPIPE)]
     ex = pipes[0].ex
     cap = pipes[0].cap
     d_img, d_kps, d_desc, d_n = pipes[0].d_cur, pipes[0].d_kps, pipes[0].d_desc, pipes[0].d_n
@@ -183,10 +184,11 @@ def main():
     n_win = max(1, B // fpk)
     lba_unique = [pkg.synth.synth_lba_problem(10 * rank + i, n_points=8000) for i in range(min(4, n_win))]
     lba_probs = [lba_unique[i % len(lba_unique)] for i in range(n_win)]
-    lbas = [pkg.LocalBA(device=local_rank) for _ in range(2)]
+    NLBA = max(1, int(os.environ.get("AOS2_BENCH_LBA_HANDLES", str(NPIPE))))   # LocalBA batches in flight (own handle + host thread each)
+    lbas = [pkg.LocalBA(device=local_rank) for _ in range(NLBA)]
     lba_prep = [h.prepare_batch(lba_probs) for h in lbas]
-    pool = ThreadPoolExecutor(2)   # LocalMapping-side threads: one per LocalBA handle
-    lba_jobs = [None, None]
+    pool = ThreadPoolExecutor(NLBA)   # LocalMapping-side threads: one per LocalBA handle
+    lba_jobs = [None] * NLBA
     # N > 1: the one exchange step of the path -- every step's keypoint / descriptor slots go to
     # rank 0 in one gather (RCCL over xGMI), enqueued behind the step on the step's own stream and left in flight while
     # the next step runs; packed by a device kernel (aos2_extractor_pack_slots)
@@ -194,9 +196,9 @@ def main():
     sb = sh.slot_bytes(cap)
     gather = None
     if world > 1:
-        gather = dict(slot=[torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(2)], work=[None, None],
+        gather = dict(slot=[torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(NPIPE)], work=[None] * NPIPE,
                       ext=[torch.cuda.ExternalStream(pp.cur.stream()) for pp in pipes],
-                      bufs=[[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(2)])
+                      bufs=[[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(NPIPE)])
 
     def gather_step(j):
         p = pipes[j]
@@ -210,24 +212,27 @@ def main():
                 gather["work"][j] = dist.gather(gather["slot"][j].cpu(), gather["bufs"][j], dst=0, async_op=True)
 
     def step(s):
-        # pipeline s % 2: its previous step (s - 2) is complete before its buffers are reused
-        p = pipes[s % 2]
-        if lba_jobs[s % 2] is not None:
-            lba_jobs[s % 2].result()
-        if gather is not None and gather["work"][s % 2] is not None:
-            gather["work"][s % 2].wait()
-            gather["work"][s % 2] = None
+        # pipeline s % NPIPE: its previous step (s - NPIPE) is complete before its buffers are reused
+        j = s % NPIPE
+        p = pipes[j]
+        jl = s % NLBA
+        if lba_jobs[jl] is not None:
+            lba_jobs[jl].result()
+        if gather is not None and gather["work"][j] is not None:
+            gather["work"][j].wait()
+            gather["work"][j] = None
         p.wait()
         p.step()
         if gather is not None:
-            gather_step(s % 2)
-        lba_jobs[s % 2] = pool.submit(lbas[s % 2].solve_prepared, lba_prep[s % 2])
+            gather_step(j)
+        lba_jobs[jl] = pool.submit(lbas[jl].solve_prepared, lba_prep[jl])
 
     def sync():
-        for j in range(2):
-            if lba_jobs[j] is not None:
-                lba_jobs[j].result()
-                lba_jobs[j] = None
+        for jl in range(NLBA):
+            if lba_jobs[jl] is not None:
+                lba_jobs[jl].result()
+                lba_jobs[jl] = None
+        for j in range(NPIPE):
             if gather is not None and gather["work"][j] is not None:
                 gather["work"][j].wait()
                 gather["work"][j] = None
@@ -322,7 +327,7 @@ def main():
     n_kp = d_n.cpu().numpy()
     gather_ok = None
     if world > 1 and rank == 0:   # the slots gathered in the last step carry every rank's keypoint counts
-        hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in gather["bufs"][(args.steps - 1) % 2]])
+        hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in gather["bufs"][(args.steps - 1) % NPIPE]])
         gather_ok = bool(((hdr > 0) & (hdr <= cap)).all())
         assert gather_ok, "gathered slot headers corrupt"
 
