@@ -229,9 +229,11 @@ __global__ __launch_bounds__(128) void k_points(const LbaWin *__restrict__ wins,
             for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
             Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
             mat3_inverse(Dm, Dinv);
+            double *Xb = W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.hpoint[l];
             for (int r = 0; r < 3; ++r) {
                 const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
                 W.x[n6 + 3 * l + r] = xl;
+                Xb[r] = Xv[r];   // push()
                 Xv[r] += xl;
                 X[r] = Xv[r];
                 sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
@@ -376,16 +378,60 @@ __global__ __launch_bounds__(128) void k_lin_points(const LbaWin *__restrict__ w
     for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
 }
 
-// buildSystem, the keyframes' side: Hpp += Jj^T Omega Jj, b_p += Jj^T omr.  One wave per free pose: lane j takes the
-// pose's edges j, j + 64, ... (the Jacobian is recomputed from the estimates: no per-edge arrays), the 64 partial sums
-// are transposed through LDS and added in lane order by 42 lanes (fixed order: bit-reproducible).  (A 256-thread
-// workgroup with a 256 x 43 tree in LDS held 88 KB per pose -- one workgroup per compute unit.)
-__global__ __launch_bounds__(64) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
+// Sum of `v` over the 16 lanes of a DPP row (xor butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror):
+// VALU speed, no LDS.  Every lane of the row ends with the row's total (lanes may differ in the last bit: the butterfly
+// adds in a lane-dependent order; callers read one fixed lane per row).
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    __shared__ double red[42 * 65];
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), kCtrl, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+
+// acc[K] of every thread of an NT-thread workgroup -> their sums (returned in threads e < K).  16-lane DPP row sums, then
+// the row totals of each value through LDS in row order: a fixed order (bit-reproducible), NT / 16 x K doubles of LDS.
+// n_items = work items of the workgroup (thread t had one iff t < n_items): waves without any skip their share, and rows
+// without any are left out of the final sums (they would add +0.0).
+template <int K, int NT = 256>
+__device__ __forceinline__ double workgroup_sum_k256(double (&acc)[K], double *red /* (NT / 16) x (K + 1) */, int n_items)
+{
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int rows_used = min(NT / 16, (n_items + 15) >> 4);
+    if (wave * 64 < n_items) {   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc[i] = row_sum_f64(acc[i]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) red[row * (K + 1) + i] = acc[i];
+        }
+    }
+    __syncthreads();
+    double sum = 0;
+    if ((int)threadIdx.x < K)
+        for (int r = 0; r < rows_used; ++r) sum += red[r * (K + 1) + threadIdx.x];
+    return sum;
+}
+
+// buildSystem, the keyframes' side: Hpp += Jj^T Omega Jj, b_p += Jj^T omr.  One 256-thread workgroup per free pose:
+// thread j takes the pose's edges j, j + 256, ... (the Jacobian is recomputed from the estimates: no per-edge arrays;
+// few edges per thread keep the chain of dependent gathers short), then workgroup_sum_k256 (fixed order).
+// (The former 256 x 43 tree in LDS held 88 KB per pose -- one workgroup per compute unit.)
+__global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
+{
+    __shared__ double red[16 * 43];
     const LbaWin &W = wins[blockIdx.y];
     if (!(init ? W.st->initp : W.st->lin)) return;
-    const int ph = blockIdx.x, lane = threadIdx.x;
+    const int ph = blockIdx.x;
     if (ph >= W.np) return;
     double T[7];
     {
@@ -396,7 +442,7 @@ __global__ __launch_bounds__(64) void k_lin_poses(const LbaWin *__restrict__ win
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int a = W.ps_off[ph] + lane; a < W.ps_off[ph + 1]; a += 64) {
+    for (int a = W.ps_off[ph] + threadIdx.x; a < W.ps_off[ph + 1]; a += 256) {
         const int k = W.ps_k[a];
         if (W.e_level1[k]) continue;
         const int stereo = W.e_stereo[k];
@@ -411,21 +457,11 @@ __global__ __launch_bounds__(64) void k_lin_poses(const LbaWin *__restrict__ win
             for (int c = 0; c < 6; ++c) acc[r * 6 + c] += Jb[r] * wo * Jb[c] + Jb[6 + r] * wo * Jb[6 + c] + Jb[12 + r] * wo * Jb[12 + c];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 42; ++i) red[i * 65 + lane] = acc[i];
-    __syncthreads();
-    if (lane < 42) {
-        double x[64];
-#pragma unroll
-        for (int j = 0; j < 64; ++j) x[j] = red[lane * 65 + j];
-        double sum = 0;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) sum += x[j];
-        if (lane < 36)
-            W.Hpp[36 * (size_t)ph + lane] = sum;
-        else
-            W.b[6 * (size_t)ph + (lane - 36)] = sum;
-    }
+    const double sum = workgroup_sum_k256<42>(acc, red, W.ps_off[ph + 1] - W.ps_off[ph]);
+    if (threadIdx.x < 36)
+        W.Hpp[36 * (size_t)ph + threadIdx.x] = sum;
+    else if (threadIdx.x < 42)
+        W.b[6 * (size_t)ph + (threadIdx.x - 36)] = sum;
 }
 
 // top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
@@ -470,22 +506,25 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
     }
 }
 
-// ---- Schur complement (block_solver.hpp:379-432), one wave per (pose, pose) block of the upper block triangle.  The
-// host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order inside a block
-// (build_schur_items).  Lane j of the block's wave takes the items j, j + 64, ...: (Hll + lambda I)^-1 of the landmark,
-// B_a Dinv B_b^T (and, on the diagonal blocks, the coefficient term B_a Dinv b_l), accumulated in registers; the 64
-// partial 6x6 sums are then transposed through LDS and added in lane order by 36 (42) lanes: no atomics, a fixed
-// order (bit-reproducible), and no per-item array in memory (a materialised item list cost 288 B written + read per
+// ---- Schur complement (block_solver.hpp:379-432), one 256-thread workgroup per (pose, pose) block of the upper block
+// triangle.  The host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order
+// inside a block (build_schur_items).  Thread j of the block takes the items j, j + 256, ...: (Hll + lambda I)^-1 of the
+// landmark, B_a Dinv B_b^T (and, on the diagonal blocks, the coefficient term B_a Dinv b_l), accumulated in registers;
+// the partial 6x6 sums are added by workgroup_sum_k256: no atomics, a fixed order (bit-reproducible), and no per-item
+// array in memory (a materialised item list cost 288 B written + read per
 // item: 0.31 ms per trial for 32 windows of 24 k edges).  Hschur = Hpp + lambda I - sum, bschur = b_p - sum.
-__global__ __launch_bounds__(64) void k_schur(const LbaWin *__restrict__ wins)
+// threads per block: measured (one 12 k-edge window / one 24 k-edge window / 32 windows of 24 k edges, whole solve):
+// 64: 1.88 / 2.27 / 4.42 ms, 128: 1.74 / 1.92 / 4.35 ms, 256: 1.71 / 1.87 / 4.78 ms (most off-diagonal blocks hold < 128 items)
+constexpr int kSchurThreads = 128;
+__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins)
 {
-    __shared__ double red[42 * 65];
+    constexpr int NT = kSchurThreads;
+    __shared__ double red[(NT / 16) * 43];
     const LbaWin &W = wins[blockIdx.y];
     if (!W.st->run) return;
     const int np = W.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
-    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int blk = blockIdx.x;
     if (blk >= nblk) return;
-    const double lambda = W.st->lambda;
     // blk -> (i1 <= i2)
     int i1 = 0, rem = blk;
     while (rem >= np - i1) {
@@ -493,14 +532,13 @@ __global__ __launch_bounds__(64) void k_schur(const LbaWin *__restrict__ wins)
         ++i1;
     }
     const int i2 = i1 + rem;
+    const double lambda = W.st->lambda;
     const bool diag = i1 == i2;
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
-    double acc[36], accb[6];
+    double acc[42];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) accb[i] = 0;
-    for (int j = lane; j < n; j += 64) {
+    for (int i = 0; i < 42; ++i) acc[i] = 0;
+    for (int j = threadIdx.x; j < n; j += NT) {
         const int ka = W.it_ka[o0 + j], kb = W.it_kb[o0 + j], l = W.it_l[o0 + j];   // three independent loads, then one level of gathers
         double D[9], Dinv[9];
 #pragma unroll
@@ -527,36 +565,22 @@ __global__ __launch_bounds__(64) void k_schur(const LbaWin *__restrict__ wins)
 #pragma unroll
             for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) accb[r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
+            for (int r = 0; r < 6; ++r) acc[36 + r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 36; ++i) red[i * 65 + lane] = acc[i];
-    if (diag) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) red[(36 + i) * 65 + lane] = accb[i];
-    }
-    __syncthreads();
-    const int e = lane;
-    if (e < (diag ? 42 : 36)) {
-        double x[64];
-#pragma unroll
-        for (int j = 0; j < 64; ++j) x[j] = red[e * 65 + j];
-        double sum = 0;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) sum += x[j];
-        if (e < 36) {
-            double v = -sum;
-            const int r = e / 6, c = e - 6 * r;
-            if (diag) {
-                v += W.Hpp[36 * (size_t)i1 + e];
-                if (r == c) v += lambda;
-            }
-            W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
-            if (!diag) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
-        } else
-            W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
-    }
+    const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
+    const int e = threadIdx.x;
+    if (e < 36) {
+        double v = -sum;
+        const int r = e / 6, c = e - 6 * r;
+        if (diag) {
+            v += W.Hpp[36 * (size_t)i1 + e];
+            if (r == c) v += lambda;
+        }
+        W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
+        if (!diag) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+    } else if (e < 42 && diag)
+        W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
 }
 
 // Dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve of the reduced
@@ -883,7 +907,9 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             upd[i] = xs[6 * tid + i];
             Wn.tmp[6 * tid + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * tid + i]);
         }
-        se3_oplus(upd, Wn.pose + 7 * (size_t)Wn.hpose[tid]);
+        double *Tp = Wn.pose + 7 * (size_t)Wn.hpose[tid], *Tbk = Wn.bk + 7 * (size_t)Wn.hpose[tid];
+        for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
+        se3_oplus(upd, Tp);
     }
 }
 
@@ -1168,7 +1194,9 @@ __global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ 
         upd[i] = W.x[6 * p + i];
         W.tmp[6 * p + i] = upd[i] * (lambda * upd[i] + W.b[6 * p + i]);
     }
-    se3_oplus(upd, W.pose + 7 * (size_t)W.hpose[p]);
+    double *Tp = W.pose + 7 * (size_t)W.hpose[p], *Tbk = W.bk + 7 * (size_t)W.hpose[p];
+    for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
+    se3_oplus(upd, Tp);
 }
 
 // The decision of one Levenberg-Marquardt trial and everything that hangs on it (levenberg.cpp:99-164,
@@ -1246,12 +1274,11 @@ __global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins
         st->lin = lin;
     }
     __syncthreads();
-    // the backup always holds the estimates a trial starts from: pop() after a rejected step, the next push() after an
-    // accepted one (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610)
+    // pop() after a rejected step (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610).  The backup holds the
+    // estimates a trial starts from: the kernels that move an estimate (the pose update of the reduced-system kernel, the
+    // landmark update of k_points) save the old value first -- push() costs no pass of its own.
     if (s_restore)
         for (int i = threadIdx.x; i < W.est_n; i += 1024) W.pose[i] = W.bk[i];
-    else
-        for (int i = threadIdx.x; i < W.est_n; i += 1024) W.bk[i] = W.pose[i];
 }
 
 // Between the two optimisations (Optimizer.cc:663-710).  (a): bDoMore = !*pbStopFlag
@@ -1769,7 +1796,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     const dim3 g_edges256(blocks(mx_E, 256), nw), g_points(mx_part, nw);
     auto enqueue_lin = [&](int init) {
         hipLaunchKernelGGL(k_lin_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, init);
-        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(64), 0, q, dw, init);
+        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, init);
     };
     auto enqueue_init = [&]() {
         hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 0);
@@ -1778,7 +1805,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     // one Levenberg-Marquardt trial: 6 launches (7 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(64), 0, q, dw);
+        if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(kSchurThreads), 0, q, dw);
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
