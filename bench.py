@@ -552,8 +552,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": fast_bytes, "kernel_ms": fast_ms,
-                         "note": "integer-VALU bound, not bandwidth bound: the kernel keeps the vector ALUs ~92 % busy (VALUBusy = "
-                                 "4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE, profiles/r01_pmc_sq_busy.csv) at the issue rates "
+                         "note": "integer-VALU bound, not bandwidth bound (see roofline_valu): the kernel keeps the vector ALUs ~95 % busy (VALUBusy = "
+                                 "4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE, profiles/r02_pmc_extract_b512.txt) at the issue rates "
                                  "measured on this chip (tools/microbench/valu_rate.hip -> profiles/r01_valu_rate.txt: 4 cycles per "
                                  "wave64 instruction for packed-16 / min / max / compare / dot / perm / mad, 2 for add / sub / logic / "
                                  "mov / f32); ~810 VALU instructions per 1.2k-pixel cell-wave, so the HBM fraction can only rise by "
@@ -574,21 +574,27 @@ def main():
              "frac": 1.57e6 * B / (stage["pyramid"] * 1e-3) / 1e9 / 8000.0,
              "note": "seven dependent launches (level k is resized from level k-1); the large levels run at 3.2-3.5 TB/s, the small "
                      "ones are launch / tail bound; VALUBusy 35 %"}]
-        # HBM-side bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes
+        # counters of the same kernel from the committed rocprofv3 --pmc passes (B = 512 > Infinity Cache; calibrated against
+        # 1 GiB copies): NOT measured in this run -- `roofline.traffic` stays null; the profiled figures are given beside it
         try:
-            import csv
-            def _pmc(path, counter):
-                for row in csv.DictReader(open(os.path.join(ROOT, "profiles", path))):
-                    if "fast_cells_kernel" in row["Kernel"]:
-                        return float(row[counter]) * 1024.0
-                return None
-            if B == 256:
-                fb, wb = _pmc("r01_pmc_fetch.csv", "FETCH_SIZE"), _pmc("r01_pmc_write.csv", "WRITE_SIZE")
-                if fb is not None and wb is not None:
-                    out["roofline"]["traffic"] = fb + wb
-                    out["roofline"]["traffic_source"] = "profiles/r01_pmc_{fetch,write}.csv (rocprofv3 --pmc, same command, B=256; uncorrected TCC_EA counters)"
-        except Exception:
-            pass
+            pc = json.load(open(os.path.join(ROOT, "profiles", "r02_extractor_counters.json")))
+            fc, cal = pc["fast_cells_kernel"], pc["calibration"]
+            per_frame = (fc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + fc["WRITE_SIZE_KB"] * cal["WRITE_SIZE_factor"]) * 1024.0 / pc["batch"]
+            out["roofline"]["traffic_profiled"] = {
+                "bytes_per_launch": per_frame * B, "over_algorithmic": per_frame * B / fast_bytes,
+                "source": pc["source"], "correction": "FETCH_SIZE x %.3f (unaligned 32-bit reads), WRITE_SIZE x 1.0" % cal["FETCH_SIZE_factor_unaligned_32bit"]}
+            insts = fc["SQ_INSTS_VALU"] / pc["batch"] * B
+            clock_ghz = fc["GRBM_GUI_ACTIVE"] / 8.0 / fc["kernel_us"] / 1e3
+            peak = 1024 * clock_ghz / 4.0   # G wave-instructions / s: 1024 SIMDs, 4 cycles per packed / compare / min / max instruction
+            out["roofline_valu"] = {
+                "bound": "valu_issue", "kernel": "fast_cells_kernel", "achieved": insts / (fast_ms * 1e-3) / 1e9, "peak": peak,
+                "unit": "G wave64-instr/s", "frac": insts / (fast_ms * 1e-3) / 1e9 / peak,
+                "valu_busy_profiled": 4.0 * fc["SQ_ACTIVE_INST_VALU"] / 1024.0 / (fc["GRBM_GUI_ACTIVE"] / 8.0),
+                "note": "the binding roof: instructions per launch = SQ_INSTS_VALU per frame of the committed PMC pass x B (a profiled constant of "
+                        "these kernels on frames of this generator), time = this run's HIP events; peak = 1024 SIMDs x %.2f GHz / 4 cycles "
+                        "(profiles/r01_valu_rate.txt)" % clock_ghz}
+        except Exception as exc:
+            out["roofline"]["traffic_profiled"] = {"error": repr(exc)}
         if world > 1:
             out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
                                            "timed region, in flight while the next step runs" % (B, sb),
