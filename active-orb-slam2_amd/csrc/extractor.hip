@@ -105,6 +105,7 @@ struct aos2_extractor {
     int n_streams = 0;
     hipEvent_t ev[8] = {};
     hipEvent_t order_ev[kMaxStreams] = {};   // aos2_extractor_stream_wait
+    int streams_used = 0;                    // streams the batches since the last wait ran on (<= chunks)
     Plan plan;
     int batch_cap = 0;
     int last_batch = 0;
@@ -600,6 +601,7 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     if (io && e->chunks <= 0 && batch >= 32) chunks = 4;   // copy / compute pipeline of the host-pointer call
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
+    e->streams_used = std::max(e->streams_used, chunks);
     auto enqueue = [&](int b0, int nb, hipStream_t s, bool timed) -> int {
         const uint8_t *img = d_imgs + (size_t)b0 * image_stride;
         uint8_t *pyr = e->d_pyr.p + (size_t)b0 * P.pyr_bytes;
@@ -695,6 +697,7 @@ static int finish_device(aos2_extractor *e)
     status[0] = e->h_status.p[0];
     status[1] = e->h_status.p[1];
     e->in_flight = 0;
+    e->streams_used = 0;
     AOS2_HIP_CHECK(hipGetLastError());
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&e->timing[i], e->ev[i], e->ev[i + 1]);
     e->timing[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - e->t_enqueue).count();
@@ -928,7 +931,8 @@ int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream)
     int st = bind_device(e->device);
     if (st) return st;
     hipStream_t waiter = static_cast<hipStream_t>(hip_stream);
-    for (int i = 0; i < e->n_streams; ++i) {
+    const int used = std::max(1, std::min(e->n_streams, e->streams_used));
+    for (int i = 0; i < used; ++i) {
         if (!e->order_ev[i]) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->order_ev[i], hipEventDisableTiming));
         AOS2_HIP_CHECK(hipEventRecord(e->order_ev[i], e->streams[i]));
         AOS2_HIP_CHECK(hipStreamWaitEvent(waiter, e->order_ev[i], 0));

@@ -22,9 +22,12 @@
 // is left alone like g2o leaves the _error of an inactive edge -- so every sum it took part in receives +0.0, which
 // is the same as leaving it out; vertices that lose all their edges keep a lambda-only diagonal block, decoupled from
 // the rest, and receive a zero update (g2o drops them from the index mapping instead: same result for the others).
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <numeric>
 #include <thread>
 #include <type_traits>
@@ -1508,6 +1511,49 @@ struct WinLayout {
     size_t n_items;
 };
 
+
+// ROCTx ranges around the host-side phases of a solve (AOS2_ROCTX=1; rocprofv3 --marker-trace shows them next to the
+// kernels).  The library is looked up at run time: no link dependency.  g2o's statistics buckets
+// (Thirdparty/g2o/g2o/core/batch_stats.h, filled in block_solver.hpp:441-453 and sparse_optimizer.cpp:376-414) map to
+// the kernels of the device program: timeResiduals -> k_points, timeLinearize + timeQuadraticForm -> k_lin_points /
+// k_lin_poses, timeSchurComplement -> k_schur, timeLinearSolver -> k_ldlt_lds / k_ldlt_solve, timeUpdate -> the pose
+// update inside the LDL^T kernel and the landmark update inside k_points.
+struct RoctxRange {
+    typedef int (*push_t)(const char *);
+    typedef int (*pop_t)();
+    static void resolve(push_t &push, pop_t &pop)
+    {
+        static push_t s_push = nullptr;
+        static pop_t s_pop = nullptr;
+        static bool tried = false;
+        if (!tried) {
+            tried = true;
+            const char *v = getenv("AOS2_ROCTX");
+            if (v && atoi(v) != 0) {
+                void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    s_push = (push_t)dlsym(h, "roctxRangePushA");
+                    s_pop = (pop_t)dlsym(h, "roctxRangePop");
+                }
+            }
+        }
+        push = s_push;
+        pop = s_pop;
+    }
+    pop_t pop_ = nullptr;
+    explicit RoctxRange(const char *name)
+    {
+        push_t push;
+        resolve(push, pop_);
+        if (push && pop_) push(name); else pop_ = nullptr;
+    }
+    ~RoctxRange()
+    {
+        if (pop_) pop_();
+    }
+};
+
 struct Bump {
     size_t size = 0;
     size_t take(size_t bytes, size_t align = 256)
@@ -1614,6 +1660,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
 
     // ---- per-window structure (host; windows in parallel when there are several)
+    auto rg = std::make_unique<RoctxRange>("LocalBA::buildStructure (index mapping, edge lists, Schur items)");
     std::vector<Pass> passes(nw);
     auto for_windows = [&](auto &&fn) {
         const int nthr = std::max(1, std::min({nw, (int)std::thread::hardware_concurrency(), 32}));
@@ -1639,6 +1686,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             return AOS2_ERR_ARG;
         }
     lap("build_pass + items");
+    rg = std::make_unique<RoctxRange>("LocalBA::stage + upload");
 
     // ---- arena layout: [staged inputs of all windows | descriptors][device-only scratch][results of all windows]
     std::vector<WinLayout> L(nw);
@@ -1843,6 +1891,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         max_i1 = std::max(max_i1, problems[act[i]].iters_first);
         max_i2 = std::max(max_i2, problems[act[i]].iters_second);
     }
+    rg = std::make_unique<RoctxRange>("LocalBA::optimize(5) + outlier pass + optimize(10) + inlier check (one device program)");
     // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
     hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw, s->debug_stop_at_poll);
     hipLaunchKernelGGL(k_begin, dim3(nw), dim3(1), 0, q, dw);
@@ -1872,6 +1921,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         if ((st = finish())) return st;
     }
     lap("continuation");
+    rg = std::make_unique<RoctxRange>("LocalBA::write-back");
     if (getenv("AOS2_LBA_TRACE"))
         for (int i = 0; i < nw; ++i) {
             const LmState *ls = state_of(i);

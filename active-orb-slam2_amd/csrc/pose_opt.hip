@@ -174,9 +174,15 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
         if (n_active > 0) {
             int nBadLM = 0;
             bool ok = true;
+            bool fresh = false;   // the residuals and s_currentChi belong to the current pose (left by an accepted trial)
             for (int i = 0; i < 10 && ok; ++i) {
+                // computeActiveErrors at the top of solve() (levenberg.cpp:75): recomputing at the pose of the accepted trial
+                // reproduces its residuals and chi2 bit for bit, so it is skipped then
                 double currentChi;
-                errors_chi2(currentChi);
+                if (fresh)
+                    currentChi = s_currentChi;
+                else
+                    errors_chi2(currentChi);
                 const double iniChi = currentChi;
                 // buildSystem: H (upper triangle, 21) + b (6)
                 double acc[27];
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
                     rho = s_rho;
                     qmax++;
                 } while (rho < 0 && qmax < 10);
+                fresh = rho > 0;   // the trial was accepted (r > 0 && isfinite(tempChi): chi2 is never negative, so r > 0 implies it)
                 const double curChi = s_currentChi;
                 if (qmax == 10 || rho == 0) {
                     ok = false;
