@@ -584,7 +584,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
 int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll);
 
 /* ------------------------------------------------------------------------------------------
- * Optimizer::PoseOptimization  (include/Optimizer.h:47, src/Optimizer.cc:239-452) -- SURVEY §8(f)
+ * Optimizer::PoseOptimization  (include/Optimizer.h:46, src/Optimizer.cc:239-452) -- SURVEY §8(f)
  * rank 1, called 1-3 times per frame right after each matcher call (Tracking.cc:870,994,1039).
  * One workgroup per frame runs the whole procedure on the device (4 rounds of up to 10
  * Levenberg-Marquardt iterations on the 6x6 system, outlier reclassification in between);

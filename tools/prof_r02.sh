@@ -1,0 +1,16 @@
+set -x
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r02
+rm -rf $O; mkdir -p $O
+cd $R && timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; cat $O/bench_default.json
+cd /tmp
+B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1
+tail -1 $O/stats.log
+cd $R
+f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp $f $O/bench_kernel_stats.csv; head -40 $f
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+du -sh $O
