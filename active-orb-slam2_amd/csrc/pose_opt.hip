@@ -2,6 +2,7 @@
 // optimization_algorithm_levenberg.cpp:61-164, linear_solver_dense.h:64-110).  SURVEY.md section 8(f) rank 1.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "lba_math.h"
 
@@ -16,10 +17,10 @@ namespace aos2 {
 // ---------------------------------------------------------------------------------------------
 struct PoseProbDev {
     int n;
-    const double *Xw, *obs;       // n x 3
-    const double *w;              // n
+    const float *Xw, *obs;        // n x 3 (the caller's float32 values; widened on use)
+    const float *w;               // n
     const uint8_t *stereo;        // n
-    double *err;                  // n x 3 scratch
+    double *err;                  // n scratch: chi2 of the edge's stored residual (e->chi2())
     uint8_t *level1, *robust;     // n scratch
     uint8_t *outlier;             // n out
     double fx, fy, cx, cy, bf;
@@ -28,9 +29,11 @@ struct PoseProbDev {
     int32_t *counts;              // [0] n_bad, [1] n_inliers
 };
 
-__device__ __forceinline__ void po_edge_error(const double *qt, const double *X, const double *obs, int stereo,
+__device__ __forceinline__ void po_edge_error(const double *qt, const float *Xf, const float *obf, int stereo,
                                               const PoseProbDev &P, double er[3])
 {
+    const double X[3] = {(double)Xf[0], (double)Xf[1], (double)Xf[2]};
+    const double obs[3] = {(double)obf[0], (double)obf[1], (double)obf[2]};
     double p[3];
     se3_map(qt, X, p);
     if (!stereo) {
@@ -49,64 +52,325 @@ __device__ __forceinline__ void po_edge_error(const double *qt, const double *X,
     }
 }
 
-// fixed-order workgroup sum of K doubles per thread -> out[K] valid in every thread after return.
-// The 256 partials of component k are added in thread order (8 slices of 32, then the 8 slice sums), instead of a
-// log-depth tree with a barrier per level.
-template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *sh /* 256 x (K+1) + 9 x K */, double *out)
+// sqrt(d) and 1 / sqrt(d) for d > 0: v_rsq_f64 + two coupled Newton (Goldschmidt) steps + one correction of the root;
+// ~10 dependent operations instead of the ~30-instruction IEEE sqrt followed by a ~30-instruction IEEE division.
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &s, double &r)
 {
-    // fixed summation order (bit-reproducible): 8 slices of 32 threads, each summed in thread order, then the 8 slice
-    // sums in slice order.  The 32 operands of a slice are fetched together before the dependent adds, and the 8-term
-    // final sums are formed once (K threads) and broadcast, instead of every thread re-adding 8 x K partials.
-    const int tid = threadIdx.x;
-    for (int i = 0; i < K; ++i) sh[tid * (K + 1) + i] = v[i];
-    __syncthreads();
-    double *part = sh + 256 * (K + 1), *fin = part + 8 * K;
-    if (tid < 8 * K) {
-        const int k = tid % K, slice = tid / K;
-        double x[32];
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double c = __builtin_fma(-g, g, d);
+    s = __builtin_fma(c, h, g);
+    r = h + h;
+}
+
+// T <- exp(upd) * T: VertexSE3Expmap::oplusImpl like se3_oplus (lba_math.h: SE3Quat::exp se3quat.h:223-257, operator*
+// :104-110), shaped for the serial path of the pose solver.  An LM step is a small rotation (|omega|^2 < 0.6), and for
+// those nothing needs a square root, a division or a sin / cos call: with z = |omega|^2 and fdlibm's minimax polynomials
+// sin t = t + t z ps(z), cos t = 1 - z / 2 + z^2 pc(z) on |t| <= pi / 4,
+//     sin t / t = 1 + z ps,   (1 - cos t) / t^2 = 1/2 - z pc,   (t - sin t) / t^3 = -ps       (the coefficients of R, V)
+// without the cancellation the quotients of se3quat.h:236-240 suffer, and the quaternion of R(omega) is
+// (omega sin(t/2) / t, cos(t/2)) = (omega (1 + zh ps(zh)) / 2, 1 - zh / 2 + zh^2 pc(zh)), zh = z / 4 -- what Eigen's
+// Quaterniond(R) + normalize() extracts from the matrix, up to rounding.  Below theta = 1e-5 the reference switches to
+// R = V = I + Omega + Omega^2 (:231-234); V keeps that, the normalised quaternion of that R equals the exact one to
+// 2e-11 relative.  The quaternion product is renormalised by a Newton step from 1 (|q|^2 = 1 + O(1e-16)).  Larger
+// rotations take the formulas as written.  Results agree with se3_oplus to a few ulp (pose tolerance: 1e-5).
+__device__ __forceinline__ void se3_oplus_fast(const double upd[6], double T[7])
+{
+    const double *omega = upd, *ups = upd + 3;
+    const double th2 = omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2];
+    // a x b with fused multiply-adds
+    auto cross = [](const double *a, const double *b, double *o) {
+        o[0] = __builtin_fma(a[1], b[2], -(a[2] * b[1]));
+        o[1] = __builtin_fma(a[2], b[0], -(a[0] * b[2]));
+        o[2] = __builtin_fma(a[0], b[1], -(a[1] * b[0]));
+    };
+    auto poly_s = [](double z) {
+        double ps = 1.58969099521155010221e-10;
+        ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+        ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+        ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+        ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+        return __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    };
+    auto poly_c = [](double z) {
+        double pc = -1.13596475577881948265e-11;
+        pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+        pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+        pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+        pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+        return __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    };
+    double e[7], bV, cV;
+    if (th2 < 0.6) {
+        const double z = th2, zh = 0.25 * th2;
+        const double ps = poly_s(z), pc = poly_c(z), psh = poly_s(zh), pch = poly_c(zh);
+        const bool tiny = th2 < 0.00001 * 0.00001;
+        bV = tiny ? 1.0 : __builtin_fma(-z, pc, 0.5);
+        cV = tiny ? 1.0 : -ps;
+        const double sv = 0.5 * __builtin_fma(zh, psh, 1.0);
+        e[0] = omega[0] * sv;
+        e[1] = omega[1] * sv;
+        e[2] = omega[2] * sv;
+        e[3] = __builtin_fma(zh * zh, pch, __builtin_fma(-0.5, zh, 1.0));
+    } else {
+        double theta, ith, sn, cs, R[9];
+        sqrt_rsqrt(th2, theta, ith);
+        sincos(theta, &sn, &cs);
+        const double ith2 = ith * ith;
+        const double a = sn * ith;
+        bV = (1 - cs) * ith2;
+        cV = (theta - sn) * (ith2 * ith);
+        const double Om[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 #pragma unroll
-        for (int t = 0; t < 32; ++t) x[t] = sh[(32 * slice + t) * (K + 1) + k];
-        double acc = 0;
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int t = 0; t < 32; ++t) acc += x[t];
-        part[slice * K + k] = acc;
+            for (int j = 0; j < 3; ++j) {
+                const double om2 = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
+                R[i * 3 + j] = I[i * 3 + j] + a * Om[i * 3 + j] + bV * om2;
+            }
+        const double t = R[0] + R[4] + R[8];
+        if (t > 0) {   // Eigen's Quaterniond(R), trace branch
+            double sq, rs;
+            sqrt_rsqrt(t + 1.0, sq, rs);
+            e[3] = 0.5 * sq;
+            const double tt = 0.5 * rs;
+            e[0] = (R[7] - R[5]) * tt;
+            e[1] = (R[2] - R[6]) * tt;
+            e[2] = (R[3] - R[1]) * tt;
+        } else {   // the other three branches, with static indices (a dynamic one would put R and e into scratch memory)
+            auto branch = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, j = (i + 1) % 3, k = (j + 1) % 3;
+                double sq, rs;
+                sqrt_rsqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0, sq, rs);
+                e[i] = 0.5 * sq;
+                const double tt = 0.5 * rs;
+                e[3] = (R[k * 3 + j] - R[j * 3 + k]) * tt;
+                e[j] = (R[j * 3 + i] + R[i * 3 + j]) * tt;
+                e[k] = (R[k * 3 + i] + R[i * 3 + k]) * tt;
+            };
+            if (R[8] > (R[4] > R[0] ? R[4] : R[0]))
+                branch(std::integral_constant<int, 2>());
+            else if (R[4] > R[0])
+                branch(std::integral_constant<int, 1>());
+            else
+                branch(std::integral_constant<int, 0>());
+        }
+        const double sg = e[3] < 0 ? -1.0 : 1.0;
+        double sq, rs;
+        sqrt_rsqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3], sq, rs);
+        rs *= sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] *= rs;
+    }
+    // V upsilon = upsilon + bV (omega x upsilon) + cV (omega x (omega x upsilon))      (V = I + bV Omega + cV Omega^2)
+    double wu[3], wwu[3];
+    cross(omega, ups, wu);
+    cross(omega, wu, wwu);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[4 + i] = __builtin_fma(cV, wwu[i], __builtin_fma(bV, wu[i], ups[i]));
+    // e * T: rotation of T's translation (v + w uv + e_v x uv, uv = 2 e_v x v) and the quaternion product
+    double rt[3], q[4], uv[3], cc[3];
+    cross(e, T + 4, uv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) uv[i] += uv[i];
+    cross(e, uv, cc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rt[i] = __builtin_fma(e[3], uv[i], T[4 + i]) + cc[i];
+    q[3] = __builtin_fma(-e[2], T[2], __builtin_fma(-e[1], T[1], __builtin_fma(-e[0], T[0], e[3] * T[3])));
+    q[0] = __builtin_fma(-e[2], T[1], __builtin_fma(e[1], T[2], __builtin_fma(e[0], T[3], e[3] * T[0])));
+    q[1] = __builtin_fma(-e[0], T[2], __builtin_fma(e[2], T[0], __builtin_fma(e[1], T[3], e[3] * T[1])));
+    q[2] = __builtin_fma(-e[1], T[0], __builtin_fma(e[0], T[1], __builtin_fma(e[2], T[3], e[3] * T[2])));
+    {
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        double rs;
+        if (fabs(n2 - 1.0) < 1e-6) {   // 1 / sqrt(1 + eps): two Newton steps from 1 (error O(eps^4))
+            const double r0 = __builtin_fma(-0.5, n2, 1.5);
+            rs = r0 * __builtin_fma(-0.5 * n2, r0 * r0, 1.5);
+        } else {
+            double sq;
+            sqrt_rsqrt(n2, sq, rs);
+        }
+        if (q[3] < 0) rs = -rs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[i] = q[i] * rs;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) T[4 + i] = e[4 + i] + rt[i];
+}
+
+// 1 / d within an ulp: v_rcp_f64 + two Newton steps (34 cycles of latency; the IEEE division sequence takes 67)
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double rd = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, rd, 1.0);
+    rd = __builtin_fma(rd, e, rd);
+    e = __builtin_fma(-d, rd, 1.0);
+    return __builtin_fma(rd, e, rd);
+}
+
+// (H + lambda I) x = b for the 6x6 system (linear_solver_dense.h:64-110: a Cholesky factorisation), H = upper triangle
+// packed row by row in Hb[0..20], b = Hb[21..26].  Returns false on a non-positive pivot ("not positive definite": the LM
+// step is rejected) and leaves x alone then, like the solver's x vector in g2o.  On the serial path of every LM trial, so
+// it is shaped for latency: the square-root-free form L D L^T (same pivots d_j as the squares of Cholesky's diagonal, so
+// the same positivity test; x equal up to rounding), right-looking so that the updates of a column are independent
+// operations, one reciprocal per pivot (rcp_newton) instead of 27 divisions + 6 square roots; everything in registers.
+__device__ __forceinline__ bool solve6(const double *Hb, double lambda, double (&x)[6])
+{
+    double a[6][6], rd[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c, ++k) a[c][r] = Hb[k];   // lower triangle a[row][col], row >= col
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a[d][d] += lambda;
+    bool pos = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double d = a[j][j];
+        if (!(d > 0)) pos = false;
+        rd[j] = rcp_newton(d);
+        double l[6];
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) l[r] = a[r][j] * rd[j];
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r)
+#pragma unroll
+            for (int c = j + 1; c <= r; ++c) a[r][c] = __builtin_fma(-l[r], a[c][j], a[r][c]);
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) a[r][j] = l[r];
+    }
+    double y[6], xv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double sacc = Hb[21 + r];
+#pragma unroll
+        for (int m = 0; m < r; ++m) sacc = __builtin_fma(-a[r][m], y[m], sacc);
+        y[r] = sacc;
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double sacc = y[r] * rd[r];
+#pragma unroll
+        for (int m = r + 1; m < 6; ++m) sacc = __builtin_fma(-a[m][r], xv[m], sacc);
+        xv[r] = sacc;
+    }
+    if (pos) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) x[r] = xv[r];
+    }
+    return pos;
+}
+
+// cycle counters of the phases (s_memtime), printed by workgroup 0: compile with -DAOS2_PO_TIMING (tools only)
+#ifdef AOS2_PO_TIMING
+#define PO_T(...) __VA_ARGS__
+#else
+#define PO_T(...)
+#endif
+
+constexpr int kPoSum = 28;   // 21 (H, upper triangle) + 6 (b) + 1 (robust chi2)
+constexpr size_t kPoLds = (4 * kPoSum + 2 * kPoSum) * sizeof(double);   // 4 wave sums, two result buffers
+
+__device__ __forceinline__ double pair_f64(unsigned lo, unsigned hi) { return __longlong_as_double(((long long)hi << 32) | lo); }
+
+// sum of x over the lane pairs {l, l + 32} (kSwap32) or {l, l + 16} of a wave, for two values at once: the lower half
+// (even 16-lane rows) ends up with the pair sums of x, the upper half (odd rows) with those of y.  One
+// v_permlane{32,16}_swap per dword (gfx950) moves x up and y down in the same instruction.
+template <bool kSwap32>
+__device__ __forceinline__ double swap_add(double x, double y)
+{
+    const long long xb = __double_as_longlong(x), yb = __double_as_longlong(y);
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    u2 lo, hi;
+    if (kSwap32) {
+        lo = __builtin_amdgcn_permlane32_swap((unsigned)xb, (unsigned)yb, false, false);
+        hi = __builtin_amdgcn_permlane32_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    } else {
+        lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+        hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    }
+    return pair_f64(lo[0], hi[0]) + pair_f64(lo[1], hi[1]);
+}
+
+template <int kCtrl>
+__device__ __forceinline__ double po_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), kCtrl, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// fixed-order workgroup sum of the 28 doubles of every thread -> fin[28] in LDS, readable by every thread after return
+// (bit-reproducible: the order is a function of the lane number only).  Per wave a reduce-scatter: the two halves of the
+// wave exchange halves of the values (28 -> 14 per lane, v_permlane32_swap), the 16-lane rows again (-> 7 per lane,
+// v_permlane16_swap), then 7 DPP row sums; 147 instructions instead of the 504 of 28 full butterflies, and 112 doubles of
+// LDS traffic per workgroup instead of 57 KB.  The 4 wave sums of each value are added by 28 threads.  Two barriers are
+// enough: a wave rewrites part[wave] only after it left the previous call's second barrier, which the readers of the
+// previous `part` reach after reading; `fin` is the caller's and alternates between two buffers.
+__device__ __forceinline__ void block_sum28(double (&v)[kPoSum], double *part /* 4 x 28 */, double *fin)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double h[14], g[7];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) h[i] = swap_add<true>(v[i], v[14 + i]);   // lanes < 32: values 0..13, lanes >= 32: 14..27
+#pragma unroll
+    for (int i = 0; i < 7; ++i) g[i] = swap_add<false>(h[i], h[7 + i]);    // row r of the wave: values 7 r .. 7 r + 6
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double x = g[i];
+        x += po_dpp_f64<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+        x += po_dpp_f64<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+        x += po_dpp_f64<0x141>(x);   // row_half_mirror
+        x += po_dpp_f64<0x140>(x);   // row_mirror
+        g[i] = x;
+    }
+    if ((lane & 15) == 0) {
+        double *dst = part + wave * kPoSum + 7 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = g[i];
     }
     __syncthreads();
-    if (tid < K) {
-        double acc = part[tid];
-#pragma unroll
-        for (int sl = 1; sl < 8; ++sl) acc += part[sl * K + tid];
-        fin[tid] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < K; ++i) out[i] = fin[i];
+    if (tid < kPoSum) fin[tid] = ((part[tid] + part[kPoSum + tid]) + part[2 * kPoSum + tid]) + part[3 * kPoSum + tid];
     __syncthreads();
 }
 
+// The whole procedure for one frame by one workgroup of 256 threads.
 // kEpt > 0: every thread keeps its (<= kEpt) edges -- map point, observation, weight, residual, flags -- in
-// registers for the whole procedure (n <= 256 * kEpt); the 40 LM iterations then touch no global memory.
+// registers for the whole procedure (n <= 256 * kEpt); the LM iterations then touch no global memory.
 // kEpt == 0: edges stay in global memory (any n).  Same arithmetic, same per-thread edge order either way.
+//
+// Every thread carries the pose and the LM state (lambda, ni, chi2) and runs the 6x6 solve, the exp-map update and the
+// accept / reject decision REDUNDANTLY from the broadcast sums: no thread-0 sections, no barriers besides the three of
+// the sum.  One pass over the edges at a pose yields residuals, robust chi2 AND the normal equations there (one sum of
+// 28): at the trial pose that is the chi2 the decision needs and -- when the trial is accepted, the usual case -- the
+// system of the next iteration (g2o recomputes the same numbers in computeActiveErrors + buildSystem at the top of the
+// next solve(), levenberg.cpp:75-88); after a rejected trial the previous system is still in registers.
 template <int kEpt>
-__global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
+__device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, double *sh, int *s_cnt)
 {
     constexpr int EPT = kEpt > 0 ? kEpt : 1;
     constexpr bool kReg = kEpt > 0;
-    double Xr[EPT][3], Or[EPT][3], Wr[EPT], Er[EPT][3];
+    float Xr[EPT][3], Or[EPT][3], Wr[EPT];
+    double Cr[EPT];   // chi2 of the edge's stored residual (what e->chi2() returns between two computeError calls)
     uint8_t Sr[EPT], L1r[EPT], Rbr[EPT], Outr[EPT];
-    extern __shared__ __attribute__((aligned(16))) double sh[];  // 256 x 28 + 9 x 27
-    __shared__ double qt[7], bk[7], xs[6];
-    __shared__ double s_lambda, s_ni, s_rho, s_currentChi;
-    __shared__ int s_flag;
-    const PoseProbDev P = probs[blockIdx.x];
     const int tid = threadIdx.x, n = P.n;
     // edge loop: thread tid owns edges tid, tid + 256, ... (slot j); accessors pick registers or global memory
 #define PO_FOR_EDGES(j, e) for (int j = 0, e = tid; e < n && (!kReg || j < EPT); ++j, e += 256)
-    auto Xp = [&](int j, int e) -> const double * { return kReg ? Xr[j] : P.Xw + 3 * e; };
-    auto Op = [&](int j, int e) -> const double * { return kReg ? Or[j] : P.obs + 3 * e; };
-    auto Ep = [&](int j, int e) -> double * { return kReg ? Er[j] : P.err + 3 * e; };
-    auto Wv = [&](int j, int e) -> double { return kReg ? Wr[j] : P.w[e]; };
+    auto Xp = [&](int j, int e) -> const float * { return kReg ? Xr[j] : P.Xw + 3 * e; };
+    auto Op = [&](int j, int e) -> const float * { return kReg ? Or[j] : P.obs + 3 * e; };
+    auto Cp = [&](int j, int e) -> double & { return kReg ? Cr[j] : P.err[e]; };
+    auto Wv = [&](int j, int e) -> double { return (double)(kReg ? Wr[j] : P.w[e]); };
     auto Sv = [&](int j, int e) -> int { return kReg ? Sr[j] : P.stereo[e]; };
     auto L1 = [&](int j, int e) -> uint8_t & { return kReg ? L1r[j] : P.level1[e]; };
     auto Rb = [&](int j, int e) -> uint8_t & { return kReg ? Rbr[j] : P.robust[e]; };
@@ -124,277 +388,255 @@ __global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDe
         L1(j, e) = 0;
         Rb(j, e) = 1;
         Ou(j, e) = 0;
-        double *er0 = Ep(j, e);
-        er0[0] = er0[1] = er0[2] = 0;
+        Cp(j, e) = 0;
     }
-    if (tid < 7) qt[tid] = P.pose_in[tid];
-    __syncthreads();
+    double qt[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qt[k] = P.pose_in[k];
     if (n < 3) {  // nInitialCorrespondences < 3 (:355-356): the pose stays, mvbOutlier was already reset (:283, :320)
         for (int e = tid; e < n; e += 256) P.outlier[e] = 0;   // (the register copies above never reach memory here)
-        if (tid < 7) P.pose_out[tid] = P.pose_in[tid];
-        if (tid == 0) { P.counts[0] = 0; P.counts[1] = 0; }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) P.pose_out[k] = qt[k];
+            P.counts[0] = 0;
+            P.counts[1] = 0;
+        }
         return;
     }
     const double delta_m = (double)(float)sqrt(5.991), delta_s = (double)(float)sqrt(7.815);
-    int nBad = 0;
-    // residuals of the active edges + robust chi2 (computeActiveErrors + activeRobustChi2)
-    auto errors_chi2 = [&](double &chi_out) {
-        double acc[1] = {0};
+    // one pass over the active edges at pose q: residuals (stored), robust chi2, H (upper triangle) and b
+    // (computeActiveErrors + activeRobustChi2 + buildSystem; types_six_dof_expmap.cpp:266-364, base_unary_edge.hpp)
+    PO_T(long long t_edges = 0, t_sum = 0, t_solve = 0, t_dec = 0, t_all = __builtin_amdgcn_s_memtime(); int n_pass = 0, n_trial = 0;)
+    auto pass = [&](const double (&q)[7], double *fin) {
+        PO_T(const long long p0 = __builtin_amdgcn_s_memtime();)
+        double acc[kPoSum];
+#pragma unroll
+        for (int k = 0; k < kPoSum; ++k) acc[k] = 0;
+        // The rotation as a matrix, once per pass (9 fused multiply-adds per point instead of the ~33 operations of Eigen's
+        // quaternion * vector), and the Jacobian from a = x / z, b = y / z: the same quantities as
+        // types_six_dof_expmap.cpp:266-364 in fewer operations -- results equal to rounding (1e-16 relative).
+        double Rm[9];
+        rot_from_quat(q, Rm);
+        const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, bf = P.bf;
 #pragma unroll EPT
         PO_FOR_EDGES(j, e) {
             if (L1(j, e)) continue;
-            double er[3];
             const int st = Sv(j, e);
-            po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
-            double *ee = Ep(j, e);
-            ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
-            double c = edge_chi2(er, Wv(j, e), st ? 3 : 2);
-            if (Rb(j, e)) {
-                double rho[2];
-                robustify(c, st ? delta_s : delta_m, rho);
-                c = rho[0];
+            const bool st3 = st != 0;
+            const float *Xf = Xp(j, e), *obf = Op(j, e);
+            const double X0 = (double)Xf[0], X1 = (double)Xf[1], X2 = (double)Xf[2];
+            const double ob[3] = {(double)obf[0], (double)obf[1], (double)obf[2]};
+            const double x = __builtin_fma(Rm[2], X2, __builtin_fma(Rm[1], X1, __builtin_fma(Rm[0], X0, q[4])));
+            const double y = __builtin_fma(Rm[5], X2, __builtin_fma(Rm[4], X1, __builtin_fma(Rm[3], X0, q[5])));
+            const double z = __builtin_fma(Rm[8], X2, __builtin_fma(Rm[7], X1, __builtin_fma(Rm[6], X0, q[6])));
+            const double invz = rcp_newton(z);   // (1 / z within an ulp)
+            const double a = x * invz, b = y * invz;
+            double er[3];
+            if (!st3) {
+                er[0] = ob[0] - __builtin_fma(a, fx, cx);
+                er[1] = ob[1] - __builtin_fma(b, fy, cy);
+                er[2] = 0;
+            } else {   // EdgeStereoSE3ProjectXYZOnlyPose::cam_project: invz is a float there (types_six_dof_expmap.cpp:338)
+                const float invzf = (float)invz;
+                const double r0 = x * invzf * fx + cx;
+                const double r1 = y * invzf * fy + cy;
+                const double r2 = r0 - bf * invzf;
+                er[0] = ob[0] - r0;
+                er[1] = ob[1] - r1;
+                er[2] = ob[2] - r2;
             }
-            acc[0] += c;
+            const double w = Wv(j, e);
+            const double c = edge_chi2(er, w, st3 ? 3 : 2);
+            Cp(j, e) = c;
+            double wo = w, r1 = 1.0, cr = c;
+            if (Rb(j, e)) {   // RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91)
+                const double delta = st3 ? delta_s : delta_m, dsqr = delta * delta;
+                if (c > dsqr) {
+                    double sq, rs;
+                    sqrt_rsqrt(c, sq, rs);
+                    cr = 2 * sq * delta - dsqr;
+                    r1 = delta * rs;
+                    wo = r1 * w;
+                }
+            }
+            acc[27] += cr;
+            double J[18];
+            const double fxz = fx * invz, fyz = fy * invz, ab = a * b;
+            J[0] = ab * fx;
+            J[1] = -(__builtin_fma(a, a, 1.0) * fx);
+            J[2] = b * fx;
+            J[3] = -fxz;
+            J[4] = 0;
+            J[5] = a * fxz;
+            J[6] = __builtin_fma(b, b, 1.0) * fy;
+            J[7] = -(ab * fy);
+            J[8] = -(a * fy);
+            J[9] = 0;
+            J[10] = -fyz;
+            J[11] = b * fyz;
+            const double bfz2 = bf * (invz * invz);
+            J[12] = __builtin_fma(-bfz2, y, J[0]);
+            J[13] = __builtin_fma(bfz2, x, J[1]);
+            J[14] = J[2];
+            J[15] = J[3];
+            J[16] = 0;
+            J[17] = J[5] - bfz2;
+            // H += J^T (wo I) J, b -= r1 J^T (w e) as fused multiply-adds into the per-thread sums (the association differs
+            // from the reference's "t = sum over rows, H += t" by rounding only: same terms, and the workgroup sum reorders
+            // them anyway).  A mono edge has no third row: its weight is 0 there.
+            // J[4] = J[6 + 3] = J[12 + 4] = 0: those products are left out (45 + 15 fused multiply-adds instead of 63 + 18)
+            const double wo2 = st3 ? wo : 0.0;
+            const double we0 = r1 * (w * er[0]), we1 = r1 * (w * er[1]), we2 = st3 ? r1 * (w * er[2]) : 0.0;
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double j0 = J[r] * wo, j1 = J[6 + r] * wo, j2 = J[12 + r] * wo2;
+                double bb = acc[21 + r];
+                if (r != 4) bb = __builtin_fma(-J[r], we0, bb);
+                if (r != 3) bb = __builtin_fma(-J[6 + r], we1, bb);
+                if (r != 4) bb = __builtin_fma(-J[12 + r], we2, bb);
+                acc[21 + r] = bb;
+#pragma unroll
+                for (int c2 = r; c2 < 6; ++c2, ++k) {
+                    double t = acc[k];
+                    if (r != 4 && c2 != 4) t = __builtin_fma(j0, J[c2], t);
+                    if (r != 3 && c2 != 3) t = __builtin_fma(j1, J[6 + c2], t);
+                    if (r != 4 && c2 != 4) t = __builtin_fma(j2, J[12 + c2], t);
+                    acc[k] = t;
+                }
+            }
         }
-        double out[1];
-        block_sum<1>(acc, sh, out);
-        chi_out = out[0];
+        PO_T(const long long p1 = __builtin_amdgcn_s_memtime();)
+        block_sum28(acc, sh, fin);
+        PO_T(const long long p2 = __builtin_amdgcn_s_memtime(); t_edges += p1 - p0; t_sum += p2 - p1; ++n_pass;)
     };
+    int nBad = 0, cur = 0;
+    double *fin0 = sh + 4 * kPoSum;   // two result buffers of the sums
+    double xs[6] = {0, 0, 0, 0, 0, 0};   // the solver's x: persists over trials and rounds
     for (int it = 0; it < 4; ++it) {
-        if (tid < 7) qt[tid] = P.pose_in[tid];  // every round restarts from pFrame->mTcw (:368)
-        __syncthreads();
-        int n_active = 0;
-        {
-            double cnt[1] = {0}, out[1];
-#pragma unroll EPT
-            PO_FOR_EDGES(j, e) cnt[0] += L1(j, e) ? 0.0 : 1.0;
-            block_sum<1>(cnt, sh, out);
-            n_active = (int)out[0];
-        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) qt[k] = P.pose_in[k];  // every round restarts from pFrame->mTcw (:368)
+        const int n_active = n - nBad;   // the edges not at level 1
         if (n_active > 0) {
             int nBadLM = 0;
-            bool ok = true;
-            bool fresh = false;   // the residuals and s_currentChi belong to the current pose (left by an accepted trial)
+            bool ok = true, have = false;   // have: Hb / currentChi / the stored chi2 belong to the current pose
+            double lambda = 0, ni = 2, currentChi = 0;
             for (int i = 0; i < 10 && ok; ++i) {
-                // computeActiveErrors at the top of solve() (levenberg.cpp:75): recomputing at the pose of the accepted trial
-                // reproduces its residuals and chi2 bit for bit, so it is skipped then
-                double currentChi;
-                if (fresh)
-                    currentChi = s_currentChi;
-                else
-                    errors_chi2(currentChi);
+                if (!have) {   // computeActiveErrors + buildSystem at the top of solve() (levenberg.cpp:75-88)
+                    pass(qt, fin0 + cur * kPoSum);
+                    currentChi = fin0[cur * kPoSum + 27];
+                }
+                const double *Hb = fin0 + cur * kPoSum;
                 const double iniChi = currentChi;
-                // buildSystem: H (upper triangle, 21) + b (6)
-                double acc[27];
+                if (i == 0) {
+                    double maxDiagonal = 0.;
+                    constexpr int di[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
-                for (int k = 0; k < 27; ++k) acc[k] = 0;
-#pragma unroll EPT
-                PO_FOR_EDGES(j, e) {
-                    if (L1(j, e)) continue;
-                    const int st = Sv(j, e), D = st ? 3 : 2;
-                    double p[3];
-                    se3_map(qt, Xp(j, e), p);
-                    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
-                    double J[18];
-                    J[0] = x * y * invz_2 * P.fx;
-                    J[1] = -(1 + (x * x * invz_2)) * P.fx;
-                    J[2] = y * invz * P.fx;
-                    J[3] = -invz * P.fx;
-                    J[4] = 0;
-                    J[5] = x * invz_2 * P.fx;
-                    J[6] = (1 + y * y * invz_2) * P.fy;
-                    J[7] = -x * y * invz_2 * P.fy;
-                    J[8] = -x * invz * P.fy;
-                    J[9] = 0;
-                    J[10] = -invz * P.fy;
-                    J[11] = y * invz_2 * P.fy;
-                    J[12] = J[0] - P.bf * y * invz_2;
-                    J[13] = J[1] + P.bf * x * invz_2;
-                    J[14] = J[2];
-                    J[15] = J[3];
-                    J[16] = 0;
-                    J[17] = J[5] - P.bf * invz_2;
-                    const double *er = Ep(j, e);
-                    const double w = Wv(j, e);
-                    double wo = w, r1 = 1.0;
-                    if (Rb(j, e)) {
-                        double rho[2];
-                        robustify(edge_chi2(er, w, D), st ? delta_s : delta_m, rho);
-                        r1 = rho[1];
-                        wo = rho[1] * w;
-                    }
-                    // static indices only (registers): the third row joins for stereo edges; 0 + a == a, so the
-                    // sums equal the d-loops of the reference order
-                    const bool st3 = D == 3;
-                    int k = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        double sacc = J[r] * (w * er[0]);
-                        sacc += J[6 + r] * (w * er[1]);
-                        if (st3) sacc += J[12 + r] * (w * er[2]);
-                        acc[21 + r] -= r1 * sacc;
-#pragma unroll
-                        for (int c = r; c < 6; ++c, ++k) {
-                            double t = J[r] * wo * J[c];
-                            t += J[6 + r] * wo * J[6 + c];
-                            if (st3) t += J[12 + r] * wo * J[12 + c];
-                            acc[k] += t;
-                        }
-                    }
+                    for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
+                    lambda = 1e-5 * maxDiagonal;
+                    ni = 2;
+                    nBadLM = 0;
                 }
-                double Hb[27];
-                block_sum<27>(acc, sh, Hb);
-                if (tid == 0) {
-                    if (i == 0) {
-                        double maxDiagonal = 0.;
-                        constexpr int di[6] = {0, 6, 11, 15, 18, 20};
-#pragma unroll
-                        for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
-                        s_lambda = 1e-5 * maxDiagonal;
-                        s_ni = 2;
-                    }
-                    s_currentChi = currentChi;
-                }
-                if (i == 0) nBadLM = 0;
-                __syncthreads();
                 double rho = 0;
                 int qmax = 0;
                 do {
-                    if (tid == 0) {
-                        for (int k = 0; k < 7; ++k) bk[k] = qt[k];
-                        // (H + lambda I) x = b by Cholesky; "not positive" -> the step is rejected.  All loops have
-                        // constant bounds and are unrolled so that L, y stay in registers (dynamic indexing would put
-                        // them in scratch memory, on the serial path of every LM step); after a non-positive pivot
-                        // the remaining arithmetic runs on but its result is discarded (pos = false).
-                        double L[36];
-                        {
-                            int k = 0;
+                    double bk[7];
 #pragma unroll
-                            for (int r = 0; r < 6; ++r)
+                    for (int k = 0; k < 7; ++k) bk[k] = qt[k];
+                    Hb = fin0 + cur * kPoSum;
+                    PO_T(const long long s0 = __builtin_amdgcn_s_memtime();)
+                    const bool pos = solve6(Hb, lambda, xs);
+                    se3_oplus_fast(xs, qt);   // (after a failed solve: the previous x once more; the trial is rejected below)
+                    double scale = 0.;
 #pragma unroll
-                                for (int c = r; c < 6; ++c, ++k) L[c * 6 + r] = L[r * 6 + c] = Hb[k];
-                        }
+                    for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + Hb[21 + j]);
+                    scale += 1e-3;
+                    double *Ht = fin0 + (cur ^ 1) * kPoSum;   // the trial's sums go to the other buffer: accepting = switching
+                    PO_T(const long long s1 = __builtin_amdgcn_s_memtime(); t_solve += s1 - s0; ++n_trial;)
+                    pass(qt, Ht);
+                    PO_T(const long long s2 = __builtin_amdgcn_s_memtime();)
+                    const double tempChi = pos ? Ht[27] : 1.7976931348623157e308;
+                    double r = currentChi - tempChi;
+                    r /= scale;
+                    have = false;
+                    if (r > 0 && isfinite(tempChi)) {
+                        const double t = 2 * r - 1;
+                        double alpha = 1. - t * t * t;
+                        alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                        const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
+                        lambda *= scaleFactor;
+                        ni = 2;
+                        currentChi = tempChi;
+                        cur ^= 1;
+                        have = true;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
 #pragma unroll
-                        for (int d = 0; d < 6; ++d) L[d * 7] += s_lambda;
-                        bool pos = true;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            double dd = L[j * 6 + j];
-#pragma unroll
-                            for (int m = 0; m < j; ++m) dd -= L[j * 6 + m] * L[j * 6 + m];
-                            if (!(dd > 0)) pos = false;
-                            dd = sqrt(dd);
-                            L[j * 6 + j] = dd;
-#pragma unroll
-                            for (int r = j + 1; r < 6; ++r) {
-                                double sacc = L[r * 6 + j];
-#pragma unroll
-                                for (int m = 0; m < j; ++m) sacc -= L[r * 6 + m] * L[j * 6 + m];
-                                L[r * 6 + j] = sacc / dd;
-                            }
-                        }
-                        if (pos) {
-                            double yv[6], xv[6];
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                double sacc = Hb[21 + r];
-#pragma unroll
-                                for (int m = 0; m < r; ++m) sacc -= L[r * 6 + m] * yv[m];
-                                yv[r] = sacc / L[r * 6 + r];
-                            }
-#pragma unroll
-                            for (int r = 5; r >= 0; --r) {
-                                double sacc = yv[r];
-#pragma unroll
-                                for (int m = r + 1; m < 6; ++m) sacc -= L[m * 6 + r] * xv[m];
-                                xv[r] = sacc / L[r * 6 + r];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) xs[r] = xv[r];
-                        }
-                        s_flag = pos ? 1 : 0;
-                        double upd[6], T[7];
-                        for (int k2 = 0; k2 < 6; ++k2) upd[k2] = xs[k2];
-                        for (int k2 = 0; k2 < 7; ++k2) T[k2] = qt[k2];
-                        se3_oplus(upd, T);
-                        for (int k2 = 0; k2 < 7; ++k2) qt[k2] = T[k2];
+                        for (int k = 0; k < 7; ++k) qt[k] = bk[k];
                     }
-                    __syncthreads();
-                    double tempChi;
-                    errors_chi2(tempChi);
-                    if (tid == 0) {
-                        if (!s_flag) tempChi = 1.7976931348623157e308;
-                        double r = s_currentChi - tempChi;
-                        double scale = 0.;
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) scale += xs[j] * (s_lambda * xs[j] + Hb[21 + j]);
-                        scale += 1e-3;
-                        r /= scale;
-                        if (r > 0 && isfinite(tempChi)) {
-                            double alpha = 1. - pow((2 * r - 1), 3.0);
-                            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
-                            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
-                            s_lambda *= scaleFactor;
-                            s_ni = 2;
-                            s_currentChi = tempChi;
-                        } else {
-                            s_lambda *= s_ni;
-                            s_ni *= 2;
-                            for (int k = 0; k < 7; ++k) qt[k] = bk[k];
-                        }
-                        s_rho = r;
-                    }
-                    __syncthreads();
-                    rho = s_rho;
+                    rho = r;
                     qmax++;
+                    PO_T(t_dec += __builtin_amdgcn_s_memtime() - s2;)
                 } while (rho < 0 && qmax < 10);
-                fresh = rho > 0;   // the trial was accepted (r > 0 && isfinite(tempChi): chi2 is never negative, so r > 0 implies it)
-                const double curChi = s_currentChi;
                 if (qmax == 10 || rho == 0) {
                     ok = false;
                 } else {
-                    if ((iniChi - curChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+                    if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
                     if (nBadLM >= 3) ok = false;
                 }
-                __syncthreads();
             }
         }
         // outlier reclassification (:371-430)
-        double bad[1] = {0}, outb[1];
+        if (tid == 0) *s_cnt = 0;
+        __syncthreads();
+        int bad = 0;
 #pragma unroll EPT
         PO_FOR_EDGES(j, e) {
             const int st = Sv(j, e);
-            if (Ou(j, e)) {
+            if (Ou(j, e)) {   // e->computeError() for the edges the optimiser skipped (:379, :406)
                 double er[3];
                 po_edge_error(qt, Xp(j, e), Op(j, e), st, P, er);
-                double *ee = Ep(j, e);
-                ee[0] = er[0]; ee[1] = er[1]; ee[2] = er[2];
+                Cp(j, e) = edge_chi2(er, Wv(j, e), st ? 3 : 2);
             }
-            const float chi2 = (float)edge_chi2(Ep(j, e), Wv(j, e), st ? 3 : 2);
+            const float chi2 = (float)Cp(j, e);
             if (chi2 > (st ? 7.815f : 5.991f)) {
                 Ou(j, e) = 1;
                 L1(j, e) = 1;
-                bad[0] += 1.0;
+                bad++;
             } else {
                 Ou(j, e) = 0;
                 L1(j, e) = 0;
             }
             if (it == 2) Rb(j, e) = 0;
         }
-        block_sum<1>(bad, sh, outb);
-        nBad = (int)outb[0];
+        if (bad) atomicAdd(s_cnt, bad);
+        __syncthreads();
+        nBad = *s_cnt;
+        __syncthreads();
         if (n < 10) break;  // optimizer.edges().size() < 10
     }
     if (kReg) {
 #pragma unroll EPT
         PO_FOR_EDGES(j, e) P.outlier[e] = Outr[j];
     }
-    if (tid < 7) P.pose_out[tid] = qt[tid];
+    PO_T(if (tid == 0 && blockIdx.x == 0) printf("PO n %d passes %d trials %d cycles: edges %lld sum %lld solve+oplus %lld decide %lld total %lld\n", n, n_pass, n_trial, t_edges, t_sum, t_solve, t_dec, __builtin_amdgcn_s_memtime() - t_all);)
     if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) P.pose_out[k] = qt[k];
         P.counts[0] = nBad;
         P.counts[1] = n - nBad;
     }
 #undef PO_FOR_EDGES
+}
+
+template <int kEpt>
+__global__ __launch_bounds__(256) void pose_optimization_kernel(const PoseProbDev *__restrict__ probs)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];  // kPoLds
+    __shared__ int s_cnt;
+    const PoseProbDev P = probs[blockIdx.x];
+    pose_optimization_body<kEpt>(P, sh, &s_cnt);
 }
 
 }  // namespace aos2
@@ -432,18 +674,20 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     for (int i = 0; i < n_problems; ++i) {
         const aos2_pose_problem_t &p = problems[i];
         const size_t n = (size_t)p.n;
-        double *xw = H.push_fill<double>(3 * n + 1, offs[i].xw), *ob = H.push_fill<double>(3 * n + 1, offs[i].obs);
-        double *w = H.push_fill<double>(n + 1, offs[i].w);
+        float *xw = H.push_fill<float>(3 * n + 1, offs[i].xw), *ob = H.push_fill<float>(3 * n + 1, offs[i].obs);
+        float *w = H.push_fill<float>(n + 1, offs[i].w);
         uint8_t *sv = H.push_fill<uint8_t>(n + 1, offs[i].st);
         if (!xw || !ob || !w || !sv) {
             set_error("internal: pose optimisation input staging");
             return AOS2_ERR_ARG;
         }
-        for (size_t k = 0; k < 3 * n; ++k) xw[k] = (double)p.Xw[k];
-        for (size_t k = 0; k < 3 * n; ++k) ob[k] = (double)p.obs[k];
-        for (size_t k = 0; k < n; ++k) w[k] = (double)p.inv_sigma2[k];
-        xw[3 * n] = ob[3 * n] = w[n] = 0.0;
-        if (n) memcpy(sv, p.stereo, n);
+        if (n) {
+            memcpy(xw, p.Xw, 12 * n);
+            memcpy(ob, p.obs, 12 * n);
+            memcpy(w, p.inv_sigma2, 4 * n);
+            memcpy(sv, p.stereo, n);
+        }
+        xw[3 * n] = ob[3 * n] = w[n] = 0.f;
         sv[n] = 0;
     }
     size_t o_probs;
@@ -455,7 +699,7 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     const size_t in_bytes = H.host_size;
     for (int i = 0; i < n_problems; ++i) {
         const size_t n = (size_t)problems[i].n;
-        offs[i].err = H.push(nullptr, (3 * n + 1) * 8);
+        offs[i].err = H.push(nullptr, (n + 1) * 8);
         offs[i].l1 = H.push(nullptr, n + 1);
         offs[i].rb = H.push(nullptr, n + 1);
     }
@@ -473,8 +717,8 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
         const aos2_pose_problem_t &p = problems[i];
         PoseProbDev &D = dev[i];
         D.n = p.n;
-        D.Xw = (const double *)(base + offs[i].xw); D.obs = (const double *)(base + offs[i].obs);
-        D.w = (const double *)(base + offs[i].w); D.stereo = base + offs[i].st;
+        D.Xw = (const float *)(base + offs[i].xw); D.obs = (const float *)(base + offs[i].obs);
+        D.w = (const float *)(base + offs[i].w); D.stereo = base + offs[i].st;
         D.err = (double *)(base + offs[i].err); D.level1 = base + offs[i].l1; D.robust = base + offs[i].rb;
         D.outlier = base + offs[i].out; D.pose_out = (double *)(base + offs[i].pose); D.counts = (int32_t *)(base + offs[i].cnt);
         D.fx = (double)p.fx; D.fy = (double)p.fy; D.cx = (double)p.cx; D.cy = (double)p.cy; D.bf = (double)p.bf;
@@ -485,7 +729,7 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     int max_n = 0;
     for (int i = 0; i < n_problems; ++i) max_n = std::max(max_n, problems[i].n);
-    const size_t po_lds = (256 * 28 + 9 * 27) * sizeof(double);
+    const size_t po_lds = kPoLds;
     if (max_n <= 256 * 4)   // the usual case (a frame has <= ~1000 map-point matches): edges live in registers
         hipLaunchKernelGGL(pose_optimization_kernel<4>, dim3(n_problems), dim3(256), po_lds, q, (const PoseProbDev *)(base + o_probs));
     else
