@@ -255,15 +255,23 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
                                                       InitB initB, EntOf ent_of, Accept accept, Blocks blocks)
 {
     __shared__ int changed;
+    // valid candidates beyond the 8 a query keeps in registers (wide windows: SearchByProjection(Current, Last) with th = 15
+    // has them for ~10 % of the queries): an LDS arena, so that no query walks its entries in global memory on the pass loop
+    // (one such query made every pass ~20 us long).  A query that finds the arena full falls back to that walk.
+    constexpr int kOvfCap = 2048;
+    __shared__ Entry ovf_arena[kOvfCap];
+    __shared__ int ovf_used;
     const int tid = threadIdx.x;
     int32_t *Bc = lds, *Bn = lds + n_f;
     for (int i = tid; i < n_f; i += NT) Bc[i] = initB(i);
+    if (tid == 0) ovf_used = 0;
     constexpr int QPT = CACHED ? kFixQpt : 1;
     Entry ce[QPT][8];
     const Entry *cent[QPT];
-    int ccnt[QPT], cchoice[QPT];
+    int ccnt[QPT], cchoice[QPT], covo[QPT], covn[QPT];
     bool cblk[QPT], covf[QPT];
     if (CACHED) {
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int q = tid + NT * j;
@@ -272,13 +280,14 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
             cchoice[j] = -2;
             cblk[j] = false;
             covf[j] = false;
+            covo[j] = -1;
+            covn[j] = 0;
             if (q < n_q) {
                 cent[j] = ent_of(q, ccnt[j]);
                 cblk[j] = blocks(q);
             }
             // keep the VALID entries (a window's population is mostly features rejected by the level / radius tests
-            // before the distance, key == KEY_NONE): a shift register, so the array is only indexed statically.  More
-            // than 8 valid ones (rare): the query rescans its entries from memory in every pass.
+            // before the distance, key == KEY_NONE): a shift register, so the array is only indexed statically.
 #pragma unroll
             for (int u = 0; u < 8; ++u) ce[j][u] = Entry{KEY_NONE, 0};
             int nvalid = 0;
@@ -296,12 +305,40 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
                     }
             }
             covf[j] = nvalid > 8;
+            if (nvalid > 8) {   // the registers hold the LAST 8 valid entries; the first nvalid - 8 go to the arena
+                const int extra = nvalid - 8;
+                const int off = atomicAdd(&ovf_used, extra);
+                if (off + extra <= kOvfCap) {
+                    covo[j] = off;
+                    covn[j] = extra;
+                    int w = 0;
+                    for (int j0 = 0; j0 < ccnt[j] && w < extra; j0 += 8) {
+                        Entry eb[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) eb[u] = j0 + u < ccnt[j] ? cent[j][j0 + u] : Entry{KEY_NONE, 0};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (eb[u].key != KEY_NONE && w < extra) ovf_arena[off + w++] = eb[u];
+                    }
+                }
+            }
         }
     } else {
         for (int q = tid; q < n_q; q += NT) choice[q] = -2;
     }
     __syncthreads();
+#ifdef AOS2_FIX_DEBUG
+    __shared__ int dbg_ovf, dbg_ent;
+    if (tid == 0) dbg_ovf = dbg_ent = 0;
+    __syncthreads();
+    if (CACHED) for (int j = 0; j < QPT; ++j) { if (covf[j]) atomicAdd(&dbg_ovf, 1); atomicAdd(&dbg_ent, ccnt[j]); }
+    int dbg_pass = 0;
+    const long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+#ifdef AOS2_FIX_DEBUG
+        ++dbg_pass;
+#endif
         if (tid == 0) changed = 0;
         for (int i = tid; i < n_f; i += NT) Bn[i] = initB(i);
         __syncthreads();
@@ -319,9 +356,17 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
                     const bool free_ = ce[j][u].key != KEY_NONE && bv[u] >= q;
                     best2_insert(b1, b2, free_ ? ((unsigned long long)ce[j][u].key << 32) | ce[j][u].payload : ~0ull);
                 }
-                if (covf[j]) {   // rare: more than 8 valid candidates
-                    b1 = b2 = ~0ull;
-                    scan_best2_free(cent[j], ccnt[j], Bc, q, idx_mask, b1, b2);
+                if (covf[j]) {   // more than 8 valid candidates
+                    if (covo[j] >= 0) {
+                        for (int t = 0; t < covn[j]; ++t) {
+                            const Entry e = ovf_arena[covo[j] + t];
+                            const bool free_ = Bc[e.payload & idx_mask] >= q;
+                            best2_insert(b1, b2, free_ ? ((unsigned long long)e.key << 32) | e.payload : ~0ull);
+                        }
+                    } else {
+                        b1 = b2 = ~0ull;
+                        scan_best2_free(cent[j], ccnt[j], Bc, q, idx_mask, b1, b2);
+                    }
                 }
                 const int c = ccnt[j] > 0 ? accept(q, best2_unpack(b1, b2)) : -1;   // (q >= n_q: ccnt = 0)
                 ch |= c != cchoice[j];
@@ -348,6 +393,9 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
         int32_t *t = Bc; Bc = Bn; Bn = t;
         __syncthreads();
     }
+#ifdef AOS2_FIX_DEBUG
+    if (tid == 0 && blockIdx.x == 0) printf("FIX n_f %d n_q %d cached %d passes %d overflow queries %d entries %d cycles %lld\n", n_f, n_q, (int)CACHED, dbg_pass, dbg_ovf, dbg_ent, __builtin_amdgcn_s_memtime() - dbg_t0);
+#endif
     if (CACHED) {
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -1965,7 +2013,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(FrameDev F2, InitDev P
 using namespace aos2;
 
 // LDS budget of the fixed-point resolve kernels (two int32 copies of B[n_f]): default dynamic-LDS limit
-constexpr size_t kFixLdsBytes = 60 * 1024;
+constexpr size_t kFixLdsBytes = 44 * 1024;   // + the 16 KB overflow arena of resolve_fixpoint_impl: within the 64 KB of a workgroup
 
 struct aos2_matcher {
     float nnratio;

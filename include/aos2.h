@@ -635,7 +635,7 @@ typedef struct {
     const float *max_dist;   /* n      GetMaxDistanceInvariance()        (SearchLocalPoints only) */
 } aos2_map_points_dev_t;
 
-/* batch frames of at most cap (<= 7680) keypoints each */
+/* batch frames of at most cap (<= 5632) keypoints each */
 int aos2_frames_create(int device, int batch, int cap, aos2_frames_t **out);
 void aos2_frames_destroy(aos2_frames_t *f);
 void *aos2_frames_stream(aos2_frames_t *f);   /* the batch's hipStream_t */
