@@ -1546,36 +1546,44 @@ __device__ __forceinline__ void assign_grid_body(int n, const float *__restrict_
         if (c >= 0) atomicAdd(&cnt[c], 1);
     }
     __syncthreads();
-    // exclusive scan of the NC counts, 256 at a time
-    for (int c0 = 0; c0 < NC; c0 += 256) {
-        const int c = c0 + tid;
-        const int v = c < NC ? cnt[c] : 0;
-        int x = v;
+    // exclusive scan of the NC counts: thread t owns the kPer consecutive cells [t kPer, (t + 1) kPer)
+    constexpr int kPer = NC / 256;
+    static_assert(NC % 256 == 0, "grid cells per thread");
+    int own[kPer], tsum = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int excl = carry + woff + x - v;
-        if (c < NC) {
-            cnt[c] = excl;
-            grid_off[c] = excl;
-        }
-        __syncthreads();
-        if (tid == 255) carry = excl + v;
-        __syncthreads();
+    for (int k = 0; k < kPer; ++k) {
+        own[k] = cnt[tid * kPer + k];
+        tsum += own[k];
     }
-    if (tid == 0) grid_off[NC] = carry;
+    int x = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();   // (also: every thread has read its counts before the offsets overwrite them)
+    int excl = x - tsum;
+    for (int w = 0; w < wave; ++w) excl += wsum[w];
+    // cnt[c] <- offset of the cell, with bit 30 set when the cell holds one feature (its rank is 0: no search below)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int c = tid * kPer + k;
+        grid_off[c] = excl;
+        cnt[c] = excl | (own[k] == 1 ? (1 << 30) : 0);
+        excl += own[k];
+    }
+    if (tid == 255) grid_off[NC] = excl;
+    __syncthreads();
+    // stable fill: the rank of feature i inside its cell = the number of earlier features of the same cell
     for (int i = tid; i < n; i += 256) {
         const int c = cell[i];
         if (c < 0) continue;
+        const int oc = cnt[c];
         int rank = 0;
-        for (int j = 0; j < i; ++j) rank += cell[j] == c;
-        grid_idx[cnt[c] + rank] = i;
+        if (!(oc & (1 << 30)))
+            for (int j = 0; j < i; ++j) rank += cell[j] == c;
+        grid_idx[(oc & ~(1 << 30)) + rank] = i;
     }
 }
 

@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()
-B = 256
-imgs = np.concatenate([pkg.synth.synth_batch(0, 32)] * 8)
+B = int(os.environ.get("OCT_B", "256"))
+imgs = np.concatenate([pkg.synth.synth_batch(0, 32)] * 8)[:B]
 ex = pkg.Extractor()
 ex.set_chunks(1)
 ex.extract_batch(imgs)
