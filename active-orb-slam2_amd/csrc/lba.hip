@@ -58,6 +58,7 @@ struct LmState {
     int32_t stop_at_poll;  // test hook: the flag counts as set from this poll on (0 = off)
     int32_t n_active;   // level-0 edges of the second optimisation
     int32_t solver_failed;  // trials whose reduced system hit a zero pivot
+    int32_t blocks_done;    // workgroups of the current k_points launch that delivered their partial sums
     int32_t ntr;            // trials recorded below (AOS2_LBA_TRACE=1 prints them)
     double tr_rho[48], tr_temp[48], tr_cur[48], tr_lambda[48];
     long long dbg[16];      // cycle counters of the last reduced-system kernel (AOS2_LBA_TRACE=1)
@@ -90,8 +91,8 @@ struct LbaWin {
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
     double *tmp;                     // scale terms of the poses (6 np)
     double *scal;                    // [3] solve ok
-    double *part;                    // per-workgroup sums of k_points: chi2 terms [0, n_part), scale terms [n_part, 2 n_part)
-    int n_part;
+    double *part;                    // per-landmark sums of k_points: chi2 terms [0, nl), scale terms [nl, 2 nl)
+    int n_part;                      // workgroups of a k_points launch for this window
     double *ldlt;                    // factorisation scratch of the global-memory variant
     int npad, ldlt_lds;
     LmState *st;
@@ -153,14 +154,18 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
         W.e_robust[i] = 1;
         W.e_level1[i] = 0;
     }
-    if (i == 0) {
+    if (blockIdx.x == 0) {   // the state record (1.8 KB): zeroed by the workgroup, not by one thread
         LmState *st = W.st;
-        *st = LmState{};
-        st->iters_max[0] = W.iters1;
-        st->iters_max[1] = W.iters2;
-        st->polls = 1;   // the entry check of Optimizer.cc:656-658 was made on the host
-        st->stop_at_poll = stop_at_poll;
-        st->n_active = W.n_edges;
+        static_assert(sizeof(LmState) % 8 == 0, "LmState is cleared as 64-bit words");
+        for (int k = threadIdx.x; k < (int)(sizeof(LmState) / 8); k += 256) reinterpret_cast<long long *>(st)[k] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            st->iters_max[0] = W.iters1;
+            st->iters_max[1] = W.iters2;
+            st->polls = 1;   // the entry check of Optimizer.cc:656-658 was made on the host
+            st->stop_at_poll = stop_at_poll;
+            st->n_active = W.n_edges;
+        }
     }
 }
 
@@ -198,23 +203,269 @@ __device__ __forceinline__ void edge_error(const Cam &cam, const double p[3], co
     }
 }
 
-// One thread per landmark, 128-thread workgroups.  solve = 1 (a Levenberg-Marquardt trial): the landmark's part of
+// The decision of one Levenberg-Marquardt trial and everything that hangs on it (levenberg.cpp:99-164,
+// sparse_optimizer.cpp:372-414): gain ratio, lambda update or pop(), the `while (rho < 0 && qmax < maxTrials &&
+// !terminate())` condition, the three ways an iteration can end the optimisation, and the `for (i < iterations &&
+// !terminate() && ok)` condition of the next iteration.  Thread 0 decides, all threads
+// restore the estimates after a rejected step.  Runs at the end of k_points(solve = 1) in the workgroup that finished
+// LAST (no launch of its own): what the other workgroups of this launch wrote -- the per-landmark sums, and on the restore
+// path their backups -- is read with device-scope loads.
+__device__ __forceinline__ double load_dev(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+// chi2 (and the scale terms x_j (lambda x_j + b_j)) of a trial from the per-landmark sums k_points left: value i goes to
+// virtual lane i % 128, a lane adds its values in ascending order, a tree adds the 128 lanes -- an order that depends on
+// the problem only, not on how the landmark kernels were launched (both landmark-kernel layouts and every batch size give
+// the same bits).  Called by all threads of a workgroup of >= 128 threads.
+__device__ __forceinline__ void canonical_sums(const LbaWin &W, bool with_scale, double &chi_out, double &scale_out)
+{
+    __shared__ double s_red[2][128];
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        double c = 0, s2 = 0;
+        for (int i = tid; i < W.nl; i += 128) {
+            c += load_dev(W.part + i);
+            if (with_scale) s2 += load_dev(W.part + W.nl + i);
+        }
+        if (with_scale)
+            for (int i = tid; i < 6 * W.np; i += 128) s2 += W.tmp[i];
+        s_red[0][tid] = c;
+        s_red[1][tid] = s2;
+    }
+    __syncthreads();
+    for (int h = 64; h > 0; h >>= 1) {
+        if (tid < h) {
+            s_red[0][tid] += s_red[0][tid + h];
+            s_red[1][tid] += s_red[1][tid + h];
+        }
+        __syncthreads();
+    }
+    chi_out = s_red[0][0];
+    scale_out = s_red[1][0];
+}
+template <int NT>
+__device__ __forceinline__ void lm_decide(const LbaWin &W)
+{
+    __shared__ int s_restore;
+    LmState *st = W.st;
+    double tempChi, scale;
+    canonical_sums(W, true, tempChi, scale);
+    if (threadIdx.x == 0) {
+        const int pass = st->phase == 0 ? 0 : 1;
+        const bool ok2 = W.np == 0 || W.scal[3] != 0.0;
+        if (!ok2) {
+            tempChi = 1.7976931348623157e308;
+            st->solver_failed++;
+        }
+        double rho = st->currentChi - tempChi;
+        scale += 1e-3;
+        rho /= scale;
+        if (!ok2) rho = -1.0;   // (currentChi - DBL_MAX) / scale: negative for the positive scale of an LM step
+        const bool accepted = rho > 0 && isfinite(tempChi);
+        if (st->ntr < 48) {
+            st->tr_rho[st->ntr] = rho; st->tr_temp[st->ntr] = tempChi; st->tr_cur[st->ntr] = st->currentChi;
+            st->tr_lambda[st->ntr] = st->lambda;
+            st->ntr++;
+        }
+        if (accepted) {
+            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
+            st->lambda *= scaleFactor;
+            st->ni = 2;
+            st->currentChi = tempChi;
+        } else {
+            st->lambda *= st->ni;
+            st->ni *= 2;
+        }
+        s_restore = accepted ? 0 : 1;
+        st->qmax++;
+        st->trials[pass]++;
+        int lin = 0;
+        const bool again = rho < 0 && st->qmax < 10 && !lm_poll(st, W.abort_word);
+        if (!again) {
+            bool term = st->qmax == 10 || rho == 0;
+            if (!term) {
+                if ((st->iniChi - st->currentChi) * 1e3 < st->iniChi)
+                    st->nBad++;
+                else
+                    st->nBad = 0;
+                term = st->nBad >= 3;
+            }
+            st->it++;
+            bool more = st->it < st->iters_max[pass];
+            if (more) more = !lm_poll(st, W.abort_word);   // evaluated before `ok`
+            if (more) more = !term;
+            if (more) {
+                st->qmax = 0;
+                st->iniChi = st->currentChi;
+                lin = accepted ? 1 : 0;   // (a step that was neither accepted nor repeated leaves the system as it is)
+            } else {
+                st->run = 0;
+                st->iters_done[pass] = st->it;
+                st->final_chi2 = st->currentChi;
+                st->final_lambda = st->lambda;
+                st->phase = pass == 0 ? 1 : 3;
+            }
+        }
+        st->lin = lin;
+    }
+    __syncthreads();
+    // pop() after a rejected step (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610).  The backup holds the
+    // estimates a trial starts from: the kernels that move an estimate (the pose update of the reduced-system kernel, the
+    // landmark update of k_points) save the old value first -- push() costs no pass of its own.
+    if (s_restore)
+        for (int i = threadIdx.x; i < W.est_n; i += NT) W.pose[i] = load_dev(W.bk + i);
+}
+
+// end of a k_points launch (solve = 1): the workgroup that finishes last takes the LM decision
+template <int NT>
+__device__ __forceinline__ void points_tail(const LbaWin &W)
+{
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&W.st->blocks_done, 1) == W.n_part - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) W.st->blocks_done = 0;
+    lm_decide<NT>(W);
+}
+
+// Landmark kernels: a 256-thread workgroup takes kLmBlock landmarks, kLmSlots threads each -- thread (landmark, slot j)
+// works on the landmark's edges j, j + kLmSlots, ... (one edge for the usual <= 8 observations) and the landmark's first
+// thread adds the per-edge terms in edge order, so the sums are the ones a thread walking the edges one after the other
+// would form (the order g2o adds them in), while the chain of dependent gathers per thread is one edge long instead of
+// the whole observation list (a single window has only ~2000 landmarks: the walk was pure latency).
+constexpr int kLmBlock = 32, kLmSlots = 8;
+
+// solve = 1 (a Levenberg-Marquardt trial): the landmark's part of
 // BlockSolver::solve -- xl = (Hll + lambda I)^-1 (bl - B^T xp), block_solver.hpp:455-480 -- and of
 // SparseOptimizer::update (X += xl), its scale terms x_j (lambda x_j + b_j), then computeActiveErrors +
 // activeRobustChi2 (sparse_optimizer.cpp:61-114) of the landmark's edges at the new estimates (the poses were
-// updated by the kernel before).  solve = 0 (top of solve() in iteration 0): the residuals only.
-// Workgroup g leaves its chi2 terms in part[g] and its scale terms in part[n_part + g]; workgroup 0 adds the scale
-// terms of the poses (tmp[0 .. 6 np)).
-__global__ __launch_bounds__(128) void k_points(const LbaWin *__restrict__ wins, int solve)
+// updated by the kernel before), and -- in the workgroup that finishes last -- the LM decision (lm_decide).
+// solve = 0 (top of solve() in iteration 0): the residuals only.
+// Landmark l leaves its chi2 terms in part[l] and its scale terms in part[nl + l] (canonical_sums adds them).
+__global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins, int solve)
+{
+    __shared__ double s_v[kLmBlock][kLmSlots][3];
+    __shared__ double s_X[kLmBlock][3];
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(solve ? W.st->run : W.st->initp) || (int)blockIdx.x >= W.n_part) return;
+    const int tid = threadIdx.x, ll = tid / kLmSlots, j = tid % kLmSlots;
+    const int l = blockIdx.x * kLmBlock + ll;
+    const bool has = l < W.nl, leader = j == 0;
+    const int n6 = 6 * W.np;
+    double sc = 0, chi = 0;
+    double *X = has ? W.point + 3 * (size_t)W.hpoint[l] : nullptr;
+    double Xv[3] = {0, 0, 0};
+    if (has)
+        for (int r = 0; r < 3; ++r) Xv[r] = X[r];
+    if (solve) {
+        const double lambda = W.st->lambda;
+        const int a0 = has ? W.pl_off[l] : 0, a1 = has ? W.pl_off[l + 1] : 0;
+        double cl[3] = {0, 0, 0};
+        if (has && leader)
+            for (int r = 0; r < 3; ++r) cl[r] = W.b[n6 + 3 * l + r];
+        for (int rd = 0; __syncthreads_or(a0 + kLmSlots * rd < a1); ++rd) {
+            const int a = a0 + kLmSlots * rd + j;
+            double v[3] = {0, 0, 0};
+            if (a < a1) {   // B_i^T (-x_p) of one free-keyframe edge
+                const int ka = W.pl_k[a];
+                const int i1 = W.k_ph[ka];
+                const double *Bi = W.Hpl + 18 * (size_t)ka;
+                double xp[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) v[c] += Bi[r * 3 + c] * xp[r];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_v[ll][j][c] = v[c];
+            __syncthreads();
+            if (leader) {
+                const int m = min(kLmSlots, a1 - (a0 + kLmSlots * rd));
+                for (int jj = 0; jj < m; ++jj)
+                    for (int c = 0; c < 3; ++c) cl[c] += s_v[ll][jj][c];
+            }
+        }
+        if (has && leader) {
+            // (Hll + lambda I)^-1: the same operations as in the Schur kernel, so the same bits
+            double Dm[9], Dinv[9];
+            for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
+            Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+            mat3_inverse(Dm, Dinv);
+            double *Xb = W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.hpoint[l];
+            for (int r = 0; r < 3; ++r) {
+                const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
+                W.x[n6 + 3 * l + r] = xl;
+                Xb[r] = Xv[r];   // push()
+                Xv[r] += xl;
+                X[r] = Xv[r];
+                s_X[ll][r] = Xv[r];
+                sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
+            }
+        }
+        __syncthreads();
+        if (has)
+            for (int r = 0; r < 3; ++r) Xv[r] = s_X[ll][r];
+    }
+    {
+        const int e0 = has ? W.pt_off[l] : 0, e1 = has ? W.pt_off[l + 1] : 0;
+        for (int rd = 0; __syncthreads_or(e0 + kLmSlots * rd < e1); ++rd) {
+            const int a = e0 + kLmSlots * rd + j;
+            double c = 0;
+            if (a < e1) {
+                const int e = W.pt_k[a];
+                if (!W.e_level1[e]) {   // an inactive edge keeps its _error (and adds nothing: chi2 >= 0, so + 0.0 is exact)
+                    double p[3], er[3];
+                    se3_map(W.pose + 7 * (size_t)W.e_pose[e], Xv, p);
+                    const int stereo = W.e_stereo[e];
+                    edge_error(W.cam, p, W.e_obs + 3 * (size_t)e, stereo, er);
+                    double *dst = W.err + 3 * (size_t)e;
+                    dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+                    c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
+                    if (W.e_robust[e]) {
+                        double rho[2];
+                        robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+                        c = rho[0];
+                    }
+                }
+            }
+            s_v[ll][j][0] = c;
+            __syncthreads();
+            if (leader) {
+                const int m = min(kLmSlots, e1 - (e0 + kLmSlots * rd));
+                for (int jj = 0; jj < m; ++jj) chi += s_v[ll][jj][0];
+            }
+        }
+    }
+    if (has && leader) {
+        W.part[l] = chi;
+        W.part[W.nl + l] = sc;
+    }
+    if (solve) points_tail<256>(W);
+}
+
+// The same work with one thread per landmark walking its edges (128-thread workgroups): the layout for many windows per
+// launch, where the landmarks alone fill the device and idle slots, barriers and LDS round trips only cost (32 windows of
+// 24 k edges: 4.4 ms against 6.4 ms).  Per landmark the operations and their order are those of k_points, so both layouts
+// leave the same bits.
+__global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, int solve)
 {
     const LbaWin &W = wins[blockIdx.y];
     if (!(solve ? W.st->run : W.st->initp) || (int)blockIdx.x >= W.n_part) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int n6 = 6 * W.np;
-    double sc = 0, chi = 0;
-    if (solve && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < n6; i += 128) sc += W.tmp[i];
     if (l < W.nl) {
+        double sc = 0, chi = 0;
         double *X = W.point + 3 * (size_t)W.hpoint[l];
         double Xv[3] = {X[0], X[1], X[2]};
         if (solve) {
@@ -224,10 +475,15 @@ __global__ __launch_bounds__(128) void k_points(const LbaWin *__restrict__ wins,
                 const int ka = W.pl_k[a];
                 const int i1 = W.k_ph[ka];
                 const double *Bi = W.Hpl + 18 * (size_t)ka;
+                double xp[6], v[3] = {0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
+#pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    for (int r = 0; r < 6; ++r) cl[c] += Bi[r * 3 + c] * (-W.x[6 * i1 + r]);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) v[c] += Bi[r * 3 + c] * xp[r];
+                for (int c = 0; c < 3; ++c) cl[c] += v[c];
             }
-            // (Hll + lambda I)^-1: the same operations as in the Schur kernel, so the same bits
             double Dm[9], Dinv[9];
             for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
             Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
@@ -259,8 +515,10 @@ __global__ __launch_bounds__(128) void k_points(const LbaWin *__restrict__ wins,
             }
             chi += c;
         }
+        W.part[l] = chi;
+        W.part[W.nl + l] = sc;
     }
-    workgroup_sum2<128>(chi, sc, W.part, W.part + W.n_part);
+    if (solve) points_tail<128>(W);
 }
 
 // J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6
@@ -313,14 +571,102 @@ __device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo,
     }
 }
 
-// buildSystem, the landmarks' side (block_solver.hpp:502-560): one thread per landmark walks its edges in insertion
-// order like g2o: linearizeOplus, Hll += Ji^T Omega Ji, b_l += Ji^T omr, and the edge's Hpl block Jj^T Omega Ji.
+// buildSystem, the landmarks' side (block_solver.hpp:502-560), kLmBlock landmarks per workgroup (see k_points): thread
+// (landmark, slot) linearises one edge at a time -- linearizeOplus, Ji^T Omega Ji, Ji^T omr, and the edge's Hpl block
+// Jj^T Omega Ji -- and the landmark's first thread adds the terms in insertion order like g2o: Hll, b_l.
 // A masked edge adds nothing (its Hpl block was zeroed when it was masked).
-__global__ __launch_bounds__(128) void k_lin_points(const LbaWin *__restrict__ wins, int init)
+__device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
 {
-    const LbaWin &W = wins[blockIdx.y];
-    if (!(init ? W.st->initp : W.st->lin)) return;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_c[kLmBlock][kLmSlots][12 + 1];
+    const int tid = threadIdx.x, ll = tid / kLmSlots, j = tid % kLmSlots;
+    const int l = blk * kLmBlock + ll;
+    const bool has = l < W.nl, leader = j == 0;
+    double Xv[3] = {0, 0, 0};
+    if (has) {
+        const double *X = W.point + 3 * (size_t)W.hpoint[l];
+        for (int r = 0; r < 3; ++r) Xv[r] = X[r];
+    }
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    const int a0 = has ? W.pt_off[l] : 0, a1 = has ? W.pt_off[l + 1] : 0;
+    for (int rd = 0; __syncthreads_or(a0 + kLmSlots * rd < a1); ++rd) {
+        const int a = a0 + kLmSlots * rd + j;
+        double cH[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cb[3] = {0, 0, 0};
+        const int k = a < a1 ? W.pt_k[a] : -1;
+        if (k >= 0 && !W.e_level1[k]) {
+            const double *T = W.pose + 7 * (size_t)W.e_pose[k];
+            const int stereo = W.e_stereo[k];
+            const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
+            double p[3], R[9];
+            se3_map(T, Xv, p);
+            rot_from_quat(T, R);
+            const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+            double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (!stereo) {
+                const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+                const double s = -1. / z;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double a0_ = s * tmp[r * 3], a1_ = s * tmp[r * 3 + 1], a2_ = s * tmp[r * 3 + 2];
+                        Ja[r * 3 + c] = a0_ * R[c] + a1_ * R[3 + c] + a2_ * R[6 + c];
+                    }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+                    Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+                    Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
+                }
+            }
+            double omr[3], wo;
+            edge_weights(W, k, stereo, omr, wo);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                cb[r] = Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cH[r * 3 + c] = Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
+            }
+            if (W.k_ph[k] >= 0) {
+                double Jb[18];
+                jac_pose(W.cam, p, stereo, Jb);
+                double *h = W.Hpl + 18 * (size_t)k;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
+                        t += Jb[6 + r] * wo * Ja[3 + c];
+                        if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
+                        h[r * 3 + c] = t;
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_c[ll][j][i] = cH[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s_c[ll][j][9 + i] = cb[i];
+        __syncthreads();
+        if (leader) {
+            const int m = min(kLmSlots, a1 - (a0 + kLmSlots * rd));
+            for (int jj = 0; jj < m; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) H[i] += s_c[ll][jj][i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bl[i] += s_c[ll][jj][9 + i];
+            }
+        }
+    }
+    if (has && leader) {
+        for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
+        for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
+    }
+}
+
+// the same with one thread per landmark walking its edges (see k_points_walk); the per-edge terms are formed and added in
+// the same order, so Hll, b_l and Hpl carry the same bits
+__device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
+{
     if (l >= W.nl) return;
     const double *X = W.point + 3 * (size_t)W.hpoint[l];
     const double Xv[3] = {X[0], X[1], X[2]};
@@ -429,12 +775,9 @@ __device__ __forceinline__ double workgroup_sum_k256(double (&acc)[K], double *r
 // thread j takes the pose's edges j, j + 256, ... (the Jacobian is recomputed from the estimates: no per-edge arrays;
 // few edges per thread keep the chain of dependent gathers short), then workgroup_sum_k256 (fixed order).
 // (The former 256 x 43 tree in LDS held 88 KB per pose -- one workgroup per compute unit.)
-__global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wins, int init)
+__device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
 {
     __shared__ double red[16 * 43];
-    const LbaWin &W = wins[blockIdx.y];
-    if (!(init ? W.st->initp : W.st->lin)) return;
-    const int ph = blockIdx.x;
     if (ph >= W.np) return;
     double T[7];
     {
@@ -467,6 +810,21 @@ __global__ __launch_bounds__(256) void k_lin_poses(const LbaWin *__restrict__ wi
         W.b[6 * (size_t)ph + (threadIdx.x - 36)] = sum;
 }
 
+// buildSystem as ONE launch: workgroups [0, np_blocks) take one free keyframe each, the others kLmBlock landmarks each (the two
+// sides are independent of each other: the landmark side no longer waits behind the keyframe side's launch).
+template <bool kWalk>
+__global__ __launch_bounds__(256) void k_lin(const LbaWin *__restrict__ wins, int init, int np_blocks)
+{
+    const LbaWin &W = wins[blockIdx.y];
+    if (!(init ? W.st->initp : W.st->lin)) return;
+    if ((int)blockIdx.x < np_blocks)
+        lin_poses_body(W, blockIdx.x);
+    else if (kWalk)
+        lin_points_walk(W, ((int)blockIdx.x - np_blocks) * 256 + threadIdx.x);
+    else
+        lin_points_body(W, (int)blockIdx.x - np_blocks);
+}
+
 // top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
 // (computeLambdaInit :166-180), ni = 2; the first trial's push() (the backup of the estimates)
 __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ wins)
@@ -494,9 +852,9 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
         __syncthreads();
     }
     for (int i = threadIdx.x; i < W.est_n; i += 1024) W.bk[i] = W.pose[i];
+    double chi, unused;
+    canonical_sums(W, false, chi, unused);
     if (threadIdx.x == 0) {
-        double chi = 0;
-        for (int g = 0; g < W.n_part; ++g) chi += W.part[g];
         st->currentChi = st->iniChi = chi;
         st->lambda = 1e-5 * sh[0];
         st->ni = 2;
@@ -1202,88 +1560,6 @@ __global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ 
     se3_oplus(upd, Tp);
 }
 
-// The decision of one Levenberg-Marquardt trial and everything that hangs on it (levenberg.cpp:99-164,
-// sparse_optimizer.cpp:372-414): gain ratio, lambda update or pop(), the `while (rho < 0 && qmax < maxTrials &&
-// !terminate())` condition, the three ways an iteration can end the optimisation, and the `for (i < iterations &&
-// !terminate() && ok)` condition of the next iteration.  One workgroup per window; thread 0 decides, all threads
-// restore the estimates after a rejected step (or back up the accepted ones for the next trial).
-__global__ __launch_bounds__(1024) void k_decide(const LbaWin *__restrict__ wins)
-{
-    __shared__ int s_restore;
-    const LbaWin &W = wins[blockIdx.x];
-    LmState *st = W.st;
-    if (!st->run) return;
-    if (threadIdx.x == 0) {
-        const int pass = st->phase == 0 ? 0 : 1;
-        double tempChi = 0, scale = 0;
-        for (int g = 0; g < W.n_part; ++g) tempChi += W.part[g];
-        for (int g = 0; g < W.n_part; ++g) scale += W.part[W.n_part + g];
-        const bool ok2 = W.np == 0 || W.scal[3] != 0.0;
-        if (!ok2) {
-            tempChi = 1.7976931348623157e308;
-            st->solver_failed++;
-        }
-        double rho = st->currentChi - tempChi;
-        scale += 1e-3;
-        rho /= scale;
-        if (!ok2) rho = -1.0;   // (currentChi - DBL_MAX) / scale: negative for the positive scale of an LM step
-        const bool accepted = rho > 0 && isfinite(tempChi);
-        if (st->ntr < 48) {
-            st->tr_rho[st->ntr] = rho; st->tr_temp[st->ntr] = tempChi; st->tr_cur[st->ntr] = st->currentChi;
-            st->tr_lambda[st->ntr] = st->lambda;
-            st->ntr++;
-        }
-        if (accepted) {
-            double alpha = 1. - pow((2 * rho - 1), 3.0);
-            alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
-            const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
-            st->lambda *= scaleFactor;
-            st->ni = 2;
-            st->currentChi = tempChi;
-        } else {
-            st->lambda *= st->ni;
-            st->ni *= 2;
-        }
-        s_restore = accepted ? 0 : 1;
-        st->qmax++;
-        st->trials[pass]++;
-        int lin = 0;
-        const bool again = rho < 0 && st->qmax < 10 && !lm_poll(st, W.abort_word);
-        if (!again) {
-            bool term = st->qmax == 10 || rho == 0;
-            if (!term) {
-                if ((st->iniChi - st->currentChi) * 1e3 < st->iniChi)
-                    st->nBad++;
-                else
-                    st->nBad = 0;
-                term = st->nBad >= 3;
-            }
-            st->it++;
-            bool more = st->it < st->iters_max[pass];
-            if (more) more = !lm_poll(st, W.abort_word);   // evaluated before `ok`
-            if (more) more = !term;
-            if (more) {
-                st->qmax = 0;
-                st->iniChi = st->currentChi;
-                lin = accepted ? 1 : 0;   // (a step that was neither accepted nor repeated leaves the system as it is)
-            } else {
-                st->run = 0;
-                st->iters_done[pass] = st->it;
-                st->final_chi2 = st->currentChi;
-                st->final_lambda = st->lambda;
-                st->phase = pass == 0 ? 1 : 3;
-            }
-        }
-        st->lin = lin;
-    }
-    __syncthreads();
-    // pop() after a rejected step (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610).  The backup holds the
-    // estimates a trial starts from: the kernels that move an estimate (the pose update of the reduced-system kernel, the
-    // landmark update of k_points) save the old value first -- push() costs no pass of its own.
-    if (s_restore)
-        for (int i = threadIdx.x; i < W.est_n; i += 1024) W.pose[i] = W.bk[i];
-}
-
 // Between the two optimisations (Optimizer.cc:663-710).  (a): bDoMore = !*pbStopFlag
 __global__ void k_trans_a(const LbaWin *__restrict__ wins)
 {
@@ -1650,6 +1926,14 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     if (nw == 0) return AOS2_OK;
     int st = lba_handle_init(s);
     if (st) return st;
+    // layout of the landmark kernels: kLmSlots threads per landmark while the landmarks of the call cannot fill the device
+    // (one or a few windows: latency), one thread per landmark beyond (throughput); same results either way.
+    // AOS2_LBA_LAYOUT=slots|walk forces one (tests).
+    size_t total_points = 0;
+    for (int i = 0; i < nw; ++i) total_points += (size_t)problems[act[i]].n_points;
+    bool walk = total_points > 16000;
+    if (const char *e = getenv("AOS2_LBA_LAYOUT")) walk = !strcmp(e, "walk");
+    const int lm_per_block = walk ? 128 : kLmBlock;
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1723,8 +2007,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.Hs = B.take(8 * n6 * n6 + 8); l.bs = B.take(8 * n6 + 8);
         l.tmp = B.take(8 * n6 + 8);
-        l.n_part = std::max(1, (int)((S.nl + 127) / 128));
-        l.scal = B.take(64); l.part = B.take(16 * (size_t)l.n_part + 8);
+        l.n_part = std::max(1, (int)((S.nl + lm_per_block - 1) / lm_per_block));
+        l.scal = B.take(64); l.part = B.take(16 * (size_t)std::max(S.nl, 1) + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
         const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + 4 * (size_t)l.npad + 2 * 16 * 17 + 16) * 8;
         l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
@@ -1842,16 +2126,24 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
     const dim3 g_edges256(blocks(mx_E, 256), nw), g_points(mx_part, nw);
+    auto enqueue_points = [&](int solve) {
+        if (walk)
+            hipLaunchKernelGGL(k_points_walk, g_points, dim3(128), 0, q, dw, solve);
+        else
+            hipLaunchKernelGGL(k_points, g_points, dim3(256), 0, q, dw, solve);
+    };
     auto enqueue_lin = [&](int init) {
-        hipLaunchKernelGGL(k_lin_points, dim3(blocks(mx_nl, 128), nw), dim3(128), 0, q, dw, init);
-        if (mx_np) hipLaunchKernelGGL(k_lin_poses, dim3(mx_np, nw), dim3(256), 0, q, dw, init);
+        if (walk)
+            hipLaunchKernelGGL(k_lin<true>, dim3(mx_np + blocks(mx_nl, 256), nw), dim3(256), 0, q, dw, init, mx_np);
+        else
+            hipLaunchKernelGGL(k_lin<false>, dim3(mx_np + blocks(mx_nl, kLmBlock), nw), dim3(256), 0, q, dw, init, mx_np);
     };
     auto enqueue_init = [&]() {
-        hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 0);
+        enqueue_points(0);
         enqueue_lin(1);
         hipLaunchKernelGGL(k_lm_init, dim3(nw), dim3(1024), 0, q, dw);
     };
-    // one Levenberg-Marquardt trial: 6 launches (7 with a reduced system beyond LDS)
+    // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
         if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(kSchurThreads), 0, q, dw);
         if (any_lds) {
@@ -1862,8 +2154,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(nw), dim3(1024), (size_t)mx_npad_glob * sizeof(double), q, dw);
             hipLaunchKernelGGL(k_update_poses, dim3(blocks(mx_np, 64), nw), dim3(64), 0, q, dw);
         }
-        hipLaunchKernelGGL(k_points, g_points, dim3(128), 0, q, dw, 1);
-        hipLaunchKernelGGL(k_decide, dim3(nw), dim3(1024), 0, q, dw);
+        enqueue_points(1);   // + the LM decision in its last workgroup
         enqueue_lin(0);
     };
     auto enqueue_transition = [&]() {

@@ -169,6 +169,26 @@ def test_lba_batch_equals_single_windows(pkg, oracle, gpu):
         assert (got["edge_outlier"] == want["edge_outlier"]).all()
 
 
+def test_lba_landmark_kernel_layouts_agree(pkg, oracle, gpu, monkeypatch):
+    """The landmark kernels have two layouts (8 threads per landmark for a few windows, one thread per landmark for many):
+    both give the same bits, for landmarks with 2 .. 30 observations (several rounds of 8) and with rejected trials."""
+    probs = [pkg.synth.synth_lba_problem(seed=51, n_local=30, n_fixed=4, n_points=120, obs_per_point=20),
+             pkg.synth.synth_lba_problem(seed=0), _hard_problem(pkg, 42, 0.5, 3, 2)]
+    assert np.bincount(probs[0]["edge_point"]).max() > 8
+    res = {}
+    for layout in ("slots", "walk"):
+        monkeypatch.setenv("AOS2_LBA_LAYOUT", layout)
+        res[layout] = [pkg.LocalBA().LocalBundleAdjustment(p) for p in probs] + pkg.LocalBA().LocalBundleAdjustmentBatch(probs)
+    monkeypatch.delenv("AOS2_LBA_LAYOUT")
+    for a, b in zip(res["slots"], res["walk"]):
+        assert a["status"] == 0 and _same(a, b)
+    for p, got in zip(probs, res["slots"]):
+        want = oracle.lba_solve(p)
+        assert got["iters"] == want["iters"]
+        assert close(got["pose_Tcw"], want["pose_Tcw"]) and close(got["point_xyz"], want["point_xyz"])
+        assert (got["edge_outlier"] == want["edge_outlier"]).all()
+
+
 def test_lba_many_free_keyframes(pkg, oracle, gpu):
     """More than 42 free keyframes (reduced camera system > 256 rows): EuRoC / KITTI windows reach this size; the
     factorisation then runs out of device memory instead of LDS."""
