@@ -103,11 +103,13 @@ struct LbaWin {
 };
 
 // bool SparseOptimizer::terminate(): counts the evaluation, latches the flag
-__device__ inline bool lm_poll(LmState *st, const int32_t *abort_word)
+// `seen` >= 0: the value of the flag read by the caller shortly before (the word lives in host memory: a read is a PCIe
+// round trip, which the decision starts ahead of its other loads)
+__device__ inline bool lm_poll(LmState *st, const int32_t *abort_word, int seen = -1)
 {
     st->polls++;
     if (st->stop_poll > 0) return true;
-    const int a = abort_word ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+    const int a = seen >= 0 ? seen : abort_word ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
     if (a || (st->stop_at_poll > 0 && st->polls >= st->stop_at_poll)) {
         st->stop_poll = st->polls;
         return true;
@@ -225,9 +227,19 @@ __device__ __forceinline__ void canonical_sums(const LbaWin &W, bool with_scale,
     const int tid = threadIdx.x;
     if (tid < 128) {
         double c = 0, s2 = 0;
-        for (int i = tid; i < W.nl; i += 128) {
-            c += load_dev(W.part + i);
-            if (with_scale) s2 += load_dev(W.part + W.nl + i);
+        for (int i0 = tid; i0 < W.nl; i0 += 128 * 8) {   // 8 values of the lane in flight, added in ascending order
+            double v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 128 * u;
+                v[u] = i < W.nl ? load_dev(W.part + i) : 0.0;
+                w[u] = with_scale && i < W.nl ? load_dev(W.part + W.nl + i) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c += v[u];     // (x + 0.0 == x past the end)
+                s2 += w[u];
+            }
         }
         if (with_scale)
             for (int i = tid; i < 6 * W.np; i += 128) s2 += W.tmp[i];
@@ -250,6 +262,8 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
 {
     __shared__ int s_restore;
     LmState *st = W.st;
+    // pbStopFlag lives in host memory: its read (a PCIe round trip) travels together with the loads of the sums
+    const int flag_seen = threadIdx.x == 0 && W.abort_word ? __hip_atomic_load(W.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
     double tempChi, scale;
     canonical_sums(W, true, tempChi, scale);
     if (threadIdx.x == 0) {
@@ -270,7 +284,8 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
             st->ntr++;
         }
         if (accepted) {
-            double alpha = 1. - pow((2 * rho - 1), 3.0);
+            const double t3 = 2 * rho - 1;
+            double alpha = 1. - t3 * t3 * t3;
             alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
             const double scaleFactor = 1. / 3. > alpha ? 1. / 3. : alpha;
             st->lambda *= scaleFactor;
@@ -284,7 +299,7 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
         st->qmax++;
         st->trials[pass]++;
         int lin = 0;
-        const bool again = rho < 0 && st->qmax < 10 && !lm_poll(st, W.abort_word);
+        const bool again = rho < 0 && st->qmax < 10 && !lm_poll(st, W.abort_word, flag_seen);
         if (!again) {
             bool term = st->qmax == 10 || rho == 0;
             if (!term) {
@@ -296,7 +311,7 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
             }
             st->it++;
             bool more = st->it < st->iters_max[pass];
-            if (more) more = !lm_poll(st, W.abort_word);   // evaluated before `ok`
+            if (more) more = !lm_poll(st, W.abort_word, flag_seen);   // evaluated before `ok`
             if (more) more = !term;
             if (more) {
                 st->qmax = 0;
