@@ -101,6 +101,7 @@ def lib():
         L.aos2_debug_octree_host.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
         L.aos2_debug_sincos_host.argtypes = [cf, C.POINTER(cf), C.POINTER(cf)]
         L.aos2_debug_sincos_device.argtypes = [vp, ci, vp, vp, ci]
+        L.aos2_debug_pose_blocks_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci]
         if hasattr(L, "aos2_matcher_create"):
             L.aos2_matcher_create.argtypes = [cf, ci, ci, C.POINTER(vp)]
             L.aos2_matcher_destroy.argtypes = [vp]
@@ -465,6 +466,17 @@ def debug_sincos_device(angles, device=0):
     c = np.zeros_like(a)
     _check(lib().aos2_debug_sincos_device(_p(a), len(a), _p(s), _p(c), device))
     return s, c
+
+
+def debug_pose_blocks_device(upd, T, Hb, lam, x0, device=0):
+    """test tap: the pose solver's exp-map update and 6x6 solve on the device, n independent cases"""
+    upd = np.ascontiguousarray(upd, np.float64); T = np.ascontiguousarray(T, np.float64)
+    Hb = np.ascontiguousarray(Hb, np.float64); lam = np.ascontiguousarray(lam, np.float64)
+    x = np.ascontiguousarray(x0, np.float64).copy()
+    n = len(lam)
+    To = np.zeros((n, 7)); ok = np.zeros(n, np.uint8)
+    _check(lib().aos2_debug_pose_blocks_device(_p(upd), _p(T), _p(To), _p(Hb), _p(lam), _p(x), _p(ok), n, device))
+    return To, x, ok
 
 
 # ------------------------------------------------------------------------------------------ matcher

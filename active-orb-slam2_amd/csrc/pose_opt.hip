@@ -755,6 +755,47 @@ int aos2_pose_optimization(aos2_lba_t *s, const aos2_pose_problem_t *problems, a
 }
 
 
+__global__ void debug_pose_blocks_kernel(const double *upd, const double *T, double *T_out, const double *Hb, const double *lambda,
+                                        double *x, uint8_t *ok, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u[6], t[7], xv[6], hb[27];
+    for (int k = 0; k < 6; ++k) u[k] = upd[6 * i + k];
+    for (int k = 0; k < 7; ++k) t[k] = T[7 * i + k];
+    se3_oplus_fast(u, t);
+    for (int k = 0; k < 7; ++k) T_out[7 * i + k] = t[k];
+    for (int k = 0; k < 27; ++k) hb[k] = Hb[27 * i + k];
+    for (int k = 0; k < 6; ++k) xv[k] = x[6 * i + k];
+    ok[i] = solve6(hb, lambda[i], xv) ? 1 : 0;
+    for (int k = 0; k < 6; ++k) x[6 * i + k] = xv[k];
+}
+
+int aos2_debug_pose_blocks_device(const double *upd, const double *T, double *T_out, const double *Hb, const double *lambda,
+                                  double *x, uint8_t *ok, int n, int device)
+{
+    int st;
+    if ((st = bind_device(device))) return st;
+    DevBuf<double> d;
+    DevBuf<uint8_t> dk;
+    const size_t N = (size_t)n;
+    if ((st = d.alloc(N * (6 + 7 + 7 + 27 + 1 + 6))) || (st = dk.alloc(N))) return st;
+    double *du = d.p, *dT = du + 6 * N, *dTo = dT + 7 * N, *dH = dTo + 7 * N, *dl = dH + 27 * N, *dx = dl + N;
+    AOS2_HIP_CHECK(hipMemcpy(du, upd, 48 * N, hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(dT, T, 56 * N, hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(dH, Hb, 216 * N, hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(dl, lambda, 8 * N, hipMemcpyHostToDevice));
+    AOS2_HIP_CHECK(hipMemcpy(dx, x, 48 * N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_pose_blocks_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, du, dT, dTo, dH, dl, dx, dk.p, n);
+    AOS2_HIP_CHECK(hipDeviceSynchronize());
+    AOS2_HIP_CHECK(hipMemcpy(T_out, dTo, 56 * N, hipMemcpyDeviceToHost));
+    AOS2_HIP_CHECK(hipMemcpy(x, dx, 48 * N, hipMemcpyDeviceToHost));
+    AOS2_HIP_CHECK(hipMemcpy(ok, dk.p, N, hipMemcpyDeviceToHost));
+    d.release();
+    dk.release();
+    return AOS2_OK;
+}
+
 float aos2_pose_optimization_last_device_ms(const aos2_lba_t *s) { return s ? s->last_pose_ms : 0.f; }
 
 }  // extern "C"

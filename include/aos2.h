@@ -700,6 +700,12 @@ int aos2_debug_octree_host(const int16_t *xs, const int16_t *ys, const uint8_t *
 /* rBRIEF steering sin/cos (csrc/sincos_exact.h) evaluated on the host / on the device */
 void aos2_debug_sincos_host(float angle_rad, float *s, float *c);
 int aos2_debug_sincos_device(const float *angles, int n, float *s, float *c, int device);
+/* building blocks of the pose solver (csrc/pose_opt.hip) on the device, n independent cases:
+ * T_out[i] = exp(upd[i]) * T[i]  (upd: 6 doubles omega | upsilon, T: 7 doubles qx qy qz qw tx ty tz), and
+ * x[i] = (H[i] + lambda[i] I)^-1 b[i] with Hb[i] = 21 doubles (upper triangle of H, row by row) + 6 doubles b;
+ * ok[i] = 0 where a pivot was not positive (x[i] is left as passed in) */
+int aos2_debug_pose_blocks_device(const double *upd, const double *T, double *T_out, const double *Hb, const double *lambda,
+                                  double *x, uint8_t *ok, int n, int device);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,45 @@ def test_pose_optimization_three_to_seven_correspondences(pkg, oracle, gpu):
             assert close(got["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16)), (n, seed)
 
 
+def test_pose_solver_building_blocks(pkg, oracle, gpu):
+    """pose_opt.hip's serial path uses its own exp-map update (polynomial small-angle form, a general form beyond
+    |omega|^2 = 0.6, the reference's first-order form below 1e-5 rad) and a square-root-free 6x6 solve: every branch against
+    the oracle's se3quat restatement / numpy, to 1e-12 (they differ by rounding only)."""
+    rng = np.random.default_rng(7)
+    n = 4000
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = np.concatenate([10.0 ** rng.uniform(-9, -5.3, n // 4), 10.0 ** rng.uniform(-5, -1, n // 4), rng.uniform(0.05, 0.77, n // 4),
+                          rng.uniform(0.78, 3.1, n - 3 * (n // 4))])   # tiny / small / moderate / general (all three trace branches)
+    upd = np.concatenate([ax * ang[:, None], rng.normal(0, 0.5, (n, 3))], 1)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q[q[:, 3] < 0] *= -1
+    T = np.concatenate([q, rng.normal(0, 3.0, (n, 3))], 1)
+    # SPD systems with a wide range of conditioning, plus a few indefinite ones
+    Hb = np.zeros((n, 27)); lam = 10.0 ** rng.uniform(-8, 2, n); xs_want = np.zeros((n, 6)); ok_want = np.ones(n, np.uint8)
+    iu = np.triu_indices(6)
+    for i in range(n):
+        A = rng.normal(size=(6, 6)) * 10.0 ** rng.uniform(-2, 3, 6)[None, :]
+        H = A.T @ A
+        if i % 97 == 0:
+            H -= 2 * (np.trace(H) + lam[i]) * np.eye(6)   # not positive definite
+            ok_want[i] = 0
+        b = rng.normal(size=6) * np.sqrt(np.diag(np.abs(H)) + 1e-3)
+        Hb[i, :21] = H[iu]; Hb[i, 21:] = b
+        if ok_want[i]:
+            xs_want[i] = np.linalg.solve(H + lam[i] * np.eye(6), b)
+    x0 = np.full((n, 6), 7.25)
+    To, xs, ok = pkg.capi.debug_pose_blocks_device(upd, T, Hb, lam, x0)
+    assert (ok == ok_want).all()
+    assert (xs[ok_want == 0] == 7.25).all()   # a failed solve leaves the solver's x alone
+    good = ok_want == 1
+    for i in np.nonzero(good)[0]:
+        H = np.zeros((6, 6)); H[iu] = Hb[i, :21]; H = H + H.T - np.diag(np.diag(H)); H += lam[i] * np.eye(6)
+        tol = 1e-13 * np.linalg.cond(H) * (np.abs(xs_want[i]).max() + 1e-300)
+        assert np.abs(xs[i] - xs_want[i]).max() <= tol + 1e-300, (i, xs[i], xs_want[i])
+    for i in range(n):
+        want = oracle.se3_mul(oracle.se3_exp(upd[i]), T[i])
+        assert np.abs(To[i] - want).max() < 1e-12 * (1 + np.abs(want).max()), (i, ang[i], To[i], want)
+
+
 def test_pose_optimization_batch_and_golden(pkg, oracle, gpu):
     probs = [pkg.synth.synth_pose_problem(100 + i, n=600 + 37 * i) for i in range(24)]
     ba = pkg.LocalBA()
