@@ -2237,6 +2237,48 @@ static int check_frame(const aos2_frame_view_t *f)
         set_error("n_f %d exceeds the LDS state table (60000)", f->n_f);
         return AOS2_ERR_ARG;
     }
+    // the arrays that become device-side indices: mGrid as CSR (monotone offsets, every listed feature exists) and the
+    // pyramid levels (they index scale_factors[] / level_sigma2[])
+    constexpr int NC = GRID_COLS * GRID_ROWS;
+    if (f->grid_off[0] != 0) {
+        set_error("bad frame view: grid_off[0] = %d", f->grid_off[0]);
+        return AOS2_ERR_ARG;
+    }
+    for (int c = 0; c < NC; ++c)
+        if (f->grid_off[c + 1] < f->grid_off[c]) {
+            set_error("bad frame view: grid_off decreases at cell %d", c);
+            return AOS2_ERR_ARG;
+        }
+    const int listed = f->grid_off[NC];
+    if (listed > f->n_f || (listed > 0 && !f->grid_idx)) {
+        set_error("bad frame view: the grid lists %d features of %d%s", listed, f->n_f, f->grid_idx ? "" : " (grid_idx is NULL)");
+        return AOS2_ERR_ARG;
+    }
+    for (int i = 0; i < listed; ++i)
+        if ((unsigned)f->grid_idx[i] >= (unsigned)f->n_f) {
+            set_error("bad frame view: grid_idx[%d] = %d is not a feature", i, f->grid_idx[i]);
+            return AOS2_ERR_ARG;
+        }
+    for (int i = 0; i < f->n_f; ++i)
+        if ((unsigned)f->kp_octave[i] >= (unsigned)f->n_levels) {
+            set_error("bad frame view: kp_octave[%d] = %d outside the %d pyramid levels", i, f->kp_octave[i], f->n_levels);
+            return AOS2_ERR_ARG;
+        }
+    return AOS2_OK;
+}
+
+// levels handed in per query (mnTrackScaleLevel, LastFrame octaves, keyframe octaves): they index the frame's scale tables
+static int check_levels(const int32_t *lv, int n, int n_levels, const char *what)
+{
+    if (n > 0 && !lv) {
+        set_error("%s is NULL", what);
+        return AOS2_ERR_ARG;
+    }
+    for (int i = 0; i < n; ++i)
+        if ((unsigned)lv[i] >= (unsigned)n_levels) {
+            set_error("%s[%d] = %d outside the %d pyramid levels", what, i, lv[i], n_levels);
+            return AOS2_ERR_ARG;
+        }
     return AOS2_OK;
 }
 
@@ -2643,6 +2685,11 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     }
     int st = check_frame(f);
     if (st) return st;
+    if (p->n_mp > 0 && (!p->track_in_view || !p->desc || !p->has_obs || !p->view_cos || !p->proj_x || !p->proj_y || !p->proj_xr)) {
+        set_error("bad map point set (NULL array)");
+        return AOS2_ERR_ARG;
+    }
+    if ((st = check_levels(p->pred_level, p->n_mp, f->n_levels, "pred_level"))) return st;
     if ((st = matcher_init(m))) return st;
     Arena A{m};
     size_t fo[12];
@@ -2701,10 +2748,13 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     int max_mp = 0, max_nf = 0;
     for (int i = 0; i < n_problems; ++i) {
         if ((st = check_frame(&frames[i]))) return st;
-        if (problems[i].n_mp < 0 || !match_f[i]) {
+        const aos2_proj_mp_t &pi = problems[i];
+        if (pi.n_mp < 0 || !match_f[i] || (pi.n_mp > 0 && (!pi.track_in_view || !pi.desc || !pi.has_obs || !pi.view_cos || !pi.proj_x ||
+                                                             !pi.proj_y || !pi.proj_xr))) {
             set_error("bad projection problem %d", i);
             return AOS2_ERR_ARG;
         }
+        if ((st = check_levels(pi.pred_level, pi.n_mp, frames[i].n_levels, "pred_level"))) return st;
         // entry budget: a search window rarely holds more than a few dozen features; 512 per map point (or the
         // whole frame if smaller) is the bound here -- AOS2_ERR_CAPACITY if a problem ever needs more
         pool_cap += (size_t)problems[i].n_mp * (size_t)std::min(frames[i].n_f, 512);
@@ -2799,6 +2849,11 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     }
     int st = check_frame(cur);
     if (st) return st;
+    if (p->n_last > 0 && (!p->last_valid || !p->world_pos || !p->desc || !p->last_angle || !p->has_obs)) {
+        set_error("bad last-frame point set (NULL array)");
+        return AOS2_ERR_ARG;
+    }
+    if ((st = check_levels(p->last_octave, p->n_last, cur->n_levels, "last_octave"))) return st;
     if ((st = matcher_init(m))) return st;
     Arena A{m};
     size_t fo[12];

@@ -98,6 +98,33 @@ def test_bad_arguments_and_missing_device(pkg):
         assert e.value.code == capi.AOS2_ERR_NO_DEVICE
 
 
+def test_matcher_rejects_inconsistent_inputs_before_any_upload(pkg):
+    """the arrays that become device-side indices (mGrid as CSR, pyramid levels) are validated on the host: a bad one is
+    AOS2_ERR_ARG with a message, on a machine without a GPU too (nothing has been uploaded yet)"""
+    capi = pkg.capi
+    f, mp = pkg.synth.synth_proj_mp_problem(3, n_f=300, n_mp=200)
+    m = pkg.Matcher()
+
+    def bad(frame, points, what):
+        with pytest.raises(capi.AosError) as e:
+            m.SearchByProjection(frame, points)
+        assert e.value.code == capi.AOS2_ERR_ARG and what in str(e.value), str(e.value)
+
+    g = dict(f); g["grid_off"] = f["grid_off"].copy(); g["grid_off"][100] = g["grid_off"][99] - 1 if g["grid_off"][99] > 0 else -1
+    bad(g, mp, "grid_off")
+    g = dict(f); g["grid_idx"] = f["grid_idx"].copy(); g["grid_idx"][0] = f["n_f"]
+    bad(g, mp, "grid_idx")
+    g = dict(f); g["kp_octave"] = f["kp_octave"].copy(); g["kp_octave"][5] = f["n_levels"]
+    bad(g, mp, "kp_octave")
+    q = dict(mp); q["pred_level"] = mp["pred_level"].copy(); q["pred_level"][7] = -1
+    bad(f, q, "pred_level")
+    cur, last = pkg.synth.synth_proj_last_problem(4, n=200)
+    l2 = dict(last); l2["last_octave"] = last["last_octave"].copy(); l2["last_octave"][3] = 99
+    with pytest.raises(capi.AosError) as e:
+        m.SearchByProjectionLast(cur, l2, 7.0, False)
+    assert e.value.code == capi.AOS2_ERR_ARG and "last_octave" in str(e.value)
+
+
 def test_descriptor_distance_host(pkg, oracle):
     rng = np.random.default_rng(0)
     for _ in range(100):
