@@ -11,7 +11,7 @@
 // The whole procedure of a window -- optimize(5), the outlier pass, optimize(10), the final inlier check -- is
 // enqueued as ONE program; the Levenberg-Marquardt control flow (rho, lambda, accept / restore, the three
 // termination rules, the iteration counters, the polls of pbStopFlag) lives in a small per-window state block on the
-// device (LmState), updated by k_decide after every trial; every other kernel is gated by that state.  The host only
+// device (LmState), updated after every trial by the landmark kernel's last workgroup (lm_decide); every kernel is gated by that state.  The host only
 // looks at the states when the program has run: a window that needed more trials than were enqueued (steps rejected
 // by the gain ratio) gets another short program.  No host round trip per trial.
 //
@@ -1806,8 +1806,8 @@ struct WinLayout {
 // ROCTx ranges around the host-side phases of a solve (AOS2_ROCTX=1; rocprofv3 --marker-trace shows them next to the
 // kernels).  The library is looked up at run time: no link dependency.  g2o's statistics buckets
 // (Thirdparty/g2o/g2o/core/batch_stats.h, filled in block_solver.hpp:441-453 and sparse_optimizer.cpp:376-414) map to
-// the kernels of the device program: timeResiduals -> k_points, timeLinearize + timeQuadraticForm -> k_lin_points /
-// k_lin_poses, timeSchurComplement -> k_schur, timeLinearSolver -> k_ldlt_lds / k_ldlt_solve, timeUpdate -> the pose
+// the kernels of the device program: timeResiduals -> k_points, timeLinearize + timeQuadraticForm -> k_lin,
+// timeSchurComplement -> k_schur, timeLinearSolver -> k_ldlt_lds / k_ldlt_solve, timeUpdate -> the pose
 // update inside the LDL^T kernel and the landmark update inside k_points.
 struct RoctxRange {
     typedef int (*push_t)(const char *);

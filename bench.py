@@ -406,7 +406,7 @@ def main():
             extra["local_ba"] = {"edges": prob["n_edges"], "keyframes": prob["n_poses"], "points": prob["n_points"],
                                  "wall_ms": lba_wall, "device_ms": r["ms_device"],
                                  "iterations": r["iters"], "trials": r["trials"],
-                                 "bound": "latency (6 dependent launches per Levenberg-Marquardt trial, the whole solve enqueued at once; half of a trial is the serial pivot chain of the reduced-system LDL^T)"}
+                                 "bound": "latency (4 dependent launches per Levenberg-Marquardt trial, the whole solve enqueued at once; half of a trial is the serial pivot chain of the reduced-system LDL^T)"}
             # independent windows (several maps / offline windows, SURVEY 8(e): LocalBA = replicas only): one handle
             # and one host thread per window; the latency-bound kernels of the windows overlap on the GPU
             import threading
