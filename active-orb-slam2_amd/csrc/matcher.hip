@@ -358,10 +358,18 @@ __device__ __forceinline__ void resolve_fixpoint_impl(int n_f, int n_q, int32_t 
                 }
                 if (covf[j]) {   // more than 8 valid candidates
                     if (covo[j] >= 0) {
-                        for (int t = 0; t < covn[j]; ++t) {
-                            const Entry e = ovf_arena[covo[j] + t];
-                            const bool free_ = Bc[e.payload & idx_mask] >= q;
-                            best2_insert(b1, b2, free_ ? ((unsigned long long)e.key << 32) | e.payload : ~0ull);
+                        for (int t0 = 0; t0 < covn[j]; t0 += 4) {   // 4 entries (and their B lookups) in flight
+                            Entry e[4];
+                            int bv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) e[u] = t0 + u < covn[j] ? ovf_arena[covo[j] + t0 + u] : Entry{KEY_NONE, 0};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) bv[u] = e[u].key != KEY_NONE ? Bc[e[u].payload & idx_mask] : -1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const bool free_ = e[u].key != KEY_NONE && bv[u] >= q;
+                                best2_insert(b1, b2, free_ ? ((unsigned long long)e[u].key << 32) | e[u].payload : ~0ull);
+                            }
                         }
                     } else {
                         b1 = b2 = ~0ull;
@@ -1548,7 +1556,7 @@ __device__ __forceinline__ void assign_grid_body(int n, const float *__restrict_
     __syncthreads();
     // exclusive scan of the NC counts: thread t owns the kPer consecutive cells [t kPer, (t + 1) kPer)
     constexpr int kPer = NC / 256;
-    static_assert(NC % 256 == 0, "grid cells per thread");
+    static_assert(NC % 256 == 0 && NC <= 4096, "grid cells per thread; 12-bit cell numbers");
     int own[kPer], tsum = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
@@ -1565,25 +1573,37 @@ __device__ __forceinline__ void assign_grid_body(int n, const float *__restrict_
     __syncthreads();   // (also: every thread has read its counts before the offsets overwrite them)
     int excl = x - tsum;
     for (int w = 0; w < wave; ++w) excl += wsum[w];
-    // cnt[c] <- offset of the cell, with bit 30 set when the cell holds one feature (its rank is 0: no search below)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const int c = tid * kPer + k;
         grid_off[c] = excl;
-        cnt[c] = excl | (own[k] == 1 ? (1 << 30) : 0);
+        cnt[c] = excl;   // from here on: the cell's fill cursor
         excl += own[k];
     }
     if (tid == 255) grid_off[NC] = excl;
     __syncthreads();
-    // stable fill: the rank of feature i inside its cell = the number of earlier features of the same cell
-    for (int i = tid; i < n; i += 256) {
-        const int c = cell[i];
-        if (c < 0) continue;
-        const int oc = cnt[c];
-        int rank = 0;
-        if (!(oc & (1 << 30)))
-            for (int j = 0; j < i; ++j) rank += cell[j] == c;
-        grid_idx[(oc & ~(1 << 30)) + rank] = i;
+    // stable fill by ONE wave, 64 features at a time in index order: the lanes that share a cell find each other with 12
+    // ballots (one per bit of the cell number), take consecutive places behind the cell's cursor in lane order, and the
+    // last of them advances the cursor (LDS operations of a wave complete in order, so the next chunk sees it).  The
+    // former per-feature count of earlier features in the same cell was O(n^2 / 256) LDS reads.
+    if (wave == 0) {
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const int c = i < n ? cell[i] : -1;
+            unsigned long long m = __ballot(c >= 0);
+#pragma unroll
+            for (int bit = 0; bit < 12; ++bit) {
+                const bool one = (c >> bit) & 1;
+                const unsigned long long bb = __ballot(one);
+                m &= one ? bb : ~bb;
+            }
+            if (c >= 0) {
+                const int below = __popcll(m & ((1ull << lane) - 1ull));
+                const int base = cnt[c];
+                grid_idx[base + below] = i;
+                if (below == __popcll(m) - 1) cnt[c] = base + below + 1;
+            }
+        }
     }
 }
 
