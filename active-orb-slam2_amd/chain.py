@@ -79,12 +79,12 @@ class TrackingChain:
     def step(self):
         """enqueue the chain for the batch"""
         B, W, H, cap, s = self.B, self.W, self.H, self.cap, self.scen
+        c = self.cur
+        c.set_pose(self.d_guess.data_ptr())   # mVelocity * mLastFrame.mTcw is known before the image: its copy runs beside the extraction
         self.ex.extract_batch_device_async(self.d_cur.data_ptr(), B, W, H, W, W * H, self.d_kps.data_ptr(), self.d_desc.data_ptr(), cap,
                                            self.d_n.data_ptr())
-        c = self.cur
         c.build(self.ex, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), W, H, self.d_depth.data_ptr(),
                 float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
-        c.set_pose(self.d_guess.data_ptr())
         c.SearchByProjectionLast(self.last, self.table, self.th_last, mono=False, check_orientation=True, d_nmatches=self.d_nm[0].data_ptr())
         c.PoseOptimization(self.table, self.d_nm[1].data_ptr())
         c.discard_outliers()

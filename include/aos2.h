@@ -653,7 +653,8 @@ int aos2_frames_wait(aos2_frames_t *f);
 int aos2_frames_build(aos2_frames_t *f, aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps,
                       const uint8_t *d_desc, const int32_t *d_n, int cap, int w, int h, const float *d_depth,
                       int depth_stride, size_t depth_image_stride, float fx, float fy, float cx, float cy, float mbf);
-/* Frame::SetPose for every frame: d_Tcw = [batch][16] float32 in device memory (mVelocity * mLastFrame.mTcw, Tracking.cc:975) */
+/* Frame::SetPose for every frame: d_Tcw = [batch][16] float32 in device memory (mVelocity * mLastFrame.mTcw, Tracking.cc:975).
+ * Independent of aos2_frames_build (which leaves mTcw alone): called before it, the copy runs beside the extraction. */
 int aos2_frames_set_pose(aos2_frames_t *f, const float *d_Tcw);
 /* mvpMapPoints (and optionally mvbOutlier) from the host: mp = [batch][cap] rows of `table` (-1 = NULL), outlier =
  * [batch][cap] or NULL (unchanged); for setting up a LastFrame batch and tests */

@@ -18,9 +18,9 @@ def t(fn, n=50):
 def extract():
     tc.ex.extract_batch_device_async(tc.d_cur.data_ptr(), B, W, H, W, W * H, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), cap, tc.d_n.data_ptr()); tc.ex.wait()
 def motion():
+    c.set_pose(tc.d_guess.data_ptr())
     tc.ex.extract_batch_device_async(tc.d_cur.data_ptr(), B, W, H, W, W * H, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), cap, tc.d_n.data_ptr())
     c.build(tc.ex, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), tc.d_n.data_ptr(), W, H, tc.d_depth.data_ptr(), *args)
-    c.set_pose(tc.d_guess.data_ptr())
     c.SearchByProjectionLast(tc.last, tc.table, tc.th_last, False, True, tc.d_nm[0].data_ptr())
     c.PoseOptimization(tc.table, tc.d_nm[1].data_ptr())
     c.wait()
