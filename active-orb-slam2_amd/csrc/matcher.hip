@@ -1072,10 +1072,14 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
 }
 
 __global__ __launch_bounds__(64) void proj_mp_entries_kernel(FrameDev F, ProjMpDev P, float th, QuerySlot *slots,
-                                                             Entry *pool, int32_t *pool_used, int pool_cap)
+                                                             Entry *pool, int32_t *pool_used, int pool_cap, int phase = 0)
 {
-    proj_mp_entries_body(F, P, th, slots, pool, pool_used, pool_cap, blockIdx.x);
+    proj_mp_entries_body(F, P, th, slots, pool, pool_used, pool_cap, blockIdx.x, 0, phase);
 }
+
+// (frames_impl.inc) exclusive scan of the window populations -> entry offsets; raises *overflow to the total if it exceeds `share`
+__global__ void frames_scan_slots_kernel(QuerySlot *__restrict__ slots, const int32_t *__restrict__ nq_of, int nq_cap, int share,
+                                         int32_t *__restrict__ overflow);
 
 // stage B
 __device__ __forceinline__ void proj_mp_resolve_body(const FrameDev &F, const ProjMpDev &P, float nnratio,
@@ -2207,6 +2211,7 @@ struct Arena {
             memcpy(f.dst, one ? m->h_out.p + (f.src - lo) : m->h_out.p + o, f.bytes);
             o += (f.bytes + 15) & ~(size_t)15;
         }
+        fetches.clear();
         return AOS2_OK;
     }
 };
@@ -2721,12 +2726,14 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     const size_t om = A.reserve_out((size_t)f->n_f * 4 + 4), on = A.reserve_out(8);
     const size_t oslots = A.reserve((size_t)(p->n_mp + 1) * sizeof(QuerySlot));
     const size_t ochoice = A.reserve((size_t)(p->n_mp + 1) * 4);
-    const size_t pool_cap = (size_t)p->n_mp * (size_t)f->n_f;   // a window holds at most every feature
-    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
-        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_mp, f->n_f);
-        return AOS2_ERR_ARG;
-    }
-    if ((st = m->pool.alloc(pool_cap + 1))) return st;
+    // Entry pool.  Usual sizes: every query owns a slice that holds the whole frame (one pass, no counting).  Large local
+    // maps (n_mp x n_f x 8 B beyond 64 MB): the pool is sized from the REAL window populations -- count pass, scan, fill
+    // pass -- starting from a budget of 64 entries per query and, if the windows of this call hold more (the scan reports
+    // the total), once more with exactly that many.  No size limit other than device memory.
+    const size_t worst = (size_t)p->n_mp * (size_t)f->n_f;   // a window holds at most every feature
+    const bool two_pass = worst * sizeof(Entry) > ((size_t)64 << 20) || getenv("AOS2_PROJ_TWO_PASS") != nullptr;
+    size_t pool_cap = two_pass ? std::max<size_t>((size_t)p->n_mp * 64, 1024) : worst;
+    if (const char *e = getenv("AOS2_PROJ_POOL_BUDGET")) pool_cap = two_pass ? (size_t)std::max(1, atoi(e)) : pool_cap;   // (tests: force the retry)
     if ((st = A.upload())) return st;
     FrameDev F = frame_dev(A, f, fo);
     ProjMpDev P{};
@@ -2735,23 +2742,48 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
     P.pred_level = A.dev<int32_t>(o3); P.view_cos = A.dev<float>(o4); P.proj_x = A.dev<float>(o5);
     P.proj_y = A.dev<float>(o6); P.proj_xr = A.dev<float>(o7);
     int32_t *d_used = A.dev<int32_t>(on) + 1;
-    AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
-    AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
-    if (p->n_mp > 0)
-        hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th,
-                           A.dev<QuerySlot>(oslots), reinterpret_cast<Entry *>(m->pool.p), d_used, (int)pool_cap);
-    if ((size_t)f->n_f * 8 <= kFixLdsBytes && !m->serial_resolve)
-        hipLaunchKernelGGL(proj_mp_resolve_fix_kernel, dim3(1), dim3(1024), (size_t)f->n_f * 8 + 16, m->stream, F, P, m->nnratio,
-                           A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
-                           A.dev<int32_t>(on), A.dev<int32_t>(ochoice));
-    else   // the one-wave sequential loop: frames with more features than the LDS copy of B holds, or AOS2_SERIAL_RESOLVE=1
-        hipLaunchKernelGGL(proj_mp_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, m->nnratio,
-                           A.dev<QuerySlot>(oslots), reinterpret_cast<const Entry *>(m->pool.p), A.dev<int32_t>(om),
-                           A.dev<int32_t>(on));
-    AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
-    A.fetch(match_f, om, (size_t)f->n_f * 4);
-    A.fetch(nmatches, on, 4);
-    if ((st = A.finish())) return st;
+    QuerySlot *d_slots = A.dev<QuerySlot>(oslots);
+    for (int attempt = 0;; ++attempt) {
+        if (pool_cap > ((size_t)1 << 31) - 2) {
+            set_error("projection search: %zu candidate entries exceed the pool's index range", pool_cap);
+            return AOS2_ERR_CAPACITY;
+        }
+        if ((st = m->pool.alloc(pool_cap + 1))) return st;
+        Entry *d_pool = reinterpret_cast<Entry *>(m->pool.p);
+        AOS2_HIP_CHECK(hipMemsetAsync(d_used, 0, 4, m->stream));
+        if (attempt == 0) AOS2_HIP_CHECK(hipEventRecord(m->ev[0], m->stream));
+        if (p->n_mp > 0) {
+            if (!two_pass)
+                hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th, d_slots, d_pool, d_used,
+                                   (int)pool_cap, 0);
+            else {
+                hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th, d_slots, d_pool, d_used,
+                                   (int)pool_cap, 1);
+                hipLaunchKernelGGL(frames_scan_slots_kernel, dim3(1), dim3(256), 0, m->stream, d_slots, (const int32_t *)nullptr,
+                                   p->n_mp, (int)pool_cap, d_used);
+                hipLaunchKernelGGL(proj_mp_entries_kernel, dim3(p->n_mp), dim3(64), 0, m->stream, F, P, th, d_slots, d_pool, d_used,
+                                   (int)pool_cap, 2);
+            }
+        }
+        if ((size_t)f->n_f * 8 <= kFixLdsBytes && !m->serial_resolve)
+            hipLaunchKernelGGL(proj_mp_resolve_fix_kernel, dim3(1), dim3(1024), (size_t)f->n_f * 8 + 16, m->stream, F, P, m->nnratio,
+                               d_slots, reinterpret_cast<const Entry *>(d_pool), A.dev<int32_t>(om), A.dev<int32_t>(on),
+                               A.dev<int32_t>(ochoice));
+        else   // the one-wave sequential loop: frames with more features than the LDS copy of B holds, or AOS2_SERIAL_RESOLVE=1
+            hipLaunchKernelGGL(proj_mp_resolve_kernel, dim3(1), dim3(64), (size_t)f->n_f + 16, m->stream, F, P, m->nnratio, d_slots,
+                               reinterpret_cast<const Entry *>(d_pool), A.dev<int32_t>(om), A.dev<int32_t>(on));
+        AOS2_HIP_CHECK(hipEventRecord(m->ev[1], m->stream));
+        int32_t tail[2] = {0, 0};   // nmatches, overflow word
+        A.fetch(match_f, om, (size_t)f->n_f * 4);
+        A.fetch(tail, on, 8);
+        if ((st = A.finish())) return st;
+        if (two_pass && (size_t)tail[1] > pool_cap && attempt == 0) {   // the windows hold tail[1] entries: once more, exactly sized
+            pool_cap = (size_t)tail[1];
+            continue;
+        }
+        *nmatches = tail[0];
+        break;
+    }
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     return AOS2_OK;
 }

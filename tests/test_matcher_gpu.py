@@ -66,6 +66,24 @@ def test_search_by_projection_vs_oracle(pkg, oracle, gpu):
     assert n == on and (match == om).all()
 
 
+def test_search_by_projection_entry_pool_from_window_populations(pkg, oracle, gpu, monkeypatch):
+    """large local maps size the candidate pool from the real window populations (count pass, scan, fill pass) instead of
+    n_mp x n_f slots; forced here on an ordinary problem, also with a budget that is too small (the call learns the total
+    from the scan and runs once more, exactly sized): same matches as the one-pass form and the oracle"""
+    f, mp = pkg.synth.synth_proj_mp_problem(11, n_f=1500, n_mp=2500, th=4.0)
+    on, om = oracle.search_by_projection_mp(f, mp)
+    for budget in (None, "300"):
+        monkeypatch.setenv("AOS2_PROJ_TWO_PASS", "1")
+        if budget:
+            monkeypatch.setenv("AOS2_PROJ_POOL_BUDGET", budget)
+        n, match = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+        assert n == on and (match == om).all()
+    monkeypatch.delenv("AOS2_PROJ_TWO_PASS")
+    monkeypatch.delenv("AOS2_PROJ_POOL_BUDGET")
+    n, match = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+    assert n == on and (match == om).all() and on > 100
+
+
 def test_search_by_projection_parallel_resolve_equals_sequential(pkg, oracle, gpu, monkeypatch):
     """the fixed-point stage B (all map points decide in parallel from B[f] = first earlier taker, iterated until the
     decisions reproduce themselves) == the one-wave sequential loop (AOS2_SERIAL_RESOLVE=1) == the oracle, also when
