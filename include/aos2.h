@@ -394,7 +394,10 @@ typedef struct {
 
 /* int ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, const float th)
  * src/ORBmatcher.cc:45-129.  match_f[n_f]: index into the map point list newly assigned to
- * F.mvpMapPoints[j], or -1 = entry unchanged. */
+ * F.mvpMapPoints[j], or -1 = entry unchanged.  Any number of map points: beyond n_mp x n_f x 8 B = 64 MB the scratch
+ * for the candidates is sized from the real window populations (two passes) instead of n_mp x n_f slots.
+ * AOS2_ERR_ARG (before anything is uploaded) if the frame view or the point set is inconsistent: non-monotone grid
+ * offsets, grid entries or pyramid levels out of range, NULL arrays. */
 int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t *f,
                                       const aos2_proj_mp_t *p, float th, int32_t *match_f,
                                       int32_t *nmatches);
