@@ -869,6 +869,15 @@ __device__ __forceinline__ int window_population(const FrameDev &F, const Window
     return wave_sum_i32(total);
 }
 
+// the same number by ONE thread: the cells of a grid column are neighbours in the CSR, so a column of the window is one
+// difference of offsets (the counting pass of the two-pass form runs a thread per query instead of a wave per query)
+__device__ __forceinline__ int window_population_solo(const FrameDev &F, const Window &w)
+{
+    int total = 0;
+    for (int ix = w.x0; ix <= w.x1; ++ix) total += F.grid_off[ix * GRID_ROWS + w.y1 + 1] - F.grid_off[ix * GRID_ROWS + w.y0];
+    return total;
+}
+
 // stage A body: writes one entry per feature of the window at out[position]
 __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &w, const Desc &dq, float x, float y,
                                                float r, int minLevel, int maxLevel, float xr_proj, float xr_tol,
@@ -1037,18 +1046,20 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 // only an overflow flag
 // phase 0: the query's entries go to its fixed slice of the pool (below).  Two-pass form (device-resident frames):
 // phase 1 only counts the window populations (slots[i].cnt), a scan assigns slots[i].ent_off, phase 2 fills.
+// kSolo (phase 1 only): the caller is one thread, not a wave.
+template <bool kSolo = false>
 __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
                                                      Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0,
                                                      int phase = 0)
 {
-    const int lane = threadIdx.x;
+    const int lane = kSolo ? 0 : (int)(threadIdx.x & 63);   // a wave per query (workgroups may hold several waves)
     QuerySlot s{0, 0};
     if (P.track_in_view[i]) {
         const float rs = mp_radius(F, P, i, th);
         const Window w = window_cells(F, P.proj_x[i], P.proj_y[i], rs);
         if (w.ok) {
-            const int pop = window_population(F, w, lane);
-            if (pop > 0 && phase == 1) {
+            const int pop = kSolo ? window_population_solo(F, w) : window_population(F, w, lane);
+            if (pop > 0 && (phase == 1 || kSolo)) {
                 s.cnt = pop;
             } else if (pop > 0) {
                 // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
@@ -1225,11 +1236,12 @@ __device__ __forceinline__ bool proj_last_blocks(const ProjLastDev &P, int q)
 
 // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  :1328-1470
 // stage A: one wave per last-frame feature: project, window, distances
+template <bool kSolo = false>
 __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const ProjLastDev &P, float th, int mono,
                                                        QuerySlot *slots, Entry *pool, int32_t *pool_used, int pool_cap,
                                                        int i, int pool_base = 0, int phase = 0)
 {
-    const int lane = threadIdx.x;
+    const int lane = kSolo ? 0 : (int)(threadIdx.x & 63);   // a wave per query (workgroups may hold several waves)
     QuerySlot s{0, 0};
     const float *T = P.Tcw, *Tl = P.Tlw;
     int row = i;
@@ -1278,8 +1290,8 @@ __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const 
             }
             const Window w = window_cells(F, u, v, radius);
             if (w.ok) {
-                const int pop = window_population(F, w, lane);
-                if (pop > 0 && phase == 1) {
+                const int pop = kSolo ? window_population_solo(F, w) : window_population(F, w, lane);
+                if (pop > 0 && (phase == 1 || kSolo)) {
                     s.cnt = pop;
                 } else if (pop > 0) {
                     const int stride = phase == 2 ? pop : pool_cap / max(P.n_last, 1);
