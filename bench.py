@@ -202,10 +202,10 @@ def main():
 
     def gather_step(j):
         p = pipes[j]
-        if gather["work"][j] is not None:
-            gather["work"][j].wait()
-        p.ex.pack_slots(B, p.d_kps.data_ptr(), p.d_desc.data_ptr(), p.d_n.data_ptr(), cap, gather["slot"][j].data_ptr(), sb, p.cur.stream())
-        with torch.cuda.stream(gather["ext"][j]):
+        with torch.cuda.stream(gather["ext"][j]):   # = the pipeline's own stream
+            if gather["work"][j] is not None:
+                gather["work"][j].wait()   # the STREAM waits for the previous gather of this slot buffer before it is packed again
+            p.ex.pack_slots(B, p.d_kps.data_ptr(), p.d_desc.data_ptr(), p.d_n.data_ptr(), cap, gather["slot"][j].data_ptr(), sb, p.cur.stream())
             if backend == "nccl":
                 gather["work"][j] = dist.gather(gather["slot"][j], gather["bufs"][j], dst=0, async_op=True)
             else:   # gloo (tests): host tensors
@@ -218,9 +218,6 @@ def main():
         jl = s % NLBA
         if lba_jobs[jl] is not None:
             lba_jobs[jl].result()
-        if gather is not None and gather["work"][j] is not None:
-            gather["work"][j].wait()
-            gather["work"][j] = None
         p.wait()
         p.step()
         if gather is not None:
