@@ -117,6 +117,21 @@ __device__ inline bool lm_poll(LmState *st, const int32_t *abort_word, int seen 
     return false;
 }
 
+// Optimizer.cc:663-666 right after optimizer.optimize(5) returned: bDoMore = !*pbStopFlag.  Called where the first
+// optimisation ends (the LM decision of its last trial, or k_prepare when it does not run at all); xmark = 1 lets the
+// transition kernel run the outlier pass.
+__device__ inline void lm_first_done(LmState *st, const int32_t *abort_word, int seen = -1)
+{
+    st->phase = 1;
+    st->xmark = 0;
+    if (lm_poll(st, abort_word, seen)) {
+        st->phase = 3;
+        return;
+    }
+    st->xmark = 1;
+    st->n_active = 0;
+}
+
 // Sums of two values per thread of an N-thread workgroup (binary trees in LDS, fixed order) -> out0[blockIdx.x], out1[blockIdx.x]
 template <int N>
 __device__ __forceinline__ void workgroup_sum2(double v0, double v1, double *out0, double *out1)
@@ -167,23 +182,17 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
             st->polls = 1;   // the entry check of Optimizer.cc:656-658 was made on the host
             st->stop_at_poll = stop_at_poll;
             st->n_active = W.n_edges;
+            // SparseOptimizer::optimize(iterations) entry, first call (sparse_optimizer.cpp:354-372): `i < iterations &&
+            // !terminate() && ok` before the first iteration
+            st->phase = 0;
+            st->it = 0;
+            if (st->iters_max[0] <= 0 || lm_poll(st, W.abort_word)) {
+                st->iters_done[0] = 0;
+                lm_first_done(st, W.abort_word);
+            } else
+                st->initp = 1;
         }
     }
-}
-
-// SparseOptimizer::optimize(iterations) entry, first call (sparse_optimizer.cpp:354-372): `i < iterations &&
-// !terminate() && ok` before the first iteration
-__global__ void k_begin(const LbaWin *__restrict__ wins)
-{
-    const LbaWin &W = wins[blockIdx.x];
-    LmState *st = W.st;
-    st->phase = 0;
-    st->it = 0;
-    if (st->iters_max[0] <= 0 || lm_poll(st, W.abort_word)) {
-        st->phase = 1;
-        st->iters_done[0] = 0;
-    } else
-        st->initp = 1;
 }
 
 // EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ::computeError (types_six_dof_expmap.h:80-141) with the camera point given
@@ -322,7 +331,10 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
                 st->iters_done[pass] = st->it;
                 st->final_chi2 = st->currentChi;
                 st->final_lambda = st->lambda;
-                st->phase = pass == 0 ? 1 : 3;
+                if (pass == 0)
+                    lm_first_done(st, W.abort_word, flag_seen);
+                else
+                    st->phase = 3;
             }
         }
         st->lin = lin;
@@ -1022,28 +1034,41 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
     double *Tb = xs + npad;                      // 2 x 16 x 17: T_k^T of the current / next panel
     LDLT_T(long long tD = 0, tP = 0, tU = 0, t_a = 0; const long long t_begin = __builtin_amdgcn_s_memtime();)
     if (tid == 0) s_fail = 0;
-    // load (identity-padded): element pairs (n is even, rows are 16-byte aligned), 8 independent 16-byte global loads in
-    // flight per thread before the stores
+    // load (identity-padded), lower BLOCK triangle only -- row r needs its columns up to the end of its diagonal block,
+    // nothing reads the blocks above the diagonal -- as element pairs (n is even, rows are 16-byte aligned): block row R
+    // holds 16 x 8 (R + 1) pairs, 64 R (R + 1) pairs lie before it.  9 independent 16-byte global loads in flight per
+    // thread before the stores: a 128 x 128 system is one round.
     {
-        const int hp = npad >> 1, npairs = npad * hp;
-        for (int p0 = tid; p0 < npairs; p0 += 8 * NT) {
-            double2 v[8];
+        const int nbr = npad >> 4, npairs = 64 * nbr * (nbr + 1);
+        auto where = [&](int q, int &r, int &c) {
+            int R = (int)((__fsqrt_rn(1.0f + (float)q * 0.0625f) - 1.0f) * 0.5f);
+            while (64 * (R + 1) * (R + 2) <= q) ++R;   // (the float estimate can be one short)
+            while (64 * R * (R + 1) > q) --R;
+            const int q1 = q - 64 * R * (R + 1), w = 8 * (R + 1);
+            const int rr = q1 / w;
+            r = 16 * R + rr;
+            c = (q1 - rr * w) << 1;
+        };
+        for (int p0 = tid; p0 < npairs; p0 += 9 * NT) {
+            double2 v[9];
+            int rr[9], cc[9];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 9; ++u) {
                 const int q = p0 + u * NT;
-                const int r = q / hp, c = (q - r * hp) << 1;
+                rr[u] = cc[u] = 0;
+                if (q < npairs) where(q, rr[u], cc[u]);
+                const int r = rr[u], c = cc[u];
                 if (q < npairs && r < n && c < n)
                     v[u] = *reinterpret_cast<const double2 *>(Wn.Hs + (size_t)r * n + c);
                 else
                     v[u] = double2{r == c ? 1.0 : 0.0, r == c + 1 ? 1.0 : 0.0};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 9; ++u) {
                 const int q = p0 + u * NT;
-                const int r = q / hp, c = (q - r * hp) << 1;
                 if (q < npairs) {
-                    M[(size_t)r * ld + c] = v[u].x;
-                    M[(size_t)r * ld + c + 1] = v[u].y;
+                    M[(size_t)rr[u] * ld + cc[u]] = v[u].x;
+                    M[(size_t)rr[u] * ld + cc[u] + 1] = v[u].y;
                 }
             }
         }
@@ -1285,7 +1310,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         }
         double *Tp = Wn.pose + 7 * (size_t)Wn.hpose[tid], *Tbk = Wn.bk + 7 * (size_t)Wn.hpose[tid];
         for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
-        se3_oplus(upd, Tp);
+        se3_oplus_fast(upd, Tp);   // (polynomial small-angle form, lba_math.h; agrees with se3_oplus to a few ulp)
     }
 }
 
@@ -1493,7 +1518,7 @@ __global__ __launch_bounds__(kLds ? 256 : 1024) void k_ldlt_solve(const LbaWin *
                     upd[i] = M[6 * lane + i];
                     Wn.tmp[6 * lane + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * lane + i]);
                 }
-                se3_oplus(upd, Wn.pose + 7 * (size_t)Wn.hpose[lane]);
+                se3_oplus_fast(upd, Wn.pose + 7 * (size_t)Wn.hpose[lane]);
             }
         }
     } else {
@@ -1572,30 +1597,19 @@ __global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ 
     }
     double *Tp = W.pose + 7 * (size_t)W.hpose[p], *Tbk = W.bk + 7 * (size_t)W.hpose[p];
     for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
-    se3_oplus(upd, Tp);
+    se3_oplus_fast(upd, Tp);
 }
 
-// Between the two optimisations (Optimizer.cc:663-710).  (a): bDoMore = !*pbStopFlag
-__global__ void k_trans_a(const LbaWin *__restrict__ wins)
+// Between the two optimisations (Optimizer.cc:667-710), one launch (the bDoMore check of :663-666 was made where the first
+// optimisation ended: lm_first_done).  Edges with chi2 above the threshold or non-positive depth leave the optimisation
+// (setLevel(1)), all edges drop their robust kernel (:672-703); the workgroup that finishes last does
+// initializeOptimization(0) (fails without level-0 edges) and the entry of optimize(10).
+__global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ wins)
 {
-    const LbaWin &W = wins[blockIdx.x];
-    LmState *st = W.st;
-    st->xmark = 0;
-    if (st->phase != 1) return;
-    if (lm_poll(st, W.abort_word)) {
-        st->phase = 3;
-        return;
-    }
-    st->xmark = 1;
-    st->n_active = 0;
-}
-
-// (b): edges with chi2 above the threshold or non-positive depth leave the optimisation (setLevel(1)), all edges drop
-// their robust kernel (:672-703)
-__global__ __launch_bounds__(256) void k_edge_mark(const LbaWin *__restrict__ wins)
-{
+    __shared__ int s_last;
     const LbaWin &W = wins[blockIdx.y];
-    if (!W.st->xmark) return;
+    LmState *st = W.st;
+    if (!st->xmark) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     int keep = 0;
     if (e < W.n_edges) {
@@ -1613,18 +1627,20 @@ __global__ __launch_bounds__(256) void k_edge_mark(const LbaWin *__restrict__ wi
         keep = bad ? 0 : 1;
     }
     const unsigned long long m = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&W.st->n_active, __popcll(m));
-}
-
-// (c): initializeOptimization(0) (fails without level-0 edges) and the entry of optimize(10)
-__global__ void k_trans_b(const LbaWin *__restrict__ wins)
-{
-    const LbaWin &W = wins[blockIdx.x];
-    LmState *st = W.st;
-    if (!st->xmark) return;
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&st->n_active, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&st->blocks_done, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    st->blocks_done = 0;
     st->xmark = 0;
     st->it = 0;
-    if (st->n_active == 0 || st->iters_max[1] <= 0 || lm_poll(st, W.abort_word)) {
+    const int n_active = __hip_atomic_load(&st->n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_active == 0 || st->iters_max[1] <= 0 || lm_poll(st, W.abort_word)) {
         st->phase = 3;
         st->iters_done[1] = 0;
     } else {
@@ -2173,9 +2189,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         enqueue_lin(0);
     };
     auto enqueue_transition = [&]() {
-        hipLaunchKernelGGL(k_trans_a, dim3(nw), dim3(1), 0, q, dw);
-        hipLaunchKernelGGL(k_edge_mark, g_edges256, dim3(256), 0, q, dw);
-        hipLaunchKernelGGL(k_trans_b, dim3(nw), dim3(1), 0, q, dw);
+        hipLaunchKernelGGL(k_transition, g_edges256, dim3(256), 0, q, dw);
     };
     // results (and states) come back as one copy; the host forwards pbStopFlag into the mapped abort words meanwhile
     auto finish = [&]() -> int {
@@ -2200,7 +2214,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     rg = std::make_unique<RoctxRange>("LocalBA::optimize(5) + outlier pass + optimize(10) + inlier check (one device program)");
     // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
     hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw, s->debug_stop_at_poll);
-    hipLaunchKernelGGL(k_begin, dim3(nw), dim3(1), 0, q, dw);
     if (max_i1 > 0) {
         enqueue_init();
         for (int t = 0; t < max_i1 + 1; ++t) enqueue_trial();

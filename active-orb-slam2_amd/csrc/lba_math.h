@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "aos2_common.h"
@@ -109,6 +110,159 @@ __device__ inline void se3_oplus(const double upd[6], double T[7])
     q[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
     quat_normalize_rot(q);
     for (int i = 0; i < 4; ++i) T[i] = q[i];
+    for (int i = 0; i < 3; ++i) T[4 + i] = e[4 + i] + rt[i];
+}
+
+// sqrt(d) and 1 / sqrt(d) for d > 0: v_rsq_f64 + two coupled Newton (Goldschmidt) steps + one correction of the root;
+// ~10 dependent operations instead of the ~30-instruction IEEE sqrt followed by a ~30-instruction IEEE division.
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &s, double &r)
+{
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double c = __builtin_fma(-g, g, d);
+    s = __builtin_fma(c, h, g);
+    r = h + h;
+}
+
+// T <- exp(upd) * T: VertexSE3Expmap::oplusImpl like se3_oplus (lba_math.h: SE3Quat::exp se3quat.h:223-257, operator*
+// :104-110), shaped for the serial path of the pose solver.  An LM step is a small rotation (|omega|^2 < 0.6), and for
+// those nothing needs a square root, a division or a sin / cos call: with z = |omega|^2 and fdlibm's minimax polynomials
+// sin t = t + t z ps(z), cos t = 1 - z / 2 + z^2 pc(z) on |t| <= pi / 4,
+//     sin t / t = 1 + z ps,   (1 - cos t) / t^2 = 1/2 - z pc,   (t - sin t) / t^3 = -ps       (the coefficients of R, V)
+// without the cancellation the quotients of se3quat.h:236-240 suffer, and the quaternion of R(omega) is
+// (omega sin(t/2) / t, cos(t/2)) = (omega (1 + zh ps(zh)) / 2, 1 - zh / 2 + zh^2 pc(zh)), zh = z / 4 -- what Eigen's
+// Quaterniond(R) + normalize() extracts from the matrix, up to rounding.  Below theta = 1e-5 the reference switches to
+// R = V = I + Omega + Omega^2 (:231-234); V keeps that, the normalised quaternion of that R equals the exact one to
+// 2e-11 relative.  The quaternion product is renormalised by a Newton step from 1 (|q|^2 = 1 + O(1e-16)).  Larger
+// rotations take the formulas as written.  Results agree with se3_oplus to a few ulp (pose tolerance: 1e-5).
+__device__ __forceinline__ void se3_oplus_fast(const double upd[6], double T[7])
+{
+    const double *omega = upd, *ups = upd + 3;
+    const double th2 = omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2];
+    // a x b with fused multiply-adds
+    auto cross = [](const double *a, const double *b, double *o) {
+        o[0] = __builtin_fma(a[1], b[2], -(a[2] * b[1]));
+        o[1] = __builtin_fma(a[2], b[0], -(a[0] * b[2]));
+        o[2] = __builtin_fma(a[0], b[1], -(a[1] * b[0]));
+    };
+    auto poly_s = [](double z) {
+        double ps = 1.58969099521155010221e-10;
+        ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+        ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+        ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+        ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+        return __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    };
+    auto poly_c = [](double z) {
+        double pc = -1.13596475577881948265e-11;
+        pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+        pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+        pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+        pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+        return __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    };
+    double e[7], bV, cV;
+    if (th2 < 0.6) {
+        const double z = th2, zh = 0.25 * th2;
+        const double ps = poly_s(z), pc = poly_c(z), psh = poly_s(zh), pch = poly_c(zh);
+        const bool tiny = th2 < 0.00001 * 0.00001;
+        bV = tiny ? 1.0 : __builtin_fma(-z, pc, 0.5);
+        cV = tiny ? 1.0 : -ps;
+        const double sv = 0.5 * __builtin_fma(zh, psh, 1.0);
+        e[0] = omega[0] * sv;
+        e[1] = omega[1] * sv;
+        e[2] = omega[2] * sv;
+        e[3] = __builtin_fma(zh * zh, pch, __builtin_fma(-0.5, zh, 1.0));
+    } else {
+        double theta, ith, sn, cs, R[9];
+        sqrt_rsqrt(th2, theta, ith);
+        sincos(theta, &sn, &cs);
+        const double ith2 = ith * ith;
+        const double a = sn * ith;
+        bV = (1 - cs) * ith2;
+        cV = (theta - sn) * (ith2 * ith);
+        const double Om[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double om2 = Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j] + Om[i * 3 + 2] * Om[6 + j];
+                R[i * 3 + j] = I[i * 3 + j] + a * Om[i * 3 + j] + bV * om2;
+            }
+        const double t = R[0] + R[4] + R[8];
+        if (t > 0) {   // Eigen's Quaterniond(R), trace branch
+            double sq, rs;
+            sqrt_rsqrt(t + 1.0, sq, rs);
+            e[3] = 0.5 * sq;
+            const double tt = 0.5 * rs;
+            e[0] = (R[7] - R[5]) * tt;
+            e[1] = (R[2] - R[6]) * tt;
+            e[2] = (R[3] - R[1]) * tt;
+        } else {   // the other three branches, with static indices (a dynamic one would put R and e into scratch memory)
+            auto branch = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, j = (i + 1) % 3, k = (j + 1) % 3;
+                double sq, rs;
+                sqrt_rsqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0, sq, rs);
+                e[i] = 0.5 * sq;
+                const double tt = 0.5 * rs;
+                e[3] = (R[k * 3 + j] - R[j * 3 + k]) * tt;
+                e[j] = (R[j * 3 + i] + R[i * 3 + j]) * tt;
+                e[k] = (R[k * 3 + i] + R[i * 3 + k]) * tt;
+            };
+            if (R[8] > (R[4] > R[0] ? R[4] : R[0]))
+                branch(std::integral_constant<int, 2>());
+            else if (R[4] > R[0])
+                branch(std::integral_constant<int, 1>());
+            else
+                branch(std::integral_constant<int, 0>());
+        }
+        const double sg = e[3] < 0 ? -1.0 : 1.0;
+        double sq, rs;
+        sqrt_rsqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3], sq, rs);
+        rs *= sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] *= rs;
+    }
+    // V upsilon = upsilon + bV (omega x upsilon) + cV (omega x (omega x upsilon))      (V = I + bV Omega + cV Omega^2)
+    double wu[3], wwu[3];
+    cross(omega, ups, wu);
+    cross(omega, wu, wwu);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[4 + i] = __builtin_fma(cV, wwu[i], __builtin_fma(bV, wu[i], ups[i]));
+    // e * T: rotation of T's translation (v + w uv + e_v x uv, uv = 2 e_v x v) and the quaternion product
+    double rt[3], q[4], uv[3], cc[3];
+    cross(e, T + 4, uv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) uv[i] += uv[i];
+    cross(e, uv, cc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rt[i] = __builtin_fma(e[3], uv[i], T[4 + i]) + cc[i];
+    q[3] = __builtin_fma(-e[2], T[2], __builtin_fma(-e[1], T[1], __builtin_fma(-e[0], T[0], e[3] * T[3])));
+    q[0] = __builtin_fma(-e[2], T[1], __builtin_fma(e[1], T[2], __builtin_fma(e[0], T[3], e[3] * T[0])));
+    q[1] = __builtin_fma(-e[0], T[2], __builtin_fma(e[2], T[0], __builtin_fma(e[1], T[3], e[3] * T[1])));
+    q[2] = __builtin_fma(-e[1], T[0], __builtin_fma(e[0], T[1], __builtin_fma(e[2], T[3], e[3] * T[2])));
+    {
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        double rs;
+        if (fabs(n2 - 1.0) < 1e-6) {   // 1 / sqrt(1 + eps): two Newton steps from 1 (error O(eps^4))
+            const double r0 = __builtin_fma(-0.5, n2, 1.5);
+            rs = r0 * __builtin_fma(-0.5 * n2, r0 * r0, 1.5);
+        } else {
+            double sq;
+            sqrt_rsqrt(n2, sq, rs);
+        }
+        if (q[3] < 0) rs = -rs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[i] = q[i] * rs;
+    }
+#pragma unroll
     for (int i = 0; i < 3; ++i) T[4 + i] = e[4 + i] + rt[i];
 }
 
