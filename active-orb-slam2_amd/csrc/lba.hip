@@ -1106,6 +1106,16 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         for (int c = 0; c < 16; ++c) row[c] = M[(size_t)(k0 + li) * ld + k0 + c];
         double cur = rv[k0 + li];
         bool bad = false;
+        // T = L_kk^-1 (unit lower triangular), lane c owns column c, built alongside the factorisation: eliminating column j
+        // gives every lane the whole column (ck[k] = a_kj, the broadcast it needs for its own row anyway) and the reciprocal
+        // pivot, i.e. L[k][j] = ck[k] rd for all k -- so t[k] -= L[k][j] t[j] costs one product and 15 - j fused
+        // multiply-adds here, instead of a second pass that re-read L through 120 LDS broadcasts per lane (1840 cycles per
+        // block).  (Rows in lanes 0..15 and T in lanes 16..31 as ONE instruction stream -- both updates are
+        // x[k] -= (x[j] rd) ck[k] -- was measured slower: 36.5 k against 34.7 k cycles for the 8 blocks, the lane-group
+        // selects and predicated stores cost more than the 7.5 multiply-adds per pivot they save.)
+        double t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = c == li ? 1.0 : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         LDLT_T(const long long q1 = __builtin_amdgcn_s_memtime(); dt1 += q1 - q0;)
 #pragma unroll
@@ -1120,10 +1130,19 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             const double rd = rcp_newton(dj);
             const double lij = ci * rd;
             const double yj = readlane_f64(cur, j);
+            const double st = rd * t[j];
 #pragma unroll
-            for (int k = j + 1; k < 16; ++k) row[k] = __builtin_fma(-lij, ck[k], row[k]);
-            // row i > j: its entry of column j becomes L[i][j]; row j keeps the pivot; rows above hold scratch there
-            row[j] = li == j ? ci : lij;
+            for (int k = j + 1; k < 16; ++k) {
+                row[k] = __builtin_fma(-lij, ck[k], row[k]);
+                t[k] = __builtin_fma(-ck[k], st, t[k]);
+            }
+            // row i > j: its entry of column j becomes L[i][j]; row j keeps the pivot; rows above hold scratch there.  Both
+            // finished values leave for LDS at once (the rows of the block without predication: the entries right of the
+            // diagonal are scratch that nothing reads; lanes >= 16 store the same values to the same places; column c of T
+            // = row c of the panel's T^T buffer, dense: zeros above the diagonal, ones on it), so the live registers shrink
+            // with j instead of holding 16 finished entries of each array to the end
+            M[(size_t)(k0 + li) * ld + k0 + j] = li == j ? ci : lij;
+            Tk[li * 17 + j] = t[j];
             cur = li > j ? __builtin_fma(-lij, yj, cur) : cur;   // forward substitution inside the block
             __builtin_amdgcn_sched_barrier(0);   // keep the pivots apart (hoisting the later pivots' reads only costs spills)
         }
@@ -1132,10 +1151,6 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             if (lane == 0) s_fail = 1;
             return;
         }
-        // rows of the block back to LDS, whole rows without predication: the diagonal carries D, the entries right of it
-        // are scratch that nothing reads (lanes >= 16 store the same values to the same places)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) M[(size_t)(k0 + li) * ld + k0 + c] = row[c];
         rv[k0 + li] = cur;   // y of this block
         wave_sync();
         {
@@ -1144,34 +1159,6 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             rdv[k0 + li] = rcp_newton(d);   // (the same operations as in the loop: the same bits)
         }
         LDLT_T(const long long q3 = __builtin_amdgcn_s_memtime(); dt3 += q3 - q2;)
-        // T = L_kk^-1 (unit lower triangular), lane c owns column c: T <- (I - l_j e_j^T) T for j = 0 .. 14, i.e.
-        // t[k] -= L[k][j] t[j] (k > j).  The entries of L come as broadcast reads, three batches of columns ahead of use.
-        {
-            double t[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = c == li ? 1.0 : 0.0;
-            auto sweep = [&](auto lo_c, auto hi_c) {
-                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-                double lb[(HI - LO) * 16];
-#pragma unroll
-                for (int j = LO; j < HI; ++j)
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) lb[(j - LO) * 16 + k] = M[(size_t)(k0 + k) * ld + k0 + j];
-#pragma unroll
-                for (int j = LO; j < HI; ++j) {
-                    const double tj = t[j];
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) t[k] = __builtin_fma(-lb[(j - LO) * 16 + k], tj, t[k]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-            sweep(std::integral_constant<int, 4>{}, std::integral_constant<int, 9>{});
-            sweep(std::integral_constant<int, 9>{}, std::integral_constant<int, 15>{});
-            // column c of T as row c of the panel's T^T buffer (dense: zeros above the diagonal, ones on it)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Tk[li * 17 + i] = t[i];
-        }
         LDLT_T(dt4 += __builtin_amdgcn_s_memtime() - q3;)
     };
     if (wave == 0) diag_block(0);
