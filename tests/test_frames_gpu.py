@@ -22,10 +22,10 @@ def ochain(oracle):
     return chain
 
 
-@pytest.mark.parametrize("seed,batch", [(1, 6), (2, 3)])
-def test_chain_stage_by_stage_vs_oracle(pkg, oracle, ochain, gpu, seed, batch):
+@pytest.mark.parametrize("seed,batch,cfg", [(1, 6, "tum"), (2, 3, "tum"), (3, 2, "euroc")])   # euroc: 752 x 480, 1200 features (> 1024 slots per frame)
+def test_chain_stage_by_stage_vs_oracle(pkg, oracle, ochain, gpu, seed, batch, cfg):
     import torch
-    scen = pkg.scenario.tracking_scenario(seed, batch, n_unique=batch)
+    scen = pkg.scenario.tracking_scenario(seed, batch, cfg=cfg, n_unique=batch)
     tc = pkg.chain.TrackingChain(scen, n_local=1500)
     B, W, H, cap = tc.B, tc.W, tc.H, tc.cap
     F = pkg.capi.Frames
