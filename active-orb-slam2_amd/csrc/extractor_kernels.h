@@ -55,6 +55,10 @@ int upload_constants(const int8_t *pattern, const int *umax, const int *gauss7, 
 void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
                    const int *yab, int batch, hipStream_t st);
+void launch_pyramid_fused(const uint8_t *img0, size_t img0_stride, int pitch0, uint8_t *pyr, size_t pyr_stride,
+                          const LevelDev *levels, int nlevels, const int4 *tile_x, const int4 *tile_y, int ntx, int nty,
+                          const int *xofs, const int *xab, const int *yofs, const int *yab, int buf_pitch, int buf_rows,
+                          size_t lds_bytes, int batch, hipStream_t st);
 void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
                  const LevelDev *levels, const CellDev *cells, int n_cells,
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,

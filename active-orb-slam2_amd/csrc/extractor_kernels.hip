@@ -1008,6 +1008,86 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole pyramid of an image in ONE launch (ComputePyramid, src/ORBextractor.cc:1107-1132: level k is cv::resize of
+// level k - 1).  A workgroup owns one tile of every level (the tiles of a workgroup sit on top of each other) and walks
+// the levels through two LDS buffers: level k - 1's region -> level k's region, of which it stores the part it owns.
+// A region holds what the workgroup owns at that level plus what its deeper levels read (a few pixels of halo, computed
+// redundantly by the neighbours; the host derives the regions from the resize tables, top level down: tile_x / tile_y,
+// int4 {own0, own1, need0, need1} per (level, tile column / row)).  Per pixel the arithmetic is resize_level_kernel's:
+// h = (a0 p[sx] + a1 p[sx + 1]) >> 4 on the two source rows, v = ((b0 h0 >> 16) + (b1 h1 >> 16) + 2) >> 2.
+// Against the 7 dependent launches of the per-level kernel: the levels are read from HBM / L2 zero times instead of once
+// each, and a single frame pays one launch.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pyramid_fused_kernel(const uint8_t *__restrict__ img0, size_t img0_stride, int pitch0,
+                                                            uint8_t *__restrict__ pyr, size_t pyr_stride,
+                                                            const LevelDev *__restrict__ levels, int nlevels,
+                                                            const int4 *__restrict__ tile_x, const int4 *__restrict__ tile_y,
+                                                            int ntx, int nty, const int *__restrict__ xofs,
+                                                            const int *__restrict__ xab, const int *__restrict__ yofs,
+                                                            const int *__restrict__ yab, int buf_pitch, int buf_rows, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t psm[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    if (b >= batch) return;
+    const int txi = (int)blockIdx.x % ntx, tyi = (int)blockIdx.x / ntx;
+    uint8_t *bufA = psm, *bufB = psm + (size_t)buf_pitch * buf_rows;
+    int *t_xo = reinterpret_cast<int *>(bufB + (size_t)buf_pitch * buf_rows);   // buf_pitch entries each
+    int *t_xa = t_xo + buf_pitch, *t_yo = t_xa + buf_pitch, *t_ya = t_yo + buf_rows;
+    // level 0: the region of the caller's image the workgroup's level-1 region reads
+    int4 px = tile_x[txi], py = tile_y[tyi];   // level 0 entries
+    {
+        const int w0 = px.w - px.z, h0 = py.w - py.z;
+        const uint8_t *src = img0 + (size_t)b * img0_stride;
+        const float inv_w = w0 > 0 ? 1.0f / (float)w0 : 0.f;
+        for (int i = tid; i < w0 * h0; i += 256) {
+            const int ry = (int)(((float)i + 0.5f) * inv_w), rx = i - ry * w0;
+            bufA[ry * buf_pitch + rx] = src[(size_t)(py.z + ry) * pitch0 + px.z + rx];
+        }
+    }
+    uint8_t *prev = bufA, *cur = bufB;
+    for (int k = 1; k < nlevels; ++k) {
+        const LevelDev lv = levels[k];
+        const int4 cx = tile_x[k * ntx + txi], cy = tile_y[k * nty + tyi];
+        const int w = cx.w - cx.z, h = cy.w - cy.z;   // this level's region
+        const int wprev = levels[k - 1].w, hmax = levels[k - 1].h - 1;
+        for (int i = tid; i < w; i += 256) {
+            t_xo[i] = xofs[lv.tab_x + cx.z + i];
+            t_xa[i] = xab[lv.tab_x + cx.z + i];
+        }
+        for (int i = tid; i < h; i += 256) {
+            t_yo[i] = yofs[lv.tab_y + cy.z + i];
+            t_ya[i] = yab[lv.tab_y + cy.z + i];
+        }
+        __syncthreads();   // tables + the previous level's region
+        uint8_t *dst = pyr + (size_t)b * pyr_stride + lv.off;
+        const float inv_w = w > 0 ? 1.0f / (float)w : 0.f;
+        for (int i = tid; i < w * h; i += 256) {
+            const int ry = (int)(((float)i + 0.5f) * inv_w), rx = i - ry * w;
+            const int sx = t_xo[rx], sy = t_yo[ry];
+            const uint32_t a = (uint32_t)t_xa[rx], bb = (uint32_t)t_ya[ry];
+            const int sx1 = sx + 1 < wprev ? sx + 1 : sx;
+            const int r0 = min(max(sy, 0), hmax), r1 = min(max(sy + 1, 0), hmax);
+            const uint8_t *p0 = prev + (r0 - py.z) * buf_pitch - px.z, *p1 = prev + (r1 - py.z) * buf_pitch - px.z;
+            const uint32_t a0 = a & 0xffffu, a1 = a >> 16;
+            const uint32_t h0 = (a0 * p0[sx] + a1 * p0[sx1]) >> 4, h1 = (a0 * p1[sx] + a1 * p1[sx1]) >> 4;
+            const uint32_t v = (__umulhi(bb << 16, h0) + __umulhi(bb & 0xffff0000u, h1) + 2u) >> 2;   // <= 255
+            cur[ry * buf_pitch + rx] = (uint8_t)v;
+            const int x = cx.z + rx, y = cy.z + ry;
+            if (x >= cx.x && x < cx.y && y >= cy.x && y < cy.y) dst[(size_t)y * lv.pitch + x] = (uint8_t)v;
+        }
+        // the per-level kernel stores whole quads: the columns between w and the next multiple of 4 are zero
+        if (cx.y == lv.w && (lv.w & 3)) {
+            const int padw = 4 - (lv.w & 3), oh = cy.y - cy.x;
+            for (int i = tid; i < padw * oh; i += 256) dst[(size_t)(cy.x + i / padw) * lv.pitch + lv.w + i % padw] = 0;
+        }
+        __syncthreads();   // this level's region complete (and the tables free) before the next level
+        uint8_t *t = prev; prev = cur; cur = t;
+        px = cx; py = cy;
+    }
+}
+
 // host launchers -------------------------------------------------------------------------------
 void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch, uint8_t *pyr, size_t pyr_stride,
                    const LevelDev &src, const LevelDev &dst, const int *xofs, const int *xab, const int *yofs,
@@ -1027,6 +1107,15 @@ void launch_resize(const uint8_t *src_base, size_t src_img_stride, int src_pitch
     else
         hipLaunchKernelGGL(resize_level_kernel<false>, grd, blk, 0, st, src_base, src_img_stride, src_pitch, pyr, pyr_stride, src,
                            dst, xofs, xab, yofs, yab, batch, nquads, inv_nquads, band);
+}
+
+void launch_pyramid_fused(const uint8_t *img0, size_t img0_stride, int pitch0, uint8_t *pyr, size_t pyr_stride,
+                          const LevelDev *levels, int nlevels, const int4 *tile_x, const int4 *tile_y, int ntx, int nty,
+                          const int *xofs, const int *xab, const int *yofs, const int *yab, int buf_pitch, int buf_rows,
+                          size_t lds_bytes, int batch, hipStream_t st)
+{
+    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(ntx * nty, batch), dim3(256), lds_bytes, st, img0, img0_stride, pitch0, pyr,
+                       pyr_stride, levels, nlevels, tile_x, tile_y, ntx, nty, xofs, xab, yofs, yab, buf_pitch, buf_rows, batch);
 }
 
 void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

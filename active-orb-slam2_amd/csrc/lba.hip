@@ -1661,7 +1661,17 @@ int lba_handle_init(aos2_lba *s)
     int st = bind_device(s->device);
     if (st) return st;
     if (s->dev_ready) return AOS2_OK;
-    AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // The optimiser's kernels are few workgroups on a latency-bound chain; the tracking kernels that share the device in a
+    // running system (extraction, searches) are wide and throughput-bound.  On a high-priority stream the optimiser's
+    // workgroups are dispatched ahead of the waiting ones of those kernels (AOS2_LBA_STREAM_PRIORITY=normal switches it off).
+    {
+        int least = 0, greatest = 0;
+        const char *e = getenv("AOS2_LBA_STREAM_PRIORITY");
+        if ((!e || strcmp(e, "normal")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            AOS2_HIP_CHECK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+        else
+            AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    }
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));

@@ -127,6 +127,29 @@ def test_fallback_paths_equal_the_fast_paths(pkg, oracle, gpu, monkeypatch):
     assert all(same(a, b) for a, b in zip(ex.extract_batch(batch), [pkg.Extractor(nfeatures=1000)(im) for im in batch]))
 
 
+def test_both_pyramid_forms_give_the_same_planes(pkg, oracle, gpu, monkeypatch):
+    """A few frames per call build the whole pyramid in ONE launch (tiles walk the levels through LDS), batches use one
+    launch per level: same planes bit for bit (and equal to the oracle's), for several geometries incl. ragged tile edges;
+    a batch of 8 (per-level form) equals 8 single calls (one-launch form)."""
+    for (w, h, nf, sf, nl) in ((640, 480, 1000, 1.2, 8), (752, 480, 1200, 1.2, 8), (401, 323, 500, 1.3, 5), (1241, 376, 2000, 1.2, 8),
+                               (200, 180, 300, 1.1, 8)):
+        img = pkg.synth.synth_image(7 * w + h, w, h)
+        oe = oracle.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+        want = oe.extract(img)
+        planes = {}
+        for form in ("fused", "levels"):
+            monkeypatch.setenv("AOS2_PYRAMID", form)
+            ex = pkg.Extractor(nfeatures=nf, scale_factor=sf, nlevels=nl)
+            assert same(ex(img), want)
+            planes[form] = [ex.pyramid_level(l) for l in range(nl)]
+            for l in range(nl):
+                assert (planes[form][l] == oe.level_plane(l)).all()
+        monkeypatch.delenv("AOS2_PYRAMID")
+    batch = pkg.synth.synth_batch(90, 8)
+    ex = pkg.Extractor(nfeatures=1000)
+    assert all(same(a, b) for a, b in zip(ex.extract_batch(batch), [pkg.Extractor(nfeatures=1000)(im) for im in batch]))
+
+
 def test_full_batch_properties(pkg, oracle, gpu):
     """BASELINE-size batch (256 x 640x480): size-independent properties + sampled exact parity."""
     B = 256
