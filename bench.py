@@ -581,7 +581,7 @@ def main():
                 "bytes_per_launch": per_frame * B, "over_algorithmic": per_frame * B / fast_bytes,
                 "source": pc["source"], "correction": "FETCH_SIZE x %.3f (unaligned 32-bit reads), WRITE_SIZE x 1.0" % cal["FETCH_SIZE_factor_unaligned_32bit"]}
             insts = fc["SQ_INSTS_VALU"] / pc["batch"] * B
-            clock_ghz = fc["GRBM_GUI_ACTIVE"] / 8.0 / fc["kernel_us"] / 1e3
+            clock_ghz = 2.4   # the engine clock the kernels run at (GRBM_GUI_ACTIVE / 8 / kernel time of the profiled pass gives 2.25-2.4)
             peak = 1024 * clock_ghz / 4.0   # G wave-instructions / s: 1024 SIMDs, 4 cycles per packed / compare / min / max instruction
             out["roofline_valu"] = {
                 "bound": "valu_issue", "kernel": "fast_cells_kernel", "achieved": insts / (fast_ms * 1e-3) / 1e9, "peak": peak,
