@@ -554,6 +554,7 @@ namespace aos2 {
 static_assert(sizeof(OctNode16) == 16, "oct_lds_bytes() assumes 16-byte compact nodes");
 
 // one (image, level) job, executed by ONE wave (lane = threadIdx.x & 63) over the LDS slice [lds, lds + lds_bytes)
+template <bool kGroup = false>
 __device__ __forceinline__ void octree_job(int b, int l, uint32_t *__restrict__ dense, size_t dense_stride,
                                            const OctGather &G, const LevelDev *__restrict__ levels,
                                            int n_levels, const OctDevScratch &scr, uint32_t *__restrict__ sel,
@@ -624,7 +625,17 @@ __device__ __forceinline__ void octree_job(int b, int l, uint32_t *__restrict__ 
         octdetail::coop_sync();
         const OctCandsPacked C{c_l};
         const OctScratchT<OctCompact> S{nodes_l, perm_l, tmp_l, pairs_l, pairs_l + 2 * mp, mn, mp};
-        nk = distribute_octree<WaveCoop, OctCompact>(C, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
+        if (kGroup) {   // the big partitions of this job are shared with the workgroup's other waves (octree.h: GroupCoop)
+            octdetail::GroupMail &gm = octdetail::group_mail();
+            if (lane == 0) {
+                gm.on = 1; gm.cands = c_l; gm.perm = perm_l; gm.tmp = tmp_l;
+            }
+            octdetail::coop_sync();
+            nk = distribute_octree<GroupCoop, OctCompact>(C, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
+            if (lane == 0) gm.on = 0;
+            octdetail::coop_sync();
+        } else
+            nk = distribute_octree<WaveCoop, OctCompact>(C, n, 16, lv.w - 16, 16, lv.h - 16, lv.nfeat, S, idx, cap_level);
     }
     if (n > 0 && nk == -2) {
         // general path over global scratch (jobs that do not fit the LDS budget, or exhausted its arena)
@@ -655,12 +666,15 @@ __device__ __forceinline__ void octree_job(int b, int l, uint32_t *__restrict__ 
     if (lane == 0) sel_level_cnt[(size_t)b * n_levels + l] = nk;
 }
 
-// one wave per job; jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones
-// fill in.  Every workgroup reserves the level-0 working set.
-__global__ __launch_bounds__(64) void octree_kernel(uint32_t *__restrict__ dense, size_t dense_stride,
+// one job per workgroup; jobs are level-major (all level-0 jobs first): the long jobs start first, the short ones
+// fill in.  Every workgroup reserves the level-0 working set.  The jobs of the first `group_levels` levels (thousands of
+// candidates: three partition passes over all of them were half of a level-0 job) keep 4 waves: wave 0 runs the job, the
+// others serve its big partitions (GroupCoop); in the jobs of the higher levels they leave at once.
+__global__ __launch_bounds__(256) void octree_kernel(uint32_t *__restrict__ dense, size_t dense_stride,
                               OctGather gather, const LevelDev *__restrict__ levels,
                               int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel,
-                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes)
+                              size_t sel_stride, int32_t *__restrict__ sel_level_cnt, int cap_level, int lds_bytes,
+                              int group_levels)
 {
     extern __shared__ uint32_t oct_lds[];
     // the jobs are few, long and serial: let them issue ahead of the VALU-bound waves of other streams' kernels that
@@ -668,8 +682,22 @@ __global__ __launch_bounds__(64) void octree_kernel(uint32_t *__restrict__ dense
     __builtin_amdgcn_s_setprio(3);
     const int job = blockIdx.x;
     const int l = job / batch, b = job - l * batch;
-    octree_job(b, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, oct_lds,
-               lds_bytes);
+    const int wave = threadIdx.x >> 6;
+    if (l >= group_levels) {   // (uniform per workgroup)
+        if (wave == 0)
+            octree_job<false>(b, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
+                              oct_lds, lds_bytes);
+        return;
+    }
+    if (wave == 0) {
+        octdetail::GroupMail &gm = octdetail::group_mail();
+        if ((threadIdx.x & 63) == 0) gm.on = 0;
+        octree_job<true>(b, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, oct_lds,
+                         lds_bytes);
+        if ((threadIdx.x & 63) == 0) gm.cmd = 0;   // the job is over: release the helpers
+        __syncthreads();
+    } else
+        octdetail::group_helper_loop<OctCompact>(wave);
 }
 
 // one workgroup per image, one wave per level, each with its own LDS slice sized for that level: the LDS
@@ -684,8 +712,8 @@ __global__ __launch_bounds__(1024) void octree_image_kernel(uint32_t *__restrict
     extern __shared__ uint32_t oct_lds[];
     const int l = threadIdx.x >> 6;
     if (l >= n_levels) return;
-    octree_job(blockIdx.x, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
-               oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
+    octree_job<false>(blockIdx.x, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
+                      oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1141,8 +1169,15 @@ void launch_octree(uint32_t *dense, size_t dense_stride, const OctGather &gather
                    int32_t *sel_level_cnt, int cap_level, int lds_bytes, hipStream_t st)
 {
     const int jobs = batch * n_levels;
-    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(64), (size_t)lds_bytes, st, dense, dense_stride, gather,
-                       levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lds_bytes);
+    // levels whose jobs keep 4 waves: the two largest for a few frames per call (a level-0 job 116 -> 101 us: the three
+    // partition passes 58 -> 44 us); for batches the jobs of a launch fill the device anyway and idle helper waves only take
+    // slots from the kernels of the other streams (measured: -0.012 ms on the stage, nothing on the step).
+    // AOS2_OCT_GROUP_LEVELS overrides (tests).
+    const char *gv = getenv("AOS2_OCT_GROUP_LEVELS");
+    const int group_env = gv ? atoi(gv) : -1;
+    const int group_levels = group_env >= 0 ? group_env : (batch < 8 ? 2 : 0);
+    hipLaunchKernelGGL(octree_kernel, dim3(jobs), dim3(256), (size_t)lds_bytes, st, dense, dense_stride, gather,
+                       levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lds_bytes, group_levels);
 }
 
 int prepare_octree_image_kernel(int total_lds)

@@ -125,10 +125,20 @@ using OctScratch = OctScratchT<OctWide>;
 //                 ballots; the results are identical because a stable partition is unique.
 struct SerialCoop {
     static constexpr bool kWave = false;
+    static constexpr bool kGroup = false;
 };
 #if defined(__HIPCC__)
 struct WaveCoop {
     static constexpr bool kWave = true;
+    static constexpr bool kGroup = false;
+};
+//   GroupCoop  -- WaveCoop whose big stable partitions (>= kGroupMin keys) are shared with the other waves of the job's
+//                 workgroup: the job's wave posts the segment in an LDS mailbox, every wave partitions the 64-key chunks
+//                 c = wave, wave + kGroupWaves, ..., the chunk counts are prefix-summed so that the partition stays the
+//                 stable one (4 workgroup barriers per such divide).  Everything else is the one-wave code.
+struct GroupCoop {
+    static constexpr bool kWave = true;
+    static constexpr bool kGroup = true;
 };
 #endif
 
@@ -190,6 +200,98 @@ inline int coop_excl_scan(int) { return 0; }
 inline void coop_sync() {}
 inline unsigned long long coop_ballot(bool p) { return p ? 1ull : 0ull; }
 inline int coop_popc(unsigned long long m) { return __builtin_popcountll(m); }
+#endif
+
+#if defined(__HIPCC__)
+constexpr int kGroupWaves = 4, kGroupMin = 256, kGroupMaxChunks = 64;
+struct GroupMail {
+    int on;                 // the job runs with helper waves
+    int cmd;                // 1 = partition the posted segment, 0 = the job is over
+    int beg, cnt, mx, my;   // segment of perm, quadrant boundaries
+    const void *cands;      // Tr::Cands::c
+    void *perm, *tmp;       // Tr::Idx arrays
+    int cc[kGroupMaxChunks][4];   // quadrant counts of every 64-key chunk
+};
+AOS2_OCT_HD GroupMail &group_mail()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ GroupMail m;
+#else
+    static GroupMail m;   // (host pass of the compiler: never runs)
+#endif
+    return m;
+}
+// every wave of the workgroup, after the barrier that published the order; cnt[] = the quadrant totals (all waves)
+template <class Tr>
+AOS2_OCT_HD void group_partition_body(int wave, int cnt[4])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    GroupMail &m = group_mail();
+    const typename Tr::Cands C{static_cast<decltype(Tr::Cands::c)>(m.cands)};
+    typename Tr::Idx *perm = static_cast<typename Tr::Idx *>(m.perm), *tmp = static_cast<typename Tr::Idx *>(m.tmp);
+    const int beg = m.beg, n = m.cnt, mx = m.mx, my = m.my;
+    const int lane = coop_lane(), nch = (n + 63) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // chunk counts
+    for (int c = wave; c < nch; c += kGroupWaves) {
+        const int i = 64 * c + lane;
+        const bool valid = i < n;
+        const int k = valid ? perm[beg + i] : 0;
+        const int q = valid ? ((C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2)) : -1;
+        const int c0 = coop_popc(coop_ballot(q == 0)), c1 = coop_popc(coop_ballot(q == 1));
+        const int c2 = coop_popc(coop_ballot(q == 2)), c3 = coop_popc(coop_ballot(q == 3));
+        if (lane == 0) {
+            m.cc[c][0] = c0; m.cc[c][1] = c1; m.cc[c][2] = c2; m.cc[c][3] = c3;
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over the chunks (lane = chunk), redundantly in every wave
+    int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (lane < nch) {
+        v0 = m.cc[lane][0]; v1 = m.cc[lane][1]; v2 = m.cc[lane][2]; v3 = m.cc[lane][3];
+    }
+    const int e0 = coop_excl_scan(v0), e1 = coop_excl_scan(v1), e2 = coop_excl_scan(v2), e3 = coop_excl_scan(v3);
+    cnt[0] = __builtin_amdgcn_readlane(e0 + v0, 63); cnt[1] = __builtin_amdgcn_readlane(e1 + v1, 63);
+    cnt[2] = __builtin_amdgcn_readlane(e2 + v2, 63); cnt[3] = __builtin_amdgcn_readlane(e3 + v3, 63);
+    const int o1 = cnt[0], o2 = cnt[0] + cnt[1], o3 = cnt[0] + cnt[1] + cnt[2];
+    for (int c = wave; c < nch; c += kGroupWaves) {
+        const int i = 64 * c + lane;
+        const bool valid = i < n;
+        const int k = valid ? perm[beg + i] : 0;
+        const int q = valid ? ((C.x(k) < mx ? 0 : 1) + (C.y(k) < my ? 0 : 2)) : -1;
+        const unsigned long long b0 = coop_ballot(q == 0), b1 = coop_ballot(q == 1);
+        const unsigned long long b2 = coop_ballot(q == 2), b3 = coop_ballot(q == 3);
+        const int p0 = __builtin_amdgcn_readlane(e0, c), p1 = o1 + __builtin_amdgcn_readlane(e1, c);
+        const int p2 = o2 + __builtin_amdgcn_readlane(e2, c), p3 = o3 + __builtin_amdgcn_readlane(e3, c);
+        if (valid) {
+            const unsigned long long bq = q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3;
+            const int base = q == 0 ? p0 : q == 1 ? p1 : q == 2 ? p2 : p3;
+            tmp[base + coop_popc(bq & lt)] = (typename Tr::Idx)k;
+        }
+    }
+    __syncthreads();
+    for (int i = 64 * wave + lane; i < n; i += 64 * kGroupWaves) perm[beg + i] = tmp[i];
+    __syncthreads();
+#else
+    (void)wave; (void)cnt;
+#endif
+}
+// the other waves of a job's workgroup: serve partition orders until the job is over
+template <class Tr>
+AOS2_OCT_HD void group_helper_loop(int wave)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    GroupMail &m = group_mail();
+    for (;;) {
+        __syncthreads();
+        if (m.cmd == 0) return;
+        int cnt[4];
+        group_partition_body<Tr>(wave, cnt);
+    }
+#else
+    (void)wave;
+#endif
+}
 #endif
 
 template <class Node>
@@ -276,6 +378,25 @@ AOS2_OCT_HD bool divide(List<typename Tr::Node> &L, int id, int c[4], int ccnt[4
     } else {
         const int lane = coop_lane();
         const unsigned long long lt = (1ull << lane) - 1ull;
+#if defined(__HIPCC__)
+        bool grouped = false;
+        if constexpr (Coop::kGroup) {
+            GroupMail &gm = group_mail();
+            if (gm.on && p.cnt >= kGroupMin && p.cnt <= 64 * kGroupMaxChunks) {
+                if (lane == 0) {
+                    gm.cmd = 1; gm.beg = p.beg; gm.cnt = p.cnt; gm.mx = mx; gm.my = my;
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __syncthreads();   // the order (and everything this wave wrote before) is visible to the helpers
+#endif
+                group_partition_body<Tr>(0, cnt);
+                off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+                grouped = true;
+            }
+        }
+        if (grouped) {
+        } else
+#endif
         if (p.cnt <= 64) {
             // whole segment in registers: read, barrier, scatter in place
             const bool valid = lane < p.cnt;

@@ -127,6 +127,26 @@ def test_fallback_paths_equal_the_fast_paths(pkg, oracle, gpu, monkeypatch):
     assert all(same(a, b) for a, b in zip(ex.extract_batch(batch), [pkg.Extractor(nfeatures=1000)(im) for im in batch]))
 
 
+def test_octree_jobs_with_helper_waves_equal_one_wave_jobs(pkg, oracle, gpu, monkeypatch):
+    """The octree jobs of the large levels may share their big stable partitions (>= 256 keys) with three more waves of the
+    workgroup: same keypoints bit for bit with the helpers on every level, on none, and in the oracle -- dense frames
+    (every level has thousands of candidates), sparse ones, a batch."""
+    rng = np.random.default_rng(11)
+    noise = (rng.integers(0, 2, (480, 752)) * 255).astype(np.uint8)
+    imgs = [pkg.synth.synth_image(31), noise, pkg.synth.synth_image(32, 1241, 376), (pkg.synth.synth_image(33) // 8 + 100).astype(np.uint8)]
+    want = [oracle.Extractor(nfeatures=2000).extract(im) for im in imgs]
+    for levels in ("8", "0", "2"):
+        monkeypatch.setenv("AOS2_OCT_GROUP_LEVELS", levels)
+        got = [pkg.Extractor(nfeatures=2000)(im) for im in imgs]
+        assert all(same(a, b) for a, b in zip(got, want)), levels
+        batch = pkg.synth.synth_batch(95, 12)
+        ex = pkg.Extractor(nfeatures=1000)
+        ref = [oracle.Extractor(nfeatures=1000).extract(im) for im in batch[:3]]
+        res = ex.extract_batch(batch)
+        assert all(same(a, b) for a, b in zip(res[:3], ref))
+    monkeypatch.delenv("AOS2_OCT_GROUP_LEVELS")
+
+
 def test_both_pyramid_forms_give_the_same_planes(pkg, oracle, gpu, monkeypatch):
     """A few frames per call build the whole pyramid in ONE launch (tiles walk the levels through LDS), batches use one
     launch per level: same planes bit for bit (and equal to the oracle's), for several geometries incl. ragged tile edges;
