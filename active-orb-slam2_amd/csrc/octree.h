@@ -682,7 +682,27 @@ AOS2_OCT_HD int distribute_octree(const typename Tr::Cands &C, int n, int minX, 
                         const int id = cand ? prv[2 * (j_start - lane) + 1] : 0;
                         const Node p = L.nodes[id];
                         const int pcnt = cand ? (int)p.cnt : 0;
-                        if (coop_ballot(pcnt > 64) != 0ull) break;  // a crowded node: the one-at-a-time loop below takes over
+                        if (coop_ballot(pcnt > 64) != 0ull) {
+                            // The largest node (lane 0: the order is by size) holds more keys than a lane partitions by itself:
+                            // that ONE divide goes the cooperative way, then the batch looks again.  (Leaving the batch for
+                            // good at the first crowded node made a level-0 job divide all its ~50 final nodes one at a time:
+                            // 54 us.)
+                            const int id0 = prv[2 * j_start + 1];
+                            int c[4], ccnt[4], nxt;
+                            if (!divide<Coop, Tr>(L, id0, c, ccnt, nxt, C, perm, tmp)) return -2;
+                            if (ncur + 4 > S.max_pairs) return -2;
+                            for (int q = 0; q < 4; ++q) {
+                                const int cn = ccnt[q];
+                                if (cn > 1) {
+                                    cur[2 * ncur] = cn;
+                                    cur[2 * ncur + 1] = c[q];
+                                    ncur++;
+                                }
+                            }
+                            --j_start;
+                            OCT_COUNT(11, 1);
+                            continue;
+                        }
                         const int hx = (p.x1 - p.x0 + 1) / 2, hy = (p.y1 - p.y0 + 1) / 2;
                         const int mx = p.x0 + hx, my = p.y0 + hy;
                         int cq[4] = {0, 0, 0, 0};
