@@ -287,7 +287,9 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
     const us2_t m1 = __builtin_elementwise_min(h1, h2), m2 = __builtin_elementwise_max(l1, l2);
     const us2_t sec_hi = __builtin_elementwise_max(m1, m2);   // second largest of a,b,c,d
     const us2_t sec_lo = __builtin_elementwise_min(m1, m2);   // second smallest
-    const us2_t bright = __builtin_elementwise_sub_sat(sec_hi, (us2_t)(v + T));
+    // sec_hi > v + T  <=>  (sec_hi -sat T) > v: no sum that could leave 16 bits, so the same code serves operands that are
+    // scaled by 256 (the odd bytes of a dword taken with one AND instead of shift + AND; T scaled alike)
+    const us2_t bright = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(sec_hi, T), v);
     const us2_t dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, T), sec_lo);
     return as_u32(bright) | as_u32(dark);
 }
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         int n1 = 0;
         bool overflowed = false;   // the survivor list was emptied at least once: NMS walks the score map instead
         const us2_t T = {(unsigned short)th, (unsigned short)th};
+        const us2_t TH = {(unsigned short)(th << 8), (unsigned short)(th << 8)};   // for operands scaled by 256 (th <= 255)
         const int nitems = nq * ch;
         for (int g0 = 0; g0 < nitems; g0 += 64) {
             if (n1 > 0 && n1 + 256 > list_cap) {  // one iteration appends <= 256 entries (wave-uniform test)
@@ -413,10 +416,9 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * TP);   // ring pixel 0 (dy=+3)
                 const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
                 const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
-                const uint32_t M = 0x00ff00ffu;
+                const uint32_t M = 0x00ff00ffu, MH = 0xff00ff00u;
                 f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(Eq & M), as_us2(N & M), as_us2(Wq & M), T);
-                f_hi = compass2(as_us2((C >> 8) & M), as_us2((S >> 8) & M), as_us2((Eq >> 8) & M), as_us2((N >> 8) & M),
-                                as_us2((Wq >> 8) & M), T);
+                f_hi = compass2(as_us2(C & MH), as_us2(S & MH), as_us2(Eq & MH), as_us2(N & MH), as_us2(Wq & MH), TH);
             }
             // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
