@@ -64,6 +64,31 @@ def test_lba_stop_flag_and_properties(pkg, oracle, gpu):
     assert close(r3["pose_Tcw"], w3["pose_Tcw"]) and close(r3["point_xyz"], w3["point_xyz"])
 
 
+def test_lba_degenerate_control_flow(pkg, oracle, gpu):
+    """corners of the device-side control flow: no first optimisation (iterations 0: the outlier pass then sees zero
+    residuals), no second one, and a window whose edges ALL leave at the outlier pass (initializeOptimization(0) finds no
+    level-0 edge: the second optimisation never starts) -- same results, iteration counts and polls as the oracle"""
+    prob = pkg.synth.synth_lba_problem(6, n_local=5, n_fixed=3, n_points=250)
+    for it in ((0, 10), (3, 0), (0, 0), (1, 1)):
+        got = pkg.LocalBA().LocalBundleAdjustment(prob, iters=it)
+        want = oracle.lba_solve(prob, iters1=it[0], iters2=it[1])
+        assert got["status"] == 0 and got["iters"] == want["iters"], it
+        assert close(got["pose_Tcw"], want["pose_Tcw"]) and close(got["point_xyz"], want["point_xyz"])
+        assert (got["edge_outlier"] == want["edge_outlier"]).all() and got["polls"] == want["polls"]
+    bad = dict(prob)
+    rng = np.random.default_rng(3)
+    obs = prob["edge_obs"].copy()
+    obs[:, :2] += rng.choice([-1.0, 1.0], (len(obs), 2)).astype(np.float32) * rng.uniform(60, 200, (len(obs), 2)).astype(np.float32)
+    bad["edge_obs"] = obs
+    got = pkg.LocalBA().LocalBundleAdjustment(bad)
+    want = oracle.lba_solve(bad)
+    assert got["iters"][0] == want["iters"][0] and (got["edge_outlier"] == want["edge_outlier"]).all()
+    if want["chi2_trace"][-1] > 1e-18:   # (two edges left: the second optimisation drives chi2 to 1e-25 and stops on rounding noise)
+        assert got["iters"] == want["iters"]
+    assert want["edge_outlier"].mean() > 0.9   # (nearly) everything is an outlier
+    assert close(got["pose_Tcw"], want["pose_Tcw"]) and close(got["point_xyz"], want["point_xyz"])
+
+
 # ---- Optimizer::PoseOptimization (SURVEY §8(f) rank 1) -----------------------------------------
 @pytest.mark.parametrize("cfg", [dict(seed=0), dict(seed=1, stereo_frac=0.0, cfg="tum"), dict(seed=2, n=300, outlier_frac=0.3),
                                  dict(seed=3, n=2000), dict(seed=4, n=8), dict(seed=5, n=2), dict(seed=6, n=40, rot_err=0.05)])
