@@ -119,3 +119,25 @@ def test_chain_tiled_batch_and_window_budget(pkg, gpu, monkeypatch):
     tc2.step()
     with pytest.raises(pkg.AosError):
         tc2.wait()
+
+
+def test_chain_with_blank_frames(pkg, gpu):
+    """a blank / constant current frame has no keypoints: no matches, PoseOptimization returns 0 before touching the pose
+    (src/Optimizer.cc:355-356), the other frames of the batch are unaffected"""
+    scen = pkg.scenario.tracking_scenario(9, 3, n_unique=3)
+    ref = pkg.chain.TrackingChain(scen, n_local=800)
+    ref.step()
+    ref.wait()
+    F = pkg.capi.Frames
+    T_ref, mp_ref, nm_ref = ref.cur.get(F.TCW), ref.cur.get(F.MAP_POINTS), ref.d_nm.cpu().numpy()
+    scen["cur"][1][:] = 0
+    scen["cur"][2][:, :] = scen["cur"][2][0, 0]
+    tc = pkg.chain.TrackingChain(scen, n_local=800)
+    tc.step()
+    tc.wait()
+    n, nm, T, mp = tc.d_n.cpu().numpy(), tc.d_nm.cpu().numpy(), tc.cur.get(F.TCW), tc.cur.get(F.MAP_POINTS)
+    assert n[0] > 500 and n[1] == 0 and n[2] == 0
+    assert (nm[:, 1:] == 0).all() and (nm[:, 0] == nm_ref[:, 0]).all() and nm[3, 0] > 100
+    for b in (1, 2):
+        assert np.array_equal(T[b], scen["Tcw_guess"][b].reshape(16)) and (mp[b] == -1).all()
+    assert T[0].tobytes() == T_ref[0].tobytes() and (mp[0] == mp_ref[0]).all()
