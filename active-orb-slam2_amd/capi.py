@@ -150,6 +150,8 @@ def lib():
             L.aos2_frames_wait.argtypes = [vp]
             L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
             L.aos2_frames_set_pose.argtypes = [vp, vp]
+            L.aos2_frames_set_distortion.argtypes = [vp, cf, cf, cf, cf, cf]
+            L.aos2_frame_image_bounds.argtypes = [ci, ci, cf, cf, cf, cf, vp, vp]
             L.aos2_frames_set_map_points.argtypes = [vp, vp, vp, vp]
             L.aos2_frames_get.argtypes = [vp, ci, vp, C.c_size_t]
             L.aos2_frames_search_by_projection_last.argtypes = [vp, vp, vp, cf, ci, ci, vp]
@@ -944,8 +946,17 @@ def map_points_dev(n, pos, desc, has_obs, normal=0, min_dist=0, max_dist=0):
     return t
 
 
+def frame_image_bounds(w, h, fx, fy, cx, cy, dist):
+    """Frame::ComputeImageBounds (src/Frame.cc:463-493) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)"""
+    d = np.zeros(5, np.float32)
+    d[: len(dist)] = np.asarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    _check(lib().aos2_frame_image_bounds(int(w), int(h), float(fx), float(fy), float(cx), float(cy), _p(d), _p(out)))
+    return out
+
+
 class Frames:
-    MAP_POINTS, OUTLIER, TCW, U_RIGHT, DEPTH, GRID_OFF, GRID_IDX = range(7)
+    MAP_POINTS, OUTLIER, TCW, U_RIGHT, DEPTH, GRID_OFF, GRID_IDX, KEYS_UN_X, KEYS_UN_Y = range(9)
 
     def __init__(self, batch, cap, device=0):
         self.L = lib()
@@ -967,6 +978,11 @@ class Frames:
     def set_pose(self, d_Tcw):
         _check(self.L.aos2_frames_set_pose(self.h, d_Tcw))
 
+    def set_distortion(self, dist):
+        """mDistCoef = k1 k2 p1 p2 k3 for the following build() calls"""
+        d = list(dist) + [0.0] * (5 - len(dist))
+        _check(self.L.aos2_frames_set_distortion(self.h, *[float(v) for v in d[:5]]))
+
     def set_map_points(self, mp, table, outlier=None):
         mp = np.ascontiguousarray(mp, np.int32).reshape(self.batch, self.cap)
         if outlier is not None:
@@ -976,7 +992,8 @@ class Frames:
     def get(self, what):
         B, cap = self.batch, self.cap
         shape, dt = {0: ((B, cap), np.int32), 1: ((B, cap), np.uint8), 2: ((B, 16), np.float32), 3: ((B, cap), np.float32),
-                     4: ((B, cap), np.float32), 5: ((B, 64 * 48 + 1), np.int32), 6: ((B, cap), np.int32)}[what]
+                     4: ((B, cap), np.float32), 5: ((B, 64 * 48 + 1), np.int32), 6: ((B, cap), np.int32), 7: ((B, cap), np.float32),
+                     8: ((B, cap), np.float32)}[what]
         a = np.zeros(shape, dt)
         _check(self.L.aos2_frames_get(self.h, what, _p(a), a.nbytes))
         return a

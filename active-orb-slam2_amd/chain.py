@@ -36,6 +36,8 @@ class TrackingChain:
         self.d_n = t.zeros((B,), dtype=t.int32, device=self.dev)
         self.d_nm = t.zeros((4, B), dtype=t.int32, device=self.dev)   # nmatches last / inliers 1 / nmatches local / inliers 2
         self.cur = capi.Frames(B, cap, device)
+        if scen.get("dist") is not None:
+            self.cur.set_distortion(scen["dist"])
         self._setup_last()
 
     # ---- LastFrame batch, MapPoint table and local lists (setup, untimed): built from the extractor's keypoints
@@ -61,6 +63,8 @@ class TrackingChain:
         self.ex_setup.extract_batch_device(self.d_last_img.data_ptr(), B, W, H, W, W * H, self.dl_kps.data_ptr(), self.dl_desc.data_ptr(),
                                            cap, self.dl_n.data_ptr())
         self.last = capi.Frames(B, cap, self.device)
+        if scen.get("dist") is not None:
+            self.last.set_distortion(scen["dist"])
         s = scen
         self.last.build(self.ex_setup, self.dl_kps.data_ptr(), self.dl_desc.data_ptr(), self.dl_n.data_ptr(), W, H,
                         self.d_last_depth.data_ptr(), float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))

@@ -29,10 +29,41 @@ struct FramesDev {
     const float *scale_factors, *inv_level_sigma2;   // [n_levels] mvScaleFactors, mvInvLevelSigma2
     float min_x, min_y, max_x, max_y, grid_w_inv, grid_h_inv;   // mnMinX .. mfGridElementHeightInv
     float fx, fy, cx, cy, mb, mbf, log_scale_factor;
+    float dist[5];                 // mDistCoef: k1 k2 p1 p2 k3 (all 0: mvKeysUn = mvKeys)
+    int has_dist;                  // mDistCoef.at<float>(0) != 0 (the reference's test, src/Frame.cc:435)
 };
 
 // the members of MapPoint the per-frame path reads (include/MapPoint.h): GetWorldPos, GetDescriptor, Observations() > 0,
 // GetNormal, GetMin/MaxDistanceInvariance
+// cv::undistortPoints(p, p, K, distCoef, noArray(), K) on one CV_32FC2 point, as Frame::UndistortKeyPoints /
+// Frame::ComputeImageBounds use it (src/Frame.cc:433-493).  OpenCV 3.2 imgproc/undistort.cpp, cvUndistortPoints: camera
+// matrix and coefficients widened to double, 5 fixed-point iterations of the inverse of the radial (k1 k2 k3) +
+// tangential (p1 p2) model, then P R = K applied, the result rounded to float.  The operation sequence is the library's
+// (the terms of the unused higher-order coefficients are kept as products with 0: they decide the sign of a zero); host
+// and device run this same function (-ffp-contract=off).
+__host__ __device__ inline void undistort_point(float fx_f, float fy_f, float cx_f, float cy_f, const float *k_f, float xin, float yin,
+                                                float &xout, float &yout)
+{
+    const double fx = (double)fx_f, fy = (double)fy_f, cx = (double)cx_f, cy = (double)cy_f;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = (double)k_f[0], k1 = (double)k_f[1], k2 = (double)k_f[2], k3 = (double)k_f[3], k4 = (double)k_f[4];
+    double x = ((double)xin - cx) * ifx, y = ((double)yin - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0. * r2 + 0. * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx;
+    const double yy = 0. * x + fy * y + cy;
+    const double ww = 1. / (0. * x + 0. * y + 1.);
+    xout = (float)(xx * ww);
+    yout = (float)(yy * ww);
+}
+
 struct MapPointsDev {
     int n;
     const float *pos;        // n x 3
@@ -58,5 +89,6 @@ struct aos2_frames {
     aos2::DevBuf<uint64_t> pool;     // candidate entries (8 B each)
     aos2::DevBuf<uint8_t> pose_mem;  // PoseOptimization problem arrays
     aos2::PinnedBuf<uint8_t> h_io;   // small page-locked staging (poses, counts)
+    float dist[5] = {0, 0, 0, 0, 0};   // mDistCoef for the next aos2_frames_build (aos2_frames_set_distortion)
     float last_ms[4] = {};
 };

@@ -20,7 +20,7 @@ def _rot(axis, ang):
     return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
 
 
-def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10):
+def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10, dist=None):
     """Images, depth maps and poses of `batch` (LastFrame, CurrentFrame) pairs (`n_unique` distinct ones, tiled)."""
     c = synth.CONFIGS[cfg]
     W, H = c["w"], c["h"]
@@ -71,7 +71,8 @@ def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | N
         E[:3, 3] = rng.normal(0, 2.0 * Z[u] / float(fx), 3)
         Tguess[u] = E @ Tcw[u]
     idx = np.arange(batch) % nu
-    return dict(cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
+    # dist: mDistCoef (k1 k2 p1 p2 k3) the frames are declared to have (the images themselves are not warped: a parity scenario)
+    return dict(dist=None if dist is None else np.asarray(dist, np.float32), cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
                 last=last, cur=cur, old=old, depth_cur=depth_cur, depth_last=depth_last, shift=shift, shift_old=shift_old, Z=Z,
                 Tlw=Tlw.astype(np.float32), Tcw_true=Tcw.astype(np.float32), Tcw_guess=Tguess.astype(np.float32))
 

@@ -656,6 +656,13 @@ int aos2_frames_wait(aos2_frames_t *f);
 int aos2_frames_build(aos2_frames_t *f, aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps,
                       const uint8_t *d_desc, const int32_t *d_n, int cap, int w, int h, const float *d_depth,
                       int depth_stride, size_t depth_image_stride, float fx, float fy, float cx, float cy, float mbf);
+/* mDistCoef (k1 k2 p1 p2 k3) for the following aos2_frames_build calls: with k1 != 0 (the reference's test, src/Frame.cc:435,
+ * :467) mvKeysUn = cv::undistortPoints(mvKeys, K, mDistCoef, noArray(), K) and the image bounds are the undistorted corners
+ * (Frame::UndistortKeyPoints / ComputeImageBounds :433-493); the depth map is still read at mvKeys (:678-683).  Default: 0. */
+int aos2_frames_set_distortion(aos2_frames_t *f, float k1, float k2, float p1, float p2, float k3);
+/* void Frame::ComputeImageBounds(const cv::Mat &imLeft)  src/Frame.cc:463-493 (once per camera: four points, host):
+ * bounds4 = mnMinX mnMaxX mnMinY mnMaxY for a w x h image; dist5 = k1 k2 p1 p2 k3 */
+int aos2_frame_image_bounds(int w, int h, float fx, float fy, float cx, float cy, const float *dist5, float *bounds4);
 /* Frame::SetPose for every frame: d_Tcw = [batch][16] float32 in device memory (mVelocity * mLastFrame.mTcw, Tracking.cc:975).
  * Independent of aos2_frames_build (which leaves mTcw alone): called before it, the copy runs beside the extraction. */
 int aos2_frames_set_pose(aos2_frames_t *f, const float *d_Tcw);
@@ -671,6 +678,8 @@ int aos2_frames_set_map_points(aos2_frames_t *f, const int32_t *mp, const uint8_
 #define AOS2_FRAMES_DEPTH 4      /* float [batch][cap]  mvDepth */
 #define AOS2_FRAMES_GRID_OFF 5   /* int32 [batch][64 * 48 + 1]  mGrid as CSR */
 #define AOS2_FRAMES_GRID_IDX 6   /* int32 [batch][cap] */
+#define AOS2_FRAMES_KEYS_UN_X 7  /* float [batch][cap]  mvKeysUn[i].pt.x */
+#define AOS2_FRAMES_KEYS_UN_Y 8  /* float [batch][cap]  mvKeysUn[i].pt.y */
 int aos2_frames_get(aos2_frames_t *f, int what, void *dst, size_t bytes);
 
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)

@@ -18,15 +18,26 @@ def frame_from_extraction(kps, desc, depth_img, scen, scale_factors, inv_sigma2)
     """Frame::Frame after ExtractORB: mvKeysUn = mvKeys (no distortion), ComputeStereoFromRGBD, AssignFeaturesToGrid"""
     W, H = scen["w"], scen["h"]
     kx, ky = np.ascontiguousarray(kps["x"], np.float32), np.ascontiguousarray(kps["y"], np.float32)
-    ur, dp = O.stereo_from_rgbd(kx, ky, kx, depth_img, scen["mbf"])
-    gwi, ghi = np.float32(64) / np.float32(W), np.float32(48) / np.float32(H)
-    goff, gidx = O.assign_features_to_grid(kx, ky, 0.0, 0.0, gwi, ghi)
+    ux, uy = kx, ky
+    min_x, max_x, min_y, max_y = np.float32(0), np.float32(W), np.float32(0), np.float32(H)
+    dist = scen.get("dist")
+    if dist is not None and dist[0] != 0:   # Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:433-493)
+        K = (scen["fx"], scen["fy"], scen["cx"], scen["cy"])
+        u = O.undistort_points(np.stack([kx, ky], 1), *K, dist)
+        ux, uy = np.ascontiguousarray(u[:, 0]), np.ascontiguousarray(u[:, 1])
+        c = O.undistort_points(np.array([[0, 0], [W, 0], [0, H], [W, H]], np.float32), *K, dist)
+        min_x, max_x = min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0])
+        min_y, max_y = min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])
+    ur, dp = O.stereo_from_rgbd(kx, ky, ux, depth_img, scen["mbf"])
+    gwi, ghi = np.float32(64) / np.float32(max_x - min_x), np.float32(48) / np.float32(max_y - min_y)
+    goff, gidx = O.assign_features_to_grid(ux, uy, min_x, min_y, gwi, ghi)
     gi = np.zeros(max(len(kx), 1), np.int32)
     gi[: len(gidx)] = gidx
+    kx, ky = ux, uy   # the searches and the pose optimisation work on mvKeysUn
     return dict(n_f=len(kx), desc_f=np.ascontiguousarray(desc), kp_x=kx, kp_y=ky, kp_octave=np.ascontiguousarray(kps["octave"], np.int32),
                 kp_angle=np.ascontiguousarray(kps["angle"], np.float32), u_right=ur.copy(), depth=dp.copy(),
                 scale_factors=np.ascontiguousarray(scale_factors, np.float32), inv_sigma2=np.ascontiguousarray(inv_sigma2, np.float32),
-                n_levels=len(scale_factors), min_x=np.float32(0), min_y=np.float32(0), max_x=np.float32(W), max_y=np.float32(H),
+                n_levels=len(scale_factors), min_x=np.float32(min_x), min_y=np.float32(min_y), max_x=np.float32(max_x), max_y=np.float32(max_y),
                 grid_w_inv=gwi, grid_h_inv=ghi, grid_off=goff, grid_idx=gi, f_mp_state=np.zeros(max(len(kx), 1), np.uint8))
 
 

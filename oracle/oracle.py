@@ -427,6 +427,19 @@ def stereo_from_rgbd(kp_x, kp_y, kpun_x, depth_img, mbf):
     return ur[: len(kp_x)], dp[: len(kp_x)]
 
 
+def undistort_points(xy, fx, fy, cx, cy, dist):
+    """cv::undistortPoints(xy, K, dist, noArray(), K) (Frame::UndistortKeyPoints / ComputeImageBounds, src/Frame.cc:433-493);
+    dist = k1 k2 p1 p2 k3"""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    d = np.zeros(5, np.float32)
+    d[: len(dist)] = np.asarray(dist, np.float32)
+    out = np.zeros_like(xy)
+    L = lib()
+    L.orc_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_undistort_points(len(xy), _p(xy), np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), _p(d), _p(out))
+    return out
+
+
 def is_in_frustum(f: dict, p: dict, viewing_cos_limit=0.5):
     """Frame::isInFrustum (src/Frame.cc:298-354) for all points of p against frame view f -> dict of the track members"""
     keep = []

@@ -1098,3 +1098,36 @@ void orc_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const flo
         }
     }
 }
+
+/* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) for CV_32FC2 points, as Frame::UndistortKeyPoints and
+ * Frame::ComputeImageBounds call it (src/Frame.cc:433-493).  OpenCV (3.2, un-vendored: CMakeLists.txt:33-39)
+ * imgproc/undistort.cpp cvUndistortPoints: camera matrix and coefficients widened to double, 5 fixed-point iterations of
+ * the inverse of the radial (k1 k2 k3) + tangential (p1 p2) model, then P * R = K applied: xx = fx x + cx with
+ * ww = 1 / (0 x + 0 y + 1).  k = k1 k2 p1 p2 k3 (mDistCoef, float32).  Results are rounded to float. */
+void orc_undistort_points(int n, const float *xy_in, float fx_f, float fy_f, float cx_f, float cy_f, const float *k_f,
+                          float *xy_out)
+{
+    const double fx = (double)fx_f, fy = (double)fy_f, cx = (double)cx_f, cy = (double)cy_f;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = (double)k_f[0], k1 = (double)k_f[1], k2 = (double)k_f[2], k3 = (double)k_f[3], k4 = (double)k_f[4];
+    for (int i = 0; i < n; ++i) {
+        double x = (double)xy_in[2 * i], y = (double)xy_in[2 * i + 1];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            /* (k[5..7] = 0: the rational numerator is 1 + ((0 r2 + 0) r2 + 0) r2 = 1) */
+            const double icdist = (1 + ((0. * r2 + 0.) * r2 + 0.) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+            const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0. * r2 + 0. * r2 * r2;
+            const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0. * r2 + 0. * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = fx * x + 0. * y + cx;
+        const double yy = 0. * x + fy * y + cy;
+        const double ww = 1. / (0. * x + 0. * y + 1.);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}

@@ -212,6 +212,8 @@ int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen
 
 int orc_assign_features_to_grid(int n, const float *kp_x, const float *kp_y, float min_x, float min_y, float grid_w_inv,
                                 float grid_h_inv, int32_t *grid_off, int32_t *grid_idx);
+/* cv::undistortPoints(src, dst, K, dist, noArray(), K) on n float points (x, y interleaved); k = k1 k2 p1 p2 k3 */
+void orc_undistort_points(int n, const float *xy_in, float fx, float fy, float cx, float cy, const float *k, float *xy_out);
 void orc_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x, const float *depth_img,
                           int stride, float mbf, float *u_right, float *depth);
 void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float min_y, float max_y, int n_levels,

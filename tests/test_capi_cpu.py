@@ -125,6 +125,17 @@ def test_matcher_rejects_inconsistent_inputs_before_any_upload(pkg):
     assert e.value.code == capi.AOS2_ERR_ARG and "last_octave" in str(e.value)
 
 
+def test_image_bounds_host_equals_oracle(pkg, oracle):
+    """Frame::ComputeImageBounds: the library's host routine (the function the device also runs on the keypoints) against
+    the oracle's cv::undistortPoints restatement, bit for bit; zero distortion = the image"""
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989
+    for dist in ([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], [0.05, 0.0, 0.0, 0.0, 0.0], [-0.28, 0.07, 0.0002, 1e-5, 0.0]):
+        c = oracle.undistort_points(np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32), fx, fy, cx, cy, dist)
+        want = np.array([min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])], np.float32)
+        assert pkg.capi.frame_image_bounds(640, 480, fx, fy, cx, cy, dist).tobytes() == want.tobytes()
+    assert (pkg.capi.frame_image_bounds(640, 480, fx, fy, cx, cy, [0, 0.1, 0, 0, 0]) == np.array([0, 640, 0, 480], np.float32)).all()
+
+
 def test_descriptor_distance_host(pkg, oracle):
     rng = np.random.default_rng(0)
     for _ in range(100):
