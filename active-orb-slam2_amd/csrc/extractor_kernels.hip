@@ -300,9 +300,9 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
 //   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords,
 //      two pixels per packed-u16 op; survivors are ballot-compacted into an LDS list
 //   2. exact score for the survivors (dense lanes); corners (S >= th) go to the score map
-//   3. NMS of the corners against the score map; kept ones to a second list
+//   3. NMS of the corners against the score map; kept ones to the cell's slots.  Every list is built in row-major
+//      order (= cv::FAST's emission order) and every compaction is stable, so nothing is sorted
 //   4. empty after NMS and th == iniThFAST -> repeat 1-3 with minThFAST (:812-816)
-//   5. rank sort of the kept list by (row, col) = cv::FAST's emission order, write the cell's slots
 __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restrict__ img0,
                                                         size_t img0_stride, int pitch0,
                                                         const uint8_t *__restrict__ pyr,
@@ -323,10 +323,6 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     uint8_t *smap = smem + tile_bytes;                         // (ch+2) x SP, 1-px zero border
     // survivors (py<<6 | px): list_cap entries; a cell that produces more is scored in instalments (below)
     uint16_t *list1 = reinterpret_cast<uint16_t *>(smap + smap_bytes);
-    // kept corners ((py<<6|px)<<8 | score) reuse the tile: NMS reads only the score map, and when the
-    // minThFAST pass needs the tile again the first pass has kept nothing, i.e. written nothing here.
-    // <= ceil(cw/2)*ceil(ch/2) entries (NMS survivors are >= 2 px apart) always fit (cw+8)*(ch+6) bytes.
-    uint32_t *list3 = reinterpret_cast<uint32_t *>(tile);
     (void)keep_cap;
 
     // Image = blockIdx.x (fastest in dispatch order, padded to a multiple of 8), cell = blockIdx.y: consecutive
@@ -371,21 +367,39 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         }
     }
     const int SH = ch + 2;
+#if defined(AOS2_FAST_ABL) && AOS2_FAST_ABL == 1
+    __syncthreads();
+    if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = tile[5] == 0x7ffffff;
+    return;
+#endif
     uint32_t *my_slots = slots + (size_t)b * slot_stride + cell.slot_off;
     int th = ini_th;
     int nkept = 0;
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = lane; i < (SH * SP + 3) >> 2; i += 64) reinterpret_cast<uint32_t *>(smap)[i] = 0;
         __syncthreads();
-        // ---- 2. exact scores of the survivors (called once per pass, or per instalment on overflow)
+        // ---- 2. exact scores of the survivors (called once per pass, or per instalment on overflow).  Corners (S >= th)
+        // go to the score map and, compacted IN PLACE (the write index never passes the read index; one wave, LDS
+        // operations in program order), to the head of the list: the list stays in row-major order.
+        int nc = 0;
         auto score_survivors = [&](int n) {
-            for (int i = lane; i < n; i += 64) {
-                const int pos = list1[i];
-                const int py = pos >> 6, px = pos & 63;
-                if (px < cw) {
-                    const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
-                    if (S >= th) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+            nc = 0;   // (instalments: the list is refilled from its start, and NMS walks the score map instead)
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                bool corner = false;
+                int pos = 0;
+                if (i < n) {
+                    pos = list1[i];
+                    const int py = pos >> 6, px = pos & 63;
+                    if (px < cw) {
+                        const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+                        corner = S >= th;
+                        if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+                    }
                 }
+                const unsigned long long bc = __ballot(corner);
+                if (corner) list1[nc + lanes_below(bc)] = (uint16_t)pos;
+                nc += __popcll(bc);
             }
         };
         // ---- 1. compass pre-test (a 9-arc contains >= 2 of the 4 compass pixels)
@@ -426,22 +440,37 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             const bool p2 = (f_lo >> 16) != 0, p3 = (f_hi >> 16) != 0;
             const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
             if ((b0 | b1 | b2 | b3) == 0ull) continue;
-            const int base = (py << 6) | x0;
-            if (p0) list1[n1 + lanes_below(b0)] = (uint16_t)base;
-            n1 += __popcll(b0);
-            if (p1) list1[n1 + lanes_below(b1)] = (uint16_t)(base + 1);
-            n1 += __popcll(b1);
-            if (p2) list1[n1 + lanes_below(b2)] = (uint16_t)(base + 2);
-            n1 += __popcll(b2);
-            if (p3) list1[n1 + lanes_below(b3)] = (uint16_t)(base + 3);
-            n1 += __popcll(b3);
+            // row-major list order (= cv::FAST's emission order, kept through scoring and NMS, so nothing is sorted
+            // later): a lane's entries follow those of all lower lanes
+            const int pos0 = (py << 6) | x0;
+            int at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, (uint32_t)n1));
+            at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, (uint32_t)at));
+            at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, (uint32_t)at));
+            at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, (uint32_t)at));
+            if (p0) list1[at] = (uint16_t)pos0;
+            at += p0;
+            if (p1) list1[at] = (uint16_t)(pos0 + 1);
+            at += p1;
+            if (p2) list1[at] = (uint16_t)(pos0 + 2);
+            at += p2;
+            if (p3) list1[at] = (uint16_t)(pos0 + 3);
+            n1 += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         }
         __syncthreads();
+#if defined(AOS2_FAST_ABL) && AOS2_FAST_ABL == 2
+        if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = (n1 + list1[n1 >> 1]) == 0x7ffffff;
+        return;
+#endif
         score_survivors(n1);
         __syncthreads();
-        // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell)
+#if defined(AOS2_FAST_ABL) && AOS2_FAST_ABL == 3
+        if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = (n1 + smap[SP + 5]) == 0x7ffffff;
+        return;
+#endif
+        // ---- 3. NMS (strictly greater than the 8 neighbours inside the cell) over the corners, in row-major order: the
+        // kept ones go straight to the cell's slots (a pass that keeps nothing writes nothing)
         nkept = 0;
-        const int n3 = overflowed ? cw * ch : n1;   // overflow: every pixel of the cell is a candidate position
+        const int n3 = overflowed ? cw * ch : nc;   // overflow: every pixel of the cell is a candidate position
         for (int i0 = 0; i0 < n3; i0 += 64) {
             const int i = i0 + lane;
             bool keep = false;
@@ -461,22 +490,18 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                            sc > m[SP - 1] && sc > m[SP] && sc > m[SP + 1];
             }
             const unsigned long long bk = __ballot(keep);
-            if (keep) list3[nkept + lanes_below(bk)] = ((uint32_t)pos << 8) | (uint32_t)sc;
+            if (keep) {
+                const uint32_t xr = (uint32_t)(cell.vx0 - 16) + ((uint32_t)pos & 63), yr = (uint32_t)(cell.vy0 - 16) + ((uint32_t)pos >> 6);
+                my_slots[nkept + lanes_below(bk)] = xr | (yr << 12) | ((uint32_t)sc << 24);
+            }
             nkept += __popcll(bk);
         }
+#if defined(AOS2_FAST_ABL) && AOS2_FAST_ABL == 4
+        break;
+#endif
         if (nkept > 0 || th == min_th) break;
         th = min_th;  // vKeysCell.empty() -> retry with minThFAST (:812-816)
         __syncthreads();
-    }
-    __syncthreads();
-    // ---- 5. emission order: rank by position (keys are unique)
-    for (int i = lane; i < nkept; i += 64) {
-        const uint32_t key = list3[i];
-        int rank = 0;
-        for (int j = 0; j < nkept; ++j) rank += list3[j] < key;
-        const uint32_t pos = key >> 8;
-        const uint32_t xr = (uint32_t)(cell.vx0 - 16) + (pos & 63), yr = (uint32_t)(cell.vy0 - 16) + (pos >> 6);
-        my_slots[rank] = xr | (yr << 12) | ((key & 255u) << 24);
     }
     if (lane == 0) cell_cnt[(size_t)b * n_cells + cell_id] = nkept;
 }
