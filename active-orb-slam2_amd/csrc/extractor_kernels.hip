@@ -347,22 +347,25 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
 
     // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c.  Lane grid (rows x ndw dwords) fixed once per wave;
     // up to 8 row steps are requested together before the first LDS write.
+    // (24-bit multiplies throughout: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter of it; every index here is far
+    // below 2^24.  The uniform parts of the addresses stay in scalar registers.)
     {
         const int nrs = max(1, (int)((64u * cell.inv_ndw) >> 16));      // rows per step = 64 / ndw (cells are < 64 px wide: ndw <= 18)
-        const int rs = (int)(((uint32_t)lane * cell.inv_ndw) >> 16), c = lane - rs * ndw;
+        const int rs = (int)(__umul24((uint32_t)lane, cell.inv_ndw) >> 16), c = lane - (int)__umul24((uint32_t)rs, (uint32_t)ndw);
         const int nrows = ch + 6;
         if (rs < nrs) {
-            const uint8_t *src = plane + (size_t)(cell.vy0 - 3 + rs) * lv.pitch + (cell.vx0 - 4) + 4 * c;
-            uint8_t *dst = tile + rs * TP + 4 * c;
+            const uint8_t *sbase = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);   // uniform
+            const uint32_t soff = __umul24((uint32_t)rs, (uint32_t)lv.pitch) + 4u * (uint32_t)c;
+            uint32_t doff = __umul24((uint32_t)rs, (uint32_t)TP) + 4u * (uint32_t)c;
             const uint32_t sstep = (uint32_t)(nrs * lv.pitch), dstep = (uint32_t)(nrs * TP);
-            for (int r0 = rs; r0 < nrows; r0 += 8 * nrs, src += 8 * (size_t)sstep, dst += 8 * dstep) {
+            for (int r0 = 0; r0 < nrows; r0 += 8 * nrs, sbase += 8 * (size_t)sstep, doff += 8 * dstep) {
                 uint32_t t[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (r0 + u * nrs < nrows) t[u] = load_u32_unaligned(src + u * sstep);
+                    if (rs < nrows - r0 - u * nrs) t[u] = load_u32_unaligned(sbase + (size_t)u * sstep + soff);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (r0 + u * nrs < nrows) *reinterpret_cast<uint32_t *>(dst + u * dstep) = t[u];
+                    if (rs < nrows - r0 - u * nrs) *reinterpret_cast<uint32_t *>(tile + doff + (uint32_t)u * dstep) = t[u];
             }
         }
     }
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     int th = ini_th;
     int nkept = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        for (int i = lane; i < (SH * SP + 3) >> 2; i += 64) reinterpret_cast<uint32_t *>(smap)[i] = 0;
+        for (int i = lane; i < (SH * SP + 15) >> 4; i += 64) reinterpret_cast<uint4 *>(smap)[i] = make_uint4(0, 0, 0, 0);   // (16-byte padded region)
         __syncthreads();
         // ---- 2. exact scores of the survivors (called once per pass, or per instalment on overflow).  Corners (S >= th)
         // go to the score map and, compacted IN PLACE (the write index never passes the read index; one wave, LDS
@@ -392,9 +395,9 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                     pos = list1[i];
                     const int py = pos >> 6, px = pos & 63;
                     if (px < cw) {
-                        const int S = fast_score_full(tile + (py + 3) * TP + 4 + px, TP);
+                        const int S = fast_score_full(tile + __umul24((uint32_t)(py + 3), (uint32_t)TP) + 4 + px, TP);
                         corner = S >= th;
-                        if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)S;
+                        if (corner) smap[__umul24((uint32_t)(py + 1), (uint32_t)SP) + px + 1] = (uint8_t)S;
                     }
                 }
                 const unsigned long long bc = __ballot(corner);
@@ -420,9 +423,9 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             uint32_t f_lo = 0, f_hi = 0;
             int py = 0, qd = 0;
             if (g < nitems) {
-                py = (int)(((uint32_t)g * cell.inv_nq) >> 16);
-                qd = g - py * nq;
-                const uint8_t *row = tile + (py + 3) * TP + 4 + 4 * qd;
+                py = (int)(__umul24((uint32_t)g, cell.inv_nq) >> 16);
+                qd = g - (int)__umul24((uint32_t)py, (uint32_t)nq);
+                const uint8_t *row = tile + __umul24((uint32_t)(py + 3), (uint32_t)TP) + 4 + 4 * qd;
                 const uint32_t C = *reinterpret_cast<const uint32_t *>(row);
                 const uint32_t Wd = *reinterpret_cast<const uint32_t *>(row - 4);
                 const uint32_t Ed = *reinterpret_cast<const uint32_t *>(row + 4);
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                     pos = (yy << 6) | (i - yy * cw);
                 }
                 const int py = pos >> 6, px = pos & 63;
-                const uint8_t *m = smap + (py + 1) * SP + px + 1;
+                const uint8_t *m = smap + __umul24((uint32_t)(py + 1), (uint32_t)SP) + px + 1;
                 sc = m[0];
                 if (sc > 0)
                     keep = sc > m[-1] && sc > m[1] && sc > m[-SP - 1] && sc > m[-SP] && sc > m[-SP + 1] &&
@@ -918,11 +921,13 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     uint32_t pre[9];
     auto prefetch = [&](const Slot &s) {
         if (s.interior && st_rs < 5) {
-            const uint8_t *src = s.plane + (size_t)(s.ky - PR + st_rs) * s.pitch + (s.kx - PR) + 4 * st_c;
-            const size_t step = (size_t)5 * s.pitch;
+            // uniform base in scalar registers + one 32-bit lane offset (24-bit multiply): no 64-bit vector arithmetic
+            const uint8_t *base = s.plane + (size_t)(s.ky - PR) * s.pitch + (s.kx - PR);
+            const uint32_t loff = __umul24((uint32_t)st_rs, (uint32_t)s.pitch) + 4u * (uint32_t)st_c;
+            const uint32_t step = 5u * (uint32_t)s.pitch;
 #pragma unroll
             for (int t = 0; t < 9; ++t)
-                if (t < 8 || st_rs < 3) pre[t] = load_u32_unaligned(src + t * step);
+                if (t < 8 || st_rs < 3) pre[t] = load_u32_unaligned(base + (loff + (uint32_t)t * step));
         }
     };
     Slot cur = locate(0);
@@ -953,7 +958,12 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         wave_lds_phase();
         // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
         int m10 = 0, m01 = 0;
+#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 1
+        m10 = cur.kx; m01 = cur.ky;
+        if (false) {
+#else
         if (ic_rs < 7) {
+#endif
             // patch dwords 1..9 cover columns 4..39.  With the precomputed byte mask: sum(u*I) over the dword
             // = (4*dj - 21) * S + T, S = sum of the kept bytes, T = sum of k * byte_k
             const int c0 = 4 * ic_dj - PR;
@@ -974,6 +984,9 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t >= hrounds) continue;   // uniform
+#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 2
+            continue;
+#endif
             // (the per-round addresses are loop-invariant and stay in registers: 76 VGPRs = 6 waves/SIMD measured
             // faster, 0.313 ms, than recomputing them per slot at 7 waves, 0.328 ms -- the kernel is VALU-bound)
             const uint32_t it = (hit2[t >> 1] >> (16 * (t & 1))) & 0xffffu;
@@ -998,9 +1011,13 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         // ---- vertical 7-tap pass over the whole 37x37 tile: item = (column x, 8 output rows); two taps per dot2
         {
             uint8_t *vb = patch;   // the raw patch is dead
+#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 3
+            for (int id = lane; id < 0; id += 64) {
+#else
             for (int id = lane; id < BW * 5; id += 64) {
-                const int seg = (id * 1772) >> 16, x = id - BW * seg;   // id / 37
-                const uint32_t *src = hbT + x * HTP + 4 * seg;
+#endif
+                const int seg = (int)(__umul24((uint32_t)id, 1772u) >> 16), x = id - BW * seg;   // id / 37
+                const uint32_t *src = hbT + __umul24((uint32_t)x, (uint32_t)HTP) + 4 * seg;
                 uint32_t P[7];
 #pragma unroll
                 for (int t = 0; t < 7; ++t) P[t] = src[t];
@@ -1014,7 +1031,7 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                     e = min(e >> 16, 255u); od = min(od >> 16, 255u);
                     w[t >> 1] |= (e | (od << 8)) << (16 * (t & 1));
                 }
-                uint32_t *dst = reinterpret_cast<uint32_t *>(vb + x * VBP) + 2 * seg;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(vb + __umul24((uint32_t)x, (uint32_t)VBP)) + 2 * seg;
                 dst[0] = w[0]; dst[1] = w[1];
             }
         }
@@ -1031,6 +1048,10 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         const uint32_t K = 0x400000u * (uint32_t)VBP + 0x4B400000u - (uint32_t)(HR * VBP + HR);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 4
+            words[r] = __ballot(patch[lane + r] < patch[lane + 7]);
+            continue;
+#endif
             const uint32_t pat = pats[r];
             int val[2];
 #pragma unroll
