@@ -226,6 +226,12 @@ __device__ __forceinline__ double load_dev(const double *p)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
 }
+// ... and the matching store: write-through at device scope (what a workgroup hands to the deciding one)
+__device__ __forceinline__ void store_dev(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
 // chi2 (and the scale terms x_j (lambda x_j + b_j)) of a trial from the per-landmark sums k_points left: value i goes to
 // virtual lane i % 128, a lane adds its values in ascending order, a tree adds the 128 lanes -- an order that depends on
 // the problem only, not on how the landmark kernels were launched (both landmark-kernel layouts and every batch size give
@@ -274,7 +280,13 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
     // pbStopFlag lives in host memory: its read (a PCIe round trip) travels together with the loads of the sums
     const int flag_seen = threadIdx.x == 0 && W.abort_word ? __hip_atomic_load(W.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
     double tempChi, scale;
+#if defined(AOS2_TAIL_TIMING)
+    const long long tt0 = wall_clock64();
+#endif
     canonical_sums(W, true, tempChi, scale);
+#if defined(AOS2_TAIL_TIMING)
+    const long long tt1 = wall_clock64();
+#endif
     if (threadIdx.x == 0) {
         const int pass = st->phase == 0 ? 0 : 1;
         const bool ok2 = W.np == 0 || W.scal[3] != 0.0;
@@ -338,6 +350,11 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
             }
         }
         st->lin = lin;
+#if defined(AOS2_TAIL_TIMING)
+        st->dbg[12] += tt1 - tt0;
+        st->dbg[13] += wall_clock64() - tt1 + (flag_seen & 0);
+        st->dbg[14] += 1;
+#endif
     }
     __syncthreads();
     // pop() after a rejected step (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610).  The backup holds the
@@ -352,14 +369,17 @@ template <int NT>
 __device__ __forceinline__ void points_tail(const LbaWin &W)
 {
     __shared__ int s_last;
+    // What this workgroup leaves for the deciding one -- the per-landmark sums and the landmark backups -- was stored
+    // write-through at device scope (store_dev), so its visibility needs the stores' completion only (every thread waits
+    // for its own, then the barrier), not a write-back of the whole L2: __threadfence() here (buffer_wbl2 by each of the
+    // ~1000 workgroups of a 32-window launch) cost 38 of the kernel's 79 us.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(&W.st->blocks_done, 1) == W.n_part - 1;
-    }
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&W.st->blocks_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W.n_part - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the reads below are device-scope loads: load_dev)
     if (threadIdx.x == 0) W.st->blocks_done = 0;
     lm_decide<NT>(W);
 }
@@ -369,7 +389,11 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
 // thread adds the per-edge terms in edge order, so the sums are the ones a thread walking the edges one after the other
 // would form (the order g2o adds them in), while the chain of dependent gathers per thread is one edge long instead of
 // the whole observation list (a single window has only ~2000 landmarks: the walk was pure latency).
+#ifndef AOS2_LBA_ABL
+#define AOS2_LBA_ABL 0
+#endif
 constexpr int kLmBlock = 32, kLmSlots = 8;
+constexpr int kWalkChunk = 4;   // edges of a landmark fetched together by the one-thread-per-landmark kernels
 
 // solve = 1 (a Levenberg-Marquardt trial): the landmark's part of
 // BlockSolver::solve -- xl = (Hll + lambda I)^-1 (bl - B^T xp), block_solver.hpp:455-480 -- and of
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
             for (int r = 0; r < 3; ++r) {
                 const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
                 W.x[n6 + 3 * l + r] = xl;
-                Xb[r] = Xv[r];   // push()
+                store_dev(Xb + r, Xv[r]);   // push() (read back by the deciding workgroup when the step is rejected)
                 Xv[r] += xl;
                 X[r] = Xv[r];
                 s_X[ll][r] = Xv[r];
@@ -475,8 +499,8 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
         }
     }
     if (has && leader) {
-        W.part[l] = chi;
-        W.part[W.nl + l] = sc;
+        store_dev(W.part + l, chi);
+        store_dev(W.part + W.nl + l, sc);
     }
     if (solve) points_tail<256>(W);
 }
@@ -498,18 +522,38 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
         if (solve) {
             const double lambda = W.st->lambda;
             double cl[3] = {W.b[n6 + 3 * l], W.b[n6 + 3 * l + 1], W.b[n6 + 3 * l + 2]};
-            for (int a = W.pl_off[l]; a < W.pl_off[l + 1]; ++a) {
-                const int ka = W.pl_k[a];
-                const int i1 = W.k_ph[ka];
-                const double *Bi = W.Hpl + 18 * (size_t)ka;
-                double xp[6], v[3] = {0, 0, 0};
+            // The walk is a chain of dependent gathers (edge list -> edge -> keyframe); kWalkChunk edges are fetched level by
+            // level together, then their terms are added in edge order (the same sums, a quarter of the round trips).
+#if AOS2_LBA_ABL == 3
+            const int a0 = 0, a1 = 0;
+#else
+            const int a0 = W.pl_off[l], a1 = W.pl_off[l + 1];
+#endif
+            for (int a = a0; a < a1; a += kWalkChunk) {
+                int ka[kWalkChunk], i1[kWalkChunk];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
+                for (int u = 0; u < kWalkChunk; ++u) ka[u] = W.pl_k[min(a + u, a1 - 1)];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.k_ph[ka[u]];
+                double Bi[kWalkChunk][18], xp[kWalkChunk][6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) v[c] += Bi[r * 3 + c] * xp[r];
-                for (int c = 0; c < 3; ++c) cl[c] += v[c];
+                for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) Bi[u][i] = W.Hpl[18 * (size_t)ka[u] + i];
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xp[u][r] = -W.x[6 * i1[u] + r];
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u) {
+                    if (a + u >= a1) break;
+                    double v[3] = {0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) v[c] += Bi[u][r * 3 + c] * xp[u][r];
+                    for (int c = 0; c < 3; ++c) cl[c] += v[c];
+                }
             }
             double Dm[9], Dinv[9];
             for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
@@ -519,33 +563,62 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
             for (int r = 0; r < 3; ++r) {
                 const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
                 W.x[n6 + 3 * l + r] = xl;
-                Xb[r] = Xv[r];   // push()
+                store_dev(Xb + r, Xv[r]);   // push()
                 Xv[r] += xl;
                 X[r] = Xv[r];
                 sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
             }
         }
-        for (int a = W.pt_off[l]; a < W.pt_off[l + 1]; ++a) {
-            const int e = W.pt_k[a];
-            if (W.e_level1[e]) continue;   // an inactive edge keeps its _error
-            double p[3], er[3];
-            se3_map(W.pose + 7 * (size_t)W.e_pose[e], Xv, p);
-            const int stereo = W.e_stereo[e];
-            edge_error(W.cam, p, W.e_obs + 3 * (size_t)e, stereo, er);
-            double *dst = W.err + 3 * (size_t)e;
-            dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-            double c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
-            if (W.e_robust[e]) {
-                double rho[2];
-                robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
-                c = rho[0];
+#if AOS2_LBA_ABL == 2
+        const int e0 = 0, e1 = 0;
+#else
+        const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
+#endif
+        for (int a = e0; a < e1; a += kWalkChunk) {
+            int e[kWalkChunk], ep[kWalkChunk];
+            uint8_t lv1[kWalkChunk], ste[kWalkChunk], rob[kWalkChunk];
+            double T[kWalkChunk][7], ob[kWalkChunk][3], ew[kWalkChunk];
+#pragma unroll
+            for (int u = 0; u < kWalkChunk; ++u) e[u] = W.pt_k[min(a + u, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < kWalkChunk; ++u) {
+                ep[u] = W.e_pose[e[u]];
+                lv1[u] = W.e_level1[e[u]];
+                ste[u] = W.e_stereo[e[u]];
+                rob[u] = W.e_robust[e[u]];
+                ew[u] = W.e_w[e[u]];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ob[u][i] = W.e_obs[3 * (size_t)e[u] + i];
             }
-            chi += c;
+#pragma unroll
+            for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+                for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
+#pragma unroll
+            for (int u = 0; u < kWalkChunk; ++u) {
+                if (a + u >= e1) break;
+                if (lv1[u]) continue;   // an inactive edge keeps its _error
+                double p[3], er[3];
+                se3_map(T[u], Xv, p);
+                const int stereo = ste[u];
+                edge_error(W.cam, p, ob[u], stereo, er);
+                double *dst = W.err + 3 * (size_t)e[u];
+                dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+                double c = edge_chi2(er, ew[u], stereo ? 3 : 2);
+                if (rob[u]) {
+                    double rho[2];
+                    robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+                    c = rho[0];
+                }
+                chi += c;
+            }
         }
-        W.part[l] = chi;
-        W.part[W.nl + l] = sc;
+        store_dev(W.part + l, chi);
+        store_dev(W.part + W.nl + l, sc);
     }
+#if AOS2_LBA_ABL != 1
     if (solve) points_tail<128>(W);
+#endif
 }
 
 // J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6
@@ -1616,13 +1689,10 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&st->n_active, __popcll(m));
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(&st->blocks_done, 1) == (int)gridDim.x - 1;
-    }
+    // (the last workgroup reads nothing of the others but n_active, an atomic: no device-scope fence)
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&st->blocks_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
-    __threadfence();
     st->blocks_done = 0;
     st->xmark = 0;
     st->it = 0;
@@ -2241,6 +2311,9 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     if (getenv("AOS2_LBA_TRACE"))
         for (int i = 0; i < nw; ++i) {
             const LmState *ls = state_of(i);
+#ifdef AOS2_TAIL_TIMING
+            fprintf(stderr, "[lba]   lm_decide (AOS2_TAIL_TIMING builds): sums %lld, decision %lld ticks of 10 ns over %lld calls\n", ls->dbg[12], ls->dbg[13], ls->dbg[14]);
+#endif
 #ifdef AOS2_LDLT_TIMING
             fprintf(stderr, "[lba] win %d reduced-system kernel cycles: load %lld, D0 %lld, P %lld, U(+lookahead D) %lld, D inside U %lld, factor %lld, backward %lld\n", i,
                     ls->dbg[0], ls->dbg[1], ls->dbg[2], ls->dbg[3], ls->dbg[4], ls->dbg[5], ls->dbg[6]);
