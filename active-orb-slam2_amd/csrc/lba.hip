@@ -652,23 +652,25 @@ __device__ __forceinline__ void jac_pose(const Cam &cam, const double p[3], int 
 
 // robustified information of an edge (BaseBinaryEdge::constructQuadraticForm, base_binary_edge.hpp:55-120):
 // omr = -rho' Omega e, wo = rho' * w
-__device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo, double omr[3], double &wo)
+__device__ __forceinline__ void edge_weights_of(const Cam &cam, const double er[3], double w, int robust, int stereo, double omr[3], double &wo)
 {
-    const double *er = W.err + 3 * (size_t)k;
-    const double w = W.e_w[k];
     // static indices only (a runtime-length loop over D would put the arrays in scratch memory)
     omr[0] = -(w * er[0]);
     omr[1] = -(w * er[1]);
     omr[2] = stereo ? -(w * er[2]) : 0.0;
     wo = w;
-    if (W.e_robust[k]) {
+    if (robust) {
         double rho[2];
-        robustify(edge_chi2(er, w, stereo ? 3 : 2), stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+        robustify(edge_chi2(er, w, stereo ? 3 : 2), stereo ? cam.delta_stereo : cam.delta_mono, rho);
         wo = rho[1] * w;
         omr[0] *= rho[1];
         omr[1] *= rho[1];
         if (stereo) omr[2] *= rho[1];
     }
+}
+__device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo, double omr[3], double &wo)
+{
+    edge_weights_of(W.cam, W.err + 3 * (size_t)k, W.e_w[k], W.e_robust[k], stereo, omr, wo);
 }
 
 // buildSystem, the landmarks' side (block_solver.hpp:502-560), kLmBlock landmarks per workgroup (see k_points): thread
@@ -771,56 +773,81 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
     const double *X = W.point + 3 * (size_t)W.hpoint[l];
     const double Xv[3] = {X[0], X[1], X[2]};
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    for (int a = W.pt_off[l]; a < W.pt_off[l + 1]; ++a) {
-        const int k = W.pt_k[a];
-        if (W.e_level1[k]) continue;
-        const double *T = W.pose + 7 * (size_t)W.e_pose[k];
-        const int stereo = W.e_stereo[k];
-        const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
-        double p[3], R[9];
-        se3_map(T, Xv, p);
-        rot_from_quat(T, R);
-        const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
-        double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (!stereo) {
-            const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-            const double s = -1. / z;
+    const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
+    for (int a = e0; a < e1; a += kWalkChunk) {
+        // kWalkChunk edges fetched level by level together (see k_points_walk), linearised and added in edge order
+        int kk[kWalkChunk], ep[kWalkChunk], ph[kWalkChunk];
+        uint8_t lv1[kWalkChunk], ste[kWalkChunk], rob[kWalkChunk];
+        double T[kWalkChunk][7], er[kWalkChunk][3], ew[kWalkChunk];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+        for (int u = 0; u < kWalkChunk; ++u) kk[u] = W.pt_k[min(a + u, e1 - 1)];
+#pragma unroll
+        for (int u = 0; u < kWalkChunk; ++u) {
+            ep[u] = W.e_pose[kk[u]];
+            ph[u] = W.k_ph[kk[u]];
+            lv1[u] = W.e_level1[kk[u]];
+            ste[u] = W.e_stereo[kk[u]];
+            rob[u] = W.e_robust[kk[u]];
+            ew[u] = W.e_w[kk[u]];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) er[u][i] = W.err[3 * (size_t)kk[u] + i];
+        }
+#pragma unroll
+        for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
+#pragma unroll
+        for (int u = 0; u < kWalkChunk; ++u) {
+            if (a + u >= e1) break;
+            if (lv1[u]) continue;
+            const int k = kk[u];
+            const int stereo = ste[u];
+            const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
+            double p[3], R[9];
+            se3_map(T[u], Xv, p);
+            rot_from_quat(T[u], R);
+            const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+            double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (!stereo) {
+                const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+                const double s = -1. / z;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
+                        Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
+                    }
+            } else {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
-                    Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
+                    Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+                    Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+                    Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
                 }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
-                Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
-                Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
             }
-        }
-        double omr[3], wo;
-        edge_weights(W, k, stereo, omr, wo);
+            double omr[3], wo;
+            edge_weights_of(W.cam, er[u], ew[u], rob[u], stereo, omr, wo);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            bl[r] += Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
+            for (int r = 0; r < 3; ++r) {
+                bl[r] += Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) H[r * 3 + c] += Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
-        }
-        if (W.k_ph[k] >= 0) {
-            double Jb[18];
-            jac_pose(W.cam, p, stereo, Jb);
-            double *h = W.Hpl + 18 * (size_t)k;
+                for (int c = 0; c < 3; ++c) H[r * 3 + c] += Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
+            }
+            if (ph[u] >= 0) {
+                double Jb[18];
+                jac_pose(W.cam, p, stereo, Jb);
+                double *h = W.Hpl + 18 * (size_t)k;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
-                    t += Jb[6 + r] * wo * Ja[3 + c];
-                    if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
-                    h[r * 3 + c] = t;
-                }
+                    for (int c = 0; c < 3; ++c) {
+                        double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
+                        t += Jb[6 + r] * wo * Ja[3 + c];
+                        if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
+                        h[r * 3 + c] = t;
+                    }
+            }
         }
     }
     for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
@@ -910,19 +937,28 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
         W.b[6 * (size_t)ph + (threadIdx.x - 36)] = sum;
 }
 
-// buildSystem as ONE launch: workgroups [0, np_blocks) take one free keyframe each, the others kLmBlock landmarks each (the two
-// sides are independent of each other: the landmark side no longer waits behind the keyframe side's launch).
+// buildSystem as ONE launch: the landmark side and the keyframe side are independent of each other.  Grid = (window, block):
+// blocks [0, nl_blocks) of a window take landmarks, the others one free keyframe each -- and the dispatcher walks x (the
+// windows) first, so the landmark workgroups of ALL windows start before any keyframe workgroup: their walks are the long
+// dependent chains of the launch (33 of its 54 us on 32 windows when they queued behind the keyframe workgroups of the
+// windows before them), the keyframe workgroups fill in behind.
 template <bool kWalk>
-__global__ __launch_bounds__(256) void k_lin(const LbaWin *__restrict__ wins, int init, int np_blocks)
+__global__ __launch_bounds__(256) void k_lin(const LbaWin *__restrict__ wins, int init, int nl_blocks)
 {
-    const LbaWin &W = wins[blockIdx.y];
+    const LbaWin &W = wins[blockIdx.x];
     if (!(init ? W.st->initp : W.st->lin)) return;
-    if ((int)blockIdx.x < np_blocks)
-        lin_poses_body(W, blockIdx.x);
+    const int blk = (int)blockIdx.y;
+#if AOS2_LBA_ABL == 5
+    if (blk >= nl_blocks) return;
+#elif AOS2_LBA_ABL == 6
+    if (blk < nl_blocks) return;
+#endif
+    if (blk >= nl_blocks)
+        lin_poses_body(W, blk - nl_blocks);
     else if (kWalk)
-        lin_points_walk(W, ((int)blockIdx.x - np_blocks) * 256 + threadIdx.x);
+        lin_points_walk(W, blk * 256 + threadIdx.x);
     else
-        lin_points_body(W, (int)blockIdx.x - np_blocks);
+        lin_points_body(W, blk);
 }
 
 // top of solve() in iteration 0 (levenberg.cpp:75-97): currentChi, lambda = 1e-5 * max |H_jj| over all free vertices
@@ -2232,9 +2268,9 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     auto enqueue_lin = [&](int init) {
         if (walk)
-            hipLaunchKernelGGL(k_lin<true>, dim3(mx_np + blocks(mx_nl, 256), nw), dim3(256), 0, q, dw, init, mx_np);
+            hipLaunchKernelGGL(k_lin<true>, dim3(nw, mx_np + blocks(mx_nl, 256)), dim3(256), 0, q, dw, init, (int)blocks(mx_nl, 256));
         else
-            hipLaunchKernelGGL(k_lin<false>, dim3(mx_np + blocks(mx_nl, kLmBlock), nw), dim3(256), 0, q, dw, init, mx_np);
+            hipLaunchKernelGGL(k_lin<false>, dim3(nw, mx_np + blocks(mx_nl, kLmBlock)), dim3(256), 0, q, dw, init, (int)blocks(mx_nl, kLmBlock));
     };
     auto enqueue_init = [&]() {
         enqueue_points(0);
