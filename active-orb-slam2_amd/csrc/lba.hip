@@ -1003,6 +1003,25 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
     }
 }
 
+// Window-to-XCD affinity for the per-window kernels: workgroups go round-robin to the 8 XCDs in linear-id order, each XCD
+// with an L2 of its own (4 MB -- about one window's working set).  1-D grid, id = g * (8 * nblk) + blk * 8 + (w % 8) with
+// w = 8 g + id % 8: window w always runs on XCD w % 8, and an XCD finishes the windows of group g before it starts those
+// of group g + 1, so the records a window's workgroups share (its Hpl blocks are read by ~2 items each per observation)
+// are served by that L2 instead of by every XCD's.
+struct WinBlock {
+    int w, blk;
+};
+__device__ __forceinline__ WinBlock xcd_affine(int nblk, int nw)
+{
+    const int id = (int)blockIdx.x, per = 8 * nblk, g = id / per, r = id - g * per;
+    WinBlock o;
+    o.blk = r >> 3;
+    o.w = 8 * g + (r & 7);
+    if (o.w >= nw) o.blk = -1;
+    return o;
+}
+static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(nblk * 8 * (size_t)((nw + 7) / 8)); }
+
 // ---- Schur complement (block_solver.hpp:379-432), one 256-thread workgroup per (pose, pose) block of the upper block
 // triangle.  The host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order
 // inside a block (build_schur_items).  Thread j of the block takes the items j, j + 256, ...: (Hll + lambda I)^-1 of the
@@ -1012,23 +1031,39 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
 // item: 0.31 ms per trial for 32 windows of 24 k edges).  Hschur = Hpp + lambda I - sum, bschur = b_p - sum.
 // threads per block: measured (one 12 k-edge window / one 24 k-edge window / 32 windows of 24 k edges, whole solve):
 // 64: 1.88 / 2.27 / 4.42 ms, 128: 1.74 / 1.92 / 4.35 ms, 256: 1.71 / 1.87 / 4.78 ms (most off-diagonal blocks hold < 128 items)
-constexpr int kSchurThreads = 128;
-__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins)
+#ifndef AOS2_SCHUR_NT
+#define AOS2_SCHUR_NT 128
+#endif
+constexpr int kSchurThreads = AOS2_SCHUR_NT;
+#ifndef AOS2_SCHUR_WPE
+#define AOS2_SCHUR_WPE 2
+#endif
+__global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(AOS2_SCHUR_WPE, AOS2_SCHUR_WPE))) void k_schur(const LbaWin *__restrict__ wins, int mx_blk, int nw)
 {
     constexpr int NT = kSchurThreads;
     __shared__ double red[(NT / 16) * 43];
-    const LbaWin &W = wins[blockIdx.y];
+    const WinBlock wb = xcd_affine(mx_blk, nw);
+    if (wb.blk < 0) return;
+    const LbaWin &W = wins[wb.w];
     if (!W.st->run) return;
     const int np = W.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
-    const int blk = blockIdx.x;
-    if (blk >= nblk) return;
-    // blk -> (i1 <= i2)
-    int i1 = 0, rem = blk;
-    while (rem >= np - i1) {
-        rem -= np - i1;
-        ++i1;
+    if (wb.blk >= nblk) return;
+    // The diagonal blocks first: they hold every observation of a keyframe (several rounds of items per thread), the
+    // off-diagonal ones the covisible landmarks of a pair (one round) -- a long workgroup dispatched last would run alone.
+    // order -> (i1 <= i2) -> blk, the block's rank in the upper triangle, row-major (the order of blk_off)
+    int i1, i2;
+    if (wb.blk < np)
+        i1 = i2 = wb.blk;
+    else {
+        int rem = wb.blk - np;
+        i1 = 0;
+        while (rem >= np - 1 - i1) {
+            rem -= np - 1 - i1;
+            ++i1;
+        }
+        i2 = i1 + 1 + rem;
     }
-    const int i2 = i1 + rem;
+    const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
     const double lambda = W.st->lambda;
     const bool diag = i1 == i2;
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
@@ -2279,7 +2314,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        if (mx_np) hipLaunchKernelGGL(k_schur, dim3((unsigned)mx_blk, nw), dim3(kSchurThreads), 0, q, dw);
+        if (mx_np) hipLaunchKernelGGL(k_schur, dim3(xcd_affine_grid(mx_blk, nw)), dim3(kSchurThreads), 0, q, dw, (int)mx_blk, nw);
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
