@@ -242,16 +242,16 @@ __device__ __forceinline__ void canonical_sums(const LbaWin &W, bool with_scale,
     const int tid = threadIdx.x;
     if (tid < 128) {
         double c = 0, s2 = 0;
-        for (int i0 = tid; i0 < W.nl; i0 += 128 * 8) {   // 8 values of the lane in flight, added in ascending order
-            double v[8], w[8];
+        for (int i0 = tid; i0 < W.nl; i0 += 128 * 16) {   // 16 values of the lane in flight, added in ascending order
+            double v[16], w[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int i = i0 + 128 * u;
                 v[u] = i < W.nl ? load_dev(W.part + i) : 0.0;
                 w[u] = with_scale && i < W.nl ? load_dev(W.part + W.nl + i) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 c += v[u];     // (x + 0.0 == x past the end)
                 s2 += w[u];
             }
@@ -1005,22 +1005,26 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
 
 // Window-to-XCD affinity for the per-window kernels: workgroups go round-robin to the 8 XCDs in linear-id order, each XCD
 // with an L2 of its own (4 MB -- about one window's working set).  1-D grid, id = g * (8 * nblk) + blk * 8 + (w % 8) with
-// w = 8 g + id % 8: window w always runs on XCD w % 8, and an XCD finishes the windows of group g before it starts those
+// w = 8 g + id % 8 (for groups of 8 windows): window w always runs on XCD w % 8, and an XCD finishes the windows of group g before it starts those
 // of group g + 1, so the records a window's workgroups share (its Hpl blocks are read by ~2 items each per observation)
 // are served by that L2 instead of by every XCD's.
 struct WinBlock {
     int w, blk;
 };
+#ifndef AOS2_XCD_GROUP
+#define AOS2_XCD_GROUP 16
+#endif
+constexpr int kXcdGroup = AOS2_XCD_GROUP;   // windows in flight together (a multiple of 8: kXcdGroup / 8 per XCD; measured 8 / 16 / 32: 50 / 47.7 / 48.3 us)
 __device__ __forceinline__ WinBlock xcd_affine(int nblk, int nw)
 {
-    const int id = (int)blockIdx.x, per = 8 * nblk, g = id / per, r = id - g * per;
+    const int id = (int)blockIdx.x, per = kXcdGroup * nblk, g = id / per, r = id - g * per;
     WinBlock o;
-    o.blk = r >> 3;
-    o.w = 8 * g + (r & 7);
+    o.blk = r / kXcdGroup;
+    o.w = kXcdGroup * g + (r % kXcdGroup);
     if (o.w >= nw) o.blk = -1;
     return o;
 }
-static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(nblk * 8 * (size_t)((nw + 7) / 8)); }
+static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(nblk * kXcdGroup * (size_t)((nw + kXcdGroup - 1) / kXcdGroup)); }
 
 // ---- Schur complement (block_solver.hpp:379-432), one 256-thread workgroup per (pose, pose) block of the upper block
 // triangle.  The host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order
@@ -1031,31 +1035,38 @@ static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(
 // item: 0.31 ms per trial for 32 windows of 24 k edges).  Hschur = Hpp + lambda I - sum, bschur = b_p - sum.
 // threads per block: measured (one 12 k-edge window / one 24 k-edge window / 32 windows of 24 k edges, whole solve):
 // 64: 1.88 / 2.27 / 4.42 ms, 128: 1.74 / 1.92 / 4.35 ms, 256: 1.71 / 1.87 / 4.78 ms (most off-diagonal blocks hold < 128 items)
-#ifndef AOS2_SCHUR_NT
-#define AOS2_SCHUR_NT 128
-#endif
-constexpr int kSchurThreads = AOS2_SCHUR_NT;
-#ifndef AOS2_SCHUR_WPE
-#define AOS2_SCHUR_WPE 2
-#endif
-__global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(AOS2_SCHUR_WPE, AOS2_SCHUR_WPE))) void k_schur(const LbaWin *__restrict__ wins, int mx_blk, int nw)
+constexpr int kSchurThreads = 256;
+// units of a window for k_schur: one per diagonal block, one per four off-diagonal blocks
+static inline size_t schur_units(size_t np) { return np + (np * (np - 1) / 2 + 3) / 4; }
+
+// A 256-thread workgroup takes one unit: a DIAGONAL block -- every observation of a keyframe, ~450 items: all four waves,
+// items strided over the 256 threads, sums through workgroup_sum_k256 -- or four OFF-DIAGONAL blocks, one per wave -- the
+// covisible landmarks of a keyframe pair, mostly < 64 items: a wave by itself, its sums through its own rows of the LDS
+// buffer, no workgroup barrier.  (With one 128-thread workgroup per block the second wave of nearly every off-diagonal
+// block held registers for nothing and the diagonal ones needed four rounds: 50 -> 46 us on 32 windows; a variant that fetched the wave's 128 Hpl blocks cooperatively into LDS -- the kernel is bound by
+// the texture path's request rate, 23 requests of 16 bytes per item: without the a-side blocks it takes 33 us -- ran at 98-112 us:
+// more dependent round trips per round and register spills.)  The diagonal
+// units come first in the grid: the long ones must not be dispatched last.
+__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, int mx_units, int nw)
 {
     constexpr int NT = kSchurThreads;
     __shared__ double red[(NT / 16) * 43];
-    const WinBlock wb = xcd_affine(mx_blk, nw);
+    const WinBlock wb = xcd_affine(mx_units, nw);
     if (wb.blk < 0) return;
     const LbaWin &W = wins[wb.w];
-    if (!W.st->run) return;
-    const int np = W.np, n6 = 6 * np, nblk = np * (np + 1) / 2;
-    if (wb.blk >= nblk) return;
-    // The diagonal blocks first: they hold every observation of a keyframe (several rounds of items per thread), the
-    // off-diagonal ones the covisible landmarks of a pair (one round) -- a long workgroup dispatched last would run alone.
-    // order -> (i1 <= i2) -> blk, the block's rank in the upper triangle, row-major (the order of blk_off)
+    // (every dependent load is a round trip of its own on the workgroup's critical path: the state words and the block's
+    // item range are requested together, before the branch on the first of them)
+    const int run = W.st->run;
+    const double lambda = W.st->lambda;
+    const int np = W.np, n6 = 6 * np, noff = np * (np - 1) / 2;
+    const bool diag = wb.blk < np;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // unit -> (i1 <= i2) -> blk, the block's rank in the upper triangle, row-major (the order of blk_off)
     int i1, i2;
-    if (wb.blk < np)
+    if (diag)
         i1 = i2 = wb.blk;
     else {
-        int rem = wb.blk - np;
+        int rem = min((wb.blk - np) * 4 + wave, max(noff - 1, 0));
         i1 = 0;
         while (rem >= np - 1 - i1) {
             rem -= np - 1 - i1;
@@ -1064,13 +1075,13 @@ __global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(A
         i2 = i1 + 1 + rem;
     }
     const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
-    const double lambda = W.st->lambda;
-    const bool diag = i1 == i2;
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
+    if (!run) return;
+    if (!diag && (wb.blk - np) * 4 + wave >= noff) return;   // (whole waves; no workgroup barrier on this path)
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int j = threadIdx.x; j < n; j += NT) {
+    for (int j = diag ? tid : lane; j < n; j += diag ? NT : 64) {
         const int ka = W.it_ka[o0 + j], kb = W.it_kb[o0 + j], l = W.it_l[o0 + j];   // three independent loads, then one level of gathers
         double D[9], Dinv[9];
 #pragma unroll
@@ -1100,8 +1111,27 @@ __global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(A
             for (int r = 0; r < 6; ++r) acc[36 + r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
         }
     }
-    const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
-    const int e = threadIdx.x;
+    double sum;
+    int e;
+    if (diag) {
+        sum = workgroup_sum_k256<42, NT>(acc, red, n);
+        e = tid;
+    } else {
+        // the wave's own four rows of `red`; LDS operations of one wave execute in order, so the reads below see the writes
+        double *wred = red + 4 * wave * 43;
+        const int rows_used = min(4, (n + 15) >> 4);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) wred[(lane >> 4) * 43 + i] = acc[i];
+        }
+        asm volatile("" ::: "memory");
+        sum = 0;
+        if (lane < 36)
+            for (int r = 0; r < rows_used; ++r) sum += wred[r * 43 + lane];
+        e = lane;
+    }
     if (e < 36) {
         double v = -sum;
         const int r = e / 6, c = e - 6 * r;
@@ -2286,7 +2316,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         mx_nl = std::max(mx_nl, S.nl);
         mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
         mx_part = std::max(mx_part, l.n_part);
-        mx_blk = std::max(mx_blk, (size_t)S.np * (S.np + 1) / 2);
+        mx_blk = std::max(mx_blk, schur_units((size_t)S.np));   // k_schur units
     }
     lap("staging");
     hipStream_t q = s->stream;
