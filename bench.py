@@ -553,8 +553,8 @@ def main():
                                  "4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE, profiles/r02_pmc_extract_b512.txt) at the issue rates "
                                  "measured on this chip (tools/microbench/valu_rate.hip -> profiles/r01_valu_rate.txt: 4 cycles per "
                                  "wave64 instruction for packed-16 / min / max / compare / dot / perm / mad, 2 for add / sub / logic / "
-                                 "mov / f32); ~810 VALU instructions per 1.2k-pixel cell-wave, so the HBM fraction can only rise by "
-                                 "removing instructions (profiles/README.md has the history: 1040 -> 810 per cell-wave this round)"},
+                                 "mov / f32); ~710 VALU instructions per 1.2k-pixel cell-wave, so the HBM fraction can only rise by "
+                                 "removing instructions (profiles/README.md has the history: 1040 -> 812 per cell-wave in round 1, -> 712 in round 2)"},
             "extra": extra,
         }
         # the other two streaming kernels of the step, from the un-chunked stage times (HIP events of the library)
