@@ -1011,20 +1011,19 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
 struct WinBlock {
     int w, blk;
 };
-#ifndef AOS2_XCD_GROUP
-#define AOS2_XCD_GROUP 16
-#endif
-constexpr int kXcdGroup = AOS2_XCD_GROUP;   // windows in flight together (a multiple of 8: kXcdGroup / 8 per XCD; measured 8 / 16 / 32: 50 / 47.7 / 48.3 us)
-__device__ __forceinline__ WinBlock xcd_affine(int nblk, int nw)
+// windows in flight together: a multiple of 8 (group / 8 per XCD; measured 8 / 16 / 32 on 32 windows: 50 / 47.7 / 48.3 us); a call
+// with fewer windows than that runs them all together (the affinity needs groups of 8)
+static inline int xcd_group(int nw) { return nw >= 16 ? 16 : nw >= 8 ? 8 : nw; }
+__device__ __forceinline__ WinBlock xcd_affine(int nblk, int nw, int group)
 {
-    const int id = (int)blockIdx.x, per = kXcdGroup * nblk, g = id / per, r = id - g * per;
+    const int id = (int)blockIdx.x, per = group * nblk, g = id / per, r = id - g * per;
     WinBlock o;
-    o.blk = r / kXcdGroup;
-    o.w = kXcdGroup * g + (r % kXcdGroup);
+    o.blk = r / group;
+    o.w = group * g + (r - o.blk * group);
     if (o.w >= nw) o.blk = -1;
     return o;
 }
-static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(nblk * kXcdGroup * (size_t)((nw + kXcdGroup - 1) / kXcdGroup)); }
+static inline unsigned xcd_affine_grid(size_t nblk, int nw) { const int G = xcd_group(nw); return (unsigned)(nblk * G * (size_t)((nw + G - 1) / G)); }
 
 // ---- Schur complement (block_solver.hpp:379-432), one 256-thread workgroup per (pose, pose) block of the upper block
 // triangle.  The host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order
@@ -1036,8 +1035,9 @@ static inline unsigned xcd_affine_grid(size_t nblk, int nw) { return (unsigned)(
 // threads per block: measured (one 12 k-edge window / one 24 k-edge window / 32 windows of 24 k edges, whole solve):
 // 64: 1.88 / 2.27 / 4.42 ms, 128: 1.74 / 1.92 / 4.35 ms, 256: 1.71 / 1.87 / 4.78 ms (most off-diagonal blocks hold < 128 items)
 constexpr int kSchurThreads = 256;
-// units of a window for k_schur: one per diagonal block, one per four off-diagonal blocks
-static inline size_t schur_units(size_t np) { return np + (np * (np - 1) / 2 + 3) / 4; }
+// units of a window for k_schur: one per diagonal block, one per `bpu` off-diagonal blocks (4 when the windows of the call
+// fill the device: a wave per block; 1 for a single window: latency, the idle waves cost nothing on an empty device)
+static inline size_t schur_units(size_t np, int bpu) { return np + (np * (np - 1) / 2 + bpu - 1) / bpu; }
 
 // A 256-thread workgroup takes one unit: a DIAGONAL block -- every observation of a keyframe, ~450 items: all four waves,
 // items strided over the 256 threads, sums through workgroup_sum_k256 -- or four OFF-DIAGONAL blocks, one per wave -- the
@@ -1047,11 +1047,11 @@ static inline size_t schur_units(size_t np) { return np + (np * (np - 1) / 2 + 3
 // the texture path's request rate, 23 requests of 16 bytes per item: without the a-side blocks it takes 33 us -- ran at 98-112 us:
 // more dependent round trips per round and register spills.)  The diagonal
 // units come first in the grid: the long ones must not be dispatched last.
-__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, int mx_units, int nw)
+__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, int mx_units, int nw, int bpu, int group)
 {
     constexpr int NT = kSchurThreads;
     __shared__ double red[(NT / 16) * 43];
-    const WinBlock wb = xcd_affine(mx_units, nw);
+    const WinBlock wb = xcd_affine(mx_units, nw, group);
     if (wb.blk < 0) return;
     const LbaWin &W = wins[wb.w];
     // (every dependent load is a round trip of its own on the workgroup's critical path: the state words and the block's
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
     if (diag)
         i1 = i2 = wb.blk;
     else {
-        int rem = min((wb.blk - np) * 4 + wave, max(noff - 1, 0));
+        int rem = min((wb.blk - np) * bpu + wave, max(noff - 1, 0));
         i1 = 0;
         while (rem >= np - 1 - i1) {
             rem -= np - 1 - i1;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
     const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
     if (!run) return;
-    if (!diag && (wb.blk - np) * 4 + wave >= noff) return;   // (whole waves; no workgroup barrier on this path)
+    if (!diag && (wave >= bpu || (wb.blk - np) * bpu + wave >= noff)) return;   // (whole waves; no workgroup barrier on this path)
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
@@ -2133,6 +2133,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     bool walk = total_points > 16000;
     if (const char *e = getenv("AOS2_LBA_LAYOUT")) walk = !strcmp(e, "walk");
     const int lm_per_block = walk ? 128 : kLmBlock;
+    const int schur_bpu = walk ? 4 : 1;   // off-diagonal blocks per k_schur workgroup
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -2316,7 +2317,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         mx_nl = std::max(mx_nl, S.nl);
         mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
         mx_part = std::max(mx_part, l.n_part);
-        mx_blk = std::max(mx_blk, schur_units((size_t)S.np));   // k_schur units
+        mx_blk = std::max(mx_blk, schur_units((size_t)S.np, schur_bpu));   // k_schur units
     }
     lap("staging");
     hipStream_t q = s->stream;
@@ -2344,7 +2345,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        if (mx_np) hipLaunchKernelGGL(k_schur, dim3(xcd_affine_grid(mx_blk, nw)), dim3(kSchurThreads), 0, q, dw, (int)mx_blk, nw);
+        if (mx_np) hipLaunchKernelGGL(k_schur, dim3(xcd_affine_grid(mx_blk, nw)), dim3(kSchurThreads), 0, q, dw, (int)mx_blk, nw, schur_bpu, xcd_group(nw));
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
