@@ -883,21 +883,31 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
                                                float r, int minLevel, int maxLevel, float xr_proj, float xr_tol,
                                                int lane, Entry *out)
 {
+    // One candidate per lane.  The cells of a grid column are neighbours in the CSR, so the window is (x1 - x0 + 1) runs of
+    // grid_idx, and position k of the window -- cells column by column, the features of a cell in their CSR order: the order
+    // GetFeaturesInArea returns them in -- is element k of the concatenated runs.  (A lane per CELL walking the cell's
+    // features one after the other kept 20-40 % of the lanes busy on a chain of dependent gathers as long as the fullest
+    // cell.)
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    const int ny = w.y1 - w.y0 + 1, ncell = (w.x1 - w.x0 + 1) * ny;
-    int base = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-        const int c = c0 + lane;
-        int beg = 0, cnt = 0;
-        if (c < ncell) {
-            const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
-            beg = F.grid_off[cell];
-            cnt = F.grid_off[cell + 1] - beg;
+    const int ncol = w.x1 - w.x0 + 1;   // <= GRID_COLS = 64: one lane per column
+    int cb = 0, cnt = 0;
+    if (lane < ncol) {
+        const int c0 = (w.x0 + lane) * GRID_ROWS;
+        cb = F.grid_off[c0 + w.y0];
+        cnt = F.grid_off[c0 + w.y1 + 1] - cb;
+    }
+    const int incl = wave_incl_scan_i32(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int delta = cb - (incl - cnt);   // run start - first position of the column
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        int src = 0;
+        for (int c = 0; c < ncol; ++c) {   // (uniform) the last column that starts at or before k
+            const int first = __builtin_amdgcn_readlane(incl - cnt, c), d = __builtin_amdgcn_readlane(delta, c);
+            if (k >= first) src = k + d;
         }
-        const int incl = wave_incl_scan_i32(cnt);
-        const int pos0 = base + incl - cnt;
-        for (int j = 0; j < cnt; ++j) {
-            const int idx = F.grid_idx[beg + j];
+        if (k < total) {
+            const int idx = F.grid_idx[src];
             const int oct = F.kp_octave[idx];
             Entry e;
             e.key = KEY_NONE;
@@ -920,11 +930,10 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
             }
             if (pass) {
                 const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
-                e.key = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
+                e.key = ((uint32_t)dist << 20) | (uint32_t)k;
             }
-            out[pos0 + j] = e;
+            out[k] = e;
         }
-        base += __builtin_amdgcn_readlane(incl, 63);
     }
 }
 
