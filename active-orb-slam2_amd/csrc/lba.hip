@@ -393,7 +393,11 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
 #define AOS2_LBA_ABL 0
 #endif
 constexpr int kLmBlock = 32, kLmSlots = 8;
-constexpr int kWalkChunk = 4;   // edges of a landmark fetched together by the one-thread-per-landmark kernels
+// edges of a landmark fetched together by the one-thread-per-landmark kernels (measured on 32 windows of 24 k edges, 6
+// observations per landmark: k_points_walk 43.4 us with 4 / 4, 38.6 with 6 / 6; the linearisation spills beyond 4)
+constexpr int kWalkChunk = 6;      // free-keyframe edges (back-substitution)
+constexpr int kWalkChunkE = 6;     // all edges (residuals)
+constexpr int kWalkChunkLin = 4;   // all edges (linearisation)
 
 // solve = 1 (a Levenberg-Marquardt trial): the landmark's part of
 // BlockSolver::solve -- xl = (Hll + lambda I)^-1 (bl - B^T xp), block_solver.hpp:455-480 -- and of
@@ -574,14 +578,14 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
 #else
         const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
 #endif
-        for (int a = e0; a < e1; a += kWalkChunk) {
-            int e[kWalkChunk], ep[kWalkChunk];
-            uint8_t lv1[kWalkChunk], ste[kWalkChunk], rob[kWalkChunk];
-            double T[kWalkChunk][7], ob[kWalkChunk][3], ew[kWalkChunk];
+        for (int a = e0; a < e1; a += kWalkChunkE) {
+            int e[kWalkChunkE], ep[kWalkChunkE];
+            uint8_t lv1[kWalkChunkE], ste[kWalkChunkE], rob[kWalkChunkE];
+            double T[kWalkChunkE][7], ob[kWalkChunkE][3], ew[kWalkChunkE];
 #pragma unroll
-            for (int u = 0; u < kWalkChunk; ++u) e[u] = W.pt_k[min(a + u, e1 - 1)];
+            for (int u = 0; u < kWalkChunkE; ++u) e[u] = W.pt_k[min(a + u, e1 - 1)];
 #pragma unroll
-            for (int u = 0; u < kWalkChunk; ++u) {
+            for (int u = 0; u < kWalkChunkE; ++u) {
                 ep[u] = W.e_pose[e[u]];
                 lv1[u] = W.e_level1[e[u]];
                 ste[u] = W.e_stereo[e[u]];
@@ -591,11 +595,11 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
                 for (int i = 0; i < 3; ++i) ob[u][i] = W.e_obs[3 * (size_t)e[u] + i];
             }
 #pragma unroll
-            for (int u = 0; u < kWalkChunk; ++u)
+            for (int u = 0; u < kWalkChunkE; ++u)
 #pragma unroll
                 for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
 #pragma unroll
-            for (int u = 0; u < kWalkChunk; ++u) {
+            for (int u = 0; u < kWalkChunkE; ++u) {
                 if (a + u >= e1) break;
                 if (lv1[u]) continue;   // an inactive edge keeps its _error
                 double p[3], er[3];
@@ -774,15 +778,15 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
     const double Xv[3] = {X[0], X[1], X[2]};
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
     const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
-    for (int a = e0; a < e1; a += kWalkChunk) {
-        // kWalkChunk edges fetched level by level together (see k_points_walk), linearised and added in edge order
-        int kk[kWalkChunk], ep[kWalkChunk], ph[kWalkChunk];
-        uint8_t lv1[kWalkChunk], ste[kWalkChunk], rob[kWalkChunk];
-        double T[kWalkChunk][7], er[kWalkChunk][3], ew[kWalkChunk];
+    for (int a = e0; a < e1; a += kWalkChunkLin) {
+        // kWalkChunkLin edges fetched level by level together (see k_points_walk), linearised and added in edge order
+        int kk[kWalkChunkLin], ep[kWalkChunkLin], ph[kWalkChunkLin];
+        uint8_t lv1[kWalkChunkLin], ste[kWalkChunkLin], rob[kWalkChunkLin];
+        double T[kWalkChunkLin][7], er[kWalkChunkLin][3], ew[kWalkChunkLin];
 #pragma unroll
-        for (int u = 0; u < kWalkChunk; ++u) kk[u] = W.pt_k[min(a + u, e1 - 1)];
+        for (int u = 0; u < kWalkChunkLin; ++u) kk[u] = W.pt_k[min(a + u, e1 - 1)];
 #pragma unroll
-        for (int u = 0; u < kWalkChunk; ++u) {
+        for (int u = 0; u < kWalkChunkLin; ++u) {
             ep[u] = W.e_pose[kk[u]];
             ph[u] = W.k_ph[kk[u]];
             lv1[u] = W.e_level1[kk[u]];
@@ -793,11 +797,11 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             for (int i = 0; i < 3; ++i) er[u][i] = W.err[3 * (size_t)kk[u] + i];
         }
 #pragma unroll
-        for (int u = 0; u < kWalkChunk; ++u)
+        for (int u = 0; u < kWalkChunkLin; ++u)
 #pragma unroll
             for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
 #pragma unroll
-        for (int u = 0; u < kWalkChunk; ++u) {
+        for (int u = 0; u < kWalkChunkLin; ++u) {
             if (a + u >= e1) break;
             if (lv1[u]) continue;
             const int k = kk[u];
