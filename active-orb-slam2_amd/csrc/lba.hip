@@ -587,9 +587,13 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
 #pragma unroll
             for (int u = 0; u < kWalkChunkE; ++u) {
                 ep[u] = W.e_pose[e[u]];
+#if AOS2_LBA_ABL == 10
+                lv1[u] = 0; ste[u] = 1; rob[u] = 1;
+#else
                 lv1[u] = W.e_level1[e[u]];
                 ste[u] = W.e_stereo[e[u]];
                 rob[u] = W.e_robust[e[u]];
+#endif
                 ew[u] = W.e_w[e[u]];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) ob[u][i] = W.e_obs[3 * (size_t)e[u] + i];
