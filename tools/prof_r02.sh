@@ -12,5 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stat
 tail -1 $O/stats.log
 cd $R
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp $f $O/bench_kernel_stats.csv; head -40 $f
+# the roofline launches inside the same trace: default bench.py (20 steps) so that bench_fast runs as in the bench line
+cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/bench.py --no-cpu-baseline --no-extra > $O/trace.log 2>&1; cd $R
+python tools/fast_kernel_from_trace.py $(find $O/trace -name "*kernel_trace.csv" | head -1) > $O/bench_fast_kernel_trace.txt; cat $O/bench_fast_kernel_trace.txt; tail -1 $O/trace.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench.py of this traced run: roofline.kernel_ms', d['roofline']['kernel_ms'])" >> $O/bench_fast_kernel_trace.txt
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 du -sh $O
