@@ -1074,7 +1074,8 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
     if (diag)
         i1 = i2 = wb.blk;
     else {
-        int rem = min((wb.blk - np) * bpu + wave, max(noff - 1, 0));
+        if (noff == 0) return;   // (a window with at most one free keyframe has no off-diagonal block: nothing to clamp to)
+        int rem = min((wb.blk - np) * bpu + wave, noff - 1);
         i1 = 0;
         while (rem >= np - 1 - i1) {
             rem -= np - 1 - i1;

@@ -233,6 +233,25 @@ def test_lba_batch_equals_single_windows(pkg, oracle, gpu):
         assert (got["edge_outlier"] == want["edge_outlier"]).all()
 
 
+def test_lba_batch_sizes_around_the_window_groups(pkg, gpu, monkeypatch):
+    """The Schur kernel maps (window, block) to workgroups in groups of 8 / 16 windows (a window stays on one XCD); the
+    linearisation's grid is (window, block).  Batches of 7, 8, 9, 16, 17 and 33 windows of mixed sizes -- partial groups,
+    windows without off-diagonal blocks (one free keyframe), both landmark-kernel layouts -- give each window the bits it
+    gets alone."""
+    cfgs = [dict(seed=61, n_local=1, n_fixed=4, n_points=120), dict(seed=62, n_local=6, n_fixed=2, n_points=260),
+            dict(seed=63, n_local=12, n_fixed=3, n_points=330, stereo_frac=0.4), dict(seed=64, n_local=3, n_fixed=0, n_points=90, include_kf0=True)]
+    uniq = [pkg.synth.synth_lba_problem(**c) for c in cfgs]
+    alone = [pkg.LocalBA().LocalBundleAdjustment(p) for p in uniq]
+    for layout in ("slots", "walk"):
+        monkeypatch.setenv("AOS2_LBA_LAYOUT", layout)
+        ba = pkg.LocalBA()
+        for n in (7, 8, 9, 16, 17, 33):
+            idx = [(3 * i + n) % len(uniq) for i in range(n)]
+            got = ba.LocalBundleAdjustmentBatch([uniq[j] for j in idx])
+            assert all(g["status"] == 0 and _same(g, alone[j]) for g, j in zip(got, idx)), (layout, n)
+    monkeypatch.delenv("AOS2_LBA_LAYOUT")
+
+
 def test_lba_landmark_kernel_layouts_agree(pkg, oracle, gpu, monkeypatch):
     """The landmark kernels have two layouts (8 threads per landmark for a few windows, one thread per landmark for many):
     both give the same bits, for landmarks with 2 .. 30 observations (several rounds of 8) and with rejected trials."""
