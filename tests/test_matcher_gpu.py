@@ -66,6 +66,18 @@ def test_search_by_projection_vs_oracle(pkg, oracle, gpu):
     assert n == on and (match == om).all()
 
 
+def test_search_windows_from_one_cell_to_the_whole_grid(pkg, oracle, gpu):
+    """The window of a query is enumerated one candidate per lane over the runs of the grid's columns: windows of a single
+    cell, of all 64 columns with thousands of candidates (many rounds of 64), at the image border, and over a nearly
+    empty grid give the reference's candidates in the reference's order (best / second-best ties decide by position)."""
+    S = pkg.synth
+    for seed, n_f, n_mp, th in ((31, 1200, 120, 150.0), (32, 3000, 60, 400.0), (33, 40, 300, 60.0), (34, 900, 900, 0.2), (35, 2000, 200, 25.0)):
+        f, mp = S.synth_proj_mp_problem(seed, n_f=n_f, n_mp=n_mp, th=th)
+        on, om = oracle.search_by_projection_mp(f, mp)
+        n, match = pkg.Matcher(float(mp["nnratio"]), True).SearchByProjection(f, mp, th=float(mp["th"]))
+        assert n == on and (match == om).all(), (seed, n, on)
+
+
 def test_search_by_projection_entry_pool_from_window_populations(pkg, oracle, gpu, monkeypatch):
     """large local maps size the candidate pool from the real window populations (count pass, scan, fill pass) instead of
     n_mp x n_f slots; forced here on an ordinary problem, also with a budget that is too small (the call learns the total
