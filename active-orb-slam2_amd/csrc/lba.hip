@@ -29,6 +29,10 @@
 #include <cstdlib>
 #include <memory>
 #include <numeric>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 
@@ -1868,10 +1872,70 @@ struct Pass {
     std::vector<int32_t> it_ka, it_kb, it_l, blk_off;   // Schur items (k_schur_items / k_schur_blocks)
     int np = 0, nl = 0;
 };
+// worker threads of a handle for the per-window host work of a batch (structure build, staging): created once -- 32
+// std::thread per phase cost ~1 ms per call
+struct WindowPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> fn;
+    int n_items = 0, generation = 0, running = 0;
+    std::atomic<int> next{0};
+    bool quit = false;
+    void start(int n)
+    {
+        for (int t = (int)th.size(); t < n; ++t)
+            th.emplace_back([this] {
+                int seen = 0;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_go.wait(lk, [&] { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation;
+                    }
+                    for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
+                    std::lock_guard<std::mutex> lk(m);
+                    if (--running == 0) cv_done.notify_one();
+                }
+            });
+    }
+    void run(int n, std::function<void(int)> f)
+    {
+        if (n <= 1 || th.empty()) {
+            for (int i = 0; i < n; ++i) f(i);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(m);
+        fn = std::move(f);
+        n_items = n;
+        next = 0;
+        running = (int)th.size();
+        ++generation;
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return running == 0; });
+    }
+    ~WindowPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+struct LbaCache {
+    std::vector<Pass> passes;
+    WindowPool pool;
+};
 
 static bool build_pass(const aos2_lba_problem_t *p, Pass &S)
 {
-    S = Pass();
+    // (the vectors keep their storage from call to call: a 24 k-edge window holds ~1.5 MB of index lists, and fresh
+    // allocations of that size are mmap / page faults / munmap every time -- 2 ms per 32-window call, half of it at scope exit)
+    S.hpose.clear(); S.hpoint.clear(); S.it_ka.clear(); S.it_kb.clear(); S.it_l.clear(); S.blk_off.clear();
+    S.np = S.nl = 0;
     const int E = p->n_edges;
     std::vector<uint8_t> pose_act(p->n_poses, 0), point_act(p->n_points, 0);
     for (int e = 0; e < E; ++e) {
@@ -2066,6 +2130,7 @@ int aos2_lba_create(int device, aos2_lba_t **out)
 void aos2_lba_destroy(aos2_lba_t *s)
 {
     if (!s) return;
+    delete static_cast<LbaCache *>(s->lba_cache);
     if (s->dev_ready) {
         (void)hipSetDevice(s->device);
         (void)hipStreamSynchronize(s->stream);
@@ -2102,12 +2167,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             set_error("bad LocalBA problem %d", w);
             return AOS2_ERR_ARG;
         }
-        for (int e = 0; e < p->n_edges; ++e)
-            if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
-                set_error("problem %d: edge %d references a vertex out of range", w, e);
-                return AOS2_ERR_ARG;
-            }
-        want_chi2 |= r->edge_chi2 != nullptr;
+        want_chi2 |= r->edge_chi2 != nullptr;   // (the edges' vertex indices are checked with the structure build, a thread per window)
     }
     // Optimizer.cc:656-658: return before optimising when the flag is already set; nothing is written back
     std::vector<int> act;
@@ -2154,25 +2214,29 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
 
     // ---- per-window structure (host; windows in parallel when there are several)
     auto rg = std::make_unique<RoctxRange>("LocalBA::buildStructure (index mapping, edge lists, Schur items)");
-    std::vector<Pass> passes(nw);
-    auto for_windows = [&](auto &&fn) {
-        const int nthr = std::max(1, std::min({nw, (int)std::thread::hardware_concurrency(), 32}));
-        if (nthr <= 1) {
-            for (int i = 0; i < nw; ++i) fn(i);
-            return;
-        }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; ++t)
-            th.emplace_back([&, t] {
-                for (int i = t; i < nw; i += nthr) fn(i);
-            });
-        for (auto &x : th) x.join();
-    };
+    if (!s->lba_cache) s->lba_cache = new LbaCache();
+    std::vector<Pass> &passes = static_cast<LbaCache *>(s->lba_cache)->passes;
+    if ((int)passes.size() < nw) passes.resize(nw);
+    WindowPool &pool = static_cast<LbaCache *>(s->lba_cache)->pool;
+    if (nw > 1) pool.start(std::max(1, std::min({nw, (int)std::thread::hardware_concurrency(), 32})));
+    auto for_windows = [&](auto &&fn) { pool.run(nw, fn); };
     std::vector<uint8_t> pass_ok(nw, 1);
+    std::vector<int> bad_edge(nw, -1);
     for_windows([&](int i) {
-        pass_ok[i] = build_pass(problems + act[i], passes[i]) ? 1 : 0;
+        const aos2_lba_problem_t *p = problems + act[i];
+        for (int e = 0; e < p->n_edges; ++e)
+            if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+                bad_edge[i] = e;
+                return;
+            }
+        pass_ok[i] = build_pass(p, passes[i]) ? 1 : 0;
         if (pass_ok[i] && passes[i].np > 0) build_schur_items(passes[i]);
     });
+    for (int i = 0; i < nw; ++i)
+        if (bad_edge[i] >= 0) {
+            set_error("problem %d: edge %d references a vertex out of range", act[i], bad_edge[i]);
+            return AOS2_ERR_ARG;
+        }
     for (int i = 0; i < nw; ++i)
         if (!pass_ok[i]) {   // (cannot come from the reference: KeyFrame observations are a map MapPoint -> index)
             set_error("problem %d: two edges connect the same keyframe and map point", act[i]);

@@ -374,6 +374,7 @@ struct aos2_lba {
     aos2::PinnedBuf<int32_t> h_abort;   // LocalBA: per-window abort words the kernels poll (mapped host memory)
     float last_pose_ms = 0;
     int debug_stop_at_poll = 0;         // test hook: treat pbStopFlag as set from this poll on (0 = off)
+    void *lba_cache = nullptr;          // LocalBA: host-side structure buffers kept between calls (lba.hip: LbaCache)
 };
 
 namespace aos2 {
