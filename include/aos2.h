@@ -578,7 +578,9 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
 /* `n_problems` independent windows (several maps, or an offline pass over many windows; SURVEY.md section 8(e):
  * LocalBA = replicas only) in one call: every kernel covers all windows, so their latency-bound Levenberg-Marquardt
  * chains overlap on the device.  results[i].status carries the per-window AOS2_OK / AOS2_ERR_STOPPED; the return
- * value is AOS2_OK unless an argument or HIP error occurred. */
+ * value is AOS2_OK unless an argument or HIP error occurred.
+ * A handle serves one call at a time (concurrent solves: one handle per calling thread); it keeps its device arena, the
+ * host-side structure buffers and the worker threads of the per-window host work between calls. */
 int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2_lba_result_t *results,
                          int n_problems);
 /* Test hook (no reference equivalent): the stop flag counts as set from its `poll`-th evaluation on (1 = the entry
