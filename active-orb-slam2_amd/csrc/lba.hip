@@ -83,15 +83,16 @@ struct LbaWin {
     uint8_t *e_robust, *e_level1;
     double *err;                     // n_edges x 3, last computed _error
     Cam cam;
-    const int32_t *k_ph, *k_lh;      // edge -> pose hidx (-1 fixed) / point hidx
+    const int32_t *pl_pos;           // edge -> its position in the landmark's free-keyframe edge list (-1: fixed keyframe)
     const int32_t *hpose, *hpoint;   // hidx -> pose / point index
     const int32_t *pt_off, *pt_k;    // edges by point (insertion order)
     const int32_t *ps_off, *ps_k;    // edges by free pose
-    const int32_t *pl_off, *pl_k;    // free-pose edges by point, ascending pose hidx
+    const int32_t *pl_off, *pl_ph;   // free-pose edges by point, ascending pose hidx: the pose hidx of each position
     // Schur complement by items: item = (landmark, free-pose edges ka <= kb of it), ranked by (pose, pose) block in
     // upper-triangular order, landmark order inside a block (build_schur_items)
     const int32_t *it_ka, *it_kb, *it_l, *blk_off;
-    double *Hpl;                     // per edge: the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
+    double *Hpl;                     // per free-keyframe edge, DENSE by its position in the pl list (a landmark's blocks are
+                                     // neighbours): the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
     double *tmp;                     // scale terms of the poses (6 np)
     double *scal;                    // [3] solve ok
@@ -435,9 +436,8 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
             const int a = a0 + kLmSlots * rd + j;
             double v[3] = {0, 0, 0};
             if (a < a1) {   // B_i^T (-x_p) of one free-keyframe edge
-                const int ka = W.pl_k[a];
-                const int i1 = W.k_ph[ka];
-                const double *Bi = W.Hpl + 18 * (size_t)ka;
+                const int i1 = W.pl_ph[a];
+                const double *Bi = W.Hpl + 18 * (size_t)a;
                 double xp[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
@@ -538,11 +538,11 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
             const int a0 = W.pl_off[l], a1 = W.pl_off[l + 1];
 #endif
             for (int a = a0; a < a1; a += kWalkChunk) {
-                int ka[kWalkChunk], i1[kWalkChunk];
+                int ka[kWalkChunk], i1[kWalkChunk];   // (positions in the list = the indices of the dense Hpl array)
 #pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u) ka[u] = W.pl_k[min(a + u, a1 - 1)];
+                for (int u = 0; u < kWalkChunk; ++u) ka[u] = min(a + u, a1 - 1);
 #pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.k_ph[ka[u]];
+                for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.pl_ph[ka[u]];
                 double Bi[kWalkChunk][18], xp[kWalkChunk][6];
 #pragma unroll
                 for (int u = 0; u < kWalkChunk; ++u)
@@ -741,10 +741,11 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) cH[r * 3 + c] = Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
             }
-            if (W.k_ph[k] >= 0) {
+            const int pp = W.pl_pos[k];
+            if (pp >= 0) {
                 double Jb[18];
                 jac_pose(W.cam, p, stereo, Jb);
-                double *h = W.Hpl + 18 * (size_t)k;
+                double *h = W.Hpl + 18 * (size_t)pp;
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -796,7 +797,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
 #pragma unroll
         for (int u = 0; u < kWalkChunkLin; ++u) {
             ep[u] = W.e_pose[kk[u]];
-            ph[u] = W.k_ph[kk[u]];
+            ph[u] = W.pl_pos[kk[u]];
             lv1[u] = W.e_level1[kk[u]];
             ste[u] = W.e_stereo[kk[u]];
             rob[u] = W.e_robust[kk[u]];
@@ -812,7 +813,6 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
         for (int u = 0; u < kWalkChunkLin; ++u) {
             if (a + u >= e1) break;
             if (lv1[u]) continue;
-            const int k = kk[u];
             const int stereo = ste[u];
             const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
             double p[3], R[9];
@@ -849,7 +849,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             if (ph[u] >= 0) {
                 double Jb[18];
                 jac_pose(W.cam, p, stereo, Jb);
-                double *h = W.Hpl + 18 * (size_t)k;
+                double *h = W.Hpl + 18 * (size_t)ph[u];
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -1794,8 +1794,9 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
         if (bad) {
             W.e_level1[e] = 1;
-            if (W.k_ph[e] >= 0)
-                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)e + i] = 0.0;
+            const int pp = W.pl_pos[e];
+            if (pp >= 0)
+                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)pp + i] = 0.0;
         }
         W.e_robust[e] = 0;
         keep = bad ? 0 : 1;
@@ -1869,6 +1870,7 @@ static bool stop_requested(const aos2_lba_problem_t *p) { return p->stop_flag &&
 // buildStructure for ALL edges (the second optimisation masks edges instead of rebuilding)
 struct Pass {
     std::vector<int32_t> k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
+    std::vector<int32_t> pl_pos, pl_ph;   // edge -> position in pl_k (-1: fixed keyframe); position -> pose hidx
     std::vector<int32_t> it_ka, it_kb, it_l, blk_off;   // Schur items (k_schur_items / k_schur_blocks)
     int np = 0, nl = 0;
 };
@@ -2000,6 +2002,12 @@ static bool build_pass(const aos2_lba_problem_t *p, Pass &S)
         for (int i = 1; i < m; ++i)
             if (S.k_ph[q[i]] == S.k_ph[q[i - 1]]) return false;   // two edges between one keyframe and one landmark
     }
+    S.pl_pos.assign(E, -1);
+    S.pl_ph.resize(S.pl_k.size());
+    for (size_t a = 0; a < S.pl_k.size(); ++a) {
+        S.pl_pos[S.pl_k[a]] = (int32_t)a;
+        S.pl_ph[a] = S.k_ph[S.pl_k[a]];
+    }
     return true;
 }
 
@@ -2017,9 +2025,9 @@ static void build_schur_items(Pass &S)
     S.it_ka.resize(n); S.it_kb.resize(n); S.it_l.resize(n);
     S.blk_off.assign(nblk + 1, 0);
     // block of (i1 <= i2) = row_base[i1] + i2 (pl_k is sorted by pose, so a <= b gives i1 <= i2)
-    std::vector<int32_t> row_base(np > 0 ? np : 1), ph(S.pl_k.size());
+    std::vector<int32_t> row_base(np > 0 ? np : 1);
+    const std::vector<int32_t> &ph = S.pl_ph;
     for (int i = 0; i < np; ++i) row_base[i] = i * np - i * (i - 1) / 2 - i;
-    for (size_t i = 0; i < S.pl_k.size(); ++i) ph[i] = S.k_ph[S.pl_k[i]];
     for (int l = 0; l < S.nl; ++l) {
         const int32_t *q = ph.data() + S.pl_off[l];
         const int m = S.pl_off[l + 1] - S.pl_off[l];
@@ -2032,14 +2040,14 @@ static void build_schur_items(Pass &S)
     std::vector<int32_t> fill(S.blk_off.begin(), S.blk_off.end() - 1);
     for (int l = 0; l < S.nl; ++l) {
         const int c0 = S.pl_off[l], m = S.pl_off[l + 1] - c0;
-        const int32_t *q = ph.data() + c0, *k = S.pl_k.data() + c0;
-        for (int a = 0; a < m; ++a) {
+        const int32_t *q = ph.data() + c0;
+        for (int a = 0; a < m; ++a) {   // (items name the two edges by their positions in the pl list = the indices of the dense Hpl array)
             int32_t *f = fill.data() + row_base[q[a]];
-            const int32_t ka = k[a];
+            const int32_t ka = c0 + a;
             for (int b = a; b < m; ++b) {
                 const int slot = f[q[b]]++;
                 S.it_ka[slot] = ka;
-                S.it_kb[slot] = k[b];
+                S.it_kb[slot] = c0 + b;
                 S.it_l[slot] = l;
             }
         }
@@ -2049,7 +2057,7 @@ static void build_schur_items(Pass &S)
 // byte offsets of one window's regions in the arena
 struct WinLayout {
     // staged (uploaded)
-    size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
+    size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off;
     // device only
     size_t est, bk, e_obs, e_w, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
@@ -2255,7 +2263,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
         l.in_Tcw = B.take(64 * NP); l.in_xyz = B.take(12 * NL); l.in_obs = B.take(12 * E); l.in_w = B.take(4 * E);
         l.e_pose = B.take(4 * E); l.e_point = B.take(4 * E); l.e_stereo = B.take(E);
-        l.k_ph = B.take(4 * E); l.k_lh = B.take(4 * E);
+        l.pl_pos = B.take(4 * E);
         l.hpose = B.take(4 * (size_t)S.np + 4); l.hpoint = B.take(4 * (size_t)S.nl + 4);
         l.pt_off = B.take(4 * ((size_t)S.nl + 1)); l.pt_k = B.take(4 * S.pt_k.size() + 4);
         l.ps_off = B.take(4 * ((size_t)S.np + 1)); l.ps_k = B.take(4 * S.ps_k.size() + 4);
@@ -2275,7 +2283,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
         l.e_obs = B.take(24 * E); l.e_w = B.take(8 * E); l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
-        l.Hpl = B.take(144 * E);
+        l.Hpl = B.take(144 * (S.pl_k.size() + 1));
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.Hs = B.take(8 * n6 * n6 + 8); l.bs = B.take(8 * n6 + 8);
@@ -2331,9 +2339,9 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         auto put = [&](size_t off, const std::vector<int32_t> &v) {
             if (!v.empty()) memcpy(hin + off, v.data(), v.size() * 4);
         };
-        put(l.k_ph, S.k_ph); put(l.k_lh, S.k_lh); put(l.hpose, S.hpose); put(l.hpoint, S.hpoint);
+        put(l.pl_pos, S.pl_pos); put(l.hpose, S.hpose); put(l.hpoint, S.hpoint);
         put(l.pt_off, S.pt_off); put(l.pt_k, S.pt_k); put(l.ps_off, S.ps_off); put(l.ps_k, S.ps_k);
-        put(l.pl_off, S.pl_off); put(l.pl_k, S.pl_k);
+        put(l.pl_off, S.pl_off); put(l.pl_k, S.pl_ph);
         put(l.it_ka, S.it_ka); put(l.it_kb, S.it_kb); put(l.it_l, S.it_l); put(l.blk_off, S.blk_off);
     });
     for (int i = 0; i < nw; ++i) {
@@ -2358,11 +2366,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.cam.bf = (double)p->bf; W.cam.bf_f = p->bf;
         W.cam.delta_mono = (double)(float)std::sqrt(5.991);
         W.cam.delta_stereo = (double)(float)std::sqrt(7.815);
-        W.k_ph = (const int32_t *)(base + l.k_ph); W.k_lh = (const int32_t *)(base + l.k_lh);
+        W.pl_pos = (const int32_t *)(base + l.pl_pos);
         W.hpose = (const int32_t *)(base + l.hpose); W.hpoint = (const int32_t *)(base + l.hpoint);
         W.pt_off = (const int32_t *)(base + l.pt_off); W.pt_k = (const int32_t *)(base + l.pt_k);
         W.ps_off = (const int32_t *)(base + l.ps_off); W.ps_k = (const int32_t *)(base + l.ps_k);
-        W.pl_off = (const int32_t *)(base + l.pl_off); W.pl_k = (const int32_t *)(base + l.pl_k);
+        W.pl_off = (const int32_t *)(base + l.pl_off); W.pl_ph = (const int32_t *)(base + l.pl_k);
         W.it_ka = (const int32_t *)(base + l.it_ka); W.it_kb = (const int32_t *)(base + l.it_kb);
         W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
         W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);

@@ -196,6 +196,7 @@ def main():
     lba_prep = [h.prepare_batch(lba_probs) for h in lbas]
     pool = ThreadPoolExecutor(NLBA)   # LocalMapping-side threads: one per LocalBA handle
     lba_jobs = [None] * NLBA
+    NO_LBA = os.environ.get("AOS2_BENCH_NO_LBA") == "1"   # diagnostics only: the tracking chains alone (the JSON line is then not the metric)
     # N > 1: the one exchange step of the path -- every step's keypoint / descriptor slots go to
     # rank 0 in one gather (RCCL over xGMI), enqueued behind the step on the step's own stream and left in flight while
     # the next step runs; packed by a device kernel (aos2_extractor_pack_slots)
@@ -229,7 +230,8 @@ def main():
         p.step()
         if gather is not None:
             gather_step(j)
-        lba_jobs[jl] = pool.submit(lbas[jl].solve_prepared, lba_prep[jl])
+        if not NO_LBA:
+            lba_jobs[jl] = pool.submit(lbas[jl].solve_prepared, lba_prep[jl])
 
     def sync():
         for jl in range(NLBA):
