@@ -2324,6 +2324,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     bool any_lds = false, any_glob = false;
     int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part = 0, mx_npad_glob = 0, mx_npad_lds = 0;
     size_t mx_blk = 0;
+    std::vector<uint8_t> up_fail(nw, 0);
     for_windows([&](int i) {
         const aos2_lba_problem_t *p = problems + act[i];
         const Pass &S = passes[i];
@@ -2343,7 +2344,17 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         put(l.pt_off, S.pt_off); put(l.pt_k, S.pt_k); put(l.ps_off, S.ps_off); put(l.ps_k, S.ps_k);
         put(l.pl_off, S.pl_off); put(l.pl_k, S.pl_ph);
         put(l.it_ka, S.it_ka); put(l.it_kb, S.it_kb); put(l.it_l, S.it_l); put(l.blk_off, S.blk_off);
+        // the window's staged region goes to the device as soon as it is assembled: its upload overlaps the staging of the
+        // other windows (one copy of everything after the staging cost 0.4 ms more per 32-window call)
+        const size_t r0 = l.in_Tcw, r1 = i + 1 < nw ? L[i + 1].in_Tcw : o_wins;
+        if (hipSetDevice(s->device) != hipSuccess || hipMemcpyAsync(base + r0, hin + r0, r1 - r0, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+            up_fail[i] = 1;
     });
+    for (int i = 0; i < nw; ++i)
+        if (up_fail[i]) {
+            set_error("LocalBA: upload of window %d failed", act[i]);
+            return AOS2_ERR_HIP;
+        }
     for (int i = 0; i < nw; ++i) {
         const aos2_lba_problem_t *p = problems + act[i];
         const Pass &S = passes[i];
@@ -2402,7 +2413,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     }
     lap("staging");
     hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base, hin, staged_bytes, hipMemcpyHostToDevice, q));
+    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_wins, hin + o_wins, staged_bytes - o_wins, hipMemcpyHostToDevice, q));   // the descriptors
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
