@@ -252,6 +252,34 @@ def test_lba_batch_sizes_around_the_window_groups(pkg, gpu, monkeypatch):
     monkeypatch.delenv("AOS2_LBA_LAYOUT")
 
 
+def test_lba_handles_come_and_go(pkg, gpu):
+    """A handle keeps worker threads and structure buffers between calls: creating, using (batches that start the pool,
+    single windows that do not, a rejected input in between) and destroying many handles leaves nothing behind and
+    changes no result."""
+    def os_threads():
+        return int(next(l for l in open("/proc/self/status") if l.startswith("Threads:")).split()[1])
+    probs = [pkg.synth.synth_lba_problem(seed=71 + i, n_local=4 + i, n_fixed=2, n_points=100 + 40 * i) for i in range(3)]
+    want = [pkg.LocalBA().LocalBundleAdjustment(p) for p in probs]
+    warm = pkg.LocalBA()
+    warm.LocalBundleAdjustmentBatch(probs)
+    warm.close()
+    before = os_threads()
+    for rep in range(40):
+        ba = pkg.LocalBA()
+        if rep % 3 == 0:
+            got = ba.LocalBundleAdjustmentBatch(probs * 3)
+            assert all(_same(g, want[i % 3]) for i, g in enumerate(got))
+        if rep % 5 == 0:
+            bad = dict(probs[0])
+            bad["edge_point"] = np.array(bad["edge_point"]).copy()
+            bad["edge_point"][7] = bad["n_points"] + 5
+            with pytest.raises(pkg.capi.AosError):
+                ba.LocalBundleAdjustmentBatch([probs[1], bad])
+        assert _same(ba.LocalBundleAdjustment(probs[rep % 3]), want[rep % 3])
+        ba.close()
+    assert os_threads() <= before   # (the pools' threads are joined when their handle goes)
+
+
 def test_lba_landmark_kernel_layouts_agree(pkg, oracle, gpu, monkeypatch):
     """The landmark kernels have two layouts (8 threads per landmark for a few windows, one thread per landmark for many):
     both give the same bits, for landmarks with 2 .. 30 observations (several rounds of 8) and with rejected trials."""
