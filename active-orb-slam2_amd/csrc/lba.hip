@@ -73,12 +73,12 @@ struct LbaWin {
     int n_poses, n_points, n_edges, np, nl, n_items;
     int iters1, iters2;              // optimize(5), optimize(10) (Optimizer.cc:661, 708)
     // raw float32 inputs as the reference holds them (staged), converted by k_prepare (Converter.cc:37-47, 83-90)
-    const float *in_Tcw, *in_xyz, *in_obs, *in_w;
+    const float *in_Tcw, *in_xyz, *in_obs, *in_w;   // (observations and information weights stay float32: the kernels widen them on
+                                                     // load -- exact -- instead of reading converted double copies, 16 bytes per edge and use)
     double *pose, *point;            // estimates, contiguous [7 n_poses | 3 n_points]
     double *bk;                      // SparseOptimizer::push backup of the same span
     int est_n;
     const int32_t *e_pose, *e_point;
-    double *e_obs, *e_w;
     const uint8_t *e_stereo;
     uint8_t *e_robust, *e_level1;
     double *err;                     // n_edges x 3, last computed _error
@@ -168,11 +168,7 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
     if (i < W.n_points)
         for (int d = 0; d < 3; ++d) W.point[3 * (size_t)i + d] = (double)W.in_xyz[3 * (size_t)i + d];
     if (i < W.n_edges) {
-        for (int d = 0; d < 3; ++d) {
-            W.e_obs[3 * (size_t)i + d] = (double)W.in_obs[3 * (size_t)i + d];
-            W.err[3 * (size_t)i + d] = 0.0;
-        }
-        W.e_w[i] = (double)W.in_w[i];
+        for (int d = 0; d < 3; ++d) W.err[3 * (size_t)i + d] = 0.0;
         W.e_robust[i] = 1;
         W.e_level1[i] = 0;
     }
@@ -487,10 +483,11 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
                     double p[3], er[3];
                     se3_map(W.pose + 7 * (size_t)W.e_pose[e], Xv, p);
                     const int stereo = W.e_stereo[e];
-                    edge_error(W.cam, p, W.e_obs + 3 * (size_t)e, stereo, er);
+                    const double ob[3] = {(double)W.in_obs[3 * (size_t)e], (double)W.in_obs[3 * (size_t)e + 1], (double)W.in_obs[3 * (size_t)e + 2]};
+                    edge_error(W.cam, p, ob, stereo, er);
                     double *dst = W.err + 3 * (size_t)e;
                     dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-                    c = edge_chi2(er, W.e_w[e], stereo ? 3 : 2);
+                    c = edge_chi2(er, (double)W.in_w[e], stereo ? 3 : 2);
                     if (W.e_robust[e]) {
                         double rho[2];
                         robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
@@ -598,9 +595,9 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
                 ste[u] = W.e_stereo[e[u]];
                 rob[u] = W.e_robust[e[u]];
 #endif
-                ew[u] = W.e_w[e[u]];
+                ew[u] = (double)W.in_w[e[u]];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) ob[u][i] = W.e_obs[3 * (size_t)e[u] + i];
+                for (int i = 0; i < 3; ++i) ob[u][i] = (double)W.in_obs[3 * (size_t)e[u] + i];
             }
 #pragma unroll
             for (int u = 0; u < kWalkChunkE; ++u)
@@ -682,7 +679,7 @@ __device__ __forceinline__ void edge_weights_of(const Cam &cam, const double er[
 }
 __device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo, double omr[3], double &wo)
 {
-    edge_weights_of(W.cam, W.err + 3 * (size_t)k, W.e_w[k], W.e_robust[k], stereo, omr, wo);
+    edge_weights_of(W.cam, W.err + 3 * (size_t)k, (double)W.in_w[k], W.e_robust[k], stereo, omr, wo);
 }
 
 // buildSystem, the landmarks' side (block_solver.hpp:502-560), kLmBlock landmarks per workgroup (see k_points): thread
@@ -801,7 +798,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             lv1[u] = W.e_level1[kk[u]];
             ste[u] = W.e_stereo[kk[u]];
             rob[u] = W.e_robust[kk[u]];
-            ew[u] = W.e_w[kk[u]];
+            ew[u] = (double)W.in_w[kk[u]];
 #pragma unroll
             for (int i = 0; i < 3; ++i) er[u][i] = W.err[3 * (size_t)kk[u] + i];
         }
@@ -1788,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
     int keep = 0;
     if (e < W.n_edges) {
         const int stereo = W.e_stereo[e];
-        const double c = edge_chi2(W.err + 3 * (size_t)e, W.e_w[e], stereo ? 3 : 2);
+        const double c = edge_chi2(W.err + 3 * (size_t)e, (double)W.in_w[e], stereo ? 3 : 2);
         double p[3];
         se3_map(W.pose + 7 * (size_t)W.e_pose[e], W.point + 3 * (size_t)W.e_point[e], p);
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
@@ -1828,7 +1825,7 @@ __global__ __launch_bounds__(256) void k_final(const LbaWin *__restrict__ wins)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < W.n_edges) {
         const int stereo = W.e_stereo[i];
-        const double c = edge_chi2(W.err + 3 * (size_t)i, W.e_w[i], stereo ? 3 : 2);
+        const double c = edge_chi2(W.err + 3 * (size_t)i, (double)W.in_w[i], stereo ? 3 : 2);
         double p[3];
         se3_map(W.pose + 7 * (size_t)W.e_pose[i], W.point + 3 * (size_t)W.e_point[i], p);
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
@@ -2060,7 +2057,7 @@ struct WinLayout {
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off;
     // device only
-    size_t est, bk, e_obs, e_w, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
+    size_t est, bk, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
     size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
     int n_part, npad, ldlt_lds;
@@ -2281,7 +2278,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
         const size_t n6 = 6 * (size_t)S.np, dim = n6 + 3 * (size_t)S.nl;
         l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
-        l.e_obs = B.take(24 * E); l.e_w = B.take(8 * E); l.robust = B.take(E); l.level1 = B.take(E);
+        l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
         l.Hpl = B.take(144 * (S.pl_k.size() + 1));
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
@@ -2370,7 +2367,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.bk = (double *)(base + l.bk);
         W.est_n = 7 * p->n_poses + 3 * p->n_points;
         W.e_pose = (const int32_t *)(base + l.e_pose); W.e_point = (const int32_t *)(base + l.e_point);
-        W.e_obs = (double *)(base + l.e_obs); W.e_w = (double *)(base + l.e_w);
+
         W.e_stereo = base + l.e_stereo; W.e_robust = base + l.robust; W.e_level1 = base + l.level1;
         W.err = (double *)(base + l.err);
         W.cam.fx = (double)p->fx; W.cam.fy = (double)p->fy; W.cam.cx = (double)p->cx; W.cam.cy = (double)p->cy;
