@@ -677,9 +677,15 @@ __device__ __forceinline__ void edge_weights_of(const Cam &cam, const double er[
         if (stereo) omr[2] *= rho[1];
     }
 }
-__device__ __forceinline__ void edge_weights(const LbaWin &W, int k, int stereo, double omr[3], double &wo)
+// ... of edge k whose landmark maps to p in its keyframe: the residual is re-formed from p and the observation (the same
+// operations on the same values as the residual pass that stored _error: the same bits, for 12 bytes of observation instead
+// of 24 of stored residual)
+__device__ __forceinline__ void edge_weights(const LbaWin &W, int k, const double p[3], int stereo, double omr[3], double &wo)
 {
-    edge_weights_of(W.cam, W.err + 3 * (size_t)k, (double)W.in_w[k], W.e_robust[k], stereo, omr, wo);
+    const double ob[3] = {(double)W.in_obs[3 * (size_t)k], (double)W.in_obs[3 * (size_t)k + 1], (double)W.in_obs[3 * (size_t)k + 2]};
+    double er[3];
+    edge_error(W.cam, p, ob, stereo, er);
+    edge_weights_of(W.cam, er, (double)W.in_w[k], W.e_robust[k], stereo, omr, wo);
 }
 
 // buildSystem, the landmarks' side (block_solver.hpp:502-560), kLmBlock landmarks per workgroup (see k_points): thread
@@ -731,7 +737,7 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
                 }
             }
             double omr[3], wo;
-            edge_weights(W, k, stereo, omr, wo);
+            edge_weights(W, k, p, stereo, omr, wo);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 cb[r] = Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
@@ -800,7 +806,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             rob[u] = W.e_robust[kk[u]];
             ew[u] = (double)W.in_w[kk[u]];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) er[u][i] = W.err[3 * (size_t)kk[u] + i];
+            for (int i = 0; i < 3; ++i) er[u][i] = (double)W.in_obs[3 * (size_t)kk[u] + i];   // (the observation; the residual is re-formed below)
         }
 #pragma unroll
         for (int u = 0; u < kWalkChunkLin; ++u)
@@ -836,7 +842,9 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
                 }
             }
             double omr[3], wo;
-            edge_weights_of(W.cam, er[u], ew[u], rob[u], stereo, omr, wo);
+            double res[3];
+            edge_error(W.cam, p, er[u], stereo, res);
+            edge_weights_of(W.cam, res, ew[u], rob[u], stereo, omr, wo);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 bl[r] += Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
@@ -931,7 +939,7 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
         double p[3], Jb[18], omr[3], wo;
         se3_map(T, W.point + 3 * (size_t)W.e_point[k], p);
         jac_pose(W.cam, p, stereo, Jb);
-        edge_weights(W, k, stereo, omr, wo);
+        edge_weights(W, k, p, stereo, omr, wo);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             acc[36 + r] += Jb[r] * omr[0] + Jb[6 + r] * omr[1] + Jb[12 + r] * omr[2];
