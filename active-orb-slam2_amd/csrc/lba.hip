@@ -1110,11 +1110,18 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
         double Bb[18], BD[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
+        if (diag) {   // (uniform) the two edges of an item are one: its block is fetched once
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
+            for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
+                for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bb[r * 3] * Dinv[c] + Bb[r * 3 + 1] * Dinv[3 + c] + Bb[r * 3 + 2] * Dinv[6 + c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
