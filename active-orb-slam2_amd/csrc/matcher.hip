@@ -1566,10 +1566,8 @@ __device__ __forceinline__ void assign_grid_body(int n, const float *__restrict_
     int32_t *cnt = gsh;                                  // NC + 1
     int16_t *cell = reinterpret_cast<int16_t *>(gsh + NC + 1);   // n
     __shared__ int32_t wsum[4];
-    __shared__ int32_t carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c <= NC; c += 256) cnt[c] = 0;
-    if (tid == 0) carry = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         const int px = (int)roundf(__fmul_rn(__fsub_rn(kp_x[i], min_x), gwi));
