@@ -294,6 +294,8 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
     return as_u32(bright) | as_u32(dark);
 }
 
+// (AOS2_FAST_ABL = 1..4, AOS2_DESC_ABL = 1..4: timing-only ablation builds of tools/build_abl_libs.sh -- the kernel stops after /
+// skips one phase, results are wrong by construction; DESIGN.md section 0, item 6 has the phase shares they gave.)
 // Phases per wave (one grid cell of one image, 64-thread workgroup = one wave, so list counters are
 // wave-uniform registers and no LDS atomics or multi-wave barriers are needed):
 //   0. stage the cell + ring halo in LDS (32-bit loads), evaluated column 0 on a dword boundary

@@ -390,6 +390,9 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
 // thread adds the per-edge terms in edge order, so the sums are the ones a thread walking the edges one after the other
 // would form (the order g2o adds them in), while the chain of dependent gathers per thread is one edge long instead of
 // the whole observation list (a single window has only ~2000 landmarks: the walk was pure latency).
+// Timing-only ablation builds (tools/build_lba_abl_libs.sh; results are wrong by construction): one phase switched off at a
+// time under rocprofv3 -- 1: k_points_walk without the deciding tail, 2: without the residual loop, 3: without the
+// back-substitution loop, 5: k_lin landmark blocks only, 6: k_lin keyframe blocks only.  (DESIGN.md 5.3's table)
 #ifndef AOS2_LBA_ABL
 #define AOS2_LBA_ABL 0
 #endif
@@ -588,13 +591,9 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
 #pragma unroll
             for (int u = 0; u < kWalkChunkE; ++u) {
                 ep[u] = W.e_pose[e[u]];
-#if AOS2_LBA_ABL == 10
-                lv1[u] = 0; ste[u] = 1; rob[u] = 1;
-#else
                 lv1[u] = W.e_level1[e[u]];
                 ste[u] = W.e_stereo[e[u]];
                 rob[u] = W.e_robust[e[u]];
-#endif
                 ew[u] = (double)W.in_w[e[u]];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) ob[u][i] = (double)W.in_obs[3 * (size_t)e[u] + i];
