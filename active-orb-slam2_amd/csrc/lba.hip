@@ -1897,9 +1897,14 @@ struct WindowPool {
     bool quit = false;
     void start(int n)
     {
+        int born;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            born = generation;   // a thread added later starts with the jobs after its creation, not with a finished one
+        }
         for (int t = (int)th.size(); t < n; ++t)
-            th.emplace_back([this] {
-                int seen = 0;
+            th.emplace_back([this, born] {
+                int seen = born;
                 for (;;) {
                     {
                         std::unique_lock<std::mutex> lk(m);
