@@ -252,6 +252,36 @@ def test_lba_batch_sizes_around_the_window_groups(pkg, gpu, monkeypatch):
     monkeypatch.delenv("AOS2_LBA_LAYOUT")
 
 
+def test_lba_batch_is_deterministic_under_concurrency(pkg, gpu):
+    """The LM decision is taken by the workgroup that finishes last from sums the other workgroups hand over (device-scope
+    write-through stores, relaxed counter; no L2 write-back): repeated solves of one batch -- alone and while a second handle
+    and the extractor keep the device busy -- give the same bits every time (tools/gpu_lba_determinism.py runs thousands)."""
+    import threading
+    u = [pkg.synth.synth_lba_problem(i, n_points=3000) for i in range(3)] + [pkg.synth.synth_lba_problem(seed=45, n_local=5, n_fixed=2, n_points=300)]
+    probs = [u[i % len(u)] for i in range(16)]
+    ba = pkg.LocalBA()
+    ref = ba.LocalBundleAdjustmentBatch(probs)
+    stop = []
+    def other_lba():
+        b2 = pkg.LocalBA()
+        while not stop:
+            b2.LocalBundleAdjustmentBatch(probs[:8])
+    def extractor():
+        ex = pkg.Extractor()
+        imgs = pkg.synth.synth_batch(0, 16)
+        while not stop:
+            ex.extract_batch(imgs)
+    th = [threading.Thread(target=other_lba), threading.Thread(target=extractor)]
+    [t.start() for t in th]
+    try:
+        for _ in range(25):
+            got = ba.LocalBundleAdjustmentBatch(probs)
+            assert all(_same(a, b) for a, b in zip(got, ref))
+    finally:
+        stop.append(1)
+        [t.join() for t in th]
+
+
 def test_lba_handles_come_and_go(pkg, gpu):
     """A handle keeps worker threads and structure buffers between calls: creating, using (batches that start the pool,
     single windows that do not, a rejected input in between) and destroying many handles leaves nothing behind and
