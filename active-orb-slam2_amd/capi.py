@@ -148,6 +148,7 @@ def lib():
             L.aos2_frames_stream.argtypes = [vp]
             L.aos2_frames_stream.restype = vp
             L.aos2_frames_wait.argtypes = [vp]
+            L.aos2_frames_wait_for_stream.argtypes = [vp, vp]
             L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
             L.aos2_frames_set_pose.argtypes = [vp, vp]
             L.aos2_frames_set_distortion.argtypes = [vp, cf, cf, cf, cf, cf]
@@ -1016,3 +1017,7 @@ class Frames:
 
     def stream(self):
         return self.L.aos2_frames_stream(self.h)
+
+    def wait_for_stream(self, hip_stream=None):
+        """device-side ordering: what is enqueued on the batch from now on runs behind the work on `hip_stream` so far"""
+        _check(self.L.aos2_frames_wait_for_stream(self.h, hip_stream))

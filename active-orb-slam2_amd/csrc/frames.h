@@ -34,7 +34,7 @@ struct FramesDev {
 };
 
 // the members of MapPoint the per-frame path reads (include/MapPoint.h): GetWorldPos, GetDescriptor, Observations() > 0,
-// GetNormal, GetMin/MaxDistanceInvariance
+// GetNormal, mfMinDistance / mfMaxDistance (raw)
 // cv::undistortPoints(p, p, K, distCoef, noArray(), K) on one CV_32FC2 point, as Frame::UndistortKeyPoints /
 // Frame::ComputeImageBounds use it (src/Frame.cc:433-493).  OpenCV 3.2 imgproc/undistort.cpp, cvUndistortPoints: camera
 // matrix and coefficients widened to double, 5 fixed-point iterations of the inverse of the radial (k1 k2 k3) +
@@ -80,6 +80,8 @@ struct aos2_frames {
     bool dev_ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {};
+    hipEvent_t order_ev = nullptr;   // ordering only (no timing): recorded on this batch's stream for a batch that reads its members
+    hipEvent_t ext_ev = nullptr;     // recorded on a caller's stream by aos2_frames_wait_for_stream
     aos2::FramesDev D = {};
     int32_t *d_overflow = nullptr;   // sticky: largest per-frame window population that exceeded the entry pool's share
     aos2::DevBuf<uint8_t> mem;       // the per-frame member arrays

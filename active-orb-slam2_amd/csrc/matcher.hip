@@ -1533,12 +1533,14 @@ __device__ __forceinline__ ProjSetup proj_gen_setup(const FrameDev &F, const Pro
             const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)P.normal[3 * i]),
                                                    __dmul_rn((double)PO[1], (double)P.normal[3 * i + 1])),
                                          __dmul_rn((double)PO[2], (double)P.normal[3 * i + 2]));
-            if (dist3D < P.min_dist[i] || dist3D > P.max_dist[i]) return S;
+            if (dist3D < __fmul_rn(0.8f, P.min_dist[i]) || dist3D > __fmul_rn(1.2f, P.max_dist[i])) return S;
             if (dot < __dmul_rn(0.5, (double)dist3D)) return S;
         }
     }
+    // range gate: Get{Min,Max}DistanceInvariance() = 0.8f * mfMinDistance / 1.2f * mfMaxDistance (src/MapPoint.cc:413-423);
+    // PredictScale below takes the raw mfMaxDistance (:427-459) -- min_dist / max_dist carry the raw members
     const float maxd = P.max_dist[i];
-    if (dist3D < P.min_dist[i] || dist3D > maxd) return S;
+    if (dist3D < __fmul_rn(0.8f, P.min_dist[i]) || dist3D > __fmul_rn(1.2f, maxd)) return S;
     // MapPoint::PredictScale (src/MapPoint.cc:427-459)
     const float ratio = __fdiv_rn(maxd, dist3D);
     const float lg = (float)log((double)ratio);
@@ -1674,7 +1676,7 @@ __global__ void is_in_frustum_kernel(ProjGenDev P, float min_x, float max_x, flo
         if (!(uu < min_x || uu > max_x) && !(vv < min_y || vv > max_y)) {
             const float PO[3] = {__fsub_rn(pw[0], P.Ow[0]), __fsub_rn(pw[1], P.Ow[1]), __fsub_rn(pw[2], P.Ow[2])};
             const float dist = norm3d(PO);
-            if (!(dist < P.min_dist[i] || dist > P.max_dist[i])) {
+            if (!(dist < __fmul_rn(0.8f, P.min_dist[i]) || dist > __fmul_rn(1.2f, P.max_dist[i]))) {   // Get{Min,Max}DistanceInvariance()
                 const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)P.normal[3 * i]),
                                                        __dmul_rn((double)PO[1], (double)P.normal[3 * i + 1])),
                                              __dmul_rn((double)PO[2], (double)P.normal[3 * i + 2]));
@@ -2312,14 +2314,16 @@ static int check_frame(const aos2_frame_view_t *f)
 }
 
 // levels handed in per query (mnTrackScaleLevel, LastFrame octaves, keyframe octaves): they index the frame's scale tables
-static int check_levels(const int32_t *lv, int n, int n_levels, const char *what)
+// (only of the queries the reference reads them for: mnTrackScaleLevel of a point that is not in view, or the octave of a
+// LastFrame feature without a usable map point, may be stale / uninitialised there -- `live` = that gate, NULL = all)
+static int check_levels(const int32_t *lv, int n, int n_levels, const char *what, const uint8_t *live = nullptr)
 {
     if (n > 0 && !lv) {
         set_error("%s is NULL", what);
         return AOS2_ERR_ARG;
     }
     for (int i = 0; i < n; ++i)
-        if ((unsigned)lv[i] >= (unsigned)n_levels) {
+        if ((!live || live[i]) && (unsigned)lv[i] >= (unsigned)n_levels) {
             set_error("%s[%d] = %d outside the %d pyramid levels", what, i, lv[i], n_levels);
             return AOS2_ERR_ARG;
         }
@@ -2733,7 +2737,7 @@ int aos2_matcher_search_by_projection(aos2_matcher_t *m, const aos2_frame_view_t
         set_error("bad map point set (NULL array)");
         return AOS2_ERR_ARG;
     }
-    if ((st = check_levels(p->pred_level, p->n_mp, f->n_levels, "pred_level"))) return st;
+    if ((st = check_levels(p->pred_level, p->n_mp, f->n_levels, "pred_level", p->track_in_view))) return st;
     if ((st = matcher_init(m))) return st;
     Arena A{m};
     size_t fo[12];
@@ -2825,7 +2829,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
             set_error("bad projection problem %d", i);
             return AOS2_ERR_ARG;
         }
-        if ((st = check_levels(pi.pred_level, pi.n_mp, frames[i].n_levels, "pred_level"))) return st;
+        if ((st = check_levels(pi.pred_level, pi.n_mp, frames[i].n_levels, "pred_level", pi.track_in_view))) return st;
         // entry budget: a search window rarely holds more than a few dozen features; 512 per map point (or the
         // whole frame if smaller) is the bound here -- AOS2_ERR_CAPACITY if a problem ever needs more
         pool_cap += (size_t)problems[i].n_mp * (size_t)std::min(frames[i].n_f, 512);
@@ -2924,7 +2928,7 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
         set_error("bad last-frame point set (NULL array)");
         return AOS2_ERR_ARG;
     }
-    if ((st = check_levels(p->last_octave, p->n_last, cur->n_levels, "last_octave"))) return st;
+    if ((st = check_levels(p->last_octave, p->n_last, cur->n_levels, "last_octave", p->last_valid))) return st;
     if ((st = matcher_init(m))) return st;
     Arena A{m};
     size_t fo[12];

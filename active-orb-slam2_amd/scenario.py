@@ -108,7 +108,7 @@ def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors,
             pos.append(Xw.astype(np.float32)); desc.append(d); has_obs.append(obs)
             normal.append((n / dist).astype(np.float32))
             mx = dist * sf[int(octave)]
-            maxd.append(np.float32(1.2 * mx)); mind.append(np.float32(0.8 * mx / sf[-1]))
+            maxd.append(np.float32(mx)); mind.append(np.float32(np.float32(mx) / np.float32(sf[-1])))   # raw mfMaxDistance / mfMinDistance (src/MapPoint.cc:406-407)
             return len(pos) - 1
 
         dl = scen["depth_last"][u]

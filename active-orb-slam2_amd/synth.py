@@ -371,7 +371,7 @@ def _points_for_view(rng, view, tgt, R, t, c, jitter=1.5):
     dist = np.linalg.norm(PO, axis=1)
     lvl = view["kp_octave"][tgt] + rng.uniform(-0.95, 0.95, n)
     max_dist = dist * 1.2 ** lvl
-    min_dist = max_dist / 1.2 ** 7 * 0.8
+    min_dist = max_dist / 1.2 ** 7                         # raw mfMinDistance / mfMaxDistance (the searches apply 0.8f / 1.2f)
     far = rng.random(n) < 0.05
     max_dist[far] *= 0.2                                   # out of the scale-invariance range
     nrm = PO / dist[:, None] + rng.normal(0, 0.25, (n, 3))
@@ -409,6 +409,36 @@ def synth_proj_gen_problem(seed: int, n_f: int = 1000, n_pts: int = 1500, cfg: s
              bf=np.float32(c["bf"]), log_scale_factor=np.float32(np.log(np.float32(1.2))),
              inv_level_sigma2=(1.0 / (sf * sf)).astype(np.float32), th=np.float32(th))
     return view, p
+
+
+
+def frustum_hand_case():
+    """Hand-computed Frame::isInFrustum / MapPoint::PredictScale cases (src/Frame.cc:326-343, src/MapPoint.cc:413-459): a
+    camera at the origin looking down +z, points on the optical axis at distance d with raw mfMaxDistance M and
+    mfMinDistance m.  The range gate is 0.8f*m <= d <= 1.2f*M, the level is ceil(log(M / d) / log(1.2)) clamped to 0..7.
+    Returns (frame view, point set, expected in_view, expected level)."""
+    c = CONFIGS["tum"]
+    rng = np.random.default_rng(5)
+    view = _view_from(rng, rng.uniform(20, c["w"] - 20, 50), rng.uniform(20, c["h"] - 20, 50), c["w"], c["h"], stereo=True)
+    #        d     M                 m     in_view level
+    rows = [(5.0, 5.0 * 1.2 ** 2.5, 0.5, 1, 3),     # ratio 1.2^2.5 -> ceil(2.5) = 3 (the 1.2x-conflated value would give 4)
+            (5.0, 5.0 * 1.2 ** 0.5, 0.5, 1, 1),     # ratio 1.2^0.5 -> 1
+            (5.0, 5.0 / 1.1, 0.5, 1, 0),            # beyond the raw maximum but inside 1.2 * M: in view, ratio < 1 -> level 0
+            (5.0, 5.0 / 1.25, 0.5, 0, 0),           # beyond 1.2 * M: rejected
+            (5.0, 40.0, 5.0 / 0.85, 1, 7),          # below the raw minimum but above 0.8 * m: in view; level clamps to 7
+            (5.0, 40.0, 5.0 / 0.75, 0, 0),          # below 0.8 * m: rejected
+            (2.0, 2.0 * 1.2 ** 6.5, 0.1, 1, 7),     # ceil(6.5) = 7
+            (2.0, 2.0 * 1.2 ** 5.5, 0.1, 1, 6)]
+    n = len(rows)
+    pos = np.array([[0, 0, r[0]] for r in rows], np.float32)
+    p = dict(n_pts=n, valid=np.ones(n, np.uint8), pos=pos, max_dist=np.array([r[1] for r in rows], np.float32),
+             min_dist=np.array([r[2] for r in rows], np.float32), normal=np.tile(np.array([0, 0, 1], np.float32), (n, 1)),
+             desc=synth_descriptors(rng, n), q_angle=np.zeros(n, np.float32), R=np.eye(3, dtype=np.float32).reshape(9),
+             t=np.zeros(3, np.float32), Ow=np.zeros(3, np.float32), R2=np.eye(3, dtype=np.float32).reshape(9), t2=np.zeros(3, np.float32),
+             fx=np.float32(c["fx"]), fy=np.float32(c["fy"]), cx=np.float32(c["cx"]), cy=np.float32(c["cy"]), bf=np.float32(c["bf"]),
+             log_scale_factor=np.float32(np.log(np.float32(1.2))), inv_level_sigma2=(1.0 / (view["scale_factors"] ** 2)).astype(np.float32),
+             th=np.float32(3.0))
+    return view, p, np.array([r[3] for r in rows], np.uint8), np.array([r[4] for r in rows], np.int32)
 
 
 def synth_sim3_problem(seed: int, n1: int = 1000, n2: int = 1000, cfg: str = "kitti", th: float = 7.5):
@@ -454,7 +484,7 @@ def synth_sim3_problem(seed: int, n1: int = 1000, n2: int = 1000, cfg: str = "ki
         desc = synth_descriptors(rng, n)
         desc[mine[ok]] = flip_bits(rng, other_view["desc_f"][theirs[ok]], 0.07)
         return dict(n_pts=n, valid=(rng.random(n) < 0.9).astype(np.uint8), pos=Xw.astype(np.float32),
-                    max_dist=max_dist.astype(np.float32), min_dist=(max_dist / 1.2 ** 7 * 0.8).astype(np.float32),
+                    max_dist=max_dist.astype(np.float32), min_dist=(max_dist / 1.2 ** 7).astype(np.float32),
                     normal=np.zeros((n, 3), np.float32), desc=desc, q_angle=np.zeros(n, np.float32),
                     R=Rw.astype(np.float32).reshape(9), t=tw.astype(np.float32), Ow=np.zeros(3, np.float32),
                     R2=R2_.astype(np.float32).reshape(9), t2=t2_.astype(np.float32), fx=np.float32(fx), fy=np.float32(fy),

@@ -438,7 +438,9 @@ typedef struct {
     int32_t n_pts;
     const uint8_t *valid;            /* the per-point gate of the reference loop head, see each function */
     const float *pos;                /* 3 per point: GetWorldPos() */
-    const float *max_dist, *min_dist;   /* GetMax/MinDistanceInvariance() */
+    const float *max_dist, *min_dist;   /* MapPoint::mfMaxDistance / mfMinDistance, RAW (include/MapPoint.h:149-150): the range gate applies
+                                      * Get{Max,Min}DistanceInvariance()'s 1.2f / 0.8f (src/MapPoint.cc:413-423) on the device and
+                                      * MapPoint::PredictScale (:427-459) divides the raw maximum by the distance */
     const float *normal;             /* 3 per point: GetNormal() (unused by SearchBySim3 and the reloc search) */
     const uint8_t *desc;             /* 32 per point: GetDescriptor() */
     const float *q_angle;            /* reloc search only: pKF->mvKeysUn[i].angle */
@@ -636,14 +638,21 @@ typedef struct {
     const uint8_t *desc;     /* n x 32 GetDescriptor() */
     const uint8_t *has_obs;  /* n      Observations() > 0 */
     const float *normal;     /* n x 3  GetNormal()                       (SearchLocalPoints only) */
-    const float *min_dist;   /* n      GetMinDistanceInvariance()        (SearchLocalPoints only) */
-    const float *max_dist;   /* n      GetMaxDistanceInvariance()        (SearchLocalPoints only) */
+    const float *min_dist;   /* n      mfMinDistance, raw (gate: 0.8f * it)  (SearchLocalPoints only) */
+    const float *max_dist;   /* n      mfMaxDistance, raw (gate: 1.2f * it; PredictScale: it / dist)  (SearchLocalPoints only) */
 } aos2_map_points_dev_t;
 
 /* batch frames of at most cap (<= 5632) keypoints each */
 int aos2_frames_create(int device, int batch, int cap, aos2_frames_t **out);
 void aos2_frames_destroy(aos2_frames_t *f);
 void *aos2_frames_stream(aos2_frames_t *f);   /* the batch's hipStream_t */
+/* Device-side ordering, no host wait: everything enqueued on the batch after this call runs behind the work enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the null stream) so far.  For the inputs the caller produces on a stream of its own:
+ * the MapPoint table, d_local, d_Tcw, the depth images.  (The batches order themselves where they read each other:
+ * aos2_frames_build behind the extractor's batch, aos2_frames_search_by_projection_last behind everything enqueued on
+ * `last`'s stream -- in a tracking loop the previous CurrentFrame batch becomes LastFrame while its PoseOptimization is
+ * still in flight.) */
+int aos2_frames_wait_for_stream(aos2_frames_t *f, void *hip_stream);
 /* waits for everything enqueued on the batch; AOS2_ERR_CAPACITY if a frame's search windows did not fit the entry pool */
 int aos2_frames_wait(aos2_frames_t *f);
 

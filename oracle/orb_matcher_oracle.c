@@ -688,7 +688,7 @@ int orc_fuse(const orc_frame_view_t *f, const orc_proj_gen_t *p, int32_t *best_i
         const float ur = u - p->bf * invz;
         float PO[3] = {p3Dw[0] - p->Ow[0], p3Dw[1] - p->Ow[1], p3Dw[2] - p->Ow[2]};
         const float dist3D = norm3(PO);
-        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        if (dist3D < 0.8f * p->min_dist[i] || dist3D > 1.2f * p->max_dist[i]) continue; /* Get{Min,Max}DistanceInvariance() src/MapPoint.cc:413-423 */
         const float *Pn = p->normal + 3 * (size_t)i;
         const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
         if (dot < 0.5 * dist3D) continue;
@@ -755,7 +755,7 @@ static int proj_sim3_kf(const orc_frame_view_t *f, const orc_proj_gen_t *p, int 
         if (!(u >= f->min_x && u < f->max_x && v >= f->min_y && v < f->max_y)) continue;
         float PO[3] = {p3Dw[0] - p->Ow[0], p3Dw[1] - p->Ow[1], p3Dw[2] - p->Ow[2]};
         const float dist3D = norm3(PO);
-        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        if (dist3D < 0.8f * p->min_dist[i] || dist3D > 1.2f * p->max_dist[i]) continue; /* Get{Min,Max}DistanceInvariance() src/MapPoint.cc:413-423 */
         const float *Pn = p->normal + 3 * (size_t)i;
         const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
         if (dot < 0.5 * dist3D) continue;
@@ -827,7 +827,7 @@ static void sim3_direction(const orc_frame_view_t *f, const orc_proj_gen_t *p, i
         const float v = p->fy * y + p->cy;
         if (!(u >= f->min_x && u < f->max_x && v >= f->min_y && v < f->max_y)) continue;
         const float dist3D = norm3(c2);
-        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        if (dist3D < 0.8f * p->min_dist[i] || dist3D > 1.2f * p->max_dist[i]) continue; /* Get{Min,Max}DistanceInvariance() src/MapPoint.cc:413-423 */
         const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
         const float radius = p->th * f->scale_factors[nPredictedLevel];
         const int nInd = features_in_area(f, u, v, radius, -1, -1, vIndices);
@@ -904,7 +904,7 @@ int orc_search_by_projection_reloc(const orc_frame_view_t *f, const orc_proj_gen
         if (v < f->min_y || v > f->max_y) continue;
         float PO[3] = {x3Dw[0] - p->Ow[0], x3Dw[1] - p->Ow[1], x3Dw[2] - p->Ow[2]};
         const float dist3D = norm3(PO);
-        if (dist3D < p->min_dist[i] || dist3D > p->max_dist[i]) continue;
+        if (dist3D < 0.8f * p->min_dist[i] || dist3D > 1.2f * p->max_dist[i]) continue; /* Get{Min,Max}DistanceInvariance() src/MapPoint.cc:413-423 */
         const int nPredictedLevel = predict_scale(p->max_dist[i], dist3D, p->log_scale_factor, f->n_levels);
         const float radius = p->th * f->scale_factors[nPredictedLevel];
         const int nInd = features_in_area(f, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
@@ -1047,7 +1047,7 @@ void orc_is_in_frustum(const orc_proj_gen_t *p, float min_x, float max_x, float 
         if (v < min_y || v > max_y) continue;
         float PO[3] = {P[0] - p->Ow[0], P[1] - p->Ow[1], P[2] - p->Ow[2]};
         const float dist = norm3(PO);
-        if (dist < p->min_dist[i] || dist > p->max_dist[i]) continue;
+        if (dist < 0.8f * p->min_dist[i] || dist > 1.2f * p->max_dist[i]) continue; /* Get{Min,Max}DistanceInvariance() src/MapPoint.cc:413-423 */
         const float *Pn = p->normal + 3 * (size_t)i;
         const double dot = (double)PO[0] * (double)Pn[0] + (double)PO[1] * (double)Pn[1] + (double)PO[2] * (double)Pn[2];
         const float viewCos = (float)(dot / dist);

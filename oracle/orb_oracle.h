@@ -191,7 +191,7 @@ typedef struct {
     int n_pts;
     const uint8_t *valid;          /* per-point static gate, see each function */
     const float *pos;              /* 3 per point: GetWorldPos() */
-    const float *max_dist, *min_dist;  /* GetMax/MinDistanceInvariance() */
+    const float *max_dist, *min_dist;  /* mfMaxDistance / mfMinDistance, RAW: the gates apply 1.2f / 0.8f, PredictScale takes the raw maximum */
     const float *normal;           /* 3 per point: GetNormal() (Fuse, SearchByProjection(KF,Scw)) */
     const uint8_t *desc;           /* 32 per point: GetDescriptor() */
     const float *q_angle;          /* SearchByProjection(F,KF): pKF->mvKeysUn[i].angle */

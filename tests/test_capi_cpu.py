@@ -116,13 +116,27 @@ def test_matcher_rejects_inconsistent_inputs_before_any_upload(pkg):
     bad(g, mp, "grid_idx")
     g = dict(f); g["kp_octave"] = f["kp_octave"].copy(); g["kp_octave"][5] = f["n_levels"]
     bad(g, mp, "kp_octave")
-    q = dict(mp); q["pred_level"] = mp["pred_level"].copy(); q["pred_level"][7] = -1
+    iv, nv = int(np.flatnonzero(mp["track_in_view"])[3]), int(np.flatnonzero(mp["track_in_view"] == 0)[0])
+    q = dict(mp); q["pred_level"] = mp["pred_level"].copy(); q["pred_level"][iv] = -1
     bad(f, q, "pred_level")
+    # mnTrackScaleLevel of a point that is NOT in view is never read by the reference (src/ORBmatcher.cc:55-61): a stale value
+    # there is legal -- the call passes validation (and, on this machine without a GPU, stops at the device)
+    q = dict(mp); q["pred_level"] = mp["pred_level"].copy(); q["pred_level"][nv] = -12345
+    if pkg.device_count() < 1:
+        with pytest.raises(capi.AosError) as e:
+            m.SearchByProjection(f, q)
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE
     cur, last = pkg.synth.synth_proj_last_problem(4, n=200)
-    l2 = dict(last); l2["last_octave"] = last["last_octave"].copy(); l2["last_octave"][3] = 99
+    lv, ln = int(np.flatnonzero(last["last_valid"])[3]), int(np.flatnonzero(last["last_valid"] == 0)[0])
+    l2 = dict(last); l2["last_octave"] = last["last_octave"].copy(); l2["last_octave"][lv] = 99
     with pytest.raises(capi.AosError) as e:
         m.SearchByProjectionLast(cur, l2, 7.0, False)
     assert e.value.code == capi.AOS2_ERR_ARG and "last_octave" in str(e.value)
+    l2 = dict(last); l2["last_octave"] = last["last_octave"].copy(); l2["last_octave"][ln] = 99   # no usable map point: never read
+    if pkg.device_count() < 1:
+        with pytest.raises(capi.AosError) as e:
+            m.SearchByProjectionLast(cur, l2, 7.0, False)
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE
 
 
 def test_image_bounds_host_equals_oracle(pkg, oracle):

@@ -153,3 +153,51 @@ def test_chain_with_blank_frames(pkg, gpu):
     for b in (1, 2):
         assert np.array_equal(T[b], scen["Tcw_guess"][b].reshape(16)) and (mp[b] == -1).all()
     assert T[0].tobytes() == T_ref[0].tobytes() and (mp[0] == mp_ref[0]).all()
+
+
+def test_rolling_last_frame_needs_no_host_wait(pkg, gpu):
+    """In a tracking loop the previous CurrentFrame batch becomes LastFrame while its PoseOptimization / SearchLocalPoints are
+    still in flight on its own stream: SearchByProjection(Current, Last) orders itself behind them on the device (no host wait
+    in between) and gives what the fully synchronous sequence gives."""
+    import torch
+    scen = pkg.scenario.tracking_scenario(11, 48, n_unique=8)
+    tc = pkg.chain.TrackingChain(scen, n_local=1200)
+    B, W, H, cap, s = tc.B, tc.W, tc.H, tc.cap, scen
+    F = pkg.capi.Frames
+    nxt = F(B, cap)
+    ex2 = pkg.Extractor(nfeatures=scen["nfeatures"])
+    k2 = torch.zeros((B, cap, 7), dtype=torch.float32, device=tc.dev)
+    d2 = torch.zeros((B, cap, 32), dtype=torch.uint8, device=tc.dev)
+    n2 = torch.zeros((B,), dtype=torch.int32, device=tc.dev)
+    nm = torch.zeros((2, B), dtype=torch.int32, device=tc.dev)
+
+    def run(sync):
+        tc.step()
+        if sync:
+            tc.wait()
+        # the camera stands still: the next frames are the same images, their pose guess is the (not yet finished) pose of
+        # the frames that now play LastFrame -- read from `tc.cur` on the device by the search itself
+        ex2.extract_batch_device_async(tc.d_cur.data_ptr(), B, W, H, W, W * H, k2.data_ptr(), d2.data_ptr(), cap, n2.data_ptr())
+        nxt.build(ex2, k2.data_ptr(), d2.data_ptr(), n2.data_ptr(), W, H, tc.d_depth.data_ptr(), float(s["fx"]), float(s["fy"]),
+                  float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+        nxt.set_pose(tc.d_guess.data_ptr())
+        nxt.SearchByProjectionLast(tc.cur, tc.table, 15.0, mono=False, check_orientation=True, d_nmatches=nm[0].data_ptr())
+        nxt.PoseOptimization(tc.table, nm[1].data_ptr())
+        nxt.wait()
+        tc.wait()
+        return nxt.get(F.MAP_POINTS), nxt.get(F.TCW), nxt.get(F.OUTLIER), nm.cpu().numpy().copy()
+
+    want = run(True)
+    assert (want[3][0] > 100).all()
+    for _ in range(3):
+        got = run(False)
+        for a, b in zip(got, want):
+            assert a.tobytes() == b.tobytes()
+    # a caller-produced input on a stream of its own: the batch is ordered behind it on the device
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g2 = tc.d_guess.clone()
+    nxt.wait_for_stream(side.cuda_stream)
+    nxt.set_pose(g2.data_ptr())
+    nxt.wait()
+    assert nxt.get(F.TCW).tobytes() == tc.d_guess.cpu().numpy().tobytes()

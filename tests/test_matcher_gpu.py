@@ -377,6 +377,15 @@ def test_is_in_frustum_feeds_search_local_points(pkg, oracle, gpu):
     assert len(m.isInFrustum(f, empty)["proj_x"]) == 0
 
 
+def test_is_in_frustum_hand_computed_levels(pkg, gpu):
+    """range gate on 1.2f * mfMaxDistance / 0.8f * mfMinDistance, PredictScale on the raw mfMaxDistance (src/Frame.cc:326-343,
+    src/MapPoint.cc:413-459): hand-computed levels, on the single-frame entry and through the Fuse / KF / reloc gates"""
+    f, p, want_in, want_lvl = pkg.synth.frustum_hand_case()
+    a = pkg.Matcher(0.8, True).isInFrustum(f, p, 0.5)
+    assert (a["track_in_view"] == want_in).all()
+    assert (a["pred_level"][want_in > 0] == want_lvl[want_in > 0]).all()
+
+
 def test_frame_grid_and_rgbd_depth_vs_oracle(pkg, oracle, gpu):
     """Frame::AssignFeaturesToGrid (src/Frame.cc:259-274) and Frame::ComputeStereoFromRGBD (:672-693)"""
     S = pkg.synth

@@ -410,7 +410,7 @@ def test_projection_family_golden_and_numpy_restatement(oracle, pkg):
             ur = u - p["bf"] / pc[2]
             PO = X - Ow
             d = np.linalg.norm(PO)
-            if (f["min_x"] <= u < f["max_x"] and f["min_y"] <= v < f["max_y"] and p["min_dist"][i] <= d <= p["max_dist"][i]
+            if (f["min_x"] <= u < f["max_x"] and f["min_y"] <= v < f["max_y"] and 0.8 * p["min_dist"][i] <= d <= 1.2 * p["max_dist"][i]
                     and PO @ p["normal"][i] >= 0.5 * d):
                 lvl = int(min(max(np.ceil(np.log(p["max_dist"][i] / d) / p["log_scale_factor"]), 0), f["n_levels"] - 1))
                 r = p["th"] * sf[lvl]
@@ -479,10 +479,19 @@ def test_is_in_frustum_numpy_restatement(oracle, pkg):
     d = np.linalg.norm(PO, axis=1)
     cosv = (PO * p["normal"]).sum(1) / d
     ok = (pc[:, 2] >= 0) & (u >= f["min_x"]) & (u <= f["max_x"]) & (v >= f["min_y"]) & (v <= f["max_y"]) & \
-         (d >= p["min_dist"]) & (d <= p["max_dist"]) & (cosv >= 0.5)
+         (d >= 0.8 * p["min_dist"]) & (d <= 1.2 * p["max_dist"]) & (cosv >= 0.5)
     assert (ok == (r["track_in_view"] > 0)).mean() > 0.998 and ok.sum() > 500
     both = ok & (r["track_in_view"] > 0)
     assert np.allclose(r["proj_x"][both], u[both], atol=2e-3) and np.allclose(r["view_cos"][both], cosv[both], atol=1e-5)
     lvl = np.clip(np.ceil(np.log(p["max_dist"] / d) / p["log_scale_factor"]), 0, f["n_levels"] - 1)
     assert (r["pred_level"][both] == lvl[both]).mean() > 0.998
     assert np.allclose(r["proj_xr"][both], u[both] - p["bf"] / pc[both, 2], atol=2e-3)
+
+
+def test_is_in_frustum_hand_computed_levels(oracle, pkg):
+    """the range gate uses 1.2f * mfMaxDistance / 0.8f * mfMinDistance, PredictScale the RAW mfMaxDistance
+    (src/Frame.cc:326-343, src/MapPoint.cc:413-459): levels and gates computed by hand"""
+    f, p, want_in, want_lvl = pkg.synth.frustum_hand_case()
+    r = oracle.is_in_frustum(f, p, 0.5)
+    assert (r["track_in_view"] == want_in).all()
+    assert (r["pred_level"][want_in > 0] == want_lvl[want_in > 0]).all()
