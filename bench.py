@@ -108,12 +108,45 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- parity of the LAST timed step (oracle imported only here): every rank checks its own frames' left keypoints /
+    # descriptors and mvuRight / mvDepth, rank 0 also the slots it gathered from every rank, all against the oracle
+    parity_checked = None
+    if args.verify is None or args.verify:
+        import __graft_entry__ as g
+        g.load_oracle()
+        import parity
+        bad = []
+        hk = lk.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.capi.KP_DTYPE).reshape(B, cap)
+        hd, hn, hur, hdp = ld.cpu().numpy(), ln.cpu().numpy(), ur.cpu().numpy(), dp.cpu().numpy()
+        for i in range(B):
+            bad += parity.stereo_slot_mismatches(pkg, hk[i], hd[i], int(hn[i]), hur[i], hdp[i], pairs[i][0], pairs[i][1], cfg,
+                                                 tag=f"rank {rank} frame {lo + i}")
+        n_slots = 0
+        if rank == 0 and world > 1:
+            import oracle as O
+            got = torch.cat([b_.cpu() for b_ in bufs[(args.steps - 1) % 2]]).numpy()   # [8][slot bytes], rank-major = frame order
+            for fr, (k_, d_) in enumerate(pkg.sharding.unpack_slots(got, cap, pkg.capi.KP_DTYPE)):
+                okl, odl = O.Extractor(nfeatures=NF).extract(pkg.synth.synth_stereo_pair(500 + fr, W, H)[0])
+                n_slots += 1
+                if len(k_) != len(okl) or k_.tobytes() != okl.tobytes() or not (d_ == odl).all():
+                    bad.append(f"gathered slot of frame {fr}: keypoints / descriptors differ from the oracle's")
+        okf = torch.tensor([0 if bad else 1, B, n_slots], dtype=torch.int64, device=cdev)
+        if world > 1:
+            mn = okf.clone()
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            dist.all_reduce(okf, op=dist.ReduceOp.SUM)
+            okf[0] = mn[0]
+        parity_checked = {"ok": bool(okf[0].item() == 1), "step": "the last timed step", "frames": int(okf[1].item()),
+                          "gathered_slots": int(okf[2].item()),
+                          "checked": "per frame on its rank: left keypoints, descriptors, mvuRight, mvDepth; on rank 0: keypoints and "
+                                     "descriptors of every gathered slot (bit-identical)",
+                          "against": "oracle (C restatement; parity unpinned by the reference)", "mismatches_rank0": bad[:10]}
     if rank == 0:
         ok = None
         if world > 1:
             hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in bufs[(args.steps - 1) % 2]])
             ok = bool(((hdr > 0) & (hdr <= cap)).all())
-        print(json.dumps({
+        print(json.dumps({"parity_checked": parity_checked, 
             "metric": "frames/sec (stereo extract + stereo match, 8 frames/step sharded, gathered) EuRoC 752x480",
             "value": total * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
@@ -122,6 +155,9 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
                                    "(%d per rank), slots gathered to rank 0 every step" % B,
                        "frames_per_step": total, "frames_per_rank": B, "slot_bytes": sb, "backend": backend, "headers_ok": ok,
                        "stereo_matches_per_frame": float((dp > 0).sum().item()) / B}}))
+        if parity_checked is not None and not parity_checked["ok"]:
+            sys.stdout.flush()
+            raise SystemExit(3)
 
 
 def main():
@@ -137,7 +173,26 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed `extra` rows (matcher / BA / stereo / vocabulary): used for the rocprofv3 summaries, whose per-kernel averages should cover the timed workload only")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="after the timed region, check results of the LAST timed step against the oracle and report them as "
+                         "`parity_checked` (default: on at N = 1 for tum, on for euroc8)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, torch.distributed.run on
+    # 127.0.0.1); under a launcher (WORLD_SIZE set) the two must agree -- an 8-GPU line is never printed by one rank
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.execv(sys.executable, cmd)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import torch  # first: the library then binds to the same HIP runtime as torch
     import torch.distributed as dist
@@ -150,6 +205,8 @@ def main():
     backend = os.environ.get("AOS2_BENCH_BACKEND", "nccl")
     if os.environ.get("AOS2_BENCH_SHARE_GPU"):
         local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -252,6 +309,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("AOS2_BENCH_FAULT"):   # test hook (tests/test_bench_gpu.py): the device table moves, the oracle's inputs do not
+        for pp in pipes:
+            pp.d_table["pos"][pp.map["mp_last"][0][pp.map["mp_last"][0] >= 0][:40].tolist()] += 0.05
     for i in range(args.warmup):
         step(i)
     sync()
@@ -268,6 +328,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- what the LAST timed step left behind, copied before anything else reuses the buffers: checked against the oracle
+    # below (`parity_checked`).  The oracle is only imported here, after the timed region.
+    do_verify = (world == 1) if args.verify is None else args.verify
+    snap = None
+    if rank == 0 and do_verify:
+        g.load_oracle()
+        import parity
+        lp, ll = pipes[(args.steps - 1) % NPIPE], lba_prep[(args.steps - 1) % NLBA]
+        snap = dict(chain=parity.chain_snapshot(pkg, lp), pipe=lp,
+                    lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win)])
     nm_host = pipes[0].d_nm.cpu().numpy()
     lba_res = lba_prep[0]["R"]
     # ---- stage times of one synchronous pass (every stage waited for: wall clock incl. launch latency)
@@ -613,35 +683,27 @@ def main():
             out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
                                            "timed region, in flight while the next step runs" % (B, sb),
                                "bytes_to_rank0_per_step": (world - 1) * B * sb, "backend": backend, "headers_ok": gather_ok}
+        co, lba_want = None, {}
+        if snap is not None or (world == 1 and not args.no_cpu_baseline):
+            O = g.load_oracle()
+            import parity
+            co = parity.ChainOracle(scen, snap["pipe"] if snap is not None else pipes[0], th_last=pipes[0].th_last, th_local=pipes[0].th_local,
+                                    nnratio_local=pipes[0].nnratio_local)
         if world == 1 and not args.no_cpu_baseline:   # rank 0 at N = 1 only
             # the SAME composite through the oracle (C restatement, one core): per frame extraction + Frame members +
             # the tracking chain (oracle/chain.py), per `fpk` frames one LocalBA window (oracle lba_solve)
-            O = g.load_oracle()
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import chain as ochain
-            oe = O.Extractor(nfeatures=NF)
-            sf, isg = oe.scale_factors, oe.inv_sigma2
-            tc0 = pipes[0]
             n_cpu = args.cpu_frames or 32
             n_cpu = max(fpk, (n_cpu // fpk) * fpk)
             tm = {}
-            oe.extract(scen["cur"][0])
+            co.oe.extract(scen["cur"][0])
             tc = time.perf_counter()
             done = 0
             for i in range(n_cpu):
-                u = i % n_unique
-                ta = time.perf_counter()
-                okps, odesc = oe.extract(scen["cur"][u])
-                tm["extract"] = tm.get("extract", 0.0) + time.perf_counter() - ta
-                ta = time.perf_counter()
-                f = ochain.frame_from_extraction(okps, odesc, scen["depth_cur"][u], scen, sf, isg)
-                tm["frame_build"] = tm.get("frame_build", 0.0) + time.perf_counter() - ta
-                lk = tc0.host_last[u][0]
-                last_h = dict(mp=tc0.last_mp[u, :len(lk)], outlier=tc0.last_outlier[u, :len(lk)], kp_octave=lk["octave"], kp_angle=lk["angle"])
-                ochain.track_frame(f, last_h, tc0.map["table"], tc0.map["local"][u], scen["Tcw_guess"][u], scen["Tlw"][u], scen, timing=tm)
+                co.unique(i % n_unique, timing=tm)
                 if (i + 1) % fpk == 0:
                     ta = time.perf_counter()
-                    O.lba_solve(lba_probs[(i // fpk) % len(lba_probs)])
+                    k = (i // fpk) % len(lba_unique)
+                    lba_want[k] = O.lba_solve(lba_unique[k])
                     tm["local_ba"] = tm.get("local_ba", 0.0) + time.perf_counter() - ta
                 done += 1
                 if time.perf_counter() - tc > 30.0 and done % fpk == 0:
@@ -671,7 +733,34 @@ def main():
                                                                       "sample": f"{tot} frames, one oracle extractor per thread"}
             except Exception as exc:  # never break the contract line
                 out["cpu_baseline"]["extract_only_frame_parallel"] = {"error": repr(exc)}
+        if snap is not None:
+            # ---- parity of the LAST timed step: every batch position whose (LastFrame, CurrentFrame) pair the oracle has run (all
+            # of them after the cpu_baseline leg, at least 8 distinct ones otherwise) and every LocalBA window of the last
+            # timed batch whose problem the oracle has solved (at least 2 distinct ones)
+            for u in range(min(n_unique, 8)):
+                co.unique(u)
+            pos = [b for b in range(B) if int(scen["index"][b]) in co.cache]
+            bad = parity.chain_mismatches(snap["chain"], co, pos)
+            if snap["lba"]:
+                for k in range(min(2, len(lba_unique))):
+                    if k not in lba_want:
+                        lba_want[k] = O.lba_solve(lba_unique[k])
+            wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
+            for w in wins:
+                bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")
+            out["parity_checked"] = {
+                "ok": not bad, "step": "the last timed step (results copied right after the timed region)",
+                "frames": len(pos), "distinct_frame_pairs": len(co.cache), "local_ba_windows": len(wins),
+                "distinct_local_ba_problems": len(set(w % len(lba_unique) for w in wins)),
+                "checked": "per frame: keypoints, descriptors, mvuRight / mvDepth, match counts of both searches, inlier counts of both "
+                           "PoseOptimizations, mvpMapPoints, mvbOutlier (bit-identical), mTcw (1e-5); per window: iteration and trial "
+                           "counts, outlier sets (identical), poses and points (1e-5), final chi2 (1e-6 relative)",
+                "against": "oracle (C restatement; parity unpinned by the reference: DESIGN.md section 3)",
+                "mismatches": bad[:10], "n_mismatches": len(bad)}
         print(json.dumps(out))
+        if snap is not None and not out["parity_checked"]["ok"]:
+            sys.stdout.flush()
+            raise SystemExit(3)   # a fast wrong result is not a result
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

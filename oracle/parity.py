@@ -1,0 +1,143 @@
+"""ORACLE (test infrastructure): comparisons of the HIP path's results with the oracle's on the SAME inputs, shared by
+tests/ and by bench.py's --verify leg (which checks the last TIMED step).  Only tests/, smoke() and bench.py may use it.
+
+Every function returns a list of mismatch descriptions (empty = parity holds) instead of asserting, so that bench.py can
+report them in its JSON line and the tests can assert on the list.
+
+Bars (north_star): keypoints, descriptors, Frame members, map point assignments, outlier flags and
+counts bit-identical; poses / points within 1e-5 absolute of the oracle's float32 write-back (plus the float32 spacing of
+the value); identical Levenberg-Marquardt iteration and trial counts.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle as O
+import chain as ochain
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool((np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 2 * np.spacing(np.abs(b).astype(np.float32))).all())
+
+
+def worst(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()) if np.size(a) else 0.0
+
+
+class ChainOracle:
+    """The oracle's results for the distinct (LastFrame, CurrentFrame) pairs of a scenario.tracking_scenario(), computed on
+    demand and kept (a tiled batch repeats them).  `tc` = the TrackingChain whose LastFrame members / map were built from
+    the scenario (chain.py builds them on the host from the extractor's keypoints of the last / older views)."""
+
+    def __init__(self, scen, tc, th_last=15.0, th_local=3.0, nnratio_local=0.8):
+        self.scen, self.tc = scen, tc
+        self.oe = O.Extractor(nfeatures=scen["nfeatures"])
+        self.th = (th_last, th_local, nnratio_local)
+        self.cache = {}
+
+    def unique(self, u, timing=None):
+        if u in self.cache and timing is None:
+            return self.cache[u]
+        import time
+        scen, tc = self.scen, self.tc
+        t0 = time.perf_counter()
+        okps, odesc = self.oe.extract(scen["cur"][u])
+        t1 = time.perf_counter()
+        f = ochain.frame_from_extraction(okps, odesc, scen["depth_cur"][u], scen, self.oe.scale_factors, self.oe.inv_sigma2)
+        t2 = time.perf_counter()
+        if timing is not None:
+            timing["extract"] = timing.get("extract", 0.0) + t1 - t0
+            timing["frame_build"] = timing.get("frame_build", 0.0) + t2 - t1
+        lk = tc.host_last[u][0]
+        last_h = dict(mp=tc.last_mp[u, :len(lk)], outlier=tc.last_outlier[u, :len(lk)], kp_octave=lk["octave"], kp_angle=lk["angle"])
+        out = ochain.track_frame(f, last_h, tc.map["table"], tc.map["local"][u], scen["Tcw_guess"][u], scen["Tlw"][u], scen,
+                                 th_last=self.th[0], th_local=self.th[1], nnratio_local=self.th[2], timing=timing)
+        self.cache[u] = (okps, odesc, f, out)
+        return self.cache[u]
+
+
+def chain_snapshot(pkg, tc):
+    """host copies of what TrackingChain.step() + wait() left on the device (taken before anything else reuses the batch)"""
+    F = pkg.capi.Frames
+    B, cap = tc.B, tc.cap
+    return dict(B=B, cap=cap, n=tc.d_n.cpu().numpy(),
+                kps=tc.d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(pkg.capi.KP_DTYPE).reshape(B, cap),
+                desc=tc.d_desc.cpu().numpy(), mp=tc.cur.get(F.MAP_POINTS), outlier=tc.cur.get(F.OUTLIER), Tcw=tc.cur.get(F.TCW),
+                u_right=tc.cur.get(F.U_RIGHT), depth=tc.cur.get(F.DEPTH), nm=tc.d_nm.cpu().numpy())
+
+
+def chain_mismatches(snap, co: ChainOracle, positions):
+    """The device-resident chain's members (chain_snapshot) against the oracle chain, for the batch positions given
+    (position b holds unique pair scen["index"][b])."""
+    scen = co.scen
+    n, kps, desc, mp, outl, T, ur, dp, nm = (snap[k] for k in ("n", "kps", "desc", "mp", "outlier", "Tcw", "u_right", "depth", "nm"))
+    bad = []
+    for b in positions:
+        u = int(scen["index"][b])
+        okps, odesc, f, w = co.unique(u)
+        tag = f"frame {b} (pair {u})"
+        if n[b] != len(okps):
+            bad.append(f"{tag}: {n[b]} keypoints, oracle {len(okps)}")
+            continue
+        k = int(n[b])
+        if kps[b, :k].tobytes() != okps.tobytes():
+            bad.append(f"{tag}: keypoints differ")
+        if not (desc[b, :k] == odesc).all():
+            bad.append(f"{tag}: descriptors differ")
+        if ur[b, :k].tobytes() != f["u_right"].tobytes() or dp[b, :k].tobytes() != f["depth"].tobytes():
+            bad.append(f"{tag}: mvuRight / mvDepth differ")
+        want_nm = (w["nmatches_last"], w["inliers_1"], w["nmatches_local"], w["inliers_2"])
+        if tuple(int(v) for v in nm[:, b]) != tuple(int(v) for v in want_nm):
+            bad.append(f"{tag}: counts {tuple(int(v) for v in nm[:, b])}, oracle {tuple(int(v) for v in want_nm)}")
+        if not (mp[b, :k] == w["mp_after_local"]).all() or not (mp[b, k:] == -1).all():
+            bad.append(f"{tag}: mvpMapPoints differ in {int((mp[b, :k] != w['mp_after_local']).sum())} features")
+        if not (outl[b, :k] == w["outlier_2"]).all():
+            bad.append(f"{tag}: mvbOutlier differs in {int((outl[b, :k] != w['outlier_2']).sum())} features")
+        if not close(T[b], w["Tcw_2"]):
+            bad.append(f"{tag}: mTcw off by {worst(T[b], w['Tcw_2']):.3g}")
+    return bad
+
+
+def lba_mismatches(got, want, tag="window"):
+    """one LocalBundleAdjustment result (capi.LocalBA._result dict) against oracle.lba_solve's"""
+    bad = []
+    if got["status"] != 0:
+        bad.append(f"{tag}: status {got['status']}")
+    if tuple(got["iters"]) != tuple(want["iters"]):
+        bad.append(f"{tag}: iterations {tuple(got['iters'])}, oracle {tuple(want['iters'])}")
+    if sum(got["trials"]) != want["trials"]:
+        bad.append(f"{tag}: {sum(got['trials'])} LM trials, oracle {want['trials']}")
+    if not close(got["pose_Tcw"], want["pose_Tcw"]):
+        bad.append(f"{tag}: poses off by {worst(got['pose_Tcw'], want['pose_Tcw']):.3g}")
+    if not close(got["point_xyz"], want["point_xyz"]):
+        bad.append(f"{tag}: points off by {worst(got['point_xyz'], want['point_xyz']):.3g}")
+    if not (got["edge_outlier"] == want["edge_outlier"]).all():
+        bad.append(f"{tag}: outlier sets differ in {int((got['edge_outlier'] != want['edge_outlier']).sum())} edges")
+    c = want["chi2_trace"][-1] if len(want["chi2_trace"]) else 0.0
+    if abs(got["final_chi2"] - c) > 1e-6 * max(c, 1e-30):
+        bad.append(f"{tag}: final chi2 {got['final_chi2']!r}, oracle {c!r}")
+    return bad
+
+
+def stereo_slot_mismatches(pkg, kps, desc, n, u_right, depth, left_img, right_img, cfg, tag="frame"):
+    """One stereo frame of the EuRoC workload (both eyes' ORBextractor::operator() + Frame::ComputeStereoMatches,
+    src/Frame.cc:495-669): left keypoints / descriptors and mvuRight / mvDepth against the oracle, bit for bit."""
+    bad = []
+    oe_l, oe_r = O.Extractor(nfeatures=cfg["nfeatures"]), O.Extractor(nfeatures=cfg["nfeatures"])
+    okl, odl = oe_l.extract(left_img)
+    okr, odr = oe_r.extract(right_img)
+    if n != len(okl):
+        return [f"{tag}: {n} keypoints, oracle {len(okl)}"]
+    if np.ascontiguousarray(kps[:n]).tobytes() != okl.tobytes():
+        bad.append(f"{tag}: left keypoints differ")
+    if not (desc[:n] == odl).all():
+        bad.append(f"{tag}: left descriptors differ")
+    mbf = np.float32(cfg["bf"])
+    mb = np.float32(mbf / np.float32(cfg["fx"]))
+    our, odp, _ = O.compute_stereo_matches(oe_l, oe_r, okl, odl, okr, odr, mb, mbf)
+    if u_right[:n].tobytes() != our.tobytes() or depth[:n].tobytes() != odp.tobytes():
+        bad.append(f"{tag}: mvuRight / mvDepth differ in {int((u_right[:n] != our).sum())} features")
+    return bad

@@ -40,17 +40,51 @@ def test_bench_contract_single_gpu(gpu):
     assert set(d["cpu_baseline"]["ms_per_frame"]) >= {"extract", "search_by_projection_last", "pose_optimization", "search_local_points", "local_ba"}
     m = d["config"]["matches_per_frame_mean"]
     assert m["search_by_projection_last"] > 100 and m["inliers_2"] > 100 and d["config"]["local_ba_iterations"][0] > 0
+    # the last timed step was checked against the oracle: every batch position and every LocalBA window of it
+    pc = d["parity_checked"]
+    assert pc["ok"] is True and pc["n_mismatches"] == 0 and pc["frames"] == 32 and pc["distinct_frame_pairs"] >= 8
+    assert pc["local_ba_windows"] == 4 and pc["distinct_local_ba_problems"] >= 2
 
 
-@pytest.mark.parametrize("workload", ["tum", "euroc8"])
-def test_bench_two_ranks_share_the_gpu(gpu, workload):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16",
-           "--no-extra", "--no-cpu-baseline", "--workload", workload]
+def test_bench_detects_a_wrong_result(gpu):
+    """the --verify leg is a real check: with one map point of the table moved after the oracle inputs were fixed
+    (AOS2_BENCH_FAULT, a test hook) the line reports the mismatch and the process fails"""
+    env = dict(os.environ)
+    env["AOS2_BENCH_FAULT"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 3 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    pc = json.loads(lines[0])["parity_checked"]
+    assert pc["ok"] is False and pc["n_mismatches"] > 0
+
+
+@pytest.mark.parametrize("workload,launcher", [("tum", "torchrun"), ("euroc8", "torchrun"), ("tum", "self"), ("euroc8", "self")])
+def test_bench_two_ranks_share_the_gpu(gpu, workload, launcher):
+    """N = 2 both ways: under torch.distributed.run (the driver's form) and as plain `python bench.py --gpus 2`, which starts
+    its own ranks"""
+    tail = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--no-extra", "--no-cpu-baseline",
+            "--workload", workload, "--verify"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     d = _run(cmd, {"AOS2_BENCH_BACKEND": "gloo", "AOS2_BENCH_SHARE_GPU": "1"})
-    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_checked"]["ok"] is True
+    if workload == "euroc8":
+        assert d["parity_checked"]["frames"] == 8 and d["parity_checked"]["gathered_slots"] == 8
     if workload == "tum":
         assert d["scaling"] == "weak" and d["exchange"]["headers_ok"] is True and d["exchange"]["bytes_to_rank0_per_step"] > 0
         assert abs(d["value"] - 2 * 16 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     else:
         assert d["scaling"] == "strong" and d["config"]["headers_ok"] is True and d["config"]["frames_per_rank"] == 4
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_gpu_count(gpu):
+    """--gpus N is what the line reports: a launcher that started another number of ranks is an error, not a mislabelled line"""
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -201,3 +201,28 @@ def test_rolling_last_frame_needs_no_host_wait(pkg, gpu):
     nxt.set_pose(g2.data_ptr())
     nxt.wait()
     assert nxt.get(F.TCW).tobytes() == tc.d_guess.cpu().numpy().tobytes()
+
+
+def test_bench_scenario_all_frames_vs_oracle(pkg, oracle, gpu):
+    """Exactly what bench.py times: `tracking_scenario(100, 256, n_unique=32)` through TrackingChain.step() (the whole chain
+    enqueued at once, asynchronously behind the extractor, n_local = 1500) -- every one of the 256 batch positions (32
+    distinct pairs, tiled) against the oracle chain: keypoints, descriptors, mvuRight / mvDepth, the match and inlier counts
+    of all four stages, mvpMapPoints, mvbOutlier bit-identical, mTcw within 1e-5.  Twice, with two steps in flight on two
+    pipelines like the bench."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    scen = pkg.scenario.tracking_scenario(100, 256, cfg="tum", n_unique=32)
+    pipes = [pkg.chain.TrackingChain(scen, n_local=1500) for _ in range(2)]
+    for p in pipes:
+        p.ex.set_chunks(1)
+    co = parity.ChainOracle(scen, pipes[0])
+    for rnd in range(2):
+        for p in pipes:
+            p.step()
+        for p in pipes:
+            p.wait()
+        for j, p in enumerate(pipes):
+            bad = parity.chain_mismatches(parity.chain_snapshot(pkg, p), co, range(256))
+            assert bad == [], (rnd, j, bad[:5])
+    nm = pipes[0].d_nm.cpu().numpy()
+    assert (nm[0] > 100).all() and (nm[3] > 100).all()

@@ -442,3 +442,33 @@ def test_lba_rejected_trials_and_early_termination(pkg, oracle, gpu, cfg):
     if cfg[0] != 44:   # these problems do contain rejected trials (lambda grows inside a pass)
         grow = [lt[i + 1] > lt[i] for i in range(len(lt) - 1) if i + 1 != n1]
         assert any(grow)
+
+
+@pytest.mark.parametrize("layout", ["slots", "walk"])
+def test_lba_bench_windows_vs_oracle(pkg, oracle, gpu, monkeypatch, layout):
+    """Exactly what bench.py times: the SURVEY 8(d) windows (`synth_lba_problem(i, n_points=8000)`: 50 keyframes, ~4000
+    points, ~24 k stereo edges), each solved alone and all together as bench.py's 32-window batch (4 distinct problems
+    tiled), in both landmark-kernel layouts -- poses, points, outlier sets, iteration and trial counts against the oracle
+    (1e-5), and the batch bit-identical to the single solves."""
+    import sys
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    monkeypatch.setenv("AOS2_LBA_LAYOUT", layout)
+    uniq = [pkg.synth.synth_lba_problem(i, n_points=8000) for i in range(4)]
+    assert all(p["n_edges"] > 20000 and p["n_poses"] == 50 for p in uniq)
+    want = [oracle.lba_solve(p) for p in uniq]
+    ba = pkg.LocalBA()
+    alone = [ba.LocalBundleAdjustment(p) for p in uniq]
+    for i, (a, w) in enumerate(zip(alone, want)):
+        assert parity.lba_mismatches(a, w, tag=f"window {i} alone ({layout})") == []
+    batch = ba.LocalBundleAdjustmentBatch([uniq[i % 4] for i in range(32)])
+    for i, got in enumerate(batch):
+        assert parity.lba_mismatches(got, want[i % 4], tag=f"window {i} of the batch ({layout})") == []
+        assert _same(got, alone[i % 4]), (layout, i)
+    # the prepared form bench.py calls (same inputs every step, results in place)
+    prep = ba.prepare_batch([uniq[i % 4] for i in range(32)])
+    for _ in range(2):
+        R = ba.solve_prepared(prep)
+    for i in range(32):
+        got = pkg.LocalBA._result(R[i], prep["arrs"][i])
+        assert parity.lba_mismatches(got, want[i % 4], tag=f"prepared window {i} ({layout})") == []

@@ -1,16 +1,22 @@
-"""One-off parity sweep (not part of the test suite): random image sizes / extractor parameters, HIP path vs oracle,
-keypoints + descriptors + every pyramid level compared bit for bit.  python tools/gpu_fuzz_extractor.py [n_cases]"""
+"""One-off parity sweep (a time-boxed slice of it runs in tests/test_fuzz_gpu.py): random image sizes / extractor parameters, HIP path vs oracle,
+keypoints + descriptors + every pyramid level compared bit for bit.  python tools/gpu_fuzz_extractor.py [n_cases [seconds]]"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle()
+budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 1e18   # optional time budget in seconds (tests/test_fuzz_gpu.py)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(12345)
 bad = 0
 rejected = 0
 t0 = time.time()
+ran = 0
 for c in range(n_cases):
+    if time.time() - t0 > budget_s:
+        break
+    ran += 1
     w = int(rng.integers(96, 1300)); h = int(rng.integers(96, 800))
     h = min(h, int(1.9 * w))   # round(w / h) == 0 is undefined behaviour in the reference (division by zero, :545)
     nf = int(rng.choice([100, 500, 1000, 2000, 3000]))
@@ -52,4 +58,4 @@ for c in range(n_cases):
             k1, d1 = oe.extract(im)
             if len(kb) != len(k1) or not (db == d1).all():
                 bad += 1; print("BATCH MISMATCH case", c, (w, h, nf, sf, nl))
-print("cases", n_cases, "rejected by design", rejected, "MISMATCHES / ERRORS", bad, "time %.1f s" % (time.time() - t0))
+print("cases", ran, "of", n_cases, "rejected by design", rejected, "MISMATCHES / ERRORS", bad, "time %.1f s" % (time.time() - t0))

@@ -1,11 +1,13 @@
-"""One-off parity sweep of the greedy / projection searches (not part of the test suite): random problem sizes, densities,
+"""One-off parity sweep of the greedy / projection searches (a time-boxed slice of it runs in tests/test_fuzz_gpu.py): random problem sizes, densities,
 radii, ratios and orientation flags, HIP path (parallel fixed-point stage B) vs the oracle.
-python tools/gpu_fuzz_matcher.py [n_cases]"""
+python tools/gpu_fuzz_matcher.py [n_cases [seconds]]"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle(); S = pkg.synth
+budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 1e18   # optional time budget in seconds (tests/test_fuzz_gpu.py)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(777)
 bad = 0
@@ -20,7 +22,11 @@ def chk(name, c, params, got, want):
         print("MISMATCH", name, "case", c, params, "n", got[0], want[0])
 
 
+ran = 0
 for c in range(n_cases):
+    if time.time() - t0 > budget_s:
+        break
+    ran += 1
     nf = int(rng.choice([8, 60, 300, 1000, 2000, 3100, 8000]))
     nq = int(rng.choice([5, 200, 1500, 3072, 3073, 4500]))
     th = float(rng.choice([1.0, 3.0, 7.0, 15.0, 40.0]))
@@ -51,4 +57,4 @@ for c in range(n_cases):
         res = pkg.Matcher(0.8, True).SearchByProjectionBatch([q[0] for q in probs], [q[1] for q in probs], th=3.0)
         for (ff, mm), r in zip(probs, res):
             chk("proj_batch", c, (ff["n_f"], mm["n_mp"]), r, O.search_by_projection_mp(ff, mm))
-print("cases", n_cases, "MISMATCHES", bad, "time %.1f s" % (time.time() - t0))
+print("cases", ran, "of", n_cases, "MISMATCHES", bad, "time %.1f s" % (time.time() - t0))

@@ -1,11 +1,13 @@
-"""One-off parity sweep (not part of the test suite) of the order-independent searches, the vocabulary and the asynchronous
-extractor call with awkward batch sizes, vs the oracle.  python tools/gpu_fuzz_more.py [n_cases]"""
+"""One-off parity sweep (a time-boxed slice of it runs in tests/test_fuzz_gpu.py) of the order-independent searches, the vocabulary and the asynchronous
+extractor call with awkward batch sizes, vs the oracle.  python tools/gpu_fuzz_more.py [n_cases [seconds]]"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle(); S = pkg.synth
+budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 1e18   # optional time budget in seconds (tests/test_fuzz_gpu.py)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(2468)
 bad = 0
@@ -19,7 +21,11 @@ def flag(name, c, params):
 
 
 dev = torch.device("cuda:0")
+ran = 0
 for c in range(n_cases):
+    if time.time() - t0 > budget_s:
+        break
+    ran += 1
     ori = bool(rng.integers(0, 2))
     # SearchForTriangulation
     n1, n2, nn = int(rng.choice([30, 600, 2100])), int(rng.choice([25, 700, 1900])), int(rng.choice([1, 20, 150]))
@@ -77,4 +83,4 @@ for c in range(n_cases):
                 wk, wd = want[bi % len(want)]
                 if n[bi] != len(wk) or kk[bi, : n[bi]].tobytes() != wk.tobytes() or not (dd[bi, : n[bi]] == wd).all():
                     flag("async", c, (B, w, h, bi)); break
-print("cases", n_cases, "MISMATCHES", bad, "time %.1f s" % (time.time() - t0))
+print("cases", ran, "of", n_cases, "MISMATCHES", bad, "time %.1f s" % (time.time() - t0))

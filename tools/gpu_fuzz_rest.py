@@ -1,11 +1,13 @@
-"""One-off parity sweep of the remaining rows (not part of the test suite): stereo matching, vocabulary transform,
+"""One-off parity sweep of the remaining rows (a time-boxed slice of it runs in tests/test_fuzz_gpu.py): stereo matching, vocabulary transform,
 PoseOptimization and LocalBundleAdjustment with random sizes / parameters vs the oracle.
-python tools/gpu_fuzz_rest.py [n_cases]"""
+python tools/gpu_fuzz_rest.py [n_cases [seconds]]"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle(); S = pkg.synth
+budget_s = float(sys.argv[2]) if len(sys.argv) > 2 else 1e18   # optional time budget in seconds (tests/test_fuzz_gpu.py)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(4321)
 bad = 0
@@ -16,7 +18,11 @@ def close(a, b, tol=1e-5):
     return (np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 2 * np.spacing(np.abs(b).astype(np.float32))).all()
 
 
+ran = 0
 for c in range(n_cases):
+    if time.time() - t0 > budget_s:
+        break
+    ran += 1
     # ---- stereo: random image size / feature count
     w, h = int(rng.integers(200, 1300)), int(rng.integers(160, 720))
     h = min(h, int(1.6 * w))
@@ -56,4 +62,4 @@ for c in range(n_cases):
                 bad += 1; print("MISMATCH lba", c, cfg)
         except Exception as e:
             bad += 1; print("ERROR lba", c, cfg, repr(e))
-print("cases", n_cases, "MISMATCHES / ERRORS", bad, "time %.1f s" % (time.time() - t0))
+print("cases", ran, "of", n_cases, "MISMATCHES / ERRORS", bad, "time %.1f s" % (time.time() - t0))
