@@ -1,0 +1,95 @@
+// Persistent C-ABI handles for the reference-signature classes of this directory: one matcher / optimiser handle per
+// calling thread, device and (nnratio, checkOri) pair, created on first use and kept (a handle owns a stream, device
+// arenas and page-locked staging buffers: creating one per call cost more than the call).  The reference constructs
+// `ORBmatcher matcher(0.9, true)` on the stack inside every tracking function (src/Tracking.cc:862, 981, 1371 ...), so
+// the class is a thin value object and the heavy state lives here.
+//
+// Device selection: the reference has no notion of a device.  A thread picks the GPU its calls run on with
+// aos2::set_thread_device(d) (thread-local, default 0: the Tracking / LocalMapping / LoopClosing threads of one System all
+// use the same GPU unless told otherwise); the handle caches are keyed by it, so switching devices mid-thread gets handles
+// of the new device instead of silently staying on the first one.
+#pragma once
+#include <chrono>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+
+#include "../../include/aos2.h"
+
+namespace aos2 {
+
+inline int &thread_device()
+{
+    thread_local int d = 0;
+    return d;
+}
+inline void set_thread_device(int device) { thread_device() = device; }
+
+inline aos2_matcher_t *matcher_handle(float nnratio, bool checkOri)
+{
+    struct Cache {
+        std::map<std::tuple<int, float, bool>, aos2_matcher_t *> m;
+        ~Cache()
+        {
+            for (auto &kv : m) aos2_matcher_destroy(kv.second);
+        }
+    };
+    thread_local Cache cache;
+    const auto key = std::make_tuple(thread_device(), nnratio, checkOri);
+    auto it = cache.m.find(key);
+    if (it != cache.m.end()) return it->second;
+    aos2_matcher_t *h = nullptr;
+    if (aos2_matcher_create(nnratio, checkOri ? 1 : 0, thread_device(), &h) != AOS2_OK)
+        throw std::runtime_error(std::string("ORBmatcher: ") + aos2_last_error());
+    cache.m[key] = h;
+    return h;
+}
+
+inline aos2_lba_t *optimizer_handle()
+{
+    struct Cache {
+        std::map<int, aos2_lba_t *> m;
+        ~Cache()
+        {
+            for (auto &kv : m) aos2_lba_destroy(kv.second);
+        }
+    };
+    thread_local Cache cache;
+    auto it = cache.m.find(thread_device());
+    if (it != cache.m.end()) return it->second;
+    aos2_lba_t *h = nullptr;
+    if (aos2_lba_create(thread_device(), &h) != AOS2_OK) throw std::runtime_error(std::string("Optimizer: ") + aos2_last_error());
+    cache.m[thread_device()] = h;
+    return h;
+}
+
+// wall-clock split of the last call of this thread through one of the classes: gather (pointer graph -> SoA), the C-ABI
+// call, scatter (indices -> pointer graph)
+struct ShimTiming {
+    double gather_us = 0, call_us = 0, scatter_us = 0;
+};
+inline ShimTiming &last_shim_timing()
+{
+    thread_local ShimTiming t;
+    return t;
+}
+
+struct ShimClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+        return us;
+    }
+};
+
+inline void check(int st, const char *what)
+{
+    if (st != AOS2_OK) throw std::runtime_error(std::string(what) + ": " + aos2_last_error());
+}
+
+}  // namespace aos2
