@@ -2,30 +2,23 @@
 // (include/ORBVocabulary.h:31-32; loaders called from src/System.cc:89-92, transform from
 // Frame::ComputeBoW src/Frame.cc:424-431 / KeyFrame::ComputeBoW, score from KeyFrameDatabase.cc:133,249
 // and LoopClosing.cc:136), forwarding to the C ABI (include/aos2.h) -> HIP kernels.
-// DBoW2::BowVector / FeatureVector keep their std::map types, filled from the key-ascending arrays.
+// DBoW2::BowVector / FeatureVector keep their std::map types (Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h), filled
+// from the key-ascending arrays.  Include AFTER the DBoW2 headers and OpenCV (or tests/cpp/refstub/slam_stub.h).
 #pragma once
 #include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
-#include "aos2_types.h"
-
-namespace DBoW2 {
-typedef unsigned int WordId;   // BowVector.h:20
-typedef double WordValue;      // :23
-typedef unsigned int NodeId;   // :26
-class BowVector : public std::map<WordId, WordValue> {};
-class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
-}  // namespace DBoW2
+#include "aos2_handles.h"
 
 namespace ORB_SLAM2 {
 
 class ORBVocabulary {
 public:
-    explicit ORBVocabulary(int device = 0)
+    ORBVocabulary()   // (the GPU is the calling thread's: aos2::set_thread_device, default 0)
     {
-        if (aos2_vocabulary_create(device, &h_) != AOS2_OK) throw std::runtime_error(aos2_last_error());
+        if (aos2_vocabulary_create(aos2::thread_device(), &h_) != AOS2_OK) throw std::runtime_error(aos2_last_error());
     }
     ~ORBVocabulary() { aos2_vocabulary_destroy(h_); }
     ORBVocabulary(const ORBVocabulary &) = delete;
@@ -43,7 +36,7 @@ public:
     int getDepthLevels() const { return aos2_vocabulary_levels(h_); }
 
     // features: one 1x32 CV_8U row per descriptor (Converter::toDescriptorVector, src/Converter.cc:27-35)
-    void transform(const std::vector<aos2::Mat8> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup)
+    void transform(const std::vector<cv::Mat> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup)
     {
         v.clear();
         fv.clear();

@@ -1,30 +1,32 @@
-// ORB_SLAM2::ORBextractor with the reference's class surface (include/ORBextractor.h:45-111),
-// forwarding to the C ABI (include/aos2.h) -> HIP kernels.  Frame.cc / Tracking.cc call it as they
-// call the reference class: ctor (Tracking.cc:120-126), operator() (Frame.cc:276-282), getters
-// (Frame.cc:37-43,94-100), public mvImagePyramid (Frame.cc:502,592,609).
+// ORB_SLAM2::ORBextractor with the REFERENCE's class surface (include/ORBextractor.h:45-111), forwarding to the C ABI
+// (include/aos2.h) -> HIP kernels.  Frame.cc / Tracking.cc call it as they call the reference class: ctor
+// (Tracking.cc:120-126), operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&, cv::OutputArray)
+// (Frame.cc:276-282), getters (Frame.cc:37-43,94-100), public mvImagePyramid (Frame.cc:502,592,609).
+// Include AFTER <opencv2/core/core.hpp> (or tests/cpp/refstub/opencv_stub.h in this image, which has no OpenCV).
 #pragma once
 #include <cassert>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
-#include "aos2_types.h"
+#include "aos2_handles.h"
 
 namespace ORB_SLAM2 {
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(aos2_keypoint_t) && sizeof(cv::KeyPoint) == 28, "cv::KeyPoint layout");
 
 class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };  // include/ORBextractor.h:49 (unused by the reference too)
 
-    // exposePyramid: copy all bordered levels back after every operator() (the reference's mvImagePyramid is always
-    // there).  Off by default: its only reader, Frame::ComputeStereoMatches, runs on the device pyramids
-    // (host/Frame.h), so the copy (8 levels, ~1.4 MB for 640x480) would be paid by every frame for nothing; a caller
-    // that does read mvImagePyramid calls FillImagePyramid() after operator().
-    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0,
-                 bool exposePyramid = false)
-        : nlevels_(nlevels), exposePyramid_(exposePyramid)
+    // The reference's five arguments; the GPU is the calling thread's (aos2::set_thread_device, default 0).
+    // mvImagePyramid: the reference's is always there after operator().  Its only reader, Frame::ComputeStereoMatches, runs on
+    // the pyramids the two extractors already hold on the device (FrameMembers.h), so by default the levels are NOT copied back
+    // after every frame (8 levels, ~1.4 MB for 640x480); a caller that does read mvImagePyramid calls FillImagePyramid() after
+    // operator(), or switches the copy on for every frame with SetExposePyramid(true).
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) : nlevels_(nlevels)
     {
-        if (aos2_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_) != AOS2_OK)
+        if (aos2_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, aos2::thread_device(), &h_) != AOS2_OK)
             throw std::invalid_argument(std::string("ORBextractor: ") + aos2_last_error());
         const float *a = aos2_extractor_scale_factors(h_), *b = aos2_extractor_inv_scale_factors(h_);
         const float *c = aos2_extractor_sigma2(h_), *d = aos2_extractor_inv_sigma2(h_);
@@ -39,26 +41,30 @@ public:
     ORBextractor &operator=(const ORBextractor &) = delete;
 
     // Compute the ORB features and descriptors on an image.  Mask is ignored (as in the reference).
-    void operator()(const aos2::Mat8 &image, const aos2::Mat8 & /*mask*/, std::vector<aos2::KeyPoint> &keypoints,
-                    aos2::Mat8 &descriptors)
+    void operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
     {
-        if (image.empty()) return;  // src/ORBextractor.cc:1046
+        if (_image.empty()) return;  // src/ORBextractor.cc:1046
+        const cv::Mat image = _image.getMat();
+        assert(image.type() == CV_8UC1);  // :1050
         const int cap = aos2_extractor_max_keypoints_for(h_, image.cols, image.rows);
-        keypoints.resize(cap);
+        _keypoints.resize(cap);
         scratch_.resize((size_t)cap * 32);
         int n = 0;
         const int st = aos2_extractor_extract(h_, image.data, image.cols, image.rows, (int)image.step,
-                                              reinterpret_cast<aos2_keypoint_t *>(keypoints.data()), scratch_.data(), cap, &n);
+                                              reinterpret_cast<aos2_keypoint_t *>(_keypoints.data()), scratch_.data(), cap, &n);
         if (st != AOS2_OK) throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
-        keypoints.resize(n);
+        _keypoints.resize(n);
         if (n == 0)
-            descriptors.release();  // :1065
+            _descriptors.release();  // :1065
         else {
-            descriptors.create(n, 32);  // :1068
-            std::copy(scratch_.begin(), scratch_.begin() + (size_t)n * 32, descriptors.data);
+            _descriptors.create(n, 32, CV_8U);  // :1068
+            cv::Mat descriptors = _descriptors.getMat();
+            for (int i = 0; i < n; ++i) memcpy(descriptors.ptr<uint8_t>(i), &scratch_[(size_t)i * 32], 32);
         }
         if (exposePyramid_) FillImagePyramid();
     }
+
+    void SetExposePyramid(bool on) { exposePyramid_ = on; }
 
     // mvImagePyramid[level] of the last operator() call: ROI (interior) of a buffer that carries the 19-px
     // REFLECT_101 frame (src/ORBextractor.cc:1113-1128)
@@ -67,11 +73,10 @@ public:
         for (int l = 0; l < nlevels_; ++l) {
             int w = 0, h = 0;
             aos2_extractor_pyramid_level_size(h_, l, &w, &h);
-            aos2::Mat8 full;
-            full.create(h + 38, w + 38);
+            cv::Mat full(h + 38, w + 38, CV_8UC1);
             if (aos2_extractor_pyramid_level(h_, 0, l, 19, full.data, (int)full.step) != AOS2_OK)
                 throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
-            mvImagePyramid[l] = full.roi(19, 19, w, h);
+            mvImagePyramid[l] = full(cv::Rect(19, 19, w, h));
         }
     }
 
@@ -82,14 +87,14 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    std::vector<aos2::Mat8> mvImagePyramid;
+    std::vector<cv::Mat> mvImagePyramid;
 
     aos2_extractor_t *handle() { return h_; }
 
 protected:
     aos2_extractor_t *h_ = nullptr;
     int nlevels_;
-    bool exposePyramid_;
+    bool exposePyramid_ = false;
     std::vector<uint8_t> scratch_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };

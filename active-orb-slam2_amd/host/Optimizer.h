@@ -1,4 +1,4 @@
-// ORB_SLAM2::Optimizer with the REFERENCE's signatures (include/Optimizer.h:45-47):
+// ORB_SLAM2::Optimizer with the REFERENCE's signatures for the two hot methods (include/Optimizer.h:45-47):
 //   void static LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap);
 //   int  static PoseOptimization(Frame *pFrame);
 // The bodies are what a maintainer puts into src/Optimizer.cc: the window gathering of :457-505 and the vertex / edge
@@ -17,25 +17,33 @@
 
 #include "aos2_handles.h"
 
+namespace aos2 {
+// Optional record of the order in which the last LocalBundleAdjustment of this thread emitted its vertices and edges
+// (KeyFrame::mnId / MapPoint::mnId): lets a test hand the SAME problem, in the same order, to another solver.
+struct LbaRecord {
+    bool enabled = false;
+    std::vector<int64_t> pose_id, point_id, edge_pose_id, edge_point_id;
+};
+inline LbaRecord &lba_record()
+{
+    thread_local LbaRecord r;
+    return r;
+}
+}  // namespace aos2
+
 namespace ORB_SLAM2 {
 
 class Optimizer {
 public:
     void static LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap);
     int static PoseOptimization(Frame *pFrame);
-
-private:
-    static double us_since(std::chrono::steady_clock::time_point t0)
-    {
-        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    }
 };
 
 // src/Optimizer.cc:454-779
 inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)
 {
-    auto t0 = std::chrono::steady_clock::now();
-    // Local KeyFrames: First Breath Search from Current Keyframe (:457-469)
+    aos2::ShimClock clk;
+    // the window: the current keyframe and its covisible keyframes, marked with the current keyframe's id (:457-469)
     std::list<KeyFrame *> lLocalKeyFrames;
     lLocalKeyFrames.push_back(pKF);
     pKF->mnBALocalForKF = pKF->mnId;
@@ -45,7 +53,7 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
         pKFi->mnBALocalForKF = pKF->mnId;
         if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
     }
-    // Local MapPoints seen in Local KeyFrames (:471-488)
+    // the map points those keyframes observe, each once, in the order their feature lists name them (:471-488)
     std::list<MapPoint *> lLocalMapPoints;
     for (KeyFrame *pKFi : lLocalKeyFrames) {
         std::vector<MapPoint *> vpMPs = pKFi->GetMapPointMatches();
@@ -55,7 +63,7 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
                 pMP->mnBALocalForKF = pKF->mnId;
             }
     }
-    // Fixed Keyframes: see Local MapPoints but are not Local Keyframes (:490-505)
+    // keyframes outside the window that observe a window point: they enter with a constant pose (:490-505)
     std::list<KeyFrame *> lFixedCameras;
     for (MapPoint *pMP : lLocalMapPoints) {
         std::map<KeyFrame *, size_t> observations = pMP->GetObservations();
@@ -121,7 +129,7 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
         }
     }
     aos2::ShimTiming &T = aos2::last_shim_timing();
-    T.gather_us = us_since(t0);
+    T.gather_us = clk.lap();
     if (pbStopFlag && *pbStopFlag) return;   // :656-658
     if (kfs.empty() || mps.empty() || edge_pose.empty()) return;
     aos2_lba_problem_t P;
@@ -138,12 +146,22 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
     aos2_lba_result_t R;
     memset(&R, 0, sizeof(R));
     R.pose_Tcw = out_T.data(); R.point_xyz = out_X.data(); R.edge_outlier = outlier.data(); R.edge_chi2 = nullptr;
-    t0 = std::chrono::steady_clock::now();
+    aos2::LbaRecord &rec = aos2::lba_record();
+    if (rec.enabled) {
+        rec.pose_id = pose_id;
+        rec.point_id = point_id;
+        rec.edge_pose_id.clear();
+        rec.edge_point_id.clear();
+        for (size_t e = 0; e < edge_pose.size(); ++e) {
+            rec.edge_pose_id.push_back(pose_id[edge_pose[e]]);
+            rec.edge_point_id.push_back(point_id[edge_point[e]]);
+        }
+    }
+    clk.lap();
     const int st = aos2_lba_solve(aos2::optimizer_handle(), &P, &R);
-    T.call_us = us_since(t0);
+    T.call_us = clk.lap();
     if (st == AOS2_ERR_STOPPED) return;
     if (st != AOS2_OK) throw std::runtime_error(std::string("LocalBundleAdjustment: ") + aos2_last_error());
-    t0 = std::chrono::steady_clock::now();
     // Check inlier observations (:712-744), erase under the map mutex (:746-757)
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
     for (size_t e = 0; e < outlier.size(); ++e) {
@@ -167,13 +185,13 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
         mps[j]->SetWorldPos(X);
         mps[j]->UpdateNormalAndDepth();
     }
-    T.scatter_us = us_since(t0);
+    T.scatter_us = clk.lap();
 }
 
 // src/Optimizer.cc:239-452
 inline int Optimizer::PoseOptimization(Frame *pFrame)
 {
-    auto t0 = std::chrono::steady_clock::now();
+    aos2::ShimClock clk;
     const int N = pFrame->N;
     std::vector<float> Xw, obs, is2;
     std::vector<uint8_t> stereo;
@@ -203,14 +221,12 @@ inline int Optimizer::PoseOptimization(Frame *pFrame)
     memset(&R, 0, sizeof(R));
     R.outlier = outlier.data();
     aos2::ShimTiming &T = aos2::last_shim_timing();
-    T.gather_us = us_since(t0);
-    t0 = std::chrono::steady_clock::now();
+    T.gather_us = clk.lap();
     if (aos2_pose_optimization(aos2::optimizer_handle(), &P, &R, 1) != AOS2_OK)
         throw std::runtime_error(std::string("PoseOptimization: ") + aos2_last_error());
-    T.call_us = us_since(t0);
-    t0 = std::chrono::steady_clock::now();
+    T.call_us = clk.lap();
     if (n < 3) {   // :355-356: return 0 before the pose is touched
-        T.scatter_us = us_since(t0);
+        T.scatter_us = clk.lap();
         return 0;
     }
     for (int k = 0; k < n; ++k) pFrame->mvbOutlier[vnIndexEdge[k]] = outlier[k] != 0;
@@ -219,7 +235,7 @@ inline int Optimizer::PoseOptimization(Frame *pFrame)
         for (int c = 0; c < 4; ++c) pose.at<float>(r, c) = R.Tcw[r * 4 + c];
     pFrame->SetPose(pose);
     pFrame->nBadPoseOpt = R.n_bad;   // :449
-    T.scatter_us = us_since(t0);
+    T.scatter_us = clk.lap();
     return R.n_inliers;
 }
 

@@ -1,20 +1,34 @@
-// TEST DRIVER: calls the reference-signature shims (active-orb-slam2_amd/host/ref/*.h) exactly like Tracking.cc /
-// LocalMapping.cc call the reference classes:
-//     ORBmatcher matcher(0.9, true);  matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, bMono);
-//     ORBmatcher matcher(0.8);        matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th);
-//     ORBmatcher matcher(0.7, true);  matcher.SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches);
-//     Optimizer::PoseOptimization(&mCurrentFrame);
-//     Optimizer::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpMap);
+// TEST DRIVER: calls the reference-signature classes (active-orb-slam2_amd/host/*.h) exactly like the reference's own call
+// sites do:
+//     Frame.cc:276-282      (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);          Frame.cc:109  ComputeStereoMatches();
+//     Tracking.cc:858,862   mCurrentFrame.ComputeBoW();   ORBmatcher matcher(0.7, true);  matcher.SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches);
+//     Tracking.cc:981       ORBmatcher matcher(0.9, true);  matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, bMono);
+//     Tracking.cc:1371      ORBmatcher matcher(0.8);        matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th);
+//     Tracking.cc:1632      matcher2.SearchByProjection(mCurrentFrame, vpCandidateKFs[i], sFound, 10, 100);
+//     Tracking.cc:695       matcher.SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100);
+//     Tracking.cc:870,994   Optimizer::PoseOptimization(&mCurrentFrame);
+//     LocalMapping.cc:81    Optimizer::LocalBundleAdjustment(mpCurrentKeyFrame, &mbAbortBA, mpMap);
+//     LocalMapping.cc:272   matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false);
+//     LocalMapping.cc:493   matcher.Fuse(pKFi, vpMapPointMatches);        LocalMapping.cc:156  pMP->ComputeDistinctiveDescriptors();
+//     LoopClosing.cc:267    matcher.SearchByBoW(mpCurrentKF, pKF, vvpMapPointMatches[i]);
+//     LoopClosing.cc:325    matcher.SearchBySim3(mpCurrentKF, pKF, vpMapPointMatches, s, R, t, 7.5);
+//     LoopClosing.cc:377    matcher.SearchByProjection(mpCurrentKF, mScw, mvpLoopMapPoints, mvpCurrentMatchedPoints, 10);
+//     LoopClosing.cc:601    matcher.Fuse(pKF, cvScw, mvpLoopMapPoints, 4, vpReplacePoints);
 // on a pointer graph (tests/cpp/refstub) built from the seeded problems of synth.py, and writes what the calls left in
-// the Frame / KeyFrame / MapPoint objects.  tests/test_ref_signature_gpu.py compares that with the ctypes path.
+// the Frame / KeyFrame / MapPoint objects.  tests/test_ref_signature_gpu.py compares that with the ORACLE.
 // usage: ref_signature_test <in.bundle> <out.bundle>      exit code 3 = no device
+#include <algorithm>
 #include <cstdio>
 #include <memory>
 
 #include "refstub/slam_stub.h"
 // (a real build includes the reference's Frame.h / KeyFrame.h / MapPoint.h / Map.h here instead)
-#include "../../active-orb-slam2_amd/host/ref/ORBmatcher.h"
-#include "../../active-orb-slam2_amd/host/ref/Optimizer.h"
+#include "../../active-orb-slam2_amd/host/ORBextractor.h"
+#include "../../active-orb-slam2_amd/host/ORBVocabulary.h"
+#include "../../active-orb-slam2_amd/host/ORBmatcher.h"
+#include "../../active-orb-slam2_amd/host/Optimizer.h"
+#include "../../active-orb-slam2_amd/host/FrameMembers.h"
+#include "../../active-orb-slam2_amd/host/MapPointMembers.h"
 #include "bundle_io.h"
 
 namespace ORB_SLAM2 {
@@ -72,6 +86,9 @@ static void fill_frame(Frame &F, const Bundle &B, const std::string &p)
     F.mDescriptors = desc_mat(B[p + "desc_f"].as<uint8_t>(), n);
     const BundleArray &sf = B[p + "scale_factors"];
     F.mvScaleFactors.assign(sf.as<float>(), sf.as<float>() + sf.count());
+    F.mvInvLevelSigma2.resize(sf.count());
+    for (size_t l = 0; l < sf.count(); ++l) F.mvInvLevelSigma2[l] = 1.0f / (F.mvScaleFactors[l] * F.mvScaleFactors[l]);
+    F.mfLogScaleFactor = logf(F.mvScaleFactors.size() > 1 ? F.mvScaleFactors[1] : 1.2f);
     F.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
     F.mvbOutlier.assign(n, false);
     Frame::mnMinX = B[p + "min_x"].scalar<float>(); Frame::mnMinY = B[p + "min_y"].scalar<float>();
@@ -87,6 +104,16 @@ static void fill_frame(Frame &F, const Bundle &B, const std::string &p)
         }
 }
 
+static DBoW2::FeatureVector feat_vec_named(const Bundle &B, const std::string &nid, const std::string &noff, const std::string &nidx)
+{
+    DBoW2::FeatureVector fv;
+    const BundleArray &id = B[nid], &off = B[noff], &idx = B[nidx];
+    for (size_t i = 0; i < id.count(); ++i)
+        for (int k = off.as<int32_t>()[i]; k < off.as<int32_t>()[i + 1]; ++k)
+            fv[(DBoW2::NodeId)id.as<int32_t>()[i]].push_back((unsigned)idx.as<int32_t>()[k]);
+    return fv;
+}
+
 static DBoW2::FeatureVector feat_vec(const Bundle &B, const std::string &sfx)
 {
     DBoW2::FeatureVector fv;
@@ -97,9 +124,149 @@ static DBoW2::FeatureVector feat_vec(const Bundle &B, const std::string &sfx)
     return fv;
 }
 
+// KeyFrame members from a frame-view bundle (the same arrays: a keyframe keeps mvKeysUn, mvuRight, mDescriptors, mGrid, bounds)
+static void fill_keyframe(KeyFrame &K, const Bundle &B, const std::string &p)
+{
+    const int n = (int)B[p + "kp_x"].count();
+    K.N = n;
+    K.mvKeys.resize(n);
+    K.mvKeysUn.resize(n);
+    for (int i = 0; i < n; ++i) {
+        cv::KeyPoint k;
+        k.pt.x = B[p + "kp_x"].as<float>()[i]; k.pt.y = B[p + "kp_y"].as<float>()[i];
+        k.angle = B[p + "kp_angle"].as<float>()[i]; k.octave = B[p + "kp_octave"].as<int32_t>()[i];
+        K.mvKeys[i] = K.mvKeysUn[i] = k;
+    }
+    const float *ur = B[p + "u_right"].as<float>();
+    K.mvuRight.assign(ur, ur + n);
+    K.mDescriptors = desc_mat(B[p + "desc_f"].as<uint8_t>(), n);
+    const BundleArray &sf = B[p + "scale_factors"];
+    K.mvScaleFactors.assign(sf.as<float>(), sf.as<float>() + sf.count());
+    K.mnScaleLevels = (int)sf.count();
+    K.mvLevelSigma2.resize(sf.count());
+    K.mvInvLevelSigma2.resize(sf.count());
+    for (size_t l = 0; l < sf.count(); ++l) {
+        K.mvLevelSigma2[l] = K.mvScaleFactors[l] * K.mvScaleFactors[l];
+        K.mvInvLevelSigma2[l] = 1.0f / K.mvLevelSigma2[l];
+    }
+    K.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+    K.mnMinX = (int)B[p + "min_x"].scalar<float>(); K.mnMinY = (int)B[p + "min_y"].scalar<float>();
+    K.mnMaxX = (int)B[p + "max_x"].scalar<float>(); K.mnMaxY = (int)B[p + "max_y"].scalar<float>();
+    K.mfGridElementWidthInv = B[p + "grid_w_inv"].scalar<float>();
+    K.mfGridElementHeightInv = B[p + "grid_h_inv"].scalar<float>();
+    const int32_t *goff = B[p + "grid_off"].as<int32_t>(), *gidx = B[p + "grid_idx"].as<int32_t>();
+    K.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
+    for (int ix = 0; ix < FRAME_GRID_COLS; ++ix)
+        for (int iy = 0; iy < FRAME_GRID_ROWS; ++iy) {
+            const int c = ix * FRAME_GRID_ROWS + iy;
+            for (int k = goff[c]; k < goff[c + 1]; ++k) K.mGrid[ix][iy].push_back((size_t)gidx[k]);
+        }
+}
+
+// camera members from a projection bundle (prefix + R / t / Ow / fx ...)
+static void set_camera(KeyFrame &K, const Bundle &B, const std::string &p)
+{
+    K.Tcw = cv::Mat(4, 4, CV_32F);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) K.Tcw.at<float>(r, c) = B[p + "R"].as<float>()[r * 3 + c];
+        K.Tcw.at<float>(r, 3) = B[p + "t"].as<float>()[r];
+    }
+    K.Tcw.at<float>(3, 3) = 1.0f;
+    K.Ow = pos_mat(B[p + "Ow"].as<float>());
+    K.fx = B[p + "fx"].scalar<float>(); K.fy = B[p + "fy"].scalar<float>(); K.cx = B[p + "cx"].scalar<float>(); K.cy = B[p + "cy"].scalar<float>();
+    K.mbf = B[p + "bf"].scalar<float>();
+    K.mfLogScaleFactor = B[p + "log_scale_factor"].scalar<float>();
+}
+
+// the map points of a projection bundle: every entry a MapPoint (valid or not: the caller turns the invalid ones into the
+// cases the method's loop head rejects)
+static std::vector<std::unique_ptr<MapPoint>> make_points(const Bundle &B, const std::string &p)
+{
+    const int n = (int)B[p + "valid"].count();
+    std::vector<std::unique_ptr<MapPoint>> pts;
+    for (int i = 0; i < n; ++i) {
+        pts.emplace_back(new MapPoint());
+        MapPoint *m = pts.back().get();
+        m->mnId = (unsigned long)i;
+        m->mWorldPos = pos_mat(B[p + "pos"].as<float>() + (size_t)i * 3);
+        m->mNormalVector = pos_mat(B[p + "normal"].as<float>() + (size_t)i * 3);
+        m->mDescriptor = row_desc(B[p + "desc"].as<uint8_t>() + (size_t)i * 32);
+        m->mfMaxDistance = B[p + "max_dist"].as<float>()[i];
+        m->mfMinDistance = B[p + "min_dist"].as<float>()[i];
+        m->nObs = 1 + i % 3;
+    }
+    return pts;
+}
+
+static cv::Mat mat3x3(const float *v)
+{
+    cv::Mat m(3, 3, CV_32F);
+    memcpy(m.data, v, 36);
+    return m;
+}
+
+static std::vector<float> flat(const cv::Mat &m)
+{
+    std::vector<float> v;
+    for (int r = 0; r < m.rows; ++r)
+        for (int c = 0; c < m.cols; ++c) v.push_back(m.at<float>(r, c));
+    return v;
+}
+
+static const unsigned long kHeld = 1000000ul;   // ids of placeholder map points a keyframe / frame holds on entry
+
+// placeholder map points on the features whose f_mp_state is not 0 (observations: 0 for state 1, else 1 + idx % 3)
+static std::vector<std::unique_ptr<MapPoint>> hold_points(KeyFrame &K, const uint8_t *state)
+{
+    std::vector<std::unique_ptr<MapPoint>> held;
+    for (int i = 0; i < K.N; ++i)
+        if (state[i]) {
+            held.emplace_back(new MapPoint());
+            MapPoint *h = held.back().get();
+            h->mnId = kHeld + (unsigned long)i;
+            h->nObs = state[i] == 2 ? 1 + i % 3 : 0;
+            h->mObservations[&K] = (size_t)i;
+            K.mvpMapPoints[i] = h;
+        }
+    return held;
+}
+
+static void run_new_call_sites(const Bundle &B, Bundle &O, std::vector<double> &timing);
+
 int main(int argc, char **argv)
 {
     if (argc < 3) return 2;
+    {   // the host side of the classes works without a GPU: constructor tables / getters (Frame.cc:37-43, 94-100), constants,
+        // vocabulary files (System.cc:89-92; the eof quirk of the binary loader: one more node and word)
+        ORBextractor ex(1000, 1.2f, 8, 20, 7);
+        const std::vector<float> sf = ex.GetScaleFactors(), isig = ex.GetInverseScaleSigmaSquares();
+        printf("levels %d scale %.3f sf7 %.6f isig7 %.6f\n", ex.GetLevels(), ex.GetScaleFactor(), sf[7], isig[7]);
+        if (ORBmatcher::TH_LOW != 50 || ORBmatcher::TH_HIGH != 100 || ORBmatcher::HISTO_LENGTH != 30) return 4;
+        ORBVocabulary voc;
+        if (!voc.empty()) return 10;
+        const int32_t parent[2] = {0, 0};
+        uint8_t vd[64] = {};
+        for (int i = 32; i < 64; ++i) vd[i] = 255;
+        const double vw[2] = {1.0, 3.0};
+        const uint8_t leaf[2] = {1, 1};
+        if (aos2_vocabulary_set_nodes(voc.handle(), 2, 1, 0, 0, 2, parent, vd, vw, leaf) != AOS2_OK || voc.size() != 2) return 11;
+        const std::string vp = std::string(argv[2]) + ".voc";
+        voc.saveToBinaryFile(vp);
+        ORBVocabulary v2;
+        if (!v2.loadFromBinaryFile(vp) || v2.size() != 3 || v2.getBranchingFactor() != 2 || v2.getDepthLevels() != 1) return 12;
+        if (aos2_device_count() >= 1) {
+            std::vector<cv::Mat> q;   // features: word 0, word 0, word 1
+            for (int i = 0; i < 3; ++i) {
+                q.push_back(cv::Mat(1, 32, CV_8U));
+                if (i == 2) memset(q.back().data, 255, 32);
+            }
+            DBoW2::BowVector bv;
+            DBoW2::FeatureVector fv;
+            v2.transform(q, bv, fv, 1);
+            if (bv.size() != 2 || bv[0] != 2.0 / 5.0 || bv[1] != 3.0 / 5.0 || fv.size() != 1 || fv[0].size() != 3) return 13;
+            if (v2.score(bv, bv) != 1.0) return 14;
+        }
+    }
     if (aos2_device_count() < 1) {
         printf("no device\n");
         return 3;
@@ -352,9 +519,14 @@ int main(int argc, char **argv)
                 if (k != cur) cur->mvpOrderedConnectedKeyFrames.push_back(k);
             Map map;
             bool abortBA = false;
+            aos2::lba_record().enabled = true;
             Optimizer::LocalBundleAdjustment(cur, &abortBA, &map);
             if (rep == 0) continue;
             note();
+            // the order in which the method emitted vertices and edges (ids): the oracle solves the same problem in the same order
+            const aos2::LbaRecord &rec = aos2::lba_record();
+            O.put("ba_rec_pose_id", 3, rec.pose_id); O.put("ba_rec_point_id", 3, rec.point_id);
+            O.put("ba_rec_edge_pose_id", 3, rec.edge_pose_id); O.put("ba_rec_edge_point_id", 3, rec.edge_point_id);
             std::vector<float> T((size_t)NP * 16), X((size_t)NL * 3);
             for (int i = 0; i < NP; ++i) memcpy(&T[(size_t)i * 16], kfs[i]->Tcw.data, 64);
             for (int j = 0; j < NL; ++j)
@@ -378,6 +550,7 @@ int main(int argc, char **argv)
             Optimizer::LocalBundleAdjustment(cur, &abortBA, &map);
             if (memcmp(probe.Tcw.data, cur->Tcw.data, 64) != 0) throw std::runtime_error("LocalBundleAdjustment ran with the stop flag set");
         }
+        run_new_call_sites(B, O, timing);
         O.put("timing_us", 4, timing);
         O.save(argv[2]);
     } catch (const std::exception &ex) {
@@ -386,4 +559,450 @@ int main(int argc, char **argv)
     }
     printf("ok\n");
     return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// the remaining call sites (bundle prefixes: kf_ fuse_ fuse3_ reloc_ sim3_ init_ tri_ bowkf_ fe_)
+// --------------------------------------------------------------------------------------------------------------------
+static void run_new_call_sites(const Bundle &B, Bundle &O, std::vector<double> &timing)
+{
+    auto note = [&]() {
+        const aos2::ShimTiming &T = aos2::last_shim_timing();
+        timing.push_back(T.gather_us); timing.push_back(T.call_us); timing.push_back(T.scatter_us);
+    };
+    // a Sim3 [s R | s t] from a projection bundle's R, t
+    auto sim3_of = [&](const std::string &p, float s) {
+        cv::Mat Scw(4, 4, CV_32F);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) Scw.at<float>(r, c) = s * B[p + "R"].as<float>()[r * 3 + c];
+            Scw.at<float>(r, 3) = s * B[p + "t"].as<float>()[r];
+        }
+        Scw.at<float>(3, 3) = 1.0f;
+        return Scw;
+    };
+    // ---------------------------------------------------------------- SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)  LoopClosing.cc:377
+    {
+        KeyFrame K;
+        fill_keyframe(K, B, "kf_f_");
+        set_camera(K, B, "kf_");
+        auto pts = make_points(B, "kf_");
+        const int n = (int)pts.size();
+        std::vector<MapPoint *> vpPoints;
+        for (auto &p : pts) vpPoints.push_back(p.get());
+        // vpMatched on entry: placeholders where the view's f_mp_state is set; an invalid point is a bad map point or one
+        // that already sits in vpMatched (:318-319)
+        std::vector<MapPoint *> vpMatched(K.N, static_cast<MapPoint *>(NULL));
+        std::vector<std::unique_ptr<MapPoint>> held;
+        std::vector<int> slots;
+        for (int i = 0; i < K.N; ++i)
+            if (B["kf_f_f_mp_state"].as<uint8_t>()[i]) {
+                held.emplace_back(new MapPoint());
+                held.back()->mnId = kHeld + (unsigned long)i;
+                vpMatched[i] = held.back().get();
+                slots.push_back(i);
+            }
+        size_t next_slot = 0;
+        for (int i = 0; i < n; ++i)
+            if (!B["kf_valid"].as<uint8_t>()[i]) {
+                if (i % 2 && next_slot < slots.size())
+                    vpMatched[slots[next_slot++]] = vpPoints[i];
+                else
+                    vpPoints[i]->mbBad = true;
+            }
+        const std::vector<MapPoint *> entry = vpMatched;
+        const cv::Mat Scw = sim3_of("kf_", 1.07f);
+        const shim_detail::Sim3Pose pose(Scw);   // (what the method itself derives from Scw: the oracle gets the same numbers)
+        ORBmatcher matcher(0.75, true);
+        {
+            std::vector<MapPoint *> warm = vpMatched;
+            matcher.SearchByProjection(&K, Scw, vpPoints, warm, (int)B["kf_th"].scalar<float>());
+        }
+        const int nm = matcher.SearchByProjection(&K, Scw, vpPoints, vpMatched, (int)B["kf_th"].scalar<float>());
+        note();
+        std::vector<int32_t> m(K.N, -1);
+        for (int j = 0; j < K.N; ++j)
+            if (vpMatched[j] != entry[j]) m[j] = (int32_t)vpMatched[j]->mnId;
+        O.put("kf_match", 1, m);
+        O.put("kf_n", 1, std::vector<int32_t>{nm});
+        O.put("kf_R", 2, flat(pose.Rcw)); O.put("kf_t", 2, flat(pose.tcw)); O.put("kf_Ow", 2, flat(pose.Ow));
+    }
+    // ---------------------------------------------------------------- Fuse(KeyFrame*, vpMapPoints, th)   LocalMapping.cc:493, 518
+    {
+        KeyFrame K;
+        fill_keyframe(K, B, "fuse_f_");
+        set_camera(K, B, "fuse_");
+        auto held = hold_points(K, B["fuse_f_f_mp_state"].as<uint8_t>());
+        for (auto &h : held)
+            if (h->mnId % 11 == 0) h->mbBad = true;   // a bad map point in the keyframe: counted, nothing replaced (:953-961)
+        auto pts = make_points(B, "fuse_");
+        const int n = (int)pts.size();
+        std::vector<MapPoint *> vpMapPoints;
+        for (auto &p : pts) vpMapPoints.push_back(p.get());
+        for (int i = 0; i < n; ++i)
+            if (!B["fuse_valid"].as<uint8_t>()[i]) {   // NULL, bad, or already in the keyframe (:844-850)
+                if (i % 3 == 0)
+                    vpMapPoints[i] = static_cast<MapPoint *>(NULL);
+                else if (i % 3 == 1)
+                    pts[i]->mbBad = true;
+                else
+                    pts[i]->mObservations[&K] = (size_t)-1;
+            }
+        ORBmatcher matcher;
+        event_log().clear();
+        const int nFused = matcher.Fuse(&K, vpMapPoints, B["fuse_th"].scalar<float>());
+        note();
+        // the map edits the loop made, in order (slam_stub.h event_log): compared with a replay of :948-969 on the oracle's search result
+        O.put("fuse_log", 1, std::vector<int32_t>(event_log().begin(), event_log().end()));
+        O.put("fuse_n", 1, std::vector<int32_t>{nFused});
+    }
+    // ---------------------------------------------------------------- Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)   LoopClosing.cc:601
+    {
+        KeyFrame K;
+        fill_keyframe(K, B, "fuse3_f_");
+        set_camera(K, B, "fuse3_");
+        auto held = hold_points(K, B["fuse3_f_f_mp_state"].as<uint8_t>());
+        auto pts = make_points(B, "fuse3_");
+        const int n = (int)pts.size();
+        std::vector<MapPoint *> vpPoints;
+        for (auto &p : pts) vpPoints.push_back(p.get());
+        std::vector<int> free_slots;
+        for (int i = 0; i < K.N; ++i)
+            if (!K.mvpMapPoints[i]) free_slots.push_back(i);
+        size_t next_slot = 0;
+        std::vector<int32_t> placed(n, -1);
+        for (int i = 0; i < n; ++i)
+            if (!B["fuse3_valid"].as<uint8_t>()[i]) {   // bad, or among the keyframe's map points on entry (:1006-1007)
+                if (i % 2 && next_slot < free_slots.size()) {
+                    placed[i] = free_slots[next_slot++];
+                    K.mvpMapPoints[placed[i]] = vpPoints[i];
+                } else
+                    pts[i]->mbBad = true;
+            }
+        const cv::Mat Scw = sim3_of("fuse3_", 0.94f);
+        const shim_detail::Sim3Pose pose(Scw);
+        std::vector<MapPoint *> vpReplacePoint(n, static_cast<MapPoint *>(NULL));
+        ORBmatcher matcher;
+        event_log().clear();
+        const int nFused = matcher.Fuse(&K, Scw, vpPoints, B["fuse3_th"].scalar<float>(), vpReplacePoint);
+        note();
+        std::vector<int32_t> rep(n, -1);
+        for (int i = 0; i < n; ++i)
+            if (vpReplacePoint[i]) rep[i] = (int32_t)(vpReplacePoint[i]->mnId >= kHeld ? vpReplacePoint[i]->mnId - kHeld : -2 - (long)vpReplacePoint[i]->mnId);
+        O.put("fuse3_replace", 1, rep);
+        O.put("fuse3_log", 1, std::vector<int32_t>(event_log().begin(), event_log().end()));
+        O.put("fuse3_placed", 1, placed);
+        O.put("fuse3_n", 1, std::vector<int32_t>{nFused});
+        O.put("fuse3_R", 2, flat(pose.Rcw)); O.put("fuse3_t", 2, flat(pose.tcw)); O.put("fuse3_Ow", 2, flat(pose.Ow));
+    }
+    // ---------------------------------------------------------------- SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   Tracking.cc:1632
+    {
+        Frame F;
+        fill_frame(F, B, "reloc_f_");
+        std::vector<std::unique_ptr<MapPoint>> heldF;
+        for (int i = 0; i < F.N; ++i)
+            if (B["reloc_f_f_mp_state"].as<uint8_t>()[i]) {
+                heldF.emplace_back(new MapPoint());
+                heldF.back()->mnId = kHeld + (unsigned long)i;
+                F.mvpMapPoints[i] = heldF.back().get();
+            }
+        F.mTcw = cv::Mat(4, 4, CV_32F);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) F.mTcw.at<float>(r, c) = B["reloc_R"].as<float>()[r * 3 + c];
+            F.mTcw.at<float>(r, 3) = B["reloc_t"].as<float>()[r];
+        }
+        F.mTcw.at<float>(3, 3) = 1.0f;
+        Frame::fx = B["reloc_fx"].scalar<float>(); Frame::fy = B["reloc_fy"].scalar<float>();
+        Frame::cx = B["reloc_cx"].scalar<float>(); Frame::cy = B["reloc_cy"].scalar<float>();
+        F.mbf = B["reloc_bf"].scalar<float>();
+        F.mfLogScaleFactor = B["reloc_log_scale_factor"].scalar<float>();
+        auto pts = make_points(B, "reloc_");
+        const int n = (int)pts.size();
+        KeyFrame K;   // the candidate keyframe: its features hold the points, mvKeysUn[i].angle is the query angle
+        K.N = n;
+        K.mvKeysUn.resize(n);
+        K.mvpMapPoints.resize(n);
+        std::set<MapPoint *> sFound;
+        for (int i = 0; i < n; ++i) {
+            K.mvKeysUn[i].angle = B["reloc_q_angle"].as<float>()[i];
+            K.mvpMapPoints[i] = pts[i].get();
+            if (!B["reloc_valid"].as<uint8_t>()[i]) {   // NULL, bad, or already found (:1489-1492)
+                if (i % 3 == 0)
+                    K.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
+                else if (i % 3 == 1)
+                    pts[i]->mbBad = true;
+                else
+                    sFound.insert(pts[i].get());
+            }
+        }
+        const cv::Mat Rcw = F.mTcw.rowRange(0, 3).colRange(0, 3), tcw = F.mTcw.rowRange(0, 3).col(3);
+        const cv::Mat Ow = -Rcw.t() * tcw;
+        ORBmatcher matcher2(0.9, B["reloc_check_orientation"].scalar<int32_t>() != 0);
+        {
+            Frame warm = F;
+            matcher2.SearchByProjection(warm, &K, sFound, B["reloc_th"].scalar<float>(), B["reloc_orb_dist"].scalar<int32_t>());
+        }
+        const int nm = matcher2.SearchByProjection(F, &K, sFound, B["reloc_th"].scalar<float>(), B["reloc_orb_dist"].scalar<int32_t>());
+        note();
+        std::vector<int32_t> m(F.N, -1);
+        for (int j = 0; j < F.N; ++j)
+            if (F.mvpMapPoints[j] && F.mvpMapPoints[j]->mnId < kHeld) m[j] = (int32_t)F.mvpMapPoints[j]->mnId;
+        O.put("reloc_match", 1, m);
+        O.put("reloc_n", 1, std::vector<int32_t>{nm});
+        O.put("reloc_Ow", 2, flat(Ow));
+    }
+    // ---------------------------------------------------------------- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)   LoopClosing.cc:325
+    {
+        KeyFrame K1, K2;
+        fill_keyframe(K1, B, "sim3_f1_");
+        fill_keyframe(K2, B, "sim3_f2_");
+        set_camera(K1, B, "sim3_p12_");
+        set_camera(K2, B, "sim3_p21_");
+        K1.mfLogScaleFactor = B["sim3_p21_log_scale_factor"].scalar<float>();   // (the target of p21 is KF1)
+        K2.mfLogScaleFactor = B["sim3_p12_log_scale_factor"].scalar<float>();
+        auto p1 = make_points(B, "sim3_p12_"), p2 = make_points(B, "sim3_p21_");
+        const int N1 = (int)p1.size(), N2 = (int)p2.size();
+        std::vector<MapPoint *> vpMatches12(N1, static_cast<MapPoint *>(NULL));
+        std::vector<std::unique_ptr<MapPoint>> extra;
+        for (int i = 0; i < N2; ++i) {
+            p2[i]->mnId = 500000ul + (unsigned long)i;
+            K2.mvpMapPoints[i] = p2[i].get();
+            if (!B["sim3_p21_valid"].as<uint8_t>()[i]) {
+                if (i % 2)
+                    K2.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
+                else
+                    p2[i]->mbBad = true;
+            }
+        }
+        int nxt2 = 0;
+        for (int i = 0; i < N1; ++i) {
+            K1.mvpMapPoints[i] = p1[i].get();
+            if (!B["sim3_p12_valid"].as<uint8_t>()[i]) {   // NULL, bad, or already matched on entry (:1128-1142, :1152-1156)
+                if (i % 3 == 0)
+                    K1.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);
+                else if (i % 3 == 1)
+                    p1[i]->mbBad = true;
+                else {
+                    // already matched to a point that keyframe 2 observes at a feature which is invalid there anyway
+                    while (nxt2 < N2 && B["sim3_p21_valid"].as<uint8_t>()[nxt2]) ++nxt2;
+                    extra.emplace_back(new MapPoint());
+                    extra.back()->mnId = 900000ul + (unsigned long)i;
+                    if (nxt2 < N2) extra.back()->mObservations[&K2] = (size_t)nxt2++;
+                    vpMatches12[i] = extra.back().get();
+                }
+            }
+        }
+        // s12, R12, t12 such that the method's own sR21 / t21 lines produce the transform of the bundle: R12 = (sR21 / s21)^T ...
+        // the bundle carries sR21 (p12.R2), t21 (p12.t2), sR12 (p21.R2), t12 (p21.t2); s12 = norm of a row of sR12
+        const cv::Mat sR12b = mat3x3(B["sim3_p21_R2"].as<float>());
+        const float s12 = (float)sqrt(sR12b.row(0).dot(sR12b.row(0)));
+        const cv::Mat R12 = sR12b / s12;
+        const cv::Mat t12 = pos_mat(B["sim3_p21_t2"].as<float>());
+        // what the method derives (same lines): handed to the oracle so that both sides see the same numbers
+        const cv::Mat sR12 = s12 * R12;
+        const cv::Mat sR21 = (1.0 / s12) * R12.t();
+        const cv::Mat t21 = -sR21 * t12;
+        const std::vector<MapPoint *> entry = vpMatches12;
+        ORBmatcher matcher(0.75, true);
+        {
+            std::vector<MapPoint *> warm = vpMatches12;
+            matcher.SearchBySim3(&K1, &K2, warm, s12, R12, t12, B["sim3_p12_th"].scalar<float>());
+        }
+        const int nFound = matcher.SearchBySim3(&K1, &K2, vpMatches12, s12, R12, t12, B["sim3_p12_th"].scalar<float>());
+        note();
+        std::vector<int32_t> m(N1, -1);
+        for (int i = 0; i < N1; ++i)
+            if (vpMatches12[i] != entry[i]) m[i] = (int32_t)(vpMatches12[i]->mnId - 500000ul);
+        O.put("sim3_match", 1, m);
+        O.put("sim3_n", 1, std::vector<int32_t>{nFound});
+        O.put("sim3_sR12", 2, flat(sR12)); O.put("sim3_sR21", 2, flat(sR21)); O.put("sim3_t21", 2, flat(t21)); O.put("sim3_t12", 2, flat(t12));
+    }
+    // ---------------------------------------------------------------- SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)   Tracking.cc:695
+    {
+        Frame F1, F2;
+        fill_frame(F2, B, "init_f_");
+        const int n1 = (int)B["init_octave1"].count();
+        F1.N = n1;
+        F1.mvKeysUn.resize(n1);
+        F1.mDescriptors = desc_mat(B["init_desc1"].as<uint8_t>(), n1);
+        std::vector<cv::Point2f> vbPrevMatched(n1);
+        for (int i = 0; i < n1; ++i) {
+            F1.mvKeysUn[i].octave = B["init_octave1"].as<int32_t>()[i];
+            F1.mvKeysUn[i].angle = B["init_angle1"].as<float>()[i];
+            vbPrevMatched[i] = cv::Point2f(B["init_prev_xy"].as<float>()[2 * i], B["init_prev_xy"].as<float>()[2 * i + 1]);
+        }
+        std::vector<int> vnMatches12;
+        ORBmatcher matcher(0.9, true);
+        const int nm = matcher.SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, B["init_window"].scalar<int32_t>());
+        note();
+        std::vector<int32_t> m(vnMatches12.begin(), vnMatches12.end());
+        std::vector<float> prev;
+        for (const cv::Point2f &q : vbPrevMatched) { prev.push_back(q.x); prev.push_back(q.y); }
+        O.put("init_match", 1, m);
+        O.put("init_prev", 2, prev);
+        O.put("init_n", 1, std::vector<int32_t>{nm});
+    }
+    // ---------------------------------------------------------------- SearchForTriangulation + SearchByBoW(KF, KF)   LocalMapping.cc:272, LoopClosing.cc:267
+    {
+        auto keyframe_pair = [&](const std::string &p, KeyFrame &K1, KeyFrame &K2, std::vector<std::unique_ptr<MapPoint>> &own, bool bad_too) {
+            KeyFrame *K[2] = {&K1, &K2};
+            for (int s = 0; s < 2; ++s) {
+                const std::string sx = s ? "2" : "1";
+                const int n = (int)B[p + "angle" + sx].count();
+                K[s]->N = n;
+                K[s]->mvKeysUn.resize(n);
+                K[s]->mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+                K[s]->mDescriptors = desc_mat(B[p + "desc" + sx].as<uint8_t>(), n);
+                K[s]->mFeatVec = feat_vec_named(B, p + "node_id" + sx, p + "node_off" + sx, p + "node_idx" + sx);
+                for (int i = 0; i < n; ++i) {
+                    K[s]->mvKeysUn[i].angle = B[p + "angle" + sx].as<float>()[i];
+                    const int has = B[p + "has_mp" + sx].as<uint8_t>()[i];
+                    if (has || (bad_too && i % 4 == 0)) {   // (SearchByBoW: a bad map point counts as none, :560-564)
+                        own.emplace_back(new MapPoint());
+                        own.back()->mnId = (unsigned long)(s * 100000 + i);
+                        own.back()->mbBad = !has;
+                        K[s]->mvpMapPoints[i] = own.back().get();
+                    }
+                }
+            }
+        };
+        {
+            KeyFrame K1, K2;
+            std::vector<std::unique_ptr<MapPoint>> own;
+            keyframe_pair("tri_", K1, K2, own, false);
+            for (int i = 0; i < K1.N; ++i) { K1.mvKeysUn[i].pt.x = B["tri_x1"].as<float>()[i]; K1.mvKeysUn[i].pt.y = B["tri_y1"].as<float>()[i]; }
+            for (int i = 0; i < K2.N; ++i) {
+                K2.mvKeysUn[i].pt.x = B["tri_x2"].as<float>()[i]; K2.mvKeysUn[i].pt.y = B["tri_y2"].as<float>()[i];
+                K2.mvKeysUn[i].octave = B["tri_octave2"].as<int32_t>()[i];
+            }
+            K1.mvuRight.assign(B["tri_u_right1"].as<float>(), B["tri_u_right1"].as<float>() + K1.N);
+            K2.mvuRight.assign(B["tri_u_right2"].as<float>(), B["tri_u_right2"].as<float>() + K2.N);
+            const BundleArray &sf = B["tri_scale_factors2"], &ls = B["tri_level_sigma2_2"];
+            K2.mvScaleFactors.assign(sf.as<float>(), sf.as<float>() + sf.count());
+            K2.mvLevelSigma2.assign(ls.as<float>(), ls.as<float>() + ls.count());
+            // poses: camera 1 centre and camera 2 pose (any consistent pair: the epipole the method computes goes to the oracle)
+            K1.Ow = pos_mat(B["tri_Cw"].as<float>());
+            K2.Tcw = pose_mat(B["tri_T2w"].as<float>());
+            K2.fx = B["tri_fx"].scalar<float>(); K2.fy = B["tri_fy"].scalar<float>(); K2.cx = B["tri_cx"].scalar<float>(); K2.cy = B["tri_cy"].scalar<float>();
+            const cv::Mat C2 = K2.GetRotation() * K1.GetCameraCenter() + K2.GetTranslation();
+            const float invz = 1.0f / C2.at<float>(2);
+            const float ex = K2.fx * C2.at<float>(0) * invz + K2.cx, ey = K2.fy * C2.at<float>(1) * invz + K2.cy;
+            const cv::Mat F12 = mat3x3(B["tri_F12"].as<float>());
+            std::vector<std::pair<size_t, size_t>> vMatchedIndices;
+            ORBmatcher matcher(0.6, B["tri_check_orientation"].scalar<int32_t>() != 0);
+            matcher.SearchForTriangulation(&K1, &K2, F12, vMatchedIndices, false);
+            const int nm = matcher.SearchForTriangulation(&K1, &K2, F12, vMatchedIndices, B["tri_only_stereo"].scalar<int32_t>() != 0);
+            note();
+            std::vector<int32_t> m(K1.N, -1);
+            for (auto &pr : vMatchedIndices) m[pr.first] = (int32_t)pr.second;
+            bool ascending = true;
+            for (size_t k = 1; k < vMatchedIndices.size(); ++k) ascending = ascending && vMatchedIndices[k - 1].first < vMatchedIndices[k].first;
+            O.put("tri_match", 1, m);
+            O.put("tri_n", 1, std::vector<int32_t>{nm, (int32_t)vMatchedIndices.size(), ascending ? 1 : 0});
+            O.put("tri_epipole", 2, std::vector<float>{ex, ey});
+        }
+        {
+            KeyFrame K1, K2;
+            std::vector<std::unique_ptr<MapPoint>> own;
+            keyframe_pair("bowkf_", K1, K2, own, true);
+            std::vector<MapPoint *> vpMatches12;
+            ORBmatcher matcher(B["bowkf_nnratio"].scalar<float>(), B["bowkf_check_orientation"].scalar<int32_t>() != 0);
+            matcher.SearchByBoW(&K1, &K2, vpMatches12);
+            const int nm = matcher.SearchByBoW(&K1, &K2, vpMatches12);
+            note();
+            std::vector<int32_t> m(K1.N, -1);
+            for (int i = 0; i < K1.N; ++i)
+                if (vpMatches12[i]) m[i] = (int32_t)(vpMatches12[i]->mnId - 100000ul);
+            O.put("bowkf_match", 1, m);
+            O.put("bowkf_n", 1, std::vector<int32_t>{nm});
+        }
+    }
+    // ---------------------------------------------------------------- the front end of a stereo Frame (src/Frame.cc:62-114) + ComputeBoW + ComputeDistinctiveDescriptors
+    {
+        const int w = B["fe_size"].as<int32_t>()[0], h = B["fe_size"].as<int32_t>()[1], nf = B["fe_size"].as<int32_t>()[2];
+        cv::Mat imLeft(h, w, CV_8UC1), imRight(h, w, CV_8UC1);
+        memcpy(imLeft.data, B["fe_left"].as<uint8_t>(), (size_t)w * h);
+        memcpy(imRight.data, B["fe_right"].as<uint8_t>(), (size_t)w * h);
+        ORBextractor left(nf, 1.2f, 8, 20, 7), right(nf, 1.2f, 8, 20, 7);
+        Frame F;
+        F.mpORBextractorLeft = &left;
+        F.mpORBextractorRight = &right;
+        // Frame::ExtractORB (src/Frame.cc:276-282)
+        (*F.mpORBextractorLeft)(imLeft, cv::Mat(), F.mvKeys, F.mDescriptors);
+        (*F.mpORBextractorRight)(imRight, cv::Mat(), F.mvKeysRight, F.mDescriptorsRight);
+        F.N = (int)F.mvKeys.size();
+        F.mvScaleFactors = left.GetScaleFactors();
+        F.mbf = B["fe_cam"].as<float>()[0];
+        F.mb = B["fe_cam"].as<float>()[1];
+        F.ComputeStereoMatches();
+        // an empty image: silent return, outputs untouched (src/ORBextractor.cc:1046)
+        std::vector<cv::KeyPoint> none(3);
+        cv::Mat dnone;
+        left(cv::Mat(), cv::Mat(), none, dnone);
+        if (none.size() != 3 || !dnone.empty()) throw std::runtime_error("empty image: outputs were touched");
+        // mvImagePyramid on demand: the ROI exposes the 19-pixel REFLECT_101 frame like the reference's
+        left(imLeft, cv::Mat(), none, dnone);
+        left.FillImagePyramid();
+        const cv::Mat &p0 = left.mvImagePyramid[0];
+        if (p0.cols != w || p0.rows != h || *(p0.data - p0.step - 1) != p0.data[p0.step + 1] || p0.data[5 * p0.step + 7] != imLeft.data[5 * (size_t)w + 7])
+            throw std::runtime_error("mvImagePyramid[0] is not the bordered level 0");
+        if (left.mvImagePyramid[7].cols != (int)lroundf((float)w * left.GetInverseScaleFactors()[7])) throw std::runtime_error("mvImagePyramid[7] size");
+        if (ORBmatcher::DescriptorDistance(F.mDescriptors.row(0), F.mDescriptors.row(0)) != 0) throw std::runtime_error("DescriptorDistance");
+        std::vector<uint8_t> kraw((size_t)F.N * 28), draw((size_t)F.N * 32);
+        memcpy(kraw.data(), F.mvKeys.data(), kraw.size());
+        for (int i = 0; i < F.N; ++i) memcpy(&draw[(size_t)i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
+        O.put("fe_kps", 0, kraw);
+        O.put("fe_desc", 0, draw);
+        O.put("fe_u_right", 2, F.mvuRight);
+        O.put("fe_depth", 2, F.mvDepth);
+        // Frame::ComputeBoW with a vocabulary of the bundle
+        ORBVocabulary voc;
+        const int32_t *kl = B["fe_voc_kl"].as<int32_t>();
+        aos2::check(aos2_vocabulary_set_nodes(voc.handle(), kl[0], kl[1], kl[2], kl[3], (int)B["fe_voc_parent"].count(), B["fe_voc_parent"].as<int32_t>(),
+                                              B["fe_voc_desc"].as<uint8_t>(), B["fe_voc_weight"].as<double>(), B["fe_voc_is_leaf"].as<uint8_t>()),
+                    "vocabulary");
+        F.mpORBvocabulary = &voc;
+        F.ComputeBoW();
+        const size_t nb = F.mBowVec.size();
+        F.ComputeBoW();   // not empty: nothing happens (src/Frame.cc:426)
+        if (F.mBowVec.size() != nb) throw std::runtime_error("ComputeBoW ran twice");
+        std::vector<int32_t> bw, fn, fo(1, 0), fi;
+        std::vector<double> bv;
+        for (auto &e : F.mBowVec) { bw.push_back((int32_t)e.first); bv.push_back(e.second); }
+        for (auto &e : F.mFeatVec) {
+            fn.push_back((int32_t)e.first);
+            for (unsigned int v : e.second) fi.push_back((int32_t)v);
+            fo.push_back((int32_t)fi.size());
+        }
+        O.put("fe_bow_word", 1, bw); O.put("fe_bow_value", 4, bv); O.put("fe_feat_node", 1, fn); O.put("fe_feat_off", 1, fo); O.put("fe_feat_idx", 1, fi);
+        if (voc.score(F.mBowVec, F.mBowVec) < 0.999) throw std::runtime_error("score(v, v)");
+        // MapPoint::ComputeDistinctiveDescriptors for the points of the bundle (observations = rows of per-keyframe matrices)
+        const int32_t *off = B["fe_obs_off"].as<int32_t>();
+        const int npts = (int)B["fe_obs_off"].count() - 1;
+        std::vector<int32_t> chosen(npts, -1);
+        for (int p = 0; p < npts; ++p) {
+            const int m = off[p + 1] - off[p];
+            std::vector<std::unique_ptr<KeyFrame>> kfs;
+            MapPoint mp;
+            for (int k = 0; k < m; ++k) {
+                kfs.emplace_back(new KeyFrame());
+                kfs.back()->mDescriptors = desc_mat(B["fe_obs_desc"].as<uint8_t>() + (size_t)(off[p] + k) * 32, 1);
+            }
+            // std::map<KeyFrame*, size_t> iterates in pointer order: hand the rows out in that order so that list position k of
+            // the bundle is the k-th observation the method visits
+            std::vector<KeyFrame *> order;
+            for (auto &k : kfs) order.push_back(k.get());
+            std::sort(order.begin(), order.end());
+            for (int k = 0; k < m; ++k) {
+                order[k]->mDescriptors = desc_mat(B["fe_obs_desc"].as<uint8_t>() + (size_t)(off[p] + k) * 32, 1);
+                mp.mObservations[order[k]] = 0;
+            }
+            mp.ComputeDistinctiveDescriptors();
+            for (int k = 0; k < m; ++k)
+                if (!mp.mDescriptor.empty() && memcmp(mp.mDescriptor.data, B["fe_obs_desc"].as<uint8_t>() + (size_t)(off[p] + k) * 32, 32) == 0) {
+                    chosen[p] = k;
+                    break;
+                }
+        }
+        O.put("fe_distinctive", 1, chosen);
+    }
 }

@@ -1,11 +1,10 @@
-"""The reference-signature shims (active-orb-slam2_amd/host/ref/ORBmatcher.h, Optimizer.h):
-    int  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)
-    int  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, float)
-    int  ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)
-    int  Optimizer::PoseOptimization(Frame*)
-    void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*)
-compiled with g++ against minimal stand-ins of Frame / KeyFrame / MapPoint / Map (tests/cpp/refstub) and driven like
-Tracking.cc / LocalMapping.cc drive the reference: what they leave in the objects equals the ctypes path's results."""
+"""The reference-signature classes (active-orb-slam2_amd/host/*.h): every public ORBmatcher method of
+include/ORBmatcher.h:37-102, ORBextractor::operator()(cv::InputArray, cv::InputArray, vector<cv::KeyPoint>&, cv::OutputArray),
+Optimizer::PoseOptimization(Frame*) / LocalBundleAdjustment(KeyFrame*, bool*, Map*), Frame::ComputeStereoMatches() /
+ComputeBoW(), MapPoint::ComputeDistinctiveDescriptors() -- compiled with g++ against minimal stand-ins of Frame / KeyFrame /
+MapPoint / Map / cv::Mat (tests/cpp/refstub) and driven the way Tracking.cc / LocalMapping.cc / LoopClosing.cc / Frame.cc
+drive the reference (tests/cpp/ref_signature_test.cpp lists the call sites).  What the calls leave in the objects equals
+the ORACLE's results on the same inputs (index arrays, counts, map edits bit-identical; poses / points 1e-5)."""
 import os
 import subprocess
 import sys
@@ -16,6 +15,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bundle_io  # noqa: E402
+
+KHELD = 1000000
 
 
 def build(tmp_path, pkg):
@@ -37,25 +38,45 @@ def make_bundle(pkg, seed=0, lba=None):
     # whose right coordinate fell left of the image border is a monocular one for both paths
     po["stereo"] = (po["stereo"].astype(bool) & (po["obs"][:, 2] >= 0)).astype(np.uint8)
     ba["edge_stereo"] = (ba["edge_stereo"].astype(bool) & (ba["edge_obs"][:, 2] >= 0)).astype(np.uint8)
+    P = dict(bow=bow, f=f, mp=mp, cur=cur, last=last, po=po, ba=ba)
+    # the remaining matcher methods
+    P["kf_f"], P["kf"] = S.synth_proj_gen_problem(100 + seed, n_f=900, n_pts=1400, cfg="kitti", th=10.0)
+    P["fuse_f"], P["fuse"] = S.synth_proj_gen_problem(110 + seed, n_f=1000, n_pts=1500, cfg="tum", th=3.0)
+    P["fuse3_f"], P["fuse3"] = S.synth_proj_gen_problem(120 + seed, n_f=900, n_pts=1300, cfg="kitti", th=4.0)
+    P["reloc_f"], P["reloc"] = S.synth_proj_gen_problem(130 + seed, n_f=1000, n_pts=1200, cfg="tum", th=10.0)
+    P["reloc"]["orb_dist"], P["reloc"]["check_orientation"] = np.int32(100), np.int32(1)
+    P["sim3_f1"], P["sim3_f2"], P["sim3_p12"], P["sim3_p21"] = S.synth_sim3_problem(140 + seed, 900, 1000)
+    P["init_f"], P["init"] = S.synth_init_problem(150 + seed, 1200, 1300)
+    P["init"]["window"] = np.int32(100)
+    tri = S.synth_triang_problem(160 + seed, 1000, 1100, n_nodes=60)
+    rng = np.random.default_rng(170 + seed)
+    T2w = np.eye(4, dtype=np.float32)
+    T2w[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    T2w[:3, 3] = rng.normal(0, 1, 3)
+    tri.update(Cw=rng.normal(0, 2, 3).astype(np.float32), T2w=T2w.reshape(16), fx=np.float32(718.856), fy=np.float32(718.856),
+               cx=np.float32(607.1928), cy=np.float32(185.2157))
+    P["tri"] = tri
+    P["bowkf"] = S.synth_bow_kf_problem(180 + seed, 900, 1000)
+    # front end: a small stereo pair, a vocabulary, observation lists
+    left, right, _ = S.synth_stereo_pair(190 + seed, 480, 360)
+    voc = S.synth_vocabulary(200 + seed, 6, 3)
+    off, od = S.synth_observations(210 + seed, 12, 9)
+    P["fe"] = dict(size=np.array([480, 360, 600], np.int32), left=left, right=right, cam=np.array([40.0, 40.0 / 435.2], np.float32),
+                   voc_kl=np.array([voc["k"], voc["L"], voc["scoring"], voc["weighting"]], np.int32), voc_parent=voc["parent"].astype(np.int32),
+                   voc_desc=voc["desc"], voc_weight=voc["weight"].astype(np.float64), voc_is_leaf=voc["is_leaf"].astype(np.uint8),
+                   obs_off=off.astype(np.int32), obs_desc=od)
+    P["voc"] = voc
     arrays = {}
-    for k, v in bow.items():
-        arrays["bow_" + k] = np.asarray(v)
-    for k, v in f.items():
-        arrays["pm_f_" + k] = np.asarray(v)
-    for k, v in mp.items():
-        arrays["pm_" + k] = np.asarray(v)
-    for k, v in cur.items():
-        arrays["pl_f_" + k] = np.asarray(v)
-    for k, v in last.items():
-        arrays["pl_" + k] = np.asarray(v)
-    for k, v in po.items():
-        arrays["po_" + k] = np.asarray(v)
-    for k, v in ba.items():
-        arrays["ba_" + k] = np.asarray(v)
+    pref = dict(bow="bow_", f="pm_f_", mp="pm_", cur="pl_f_", last="pl_", po="po_", ba="ba_", kf_f="kf_f_", kf="kf_", fuse_f="fuse_f_",
+                fuse="fuse_", fuse3_f="fuse3_f_", fuse3="fuse3_", reloc_f="reloc_f_", reloc="reloc_", sim3_f1="sim3_f1_", sim3_f2="sim3_f2_",
+                sim3_p12="sim3_p12_", sim3_p21="sim3_p21_", init_f="init_f_", init="init_", tri="tri_", bowkf="bowkf_", fe="fe_")
+    for key, px in pref.items():
+        for k, v in P[key].items():
+            arrays[px + k] = np.asarray(v)
     for k, v in list(arrays.items()):   # scalars travel as float32 / int32
         if v.ndim == 0:
             arrays[k] = v.astype(np.float32) if v.dtype.kind == "f" else v.astype(np.int32)
-    return arrays, dict(bow=bow, f=f, mp=mp, cur=cur, last=last, po=po, ba=ba)
+    return arrays, P
 
 
 def test_shims_compile_without_device(pkg, tmp_path):
@@ -63,44 +84,191 @@ def test_shims_compile_without_device(pkg, tmp_path):
     arrays, _ = make_bundle(pkg)
     bundle_io.save(tmp_path / "in.bundle", arrays)
     r = subprocess.run([exe, str(tmp_path / "in.bundle"), str(tmp_path / "out.bundle")], capture_output=True, text=True)
-    assert r.returncode in (0, 3)
+    assert r.returncode in (0, 3), r.stdout + r.stderr
+    assert "levels 8 scale 1.200 sf7 3.583182" in r.stdout   # constructor tables / getters: host side, no GPU needed
     if pkg.device_count() == 0:
         assert r.returncode == 3   # loud: no device, nothing computed
 
 
+def replay_fuse(best_idx, valid, kf_state):
+    """Replay of the map edits of Fuse(pKF, vpMapPoints) (src/ORBmatcher.cc:948-969) on a search result, with the stand-in
+    data model of tests/cpp/refstub/slam_stub.h (observation counters: held point 1 + idx % 3 or 0, candidate 1 + i % 3;
+    held points with (KHELD + idx) % 11 == 0 are bad).  Returns (nFused, event log as the driver records it)."""
+    slot = {int(i): ("h", int(i)) for i in np.flatnonzero(kf_state)}
+    obs_h = {i: (1 + i % 3 if kf_state[i] == 2 else 0) for i in slot}
+    bad_h = {i for i in slot if (KHELD + i) % 11 == 0}
+    n = len(best_idx)
+    obs_p = {i: 1 + i % 3 for i in range(n)}
+    bad_p, in_kf = set(), set()
+    log, nfused = [], 0
+    for i in range(n):
+        b = int(best_idx[i])
+        if b < 0 or not valid[i] or i in bad_p or i in in_kf:
+            continue
+        holder = slot.get(b)
+        if holder is not None:
+            kind, j = holder
+            hbad = (j in bad_h) if kind == "h" else (j in bad_p)
+            if not hbad:
+                hobs = obs_h[j] if kind == "h" else obs_p[j]
+                hid = KHELD + j if kind == "h" else j
+                if hobs > obs_p[i]:     # pMP->Replace(pMPinKF): the candidate has no observations to move
+                    log += [ord("R"), i, hid]
+                    bad_p.add(i)
+                else:                   # pMPinKF->Replace(pMP): its observation in this keyframe moves to the candidate
+                    log += [ord("R"), hid, i, ord("A"), i, b]
+                    (bad_h if kind == "h" else bad_p).add(j)
+                    slot[b] = ("p", i)
+                    obs_p[i] += 1
+                    in_kf.add(i)
+        else:
+            log += [ord("A"), i, b]
+            slot[b] = ("p", i)
+            obs_p[i] += 1
+            in_kf.add(i)
+        nfused += 1
+    return nfused, np.array(log, np.int32)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,lba", [(0, None), (1, dict(seed=91, n_local=9, n_fixed=0, n_points=500, include_kf0=True, stereo_frac=0.3))])
-def test_shims_equal_ctypes_path(pkg, gpu, tmp_path, seed, lba):
+def test_call_sites_equal_the_oracle(pkg, oracle, gpu, tmp_path, seed, lba):
+    O = oracle
     exe = build(tmp_path, pkg)
     arrays, P = make_bundle(pkg, seed, lba)
     bundle_io.save(tmp_path / "in.bundle", arrays)
     r = subprocess.run([exe, str(tmp_path / "in.bundle"), str(tmp_path / "out.bundle")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     out = bundle_io.load(tmp_path / "out.bundle")
-    # SearchByBoW
-    n, m = pkg.Matcher(float(P["bow"]["nnratio"]), True).SearchByBoW(P["bow"])
+    # SearchByBoW(KF, F)
+    n, m = O.search_by_bow(P["bow"])
     assert int(out["bow_n"][0]) == n and n > 100 and (out["bow_match"] == m).all()
     # SearchByProjection(F, vpMapPoints, th)
-    n, m = pkg.Matcher(float(P["mp"]["nnratio"]), True).SearchByProjection(P["f"], P["mp"], float(P["mp"]["th"]))
+    n, m = O.search_by_projection_mp(P["f"], P["mp"])
     assert int(out["pm_n"][0]) == n and n > 50 and (out["pm_match"] == m).all()
     # SearchByProjection(Current, Last, th, bMono): the rotation check resets culled features to NULL
-    n, m = pkg.Matcher(0.9, bool(P["last"]["check_orientation"])).SearchByProjectionLast(P["cur"], P["last"], float(P["last"]["th"]), int(P["last"]["mono"]))
+    n, m = O.search_by_projection_last(P["cur"], P["last"])
     assert int(out["pl_n"][0]) == n and n > 50 and (out["pl_match"] == np.where(m == -2, -1, m)).all()
     # PoseOptimization(Frame*)
-    r1 = pkg.LocalBA().PoseOptimization(P["po"])
-    assert tuple(out["po_n"]) == (r1["n_inliers"], r1["n_bad"]) and (out["po_outlier"] == r1["outlier"]).all()
-    assert out["po_Tcw"].tobytes() == r1["Tcw"].tobytes()
-    # LocalBundleAdjustment(KeyFrame*, bool*, Map*): the shim emits the points in the order it meets them in the local
-    # keyframes' feature lists (Optimizer.cc:471-488), so sums run in another order than for the synth arrays: 1e-5
-    # plus the float32 ulp of the largest value (poses up to 32 m: 4e-6, points up to 64 m: 8e-6), DESIGN.md section 2.7
-    r2 = pkg.LocalBA().LocalBundleAdjustment(P["ba"])
+    w = O.pose_optimization(P["po"])
+    assert int(out["po_n"][0]) == w["n_inliers"] and (out["po_outlier"] == w["outlier"][: len(out["po_outlier"])]).all()
+    assert np.abs(out["po_Tcw"].astype(np.float64) - w["Tcw"].reshape(-1)).max() <= 1e-5
+    # LocalBundleAdjustment(KeyFrame*, bool*, Map*): the method emits the points in the order it meets them in the local
+    # keyframes' feature lists (Optimizer.cc:471-488) and the edges per point by ascending keyframe id: the oracle solves the
+    # problem in exactly that order (recorded by the method, aos2::LbaRecord) -> 1e-5, identical erased observations
     ba = P["ba"]
+    pid = {int(v): i for i, v in enumerate(ba["pose_id"])}
+    qid = {int(v): i for i, v in enumerate(ba["point_id"])}
+    porder = np.array([pid[int(v)] for v in out["ba_rec_pose_id"]])
+    qorder = np.array([qid[int(v)] for v in out["ba_rec_point_id"]])
+    edge_of = {(int(ba["edge_pose"][e]), int(ba["edge_point"][e])): e for e in range(ba["n_edges"])}
+    eorder = np.array([edge_of[(pid[int(a)], qid[int(b)])] for a, b in zip(out["ba_rec_edge_pose_id"], out["ba_rec_edge_point_id"])])
+    assert len(porder) == ba["n_poses"] and len(qorder) == ba["n_points"] and len(eorder) == ba["n_edges"]
+    pinv, qinv = np.argsort(porder), np.argsort(qorder)
+    perm = dict(ba)
+    for k in ("pose_Tcw", "pose_fixed", "pose_id"):
+        perm[k] = ba[k][porder]
+    for k in ("point_xyz", "point_id"):
+        perm[k] = ba[k][qorder]
+    for k in ("edge_obs", "edge_stereo", "edge_inv_sigma2"):
+        perm[k] = ba[k][eorder]
+    perm["edge_pose"] = pinv[ba["edge_pose"][eorder]].astype(np.int32)
+    perm["edge_point"] = qinv[ba["edge_point"][eorder]].astype(np.int32)
+    w = O.lba_solve(perm)
+    got_T, got_X = out["ba_pose_Tcw"].reshape(-1, 16), out["ba_point_xyz"].reshape(-1, 3)
     free = ba["pose_fixed"] == 0
-    assert np.abs(out["ba_pose_Tcw"].reshape(-1, 16) - r2["pose_Tcw"]).max() <= 1e-5 + 4e-6
-    assert np.abs(out["ba_point_xyz"].reshape(-1, 3) - r2["point_xyz"]).max() <= 1e-5 + 8e-6
-    assert (out["ba_pose_Tcw"].reshape(-1, 16)[~free] == ba["pose_Tcw"][~free]).all()   # fixed cameras are not written back
-    assert (out["ba_erased"] == r2["edge_outlier"]).all() and r2["edge_outlier"].sum() > 0
+    tol = lambda ref: 1e-5 + 2 * np.spacing(np.abs(ref).astype(np.float32))   # noqa: E731
+    assert (np.abs(got_T[porder][free[porder]].astype(np.float64) - w["pose_Tcw"][free[porder]]) <= tol(w["pose_Tcw"][free[porder]])).all()
+    assert (np.abs(got_X[qorder].astype(np.float64) - w["point_xyz"]) <= tol(w["point_xyz"])).all()
+    assert (got_T[~free] == ba["pose_Tcw"][~free]).all()   # fixed cameras are not written back
+    assert (out["ba_erased"][eorder] == w["edge_outlier"]).all() and w["edge_outlier"].sum() > 0
     assert int(out["ba_n"][0]) == ba["n_points"]   # UpdateNormalAndDepth for every local map point
-    t = out["timing_us"].reshape(-1, 3)
-    print("\nshim timing (gather, C-ABI call, scatter) us:", dict(zip(["SearchByBoW", "SearchByProjection(F,MPs)", "SearchByProjection(Cur,Last)",
-                                                                        "PoseOptimization", "LocalBundleAdjustment"], t.round(1).tolist())))
+
+    def with_pose(p, R=None, t=None, Ow=None, **kw):
+        q = dict(p)
+        for k, v in dict(R=R, t=t, Ow=Ow, **kw).items():
+            if v is not None:
+                q[k] = np.asarray(v, np.float32).reshape(-1)
+        return q
+    # SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): R, t, Ow as the method derived them from Scw
+    q = with_pose(P["kf"], out["kf_R"], out["kf_t"], out["kf_Ow"])
+    q["th"] = np.float32(int(P["kf"]["th"]))
+    n, m = O.search_by_projection_kf(P["kf_f"], q)
+    assert int(out["kf_n"][0]) == n and n > 50 and (out["kf_match"] == m).all()
+    # Fuse(pKF, vpMapPoints, th): the map edits equal a replay of :948-969 on the oracle's search result
+    n, bi, bd = O.fuse(P["fuse_f"], P["fuse"], sim3=False)
+    nf, log = replay_fuse(bi, P["fuse"]["valid"], P["fuse_f"]["f_mp_state"])
+    assert int(out["fuse_n"][0]) == nf and nf > 50 and len(log) == len(out["fuse_log"]) and (out["fuse_log"] == log).all()
+    assert (log.reshape(-1, 3)[:, 0] == ord("R")).sum() > 5
+    # Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+    q = with_pose(P["fuse3"], out["fuse3_R"], out["fuse3_t"], out["fuse3_Ow"])
+    n, bi, bd = O.fuse(P["fuse3_f"], q, sim3=True)
+    st = P["fuse3_f"]["f_mp_state"]
+    slot = {int(i): KHELD + int(i) for i in np.flatnonzero(st)}
+    for i, s_ in enumerate(out["fuse3_placed"]):
+        if s_ >= 0:
+            slot[int(s_)] = i
+    rep, log, nf = np.full(len(bi), -1, np.int32), [], 0
+    for i in range(len(bi)):
+        b = int(bi[i])
+        if b < 0 or not P["fuse3"]["valid"][i]:
+            continue
+        h = slot.get(b)
+        if h is not None:
+            rep[i] = h - KHELD if h >= KHELD else -2 - h
+        else:
+            log += [ord("A"), i, b]
+            slot[b] = i
+        nf += 1
+    assert int(out["fuse3_n"][0]) == nf and nf > 50 and (out["fuse3_replace"] == rep).all() and (out["fuse3_log"] == np.array(log, np.int32)).all()
+    # SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+    q = with_pose(P["reloc"], Ow=out["reloc_Ow"])
+    n, m = O.search_by_projection_reloc(P["reloc_f"], q, 100, True)
+    assert int(out["reloc_n"][0]) == n and n > 50 and (out["reloc_match"] == np.where(m == -2, -1, m)).all()
+    # SearchBySim3
+    q12 = with_pose(P["sim3_p12"], R2=out["sim3_sR21"], t2=out["sim3_t21"])
+    q21 = with_pose(P["sim3_p21"], R2=out["sim3_sR12"], t2=out["sim3_t12"])
+    n, m = O.search_by_sim3(P["sim3_f1"], P["sim3_f2"], q12, q21)
+    assert int(out["sim3_n"][0]) == n and n > 50 and (out["sim3_match"] == m).all()
+    # SearchForInitialization (+ the vbPrevMatched update of :512-515)
+    n, m = O.search_for_initialization(P["init_f"], P["init"], 100, 0.9, True)
+    assert int(out["init_n"][0]) == n and n > 50 and (out["init_match"] == m).all()
+    prev = P["init"]["prev_xy"].copy()
+    hit = m >= 0
+    prev[hit, 0], prev[hit, 1] = P["init_f"]["kp_x"][m[hit]], P["init_f"]["kp_y"][m[hit]]
+    assert out["init_prev"].reshape(-1, 2).tobytes() == prev.astype(np.float32).tobytes()
+    # SearchForTriangulation (the epipole as the method computed it from the poses), SearchByBoW(KF, KF)
+    t = dict(P["tri"])
+    t["ex"], t["ey"] = np.float32(out["tri_epipole"][0]), np.float32(out["tri_epipole"][1])
+    n, m = O.search_for_triangulation(t)
+    assert tuple(out["tri_n"]) == (n, n, 1) and n > 50 and (out["tri_match"] == m).all()
+    n, m = O.search_by_bow_kf(P["bowkf"])
+    assert int(out["bowkf_n"][0]) == n and n > 50 and (out["bowkf_match"] == m).all()
+    # front end: operator()(cv::InputArray ...), Frame::ComputeStereoMatches(), Frame::ComputeBoW(), ComputeDistinctiveDescriptors()
+    fe = P["fe"]
+    eL, eR = O.Extractor(nfeatures=600), O.Extractor(nfeatures=600)
+    kl, dl = eL.extract(fe["left"])
+    kr, dr = eR.extract(fe["right"])
+    assert out["fe_kps"].tobytes() == kl.tobytes() and (out["fe_desc"].reshape(-1, 32) == dl).all() and len(kl) > 300
+    our, odp, _ = O.compute_stereo_matches(eL, eR, kl, dl, kr, dr, fe["cam"][1], fe["cam"][0])
+    assert out["fe_u_right"].tobytes() == our.tobytes() and out["fe_depth"].tobytes() == odp.tobytes() and (odp > 0).sum() > 50
+    OV = O.Vocabulary()
+    voc = P["voc"]
+    OV.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    wv = OV.transform(dl, 4)
+    assert len(wv["bow_word"]) > 5
+    assert (out["fe_bow_word"] == wv["bow_word"].astype(np.int32)).all() and out["fe_bow_value"].tobytes() == wv["bow_value"].tobytes()
+    assert (out["fe_feat_node"] == wv["fv_node"]).all() and (out["fe_feat_off"] == wv["fv_off"]).all() and (out["fe_feat_idx"] == wv["fv_idx"]).all()
+    assert (out["fe_distinctive"] == O.compute_distinctive_descriptors(fe["obs_off"], fe["obs_desc"])).all()
+    t_ = out["timing_us"].reshape(-1, 3)
+    names = ["SearchByBoW(KF,F)", "SearchByProjection(F,MPs)", "SearchByProjection(Cur,Last)", "PoseOptimization", "LocalBundleAdjustment",
+             "SearchByProjection(KF,Scw)", "Fuse(KF,MPs)", "Fuse(KF,Scw)", "SearchByProjection(F,KF,reloc)", "SearchBySim3",
+             "SearchForInitialization", "SearchForTriangulation", "SearchByBoW(KF,KF)"]
+    print("\nwall time per call, gather / C-ABI call / scatter (us):")
+    for nm_, row in zip(names, t_.round(1).tolist()):
+        print("  %-32s %9.1f %9.1f %9.1f" % (nm_, *row))
+    if os.environ.get("AOS2_SHIM_TIMING_OUT"):
+        with open(os.environ["AOS2_SHIM_TIMING_OUT"], "a") as fh:
+            fh.write("seed %d: wall time per call through the reference-signature classes, gather / C-ABI call / scatter (us)\n" % seed)
+            for nm_, row in zip(names, t_.round(1).tolist()):
+                fh.write("  %-32s %9.1f %9.1f %9.1f\n" % (nm_, *row))
