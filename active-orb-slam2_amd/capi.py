@@ -112,6 +112,10 @@ def lib():
             L.aos2_matcher_hamming_best2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp]
             L.aos2_matcher_hamming_best2_device.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, C.POINTER(cf)]
             L.aos2_matcher_search_by_bow.argtypes = [vp, vp, ci, vp, vp]
+            L.aos2_matcher_search_by_bow_device.argtypes = [vp, vp, ci, vp, vp]
+            L.aos2_matcher_search_by_bow_frames.argtypes = [vp, vp, vp, vp]
+            L.aos2_vocabulary_stream.argtypes = [vp]
+            L.aos2_vocabulary_stream.restype = vp
             if hasattr(L, "aos2_matcher_search_by_bow_kf"):
                 L.aos2_matcher_search_by_bow_kf.argtypes = [vp, vp, ci, vp, vp]
                 L.aos2_matcher_search_for_triangulation.argtypes = [vp, vp, ci, ci, vp, vp]
@@ -149,6 +153,8 @@ def lib():
             L.aos2_frames_stream.restype = vp
             L.aos2_frames_wait.argtypes = [vp]
             L.aos2_frames_wait_for_stream.argtypes = [vp, vp]
+            L.aos2_frames_device_ptr.argtypes = [vp, ci]
+            L.aos2_frames_device_ptr.restype = vp
             L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
             L.aos2_frames_set_pose.argtypes = [vp, vp]
             L.aos2_frames_set_distortion.argtypes = [vp, cf, cf, cf, cf, cf]
@@ -415,6 +421,9 @@ class Vocabulary:
                                                        V(d_no or None)))
         return float(self.L.aos2_vocabulary_last_device_ms(self.h))
 
+    def stream(self):
+        return self.L.aos2_vocabulary_stream(self.h)
+
     def score(self, a, b):
         w1, v1 = np.ascontiguousarray(a["bow_word"], np.uint32), np.ascontiguousarray(a["bow_value"], np.float64)
         w2, v2 = np.ascontiguousarray(b["bow_word"], np.uint32), np.ascontiguousarray(b["bow_value"], np.float64)
@@ -489,6 +498,12 @@ class _BowPair(C.Structure):
                 ("n_nodes_kf", C.c_int32), ("n_nodes_f", C.c_int32),
                 ("node_id_kf", C.c_void_p), ("node_off_kf", C.c_void_p), ("node_idx_kf", C.c_void_p),
                 ("node_id_f", C.c_void_p), ("node_off_f", C.c_void_p), ("node_idx_f", C.c_void_p)]
+
+
+class _BowFrames(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("cap", C.c_int32)] + [(k, C.c_void_p) for k in (
+        "d_desc_kf", "d_kps_kf", "d_n_kf", "d_desc_f", "d_kps_f", "d_n_f", "kf_has_mp", "d_kf_fv_node", "d_kf_fv_off", "d_kf_fv_idx",
+        "d_kf_n_fv", "d_f_fv_node", "d_f_fv_off", "d_f_fv_idx", "d_f_n_fv")]
 
 
 class _BowKfPair(C.Structure):
@@ -634,6 +649,40 @@ class Matcher:
         _check(self.L.aos2_matcher_search_by_bow(self.h, C.byref(arr), len(problems), ptrs, _p(nm)))
         res = [(int(nm[i]), outs[i][: len(problems[i]["desc_f"])]) for i in range(len(problems))]
         return res[0] if single else res
+
+    def SearchByBoWDevice(self, pairs):
+        """aos2_matcher_search_by_bow_device: pairs = list of dicts with DEVICE addresses (ints) desc_kf, desc_f, angle_kf,
+        angle_f, sizes n_kf / n_f, and host arrays kf_has_mp, node_id_* / node_off_* / node_idx_* -> [(nmatches, match_f)]"""
+        keep = []
+        n = len(pairs)
+        arr = (_BowPair * n)()
+        outs = []
+        for i, p in enumerate(pairs):
+            a = arr[i]
+            a.n_kf, a.n_f = int(p["n_kf"]), int(p["n_f"])
+            a.desc_kf, a.desc_f, a.angle_kf, a.angle_f = int(p["desc_kf"]), int(p["desc_f"]), int(p["angle_kf"]), int(p["angle_f"])
+            a.n_nodes_kf, a.n_nodes_f = len(p["node_id_kf"]), len(p["node_id_f"])
+            for name in ("kf_has_mp", "node_id_kf", "node_off_kf", "node_idx_kf", "node_id_f", "node_off_f", "node_idx_f"):
+                v = np.ascontiguousarray(p[name], _DTYPES[name])
+                if v.size == 0:
+                    v = np.zeros(1, _DTYPES[name])
+                keep.append(v)
+                setattr(a, name, v.ctypes.data)
+            outs.append(np.zeros(max(a.n_f, 1), np.int32))
+        ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        nm = np.zeros(n, np.int32)
+        _check(self.L.aos2_matcher_search_by_bow_device(self.h, C.byref(arr), n, ptrs, _p(nm)))
+        return [(int(nm[i]), outs[i][: int(pairs[i]["n_f"])]) for i in range(n)]
+
+    def SearchByBoWFrames(self, n_frames, cap, kf_has_mp, match_f, nmatches, **dev):
+        """aos2_matcher_search_by_bow_frames: dev = the device addresses (ints) named like aos2_bow_frames_t's fields;
+        kf_has_mp uint8 [n][cap], match_f int32 [n][cap], nmatches int32 [n]: host arrays (filled in place)"""
+        q = _BowFrames()
+        q.n_frames, q.cap = int(n_frames), int(cap)
+        for k, v in dev.items():
+            setattr(q, k, int(v))
+        q.kf_has_mp = kf_has_mp.ctypes.data
+        _check(self.L.aos2_matcher_search_by_bow_frames(self.h, C.byref(q), _p(match_f), _p(nmatches)))
 
     def _kfkf(self, struct_t, fn, problems, *extra):
         single = isinstance(problems, dict)
@@ -1017,6 +1066,12 @@ class Frames:
 
     def stream(self):
         return self.L.aos2_frames_stream(self.h)
+
+    KEYS_ANGLE, KEYS_OCTAVE = 9, 10
+
+    def device_ptr(self, what):
+        """device address (int) of a member array [batch][cap]"""
+        return self.L.aos2_frames_device_ptr(self.h, int(what)) or 0
 
     def wait_for_stream(self, hip_stream=None):
         """device-side ordering: what is enqueued on the batch from now on runs behind the work on `hip_stream` so far"""

@@ -98,3 +98,64 @@ class TrackingChain:
     def wait(self):
         self.cur.wait()
         self.ex.wait()
+
+
+class ReferenceKeyFrameBoW:
+    """Harness (tests/, bench.py): the front part of Tracking::TrackReferenceKeyFrame (src/Tracking.cc:858-866) for the first
+    `n_frames` frames of a TrackingChain's batch, their reference keyframe being the frame's LastFrame:
+
+        mCurrentFrame.ComputeBoW();                                        Frame::ComputeBoW, src/Frame.cc:424-431
+        ORBmatcher matcher(0.7, true);
+        int nmatches = matcher.SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches);
+
+    Descriptors and keys stay in HBM: aos2_vocabulary_transform_device on the extractor's device output, ordered behind the
+    extraction on the device, then aos2_matcher_search_by_bow_frames; only the FeatureVector CSRs (a few KB per frame), the
+    keyframes' map point flags and the results cross PCIe.  `order()` is called by the thread that enqueued the extraction,
+    `run()` may run on another thread (the calls of a step are serial per handle)."""
+
+    def __init__(self, tc: TrackingChain, voc: dict, n_frames: int, nnratio: float = 0.7, levelsup: int = 4):
+        t = tc.torch
+        self.tc, self.n, self.levelsup = tc, int(n_frames), levelsup
+        self.voc = capi.Vocabulary(device=tc.device)
+        self.voc.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+        self.m = capi.Matcher(nnratio, True, device=tc.device)
+        n, cap = self.n, tc.cap
+        mk = lambda shape, dt: t.zeros(shape, dtype=dt, device=tc.dev)   # noqa: E731
+        self.bw, self.bv, self.nb = mk((n, cap), t.int32), mk((n, cap), t.float64), mk((n,), t.int32)
+        self.fn, self.fo, self.fi, self.nf = mk((n, cap), t.int32), mk((n, cap + 1), t.int32), mk((n, cap), t.int32), mk((n,), t.int32)
+        # the reference keyframes computed their BoW when they were created (KeyFrame::ComputeBoW): once, here, into buffers
+        # of their own
+        self.kf = [self.bw.clone(), self.bv.clone(), self.nb.clone(), self.fn.clone(), self.fo.clone(), self.fi.clone(), self.nf.clone()]
+        self._transform(tc.dl_desc, tc.dl_n, self.kf)
+        self.kf_has_mp = np.zeros((n, cap), np.uint8)
+        self.kf_has_mp[:, :] = tc.last_mp[:n] >= 0
+        self.match = np.full((n, cap), -1, np.int32)
+        self.nmatches = np.zeros(n, np.int32)
+        t.cuda.synchronize()
+        self.results, self.last_ms = None, (0.0, 0.0)
+
+    def _transform(self, d_desc, d_n, out=None):
+        o = out or [self.bw, self.bv, self.nb, self.fn, self.fo, self.fi, self.nf]
+        return self.voc.transform_device(self.n, d_desc.data_ptr(), d_n.data_ptr(), self.tc.cap, self.levelsup, *(x.data_ptr() for x in o))
+
+    def order(self):
+        """the transform's stream waits for the extraction enqueued so far (device-side; the caller's thread)"""
+        self.tc.ex.stream_wait(self.voc.stream())
+
+    def run(self):
+        tc = self.tc
+        ms_t = self._transform(tc.d_desc, tc.d_n)    # returns when done: the extraction of this step is complete, too
+        k = self.kf
+        self.m.SearchByBoWFrames(self.n, tc.cap, self.kf_has_mp, self.match, self.nmatches,
+                                 d_desc_kf=tc.dl_desc.data_ptr(), d_kps_kf=tc.dl_kps.data_ptr(), d_n_kf=tc.dl_n.data_ptr(),
+                                 d_desc_f=tc.d_desc.data_ptr(), d_kps_f=tc.d_kps.data_ptr(), d_n_f=tc.d_n.data_ptr(),
+                                 d_kf_fv_node=k[3].data_ptr(), d_kf_fv_off=k[4].data_ptr(), d_kf_fv_idx=k[5].data_ptr(), d_kf_n_fv=k[6].data_ptr(),
+                                 d_f_fv_node=self.fn.data_ptr(), d_f_fv_off=self.fo.data_ptr(), d_f_fv_idx=self.fi.data_ptr(), d_f_n_fv=self.nf.data_ptr())
+        self.last_ms = (ms_t, self.m.last_device_ms())
+        self.results = None
+        return self
+
+    def get_results(self):
+        """[(nmatches, match_f[:N])] of the last run (host copies)"""
+        n_f = self.tc.d_n[: self.n].cpu().numpy()
+        return [(int(self.nmatches[b]), self.match[b, : n_f[b]].copy()) for b in range(self.n)]

@@ -347,10 +347,14 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     const int nq = (cw + 3) >> 2;           // 4-pixel groups per row
     const int ndw = nq + 2;                 // dwords staged per row: [halo | nq quads | halo]
 
-    // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c.  Lane grid (rows x ndw dwords) fixed once per wave;
-    // up to 8 row steps are requested together before the first LDS write.
+    // ---- 0. stage: LDS column c <-> level column vx0 - 4 + c.  Lane grid (rows x ndw dwords) fixed once per wave.
     // (24-bit multiplies throughout: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter of it; every index here is far
     // below 2^24.  The uniform parts of the addresses stay in scalar registers.)
+    // The tile's pitch is the cell's own 4 * ndw bytes (<= the TP the LDS region was sized for): lane (rs, c) of a row step
+    // then owns LDS dword rs * ndw + c = its lane number, which is the one layout gfx950's LDS-DMA can write
+    // (global_load_lds_dword: per-lane global address, LDS destination = M0 base + 4 * lane) -- the tile goes from HBM / L2
+    // to LDS without passing through VGPRs and without a ds_write per row step.
+    const int tp = 4 * ndw;
     {
         const int nrs = max(1, (int)((64u * cell.inv_ndw) >> 16));      // rows per step = 64 / ndw (cells are < 64 px wide: ndw <= 18)
         const int rs = (int)(__umul24((uint32_t)lane, cell.inv_ndw) >> 16), c = lane - (int)__umul24((uint32_t)rs, (uint32_t)ndw);
@@ -358,8 +362,18 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         if (rs < nrs) {
             const uint8_t *sbase = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);   // uniform
             const uint32_t soff = __umul24((uint32_t)rs, (uint32_t)lv.pitch) + 4u * (uint32_t)c;
-            uint32_t doff = __umul24((uint32_t)rs, (uint32_t)TP) + 4u * (uint32_t)c;
-            const uint32_t sstep = (uint32_t)(nrs * lv.pitch), dstep = (uint32_t)(nrs * TP);
+            const uint32_t sstep = (uint32_t)(nrs * lv.pitch);
+#if !defined(AOS2_FAST_STAGE_VGPR)
+            const uint32_t dstep = (uint32_t)(nrs * tp);   // = 4 * nrs * ndw: the dwords one step's lanes cover
+            uint32_t dbase = 0;
+            for (int r0 = 0; r0 < nrows; r0 += nrs, sbase += sstep, dbase += dstep)
+                if (rs < nrows - r0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + soff),
+                                                     (__attribute__((address_space(3))) void *)(tile + dbase), 4, 0, 0);
+#else
+            // (the round-2 form: up to 8 row steps requested together into registers, then written to LDS)
+            uint32_t doff = __umul24((uint32_t)rs, (uint32_t)tp) + 4u * (uint32_t)c;
+            const uint32_t dstep = (uint32_t)(nrs * tp);
             for (int r0 = 0; r0 < nrows; r0 += 8 * nrs, sbase += 8 * (size_t)sstep, doff += 8 * dstep) {
                 uint32_t t[8];
 #pragma unroll
@@ -369,6 +383,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 for (int u = 0; u < 8; ++u)
                     if (rs < nrows - r0 - u * nrs) *reinterpret_cast<uint32_t *>(tile + doff + (uint32_t)u * dstep) = t[u];
             }
+#endif
         }
     }
     const int SH = ch + 2;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                     pos = list1[i];
                     const int py = pos >> 6, px = pos & 63;
                     if (px < cw) {
-                        const int S = fast_score_full(tile + __umul24((uint32_t)(py + 3), (uint32_t)TP) + 4 + px, TP);
+                        const int S = fast_score_full(tile + __umul24((uint32_t)(py + 3), (uint32_t)tp) + 4 + px, tp);
                         corner = S >= th;
                         if (corner) smap[__umul24((uint32_t)(py + 1), (uint32_t)SP) + px + 1] = (uint8_t)S;
                     }
@@ -427,12 +442,12 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             if (g < nitems) {
                 py = (int)(__umul24((uint32_t)g, cell.inv_nq) >> 16);
                 qd = g - (int)__umul24((uint32_t)py, (uint32_t)nq);
-                const uint8_t *row = tile + __umul24((uint32_t)(py + 3), (uint32_t)TP) + 4 + 4 * qd;
+                const uint8_t *row = tile + __umul24((uint32_t)(py + 3), (uint32_t)tp) + 4 + 4 * qd;
                 const uint32_t C = *reinterpret_cast<const uint32_t *>(row);
                 const uint32_t Wd = *reinterpret_cast<const uint32_t *>(row - 4);
                 const uint32_t Ed = *reinterpret_cast<const uint32_t *>(row + 4);
-                const uint32_t N = *reinterpret_cast<const uint32_t *>(row - 3 * TP);   // ring pixel 8 (dy=-3)
-                const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * TP);   // ring pixel 0 (dy=+3)
+                const uint32_t N = *reinterpret_cast<const uint32_t *>(row - 3 * tp);   // ring pixel 8 (dy=-3)
+                const uint32_t S = *reinterpret_cast<const uint32_t *>(row + 3 * tp);   // ring pixel 0 (dy=+3)
                 const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
                 const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
                 const uint32_t M = 0x00ff00ffu, MH = 0xff00ff00u;

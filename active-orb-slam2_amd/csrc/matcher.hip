@@ -2080,6 +2080,8 @@ struct aos2_matcher {
     PinnedBuf<uint8_t> h_out;  // page-locked: the results on their way back
     DevBuf<uint32_t> part;     // hamming partials
     DevBuf<uint64_t> pool;     // candidate entries of the projection searches (8 B each)
+    DevBuf<float> fr_angle;    // aos2_matcher_search_by_bow_frames: dense key angles of the two frame batches
+    PinnedBuf<uint8_t> fr_host;   // ... and the host copies of their FeatureVectors and counts
     float last_ms = 0;         // device time of the kernels of the last search call
     bool serial_resolve = false;   // AOS2_SERIAL_RESOLVE=1: the one-wave sequential stage B (tests compare both)
 };
@@ -2356,6 +2358,8 @@ void aos2_matcher_destroy(aos2_matcher_t *m)
         m->h_out.release();
         m->part.release();
         m->pool.release();
+        m->fr_angle.release();
+        m->fr_host.release();
         for (auto &e : m->ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(m->stream);
     }
@@ -2442,8 +2446,11 @@ int aos2_matcher_hamming_best2(aos2_matcher_t *m, const uint8_t *q, int nq, cons
 
 // shared by SearchByBoW(KF, F) (kf_kf = 0, match_out[p] has n_f entries) and SearchByBoW(KF1, KF2)
 // (kf_kf = 1, f_has_mp[p] = has_mp2, match_out[p] has n_kf entries)
+// dev_inputs: desc_kf / desc_f / angle_kf / angle_f of the pairs are DEVICE arrays (the descriptors and keys of frames that
+// already live in HBM, e.g. a device-resident Frames batch): they are used in place; the FeatureVector CSRs, kf_has_mp
+// and the results stay host arrays (a few KB per pair)
 static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_t *const *f_has_mp, int n_pairs, int kf_kf,
-                   int32_t *const *match_f, int32_t *nmatches)
+                   int32_t *const *match_f, int32_t *nmatches, bool dev_inputs = false)
 {
     int st = matcher_init(m);
     if (st) return st;
@@ -2491,10 +2498,12 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         }
         Off &o = offs[p];
         o.nq = (int)queries.size();
-        o.o[0] = A.push(P.desc_kf, (size_t)P.n_kf * 32);
-        o.o[1] = A.push(P.desc_f, (size_t)P.n_f * 32);
-        o.o[2] = A.push(P.angle_kf, (size_t)P.n_kf * 4);
-        o.o[3] = A.push(P.angle_f, (size_t)P.n_f * 4);
+        if (!dev_inputs) {
+            o.o[0] = A.push(P.desc_kf, (size_t)P.n_kf * 32);
+            o.o[1] = A.push(P.desc_f, (size_t)P.n_f * 32);
+            o.o[2] = A.push(P.angle_kf, (size_t)P.n_kf * 4);
+            o.o[3] = A.push(P.angle_f, (size_t)P.n_f * 4);
+        }
         o.o[4] = A.push(P.node_idx_f, (size_t)(P.n_nodes_f ? P.node_off_f[P.n_nodes_f] : 0) * 4);
         o.o[5] = A.push(queries.data(), queries.size() * sizeof(BowQuery));
         o.o[6] = A.reserve(ent * sizeof(Entry) + 8);
@@ -2521,8 +2530,12 @@ static int bow_run(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, const uint8_
         const Off &o = offs[p];
         BowPairDev &D = dev[p];
         D.n_kf = P.n_kf; D.n_f = P.n_f; D.n_queries = o.nq;
-        D.desc_kf = A.dev<uint8_t>(o.o[0]); D.desc_f = A.dev<uint8_t>(o.o[1]);
-        D.angle_kf = A.dev<float>(o.o[2]); D.angle_f = A.dev<float>(o.o[3]);
+        if (dev_inputs) {
+            D.desc_kf = P.desc_kf; D.desc_f = P.desc_f; D.angle_kf = P.angle_kf; D.angle_f = P.angle_f;
+        } else {
+            D.desc_kf = A.dev<uint8_t>(o.o[0]); D.desc_f = A.dev<uint8_t>(o.o[1]);
+            D.angle_kf = A.dev<float>(o.o[2]); D.angle_f = A.dev<float>(o.o[3]);
+        }
         D.node_idx_f = A.dev<int32_t>(o.o[4]); D.queries = A.dev<BowQuery>(o.o[5]); D.entries = A.dev<Entry>(o.o[6]);
         D.match_f = A.dev<int32_t>(o.o[7]); D.bin_f = A.dev<uint32_t>(o.o[8]); D.nmatches = A.dev<int32_t>(o.o[9]);
         D.kf_kf = kf_kf;
@@ -2566,6 +2579,76 @@ int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, 
         return AOS2_ERR_ARG;
     }
     return bow_run(m, pairs, nullptr, n_pairs, 0, match_f, nmatches);
+}
+
+int aos2_matcher_search_by_bow_device(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs, int32_t *const *match_f,
+                                      int32_t *nmatches)
+{
+    if (!m || !pairs || n_pairs <= 0 || !match_f || !nmatches) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    return bow_run(m, pairs, nullptr, n_pairs, 0, match_f, nmatches, true);
+}
+
+// mvKeys[i].angle of [n][cap] keypoints (28-byte cv::KeyPoint records) as the dense float array the search reads
+__global__ void key_angles_kernel(const aos2_keypoint_t *__restrict__ kps, float *__restrict__ angle, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) angle[i] = kps[i].angle;
+}
+
+int aos2_matcher_search_by_bow_frames(aos2_matcher_t *m, const aos2_bow_frames_t *q, int32_t *match_f, int32_t *nmatches)
+{
+    if (!m || !q || !match_f || !nmatches || q->n_frames <= 0 || q->cap <= 0 || !q->d_desc_kf || !q->d_kps_kf || !q->d_n_kf || !q->d_desc_f ||
+        !q->d_kps_f || !q->d_n_f || !q->kf_has_mp || !q->d_kf_fv_node || !q->d_kf_fv_off || !q->d_kf_fv_idx || !q->d_kf_n_fv ||
+        !q->d_f_fv_node || !q->d_f_fv_off || !q->d_f_fv_idx || !q->d_f_n_fv) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = matcher_init(m);
+    if (st) return st;
+    const size_t n = (size_t)q->n_frames, cap = (size_t)q->cap, tot = n * cap;
+    if ((st = m->fr_angle.alloc(2 * tot))) return st;
+    // host copies: per side n counts | n fv counts | fv_node [n][cap] | fv_off [n][cap + 1] | fv_idx [n][cap]
+    const size_t side = 4 * (2 * n + tot + n * (cap + 1) + tot);
+    if ((st = m->fr_host.alloc(2 * side))) return st;
+    hipStream_t s = m->stream;
+    hipLaunchKernelGGL(key_angles_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, q->d_kps_kf, m->fr_angle.p, tot);
+    hipLaunchKernelGGL(key_angles_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, q->d_kps_f, m->fr_angle.p + tot, tot);
+    struct Side { int32_t *n, *n_fv, *node, *off, *idx; } H[2];
+    const int32_t *src[2][5] = {{q->d_n_kf, q->d_kf_n_fv, q->d_kf_fv_node, q->d_kf_fv_off, q->d_kf_fv_idx},
+                                {q->d_n_f, q->d_f_n_fv, q->d_f_fv_node, q->d_f_fv_off, q->d_f_fv_idx}};
+    const size_t cnt[5] = {n, n, tot, n * (cap + 1), tot};
+    for (int k = 0; k < 2; ++k) {
+        int32_t *base = reinterpret_cast<int32_t *>(m->fr_host.p + k * side);
+        int32_t **dst[5] = {&H[k].n, &H[k].n_fv, &H[k].node, &H[k].off, &H[k].idx};
+        for (int a = 0; a < 5; ++a) {
+            *dst[a] = base;
+            AOS2_HIP_CHECK(hipMemcpyAsync(base, src[k][a], 4 * cnt[a], hipMemcpyDeviceToHost, s));
+            base += cnt[a];
+        }
+    }
+    AOS2_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<aos2_bow_pair_t> pairs(n);
+    std::vector<int32_t *> mptr(n);
+    for (size_t b = 0; b < n; ++b) {
+        aos2_bow_pair_t &P = pairs[b];
+        P.n_kf = H[0].n[b]; P.n_f = H[1].n[b];
+        if (P.n_kf < 0 || P.n_kf > (int)cap || P.n_f < 0 || P.n_f > (int)cap || H[0].n_fv[b] < 0 || H[0].n_fv[b] > (int)cap || H[1].n_fv[b] < 0 ||
+            H[1].n_fv[b] > (int)cap) {
+            set_error("frame %zu: counts outside the capacity %zu", b, cap);
+            return AOS2_ERR_ARG;
+        }
+        P.desc_kf = q->d_desc_kf + b * cap * 32; P.desc_f = q->d_desc_f + b * cap * 32;
+        P.angle_kf = m->fr_angle.p + b * cap; P.angle_f = m->fr_angle.p + tot + b * cap;
+        P.kf_has_mp = q->kf_has_mp + b * cap;
+        P.n_nodes_kf = H[0].n_fv[b]; P.n_nodes_f = H[1].n_fv[b];
+        P.node_id_kf = H[0].node + b * cap; P.node_off_kf = H[0].off + b * (cap + 1); P.node_idx_kf = H[0].idx + b * cap;
+        P.node_id_f = H[1].node + b * cap; P.node_off_f = H[1].off + b * (cap + 1); P.node_idx_f = H[1].idx + b * cap;
+        mptr[b] = match_f + b * cap;
+    }
+    return bow_run(m, pairs.data(), nullptr, (int)n, 0, mptr.data(), nmatches, true);
 }
 
 int aos2_matcher_search_by_bow_kf(aos2_matcher_t *m, const aos2_bow_kf_pair_t *pairs, int n_pairs, int32_t *const *match12,

@@ -549,6 +549,11 @@ int aos2_vocabulary_nodes(const aos2_vocabulary_t *v) { return v ? (int)v->nodes
 unsigned aos2_vocabulary_size(const aos2_vocabulary_t *v) { return v ? v->n_words : 0; }
 int aos2_vocabulary_empty(const aos2_vocabulary_t *v) { return !v || v->n_words == 0; }
 float aos2_vocabulary_last_device_ms(const aos2_vocabulary_t *v) { return v ? v->last_ms : 0.0f; }
+void *aos2_vocabulary_stream(aos2_vocabulary_t *v)
+{
+    if (!v || voc_init_device(v)) return nullptr;
+    return v->stream;
+}
 
 static int voc_run(aos2_vocabulary *v, int batch, const uint8_t *d_desc, const int32_t *d_n, int cap, int levelsup,
                    const AssembleOut &O, uint32_t *d_word_of, uint32_t *d_node_of)

@@ -11,7 +11,9 @@ step      = one pass of the whole per-frame hot path over one batch of B synthet
               Optimizer::PoseOptimization + outlier discard
               Tracking::SearchLocalPoints: isInFrustum + ORBmatcher::SearchByProjection(Frame, local map points)   (match)
               Optimizer::PoseOptimization
-            plus, for every `--frames-per-keyframe` (default 8) frames, one Optimizer::LocalBundleAdjustment window of the
+            plus, for every `--frames-per-keyframe` (default 8) frames, the keyframe work: Frame::ComputeBoW (ORBVocabulary::transform)
+            + ORBmatcher::SearchByBoW(reference keyframe, frame) (Tracking::TrackReferenceKeyFrame's front part, device-resident)
+            and one Optimizer::LocalBundleAdjustment window of the
             SURVEY section 8(d) size (20 local + 30 fixed keyframes, ~24 k stereo edges), solved by
             aos2_lba_solve_batch concurrently with the tracking chain like the reference's LocalMapping thread
             (host-resident problem arrays: their upload is inside the timed region).
@@ -246,9 +248,18 @@ def main():
             pp.ex.set_chunks(1)
     ex = pipes[0].ex
     cap = pipes[0].cap
+    # ---- per keyframe (every `frames_per_keyframe` frames) the front part of Tracking::TrackReferenceKeyFrame (Tracking.cc:858-866):
+    # Frame::ComputeBoW (ORBVocabulary::transform, a vocabulary of the ORBvoc shape k = 10, L = 6) + SearchByBoW(reference
+    # keyframe, frame), device-resident (chain.ReferenceKeyFrameBoW), on a thread of its own beside the chain
+    fpk = max(1, args.frames_per_keyframe)
+    n_bow = max(1, B // fpk)
+    NO_BOW = os.environ.get("AOS2_BENCH_NO_BOW") == "1"   # diagnostics only
+    voc_nodes = None if NO_BOW else pkg.synth.synth_vocabulary(400, 10, int(os.environ.get("AOS2_BENCH_VOC_LEVELS", "6")))
+    bows = [] if NO_BOW else [pkg.chain.ReferenceKeyFrameBoW(pp, voc_nodes, n_bow) for pp in pipes]
+    bow_pool = ThreadPoolExecutor(NPIPE)
+    bow_jobs = [None] * NPIPE
     d_img, d_kps, d_desc, d_n = pipes[0].d_cur, pipes[0].d_kps, pipes[0].d_desc, pipes[0].d_n
     # ---- LocalBA windows of the step: one per frames_per_keyframe frames, 4 distinct problems tiled
-    fpk = max(1, args.frames_per_keyframe)
     n_win = max(1, B // fpk)
     lba_unique = [pkg.synth.synth_lba_problem(10 * rank + i, n_points=8000) for i in range(min(4, n_win))]
     lba_probs = [lba_unique[i % len(lba_unique)] for i in range(n_win)]
@@ -287,8 +298,14 @@ def main():
         jl = s % NLBA
         if lba_jobs[jl] is not None:
             lba_jobs[jl].result()
+        if bow_jobs[j] is not None:
+            bow_jobs[j].result()
+            bow_jobs[j] = None
         p.wait()
         p.step()
+        if bows:
+            bows[j].order()   # the transform's stream waits for this step's extraction (device side)
+            bow_jobs[j] = bow_pool.submit(bows[j].run)
         if gather is not None:
             gather_step(j)
         if not NO_LBA:
@@ -300,6 +317,9 @@ def main():
                 lba_jobs[jl].result()
                 lba_jobs[jl] = None
         for j in range(NPIPE):
+            if bow_jobs[j] is not None:
+                bow_jobs[j].result()
+                bow_jobs[j] = None
             if gather is not None and gather["work"][j] is not None:
                 gather["work"][j].wait()
                 gather["work"][j] = None
@@ -336,8 +356,23 @@ def main():
         g.load_oracle()
         import parity
         lp, ll = pipes[(args.steps - 1) % NPIPE], lba_prep[(args.steps - 1) % NLBA]
-        snap = dict(chain=parity.chain_snapshot(pkg, lp), pipe=lp,
+        lb = bows[(args.steps - 1) % NPIPE] if bows else None
+        snap = dict(chain=parity.chain_snapshot(pkg, lp), pipe=lp, bow=None if lb is None else lb.get_results(),
                     lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win)])
+    # ---- the same steps without the reference-keyframe BoW leg: the composite as round 2 measured it (comparability only)
+    dt_nobow = None
+    if bows and os.environ.get("AOS2_BENCH_SKIP_R02_FORM") != "1":
+        saved, n2 = list(bows), max(10, min(args.steps, 50))
+        bows.clear()
+        for i in range(2):
+            step(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n2):
+            step(i)
+        sync()
+        dt_nobow = (time.perf_counter() - t0) / n2
+        bows.extend(saved)
     nm_host = pipes[0].d_nm.cpu().numpy()
     lba_res = lba_prep[0]["R"]
     # ---- stage times of one synchronous pass (every stage waited for: wall clock incl. launch latency)
@@ -366,6 +401,12 @@ def main():
     composite_stage["pose_optimization_1"] = timed(_w(lambda: (p0.cur.PoseOptimization(p0.table, p0.d_nm[1].data_ptr()), p0.cur.discard_outliers())))
     composite_stage["search_local_points"] = timed(_w(lambda: p0.cur.SearchLocalPoints(p0.table, p0.d_local.data_ptr(), N_LOCAL, p0.th_local, p0.nnratio_local, p0.d_nm[2].data_ptr())))
     composite_stage["pose_optimization_2"] = timed(_w(lambda: p0.cur.PoseOptimization(p0.table, p0.d_nm[3].data_ptr())))
+    if bows:
+        def _bow():
+            bows[0].order()
+            bows[0].run()
+        composite_stage["reference_keyframe_bow_wall"] = timed(_bow)
+        composite_stage["reference_keyframe_bow_device"] = {"transform": bows[0].last_ms[0], "search_by_bow": bows[0].last_ms[1], "frames": n_bow}
     composite_stage["local_ba_batch_wall"] = timed(lambda: lbas[0].solve_prepared(lba_prep[0]))
     composite_stage["local_ba_batch_device"] = float(lba_prep[0]["R"][0].ms_device)
     composite_stage["note"] = ("one synchronous pass, every stage waited for (wall clock incl. launch latency); the timed steps enqueue "
@@ -416,7 +457,10 @@ def main():
         assert gather_ok, "gathered slot headers corrupt"
 
     # secondary measurements of the other hot-path rows (reported, not part of `value`)
-    extra = {"extract_only": {
+    extra = {"composite_without_reference_keyframe_bow": None if dt_nobow is None else {
+                 "note": "the timed steps without the per-keyframe ComputeBoW + SearchByBoW leg = the composite of round 2's bench line",
+                 "frames_per_s": world * B / dt_nobow, "ms_per_step": dt_nobow * 1e3},
+             "extract_only": {
         "note": "BASELINE configs[1]: ORBextractor::operator() alone over the same frames (round 1's headline)",
         "frames_per_s_async": world * B * args.steps / dt_extract, "ms_per_step_async": dt_extract / args.steps * 1e3,
         "frames_per_s_synchronous_call": world * B * args.steps / dt_sync, "ms_per_step_synchronous_call": dt_sync / args.steps * 1e3,
@@ -577,7 +621,7 @@ def main():
             extra["rank4_matcher"] = r4
             # ORBVocabulary::transform with a vocabulary of the real ORBvoc shape (k=10, L=6: 1.1 M nodes),
             # 64 frames x 1000 descriptors, device-resident
-            voc = S.synth_vocabulary(400, 10, 6)
+            voc = voc_nodes if (voc_nodes is not None and voc_nodes["L"] == 6) else S.synth_vocabulary(400, 10, 6)
             vv = pkg.Vocabulary(device=local_rank)
             vv.set_nodes(10, 6, 0, 0, voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
             vb, vcap = 64, 1000
@@ -619,7 +663,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "TUM 640x480 RGB-D, 1000 features, 8 levels, scale 1.2, FAST 20/7: per frame ORBextractor::operator() + "
                                    "Frame::Frame + SearchByProjection(Current, Last) + PoseOptimization + SearchLocalPoints(%d local map "
-                                   "points) + PoseOptimization; per %d frames one LocalBundleAdjustment window (%d keyframes, %d points, %d "
+                                   "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "
+                                   "SearchByBoW(reference keyframe, frame) and one LocalBundleAdjustment window (%d keyframes, %d points, %d "
                                    "edges: SURVEY 8(d))" % (N_LOCAL, fpk, lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
@@ -701,6 +746,8 @@ def main():
             for i in range(n_cpu):
                 co.unique(i % n_unique, timing=tm)
                 if (i + 1) % fpk == 0:
+                    if voc_nodes is not None:   # the keyframe's Frame::ComputeBoW + SearchByBoW(reference keyframe, frame)
+                        parity.bow_leg_mismatches(None, co, voc_nodes, [i % n_unique], timing=tm)
                     ta = time.perf_counter()
                     k = (i // fpk) % len(lba_unique)
                     lba_want[k] = O.lba_solve(lba_unique[k])
@@ -745,15 +792,21 @@ def main():
                 for k in range(min(2, len(lba_unique))):
                     if k not in lba_want:
                         lba_want[k] = O.lba_solve(lba_unique[k])
+            n_bow_checked = 0
+            if snap["bow"] is not None:
+                bpos = [b for b in range(n_bow) if int(scen["index"][b]) in co.cache]
+                bad += parity.bow_leg_mismatches(snap["bow"], co, voc_nodes, bpos)
+                n_bow_checked = len(bpos)
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
             for w in wins:
                 bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")
             out["parity_checked"] = {
                 "ok": not bad, "step": "the last timed step (results copied right after the timed region)",
-                "frames": len(pos), "distinct_frame_pairs": len(co.cache), "local_ba_windows": len(wins),
+                "frames": len(pos), "distinct_frame_pairs": len(co.cache), "reference_keyframe_bow_frames": n_bow_checked, "local_ba_windows": len(wins),
                 "distinct_local_ba_problems": len(set(w % len(lba_unique) for w in wins)),
                 "checked": "per frame: keypoints, descriptors, mvuRight / mvDepth, match counts of both searches, inlier counts of both "
-                           "PoseOptimizations, mvpMapPoints, mvbOutlier (bit-identical), mTcw (1e-5); per window: iteration and trial "
+                           "PoseOptimizations, mvpMapPoints, mvbOutlier (bit-identical), mTcw (1e-5); per keyframe frame: the SearchByBoW match "
+                           "array and count behind ComputeBoW (bit-identical); per window: iteration and trial "
                            "counts, outlier sets (identical), poses and points (1e-5), final chi2 (1e-6 relative)",
                 "against": "oracle (C restatement; parity unpinned by the reference: DESIGN.md section 3)",
                 "mismatches": bad[:10], "n_mismatches": len(bad)}

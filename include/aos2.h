@@ -253,6 +253,9 @@ int aos2_vocabulary_transform_device(aos2_vocabulary_t *v, int batch, const uint
                                      int32_t *d_fv_node, int32_t *d_fv_off, int32_t *d_fv_idx,
                                      int32_t *d_n_fv, uint32_t *d_word_of, uint32_t *d_node_of);
 float aos2_vocabulary_last_device_ms(const aos2_vocabulary_t *v);
+/* the handle's hipStream_t (the transforms run on it): lets a caller order a transform behind the producer of d_desc on
+ * the device, e.g. aos2_extractor_stream_wait(e, aos2_vocabulary_stream(v)) after enqueuing the extraction */
+void *aos2_vocabulary_stream(aos2_vocabulary_t *v);
 /* double score(const BowVector&, const BowVector&) :1191-1195 for L1_NORM
  * (L1Scoring::score, Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-72); host scalar helper. */
 int aos2_vocabulary_score(const aos2_vocabulary_t *v, const uint32_t *w1, const double *v1, int n1,
@@ -314,6 +317,31 @@ typedef struct {
  * or -1 (NULL).  nmatches[p] = return value. */
 int aos2_matcher_search_by_bow(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs,
                                int32_t *const *match_f, int32_t *nmatches);
+
+/* The same search on frames whose descriptors and keys already live in HBM (a device-resident Frames batch, the
+ * extractor's device outputs): desc_kf / desc_f / angle_kf / angle_f of the pairs are DEVICE arrays and are used in place
+ * (32 KB + 4 KB per frame that do not cross PCIe); kf_has_mp, the FeatureVector CSRs (the host merge-joins them, :181-258)
+ * and the results are host arrays, a few KB per pair.  The caller has completed (or ordered this handle's work behind) the
+ * producers of the device arrays. */
+int aos2_matcher_search_by_bow_device(aos2_matcher_t *m, const aos2_bow_pair_t *pairs, int n_pairs,
+                                      int32_t *const *match_f, int32_t *nmatches);
+
+/* The per-keyframe front part of Tracking::TrackReferenceKeyFrame (src/Tracking.cc:858-866) for `n_frames` (reference
+ * keyframe b, frame b) pairs whose members live in HBM as the extractor and aos2_vocabulary_transform_device wrote them:
+ * descriptors [n][cap][32], keypoints [n][cap] (mvKeys: the angle is read), counts [n], FeatureVectors fv_node [n][cap],
+ * fv_off [n][cap + 1], fv_idx [n][cap], n_fv [n] -- all DEVICE arrays; kf_has_mp [n][cap] is a HOST array (map state:
+ * vpMapPointsKF[i] != NULL && !isBad()).  The call copies the FeatureVectors and counts to the host (a few KB per frame),
+ * merge-joins them there, and runs aos2_matcher_search_by_bow_device.  match_f: HOST [n][cap], nmatches: HOST [n]. */
+typedef struct {
+    int32_t n_frames, cap;
+    const uint8_t *d_desc_kf;          const aos2_keypoint_t *d_kps_kf;  const int32_t *d_n_kf;
+    const uint8_t *d_desc_f;           const aos2_keypoint_t *d_kps_f;   const int32_t *d_n_f;
+    const uint8_t *kf_has_mp;
+    const int32_t *d_kf_fv_node, *d_kf_fv_off, *d_kf_fv_idx, *d_kf_n_fv;
+    const int32_t *d_f_fv_node, *d_f_fv_off, *d_f_fv_idx, *d_f_n_fv;
+} aos2_bow_frames_t;
+int aos2_matcher_search_by_bow_frames(aos2_matcher_t *m, const aos2_bow_frames_t *q, int32_t *match_f,
+                                      int32_t *nmatches);
 
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)
  * src/ORBmatcher.cc:522-655 (LoopClosing.cc:? / Tracking relocalisation candidates).
@@ -691,7 +719,13 @@ int aos2_frames_set_map_points(aos2_frames_t *f, const int32_t *mp, const uint8_
 #define AOS2_FRAMES_GRID_IDX 6   /* int32 [batch][cap] */
 #define AOS2_FRAMES_KEYS_UN_X 7  /* float [batch][cap]  mvKeysUn[i].pt.x */
 #define AOS2_FRAMES_KEYS_UN_Y 8  /* float [batch][cap]  mvKeysUn[i].pt.y */
+#define AOS2_FRAMES_KEYS_ANGLE 9 /* float [batch][cap]  mvKeysUn[i].angle (= mvKeys[i].angle)   (device pointer only) */
+#define AOS2_FRAMES_KEYS_OCTAVE 10 /* int32 [batch][cap] mvKeysUn[i].octave                      (device pointer only) */
 int aos2_frames_get(aos2_frames_t *f, int what, void *dst, size_t bytes);
+/* the member array itself in device memory ([batch][cap] ...), valid while the batch lives; NULL before the first build.
+ * For handing Frame members to the other device-resident entry points (aos2_matcher_search_by_bow_device) without a copy;
+ * the caller orders its reads behind the batch's stream (aos2_frames_wait or an event on aos2_frames_stream). */
+const void *aos2_frames_device_ptr(aos2_frames_t *f, int what);
 
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
  * src/ORBmatcher.cc:1328-1470 for the pairs (cur frame b, last frame b): reads last's mvpMapPoints / mvbOutlier /

@@ -141,3 +141,40 @@ def stereo_slot_mismatches(pkg, kps, desc, n, u_right, depth, left_img, right_im
     if u_right[:n].tobytes() != our.tobytes() or depth[:n].tobytes() != odp.tobytes():
         bad.append(f"{tag}: mvuRight / mvDepth differ in {int((u_right[:n] != our).sum())} features")
     return bad
+
+
+def bow_leg_mismatches(results, co: ChainOracle, voc: dict, positions, nnratio=0.7, levelsup=4, timing=None):
+    """chain.ReferenceKeyFrameBoW's results (Frame::ComputeBoW + SearchByBoW(reference keyframe, frame), src/Tracking.cc:858-866)
+    for the batch positions given, against the oracle's vocabulary transform and SearchByBoW on the oracle's own extraction
+    of the same images: match arrays and counts bit-identical."""
+    import time
+    tc, scen = co.tc, co.scen
+    if not hasattr(co, "_ov"):
+        co._ov = O.Vocabulary()
+        co._ov.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+        co._kf_bow = {}
+    bad = []
+    for b in positions:
+        u = int(scen["index"][b])
+        okps, odesc, f, w = co.unique(u)
+        lk, ld = tc.host_last[u]
+        if u not in co._kf_bow:
+            co._kf_bow[u] = co._ov.transform(ld, levelsup)   # KeyFrame::ComputeBoW, once per keyframe
+        t0 = time.perf_counter()
+        fb = co._ov.transform(odesc, levelsup)
+        t1 = time.perf_counter()
+        kb = co._kf_bow[u]
+        prob = dict(desc_kf=ld, desc_f=odesc, kf_has_mp=(tc.last_mp[u, :len(lk)] >= 0).astype(np.uint8), angle_kf=lk["angle"],
+                    angle_f=okps["angle"], node_id_kf=kb["fv_node"], node_off_kf=kb["fv_off"], node_idx_kf=kb["fv_idx"],
+                    node_id_f=fb["fv_node"], node_off_f=fb["fv_off"], node_idx_f=fb["fv_idx"], nnratio=np.float32(nnratio),
+                    check_orientation=1)
+        n, m = O.search_by_bow(prob)
+        if timing is not None:
+            timing["compute_bow"] = timing.get("compute_bow", 0.0) + t1 - t0
+            timing["search_by_bow"] = timing.get("search_by_bow", 0.0) + time.perf_counter() - t1
+        if results is None:
+            continue
+        gn, gm = results[b]
+        if gn != n or len(gm) != len(m) or not (np.asarray(gm) == m).all():
+            bad.append(f"frame {b} (pair {u}): SearchByBoW {gn} matches, oracle {n}" + ("" if len(gm) != len(m) else f", {int((np.asarray(gm) != m).sum())} entries differ"))
+    return bad

@@ -226,3 +226,39 @@ def test_bench_scenario_all_frames_vs_oracle(pkg, oracle, gpu):
             assert bad == [], (rnd, j, bad[:5])
     nm = pipes[0].d_nm.cpu().numpy()
     assert (nm[0] > 100).all() and (nm[3] > 100).all()
+
+
+def test_reference_keyframe_bow_leg_vs_oracle(pkg, oracle, gpu):
+    """Tracking::TrackReferenceKeyFrame's front part on device-resident frames (src/Tracking.cc:858-866): Frame::ComputeBoW =
+    the vocabulary transform on the extractor's device output, ordered behind the extraction on the device, then
+    SearchByBoW(reference keyframe, frame) with descriptors and keys used in place (aos2_matcher_search_by_bow_device) --
+    match arrays and counts equal the oracle's transform + SearchByBoW on its own extraction; run twice behind two steps."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    scen = pkg.scenario.tracking_scenario(21, 12, n_unique=6)
+    tc = pkg.chain.TrackingChain(scen, n_local=1000)
+    voc = pkg.synth.synth_vocabulary(401, 10, 4)
+    leg = pkg.chain.ReferenceKeyFrameBoW(tc, voc, 10)
+    co = parity.ChainOracle(scen, tc)
+    for _ in range(2):
+        tc.step()
+        leg.order()
+        leg.run()
+        tc.wait()
+        res = leg.get_results()
+        assert parity.bow_leg_mismatches(res, co, voc, range(10)) == []
+        assert all(n > 40 for n, _ in res), [n for n, _ in res]
+    # the device-input form equals the host-pointer form on the same arrays
+    b = 3
+    kd, kk = tc.host_last[b][1], tc.host_last[b][0]
+    n_f = int(tc.d_n[b].item())
+    fd = tc.d_desc[b, :n_f].cpu().numpy()
+    fa = tc.d_kps[b, :n_f, 3].cpu().numpy()
+    kb, fb = pkg.Vocabulary(), None
+    kb.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+    tk, tf = kb.transform(kd, 4), kb.transform(fd, 4)
+    prob = dict(desc_kf=kd, desc_f=fd, kf_has_mp=(tc.last_mp[b, :len(kk)] >= 0).astype(np.uint8), angle_kf=kk["angle"], angle_f=fa,
+                node_id_kf=tk["fv_node"], node_off_kf=tk["fv_off"], node_idx_kf=tk["fv_idx"], node_id_f=tf["fv_node"],
+                node_off_f=tf["fv_off"], node_idx_f=tf["fv_idx"])
+    n, m = pkg.Matcher(0.7, True).SearchByBoW(prob)
+    assert n == res[b][0] and (m == res[b][1]).all()
