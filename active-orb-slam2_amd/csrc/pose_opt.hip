@@ -126,7 +126,8 @@ __device__ __forceinline__ bool solve6(const double *Hb, double lambda, double (
 #endif
 
 constexpr int kPoSum = 28;   // 21 (H, upper triangle) + 6 (b) + 1 (robust chi2)
-constexpr size_t kPoLds = (4 * kPoSum + 2 * kPoSum) * sizeof(double);   // 4 wave sums, two result buffers
+constexpr size_t kPoLds = (4 * kPoSum + 2 * kPoSum) * sizeof(double);   // 4 wave sums, two result buffers (256 threads)
+constexpr size_t po_lds_bytes(int nt) { return ((size_t)(nt / 64) * kPoSum + 2 * kPoSum) * sizeof(double); }
 
 __device__ __forceinline__ double pair_f64(unsigned lo, unsigned hi) { return __longlong_as_double(((long long)hi << 32) | lo); }
 
@@ -165,8 +166,10 @@ __device__ __forceinline__ double po_dpp_f64(double v)
 // LDS traffic per workgroup instead of 57 KB.  The 4 wave sums of each value are added by 28 threads.  Two barriers are
 // enough: a wave rewrites part[wave] only after it left the previous call's second barrier, which the readers of the
 // previous `part` reach after reading; `fin` is the caller's and alternates between two buffers.
-__device__ __forceinline__ void block_sum28(double (&v)[kPoSum], double *part /* 4 x 28 */, double *fin)
+template <int NT = 256>
+__device__ __forceinline__ void block_sum28(double (&v)[kPoSum], double *part /* NT / 64 x 28 */, double *fin)
 {
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double h[14], g[7];
 #pragma unroll
@@ -188,7 +191,12 @@ __device__ __forceinline__ void block_sum28(double (&v)[kPoSum], double *part /*
         for (int i = 0; i < 7; ++i) dst[i] = g[i];
     }
     __syncthreads();
-    if (tid < kPoSum) fin[tid] = ((part[tid] + part[kPoSum + tid]) + part[2 * kPoSum + tid]) + part[3 * kPoSum + tid];
+    if (tid < kPoSum) {   // the wave sums in wave order (for 4 waves: ((p0 + p1) + p2) + p3)
+        double sacc = part[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sacc += part[w * kPoSum + tid];
+        fin[tid] = sacc;
+    }
     __syncthreads();
 }
 
@@ -203,7 +211,10 @@ __device__ __forceinline__ void block_sum28(double (&v)[kPoSum], double *part /*
 // 28): at the trial pose that is the chi2 the decision needs and -- when the trial is accepted, the usual case -- the
 // system of the next iteration (g2o recomputes the same numbers in computeActiveErrors + buildSystem at the top of the
 // next solve(), levenberg.cpp:75-88); after a rejected trial the previous system is still in registers.
-template <int kEpt>
+// NT: threads of the workgroup (256, or 512 / 1024 for the latency-bound small batches: fewer edges per thread = a shorter
+// dependent chain per pass; the per-thread edge order and the order of the wave sums are functions of NT, so results of
+// different NT agree to rounding, not bit for bit -- a batch always runs ONE variant).
+template <int kEpt, int NT = 256>
 __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, double *sh, int *s_cnt)
 {
     constexpr int EPT = kEpt > 0 ? kEpt : 1;
@@ -213,7 +224,7 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
     uint8_t Sr[EPT], L1r[EPT], Rbr[EPT], Outr[EPT];
     const int tid = threadIdx.x, n = P.n;
     // edge loop: thread tid owns edges tid, tid + 256, ... (slot j); accessors pick registers or global memory
-#define PO_FOR_EDGES(j, e) for (int j = 0, e = tid; e < n && (!kReg || j < EPT); ++j, e += 256)
+#define PO_FOR_EDGES(j, e) for (int j = 0, e = tid; e < n && (!kReg || j < EPT); ++j, e += NT)
     auto Xp = [&](int j, int e) -> const float * { return kReg ? Xr[j] : P.Xw + 3 * e; };
     auto Op = [&](int j, int e) -> const float * { return kReg ? Or[j] : P.obs + 3 * e; };
     auto Cp = [&](int j, int e) -> double & { return kReg ? Cr[j] : P.err[e]; };
@@ -241,7 +252,7 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
 #pragma unroll
     for (int k = 0; k < 7; ++k) qt[k] = P.pose_in[k];
     if (n < 3) {  // nInitialCorrespondences < 3 (:355-356): the pose stays, mvbOutlier was already reset (:283, :320)
-        for (int e = tid; e < n; e += 256) P.outlier[e] = 0;   // (the register copies above never reach memory here)
+        for (int e = tid; e < n; e += NT) P.outlier[e] = 0;   // (the register copies above never reach memory here)
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) P.pose_out[k] = qt[k];
@@ -354,11 +365,11 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
             }
         }
         PO_T(const long long p1 = __builtin_amdgcn_s_memtime();)
-        block_sum28(acc, sh, fin);
+        block_sum28<NT>(acc, sh, fin);
         PO_T(const long long p2 = __builtin_amdgcn_s_memtime(); t_edges += p1 - p0; t_sum += p2 - p1; ++n_pass;)
     };
     int nBad = 0, cur = 0;
-    double *fin0 = sh + 4 * kPoSum;   // two result buffers of the sums
+    double *fin0 = sh + (NT / 64) * kPoSum;   // two result buffers of the sums
     double xs[6] = {0, 0, 0, 0, 0, 0};   // the solver's x: persists over trials and rounds
     for (int it = 0; it < 4; ++it) {
 #pragma unroll

@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # (0.4 s of timed region: 20 steps = 80 ms left single host hiccups of a few ms visible as +-8 %)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (512 x 0.95 MB of pyramid = 490 MB: beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--frames-per-keyframe", type=int, default=8, help="one LocalBA window per this many frames")
     ap.add_argument("--workload", default="tum", choices=["tum", "euroc8"],
                     help="tum = the BASELINE composite (default); euroc8 = BASELINE configs[4]: 8 EuRoC stereo frames per step "
@@ -513,6 +513,23 @@ def main():
             tf["total_ms"] = sum(tf.values())
             tf["note"] = "single 640x480 frame, 1000 features, 1000 last-frame points, 800 pose correspondences; host buffers in and out"
             extra["tracking_frame_chain_wall_ms"] = tf
+            # ONE sequence, one frame at a time, device-resident (the reference's real calling pattern, Tracking::Track /
+            # Examples/RGB-D/rgbd_tum.cc:91-108): the whole chain of a frame enqueued and waited for, median of 40
+            sc1 = pkg.scenario.tracking_scenario(5, 1, n_unique=1)
+            tc1 = pkg.chain.TrackingChain(sc1, device=local_rank, n_local=N_LOCAL)
+            lat = []
+            for it_ in range(45):
+                torch.cuda.synchronize()
+                ta_ = time.perf_counter()
+                tc1.step()
+                tc1.wait()
+                lat.append(time.perf_counter() - ta_)
+            ms1 = float(np.median(lat[5:])) * 1e3
+            extra["single_sequence"] = {"ms_per_frame": ms1, "frames_per_s": 1e3 / ms1,
+                                        "note": "B = 1, device-resident chain: operator() + Frame::Frame + SearchByProjection(Current, Last) + "
+                                                "PoseOptimization + SearchLocalPoints + PoseOptimization, enqueue + wait per frame (latency-bound: "
+                                                "dependent single-workgroup kernels -- PoseOptimization, the level-0 octree, the greedy resolves)"}
+            del tc1
             pb = [S.synth_proj_mp_problem(700 + i) for i in range(64)]
             m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
             m2.SearchByProjectionBatch([q[0] for q in pb], [q[1] for q in pb], th=3.0)
@@ -681,12 +698,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fast_cells_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_launch": fast_bytes, "kernel_ms": fast_ms,
-                         "note": "integer-VALU bound, not bandwidth bound (see roofline_valu): the kernel keeps the vector ALUs ~95 % busy (VALUBusy = "
-                                 "4 * SQ_ACTIVE_INST_VALU / SIMDs / GRBM_GUI_ACTIVE, profiles/r02_pmc_extract_b512.txt) at the issue rates "
-                                 "measured on this chip (tools/microbench/valu_rate.hip -> profiles/r01_valu_rate.txt: 4 cycles per "
-                                 "wave64 instruction for packed-16 / min / max / compare / dot / perm / mad, 2 for add / sub / logic / "
-                                 "mov / f32); ~710 VALU instructions per 1.2k-pixel cell-wave, so the HBM fraction can only rise by "
-                                 "removing instructions (profiles/README.md has the history: 1040 -> 812 per cell-wave in round 1, -> 712 in round 2)"},
+                         "note": "integer-VALU bound, not bandwidth bound (see roofline_valu): ~710 VALU instructions per 1.2k-pixel cell-wave at "
+                                 "the issue rates measured on this chip (tools/microbench/valu_rate.hip -> profiles/r01_valu_rate.txt: 4 cycles "
+                                 "per wave64 instruction for packed-16 / min / max / compare / dot / perm / mad, 2 for add / sub / logic / mov / "
+                                 "f32), so the HBM fraction can only rise by removing instructions (profiles/README.md has the history: 1040 -> "
+                                 "812 per cell-wave in round 1, -> 712 in round 2; round 3: the tile is staged by LDS-DMA, 0.109 -> 0.123 at "
+                                 "B = 512)"},
             "extra": extra,
         }
         # the other two streaming kernels of the step, from the un-chunked stage times (HIP events of the library)
@@ -706,7 +723,8 @@ def main():
         # counters of the same kernel from the committed rocprofv3 --pmc passes (B = 512 > Infinity Cache; calibrated against
         # 1 GiB copies): NOT measured in this run -- `roofline.traffic` stays null; the profiled figures are given beside it
         try:
-            pc = json.load(open(os.path.join(ROOT, "profiles", "r02_extractor_counters.json")))
+            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
+            pc = json.load(open(cpath))
             fc, cal = pc["fast_cells_kernel"], pc["calibration"]
             per_frame = (fc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + fc["WRITE_SIZE_KB"] * cal["WRITE_SIZE_factor"]) * 1024.0 / pc["batch"]
             out["roofline"]["traffic_profiled"] = {
@@ -714,14 +732,23 @@ def main():
                 "source": pc["source"], "correction": "FETCH_SIZE x %.3f (unaligned 32-bit reads), WRITE_SIZE x 1.0" % cal["FETCH_SIZE_factor_unaligned_32bit"]}
             insts = fc["SQ_INSTS_VALU"] / pc["batch"] * B
             clock_ghz = 2.4   # the engine clock the kernels run at (GRBM_GUI_ACTIVE / 8 / kernel time of the profiled pass gives 2.25-2.4)
-            peak = 1024 * clock_ghz / 4.0   # G wave-instructions / s: 1024 SIMDs, 4 cycles per packed / compare / min / max instruction
+            # issue cost of the kernel's instruction mix: add / sub / logic / mov / right shifts / bitop3 issue in 2 cycles per wave64
+            # instruction, the packed-16 / compare / min / max / mad / perm ones in 4 (profiles/r01_valu_rate.txt); the share of each
+            # class from the kernel's ISA listing (tools/isa_valu_mix.py, a static count)
+            mixp = os.path.join(ROOT, "profiles", "r03_fast_isa_mix.json")
+            mix = json.load(open(mixp)) if os.path.exists(mixp) else {"mean_cycles_per_instruction": 4.0, "two_cycle_share": 0.0}
+            cyc = float(mix["mean_cycles_per_instruction"])
+            peak = 1024 * clock_ghz / cyc   # G wave-instructions / s: 1024 SIMDs
             out["roofline_valu"] = {
                 "bound": "valu_issue", "kernel": "fast_cells_kernel", "achieved": insts / (fast_ms * 1e-3) / 1e9, "peak": peak,
                 "unit": "G wave64-instr/s", "frac": insts / (fast_ms * 1e-3) / 1e9 / peak,
-                "valu_busy_profiled": 4.0 * fc["SQ_ACTIVE_INST_VALU"] / 1024.0 / (fc["GRBM_GUI_ACTIVE"] / 8.0),
+                "mean_issue_cycles_per_instruction": cyc, "two_cycle_instruction_share": mix["two_cycle_share"],
+                "frac_if_every_instruction_cost_4_cycles": insts / (fast_ms * 1e-3) / 1e9 / (1024 * clock_ghz / 4.0),
                 "note": "the binding roof: instructions per launch = SQ_INSTS_VALU per frame of the committed PMC pass x B (a profiled constant of "
-                        "these kernels on frames of this generator), time = this run's HIP events; peak = 1024 SIMDs x %.2f GHz / 4 cycles "
-                        "(profiles/r01_valu_rate.txt)" % clock_ghz}
+                        "these kernels on frames of this generator), time = this run's HIP events; peak = 1024 SIMDs x %.2f GHz / %.2f cycles per "
+                        "instruction of this kernel's mix (static share of 2-cycle instructions %.0f %%; profiles/r01_valu_rate.txt).  "
+                        "SQ_ACTIVE_INST_VALU ticks once per instruction whatever it costs, so a VALUBusy figure derived from it is the "
+                        "4-cycle pricing, not an independent measurement" % (clock_ghz, cyc, 100.0 * mix["two_cycle_share"])}
         except Exception as exc:
             out["roofline"]["traffic_profiled"] = {"error": repr(exc)}
         if world > 1:
