@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend):
+def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend, dist_on):
     """BASELINE configs[4]: EuRoC 752x480 stereo, nfeatures 1200, 8 frames per step sharded over the ranks (strong scaling:
     8 / N frames per rank), every step's slots gathered to rank 0 inside the timed region.  One step of a rank =
     both eyes' ORBextractor::operator() + Frame::ComputeStereoMatches for its frames + pack + gather."""
@@ -76,7 +76,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
         pkg.capi.compute_stereo_matches_device(xl, xr, B, lk.data_ptr(), ld.data_ptr(), ln.data_ptr(), rk.data_ptr(), rd.data_ptr(),
                                                rn.data_ptr(), cap, mb, mbf, ur.data_ptr(), dp.data_ptr())
         xl.pack_slots(B, lk.data_ptr(), ld.data_ptr(), ln.data_ptr(), cap, slot[j].data_ptr(), sb, None)   # the null stream
-        if world > 1:
+        if dist_on:
             if backend == "nccl":
                 work[j] = dist.gather(slot[j], bufs[j], dst=0, async_op=True)
             else:
@@ -90,7 +90,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
         xl.wait()
         xr.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -106,7 +106,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -124,7 +124,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
             bad += parity.stereo_slot_mismatches(pkg, hk[i], hd[i], int(hn[i]), hur[i], hdp[i], pairs[i][0], pairs[i][1], cfg,
                                                  tag=f"rank {rank} frame {lo + i}")
         n_slots = 0
-        if rank == 0 and world > 1:
+        if rank == 0 and dist_on:
             import oracle as O
             got = torch.cat([b_.cpu() for b_ in bufs[(args.steps - 1) % 2]]).numpy()   # [8][slot bytes], rank-major = frame order
             for fr, (k_, d_) in enumerate(pkg.sharding.unpack_slots(got, cap, pkg.capi.KP_DTYPE)):
@@ -133,7 +133,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
                 if len(k_) != len(okl) or k_.tobytes() != okl.tobytes() or not (d_ == odl).all():
                     bad.append(f"gathered slot of frame {fr}: keypoints / descriptors differ from the oracle's")
         okf = torch.tensor([0 if bad else 1, B, n_slots], dtype=torch.int64, device=cdev)
-        if world > 1:
+        if dist_on:
             mn = okf.clone()
             dist.all_reduce(mn, op=dist.ReduceOp.MIN)
             dist.all_reduce(okf, op=dist.ReduceOp.SUM)
@@ -145,7 +145,7 @@ def run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backe
                           "against": "oracle (C restatement; parity unpinned by the reference)", "mismatches_rank0": bad[:10]}
     if rank == 0:
         ok = None
-        if world > 1:
+        if dist_on:
             hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in bufs[(args.steps - 1) % 2]])
             ok = bool(((hdr > 0) & (hdr <= cap)).all())
         print(json.dumps({"parity_checked": parity_checked, 
@@ -211,7 +211,13 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # the exchange step and the collectives run with more than one rank -- or with ONE rank when AOS2_BENCH_FORCE_DIST=1 (a test
+    # hook: the RCCL code path -- process group on the device, gather of device slots on the step's stream, all-reduce, barrier
+    # -- on a box with a single GPU; the line then still reports n_gpus = 1)
+    dist_on = world > 1 or os.environ.get("AOS2_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
@@ -221,8 +227,8 @@ def main():
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     pkg = g.load_package()
     if args.workload == "euroc8":
-        run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend)
-        if world > 1:
+        run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend, dist_on)
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -275,7 +281,7 @@ def main():
     sh = pkg.sharding
     sb = sh.slot_bytes(cap)
     gather = None
-    if world > 1:
+    if dist_on:
         gather = dict(slot=[torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(NPIPE)], work=[None] * NPIPE,
                       ext=[torch.cuda.ExternalStream(pp.cur.stream()) for pp in pipes],
                       bufs=[[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(NPIPE)])
@@ -325,7 +331,7 @@ def main():
                 gather["work"][j] = None
             pipes[j].wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -344,7 +350,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -451,7 +457,7 @@ def main():
 
     n_kp = d_n.cpu().numpy()
     gather_ok = None
-    if world > 1 and rank == 0:   # the slots gathered in the last step carry every rank's keypoint counts
+    if dist_on and rank == 0:   # the slots gathered in the last step carry every rank's keypoint counts
         hdr = torch.stack([b_[:, :4].contiguous().cpu().view(torch.int32).reshape(-1) for b_ in gather["bufs"][(args.steps - 1) % NPIPE]])
         gather_ok = bool(((hdr > 0) & (hdr <= cap)).all())
         assert gather_ok, "gathered slot headers corrupt"
@@ -751,7 +757,7 @@ def main():
                         "4-cycle pricing, not an independent measurement" % (clock_ghz, cyc, 100.0 * mix["two_cycle_share"])}
         except Exception as exc:
             out["roofline"]["traffic_profiled"] = {"error": repr(exc)}
-        if world > 1:
+        if dist_on:
             out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
                                            "timed region, in flight while the next step runs" % (B, sb),
                                "bytes_to_rank0_per_step": (world - 1) * B * sb, "backend": backend, "headers_ok": gather_ok}
@@ -841,7 +847,7 @@ def main():
         if snap is not None and not out["parity_checked"]["ok"]:
             sys.stdout.flush()
             raise SystemExit(3)   # a fast wrong result is not a result
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -88,3 +88,18 @@ def test_bench_refuses_a_rank_count_that_is_not_the_gpu_count(gpu):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("workload", ["tum", "euroc8"])
+def test_bench_rccl_path_on_one_gpu(gpu, workload):
+    """The exchange step over RCCL itself (torch.distributed backend "nccl" = RCCL): a one-rank process group on the box's GPU runs
+    the code the multi-GPU ranks run -- process group bound to the device, the step's slots packed by the device kernel and
+    gathered as DEVICE tensors on the step's own stream, the all-reduce of the timing, the barriers -- and rank 0 checks the
+    gathered slots (AOS2_BENCH_FORCE_DIST is a test hook; with N GPUs the driver's torchrun launch takes the same path)."""
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "16", "--no-extra", "--no-cpu-baseline",
+              "--workload", workload, "--verify"], {"AOS2_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["parity_checked"]["ok"] is True
+    if workload == "tum":
+        assert d["exchange"]["backend"] == "nccl" and d["exchange"]["headers_ok"] is True
+    else:
+        assert d["config"]["backend"] == "nccl" and d["config"]["headers_ok"] is True and d["parity_checked"]["gathered_slots"] == 8
