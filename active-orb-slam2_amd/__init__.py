@@ -3,5 +3,5 @@
 The directory name contains '-', so import it through `__graft_entry__.load_package()` (or
 importlib) under the module name `active_orb_slam2_amd`.
 """
-from . import capi, sharding, synth, scenario, chain  # noqa: F401
+from . import capi, sharding, synth, scenario, chain, datasets  # noqa: F401
 from .capi import (Extractor, Matcher, LocalBA, Frames, ComputeStereoMatches, Vocabulary, LibraryMissing, AosError, device_count, lib_path, host_empty)  # noqa: F401

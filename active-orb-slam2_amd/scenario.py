@@ -100,7 +100,7 @@ def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors,
         Z = scen["Z"][u]
         rows_last, rows_old = [], []
 
-        def add(x_l, y_l, octave, d, obs):
+        def add(x_l, y_l, octave, d, obs, Z=Z):
             Xl = np.array([(x_l - cx) * Z / fx, (y_l - cy) * Z / fy, Z])
             Xw = Rwl @ Xl + twl
             n = Xw - Ow
@@ -112,10 +112,12 @@ def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors,
             return len(pos) - 1
 
         dl = scen["depth_last"][u]
+        real = bool(scen.get("real"))   # real frames: every map point takes the depth the sensor measured at its keypoint
         for i, k in enumerate(last_kps[u]):
             if dl[int(k["y"]), int(k["x"])] <= 0 or rng.random() < 0.08:
                 continue   # no depth -> no map point was created for it; a few more stay NULL
-            mp_last[u, i] = add(float(k["x"]), float(k["y"]), k["octave"], last_desc[u][i], 1 if rng.random() < 0.9 else 0)
+            zk = float(dl[int(k["y"]), int(k["x"])]) if real else Z
+            mp_last[u, i] = add(float(k["x"]), float(k["y"]), k["octave"], last_desc[u][i], 1 if rng.random() < 0.9 else 0, zk)
             rows_last.append(mp_last[u, i])
             if rng.random() < 0.03:
                 outl_last[u, i] = 1   # LastFrame.mvbOutlier
@@ -123,7 +125,12 @@ def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors,
         for i, k in enumerate(old_kps[u]):
             if rng.random() < 0.5:
                 continue
-            rows_old.append(add(float(k["x"]) + ex, float(k["y"]) + ey, k["octave"], old_desc[u][i], 1))
+            zk = Z
+            if real:   # (the "older" view of a real pair is the last frame itself: points the last frame does not hold)
+                if mp_last[u, i] >= 0 or dl[int(k["y"]), int(k["x"])] <= 0:
+                    continue
+                zk = float(dl[int(k["y"]), int(k["x"])])
+            rows_old.append(add(float(k["x"]) + ex, float(k["y"]) + ey, k["octave"], old_desc[u][i], 1, zk))
         junk = []
         for _ in range(60):   # points behind the camera / far outside the image: rejected by isInFrustum
             Xl = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-5, 0.5)])
@@ -138,3 +145,20 @@ def build_map(scen: dict, last_kps, last_desc, old_kps, old_desc, scale_factors,
                  has_obs=np.asarray(has_obs, np.uint8), normal=np.stack(normal).astype(np.float32),
                  min_dist=np.asarray(mind, np.float32), max_dist=np.asarray(maxd, np.float32))
     return dict(table=table, mp_last=mp_last, outlier_last=outl_last, local=local, n_local=n_local)
+
+
+def tracking_scenario_real(pairs: dict, batch: int, cfg: str = "tum"):
+    """The scenario dict of tracking_scenario() from REAL (LastFrame, CurrentFrame) pairs (datasets.tum_pairs): images and
+    depth maps as recorded; the world frame is the last camera's (mTcw of LastFrame = identity) and the motion-model
+    guess for the current frame is "no motion" (consecutive frames of a 30 Hz sequence move by a few pixels: inside the
+    15-pixel window of SearchByProjection(Current, Last)).  The map is still built from the extractor's keypoints by
+    build_map(), every point at the depth the sensor measured there.  Ground-truth poses are not used (Tcw_true = the guess)."""
+    c = synth.CONFIGS[cfg]
+    nu = len(pairs["last"])
+    H, W = pairs["last"].shape[1:]
+    eye = np.tile(np.eye(4, dtype=np.float32), (nu, 1, 1))
+    fx, fy, cx, cy, mbf = (np.float32(c[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
+    return dict(real=True, dist=None, cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch,
+                n_unique=nu, index=np.arange(batch) % nu, last=pairs["last"], cur=pairs["cur"], old=pairs["last"],
+                depth_cur=pairs["depth_cur"], depth_last=pairs["depth_last"], shift=np.zeros((nu, 2), np.int32),
+                shift_old=np.zeros((nu, 2), np.int32), Z=np.ones(nu), Tlw=eye.copy(), Tcw_true=eye.copy(), Tcw_guess=eye.copy())

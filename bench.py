@@ -240,7 +240,13 @@ def main():
     import threading
     from concurrent.futures import ThreadPoolExecutor
     n_unique = min(B, 32)
-    scen = pkg.scenario.tracking_scenario(100 + rank, B, cfg="tum", n_unique=n_unique)
+    real = pkg.datasets.dataset_from_env("tum")   # $TUM_FR1_DESK: the recorded frames instead of the generator's
+    if real:
+        pr = pkg.datasets.tum_pairs(real[1], n_unique, step=7 + rank)
+        scen = pkg.scenario.tracking_scenario_real(pr, B, cfg="tum")
+        scen["dist"] = np.asarray([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)   # Examples/RGB-D/TUM1.yaml
+    else:
+        scen = pkg.scenario.tracking_scenario(100 + rank, B, cfg="tum", n_unique=n_unique)
     base = scen["cur"]
     N_LOCAL = 1500
     NPIPE = max(1, int(os.environ.get("AOS2_BENCH_INFLIGHT", "2")))   # steps in flight (each with its own buffers)
@@ -683,7 +689,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8 (extract, match) + f64 (PoseOptimization, LocalBA)",
-            "data": "synthetic",
+            "data": "real (TUM fr1_desk frames from $TUM_FR1_DESK; LocalBA windows synthetic)" if real else "synthetic",
             "config": {"workload": "TUM 640x480 RGB-D, 1000 features, 8 levels, scale 1.2, FAST 20/7: per frame ORBextractor::operator() + "
                                    "Frame::Frame + SearchByProjection(Current, Last) + PoseOptimization + SearchLocalPoints(%d local map "
                                    "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "

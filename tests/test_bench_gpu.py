@@ -103,3 +103,16 @@ def test_bench_rccl_path_on_one_gpu(gpu, workload):
         assert d["exchange"]["backend"] == "nccl" and d["exchange"]["headers_ok"] is True
     else:
         assert d["config"]["backend"] == "nccl" and d["config"]["headers_ok"] is True and d["parity_checked"]["gathered_slots"] == 8
+
+
+def test_bench_on_a_recorded_sequence(gpu, tmp_path):
+    """$TUM_FR1_DESK set: bench.py reads its frame pairs from the dataset directory, says so in `data`, and the last timed step
+    still equals the oracle"""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import __graft_entry__ as g
+    from test_datasets_cpu import _mini_tum
+    _mini_tum(g.load_package(), tmp_path, n=12)
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "16", "--cpu-frames", "8", "--no-extra"],
+             {"TUM_FR1_DESK": str(tmp_path)})
+    assert d["data"].startswith("real") and d["parity_checked"]["ok"] is True and d["parity_checked"]["frames"] >= 8
+    assert d["config"]["matches_per_frame_mean"]["search_by_projection_last"] > 50

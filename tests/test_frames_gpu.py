@@ -262,3 +262,23 @@ def test_reference_keyframe_bow_leg_vs_oracle(pkg, oracle, gpu):
                 node_off_f=tf["fv_off"], node_idx_f=tf["fv_idx"])
     n, m = pkg.Matcher(0.7, True).SearchByBoW(prob)
     assert n == res[b][0] and (m == res[b][1]).all()
+
+
+def test_chain_on_recorded_pairs_vs_oracle(pkg, oracle, gpu, tmp_path):
+    """the optional real-data path: (LastFrame, CurrentFrame) pairs read from a TUM-format directory (PNG decoding, timestamp
+    association, depth in metres, TUM1.yaml's distortion) go through the same chain and equal the oracle like the generated ones"""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parity
+    from test_datasets_cpu import _mini_tum
+    _mini_tum(pkg, tmp_path, n=5)
+    pr = pkg.datasets.tum_pairs(str(tmp_path), 4)
+    scen = pkg.scenario.tracking_scenario_real(pr, 8)
+    scen["dist"] = np.asarray(TUM1_DIST, np.float32)
+    tc = pkg.chain.TrackingChain(scen, n_local=1200)
+    tc.step()
+    tc.wait()
+    co = parity.ChainOracle(scen, tc)
+    assert parity.chain_mismatches(parity.chain_snapshot(pkg, tc), co, range(8)) == []
+    nm = tc.d_nm.cpu().numpy()
+    assert (nm[0] > 50).all() and (nm[3] > 30).all(), nm
