@@ -191,7 +191,7 @@ class _HostBlock:
         self.p = p.value
 
     def __del__(self):
-        if getattr(self, "p", None):
+        if getattr(self, "p", None) and C is not None:   # (at interpreter shutdown the module globals may already be gone)
             self.L.aos2_host_free(C.c_void_p(self.p))
             self.p = None
 

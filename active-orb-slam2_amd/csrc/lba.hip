@@ -629,32 +629,55 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
 #endif
 }
 
-// J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6
+// J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6.
+// One division per edge: with iz = 1 / z, a = x iz, b = y iz the entries x y / z^2 fx, (1 + x^2 / z^2) fx, y / z fx, ... are
+// products (the reference divides ~13 times per edge here and ~9 more in the landmark Jacobian; an f64 division is ~10
+// dependent instructions on this part).  Same quantities, equal to rounding (1e-16 relative) -- like the pose-only kernel.
 __device__ __forceinline__ void jac_pose(const Cam &cam, const double p[3], int stereo, double Jb[18])
 {
     const double fx = cam.fx, fy = cam.fy, bf = cam.bf;
-    const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
-    Jb[0] = x * y / z_2 * fx;
-    Jb[1] = -(1 + (x * x / z_2)) * fx;
-    Jb[2] = y / z * fx;
-    Jb[3] = -1. / z * fx;
+    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz, ab = a * b;
+    Jb[0] = ab * fx;
+    Jb[1] = -(1 + a * a) * fx;
+    Jb[2] = b * fx;
+    Jb[3] = -(iz * fx);
     Jb[4] = 0;
-    Jb[5] = x / z_2 * fx;
-    Jb[6] = (1 + y * y / z_2) * fy;
-    Jb[7] = -x * y / z_2 * fy;
-    Jb[8] = -x / z * fy;
+    Jb[5] = a * iz * fx;
+    Jb[6] = (1 + b * b) * fy;
+    Jb[7] = -(ab * fy);
+    Jb[8] = -(a * fy);
     Jb[9] = 0;
-    Jb[10] = -1. / z * fy;
-    Jb[11] = y / z_2 * fy;
+    Jb[10] = -(iz * fy);
+    Jb[11] = b * iz * fy;
 #pragma unroll
     for (int i = 12; i < 18; ++i) Jb[i] = 0;
     if (stereo) {
-        Jb[12] = Jb[0] - bf * y / z_2;
-        Jb[13] = Jb[1] + bf * x / z_2;
+        const double bfz2 = bf * (iz * iz);
+        Jb[12] = Jb[0] - bfz2 * p[1];
+        Jb[13] = Jb[1] + bfz2 * p[0];
         Jb[14] = Jb[2];
         Jb[15] = Jb[3];
         Jb[16] = 0;
-        Jb[17] = Jb[5] - bf / z_2;
+        Jb[17] = Jb[5] - bfz2;
+    }
+}
+
+// J_point of an edge (the same linearizeOplus): -1 / z [fx 0 -x / z fx; 0 fy -y / z fy] R for the two pixel rows (mono and
+// stereo edges alike), the stereo row = row 0 - bf / z^2 R_2.  R = the keyframe's rotation (row-major), one division.
+__device__ __forceinline__ void jac_point(const Cam &cam, const double R[9], const double p[3], int stereo, double Ja[9])
+{
+    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz;
+    const double fxz = cam.fx * iz, fyz = cam.fy * iz, afxz = a * fxz, bfyz = b * fyz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Ja[c] = afxz * R[6 + c] - fxz * R[c];
+        Ja[3 + c] = bfyz * R[6 + c] - fyz * R[3 + c];
+        Ja[6 + c] = 0;
+    }
+    if (stereo) {
+        const double bfz2 = cam.bf * (iz * iz);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ja[6 + c] = Ja[c] - bfz2 * R[6 + c];
     }
 }
 
@@ -711,30 +734,11 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
         if (k >= 0 && !W.e_level1[k]) {
             const double *T = W.pose + 7 * (size_t)W.e_pose[k];
             const int stereo = W.e_stereo[k];
-            const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
             double p[3], R[9];
             se3_map(T, Xv, p);
             rot_from_quat(T, R);
-            const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
-            double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (!stereo) {
-                const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-                const double s = -1. / z;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const double a0_ = s * tmp[r * 3], a1_ = s * tmp[r * 3 + 1], a2_ = s * tmp[r * 3 + 2];
-                        Ja[r * 3 + c] = a0_ * R[c] + a1_ * R[3 + c] + a2_ * R[6 + c];
-                    }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
-                    Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
-                    Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
-                }
-            }
+            double Ja[9];
+            jac_point(W.cam, R, p, stereo, Ja);
             double omr[3], wo;
             edge_weights(W, k, p, stereo, omr, wo);
 #pragma unroll
@@ -816,30 +820,11 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             if (a + u >= e1) break;
             if (lv1[u]) continue;
             const int stereo = ste[u];
-            const double fx = W.cam.fx, fy = W.cam.fy, bf = W.cam.bf;
             double p[3], R[9];
             se3_map(T[u], Xv, p);
             rot_from_quat(T[u], R);
-            const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
-            double Ja[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (!stereo) {
-                const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
-                const double s = -1. / z;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const double a0 = s * tmp[r * 3], a1 = s * tmp[r * 3 + 1], a2 = s * tmp[r * 3 + 2];
-                        Ja[r * 3 + c] = a0 * R[c] + a1 * R[3 + c] + a2 * R[6 + c];
-                    }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    Ja[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
-                    Ja[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
-                    Ja[6 + c] = Ja[c] - bf * R[6 + c] / z_2;
-                }
-            }
+            double Ja[9];
+            jac_point(W.cam, R, p, stereo, Ja);
             double omr[3], wo;
             double res[3];
             edge_error(W.cam, p, er[u], stereo, res);
