@@ -2919,9 +2919,10 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
         max_mp = std::max(max_mp, problems[i].n_mp);
         max_nf = std::max(max_nf, frames[i].n_f);
     }
-    if (pool_cap * sizeof(Entry) > ((size_t)1 << 31)) {
-        set_error("batched projection search needs a %zu-entry pool (> 2 GiB)", pool_cap);
-        return AOS2_ERR_ARG;
+    // (entry offsets are 32-bit: 2^31 entries = 16 GiB of the device's 288 GB; what actually limits a call is the allocation)
+    if (pool_cap > ((size_t)1 << 31) - 2) {
+        set_error("batched projection search: %zu candidate entries exceed the pool's index range", pool_cap);
+        return AOS2_ERR_CAPACITY;
     }
     if ((st = matcher_init(m))) return st;
     Arena A{m};
@@ -3023,8 +3024,8 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     const size_t oslots = A.reserve((size_t)(p->n_last + 1) * sizeof(QuerySlot));
     const size_t ochoice = A.reserve((size_t)(p->n_last + 1) * 4);
     const size_t pool_cap = (size_t)p->n_last * (size_t)cur->n_f;
-    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
-        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_last, cur->n_f);
+    if (pool_cap > ((size_t)1 << 31) - 2) {   // (32-bit entry offsets: 16 GiB of the device's 288 GB)
+        set_error("projection search of %d points x %d features exceeds the pool's index range", p->n_last, cur->n_f);
         return AOS2_ERR_ARG;
     }
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
@@ -3330,9 +3331,11 @@ static int projgen_serial(aos2_matcher_t *m, const aos2_frame_view_t *f, const a
     const size_t oslots = A.reserve((size_t)(p->n_pts + 1) * sizeof(QuerySlot));
     const size_t ochoice = A.reserve((size_t)(p->n_pts + 1) * 4);
     const size_t pool_cap = (size_t)p->n_pts * (size_t)f->n_f;
-    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
-        set_error("projection search of %d points x %d features exceeds the 1 GiB entry pool", p->n_pts, f->n_f);
-        return AOS2_ERR_ARG;
+    // one slice of n_f entries per point, so that no window can overflow its slice (entry offsets are 32-bit: 2^31 entries =
+    // 16 GiB of the device's 288 GB; beyond that AOS2_ERR_CAPACITY, below it only the allocation itself can fail)
+    if (pool_cap > ((size_t)1 << 31) - 2) {
+        set_error("projection search of %d points x %d features: %zu candidate entries exceed the pool's index range", p->n_pts, f->n_f, pool_cap);
+        return AOS2_ERR_CAPACITY;
     }
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = A.upload())) return st;
@@ -3402,8 +3405,8 @@ int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_v
     const size_t om = A.reserve(n * 8 + 8), on = A.reserve(8);
     const size_t oslots = A.reserve((n + 1) * sizeof(QuerySlot));
     const size_t pool_cap = n * (size_t)f2->n_f;
-    if (pool_cap * sizeof(Entry) > ((size_t)1 << 30)) {
-        set_error("initialization search of %d x %d features exceeds the 1 GiB entry pool", n1, f2->n_f);
+    if (pool_cap > ((size_t)1 << 31) - 2) {   // (32-bit entry offsets: 16 GiB of the device's 288 GB)
+        set_error("initialization search of %d x %d features exceeds the pool's index range", n1, f2->n_f);
         return AOS2_ERR_ARG;
     }
     if ((st = m->pool.alloc(pool_cap + 1))) return st;

@@ -458,3 +458,17 @@ def test_one_handle_across_growing_and_shrinking_calls(pkg, oracle, gpu):
         n, match = m.SearchByBoW(small)
         on, om = oracle.search_by_bow(small)
         assert n == on and (match == om).all()
+
+
+def test_projection_searches_beyond_a_gibibyte_of_candidates(pkg, oracle, gpu):
+    """SearchByProjection(pKF, Scw, ...) and the relocalisation search give every point a slice of n_f candidate entries: 20 000
+    loop-closure points x 8000 features = 1.3 GB of entries -- rejected with an error until round 3 (a 1 GiB cap written for a
+    smaller device), now limited only by the 32-bit entry offsets (16 GiB) and the allocation: same results as the oracle"""
+    f, p = pkg.synth.synth_proj_gen_problem(91, n_f=8000, n_pts=20000, cfg="kitti", th=10.0)
+    m = pkg.Matcher(0.75, True)
+    n, match = m.SearchByProjectionKF(f, p)
+    on, om = oracle.search_by_projection_kf(f, p)
+    assert n == on and (match == om).all() and n > 500
+    n, match = m.SearchByProjectionReloc(f, p, 100)
+    on, om = oracle.search_by_projection_reloc(f, p, 100, True)
+    assert n == on and (match == om).all() and n > 500
