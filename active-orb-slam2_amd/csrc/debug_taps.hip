@@ -45,4 +45,36 @@ int aos2_debug_sincos_device(const float *angles, int n, float *s, float *c, int
     return AOS2_OK;
 }
 
+// PNG scanline filters undone in place (PNG specification, section 9: None / Sub / Up / Average / Paeth): `rows` = h rows of
+// 1 filter byte + stride data bytes as they come out of zlib; bpp = bytes per complete pixel.  Host code for the optional
+// real-data loaders (active-orb-slam2_amd/datasets.py): the Average / Paeth recurrences run byte by byte along a row.
+int aos2_png_unfilter(uint8_t *rows, int h, int stride, int bpp)
+{
+    if (!rows || h < 0 || stride <= 0 || bpp <= 0) return AOS2_ERR_ARG;
+    const size_t pitch = (size_t)stride + 1;
+    for (int y = 0; y < h; ++y) {
+        uint8_t *cur = rows + (size_t)y * pitch + 1;
+        const uint8_t *up = y ? rows + (size_t)(y - 1) * pitch + 1 : nullptr;
+        const int ft = rows[(size_t)y * pitch];
+        for (int x = 0; x < stride; ++x) {
+            const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int pred = 0;
+            switch (ft) {
+            case 0: break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: {
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                break;
+            }
+            default: return AOS2_ERR_ARG;
+            }
+            cur[x] = (uint8_t)(cur[x] + pred);
+        }
+    }
+    return AOS2_OK;
+}
+
 }  // extern "C"

@@ -47,6 +47,34 @@ def read_png(path: str) -> np.ndarray:
     bpp = ch * depth // 8
     stride = w * bpp
     data = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, stride + 1)
+    out = _unfilter(data, h, stride, bpp)
+    if depth == 16:
+        return out.reshape(h, w, 2).astype(np.uint16)[:, :, 0] * 256 + out.reshape(h, w, 2)[:, :, 1]
+    return out.reshape(h, w) if ch == 1 else out.reshape(h, w, ch)
+
+
+def _native_unfilter():
+    """aos2_png_unfilter of the built library, or None (the loaders then fall back to numpy / Python)"""
+    if os.environ.get("AOS2_PNG_PYTHON") == "1":
+        return None
+    try:
+        import ctypes as C
+        from . import capi
+        fn = capi.lib().aos2_png_unfilter
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        return fn
+    except Exception:   # no library / an older one: the pure-Python path below
+        return None
+
+
+def _unfilter(data: np.ndarray, h: int, stride: int, bpp: int) -> np.ndarray:
+    """the scanline filters undone: by the library's host routine (aos2_png_unfilter) when it is built, else in numpy / Python"""
+    fn = _native_unfilter()
+    if fn is not None:
+        buf = np.ascontiguousarray(data).copy()
+        if fn(buf.ctypes.data, h, stride, bpp) != 0:
+            raise ValueError("unknown PNG filter type")
+        return np.ascontiguousarray(buf[:, 1:])
     out = np.zeros((h, stride), np.uint8)
     prev = np.zeros(stride, np.int32)
     for y in range(h):
@@ -73,9 +101,7 @@ def read_png(path: str) -> np.ndarray:
                     cur[x] = (cur[x] + (a if pa <= pb and pa <= pc else b if pb <= pc else c)) & 255
         out[y] = cur
         prev = cur
-    if depth == 16:
-        return out.reshape(h, w, 2).astype(np.uint16)[:, :, 0] * 256 + out.reshape(h, w, 2)[:, :, 1]
-    return out.reshape(h, w) if ch == 1 else out.reshape(h, w, ch)
+    return out
 
 
 def write_png(path: str, img: np.ndarray):

@@ -749,6 +749,12 @@ int aos2_frames_search_local_points(aos2_frames_t *f, const aos2_map_points_dev_
                                     int n_local, float th, float nnratio, int32_t *d_nmatches);
 
 /* ------------------------------------------------------------------------------------------
+ * Dataset helper (host code; the reference reads its datasets with cv::imread, Examples/RGB-D/rgbd_tum.cc:77-78): the PNG
+ * scanline filters undone in place -- rows = h rows of 1 filter byte + stride data bytes as inflated, bpp = bytes per pixel.
+ * ------------------------------------------------------------------------------------------ */
+int aos2_png_unfilter(uint8_t *rows, int h, int stride, int bpp);
+
+/* ------------------------------------------------------------------------------------------
  * Test taps (no reference equivalent): shared primitives run in isolation.
  * ------------------------------------------------------------------------------------------ */
 /* DistributeOctTree (src/ORBextractor.cc:539-763) on the HOST with the routine the device kernel

@@ -47,8 +47,12 @@ def _png_with_filters(path, img):
                  chunk(b"IDAT", zlib.compress(bytes(rows))[:40]) + chunk(b"IDAT", zlib.compress(bytes(rows))[40:]) + chunk(b"IEND", b""))
 
 
-def test_png_decoder_all_filters(pkg, tmp_path):
+@pytest.mark.parametrize("native", [True, False])
+def test_png_decoder_all_filters(pkg, tmp_path, monkeypatch, native):
     D = pkg.datasets
+    if not native:
+        monkeypatch.setenv("AOS2_PNG_PYTHON", "1")   # the numpy / Python fallback instead of the library's host routine
+    assert (D._native_unfilter() is not None) == native
     rng = np.random.default_rng(0)
     for name, img in (("g8", rng.integers(0, 256, (37, 53), dtype=np.uint8)), ("g16", rng.integers(0, 65536, (21, 30)).astype(np.uint16)),
                       ("rgb", rng.integers(0, 256, (19, 41, 3), dtype=np.uint8))):
