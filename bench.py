@@ -697,6 +697,9 @@ def main():
                                    "edges: SURVEY 8(d))" % (N_LOCAL, fpk, lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
+                       "host_threads": "the GPU path is driven by 1 enqueueing thread + %d LocalMapping-side threads (one per LocalBA handle), each handle "
+                                       "building its windows' index structures on up to %d worker threads, + %d threads for the keyframe BoW leg; "
+                                       "cpu_baseline is ONE core (the reference's threading per stage)" % (NLBA, min(n_win, os.cpu_count() or 1, 32), NPIPE),
                        "independent_frame_pairs": "the B frames of a step are B independent (LastFrame, CurrentFrame) pairs (32 distinct, "
                                                   "tiled); the chain of ONE sequence is sequential in time and is reported as "
                                                   "extra.tracking_frame_chain_wall_ms",
