@@ -154,6 +154,8 @@ def lib():
             L.aos2_frames_wait.argtypes = [vp]
             L.aos2_frames_wait_for_stream.argtypes = [vp, vp]
             L.aos2_frames_device_ptr.argtypes = [vp, ci]
+            L.aos2_frames_search_for_triangulation.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+            L.aos2_frames_fuse.argtypes = [vp, vp, ci, ci, vp, vp, cf, vp, vp]
             L.aos2_frames_device_ptr.restype = vp
             L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
             L.aos2_frames_set_pose.argtypes = [vp, vp]
@@ -1005,6 +1007,11 @@ def frame_image_bounds(w, h, fx, fy, cx, cy, dist):
     return out
 
 
+class _FramesTriang(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32)] + [(k, C.c_void_p) for k in ("kf1", "kf2", "F12", "epipole", "d_node_of1", "d_fv_node1", "d_fv_off1",
+                                                                      "d_fv_idx1", "d_n_fv1", "d_fv_node2", "d_fv_off2", "d_fv_idx2", "d_n_fv2")]
+
+
 class Frames:
     MAP_POINTS, OUTLIER, TCW, U_RIGHT, DEPTH, GRID_OFF, GRID_IDX, KEYS_UN_X, KEYS_UN_Y = range(9)
 
@@ -1072,6 +1079,26 @@ class Frames:
     def device_ptr(self, what):
         """device address (int) of a member array [batch][cap]"""
         return self.L.aos2_frames_device_ptr(self.h, int(what)) or 0
+
+    def SearchForTriangulation(self, other, kf1, kf2, F12, epipole, d_node_of1, fv1, fv2, d_match12, d_nmatches,
+                               only_stereo=False, check_orientation=True):
+        """aos2_frames_search_for_triangulation: pairs (frame kf1[p] of this batch, frame kf2[p] of `other`); kf1 / kf2 int32 [n], F12 float32
+        [n][9], epipole float32 [n][2]: host arrays; d_node_of1 and fv1 / fv2 = (fv_node, fv_off, fv_idx, n_fv): device addresses (ints);
+        results in d_match12 [n][cap], d_nmatches [n]"""
+        kf1, kf2 = np.ascontiguousarray(kf1, np.int32), np.ascontiguousarray(kf2, np.int32)
+        F12, epipole = np.ascontiguousarray(F12, np.float32), np.ascontiguousarray(epipole, np.float32)
+        q = _FramesTriang()
+        q.n_pairs = len(kf1)
+        q.kf1, q.kf2, q.F12, q.epipole = kf1.ctypes.data, kf2.ctypes.data, F12.ctypes.data, epipole.ctypes.data
+        q.d_node_of1 = int(d_node_of1)
+        q.d_fv_node1, q.d_fv_off1, q.d_fv_idx1, q.d_n_fv1 = (int(x) for x in fv1)
+        q.d_fv_node2, q.d_fv_off2, q.d_fv_idx2, q.d_n_fv2 = (int(x) for x in fv2)
+        _check(self.L.aos2_frames_search_for_triangulation(self.h, other.h, C.byref(q), int(only_stereo), int(check_orientation), d_match12, d_nmatches))
+
+    def Fuse(self, table, target, d_rows, n_pts, th, d_best_idx, d_best_dist):
+        """aos2_frames_fuse: target int32 [n] host (frames of this batch), d_rows device [n][n_pts] table rows (-1 = rejected by the loop head)"""
+        target = np.ascontiguousarray(target, np.int32)
+        _check(self.L.aos2_frames_fuse(self.h, C.byref(table), len(target), int(n_pts), target.ctypes.data, d_rows, float(th), d_best_idx, d_best_dist))
 
     def wait_for_stream(self, hip_stream=None):
         """device-side ordering: what is enqueued on the batch from now on runs behind the work on `hip_stream` so far"""

@@ -159,3 +159,85 @@ class ReferenceKeyFrameBoW:
         """[(nmatches, match_f[:N])] of the last run (host copies)"""
         n_f = self.tc.d_n[: self.n].cpu().numpy()
         return [(int(self.nmatches[b]), self.match[b, : n_f[b]].copy()) for b in range(self.n)]
+
+
+class KeyFrameWork:
+    """Harness (tests/, bench.py): the matcher work of a new keyframe in LocalMapping on device-resident keyframes, for the first
+    `n_kf` frames of a TrackingChain's LastFrame batch (keyframe 1 = that frame) and `n_nb` neighbour keyframes each
+    (scenario.keyframe_neighbours):
+
+        CreateNewMapPoints (src/LocalMapping.cc:272):   matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false)
+        SearchInNeighbors  (src/LocalMapping.cc:493):   matcher.Fuse(pKFi, vpMapPointMatches)      -- the search part
+
+    one aos2_frames_search_for_triangulation and one aos2_frames_fuse per step for all n_kf * n_nb pairs.  Keys, descriptors,
+    grids, FeatureVectors and the MapPoint table stay in HBM; the pair list, F12 and the fuse targets are host arrays, the
+    results come back for the host-side map bookkeeping."""
+
+    def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0):
+        t, scen = tc.torch, tc.scen
+        self.tc, self.n_kf, self.n_nb, self.fuse_th = tc, int(n_kf), int(n_nb), float(fuse_th)
+        nu, cap, W, H = scen["n_unique"], tc.cap, tc.W, tc.H
+        self.nb = scenario.keyframe_neighbours(scen, n_nb)
+        NB = nu * n_nb
+        self.voc = capi.Vocabulary(device=tc.device)
+        self.voc.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+        # ---- the neighbour keyframes: extraction, Frame members, pose, map point flags, FeatureVectors
+        self.ex = capi.Extractor(nfeatures=scen["nfeatures"], device=tc.device)
+        self.d_img = t.from_numpy(self.nb["imgs"]).to(tc.dev)
+        z = lambda shape, dt: t.zeros(shape, dtype=dt, device=tc.dev)   # noqa: E731
+        self.n_kps, self.n_desc, self.n_n = z((NB, cap, 7), t.float32), z((NB, cap, 32), t.uint8), z((NB,), t.int32)
+        self.ex.extract_batch_device(self.d_img.data_ptr(), NB, W, H, W, W * H, self.n_kps.data_ptr(), self.n_desc.data_ptr(), cap, self.n_n.data_ptr())
+        self.d_depth = t.from_numpy(np.repeat(scen["Z"].astype(np.float32), n_nb)).to(tc.dev)[:, None, None].expand(NB, H, W).contiguous()
+        self.kfs = capi.Frames(NB, cap, tc.device)
+        self.kfs.build(self.ex, self.n_kps.data_ptr(), self.n_desc.data_ptr(), self.n_n.data_ptr(), W, H, self.d_depth.data_ptr(),
+                       float(scen["fx"]), float(scen["fy"]), float(scen["cx"]), float(scen["cy"]), float(scen["mbf"]))
+        self.d_Tkw = t.from_numpy(np.ascontiguousarray(self.nb["Tkw"].reshape(NB, 16))).to(tc.dev)
+        t.cuda.synchronize()
+        self.kfs.set_pose(self.d_Tkw.data_ptr())
+        rng = np.random.default_rng(66000 + scen["seed"])
+        n_host = self.n_n.cpu().numpy()
+        self.nb_mp = np.full((NB, cap), -1, np.int32)   # 40 % of a neighbour's features hold a map point already (row 0 stands for it)
+        for j in range(NB):
+            self.nb_mp[j, : n_host[j]] = np.where(rng.random(n_host[j]) < 0.4, 0, -1)
+        self.kfs.set_map_points(self.nb_mp, tc.table)
+        fv = lambda n: [z((n, cap), t.int32), z((n, cap), t.float64), z((n,), t.int32), z((n, cap), t.int32), z((n, cap + 1), t.int32),   # noqa: E731
+                        z((n, cap), t.int32), z((n,), t.int32), z((n, cap), t.int32), z((n, cap), t.int32)]
+        self.fv2 = fv(NB)
+        t.cuda.synchronize()
+        self.voc.transform_device(NB, self.n_desc.data_ptr(), self.n_n.data_ptr(), cap, levelsup, *(x.data_ptr() for x in self.fv2))
+        # ---- keyframe 1 side: the LastFrame batch; the node of every feature (the FeatureVector key it is filed under)
+        B = tc.B
+        self.fv1 = fv(B)
+        self.voc.transform_device(B, tc.dl_desc.data_ptr(), tc.dl_n.data_ptr(), cap, levelsup, *(x.data_ptr() for x in self.fv1))
+        # ---- pairs and fuse problems
+        idx = scen["index"]
+        self.kf1 = np.repeat(np.arange(self.n_kf, dtype=np.int32), n_nb)
+        self.kf2 = np.concatenate([idx[b] * n_nb + np.arange(n_nb) for b in range(self.n_kf)]).astype(np.int32)
+        self.F12 = np.ascontiguousarray(self.nb["F12"][self.kf2])
+        self.epipole = np.zeros((len(self.kf1), 2), np.float32)   # (sideways motion: the epipole is at infinity; every neighbour feature is a
+        # stereo one here, so the reference's test `!bStereo1 && !bStereo2` (:739) never reads it)
+        rows = tc.last_mp[self.kf1].copy()                          # vpMapPointMatches of keyframe 1, per (keyframe, neighbour) problem
+        drop = rng.random(rows.shape) < 0.1                         # IsInKeyFrame(pKFi) / isBad(): the loop head's gate (:844-850)
+        rows[drop] = -1
+        self.fuse_rows = rows
+        self.d_rows = t.from_numpy(rows).to(tc.dev)
+        P = len(self.kf1)
+        self.d_match12, self.d_nm = z((P, cap), t.int32), z((P,), t.int32)
+        self.d_best_idx, self.d_best_dist = z((P, cap), t.int32), z((P, cap), t.int32)
+        t.cuda.synchronize()
+        self.last_ms = (0.0, 0.0)
+
+    def run(self):
+        import time
+        tc = self.tc
+        t0 = time.perf_counter()
+        tc.last.SearchForTriangulation(self.kfs, self.kf1, self.kf2, self.F12, self.epipole, self.fv1[8].data_ptr(),
+                                       [self.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [self.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
+                                       self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=False, check_orientation=False)
+        t1 = time.perf_counter()
+        self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
+        t2 = time.perf_counter()
+        self.match12, self.nm = self.d_match12.cpu().numpy(), self.d_nm.cpu().numpy()      # vMatchedIndices for the triangulation loop,
+        self.best_idx, self.best_dist = self.d_best_idx.cpu().numpy(), self.d_best_dist.cpu().numpy()   # best_idx for the fuse bookkeeping
+        self.last_ms = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
+        return self

@@ -91,6 +91,8 @@ struct aos2_frames {
     aos2::DevBuf<uint64_t> pool;     // candidate entries (8 B each)
     aos2::DevBuf<uint8_t> pose_mem;  // PoseOptimization problem arrays
     aos2::PinnedBuf<uint8_t> h_io;   // small page-locked staging (poses, counts)
+    aos2::PinnedBuf<uint8_t> kf_host;   // keyframe work (triangulation pairs, fuse targets): staging ...
+    aos2::DevBuf<uint8_t> kf_dev;       // ... and its device copy
     float dist[5] = {0, 0, 0, 0, 0};   // mDistCoef for the next aos2_frames_build (aos2_frames_set_distortion)
     float last_ms[4] = {};
 };

@@ -72,7 +72,7 @@ def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | N
         Tguess[u] = E @ Tcw[u]
     idx = np.arange(batch) % nu
     # dist: mDistCoef (k1 k2 p1 p2 k3) the frames are declared to have (the images themselves are not warped: a parity scenario)
-    return dict(dist=None if dist is None else np.asarray(dist, np.float32), cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
+    return dict(seed=seed, margin=M, max_shift=max_shift, dist=None if dist is None else np.asarray(dist, np.float32), cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
                 last=last, cur=cur, old=old, depth_cur=depth_cur, depth_last=depth_last, shift=shift, shift_old=shift_old, Z=Z,
                 Tlw=Tlw.astype(np.float32), Tcw_true=Tcw.astype(np.float32), Tcw_guess=Tguess.astype(np.float32))
 
@@ -162,3 +162,45 @@ def tracking_scenario_real(pairs: dict, batch: int, cfg: str = "tum"):
                 n_unique=nu, index=np.arange(batch) % nu, last=pairs["last"], cur=pairs["cur"], old=pairs["last"],
                 depth_cur=pairs["depth_cur"], depth_last=pairs["depth_last"], shift=np.zeros((nu, 2), np.int32),
                 shift_old=np.zeros((nu, 2), np.int32), Z=np.ones(nu), Tlw=eye.copy(), Tcw_true=eye.copy(), Tcw_guess=eye.copy())
+
+
+def keyframe_neighbours(scen: dict, n_nb: int = 20):
+    """Neighbour keyframes for the keyframe work of LocalMapping (CreateNewMapPoints / SearchInNeighbors, src/LocalMapping.cc:
+    207-453, 455-560): `n_nb` more views of every distinct scene of a tracking_scenario(), the camera translated parallel to the
+    image plane like the scenario's other views (the image = the scene's canvas shifted by whole pixels + pixel noise).  Returns
+    images [n_unique * n_nb, H, W], their poses Tkw (float32 4x4) and, per (scene, neighbour), the fundamental matrix F12 between the
+    scene's LastFrame view (keyframe 1) and the neighbour (keyframe 2) as LocalMapping::ComputeF12 forms it (:603-618):
+    R12 = R1w R2w^T, t12 = -R12 t2w + t1w, F12 = K^-T [t12]x R12 K^-1."""
+    if scen.get("real"):
+        raise ValueError("neighbour keyframes are generated from the synthetic scenes' canvases")
+    W, H, M, nu = scen["w"], scen["h"], scen["margin"], scen["n_unique"]
+    fx, fy, cx, cy = (float(scen[k]) for k in ("fx", "fy", "cx", "cy"))
+    rng = np.random.default_rng(55000 + scen["seed"])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    Ki = np.linalg.inv(K)
+    imgs = np.zeros((nu * n_nb, H, W), np.uint8)
+    Tkw = np.zeros((nu * n_nb, 4, 4), np.float32)
+    F12 = np.zeros((nu * n_nb, 9), np.float32)
+    shift = np.zeros((nu * n_nb, 2), np.int32)
+    for u in range(nu):
+        canvas = synth.synth_image(scen["seed"] * 1000 + u, W + 2 * M, H + 2 * M).astype(np.float32)
+        T1w = scen["Tlw"][u].astype(np.float64)
+        Z = float(scen["Z"][u])
+        for k in range(n_nb):
+            while True:
+                dx, dy = (int(v) for v in rng.integers(-scen["max_shift"], scen["max_shift"] + 1, 2))
+                if dx or dy:
+                    break
+            j = u * n_nb + k
+            shift[j] = (dx, dy)
+            imgs[j] = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
+            T21 = np.eye(4)
+            T21[:3, 3] = -np.array([dx * Z / fx, dy * Z / fy, 0.0])
+            T2w = T21 @ T1w
+            Tkw[j] = T2w
+            R1w, t1w, R2w, t2w = T1w[:3, :3], T1w[:3, 3], T2w[:3, :3], T2w[:3, 3]
+            R12 = R1w @ R2w.T
+            t12 = -R12 @ t2w + t1w
+            tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+            F12[j] = (Ki.T @ tx @ R12 @ Ki).astype(np.float32).reshape(9)
+    return dict(n_nb=n_nb, imgs=imgs, Tkw=Tkw, F12=F12, shift=shift)

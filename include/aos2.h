@@ -748,6 +748,40 @@ int aos2_frames_discard_outliers(aos2_frames_t *f);
 int aos2_frames_search_local_points(aos2_frames_t *f, const aos2_map_points_dev_t *mps, const int32_t *d_local,
                                     int n_local, float th, float nnratio, int32_t *d_nmatches);
 
+/* Keyframe work on device-resident batches: a keyframe is a frame of a built batch (KeyFrame::KeyFrame copies exactly these
+ * Frame members, src/KeyFrame.cc:37-62) with its mvpMapPoints set (aos2_frames_set_map_points or the tracking chain) and its
+ * FeatureVector in HBM as aos2_vocabulary_transform_device wrote it.
+ *
+ * int ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  src/ORBmatcher.cc:657-823 for n_pairs
+ * (frame kf1[p] of `a`, frame kf2[p] of `b`) pairs -- LocalMapping::CreateNewMapPoints calls it once per neighbour keyframe
+ * (src/LocalMapping.cc:272).  F12 (LocalMapping::ComputeF12) and the epipole (:663-670) are the caller's cv::Mat lines: host
+ * arrays.  d_node_of1 = the node id of every feature of `a`'s frames at the FeatureVector level (aos2_vocabulary_transform_device's
+ * d_node_of), d_fv_*1 / d_fv_*2 = the FeatureVectors of `a`'s / `b`'s frames (a feature whose word has weight 0 is in no
+ * FeatureVector -- DBoW2 transform -- and the loop over KF1's FeatureVector never reaches it); all [batch][cap] device arrays
+ * of the respective batch ([batch][cap + 1] for the offsets).
+ * d_match12: DEVICE [n_pairs][cap of a] = vMatches12 (KF2 feature index or -1; vMatchedPairs = its non-negative entries in
+ * ascending i), d_nmatches: DEVICE [n_pairs].  Returns when the results are complete. */
+typedef struct {
+    int32_t n_pairs;
+    const int32_t *kf1, *kf2;      /* host [n_pairs] */
+    const float *F12;              /* host [n_pairs][9], row-major */
+    const float *epipole;          /* host [n_pairs][2]: ex, ey */
+    const uint32_t *d_node_of1;
+    const int32_t *d_fv_node1, *d_fv_off1, *d_fv_idx1, *d_n_fv1;
+    const int32_t *d_fv_node2, *d_fv_off2, *d_fv_idx2, *d_n_fv2;
+} aos2_frames_triang_t;
+int aos2_frames_search_for_triangulation(aos2_frames_t *a, aos2_frames_t *b, const aos2_frames_triang_t *q,
+                                         int only_stereo, int check_orientation, int32_t *d_match12,
+                                         int32_t *d_nmatches);
+/* The search part of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th)  src/ORBmatcher.cc:825-975
+ * for n_problems (target keyframe = frame target[p] of `kfs`, candidates = d_rows[p][0..n_pts): rows of the table, -1 where the
+ * loop head rejects the point: NULL, isBad() or IsInKeyFrame(pKF) -- map state the caller evaluates) -- LocalMapping::
+ * SearchInNeighbors calls it once per neighbour (src/LocalMapping.cc:493).  d_best_idx / d_best_dist: DEVICE [n_problems][n_pts]
+ * as aos2_matcher_fuse returns them; the Replace / AddObservation bookkeeping of :948-969 consumes them on the host. */
+int aos2_frames_fuse(aos2_frames_t *kfs, const aos2_map_points_dev_t *mps, int n_problems, int n_pts,
+                     const int32_t *target, const int32_t *d_rows, float th, int32_t *d_best_idx,
+                     int32_t *d_best_dist);
+
 /* ------------------------------------------------------------------------------------------
  * Dataset helper (host code; the reference reads its datasets with cv::imread, Examples/RGB-D/rgbd_tum.cc:77-78): the PNG
  * scanline filters undone in place -- rows = h rows of 1 filter byte + stride data bytes as inflated, bpp = bytes per pixel.

@@ -161,6 +161,8 @@ class Extractor:
         desc = np.zeros((cap, 32), dtype=np.uint8)
         n = C.c_int(0)
         st = self.L.orc_extractor_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap, C.byref(n))
+        if st == -2 and n.value > cap:   # DistributeOctTree returned more than fits (wide images: up to 4 * round(W / H) extra per level): once more with room
+            return self.extract(img, cap=n.value)
         if st != 0:
             raise RuntimeError(f"oracle extract failed: {st}")
         return kps[: n.value].copy(), desc[: n.value].copy()

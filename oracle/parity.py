@@ -178,3 +178,73 @@ def bow_leg_mismatches(results, co: ChainOracle, voc: dict, positions, nnratio=0
         if gn != n or len(gm) != len(m) or not (np.asarray(gm) == m).all():
             bad.append(f"frame {b} (pair {u}): SearchByBoW {gn} matches, oracle {n}" + ("" if len(gm) != len(m) else f", {int((np.asarray(gm) != m).sum())} entries differ"))
     return bad
+
+
+def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, timing=None):
+    """chain.KeyFrameWork's results (SearchForTriangulation + the search part of Fuse for (keyframe, neighbour) pairs,
+    src/LocalMapping.cc:272, 493) for the pair indices given, against the oracle on its own extraction of the same images:
+    vMatches12 / counts and Fuse's best_idx / best_dist bit-identical.  kw = None: only run (and time) the oracle side."""
+    import time
+    tc, scen = co.tc, co.scen
+    if not hasattr(co, "_ov"):
+        co._ov = O.Vocabulary()
+        co._ov.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
+        co._kf_bow = {}
+    if not hasattr(co, "_nb"):
+        co._nb, co._kf1 = {}, {}
+    sf, isg = co.oe.scale_factors, co.oe.inv_sigma2
+    table = tc.map["table"]
+    bad = []
+    src = kw if kw is not None else co._kw_inputs
+    for p in pairs:
+        b, j = int(src.kf1[p]), int(src.kf2[p])
+        u = int(scen["index"][b])
+        if u not in co._kf1:   # keyframe 1 = the scene's LastFrame view
+            lk, ld = tc.host_last[u]
+            f1 = ochain.frame_from_extraction(lk, ld, scen["depth_last"][u], scen, sf, isg)
+            co._kf1[u] = (lk, ld, f1, co._ov.transform(ld, levelsup))
+        if j not in co._nb:    # the neighbour keyframe: the oracle's own extraction + Frame members + BoW
+            okps, odesc = co.oe.extract(src.nb["imgs"][j])
+            depth = np.full((scen["h"], scen["w"]), np.float32(scen["Z"][j // src.n_nb]), np.float32)
+            f2 = ochain.frame_from_extraction(okps, odesc, depth, scen, sf, isg)
+            co._nb[j] = (okps, odesc, f2, co._ov.transform(odesc, levelsup))
+        lk, ld, f1, b1 = co._kf1[u]
+        okps, odesc, f2, b2 = co._nb[j]
+        n1, n2 = len(lk), len(okps)
+        t0 = time.perf_counter()
+        prob = dict(desc1=ld, desc2=odesc, has_mp1=(tc.last_mp[b, :n1] >= 0).astype(np.uint8), has_mp2=(src.nb_mp[j, :n2] >= 0).astype(np.uint8),
+                    x1=f1["kp_x"], y1=f1["kp_y"], angle1=np.ascontiguousarray(lk["angle"], np.float32), u_right1=f1["u_right"],
+                    x2=f2["kp_x"], y2=f2["kp_y"], angle2=np.ascontiguousarray(okps["angle"], np.float32), u_right2=f2["u_right"],
+                    octave2=np.ascontiguousarray(okps["octave"], np.int32), scale_factors2=np.ascontiguousarray(sf, np.float32),
+                    level_sigma2_2=(np.asarray(sf, np.float32) * np.asarray(sf, np.float32)).astype(np.float32), F12=src.F12[p],
+                    ex=np.float32(src.epipole[p, 0]), ey=np.float32(src.epipole[p, 1]), only_stereo=0, check_orientation=0,
+                    node_id1=b1["fv_node"], node_off1=b1["fv_off"], node_idx1=b1["fv_idx"], node_id2=b2["fv_node"], node_off2=b2["fv_off"],
+                    node_idx2=b2["fv_idx"])
+        n, m = O.search_for_triangulation(prob)
+        t1 = time.perf_counter()
+        # Fuse(pKFi = the neighbour, vpMapPointMatches of keyframe 1): the candidates are table rows
+        rows = src.fuse_rows[p]
+        T = src.nb["Tkw"][j].astype(np.float32)
+        R, t = np.ascontiguousarray(T[:3, :3]), np.ascontiguousarray(T[:3, 3])
+        Rd, td = R.astype(np.float64), t.astype(np.float64)
+        Ow = np.array([-((Rd[0, k] * td[0] + Rd[1, k] * td[1]) + Rd[2, k] * td[2]) for k in range(3)]).astype(np.float32)
+        rr = np.where(rows >= 0, rows, 0)
+        pts = dict(n_pts=len(rows), valid=(rows >= 0).astype(np.uint8), pos=table["pos"][rr], max_dist=table["max_dist"][rr],
+                   min_dist=table["min_dist"][rr], normal=table["normal"][rr], desc=table["desc"][rr], q_angle=np.zeros(len(rows), np.float32),
+                   R=R.reshape(9), t=t, Ow=Ow, R2=np.zeros(9, np.float32), t2=np.zeros(3, np.float32), fx=np.float32(scen["fx"]),
+                   fy=np.float32(scen["fy"]), cx=np.float32(scen["cx"]), cy=np.float32(scen["cy"]), bf=np.float32(scen["mbf"]),
+                   log_scale_factor=np.float32(np.log(np.float64(f2["scale_factors"][1]))), inv_level_sigma2=f2["inv_sigma2"],
+                   th=np.float32(src.fuse_th))
+        nf, bi, bd = O.fuse(f2, pts, sim3=False)
+        t2 = time.perf_counter()
+        if timing is not None:
+            timing["search_for_triangulation"] = timing.get("search_for_triangulation", 0.0) + t1 - t0
+            timing["fuse"] = timing.get("fuse", 0.0) + t2 - t1
+        if kw is None:
+            continue
+        tag = f"keyframe {b} / neighbour {j}"
+        if int(kw.nm[p]) != n or not (kw.match12[p, :n1] == m).all() or not (kw.match12[p, n1:] == -1).all():
+            bad.append(f"{tag}: SearchForTriangulation {int(kw.nm[p])} matches, oracle {n}; {int((kw.match12[p, :n1] != m).sum())} entries differ")
+        if not (kw.best_idx[p] == bi).all() or not (kw.best_dist[p] == bd).all():
+            bad.append(f"{tag}: Fuse best_idx differs in {int((kw.best_idx[p] != bi).sum())} of {int((rows >= 0).sum())} candidates (oracle fuses {nf})")
+    return bad

@@ -349,3 +349,16 @@ def test_async_flight_with_mixed_batch_sizes(pkg, gpu):
             ka, kb, da, db = a[0].cpu().numpy(), b_[0].cpu().numpy(), a[1].cpu().numpy(), b_[1].cpu().numpy()
             for b in range(B):
                 assert (ka[b, : n[b]] == kb[b, : n[b]]).all() and (da[b, : n[b]] == db[b, : n[b]]).all()
+
+
+def test_very_wide_image_exceeds_twice_the_feature_budget(pkg, oracle, gpu):
+    """1171 x 131 at 100 features / 5 levels: DistributeOctTree starts from round(W / H) = 11 root nodes per level and returns 268
+    keypoints -- more than 2 * nfeatures + 64 (found by the long fuzz sweep of round 3: the ORACLE's binding had that capacity;
+    the library sizes by aos2_extractor_max_keypoints_for).  Bit-identical all the same."""
+    img = pkg.synth.synth_image(1000 + 1996, 1171, 131)
+    kw = dict(nfeatures=100, scale_factor=1.2, nlevels=5, ini_th=20, min_th=5)
+    ex = pkg.Extractor(**kw)
+    k, d = ex(img)
+    ok, od = oracle.Extractor(**kw).extract(img)
+    assert len(k) == len(ok) == 268 and k.tobytes() == ok.tobytes() and (d == od).all()
+    assert ex.max_keypoints_for(1171, 131) >= 268

@@ -282,3 +282,27 @@ def test_chain_on_recorded_pairs_vs_oracle(pkg, oracle, gpu, tmp_path):
     assert parity.chain_mismatches(parity.chain_snapshot(pkg, tc), co, range(8)) == []
     nm = tc.d_nm.cpu().numpy()
     assert (nm[0] > 50).all() and (nm[3] > 30).all(), nm
+
+
+def test_keyframe_work_vs_oracle(pkg, oracle, gpu):
+    """LocalMapping's matcher work for a new keyframe on device-resident keyframes (src/LocalMapping.cc:272, 493):
+    SearchForTriangulation(keyframe, neighbour, F12, ...) and the search part of Fuse(neighbour, the keyframe's map points) for every
+    (keyframe, neighbour) pair in one call each -- vMatches12, counts, best_idx / best_dist equal the oracle's on its own extraction
+    of the same images; matches exist (the neighbours see the same scene)."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    scen = pkg.scenario.tracking_scenario(31, 6, n_unique=3)
+    tc = pkg.chain.TrackingChain(scen, n_local=800)
+    voc = pkg.synth.synth_vocabulary(402, 10, 4)
+    kw = pkg.chain.KeyFrameWork(tc, voc, n_kf=5, n_nb=4)
+    co = parity.ChainOracle(scen, tc)
+    for _ in range(2):
+        kw.run()
+        assert parity.keyframe_work_mismatches(kw, co, voc, range(len(kw.kf1))) == []
+    assert (kw.nm > 20).all(), kw.nm
+    assert ((kw.best_idx >= 0).sum(1) > 50).all()
+    # pairs that name keyframes outside the batches are rejected before anything runs
+    with pytest.raises(pkg.AosError):
+        tc.last.SearchForTriangulation(kw.kfs, [0], [10 ** 6], kw.F12[:1], kw.epipole[:1], kw.fv1[8].data_ptr(),
+                                       [kw.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [kw.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
+                                       kw.d_match12.data_ptr(), kw.d_nm.data_ptr())
