@@ -224,6 +224,9 @@ class KeyFrameWork:
         P = len(self.kf1)
         self.d_match12, self.d_nm = z((P, cap), t.int32), z((P,), t.int32)
         self.d_best_idx, self.d_best_dist = z((P, cap), t.int32), z((P, cap), t.int32)
+        # the results of a step land in pinned host memory (one copy per array; LocalMapping's bookkeeping reads them there)
+        self.h_out = [t.empty((P, cap), dtype=t.int32).pin_memory() for _ in range(3)] + [t.empty((P,), dtype=t.int32).pin_memory()]
+        self.copy_stream = t.cuda.Stream(device=tc.dev)
         t.cuda.synchronize()
         self.last_ms = (0.0, 0.0)
 
@@ -237,7 +240,18 @@ class KeyFrameWork:
         t1 = time.perf_counter()
         self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
         t2 = time.perf_counter()
-        self.match12, self.nm = self.d_match12.cpu().numpy(), self.d_nm.cpu().numpy()      # vMatchedIndices for the triangulation loop,
-        self.best_idx, self.best_dist = self.d_best_idx.cpu().numpy(), self.d_best_dist.cpu().numpy()   # best_idx for the fuse bookkeeping
+        # (both calls return with their results complete; the copies run on a stream of this object)
+        with tc.torch.cuda.stream(self.copy_stream):
+            for h, d in zip(self.h_out, (self.d_match12, self.d_best_idx, self.d_best_dist, self.d_nm)):
+                h.copy_(d, non_blocking=True)
+        self.copy_stream.synchronize()
+        self.match12, self.best_idx, self.best_dist, self.nm = (h.numpy() for h in self.h_out)   # vMatchedIndices / Fuse's best_idx: host views
         self.last_ms = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
         return self
+
+    def snapshot(self):
+        """the inputs (by reference) and the last results (copies), for oracle/parity.py"""
+        import types
+        return types.SimpleNamespace(kf1=self.kf1, kf2=self.kf2, nb=self.nb, nb_mp=self.nb_mp, F12=self.F12, epipole=self.epipole,
+                                     fuse_rows=self.fuse_rows, n_nb=self.n_nb, fuse_th=self.fuse_th, match12=self.match12.copy(),
+                                     nm=self.nm.copy(), best_idx=self.best_idx.copy(), best_dist=self.best_dist.copy())

@@ -12,7 +12,9 @@ step      = one pass of the whole per-frame hot path over one batch of B synthet
               Tracking::SearchLocalPoints: isInFrustum + ORBmatcher::SearchByProjection(Frame, local map points)   (match)
               Optimizer::PoseOptimization
             plus, for every `--frames-per-keyframe` (default 8) frames, the keyframe work: Frame::ComputeBoW (ORBVocabulary::transform)
-            + ORBmatcher::SearchByBoW(reference keyframe, frame) (Tracking::TrackReferenceKeyFrame's front part, device-resident)
+            + ORBmatcher::SearchByBoW(reference keyframe, frame) (Tracking::TrackReferenceKeyFrame's front part, device-resident),
+            LocalMapping's matcher calls for it -- ORBmatcher::SearchForTriangulation against its 10 neighbour keyframes
+            (CreateNewMapPoints) and the search of ORBmatcher::Fuse into each of them (SearchInNeighbors), device-resident --
             and one Optimizer::LocalBundleAdjustment window of the
             SURVEY section 8(d) size (20 local + 30 fixed keyframes, ~24 k stereo edges), solved by
             aos2_lba_solve_batch concurrently with the tracking chain like the reference's LocalMapping thread
@@ -268,8 +270,21 @@ def main():
     NO_BOW = os.environ.get("AOS2_BENCH_NO_BOW") == "1"   # diagnostics only
     voc_nodes = None if NO_BOW else pkg.synth.synth_vocabulary(400, 10, int(os.environ.get("AOS2_BENCH_VOC_LEVELS", "6")))
     bows = [] if NO_BOW else [pkg.chain.ReferenceKeyFrameBoW(pp, voc_nodes, n_bow) for pp in pipes]
+    # ---- and LocalMapping's matcher work for that keyframe (chain.KeyFrameWork, device-resident keyframes): SearchForTriangulation
+    # against its nn = 10 best covisible keyframes (CreateNewMapPoints, src/LocalMapping.cc:214-272) and the search part of Fuse of
+    # its map points into each of them (SearchInNeighbors, :461-493); on the same side thread as the BoW leg
+    # (the neighbour views come from the generator's scenes: with recorded frames the leg is left out and the line says so)
+    NO_KFW = NO_BOW or bool(real) or os.environ.get("AOS2_BENCH_NO_KEYFRAME_WORK") == "1"
+    N_NB = 10
+    kfws = [] if NO_KFW else [pkg.chain.KeyFrameWork(pp, voc_nodes, n_bow, n_nb=N_NB) for pp in pipes]
     bow_pool = ThreadPoolExecutor(NPIPE)
     bow_jobs = [None] * NPIPE
+
+    def keyframe_job(j):
+        if bows:
+            bows[j].run()
+        if kfws:
+            kfws[j].run()
     d_img, d_kps, d_desc, d_n = pipes[0].d_cur, pipes[0].d_kps, pipes[0].d_desc, pipes[0].d_n
     # ---- LocalBA windows of the step: one per frames_per_keyframe frames, 4 distinct problems tiled
     n_win = max(1, B // fpk)
@@ -317,7 +332,8 @@ def main():
         p.step()
         if bows:
             bows[j].order()   # the transform's stream waits for this step's extraction (device side)
-            bow_jobs[j] = bow_pool.submit(bows[j].run)
+        if bows or kfws:
+            bow_jobs[j] = bow_pool.submit(keyframe_job, j)
         if gather is not None:
             gather_step(j)
         if not NO_LBA:
@@ -370,21 +386,28 @@ def main():
         lp, ll = pipes[(args.steps - 1) % NPIPE], lba_prep[(args.steps - 1) % NLBA]
         lb = bows[(args.steps - 1) % NPIPE] if bows else None
         snap = dict(chain=parity.chain_snapshot(pkg, lp), pipe=lp, bow=None if lb is None else lb.get_results(),
+                    kfw=kfws[(args.steps - 1) % NPIPE].snapshot() if kfws else None,
                     lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win)])
-    # ---- the same steps without the reference-keyframe BoW leg: the composite as round 2 measured it (comparability only)
-    dt_nobow = None
+    # ---- the same steps without the keyframe legs: the composite as round 2 measured it, and with the BoW leg only (comparability)
+    dt_nobow = dt_bowonly = None
     if bows and os.environ.get("AOS2_BENCH_SKIP_R02_FORM") != "1":
-        saved, n2 = list(bows), max(10, min(args.steps, 50))
+        def short_run(n2):
+            for i in range(2):
+                step(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(n2):
+                step(i)
+            sync()
+            return (time.perf_counter() - t0) / n2
+        saved, saved_kfw, n2 = list(bows), list(kfws), max(10, min(args.steps, 50))
+        if kfws:
+            kfws.clear()
+            dt_bowonly = short_run(n2)
         bows.clear()
-        for i in range(2):
-            step(i)
-        sync()
-        t0 = time.perf_counter()
-        for i in range(n2):
-            step(i)
-        sync()
-        dt_nobow = (time.perf_counter() - t0) / n2
+        dt_nobow = short_run(n2)
         bows.extend(saved)
+        kfws.extend(saved_kfw)
     nm_host = pipes[0].d_nm.cpu().numpy()
     lba_res = lba_prep[0]["R"]
     # ---- stage times of one synchronous pass (every stage waited for: wall clock incl. launch latency)
@@ -419,6 +442,10 @@ def main():
             bows[0].run()
         composite_stage["reference_keyframe_bow_wall"] = timed(_bow)
         composite_stage["reference_keyframe_bow_device"] = {"transform": bows[0].last_ms[0], "search_by_bow": bows[0].last_ms[1], "frames": n_bow}
+    if kfws:
+        composite_stage["keyframe_work_wall"] = timed(kfws[0].run)
+        composite_stage["keyframe_work_calls"] = {"search_for_triangulation": kfws[0].last_ms[0], "fuse": kfws[0].last_ms[1],
+                                                  "pairs": len(kfws[0].kf1), "keyframes": n_bow, "neighbours": N_NB}
     composite_stage["local_ba_batch_wall"] = timed(lambda: lbas[0].solve_prepared(lba_prep[0]))
     composite_stage["local_ba_batch_device"] = float(lba_prep[0]["R"][0].ms_device)
     composite_stage["note"] = ("one synchronous pass, every stage waited for (wall clock incl. launch latency); the timed steps enqueue "
@@ -470,8 +497,12 @@ def main():
 
     # secondary measurements of the other hot-path rows (reported, not part of `value`)
     extra = {"composite_without_reference_keyframe_bow": None if dt_nobow is None else {
-                 "note": "the timed steps without the per-keyframe ComputeBoW + SearchByBoW leg = the composite of round 2's bench line",
+                 "note": "the timed steps without the per-keyframe legs (ComputeBoW + SearchByBoW, SearchForTriangulation + Fuse) = the "
+                         "composite of round 2's bench line",
                  "frames_per_s": world * B / dt_nobow, "ms_per_step": dt_nobow * 1e3},
+             "composite_with_the_bow_leg_only": None if dt_bowonly is None else {
+                 "note": "the timed steps with ComputeBoW + SearchByBoW per keyframe but without SearchForTriangulation + Fuse",
+                 "frames_per_s": world * B / dt_bowonly, "ms_per_step": dt_bowonly * 1e3},
              "extract_only": {
         "note": "BASELINE configs[1]: ORBextractor::operator() alone over the same frames (round 1's headline)",
         "frames_per_s_async": world * B * args.steps / dt_extract, "ms_per_step_async": dt_extract / args.steps * 1e3,
@@ -693,12 +724,14 @@ def main():
             "config": {"workload": "TUM 640x480 RGB-D, 1000 features, 8 levels, scale 1.2, FAST 20/7: per frame ORBextractor::operator() + "
                                    "Frame::Frame + SearchByProjection(Current, Last) + PoseOptimization + SearchLocalPoints(%d local map "
                                    "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "
-                                   "SearchByBoW(reference keyframe, frame) and one LocalBundleAdjustment window (%d keyframes, %d points, %d "
-                                   "edges: SURVEY 8(d))" % (N_LOCAL, fpk, lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
+                                   "SearchByBoW(reference keyframe, frame), %s"
+                                   "and one LocalBundleAdjustment window (%d keyframes, %d points, %d "
+                                   "edges: SURVEY 8(d))" % (N_LOCAL, fpk, ("SearchForTriangulation + Fuse (search) against %d neighbour keyframes " % N_NB) if kfws else "",
+                                                            lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "host_threads": "the GPU path is driven by 1 enqueueing thread + %d LocalMapping-side threads (one per LocalBA handle), each handle "
-                                       "building its windows' index structures on up to %d worker threads, + %d threads for the keyframe BoW leg; "
+                                       "building its windows' index structures on up to %d worker threads, + %d threads for the keyframe legs (BoW, triangulation / fuse searches); "
                                        "cpu_baseline is ONE core (the reference's threading per stage)" % (NLBA, min(n_win, os.cpu_count() or 1, 32), NPIPE),
                        "independent_frame_pairs": "the B frames of a step are B independent (LastFrame, CurrentFrame) pairs (32 distinct, "
                                                   "tiled); the chain of ONE sequence is sequential in time and is reported as "
@@ -790,14 +823,18 @@ def main():
                 if (i + 1) % fpk == 0:
                     if voc_nodes is not None:   # the keyframe's Frame::ComputeBoW + SearchByBoW(reference keyframe, frame)
                         parity.bow_leg_mismatches(None, co, voc_nodes, [i % n_unique], timing=tm)
+                    if kfws:   # LocalMapping's SearchForTriangulation + Fuse of that keyframe against its neighbours
+                        co._kw_inputs = kfws[0]
+                        kb = (i // fpk) % n_bow
+                        parity.keyframe_work_mismatches(None, co, voc_nodes, range(kb * N_NB, (kb + 1) * N_NB), timing=tm)
                     ta = time.perf_counter()
                     k = (i // fpk) % len(lba_unique)
                     lba_want[k] = O.lba_solve(lba_unique[k])
                     tm["local_ba"] = tm.get("local_ba", 0.0) + time.perf_counter() - ta
                 done += 1
-                if time.perf_counter() - tc > 30.0 and done % fpk == 0:
+                if time.perf_counter() - tc - tm.get("_setup", 0.0) > 30.0 and done % fpk == 0:
                     break
-            tc = time.perf_counter() - tc
+            tc = time.perf_counter() - tc - tm.pop("_setup", 0.0)   # (the neighbour keyframes' own extraction is not work of the step)
             out["cpu_baseline"] = {"value": done / tc, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{done} of the same frame pairs + {done // fpk} of the same LocalBA windows through the oracle "
                                              f"(C restatement -O3 + numpy glue, 1 thread); host has {os.cpu_count()} cores",
@@ -839,16 +876,25 @@ def main():
                 bpos = [b for b in range(n_bow) if int(scen["index"][b]) in co.cache]
                 bad += parity.bow_leg_mismatches(snap["bow"], co, voc_nodes, bpos)
                 n_bow_checked = len(bpos)
+            n_kfw_checked = 0
+            if snap["kfw"] is not None:   # every pair whose neighbour the oracle has extracted already + the first 2 keyframes' pairs
+                kq = snap["kfw"]
+                have = getattr(co, "_nb", {})
+                kp_ = [q for q in range(len(kq.kf1)) if int(kq.kf2[q]) in have or q < 2 * N_NB]
+                bad += parity.keyframe_work_mismatches(kq, co, voc_nodes, kp_)
+                n_kfw_checked = len(kp_)
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
             for w in wins:
                 bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")
             out["parity_checked"] = {
                 "ok": not bad, "step": "the last timed step (results copied right after the timed region)",
-                "frames": len(pos), "distinct_frame_pairs": len(co.cache), "reference_keyframe_bow_frames": n_bow_checked, "local_ba_windows": len(wins),
+                "frames": len(pos), "distinct_frame_pairs": len(co.cache), "reference_keyframe_bow_frames": n_bow_checked,
+                "keyframe_neighbour_pairs": n_kfw_checked, "local_ba_windows": len(wins),
                 "distinct_local_ba_problems": len(set(w % len(lba_unique) for w in wins)),
                 "checked": "per frame: keypoints, descriptors, mvuRight / mvDepth, match counts of both searches, inlier counts of both "
                            "PoseOptimizations, mvpMapPoints, mvbOutlier (bit-identical), mTcw (1e-5); per keyframe frame: the SearchByBoW match "
-                           "array and count behind ComputeBoW (bit-identical); per window: iteration and trial "
+                           "array and count behind ComputeBoW (bit-identical); per (keyframe, neighbour) pair: vMatches12 and count of "
+                           "SearchForTriangulation, best index / distance of Fuse's search (bit-identical); per window: iteration and trial "
                            "counts, outlier sets (identical), poses and points (1e-5), final chi2 (1e-6 relative)",
                 "against": "oracle (C restatement; parity unpinned by the reference: DESIGN.md section 3)",
                 "mismatches": bad[:10], "n_mismatches": len(bad)}

@@ -199,6 +199,7 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, 
     for p in pairs:
         b, j = int(src.kf1[p]), int(src.kf2[p])
         u = int(scen["index"][b])
+        ts = time.perf_counter()
         if u not in co._kf1:   # keyframe 1 = the scene's LastFrame view
             lk, ld = tc.host_last[u]
             f1 = ochain.frame_from_extraction(lk, ld, scen["depth_last"][u], scen, sf, isg)
@@ -208,6 +209,8 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, 
             depth = np.full((scen["h"], scen["w"]), np.float32(scen["Z"][j // src.n_nb]), np.float32)
             f2 = ochain.frame_from_extraction(okps, odesc, depth, scen, sf, isg)
             co._nb[j] = (okps, odesc, f2, co._ov.transform(odesc, levelsup))
+        if timing is not None:   # (the keyframes exist before the step: their extraction is not part of it)
+            timing["_setup"] = timing.get("_setup", 0.0) + time.perf_counter() - ts
         lk, ld, f1, b1 = co._kf1[u]
         okps, odesc, f2, b2 = co._nb[j]
         n1, n2 = len(lk), len(okps)

@@ -44,6 +44,9 @@ def test_bench_contract_single_gpu(gpu):
     pc = d["parity_checked"]
     assert pc["ok"] is True and pc["n_mismatches"] == 0 and pc["frames"] >= 8 and pc["distinct_frame_pairs"] >= 8
     assert pc["local_ba_windows"] >= 2 and pc["distinct_local_ba_problems"] >= 2
+    # ... and the keyframe legs: the BoW searches and LocalMapping's (keyframe, neighbour) searches
+    assert pc["reference_keyframe_bow_frames"] >= 1 and pc["keyframe_neighbour_pairs"] >= 20
+    assert {"search_for_triangulation", "fuse", "search_by_bow"} <= set(d["cpu_baseline"]["ms_per_frame"])
 
 
 def test_bench_detects_a_wrong_result(gpu):
