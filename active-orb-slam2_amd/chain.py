@@ -173,9 +173,12 @@ class KeyFrameWork:
     grids, FeatureVectors and the MapPoint table stay in HBM; the pair list, F12 and the fuse targets are host arrays, the
     results come back for the host-side map bookkeeping."""
 
-    def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0):
+    def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0,
+                 only_stereo: bool = False, check_orientation: bool = False, epipole=None):
         t, scen = tc.torch, tc.scen
         self.tc, self.n_kf, self.n_nb, self.fuse_th = tc, int(n_kf), int(n_nb), float(fuse_th)
+        # CreateNewMapPoints builds `ORBmatcher matcher(0.6, false)` and passes bOnlyStereo = false (src/LocalMapping.cc:221, 272)
+        self.only_stereo, self.check_orientation, self.levelsup = bool(only_stereo), bool(check_orientation), int(levelsup)
         nu, cap, W, H = scen["n_unique"], tc.cap, tc.W, tc.H
         self.nb = scenario.keyframe_neighbours(scen, n_nb)
         NB = nu * n_nb
@@ -214,8 +217,8 @@ class KeyFrameWork:
         self.kf1 = np.repeat(np.arange(self.n_kf, dtype=np.int32), n_nb)
         self.kf2 = np.concatenate([idx[b] * n_nb + np.arange(n_nb) for b in range(self.n_kf)]).astype(np.int32)
         self.F12 = np.ascontiguousarray(self.nb["F12"][self.kf2])
-        self.epipole = np.zeros((len(self.kf1), 2), np.float32)   # (sideways motion: the epipole is at infinity; every neighbour feature is a
-        # stereo one here, so the reference's test `!bStereo1 && !bStereo2` (:739) never reads it)
+        # (sideways motion: the epipole is at infinity; the parity sweeps pass finite ones to drive the mono-mono test of :739-745)
+        self.epipole = np.zeros((len(self.kf1), 2), np.float32) if epipole is None else np.ascontiguousarray(epipole, np.float32).reshape(len(self.kf1), 2)
         rows = tc.last_mp[self.kf1].copy()                          # vpMapPointMatches of keyframe 1, per (keyframe, neighbour) problem
         drop = rng.random(rows.shape) < 0.1                         # IsInKeyFrame(pKFi) / isBad(): the loop head's gate (:844-850)
         rows[drop] = -1
@@ -236,7 +239,8 @@ class KeyFrameWork:
         t0 = time.perf_counter()
         tc.last.SearchForTriangulation(self.kfs, self.kf1, self.kf2, self.F12, self.epipole, self.fv1[8].data_ptr(),
                                        [self.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [self.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
-                                       self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=False, check_orientation=False)
+                                       self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=self.only_stereo,
+                                       check_orientation=self.check_orientation)
         t1 = time.perf_counter()
         self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
         t2 = time.perf_counter()
@@ -253,5 +257,6 @@ class KeyFrameWork:
         """the inputs (by reference) and the last results (copies), for oracle/parity.py"""
         import types
         return types.SimpleNamespace(kf1=self.kf1, kf2=self.kf2, nb=self.nb, nb_mp=self.nb_mp, F12=self.F12, epipole=self.epipole,
-                                     fuse_rows=self.fuse_rows, n_nb=self.n_nb, fuse_th=self.fuse_th, match12=self.match12.copy(),
+                                     fuse_rows=self.fuse_rows, n_nb=self.n_nb, fuse_th=self.fuse_th, only_stereo=self.only_stereo,
+                                     check_orientation=self.check_orientation, levelsup=self.levelsup, match12=self.match12.copy(),
                                      nm=self.nm.copy(), best_idx=self.best_idx.copy(), best_dist=self.best_dist.copy())

@@ -180,7 +180,7 @@ def bow_leg_mismatches(results, co: ChainOracle, voc: dict, positions, nnratio=0
     return bad
 
 
-def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, timing=None):
+def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=None, timing=None):
     """chain.KeyFrameWork's results (SearchForTriangulation + the search part of Fuse for (keyframe, neighbour) pairs,
     src/LocalMapping.cc:272, 493) for the pair indices given, against the oracle on its own extraction of the same images:
     vMatches12 / counts and Fuse's best_idx / best_dist bit-identical.  kw = None: only run (and time) the oracle side."""
@@ -196,6 +196,8 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, 
     table = tc.map["table"]
     bad = []
     src = kw if kw is not None else co._kw_inputs
+    levelsup = int(getattr(src, "levelsup", 4)) if levelsup is None else levelsup
+    only_stereo, check_ori = int(getattr(src, "only_stereo", False)), int(getattr(src, "check_orientation", False))
     for p in pairs:
         b, j = int(src.kf1[p]), int(src.kf2[p])
         u = int(scen["index"][b])
@@ -220,7 +222,7 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=4, 
                     x2=f2["kp_x"], y2=f2["kp_y"], angle2=np.ascontiguousarray(okps["angle"], np.float32), u_right2=f2["u_right"],
                     octave2=np.ascontiguousarray(okps["octave"], np.int32), scale_factors2=np.ascontiguousarray(sf, np.float32),
                     level_sigma2_2=(np.asarray(sf, np.float32) * np.asarray(sf, np.float32)).astype(np.float32), F12=src.F12[p],
-                    ex=np.float32(src.epipole[p, 0]), ey=np.float32(src.epipole[p, 1]), only_stereo=0, check_orientation=0,
+                    ex=np.float32(src.epipole[p, 0]), ey=np.float32(src.epipole[p, 1]), only_stereo=only_stereo, check_orientation=check_ori,
                     node_id1=b1["fv_node"], node_off1=b1["fv_off"], node_idx1=b1["fv_idx"], node_id2=b2["fv_node"], node_off2=b2["fv_off"],
                     node_idx2=b2["fv_idx"])
         n, m = O.search_for_triangulation(prob)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,cases,seconds,at_least", [("extractor", 400, 30, 6), ("matcher", 100, 30, 2), ("rest", 100, 30, 3),
-                                                         ("more", 100, 30, 3)])
+                                                         ("more", 100, 30, 3), ("keyframes", 100, 30, 3)])
 def test_fuzz_slice(gpu, tool, cases, seconds, at_least):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", f"gpu_fuzz_{tool}.py"), str(cases), str(seconds)], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
