@@ -168,8 +168,11 @@ class KeyFrameWork:
 
         CreateNewMapPoints (src/LocalMapping.cc:272):   matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false)
         SearchInNeighbors  (src/LocalMapping.cc:493):   matcher.Fuse(pKFi, vpMapPointMatches)      -- the search part
+        SearchInNeighbors  (src/LocalMapping.cc:518):   matcher.Fuse(mpCurrentKeyFrame, vpFuseCandidates)   -- the map points of the
+                                                        neighbourhood (here: the keyframe's local map points) into the keyframe itself
 
-    one aos2_frames_search_for_triangulation and one aos2_frames_fuse per step for all n_kf * n_nb pairs.  Keys, descriptors,
+    one aos2_frames_search_for_triangulation and one aos2_frames_fuse per step for all n_kf * n_nb pairs, one aos2_frames_fuse for
+    the n_kf reverse problems.  Keys, descriptors,
     grids, FeatureVectors and the MapPoint table stay in HBM; the pair list, F12 and the fuse targets are host arrays, the
     results come back for the host-side map bookkeeping."""
 
@@ -224,6 +227,17 @@ class KeyFrameWork:
         rows[drop] = -1
         self.fuse_rows = rows
         self.d_rows = t.from_numpy(rows).to(tc.dev)
+        # the reverse problems (:503-518): candidates = the local map points of the keyframe's scene; the loop head (:844-850) drops
+        # those the keyframe holds already (IsInKeyFrame) and a few bad ones
+        loc = tc.map["local"][idx[: self.n_kf]].astype(np.int32).copy()
+        for b in range(self.n_kf):
+            held = tc.last_mp[b][tc.last_mp[b] >= 0]
+            loc[b][np.isin(loc[b], held)] = -1
+        loc[rng.random(loc.shape) < 0.05] = -1
+        self.rev_rows, self.rev_target = loc, np.arange(self.n_kf, dtype=np.int32)
+        self.d_rev_rows = t.from_numpy(loc).to(tc.dev)
+        self.d_rev_idx, self.d_rev_dist = z(loc.shape, t.int32), z(loc.shape, t.int32)
+        self.h_rev = [t.empty(loc.shape, dtype=t.int32).pin_memory() for _ in range(2)]
         P = len(self.kf1)
         self.d_match12, self.d_nm = z((P, cap), t.int32), z((P,), t.int32)
         self.d_best_idx, self.d_best_dist = z((P, cap), t.int32), z((P, cap), t.int32)
@@ -243,13 +257,16 @@ class KeyFrameWork:
                                        check_orientation=self.check_orientation)
         t1 = time.perf_counter()
         self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
+        tc.last.Fuse(tc.table, self.rev_target, self.d_rev_rows.data_ptr(), self.rev_rows.shape[1], self.fuse_th, self.d_rev_idx.data_ptr(),
+                     self.d_rev_dist.data_ptr())
         t2 = time.perf_counter()
-        # (both calls return with their results complete; the copies run on a stream of this object)
+        # (the calls return with their results complete; the copies run on a stream of this object)
         with tc.torch.cuda.stream(self.copy_stream):
-            for h, d in zip(self.h_out, (self.d_match12, self.d_best_idx, self.d_best_dist, self.d_nm)):
+            for h, d in zip(self.h_out + self.h_rev, (self.d_match12, self.d_best_idx, self.d_best_dist, self.d_nm, self.d_rev_idx, self.d_rev_dist)):
                 h.copy_(d, non_blocking=True)
         self.copy_stream.synchronize()
         self.match12, self.best_idx, self.best_dist, self.nm = (h.numpy() for h in self.h_out)   # vMatchedIndices / Fuse's best_idx: host views
+        self.rev_idx, self.rev_dist = (h.numpy() for h in self.h_rev)
         self.last_ms = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
         return self
 
@@ -258,5 +275,6 @@ class KeyFrameWork:
         import types
         return types.SimpleNamespace(kf1=self.kf1, kf2=self.kf2, nb=self.nb, nb_mp=self.nb_mp, F12=self.F12, epipole=self.epipole,
                                      fuse_rows=self.fuse_rows, n_nb=self.n_nb, fuse_th=self.fuse_th, only_stereo=self.only_stereo,
-                                     check_orientation=self.check_orientation, levelsup=self.levelsup, match12=self.match12.copy(),
+                                     check_orientation=self.check_orientation, levelsup=self.levelsup, rev_rows=self.rev_rows, rev_idx=self.rev_idx.copy(),
+                                     rev_dist=self.rev_dist.copy(), match12=self.match12.copy(),
                                      nm=self.nm.copy(), best_idx=self.best_idx.copy(), best_dist=self.best_dist.copy())

@@ -14,7 +14,8 @@ step      = one pass of the whole per-frame hot path over one batch of B synthet
             plus, for every `--frames-per-keyframe` (default 8) frames, the keyframe work: Frame::ComputeBoW (ORBVocabulary::transform)
             + ORBmatcher::SearchByBoW(reference keyframe, frame) (Tracking::TrackReferenceKeyFrame's front part, device-resident),
             LocalMapping's matcher calls for it -- ORBmatcher::SearchForTriangulation against its 10 neighbour keyframes
-            (CreateNewMapPoints) and the search of ORBmatcher::Fuse into each of them (SearchInNeighbors), device-resident --
+            (CreateNewMapPoints), the search of ORBmatcher::Fuse into each of them and of the scene's local map points into the
+            keyframe itself (SearchInNeighbors), device-resident --
             and one Optimizer::LocalBundleAdjustment window of the
             SURVEY section 8(d) size (20 local + 30 fixed keyframes, ~24 k stereo edges), solved by
             aos2_lba_solve_batch concurrently with the tracking chain like the reference's LocalMapping thread
@@ -272,7 +273,8 @@ def main():
     bows = [] if NO_BOW else [pkg.chain.ReferenceKeyFrameBoW(pp, voc_nodes, n_bow) for pp in pipes]
     # ---- and LocalMapping's matcher work for that keyframe (chain.KeyFrameWork, device-resident keyframes): SearchForTriangulation
     # against its nn = 10 best covisible keyframes (CreateNewMapPoints, src/LocalMapping.cc:214-272) and the search part of Fuse of
-    # its map points into each of them (SearchInNeighbors, :461-493); on the same side thread as the BoW leg
+    # its map points into each of them and of the scene's local map points into the keyframe (SearchInNeighbors, :461-518); on the same
+    # side thread as the BoW leg
     # (the neighbour views come from the generator's scenes: with recorded frames the leg is left out and the line says so)
     NO_KFW = NO_BOW or bool(real) or os.environ.get("AOS2_BENCH_NO_KEYFRAME_WORK") == "1"
     N_NB = 10
@@ -726,7 +728,7 @@ def main():
                                    "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "
                                    "SearchByBoW(reference keyframe, frame), %s"
                                    "and one LocalBundleAdjustment window (%d keyframes, %d points, %d "
-                                   "edges: SURVEY 8(d))" % (N_LOCAL, fpk, ("SearchForTriangulation + Fuse (search) against %d neighbour keyframes " % N_NB) if kfws else "",
+                                   "edges: SURVEY 8(d))" % (N_LOCAL, fpk, ("SearchForTriangulation + Fuse (search) against %d neighbour keyframes + Fuse of the local map points into the keyframe " % N_NB) if kfws else "",
                                                             lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
@@ -894,7 +896,7 @@ def main():
                 "checked": "per frame: keypoints, descriptors, mvuRight / mvDepth, match counts of both searches, inlier counts of both "
                            "PoseOptimizations, mvpMapPoints, mvbOutlier (bit-identical), mTcw (1e-5); per keyframe frame: the SearchByBoW match "
                            "array and count behind ComputeBoW (bit-identical); per (keyframe, neighbour) pair: vMatches12 and count of "
-                           "SearchForTriangulation, best index / distance of Fuse's search (bit-identical); per window: iteration and trial "
+                           "SearchForTriangulation, best index / distance of Fuse's search, both directions (bit-identical); per window: iteration and trial "
                            "counts, outlier sets (identical), poses and points (1e-5), final chi2 (1e-6 relative)",
                 "against": "oracle (C restatement; parity unpinned by the reference: DESIGN.md section 3)",
                 "mismatches": bad[:10], "n_mismatches": len(bad)}

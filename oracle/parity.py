@@ -229,17 +229,7 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=Non
         t1 = time.perf_counter()
         # Fuse(pKFi = the neighbour, vpMapPointMatches of keyframe 1): the candidates are table rows
         rows = src.fuse_rows[p]
-        T = src.nb["Tkw"][j].astype(np.float32)
-        R, t = np.ascontiguousarray(T[:3, :3]), np.ascontiguousarray(T[:3, 3])
-        Rd, td = R.astype(np.float64), t.astype(np.float64)
-        Ow = np.array([-((Rd[0, k] * td[0] + Rd[1, k] * td[1]) + Rd[2, k] * td[2]) for k in range(3)]).astype(np.float32)
-        rr = np.where(rows >= 0, rows, 0)
-        pts = dict(n_pts=len(rows), valid=(rows >= 0).astype(np.uint8), pos=table["pos"][rr], max_dist=table["max_dist"][rr],
-                   min_dist=table["min_dist"][rr], normal=table["normal"][rr], desc=table["desc"][rr], q_angle=np.zeros(len(rows), np.float32),
-                   R=R.reshape(9), t=t, Ow=Ow, R2=np.zeros(9, np.float32), t2=np.zeros(3, np.float32), fx=np.float32(scen["fx"]),
-                   fy=np.float32(scen["fy"]), cx=np.float32(scen["cx"]), cy=np.float32(scen["cy"]), bf=np.float32(scen["mbf"]),
-                   log_scale_factor=np.float32(np.log(np.float64(f2["scale_factors"][1]))), inv_level_sigma2=f2["inv_sigma2"],
-                   th=np.float32(src.fuse_th))
+        pts = _fuse_points(rows, src.nb["Tkw"][j], table, scen, f2, src.fuse_th)
         nf, bi, bd = O.fuse(f2, pts, sim3=False)
         t2 = time.perf_counter()
         if timing is not None:
@@ -252,4 +242,30 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=Non
             bad.append(f"{tag}: SearchForTriangulation {int(kw.nm[p])} matches, oracle {n}; {int((kw.match12[p, :n1] != m).sum())} entries differ")
         if not (kw.best_idx[p] == bi).all() or not (kw.best_dist[p] == bd).all():
             bad.append(f"{tag}: Fuse best_idx differs in {int((kw.best_idx[p] != bi).sum())} of {int((rows >= 0).sum())} candidates (oracle fuses {nf})")
+    # Fuse(mpCurrentKeyFrame, vpFuseCandidates) (src/LocalMapping.cc:518) for the keyframes the pairs name: the candidates into the keyframe itself
+    for b in sorted(set(int(src.kf1[p]) for p in pairs)):
+        u = int(scen["index"][b])
+        lk, ld, f1, b1 = co._kf1[u]
+        t0 = time.perf_counter()
+        pts = _fuse_points(src.rev_rows[b], scen["Tlw"][u], table, scen, f1, src.fuse_th)
+        nf, bi, bd = O.fuse(f1, pts, sim3=False)
+        if timing is not None:
+            timing["fuse"] = timing.get("fuse", 0.0) + time.perf_counter() - t0
+        if kw is not None and (not (kw.rev_idx[b] == bi).all() or not (kw.rev_dist[b] == bd).all()):
+            bad.append(f"keyframe {b}: Fuse of the neighbourhood's points into it: best_idx differs in {int((kw.rev_idx[b] != bi).sum())} of "
+                       f"{int((src.rev_rows[b] >= 0).sum())} candidates (oracle fuses {nf})")
     return bad
+
+
+def _fuse_points(rows, Tcw, table, scen, f, th):
+    """the candidate set of one Fuse(pKF, vpMapPoints, th) call as the oracle takes it: table rows (-1 = rejected by the loop head), pKF's pose"""
+    T = np.asarray(Tcw, np.float32)
+    R, t = np.ascontiguousarray(T[:3, :3]), np.ascontiguousarray(T[:3, 3])
+    Rd, td = R.astype(np.float64), t.astype(np.float64)
+    Ow = np.array([-((Rd[0, k] * td[0] + Rd[1, k] * td[1]) + Rd[2, k] * td[2]) for k in range(3)]).astype(np.float32)
+    rr = np.where(rows >= 0, rows, 0)
+    return dict(n_pts=len(rows), valid=(rows >= 0).astype(np.uint8), pos=table["pos"][rr], max_dist=table["max_dist"][rr],
+                min_dist=table["min_dist"][rr], normal=table["normal"][rr], desc=table["desc"][rr], q_angle=np.zeros(len(rows), np.float32),
+                R=R.reshape(9), t=t, Ow=Ow, R2=np.zeros(9, np.float32), t2=np.zeros(3, np.float32), fx=np.float32(scen["fx"]),
+                fy=np.float32(scen["fy"]), cx=np.float32(scen["cx"]), cy=np.float32(scen["cy"]), bf=np.float32(scen["mbf"]),
+                log_scale_factor=np.float32(np.log(np.float64(f["scale_factors"][1]))), inv_level_sigma2=f["inv_sigma2"], th=np.float32(th))

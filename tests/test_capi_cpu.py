@@ -89,6 +89,12 @@ def test_bad_arguments_and_missing_device(pkg):
         with pytest.raises(capi.AosError) as e:
             ex(np.zeros((480, 640), np.uint8))
         assert e.value.code == capi.AOS2_ERR_NO_DEVICE  # loud failure, no CPU fallback
+        # the keyframe entry points on batches that were never built: an argument error, nothing is touched
+        fa, fb = pkg.capi.Frames(2, 64), pkg.capi.Frames(2, 64)
+        z = np.zeros(1, np.int32)
+        with pytest.raises(capi.AosError) as e:
+            fa.SearchForTriangulation(fb, z, z, np.zeros((1, 9), np.float32), np.zeros((1, 2), np.float32), 8, [8] * 4, [8] * 4, 8, 8)
+        assert e.value.code == capi.AOS2_ERR_ARG
         with pytest.raises(capi.AosError) as e:
             pkg.Matcher().hamming_best2(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
         assert e.value.code == capi.AOS2_ERR_NO_DEVICE

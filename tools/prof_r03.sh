@@ -33,6 +33,8 @@ cat $O/pmc_extract_b512.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lbab -- python $R/tools/gpu_lba_batch_prof.py > $O/lba_batch.log 2>&1
 cp $(find $O/lbab -name "*kernel_stats.csv" | head -1) $O/lba_batch_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kfw -- python $R/tools/gpu_keyframe_prof.py 2>&1 | grep "keyframe work" > $O/keyframe_work.txt
+python $R/tools/kstats.py $O/kfw 8 >> $O/keyframe_work.txt
 cd $R
 python tools/gpu_chain_latency.py 2>&1 | grep -v "amdgpu.ids" > $O/chain_latency.txt
 cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain -- python $R/tools/gpu_chain_latency.py > /dev/null 2>&1; python $R/tools/kstats.py $O/chain 24 >> $O/chain_latency.txt; cd $R
