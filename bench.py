@@ -879,10 +879,9 @@ def main():
                 bad += parity.bow_leg_mismatches(snap["bow"], co, voc_nodes, bpos)
                 n_bow_checked = len(bpos)
             n_kfw_checked = 0
-            if snap["kfw"] is not None:   # every pair whose neighbour the oracle has extracted already + the first 2 keyframes' pairs
+            if snap["kfw"] is not None:   # every (keyframe, neighbour) pair of the step and every reverse fuse
                 kq = snap["kfw"]
-                have = getattr(co, "_nb", {})
-                kp_ = [q for q in range(len(kq.kf1)) if int(kq.kf2[q]) in have or q < 2 * N_NB]
+                kp_ = list(range(len(kq.kf1)))
                 bad += parity.keyframe_work_mismatches(kq, co, voc_nodes, kp_)
                 n_kfw_checked = len(kp_)
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
