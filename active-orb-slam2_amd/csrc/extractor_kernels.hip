@@ -277,20 +277,21 @@ typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2_t as_us2(uint32_t x) { return __builtin_bit_cast(us2_t, x); }
 __device__ __forceinline__ uint32_t as_u32(us2_t x) { return __builtin_bit_cast(uint32_t, x); }
 
-// compass pre-test on two pixels at once (packed u16 lanes): non-zero lane <=> at least two of the
-// four compass pixels are brighter than v+t, or at least two are darker than v-t
-// (= the second largest exceeds v+t, or the second smallest is below v-t)
+// compass pre-test on two pixels at once (packed u16 lanes): non-zero lane <=> one pixel of EACH antipodal compass pair -- (a, b) =
+// ring pixels 0 / 8, (c, d) = ring pixels 4 / 12 -- is brighter than v+t, or one of each pair is darker than v-t.  A contiguous arc of 9 of
+// the 16 ring pixels holds ring pixel i or i + 8 for every i, so every FAST-9 corner passes; pixels with two bright compass pixels of
+// the SAME pair (no 9-arc can hold both without one of the other pair) do not -- tighter than "two of the four" and two instructions
+// shorter (round 3; the survivors are scored exactly either way, so the result is the same).
 __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c, us2_t d, us2_t T)
 {
     const us2_t h1 = __builtin_elementwise_max(a, b), l1 = __builtin_elementwise_min(a, b);
     const us2_t h2 = __builtin_elementwise_max(c, d), l2 = __builtin_elementwise_min(c, d);
-    const us2_t m1 = __builtin_elementwise_min(h1, h2), m2 = __builtin_elementwise_max(l1, l2);
-    const us2_t sec_hi = __builtin_elementwise_max(m1, m2);   // second largest of a,b,c,d
-    const us2_t sec_lo = __builtin_elementwise_min(m1, m2);   // second smallest
-    // sec_hi > v + T  <=>  (sec_hi -sat T) > v: no sum that could leave 16 bits, so the same code serves operands that are
+    const us2_t hi = __builtin_elementwise_min(h1, h2);   // the smaller of the pairs' maxima: both pairs have a pixel above it or equal
+    const us2_t lo = __builtin_elementwise_max(l1, l2);
+    // hi > v + T  <=>  (hi -sat T) > v: no sum that could leave 16 bits, so the same code serves operands that are
     // scaled by 256 (the odd bytes of a dword taken with one AND instead of shift + AND; T scaled alike)
-    const us2_t bright = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(sec_hi, T), v);
-    const us2_t dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, T), sec_lo);
+    const us2_t bright = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(hi, T), v);
+    const us2_t dark = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, T), lo);
     return as_u32(bright) | as_u32(dark);
 }
 
@@ -299,7 +300,7 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
 // Phases per wave (one grid cell of one image, 64-thread workgroup = one wave, so list counters are
 // wave-uniform registers and no LDS atomics or multi-wave barriers are needed):
 //   0. stage the cell + ring halo in LDS (32-bit loads), evaluated column 0 on a dword boundary
-//   1. compass pre-test on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords,
+//   1. compass pre-test (one pixel of each antipodal compass pair) on every pixel, 4 horizontally adjacent pixels per lane from 5 LDS dwords,
 //      two pixels per packed-u16 op; survivors are ballot-compacted into an LDS list
 //   2. exact score for the survivors (dense lanes); corners (S >= th) go to the score map
 //   3. NMS of the corners against the score map; kept ones to the cell's slots.  Every list is built in row-major
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 nc += __popcll(bc);
             }
         };
-        // ---- 1. compass pre-test (a 9-arc contains >= 2 of the 4 compass pixels)
+        // ---- 1. compass pre-test (a 9-arc contains one pixel of each antipodal compass pair)
         int n1 = 0;
         bool overflowed = false;   // the survivor list was emptied at least once: NMS walks the score map instead
         const us2_t T = {(unsigned short)th, (unsigned short)th};
@@ -451,8 +452,13 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
                 const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
                 const uint32_t M = 0x00ff00ffu, MH = 0xff00ff00u;
-                f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(Eq & M), as_us2(N & M), as_us2(Wq & M), T);
-                f_hi = compass2(as_us2(C & MH), as_us2(S & MH), as_us2(Eq & MH), as_us2(N & MH), as_us2(Wq & MH), TH);
+                f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(N & M), as_us2(Eq & M), as_us2(Wq & M), T);
+                // the odd pixels in the high byte of each 16-bit lane, the even pixels' bytes left below them as "fraction": a maximum / minimum of
+                // such lanes has the exact high byte, and with H, L, V the high bytes and t the threshold `(H - t) * 256 + g > V * 256 + g'` can
+                // differ from `H - t > V` only for H - t == V (the fractions g, g' < 256): a pixel exactly AT the threshold may survive to the
+                // exact score, none above it is lost -- five mask instructions less
+                (void)MH;
+                f_hi = compass2(as_us2(C), as_us2(S), as_us2(N), as_us2(Eq), as_us2(Wq), TH);
             }
             // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
