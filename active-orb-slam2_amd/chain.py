@@ -177,12 +177,13 @@ class KeyFrameWork:
     results come back for the host-side map bookkeeping."""
 
     def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0,
-                 only_stereo: bool = False, check_orientation: bool = False, epipole=None):
+                 only_stereo: bool = False, check_orientation: bool = False, epipole=None, nb_cap: int | None = None):
         t, scen = tc.torch, tc.scen
         self.tc, self.n_kf, self.n_nb, self.fuse_th = tc, int(n_kf), int(n_nb), float(fuse_th)
         # CreateNewMapPoints builds `ORBmatcher matcher(0.6, false)` and passes bOnlyStereo = false (src/LocalMapping.cc:221, 272)
         self.only_stereo, self.check_orientation, self.levelsup = bool(only_stereo), bool(check_orientation), int(levelsup)
-        nu, cap, W, H = scen["n_unique"], tc.cap, tc.W, tc.H
+        nu, cap1, W, H = scen["n_unique"], tc.cap, tc.W, tc.H
+        cap = int(nb_cap or cap1)   # keypoint capacity of the neighbour batch (the two batches of a pair may differ)
         self.nb = scenario.keyframe_neighbours(scen, n_nb)
         NB = nu * n_nb
         self.voc = capi.Vocabulary(device=tc.device)
@@ -213,8 +214,10 @@ class KeyFrameWork:
         self.voc.transform_device(NB, self.n_desc.data_ptr(), self.n_n.data_ptr(), cap, levelsup, *(x.data_ptr() for x in self.fv2))
         # ---- keyframe 1 side: the LastFrame batch; the node of every feature (the FeatureVector key it is filed under)
         B = tc.B
-        self.fv1 = fv(B)
-        self.voc.transform_device(B, tc.dl_desc.data_ptr(), tc.dl_n.data_ptr(), cap, levelsup, *(x.data_ptr() for x in self.fv1))
+        fv1 = lambda n: [z((n, cap1), t.int32), z((n, cap1), t.float64), z((n,), t.int32), z((n, cap1), t.int32), z((n, cap1 + 1), t.int32),   # noqa: E731
+                         z((n, cap1), t.int32), z((n,), t.int32), z((n, cap1), t.int32), z((n, cap1), t.int32)]
+        self.fv1 = fv1(B)
+        self.voc.transform_device(B, tc.dl_desc.data_ptr(), tc.dl_n.data_ptr(), cap1, levelsup, *(x.data_ptr() for x in self.fv1))
         # ---- pairs and fuse problems
         idx = scen["index"]
         self.kf1 = np.repeat(np.arange(self.n_kf, dtype=np.int32), n_nb)
@@ -239,10 +242,10 @@ class KeyFrameWork:
         self.d_rev_idx, self.d_rev_dist = z(loc.shape, t.int32), z(loc.shape, t.int32)
         self.h_rev = [t.empty(loc.shape, dtype=t.int32).pin_memory() for _ in range(2)]
         P = len(self.kf1)
-        self.d_match12, self.d_nm = z((P, cap), t.int32), z((P,), t.int32)
-        self.d_best_idx, self.d_best_dist = z((P, cap), t.int32), z((P, cap), t.int32)
+        self.d_match12, self.d_nm = z((P, cap1), t.int32), z((P,), t.int32)
+        self.d_best_idx, self.d_best_dist = z((P, cap1), t.int32), z((P, cap1), t.int32)
         # the results of a step land in pinned host memory (one copy per array; LocalMapping's bookkeeping reads them there)
-        self.h_out = [t.empty((P, cap), dtype=t.int32).pin_memory() for _ in range(3)] + [t.empty((P,), dtype=t.int32).pin_memory()]
+        self.h_out = [t.empty((P, cap1), dtype=t.int32).pin_memory() for _ in range(3)] + [t.empty((P,), dtype=t.int32).pin_memory()]
         self.copy_stream = t.cuda.Stream(device=tc.dev)
         t.cuda.synchronize()
         self.last_ms = (0.0, 0.0)

@@ -31,7 +31,7 @@ for c in range(n_cases):
     # a finite epipole inside the image for half of the cases: drives the mono-mono proximity test (src/ORBmatcher.cc:739-745)
     ep = None if c % 2 else np.stack([rng.uniform(0, scen["w"], P), rng.uniform(0, scen["h"], P)], 1).astype(np.float32)
     kw = pkg.chain.KeyFrameWork(tc, voc, n_kf=n_kf, n_nb=n_nb, levelsup=levelsup, fuse_th=params["th"], only_stereo=params["only_stereo"],
-                                check_orientation=params["ori"], epipole=ep)
+                                check_orientation=params["ori"], epipole=ep, nb_cap=tc.cap + int(rng.choice([0, 8, 72])))
     co = parity.ChainOracle(scen, tc)
     kw.run()
     m = parity.keyframe_work_mismatches(kw, co, voc, range(P))
