@@ -371,7 +371,7 @@ static int build_plan(aos2_extractor *e, int w, int h)
         P.oct_node_total += (size_t)L.oct_node_cap;
     }
     // LDS tile: [4-byte left halo | nq quads | 4-byte right halo] per row, evaluated column 0 at byte 4
-    P.TP = 4 * ((P.max_cw + 3) / 4) + 8;
+    P.TP = (4 * ((P.max_cw + 3) / 4) + 8 + 15) & ~15;   // (a multiple of 16: the tile is staged 16 bytes per lane)
     P.TH = P.max_ch + 6;
     P.SP = (P.max_cw + 2 + 3) & ~3;
     // every pixel of every 4-px group may survive the pre-test (columns >= cw of the last group are

@@ -355,6 +355,29 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     // then owns LDS dword rs * ndw + c = its lane number, which is the one layout gfx950's LDS-DMA can write
     // (global_load_lds_dword: per-lane global address, LDS destination = M0 base + 4 * lane) -- the tile goes from HBM / L2
     // to LDS without passing through VGPRs and without a ds_write per row step.
+#if !defined(AOS2_FAST_STAGE_DWORD) && !defined(AOS2_FAST_STAGE_VGPR)
+    // (round 3, second step) 16 bytes per lane: global_load_lds_dwordx4 -- a row is n16 = ceil(ndw / 4) lanes, the pitch 16 * n16, a
+    // 41-row tile two instructions instead of eight; the bytes past the right halo come from the same image row (the 16-pixel border)
+    const int n16 = (ndw + 3) >> 2;
+    const int tp = 16 * n16;
+    {
+        const uint32_t inv = 65536u / (uint32_t)n16 + 1u;
+        const int nrs = (int)((64u * inv) >> 16);      // rows per step = 64 / n16 (n16 <= 5)
+        const int rs = (int)(__umul24((uint32_t)lane, inv) >> 16), c = lane - (int)__umul24((uint32_t)rs, (uint32_t)n16);
+        const int nrows = ch + 6;
+        if (rs < nrs) {
+            const uint8_t *sbase = plane + (size_t)(cell.vy0 - 3) * lv.pitch + (cell.vx0 - 4);   // uniform
+            const uint32_t soff = __umul24((uint32_t)rs, (uint32_t)lv.pitch) + 16u * (uint32_t)c;
+            const uint32_t sstep = (uint32_t)(nrs * lv.pitch);
+            const uint32_t dstep = (uint32_t)(nrs * tp);   // the bytes one step's lanes cover
+            uint32_t dbase = 0;
+            for (int r0 = 0; r0 < nrows; r0 += nrs, sbase += sstep, dbase += dstep)
+                if (rs < nrows - r0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sbase + soff),
+                                                     (__attribute__((address_space(3))) void *)(tile + dbase), 16, 0, 0);
+        }
+    }
+#else
     const int tp = 4 * ndw;
     {
         const int nrs = max(1, (int)((64u * cell.inv_ndw) >> 16));      // rows per step = 64 / ndw (cells are < 64 px wide: ndw <= 18)
@@ -387,6 +410,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
 #endif
         }
     }
+#endif
     const int SH = ch + 2;
 #if defined(AOS2_FAST_ABL) && AOS2_FAST_ABL == 1
     __syncthreads();
