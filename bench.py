@@ -732,6 +732,11 @@ def main():
                                                             lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"]),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
+                       "keyframe_legs_per_step": {"reference_keyframe_bow_searches": n_bow if bows else 0,
+                                                  "triangulation_and_fuse_pairs": len(kfws[0].kf1) if kfws else 0,
+                                                  "reverse_fuse_problems": n_bow if kfws else 0,
+                                                  "note": None if kfws or not real else "the neighbour keyframes are views of the generator's scenes: with recorded "
+                                                          "frames the triangulation / fuse leg is left out"},
                        "host_threads": "the GPU path is driven by 1 enqueueing thread + %d LocalMapping-side threads (one per LocalBA handle), each handle "
                                        "building its windows' index structures on up to %d worker threads, + %d threads for the keyframe legs (BoW, triangulation / fuse searches); "
                                        "cpu_baseline is ONE core (the reference's threading per stage)" % (NLBA, min(n_win, os.cpu_count() or 1, 32), NPIPE),
