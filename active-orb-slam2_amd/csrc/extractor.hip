@@ -348,7 +348,14 @@ static int build_plan(aos2_extractor *e, int w, int h)
                     const uint32_t nq = (uint32_t)(c.cw + 3) / 4;
                     c.inv_nq = 65536u / nq + 1;
                     c.inv_ndw = 65536u / (nq + 2) + 1;
+                    c.inv_n16 = 65536u / ((nq + 2 + 3) / 4) + 1;
                 }
+                if (L.off > 0xffffffffull || L.pitch > 0xffff) {
+                    set_error("pyramid of a %dx%d image exceeds the 32-bit plane offsets", w, h);
+                    return AOS2_ERR_ARG;
+                }
+                c.pitch = (uint16_t)L.pitch;
+                c.plane_off = (uint32_t)L.off;
                 slot += (size_t)((c.cw + 1) / 2) * ((c.ch + 1) / 2);
                 P.max_cw = std::max<int>(P.max_cw, c.cw);
                 P.max_ch = std::max<int>(P.max_ch, c.ch);

@@ -26,11 +26,15 @@ struct CellDev {
     int16_t level;
     int16_t vx0, vy0;     // first evaluated pixel of the cell (level interior coordinates)
     int16_t cw, ch;       // evaluated columns / rows
-    int16_t pad;
+    uint16_t pitch;       // row pitch of the level's plane (levels >= 1; level 0 is the caller's image with the caller's pitch)
     int32_t slot_off;     // offset of the cell's candidate slots inside one image's slot block
     uint32_t inv_ndw;     // 65536 / (quads per row + 2) + 1: exact i / ndw for i < 4096 by mul-shift
     uint32_t inv_nq;      // 65536 / quads per row + 1
+    uint32_t plane_off;   // byte offset of the level's plane inside one image's pyramid block (LevelDev::off): the FAST kernel
+                          // needs nothing else of the level, so its first loads are ONE record instead of a cell -> level chain
+    uint32_t inv_n16;     // 65536 / (16-byte groups per tile row) + 1
 };
+static_assert(sizeof(CellDev) == 32, "the FAST kernel loads a cell record as eight dwords");
 
 // inputs of the octree jobs' candidate gather (FAST's per-cell slots) and the per-(image, level) candidate count
 struct OctGather {

@@ -336,9 +336,22 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     const int b = blockIdx.x;
     if (b >= batch) return;
     const int cell_id = (int)blockIdx.y;
-    const CellDev cell = cells[cell_id];
-    LevelDev lv = levels[cell.level];
-    const uint8_t *plane = pyr + (size_t)b * pyr_stride + lv.off;
+    // the cell record as eight scalar dwords (one load; the 16-bit fields unpacked by scalar shifts): everything the kernel needs of
+    // the level -- plane offset and pitch -- is in it, so no second, dependent load stands before the tile's first request
+    CellDev cell;
+    {
+        const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(cells + cell_id);
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = cw32[i];
+        cell.level = (int16_t)(w[0] & 0xffffu); cell.vx0 = (int16_t)(w[0] >> 16);
+        cell.vy0 = (int16_t)(w[1] & 0xffffu); cell.cw = (int16_t)(w[1] >> 16);
+        cell.ch = (int16_t)(w[2] & 0xffffu); cell.pitch = (uint16_t)(w[2] >> 16);
+        cell.slot_off = (int32_t)w[3]; cell.inv_ndw = w[4]; cell.inv_nq = w[5]; cell.plane_off = w[6]; cell.inv_n16 = w[7];
+    }
+    (void)levels;
+    struct { int pitch; } lv{(int)cell.pitch};
+    const uint8_t *plane = pyr + (size_t)b * pyr_stride + cell.plane_off;
     if (cell.level == 0) {  // level 0 is the caller's image itself (no copy)
         plane = img0 + (size_t)b * img0_stride;
         lv.pitch = pitch0;
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
     const int n16 = (ndw + 3) >> 2;
     const int tp = 16 * n16;
     {
-        const uint32_t inv = 65536u / (uint32_t)n16 + 1u;
+        const uint32_t inv = cell.inv_n16;
         const int nrs = (int)((64u * inv) >> 16);      // rows per step = 64 / n16 (n16 <= 5)
         const int rs = (int)(__umul24((uint32_t)lane, inv) >> 16), c = lane - (int)__umul24((uint32_t)rs, (uint32_t)n16);
         const int nrows = ch + 6;
