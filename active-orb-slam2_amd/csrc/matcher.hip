@@ -941,6 +941,15 @@ struct QuerySlot {
     int32_t cnt;      // window population (0 = query skipped / empty window)
     int32_t ent_off;  // offset of its entries in the pool
 };
+// what the counting pass of a two-pass window search found out about a query with a non-empty window: the fill pass (a wave per
+// query, hundreds of thousands of them per batch, each a chain of dependent loads) reads this record and its slot instead of
+// repeating map point -> position -> projection -> octave -> scale factor -> window
+struct QueryRec {
+    float u, v, radius, ur;
+    int16_t minL, maxL;
+    int32_t row;      // descriptor row of the query
+};
+static_assert(sizeof(QueryRec) == 24, "QueryRec layout");
 
 // best / second of one query in stage B; e = entries of the first 64 candidates (prefetched)
 struct Pick {
@@ -1059,9 +1068,18 @@ __device__ __forceinline__ float mp_radius(const FrameDev &F, const ProjMpDev &P
 template <bool kSolo = false>
 __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const ProjMpDev &P, float th, QuerySlot *slots,
                                                      Entry *pool, int32_t *pool_used, int pool_cap, int i, int pool_base = 0,
-                                                     int phase = 0)
+                                                     int phase = 0, QueryRec *rec = nullptr)
 {
     const int lane = kSolo ? 0 : (int)(threadIdx.x & 63);   // a wave per query (workgroups may hold several waves)
+    if (phase == 2 && rec) {   // fill pass with the counting pass's record (QueryRec): slot + record, then straight to the window
+        const QuerySlot sl = slots[i];
+        if (sl.cnt <= 0) return;
+        const QueryRec r = rec[i];
+        const Window w = window_cells(F, r.u, r.v, r.radius);
+        window_entries(F, w, load_desc(P.desc + (size_t)r.row * 32), r.u, r.v, r.radius, r.minL, r.maxL, r.ur, r.radius, lane,
+                       pool + sl.ent_off);
+        return;
+    }
     QuerySlot s{0, 0};
     if (P.track_in_view[i]) {
         const float rs = mp_radius(F, P, i, th);
@@ -1070,6 +1088,13 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
             const int pop = kSolo ? window_population_solo(F, w) : window_population(F, w, lane);
             if (pop > 0 && (phase == 1 || kSolo)) {
                 s.cnt = pop;
+                if (rec && lane == 0) {
+                    const int lvl = P.pred_level[i];
+                    QueryRec r;
+                    r.u = P.proj_x[i]; r.v = P.proj_y[i]; r.radius = rs; r.ur = P.proj_xr[i];
+                    r.minL = (int16_t)(lvl - 1); r.maxL = (int16_t)lvl; r.row = P.desc_idx ? P.desc_idx[i] : i;
+                    rec[i] = r;
+                }
             } else if (pop > 0) {
                 // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
                 const int stride = phase == 2 ? pop : pool_cap / max(P.n_mp, 1);
@@ -1248,9 +1273,18 @@ __device__ __forceinline__ bool proj_last_blocks(const ProjLastDev &P, int q)
 template <bool kSolo = false>
 __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const ProjLastDev &P, float th, int mono,
                                                        QuerySlot *slots, Entry *pool, int32_t *pool_used, int pool_cap,
-                                                       int i, int pool_base = 0, int phase = 0)
+                                                       int i, int pool_base = 0, int phase = 0, QueryRec *rec = nullptr)
 {
     const int lane = kSolo ? 0 : (int)(threadIdx.x & 63);   // a wave per query (workgroups may hold several waves)
+    if (phase == 2 && rec) {   // fill pass with the counting pass's record: slot + record, then straight to the window
+        const QuerySlot sl = slots[i];
+        if (sl.cnt <= 0) return;
+        const QueryRec r = rec[i];
+        const Window w = window_cells(F, r.u, r.v, r.radius);
+        window_entries(F, w, load_desc(P.desc + (size_t)r.row * 32), r.u, r.v, r.radius, r.minL, r.maxL, r.ur, r.radius, lane,
+                       pool + sl.ent_off);
+        return;
+    }
     QuerySlot s{0, 0};
     const float *T = P.Tcw, *Tl = P.Tlw;
     int row = i;
@@ -1302,6 +1336,12 @@ __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const 
                 const int pop = kSolo ? window_population_solo(F, w) : window_population(F, w, lane);
                 if (pop > 0 && (phase == 1 || kSolo)) {
                     s.cnt = pop;
+                    if (rec && lane == 0) {
+                        QueryRec r;
+                        r.u = u; r.v = v; r.radius = radius; r.ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
+                        r.minL = (int16_t)minL; r.maxL = (int16_t)maxL; r.row = row;
+                        rec[i] = r;
+                    }
                 } else if (pop > 0) {
                     const int stride = phase == 2 ? pop : pool_cap / max(P.n_last, 1);
                     const int off = phase == 2 ? slots[i].ent_off : pool_base + i * stride;
