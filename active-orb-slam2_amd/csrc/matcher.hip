@@ -1749,27 +1749,36 @@ __global__ void is_in_frustum_kernel(ProjGenDev P, float min_x, float max_x, flo
 __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGenDev &P, const Window &w, const Desc &dq,
                                                 const ProjSetup &S, int lane, uint32_t &payload)
 {
-    const int ny = w.y1 - w.y0 + 1, ncell = (w.x1 - w.x0 + 1) * ny;
-    int base = 0;
+    // One candidate per lane, like window_entries: a lane per grid COLUMN finds the column's run of grid_idx, position k of the
+    // window (cells column by column, the features of a cell in their CSR order) is element k of the concatenated runs.  (A lane
+    // per cell walking its features one after the other is a chain of dependent gathers as long as the fullest cell -- the
+    // form this routine had until round 3.)
+    const int ncol = w.x1 - w.x0 + 1;   // <= GRID_COLS = 64
+    int cb = 0, cnt = 0;
+    if (lane < ncol) {
+        const int c0 = (w.x0 + lane) * GRID_ROWS;
+        cb = F.grid_off[c0 + w.y0];
+        cnt = F.grid_off[c0 + w.y1 + 1] - cb;
+    }
+    const int incl = wave_incl_scan_i32(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int delta = cb - (incl - cnt);   // run start - first position of the column
     uint32_t key = KEY_NONE;
     payload = 0;
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-        const int c = c0 + lane;
-        int beg = 0, cnt = 0;
-        if (c < ncell) {
-            const int cell = (w.x0 + c / ny) * GRID_ROWS + w.y0 + c % ny;
-            beg = F.grid_off[cell];
-            cnt = F.grid_off[cell + 1] - beg;
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        int src = 0;
+        for (int c = 0; c < ncol; ++c) {   // (uniform) the last column that starts at or before k
+            const int first = __builtin_amdgcn_readlane(incl - cnt, c), d = __builtin_amdgcn_readlane(delta, c);
+            if (k >= first) src = k + d;
         }
-        const int incl = wave_incl_scan_i32(cnt);
-        const int pos0 = base + incl - cnt;
-        for (int j = 0; j < cnt; ++j) {
-            const int idx = F.grid_idx[beg + j];
+        if (k < total) {
+            const int idx = F.grid_idx[src];
             const float kx = F.kp_x[idx], ky = F.kp_y[idx];
-            if (!(fabsf(__fsub_rn(kx, S.u)) < S.radius && fabsf(__fsub_rn(ky, S.v)) < S.radius)) continue;
+            bool pass = fabsf(__fsub_rn(kx, S.u)) < S.radius && fabsf(__fsub_rn(ky, S.v)) < S.radius;
             const int oct = F.kp_octave[idx];
-            if (oct < S.level - 1 || oct > S.level) continue;
-            if (P.mode == 0) {  // reprojection error gates of Fuse (:911-935)
+            if (oct < S.level - 1 || oct > S.level) pass = false;
+            if (pass && P.mode == 0) {  // reprojection error gates of Fuse (:911-935)
                 const float ex = __fsub_rn(S.u, kx), ey = __fsub_rn(S.v, ky);
                 const float kr = F.u_right[idx];
                 float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
@@ -1779,16 +1788,17 @@ __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGen
                     e2 = __fadd_rn(e2, __fmul_rn(er, er));
                     lim = 7.8;
                 }
-                if ((double)__fmul_rn(e2, P.inv_level_sigma2[oct]) > lim) continue;
+                if ((double)__fmul_rn(e2, P.inv_level_sigma2[oct]) > lim) pass = false;
             }
-            const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
-            const uint32_t k = ((uint32_t)dist << 20) | (uint32_t)(pos0 + j);
-            if (k < key) {
-                key = k;
-                payload = (uint32_t)idx;
+            if (pass) {
+                const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+                const uint32_t kk = ((uint32_t)dist << 20) | (uint32_t)k;
+                if (kk < key) {
+                    key = kk;
+                    payload = (uint32_t)idx;
+                }
             }
         }
-        base += __builtin_amdgcn_readlane(incl, 63);
     }
     uint32_t k1 = key, k2 = KEY_NONE;
     wave_min2(k1, k2);
