@@ -49,6 +49,14 @@ def test_bench_contract_single_gpu(gpu):
     assert {"search_for_triangulation", "fuse", "search_by_bow"} <= set(d["cpu_baseline"]["ms_per_frame"])
 
 
+def test_bench_with_the_large_batch_pose_optimization_form(gpu):
+    """batches of more than 256 frames run PoseOptimization with 128 threads per frame (all frames resident at once); forced here on a
+    small batch: the last timed step still equals the oracle (inlier counts, outlier flags bit-identical, poses 1e-5)"""
+    d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-extra"],
+             {"AOS2_PO_THREADS": "128"})
+    assert d["parity_checked"]["ok"] is True and d["parity_checked"]["frames"] == 16
+
+
 def test_bench_detects_a_wrong_result(gpu):
     """the --verify leg is a real check: with one map point of the table moved after the oracle inputs were fixed
     (AOS2_BENCH_FAULT, a test hook) the line reports the mismatch and the process fails"""
