@@ -943,8 +943,10 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
 // windows) first, so the landmark workgroups of ALL windows start before any keyframe workgroup: their walks are the long
 // dependent chains of the launch (33 of its 54 us on 32 windows when they queued behind the keyframe workgroups of the
 // windows before them), the keyframe workgroups fill in behind.
+// (three waves per SIMD: 174 -> 168 registers for 12 bytes of scratch per lane; the walk moves scattered bytes and gains from the third
+// wave: 36.2 -> 34.4 us on 32 windows.  k_points_walk, 172 registers, does not: 34.2 -> 35.0 us, left at two.)
 template <bool kWalk>
-__global__ __launch_bounds__(256) void k_lin(const LbaWin *__restrict__ wins, int init, int nl_blocks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lin(const LbaWin *__restrict__ wins, int init, int nl_blocks)
 {
     const LbaWin &W = wins[blockIdx.x];
     if (!(init ? W.st->initp : W.st->lin)) return;
