@@ -908,7 +908,11 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
         }
         if (k < total) {
             const int idx = F.grid_idx[src];
+            // everything the gates and the distance need of the candidate is requested at once: gate by gate (octave, then position,
+            // then uRight, then the descriptor) is four dependent round trips on a wave whose whole life is a handful of them
             const int oct = F.kp_octave[idx];
+            const float kx = F.kp_x[idx], ky = F.kp_y[idx], ur = F.u_right[idx];
+            const Desc dc = load_desc(F.desc_f + (size_t)idx * 32);
             Entry e;
             e.key = KEY_NONE;
             e.payload = (uint32_t)idx | ((uint32_t)oct << 24);
@@ -917,19 +921,16 @@ __device__ __forceinline__ void window_entries(const FrameDev &F, const Window &
                 if (oct < minLevel) pass = false;
                 if (maxLevel >= 0 && oct > maxLevel) pass = false;
             }
-            if (pass) {
-                const float distx = __fsub_rn(F.kp_x[idx], x), disty = __fsub_rn(F.kp_y[idx], y);
-                pass = fabsf(distx) < r && fabsf(disty) < r;
+            {
+                const float distx = __fsub_rn(kx, x), disty = __fsub_rn(ky, y);
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) pass = false;
+            }
+            if (ur > 0) {
+                const float er = fabsf(__fsub_rn(xr_proj, ur));
+                if (er > xr_tol) pass = false;
             }
             if (pass) {
-                const float ur = F.u_right[idx];
-                if (ur > 0) {
-                    const float er = fabsf(__fsub_rn(xr_proj, ur));
-                    if (er > xr_tol) pass = false;
-                }
-            }
-            if (pass) {
-                const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+                const int dist = hamming(dq, dc);
                 e.key = ((uint32_t)dist << 20) | (uint32_t)k;
             }
             out[k] = e;
@@ -1774,13 +1775,15 @@ __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGen
         }
         if (k < total) {
             const int idx = F.grid_idx[src];
+            // (the candidate's position, octave, uRight and descriptor are requested together: gate by gate they are dependent round trips)
             const float kx = F.kp_x[idx], ky = F.kp_y[idx];
-            bool pass = fabsf(__fsub_rn(kx, S.u)) < S.radius && fabsf(__fsub_rn(ky, S.v)) < S.radius;
             const int oct = F.kp_octave[idx];
+            const float kr = P.mode == 0 ? F.u_right[idx] : 0.0f;
+            const Desc dc = load_desc(F.desc_f + (size_t)idx * 32);
+            bool pass = fabsf(__fsub_rn(kx, S.u)) < S.radius && fabsf(__fsub_rn(ky, S.v)) < S.radius;
             if (oct < S.level - 1 || oct > S.level) pass = false;
             if (pass && P.mode == 0) {  // reprojection error gates of Fuse (:911-935)
                 const float ex = __fsub_rn(S.u, kx), ey = __fsub_rn(S.v, ky);
-                const float kr = F.u_right[idx];
                 float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
                 double lim = 5.99;
                 if (kr >= 0) {
@@ -1791,7 +1794,7 @@ __device__ __forceinline__ uint32_t window_best(const FrameDev &F, const ProjGen
                 if ((double)__fmul_rn(e2, P.inv_level_sigma2[oct]) > lim) pass = false;
             }
             if (pass) {
-                const int dist = hamming(dq, load_desc(F.desc_f + (size_t)idx * 32));
+                const int dist = hamming(dq, dc);
                 const uint32_t kk = ((uint32_t)dist << 20) | (uint32_t)k;
                 if (kk < key) {
                     key = kk;
