@@ -184,8 +184,9 @@ class KeyFrameWork:
         self.only_stereo, self.check_orientation, self.levelsup = bool(only_stereo), bool(check_orientation), int(levelsup)
         nu, cap1, W, H = scen["n_unique"], tc.cap, tc.W, tc.H
         cap = int(nb_cap or cap1)   # keypoint capacity of the neighbour batch (the two batches of a pair may differ)
-        self.nb = scenario.keyframe_neighbours(scen, n_nb)
-        NB = nu * n_nb
+        # (only the scenes the first n_kf batch positions show need neighbour keyframes)
+        self.nb = scenario.keyframe_neighbours(scen, n_nb, n_scenes=int(scen["index"][: self.n_kf].max()) + 1)
+        NB = self.nb["n_scenes"] * n_nb
         self.voc = capi.Vocabulary(device=tc.device)
         self.voc.set_nodes(voc["k"], voc["L"], voc["scoring"], voc["weighting"], voc["parent"], voc["desc"], voc["weight"], voc["is_leaf"])
         # ---- the neighbour keyframes: extraction, Frame members, pose, map point flags, FeatureVectors
@@ -194,7 +195,7 @@ class KeyFrameWork:
         z = lambda shape, dt: t.zeros(shape, dtype=dt, device=tc.dev)   # noqa: E731
         self.n_kps, self.n_desc, self.n_n = z((NB, cap, 7), t.float32), z((NB, cap, 32), t.uint8), z((NB,), t.int32)
         self.ex.extract_batch_device(self.d_img.data_ptr(), NB, W, H, W, W * H, self.n_kps.data_ptr(), self.n_desc.data_ptr(), cap, self.n_n.data_ptr())
-        self.d_depth = t.from_numpy(np.repeat(scen["Z"].astype(np.float32), n_nb)).to(tc.dev)[:, None, None].expand(NB, H, W).contiguous()
+        self.d_depth = t.from_numpy(np.repeat(scen["Z"][: self.nb["n_scenes"]].astype(np.float32), n_nb)).to(tc.dev)[:, None, None].expand(NB, H, W).contiguous()
         self.kfs = capi.Frames(NB, cap, tc.device)
         self.kfs.build(self.ex, self.n_kps.data_ptr(), self.n_desc.data_ptr(), self.n_n.data_ptr(), W, H, self.d_depth.data_ptr(),
                        float(scen["fx"]), float(scen["fy"]), float(scen["cx"]), float(scen["cy"]), float(scen["mbf"]))

@@ -123,12 +123,27 @@ protected:
             S.state[i] = !pMP ? 0 : (pMP->Observations() > 0 ? 2 : 1);
         }
     }
-    // KeyFrame (mGrid is a vector of vectors there, the image bounds are ints: include/KeyFrame.h:198-223)
+    // KeyFrame: KeyFrame::mGrid is PROTECTED in the reference (include/KeyFrame.h:206,223; the reference's matcher goes through
+    // KeyFrame::GetFeaturesInArea) and ORBmatcher is no friend, so the cell lists are rebuilt from public members with the rule
+    // that made them -- Frame::AssignFeaturesToGrid / Frame::PosInGrid (src/Frame.cc:262-274, 411-421) on mvKeysUn with Frame's
+    // static bounds (KeyFrame::KeyFrame copies F.mGrid, src/KeyFrame.cc:48-54; the keyframe's own mnMinX / mnMinY are the same
+    // bounds truncated to int, used below only where KeyFrame::GetFeaturesInArea uses them).  Ascending feature index inside a
+    // cell = the push_back order of AssignFeaturesToGrid.
     static void snapshot(KeyFrame *pKF, View &S)
     {
+        static thread_local std::vector<std::vector<std::size_t>> cells;
+        cells.resize((std::size_t)FRAME_GRID_COLS * FRAME_GRID_ROWS);
+        for (auto &c : cells) c.clear();
+        for (int i = 0; i < pKF->N; ++i) {
+            const cv::KeyPoint &kp = pKF->mvKeysUn[i];
+            const int posX = (int)std::round((kp.pt.x - Frame::mnMinX) * Frame::mfGridElementWidthInv);
+            const int posY = (int)std::round((kp.pt.y - Frame::mnMinY) * Frame::mfGridElementHeightInv);
+            if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+            cells[(std::size_t)posX * FRAME_GRID_ROWS + posY].push_back((std::size_t)i);
+        }
         fill_view(S, pKF->N, pKF->mvKeysUn, pKF->mDescriptors, pKF->mvuRight, pKF->mvScaleFactors, (float)pKF->mnMinX, (float)pKF->mnMinY,
                   (float)pKF->mnMaxX, (float)pKF->mnMaxY, pKF->mfGridElementWidthInv, pKF->mfGridElementHeightInv,
-                  [pKF](int ix, int iy) -> const std::vector<std::size_t> & { return pKF->mGrid[ix][iy]; });
+                  [](int ix, int iy) -> const std::vector<std::size_t> & { return cells[(std::size_t)ix * FRAME_GRID_ROWS + iy]; });
     }
 
     // a set of map points to project: the per-point members every projection method reads

@@ -20,6 +20,57 @@ def _rot(axis, ang):
     return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
 
 
+def pmap(fn, items, workers=None):
+    """[fn(x) for x in items], on forked worker processes when there are enough items to pay for them (the generators are
+    numpy + Python loops: 0.2 s per scene, 2 s per LocalBA window; a bench line holds hundreds).  The result does not depend on
+    the number of workers (every item draws from a generator of its own).  Falls back to the serial loop."""
+    import os
+    items = list(items)
+    if workers is None:
+        workers = min(len(items) // 4, (os.cpu_count() or 1) - 2, 96)
+    if int(os.environ.get("AOS2_SYNTH_WORKERS", workers)) <= 1 or len(items) < 8:
+        return [fn(x) for x in items]
+    workers = int(os.environ.get("AOS2_SYNTH_WORKERS", workers))
+    try:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(fn, items, chunksize=max(1, len(items) // (4 * workers)))
+    except Exception:   # noqa: BLE001  (no fork, no semaphores, ...): the serial loop gives the same arrays
+        return [fn(x) for x in items]
+
+
+def _scene(a):
+    """one distinct (LastFrame, CurrentFrame, older view) scene; every draw from the scene's own generator"""
+    seed, u, W, H, M, max_shift, fx, fy = a
+    rng = np.random.default_rng([77000 + seed, u])
+    canvas8 = synth.synth_image(seed * 1000 + u, W + 2 * M, H + 2 * M)
+    canvas = canvas8.astype(np.float32)
+    dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+    ex, ey = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+    last = canvas[M:M + H, M:M + W].astype(np.uint8)
+    cur = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
+    old = np.clip(np.rint(canvas[M + ey:M + ey + H, M + ex:M + ex + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
+    Z = rng.uniform(1.5, 3.0)
+    holes = np.zeros((2, 12, 4), np.int32)   # invalid-depth holes: monocular observations (mvuRight < 0)
+    for d in range(2):
+        for k in range(12):
+            x0, y0 = int(rng.integers(0, W - 40)), int(rng.integers(0, H - 40))
+            holes[d, k] = (y0, y0 + int(rng.integers(8, 40)), x0, x0 + int(rng.integers(8, 40)))
+    # world frame: an arbitrary rigid transform of the last camera frame
+    T = np.eye(4)
+    T[:3, :3] = _rot(rng.normal(size=3), rng.uniform(0, np.pi))
+    T[:3, 3] = rng.uniform(-5, 5, 3)
+    # the camera translates parallel to the image plane: a feature at u_l in the last image appears at u_l - dx
+    Tcl = np.eye(4)
+    Tcl[:3, 3] = -np.array([dx * Z / float(fx), dy * Z / float(fy), 0.0])
+    Tcw = Tcl @ T
+    # motion-model guess (mVelocity * mLastFrame.mTcw): the true pose off by a fraction of a degree and ~2 px
+    E = np.eye(4)
+    E[:3, :3] = _rot(rng.normal(size=3), rng.normal(0, 0.002))
+    E[:3, 3] = rng.normal(0, 2.0 * Z / float(fx), 3)
+    return dict(canvas=canvas8, last=last, cur=cur, old=old, Z=Z, holes=holes, shift=(dx, dy), shift_old=(ex, ey), Tlw=T, Tcw=Tcw, Tguess=E @ Tcw)
+
+
 def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10, dist=None):
     """Images, depth maps and poses of `batch` (LastFrame, CurrentFrame) pairs (`n_unique` distinct ones, tiled)."""
     c = synth.CONFIGS[cfg]
@@ -27,53 +78,24 @@ def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | N
     fx, fy, cx, cy, mbf = (np.float32(c[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
     M = 2 * max_shift + 4
     nu = min(batch, n_unique or batch)
-    rng = np.random.default_rng(77000 + seed)
-    last = np.zeros((nu, H, W), np.uint8)
-    cur = np.zeros((nu, H, W), np.uint8)
-    old = np.zeros((nu, H, W), np.uint8)
+    sc = pmap(_scene, [(seed, u, W, H, M, max_shift, float(fx), float(fy)) for u in range(nu)])
+    last, cur, old = (np.stack([q[k] for q in sc]) for k in ("last", "cur", "old"))
     depth_cur = np.zeros((nu, H, W), np.float32)
     depth_last = np.zeros((nu, H, W), np.float32)
-    shift = np.zeros((nu, 2), np.int32)
-    shift_old = np.zeros((nu, 2), np.int32)
-    Z = np.zeros(nu, np.float64)
-    Tlw = np.zeros((nu, 4, 4), np.float64)
-    Tcw = np.zeros((nu, 4, 4), np.float64)
-    Tguess = np.zeros((nu, 4, 4), np.float64)
-    for u in range(nu):
-        canvas = synth.synth_image(seed * 1000 + u, W + 2 * M, H + 2 * M).astype(np.float32)
-        dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
-        ex, ey = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
-        shift[u] = (dx, dy)
-        shift_old[u] = (ex, ey)
-        last[u] = canvas[M:M + H, M:M + W].astype(np.uint8)
-        cur[u] = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
-        old[u] = np.clip(np.rint(canvas[M + ey:M + ey + H, M + ex:M + ex + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
-        Z[u] = rng.uniform(1.5, 3.0)
-        for dimg in (depth_cur[u], depth_last[u]):
-            dimg[:] = np.float32(Z[u])
-            for _ in range(12):   # invalid-depth holes: monocular observations (mvuRight < 0)
-                x0, y0 = int(rng.integers(0, W - 40)), int(rng.integers(0, H - 40))
-                dimg[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(8, 40))] = 0.0
-        # world frame: an arbitrary rigid transform of the last camera frame
-        Rlw = _rot(rng.normal(size=3), rng.uniform(0, np.pi))
-        T = np.eye(4)
-        T[:3, :3] = Rlw
-        T[:3, 3] = rng.uniform(-5, 5, 3)
-        Tlw[u] = T
-        # the camera translates parallel to the image plane: a feature at u_l in the last image appears at u_l - dx
-        t_l = np.array([dx * Z[u] / float(fx), dy * Z[u] / float(fy), 0.0])
-        Tcl = np.eye(4)
-        Tcl[:3, 3] = -t_l
-        Tcw[u] = Tcl @ T
-        # motion-model guess (mVelocity * mLastFrame.mTcw): the true pose off by a fraction of a degree and ~2 px
-        E = np.eye(4)
-        E[:3, :3] = _rot(rng.normal(size=3), rng.normal(0, 0.002))
-        E[:3, 3] = rng.normal(0, 2.0 * Z[u] / float(fx), 3)
-        Tguess[u] = E @ Tcw[u]
+    for u, q in enumerate(sc):
+        for d, dimg in enumerate((depth_cur[u], depth_last[u])):
+            dimg[:] = np.float32(q["Z"])
+            for y0, y1, x0, x1 in q["holes"][d]:
+                dimg[y0:y1, x0:x1] = 0.0
+    Z = np.array([q["Z"] for q in sc], np.float64)
+    Tlw, Tcw, Tguess = (np.stack([q[k] for q in sc]) for k in ("Tlw", "Tcw", "Tguess"))
+    shift = np.array([q["shift"] for q in sc], np.int32).reshape(nu, 2)
+    shift_old = np.array([q["shift_old"] for q in sc], np.int32).reshape(nu, 2)
     idx = np.arange(batch) % nu
     # dist: mDistCoef (k1 k2 p1 p2 k3) the frames are declared to have (the images themselves are not warped: a parity scenario)
     return dict(seed=seed, margin=M, max_shift=max_shift, dist=None if dist is None else np.asarray(dist, np.float32), cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
                 last=last, cur=cur, old=old, depth_cur=depth_cur, depth_last=depth_last, shift=shift, shift_old=shift_old, Z=Z,
+                canvas=[q["canvas"] for q in sc],
                 Tlw=Tlw.astype(np.float32), Tcw_true=Tcw.astype(np.float32), Tcw_guess=Tguess.astype(np.float32))
 
 
@@ -164,43 +186,50 @@ def tracking_scenario_real(pairs: dict, batch: int, cfg: str = "tum"):
                 shift_old=np.zeros((nu, 2), np.int32), Z=np.ones(nu), Tlw=eye.copy(), Tcw_true=eye.copy(), Tcw_guess=eye.copy())
 
 
-def keyframe_neighbours(scen: dict, n_nb: int = 20):
+def _neighbours(a):
+    """the `n_nb` neighbour views of one scene; every draw from the scene's own generator"""
+    seed, u, canvas8, W, H, M, max_shift, n_nb, fx, fy, cx, cy, T1w, Z = a
+    rng = np.random.default_rng([55000 + seed, u])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    Ki = np.linalg.inv(K)
+    canvas = canvas8.astype(np.float32)
+    imgs = np.zeros((n_nb, H, W), np.uint8)
+    Tkw = np.zeros((n_nb, 4, 4), np.float32)
+    F12 = np.zeros((n_nb, 9), np.float32)
+    shift = np.zeros((n_nb, 2), np.int32)
+    for k in range(n_nb):
+        while True:
+            dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+            if dx or dy:
+                break
+        shift[k] = (dx, dy)
+        imgs[k] = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
+        T21 = np.eye(4)
+        T21[:3, 3] = -np.array([dx * Z / fx, dy * Z / fy, 0.0])
+        T2w = T21 @ T1w
+        Tkw[k] = T2w
+        R1w, t1w, R2w, t2w = T1w[:3, :3], T1w[:3, 3], T2w[:3, :3], T2w[:3, 3]
+        R12 = R1w @ R2w.T
+        t12 = -R12 @ t2w + t1w
+        tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+        F12[k] = (Ki.T @ tx @ R12 @ Ki).astype(np.float32).reshape(9)
+    return imgs, Tkw, F12, shift
+
+
+def keyframe_neighbours(scen: dict, n_nb: int = 20, n_scenes: int | None = None):
     """Neighbour keyframes for the keyframe work of LocalMapping (CreateNewMapPoints / SearchInNeighbors, src/LocalMapping.cc:
-    207-453, 455-560): `n_nb` more views of every distinct scene of a tracking_scenario(), the camera translated parallel to the
+    207-453, 455-560): `n_nb` more views of each of the first `n_scenes` distinct scenes of a tracking_scenario() (default: all),
+    the camera translated parallel to the
     image plane like the scenario's other views (the image = the scene's canvas shifted by whole pixels + pixel noise).  Returns
-    images [n_unique * n_nb, H, W], their poses Tkw (float32 4x4) and, per (scene, neighbour), the fundamental matrix F12 between the
+    images [n_scenes * n_nb, H, W], their poses Tkw (float32 4x4) and, per (scene, neighbour), the fundamental matrix F12 between the
     scene's LastFrame view (keyframe 1) and the neighbour (keyframe 2) as LocalMapping::ComputeF12 forms it (:603-618):
     R12 = R1w R2w^T, t12 = -R12 t2w + t1w, F12 = K^-T [t12]x R12 K^-1."""
     if scen.get("real"):
         raise ValueError("neighbour keyframes are generated from the synthetic scenes' canvases")
     W, H, M, nu = scen["w"], scen["h"], scen["margin"], scen["n_unique"]
+    ns = nu if n_scenes is None else min(int(n_scenes), nu)
     fx, fy, cx, cy = (float(scen[k]) for k in ("fx", "fy", "cx", "cy"))
-    rng = np.random.default_rng(55000 + scen["seed"])
-    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
-    Ki = np.linalg.inv(K)
-    imgs = np.zeros((nu * n_nb, H, W), np.uint8)
-    Tkw = np.zeros((nu * n_nb, 4, 4), np.float32)
-    F12 = np.zeros((nu * n_nb, 9), np.float32)
-    shift = np.zeros((nu * n_nb, 2), np.int32)
-    for u in range(nu):
-        canvas = synth.synth_image(scen["seed"] * 1000 + u, W + 2 * M, H + 2 * M).astype(np.float32)
-        T1w = scen["Tlw"][u].astype(np.float64)
-        Z = float(scen["Z"][u])
-        for k in range(n_nb):
-            while True:
-                dx, dy = (int(v) for v in rng.integers(-scen["max_shift"], scen["max_shift"] + 1, 2))
-                if dx or dy:
-                    break
-            j = u * n_nb + k
-            shift[j] = (dx, dy)
-            imgs[j] = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
-            T21 = np.eye(4)
-            T21[:3, 3] = -np.array([dx * Z / fx, dy * Z / fy, 0.0])
-            T2w = T21 @ T1w
-            Tkw[j] = T2w
-            R1w, t1w, R2w, t2w = T1w[:3, :3], T1w[:3, 3], T2w[:3, :3], T2w[:3, 3]
-            R12 = R1w @ R2w.T
-            t12 = -R12 @ t2w + t1w
-            tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
-            F12[j] = (Ki.T @ tx @ R12 @ Ki).astype(np.float32).reshape(9)
-    return dict(n_nb=n_nb, imgs=imgs, Tkw=Tkw, F12=F12, shift=shift)
+    out = pmap(_neighbours, [(scen["seed"], u, scen["canvas"][u], W, H, M, scen["max_shift"], n_nb, fx, fy, cx, cy,
+                              scen["Tlw"][u].astype(np.float64), float(scen["Z"][u])) for u in range(ns)])
+    return dict(n_nb=n_nb, n_scenes=ns, imgs=np.concatenate([o[0] for o in out]), Tkw=np.concatenate([o[1] for o in out]),
+                F12=np.concatenate([o[2] for o in out]), shift=np.concatenate([o[3] for o in out]))

@@ -5,8 +5,7 @@ Every function returns a list of mismatch descriptions (empty = parity holds) in
 report them in its JSON line and the tests can assert on the list.
 
 Bars (north_star): keypoints, descriptors, Frame members, map point assignments, outlier flags and
-counts bit-identical; poses / points within 1e-5 absolute of the oracle's float32 write-back (plus the float32 spacing of
-the value); identical Levenberg-Marquardt iteration and trial counts.
+counts bit-identical; poses / points within 1e-5 absolute of the oracle's float32 write-back (close()); identical Levenberg-Marquardt iteration and trial counts.
 """
 from __future__ import annotations
 
@@ -15,12 +14,30 @@ import numpy as np
 import oracle as O
 import chain as ochain
 
-TOL = 1e-5
+TOL = 1e-5          # north_star's bar for poses / points, absolute, literally
+WORST = {}          # worst |difference| seen per quantity since reset_worst() (reported by bench.py / the tests' messages)
 
 
-def close(a, b, tol=TOL):
-    a, b = np.asarray(a), np.asarray(b)
-    return bool((np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol + 2 * np.spacing(np.abs(b).astype(np.float32))).all())
+def reset_worst():
+    WORST.clear()
+
+
+def close(a, b, tol=TOL, key=None):
+    """|a - b| <= 1e-5 everywhere.  The one exception is a float32 value of magnitude >= 128: there the spacing of the float32
+    the reference writes back (Converter::toCvMat, Optimizer.cc:763-778) is 1.5e-5 or more, so ONE float32 step is the
+    resolution of the stored value -- allowed there and nowhere else (no synthetic case of this repo reaches it: the worst
+    observed differences are recorded in WORST and reported)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return True
+    d = np.abs(a - b)
+    if key is not None:
+        WORST[key] = max(WORST.get(key, 0.0), float(d.max()))
+    big = np.abs(b) >= 128.0
+    ok = d <= tol
+    if big.any():
+        ok = ok | (big & (d <= np.spacing(np.abs(b).astype(np.float32)).astype(np.float64)))
+    return bool(ok.all())
 
 
 def worst(a, b):
@@ -96,7 +113,7 @@ def chain_mismatches(snap, co: ChainOracle, positions):
             bad.append(f"{tag}: mvpMapPoints differ in {int((mp[b, :k] != w['mp_after_local']).sum())} features")
         if not (outl[b, :k] == w["outlier_2"]).all():
             bad.append(f"{tag}: mvbOutlier differs in {int((outl[b, :k] != w['outlier_2']).sum())} features")
-        if not close(T[b], w["Tcw_2"]):
+        if not close(T[b], w["Tcw_2"], key="mTcw"):
             bad.append(f"{tag}: mTcw off by {worst(T[b], w['Tcw_2']):.3g}")
     return bad
 
@@ -110,13 +127,14 @@ def lba_mismatches(got, want, tag="window"):
         bad.append(f"{tag}: iterations {tuple(got['iters'])}, oracle {tuple(want['iters'])}")
     if sum(got["trials"]) != want["trials"]:
         bad.append(f"{tag}: {sum(got['trials'])} LM trials, oracle {want['trials']}")
-    if not close(got["pose_Tcw"], want["pose_Tcw"]):
+    if not close(got["pose_Tcw"], want["pose_Tcw"], key="lba_pose"):
         bad.append(f"{tag}: poses off by {worst(got['pose_Tcw'], want['pose_Tcw']):.3g}")
-    if not close(got["point_xyz"], want["point_xyz"]):
+    if not close(got["point_xyz"], want["point_xyz"], key="lba_point"):
         bad.append(f"{tag}: points off by {worst(got['point_xyz'], want['point_xyz']):.3g}")
     if not (got["edge_outlier"] == want["edge_outlier"]).all():
         bad.append(f"{tag}: outlier sets differ in {int((got['edge_outlier'] != want['edge_outlier']).sum())} edges")
     c = want["chi2_trace"][-1] if len(want["chi2_trace"]) else 0.0
+    WORST["lba_final_chi2_rel"] = max(WORST.get("lba_final_chi2_rel", 0.0), abs(got["final_chi2"] - c) / max(c, 1e-30))
     if abs(got["final_chi2"] - c) > 1e-6 * max(c, 1e-30):
         bad.append(f"{tag}: final chi2 {got['final_chi2']!r}, oracle {c!r}")
     return bad

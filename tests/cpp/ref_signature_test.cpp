@@ -154,13 +154,25 @@ static void fill_keyframe(KeyFrame &K, const Bundle &B, const std::string &p)
     K.mnMaxX = (int)B[p + "max_x"].scalar<float>(); K.mnMaxY = (int)B[p + "max_y"].scalar<float>();
     K.mfGridElementWidthInv = B[p + "grid_w_inv"].scalar<float>();
     K.mfGridElementHeightInv = B[p + "grid_h_inv"].scalar<float>();
+    // KeyFrame::mGrid is protected (include/KeyFrame.h:223): the shim rebuilds the cell lists from mvKeysUn with Frame's static
+    // bounds (Frame::PosInGrid, src/Frame.cc:411-421).  Here: that rule reproduces the grid the bundle's generator made.
+    Frame::mnMinX = B[p + "min_x"].scalar<float>(); Frame::mnMinY = B[p + "min_y"].scalar<float>();
+    Frame::mnMaxX = B[p + "max_x"].scalar<float>(); Frame::mnMaxY = B[p + "max_y"].scalar<float>();
+    Frame::mfGridElementWidthInv = K.mfGridElementWidthInv;
+    Frame::mfGridElementHeightInv = K.mfGridElementHeightInv;
     const int32_t *goff = B[p + "grid_off"].as<int32_t>(), *gidx = B[p + "grid_idx"].as<int32_t>();
-    K.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
-    for (int ix = 0; ix < FRAME_GRID_COLS; ++ix)
-        for (int iy = 0; iy < FRAME_GRID_ROWS; ++iy) {
-            const int c = ix * FRAME_GRID_ROWS + iy;
-            for (int k = goff[c]; k < goff[c + 1]; ++k) K.mGrid[ix][iy].push_back((size_t)gidx[k]);
-        }
+    std::vector<std::vector<int32_t>> cells((size_t)FRAME_GRID_COLS * FRAME_GRID_ROWS);
+    for (int i = 0; i < n; ++i) {
+        const int px = (int)std::round((K.mvKeysUn[i].pt.x - Frame::mnMinX) * Frame::mfGridElementWidthInv);
+        const int py = (int)std::round((K.mvKeysUn[i].pt.y - Frame::mnMinY) * Frame::mfGridElementHeightInv);
+        if (px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS) continue;
+        cells[(size_t)px * FRAME_GRID_ROWS + py].push_back(i);
+    }
+    for (size_t c = 0; c < cells.size(); ++c) {
+        bool same = (int)cells[c].size() == goff[c + 1] - goff[c];
+        for (size_t k = 0; same && k < cells[c].size(); ++k) same = cells[c][k] == gidx[goff[c] + (int)k];
+        if (!same) throw std::runtime_error("fill_keyframe(" + p + "): Frame::PosInGrid does not reproduce the bundle's grid cell " + std::to_string(c));
+    }
 }
 
 // camera members from a projection bundle (prefix + R / t / Ow / fx ...)

@@ -108,7 +108,6 @@ public:
     std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;   // (const int in the reference, include/KeyFrame.h:198-201)
     float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
-    std::vector<std::vector<std::vector<size_t>>> mGrid;   // [64][48]
 
     cv::Mat GetPose() { return Tcw.clone(); }
     void SetPose(const cv::Mat &T) { Tcw = T.clone(); }
@@ -139,6 +138,10 @@ public:
     std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames;
     bool mbBad = false;
     int nErased = 0;
+
+protected:
+    // protected like the reference's (include/KeyFrame.h:206,223): the shim must not read it
+    std::vector<std::vector<std::vector<size_t>>> mGrid;   // [64][48]
 };
 
 inline void MapPoint::Replace(MapPoint *pMP)
