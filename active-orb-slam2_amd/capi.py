@@ -142,6 +142,8 @@ def lib():
             L.aos2_lba_solve.argtypes = [vp, vp, vp]
             L.aos2_lba_solve_batch.argtypes = [vp, vp, vp, ci]
             L.aos2_lba_debug_stop_at_poll.argtypes = [vp, ci]
+            L.aos2_lba_set_host_threads.argtypes = [vp, ci]
+            L.aos2_lba_last_program.argtypes = [vp, vp, vp]
             if hasattr(L, "aos2_pose_optimization"):
                 L.aos2_pose_optimization.argtypes = [vp, vp, vp, ci]
                 L.aos2_pose_optimization_last_device_ms.argtypes = [vp]
@@ -949,6 +951,15 @@ class LocalBA:
     def solve_prepared(self, prep):
         _check(self.L.aos2_lba_solve_batch(self.h, C.byref(prep["S"]), C.byref(prep["R"]), prep["n"]))
         return prep["R"]
+
+    def set_host_threads(self, n):
+        _check(self.L.aos2_lba_set_host_threads(self.h, int(n)))
+
+    def last_program(self):
+        """(trial slots enqueued for every window, host rounds) of the last solve"""
+        a, b = C.c_int32(), C.c_int32()
+        _check(self.L.aos2_lba_last_program(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def debug_stop_at_poll(self, poll):
         _check(self.L.aos2_lba_debug_stop_at_poll(self.h, int(poll)))

@@ -1935,6 +1935,24 @@ struct LbaCache {
     WindowPool pool;
 };
 
+// worker threads of a batch's per-window host work (structure build, staging): the handle's setting, else
+// AOS2_LBA_HOST_THREADS, else the host's cores shared among the ranks of the node (LOCAL_WORLD_SIZE / WORLD_SIZE as the
+// launcher exports them: 8 ranks x 2 handles x 32 threads would be 512 threads on 256 cores), at most 32, at most one per window
+static int lba_host_threads(const aos2_lba *s, int nw)
+{
+    int n = s->host_threads;
+    if (n <= 0)
+        if (const char *e = getenv("AOS2_LBA_HOST_THREADS")) n = atoi(e);
+    if (n <= 0) {
+        int ranks = 1;
+        const char *e = getenv("LOCAL_WORLD_SIZE");
+        if (!e) e = getenv("WORLD_SIZE");
+        if (e && atoi(e) > 1) ranks = atoi(e);
+        n = std::min(32, std::max(1, (int)std::thread::hardware_concurrency() / ranks));
+    }
+    return std::max(1, std::min(n, nw));
+}
+
 static bool build_pass(const aos2_lba_problem_t *p, Pass &S)
 {
     // (the vectors keep their storage from call to call: a 24 k-edge window holds ~1.5 MB of index lists, and fresh
@@ -2155,6 +2173,21 @@ void aos2_lba_destroy(aos2_lba_t *s)
     delete s;
 }
 
+int aos2_lba_set_host_threads(aos2_lba_t *s, int n)
+{
+    if (!s || n < 0) return AOS2_ERR_ARG;
+    s->host_threads = n;
+    return AOS2_OK;
+}
+
+int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *host_rounds)
+{
+    if (!s) return AOS2_ERR_ARG;
+    if (trial_slots) *trial_slots = s->last_trial_slots;
+    if (host_rounds) *host_rounds = s->last_host_rounds;
+    return AOS2_OK;
+}
+
 int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll)
 {
     if (!s || poll < 0) return AOS2_ERR_ARG;
@@ -2229,7 +2262,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     std::vector<Pass> &passes = static_cast<LbaCache *>(s->lba_cache)->passes;
     if ((int)passes.size() < nw) passes.resize(nw);
     WindowPool &pool = static_cast<LbaCache *>(s->lba_cache)->pool;
-    if (nw > 1) pool.start(std::max(1, std::min({nw, (int)std::thread::hardware_concurrency(), 32})));
+    if (nw > 1) pool.start(lba_host_threads(s, nw));
     auto for_windows = [&](auto &&fn) { pool.run(nw, fn); };
     std::vector<uint8_t> pass_ok(nw, 1);
     std::vector<int> bad_edge(nw, -1);
@@ -2477,6 +2510,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     }
     rg = std::make_unique<RoctxRange>("LocalBA::optimize(5) + outlier pass + optimize(10) + inlier check (one device program)");
     // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
+    s->last_trial_slots = (max_i1 > 0 ? max_i1 + 1 : 0) + (max_i2 > 0 ? max_i2 + 1 : 0);
+    s->last_host_rounds = 1;
     hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw, s->debug_stop_at_poll);
     if (max_i1 > 0) {
         enqueue_init();
@@ -2501,6 +2536,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         enqueue_transition();
         enqueue_init();
         for (int t = 0; t < 4; ++t) enqueue_trial();
+        s->last_trial_slots += 4;
+        s->last_host_rounds++;
         if ((st = finish())) return st;
     }
     lap("continuation");

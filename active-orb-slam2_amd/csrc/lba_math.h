@@ -375,6 +375,8 @@ struct aos2_lba {
     float last_pose_ms = 0;
     int debug_stop_at_poll = 0;         // test hook: treat pbStopFlag as set from this poll on (0 = off)
     void *lba_cache = nullptr;          // LocalBA: host-side structure buffers kept between calls (lba.hip: LbaCache)
+    int host_threads = 0;               // LocalBA: worker threads of the per-window host work (0 = default, aos2_lba_set_host_threads)
+    int last_trial_slots = 0, last_host_rounds = 0;   // the device program of the last solve (aos2_lba_last_program)
 };
 
 namespace aos2 {

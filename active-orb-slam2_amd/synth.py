@@ -711,6 +711,31 @@ def synth_lba_problem(seed: int, n_local: int = 20, n_fixed: int = 30, n_points:
                 fx=fx, fy=fy, cx=cx, cy=cy, bf=bf)
 
 
+def lba_window_mix(seed: int, n_windows: int):
+    """Parameters of `n_windows` DIFFERENT LocalBundleAdjustment windows like LocalMapping meets them (src/Optimizer.cc:457-505:
+    the local keyframes are the covisibility neighbourhood of the new keyframe, the fixed ones whatever else sees its points):
+    10-40 local keyframes, 0.5-1.5 times as many fixed ones, 3 000-9 000 candidate points (about 70 % of them end up in the
+    window: 2-6 k), 4-8 observations per point, 5-20 % gross outliers.  Keyword dicts for synth_lba_problem()."""
+    rng = np.random.default_rng(31000 + seed)
+    mix = []
+    for i in range(n_windows):
+        n_local = int(rng.integers(10, 41))
+        n_fixed = int(np.clip(round(n_local * rng.uniform(0.5, 1.5)), 2, 45))
+        mix.append(dict(seed=100000 + 1000 * seed + i, n_local=n_local, n_fixed=n_fixed, n_points=int(rng.integers(3000, 9001)),
+                        obs_per_point=int(rng.integers(4, 9)), outlier_frac=float(rng.uniform(0.05, 0.20))))
+    return mix
+
+
+def _lba_from_kwargs(kw):
+    return synth_lba_problem(**kw)
+
+
+def synth_lba_problems(mix):
+    """synth_lba_problem(**kw) for every kw of `mix` (worker processes when there are many: scenario.pmap)"""
+    from . import scenario
+    return scenario.pmap(_lba_from_kwargs, list(mix))
+
+
 def tcw_to_qt(Tcw16):
     """Converter::toSE3Quat (src/Converter.cc:37-47): float32 4x4 -> (qx qy qz qw tx ty tz) double."""
     T = np.asarray(Tcw16, dtype=np.float32).reshape(4, 4).astype(np.float64)

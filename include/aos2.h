@@ -613,6 +613,14 @@ int aos2_lba_solve(aos2_lba_t *s, const aos2_lba_problem_t *p, aos2_lba_result_t
  * host-side structure buffers and the worker threads of the per-window host work between calls. */
 int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2_lba_result_t *results,
                          int n_problems);
+/* Worker threads of a batch's per-window host work (index structures, staging); 0 = default: AOS2_LBA_HOST_THREADS, else
+ * min(32, host cores / ranks of the node (LOCAL_WORLD_SIZE or WORLD_SIZE)), never more than windows in the call.  No reference
+ * equivalent (g2o builds its structure on the calling thread, sparse_optimizer.cpp:354-372). */
+int aos2_lba_set_host_threads(aos2_lba_t *s, int n);
+/* The device program of the last solve of this handle: `trial_slots` = Levenberg-Marquardt trials enqueued for EVERY window of
+ * the call (iterations + 1 per optimisation, + 4 per continuation round; a window that needs fewer leaves its slots empty --
+ * the lock-step cost of a heterogeneous batch), `host_rounds` = times the host waited for the device (1 = no continuation). */
+int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *host_rounds);
 /* Test hook (no reference equivalent): the stop flag counts as set from its `poll`-th evaluation on (1 = the entry
  * check), as if another thread had set it at that moment; 0 switches the hook off.  Used with
  * aos2_lba_result_t.stop_poll to reproduce an asynchronous abort deterministically. */

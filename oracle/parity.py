@@ -76,6 +76,31 @@ class ChainOracle:
         return self.cache[u]
 
 
+def _precompute(self, us, threads=8):
+    """fill the cache for the distinct pairs `us` on `threads` host threads (one oracle extractor per thread; the C
+    functions hold no state and release the GIL)"""
+    todo = [u for u in us if u not in self.cache]
+    if threads <= 1 or len(todo) < 4:
+        for u in todo:
+            self.unique(u)
+        return
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    tl = threading.local()
+
+    def work(u):
+        co = getattr(tl, "co", None)
+        if co is None:
+            co = tl.co = ChainOracle(self.scen, self.tc, *self.th)
+            co.cache = self.cache
+        co.unique(u)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, todo))
+
+
+ChainOracle.precompute = _precompute
+
+
 def chain_snapshot(pkg, tc):
     """host copies of what TrackingChain.step() + wait() left on the device (taken before anything else reuses the batch)"""
     F = pkg.capi.Frames

@@ -42,8 +42,12 @@ def test_bench_contract_single_gpu(gpu):
     assert m["search_by_projection_last"] > 100 and m["inliers_2"] > 100 and d["config"]["local_ba_iterations"][0] > 0
     # the last timed step was checked against the oracle: every batch position and every LocalBA window of it
     pc = d["parity_checked"]
-    assert pc["ok"] is True and pc["n_mismatches"] == 0 and pc["frames"] >= 8 and pc["distinct_frame_pairs"] >= 8
-    assert pc["local_ba_windows"] >= 2 and pc["distinct_local_ba_problems"] >= 2
+    assert pc["ok"] is True and pc["n_mismatches"] == 0 and pc["frames"] == 32 and pc["distinct_frame_pairs"] == 32   # no tiling
+    assert pc["local_ba_windows"] == 4 and pc["distinct_local_ba_problems"] == 4   # every window a different problem
+    assert max(pc["worst_abs_diff"][k] for k in ("mTcw", "lba_pose", "lba_point")) <= 1e-5   # the worst difference is reported
+    ls = d["extra"]["local_ba_lock_step"]
+    assert ls["trial_slots_enqueued_per_window"] >= 17 and ls["slots_over_trials"] >= 1.0 and d["config"]["local_ba_mix"] == "heterogeneous"
+    assert len(d["config"]["frames_per_s_per_rank"]) == 1 and d["config"]["host_threads_per_rank"]["local_ba_workers_per_handle"] >= 1
     # ... and the keyframe legs: the BoW searches and LocalMapping's (keyframe, neighbour) searches
     assert pc["reference_keyframe_bow_frames"] >= 1 and pc["keyframe_neighbour_pairs"] >= 20
     assert {"search_for_triangulation", "fuse", "search_by_bow"} <= set(d["cpu_baseline"]["ms_per_frame"])
@@ -83,6 +87,8 @@ def test_bench_two_ranks_share_the_gpu(gpu, workload, launcher):
         cmd = [sys.executable] + tail
     d = _run(cmd, {"AOS2_BENCH_BACKEND": "gloo", "AOS2_BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["parity_checked"]["ok"] is True
+    if workload == "tum":
+        assert len(d["config"]["frames_per_s_per_rank"]) == 2
     if workload == "euroc8":
         assert d["parity_checked"]["frames"] == 8 and d["parity_checked"]["gathered_slots"] == 8
     if workload == "tum":
