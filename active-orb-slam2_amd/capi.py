@@ -80,6 +80,7 @@ def lib():
         if hasattr(L, "aos2_compute_stereo_matches"):
             L.aos2_compute_stereo_matches.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
             L.aos2_compute_stereo_matches_device.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
+            L.aos2_compute_stereo_matches_device_async.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
             L.aos2_compute_stereo_matches_last_device_ms.restype = cf
             L.aos2_compute_stereo_matches_last_device_ms.argtypes = [vp]
         if hasattr(L, "aos2_vocabulary_create"):
@@ -160,6 +161,7 @@ def lib():
             L.aos2_frames_fuse.argtypes = [vp, vp, ci, ci, vp, vp, cf, vp, vp]
             L.aos2_frames_device_ptr.restype = vp
             L.aos2_frames_build.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, ci, C.c_size_t, cf, cf, cf, cf, cf]
+            L.aos2_frames_build_stereo.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, vp, vp, cf, cf, cf, cf, cf]
             L.aos2_frames_set_pose.argtypes = [vp, vp]
             L.aos2_frames_set_distortion.argtypes = [vp, cf, cf, cf, cf, cf]
             L.aos2_frame_image_bounds.argtypes = [ci, ci, cf, cf, cf, cf, vp, vp]
@@ -457,6 +459,14 @@ def compute_stereo_matches_device(left: Extractor, right: Extractor, batch, d_kp
     _check(left.L.aos2_compute_stereo_matches_device(left.h, right.h, batch, V(d_kpl), V(d_dl), V(d_nl), V(d_kpr),
                                                      V(d_dr), V(d_nr), cap, mb, mbf, V(d_ur), V(d_depth)))
     return float(left.L.aos2_compute_stereo_matches_last_device_ms(left.h))
+
+
+def compute_stereo_matches_device_async(left: Extractor, right: Extractor, batch, d_kpl, d_dl, d_nl, d_kpr, d_dr, d_nr, cap,
+                                        mb, mbf, d_ur, d_depth):
+    """the same, enqueued behind both extractors' batches in flight (no host wait)"""
+    V = C.c_void_p
+    _check(left.L.aos2_compute_stereo_matches_device_async(left.h, right.h, batch, V(d_kpl), V(d_dl), V(d_nl), V(d_kpr),
+                                                           V(d_dr), V(d_nr), cap, mb, mbf, V(d_ur), V(d_depth)))
 
 
 def debug_octree_host(xs, ys, score, minX, maxX, minY, maxY, N):
@@ -1042,6 +1052,11 @@ class Frames:
     def build(self, extractor, d_kps, d_desc, d_n, w, h, d_depth, fx, fy, cx, cy, mbf, depth_stride=None, depth_image_stride=None):
         _check(self.L.aos2_frames_build(self.h, extractor.h, self.batch, d_kps, d_desc, d_n, self.cap, w, h, d_depth or None,
                                         depth_stride or w, depth_image_stride or w * h, fx, fy, cx, cy, mbf))
+
+    def build_stereo(self, extractor_left, d_kps, d_desc, d_n, w, h, d_u_right, d_depth_kp, fx, fy, cx, cy, mbf):
+        """Frame::Frame(imLeft, imRight, ...) after ExtractORB x 2 + ComputeStereoMatches (src/Frame.cc:57-113)"""
+        _check(self.L.aos2_frames_build_stereo(self.h, extractor_left.h, self.batch, d_kps, d_desc, d_n, self.cap, w, h, d_u_right, d_depth_kp,
+                                               fx, fy, cx, cy, mbf))
 
     def set_pose(self, d_Tcw):
         _check(self.L.aos2_frames_set_pose(self.h, d_Tcw))

@@ -1123,7 +1123,7 @@ static int stereo_check(const aos2_extractor *l, const aos2_extractor *r)
 
 static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int batch, const aos2_keypoint_t *d_kpl,
                       const uint8_t *d_dl, const int32_t *d_nl, const aos2_keypoint_t *d_kpr, const uint8_t *d_dr,
-                      const int32_t *d_nr, int cap, int max_n_left, float mb, float mbf, float *d_ur, float *d_depth)
+                      const int32_t *d_nr, int cap, int max_n_left, float mb, float mbf, float *d_ur, float *d_depth, bool sync = true)
 {
     int st;
     if ((st = l->st_sad.alloc((size_t)batch * cap))) return st;
@@ -1142,11 +1142,35 @@ static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int
     AOS2_HIP_CHECK(hipEventRecord(l->ev[0], l->stream));
     if ((st = launch_stereo(a, max_n_left, l->stream))) return st;
     AOS2_HIP_CHECK(hipEventRecord(l->ev[1], l->stream));
+    if (!sync) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamSynchronize(l->stream));
     float ms = 0;
     AOS2_HIP_CHECK(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
     l->stereo_ms = ms;
     return AOS2_OK;
+}
+
+// The stereo Frame constructor's pipeline without a host wait (src/Frame.cc:57-113: the two ExtractORB threads are joined, then
+// ComputeStereoMatches runs): left's first stream waits -- on the device -- for every stream of both extractors' batches in
+// flight, the stereo kernels are enqueued behind, and whatever orders itself behind `left` afterwards (aos2_extractor_stream_wait,
+// aos2_frames_build_stereo, aos2_extractor_wait) is ordered behind them.
+int aos2_compute_stereo_matches_device_async(aos2_extractor_t *left, aos2_extractor_t *right, int batch,
+                                             const aos2_keypoint_t *d_kp_left, const uint8_t *d_desc_left,
+                                             const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
+                                             const uint8_t *d_desc_right, const int32_t *d_n_right, int cap, float mb,
+                                             float mbf, float *d_u_right, float *d_depth)
+{
+    int st;
+    if ((st = stereo_check(left, right))) return st;
+    if (!d_kp_left || !d_desc_left || !d_n_left || !d_kp_right || !d_desc_right || !d_n_right || !d_u_right ||
+        !d_depth || cap <= 0 || batch <= 0 || batch > left->last_batch || batch > right->last_batch || !(mb > 0) || left == right) {
+        set_error("ComputeStereoMatches: bad argument");
+        return AOS2_ERR_ARG;
+    }
+    if ((st = bind_device(left->device))) return st;
+    if ((st = aos2_extractor_stream_wait(left, left->stream)) || (st = aos2_extractor_stream_wait(right, left->stream))) return st;
+    return stereo_run(left, right, 0, batch, d_kp_left, d_desc_left, d_n_left, d_kp_right, d_desc_right, d_n_right, cap,
+                      cap, mb, mbf, d_u_right, d_depth, false);
 }
 
 int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t *right, int batch,

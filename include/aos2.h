@@ -164,6 +164,15 @@ int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t 
                                        const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
                                        const uint8_t *d_desc_right, const int32_t *d_n_right,
                                        int cap, float mb, float mbf, float *d_u_right, float *d_depth);
+/* The same without a host wait: left's first stream waits on the device for both extractors' batches in flight
+ * (aos2_extractor_extract_batch_device_async -- the two ExtractORB threads of src/Frame.cc:103-109 joined), the kernels
+ * are enqueued behind; what orders itself behind `left` afterwards (aos2_extractor_stream_wait, aos2_frames_build_stereo,
+ * aos2_extractor_wait) runs behind them.  No device time is recorded. */
+int aos2_compute_stereo_matches_device_async(aos2_extractor_t *left, aos2_extractor_t *right, int batch,
+                                             const aos2_keypoint_t *d_kp_left, const uint8_t *d_desc_left,
+                                             const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
+                                             const uint8_t *d_desc_right, const int32_t *d_n_right,
+                                             int cap, float mb, float mbf, float *d_u_right, float *d_depth);
 /* device time (ms) of the kernels of the last ComputeStereoMatches call on `left` */
 float aos2_compute_stereo_matches_last_device_ms(const aos2_extractor_t *left);
 
@@ -703,6 +712,13 @@ int aos2_frames_wait(aos2_frames_t *f);
 int aos2_frames_build(aos2_frames_t *f, aos2_extractor_t *e, int batch, const aos2_keypoint_t *d_kps,
                       const uint8_t *d_desc, const int32_t *d_n, int cap, int w, int h, const float *d_depth,
                       int depth_stride, size_t depth_image_stride, float fx, float fy, float cx, float cy, float mbf);
+/* Frame::Frame(imLeft, imRight, ...)  src/Frame.cc:57-113, the part after the two ExtractORB calls and ComputeStereoMatches:
+ * the same members as aos2_frames_build with mvuRight / mvDepth taken from d_u_right / d_depth_kp ([batch][cap], the device
+ * outputs of aos2_compute_stereo_matches_device[_async] on `e_left`, which may still be in flight: the call orders itself
+ * behind `e_left` on the device). */
+int aos2_frames_build_stereo(aos2_frames_t *f, aos2_extractor_t *e_left, int batch, const aos2_keypoint_t *d_kps,
+                             const uint8_t *d_desc, const int32_t *d_n, int cap, int w, int h, const float *d_u_right,
+                             const float *d_depth_kp, float fx, float fy, float cx, float cy, float mbf);
 /* mDistCoef (k1 k2 p1 p2 k3) for the following aos2_frames_build calls: with k1 != 0 (the reference's test, src/Frame.cc:435,
  * :467) mvKeysUn = cv::undistortPoints(mvKeys, K, mDistCoef, noArray(), K) and the image bounds are the undistorted corners
  * (Frame::UndistortKeyPoints / ComputeImageBounds :433-493); the depth map is still read at mvKeys (:678-683).  Default: 0. */
