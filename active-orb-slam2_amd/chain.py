@@ -80,15 +80,27 @@ class TrackingChain:
         self.d_local = t.from_numpy(np.ascontiguousarray(m["local"][idx])).to(self.dev)
         self.last.wait()
 
-    def step(self):
-        """enqueue the chain for the batch"""
-        B, W, H, cap, s = self.B, self.W, self.H, self.cap, self.scen
-        c = self.cur
-        c.set_pose(self.d_guess.data_ptr())   # mVelocity * mLastFrame.mTcw is known before the image: its copy runs beside the extraction
+    def enqueue_extract(self):
+        """ExtractORB (src/Frame.cc:276-282) for the batch, asynchronous"""
+        B, W, H, cap = self.B, self.W, self.H, self.cap
         self.ex.extract_batch_device_async(self.d_cur.data_ptr(), B, W, H, W, W * H, self.d_kps.data_ptr(), self.d_desc.data_ptr(), cap,
                                            self.d_n.data_ptr())
-        c.build(self.ex, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), W, H, self.d_depth.data_ptr(),
-                float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+
+    def enqueue_build(self):
+        """the rest of Frame::Frame(imGray, imDepth, ...) (src/Frame.cc:116-170), ordered behind the extraction on the device"""
+        W, H, s = self.W, self.H, self.scen
+        self.cur.build(self.ex, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), W, H, self.d_depth.data_ptr(),
+                       float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+
+    def wait_extract(self):
+        self.ex.wait()
+
+    def step(self):
+        """enqueue the chain for the batch"""
+        c = self.cur
+        c.set_pose(self.d_guess.data_ptr())   # mVelocity * mLastFrame.mTcw is known before the image: its copy runs beside the extraction
+        self.enqueue_extract()
+        self.enqueue_build()
         c.SearchByProjectionLast(self.last, self.table, self.th_last, mono=False, check_orientation=True, d_nmatches=self.d_nm[0].data_ptr())
         c.PoseOptimization(self.table, self.d_nm[1].data_ptr())
         c.discard_outliers()
@@ -98,6 +110,48 @@ class TrackingChain:
     def wait(self):
         self.cur.wait()
         self.ex.wait()
+
+
+class StereoTrackingChain(TrackingChain):
+    """The same chain behind the STEREO Frame constructor (src/Frame.cc:57-113; Examples/Stereo/stereo_kitti.cc:108-117 per frame):
+    both eyes' ORBextractor::operator() on a handle of their own (the two ExtractORB threads, :103-109), Frame::ComputeStereoMatches
+    (:495-669) behind both on the device, then the Frame members with mvuRight / mvDepth taken from it.  The scenario is
+    tracking_scenario(..., stereo=True)."""
+
+    def __init__(self, scen: dict, device: int = 0, **kw):
+        super().__init__(scen, device=device, **kw)
+        t, B, cap = self.torch, self.B, self.cap
+        self.ex_r = capi.Extractor(nfeatures=scen["nfeatures"], device=device)
+        self.d_right = t.from_numpy(scen["right_cur"][scen["index"]]).to(self.dev)
+        self.r_kps = t.zeros((B, cap, 7), dtype=t.float32, device=self.dev)
+        self.r_desc = t.zeros((B, cap, 32), dtype=t.uint8, device=self.dev)
+        self.r_n = t.zeros((B,), dtype=t.int32, device=self.dev)
+        self.d_ur = t.zeros((B, cap), dtype=t.float32, device=self.dev)
+        self.d_dp = t.zeros((B, cap), dtype=t.float32, device=self.dev)
+        self.mbf = np.float32(scen["mbf"])
+        self.mb = np.float32(self.mbf / np.float32(scen["fx"]))   # mb = mbf / fx (src/Frame.cc:86)
+
+    def enqueue_extract(self):
+        B, W, H, cap = self.B, self.W, self.H, self.cap
+        super().enqueue_extract()
+        self.ex_r.extract_batch_device_async(self.d_right.data_ptr(), B, W, H, W, W * H, self.r_kps.data_ptr(), self.r_desc.data_ptr(), cap,
+                                             self.r_n.data_ptr())
+        capi.compute_stereo_matches_device_async(self.ex, self.ex_r, B, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(),
+                                                 self.r_kps.data_ptr(), self.r_desc.data_ptr(), self.r_n.data_ptr(), cap, self.mb, self.mbf,
+                                                 self.d_ur.data_ptr(), self.d_dp.data_ptr())
+
+    def enqueue_build(self):
+        W, H, s = self.W, self.H, self.scen
+        self.cur.build_stereo(self.ex, self.d_kps.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), W, H, self.d_ur.data_ptr(),
+                              self.d_dp.data_ptr(), float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))
+
+    def wait_extract(self):
+        self.ex.wait()
+        self.ex_r.wait()
+
+    def wait(self):
+        super().wait()
+        self.ex_r.wait()
 
 
 class ReferenceKeyFrameBoW:

@@ -100,6 +100,7 @@ struct LbaWin {
     int n_part;                      // workgroups of a k_points launch for this window
     double *ldlt;                    // factorisation scratch of the global-memory variant
     int npad, ldlt_lds;
+    int hs_ld;                       // leading dimension of Hs: 6 np, or npad when the reduced system is factorised in place (beyond LDS)
     LmState *st;
     const int32_t *abort_word;       // mapped host memory: the forwarded pbStopFlag
     float *out_Tcw, *out_xyz;        // Converter::toCvMat / toCvMat(Vector3d) write-back (Optimizer.cc:763-778)
@@ -171,6 +172,13 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
         for (int d = 0; d < 3; ++d) W.err[3 * (size_t)i + d] = 0.0;
         W.e_robust[i] = 1;
         W.e_level1[i] = 0;
+    }
+    if (blockIdx.x == 0 && !W.ldlt_lds) {   // reduced system factorised in place: the identity tail of the padded matrix, once
+        const int n = 6 * W.np, npad = W.npad;
+        for (int q = threadIdx.x; q < (npad - n) * npad; q += 256) {
+            const int r = n + q / npad, c = q % npad;
+            W.Hs[(size_t)r * npad + c] = r == c ? 1.0 : 0.0;
+        }
     }
     if (blockIdx.x == 0) {   // the state record (1.8 KB): zeroed by the workgroup, not by one thread
         LmState *st = W.st;
@@ -1150,8 +1158,8 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
             v += W.Hpp[36 * (size_t)i1 + e];
             if (r == c) v += lambda;
         }
-        W.Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] = v;
-        if (!diag) W.Hs[(size_t)(6 * i2 + c) * n6 + 6 * i1 + r] = v;
+        W.Hs[(size_t)(6 * i1 + r) * W.hs_ld + 6 * i2 + c] = v;
+        if (!diag) W.Hs[(size_t)(6 * i2 + c) * W.hs_ld + 6 * i1 + r] = v;
     } else if (e < 42 && diag)
         W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
 }
@@ -1198,32 +1206,46 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 #else
 #define LDLT_T(...)
 #endif
-__global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ wins)
+// kGlob: the same algorithm for a reduced system beyond LDS (more than 21 free keyframes: npad > 128) -- the matrix lives in the
+// device memory (in place in Wn.Hs, which k_schur wrote with leading dimension npad: 240 x 240 doubles at 40 free keyframes,
+// L2-resident), everything else (the panel's L D,
+// the vectors, T) stays in LDS.  What one wave stores and another wave of the workgroup loads afterwards is ordered by
+// __syncthreads() (the compute unit's vector cache is write-through and shared by the workgroup's waves); inside wave 0 by
+// wave_sync() = completion of the wave's outstanding stores.  The pivot chain of the diagonal blocks never touches memory, so
+// what the variant pays is one device-memory round trip per phase instead of an LDS one (measured: DESIGN.md 5.3).
+typedef double __attribute__((address_space(1))) gdouble_t;
+#ifndef AOS2_LDLT_TILE_BATCH
+#define AOS2_LDLT_TILE_BATCH 4
+#endif
+constexpr int kTileBatch = AOS2_LDLT_TILE_BATCH;
+template <bool kGlob>
+__device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
 {
     constexpr int NT = 512, NW = 8;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_fail;
-    const LbaWin &Wn = wins[blockIdx.x];
-    if (!Wn.st->run || Wn.np == 0 || !Wn.ldlt_lds) return;
     const int n = 6 * Wn.np, npad = Wn.npad;
     const double lambda = Wn.st->lambda;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // odd leading dimensions: column-direction accesses (MFMA operands, substitution) fall on distinct banks
-    const int ld = npad + 1, lw = 17;
-    double *M = sm;                              // npad x ld: lower triangle = the matrix, then L; upper triangle of the diagonal blocks = T
-    double *W = M + (size_t)npad * ld;           // npad x lw: L * D of the current panel
+    const int ld = kGlob ? npad : npad + 1, lw = 17;   // (device scratch: rows on 128-byte boundaries)
+    using mptr_t = std::conditional_t<kGlob, gdouble_t *, double *>;
+    // npad x ld: lower triangle = the matrix, then L.  kGlob: k_schur wrote the matrix straight into this layout (Wn.hs_ld = npad,
+    // identity tail set once by k_prepare; the tail stays an identity under the factorisation) -- factorised in place
+    mptr_t M = kGlob ? (mptr_t)Wn.Hs : (mptr_t)sm;
+    double *W = kGlob ? sm : sm + (size_t)npad * ld;   // npad x lw: L * D of the current panel
     double *dvec = W + (size_t)npad * lw;        // npad: D
     double *rdv = dvec + npad;                   // npad: 1 / D
     double *rv = rdv + npad;                     // npad: residual of the forward substitution, then y, then D^-1 y, then s
     double *xs = rv + npad;                      // npad: solution
     double *Tb = xs + npad;                      // 2 x 16 x 17: T_k^T of the current / next panel
+    double *Dst = Tb + 2 * 16 * 17;              // kGlob: 16 x 17, the next diagonal block on its way from the trailing update to wave 0's rows
     LDLT_T(long long tD = 0, tP = 0, tU = 0, t_a = 0; const long long t_begin = __builtin_amdgcn_s_memtime();)
     if (tid == 0) s_fail = 0;
     // load (identity-padded), lower BLOCK triangle only -- row r needs its columns up to the end of its diagonal block,
     // nothing reads the blocks above the diagonal -- as element pairs (n is even, rows are 16-byte aligned): block row R
     // holds 16 x 8 (R + 1) pairs, 64 R (R + 1) pairs lie before it.  9 independent 16-byte global loads in flight per
     // thread before the stores: a 128 x 128 system is one round.
-    {
+    if (!kGlob) {
         const int nbr = npad >> 4, npairs = 64 * nbr * (nbr + 1);
         auto where = [&](int q, int &r, int &c) {
             int R = (int)((__fsqrt_rn(1.0f + (float)q * 0.0625f) - 1.0f) * 0.5f);
@@ -1262,9 +1284,15 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
     __syncthreads();
     LDLT_T(const long long t_loaded = __builtin_amdgcn_s_memtime();)
     auto wave_sync = [] {   // LDS writes of this wave visible to its other lanes (one wave: LDS operations execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (kGlob) {   // ... and its stores to the device scratch complete before its other lanes load them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     };
     // D_k (wave 0 only; lanes >= 16 mirror lanes 0..15, their results are not stored).  Measured single-wave latencies
     // (tools/microbench/f64_latency.hip): dependent f64 FMA 9 cycles, IEEE division 67, v_rcp_f64 + 2 Newton steps 34,
@@ -1281,14 +1309,20 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         e = __builtin_fma(-d, rd, 1.0);
         return __builtin_fma(rd, e, rd);
     };
-    auto diag_block = [&](int k0) {
+    auto diag_block = [&](int k0, bool staged) {
         LDLT_T(const long long q0 = __builtin_amdgcn_s_memtime();)
         const int li = lane & 15;
         double *colbuf = xs;   // 16 doubles of scratch (xs is unused until the backward pass)
         double *Tk = Tb + ((k0 >> 4) & 1) * (16 * 17);
         double row[16];
+        if (kGlob && staged) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) row[c] = M[(size_t)(k0 + li) * ld + k0 + c];
+            for (int c = 0; c < 16; ++c) row[c] = Dst[li * 17 + c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = M[(size_t)(k0 + li) * ld + k0 + c];
+        }
+        double dsave = 1.0;
         double cur = rv[k0 + li];
         bool bad = false;
         // T = L_kk^-1 (unit lower triangular), lane c owns column c, built alongside the factorisation: eliminating column j
@@ -1306,6 +1340,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const double ci = row[j];
+            if (kGlob) dsave = li == j ? ci : dsave;   // the pivot of this lane's row (what is stored at M[k0 + li][k0 + li] below)
             if (j < 15) colbuf[li] = ci;
             const double dj = readlane_f64(ci, j);
             if (dj == 0.0 || dj != dj) bad = true;
@@ -1326,7 +1361,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             // diagonal are scratch that nothing reads; lanes >= 16 store the same values to the same places; column c of T
             // = row c of the panel's T^T buffer, dense: zeros above the diagonal, ones on it), so the live registers shrink
             // with j instead of holding 16 finished entries of each array to the end
-            M[(size_t)(k0 + li) * ld + k0 + j] = li == j ? ci : lij;
+            M[(size_t)(k0 + li) * ld + k0 + j] = li == j ? ci : lij;   // (lanes >= 16 repeat the stores of lanes 0..15: a predicate here costs 85 registers and spills)
             Tk[li * 17 + j] = t[j];
             cur = li > j ? __builtin_fma(-lij, yj, cur) : cur;   // forward substitution inside the block
             __builtin_amdgcn_sched_barrier(0);   // keep the pivots apart (hoisting the later pivots' reads only costs spills)
@@ -1339,14 +1374,14 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         rv[k0 + li] = cur;   // y of this block
         wave_sync();
         {
-            const double d = M[(size_t)(k0 + li) * ld + k0 + li];
+            const double d = kGlob ? dsave : (double)M[(size_t)(k0 + li) * ld + k0 + li];
             dvec[k0 + li] = d;
             rdv[k0 + li] = rcp_newton(d);   // (the same operations as in the loop: the same bits)
         }
         LDLT_T(const long long q3 = __builtin_amdgcn_s_memtime(); dt3 += q3 - q2;)
         LDLT_T(dt4 += __builtin_amdgcn_s_memtime() - q3;)
     };
-    if (wave == 0) diag_block(0);
+    if (wave == 0) diag_block(0, false);
     __syncthreads();
     LDLT_T(const long long t_d0 = __builtin_amdgcn_s_memtime();)
     const int nb = npad >> 4;
@@ -1379,7 +1414,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         for (int i = k0 + 16 + tid; i < npad; i += NT) {
             double l[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) l[c] = M[(size_t)i * ld + k0 + c];
+            for (int c = 0; c < 16; ++c) l[c] = kGlob ? W[(size_t)i * lw + c] * rdv[k0 + c] : (double)M[(size_t)i * ld + k0 + c];   // (L = W D^-1: the product the panel stored, the same bits)
             double ri = rv[i];
 #pragma unroll
             for (int c = 0; c < 16; ++c) ri -= l[c] * rv[k0 + c];
@@ -1389,24 +1424,37 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         // ---- U_k: trailing update with f64 MFMA on the lower-triangle tiles (I >= J > kb); tile 0 = (kb+1, kb+1) goes
         // to wave 0, which then factorises that block while the other waves finish the update
         const int ntiles = m * (m + 1) / 2;
-        auto tile = [&](int t) {
+        auto tile_at = [&](int t, int &I0, int &J0) {
             int ii = 0, rem = t;
             while (rem > ii) {  // row-major lower triangle: row ii holds ii+1 tiles
                 rem -= ii + 1;
                 ++ii;
             }
-            const int I0 = (kb + 1 + ii) << 4, J0 = (kb + 1 + rem) << 4;
+            I0 = (kb + 1 + ii) << 4;
+            J0 = (kb + 1 + rem) << 4;
+        };
+        // B[k][j] = L[J0 + j][k0 + k]: from the matrix, or (kGlob) as the product W D^-1 the panel stored there -- the same bits, from LDS
+        auto lval = [&](int J0, int kk) -> double {
+            return kGlob ? W[(size_t)(J0 + col) * lw + 4 * kk + rq] * rdv[k0 + 4 * kk + rq] : (double)M[(size_t)(J0 + col) * ld + k0 + 4 * kk + rq];
+        };
+        auto tile = [&](int t) {
+            int I0, J0;
+            tile_at(t, I0, J0);
             double4_t acc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const double av = -W[(size_t)(I0 + col) * lw + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
-                const double bv = M[(size_t)(J0 + col) * ld + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lval(J0, kk), acc, 0, 0, 0);
             }
+            if (kGlob && t == 0) {   // the next diagonal block: to wave 0's rows through LDS, not through the device scratch
 #pragma unroll
-            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
+                for (int r = 0; r < 4; ++r) Dst[(rq + 4 * r) * 17 + col] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
+            }
         };
         if (wave == 0) {
             if (ntiles > 0) {
@@ -1415,8 +1463,32 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
                 tile(0);
                 wave_sync();
                 LDLT_T(const long long t_d = __builtin_amdgcn_s_memtime();)
-                diag_block(k0 + 16);
+                diag_block(k0 + 16, true);
                 LDLT_T(tD += __builtin_amdgcn_s_memtime() - t_d;)
+            }
+        } else if (kGlob) {
+            // kTileBatch tiles of a wave in flight together: a tile is one round trip to the device scratch, not an LDS one
+            for (int t = wave; t < ntiles; t += kTileBatch * (NW - 1)) {
+                int I0[kTileBatch], J0[kTileBatch];
+                double4_t acc[kTileBatch];
+#pragma unroll
+                for (int u = 0; u < kTileBatch; ++u) tile_at(min(t + u * (NW - 1), ntiles - 1), I0[u], J0[u]);
+#pragma unroll
+                for (int u = 0; u < kTileBatch; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[u][r] = M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col];
+#pragma unroll
+                for (int u = 0; u < kTileBatch; ++u)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double av = -W[(size_t)(I0[u] + col) * lw + 4 * kk + rq];
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lval(J0[u], kk), acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < kTileBatch; ++u)
+                    if (t + u * (NW - 1) < ntiles)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col] = acc[u][r];
             }
         } else {
             for (int t = wave; t < ntiles; t += NW - 1) tile(t);
@@ -1432,11 +1504,13 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
     // ---- backward substitution: x = L^-T D^-1 y; per block x_k = T_k^T s_k, then the rows above take L_k^T x_k
     for (int i = tid; i < npad; i += NT) rv[i] = rv[i] * rdv[i];
     __syncthreads();
-    auto back_block = [&](int k0) {   // wave 0: L_kk^T x_k = s_k, k descending inside the block
+    auto back_load = [&](int k0, double (&lcol)[16]) {   // L[j][i] for j > i of the diagonal block (the rest is unused)
         const int li = lane & 15;
-        double lcol[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) lcol[j] = M[(size_t)(k0 + j) * ld + k0 + li];   // L[j][i] for j > i (the rest is unused)
+        for (int j = 0; j < 16; ++j) lcol[j] = M[(size_t)(k0 + j) * ld + k0 + li];
+    };
+    auto back_block = [&](int k0, const double (&lcol)[16]) {   // wave 0: L_kk^T x_k = s_k, k descending inside the block
+        const int li = lane & 15;
         double cur = rv[k0 + li];
 #pragma unroll
         for (int j = 15; j >= 1; --j) {
@@ -1445,7 +1519,11 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
         }
         xs[k0 + li] = cur;
     };
-    if (wave == 0) back_block((nb - 1) << 4);
+    if (wave == 0) {
+        double lc[16];
+        back_load((nb - 1) << 4, lc);
+        back_block((nb - 1) << 4, lc);
+    }
     __syncthreads();
     for (int kb = nb - 1; kb > 0; --kb) {
         const int k0 = kb << 4;
@@ -1460,9 +1538,11 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
             rv[i] = acc;
         };
         if (wave == 0) {
+            double lc[16];
+            back_load(k0 - 16, lc);   // (independent of x: requested together with the rows' entries -- one round trip, not two, when the matrix is in device memory)
             if (lane < 16) update_row(k0 - 16 + lane);
             wave_sync();
-            back_block(k0 - 16);
+            back_block(k0 - 16, lc);
         } else {
             for (int i = tid - 64; i < k0 - 16; i += NT - 64) update_row(i);
         }
@@ -1486,290 +1566,20 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
     }
 }
 
-template <bool kLds>
-__global__ __launch_bounds__(kLds ? 256 : 1024) void k_ldlt_solve(const LbaWin *__restrict__ wins)
+__global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ wins)
 {
-    constexpr int NT = kLds ? 256 : 1024, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
-    if (!Wn.st->run || Wn.np == 0 || (Wn.ldlt_lds != 0) != kLds) return;
-    const int n = 6 * Wn.np, npad = Wn.npad;
-    const double lambda = Wn.st->lambda;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // odd leading dimensions: column-direction accesses (panel rows, MFMA operands, substitution)
-    // then fall on distinct LDS banks instead of one
-    const int ld = npad + 1, lw = 17;
-    // kLds: the pointers below derive from the LDS array only, so the compiler emits ds_* accesses
-    // (a runtime-selected pointer would turn every access into a slow flat_* instruction)
-    double *M = kLds ? sm : Wn.ldlt;                     // npad x ld (lower triangle is used)
-    double *W = M + (size_t)npad * ld;                   // npad x lw
-    double *dvec = W + (size_t)npad * lw;                // npad
-    __shared__ int s_fail;
-    if (tid == 0) s_fail = 0;
-    // load (identity-padded): 8 independent global loads in flight per thread before the stores
-    for (int r0 = tid >> 5; r0 < npad; r0 += 8 * (NT / 32)) {
-        for (int c = tid & 31; c < npad; c += 32) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 + (NT / 32) * u;
-                v[u] = (r < n && c < n) ? Wn.Hs[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = r0 + (NT / 32) * u;
-                if (r < npad) M[(size_t)r * ld + c] = v[u];
-            }
-        }
-    }
-    __syncthreads();
-    const int nb = npad >> 4;
-    for (int kb = 0; kb < nb; ++kb) {
-        const int k0 = kb << 4;
-        // ---- (1) diagonal block, wave 0: lane i < 16 keeps row i of the block in registers; the
-        // pivot and the column entries travel through v_readlane (SGPR broadcast), no LDS round trips
-        if (wave == 0) {
-            double row[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) row[c] = lane < 16 ? M[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double dj = readlane_f64(row[j], j);
-                if (dj == 0.0 || dj != dj) bad = true;
-                if (!bad) {
-                    const double ci = row[j];
-                    const double lij = ci / dj;
-#pragma unroll
-                    for (int k = j + 1; k < 16; ++k) {
-                        const double ck = readlane_f64(ci, k);
-                        if (lane > j && k <= lane) row[k] -= lij * ck;
-                    }
-                    if (lane > j) row[j] = lij;
-                    if (lane == 0) dvec[k0 + j] = dj;
-                }
-            }
-            if (bad && lane == 0) s_fail = 1;
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c <= lane) M[(size_t)(k0 + lane) * ld + k0 + c] = row[c];
-            }
-        }
-        __syncthreads();
-        if (s_fail) break;
-        // ---- (2) panel below the block
-        for (int i = k0 + 16 + tid; i < npad; i += NT) {
-            double w[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double sacc = M[(size_t)i * ld + k0 + c];
-#pragma unroll
-                for (int m = 0; m < c; ++m) sacc -= w[m] * M[(size_t)(k0 + c) * ld + k0 + m];
-                w[c] = sacc;
-                M[(size_t)i * ld + k0 + c] = sacc / dvec[k0 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) W[(size_t)i * lw + c] = w[c];
-        }
-        __syncthreads();
-        // ---- (3) trailing update with f64 MFMA, lower-triangle tiles (I >= J > kb)
-        const int m = nb - kb - 1;
-        const int ntiles = m * (m + 1) / 2;
-        for (int t = wave; t < ntiles; t += NW) {
-            int ii = 0, rem = t;
-            while (rem > ii) {  // row-major lower triangle: row ii holds ii+1 tiles
-                rem -= ii + 1;
-                ++ii;
-            }
-            const int I0 = (kb + 1 + ii) << 4, J0 = (kb + 1 + rem) << 4;
-            double4_t acc;
-            const int col = lane & 15, rq = lane >> 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double av = -W[(size_t)(I0 + col) * lw + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
-                const double bv = M[(size_t)(J0 + col) * ld + k0 + 4 * kk + rq];    // B[k][j] = L[J0+j][k0+k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
-        }
-        __syncthreads();
-    }
-    if (s_fail) {
-        if (tid == 0) Wn.scal[3] = 0.0;
-        return;
-    }
-    if (kLds) {
-        // ---- solve L D L^T x = bs by wave 0; element i lives in lane i % 64, slot i / 64 (npad <= 128).
-        // Blocked by the 16-column panels: the 16 x 16 triangle of a panel is solved among its 16 lanes with v_readlane
-        // broadcasts (its L entries fetched once), then every other row takes its 16-term update from 16 independent
-        // LDS reads.  Per element the subtractions happen in the same order as the column-by-column loop (k ascending
-        // forward, descending backward), so the result is bit-identical to it.
-        if (wave == 0) {
-            double xv[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int i = lane + 64 * s;
-                xv[s] = i < n ? Wn.bs[i] : 0.0;
-            }
-            for (int kb = 0; kb < nb; ++kb) {  // forward: y_i -= L[i][k] y_k, k ascending
-                const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
-                const bool in_blk = li >= 0 && li < 16;
-                double lrow[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < li) ? M[(size_t)(k0 + li) * ld + k0 + c] : 0.0;
-                double cur = slot == 0 ? xv[0] : xv[1], yb[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    yb[j] = readlane_f64(cur, lane0 + j);
-                    if (in_blk && li > j) cur -= lrow[j] * yb[j];
-                }
-                if (slot == 0) xv[0] = cur; else xv[1] = cur;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int i = lane + 64 * s;
-                    if (i >= k0 + 16 && i < npad) {
-                        double l[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) l[j] = M[(size_t)i * ld + k0 + j];
-                        double acc = xv[s];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) acc -= l[j] * yb[j];
-                        xv[s] = acc;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int i = lane + 64 * s;
-                if (i < npad) xv[s] /= dvec[i];
-            }
-            for (int kb = nb - 1; kb >= 0; --kb) {  // backward: x_i -= L[k][i] x_k, k descending
-                const int k0 = kb << 4, slot = k0 >> 6, lane0 = k0 & 63, li = lane - lane0;
-                const bool in_blk = li >= 0 && li < 16;
-                double lcol[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > li) ? M[(size_t)(k0 + j) * ld + k0 + li] : 0.0;
-                double cur = slot == 0 ? xv[0] : xv[1], xb[16];
-#pragma unroll
-                for (int j = 15; j >= 0; --j) {
-                    xb[j] = readlane_f64(cur, lane0 + j);
-                    if (in_blk && li < j) cur -= lcol[j] * xb[j];
-                }
-                if (slot == 0) xv[0] = cur; else xv[1] = cur;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int i = lane + 64 * s;
-                    if (i < k0) {
-                        double l[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) l[j] = M[(size_t)(k0 + j) * ld + i];
-                        double acc = xv[s];
-#pragma unroll
-                        for (int j = 15; j >= 0; --j) acc -= l[j] * xb[j];
-                        xv[s] = acc;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int i = lane + 64 * s;
-                if (i < n) Wn.x[i] = xv[s];
-                if (i < n) M[i] = xv[s];   // the factor is dead: its first row carries x to the pose update
-            }
-            if (lane == 0) Wn.scal[3] = 1.0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < Wn.np) {   // (np <= 21 here) VertexSE3Expmap::oplusImpl + the poses' scale terms
-                double upd[6];
-                for (int i = 0; i < 6; ++i) {
-                    upd[i] = M[6 * lane + i];
-                    Wn.tmp[6 * lane + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * lane + i]);
-                }
-                se3_oplus_fast(upd, Wn.pose + 7 * (size_t)Wn.hpose[lane]);
-            }
-        }
-    } else {
-        // any size: the vector lives in LDS (sm[npad]); per 16-column panel the triangle is solved by 16 lanes of wave 0,
-        // the remaining rows are updated by all threads (same per-element order of subtractions as above)
-        double *xs = sm;
-        for (int i = tid; i < npad; i += NT) xs[i] = i < n ? Wn.bs[i] : 0.0;
-        __syncthreads();
-        for (int kb = 0; kb < nb; ++kb) {
-            const int k0 = kb << 4;
-            if (wave == 0) {
-                const bool in_blk = lane < 16;
-                double lrow[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) lrow[c] = (in_blk && c < lane) ? M[(size_t)(k0 + lane) * ld + k0 + c] : 0.0;
-                double cur = in_blk ? xs[k0 + lane] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double yj = readlane_f64(cur, j);
-                    if (in_blk && lane > j) cur -= lrow[j] * yj;
-                }
-                if (in_blk) xs[k0 + lane] = cur;
-            }
-            __syncthreads();
-            for (int i = k0 + 16 + tid; i < npad; i += NT) {
-                double acc = xs[i];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc -= M[(size_t)i * ld + k0 + j] * xs[k0 + j];
-                xs[i] = acc;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < npad; i += NT) xs[i] /= dvec[i];
-        __syncthreads();
-        for (int kb = nb - 1; kb >= 0; --kb) {
-            const int k0 = kb << 4;
-            if (wave == 0) {
-                const bool in_blk = lane < 16;
-                double lcol[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) lcol[j] = (in_blk && j > lane) ? M[(size_t)(k0 + j) * ld + k0 + lane] : 0.0;
-                double cur = in_blk ? xs[k0 + lane] : 0.0;
-#pragma unroll
-                for (int j = 15; j >= 0; --j) {
-                    const double xj = readlane_f64(cur, j);
-                    if (in_blk && lane < j) cur -= lcol[j] * xj;
-                }
-                if (in_blk) xs[k0 + lane] = cur;
-            }
-            __syncthreads();
-            for (int i = tid; i < k0; i += NT) {
-                double acc = xs[i];
-#pragma unroll
-                for (int j = 15; j >= 0; --j) acc -= M[(size_t)(k0 + j) * ld + i] * xs[k0 + j];
-                xs[i] = acc;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < n; i += NT) Wn.x[i] = xs[i];
-        if (tid == 0) Wn.scal[3] = 1.0;
-    }
+    if (!Wn.st->run || Wn.np == 0 || !Wn.ldlt_lds) return;
+    ldlt_body<false>(Wn, sm);
 }
-
-// global-memory variant only: VertexSE3Expmap::oplusImpl + the poses' scale terms
-__global__ __launch_bounds__(64) void k_update_poses(const LbaWin *__restrict__ wins)
+// (a kernel of its own: both forms in one kernel cost the LDS form 25 spilled registers)
+__global__ __launch_bounds__(512) void k_ldlt_dev(const LbaWin *__restrict__ wins)
 {
-    const LbaWin &W = wins[blockIdx.y];
-    if (!W.st->run || W.ldlt_lds || W.scal[3] == 0.0) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= W.np) return;
-    const double lambda = W.st->lambda;
-    double upd[6];
-    for (int i = 0; i < 6; ++i) {
-        upd[i] = W.x[6 * p + i];
-        W.tmp[6 * p + i] = upd[i] * (lambda * upd[i] + W.b[6 * p + i]);
-    }
-    double *Tp = W.pose + 7 * (size_t)W.hpose[p], *Tbk = W.bk + 7 * (size_t)W.hpose[p];
-    for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
-    se3_oplus_fast(upd, Tp);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const LbaWin &Wn = wins[blockIdx.x];
+    if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds) return;
+    ldlt_body<true>(Wn, sm);
 }
 
 // Between the two optimisations (Optimizer.cc:667-710), one launch (the bDoMore check of :663-666 was made where the first
@@ -2322,14 +2132,17 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.Hpl = B.take(144 * (S.pl_k.size() + 1));
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
-        l.Hs = B.take(8 * n6 * n6 + 8); l.bs = B.take(8 * n6 + 8);
+        l.npad = (int)((n6 + 15) & ~(size_t)15);
+        {
+            const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + 4 * (size_t)l.npad + 2 * 16 * 17 + 16) * 8;
+            l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
+        }
+        // (beyond LDS the reduced system is factorised in place: k_schur writes it with leading dimension npad)
+        l.Hs = B.take(l.ldlt_lds ? 8 * n6 * n6 + 8 : 8 * (size_t)l.npad * l.npad + 8, 256); l.bs = B.take(8 * n6 + 8);
         l.tmp = B.take(8 * n6 + 8);
         l.n_part = std::max(1, (int)((S.nl + lm_per_block - 1) / lm_per_block));
         l.scal = B.take(64); l.part = B.take(16 * (size_t)std::max(S.nl, 1) + 8);
-        l.npad = (int)((n6 + 15) & ~(size_t)15);
-        const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + 4 * (size_t)l.npad + 2 * 16 * 17 + 16) * 8;
-        l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
-        l.ldlt = B.take(l.ldlt_lds ? 8 : ldlt_bytes);
+        l.ldlt = B.take(8);
     }
     const size_t o_res = B.take(0);
     for (int i = 0; i < nw; ++i) {
@@ -2426,6 +2239,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
         W.n_part = l.n_part;
         W.ldlt = (double *)(base + l.ldlt); W.npad = l.npad; W.ldlt_lds = l.ldlt_lds;
+        W.hs_ld = l.ldlt_lds ? 6 * S.np : l.npad;
         W.st = (LmState *)(base + l.st);
         W.abort_word = d_abort + i;
         W.out_Tcw = (float *)(base + l.out_Tcw); W.out_xyz = (float *)(base + l.out_xyz);
@@ -2474,13 +2288,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
         if (mx_np) hipLaunchKernelGGL(k_schur, dim3(xcd_affine_grid(mx_blk, nw)), dim3(kSchurThreads), 0, q, dw, (int)mx_blk, nw, schur_bpu, xcd_group(nw));
+        if (any_glob)   // (first: the longer of the two)
+            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
-        }
-        if (any_glob) {
-            hipLaunchKernelGGL(k_ldlt_solve<false>, dim3(nw), dim3(1024), (size_t)mx_npad_glob * sizeof(double), q, dw);
-            hipLaunchKernelGGL(k_update_poses, dim3(blocks(mx_np, 64), nw), dim3(64), 0, q, dw);
         }
         enqueue_points(1);   // + the LM decision in its last workgroup
         enqueue_lin(0);

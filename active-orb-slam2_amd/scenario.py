@@ -41,9 +41,10 @@ def pmap(fn, items, workers=None):
 
 def _scene(a):
     """one distinct (LastFrame, CurrentFrame, older view) scene; every draw from the scene's own generator"""
-    seed, u, W, H, M, max_shift, fx, fy = a
+    seed, u, W, H, M, max_shift, fx, fy, bf, stereo = a
     rng = np.random.default_rng([77000 + seed, u])
-    canvas8 = synth.synth_image(seed * 1000 + u, W + 2 * M, H + 2 * M)
+    DMAX = 64 if stereo else 0   # stereo: the canvas extends to the right by the largest disparity
+    canvas8 = synth.synth_image(seed * 1000 + u, W + 2 * M + DMAX, H + 2 * M)
     canvas = canvas8.astype(np.float32)
     dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
     ex, ey = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
@@ -51,6 +52,14 @@ def _scene(a):
     cur = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx:M + dx + W] + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
     old = np.clip(np.rint(canvas[M + ey:M + ey + H, M + ex:M + ex + W] + rng.normal(0, 1.0, (H, W))), 0, 255).astype(np.uint8)
     Z = rng.uniform(1.5, 3.0)
+    right = None
+    if stereo:
+        # a rectified stereo camera (baseline bf / fx) in front of the plane: a feature at x in the left image appears at x - D in
+        # the right one, D = bf / Z -- a whole number of pixels here (the plane's depth is chosen that way; the sub-pixel
+        # refinement of ComputeStereoMatches then works on pixel noise only)
+        D = int(rng.integers(6, DMAX - 3))
+        Z = float(bf) / D
+        right = np.clip(np.rint(canvas[M + dy:M + dy + H, M + dx + D:M + dx + D + W] + rng.normal(0, 1.5, (H, W))), 0, 255).astype(np.uint8)
     holes = np.zeros((2, 12, 4), np.int32)   # invalid-depth holes: monocular observations (mvuRight < 0)
     for d in range(2):
         for k in range(12):
@@ -68,17 +77,20 @@ def _scene(a):
     E = np.eye(4)
     E[:3, :3] = _rot(rng.normal(size=3), rng.normal(0, 0.002))
     E[:3, 3] = rng.normal(0, 2.0 * Z / float(fx), 3)
-    return dict(canvas=canvas8, last=last, cur=cur, old=old, Z=Z, holes=holes, shift=(dx, dy), shift_old=(ex, ey), Tlw=T, Tcw=Tcw, Tguess=E @ Tcw)
+    return dict(canvas=canvas8, last=last, cur=cur, old=old, right=right, Z=Z, holes=holes, shift=(dx, dy), shift_old=(ex, ey), Tlw=T, Tcw=Tcw, Tguess=E @ Tcw)
 
 
-def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10, dist=None):
-    """Images, depth maps and poses of `batch` (LastFrame, CurrentFrame) pairs (`n_unique` distinct ones, tiled)."""
+def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | None = None, max_shift: int = 10, dist=None, stereo: bool = False):
+    """Images, depth maps and poses of `batch` (LastFrame, CurrentFrame) pairs (`n_unique` distinct ones, tiled).
+    stereo: every CurrentFrame also has a right image (`right_cur`; the stereo Frame constructor, src/Frame.cc:57-113, takes
+    mvuRight / mvDepth from ComputeStereoMatches instead of a depth image; the LastFrame / older views keep their depth maps:
+    they are the scenario's given state)."""
     c = synth.CONFIGS[cfg]
     W, H = c["w"], c["h"]
     fx, fy, cx, cy, mbf = (np.float32(c[k]) for k in ("fx", "fy", "cx", "cy", "bf"))
     M = 2 * max_shift + 4
     nu = min(batch, n_unique or batch)
-    sc = pmap(_scene, [(seed, u, W, H, M, max_shift, float(fx), float(fy)) for u in range(nu)])
+    sc = pmap(_scene, [(seed, u, W, H, M, max_shift, float(fx), float(fy), float(mbf), bool(stereo)) for u in range(nu)])
     last, cur, old = (np.stack([q[k] for q in sc]) for k in ("last", "cur", "old"))
     depth_cur = np.zeros((nu, H, W), np.float32)
     depth_last = np.zeros((nu, H, W), np.float32)
@@ -95,7 +107,7 @@ def tracking_scenario(seed: int, batch: int, cfg: str = "tum", n_unique: int | N
     # dist: mDistCoef (k1 k2 p1 p2 k3) the frames are declared to have (the images themselves are not warped: a parity scenario)
     return dict(seed=seed, margin=M, max_shift=max_shift, dist=None if dist is None else np.asarray(dist, np.float32), cfg=cfg, w=W, h=H, fx=fx, fy=fy, cx=cx, cy=cy, mbf=mbf, nfeatures=c["nfeatures"], batch=batch, n_unique=nu, index=idx,
                 last=last, cur=cur, old=old, depth_cur=depth_cur, depth_last=depth_last, shift=shift, shift_old=shift_old, Z=Z,
-                canvas=[q["canvas"] for q in sc],
+                canvas=[q["canvas"] for q in sc], stereo=bool(stereo), right_cur=np.stack([q["right"] for q in sc]) if stereo else None,
                 Tlw=Tlw.astype(np.float32), Tcw_true=Tcw.astype(np.float32), Tcw_guess=Tguess.astype(np.float32))
 
 

@@ -170,10 +170,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # (0.4 s of timed region: 20 steps = 80 ms left single host hiccups of a few ms visible as +-8 %)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (512 x 0.95 MB of pyramid = 490 MB: beyond the 256 MiB Infinity Cache)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: tum 512 -- 512 x 0.95 MB of pyramid = 490 MB: beyond the 256 MiB "
+                                                          "Infinity Cache; kitti 256 stereo pairs -- 512 x 1.44 MB)")
     ap.add_argument("--frames-per-keyframe", type=int, default=8, help="one LocalBA window per this many frames")
-    ap.add_argument("--workload", default="tum", choices=["tum", "euroc8"],
-                    help="tum = the BASELINE composite (default); euroc8 = BASELINE configs[4]: 8 EuRoC stereo frames per step "
+    ap.add_argument("--workload", default="tum", choices=["tum", "kitti", "euroc8"],
+                    help="tum = the BASELINE composite (default); kitti = BASELINE configs[2] + [3]: KITTI 00 stereo 1241x376, 2000 features -- "
+                         "both eyes' extraction on two handles, ComputeStereoMatches, the tracking chain, per keyframe ComputeBoW + SearchByBoW "
+                         "and one 20-keyframe LocalBA window; euroc8 = BASELINE configs[4]: 8 EuRoC stereo frames per step "
                          "sharded over the ranks (strong scaling), gathered to rank 0 every step")
     ap.add_argument("--lba-mix", default="heterogeneous", choices=["heterogeneous", "homogeneous"],
                     help="LocalBA windows of the timed step: heterogeneous = every window a different problem (10-40 local keyframes, "
@@ -238,9 +241,13 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    cfg = pkg.synth.CONFIGS["tum"]
+    KITTI = args.workload == "kitti"
+    cfg_name = "kitti" if KITTI else "tum"
+    cfg = pkg.synth.CONFIGS[cfg_name]
     W, H, NF = cfg["w"], cfg["h"], cfg["nfeatures"]
-    B = args.batch
+    B = args.batch or (256 if KITTI else 512)
+    if KITTI:
+        args.no_extra = True   # (the untimed `extra` rows are measured on the TUM workload)
 
     # ---- scenario: B (LastFrame, CurrentFrame) pairs per step, ALL DISTINCT (no tiling), a different set for every pipeline
     # (step in flight) and every rank, resident in HBM.  AOS2_BENCH_UNIQUE=n tiles n distinct pairs instead (round 3's line: 32).
@@ -248,7 +255,7 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     NPIPE = max(1, int(os.environ.get("AOS2_BENCH_INFLIGHT", "2")))   # steps in flight (each with its own buffers)
     n_unique = max(1, min(B, int(os.environ.get("AOS2_BENCH_UNIQUE", str(B)))))
-    real = pkg.datasets.dataset_from_env("tum")   # $TUM_FR1_DESK: the recorded frames instead of the generator's
+    real = None if KITTI else pkg.datasets.dataset_from_env("tum")   # $TUM_FR1_DESK: the recorded frames instead of the generator's
     if real:
         n_unique = min(n_unique, 32)
         pr = pkg.datasets.tum_pairs(real[1], n_unique, step=7 + rank)
@@ -256,11 +263,12 @@ def main():
         scen["dist"] = np.asarray([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)   # Examples/RGB-D/TUM1.yaml
         scens = [scen] * NPIPE
     else:
-        scens = [pkg.scenario.tracking_scenario(100 + rank + 1000 * j, B, cfg="tum", n_unique=n_unique) for j in range(NPIPE)]
+        scens = [pkg.scenario.tracking_scenario(100 + rank + 1000 * j, B, cfg=cfg_name, n_unique=n_unique, stereo=KITTI) for j in range(NPIPE)]
         scen = scens[0]
     base = scen["cur"]
     N_LOCAL = 1500
-    pipes = [pkg.chain.TrackingChain(scens[j], device=local_rank, n_local=N_LOCAL) for j in range(NPIPE)]
+    Chain = pkg.chain.StereoTrackingChain if KITTI else pkg.chain.TrackingChain   # kitti: the stereo Frame constructor (src/Frame.cc:57-113)
+    pipes = [Chain(scens[j], device=local_rank, n_local=N_LOCAL) for j in range(NPIPE)]
     # The extractor cuts a batch into chunks on streams of their own so that a chunk's latency-bound octree overlaps the
     # VALU-bound kernels of the others (best for the extractor alone: 3 chunks).  In the composite the other step in flight
     # and the LocalBA batch provide that overlap already, and more streams only contend: measured 53.4 k frames/s with 3
@@ -268,6 +276,8 @@ def main():
     if "AOS2_CHUNKS" not in os.environ:
         for pp in pipes:
             pp.ex.set_chunks(1)
+            if KITTI:
+                pp.ex_r.set_chunks(1)
     ex = pipes[0].ex
     cap = pipes[0].cap
     # ---- per keyframe (every `frames_per_keyframe` frames) the front part of Tracking::TrackReferenceKeyFrame (Tracking.cc:858-866):
@@ -283,7 +293,7 @@ def main():
     # its map points into each of them and of the scene's local map points into the keyframe (SearchInNeighbors, :461-518); on the same
     # side thread as the BoW leg
     # (the neighbour views come from the generator's scenes: with recorded frames the leg is left out and the line says so)
-    NO_KFW = NO_BOW or bool(real) or os.environ.get("AOS2_BENCH_NO_KEYFRAME_WORK") == "1"
+    NO_KFW = NO_BOW or bool(real) or KITTI or os.environ.get("AOS2_BENCH_NO_KEYFRAME_WORK") == "1"
     N_NB = 10
     kfws = [] if NO_KFW else [pkg.chain.KeyFrameWork(pp, voc_nodes, n_bow, n_nb=N_NB) for pp in pipes]
     bow_pool = ThreadPoolExecutor(NPIPE)
@@ -301,7 +311,11 @@ def main():
     n_win = max(1, B // fpk)
     lba_hom_unique = [pkg.synth.synth_lba_problem(10 * rank + i, n_points=8000) for i in range(min(4, n_win))]
     lba_hom = [lba_hom_unique[i % len(lba_hom_unique)] for i in range(n_win)]
-    if args.lba_mix == "heterogeneous":
+    if KITTI:   # BASELINE configs[3]: the 20-keyframe window of SURVEY 8(d) (20 local + 30 fixed keyframes, ~24 k stereo edges), every one a different problem
+        lba_mix = [dict(seed=200000 + 1000 * rank + i, n_local=20, n_fixed=30, n_points=8000) for i in range(n_win)]
+        lba_unique = pkg.synth.synth_lba_problems(lba_mix)
+        lba_probs = lba_unique
+    elif args.lba_mix == "heterogeneous":
         lba_mix = pkg.synth.lba_window_mix(rank, n_win)
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)
         lba_probs = lba_unique
@@ -445,7 +459,7 @@ def main():
             sync()
             return (time.perf_counter() - t0) / n2
         saved, saved_kfw, n2 = list(bows), list(kfws), max(10, min(args.steps, 50))
-        if lba_mix is not None and not NO_LBA:   # the same steps with round 3's LocalBA windows (SURVEY 8(d) size, 4 distinct, tiled)
+        if lba_mix is not None and not NO_LBA and not KITTI:   # the same steps with round 3's LocalBA windows (SURVEY 8(d) size, 4 distinct, tiled)
             saved_prep = list(lba_prep)
             lba_prep[:] = [h.prepare_batch(lba_hom) for h in lbas]
             dt_hom = short_run(n2)
@@ -468,11 +482,17 @@ def main():
     p0, sc = pipes[0], scen
     W_, H_ = W, H
     composite_stage = {}
-    composite_stage["extract"] = timed(lambda: p0.ex.extract_batch_device(p0.d_cur.data_ptr(), B, W_, H_, W_, W_ * H_, p0.d_kps.data_ptr(),
-                                                                         p0.d_desc.data_ptr(), cap, p0.d_n.data_ptr()))
+    if KITTI:
+        def _one_eye():
+            p0.ex.extract_batch_device_async(p0.d_cur.data_ptr(), B, W_, H_, W_, W_ * H_, p0.d_kps.data_ptr(), p0.d_desc.data_ptr(), cap, p0.d_n.data_ptr())
+            p0.ex.wait()
+        composite_stage["extract_left_eye_alone"] = timed(_one_eye)
+    def _extract():   # (kitti: both eyes on their handles + ComputeStereoMatches behind them)
+        p0.enqueue_extract()
+        p0.wait_extract()
+    composite_stage["extract_both_eyes_and_stereo_matches" if KITTI else "extract"] = timed(_extract)
     def _build():
-        p0.cur.build(p0.ex, p0.d_kps.data_ptr(), p0.d_desc.data_ptr(), p0.d_n.data_ptr(), W_, H_, p0.d_depth.data_ptr(), float(sc["fx"]),
-                     float(sc["fy"]), float(sc["cx"]), float(sc["cy"]), float(sc["mbf"]))
+        p0.enqueue_build()
         p0.cur.set_pose(p0.d_guess.data_ptr())
         p0.cur.wait()
     composite_stage["frame_build"] = timed(_build)
@@ -767,11 +787,11 @@ def main():
     else:
         lba_desc = "%d keyframes, %d points, %d edges: SURVEY 8(d); 4 distinct problems tiled" % (lba_probs[0]["n_poses"], lba_probs[0]["n_points"], lba_probs[0]["n_edges"])
     if rank == 0:
-        P = 950_532  # sum of level pixels for 640x480
+        P = 1_444_097 if KITTI else 950_532  # sum of level pixels for 1241x376 / 640x480
         fast_bytes = P * B
         achieved = fast_bytes / (fast_ms * 1e-3) / 1e9
         out = {
-            "metric": "frames/sec (extract+match+localBA) TUM 640x480",
+            "metric": "stereo frames/sec (extract x2 + stereo match + track + BoW + localBA) KITTI 1241x376" if KITTI else "frames/sec (extract+match+localBA) TUM 640x480",
             "value": world * B * args.steps / dt,
             "unit": "frames/s",
             "n_gpus": world,
@@ -783,7 +803,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 (extract, match) + f64 (PoseOptimization, LocalBA)",
             "data": "real (TUM fr1_desk frames from $TUM_FR1_DESK; LocalBA windows synthetic)" if real else "synthetic",
-            "config": {"workload": "TUM 640x480 RGB-D, 1000 features, 8 levels, scale 1.2, FAST 20/7: per frame ORBextractor::operator() + "
+            "config": {"workload": ("BASELINE configs[2] + [3]: KITTI 00 stereo 1241x376, 2000 features, 8 levels, scale 1.2, FAST 20/7 (Examples/Stereo/KITTI00-02.yaml): "
+                                    "per stereo frame both eyes' ORBextractor::operator() on two handles + Frame::ComputeStereoMatches + " if KITTI else
+                                    "TUM 640x480 RGB-D, 1000 features, 8 levels, scale 1.2, FAST 20/7: per frame ORBextractor::operator() + ") +
                                    "Frame::Frame + SearchByProjection(Current, Last) + PoseOptimization + SearchLocalPoints(%d local map "
                                    "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "
                                    "SearchByBoW(reference keyframe, frame), %s"
@@ -825,6 +847,7 @@ def main():
             "extra": extra,
         }
         # the other two streaming kernels of the step, from the un-chunked stage times (HIP events of the library)
+        pyr_bytes = 2.0 * P - W * H - round(W / 3.583181) * round(H / 3.583181)   # every level but the last read once, every level but the first written once (tum: 1.57e6)
         out["roofline_other"] = [
             {"kernel": "describe_kernel", "bound": "hbm", "kernel_ms": stage["describe"],
              "algorithmic_bytes_per_launch": float(n_kp.sum()) * (749 + 512 + 60),
@@ -833,14 +856,16 @@ def main():
              "note": "integer-VALU bound as well (VALUBusy ~87 %, profiles/r01_pmc_sq_busy.csv): ~585 VALU instructions per keypoint "
                      "(7x7 blur of the 43x37 patch = 55 %, 512 steered samples = 20 %, IC_Angle + exact sin/cos = 20 %)"},
             {"kernel": "resize_level_kernel x7", "bound": "hbm", "kernel_ms": stage["pyramid"],
-             "algorithmic_bytes_per_launch": 1.57e6 * B,
-             "achieved": 1.57e6 * B / (stage["pyramid"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-             "frac": 1.57e6 * B / (stage["pyramid"] * 1e-3) / 1e9 / 8000.0,
+             "algorithmic_bytes_per_launch": pyr_bytes * B,
+             "achieved": pyr_bytes * B / (stage["pyramid"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+             "frac": pyr_bytes * B / (stage["pyramid"] * 1e-3) / 1e9 / 8000.0,
              "note": "seven dependent launches (level k is resized from level k-1); the large levels run at 3.2-3.5 TB/s, the small "
                      "ones are launch / tail bound; VALUBusy 35 %"}]
         # counters of the same kernel from the committed rocprofv3 --pmc passes (B = 512 > Infinity Cache; calibrated against
         # 1 GiB copies): NOT measured in this run -- `roofline.traffic` stays null; the profiled figures are given beside it
         try:
+            if KITTI:
+                raise LookupError("the committed PMC passes are of the TUM workload")
             cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
             pc = json.load(open(cpath))
             fc, cal = pc["fast_cells_kernel"], pc["calibration"]

@@ -41,6 +41,17 @@ def frame_from_extraction(kps, desc, depth_img, scen, scale_factors, inv_sigma2)
                 grid_w_inv=gwi, grid_h_inv=ghi, grid_off=goff, grid_idx=gi, f_mp_state=np.zeros(max(len(kx), 1), np.uint8))
 
 
+def frame_from_stereo(oe_l, oe_r, kps, desc, kps_r, desc_r, scen, scale_factors, inv_sigma2):
+    """Frame::Frame(imLeft, imRight, ...) after the two ExtractORB calls (src/Frame.cc:57-113): the members of
+    frame_from_extraction() with mvuRight / mvDepth from ComputeStereoMatches (:495-669; oe_l / oe_r hold the two pyramids)"""
+    f = frame_from_extraction(kps, desc, np.zeros((scen["h"], scen["w"]), np.float32), scen, scale_factors, inv_sigma2)
+    mbf = np.float32(scen["mbf"])
+    mb = np.float32(mbf / np.float32(scen["fx"]))
+    ur, dp, _ = O.compute_stereo_matches(oe_l, oe_r, kps, desc, kps_r, desc_r, mb, mbf)
+    f["u_right"], f["depth"] = ur.copy(), dp.copy()
+    return f
+
+
 def _pose_problem(f, mp, table, Tcw, scen):
     idx = np.nonzero(mp >= 0)[0]
     rows = mp[idx]

@@ -52,6 +52,7 @@ class ChainOracle:
     def __init__(self, scen, tc, th_last=15.0, th_local=3.0, nnratio_local=0.8):
         self.scen, self.tc = scen, tc
         self.oe = O.Extractor(nfeatures=scen["nfeatures"])
+        self.oe_r = O.Extractor(nfeatures=scen["nfeatures"]) if scen.get("stereo") else None
         self.th = (th_last, th_local, nnratio_local)
         self.cache = {}
 
@@ -61,9 +62,20 @@ class ChainOracle:
         import time
         scen, tc = self.scen, self.tc
         t0 = time.perf_counter()
-        okps, odesc = self.oe.extract(scen["cur"][u])
-        t1 = time.perf_counter()
-        f = ochain.frame_from_extraction(okps, odesc, scen["depth_cur"][u], scen, self.oe.scale_factors, self.oe.inv_sigma2)
+        if self.oe_r is not None:
+            # the stereo Frame constructor: the two eyes are extracted by two threads (src/Frame.cc:103-109), then ComputeStereoMatches
+            import threading
+            res = {}
+            thr = threading.Thread(target=lambda: res.__setitem__("r", self.oe_r.extract(scen["right_cur"][u])))
+            thr.start()
+            okps, odesc = self.oe.extract(scen["cur"][u])
+            thr.join()
+            t1 = time.perf_counter()
+            f = ochain.frame_from_stereo(self.oe, self.oe_r, okps, odesc, res["r"][0], res["r"][1], scen, self.oe.scale_factors, self.oe.inv_sigma2)
+        else:
+            okps, odesc = self.oe.extract(scen["cur"][u])
+            t1 = time.perf_counter()
+            f = ochain.frame_from_extraction(okps, odesc, scen["depth_cur"][u], scen, self.oe.scale_factors, self.oe.inv_sigma2)
         t2 = time.perf_counter()
         if timing is not None:
             timing["extract"] = timing.get("extract", 0.0) + t1 - t0
