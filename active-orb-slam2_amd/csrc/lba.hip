@@ -91,6 +91,9 @@ struct LbaWin {
     // Schur complement by items: item = (landmark, free-pose edges ka <= kb of it), ranked by (pose, pose) block in
     // upper-triangular order, landmark order inside a block (build_schur_items)
     const int32_t *it_ka, *it_kb, *it_l, *blk_off;
+    // k_schur's packed units (build_schur_units): rows of <= 16 items of ONE off-diagonal block, 16 rows per workgroup
+    const int32_t *sr_o0, *sr_info, *sr_ij;   // per row: first item; items | row-in-block << 8 | rows-of-block << 16; i1 | i2 << 16
+    int n_srows;
     double *Hpl;                     // per free-keyframe edge, DENSE by its position in the pl list (a landmark's blocks are
                                      // neighbours): the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
@@ -1014,28 +1017,6 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
     }
 }
 
-// Window-to-XCD affinity for the per-window kernels: workgroups go round-robin to the 8 XCDs in linear-id order, each XCD
-// with an L2 of its own (4 MB -- about one window's working set).  1-D grid, id = g * (8 * nblk) + blk * 8 + (w % 8) with
-// w = 8 g + id % 8 (for groups of 8 windows): window w always runs on XCD w % 8, and an XCD finishes the windows of group g before it starts those
-// of group g + 1, so the records a window's workgroups share (its Hpl blocks are read by ~2 items each per observation)
-// are served by that L2 instead of by every XCD's.
-struct WinBlock {
-    int w, blk;
-};
-// windows in flight together: a multiple of 8 (group / 8 per XCD; measured 8 / 16 / 32 on 32 windows: 50 / 47.7 / 48.3 us); a call
-// with fewer windows than that runs them all together (the affinity needs groups of 8)
-static inline int xcd_group(int nw) { return nw >= 16 ? 16 : nw >= 8 ? 8 : nw; }
-__device__ __forceinline__ WinBlock xcd_affine(int nblk, int nw, int group)
-{
-    const int id = (int)blockIdx.x, per = group * nblk, g = id / per, r = id - g * per;
-    WinBlock o;
-    o.blk = r / group;
-    o.w = group * g + (r - o.blk * group);
-    if (o.w >= nw) o.blk = -1;
-    return o;
-}
-static inline unsigned xcd_affine_grid(size_t nblk, int nw) { const int G = xcd_group(nw); return (unsigned)(nblk * G * (size_t)((nw + G - 1) / G)); }
-
 // ---- Schur complement (block_solver.hpp:379-432), one 256-thread workgroup per (pose, pose) block of the upper block
 // triangle.  The host ranks the items -- (landmark, free-pose edges ka <= kb of it) -- by their block, landmark order
 // inside a block (build_schur_items).  Thread j of the block takes the items j, j + 256, ...: (Hll + lambda I)^-1 of the
@@ -1046,111 +1027,65 @@ static inline unsigned xcd_affine_grid(size_t nblk, int nw) { const int G = xcd_
 // threads per block: measured (one 12 k-edge window / one 24 k-edge window / 32 windows of 24 k edges, whole solve):
 // 64: 1.88 / 2.27 / 4.42 ms, 128: 1.74 / 1.92 / 4.35 ms, 256: 1.71 / 1.87 / 4.78 ms (most off-diagonal blocks hold < 128 items)
 constexpr int kSchurThreads = 256;
-// units of a window for k_schur: one per diagonal block, one per `bpu` off-diagonal blocks (4 when the windows of the call
-// fill the device: a wave per block; 1 for a single window: latency, the idle waves cost nothing on an empty device)
-static inline size_t schur_units(size_t np, int bpu) { return np + (np * (np - 1) / 2 + bpu - 1) / bpu; }
+// Work units of k_schur, one 256-thread workgroup each (build_schur_units ranks them, the host lays the units of all windows of
+// the call out as ONE task list -- no grid padded to the largest window, no workgroup that only finds out it has nothing to do):
+//   DIAG  a diagonal (pose, pose) block: every observation of a keyframe, hundreds to thousands of items, strided over the
+//         256 threads, sums through workgroup_sum_k256;
+//   BIG   an off-diagonal block of more than 256 items, the same way;
+//   PACK  16 ROWS of 16 lanes; a row holds up to 16 consecutive items of ONE off-diagonal block (a block of n items takes
+//         ceil(n / 16) consecutive rows of one unit), one item per thread: the covisible landmarks of most keyframe pairs are a
+//         few dozen, often fewer than 16 -- one wave per block left 40-85 % of the lanes idle and a window of 40 free keyframes
+//         cost 235 workgroups.  Row sums by DPP, then a block's rows are added in row order: for a block of up to 64 items
+//         exactly the sums (and bits) of the one-wave-per-block form.
+constexpr int kSchurDiag = 0, kSchurBig = 1, kSchurPack = 2;
+struct SchurTask {
+    int32_t w;      // window (-1: padding of the XCD interleave)
+    int32_t code;   // kind << 28 | argument (DIAG: i; BIG: block rank; PACK: first row)
+};
 
-// A 256-thread workgroup takes one unit: a DIAGONAL block -- every observation of a keyframe, ~450 items: all four waves,
-// items strided over the 256 threads, sums through workgroup_sum_k256 -- or four OFF-DIAGONAL blocks, one per wave -- the
-// covisible landmarks of a keyframe pair, mostly < 64 items: a wave by itself, its sums through its own rows of the LDS
-// buffer, no workgroup barrier.  (With one 128-thread workgroup per block the second wave of nearly every off-diagonal
-// block held registers for nothing and the diagonal ones needed four rounds: 50 -> 46 us on 32 windows; a variant that fetched the wave's 128 Hpl blocks cooperatively into LDS -- the kernel is bound by
-// the texture path's request rate, 23 requests of 16 bytes per item: without the a-side blocks it takes 33 us -- ran at 98-112 us:
-// more dependent round trips per round and register spills.)  The diagonal
-// units come first in the grid: the long ones must not be dispatched last.
-__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, int mx_units, int nw, int bpu, int group)
+__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, bool diag, bool with_b, int n6, double (&acc)[42])
 {
-    constexpr int NT = kSchurThreads;
-    __shared__ double red[(NT / 16) * 43];
-    const WinBlock wb = xcd_affine(mx_units, nw, group);
-    if (wb.blk < 0) return;
-    const LbaWin &W = wins[wb.w];
-    // (every dependent load is a round trip of its own on the workgroup's critical path: the state words and the block's
-    // item range are requested together, before the branch on the first of them)
-    const int run = W.st->run;
-    const double lambda = W.st->lambda;
-    const int np = W.np, n6 = 6 * np, noff = np * (np - 1) / 2;
-    const bool diag = wb.blk < np;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // unit -> (i1 <= i2) -> blk, the block's rank in the upper triangle, row-major (the order of blk_off)
-    int i1, i2;
-    if (diag)
-        i1 = i2 = wb.blk;
-    else {
-        if (noff == 0) return;   // (a window with at most one free keyframe has no off-diagonal block: nothing to clamp to)
-        int rem = min((wb.blk - np) * bpu + wave, noff - 1);
-        i1 = 0;
-        while (rem >= np - 1 - i1) {
-            rem -= np - 1 - i1;
-            ++i1;
-        }
-        i2 = i1 + 1 + rem;
-    }
-    const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
-    const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
-    if (!run) return;
-    if (!diag && (wave >= bpu || (wb.blk - np) * bpu + wave >= noff)) return;   // (whole waves; no workgroup barrier on this path)
-    double acc[42];
+    const int ka = W.it_ka[j], kb = W.it_kb[j], l = W.it_l[j];   // three independent loads, then one level of gathers
+    double D[9], Dinv[9];
 #pragma unroll
-    for (int i = 0; i < 42; ++i) acc[i] = 0;
-    for (int j = diag ? tid : lane; j < n; j += diag ? NT : 64) {
-        const int ka = W.it_ka[o0 + j], kb = W.it_kb[o0 + j], l = W.it_l[o0 + j];   // three independent loads, then one level of gathers
-        double D[9], Dinv[9];
+    for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    mat3_inverse(D, Dinv);
+    const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
+    double Bb[18], BD[18];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
-        D[0] += lambda; D[4] += lambda; D[8] += lambda;
-        mat3_inverse(D, Dinv);
-        const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
-        double Bb[18], BD[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
-        if (diag) {   // (uniform) the two edges of an item are one: its block is fetched once
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bb[r * 3] * Dinv[c] + Bb[r * 3 + 1] * Dinv[3 + c] + Bb[r * 3 + 2] * Dinv[6 + c];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
-            }
-        }
+    for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
+    if (diag) {   // (uniform) the two edges of an item are one: its block is fetched once
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
-        if (diag) {   // (ka == kb: one edge per (keyframe, landmark) pair)
-            const double *bl = W.b + n6 + 3 * (size_t)l;
-            double db[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[36 + r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
-        }
-    }
-    double sum;
-    int e;
-    if (diag) {
-        sum = workgroup_sum_k256<42, NT>(acc, red, n);
-        e = tid;
+            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bb[r * 3] * Dinv[c] + Bb[r * 3 + 1] * Dinv[3 + c] + Bb[r * 3 + 2] * Dinv[6 + c];
     } else {
-        // the wave's own four rows of `red`; LDS operations of one wave execute in order, so the reads below see the writes
-        double *wred = red + 4 * wave * 43;
-        const int rows_used = min(4, (n + 15) >> 4);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
-        if ((lane & 15) == 0) {
+        for (int r = 0; r < 6; ++r) {
+            const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
 #pragma unroll
-            for (int i = 0; i < 36; ++i) wred[(lane >> 4) * 43 + i] = acc[i];
+            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
         }
-        asm volatile("" ::: "memory");
-        sum = 0;
-        if (lane < 36)
-            for (int r = 0; r < rows_used; ++r) sum += wred[r * 43 + lane];
-        e = lane;
     }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
+    if (with_b) {   // (ka == kb: one edge per (keyframe, landmark) pair)
+        const double *bl = W.b + n6 + 3 * (size_t)l;
+        double db[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[36 + r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
+    }
+}
+
+// Hschur = Hpp + lambda I - sum (diagonal), -sum (off-diagonal, both triangles); bschur = b_p - sum
+__device__ __forceinline__ void schur_store(const LbaWin &W, int i1, int i2, int e, double sum, double lambda)
+{
+    const bool diag = i1 == i2;
     if (e < 36) {
         double v = -sum;
         const int r = e / 6, c = e - 6 * r;
@@ -1162,6 +1097,77 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
         if (!diag) W.Hs[(size_t)(6 * i2 + c) * W.hs_ld + 6 * i1 + r] = v;
     } else if (e < 42 && diag)
         W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
+}
+
+__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks)
+{
+    constexpr int NT = kSchurThreads;
+    __shared__ double red[(NT / 16) * 43];
+    __shared__ int32_t s_info[16], s_ij[16];
+    const SchurTask tk = tasks[blockIdx.x];
+    if (tk.w < 0) return;
+    const LbaWin &W = wins[tk.w];
+    // (every dependent load is a round trip of its own on the workgroup's critical path: the state words and the unit's
+    // item range are requested together, before the branch on the first of them)
+    const int run = W.st->run;
+    const double lambda = W.st->lambda;
+    const int np = W.np, n6 = 6 * np;
+    const int kind = tk.code >> 28, arg = tk.code & 0x0fffffff;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[42];
+#pragma unroll
+    for (int i = 0; i < 42; ++i) acc[i] = 0;
+    if (kind == kSchurPack) {
+        const int row = tid >> 4, li = tid & 15, r = arg + row;
+        int o0 = 0, info = 0, ij = 0;
+        if (r < W.n_srows) {
+            o0 = W.sr_o0[r];
+            info = W.sr_info[r];
+            ij = W.sr_ij[r];
+        }
+        if (!run) return;
+        if (li == 0) {
+            s_info[row] = info;
+            s_ij[row] = ij;
+        }
+        if (li < (info & 255)) schur_item(W, o0 + li, lambda, false, false, n6, acc);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
+        if (li == 0) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) red[row * 43 + i] = acc[i];
+        }
+        __syncthreads();
+        // a block's rows are neighbours inside the unit: its first row's slot adds them in row order
+        for (int rr = wave; rr < 16; rr += NT / 64) {
+            const int inf = s_info[rr], nrb = (inf >> 16) & 255;
+            if (((inf >> 8) & 255) != 0 || nrb == 0 || lane >= 36) continue;
+            double sum = 0;
+            for (int k = 0; k < nrb; ++k) sum += red[(rr + k) * 43 + lane];
+            schur_store(W, s_ij[rr] & 0xffff, s_ij[rr] >> 16, lane, sum, lambda);
+        }
+        return;
+    }
+    // DIAG / BIG: one block, items strided over the workgroup
+    int i1, i2;
+    if (kind == kSchurDiag)
+        i1 = i2 = arg;
+    else {   // block rank -> (i1 < i2), row-major upper triangle (the order of blk_off)
+        int rem = arg;
+        i1 = 0;
+        while (rem >= np - i1) {
+            rem -= np - i1;
+            ++i1;
+        }
+        i2 = i1 + rem;
+    }
+    const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
+    const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
+    if (!run) return;
+    const bool diag = kind == kSchurDiag;
+    for (int j = tid; j < n; j += NT) schur_item(W, o0 + j, lambda, diag, diag, n6, acc);
+    const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
+    schur_store(W, i1, i2, tid, sum, lambda);
 }
 
 // Dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve of the reduced
@@ -1680,6 +1686,7 @@ struct Pass {
     std::vector<int32_t> k_ph, k_lh, hpose, hpoint, pt_off, pt_k, ps_off, ps_k, pl_off, pl_k;
     std::vector<int32_t> pl_pos, pl_ph;   // edge -> position in pl_k (-1: fixed keyframe); position -> pose hidx
     std::vector<int32_t> it_ka, it_kb, it_l, blk_off;   // Schur items (k_schur_items / k_schur_blocks)
+    std::vector<int32_t> sr_o0, sr_info, sr_ij, units;    // k_schur's row table and unit codes (build_schur_units)
     int np = 0, nl = 0;
 };
 // worker threads of a handle for the per-window host work of a batch (structure build, staging): created once -- 32
@@ -1885,11 +1892,47 @@ static void build_schur_items(Pass &S)
     }
 }
 
+// k_schur's units of a window (see the kernel): DIAG units first (the long ones must not be dispatched last), then the BIG
+// off-diagonal blocks, then the PACK units -- off-diagonal blocks in rank order, ceil(n / 16) rows each (an empty block keeps one
+// row: its zeros are written like any other sum), a block never split across two units.
+static void build_schur_units(Pass &S)
+{
+    S.sr_o0.clear(); S.sr_info.clear(); S.sr_ij.clear(); S.units.clear();
+    const int np = S.np;
+    for (int i = 0; i < np; ++i) S.units.push_back((kSchurDiag << 28) | i);
+    std::vector<int32_t> pack_first;
+    int in_unit = 0;
+    for (int i1 = 0, blk = 0; i1 < np; ++i1)
+        for (int i2 = i1; i2 < np; ++i2, ++blk) {
+            if (i2 == i1) continue;
+            const int o0 = S.blk_off[blk], n = S.blk_off[blk + 1] - o0;
+            if (n > 256) {
+                S.units.push_back((kSchurBig << 28) | blk);
+                continue;
+            }
+            const int nrows = std::max(1, (n + 15) / 16);
+            if (in_unit + nrows > 16) {   // pad the unit: a block's rows stay together
+                for (; in_unit < 16; ++in_unit) {
+                    S.sr_o0.push_back(0); S.sr_info.push_back(0); S.sr_ij.push_back(0);
+                }
+                in_unit = 0;
+            }
+            if (in_unit == 0) pack_first.push_back((int32_t)S.sr_o0.size());
+            for (int r = 0; r < nrows; ++r) {
+                S.sr_o0.push_back(o0 + 16 * r);
+                S.sr_info.push_back(std::max(0, std::min(16, n - 16 * r)) | (r << 8) | (nrows << 16));
+                S.sr_ij.push_back(i1 | (i2 << 16));
+            }
+            in_unit = (in_unit + nrows) % 16;
+        }
+    for (int32_t f : pack_first) S.units.push_back((kSchurPack << 28) | f);
+}
+
 // byte offsets of one window's regions in the arena
 struct WinLayout {
     // staged (uploaded)
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
-        pl_off, pl_k, it_ka, it_kb, it_l, blk_off;
+        pl_off, pl_k, it_ka, it_kb, it_l, blk_off, sr_o0, sr_info, sr_ij;
     // device only
     size_t est, bk, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
@@ -2056,7 +2099,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     bool walk = total_points > 16000;
     if (const char *e = getenv("AOS2_LBA_LAYOUT")) walk = !strcmp(e, "walk");
     const int lm_per_block = walk ? 128 : kLmBlock;
-    const int schur_bpu = walk ? 4 : 1;   // off-diagonal blocks per k_schur workgroup
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -2084,7 +2126,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
                 return;
             }
         pass_ok[i] = build_pass(p, passes[i]) ? 1 : 0;
-        if (pass_ok[i] && passes[i].np > 0) build_schur_items(passes[i]);
+        if (pass_ok[i] && passes[i].np > 0) {
+            build_schur_items(passes[i]);
+            build_schur_units(passes[i]);
+        } else
+            passes[i].units.clear();
     });
     for (int i = 0; i < nw; ++i)
         if (bad_edge[i] >= 0) {
@@ -2117,7 +2163,42 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.n_items = S.it_ka.size();
         l.it_ka = B.take(4 * l.n_items + 4); l.it_kb = B.take(4 * l.n_items + 4); l.it_l = B.take(4 * l.n_items + 4);
         l.blk_off = B.take(4 * S.blk_off.size() + 4);
+        l.sr_o0 = B.take(4 * S.sr_o0.size() + 4); l.sr_info = B.take(4 * S.sr_o0.size() + 4); l.sr_ij = B.take(4 * S.sr_o0.size() + 4);
     }
+    // k_schur's task list: the units of all windows, window w on XCD w' (workgroups go round-robin to the 8 XCDs in linear-id order,
+    // each with an L2 of its own -- 4 MB, about one window's working set: the Hpl blocks a window's items share are then served by
+    // one L2), the windows dealt to the XCDs largest first (every XCD gets about the same number of units), two windows of an XCD
+    // at a time, unit by unit -- their DIAG units first.  Padding entries (w = -1) keep the 8 queues in step.
+    std::vector<SchurTask> tasks;
+    {
+        std::vector<int> order(nw);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return passes[a].units.size() > passes[b].units.size(); });
+        const int NX = nw >= 8 ? 8 : 1;
+        std::vector<std::vector<int>> xw(NX);
+        std::vector<size_t> load(NX, 0);
+        for (int w : order) {
+            const int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            xw[x].push_back(w);
+            load[x] += passes[w].units.size();
+        }
+        std::vector<std::vector<SchurTask>> qx(NX);
+        for (int x = 0; x < NX; ++x)
+            for (size_t k = 0; k < xw[x].size(); k += 2) {
+                const int a = xw[x][k], b = k + 1 < xw[x].size() ? xw[x][k + 1] : -1;
+                const size_t na = passes[a].units.size(), nb2 = b >= 0 ? passes[b].units.size() : 0;
+                for (size_t u = 0; u < std::max(na, nb2); ++u) {
+                    if (u < na) qx[x].push_back(SchurTask{a, passes[a].units[u]});
+                    if (u < nb2) qx[x].push_back(SchurTask{b, passes[b].units[u]});
+                }
+            }
+        size_t mxq = 0;
+        for (auto &q_ : qx) mxq = std::max(mxq, q_.size());
+        tasks.assign(mxq * NX, SchurTask{-1, 0});
+        for (int x = 0; x < NX; ++x)
+            for (size_t k = 0; k < qx[x].size(); ++k) tasks[k * NX + x] = qx[x][k];
+    }
+    const size_t o_tasks = B.take(sizeof(SchurTask) * tasks.size() + 8);
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
     for (int i = 0; i < nw; ++i) {
@@ -2172,7 +2253,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
     bool any_lds = false, any_glob = false;
     int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part = 0, mx_npad_glob = 0, mx_npad_lds = 0;
-    size_t mx_blk = 0;
     std::vector<uint8_t> up_fail(nw, 0);
     for_windows([&](int i) {
         const aos2_lba_problem_t *p = problems + act[i];
@@ -2193,9 +2273,10 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         put(l.pt_off, S.pt_off); put(l.pt_k, S.pt_k); put(l.ps_off, S.ps_off); put(l.ps_k, S.ps_k);
         put(l.pl_off, S.pl_off); put(l.pl_k, S.pl_ph);
         put(l.it_ka, S.it_ka); put(l.it_kb, S.it_kb); put(l.it_l, S.it_l); put(l.blk_off, S.blk_off);
+        put(l.sr_o0, S.sr_o0); put(l.sr_info, S.sr_info); put(l.sr_ij, S.sr_ij);
         // the window's staged region goes to the device as soon as it is assembled: its upload overlaps the staging of the
         // other windows (one copy of everything after the staging cost 0.4 ms more per 32-window call)
-        const size_t r0 = l.in_Tcw, r1 = i + 1 < nw ? L[i + 1].in_Tcw : o_wins;
+        const size_t r0 = l.in_Tcw, r1 = i + 1 < nw ? L[i + 1].in_Tcw : o_tasks;
         if (hipSetDevice(s->device) != hipSuccess || hipMemcpyAsync(base + r0, hin + r0, r1 - r0, hipMemcpyHostToDevice, s->stream) != hipSuccess)
             up_fail[i] = 1;
     });
@@ -2233,6 +2314,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.pl_off = (const int32_t *)(base + l.pl_off); W.pl_ph = (const int32_t *)(base + l.pl_k);
         W.it_ka = (const int32_t *)(base + l.it_ka); W.it_kb = (const int32_t *)(base + l.it_kb);
         W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
+        W.sr_o0 = (const int32_t *)(base + l.sr_o0); W.sr_info = (const int32_t *)(base + l.sr_info); W.sr_ij = (const int32_t *)(base + l.sr_ij);
+        W.n_srows = (int)S.sr_o0.size();
         W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
         W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
         W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
@@ -2259,11 +2342,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         mx_nl = std::max(mx_nl, S.nl);
         mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
         mx_part = std::max(mx_part, l.n_part);
-        mx_blk = std::max(mx_blk, schur_units((size_t)S.np, schur_bpu));   // k_schur units
     }
     lap("staging");
     hipStream_t q = s->stream;
-    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_wins, hin + o_wins, staged_bytes - o_wins, hipMemcpyHostToDevice, q));   // the descriptors
+    if (!tasks.empty()) memcpy(hin + o_tasks, tasks.data(), sizeof(SchurTask) * tasks.size());
+    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_tasks, hin + o_tasks, staged_bytes - o_tasks, hipMemcpyHostToDevice, q));   // k_schur's task list, the descriptors
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
@@ -2287,7 +2370,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        if (mx_np) hipLaunchKernelGGL(k_schur, dim3(xcd_affine_grid(mx_blk, nw)), dim3(kSchurThreads), 0, q, dw, (int)mx_blk, nw, schur_bpu, xcd_group(nw));
+        if (!tasks.empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks.size()), dim3(kSchurThreads), 0, q, dw, (const SchurTask *)(base + o_tasks));
         if (any_glob)   // (first: the longer of the two)
             hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
         if (any_lds) {

@@ -53,6 +53,21 @@ def test_bench_contract_single_gpu(gpu):
     assert {"search_for_triangulation", "fuse", "search_by_bow"} <= set(d["cpu_baseline"]["ms_per_frame"])
 
 
+def test_bench_kitti_slice(gpu):
+    """BASELINE configs[2] + [3] as a bench line (--workload kitti): a 2-step slice -- both eyes' extraction on two handles,
+    ComputeStereoMatches and the stereo Frame members on the device, the tracking chain, the keyframe's BoW search and the 20-keyframe
+    LocalBA windows; the last timed step equals the oracle (mvuRight / mvDepth from the oracle's ComputeStereoMatches, bit for bit)"""
+    d = _run([sys.executable, "bench.py", "--workload", "kitti", "--steps", "2", "--warmup", "1", "--batch", "16", "--cpu-frames", "8"])
+    assert d["metric"].startswith("stereo frames/sec") and "KITTI" in d["config"]["workload"] and d["n_gpus"] == 1
+    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    pc = d["parity_checked"]
+    assert pc["ok"] is True and pc["frames"] == 16 and pc["distinct_frame_pairs"] == 16 and pc["local_ba_windows"] == 2
+    assert pc["reference_keyframe_bow_frames"] == 2 and pc["keyframe_neighbour_pairs"] == 0
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 1444097 * 16 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["value"] > 0 and "extract_both_eyes_and_stereo_matches" in d["stage_ms"]
+    assert d["config"]["keypoints_per_frame_mean"] > 1500 and d["config"]["matches_per_frame_mean"]["inliers_2"] > 100
+
+
 def test_bench_with_the_large_batch_pose_optimization_form(gpu):
     """batches of more than 256 frames run PoseOptimization with 128 threads per frame (all frames resident at once); forced here on a
     small batch: the last timed step still equals the oracle (inlier counts, outlier flags bit-identical, poses 1e-5)"""
