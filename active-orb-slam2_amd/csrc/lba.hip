@@ -111,6 +111,14 @@ struct LbaWin {
     uint8_t *out_outlier;
 };
 
+// One workgroup's share of a launch: (window, what).  The host lays the work of ALL windows of a call out as task lists (one per
+// kernel family) instead of grids padded to the largest window -- the windows of a batch differ (10-40 keyframes, 2-6 k points),
+// and a workgroup that only finds out it has nothing to do still holds a slot for two dependent loads.
+struct SchurTask {
+    int32_t w;      // window (-1: padding)
+    int32_t code;   // k_schur: kind << 28 | argument; k_lin: kind << 28 | block; k_points: block
+};
+
 // bool SparseOptimizer::terminate(): counts the evaluation, latches the flag
 // `seen` >= 0: the value of the flag read by the caller shortly before (the word lives in host memory: a read is a PCIe
 // round trip, which the decision starts ahead of its other loads)
@@ -421,14 +429,15 @@ constexpr int kWalkChunkLin = 4;   // all edges (linearisation)
 // updated by the kernel before), and -- in the workgroup that finishes last -- the LM decision (lm_decide).
 // solve = 0 (top of solve() in iteration 0): the residuals only.
 // Landmark l leaves its chi2 terms in part[l] and its scale terms in part[nl + l] (canonical_sums adds them).
-__global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins, int solve)
+__global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
 {
     __shared__ double s_v[kLmBlock][kLmSlots][3];
     __shared__ double s_X[kLmBlock][3];
-    const LbaWin &W = wins[blockIdx.y];
-    if (!(solve ? W.st->run : W.st->initp) || (int)blockIdx.x >= W.n_part) return;
+    const SchurTask tk = tasks[blockIdx.x];
+    const LbaWin &W = wins[tk.w];
+    if (!(solve ? W.st->run : W.st->initp)) return;
     const int tid = threadIdx.x, ll = tid / kLmSlots, j = tid % kLmSlots;
-    const int l = blockIdx.x * kLmBlock + ll;
+    const int l = tk.code * kLmBlock + ll;
     const bool has = l < W.nl, leader = j == 0;
     const int n6 = 6 * W.np;
     double sc = 0, chi = 0;
@@ -528,11 +537,12 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
 // launch, where the landmarks alone fill the device and idle slots, barriers and LDS round trips only cost (32 windows of
 // 24 k edges: 4.4 ms against 6.4 ms).  Per landmark the operations and their order are those of k_points, so both layouts
 // leave the same bits.
-__global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, int solve)
+__global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
 {
-    const LbaWin &W = wins[blockIdx.y];
-    if (!(solve ? W.st->run : W.st->initp) || (int)blockIdx.x >= W.n_part) return;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const SchurTask tk = tasks[blockIdx.x];
+    const LbaWin &W = wins[tk.w];
+    if (!(solve ? W.st->run : W.st->initp)) return;
+    const int l = tk.code * blockDim.x + threadIdx.x;
     const int n6 = 6 * W.np;
     if (l < W.nl) {
         double sc = 0, chi = 0;
@@ -949,26 +959,28 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
         W.b[6 * (size_t)ph + (threadIdx.x - 36)] = sum;
 }
 
-// buildSystem as ONE launch: the landmark side and the keyframe side are independent of each other.  Grid = (window, block):
-// blocks [0, nl_blocks) of a window take landmarks, the others one free keyframe each -- and the dispatcher walks x (the
-// windows) first, so the landmark workgroups of ALL windows start before any keyframe workgroup: their walks are the long
+// buildSystem as ONE launch: the landmark side and the keyframe side are independent of each other.  The task list holds the
+// landmark blocks of all windows (block by block across the windows), then one task per free keyframe, so the landmark
+// workgroups of ALL windows start before any keyframe workgroup: their walks are the long
 // dependent chains of the launch (33 of its 54 us on 32 windows when they queued behind the keyframe workgroups of the
 // windows before them), the keyframe workgroups fill in behind.
 // (three waves per SIMD: 174 -> 168 registers for 12 bytes of scratch per lane; the walk moves scattered bytes and gains from the third
 // wave: 36.2 -> 34.4 us on 32 windows.  k_points_walk, 172 registers, does not: 34.2 -> 35.0 us, left at two.)
 template <bool kWalk>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lin(const LbaWin *__restrict__ wins, int init, int nl_blocks)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lin(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int init)
 {
-    const LbaWin &W = wins[blockIdx.x];
+    const SchurTask tk = tasks[blockIdx.x];
+    const LbaWin &W = wins[tk.w];
     if (!(init ? W.st->initp : W.st->lin)) return;
-    const int blk = (int)blockIdx.y;
+    const int blk = tk.code & 0x0fffffff;
+    const bool keyframe = (tk.code >> 28) != 0;
 #if AOS2_LBA_ABL == 5
-    if (blk >= nl_blocks) return;
+    if (keyframe) return;
 #elif AOS2_LBA_ABL == 6
-    if (blk < nl_blocks) return;
+    if (!keyframe) return;
 #endif
-    if (blk >= nl_blocks)
-        lin_poses_body(W, blk - nl_blocks);
+    if (keyframe)
+        lin_poses_body(W, blk);
     else if (kWalk)
         lin_points_walk(W, blk * 256 + threadIdx.x);
     else
@@ -1038,11 +1050,7 @@ constexpr int kSchurThreads = 256;
 //         cost 235 workgroups.  Row sums by DPP, then a block's rows are added in row order: for a block of up to 64 items
 //         exactly the sums (and bits) of the one-wave-per-block form.
 constexpr int kSchurDiag = 0, kSchurBig = 1, kSchurPack = 2;
-struct SchurTask {
-    int32_t w;      // window (-1: padding of the XCD interleave)
-    int32_t code;   // kind << 28 | argument (DIAG: i; BIG: block rank; PACK: first row)
-};
-
+// (SchurTask.code = kind << 28 | argument -- DIAG: i; BIG: block rank; PACK: first row; w = -1: padding of the XCD interleave)
 __device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, bool diag, bool with_b, int n6, double (&acc)[42])
 {
     const int ka = W.it_ka[j], kb = W.it_kb[j], l = W.it_l[j];   // three independent loads, then one level of gathers
@@ -2198,7 +2206,29 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         for (int x = 0; x < NX; ++x)
             for (size_t k = 0; k < qx[x].size(); ++k) tasks[k * NX + x] = qx[x][k];
     }
-    const size_t o_tasks = B.take(sizeof(SchurTask) * tasks.size() + 8);
+    // ... and the landmark kernels' lists: block b of every window before block b + 1 of any (the windows advance side by side);
+    // k_lin: every landmark block first (the long dependent chains of the launch), then one task per free keyframe
+    std::vector<SchurTask> pts_tasks, lin_tasks;
+    {
+        const int lin_block = walk ? 256 : kLmBlock;
+        int mx_pb = 0, mx_lb = 0, mx_k = 0;
+        std::vector<int> npb(nw), nlb(nw);
+        for (int i = 0; i < nw; ++i) {
+            npb[i] = std::max(1, (passes[i].nl + lm_per_block - 1) / lm_per_block);   // = WinLayout::n_part
+            nlb[i] = (passes[i].nl + lin_block - 1) / lin_block;
+            mx_pb = std::max(mx_pb, npb[i]); mx_lb = std::max(mx_lb, nlb[i]); mx_k = std::max(mx_k, passes[i].np);
+        }
+        for (int b = 0; b < mx_pb; ++b)
+            for (int i = 0; i < nw; ++i)
+                if (b < npb[i]) pts_tasks.push_back(SchurTask{i, b});
+        for (int b = 0; b < mx_lb; ++b)
+            for (int i = 0; i < nw; ++i)
+                if (b < nlb[i]) lin_tasks.push_back(SchurTask{i, b});
+        for (int k = 0; k < mx_k; ++k)
+            for (int i = 0; i < nw; ++i)
+                if (k < passes[i].np) lin_tasks.push_back(SchurTask{i, (1 << 28) | k});
+    }
+    const size_t o_tasks = B.take(sizeof(SchurTask) * (tasks.size() + pts_tasks.size() + lin_tasks.size()) + 8);
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
     for (int i = 0; i < nw; ++i) {
@@ -2346,22 +2376,28 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     lap("staging");
     hipStream_t q = s->stream;
     if (!tasks.empty()) memcpy(hin + o_tasks, tasks.data(), sizeof(SchurTask) * tasks.size());
+    memcpy(hin + o_tasks + sizeof(SchurTask) * tasks.size(), pts_tasks.data(), sizeof(SchurTask) * pts_tasks.size());
+    if (!lin_tasks.empty())
+        memcpy(hin + o_tasks + sizeof(SchurTask) * (tasks.size() + pts_tasks.size()), lin_tasks.data(), sizeof(SchurTask) * lin_tasks.size());
+    const SchurTask *d_schur_tasks = (const SchurTask *)(base + o_tasks), *d_pts_tasks = d_schur_tasks + tasks.size(),
+                    *d_lin_tasks = d_pts_tasks + pts_tasks.size();
     AOS2_HIP_CHECK(hipMemcpyAsync(base + o_tasks, hin + o_tasks, staged_bytes - o_tasks, hipMemcpyHostToDevice, q));   // k_schur's task list, the descriptors
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
-    const dim3 g_edges256(blocks(mx_E, 256), nw), g_points(mx_part, nw);
+    const dim3 g_edges256(blocks(mx_E, 256), nw);
     auto enqueue_points = [&](int solve) {
         if (walk)
-            hipLaunchKernelGGL(k_points_walk, g_points, dim3(128), 0, q, dw, solve);
+            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)pts_tasks.size()), dim3(128), 0, q, dw, d_pts_tasks, solve);
         else
-            hipLaunchKernelGGL(k_points, g_points, dim3(256), 0, q, dw, solve);
+            hipLaunchKernelGGL(k_points, dim3((unsigned)pts_tasks.size()), dim3(256), 0, q, dw, d_pts_tasks, solve);
     };
     auto enqueue_lin = [&](int init) {
+        if (lin_tasks.empty()) return;
         if (walk)
-            hipLaunchKernelGGL(k_lin<true>, dim3(nw, mx_np + blocks(mx_nl, 256)), dim3(256), 0, q, dw, init, (int)blocks(mx_nl, 256));
+            hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);
         else
-            hipLaunchKernelGGL(k_lin<false>, dim3(nw, mx_np + blocks(mx_nl, kLmBlock)), dim3(256), 0, q, dw, init, (int)blocks(mx_nl, kLmBlock));
+            hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);
     };
     auto enqueue_init = [&]() {
         enqueue_points(0);
@@ -2370,7 +2406,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     };
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
-        if (!tasks.empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks.size()), dim3(kSchurThreads), 0, q, dw, (const SchurTask *)(base + o_tasks));
+        if (!tasks.empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks.size()), dim3(kSchurThreads), 0, q, dw, d_schur_tasks);
         if (any_glob)   // (first: the longer of the two)
             hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
         if (any_lds) {

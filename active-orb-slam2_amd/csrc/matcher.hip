@@ -2693,6 +2693,20 @@ int aos2_matcher_search_by_bow_frames(aos2_matcher_t *m, const aos2_bow_frames_t
             set_error("frame %zu: counts outside the capacity %zu", b, cap);
             return AOS2_ERR_ARG;
         }
+        // the FeatureVector CSRs came back from the device (a transform that was not ordered before this call leaves stale
+        // buffers): bow_run uses them as host copy lengths and indices, so offsets must be monotone from 0 and indices in range
+        for (int k = 0; k < 2; ++k) {
+            const int32_t *off = H[k].off + b * (cap + 1), *idx = H[k].idx + b * cap;
+            const int nfv = H[k].n_fv[b], nfe = k == 0 ? P.n_kf : P.n_f;
+            bool ok = nfv == 0 || off[0] == 0;
+            for (int v = 0; ok && v < nfv; ++v) ok = off[v + 1] >= off[v] && off[v + 1] <= (int32_t)cap;
+            for (int e = 0; ok && nfv > 0 && e < off[nfv]; ++e) ok = idx[e] >= 0 && idx[e] < nfe;
+            if (!ok) {
+                set_error("frame %zu: inconsistent FeatureVector (%s side): offsets not monotone within the capacity or a feature index out of range",
+                          b, k == 0 ? "keyframe" : "frame");
+                return AOS2_ERR_ARG;
+            }
+        }
         P.desc_kf = q->d_desc_kf + b * cap * 32; P.desc_f = q->d_desc_f + b * cap * 32;
         P.angle_kf = m->fr_angle.p + b * cap; P.angle_f = m->fr_angle.p + tot + b * cap;
         P.kf_has_mp = q->kf_has_mp + b * cap;
@@ -3079,7 +3093,7 @@ int aos2_matcher_search_by_projection_last(aos2_matcher_t *m, const aos2_frame_v
     const size_t pool_cap = (size_t)p->n_last * (size_t)cur->n_f;
     if (pool_cap > ((size_t)1 << 31) - 2) {   // (32-bit entry offsets: 16 GiB of the device's 288 GB)
         set_error("projection search of %d points x %d features exceeds the pool's index range", p->n_last, cur->n_f);
-        return AOS2_ERR_ARG;
+        return AOS2_ERR_CAPACITY;
     }
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = A.upload())) return st;
@@ -3460,7 +3474,7 @@ int aos2_matcher_search_for_initialization(aos2_matcher_t *m, const aos2_frame_v
     const size_t pool_cap = n * (size_t)f2->n_f;
     if (pool_cap > ((size_t)1 << 31) - 2) {   // (32-bit entry offsets: 16 GiB of the device's 288 GB)
         set_error("initialization search of %d x %d features exceeds the pool's index range", n1, f2->n_f);
-        return AOS2_ERR_ARG;
+        return AOS2_ERR_CAPACITY;
     }
     if ((st = m->pool.alloc(pool_cap + 1))) return st;
     if ((st = A.upload())) return st;

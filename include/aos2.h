@@ -761,6 +761,10 @@ int aos2_frames_search_by_projection_last(aos2_frames_t *cur, const aos2_frames_
                                           int check_orientation, int32_t *d_nmatches);
 /* int Optimizer::PoseOptimization(Frame *pFrame)  src/Optimizer.cc:239-452 for every frame: edges from the features
  * that hold a map point (:260-350), result in mTcw and mvbOutlier; d_inliers [batch] (may be NULL) = return values */
+/* (Two kernel forms: batches of more than 256 frames run 128 threads per frame with 9 edge slots each, smaller ones 256 threads
+ * with 4; the edge order per thread and the order of the wave sums differ, so the SAME frame may get pose bits that differ in the
+ * last places -- within 1e-5 of the oracle either way -- depending on the size of the batch it is in.  AOS2_PO_THREADS = 128 / 256
+ * in the environment forces one form for every batch size.) */
 int aos2_frames_pose_optimization(aos2_frames_t *f, const aos2_map_points_dev_t *mps, int32_t *d_inliers);
 /* Tracking::TrackWithMotionModel :1008-1025 after PoseOptimization: a feature flagged as outlier loses its map point
  * (mvpMapPoints[i] = NULL, mvbOutlier[i] = false; the point counts as seen in this frame) */
