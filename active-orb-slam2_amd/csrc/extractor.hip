@@ -123,6 +123,11 @@ struct aos2_extractor {
     DevBuf<int32_t> d_status;   // sticky [lowest octree failure code, largest n_out] of the batches in flight
     const uint8_t *img0 = nullptr;  // level 0 of the last batch = the caller's (device) images
     size_t img0_stride = 0;
+    // AOS2_DESC_BLUR=level: the reference's whole-level GaussianBlur as a streaming pass, describe on the blurred planes
+    bool blur_level = false;
+    BlurPlanHost blur_plan_h = {};
+    size_t blur_bytes = 0;           // per image
+    DevBuf<uint8_t> d_blur;
     int pitch0 = 0;
     DevBuf<uint8_t> d_pyr, d_in, d_desc;
     DevBuf<uint32_t> d_slots, d_dense, d_sel;
@@ -535,6 +540,10 @@ static int ensure_batch(aos2_extractor *e, int batch)
     } else {
         if ((st = e->h_sel.alloc((size_t)L * e->cap_level * batch))) return st;
     }
+    if (e->blur_level) {
+        e->blur_bytes = blur_plan(P.levels.data(), L, P.pyr_bytes, &e->blur_plan_h);
+        if ((st = e->d_blur.alloc(e->blur_bytes * batch + 256))) return st;
+    }
     // row h of every plane (1 guard row) and pitch padding are read by 32-bit tile loads: keep
     // them defined
     AOS2_HIP_CHECK(hipMemsetAsync(e->d_pyr.p, 0, P.pyr_bytes * batch + 256, e->stream));
@@ -729,6 +738,13 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
                               e->cap_level, e->oct_lds, s);
         }
         if (timed) AOS2_HIP_CHECK(hipEventRecord(e->ev[4], s));
+        if (e->blur_level) {   // (inside the describe stage's events: the A/B compares the stage as a whole)
+            uint8_t *bl = e->d_blur.p + (size_t)b0 * e->blur_bytes;
+            launch_blur_levels(img, image_stride, stride, pyr, P.pyr_bytes, P.d_levels.p, L, e->blur_plan_h, bl, e->blur_bytes, nb, s);
+            launch_describe_blur(img, image_stride, stride, pyr, P.pyr_bytes, bl, e->blur_bytes, e->blur_plan_h, P.d_levels.p, L, sel,
+                                 (size_t)L * e->cap_level, e->cap_level, sel_cnt, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32, cap,
+                                 d_nout + b0, nb, e->d_status.p, s);
+        } else
         launch_describe(img, image_stride, stride, pyr, P.pyr_bytes, P.d_levels.p, L, sel, (size_t)L * e->cap_level,
                         e->cap_level, sel_cnt, d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * 32, cap, d_nout + b0, nb,
                         e->umax_nibbles, e->d_status.p, s);
@@ -884,6 +900,7 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     const unsigned hc = std::thread::hardware_concurrency();
     e->host_threads = (int)std::min(32u, std::max(1u, hc));
     if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));
+    if (const char *v = getenv("AOS2_DESC_BLUR")) e->blur_level = strcmp(v, "level") == 0;
     if (const char *v = getenv("AOS2_CHUNKS")) e->chunks = std::max(0, std::min(kMaxStreams, atoi(v)));
     *out = e;
     return AOS2_OK;
@@ -896,7 +913,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         (void)hipSetDevice(e->device);
         for (auto &sx : e->streams) (void)hipStreamSynchronize(sx);
         e->plan.release_device();
-        e->d_pyr.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
+        e->d_pyr.release(); e->d_blur.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
         e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_level_cnt.release(); e->d_sel_cnt.release();
         e->d_nout.release(); e->d_kps.release();
         e->st_sad.release(); e->st_rows.release(); e->st_io.release(); e->st_host.release();

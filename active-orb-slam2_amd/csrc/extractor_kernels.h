@@ -98,4 +98,20 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, int32_t *status, hipStream_t st);
 
+// whole-level blur (AOS2_DESC_BLUR=level): plan of the blurred planes, the streaming blur, describe on blurred levels
+struct BlurPlanHost {
+    int first[9];
+    int nq[8];
+    uint32_t dst_off[8];
+    int dst_pitch[8];
+};
+size_t blur_plan(const LevelDev *h_levels, int n_levels, size_t pyr_bytes, BlurPlanHost *out);   // returns bytes per image
+void launch_blur_levels(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                        const LevelDev *levels, int n_levels, const BlurPlanHost &plan, uint8_t *blur, size_t blur_stride, int batch,
+                        hipStream_t st);
+void launch_describe_blur(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                          const uint8_t *blur, size_t blur_stride, const BlurPlanHost &plan, const LevelDev *levels, int n_levels,
+                          const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
+                          aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, int32_t *status, hipStream_t st);
+
 }  // namespace aos2

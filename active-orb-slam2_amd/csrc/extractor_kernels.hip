@@ -1145,6 +1145,234 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// The reference's own form of the blur (src/ORBextractor.cc:1085-1086: GaussianBlur(workingMat, 7x7, sigma 2, BORDER_REFLECT_101)
+// of every whole level before its descriptors) as a streaming pass: AOS2_DESC_BLUR=level.  A/B against the per-keypoint blur
+// of describe_kernel above (profiles/README.md, round 4): the whole pyramid is blurred once (0.95 M pixels per 640x480 frame
+// instead of ~1.5 M pixel-blurs over the overlapping 43x37 patches of 1000 keypoints) but goes to HBM and back.
+//
+// blur_levels_kernel: one launch for all levels.  A lane owns 4 adjacent output pixels x BL_ROWS rows: per source row one
+// horizontal pass (the three dwords around the quad, 10 v_dot4 with the taps shifted in the weights -- describe_kernel's h-pass),
+// the last 7 rows' sums stay in registers, per output row the symmetric vertical pass (3 adds + 4 multiply-adds per pixel),
+// (sum + 2^15) >> 16 saturated, one aligned 32-bit store.  Same integer arithmetic as the per-keypoint form: same bytes.
+// ---------------------------------------------------------------------------------------------
+constexpr int BL_ROWS = 16;
+struct BlurPlan {
+    int first[9];            // first item of each level (item = (band, quad)); first[n_levels] = total
+    int nq[8];               // quads per row
+    uint32_t dst_off[8];     // byte offset of the level's blurred plane inside one image's block
+    int dst_pitch[8];
+};
+
+__global__ __launch_bounds__(256) void blur_levels_kernel(const uint8_t *__restrict__ img0, size_t img0_stride, int pitch0,
+                                                          const uint8_t *__restrict__ pyr, size_t pyr_stride,
+                                                          const LevelDev *__restrict__ levels, int n_levels, BlurPlan plan,
+                                                          uint8_t *__restrict__ blur, size_t blur_stride)
+{
+    const int b = blockIdx.y;
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= plan.first[n_levels]) return;
+    int l = 0;
+    while (l + 1 < n_levels && it >= plan.first[l + 1]) ++l;
+    const LevelDev &L = levels[l];
+    const int w = L.w, h = L.h, pitch = l == 0 ? pitch0 : L.pitch;
+    const uint8_t *plane = l == 0 ? img0 + (size_t)b * img0_stride : pyr + (size_t)b * pyr_stride + L.off;
+    uint8_t *dst = blur + (size_t)b * blur_stride + plan.dst_off[l];
+    const int dpitch = plan.dst_pitch[l];
+    const int id = it - plan.first[l], nq = plan.nq[l];
+    const int band = id / nq, q = id - band * nq;
+    const int x0 = 4 * q, y0 = band * BL_ROWS;
+    const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+    const uint32_t g[7] = {g0, g1, g2, g3, g2, g1, g0};
+    auto wq = [&](int first) {   // weights of taps first .. first+3 (taps outside 0..6 are 0)
+        uint32_t wv = 0;
+        for (int k = 0; k < 4; ++k)
+            if (first + k >= 0 && first + k < 7) wv |= g[first + k] << (8 * k);
+        return wv;
+    };
+    const uint32_t WA0 = wq(0), WA1 = wq(4), WB0 = wq(-1), WB1 = wq(3), WC0 = wq(-2), WC1 = wq(2), WC2 = wq(6);
+    const uint32_t WD0 = wq(-3), WD1 = wq(1), WD2 = wq(5);
+    const bool inner = x0 >= 3 && x0 + 8 < w;   // the 12 bytes x0 - 3 .. x0 + 8 lie inside the row
+    uint32_t hs[7][4];
+#pragma unroll
+    for (int r = 0; r < BL_ROWS + 6; ++r) {
+        // source row y0 + r - 3 (REFLECT_101 at the level's edges); rows past the band's last needed one are skipped
+        const int ys = y0 + r - 3;
+        uint32_t D0, D1, D2;
+        if (ys - 3 < h) {   // (row ys feeds output rows ys - 3 .. ys + 3: needed iff ys - 3 < h)
+            const uint8_t *row = plane + (size_t)reflect101(ys, h) * pitch;
+            if (inner) {
+                D0 = load_u32_unaligned(row + x0 - 3);
+                D1 = load_u32_unaligned(row + x0 + 1);
+                D2 = load_u32_unaligned(row + x0 + 5);
+            } else {
+                uint32_t d[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 10; ++k) d[k >> 2] |= (uint32_t)row[reflect101(x0 - 3 + k, w)] << (8 * (k & 3));
+                D0 = d[0]; D1 = d[1]; D2 = d[2];
+            }
+        } else
+            D0 = D1 = D2 = 0;
+        uint32_t *o = hs[r % 7];
+        o[0] = __builtin_amdgcn_udot4(D0, WA0, __builtin_amdgcn_udot4(D1, WA1, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(D0, WB0, __builtin_amdgcn_udot4(D1, WB1, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(D0, WC0, __builtin_amdgcn_udot4(D1, WC1, __builtin_amdgcn_udot4(D2, WC2, 0u, false), false), false);
+        o[3] = __builtin_amdgcn_udot4(D0, WD0, __builtin_amdgcn_udot4(D1, WD1, __builtin_amdgcn_udot4(D2, WD2, 0u, false), false), false);
+        if (r >= 6) {
+            const int y = y0 + r - 6;
+            if (y < h) {
+                uint32_t out = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t a0 = hs[(r - 6) % 7][k] + hs[r % 7][k], a1 = hs[(r - 5) % 7][k] + hs[(r - 1) % 7][k];
+                    const uint32_t a2 = hs[(r - 4) % 7][k] + hs[(r - 2) % 7][k], a3 = hs[(r - 3) % 7][k];
+                    uint32_t v = __umul24(a0, g0) + (1u << 15);
+                    v += __umul24(a1, g1);
+                    v += __umul24(a2, g2);
+                    v += __umul24(a3, g3);
+                    out |= min(v >> 16, 255u) << (8 * k);
+                }
+                *reinterpret_cast<uint32_t *>(dst + (size_t)y * dpitch + x0) = out;
+            }
+        }
+    }
+}
+
+// describe_kernel on a blurred pyramid: per keypoint the raw 31-row disc for IC_Angle and the 37x37 blurred tile are staged (no
+// reflection: a keypoint lies >= 19 pixels inside its level, the pattern reaches 18), then the steered comparisons.
+constexpr int RP = 9;      // dwords per raw row staged (36 bytes: columns -17 .. +18; IC_Angle reads -15 .. +15)
+constexpr int BP = 40;     // byte pitch of the blurred tile in LDS ([y][x], 37 used)
+__global__ __launch_bounds__(64) void describe_blur_kernel(const uint8_t *__restrict__ img0, size_t img0_stride, int pitch0,
+                                                           const uint8_t *__restrict__ pyr, size_t pyr_stride,
+                                                           const uint8_t *__restrict__ blur, size_t blur_stride, BlurPlan plan,
+                                                           const LevelDev *__restrict__ levels, int n_levels,
+                                                           const uint32_t *__restrict__ sel, size_t sel_stride, int cap_level,
+                                                           const int32_t *__restrict__ sel_level_cnt,
+                                                           aos2_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int cap,
+                                                           int32_t *__restrict__ n_out, int32_t *__restrict__ status, int batch)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[31 * RP + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t bl32[BW * (BP / 4)];
+    const int b = blockIdx.x;
+    if (b >= batch) return;
+    const int lane = threadIdx.x;
+    const int k0 = blockIdx.y * DK;
+    int lv_pitch = 0, lv_sp = 0, lv_bpitch = 0;
+    uint32_t lv_off = 0, lv_boff = 0;
+    float lv_scale = 0.f;
+    if (lane < n_levels) {
+        const LevelDev &L = levels[lane];
+        lv_pitch = lane == 0 ? pitch0 : L.pitch; lv_off = (uint32_t)L.off;
+        lv_sp = L.scaled_patch; lv_scale = L.scale;
+        lv_boff = plan.dst_off[lane]; lv_bpitch = plan.dst_pitch[lane];
+    }
+    const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
+    int my_level = -1, my_kin = k0 + lane, total = 0, worst = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int c = cnt[l] > 0 ? cnt[l] : 0;
+        worst = min(worst, cnt[l]);
+        if (my_level < 0 && my_kin < c) my_level = l;
+        if (my_level < 0) my_kin -= c;
+        total += c;
+    }
+    if (k0 == 0 && lane == 0) {
+        n_out[b] = total;
+        if (worst < 0) atomicMin(status, worst);
+        if (total > cap) atomicMax(status + 1, total);
+    }
+    const int nk = min(DK, min(total, cap) - k0);
+    if (nk <= 0) return;
+    uint32_t my_sel = 0;
+    if (lane < nk) my_sel = sel[(size_t)b * sel_stride + (size_t)my_level * cap_level + my_kin];
+    const uint8_t *img_pyr = pyr + (size_t)b * pyr_stride, *img_l0 = img0 + (size_t)b * img0_stride;
+    const uint8_t *img_bl = blur + (size_t)b * blur_stride;
+    const uint8_t *bl8 = reinterpret_cast<const uint8_t *>(bl32);
+    uint32_t pats[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pats[r] = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * (r * 64 + lane)]);
+    const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1;   // IC_Angle: 7 rows x 9 dwords
+    // staging grids: raw 31 rows x 9 dwords = 279 items (5 rounds), blurred 37 rows x 10 dwords = 370 items (6 rounds)
+    for (int i = 0; i < nk; ++i) {
+        const int k = k0 + i;
+        const int level = __builtin_amdgcn_readlane(my_level, i);
+        const uint32_t csel = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, i);
+        const int kx = (int)(csel & 0xfff) + 16, ky = (int)((csel >> 12) & 0xfff) + 16, score = (int)(csel >> 24);
+        const int pitch = __builtin_amdgcn_readlane(lv_pitch, level), bpitch = __builtin_amdgcn_readlane(lv_bpitch, level);
+        const uint8_t *plane = level == 0 ? img_l0 : img_pyr + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, level);
+        const uint8_t *bplane = img_bl + (uint32_t)__builtin_amdgcn_readlane((int)lv_boff, level);
+        uint32_t rw[5], bw[6];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int id = lane + 64 * t, rr = id / RP, cc = id - rr * RP;
+            rw[t] = id < 31 * RP ? load_u32_unaligned(plane + (size_t)(ky - 15 + rr) * pitch + (kx - 17 + 4 * cc)) : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int id = lane + 64 * t, rr = id / 10, cc = id - rr * 10;
+            bw[t] = id < BW * 10 ? load_u32_unaligned(bplane + (size_t)(ky - HR + rr) * bpitch + (kx - HR + 4 * cc)) : 0u;
+        }
+        wave_lds_phase();   // (the previous keypoint's reads are done)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (lane + 64 * t < 31 * RP) raw32[lane + 64 * t] = rw[t];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+            if (lane + 64 * t < BW * 10) bl32[lane + 64 * t] = bw[t];
+        wave_lds_phase();
+        // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword.  Raw dword (row vr, dj - 1) holds the
+        // columns u = 4 dj - 21 .. 4 dj - 18 -- the alignment of describe_kernel's patch dwords 1..9, so its byte masks apply
+        int m10 = 0, m01 = 0;
+        if (ic_rs < 7) {
+            const int c0 = 4 * ic_dj - PR;
+            for (int vr = ic_rs; vr < 31; vr += 7) {
+                const uint32_t d = raw32[vr * RP + ic_dj - 1] & c_icmask[vr * 9 + ic_dj - 1];
+                const int S = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
+                const int T = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
+                m10 += c0 * S + T;
+                m01 += (vr - 15) * S;
+            }
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float ang = __fmul_rn(angle, factorPI);
+        float a, bb;
+        sincos_exact(ang, &bb, &a);
+        unsigned long long words[4];
+        const float MAGIC = 12582912.f;
+        const uint32_t K = 0x400000u * (uint32_t)BP + 0x4B400000u - (uint32_t)(HR * BP + HR);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t pat = pats[r];
+            int val[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float px = (float)(int8_t)(pat >> (16 * q)), py = (float)(int8_t)(pat >> (16 * q + 8));
+                const float fy = __fadd_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)), MAGIC);
+                const float fx = __fadd_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)), MAGIC);
+                const uint32_t off = (uint32_t)(__mul24(__builtin_bit_cast(int, fy), BP) + __builtin_bit_cast(int, fx)) - K;
+                val[q] = bl8[off];
+            }
+            words[r] = __ballot(val[0] < val[1]);
+        }
+        if (lane == 0) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
+            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+            aos2_keypoint_t kp;
+            const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv_scale), level));
+            kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
+            kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
+            kp.size = (float)__builtin_amdgcn_readlane(lv_sp, level);
+            kp.angle = angle;
+            kp.response = (float)score;
+            kp.octave = level;
+            kp.class_id = -1;
+            kps[(size_t)b * cap + k] = kp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The whole pyramid of an image in ONE launch (ComputePyramid, src/ORBextractor.cc:1107-1132: level k is cv::resize of
 // level k - 1).  A workgroup owns one tile of every level (the tiles of a workgroup sit on top of each other) and walks
 // the levels through two LDS buffers: level k - 1's region -> level k's region, of which it stores the part it owns.
@@ -1299,6 +1527,52 @@ void launch_octree_image(uint32_t *dense, size_t dense_stride, const OctGather &
 {
     hipLaunchKernelGGL(octree_image_kernel, dim3(batch), dim3(64 * n_levels), (size_t)lay.total, st, dense, dense_stride,
                        gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
+}
+
+// blurred planes of one image: level 0 first (pitch = width rounded up to 16), then the levels >= 1 at their pyramid offsets
+size_t blur_plan(const LevelDev *h_levels, int n_levels, size_t pyr_bytes, BlurPlanHost *out)
+{
+    const size_t l0 = (size_t)((h_levels[0].w + 15) & ~15) * h_levels[0].h;
+    const size_t l0_bytes = (l0 + 255) & ~(size_t)255;
+    int first = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        out->first[l] = first;
+        out->nq[l] = (h_levels[l].w + 3) / 4;
+        first += out->nq[l] * ((h_levels[l].h + BL_ROWS - 1) / BL_ROWS);
+        out->dst_off[l] = l == 0 ? 0u : (uint32_t)(l0_bytes + h_levels[l].off);
+        out->dst_pitch[l] = l == 0 ? (h_levels[0].w + 15) & ~15 : h_levels[l].pitch;
+    }
+    out->first[n_levels] = first;
+    return l0_bytes + pyr_bytes;
+}
+
+static BlurPlan to_dev(const BlurPlanHost &h)
+{
+    BlurPlan p;
+    for (int i = 0; i < 9; ++i) p.first[i] = h.first[i];
+    for (int i = 0; i < 8; ++i) {
+        p.nq[i] = h.nq[i]; p.dst_off[i] = h.dst_off[i]; p.dst_pitch[i] = h.dst_pitch[i];
+    }
+    return p;
+}
+
+void launch_blur_levels(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                        const LevelDev *levels, int n_levels, const BlurPlanHost &plan, uint8_t *blur, size_t blur_stride, int batch,
+                        hipStream_t st)
+{
+    dim3 grd((plan.first[n_levels] + 255) / 256, batch);
+    hipLaunchKernelGGL(blur_levels_kernel, grd, dim3(256), 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, to_dev(plan),
+                       blur, blur_stride);
+}
+
+void launch_describe_blur(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
+                          const uint8_t *blur, size_t blur_stride, const BlurPlanHost &plan, const LevelDev *levels, int n_levels,
+                          const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
+                          aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, int32_t *status, hipStream_t st)
+{
+    dim3 blk(64), grd((batch + 7) & ~7, (cap + DK - 1) / DK);
+    hipLaunchKernelGGL(describe_blur_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, blur, blur_stride, to_dev(plan),
+                       levels, n_levels, sel, sel_stride, cap_level, sel_level_cnt, kps, desc, cap, n_out, status, batch);
 }
 
 void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,

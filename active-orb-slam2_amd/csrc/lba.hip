@@ -1236,7 +1236,7 @@ template <bool kGlob>
 __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
 {
     constexpr int NT = 512, NW = 8;
-    __shared__ int s_fail;
+    __shared__ int s_fail, s_tile;
     const int n = 6 * Wn.np, npad = Wn.npad;
     const double lambda = Wn.st->lambda;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1405,6 +1405,13 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
         const int m = nb - kb - 1;
         LDLT_T(t_a = __builtin_amdgcn_s_memtime();)
         // ---- P_k: W_I = A_Ik T^T (one 16-row tile per wave turn), L_Ik = W_I D^-1
+        // (kGlob: wave 0 requests the entries of the NEXT diagonal block -- tile 0 of the trailing update, final since the last
+        // panel's update -- before the panel: its round trip to device memory is off the critical path of the look-ahead)
+        double4_t acc0 = {0, 0, 0, 0};
+        if (kGlob && wave == 0 && m > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[r] = M[(size_t)(k0 + 16 + rq + 4 * r) * ld + k0 + 16 + col];
+        }
         for (int ti = wave; ti < m; ti += NW) {
             const int I0 = (kb + 1 + ti) << 4;
             double4_t acc = {0, 0, 0, 0};
@@ -1423,6 +1430,7 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
                 M[(size_t)(I0 + rq + 4 * r) * ld + k0 + col] = acc[r] * rd;
             }
         }
+        if (kGlob && tid == 0) s_tile = 1;   // (tile 0 is wave 0's)
         __syncthreads();
         // forward substitution of the rows below: r_i -= sum_c L[i][k0 + c] y_c (c ascending)
         for (int i = k0 + 16 + tid; i < npad; i += NT) {
@@ -1455,8 +1463,12 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
             int I0, J0;
             tile_at(t, I0, J0);
             double4_t acc;
+            if (kGlob && t == 0)
+                acc = acc0;
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
+                for (int r = 0; r < 4; ++r) acc[r] = M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col];
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const double av = -W[(size_t)(I0 + col) * lw + 4 * kk + rq];          // A[i = lane&15][k = lane>>4]
@@ -1470,27 +1482,33 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
                 for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
             }
         };
-        if (wave == 0) {
-            if (ntiles > 0) {
-                // (the rows k0+16 .. k0+31 of the forward substitution above belong to threads 0..15 = this wave)
-                wave_sync();
-                tile(0);
-                wave_sync();
-                LDLT_T(const long long t_d = __builtin_amdgcn_s_memtime();)
-                diag_block(k0 + 16, true);
-                LDLT_T(tD += __builtin_amdgcn_s_memtime() - t_d;)
-            }
-        } else if (kGlob) {
-            // kTileBatch tiles of a wave in flight together: a tile is one round trip to the device scratch, not an LDS one
-            for (int t = wave; t < ntiles; t += kTileBatch * (NW - 1)) {
-                int I0[kTileBatch], J0[kTileBatch];
-                double4_t acc[kTileBatch];
+        // kGlob: the tiles are handed out kTileBatch at a time from a counter in LDS (a tile's result does not depend on the wave
+        // that forms it), the next batch's entries are requested before the current batch's products are formed (a batch is a
+        // round trip to device memory), and wave 0 joins when its diagonal block is done: at 30-40 free keyframes the trailing
+        // update, not the pivot chain, was the longer side of the look-ahead (measured: DESIGN.md 5.3)
+        auto run_tiles = [&]() {
+            auto grab = [&]() {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&s_tile, kTileBatch);
+                return __builtin_amdgcn_readfirstlane(t);
+            };
+            int I0[kTileBatch], J0[kTileBatch];
+            double4_t acc[kTileBatch];
+            auto fetch = [&](int t, int (&I)[kTileBatch], int (&J)[kTileBatch], double4_t (&a)[kTileBatch]) {
 #pragma unroll
-                for (int u = 0; u < kTileBatch; ++u) tile_at(min(t + u * (NW - 1), ntiles - 1), I0[u], J0[u]);
+                for (int u = 0; u < kTileBatch; ++u) tile_at(min(t + u, ntiles - 1), I[u], J[u]);
 #pragma unroll
                 for (int u = 0; u < kTileBatch; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[u][r] = M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col];
+                    for (int r = 0; r < 4; ++r) a[u][r] = M[(size_t)(I[u] + rq + 4 * r) * ld + J[u] + col];
+            };
+            int t = grab();
+            if (t < ntiles) fetch(t, I0, J0, acc);
+            while (t < ntiles) {
+                const int tn = grab();
+                int In[kTileBatch], Jn[kTileBatch];
+                double4_t an[kTileBatch];
+                if (tn < ntiles) fetch(tn, In, Jn, an);
 #pragma unroll
                 for (int u = 0; u < kTileBatch; ++u)
 #pragma unroll
@@ -1500,10 +1518,29 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
                     }
 #pragma unroll
                 for (int u = 0; u < kTileBatch; ++u)
-                    if (t + u * (NW - 1) < ntiles)
+                    if (t + u < ntiles)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col] = acc[u][r];
+                t = tn;
+#pragma unroll
+                for (int u = 0; u < kTileBatch; ++u) {
+                    I0[u] = In[u]; J0[u] = Jn[u]; acc[u] = an[u];
+                }
             }
+        };
+        if (wave == 0) {
+            if (ntiles > 0) {
+                // (the rows k0+16 .. k0+31 of the forward substitution above belong to threads 0..15 = this wave)
+                wave_sync();
+                tile(0);
+                wave_sync();
+                LDLT_T(const long long t_d = __builtin_amdgcn_s_memtime();)
+                diag_block(k0 + 16, true);
+                LDLT_T(tD += __builtin_amdgcn_s_memtime() - t_d;)
+                if (kGlob) run_tiles();
+            }
+        } else if (kGlob) {
+            run_tiles();
         } else {
             for (int t = wave; t < ntiles; t += NW - 1) tile(t);
         }
@@ -1680,8 +1717,18 @@ int lba_handle_init(aos2_lba *s)
             AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     }
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            AOS2_HIP_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, greatest));
+        else
+            AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+        AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -2029,6 +2076,9 @@ void aos2_lba_destroy(aos2_lba_t *s)
         s->h_in.release();
         s->h_abort.release();
         for (auto &e : s->ev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(s->ev_fork);
+        (void)hipEventDestroy(s->ev_join);
+        (void)hipStreamDestroy(s->stream2);
         (void)hipStreamDestroy(s->stream);
     }
     delete s;
@@ -2407,11 +2457,21 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
     auto enqueue_trial = [&]() {
         if (!tasks.empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks.size()), dim3(kSchurThreads), 0, q, dw, d_schur_tasks);
-        if (any_glob)   // (first: the longer of the two)
-            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
+        // the two forms of the reduced-system kernel work on different windows: side by side (the LDS form on a stream of its own)
+        const bool both = any_glob && any_lds;
+        if (both) {
+            (void)hipEventRecord(s->ev_fork, q);
+            (void)hipStreamWaitEvent(s->stream2, s->ev_fork, 0);
+        }
         if (any_lds) {
             const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
-            hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, q, dw);
+            hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, both ? s->stream2 : q, dw);
+        }
+        if (any_glob)
+            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
+        if (both) {
+            (void)hipEventRecord(s->ev_join, s->stream2);
+            (void)hipStreamWaitEvent(q, s->ev_join, 0);
         }
         enqueue_points(1);   // + the LM decision in its last workgroup
         enqueue_lin(0);

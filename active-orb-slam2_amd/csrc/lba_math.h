@@ -368,6 +368,8 @@ struct aos2_lba {
     bool dev_ready = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {};   // [0], [1]: device time of a call; [2]: spare
+    hipStream_t stream2 = nullptr;      // LocalBA: the LDS form of the reduced-system kernel runs here beside the device-memory form
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     aos2::DevBuf<uint8_t> arena;
     aos2::PinnedBuf<uint8_t> h_stage;   // results on their way back
     aos2::PinnedBuf<uint8_t> h_in;      // staged inputs (the arena's prefix)
