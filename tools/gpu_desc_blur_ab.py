@@ -21,7 +21,7 @@ for cfg, seeds in (("tum", (1, 2, 3)), ("kitti", (4,)), ("euroc", (5,))):
         same = len(k) == len(ok) and k.tobytes() == ok.tobytes() and (d == od).all()
         bad += not same
         print(f"[{mode}] {cfg} seed {sd}: {len(k)} keypoints, equal to the oracle: {same}" + ("" if same else f" ({int((d != od).any(1).sum()) if len(k) == len(ok) else -1} descriptors differ)"))
-for wh in ((250, 170), (333, 211)):
+for wh in ((400, 300), (515, 389)):
     img = pkg.synth.synth_image(9, *wh)
     k, d = pkg.Extractor(nfeatures=300)(img)
     ok, od = O.Extractor(nfeatures=300).extract(img)
