@@ -102,6 +102,7 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
 struct BlurPlanHost {
     int first[9];
     int nq[8];
+    int nq_in[8];
     uint32_t dst_off[8];
     int dst_pitch[8];
 };

@@ -1159,6 +1159,9 @@ constexpr int BL_ROWS = 16;
 struct BlurPlan {
     int first[9];            // first item of each level (item = (band, quad)); first[n_levels] = total
     int nq[8];               // quads per row
+    int nq_in[8];            // ... of which interior (quads 1 .. nq_in: the 12 bytes around them lie inside the row); a level's interior
+                             // items come first, the edge quads (0 and the last two or three of a row, REFLECT_101 byte by byte) behind
+                             // them in waves of their own: mixed into every wave they doubled the kernel's time
     uint32_t dst_off[8];     // byte offset of the level's blurred plane inside one image's block
     int dst_pitch[8];
 };
@@ -1178,8 +1181,17 @@ __global__ __launch_bounds__(256) void blur_levels_kernel(const uint8_t *__restr
     const uint8_t *plane = l == 0 ? img0 + (size_t)b * img0_stride : pyr + (size_t)b * pyr_stride + L.off;
     uint8_t *dst = blur + (size_t)b * blur_stride + plan.dst_off[l];
     const int dpitch = plan.dst_pitch[l];
-    const int id = it - plan.first[l], nq = plan.nq[l];
-    const int band = id / nq, q = id - band * nq;
+    const int id = it - plan.first[l], nq = plan.nq[l], nqi = plan.nq_in[l], nbands = (h + BL_ROWS - 1) / BL_ROWS;
+    int band, q;
+    if (id < nbands * nqi) {
+        band = id / nqi;
+        q = 1 + (id - band * nqi);
+    } else {
+        const int ne = nq - nqi, ie = id - nbands * nqi;
+        band = ie / ne;
+        q = ie - band * ne;
+        q = q == 0 ? 0 : nqi + q;   // quad 0, then the quads behind the interior ones
+    }
     const int x0 = 4 * q, y0 = band * BL_ROWS;
     const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
     const uint32_t g[7] = {g0, g1, g2, g3, g2, g1, g0};
@@ -1290,26 +1302,41 @@ __global__ __launch_bounds__(64) void describe_blur_kernel(const uint8_t *__rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) pats[r] = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * (r * 64 + lane)]);
     const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1;   // IC_Angle: 7 rows x 9 dwords
-    // staging grids: raw 31 rows x 9 dwords = 279 items (5 rounds), blurred 37 rows x 10 dwords = 370 items (6 rounds)
-    for (int i = 0; i < nk; ++i) {
-        const int k = k0 + i;
-        const int level = __builtin_amdgcn_readlane(my_level, i);
+    // staging grids: raw 31 rows x 9 dwords = 279 items (5 rounds), blurred 37 rows x 10 dwords = 370 items (6 rounds); the loads
+    // of keypoint i + 1 are in flight while keypoint i is processed out of LDS (like describe_kernel's prefetch)
+    struct Slot {
+        int level, kx, ky, score;
+    };
+    auto locate = [&](int i) {
+        Slot sl;
+        sl.level = __builtin_amdgcn_readlane(my_level, i);
         const uint32_t csel = (uint32_t)__builtin_amdgcn_readlane((int)my_sel, i);
-        const int kx = (int)(csel & 0xfff) + 16, ky = (int)((csel >> 12) & 0xfff) + 16, score = (int)(csel >> 24);
-        const int pitch = __builtin_amdgcn_readlane(lv_pitch, level), bpitch = __builtin_amdgcn_readlane(lv_bpitch, level);
-        const uint8_t *plane = level == 0 ? img_l0 : img_pyr + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, level);
-        const uint8_t *bplane = img_bl + (uint32_t)__builtin_amdgcn_readlane((int)lv_boff, level);
-        uint32_t rw[5], bw[6];
+        sl.kx = (int)(csel & 0xfff) + 16;
+        sl.ky = (int)((csel >> 12) & 0xfff) + 16;
+        sl.score = (int)(csel >> 24);
+        return sl;
+    };
+    uint32_t rw[5], bw[6];
+    auto prefetch = [&](const Slot &sl) {
+        const int pitch = __builtin_amdgcn_readlane(lv_pitch, sl.level), bpitch = __builtin_amdgcn_readlane(lv_bpitch, sl.level);
+        const uint8_t *plane = sl.level == 0 ? img_l0 : img_pyr + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, sl.level);
+        const uint8_t *bplane = img_bl + (uint32_t)__builtin_amdgcn_readlane((int)lv_boff, sl.level);
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             const int id = lane + 64 * t, rr = id / RP, cc = id - rr * RP;
-            rw[t] = id < 31 * RP ? load_u32_unaligned(plane + (size_t)(ky - 15 + rr) * pitch + (kx - 17 + 4 * cc)) : 0u;
+            rw[t] = id < 31 * RP ? load_u32_unaligned(plane + (size_t)(sl.ky - 15 + rr) * pitch + (sl.kx - 17 + 4 * cc)) : 0u;
         }
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             const int id = lane + 64 * t, rr = id / 10, cc = id - rr * 10;
-            bw[t] = id < BW * 10 ? load_u32_unaligned(bplane + (size_t)(ky - HR + rr) * bpitch + (kx - HR + 4 * cc)) : 0u;
+            bw[t] = id < BW * 10 ? load_u32_unaligned(bplane + (size_t)(sl.ky - HR + rr) * bpitch + (sl.kx - HR + 4 * cc)) : 0u;
         }
+    };
+    Slot cur = locate(0);
+    prefetch(cur);
+    for (int i = 0; i < nk; ++i) {
+        const int k = k0 + i;
+        const int level = cur.level, kx = cur.kx, ky = cur.ky, score = cur.score;
         wave_lds_phase();   // (the previous keypoint's reads are done)
 #pragma unroll
         for (int t = 0; t < 5; ++t)
@@ -1317,6 +1344,10 @@ __global__ __launch_bounds__(64) void describe_blur_kernel(const uint8_t *__rest
 #pragma unroll
         for (int t = 0; t < 6; ++t)
             if (lane + 64 * t < BW * 10) bl32[lane + 64 * t] = bw[t];
+        if (i + 1 < nk) {
+            cur = locate(i + 1);
+            prefetch(cur);
+        }
         wave_lds_phase();
         // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword.  Raw dword (row vr, dj - 1) holds the
         // columns u = 4 dj - 21 .. 4 dj - 18 -- the alignment of describe_kernel's patch dwords 1..9, so its byte masks apply
@@ -1538,6 +1569,7 @@ size_t blur_plan(const LevelDev *h_levels, int n_levels, size_t pyr_bytes, BlurP
     for (int l = 0; l < n_levels; ++l) {
         out->first[l] = first;
         out->nq[l] = (h_levels[l].w + 3) / 4;
+        out->nq_in[l] = std::max(0, std::min(out->nq[l] - 1, (h_levels[l].w - 9) / 4));   // quads q >= 1 with 4 q + 8 < w
         first += out->nq[l] * ((h_levels[l].h + BL_ROWS - 1) / BL_ROWS);
         out->dst_off[l] = l == 0 ? 0u : (uint32_t)(l0_bytes + h_levels[l].off);
         out->dst_pitch[l] = l == 0 ? (h_levels[0].w + 15) & ~15 : h_levels[l].pitch;
@@ -1551,7 +1583,7 @@ static BlurPlan to_dev(const BlurPlanHost &h)
     BlurPlan p;
     for (int i = 0; i < 9; ++i) p.first[i] = h.first[i];
     for (int i = 0; i < 8; ++i) {
-        p.nq[i] = h.nq[i]; p.dst_off[i] = h.dst_off[i]; p.dst_pitch[i] = h.dst_pitch[i];
+        p.nq[i] = h.nq[i]; p.nq_in[i] = h.nq_in[i]; p.dst_off[i] = h.dst_off[i]; p.dst_pitch[i] = h.dst_pitch[i];
     }
     return p;
 }
