@@ -934,14 +934,7 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     const uint8_t *img_l0 = img0 + (size_t)b * img0_stride;
     uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
     // per-lane constants of the three lane grids (each split done once)
-#ifdef AOS2_DESC_STAGE_DWORD
     const int st_rs = (lane * 373) >> 12, st_c = lane - 11 * st_rs;   // staging: 5 rows x 11 dwords
-#else
-    // staging: 21 rows x 3 chunks of 16 bytes per round, 3 rounds (rows 0-20, 21-41, 42): the stage is bound by the texture
-    // path's time per wave-load of scattered rows (round 4: a variant WITHOUT the blur arithmetic ran no faster), and a 48-byte
-    // row takes 3 lanes of a 16-byte load instead of 11 lanes of a 4-byte one -- 3 load instructions per patch, not 9
-    const int st_rs = (lane * 171) >> 9, st_c = lane - 3 * st_rs;       // lane / 3, lane % 3 (lanes 0..62)
-#endif
     const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1; // IC_Angle: 7 rows x 9 dwords
     // Gaussian weights (8 fractional bits, sum 257): bytes for the h-pass dot4, u16 pairs for the v-pass dot2
     const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
@@ -982,26 +975,9 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         s.h = __builtin_amdgcn_readlane(lv_h, s.level);
         s.pitch = __builtin_amdgcn_readlane(lv_pitch, s.level);
         s.plane = s.level == 0 ? img_l0 : img_pyr + (uint32_t)__builtin_amdgcn_readlane((int)lv_off, s.level);
-#ifndef AOS2_DESC_STAGE_DWORD
-        s.interior = s.kx - PR >= 0 && s.kx - PR + 48 <= s.w && s.ky - PR >= 0 && s.ky + PR < s.h;   // (48 bytes of every row are read)
-#else
         s.interior = s.kx - PR >= 0 && s.kx + PR + 1 < s.w && s.ky - PR >= 0 && s.ky + PR < s.h;
-#endif
         return s;
     };
-#ifndef AOS2_DESC_STAGE_DWORD
-    uint4 pre4[3];
-    auto prefetch = [&](const Slot &s) {
-        if (s.interior && lane < 63) {
-            const uint8_t *base = s.plane + (size_t)(s.ky - PR) * s.pitch + (s.kx - PR);
-            const uint32_t loff = __umul24((uint32_t)st_rs, (uint32_t)s.pitch) + 16u * (uint32_t)st_c;
-            const uint32_t step = 21u * (uint32_t)s.pitch;
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (t < 2 || st_rs < 1) __builtin_memcpy(&pre4[t], base + (loff + (uint32_t)t * step), 16);
-        }
-    };
-#else
     uint32_t pre[9];
     auto prefetch = [&](const Slot &s) {
         if (s.interior && st_rs < 5) {
@@ -1014,28 +990,18 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                 if (t < 8 || st_rs < 3) pre[t] = load_u32_unaligned(base + (loff + (uint32_t)t * step));
         }
     };
-#endif
     Slot cur = locate(0);
     prefetch(cur);
     for (int i = 0; i < nk; ++i) {
         const int k = k0 + i;
         // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
         if (cur.interior) {
-#ifndef AOS2_DESC_STAGE_DWORD
-            if (lane < 63) {
-                uint4 *dst = reinterpret_cast<uint4 *>(patch32 + st_rs * PD + 4 * st_c);
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (t < 2 || st_rs < 1) dst[t * 21 * (PD / 4)] = pre4[t];
-            }
-#else
             if (st_rs < 5) {
                 uint32_t *dst = patch32 + st_rs * PD + st_c;
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
                     if (t < 8 || st_rs < 3) dst[t * 5 * PD] = pre[t];
             }
-#endif
         } else {
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)   // rare path: keep it out of the register budget
             for (int q = lane; q < PW * PW; q += 64) {
