@@ -145,6 +145,7 @@ def lib():
             L.aos2_lba_debug_stop_at_poll.argtypes = [vp, ci]
             L.aos2_lba_set_host_threads.argtypes = [vp, ci]
             L.aos2_lba_last_program.argtypes = [vp, vp, vp]
+            L.aos2_lba_debug_host_phase.argtypes = [vp, ci, ci, vp, vp]
             if hasattr(L, "aos2_pose_optimization"):
                 L.aos2_pose_optimization.argtypes = [vp, vp, vp, ci]
                 L.aos2_pose_optimization_last_device_ms.argtypes = [vp]
@@ -884,6 +885,25 @@ class _PoseProblem(C.Structure):
 
 class _PoseResult(C.Structure):
     _fields_ = [("Tcw", C.c_float * 16), ("outlier", C.c_void_p), ("n_bad", C.c_int32), ("n_inliers", C.c_int32)]
+
+
+def lba_host_phase(probs, threads):
+    """aos2_lba_debug_host_phase: (build ms, stage ms) of the host part of a LocalBA batch; needs no device"""
+    n = len(probs)
+    keep = []
+    S = (_LbaProblem * n)()
+    for i, prob in enumerate(probs):
+        s = S[i]
+        s.n_poses, s.n_points, s.n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
+        for name, dt in (("pose_Tcw", np.float32), ("pose_fixed", np.uint8), ("pose_id", np.int64), ("point_xyz", np.float32),
+                         ("point_id", np.int64), ("edge_pose", np.int32), ("edge_point", np.int32), ("edge_obs", np.float32),
+                         ("edge_stereo", np.uint8), ("edge_inv_sigma2", np.float32)):
+            a = np.ascontiguousarray(prob[name], dt)
+            keep.append(a)
+            setattr(s, name, a.ctypes.data)
+    b, st = C.c_double(), C.c_double()
+    _check(lib().aos2_lba_debug_host_phase(C.byref(S), n, int(threads), C.byref(b), C.byref(st)))
+    return float(b.value), float(st.value)
 
 
 class LocalBA:

@@ -2099,6 +2099,63 @@ int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *ho
     return AOS2_OK;
 }
 
+// The host part of aos2_lba_solve_batch without a device: the per-window index structures (build_pass, Schur items and units)
+// and the staging copies (into pageable memory here), on `threads` worker threads.  For measuring / testing how the host phases of
+// several ranks share a node's cores (tests/test_sharding_cpu.py); returns the wall time of the two phases.
+int aos2_lba_debug_host_phase(const aos2_lba_problem_t *problems, int n_problems, int threads, double *build_ms, double *stage_ms)
+{
+    if (!problems || n_problems <= 0 || threads <= 0) return AOS2_ERR_ARG;
+    std::vector<Pass> passes(n_problems);
+    WindowPool pool;
+    if (n_problems > 1 && threads > 1) pool.start(std::min(threads, n_problems));
+    std::vector<uint8_t> ok(n_problems, 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    pool.run(n_problems, [&](int i) {
+        const aos2_lba_problem_t *p = problems + i;
+        for (int e = 0; e < p->n_edges; ++e)
+            if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) {
+                ok[i] = 0;
+                return;
+            }
+        ok[i] = build_pass(p, passes[i]) ? 1 : 0;
+        if (ok[i] && passes[i].np > 0) {
+            build_schur_items(passes[i]);
+            build_schur_units(passes[i]);
+        }
+    });
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n_problems; ++i)
+        if (!ok[i]) {
+            set_error("problem %d: bad edge", i);
+            return AOS2_ERR_ARG;
+        }
+    std::vector<std::vector<uint8_t>> stage(n_problems);
+    pool.run(n_problems, [&](int i) {
+        const aos2_lba_problem_t *p = problems + i;
+        const Pass &S = passes[i];
+        const size_t NP = p->n_poses, NL = p->n_points, E = p->n_edges;
+        const std::vector<int32_t> *lists[] = {&S.pl_pos, &S.hpose, &S.hpoint, &S.pt_off, &S.pt_k, &S.ps_off, &S.ps_k, &S.pl_off, &S.pl_ph,
+                                               &S.it_ka, &S.it_kb, &S.it_l, &S.blk_off, &S.sr_o0, &S.sr_info, &S.sr_ij};
+        size_t bytes = 64 * NP + 12 * NL + 12 * E + 4 * E + 4 * E + 4 * E + E;
+        for (auto *v : lists) bytes += 4 * v->size();
+        std::vector<uint8_t> &buf = stage[i];
+        buf.resize(bytes);
+        uint8_t *d = buf.data();
+        auto put = [&](const void *src, size_t n) {
+            memcpy(d, src, n);
+            d += n;
+        };
+        put(p->pose_Tcw, 64 * NP); put(p->point_xyz, 12 * NL); put(p->edge_obs, 12 * E); put(p->edge_inv_sigma2, 4 * E);
+        put(p->edge_pose, 4 * E); put(p->edge_point, 4 * E); put(p->edge_stereo, E);
+        for (auto *v : lists)
+            if (!v->empty()) put(v->data(), 4 * v->size());
+    });
+    const auto t2 = std::chrono::steady_clock::now();
+    if (build_ms) *build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (stage_ms) *stage_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    return AOS2_OK;
+}
+
 int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll)
 {
     if (!s || poll < 0) return AOS2_ERR_ARG;

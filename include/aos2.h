@@ -630,6 +630,10 @@ int aos2_lba_set_host_threads(aos2_lba_t *s, int n);
  * the call (iterations + 1 per optimisation, + 4 per continuation round; a window that needs fewer leaves its slots empty --
  * the lock-step cost of a heterogeneous batch), `host_rounds` = times the host waited for the device (1 = no continuation). */
 int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *host_rounds);
+/* Measurement hook (no device, no reference equivalent): the HOST part of aos2_lba_solve_batch for `n_problems` windows -- the
+ * per-window index structures and the staging copies -- on `threads` worker threads; wall milliseconds of the two phases. */
+int aos2_lba_debug_host_phase(const aos2_lba_problem_t *problems, int n_problems, int threads, double *build_ms,
+                              double *stage_ms);
 /* Test hook (no reference equivalent): the stop flag counts as set from its `poll`-th evaluation on (1 = the entry
  * check), as if another thread had set it at that moment; 0 switches the hook off.  Used with
  * aos2_lba_result_t.stop_poll to reproduce an asynchronous abort deterministically. */

@@ -83,3 +83,50 @@ def test_shard_range_partitions(pkg):
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
     assert sh.slot_bytes(1200) % 16 == 0
+
+
+_HOST_PHASE_PROBS = {}   # filled by the parent before it forks the "ranks"
+
+
+def _host_phase_worker(rank, threads, barrier, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    probs = _HOST_PHASE_PROBS[rank]
+    pkg.capi.lba_host_phase(probs, threads)   # (first touch of the buffers)
+    barrier.wait()
+    t0 = time.perf_counter()
+    b, s = pkg.capi.lba_host_phase(probs, threads)
+    q.put((rank, b, s, (time.perf_counter() - t0) * 1e3))
+
+
+def test_lba_host_phase_of_eight_ranks_shares_the_cores(pkg):
+    """8 ranks' LocalBA handles build their windows' index structures at the same time.  Every rank caps its
+    worker pool at cores / ranks (lba.hip: lba_host_threads; bench.py passes cores / (ranks x handles)), so 8 processes running the
+    host part of a batch concurrently must not take much longer than one process alone with the same number of threads (an
+    oversubscribed node -- 8 x 2 x 32 threads on the cores of one rank -- would)."""
+    ranks, n_win = 8, 6
+    threads = max(1, (os.cpu_count() or 1) // ranks)
+    mix = pkg.synth.lba_window_mix(0, n_win)
+    for m in mix:
+        m["n_points"] = 1200 + m["n_points"] // 8   # (small windows: the generator, not the phase under test, is the slow part here)
+    probs = [pkg.synth.synth_lba_problem(**kw) for kw in mix]
+    for r in range(ranks):
+        _HOST_PHASE_PROBS[r] = probs[r % n_win:] + probs[:r % n_win]
+    ctx = mp.get_context("fork")
+
+    def run(n_proc):
+        barrier, q = ctx.Barrier(n_proc), ctx.Queue()
+        ps = [ctx.Process(target=_host_phase_worker, args=(r, threads, barrier, q)) for r in range(n_proc)]
+        [p.start() for p in ps]
+        out = [q.get(timeout=600) for _ in ps]
+        [p.join() for p in ps]
+        return max(o[3] for o in out)
+    alone = min(run(1) for _ in range(3))
+    together = min(run(ranks) for _ in range(3))
+    print(f"LocalBA host phase, {n_win} windows, {threads} thread(s) per rank: alone {alone:.1f} ms, {ranks} ranks at once {together:.1f} ms "
+          f"({os.cpu_count()} cores)")
+    # every core busy with one rank's thread: a generous bound that an oversubscribed pool (8 x 32 threads time-sliced on these
+    # cores) would still break
+    assert together < 4.0 * alone + 10.0, (alone, together)
