@@ -1051,7 +1051,11 @@ constexpr int kSchurThreads = 256;
 //         exactly the sums (and bits) of the one-wave-per-block form.
 constexpr int kSchurDiag = 0, kSchurBig = 1, kSchurPack = 2;
 // (SchurTask.code = kind << 28 | argument -- DIAG: i; BIG: block rank; PACK: first row; w = -1: padding of the XCD interleave)
-__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, bool diag, bool with_b, int n6, double (&acc)[42])
+// one item: (Hll + lambda I)^-1 of the landmark, then row by row of B_a: the row of B_a D^-1 (3 values) and its 6 products with the
+// rows of B_b -- the same operations in the same order as forming all of B_a D^-1 first, with 15 doubles less alive (the kernel is
+// bound by the workgroups resident per compute unit: 204 registers = two workgroups, <= 168 = three)
+template <bool kDiag>
+__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, int n6, double (&acc)[42])
 {
     const int ka = W.it_ka[j], kb = W.it_kb[j], l = W.it_l[j];   // three independent loads, then one level of gathers
     double D[9], Dinv[9];
@@ -1060,27 +1064,19 @@ __device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     mat3_inverse(D, Dinv);
     const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
-    double Bb[18], BD[18];
+    double Bb[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
-    if (diag) {   // (uniform) the two edges of an item are one: its block is fetched once
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r) {
+        // (diagonal block: the two edges of an item are one, its block is fetched once)
+        const double b0 = kDiag ? Bb[r * 3] : Bi[r * 3], b1 = kDiag ? Bb[r * 3 + 1] : Bi[r * 3 + 1], b2 = kDiag ? Bb[r * 3 + 2] : Bi[r * 3 + 2];
+        const double d0 = b0 * Dinv[0] + b1 * Dinv[3] + b2 * Dinv[6], d1 = b0 * Dinv[1] + b1 * Dinv[4] + b2 * Dinv[7],
+                     d2 = b0 * Dinv[2] + b1 * Dinv[5] + b2 * Dinv[8];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bb[r * 3] * Dinv[c] + Bb[r * 3 + 1] * Dinv[3 + c] + Bb[r * 3 + 2] * Dinv[6 + c];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double b0 = Bi[r * 3], b1 = Bi[r * 3 + 1], b2 = Bi[r * 3 + 2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) BD[r * 3 + c] = b0 * Dinv[c] + b1 * Dinv[3 + c] + b2 * Dinv[6 + c];
-        }
+        for (int c = 0; c < 6; ++c) acc[r * 6 + c] += d0 * Bb[c * 3] + d1 * Bb[c * 3 + 1] + d2 * Bb[c * 3 + 2];
     }
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[r * 6 + c] += BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
-    if (with_b) {   // (ka == kb: one edge per (keyframe, landmark) pair)
+    if (kDiag) {   // (ka == kb: one edge per (keyframe, landmark) pair)
         const double *bl = W.b + n6 + 3 * (size_t)l;
         double db[3];
 #pragma unroll
@@ -1107,7 +1103,11 @@ __device__ __forceinline__ void schur_store(const LbaWin &W, int i1, int i2, int
         W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
 }
 
-__global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks)
+#ifndef AOS2_SCHUR_WPE
+#define AOS2_SCHUR_WPE 3   // workgroups per compute unit (one wave of a workgroup per SIMD): 3 = 168 registers, 5 of them spilled
+#endif
+__global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(AOS2_SCHUR_WPE, AOS2_SCHUR_WPE)))
+void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks)
 {
     constexpr int NT = kSchurThreads;
     __shared__ double red[(NT / 16) * 43];
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
             s_info[row] = info;
             s_ij[row] = ij;
         }
-        if (li < (info & 255)) schur_item(W, o0 + li, lambda, false, false, n6, acc);
+        if (li < (info & 255)) schur_item<false>(W, o0 + li, lambda, n6, acc);
 #pragma unroll
         for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
         if (li == 0) {
@@ -1172,8 +1172,10 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur(const LbaWin *__restric
     const int blk = i1 * np - i1 * (i1 - 1) / 2 + (i2 - i1);
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
     if (!run) return;
-    const bool diag = kind == kSchurDiag;
-    for (int j = tid; j < n; j += NT) schur_item(W, o0 + j, lambda, diag, diag, n6, acc);
+    if (kind == kSchurDiag)
+        for (int j = tid; j < n; j += NT) schur_item<true>(W, o0 + j, lambda, n6, acc);
+    else
+        for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, acc);
     const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
     schur_store(W, i1, i2, tid, sum, lambda);
 }
