@@ -362,3 +362,22 @@ def test_very_wide_image_exceeds_twice_the_feature_budget(pkg, oracle, gpu):
     ok, od = oracle.Extractor(**kw).extract(img)
     assert len(k) == len(ok) == 268 and k.tobytes() == ok.tobytes() and (d == od).all()
     assert ex.max_keypoints_for(1171, 131) >= 268
+
+
+def test_whole_level_blur_form_equals_the_per_keypoint_form(pkg, oracle, gpu, monkeypatch):
+    """AOS2_DESC_BLUR=level (the reference's own order: GaussianBlur of every whole level, then the descriptors on the blurred
+    planes -- measured slower, kept for the A/B of profiles/r04_desc_blur_ab.txt) gives the same keypoints and descriptors, also
+    at the level borders (keypoints 19 pixels from an edge: the blur's REFLECT_101 columns / rows are sampled)."""
+    monkeypatch.setenv("AOS2_DESC_BLUR", "level")
+    for cfg, seed in (("tum", 11), ("kitti", 12)):
+        c = pkg.synth.CONFIGS[cfg]
+        img = pkg.synth.synth_image(seed, c["w"], c["h"])
+        k, d = pkg.Extractor(nfeatures=c["nfeatures"])(img)
+        ok, od = oracle.Extractor(nfeatures=c["nfeatures"]).extract(img)
+        assert len(k) == len(ok) and k.tobytes() == ok.tobytes() and (d == od).all()
+        assert (k["x"] < 24 * k["size"] / 31).any() or (k["y"] < 24 * k["size"] / 31).any()   # some keypoints sit next to a border
+    imgs = np.stack([pkg.synth.synth_image(20 + i, 401, 303) for i in range(5)])
+    ex = pkg.Extractor(nfeatures=500)
+    for (k, d), img in zip(ex.extract_batch(imgs), imgs):
+        ok, od = oracle.Extractor(nfeatures=500).extract(img)
+        assert k.tobytes() == ok.tobytes() and (d == od).all()

@@ -310,3 +310,27 @@ def test_keyframe_work_vs_oracle(pkg, oracle, gpu):
         tc.last.SearchForTriangulation(kw.kfs, [0], [10 ** 6], kw.F12[:1], kw.epipole[:1], kw.fv1[8].data_ptr(),
                                        [kw.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [kw.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
                                        kw.d_match12.data_ptr(), kw.d_nm.data_ptr())
+
+
+def test_stereo_frame_chain_vs_oracle(pkg, oracle, gpu):
+    """The stereo Frame constructor on the device (src/Frame.cc:57-113: both eyes extracted on two handles, ComputeStereoMatches
+    enqueued behind both without a host wait, aos2_frames_build_stereo) and the tracking chain behind it, KITTI geometry (2000
+    features: frames beyond 1536 queries take the 1024-thread greedy resolve), against the oracle chain whose Frame members come from
+    the oracle's ComputeStereoMatches: mvuRight / mvDepth and every later member bit for bit, poses 1e-5."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    scen = pkg.scenario.tracking_scenario(41, 3, cfg="kitti", n_unique=3, stereo=True)
+    tc = pkg.chain.StereoTrackingChain(scen, n_local=1500)
+    assert tc.cap > 1536
+    tc.step()
+    tc.wait()
+    co = parity.ChainOracle(scen, tc, th_last=tc.th_last, th_local=tc.th_local, nnratio_local=tc.nnratio_local)
+    snap = parity.chain_snapshot(pkg, tc)
+    assert parity.chain_mismatches(snap, co, range(3)) == []
+    assert (snap["depth"][:, :1500] > 0).sum() > 1500 and (snap["nm"][0] > 300).all()   # stereo matches exist, the chain tracks
+    # the synchronous ComputeStereoMatches call on the same extractions gives the same arrays
+    import torch
+    ur, dp = torch.zeros_like(tc.d_ur), torch.zeros_like(tc.d_dp)
+    pkg.capi.compute_stereo_matches_device(tc.ex, tc.ex_r, tc.B, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), tc.d_n.data_ptr(), tc.r_kps.data_ptr(),
+                                           tc.r_desc.data_ptr(), tc.r_n.data_ptr(), tc.cap, tc.mb, tc.mbf, ur.data_ptr(), dp.data_ptr())
+    assert torch.equal(ur, tc.d_ur) and torch.equal(dp, tc.d_dp)

@@ -475,3 +475,31 @@ def test_lba_bench_windows_vs_oracle(pkg, oracle, gpu, monkeypatch, layout):
     for i in range(32):
         got = pkg.LocalBA._result(R[i], prep["arrs"][i])
         assert parity.lba_mismatches(got, want[i % 4], tag=f"prepared window {i} ({layout})") == []
+
+
+def test_lba_mixed_window_batch_vs_oracle(pkg, oracle, gpu):
+    """A batch of DIFFERENT windows (synth.lba_window_mix: reduced systems inside and beyond LDS, sparse and dense covisibility) and
+    two hand-made extremes -- three keyframes sharing every point (off-diagonal blocks of > 256 items: k_schur's BIG units) and a
+    window whose second keyframe pair shares nothing (an empty block still gets its zeros): every window equals the oracle, and
+    the batch gives the bits of the windows solved alone (task lists, PACK units, the two reduced-system kernels side by side)."""
+    mix = pkg.synth.lba_window_mix(3, 6)
+    for m in mix:
+        m["n_points"] = 1500 + m["n_points"] // 6
+    probs = [pkg.synth.synth_lba_problem(**m) for m in mix]
+    probs.append(pkg.synth.synth_lba_problem(seed=61, n_local=3, n_fixed=1, n_points=1400, obs_per_point=4))
+    nfree = [int((p["pose_fixed"] == 0).sum()) for p in probs]
+    assert min(nfree) <= 21 < max(nfree)   # both forms of the reduced-system kernel
+    big = probs[-1]
+    free = np.flatnonzero(big["pose_fixed"] == 0)
+    both = np.intersect1d(big["edge_point"][big["edge_pose"] == free[0]], big["edge_point"][big["edge_pose"] == free[1]])
+    assert len(both) > 256   # a BIG off-diagonal block
+    ba = pkg.LocalBA()
+    batch = ba.LocalBundleAdjustmentBatch(probs)
+    assert ba.last_program()[0] >= 17
+    for p, got in zip(probs, batch):
+        want = oracle.lba_solve(p)
+        alone = pkg.LocalBA().LocalBundleAdjustment(p)
+        assert got["status"] == 0 and got["iters"] == want["iters"] and sum(got["trials"]) == want["trials"]
+        assert close(got["pose_Tcw"], want["pose_Tcw"], key="mix_pose") and close(got["point_xyz"], want["point_xyz"], key="mix_point")
+        assert (got["edge_outlier"] == want["edge_outlier"]).all()
+        assert _same(got, alone)
