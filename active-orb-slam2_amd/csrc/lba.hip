@@ -1230,14 +1230,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src)
 // wave_sync() = completion of the wave's outstanding stores.  The pivot chain of the diagonal blocks never touches memory, so
 // what the variant pays is one device-memory round trip per phase instead of an LDS one (measured: DESIGN.md 5.3).
 typedef double __attribute__((address_space(1))) gdouble_t;
-// LDS of k_ldlt_dev for a padded dimension: panel W, four vectors, T (two panels), the staged diagonal block; with_next: + the next
-// panel's diagonal block and column (host and kernel use the same formula: the kernel takes the staged form iff it fits)
-constexpr size_t kLdltDevLdsMax = 150 * 1024;
-__host__ __device__ inline size_t ldlt_dev_lds_doubles(int npad, bool with_next)
-{
-    const size_t nb = (size_t)npad / 16;
-    return (size_t)npad * 17 + 4 * (size_t)npad + 3 * 16 * 17 + 16 + (with_next ? 16 * 17 + (nb > 2 ? nb - 2 : 0) * 16 * 17 : 0);
-}
 #ifndef AOS2_LDLT_TILE_BATCH
 #define AOS2_LDLT_TILE_BATCH 4
 #endif
@@ -1263,12 +1255,6 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
     double *xs = rv + npad;                      // npad: solution
     double *Tb = xs + npad;                      // 2 x 16 x 17: T_k^T of the current / next panel
     double *Dst = Tb + 2 * 16 * 17;              // kGlob: 16 x 17, the next diagonal block on its way from the trailing update to wave 0's rows
-    // kGlob, when LDS has room (ldlt_dev_lds_doubles: up to ~45 free keyframes): what the NEXT panel reads of this panel's trailing
-    // update also travels through LDS -- the diagonal block after the next (Dnx) and the column below the next diagonal block (Anx,
-    // one 16 x 17 slot per row block) -- and the panel's L goes to device memory AFTER the barrier that follows it.  Then no barrier
-    // of the factorisation waits for stores that were only just issued (round 4: those drains were 6 of a panel's 16 k cycles).
-    double *Dnx = Dst + 16 * 17, *Anx = Dnx + 16 * 17;
-    const bool anx = kGlob && ldlt_dev_lds_doubles(npad, true) * sizeof(double) <= kLdltDevLdsMax;
     LDLT_T(long long tD = 0, tP = 0, tU = 0, t_a = 0; const long long t_begin = __builtin_amdgcn_s_memtime();)
     if (tid == 0) s_fail = 0;
     // load (identity-padded), lower BLOCK triangle only -- row r needs its columns up to the end of its diagonal block,
@@ -1425,53 +1411,29 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
         // panel's update -- before the panel: its round trip to device memory is off the critical path of the look-ahead)
         double4_t acc0 = {0, 0, 0, 0};
         if (kGlob && wave == 0 && m > 0) {
-            if (anx && kb > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc0[r] = Dnx[(rq + 4 * r) * 17 + col];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc0[r] = M[(size_t)(k0 + 16 + rq + 4 * r) * ld + k0 + 16 + col];
-            }
+            for (int r = 0; r < 4; ++r) acc0[r] = M[(size_t)(k0 + 16 + rq + 4 * r) * ld + k0 + 16 + col];
         }
-        double4_t lpend[4];   // (anx) the panel's L tiles of this wave, stored to device memory after the barrier
-        int npend = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) lpend[u] = double4_t{0, 0, 0, 0};
-        for (int ti = wave, u = 0; ti < m; ti += NW, ++u) {
+        for (int ti = wave; ti < m; ti += NW) {
             const int I0 = (kb + 1 + ti) << 4;
             double4_t acc = {0, 0, 0, 0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int c = 4 * kk + rq;
-                const double av = (anx && kb > 0) ? Anx[(size_t)ti * (16 * 17) + col * 17 + c] : (double)M[(size_t)(I0 + col) * ld + k0 + c];   // A[i = col][c]
+                const double av = M[(size_t)(I0 + col) * ld + k0 + c];                                  // A[i = col][c]
                 const double tv = Tb[(kb & 1) * (16 * 17) + c * 17 + col];                                // B[c][j = col] = T[j][c]
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tv, acc, 0, 0, 0);
             }
             const double rd = rdv[k0 + col];
             // the tile's A entries were all read by the MFMAs above (this wave only): overwrite them with L
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W[(size_t)(I0 + rq + 4 * r) * lw + col] = acc[r];
-            if (anx && u < 4) {
-                // (static indices: the deferred tiles live in registers)
-                const double4_t lv = {acc[0] * rd, acc[1] * rd, acc[2] * rd, acc[3] * rd};
-                if (u == 0) lpend[0] = lv; else if (u == 1) lpend[1] = lv; else if (u == 2) lpend[2] = lv; else lpend[3] = lv;
-                npend = u + 1;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + k0 + col] = acc[r] * rd;
+            for (int r = 0; r < 4; ++r) {
+                W[(size_t)(I0 + rq + 4 * r) * lw + col] = acc[r];
+                M[(size_t)(I0 + rq + 4 * r) * ld + k0 + col] = acc[r] * rd;
             }
         }
         if (kGlob && tid == 0) s_tile = 1;   // (tile 0 is wave 0's)
         __syncthreads();
-        if (anx) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < npend) {
-                    const int I0 = (kb + 1 + wave + u * NW) << 4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + k0 + col] = lpend[u][r];
-                }
-        }
         // forward substitution of the rows below: r_i -= sum_c L[i][k0 + c] y_c (c ascending)
         for (int i = k0 + 16 + tid; i < npad; i += NT) {
             double l[16];
@@ -1517,9 +1479,6 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
             if (kGlob && t == 0) {   // the next diagonal block: to wave 0's rows through LDS, not through the device scratch
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Dst[(rq + 4 * r) * 17 + col] = acc[r];
-            } else if (anx && J0 == k0 + 16) {   // (tile() only runs t == 0 in the staged form: never taken; run_tiles has the same rule)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Anx[(size_t)((I0 >> 4) - (kb + 2)) * (16 * 17) + (rq + 4 * r) * 17 + col] = acc[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) M[(size_t)(I0 + rq + 4 * r) * ld + J0 + col] = acc[r];
@@ -1561,19 +1520,9 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
                     }
 #pragma unroll
                 for (int u = 0; u < kTileBatch; ++u)
-                    if (t + u < ntiles) {
-                        if (anx && J0[u] == k0 + 16) {          // the next panel's column: to its slot in LDS (never read from device memory)
+                    if (t + u < ntiles)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) Anx[(size_t)((I0[u] >> 4) - (kb + 2)) * (16 * 17) + (rq + 4 * r) * 17 + col] = acc[u][r];
-                        } else {
-                            if (anx && I0[u] == k0 + 32 && J0[u] == k0 + 32) {   // the diagonal block after the next: also to LDS
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) Dnx[(rq + 4 * r) * 17 + col] = acc[u][r];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col] = acc[u][r];
-                        }
-                    }
+                        for (int r = 0; r < 4; ++r) M[(size_t)(I0[u] + rq + 4 * r) * ld + J0[u] + col] = acc[u][r];
                 t = tn;
 #pragma unroll
                 for (int u = 0; u < kTileBatch; ++u) {
@@ -1597,10 +1546,7 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
         } else {
             for (int t = wave; t < ntiles; t += NW - 1) tile(t);
         }
-        if (anx)   // what the next panel reads of this update is in LDS: the barrier waits for LDS only, not for the tiles' stores to device memory
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else
-            __syncthreads();
+        __syncthreads();
         LDLT_T(tU += __builtin_amdgcn_s_memtime() - t_a;)
     }
     LDLT_T(const long long t_fact = __builtin_amdgcn_s_memtime();)
@@ -1784,7 +1730,7 @@ int lba_handle_init(aos2_lba *s)
     }
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -2445,7 +2391,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // ---- staging (parallel) + descriptors
     LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
     bool any_lds = false, any_glob = false;
-    size_t mx_dev_lds = 0;
     int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part = 0, mx_npad_glob = 0, mx_npad_lds = 0;
     std::vector<uint8_t> up_fail(nw, 0);
     for_windows([&](int i) {
@@ -2529,8 +2474,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             } else {
                 any_glob = true;
                 mx_npad_glob = std::max(mx_npad_glob, l.npad);
-                const size_t with_next = ldlt_dev_lds_doubles(l.npad, true) * sizeof(double);
-                mx_dev_lds = std::max(mx_dev_lds, with_next <= kLdltDevLdsMax ? with_next : ldlt_dev_lds_doubles(l.npad, false) * sizeof(double));
             }
         }
         mx_E = std::max(mx_E, p->n_edges);
@@ -2584,7 +2527,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, both ? s->stream2 : q, dw);
         }
         if (any_glob)
-            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), mx_dev_lds, q, dw);
+            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
         if (both) {
             (void)hipEventRecord(s->ev_join, s->stream2);
             (void)hipStreamWaitEvent(q, s->ev_join, 0);
