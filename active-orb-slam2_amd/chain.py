@@ -231,8 +231,14 @@ class KeyFrameWork:
     results come back for the host-side map bookkeeping."""
 
     def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0,
-                 only_stereo: bool = False, check_orientation: bool = False, epipole=None, nb_cap: int | None = None):
+                 only_stereo: bool = False, check_orientation: bool = False, epipole=None, nb_cap: int | None = None, n_second: int = 0):
         t, scen = tc.torch, tc.scen
+        # n_nb first-order neighbours (CreateNewMapPoints triangulates against them, SearchInNeighbors fuses into them) and, per
+        # first-order neighbour, n_second second-order ones that are fuse targets only (src/LocalMapping.cc:475-485: up to 5 each,
+        # minus those that are first-order targets already)
+        n_first = int(n_nb)
+        self.n_first, self.n_second = n_first, int(n_second)
+        n_nb = n_first * (1 + int(n_second))   # neighbour keyframes per scene = fuse targets per keyframe
         self.tc, self.n_kf, self.n_nb, self.fuse_th = tc, int(n_kf), int(n_nb), float(fuse_th)
         # CreateNewMapPoints builds `ORBmatcher matcher(0.6, false)` and passes bOnlyStereo = false (src/LocalMapping.cc:221, 272)
         self.only_stereo, self.check_orientation, self.levelsup = bool(only_stereo), bool(check_orientation), int(levelsup)
@@ -280,6 +286,12 @@ class KeyFrameWork:
         self.F12 = np.ascontiguousarray(self.nb["F12"][self.kf2])
         # (sideways motion: the epipole is at infinity; the parity sweeps pass finite ones to drive the mono-mono test of :739-745)
         self.epipole = np.zeros((len(self.kf1), 2), np.float32) if epipole is None else np.ascontiguousarray(epipole, np.float32).reshape(len(self.kf1), 2)
+        # the pairs SearchForTriangulation runs on: a keyframe's first n_first neighbours; tri_of[pair] = its row in the results or -1
+        self.tri_pairs = np.flatnonzero((np.arange(len(self.kf1)) % n_nb) < n_first).astype(np.int32)
+        self.tri_of = np.full(len(self.kf1), -1, np.int32)
+        self.tri_of[self.tri_pairs] = np.arange(len(self.tri_pairs), dtype=np.int32)
+        self.t_kf1, self.t_kf2 = np.ascontiguousarray(self.kf1[self.tri_pairs]), np.ascontiguousarray(self.kf2[self.tri_pairs])
+        self.t_F12, self.t_epipole = np.ascontiguousarray(self.F12[self.tri_pairs]), np.ascontiguousarray(self.epipole[self.tri_pairs])
         rows = tc.last_mp[self.kf1].copy()                          # vpMapPointMatches of keyframe 1, per (keyframe, neighbour) problem
         drop = rng.random(rows.shape) < 0.1                         # IsInKeyFrame(pKFi) / isBad(): the loop head's gate (:844-850)
         rows[drop] = -1
@@ -296,11 +308,12 @@ class KeyFrameWork:
         self.d_rev_rows = t.from_numpy(loc).to(tc.dev)
         self.d_rev_idx, self.d_rev_dist = z(loc.shape, t.int32), z(loc.shape, t.int32)
         self.h_rev = [t.empty(loc.shape, dtype=t.int32).pin_memory() for _ in range(2)]
-        P = len(self.kf1)
-        self.d_match12, self.d_nm = z((P, cap1), t.int32), z((P,), t.int32)
+        P, PT = len(self.kf1), len(self.tri_pairs)
+        self.d_match12, self.d_nm = z((PT, cap1), t.int32), z((PT,), t.int32)
         self.d_best_idx, self.d_best_dist = z((P, cap1), t.int32), z((P, cap1), t.int32)
         # the results of a step land in pinned host memory (one copy per array; LocalMapping's bookkeeping reads them there)
-        self.h_out = [t.empty((P, cap1), dtype=t.int32).pin_memory() for _ in range(3)] + [t.empty((P,), dtype=t.int32).pin_memory()]
+        self.h_out = [t.empty((PT, cap1), dtype=t.int32).pin_memory()] + [t.empty((P, cap1), dtype=t.int32).pin_memory() for _ in range(2)] + \
+                     [t.empty((PT,), dtype=t.int32).pin_memory()]
         self.copy_stream = t.cuda.Stream(device=tc.dev)
         t.cuda.synchronize()
         self.last_ms = (0.0, 0.0)
@@ -309,7 +322,7 @@ class KeyFrameWork:
         import time
         tc = self.tc
         t0 = time.perf_counter()
-        tc.last.SearchForTriangulation(self.kfs, self.kf1, self.kf2, self.F12, self.epipole, self.fv1[8].data_ptr(),
+        tc.last.SearchForTriangulation(self.kfs, self.t_kf1, self.t_kf2, self.t_F12, self.t_epipole, self.fv1[8].data_ptr(),
                                        [self.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [self.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
                                        self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=self.only_stereo,
                                        check_orientation=self.check_orientation)
@@ -331,7 +344,7 @@ class KeyFrameWork:
     def snapshot(self):
         """the inputs (by reference) and the last results (copies), for oracle/parity.py"""
         import types
-        return types.SimpleNamespace(kf1=self.kf1, kf2=self.kf2, nb=self.nb, nb_mp=self.nb_mp, F12=self.F12, epipole=self.epipole,
+        return types.SimpleNamespace(kf1=self.kf1, kf2=self.kf2, nb=self.nb, nb_mp=self.nb_mp, F12=self.F12, epipole=self.epipole, tri_of=self.tri_of,
                                      fuse_rows=self.fuse_rows, n_nb=self.n_nb, fuse_th=self.fuse_th, only_stereo=self.only_stereo,
                                      check_orientation=self.check_orientation, levelsup=self.levelsup, rev_rows=self.rev_rows, rev_idx=self.rev_idx.copy(),
                                      rev_dist=self.rev_dist.copy(), match12=self.match12.copy(),

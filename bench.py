@@ -295,7 +295,11 @@ def main():
     # (the neighbour views come from the generator's scenes: with recorded frames the leg is left out and the line says so)
     NO_KFW = NO_BOW or bool(real) or KITTI or os.environ.get("AOS2_BENCH_NO_KEYFRAME_WORK") == "1"
     N_NB = 10
-    kfws = [] if NO_KFW else [pkg.chain.KeyFrameWork(pp, voc_nodes, n_bow, n_nb=N_NB) for pp in pipes]
+    # SearchInNeighbors also fuses into second-order neighbours (src/LocalMapping.cc:475-485: GetBestCovisibilityKeyFrames(5) of every
+    # first-order neighbour, minus those that are first-order targets already -- covisibility lists overlap heavily): 2 new ones per
+    # first-order neighbour here = 30 Fuse targets per keyframe (AOS2_BENCH_SECOND_NEIGHBOURS; 0 = round 3's step)
+    N_SECOND = max(0, int(os.environ.get("AOS2_BENCH_SECOND_NEIGHBOURS", "2")))
+    kfws = [] if NO_KFW else [pkg.chain.KeyFrameWork(pp, voc_nodes, n_bow, n_nb=N_NB, n_second=N_SECOND) for pp in pipes]
     bow_pool = ThreadPoolExecutor(NPIPE)
     bow_jobs = [None] * NPIPE
 
@@ -514,7 +518,8 @@ def main():
     if kfws:
         composite_stage["keyframe_work_wall"] = timed(kfws[0].run)
         composite_stage["keyframe_work_calls"] = {"search_for_triangulation": kfws[0].last_ms[0], "fuse": kfws[0].last_ms[1],
-                                                  "pairs": len(kfws[0].kf1), "keyframes": n_bow, "neighbours": N_NB}
+                                                  "fuse_pairs": len(kfws[0].kf1), "triangulation_pairs": len(kfws[0].tri_pairs), "keyframes": n_bow,
+                                                  "neighbours": N_NB, "second_order_fuse_targets_per_neighbour": N_SECOND}
     composite_stage["local_ba_batch_wall"] = timed(lambda: lbas[0].solve_prepared(lba_prep[0]))
     composite_stage["local_ba_batch_device"] = float(lba_prep[0]["R"][0].ms_device)
     composite_stage["note"] = ("one synchronous pass, every stage waited for (wall clock incl. launch latency); the timed steps enqueue "
@@ -809,7 +814,7 @@ def main():
                                    "Frame::Frame + SearchByProjection(Current, Last) + PoseOptimization + SearchLocalPoints(%d local map "
                                    "points) + PoseOptimization; per %d frames one keyframe: Frame::ComputeBoW (vocabulary k = 10, L = 6) + "
                                    "SearchByBoW(reference keyframe, frame), %s"
-                                   "and one LocalBundleAdjustment window (%s)" % (N_LOCAL, fpk, ("SearchForTriangulation + Fuse (search) against %d neighbour keyframes + Fuse of the local map points into the keyframe " % N_NB) if kfws else "",
+                                   "and one LocalBundleAdjustment window (%s)" % (N_LOCAL, fpk, ("SearchForTriangulation against %d neighbour keyframes + Fuse (search) into them and %d second-order neighbours + Fuse of the local map points into the keyframe " % (N_NB, N_NB * N_SECOND)) if kfws else "",
                                                             lba_desc),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
@@ -818,7 +823,8 @@ def main():
                        "host_threads_per_rank": {"enqueue": 1, "local_ba_handles": NLBA, "local_ba_workers_per_handle": lba_threads,
                                                  "keyframe_legs": NPIPE, "host_cores": os.cpu_count()},
                        "keyframe_legs_per_step": {"reference_keyframe_bow_searches": n_bow if bows else 0,
-                                                  "triangulation_and_fuse_pairs": len(kfws[0].kf1) if kfws else 0,
+                                                  "triangulation_pairs": len(kfws[0].tri_pairs) if kfws else 0,
+                                                  "fuse_pairs": len(kfws[0].kf1) if kfws else 0,
                                                   "reverse_fuse_problems": n_bow if kfws else 0,
                                                   "note": None if kfws or not real else "the neighbour keyframes are views of the generator's scenes: with recorded "
                                                           "frames the triangulation / fuse leg is left out"},
@@ -921,7 +927,7 @@ def main():
                     if kfws:   # LocalMapping's SearchForTriangulation + Fuse of that keyframe against its neighbours
                         co._kw_inputs = kfws[jv]
                         kb = (i // fpk) % n_bow
-                        parity.keyframe_work_mismatches(None, co, voc_nodes, range(kb * N_NB, (kb + 1) * N_NB), timing=tm)
+                        parity.keyframe_work_mismatches(None, co, voc_nodes, range(kb * kfws[jv].n_nb, (kb + 1) * kfws[jv].n_nb), timing=tm)
                     ta = time.perf_counter()
                     k = (i // fpk) % len(lba_unique)
                     lba_want[k] = O.lba_solve(lba_unique[k])

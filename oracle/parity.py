@@ -280,7 +280,8 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=Non
                     ex=np.float32(src.epipole[p, 0]), ey=np.float32(src.epipole[p, 1]), only_stereo=only_stereo, check_orientation=check_ori,
                     node_id1=b1["fv_node"], node_off1=b1["fv_off"], node_idx1=b1["fv_idx"], node_id2=b2["fv_node"], node_off2=b2["fv_off"],
                     node_idx2=b2["fv_idx"])
-        n, m = O.search_for_triangulation(prob)
+        tri = int(src.tri_of[p]) if hasattr(src, "tri_of") else p   # (second-order neighbours are fuse targets only: no triangulation)
+        n, m = O.search_for_triangulation(prob) if tri >= 0 else (0, None)
         t1 = time.perf_counter()
         # Fuse(pKFi = the neighbour, vpMapPointMatches of keyframe 1): the candidates are table rows
         rows = src.fuse_rows[p]
@@ -293,8 +294,8 @@ def keyframe_work_mismatches(kw, co: ChainOracle, voc: dict, pairs, levelsup=Non
         if kw is None:
             continue
         tag = f"keyframe {b} / neighbour {j}"
-        if int(kw.nm[p]) != n or not (kw.match12[p, :n1] == m).all() or not (kw.match12[p, n1:] == -1).all():
-            bad.append(f"{tag}: SearchForTriangulation {int(kw.nm[p])} matches, oracle {n}; {int((kw.match12[p, :n1] != m).sum())} entries differ")
+        if tri >= 0 and (int(kw.nm[tri]) != n or not (kw.match12[tri, :n1] == m).all() or not (kw.match12[tri, n1:] == -1).all()):
+            bad.append(f"{tag}: SearchForTriangulation {int(kw.nm[tri])} matches, oracle {n}; {int((kw.match12[tri, :n1] != m).sum())} entries differ")
         if not (kw.best_idx[p] == bi).all() or not (kw.best_dist[p] == bd).all():
             bad.append(f"{tag}: Fuse best_idx differs in {int((kw.best_idx[p] != bi).sum())} of {int((rows >= 0).sum())} candidates (oracle fuses {nf})")
     # Fuse(mpCurrentKeyFrame, vpFuseCandidates) (src/LocalMapping.cc:518) for the keyframes the pairs name: the candidates into the keyframe itself

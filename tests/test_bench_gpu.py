@@ -49,7 +49,9 @@ def test_bench_contract_single_gpu(gpu):
     assert ls["trial_slots_enqueued_per_window"] >= 17 and ls["slots_over_trials"] >= 1.0 and d["config"]["local_ba_mix"] == "heterogeneous"
     assert len(d["config"]["frames_per_s_per_rank"]) == 1 and d["config"]["host_threads_per_rank"]["local_ba_workers_per_handle"] >= 1
     # ... and the keyframe legs: the BoW searches and LocalMapping's (keyframe, neighbour) searches
-    assert pc["reference_keyframe_bow_frames"] >= 1 and pc["keyframe_neighbour_pairs"] >= 20
+    assert pc["reference_keyframe_bow_frames"] >= 1 and pc["keyframe_neighbour_pairs"] == 4 * 30   # 10 first-order + 20 second-order Fuse targets per keyframe
+    kl = d["config"]["keyframe_legs_per_step"]
+    assert kl["triangulation_pairs"] == 4 * 10 and kl["fuse_pairs"] == 4 * 30
     assert {"search_for_triangulation", "fuse", "search_by_bow"} <= set(d["cpu_baseline"]["ms_per_frame"])
 
 

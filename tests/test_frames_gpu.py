@@ -305,6 +305,13 @@ def test_keyframe_work_vs_oracle(pkg, oracle, gpu):
         assert parity.keyframe_work_mismatches(kw, co, voc, range(len(kw.kf1))) == []
     assert (kw.nm > 20).all(), kw.nm
     assert ((kw.best_idx >= 0).sum(1) > 50).all()
+    # with second-order neighbours (SearchInNeighbors, src/LocalMapping.cc:475-485): Fuse targets only -- 3 first-order neighbours are
+    # triangulated against, 3 + 3 x 2 = 9 keyframes per keyframe are fused into
+    kw2 = pkg.chain.KeyFrameWork(tc, voc, n_kf=4, n_nb=3, n_second=2)
+    assert len(kw2.kf1) == 4 * 9 and len(kw2.tri_pairs) == 4 * 3 and (kw2.tri_of >= 0).sum() == 12
+    kw2.run()
+    assert parity.keyframe_work_mismatches(kw2.snapshot(), co, voc, range(len(kw2.kf1))) == []
+    assert kw2.match12.shape[0] == 12 and kw2.best_idx.shape[0] == 36 and ((kw2.best_idx >= 0).sum(1) > 50).all()
     # pairs that name keyframes outside the batches are rejected before anything runs
     with pytest.raises(pkg.AosError):
         tc.last.SearchForTriangulation(kw.kfs, [0], [10 ** 6], kw.F12[:1], kw.epipole[:1], kw.fv1[8].data_ptr(),
