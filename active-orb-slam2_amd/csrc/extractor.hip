@@ -547,6 +547,10 @@ static int ensure_batch(aos2_extractor *e, int batch)
     // row h of every plane (1 guard row) and pitch padding are read by 32-bit tile loads: keep
     // them defined
     AOS2_HIP_CHECK(hipMemsetAsync(e->d_pyr.p, 0, P.pyr_bytes * batch + 256, e->stream));
+    // The chunks of the batch that follows run on streams of their own: they must not start while this memset is still running on
+    // the first stream (round 4: a fresh handle given 1920 images -- 2 GB of pyramid, a memset of ~1 ms -- had the pyramids of its
+    // second and third chunk zeroed under them; 720 images lost a few frames at the end, 256 none).  Once per capacity growth.
+    AOS2_HIP_CHECK(hipStreamSynchronize(e->stream));
     e->batch_cap = batch;
     return AOS2_OK;
 }

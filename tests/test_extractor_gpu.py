@@ -381,3 +381,24 @@ def test_whole_level_blur_form_equals_the_per_keypoint_form(pkg, oracle, gpu, mo
     for (k, d), img in zip(ex.extract_batch(imgs), imgs):
         ok, od = oracle.Extractor(nfeatures=500).extract(img)
         assert k.tobytes() == ok.tobytes() and (d == od).all()
+
+
+def test_first_large_batch_on_a_fresh_handle(pkg, oracle, gpu):
+    """A fresh handle whose FIRST call is a large batch (default chunking: three streams): the pyramid block's initial memset on the
+    first stream must be over before the other chunks' streams write their pyramids (round 4: 1920 images lost every frame of the
+    second and third chunk, 720 a few at the end)."""
+    import torch
+    W, H, B = 640, 480, 1536
+    uni = np.stack([pkg.synth.synth_image(300 + i, W, H) for i in range(8)])
+    oe = oracle.Extractor(nfeatures=1000)
+    want = [oe.extract(u) for u in uni]
+    d_img = torch.from_numpy(uni[np.arange(B) % 8]).cuda()
+    ex = pkg.Extractor(nfeatures=1000)
+    cap = ex.max_keypoints_for(W, H)
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr())
+    nh, dh = n.cpu().numpy(), desc.cpu().numpy()
+    bad = [b for b in range(B) if nh[b] != len(want[b % 8][0]) or not (dh[b, :nh[b]] == want[b % 8][1]).all()]
+    assert bad == []

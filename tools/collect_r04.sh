@@ -5,6 +5,7 @@ O=gpurun_out/prof_r04
 cp $O/bench_default.json profiles/r04_bench_n1.json
 cp $O/bench_homogeneous.json profiles/r04_bench_n1_homogeneous_lba.json
 cp $O/bench_kitti.json profiles/r04_bench_kitti.json
+cp $O/bench_r03_form.json profiles/r04_bench_n1_r03_form.json
 cp $O/bench_profiled.json profiles/r04_bench_profiled_run.json
 cp $O/bench_kernel_stats.csv profiles/r04_bench_b512_kernel_stats.csv
 cp $O/bench_fast_kernel_trace.txt profiles/r04_bench_fast_kernel_trace.txt

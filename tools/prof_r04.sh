@@ -12,6 +12,8 @@ cd $R && timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1;
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json
 python bench.py --lba-mix homogeneous --no-extra > $O/bench_homogeneous.json 2> $O/bench_homogeneous.err
+# round 3's step exactly (32 distinct frame pairs tiled, 4 LocalBA problems of one size tiled, first-order Fuse targets only): like for like
+AOS2_BENCH_SECOND_NEIGHBOURS=0 AOS2_BENCH_UNIQUE=32 python bench.py --lba-mix homogeneous --no-extra --no-cpu-baseline > $O/bench_r03_form.json 2> $O/bench_r03_form.err
 python bench.py --workload kitti > $O/bench_kitti.json 2> $O/bench_kitti.err; tail -c 300 $O/bench_kitti.json
 cd /tmp
 # ---- one profiled run: stats + trace + the run's own line
