@@ -55,8 +55,6 @@ struct LmState {
     int32_t lin;        // the system is (re)linearised at the current estimates (after an accepted step)
     int32_t initp;      // start of an optimize() call: residuals, system, lambda init pending
     int32_t xmark;      // transition: the outlier pass runs
-    int32_t cur;        // which of the two landmark-side system buffers (Hll, b_l, Hpl) is the current linearisation (fused walk: the
-                        // landmark pass of a trial linearises at the NEW estimates into the other one, an accepted step swaps them)
     int32_t it, qmax, nBad;
     int32_t iters_max[2], iters_done[2], trials[2];
     int32_t polls;      // evaluations of terminate() so far (the host's entry check is the first)
@@ -99,7 +97,6 @@ struct LbaWin {
     double *Hpl;                     // per free-keyframe edge, DENSE by its position in the pl list (a landmark's blocks are
                                      // neighbours): the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
-    double *Hpl2, *Hll2, *bl2;       // the second landmark-side buffer set (LmState::cur)
     double *tmp;                     // scale terms of the poses (6 np)
     double *scal;                    // [3] solve ok
     double *part;                    // per-landmark sums of k_points: chi2 terms [0, nl), scale terms [nl, 2 nl)
@@ -121,18 +118,6 @@ struct SchurTask {
     int32_t w;      // window (-1: padding)
     int32_t code;   // k_schur: kind << 28 | argument; k_lin: kind << 28 | block; k_points: block
 };
-
-struct SysBuf {
-    double *Hpl, *Hll, *bl;   // per free-keyframe edge 18, per landmark 9, per landmark 3
-};
-__device__ __forceinline__ SysBuf sys_of(const LbaWin &W, int c)
-{
-    SysBuf s;
-    s.Hpl = c ? W.Hpl2 : W.Hpl;
-    s.Hll = c ? W.Hll2 : W.Hll;
-    s.bl = c ? W.bl2 : W.b + 6 * (size_t)W.np;
-    return s;
-}
 
 // bool SparseOptimizer::terminate(): counts the evaluation, latches the flag
 // `seen` >= 0: the value of the flag read by the caller shortly before (the word lives in host memory: a read is a PCIe
@@ -308,7 +293,7 @@ __device__ __forceinline__ void canonical_sums(const LbaWin &W, bool with_scale,
     scale_out = s_red[1][0];
 }
 template <int NT>
-__device__ __forceinline__ void lm_decide(const LbaWin &W, bool fused)
+__device__ __forceinline__ void lm_decide(const LbaWin &W)
 {
     __shared__ int s_restore;
     LmState *st = W.st;
@@ -373,10 +358,6 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W, bool fused)
                 st->qmax = 0;
                 st->iniChi = st->currentChi;
                 lin = accepted ? 1 : 0;   // (a step that was neither accepted nor repeated leaves the system as it is)
-                if (accepted && fused) {  // the landmark side was linearised at the accepted estimates by the pass that just ended
-                    lin = 2;              // (k_lin: the keyframe side only)
-                    st->cur ^= 1;
-                }
             } else {
                 st->run = 0;
                 st->iters_done[pass] = st->it;
@@ -405,7 +386,7 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W, bool fused)
 
 // end of a k_points launch (solve = 1): the workgroup that finishes last takes the LM decision
 template <int NT>
-__device__ __forceinline__ void points_tail(const LbaWin &W, bool fused = false)
+__device__ __forceinline__ void points_tail(const LbaWin &W)
 {
     __shared__ int s_last;
     // What this workgroup leaves for the deciding one -- the per-landmark sums and the landmark backups -- was stored
@@ -420,7 +401,7 @@ __device__ __forceinline__ void points_tail(const LbaWin &W, bool fused = false)
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the reads below are device-scope loads: load_dev)
     if (threadIdx.x == 0) W.st->blocks_done = 0;
-    lm_decide<NT>(W, fused);
+    lm_decide<NT>(W);
 }
 
 // Landmark kernels: a 256-thread workgroup takes kLmBlock landmarks, kLmSlots threads each -- thread (landmark, slot j)
@@ -466,17 +447,16 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
         for (int r = 0; r < 3; ++r) Xv[r] = X[r];
     if (solve) {
         const double lambda = W.st->lambda;
-        const SysBuf Sc = sys_of(W, W.st->cur);
         const int a0 = has ? W.pl_off[l] : 0, a1 = has ? W.pl_off[l + 1] : 0;
         double cl[3] = {0, 0, 0};
         if (has && leader)
-            for (int r = 0; r < 3; ++r) cl[r] = Sc.bl[3 * l + r];
+            for (int r = 0; r < 3; ++r) cl[r] = W.b[n6 + 3 * l + r];
         for (int rd = 0; __syncthreads_or(a0 + kLmSlots * rd < a1); ++rd) {
             const int a = a0 + kLmSlots * rd + j;
             double v[3] = {0, 0, 0};
             if (a < a1) {   // B_i^T (-x_p) of one free-keyframe edge
                 const int i1 = W.pl_ph[a];
-                const double *Bi = Sc.Hpl + 18 * (size_t)a;
+                const double *Bi = W.Hpl + 18 * (size_t)a;
                 double xp[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
@@ -497,7 +477,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
         if (has && leader) {
             // (Hll + lambda I)^-1: the same operations as in the Schur kernel, so the same bits
             double Dm[9], Dinv[9];
-            for (int i = 0; i < 9; ++i) Dm[i] = Sc.Hll[9 * (size_t)l + i];
+            for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
             Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
             mat3_inverse(Dm, Dinv);
             double *Xb = W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.hpoint[l];
@@ -508,7 +488,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
                 Xv[r] += xl;
                 X[r] = Xv[r];
                 s_X[ll][r] = Xv[r];
-                sc += xl * (lambda * xl + Sc.bl[3 * l + r]);
+                sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
             }
         }
         __syncthreads();
@@ -557,6 +537,119 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
 // launch, where the landmarks alone fill the device and idle slots, barriers and LDS round trips only cost (32 windows of
 // 24 k edges: 4.4 ms against 6.4 ms).  Per landmark the operations and their order are those of k_points, so both layouts
 // leave the same bits.
+__global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
+{
+    const SchurTask tk = tasks[blockIdx.x];
+    const LbaWin &W = wins[tk.w];
+    if (!(solve ? W.st->run : W.st->initp)) return;
+    const int l = tk.code * blockDim.x + threadIdx.x;
+    const int n6 = 6 * W.np;
+    if (l < W.nl) {
+        double sc = 0, chi = 0;
+        double *X = W.point + 3 * (size_t)W.hpoint[l];
+        double Xv[3] = {X[0], X[1], X[2]};
+        if (solve) {
+            const double lambda = W.st->lambda;
+            double cl[3] = {W.b[n6 + 3 * l], W.b[n6 + 3 * l + 1], W.b[n6 + 3 * l + 2]};
+            // The walk is a chain of dependent gathers (edge list -> edge -> keyframe); kWalkChunk edges are fetched level by
+            // level together, then their terms are added in edge order (the same sums, a quarter of the round trips).
+#if AOS2_LBA_ABL == 3
+            const int a0 = 0, a1 = 0;
+#else
+            const int a0 = W.pl_off[l], a1 = W.pl_off[l + 1];
+#endif
+            for (int a = a0; a < a1; a += kWalkChunk) {
+                int ka[kWalkChunk], i1[kWalkChunk];   // (positions in the list = the indices of the dense Hpl array)
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u) ka[u] = min(a + u, a1 - 1);
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.pl_ph[ka[u]];
+                double Bi[kWalkChunk][18], xp[kWalkChunk][6];
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) Bi[u][i] = W.Hpl[18 * (size_t)ka[u] + i];
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xp[u][r] = -W.x[6 * i1[u] + r];
+#pragma unroll
+                for (int u = 0; u < kWalkChunk; ++u) {
+                    if (a + u >= a1) break;
+                    double v[3] = {0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) v[c] += Bi[u][r * 3 + c] * xp[u][r];
+                    for (int c = 0; c < 3; ++c) cl[c] += v[c];
+                }
+            }
+            double Dm[9], Dinv[9];
+            for (int i = 0; i < 9; ++i) Dm[i] = W.Hll[9 * (size_t)l + i];
+            Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
+            mat3_inverse(Dm, Dinv);
+            double *Xb = W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.hpoint[l];
+            for (int r = 0; r < 3; ++r) {
+                const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
+                W.x[n6 + 3 * l + r] = xl;
+                store_dev(Xb + r, Xv[r]);   // push()
+                Xv[r] += xl;
+                X[r] = Xv[r];
+                sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
+            }
+        }
+#if AOS2_LBA_ABL == 2
+        const int e0 = 0, e1 = 0;
+#else
+        const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
+#endif
+        for (int a = e0; a < e1; a += kWalkChunkE) {
+            int e[kWalkChunkE], ep[kWalkChunkE];
+            uint8_t lv1[kWalkChunkE], ste[kWalkChunkE], rob[kWalkChunkE];
+            double T[kWalkChunkE][7], ob[kWalkChunkE][3], ew[kWalkChunkE];
+#pragma unroll
+            for (int u = 0; u < kWalkChunkE; ++u) e[u] = W.pt_k[min(a + u, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < kWalkChunkE; ++u) {
+                ep[u] = W.e_pose[e[u]];
+                lv1[u] = W.e_level1[e[u]];
+                ste[u] = W.e_stereo[e[u]];
+                rob[u] = W.e_robust[e[u]];
+                ew[u] = (double)W.in_w[e[u]];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ob[u][i] = (double)W.in_obs[3 * (size_t)e[u] + i];
+            }
+#pragma unroll
+            for (int u = 0; u < kWalkChunkE; ++u)
+#pragma unroll
+                for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
+#pragma unroll
+            for (int u = 0; u < kWalkChunkE; ++u) {
+                if (a + u >= e1) break;
+                if (lv1[u]) continue;   // an inactive edge keeps its _error
+                double p[3], er[3];
+                se3_map(T[u], Xv, p);
+                const int stereo = ste[u];
+                edge_error(W.cam, p, ob[u], stereo, er);
+                double *dst = W.err + 3 * (size_t)e[u];
+                dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+                double c = edge_chi2(er, ew[u], stereo ? 3 : 2);
+                if (rob[u]) {
+                    double rho[2];
+                    robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
+                    c = rho[0];
+                }
+                chi += c;
+            }
+        }
+        store_dev(W.part + l, chi);
+        store_dev(W.part + W.nl + l, sc);
+    }
+#if AOS2_LBA_ABL != 1
+    if (solve) points_tail<128>(W);
+#endif
+}
+
 // J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6.
 // One division per edge: with iz = 1 / z, a = x iz, b = y iz the entries x y / z^2 fx, (1 + x^2 / z^2) fx, y / z fx, ... are
 // products (the reference divides ~13 times per edge here and ~9 more in the landmark Jacobian; an f64 division is ~10
@@ -638,161 +731,6 @@ __device__ __forceinline__ void edge_weights(const LbaWin &W, int k, const doubl
     edge_weights_of(W.cam, er, (double)W.in_w[k], W.e_robust[k], stereo, omr, wo);
 }
 
-// kFused (round 4): the landmark pass of a trial also LINEARISES the landmark side at the new estimates -- Hll, b_l and the Hpl blocks,
-// the work of k_lin's landmark blocks, on the edges and keyframe poses the residual pass has in registers anyway -- into the
-// buffer set that is not the current one; the decision swaps the sets when the step is accepted (LmState::cur) and k_lin then only
-// has the keyframe side left.  Speculative: a rejected step (or the last trial of an optimisation) leaves the result unused.  Per
-// edge the operations and their order are those of lin_points_walk: same bits as the separate pass.
-template <bool kFused>
-__global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
-{
-    const SchurTask tk = tasks[blockIdx.x];
-    const LbaWin &W = wins[tk.w];
-    if (!(solve ? W.st->run : W.st->initp)) return;
-    const int l = tk.code * blockDim.x + threadIdx.x;
-    const int n6 = 6 * W.np;
-    const bool spec = kFused && solve;
-    if (l < W.nl) {
-        double sc = 0, chi = 0;
-        double *X = W.point + 3 * (size_t)W.hpoint[l];
-        double Xv[3] = {X[0], X[1], X[2]};
-        const int cur = W.st->cur;
-        const SysBuf Sc = sys_of(W, cur), Sn = sys_of(W, cur ^ 1);
-        if (solve) {
-            const double lambda = W.st->lambda;
-            double cl[3] = {Sc.bl[3 * l], Sc.bl[3 * l + 1], Sc.bl[3 * l + 2]};
-            // The walk is a chain of dependent gathers (edge list -> edge -> keyframe); kWalkChunk edges are fetched level by
-            // level together, then their terms are added in edge order (the same sums, a quarter of the round trips).
-#if AOS2_LBA_ABL == 3
-            const int a0 = 0, a1 = 0;
-#else
-            const int a0 = W.pl_off[l], a1 = W.pl_off[l + 1];
-#endif
-            for (int a = a0; a < a1; a += kWalkChunk) {
-                int ka[kWalkChunk], i1[kWalkChunk];   // (positions in the list = the indices of the dense Hpl array)
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u) ka[u] = min(a + u, a1 - 1);
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.pl_ph[ka[u]];
-                double Bi[kWalkChunk][18], xp[kWalkChunk][6];
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u)
-#pragma unroll
-                    for (int i = 0; i < 18; ++i) Bi[u][i] = Sc.Hpl[18 * (size_t)ka[u] + i];
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) xp[u][r] = -W.x[6 * i1[u] + r];
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u) {
-                    if (a + u >= a1) break;
-                    double v[3] = {0, 0, 0};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) v[c] += Bi[u][r * 3 + c] * xp[u][r];
-                    for (int c = 0; c < 3; ++c) cl[c] += v[c];
-                }
-            }
-            double Dm[9], Dinv[9];
-            for (int i = 0; i < 9; ++i) Dm[i] = Sc.Hll[9 * (size_t)l + i];
-            Dm[0] += lambda; Dm[4] += lambda; Dm[8] += lambda;
-            mat3_inverse(Dm, Dinv);
-            double *Xb = W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.hpoint[l];
-            for (int r = 0; r < 3; ++r) {
-                const double xl = Dinv[r * 3] * cl[0] + Dinv[r * 3 + 1] * cl[1] + Dinv[r * 3 + 2] * cl[2];
-                W.x[n6 + 3 * l + r] = xl;
-                store_dev(Xb + r, Xv[r]);   // push()
-                Xv[r] += xl;
-                X[r] = Xv[r];
-                sc += xl * (lambda * xl + Sc.bl[3 * l + r]);
-            }
-        }
-#if AOS2_LBA_ABL == 2
-        const int e0 = 0, e1 = 0;
-#else
-        const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
-#endif
-        constexpr int CH = kFused ? kWalkChunkLin : kWalkChunkE;
-        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-        for (int a = e0; a < e1; a += CH) {
-            int e[CH], ep[CH], ph[CH];
-            uint8_t lv1[CH], ste[CH], rob[CH];
-            double T[CH][7], ob[CH][3], ew[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) e[u] = W.pt_k[min(a + u, e1 - 1)];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                ep[u] = W.e_pose[e[u]];
-                ph[u] = spec ? W.pl_pos[e[u]] : -1;
-                lv1[u] = W.e_level1[e[u]];
-                ste[u] = W.e_stereo[e[u]];
-                rob[u] = W.e_robust[e[u]];
-                ew[u] = (double)W.in_w[e[u]];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) ob[u][i] = (double)W.in_obs[3 * (size_t)e[u] + i];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-#pragma unroll
-                for (int i = 0; i < 7; ++i) T[u][i] = W.pose[7 * (size_t)ep[u] + i];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if (a + u >= e1) break;
-                if (lv1[u]) continue;   // an inactive edge keeps its _error
-                double p[3], er[3];
-                se3_map(T[u], Xv, p);
-                const int stereo = ste[u];
-                edge_error(W.cam, p, ob[u], stereo, er);
-                double *dst = W.err + 3 * (size_t)e[u];
-                dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
-                double c = edge_chi2(er, ew[u], stereo ? 3 : 2);
-                if (rob[u]) {
-                    double rho[2];
-                    robustify(c, stereo ? W.cam.delta_stereo : W.cam.delta_mono, rho);
-                    c = rho[0];
-                }
-                chi += c;
-                if (spec) {   // linearizeOplus + constructQuadraticForm of the edge at the new estimates (lin_points_walk's operations)
-                    double R[9], Ja[9], omr[3], wo;
-                    rot_from_quat(T[u], R);
-                    jac_point(W.cam, R, p, stereo, Ja);
-                    edge_weights_of(W.cam, er, ew[u], rob[u], stereo, omr, wo);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        bl[r] += Ja[r] * omr[0] + Ja[3 + r] * omr[1] + Ja[6 + r] * omr[2];
-#pragma unroll
-                        for (int cc = 0; cc < 3; ++cc) H[r * 3 + cc] += Ja[r] * wo * Ja[cc] + Ja[3 + r] * wo * Ja[3 + cc] + Ja[6 + r] * wo * Ja[6 + cc];
-                    }
-                    if (ph[u] >= 0) {
-                        double Jb[18];
-                        jac_pose(W.cam, p, stereo, Jb);
-                        double *h = Sn.Hpl + 18 * (size_t)ph[u];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < 3; ++cc) {
-                                double t = Jb[r] * wo * Ja[cc];       // 0 + a == a: same sums as the d-loop
-                                t += Jb[6 + r] * wo * Ja[3 + cc];
-                                if (stereo) t += Jb[12 + r] * wo * Ja[6 + cc];
-                                h[r * 3 + cc] = t;
-                            }
-                    }
-                }
-            }
-        }
-        if (spec) {
-            for (int i = 0; i < 9; ++i) Sn.Hll[9 * (size_t)l + i] = H[i];
-            for (int i = 0; i < 3; ++i) Sn.bl[3 * (size_t)l + i] = bl[i];
-        }
-        store_dev(W.part + l, chi);
-        store_dev(W.part + W.nl + l, sc);
-    }
-#if AOS2_LBA_ABL != 1
-    if (solve) points_tail<128>(W, kFused);
-#endif
-}
-
 // buildSystem, the landmarks' side (block_solver.hpp:502-560), kLmBlock landmarks per workgroup (see k_points): thread
 // (landmark, slot) linearises one edge at a time -- linearizeOplus, Ji^T Omega Ji, Ji^T omr, and the edge's Hpl block
 // Jj^T Omega Ji -- and the landmark's first thread adds the terms in insertion order like g2o: Hll, b_l.
@@ -809,7 +747,6 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
         for (int r = 0; r < 3; ++r) Xv[r] = X[r];
     }
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    const SysBuf Sc = sys_of(W, W.st->cur);
     const int a0 = has ? W.pt_off[l] : 0, a1 = has ? W.pt_off[l + 1] : 0;
     for (int rd = 0; __syncthreads_or(a0 + kLmSlots * rd < a1); ++rd) {
         const int a = a0 + kLmSlots * rd + j;
@@ -835,7 +772,7 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
             if (pp >= 0) {
                 double Jb[18];
                 jac_pose(W.cam, p, stereo, Jb);
-                double *h = Sc.Hpl + 18 * (size_t)pp;
+                double *h = W.Hpl + 18 * (size_t)pp;
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -863,8 +800,8 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
         }
     }
     if (has && leader) {
-        for (int i = 0; i < 9; ++i) Sc.Hll[9 * (size_t)l + i] = H[i];
-        for (int i = 0; i < 3; ++i) Sc.bl[3 * (size_t)l + i] = bl[i];
+        for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
+        for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
     }
 }
 
@@ -876,7 +813,6 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
     const double *X = W.point + 3 * (size_t)W.hpoint[l];
     const double Xv[3] = {X[0], X[1], X[2]};
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    const SysBuf Sc = sys_of(W, W.st->cur);
     const int e0 = W.pt_off[l], e1 = W.pt_off[l + 1];
     for (int a = e0; a < e1; a += kWalkChunkLin) {
         // kWalkChunkLin edges fetched level by level together (see k_points_walk), linearised and added in edge order
@@ -923,7 +859,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             if (ph[u] >= 0) {
                 double Jb[18];
                 jac_pose(W.cam, p, stereo, Jb);
-                double *h = Sc.Hpl + 18 * (size_t)ph[u];
+                double *h = W.Hpl + 18 * (size_t)ph[u];
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -936,8 +872,8 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
             }
         }
     }
-    for (int i = 0; i < 9; ++i) Sc.Hll[9 * (size_t)l + i] = H[i];
-    for (int i = 0; i < 3; ++i) Sc.bl[3 * (size_t)l + i] = bl[i];
+    for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
+    for (int i = 0; i < 3; ++i) W.b[6 * (size_t)W.np + 3 * (size_t)l + i] = bl[i];
 }
 
 // Sum of `v` over the 16 lanes of a DPP row (xor butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror):
@@ -1035,11 +971,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
     const SchurTask tk = tasks[blockIdx.x];
     const LbaWin &W = wins[tk.w];
-    const int mode = init ? W.st->initp : W.st->lin;   // lin: 1 = both sides, 2 = the keyframe side only (the fused landmark pass did the rest)
-    if (!mode) return;
+    if (!(init ? W.st->initp : W.st->lin)) return;
     const int blk = tk.code & 0x0fffffff;
     const bool keyframe = (tk.code >> 28) != 0;
-    if (!init && mode == 2 && !keyframe) return;
 #if AOS2_LBA_ABL == 5
     if (keyframe) return;
 #elif AOS2_LBA_ABL == 6
@@ -1069,7 +1003,7 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
             v = W.Hpp[36 * (size_t)(i / 6) + (i % 6) * 7];
         else {
             const int j = i - n6;
-            v = sys_of(W, st->cur).Hll[9 * (size_t)(j / 3) + (j % 3) * 4];
+            v = W.Hll[9 * (size_t)(j / 3) + (j % 3) * 4];
         }
         acc = fmax(acc, fabs(v));
     }
@@ -1121,15 +1055,15 @@ constexpr int kSchurDiag = 0, kSchurBig = 1, kSchurPack = 2;
 // rows of B_b -- the same operations in the same order as forming all of B_a D^-1 first, with 15 doubles less alive (the kernel is
 // bound by the workgroups resident per compute unit: 204 registers = two workgroups, <= 168 = three)
 template <bool kDiag>
-__device__ __forceinline__ void schur_item(const LbaWin &W, const SysBuf &Sc, int j, double lambda, double (&acc)[42])
+__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, int n6, double (&acc)[42])
 {
     const int ka = W.it_ka[j], kb = W.it_kb[j], l = W.it_l[j];   // three independent loads, then one level of gathers
     double D[9], Dinv[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) D[i] = Sc.Hll[9 * (size_t)l + i];
+    for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     mat3_inverse(D, Dinv);
-    const double *Bi = Sc.Hpl + 18 * (size_t)ka, *Bj = Sc.Hpl + 18 * (size_t)kb;
+    const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
     double Bb[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
@@ -1143,7 +1077,7 @@ __device__ __forceinline__ void schur_item(const LbaWin &W, const SysBuf &Sc, in
         for (int c = 0; c < 6; ++c) acc[r * 6 + c] += d0 * Bb[c * 3] + d1 * Bb[c * 3 + 1] + d2 * Bb[c * 3 + 2];
     }
     if (kDiag) {   // (ka == kb: one edge per (keyframe, landmark) pair)
-        const double *bl = Sc.bl + 3 * (size_t)l;
+        const double *bl = W.b + n6 + 3 * (size_t)l;
         double db[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
@@ -1185,8 +1119,7 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
     // item range are requested together, before the branch on the first of them)
     const int run = W.st->run;
     const double lambda = W.st->lambda;
-    const SysBuf Sc = sys_of(W, W.st->cur);
-    const int np = W.np;
+    const int np = W.np, n6 = 6 * np;
     const int kind = tk.code >> 28, arg = tk.code & 0x0fffffff;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[42];
@@ -1205,7 +1138,7 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
             s_info[row] = info;
             s_ij[row] = ij;
         }
-        if (li < (info & 255)) schur_item<false>(W, Sc, o0 + li, lambda, acc);
+        if (li < (info & 255)) schur_item<false>(W, o0 + li, lambda, n6, acc);
 #pragma unroll
         for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
         if (li == 0) {
@@ -1240,9 +1173,9 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
     if (!run) return;
     if (kind == kSchurDiag)
-        for (int j = tid; j < n; j += NT) schur_item<true>(W, Sc, o0 + j, lambda, acc);
+        for (int j = tid; j < n; j += NT) schur_item<true>(W, o0 + j, lambda, n6, acc);
     else
-        for (int j = tid; j < n; j += NT) schur_item<false>(W, Sc, o0 + j, lambda, acc);
+        for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, acc);
     const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
     schur_store(W, i1, i2, tid, sum, lambda);
 }
@@ -1724,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
             W.e_level1[e] = 1;
             const int pp = W.pl_pos[e];
             if (pp >= 0)
-                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)pp + i] = W.Hpl2[18 * (size_t)pp + i] = 0.0;   // (both buffer sets: neither pass writes a masked edge's block again)
+                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)pp + i] = 0.0;
         }
         W.e_robust[e] = 0;
         keep = bad ? 0 : 1;
@@ -2058,7 +1991,7 @@ struct WinLayout {
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off, sr_o0, sr_info, sr_ij;
     // device only
-    size_t est, bk, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt, Hpl2, Hll2, bl2;
+    size_t est, bk, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
     size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
     int n_part, npad, ldlt_lds;
@@ -2283,10 +2216,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     bool walk = total_points > 16000;
     if (const char *e = getenv("AOS2_LBA_LAYOUT")) walk = !strcmp(e, "walk");
     const int lm_per_block = walk ? 128 : kLmBlock;
-    // walk layout: the landmark pass of a trial also linearises the landmark side (k_points_walk<true>; AOS2_LBA_FUSED=0 keeps the
-    // separate k_lin pass -- same bits either way)
-    bool fused = walk;
-    if (const char *e = getenv("AOS2_LBA_FUSED")) fused = walk && atoi(e) != 0;
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -2389,7 +2318,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // ... and the landmark kernels' lists: block b of every window before block b + 1 of any (the windows advance side by side);
     // k_lin: every landmark block first (the long dependent chains of the launch), then one task per free keyframe
     std::vector<SchurTask> pts_tasks, lin_tasks;
-    size_t n_lin_landmark_tasks = 0;
     {
         const int lin_block = walk ? 256 : kLmBlock;
         int mx_pb = 0, mx_lb = 0, mx_k = 0;
@@ -2405,7 +2333,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         for (int b = 0; b < mx_lb; ++b)
             for (int i = 0; i < nw; ++i)
                 if (b < nlb[i]) lin_tasks.push_back(SchurTask{i, b});
-        n_lin_landmark_tasks = lin_tasks.size();
         for (int k = 0; k < mx_k; ++k)
             for (int i = 0; i < nw; ++i)
                 if (k < passes[i].np) lin_tasks.push_back(SchurTask{i, (1 << 28) | k});
@@ -2423,7 +2350,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
         l.Hpl = B.take(144 * (S.pl_k.size() + 1));
-        l.Hpl2 = B.take(144 * (S.pl_k.size() + 1)); l.Hll2 = B.take(72 * (size_t)S.nl + 8); l.bl2 = B.take(24 * (size_t)S.nl + 8);
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
@@ -2530,7 +2456,6 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.sr_o0 = (const int32_t *)(base + l.sr_o0); W.sr_info = (const int32_t *)(base + l.sr_info); W.sr_ij = (const int32_t *)(base + l.sr_ij);
         W.n_srows = (int)S.sr_o0.size();
         W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
-        W.Hpl2 = (double *)(base + l.Hpl2); W.Hll2 = (double *)(base + l.Hll2); W.bl2 = (double *)(base + l.bl2);
         W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
         W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
@@ -2571,20 +2496,14 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
     const dim3 g_edges256(blocks(mx_E, 256), nw);
     auto enqueue_points = [&](int solve) {
-        if (walk && fused)
-            hipLaunchKernelGGL(k_points_walk<true>, dim3((unsigned)pts_tasks.size()), dim3(128), 0, q, dw, d_pts_tasks, solve);
-        else if (walk)
-            hipLaunchKernelGGL(k_points_walk<false>, dim3((unsigned)pts_tasks.size()), dim3(128), 0, q, dw, d_pts_tasks, solve);
+        if (walk)
+            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)pts_tasks.size()), dim3(128), 0, q, dw, d_pts_tasks, solve);
         else
             hipLaunchKernelGGL(k_points, dim3((unsigned)pts_tasks.size()), dim3(256), 0, q, dw, d_pts_tasks, solve);
     };
     auto enqueue_lin = [&](int init) {
         if (lin_tasks.empty()) return;
-        if (walk && fused && !init) {   // inside a trial only the keyframe side is left: the tail of the task list
-            if (lin_tasks.size() > n_lin_landmark_tasks)
-                hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)(lin_tasks.size() - n_lin_landmark_tasks)), dim3(256), 0, q, dw,
-                                   d_lin_tasks + n_lin_landmark_tasks, init);
-        } else if (walk)
+        if (walk)
             hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);
         else
             hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);

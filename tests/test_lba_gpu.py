@@ -503,25 +503,3 @@ def test_lba_mixed_window_batch_vs_oracle(pkg, oracle, gpu):
         assert close(got["pose_Tcw"], want["pose_Tcw"], key="mix_pose") and close(got["point_xyz"], want["point_xyz"], key="mix_point")
         assert (got["edge_outlier"] == want["edge_outlier"]).all()
         assert _same(got, alone)
-
-
-def test_lba_fused_landmark_pass_equals_the_separate_linearisation(pkg, oracle, gpu, monkeypatch):
-    """Walk layout (many windows per call): the landmark pass of a trial also linearises the landmark side at the new estimates into
-    the second buffer set, an accepted step swaps the sets (k_points_walk<true>, LmState::cur).  AOS2_LBA_FUSED=0 keeps the separate
-    k_lin pass: same bits -- on windows with rejected trials, early termination, masked edges of the second optimisation and reduced
-    systems of both forms -- and both equal the oracle."""
-    probs = [_hard_problem(pkg, 42, 0.5, 3, 2), _hard_problem(pkg, 43, 0.3, 2, 3), pkg.synth.synth_lba_problem(seed=0),
-             pkg.synth.synth_lba_problem(seed=3, include_kf0=True, outlier_frac=0.15),
-             pkg.synth.synth_lba_problem(seed=77, n_local=30, n_fixed=12, n_points=2500, obs_per_point=7, outlier_frac=0.2)]
-    monkeypatch.setenv("AOS2_LBA_LAYOUT", "walk")
-    res = {}
-    for f in ("1", "0"):
-        monkeypatch.setenv("AOS2_LBA_FUSED", f)
-        res[f] = pkg.LocalBA().LocalBundleAdjustmentBatch(probs)
-    assert any(sum(r["trials"]) > sum(r["iters"]) for r in res["1"])   # rejected trials occur
-    for a, b, p in zip(res["1"], res["0"], probs):
-        assert a["status"] == 0 and _same(a, b)
-        want = oracle.lba_solve(p)
-        assert a["iters"] == want["iters"] and sum(a["trials"]) == want["trials"]
-        assert close(a["pose_Tcw"], want["pose_Tcw"]) and close(a["point_xyz"], want["point_xyz"])
-        assert (a["edge_outlier"] == want["edge_outlier"]).all()
