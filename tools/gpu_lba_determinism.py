@@ -9,6 +9,7 @@ import __graft_entry__ as g
 pkg = g.load_package()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 u = [pkg.synth.synth_lba_problem(i, n_points=8000) for i in range(4)] + [pkg.synth.synth_lba_problem(40 + i) for i in range(4)]
+u += pkg.synth.synth_lba_problems(pkg.synth.lba_window_mix(5, 8))   # round 4: windows of different sizes, reduced systems inside and beyond LDS
 probs = [u[i % len(u)] for i in range(32)]
 def key(res):
     return b"".join(np.asarray(r["pose_Tcw"]).tobytes() + np.asarray(r["point_xyz"]).tobytes() + np.asarray(r["edge_outlier"]).tobytes() for r in res)
