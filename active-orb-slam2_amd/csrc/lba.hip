@@ -94,8 +94,13 @@ struct LbaWin {
     // k_schur's packed units (build_schur_units): rows of <= 16 items of ONE off-diagonal block, 16 rows per workgroup
     const int32_t *sr_o0, *sr_info, *sr_ij;   // per row: first item; items | row-in-block << 8 | rows-of-block << 16; i1 | i2 << 16
     int n_srows;
-    double *Hpl;                     // per free-keyframe edge, DENSE by its position in the pl list (a landmark's blocks are
-                                     // neighbours): the 6x3 block J_pose^T Omega J_point (zero for a masked edge)
+    // Linearisation record of a free-keyframe edge, DENSE by its position in the pl list (a landmark's records are
+    // neighbours): {a = x / z, b = y / z, iz = 1 / z of the camera-frame point, robustified information w} -- 32 bytes in
+    // place of the edge's 144-byte Hpl block J_pose^T (w Omega) J_point, which factors as -E^T C R (EdgeLin below; R: the
+    // keyframe's rotation at the linearisation point, Rl) and is applied in that form.  w < 0 marks a stereo edge (|w| is
+    // the weight); a masked edge holds zeros: every product it takes part in is +-0.
+    double *lrec;
+    double *Rl;                      // 9 per free keyframe (hidx): rotation the system was linearised at (k_lin)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
     double *tmp;                     // scale terms of the poses (6 np)
     double *scal;                    // [3] solve ok
@@ -404,6 +409,115 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
     lm_decide<NT>(W);
 }
 
+// J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6.
+// One division per edge: with iz = 1 / z, a = x iz, b = y iz the entries x y / z^2 fx, (1 + x^2 / z^2) fx, y / z fx, ... are
+// products (the reference divides ~13 times per edge here and ~9 more in the landmark Jacobian; an f64 division is ~10
+// dependent instructions on this part).  Same quantities, equal to rounding (1e-16 relative) -- like the pose-only kernel.
+__device__ __forceinline__ void jac_pose(const Cam &cam, const double p[3], int stereo, double Jb[18])
+{
+    const double fx = cam.fx, fy = cam.fy, bf = cam.bf;
+    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz, ab = a * b;
+    Jb[0] = ab * fx;
+    Jb[1] = -(1 + a * a) * fx;
+    Jb[2] = b * fx;
+    Jb[3] = -(iz * fx);
+    Jb[4] = 0;
+    Jb[5] = a * iz * fx;
+    Jb[6] = (1 + b * b) * fy;
+    Jb[7] = -(ab * fy);
+    Jb[8] = -(a * fy);
+    Jb[9] = 0;
+    Jb[10] = -(iz * fy);
+    Jb[11] = b * iz * fy;
+#pragma unroll
+    for (int i = 12; i < 18; ++i) Jb[i] = 0;
+    if (stereo) {
+        const double bfz2 = bf * (iz * iz);
+        Jb[12] = Jb[0] - bfz2 * p[1];
+        Jb[13] = Jb[1] + bfz2 * p[0];
+        Jb[14] = Jb[2];
+        Jb[15] = Jb[3];
+        Jb[16] = 0;
+        Jb[17] = Jb[5] - bfz2;
+    }
+}
+
+// J_point of an edge (the same linearizeOplus): -1 / z [fx 0 -x / z fx; 0 fy -y / z fy] R for the two pixel rows (mono and
+// stereo edges alike), the stereo row = row 0 - bf / z^2 R_2.  R = the keyframe's rotation (row-major), one division.
+__device__ __forceinline__ void jac_point(const Cam &cam, const double R[9], const double p[3], int stereo, double Ja[9])
+{
+    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz;
+    const double fxz = cam.fx * iz, fyz = cam.fy * iz, afxz = a * fxz, bfyz = b * fyz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Ja[c] = afxz * R[6 + c] - fxz * R[c];
+        Ja[3 + c] = bfyz * R[6 + c] - fyz * R[3 + c];
+        Ja[6 + c] = 0;
+    }
+    if (stereo) {
+        const double bfz2 = cam.bf * (iz * iz);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ja[6 + c] = Ja[c] - bfz2 * R[6 + c];
+    }
+}
+
+// ---- linearisation records (LbaWin::lrec).  With a = x / z, b = y / z, iz = 1 / z the Jacobians of an edge
+// (linearizeOplus, jac_pose / jac_point above) are  J_pose = Pt E,  J_point = -iz Pt R  with
+//     Pt = [fx 0 -a fx; 0 fy -b fy; (stereo) fx 0 bf iz - a fx],   E = [ [a b 1]x | -iz I ]  (3 x 6),
+// so the edge's Hpl block is  J_pose^T w J_point = -E^T C R,  C = w iz Pt^T Pt  (symmetric 3 x 3, C01 = 0): six numbers
+// formed from the record in ~20 operations, and the products with E are cross products with (a, b, 1).
+typedef double dbl4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lrec_store(const LbaWin &W, int pos, const double p[3], double wo, int stereo)
+{
+    const double iz = 1.0 / p[2];
+    const dbl4_t v = {p[0] * iz, p[1] * iz, iz, stereo ? -wo : wo};
+    *reinterpret_cast<dbl4_t *>(W.lrec + 4 * (size_t)pos) = v;
+}
+__device__ __forceinline__ void lrec_mask(const LbaWin &W, int pos)
+{
+    const dbl4_t v = {0.0, 0.0, 0.0, 0.0};
+    *reinterpret_cast<dbl4_t *>(W.lrec + 4 * (size_t)pos) = v;
+}
+__device__ __forceinline__ dbl4_t lrec_load(const LbaWin &W, int pos) { return *reinterpret_cast<const dbl4_t *>(W.lrec + 4 * (size_t)pos); }
+struct EdgeLin {
+    double a, b, iz;
+    double C00, C02, C11, C12, C22;
+};
+__device__ __forceinline__ EdgeLin lrec_form(const Cam &cam, const dbl4_t rec)
+{
+    EdgeLin L;
+    L.a = rec.x; L.b = rec.y; L.iz = rec.z;
+    const bool stereo = rec.w < 0.0;
+    const double s = fabs(rec.w) * L.iz;
+    const double fx2 = cam.fx * cam.fx, fy2 = cam.fy * cam.fy;
+    // (a mono edge adds exact zeros for the third row)
+    const double fs = stereo ? cam.fx : 0.0, c = stereo ? cam.bf * L.iz - L.a * cam.fx : 0.0;
+    L.C00 = (fx2 + fs * fs) * s;
+    L.C02 = (fs * c - L.a * fx2) * s;
+    L.C11 = fy2 * s;
+    L.C12 = -(L.b * fy2) * s;
+    L.C22 = (L.a * L.a * fx2 + L.b * L.b * fy2 + c * c) * s;
+    return L;
+}
+// C t
+__device__ __forceinline__ void lrec_C(const EdgeLin &L, const double t[3], double h[3])
+{
+    h[0] = L.C00 * t[0] + L.C02 * t[2];
+    h[1] = L.C11 * t[1] + L.C12 * t[2];
+    h[2] = L.C02 * t[0] + L.C12 * t[1] + L.C22 * t[2];
+}
+// B^T xp of a free-keyframe edge (block_solver.hpp:455-480 multiplies by the stored Hpl block B):
+// B^T xp = -R^T C E xp,  E xp = (a, b, 1) x omega - iz upsilon  for xp = (omega, upsilon)
+__device__ __forceinline__ void lrec_backsub(const Cam &cam, const dbl4_t rec, const double R[9], const double xp[6], double v[3])
+{
+    const EdgeLin L = lrec_form(cam, rec);
+    const double t[3] = {L.b * xp[2] - xp[1] - L.iz * xp[3], xp[0] - L.a * xp[2] - L.iz * xp[4], L.a * xp[1] - L.b * xp[0] - L.iz * xp[5]};
+    double h[3];
+    lrec_C(L, t, h);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = -(R[c] * h[0] + R[3 + c] * h[1] + R[6 + c] * h[2]);
+}
+
 // Landmark kernels: a 256-thread workgroup takes kLmBlock landmarks, kLmSlots threads each -- thread (landmark, slot j)
 // works on the landmark's edges j, j + kLmSlots, ... (one edge for the usual <= 8 observations) and the landmark's first
 // thread adds the per-edge terms in edge order, so the sums are the ones a thread walking the edges one after the other
@@ -418,7 +532,10 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
 constexpr int kLmBlock = 32, kLmSlots = 8;
 // edges of a landmark fetched together by the one-thread-per-landmark kernels (measured on 32 windows of 24 k edges, 6
 // observations per landmark: k_points_walk 43.4 us with 4 / 4, 38.6 with 6 / 6; the linearisation spills beyond 4)
-constexpr int kWalkChunk = 6;      // free-keyframe edges (back-substitution)
+#ifndef AOS2_WALK_CHUNK
+#define AOS2_WALK_CHUNK 4
+#endif
+constexpr int kWalkChunk = AOS2_WALK_CHUNK;   // free-keyframe edges (back-substitution)
 constexpr int kWalkChunkE = 6;     // all edges (residuals)
 constexpr int kWalkChunkLin = 4;   // all edges (linearisation)
 
@@ -456,14 +573,13 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
             double v[3] = {0, 0, 0};
             if (a < a1) {   // B_i^T (-x_p) of one free-keyframe edge
                 const int i1 = W.pl_ph[a];
-                const double *Bi = W.Hpl + 18 * (size_t)a;
-                double xp[6];
+                const dbl4_t rec = lrec_load(W, a);
+                double xp[6], R[9];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) xp[r] = -W.x[6 * i1 + r];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) v[c] += Bi[r * 3 + c] * xp[r];
+                for (int i = 0; i < 9; ++i) R[i] = W.Rl[9 * (size_t)i1 + i];
+                lrec_backsub(W.cam, rec, R, xp, v);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) s_v[ll][j][c] = v[c];
@@ -564,23 +680,22 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
                 for (int u = 0; u < kWalkChunk; ++u) ka[u] = min(a + u, a1 - 1);
 #pragma unroll
                 for (int u = 0; u < kWalkChunk; ++u) i1[u] = W.pl_ph[ka[u]];
-                double Bi[kWalkChunk][18], xp[kWalkChunk][6];
+                dbl4_t rec[kWalkChunk];
+                double xp[kWalkChunk][6], Rr[kWalkChunk][9];
 #pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u)
+                for (int u = 0; u < kWalkChunk; ++u) rec[u] = lrec_load(W, ka[u]);
 #pragma unroll
-                    for (int i = 0; i < 18; ++i) Bi[u][i] = W.Hpl[18 * (size_t)ka[u] + i];
-#pragma unroll
-                for (int u = 0; u < kWalkChunk; ++u)
+                for (int u = 0; u < kWalkChunk; ++u) {
 #pragma unroll
                     for (int r = 0; r < 6; ++r) xp[u][r] = -W.x[6 * i1[u] + r];
 #pragma unroll
+                    for (int i = 0; i < 9; ++i) Rr[u][i] = W.Rl[9 * (size_t)i1[u] + i];
+                }
+#pragma unroll
                 for (int u = 0; u < kWalkChunk; ++u) {
                     if (a + u >= a1) break;
-                    double v[3] = {0, 0, 0};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) v[c] += Bi[u][r * 3 + c] * xp[u][r];
+                    double v[3];
+                    lrec_backsub(W.cam, rec[u], Rr[u], xp[u], v);
                     for (int c = 0; c < 3; ++c) cl[c] += v[c];
                 }
             }
@@ -650,58 +765,6 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
 #endif
 }
 
-// J_pose of an edge (linearizeOplus, types_six_dof_expmap.cpp:103-157, 188-234): rows 0-1 (and 2 for stereo) x 6.
-// One division per edge: with iz = 1 / z, a = x iz, b = y iz the entries x y / z^2 fx, (1 + x^2 / z^2) fx, y / z fx, ... are
-// products (the reference divides ~13 times per edge here and ~9 more in the landmark Jacobian; an f64 division is ~10
-// dependent instructions on this part).  Same quantities, equal to rounding (1e-16 relative) -- like the pose-only kernel.
-__device__ __forceinline__ void jac_pose(const Cam &cam, const double p[3], int stereo, double Jb[18])
-{
-    const double fx = cam.fx, fy = cam.fy, bf = cam.bf;
-    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz, ab = a * b;
-    Jb[0] = ab * fx;
-    Jb[1] = -(1 + a * a) * fx;
-    Jb[2] = b * fx;
-    Jb[3] = -(iz * fx);
-    Jb[4] = 0;
-    Jb[5] = a * iz * fx;
-    Jb[6] = (1 + b * b) * fy;
-    Jb[7] = -(ab * fy);
-    Jb[8] = -(a * fy);
-    Jb[9] = 0;
-    Jb[10] = -(iz * fy);
-    Jb[11] = b * iz * fy;
-#pragma unroll
-    for (int i = 12; i < 18; ++i) Jb[i] = 0;
-    if (stereo) {
-        const double bfz2 = bf * (iz * iz);
-        Jb[12] = Jb[0] - bfz2 * p[1];
-        Jb[13] = Jb[1] + bfz2 * p[0];
-        Jb[14] = Jb[2];
-        Jb[15] = Jb[3];
-        Jb[16] = 0;
-        Jb[17] = Jb[5] - bfz2;
-    }
-}
-
-// J_point of an edge (the same linearizeOplus): -1 / z [fx 0 -x / z fx; 0 fy -y / z fy] R for the two pixel rows (mono and
-// stereo edges alike), the stereo row = row 0 - bf / z^2 R_2.  R = the keyframe's rotation (row-major), one division.
-__device__ __forceinline__ void jac_point(const Cam &cam, const double R[9], const double p[3], int stereo, double Ja[9])
-{
-    const double iz = 1.0 / p[2], a = p[0] * iz, b = p[1] * iz;
-    const double fxz = cam.fx * iz, fyz = cam.fy * iz, afxz = a * fxz, bfyz = b * fyz;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Ja[c] = afxz * R[6 + c] - fxz * R[c];
-        Ja[3 + c] = bfyz * R[6 + c] - fyz * R[3 + c];
-        Ja[6 + c] = 0;
-    }
-    if (stereo) {
-        const double bfz2 = cam.bf * (iz * iz);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Ja[6 + c] = Ja[c] - bfz2 * R[6 + c];
-    }
-}
-
 // robustified information of an edge (BaseBinaryEdge::constructQuadraticForm, base_binary_edge.hpp:55-120):
 // omr = -rho' Omega e, wo = rho' * w
 __device__ __forceinline__ void edge_weights_of(const Cam &cam, const double er[3], double w, int robust, int stereo, double omr[3], double &wo)
@@ -769,20 +832,7 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
                 for (int c = 0; c < 3; ++c) cH[r * 3 + c] = Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
             }
             const int pp = W.pl_pos[k];
-            if (pp >= 0) {
-                double Jb[18];
-                jac_pose(W.cam, p, stereo, Jb);
-                double *h = W.Hpl + 18 * (size_t)pp;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
-                        t += Jb[6 + r] * wo * Ja[3 + c];
-                        if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
-                        h[r * 3 + c] = t;
-                    }
-            }
+            if (pp >= 0) lrec_store(W, pp, p, wo, stereo);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) s_c[ll][j][i] = cH[i];
@@ -856,20 +906,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) H[r * 3 + c] += Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
             }
-            if (ph[u] >= 0) {
-                double Jb[18];
-                jac_pose(W.cam, p, stereo, Jb);
-                double *h = W.Hpl + 18 * (size_t)ph[u];
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        double t = Jb[r] * wo * Ja[c];       // 0 + a == a: same sums as the d-loop
-                        t += Jb[6 + r] * wo * Ja[3 + c];
-                        if (stereo) t += Jb[12 + r] * wo * Ja[6 + c];
-                        h[r * 3 + c] = t;
-                    }
-            }
+            if (ph[u] >= 0) lrec_store(W, ph[u], p, wo, stereo);
         }
     }
     for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
@@ -933,6 +970,12 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
         const double *Tp = W.pose + 7 * (size_t)W.hpose[ph];
 #pragma unroll
         for (int i = 0; i < 7; ++i) T[i] = Tp[i];
+    }
+    if (threadIdx.x == 0) {   // the rotation the landmark side linearises at (the same function of the same values)
+        double R[9];
+        rot_from_quat(T, R);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) W.Rl[9 * (size_t)ph + i] = R[i];
     }
     double acc[42];
 #pragma unroll
@@ -1051,38 +1094,97 @@ constexpr int kSchurThreads = 256;
 //         exactly the sums (and bits) of the one-wave-per-block form.
 constexpr int kSchurDiag = 0, kSchurBig = 1, kSchurPack = 2;
 // (SchurTask.code = kind << 28 | argument -- DIAG: i; BIG: block rank; PACK: first row; w = -1: padding of the XCD interleave)
-// one item: (Hll + lambda I)^-1 of the landmark, then row by row of B_a: the row of B_a D^-1 (3 values) and its 6 products with the
-// rows of B_b -- the same operations in the same order as forming all of B_a D^-1 first, with 15 doubles less alive (the kernel is
-// bound by the workgroups resident per compute unit: 204 registers = two workgroups, <= 168 = three)
+// one item: (Hll + lambda I)^-1 of the landmark, and B_a D^-1 B_b^T in factored form.  With B = -E^T C R (lrec_form)
+//     B_a D^-1 B_b^T = E_a^T Q E_b,   Q = C_a (R_a D^-1 R_b^T) C_b   (3 x 3),
+// and the products with E = [ [a b 1]x | -iz I ] are cross products: the two 144-byte blocks are neither stored nor fetched --
+// each side is its 32-byte record (LbaWin::lrec) and the keyframe's rotation (uniform over the block: a broadcast load) --
+// and an item takes ~360 operations instead of the ~350 of the stored-block form plus 23 divergent 16-byte requests (9 now).
+#ifndef AOS2_SCHUR_FMA
+#define AOS2_SCHUR_FMA 0
+#endif
+__device__ __forceinline__ double sf(double a, double b, double c)
+{
+#if AOS2_SCHUR_FMA
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
 template <bool kDiag>
-__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, int n6, double (&acc)[42])
+__device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda, int n6, const double *__restrict__ Ra_g,
+                                           const double *__restrict__ Rb_g, double (&acc)[42])
 {
     const int ka = W.it_ka[j], kb = W.it_kb[j], l = W.it_l[j];   // three independent loads, then one level of gathers
+    const dbl4_t rb = lrec_load(W, kb);
+    const dbl4_t ra = kDiag ? rb : lrec_load(W, ka);             // (diagonal block: the two edges of an item are one)
     double D[9], Dinv[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) D[i] = W.Hll[9 * (size_t)l + i];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     mat3_inverse(D, Dinv);
-    const double *Bi = W.Hpl + 18 * (size_t)ka, *Bj = W.Hpl + 18 * (size_t)kb;
-    double Bb[18];
+    double Ra[9], G[9];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) Bb[i] = Bj[i];
+    for (int i = 0; i < 9; ++i) Ra[i] = Ra_g[i];
+    {
+        double G0[9];   // R_a D^-1
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        // (diagonal block: the two edges of an item are one, its block is fetched once)
-        const double b0 = kDiag ? Bb[r * 3] : Bi[r * 3], b1 = kDiag ? Bb[r * 3 + 1] : Bi[r * 3 + 1], b2 = kDiag ? Bb[r * 3 + 2] : Bi[r * 3 + 2];
-        const double d0 = b0 * Dinv[0] + b1 * Dinv[3] + b2 * Dinv[6], d1 = b0 * Dinv[1] + b1 * Dinv[4] + b2 * Dinv[7],
-                     d2 = b0 * Dinv[2] + b1 * Dinv[5] + b2 * Dinv[8];
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[r * 6 + c] += d0 * Bb[c * 3] + d1 * Bb[c * 3 + 1] + d2 * Bb[c * 3 + 2];
+            for (int c = 0; c < 3; ++c) G0[r * 3 + c] = sf(Ra[r * 3 + 2], Dinv[6 + c], sf(Ra[r * 3 + 1], Dinv[3 + c], Ra[r * 3] * Dinv[c]));
+        if (kDiag) {   // the coefficient term B_a D^-1 b_l = -E_a^T C_a (R_a D^-1 b_l)
+            const double *bl = W.b + n6 + 3 * (size_t)l;
+            const double b0 = bl[0], b1 = bl[1], b2 = bl[2];
+            const EdgeLin La = lrec_form(W.cam, ra);
+            const double t[3] = {G0[0] * b0 + G0[1] * b1 + G0[2] * b2, G0[3] * b0 + G0[4] * b1 + G0[5] * b2, G0[6] * b0 + G0[7] * b1 + G0[8] * b2};
+            double h[3];
+            lrec_C(La, t, h);
+            acc[36] += La.b * h[2] - h[1];
+            acc[37] += h[0] - La.a * h[2];
+            acc[38] += La.a * h[1] - La.b * h[0];
+            acc[39] += La.iz * h[0];
+            acc[40] += La.iz * h[1];
+            acc[41] += La.iz * h[2];
+        }
+        double Rb[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rb[i] = kDiag ? Ra[i] : Rb_g[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G[r * 3 + c] = sf(G0[r * 3 + 2], Rb[c * 3 + 2], sf(G0[r * 3 + 1], Rb[c * 3 + 1], G0[r * 3] * Rb[c * 3]));
     }
-    if (kDiag) {   // (ka == kb: one edge per (keyframe, landmark) pair)
-        const double *bl = W.b + n6 + 3 * (size_t)l;
-        double db[3];
+    const EdgeLin La = lrec_form(W.cam, ra), Lb = kDiag ? La : lrec_form(W.cam, rb);
+    double Q[9];
+    {
+        double CG[9];   // C_a G
 #pragma unroll
-        for (int r = 0; r < 3; ++r) db[r] = Dinv[r * 3] * bl[0] + Dinv[r * 3 + 1] * bl[1] + Dinv[r * 3 + 2] * bl[2];
+        for (int c = 0; c < 3; ++c) {
+            CG[c] = sf(La.C02, G[6 + c], La.C00 * G[c]);
+            CG[3 + c] = sf(La.C12, G[6 + c], La.C11 * G[3 + c]);
+            CG[6 + c] = sf(La.C22, G[6 + c], sf(La.C12, G[3 + c], La.C02 * G[c]));
+        }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc[36 + r] += Bb[r * 3] * db[0] + Bb[r * 3 + 1] * db[1] + Bb[r * 3 + 2] * db[2];
+        for (int r = 0; r < 3; ++r) {
+            Q[r * 3] = sf(CG[r * 3 + 2], Lb.C02, CG[r * 3] * Lb.C00);
+            Q[r * 3 + 1] = sf(CG[r * 3 + 2], Lb.C12, CG[r * 3 + 1] * Lb.C11);
+            Q[r * 3 + 2] = sf(CG[r * 3 + 2], Lb.C22, sf(CG[r * 3 + 1], Lb.C12, CG[r * 3] * Lb.C02));
+        }
+    }
+    // U = Q E_b (3 x 6), then E_a^T U: rows 0-2 = [a b 1]x^T U, rows 3-5 = -iz_a U
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double u[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double q0 = Q[r * 3], q1 = Q[r * 3 + 1], q2 = Q[r * 3 + 2];
+            u[r] = c == 0 ? q1 - Lb.b * q2 : c == 1 ? Lb.a * q2 - q0 : c == 2 ? Lb.b * q0 - Lb.a * q1 : -(Lb.iz * Q[r * 3 + (c - 3)]);
+        }
+        acc[c] += u[1] - La.b * u[2];
+        acc[6 + c] += La.a * u[2] - u[0];
+        acc[12 + c] += La.b * u[0] - La.a * u[1];
+        acc[18 + c] += -(La.iz * u[0]);
+        acc[24 + c] += -(La.iz * u[1]);
+        acc[30 + c] += -(La.iz * u[2]);
     }
 }
 
@@ -1104,7 +1206,7 @@ __device__ __forceinline__ void schur_store(const LbaWin &W, int i1, int i2, int
 }
 
 #ifndef AOS2_SCHUR_WPE
-#define AOS2_SCHUR_WPE 3   // workgroups per compute unit (one wave of a workgroup per SIMD): 3 = 168 registers, 5 of them spilled
+#define AOS2_SCHUR_WPE 3   // workgroups per compute unit (one wave of a workgroup per SIMD)
 #endif
 __global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(AOS2_SCHUR_WPE, AOS2_SCHUR_WPE)))
 void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks)
@@ -1138,7 +1240,7 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
             s_info[row] = info;
             s_ij[row] = ij;
         }
-        if (li < (info & 255)) schur_item<false>(W, o0 + li, lambda, n6, acc);
+        if (li < (info & 255)) schur_item<false>(W, o0 + li, lambda, n6, W.Rl + 9 * (size_t)(ij & 0xffff), W.Rl + 9 * (size_t)(ij >> 16), acc);
 #pragma unroll
         for (int i = 0; i < 36; ++i) acc[i] = row_sum_f64(acc[i]);
         if (li == 0) {
@@ -1173,9 +1275,9 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
     const int o0 = W.blk_off[blk], n = W.blk_off[blk + 1] - o0;
     if (!run) return;
     if (kind == kSchurDiag)
-        for (int j = tid; j < n; j += NT) schur_item<true>(W, o0 + j, lambda, n6, acc);
+        for (int j = tid; j < n; j += NT) schur_item<true>(W, o0 + j, lambda, n6, W.Rl + 9 * (size_t)i1, W.Rl + 9 * (size_t)i1, acc);
     else
-        for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, acc);
+        for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, W.Rl + 9 * (size_t)i1, W.Rl + 9 * (size_t)i2, acc);
     const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
     schur_store(W, i1, i2, tid, sum, lambda);
 }
@@ -1656,8 +1758,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
         if (bad) {
             W.e_level1[e] = 1;
             const int pp = W.pl_pos[e];
-            if (pp >= 0)
-                for (int i = 0; i < 18; ++i) W.Hpl[18 * (size_t)pp + i] = 0.0;
+            if (pp >= 0) lrec_mask(W, pp);
         }
         W.e_robust[e] = 0;
         keep = bad ? 0 : 1;
@@ -1991,7 +2092,7 @@ struct WinLayout {
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off, sr_o0, sr_info, sr_ij;
     // device only
-    size_t est, bk, robust, level1, err, Hpl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
+    size_t est, bk, robust, level1, err, lrec, Rl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
     size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
     int n_part, npad, ldlt_lds;
@@ -2349,7 +2450,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
         l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
-        l.Hpl = B.take(144 * (S.pl_k.size() + 1));
+        l.lrec = B.take(32 * (S.pl_k.size() + 1)); l.Rl = B.take(72 * (size_t)S.np + 8);
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
@@ -2455,7 +2556,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
         W.sr_o0 = (const int32_t *)(base + l.sr_o0); W.sr_info = (const int32_t *)(base + l.sr_info); W.sr_ij = (const int32_t *)(base + l.sr_ij);
         W.n_srows = (int)S.sr_o0.size();
-        W.Hpl = (double *)(base + l.Hpl); W.Hpp = (double *)(base + l.Hpp);
+        W.lrec = (double *)(base + l.lrec); W.Rl = (double *)(base + l.Rl); W.Hpp = (double *)(base + l.Hpp);
         W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
         W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
