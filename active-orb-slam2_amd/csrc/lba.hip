@@ -64,6 +64,12 @@ struct LmState {
     int32_t solver_failed;  // trials whose reduced system hit a zero pivot
     int32_t blocks_done;    // workgroups of the current k_points launch that delivered their partial sums
     int32_t ntr;            // trials recorded below (AOS2_LBA_TRACE=1 prints them)
+    // Where the edges' _error of the LAST residual evaluation can be re-formed from (the trials do not store 24 bytes per edge;
+    // the two passes that read _error -- the outlier pass and the final check -- re-form it): 0 = nowhere, the stored values
+    // stand (no evaluation since they were written); 1 = the current estimates (evaluation at the start of an optimisation, or
+    // an accepted trial); 2 = the backup, which after a rejected trial holds the trial's estimates (pop() swaps).
+    int32_t err_at;
+    int32_t pad_;
     double tr_rho[48], tr_temp[48], tr_cur[48], tr_lambda[48];
     long long dbg[16];      // cycle counters of the last reduced-system kernel (AOS2_LBA_TRACE=1)
 };
@@ -337,9 +343,11 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
             st->lambda *= scaleFactor;
             st->ni = 2;
             st->currentChi = tempChi;
+            st->err_at = 1;
         } else {
             st->lambda *= st->ni;
             st->ni *= 2;
+            st->err_at = 2;
         }
         s_restore = accepted ? 0 : 1;
         st->qmax++;
@@ -385,8 +393,14 @@ __device__ __forceinline__ void lm_decide(const LbaWin &W)
     // pop() after a rejected step (SparseOptimizer::push / pop, sparse_optimizer.cpp:600-610).  The backup holds the
     // estimates a trial starts from: the kernels that move an estimate (the pose update of the reduced-system kernel, the
     // landmark update of k_points) save the old value first -- push() costs no pass of its own.
+    // The trial's estimates are kept in the backup's place (a swap): the edges' _error after a rejected trial is the
+    // one computed AT the trial (computeActiveErrors ran before pop()), and the passes that read it re-form it from there.
     if (s_restore)
-        for (int i = threadIdx.x; i < W.est_n; i += NT) W.pose[i] = load_dev(W.bk + i);
+        for (int i = threadIdx.x; i < W.est_n; i += NT) {
+            const double trial = load_dev(W.pose + i);
+            W.pose[i] = load_dev(W.bk + i);
+            W.bk[i] = trial;
+        }
 }
 
 // end of a k_points launch (solve = 1): the workgroup that finishes last takes the LM decision
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
                 W.x[n6 + 3 * l + r] = xl;
                 store_dev(Xb + r, Xv[r]);   // push() (read back by the deciding workgroup when the step is rejected)
                 Xv[r] += xl;
-                X[r] = Xv[r];
+                store_dev(X + r, Xv[r]);   // (read back by the deciding workgroup when the step is rejected: the swap)
                 s_X[ll][r] = Xv[r];
                 sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
             }
@@ -623,9 +637,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
                     se3_map(W.pose + 7 * (size_t)W.e_pose[e], Xv, p);
                     const int stereo = W.e_stereo[e];
                     const double ob[3] = {(double)W.in_obs[3 * (size_t)e], (double)W.in_obs[3 * (size_t)e + 1], (double)W.in_obs[3 * (size_t)e + 2]};
-                    edge_error(W.cam, p, ob, stereo, er);
-                    double *dst = W.err + 3 * (size_t)e;
-                    dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+                    edge_error(W.cam, p, ob, stereo, er);   // (_error is not stored: LmState::err_at)
                     c = edge_chi2(er, (double)W.in_w[e], stereo ? 3 : 2);
                     if (W.e_robust[e]) {
                         double rho[2];
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
                 W.x[n6 + 3 * l + r] = xl;
                 store_dev(Xb + r, Xv[r]);   // push()
                 Xv[r] += xl;
-                X[r] = Xv[r];
+                store_dev(X + r, Xv[r]);
                 sc += xl * (lambda * xl + W.b[n6 + 3 * l + r]);
             }
         }
@@ -745,9 +757,7 @@ __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ 
                 double p[3], er[3];
                 se3_map(T[u], Xv, p);
                 const int stereo = ste[u];
-                edge_error(W.cam, p, ob[u], stereo, er);
-                double *dst = W.err + 3 * (size_t)e[u];
-                dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+                edge_error(W.cam, p, ob[u], stereo, er);   // (_error is not stored: LmState::err_at)
                 double c = edge_chi2(er, ew[u], stereo ? 3 : 2);
                 if (rob[u]) {
                     double rho[2];
@@ -1069,6 +1079,7 @@ __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ win
         st->initp = 0;
         st->lin = 0;
         st->run = 1;
+        st->err_at = 1;   // (the residual pass before this launch)
     }
 }
 
@@ -1654,6 +1665,11 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
     LDLT_T(const long long t_fact = __builtin_amdgcn_s_memtime();)
     if (s_fail) {
         if (tid == 0) Wn.scal[3] = 0.0;
+        if (tid < Wn.np) {   // the trial is rejected (lm_decide): its pop() must find the estimates it started from
+            const double *Tp = Wn.pose + 7 * (size_t)Wn.hpose[tid];
+            double *Tbk = Wn.bk + 7 * (size_t)Wn.hpose[tid];
+            for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];
+        }
         return;
     }
     // ---- backward substitution: x = L^-T D^-1 y; per block x_k = T_k^T s_k, then the rows above take L_k^T x_k
@@ -1741,19 +1757,40 @@ __global__ __launch_bounds__(512) void k_ldlt_dev(const LbaWin *__restrict__ win
 // optimisation ended: lm_first_done).  Edges with chi2 above the threshold or non-positive depth leave the optimisation
 // (setLevel(1)), all edges drop their robust kernel (:672-703); the workgroup that finishes last does
 // initializeOptimization(0) (fails without level-0 edges) and the entry of optimize(10).
+// _error of edge e as the last residual evaluation left it (LmState::err_at): re-formed with the operations of the residual pass
+// from the estimates it ran on (p_cur = the edge's camera point at the CURRENT estimates, which the caller needs anyway), and stored
+// when `keep` -- the values an edge keeps while it is inactive
+__device__ __forceinline__ void edge_last_error(const LbaWin &W, int e, int at, const double p_cur[3], int stereo, bool keep, double er[3])
+{
+    double *dst = W.err + 3 * (size_t)e;
+    if (at == 0) {
+        er[0] = dst[0]; er[1] = dst[1]; er[2] = dst[2];
+        return;
+    }
+    double p[3] = {p_cur[0], p_cur[1], p_cur[2]};
+    if (at == 2) se3_map(W.bk + 7 * (size_t)W.e_pose[e], W.bk + 7 * (size_t)W.n_poses + 3 * (size_t)W.e_point[e], p);
+    const double ob[3] = {(double)W.in_obs[3 * (size_t)e], (double)W.in_obs[3 * (size_t)e + 1], (double)W.in_obs[3 * (size_t)e + 2]};
+    edge_error(W.cam, p, ob, stereo, er);
+    if (keep) {
+        dst[0] = er[0]; dst[1] = er[1]; dst[2] = er[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ wins)
 {
     __shared__ int s_last;
     const LbaWin &W = wins[blockIdx.y];
     LmState *st = W.st;
     if (!st->xmark) return;
+    const int err_at = st->err_at;   // (reset by the workgroup that finishes last: after every workgroup's read)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     int keep = 0;
     if (e < W.n_edges) {
         const int stereo = W.e_stereo[e];
-        const double c = edge_chi2(W.err + 3 * (size_t)e, (double)W.in_w[e], stereo ? 3 : 2);
-        double p[3];
+        double p[3], er[3];
         se3_map(W.pose + 7 * (size_t)W.e_pose[e], W.point + 3 * (size_t)W.e_point[e], p);
+        edge_last_error(W, e, err_at, p, stereo, true, er);
+        const double c = edge_chi2(er, (double)W.in_w[e], stereo ? 3 : 2);
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
         if (bad) {
             W.e_level1[e] = 1;
@@ -1773,6 +1810,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
     st->blocks_done = 0;
     st->xmark = 0;
     st->it = 0;
+    st->err_at = 0;   // (the stored values stand until the second optimisation evaluates)
     const int n_active = __hip_atomic_load(&st->n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n_active == 0 || st->iters_max[1] <= 0 || lm_poll(st, W.abort_word)) {
         st->phase = 3;
@@ -1790,9 +1828,10 @@ __global__ __launch_bounds__(256) void k_final(const LbaWin *__restrict__ wins)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < W.n_edges) {
         const int stereo = W.e_stereo[i];
-        const double c = edge_chi2(W.err + 3 * (size_t)i, (double)W.in_w[i], stereo ? 3 : 2);
-        double p[3];
+        double p[3], er[3];
         se3_map(W.pose + 7 * (size_t)W.e_pose[i], W.point + 3 * (size_t)W.e_point[i], p);
+        edge_last_error(W, i, W.e_level1[i] ? 0 : W.st->err_at, p, stereo, false, er);   // (an inactive edge kept its _error)
+        const double c = edge_chi2(er, (double)W.in_w[i], stereo ? 3 : 2);
         const bool bad = c > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
         if (W.out_chi2) W.out_chi2[i] = c;
         W.out_outlier[i] = bad ? 1 : 0;
