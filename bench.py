@@ -33,6 +33,12 @@ import os
 import sys
 import time
 
+# A step keeps ~12 HIP streams busy (2 pipelines x (extractor chunks + Frame stream + keyframe legs) + 2 LocalBA handles x 2 streams).  The ROCm
+# runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue are serialised, and which ones share
+# is decided by creation order.  Measured on one box (tools/bench_hwq_sweep.sh): 4 queues 50.2 k, 8 queues 60.0 k, 16 queues 61.2 k frames/s
+# (and 50-61 k from run to run with the default).  Must be in the environment before the runtime initialises; a caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -819,6 +825,7 @@ def main():
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
+                       "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "frames_per_s_per_rank": [B * args.steps / d_ for d_ in dt_ranks],
                        "host_threads_per_rank": {"enqueue": 1, "local_ba_handles": NLBA, "local_ba_workers_per_handle": lba_threads,
                                                  "keyframe_legs": NPIPE, "host_cores": os.cpu_count()},
