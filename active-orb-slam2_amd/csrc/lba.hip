@@ -412,6 +412,12 @@ __device__ __forceinline__ void points_tail(const LbaWin &W)
     // write-through at device scope (store_dev), so its visibility needs the stores' completion only (every thread waits
     // for its own, then the barrier), not a write-back of the whole L2: __threadfence() here (buffer_wbl2 by each of the
     // ~1000 workgroups of a 32-window launch) cost 38 of the kernel's 79 us.
+    // (Round 4: the workgroup-scope release fence alone does NOT wait for them -- outside tgsplit mode the compiler emits only
+    // `s_waitcnt lgkmcnt(0)` for it, and the counter's atomic could reach its L2 channel before a sum's store reached its own:
+    // a deciding workgroup then read a stale sum.  Two window groups running side by side made it show -- 4 wrong windows in
+    // ~250 batches of 17 on two of three boxes, none in 3.6 M hand-overs of the round-2 stress on a quiet device.  Every thread
+    // now waits for the completion of its own write-through stores explicitly.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1802,6 +1808,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
     }
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&st->n_active, __popcll(m));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the waves' additions are performed before the workgroup reports itself done: see points_tail)
     __syncthreads();
     // (the last workgroup reads nothing of the others but n_active, an atomic: no device-scope fence)
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&st->blocks_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
@@ -1867,6 +1874,13 @@ int lba_handle_init(aos2_lba *s)
             AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        for (hipStream_t *q : {&s->stream_b, &s->stream2_b}) {
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+                AOS2_HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
+            else
+                AOS2_HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+        }
+        for (hipEvent_t *e : {&s->ev_fork_b, &s->ev_join_b, &s->ev_up, &s->ev_stag, &s->ev_done_b}) AOS2_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
@@ -2220,6 +2234,10 @@ void aos2_lba_destroy(aos2_lba_t *s)
         for (auto &e : s->ev) (void)hipEventDestroy(e);
         (void)hipEventDestroy(s->ev_fork);
         (void)hipEventDestroy(s->ev_join);
+        for (hipEvent_t e : {s->ev_fork_b, s->ev_join_b, s->ev_up, s->ev_stag, s->ev_done_b}) (void)hipEventDestroy(e);
+        (void)hipStreamSynchronize(s->stream_b);
+        (void)hipStreamDestroy(s->stream2_b);
+        (void)hipStreamDestroy(s->stream_b);
         (void)hipStreamDestroy(s->stream2);
         (void)hipStreamDestroy(s->stream);
     }
@@ -2348,6 +2366,26 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     if (nw == 0) return AOS2_OK;
     int st = lba_handle_init(s);
     if (st) return st;
+    // Window groups.  A trial is three wide launches (Schur, back-substitution, linearisation: every window's landmarks) and one
+    // narrow one (the reduced systems: ONE workgroup per window, the longest launch of the mixed batch, during which most of the device
+    // idles).  A batch of many windows runs as TWO groups with the same program each, on their own streams, the second started
+    // behind the first group's first Schur launch: one group's reduced systems are factorised while the other group's landmark
+    // kernels fill the device.  Windows are dealt to the groups by size (edges), largest first, so both get the same mix; the
+    // windows of a group are neighbours in the descriptor array.  (AOS2_LBA_GROUPS=1 switches it off.)
+    int G = nw >= 16 ? 2 : 1;
+    if (const char *e = getenv("AOS2_LBA_GROUPS")) G = std::max(1, std::min(2, atoi(e)));
+    if (G > nw) G = 1;
+    int goff[3] = {0, nw, nw};
+    if (G == 2) {
+        std::vector<int> order(act);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return problems[a].n_edges > problems[b].n_edges; });
+        std::vector<int> g0, g1;
+        for (size_t k = 0; k < order.size(); ++k) (((k & 3) == 0 || (k & 3) == 3) ? g0 : g1).push_back(order[k]);   // a b b a | a b b a ...
+        act = g0;
+        act.insert(act.end(), g1.begin(), g1.end());
+        goff[1] = (int)g0.size();
+    }
+    s->last_groups = G;
     // layout of the landmark kernels: kLmSlots threads per landmark while the landmarks of the call cannot fill the device
     // (one or a few windows: latency), one thread per landmark beyond (throughput); same results either way.
     // AOS2_LBA_LAYOUT=slots|walk forces one (tests).
@@ -2426,12 +2464,14 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // each with an L2 of its own -- 4 MB, about one window's working set: the Hpl blocks a window's items share are then served by
     // one L2), the windows dealt to the XCDs largest first (every XCD gets about the same number of units), two windows of an XCD
     // at a time, unit by unit -- their DIAG units first.  Padding entries (w = -1) keep the 8 queues in step.
-    std::vector<SchurTask> tasks;
-    {
-        std::vector<int> order(nw);
-        std::iota(order.begin(), order.end(), 0);
+    std::vector<SchurTask> tasks_g[2], pts_tasks_g[2], lin_tasks_g[2];
+    for (int g = 0; g < G; ++g) {
+        std::vector<SchurTask> &tasks = tasks_g[g];
+        const int w0 = goff[g], nwg = goff[g + 1] - goff[g];
+        std::vector<int> order(nwg);
+        std::iota(order.begin(), order.end(), w0);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return passes[a].units.size() > passes[b].units.size(); });
-        const int NX = nw >= 8 ? 8 : 1;
+        const int NX = nwg >= 8 ? 8 : 1;
         std::vector<std::vector<int>> xw(NX);
         std::vector<size_t> load(NX, 0);
         for (int w : order) {
@@ -2457,27 +2497,30 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     }
     // ... and the landmark kernels' lists: block b of every window before block b + 1 of any (the windows advance side by side);
     // k_lin: every landmark block first (the long dependent chains of the launch), then one task per free keyframe
-    std::vector<SchurTask> pts_tasks, lin_tasks;
-    {
+    size_t n_all_tasks = 0;
+    for (int g = 0; g < G; ++g) {
+        std::vector<SchurTask> &pts_tasks = pts_tasks_g[g], &lin_tasks = lin_tasks_g[g];
+        const int w0 = goff[g], w1 = goff[g + 1];
         const int lin_block = walk ? 256 : kLmBlock;
         int mx_pb = 0, mx_lb = 0, mx_k = 0;
         std::vector<int> npb(nw), nlb(nw);
-        for (int i = 0; i < nw; ++i) {
+        for (int i = w0; i < w1; ++i) {
             npb[i] = std::max(1, (passes[i].nl + lm_per_block - 1) / lm_per_block);   // = WinLayout::n_part
             nlb[i] = (passes[i].nl + lin_block - 1) / lin_block;
             mx_pb = std::max(mx_pb, npb[i]); mx_lb = std::max(mx_lb, nlb[i]); mx_k = std::max(mx_k, passes[i].np);
         }
         for (int b = 0; b < mx_pb; ++b)
-            for (int i = 0; i < nw; ++i)
+            for (int i = w0; i < w1; ++i)
                 if (b < npb[i]) pts_tasks.push_back(SchurTask{i, b});
         for (int b = 0; b < mx_lb; ++b)
-            for (int i = 0; i < nw; ++i)
+            for (int i = w0; i < w1; ++i)
                 if (b < nlb[i]) lin_tasks.push_back(SchurTask{i, b});
         for (int k = 0; k < mx_k; ++k)
-            for (int i = 0; i < nw; ++i)
+            for (int i = w0; i < w1; ++i)
                 if (k < passes[i].np) lin_tasks.push_back(SchurTask{i, (1 << 28) | k});
+        n_all_tasks += tasks_g[g].size() + pts_tasks.size() + lin_tasks.size();
     }
-    const size_t o_tasks = B.take(sizeof(SchurTask) * (tasks.size() + pts_tasks.size() + lin_tasks.size()) + 8);
+    const size_t o_tasks = B.take(sizeof(SchurTask) * n_all_tasks + 8);
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
     for (int i = 0; i < nw; ++i) {
@@ -2530,8 +2573,10 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
 
     // ---- staging (parallel) + descriptors
     LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
-    bool any_lds = false, any_glob = false;
-    int mx_E = 0, mx_np = 0, mx_nl = 0, mx_pts = 0, mx_part = 0, mx_npad_glob = 0, mx_npad_lds = 0;
+    struct GroupDims {
+        bool any_lds = false, any_glob = false;
+        int mx_E = 0, mx_pts = 0, mx_npad_glob = 0, mx_npad_lds = 0;
+    } gd[2];
     std::vector<uint8_t> up_fail(nw, 0);
     for_windows([&](int i) {
         const aos2_lba_problem_t *p = problems + act[i];
@@ -2607,80 +2652,104 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.out_Tcw = (float *)(base + l.out_Tcw); W.out_xyz = (float *)(base + l.out_xyz);
         W.out_outlier = base + l.out_outlier;
         W.out_chi2 = want_chi2 ? (double *)(base + l.out_chi2) : nullptr;
+        GroupDims &D = gd[i >= goff[1] ? 1 : 0];
         if (S.np > 0) {
             if (l.ldlt_lds) {
-                any_lds = true;
-                mx_npad_lds = std::max(mx_npad_lds, l.npad);
+                D.any_lds = true;
+                D.mx_npad_lds = std::max(D.mx_npad_lds, l.npad);
             } else {
-                any_glob = true;
-                mx_npad_glob = std::max(mx_npad_glob, l.npad);
+                D.any_glob = true;
+                D.mx_npad_glob = std::max(D.mx_npad_glob, l.npad);
             }
         }
-        mx_E = std::max(mx_E, p->n_edges);
-        mx_np = std::max(mx_np, S.np);
-        mx_nl = std::max(mx_nl, S.nl);
-        mx_pts = std::max(mx_pts, std::max(p->n_points, p->n_poses));
-        mx_part = std::max(mx_part, l.n_part);
+        D.mx_E = std::max(D.mx_E, p->n_edges);
+        D.mx_pts = std::max(D.mx_pts, std::max(p->n_points, p->n_poses));
     }
     lap("staging");
     hipStream_t q = s->stream;
-    if (!tasks.empty()) memcpy(hin + o_tasks, tasks.data(), sizeof(SchurTask) * tasks.size());
-    memcpy(hin + o_tasks + sizeof(SchurTask) * tasks.size(), pts_tasks.data(), sizeof(SchurTask) * pts_tasks.size());
-    if (!lin_tasks.empty())
-        memcpy(hin + o_tasks + sizeof(SchurTask) * (tasks.size() + pts_tasks.size()), lin_tasks.data(), sizeof(SchurTask) * lin_tasks.size());
-    const SchurTask *d_schur_tasks = (const SchurTask *)(base + o_tasks), *d_pts_tasks = d_schur_tasks + tasks.size(),
-                    *d_lin_tasks = d_pts_tasks + pts_tasks.size();
-    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_tasks, hin + o_tasks, staged_bytes - o_tasks, hipMemcpyHostToDevice, q));   // k_schur's task list, the descriptors
+    // the task lists of the groups, one after the other: [schur | points | lin] per group
+    const SchurTask *d_schur_tasks[2], *d_pts_tasks[2], *d_lin_tasks[2];
+    {
+        size_t o = o_tasks;
+        for (int g = 0; g < G; ++g)
+            for (int k = 0; k < 3; ++k) {
+                const std::vector<SchurTask> &v = k == 0 ? tasks_g[g] : k == 1 ? pts_tasks_g[g] : lin_tasks_g[g];
+                (k == 0 ? d_schur_tasks : k == 1 ? d_pts_tasks : d_lin_tasks)[g] = (const SchurTask *)(base + o);
+                if (!v.empty()) memcpy(hin + o, v.data(), sizeof(SchurTask) * v.size());
+                o += sizeof(SchurTask) * v.size();
+            }
+    }
+    AOS2_HIP_CHECK(hipMemcpyAsync(base + o_tasks, hin + o_tasks, staged_bytes - o_tasks, hipMemcpyHostToDevice, q));   // the task lists, the descriptors
     AOS2_HIP_CHECK(hipEventRecord(s->ev[0], q));
     const LbaWin *dw = (const LbaWin *)(base + o_wins);
     auto blocks = [](size_t n, int t) { return (unsigned)((n + t - 1) / t); };
-    const dim3 g_edges256(blocks(mx_E, 256), nw);
-    auto enqueue_points = [&](int solve) {
+    hipStream_t gq[2] = {s->stream, s->stream_b}, gq2[2] = {s->stream2, s->stream2_b};
+    if (getenv("AOS2_LBA_GROUPS_SERIAL")) gq[1] = gq[0], gq2[1] = gq2[0];   // (debugging: the groups one after the other)
+    hipEvent_t gfork[2] = {s->ev_fork, s->ev_fork_b}, gjoin[2] = {s->ev_join, s->ev_join_b};
+    if (G == 2) {   // the second group's stream starts behind the upload
+        AOS2_HIP_CHECK(hipEventRecord(s->ev_up, q));
+        AOS2_HIP_CHECK(hipStreamWaitEvent(gq[1], s->ev_up, 0));
+    }
+    auto enqueue_points = [&](int g, int solve) {
         if (walk)
-            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)pts_tasks.size()), dim3(128), 0, q, dw, d_pts_tasks, solve);
+            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)pts_tasks_g[g].size()), dim3(128), 0, gq[g], dw, d_pts_tasks[g], solve);
         else
-            hipLaunchKernelGGL(k_points, dim3((unsigned)pts_tasks.size()), dim3(256), 0, q, dw, d_pts_tasks, solve);
+            hipLaunchKernelGGL(k_points, dim3((unsigned)pts_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_pts_tasks[g], solve);
     };
-    auto enqueue_lin = [&](int init) {
-        if (lin_tasks.empty()) return;
+    auto enqueue_lin = [&](int g, int init) {
+        if (lin_tasks_g[g].empty()) return;
         if (walk)
-            hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);
+            hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)lin_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_lin_tasks[g], init);
         else
-            hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)lin_tasks.size()), dim3(256), 0, q, dw, d_lin_tasks, init);
+            hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)lin_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_lin_tasks[g], init);
     };
-    auto enqueue_init = [&]() {
-        enqueue_points(0);
-        enqueue_lin(1);
-        hipLaunchKernelGGL(k_lm_init, dim3(nw), dim3(1024), 0, q, dw);
+    auto nwg = [&](int g) { return goff[g + 1] - goff[g]; };
+    auto enqueue_init = [&](int g) {
+        enqueue_points(g, 0);
+        enqueue_lin(g, 1);
+        hipLaunchKernelGGL(k_lm_init, dim3(nwg(g)), dim3(1024), 0, gq[g], dw + goff[g]);
     };
     // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
-    auto enqueue_trial = [&]() {
-        if (!tasks.empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks.size()), dim3(kSchurThreads), 0, q, dw, d_schur_tasks);
+    bool stagger_pending = G == 2 && !getenv("AOS2_LBA_NO_STAGGER");
+    auto enqueue_trial = [&](int g) {
+        const GroupDims &D = gd[g];
+        if (!tasks_g[g].empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks_g[g].size()), dim3(kSchurThreads), 0, gq[g], dw, d_schur_tasks[g]);
+        if (g == 0 && stagger_pending) {   // the other group starts here: half a trial behind
+            (void)hipEventRecord(s->ev_stag, gq[0]);
+            (void)hipStreamWaitEvent(gq[1], s->ev_stag, 0);
+            stagger_pending = false;
+        }
         // the two forms of the reduced-system kernel work on different windows: side by side (the LDS form on a stream of its own)
-        const bool both = any_glob && any_lds;
+        const bool both = D.any_glob && D.any_lds;
         if (both) {
-            (void)hipEventRecord(s->ev_fork, q);
-            (void)hipStreamWaitEvent(s->stream2, s->ev_fork, 0);
+            (void)hipEventRecord(gfork[g], gq[g]);
+            (void)hipStreamWaitEvent(gq2[g], gfork[g], 0);
         }
-        if (any_lds) {
-            const size_t need = ((size_t)mx_npad_lds * (mx_npad_lds + 1) + (size_t)mx_npad_lds * 17 + 4 * (size_t)mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
-            hipLaunchKernelGGL(k_ldlt_lds, dim3(nw), dim3(512), need, both ? s->stream2 : q, dw);
+        if (D.any_lds) {
+            const size_t need = ((size_t)D.mx_npad_lds * (D.mx_npad_lds + 1) + (size_t)D.mx_npad_lds * 17 + 4 * (size_t)D.mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
+            hipLaunchKernelGGL(k_ldlt_lds, dim3(nwg(g)), dim3(512), need, both ? gq2[g] : gq[g], dw + goff[g]);
         }
-        if (any_glob)
-            hipLaunchKernelGGL(k_ldlt_dev, dim3(nw), dim3(512), ((size_t)mx_npad_glob * 17 + 4 * (size_t)mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), q, dw);
+        if (D.any_glob)
+            hipLaunchKernelGGL(k_ldlt_dev, dim3(nwg(g)), dim3(512), ((size_t)D.mx_npad_glob * 17 + 4 * (size_t)D.mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), gq[g],
+                               dw + goff[g]);
         if (both) {
-            (void)hipEventRecord(s->ev_join, s->stream2);
-            (void)hipStreamWaitEvent(q, s->ev_join, 0);
+            (void)hipEventRecord(gjoin[g], gq2[g]);
+            (void)hipStreamWaitEvent(gq[g], gjoin[g], 0);
         }
-        enqueue_points(1);   // + the LM decision in its last workgroup
-        enqueue_lin(0);
+        enqueue_points(g, 1);   // + the LM decision in its last workgroup
+        enqueue_lin(g, 0);
     };
-    auto enqueue_transition = [&]() {
-        hipLaunchKernelGGL(k_transition, g_edges256, dim3(256), 0, q, dw);
+    auto enqueue_transition = [&](int g) {
+        hipLaunchKernelGGL(k_transition, dim3(blocks(gd[g].mx_E, 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g]);
     };
     // results (and states) come back as one copy; the host forwards pbStopFlag into the mapped abort words meanwhile
     auto finish = [&]() -> int {
-        hipLaunchKernelGGL(k_final, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw);
+        for (int g = 0; g < G; ++g)
+            hipLaunchKernelGGL(k_final, dim3(blocks(std::max(gd[g].mx_E, gd[g].mx_pts), 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g]);
+        if (G == 2) {
+            AOS2_HIP_CHECK(hipEventRecord(s->ev_done_b, gq[1]));
+            AOS2_HIP_CHECK(hipStreamWaitEvent(q, s->ev_done_b, 0));
+        }
         AOS2_HIP_CHECK(hipEventRecord(s->ev[1], q));
         AOS2_HIP_CHECK(hipMemcpyAsync(s->h_stage.p, base + o_res, res_bytes, hipMemcpyDeviceToHost, q));
         if (any_flag) {
@@ -2702,15 +2771,17 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
     s->last_trial_slots = (max_i1 > 0 ? max_i1 + 1 : 0) + (max_i2 > 0 ? max_i2 + 1 : 0);
     s->last_host_rounds = 1;
-    hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(mx_E, mx_pts), 256), nw), dim3(256), 0, q, dw, s->debug_stop_at_poll);
-    if (max_i1 > 0) {
-        enqueue_init();
-        for (int t = 0; t < max_i1 + 1; ++t) enqueue_trial();
-    }
-    enqueue_transition();
-    if (max_i2 > 0) {
-        enqueue_init();
-        for (int t = 0; t < max_i2 + 1; ++t) enqueue_trial();
+    for (int g = 0; g < G; ++g) {
+        hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(gd[g].mx_E, gd[g].mx_pts), 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g], s->debug_stop_at_poll);
+        if (max_i1 > 0) {
+            enqueue_init(g);
+            for (int t = 0; t < max_i1 + 1; ++t) enqueue_trial(g);
+        }
+        enqueue_transition(g);
+        if (max_i2 > 0) {
+            enqueue_init(g);
+            for (int t = 0; t < max_i2 + 1; ++t) enqueue_trial(g);
+        }
     }
     if ((st = finish())) return st;
     lap("program");
@@ -2723,9 +2794,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             set_error("internal: LocalBA program did not finish");
             return AOS2_ERR_ARG;
         }
-        enqueue_transition();
-        enqueue_init();
-        for (int t = 0; t < 4; ++t) enqueue_trial();
+        for (int g = 0; g < G; ++g) {
+            enqueue_transition(g);
+            enqueue_init(g);
+            for (int t = 0; t < 4; ++t) enqueue_trial(g);
+        }
         s->last_trial_slots += 4;
         s->last_host_rounds++;
         if ((st = finish())) return st;

@@ -370,6 +370,10 @@ struct aos2_lba {
     hipEvent_t ev[3] = {};   // [0], [1]: device time of a call; [2]: spare
     hipStream_t stream2 = nullptr;      // LocalBA: the LDS form of the reduced-system kernel runs here beside the device-memory form
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // LocalBA: a batch of many windows runs as TWO groups whose programs are staggered on their own streams (lba.hip, solve_batch)
+    hipStream_t stream_b = nullptr, stream2_b = nullptr;
+    hipEvent_t ev_fork_b = nullptr, ev_join_b = nullptr, ev_up = nullptr, ev_stag = nullptr, ev_done_b = nullptr;
+    int last_groups = 1;
     aos2::DevBuf<uint8_t> arena;
     aos2::PinnedBuf<uint8_t> h_stage;   // results on their way back
     aos2::PinnedBuf<uint8_t> h_in;      // staged inputs (the arena's prefix)
