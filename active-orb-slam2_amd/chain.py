@@ -59,6 +59,7 @@ class TrackingChain:
         self.dl_kps = t.zeros((B, cap, 7), dtype=t.float32, device=self.dev)
         self.dl_desc = t.zeros((B, cap, 32), dtype=t.uint8, device=self.dev)
         self.dl_n = t.zeros((B,), dtype=t.int32, device=self.dev)
+        t.cuda.synchronize()   # (torch's fills run on torch's stream, the library on its own: the fills first)
         W, H = self.W, self.H
         self.ex_setup.extract_batch_device(self.d_last_img.data_ptr(), B, W, H, W, W * H, self.dl_kps.data_ptr(), self.dl_desc.data_ptr(),
                                            cap, self.dl_n.data_ptr())
@@ -128,6 +129,7 @@ class StereoTrackingChain(TrackingChain):
         self.r_n = t.zeros((B,), dtype=t.int32, device=self.dev)
         self.d_ur = t.zeros((B, cap), dtype=t.float32, device=self.dev)
         self.d_dp = t.zeros((B, cap), dtype=t.float32, device=self.dev)
+        t.cuda.synchronize()
         self.mbf = np.float32(scen["mbf"])
         self.mb = np.float32(self.mbf / np.float32(scen["fx"]))   # mb = mbf / fx (src/Frame.cc:86)
 
@@ -180,6 +182,7 @@ class ReferenceKeyFrameBoW:
         # the reference keyframes computed their BoW when they were created (KeyFrame::ComputeBoW): once, here, into buffers
         # of their own
         self.kf = [self.bw.clone(), self.bv.clone(), self.nb.clone(), self.fn.clone(), self.fo.clone(), self.fi.clone(), self.nf.clone()]
+        t.cuda.synchronize()   # torch's zero fills run on torch's stream, the transform on the vocabulary's: the fills first
         self._transform(tc.dl_desc, tc.dl_n, self.kf)
         self.kf_has_mp = np.zeros((n, cap), np.uint8)
         self.kf_has_mp[:, :] = tc.last_mp[:n] >= 0
@@ -254,6 +257,7 @@ class KeyFrameWork:
         self.d_img = t.from_numpy(self.nb["imgs"]).to(tc.dev)
         z = lambda shape, dt: t.zeros(shape, dtype=dt, device=tc.dev)   # noqa: E731
         self.n_kps, self.n_desc, self.n_n = z((NB, cap, 7), t.float32), z((NB, cap, 32), t.uint8), z((NB,), t.int32)
+        t.cuda.synchronize()
         self.ex.extract_batch_device(self.d_img.data_ptr(), NB, W, H, W, W * H, self.n_kps.data_ptr(), self.n_desc.data_ptr(), cap, self.n_n.data_ptr())
         self.d_depth = t.from_numpy(np.repeat(scen["Z"][: self.nb["n_scenes"]].astype(np.float32), n_nb)).to(tc.dev)[:, None, None].expand(NB, H, W).contiguous()
         self.kfs = capi.Frames(NB, cap, tc.device)
@@ -278,6 +282,7 @@ class KeyFrameWork:
         fv1 = lambda n: [z((n, cap1), t.int32), z((n, cap1), t.float64), z((n,), t.int32), z((n, cap1), t.int32), z((n, cap1 + 1), t.int32),   # noqa: E731
                          z((n, cap1), t.int32), z((n,), t.int32), z((n, cap1), t.int32), z((n, cap1), t.int32)]
         self.fv1 = fv1(B)
+        t.cuda.synchronize()   # (as above: the buffers' zero fills must not land on the transform's output)
         self.voc.transform_device(B, tc.dl_desc.data_ptr(), tc.dl_n.data_ptr(), cap1, levelsup, *(x.data_ptr() for x in self.fv1))
         # ---- pairs and fuse problems
         idx = scen["index"]

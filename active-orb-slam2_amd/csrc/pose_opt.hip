@@ -233,20 +233,29 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
     auto L1 = [&](int j, int e) -> uint8_t & { return kReg ? L1r[j] : P.level1[e]; };
     auto Rb = [&](int j, int e) -> uint8_t & { return kReg ? Rbr[j] : P.robust[e]; };
     auto Ou = [&](int j, int e) -> uint8_t & { return kReg ? Outr[j] : P.outlier[e]; };
-#pragma unroll EPT
-    PO_FOR_EDGES(j, e) {
-        if (kReg) {
+    if constexpr (kReg) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {   // (an empty slot holds zeros: the K-at-a-time edge block evaluates it with weight 0)
+            const int e = tid + j * NT;
+            const bool in = e < n;
             for (int k = 0; k < 3; ++k) {
-                Xr[j][k] = P.Xw[3 * e + k];
-                Or[j][k] = P.obs[3 * e + k];
+                Xr[j][k] = in ? P.Xw[3 * e + k] : 0.f;
+                Or[j][k] = in ? P.obs[3 * e + k] : 0.f;
             }
-            Wr[j] = P.w[e];
-            Sr[j] = P.stereo[e];
+            Wr[j] = in ? P.w[e] : 0.f;
+            Sr[j] = in ? P.stereo[e] : 0;
+            L1r[j] = 0;
+            Rbr[j] = 1;
+            Outr[j] = 0;
+            Cr[j] = 0;
         }
-        L1(j, e) = 0;
-        Rb(j, e) = 1;
-        Ou(j, e) = 0;
-        Cp(j, e) = 0;
+    } else {
+        PO_FOR_EDGES(j, e) {
+            L1(j, e) = 0;
+            Rb(j, e) = 1;
+            Ou(j, e) = 0;
+            Cp(j, e) = 0;
+        }
     }
     double qt[7];
 #pragma unroll
@@ -265,6 +274,106 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
     // one pass over the active edges at pose q: residuals (stored), robust chi2, H (upper triangle) and b
     // (computeActiveErrors + activeRobustChi2 + buildSystem; types_six_dof_expmap.cpp:266-364, base_unary_edge.hpp)
     PO_T(long long t_edges = 0, t_sum = 0, t_solve = 0, t_dec = 0, t_all = __builtin_amdgcn_s_memtime(); int n_pass = 0, n_trial = 0;)
+    // kReg: the edges of a wave's threads are processed K at a time as ONE straight-line block (no branch: the mono / stereo forms,
+    // the Huber case and "edge is at level 1 / slot is empty" are selects; an inactive slot is the point (0, 0, 1) with weight 0, whose
+    // terms are exact zeros), so that the K dependent chains -- ~200 f64 instructions of 9 cycles latency each -- interleave.  K is
+    // the number of slots the WAVE uses (a scalar branch); the sums take the slots' terms in slot order, as the one-by-one loop did.
+    const int nsl_wave = kReg ? __builtin_amdgcn_readfirstlane(min(EPT, max(0, (n - (tid & ~63) + NT - 1) / NT))) : 0;
+    auto edges = [&](auto kc, auto jc, double (&acc)[kPoSum], const double (&q)[7], const double (&Rm)[9]) {
+        constexpr int K = decltype(kc)::value, J0 = decltype(jc)::value;
+        const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, bf = P.bf;
+        double x[K], y[K], z[K], invz[K], a[K], b[K], w[K], er[K][3], c[K], wo[K], r1[K], cr[K];
+        bool st3[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = J0 + k;
+            const bool act = tid + j * NT < n && !L1r[j];
+            st3[k] = Sr[j] != 0;
+            const double X0 = (double)Xr[j][0], X1 = (double)Xr[j][1], X2 = (double)Xr[j][2];
+            const double xx = __builtin_fma(Rm[2], X2, __builtin_fma(Rm[1], X1, __builtin_fma(Rm[0], X0, q[4])));
+            const double yy = __builtin_fma(Rm[5], X2, __builtin_fma(Rm[4], X1, __builtin_fma(Rm[3], X0, q[5])));
+            const double zz = __builtin_fma(Rm[8], X2, __builtin_fma(Rm[7], X1, __builtin_fma(Rm[6], X0, q[6])));
+            x[k] = act ? xx : 0.0;
+            y[k] = act ? yy : 0.0;
+            z[k] = act ? zz : 1.0;
+            w[k] = act ? (double)Wr[j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) invz[k] = rcp_newton(z[k]);   // (1 / z within an ulp)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = J0 + k;
+            a[k] = x[k] * invz[k];
+            b[k] = y[k] * invz[k];
+            const double ob0 = (double)Or[j][0], ob1 = (double)Or[j][1], ob2 = (double)Or[j][2];
+            // EdgeStereoSE3ProjectXYZOnlyPose::cam_project: invz is a float there (types_six_dof_expmap.cpp:338)
+            const float invzf = (float)invz[k];
+            const double s0 = x[k] * invzf * fx + cx;
+            const double s1 = y[k] * invzf * fy + cy;
+            const double s2 = s0 - bf * invzf;
+            er[k][0] = ob0 - (st3[k] ? s0 : __builtin_fma(a[k], fx, cx));
+            er[k][1] = ob1 - (st3[k] ? s1 : __builtin_fma(b[k], fy, cy));
+            er[k][2] = st3[k] ? ob2 - s2 : 0.0;
+            c[k] = edge_chi2(er[k], w[k], 3);   // (a mono edge's third term is an exact zero)
+            Cr[j] = c[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {   // RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91)
+            const int j = J0 + k;
+            const double delta = st3[k] ? delta_s : delta_m, dsqr = delta * delta;
+            double sq, rs;
+            sqrt_rsqrt(c[k], sq, rs);
+            const bool hub = Rbr[j] && c[k] > dsqr;
+            cr[k] = hub ? 2 * sq * delta - dsqr : c[k];
+            r1[k] = hub ? delta * rs : 1.0;
+            wo[k] = hub ? r1[k] * w[k] : w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            acc[27] += cr[k];
+            double J[18];
+            const double fxz = fx * invz[k], fyz = fy * invz[k], ab = a[k] * b[k];
+            J[0] = ab * fx;
+            J[1] = -(__builtin_fma(a[k], a[k], 1.0) * fx);
+            J[2] = b[k] * fx;
+            J[3] = -fxz;
+            J[4] = 0;
+            J[5] = a[k] * fxz;
+            J[6] = __builtin_fma(b[k], b[k], 1.0) * fy;
+            J[7] = -(ab * fy);
+            J[8] = -(a[k] * fy);
+            J[9] = 0;
+            J[10] = -fyz;
+            J[11] = b[k] * fyz;
+            const double bfz2 = bf * (invz[k] * invz[k]);
+            J[12] = __builtin_fma(-bfz2, y[k], J[0]);
+            J[13] = __builtin_fma(bfz2, x[k], J[1]);
+            J[14] = J[2];
+            J[15] = J[3];
+            J[16] = 0;
+            J[17] = J[5] - bfz2;
+            const double wo2 = st3[k] ? wo[k] : 0.0;
+            const double we0 = r1[k] * (w[k] * er[k][0]), we1 = r1[k] * (w[k] * er[k][1]), we2 = st3[k] ? r1[k] * (w[k] * er[k][2]) : 0.0;
+            int m = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double j0 = J[r] * wo[k], j1 = J[6 + r] * wo[k], j2 = J[12 + r] * wo2;
+                double bb = acc[21 + r];
+                if (r != 4) bb = __builtin_fma(-J[r], we0, bb);
+                if (r != 3) bb = __builtin_fma(-J[6 + r], we1, bb);
+                if (r != 4) bb = __builtin_fma(-J[12 + r], we2, bb);
+                acc[21 + r] = bb;
+#pragma unroll
+                for (int c2 = r; c2 < 6; ++c2, ++m) {
+                    double t = acc[m];
+                    if (r != 4 && c2 != 4) t = __builtin_fma(j0, J[c2], t);
+                    if (r != 3 && c2 != 3) t = __builtin_fma(j1, J[6 + c2], t);
+                    if (r != 4 && c2 != 4) t = __builtin_fma(j2, J[12 + c2], t);
+                    acc[m] = t;
+                }
+            }
+        }
+    };
     auto pass = [&](const double (&q)[7], double *fin) {
         PO_T(const long long p0 = __builtin_amdgcn_s_memtime();)
         double acc[kPoSum];
@@ -275,6 +384,29 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
         // types_six_dof_expmap.cpp:266-364 in fewer operations -- results equal to rounding (1e-16 relative).
         double Rm[9];
         rot_from_quat(q, Rm);
+        if constexpr (kReg) {
+            using std::integral_constant;
+            if constexpr (EPT == 4) {
+                if (nsl_wave == 1) edges(integral_constant<int, 1>(), integral_constant<int, 0>(), acc, q, Rm);
+                else if (nsl_wave == 2) edges(integral_constant<int, 2>(), integral_constant<int, 0>(), acc, q, Rm);
+                else if (nsl_wave == 3) edges(integral_constant<int, 3>(), integral_constant<int, 0>(), acc, q, Rm);
+                else if (nsl_wave == 4) edges(integral_constant<int, 4>(), integral_constant<int, 0>(), acc, q, Rm);
+            } else {
+                auto chunks = [&](auto self, auto jc) {
+                    constexpr int jj = decltype(jc)::value;
+                    if constexpr (jj < EPT) {
+                        if constexpr (jj + 1 < EPT) {
+                            if (jj + 1 < nsl_wave) edges(integral_constant<int, 2>(), jc, acc, q, Rm);
+                            else if (jj < nsl_wave) edges(integral_constant<int, 1>(), jc, acc, q, Rm);
+                        } else {
+                            if (jj < nsl_wave) edges(integral_constant<int, 1>(), jc, acc, q, Rm);
+                        }
+                        self(self, integral_constant<int, jj + 2>());
+                    }
+                };
+                chunks(chunks, integral_constant<int, 0>());
+            }
+        } else {
         const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy, bf = P.bf;
 #pragma unroll EPT
         PO_FOR_EDGES(j, e) {
@@ -364,6 +496,7 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
                 }
             }
         }
+        }
         PO_T(const long long p1 = __builtin_amdgcn_s_memtime();)
         block_sum28<NT>(acc, sh, fin);
         PO_T(const long long p2 = __builtin_amdgcn_s_memtime(); t_edges += p1 - p0; t_sum += p2 - p1; ++n_pass;)
@@ -380,40 +513,56 @@ __device__ __forceinline__ void pose_optimization_body(const PoseProbDev &P, dou
             bool ok = true, have = false;   // have: Hb / currentChi / the stored chi2 belong to the current pose
             double lambda = 0, ni = 2, currentChi = 0;
             for (int i = 0; i < 10 && ok; ++i) {
-                if (!have) {   // computeActiveErrors + buildSystem at the top of solve() (levenberg.cpp:75-88)
-                    pass(qt, fin0 + cur * kPoSum);
-                    currentChi = fin0[cur * kPoSum + 27];
-                }
-                const double *Hb = fin0 + cur * kPoSum;
-                const double iniChi = currentChi;
-                if (i == 0) {
-                    double maxDiagonal = 0.;
-                    constexpr int di[6] = {0, 6, 11, 15, 18, 20};
+                // ONE call site of the edge pass: the pass at the top of solve() (computeActiveErrors + buildSystem, levenberg.cpp:75-88
+                // -- needed when the sums of the current pose are not there: the first iteration of a round, or after a rejected last
+                // trial) runs as a preliminary turn of the trial loop
+                bool init = !have;
+                double iniChi = currentChi;
+                auto begin_iter = [&]() {
+                    iniChi = currentChi;
+                    if (i == 0) {
+                        const double *Hb = fin0 + cur * kPoSum;
+                        double maxDiagonal = 0.;
+                        constexpr int di[6] = {0, 6, 11, 15, 18, 20};
 #pragma unroll
-                    for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
-                    lambda = 1e-5 * maxDiagonal;
-                    ni = 2;
-                    nBadLM = 0;
-                }
-                double rho = 0;
+                        for (int d = 0; d < 6; ++d) maxDiagonal = fmax(fabs(Hb[di[d]]), maxDiagonal);
+                        lambda = 1e-5 * maxDiagonal;
+                        ni = 2;
+                        nBadLM = 0;
+                    }
+                };
+                if (!init) begin_iter();
+                double rho = 0, scale = 0;
                 int qmax = 0;
+                bool pos = true;
+                double bk[7];
                 do {
-                    double bk[7];
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) bk[k] = qt[k];
-                    Hb = fin0 + cur * kPoSum;
+                    double *dst = fin0 + cur * kPoSum;
                     PO_T(const long long s0 = __builtin_amdgcn_s_memtime();)
-                    const bool pos = solve6(Hb, lambda, xs);
-                    se3_oplus_fast(xs, qt);   // (after a failed solve: the previous x once more; the trial is rejected below)
-                    double scale = 0.;
+                    if (!init) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + Hb[21 + j]);
-                    scale += 1e-3;
-                    double *Ht = fin0 + (cur ^ 1) * kPoSum;   // the trial's sums go to the other buffer: accepting = switching
-                    PO_T(const long long s1 = __builtin_amdgcn_s_memtime(); t_solve += s1 - s0; ++n_trial;)
-                    pass(qt, Ht);
+                        for (int k = 0; k < 7; ++k) bk[k] = qt[k];
+                        const double *Hb = fin0 + cur * kPoSum;
+                        pos = solve6(Hb, lambda, xs);
+                        se3_oplus_fast(xs, qt);   // (after a failed solve: the previous x once more; the trial is rejected below)
+                        scale = 0.;
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) scale += xs[j] * (lambda * xs[j] + Hb[21 + j]);
+                        scale += 1e-3;
+                        dst = fin0 + (cur ^ 1) * kPoSum;   // the trial's sums go to the other buffer: accepting = switching
+                        PO_T(++n_trial;)
+                    }
+                    PO_T(const long long s1 = __builtin_amdgcn_s_memtime(); t_solve += s1 - s0;)
+                    pass(qt, dst);
+                    if (init) {
+                        currentChi = dst[27];
+                        begin_iter();
+                        init = false;
+                        rho = -1;   // (stay in the loop: the first trial follows)
+                        continue;
+                    }
                     PO_T(const long long s2 = __builtin_amdgcn_s_memtime();)
-                    const double tempChi = pos ? Ht[27] : 1.7976931348623157e308;
+                    const double tempChi = pos ? dst[27] : 1.7976931348623157e308;
                     double r = currentChi - tempChi;
                     r /= scale;
                     have = false;
