@@ -144,6 +144,7 @@ def lib():
             L.aos2_lba_solve_batch.argtypes = [vp, vp, vp, ci]
             L.aos2_lba_debug_stop_at_poll.argtypes = [vp, ci]
             L.aos2_lba_set_host_threads.argtypes = [vp, ci]
+            L.aos2_lba_set_window_groups.argtypes = [vp, ci]
             L.aos2_lba_last_program.argtypes = [vp, vp, vp]
             L.aos2_lba_debug_host_phase.argtypes = [vp, ci, ci, vp, vp]
             if hasattr(L, "aos2_pose_optimization"):
@@ -984,6 +985,10 @@ class LocalBA:
 
     def set_host_threads(self, n):
         _check(self.L.aos2_lba_set_host_threads(self.h, int(n)))
+
+    def set_window_groups(self, n):
+        """0 = default, 1 = one program for all windows of a batch, 2 = two staggered window groups (include/aos2.h)"""
+        _check(self.L.aos2_lba_set_window_groups(self.h, int(n)))
 
     def last_program(self):
         """(trial slots enqueued for every window, host rounds) of the last solve"""

@@ -112,6 +112,38 @@ class TrackingChain:
         self.cur.wait()
         self.ex.wait()
 
+    # ---- ONE sequence, frame after frame, with the NEXT image's ExtractORB already running: the extraction of frame t + 1 depends on
+    # nothing of frame t (Tracking::GrabImageRGBD builds the Frame from the image alone, src/Tracking.cc:207-235), so it is enqueued
+    # on the extractor's stream as soon as frame t's Frame::Frame has taken its own extraction, beside frame t's searches and
+    # PoseOptimizations.  Two output buffer sets; the frame's latency is unchanged, the period is max(extraction, tracking).
+    def step_pipelined(self):
+        t = self.torch
+        if not hasattr(self, "_sets"):
+            self._sets = [(self.d_kps, self.d_desc, self.d_n), (t.zeros_like(self.d_kps), t.zeros_like(self.d_desc), t.zeros_like(self.d_n))]
+            t.cuda.synchronize()
+            self._k = 0
+            self._extract_into(self._sets[0])
+        B, W, H, s, c = self.B, self.W, self.H, self.scen, self.cur
+        kps, desc, n = self._sets[self._k]
+        c.set_pose(self.d_guess.data_ptr())
+        c.build(self.ex, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), W, H, self.d_depth.data_ptr(),
+                float(s["fx"]), float(s["fy"]), float(s["cx"]), float(s["cy"]), float(s["mbf"]))   # (waits, on the device, for the extraction enqueued so far: this frame's)
+        self._k ^= 1
+        self._extract_into(self._sets[self._k])   # the next image
+        c.SearchByProjectionLast(self.last, self.table, self.th_last, mono=False, check_orientation=True, d_nmatches=self.d_nm[0].data_ptr())
+        c.PoseOptimization(self.table, self.d_nm[1].data_ptr())
+        c.discard_outliers()
+        c.SearchLocalPoints(self.table, self.d_local.data_ptr(), self.n_local, self.th_local, self.nnratio_local, self.d_nm[2].data_ptr())
+        c.PoseOptimization(self.table, self.d_nm[3].data_ptr())
+
+    def _extract_into(self, bufs):
+        B, W, H = self.B, self.W, self.H
+        self.ex.extract_batch_device_async(self.d_cur.data_ptr(), B, W, H, W, W * H, bufs[0].data_ptr(), bufs[1].data_ptr(), self.cap, bufs[2].data_ptr())
+
+    def wait_frame(self):
+        """the frame of the last step_pipelined() is complete (the next image's extraction may still run)"""
+        self.cur.wait()
+
 
 class StereoTrackingChain(TrackingChain):
     """The same chain behind the STEREO Frame constructor (src/Frame.cc:57-113; Examples/Stereo/stereo_kitti.cc:108-117 per frame):

@@ -1874,18 +1874,31 @@ int lba_handle_init(aos2_lba *s)
             AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        for (hipStream_t *q : {&s->stream_b, &s->stream2_b}) {
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-                AOS2_HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
-            else
-                AOS2_HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
-        }
-        for (hipEvent_t *e : {&s->ev_fork_b, &s->ev_join_b, &s->ev_up, &s->ev_stag, &s->ev_done_b}) AOS2_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     s->dev_ready = true;
+    return AOS2_OK;
+}
+
+// The second window group's streams and events, created when a call first runs two groups: a handle that never does keeps two
+// streams.  (The runtime maps the streams of a priority class onto GPU_MAX_HW_QUEUES = 4 hardware queues by creation order and
+// serialises those that share one: two handles solving side by side, each with four streams, had their main streams on the same
+// queue in some processes and not in others -- 50 k against 60 k frames/s of the composite from run to run.)
+static int lba_group_streams(aos2_lba *s)
+{
+    if (s->stream_b) return AOS2_OK;
+    int least = 0, greatest = 0;
+    const char *e = getenv("AOS2_LBA_STREAM_PRIORITY");
+    const bool prio = (!e || strcmp(e, "normal")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
+    for (hipStream_t *q : {&s->stream_b, &s->stream2_b}) {
+        if (prio)
+            AOS2_HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
+        else
+            AOS2_HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+    }
+    for (hipEvent_t *ev : {&s->ev_fork_b, &s->ev_join_b, &s->ev_up, &s->ev_stag, &s->ev_done_b}) AOS2_HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return AOS2_OK;
 }
 
@@ -2234,10 +2247,12 @@ void aos2_lba_destroy(aos2_lba_t *s)
         for (auto &e : s->ev) (void)hipEventDestroy(e);
         (void)hipEventDestroy(s->ev_fork);
         (void)hipEventDestroy(s->ev_join);
-        for (hipEvent_t e : {s->ev_fork_b, s->ev_join_b, s->ev_up, s->ev_stag, s->ev_done_b}) (void)hipEventDestroy(e);
-        (void)hipStreamSynchronize(s->stream_b);
-        (void)hipStreamDestroy(s->stream2_b);
-        (void)hipStreamDestroy(s->stream_b);
+        if (s->stream_b) {
+            for (hipEvent_t e : {s->ev_fork_b, s->ev_join_b, s->ev_up, s->ev_stag, s->ev_done_b}) (void)hipEventDestroy(e);
+            (void)hipStreamSynchronize(s->stream_b);
+            (void)hipStreamDestroy(s->stream2_b);
+            (void)hipStreamDestroy(s->stream_b);
+        }
         (void)hipStreamDestroy(s->stream2);
         (void)hipStreamDestroy(s->stream);
     }
@@ -2248,6 +2263,13 @@ int aos2_lba_set_host_threads(aos2_lba_t *s, int n)
 {
     if (!s || n < 0) return AOS2_ERR_ARG;
     s->host_threads = n;
+    return AOS2_OK;
+}
+
+int aos2_lba_set_window_groups(aos2_lba_t *s, int n)
+{
+    if (!s || n < 0 || n > 2) return AOS2_ERR_ARG;
+    s->window_groups = n;
     return AOS2_OK;
 }
 
@@ -2371,10 +2393,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // idles).  A batch of many windows runs as TWO groups with the same program each, on their own streams, the second started
     // behind the first group's first Schur launch: one group's reduced systems are factorised while the other group's landmark
     // kernels fill the device.  Windows are dealt to the groups by size (edges), largest first, so both get the same mix; the
-    // windows of a group are neighbours in the descriptor array.  (AOS2_LBA_GROUPS=1 switches it off.)
-    int G = nw >= 16 ? 2 : 1;
+    // windows of a group are neighbours in the descriptor array.  (aos2_lba_set_window_groups; AOS2_LBA_GROUPS overrides.)
+    int G = s->window_groups ? s->window_groups : nw >= 16 ? 2 : 1;
     if (const char *e = getenv("AOS2_LBA_GROUPS")) G = std::max(1, std::min(2, atoi(e)));
     if (G > nw) G = 1;
+    if (G == 2 && (st = lba_group_streams(s))) return st;
     int goff[3] = {0, nw, nw};
     if (G == 2) {
         std::vector<int> order(act);

@@ -374,6 +374,7 @@ struct aos2_lba {
     hipStream_t stream_b = nullptr, stream2_b = nullptr;
     hipEvent_t ev_fork_b = nullptr, ev_join_b = nullptr, ev_up = nullptr, ev_stag = nullptr, ev_done_b = nullptr;
     int last_groups = 1;
+    int window_groups = 0;              // LocalBA: 0 = default (two groups for batches of >= 16 windows), 1 / 2 (aos2_lba_set_window_groups)
     aos2::DevBuf<uint8_t> arena;
     aos2::PinnedBuf<uint8_t> h_stage;   // results on their way back
     aos2::PinnedBuf<uint8_t> h_in;      // staged inputs (the arena's prefix)

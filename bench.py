@@ -33,11 +33,11 @@ import os
 import sys
 import time
 
-# A step keeps ~12 HIP streams busy (2 pipelines x (extractor chunks + Frame stream + keyframe legs) + 2 LocalBA handles x 2 streams).  The ROCm
-# runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue are serialised, and which ones share
-# is decided by creation order.  Measured on one box (tools/bench_hwq_sweep.sh): 4 queues 50.2 k, 8 queues 60.0 k, 16 queues 61.2 k frames/s
-# (and 50-61 k from run to run with the default).  Must be in the environment before the runtime initialises; a caller's own setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# A step keeps ~12 HIP streams busy (2 pipelines x (extractor + Frame stream + keyframe legs) + 2 LocalBA handles x 2 streams).  The ROCm runtime
+# maps the streams of a priority class onto GPU_MAX_HW_QUEUES hardware queues (default 4) by creation order and serialises those that share
+# one.  Measured (tools/bench_hwq_sweep.sh, three boxes): the default is the best setting now that a LocalBA handle creates two streams
+# (four handles' worth of high-priority streams used to land two on a queue in some processes: 50 k against 60 k frames/s from run to run);
+# 8 queues 52 k, 16 queues 42 k (10 ms stalls in the synchronous passes), 32 queues 23 k.  Left to the runtime unless the caller sets it.
 
 import numpy as np
 
@@ -336,8 +336,12 @@ def main():
     # host threads of a handle's per-window work: the node's cores shared among ranks and handles (8 ranks x 2 handles x 32 threads
     # would be 512 threads on 256 cores)
     lba_threads = max(1, min(32, n_win, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)) * NLBA)))
+    # two handles solve side by side beside the tracking kernels: one program per batch (a handle's two staggered window groups are the
+    # faster form only for a batch that has the device to itself: 61 k against 54 k frames/s here; AOS2_BENCH_LBA_GROUPS overrides)
+    LBA_GROUPS = int(os.environ.get("AOS2_BENCH_LBA_GROUPS", "1" if NLBA > 1 else "0"))
     for h in lbas:
         h.set_host_threads(lba_threads)
+        h.set_window_groups(LBA_GROUPS)
     lba_prep = [h.prepare_batch(lba_probs) for h in lbas]
     pool = ThreadPoolExecutor(NLBA)   # LocalMapping-side threads: one per LocalBA handle
     lba_jobs = [None] * NLBA
@@ -653,7 +657,20 @@ def main():
                 tc1.wait()
                 lat.append(time.perf_counter() - ta_)
             ms1 = float(np.median(lat[5:])) * 1e3
+            # ... and with the next image's ExtractORB enqueued beside the frame's tracking (chain.step_pipelined): wall clock of 200 frames
+            tc1.wait()
+            for it_ in range(10):
+                tc1.step_pipelined(); tc1.wait_frame()
+            ta_ = time.perf_counter()
+            for it_ in range(200):
+                tc1.step_pipelined(); tc1.wait_frame()
+            ms1p = (time.perf_counter() - ta_) * 1e3 / 200
+            tc1.wait()
             extra["single_sequence"] = {"ms_per_frame": ms1, "frames_per_s": 1e3 / ms1,
+                                        "next_image_extracted_beside_tracking": {"ms_per_frame": ms1p, "frames_per_s": 1e3 / ms1p,
+                                            "note": "the same chain, every frame waited for before the next one's Frame::Frame, but the NEXT image's "
+                                                    "operator() is enqueued on the extractor's stream while this frame is tracked (it depends on the image "
+                                                    "alone, Tracking.cc:207-235): period = max(extraction, tracking); a frame's latency is ms_per_frame above"},
                                         "note": "B = 1, device-resident chain: operator() + Frame::Frame + SearchByProjection(Current, Last) + "
                                                 "PoseOptimization + SearchLocalPoints + PoseOptimization, enqueue + wait per frame (latency-bound: "
                                                 "dependent single-workgroup kernels -- PoseOptimization, the level-0 octree, the greedy resolves)"}
@@ -825,7 +842,7 @@ def main():
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
-                       "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "local_ba_window_groups_per_handle": LBA_GROUPS,
                        "frames_per_s_per_rank": [B * args.steps / d_ for d_ in dt_ranks],
                        "host_threads_per_rank": {"enqueue": 1, "local_ba_handles": NLBA, "local_ba_workers_per_handle": lba_threads,
                                                  "keyframe_legs": NPIPE, "host_cores": os.cpu_count()},

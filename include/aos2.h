@@ -626,6 +626,12 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
  * min(32, host cores / ranks of the node (LOCAL_WORLD_SIZE or WORLD_SIZE)), never more than windows in the call.  No reference
  * equivalent (g2o builds its structure on the calling thread, sparse_optimizer.cpp:354-372). */
 int aos2_lba_set_host_threads(aos2_lba_t *s, int n);
+/* Window groups of a batch: 2 = the windows are dealt to two groups whose programs run on streams of their own, half a trial apart,
+ * so that one group's reduced systems (one workgroup per window) are factorised while the other's landmark kernels fill the device --
+ * the faster form for a batch that has the device to itself (64 mixed windows 5.7 -> 5.2 ms); 1 = one program for all windows -- the
+ * faster form when other work shares the device (two handles solving side by side beside the tracking kernels: 61 k against 54 k
+ * frames/s of bench.py's composite); 0 = default: 2 for calls of >= 16 windows.  Results do not depend on it.  No reference equivalent. */
+int aos2_lba_set_window_groups(aos2_lba_t *s, int n);
 /* The device program of the last solve of this handle: `trial_slots` = Levenberg-Marquardt trials enqueued for EVERY window of
  * the call (iterations + 1 per optimisation, + 4 per continuation round; a window that needs fewer leaves its slots empty --
  * the lock-step cost of a heterogeneous batch), `host_rounds` = times the host waited for the device (1 = no continuation). */

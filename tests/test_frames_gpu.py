@@ -207,6 +207,26 @@ def test_rolling_last_frame_needs_no_host_wait(pkg, gpu):
     assert nxt.get(F.TCW).tobytes() == tc.d_guess.cpu().numpy().tobytes()
 
 
+def test_next_image_extracted_beside_the_tracking_of_this_one(pkg, gpu):
+    """ONE sequence, frame after frame (chain.step_pipelined): the next image's ORBextractor::operator() is enqueued while the current
+    frame is tracked, into the other output buffer set -- every frame's results are those of the plain enqueue-and-wait chain, bit
+    for bit."""
+    scen = pkg.scenario.tracking_scenario(5, 1, n_unique=1)
+    tc = pkg.chain.TrackingChain(scen, n_local=1500)
+    F = pkg.capi.Frames
+    tc.step()
+    tc.wait()
+    want = (tc.cur.get(F.MAP_POINTS), tc.cur.get(F.TCW), tc.cur.get(F.OUTLIER), tc.d_nm.cpu().numpy().copy())
+    assert want[3][1, 0] > 100 and want[3][3, 0] > 100
+    for _ in range(6):
+        tc.step_pipelined()
+        tc.wait_frame()
+        got = (tc.cur.get(F.MAP_POINTS), tc.cur.get(F.TCW), tc.cur.get(F.OUTLIER), tc.d_nm.cpu().numpy().copy())
+        for a, b in zip(got, want):
+            assert a.tobytes() == b.tobytes()
+    tc.wait()
+
+
 def test_bench_scenario_all_frames_vs_oracle(pkg, oracle, gpu):
     """Exactly what bench.py times: `tracking_scenario(100, 256, n_unique=32)` through TrackingChain.step() (the whole chain
     enqueued at once, asynchronously behind the extractor, n_local = 1500) -- every one of the 256 batch positions (32

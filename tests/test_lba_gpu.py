@@ -253,6 +253,16 @@ def test_lba_batch_sizes_around_the_window_groups(pkg, gpu, monkeypatch):
             got = ba.LocalBundleAdjustmentBatch([uniq[j] for j in idx])
             assert all(g["status"] == 0 and _same(g, alone[j]) for g, j in zip(got, idx)), (layout, n)
     monkeypatch.delenv("AOS2_LBA_LAYOUT")
+    # aos2_lba_set_window_groups: one program for the batch / two staggered groups (the default from 16 windows on) -- the same bits
+    idx = [(3 * i + 5) % len(uniq) for i in range(33)]
+    for groups in (1, 2, 0):
+        ba = pkg.LocalBA()
+        ba.set_window_groups(groups)
+        for _ in range(2):
+            got = ba.LocalBundleAdjustmentBatch([uniq[j] for j in idx])
+            assert all(g["status"] == 0 and _same(g, alone[j]) for g, j in zip(got, idx)), groups
+    with pytest.raises(Exception):
+        ba.set_window_groups(3)
 
 
 def test_lba_batch_is_deterministic_under_concurrency(pkg, gpu):
