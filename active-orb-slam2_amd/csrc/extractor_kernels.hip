@@ -5,6 +5,10 @@
 #include <algorithm>
 #include <cmath>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "written for gfx950 (MI355X) only: global_load_lds_dwordx4, v_pk_maximum3_f16, v_permlane{16,32}_swap (Makefile: ARCH = gfx950)"
+#endif
+
 #include "extractor_kernels.h"
 #include "octree.h"
 #include "sincos_exact.h"
@@ -310,7 +314,6 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                                                         size_t img0_stride, int pitch0,
                                                         const uint8_t *__restrict__ pyr,
                                                         size_t pyr_stride,
-                                                        const LevelDev *__restrict__ levels,
                                                         const CellDev *__restrict__ cells,
                                                         int n_cells, int ini_th, int min_th,
                                                         int TP, int TH, int SP,
@@ -349,7 +352,6 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         cell.ch = (int16_t)(w[2] & 0xffffu); cell.pitch = (uint16_t)(w[2] >> 16);
         cell.slot_off = (int32_t)w[3]; cell.inv_ndw = w[4]; cell.inv_nq = w[5]; cell.plane_off = w[6]; cell.inv_n16 = w[7];
     }
-    (void)levels;
     struct { int pitch; } lv{(int)cell.pitch};
     const uint8_t *plane = pyr + (size_t)b * pyr_stride + cell.plane_off;
     if (cell.level == 0) {  // level 0 is the caller's image itself (no copy)
@@ -1514,12 +1516,12 @@ void launch_pyramid_fused(const uint8_t *img0, size_t img0_stride, int pitch0, u
 }
 
 void launch_fast(const uint8_t *img0, size_t img0_stride, int pitch0, const uint8_t *pyr, size_t pyr_stride,
-                 const LevelDev *levels, const CellDev *cells, int n_cells,
+                 const LevelDev * /*levels: the cell records carry their level's plane offset and pitch*/, const CellDev *cells, int n_cells,
                  int ini_th, int min_th, int TP, int TH, int SP, size_t lds_bytes, int list_cap, int keep_cap,
                  uint32_t *slots, size_t slot_stride, int32_t *cell_cnt, int batch, hipStream_t st)
 {
     dim3 blk(64), grd((batch + 7) & ~7, n_cells);
-    hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, cells, n_cells, ini_th,
+    hipLaunchKernelGGL(fast_cells_kernel, grd, blk, lds_bytes, st, img0, img0_stride, pitch0, pyr, pyr_stride, cells, n_cells, ini_th,
                        min_th, TP, TH, SP, slots, slot_stride, cell_cnt, list_cap, keep_cap, batch);
 }
 

@@ -17,3 +17,4 @@ cp $O/ldlt_phase_cycles.txt profiles/r04_ldlt_phase_cycles.txt
 cp $O/desc_blur_ab.txt profiles/r04_desc_blur_ab.txt
 cp $O/chain_latency.txt profiles/r04_chain_latency.txt
 cp $O/pytest_gpu.log profiles/r04_pytest_gpu.log
+[ -f $O/lba_unprofiled.txt ] && cp $O/lba_unprofiled.txt profiles/r04_lba_unprofiled.txt

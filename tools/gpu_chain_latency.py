@@ -27,14 +27,7 @@ def motion():
 def full():
     tc.step(); tc.wait()
 r = {"extract_ms": t(extract), "extract+frame+search_last+pose_ms": t(motion), "full_chain_ms": t(full)}
-tc.wait()
-for _ in range(10):
-    tc.step_pipelined(); tc.wait_frame()
-a = time.perf_counter()
-for _ in range(200):
-    tc.step_pipelined(); tc.wait_frame()
-r["next_image_extracted_beside_tracking_ms_per_frame"] = (time.perf_counter() - a) * 1e3 / 200
-tc.wait()
+# (the pipelined sequence -- next image beside this frame -- is measured and traced by tools/gpu_pipelined_trace.py)
 def stage(fn):
     def f():
         fn(); c.wait()

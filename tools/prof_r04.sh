@@ -45,5 +45,9 @@ AOS2_DESC_BLUR=level rocprofv3 --kernel-trace --stats --output-format csv -d $O/
 cd $R
 python tools/gpu_chain_latency.py 2>&1 | grep -v "amdgpu.ids" > $O/chain_latency.txt
 cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/chain -- python $R/tools/gpu_chain_latency.py > /dev/null 2>&1; python $R/tools/kstats.py $O/chain 24 >> $O/chain_latency.txt; cd $R
+echo "# ---- ONE sequence with the next image's ExtractORB beside this frame's tracking (tools/gpu_pipelined_trace.py)" >> $O/chain_latency.txt
+python tools/gpu_pipelined_trace.py 2>&1 | grep "per frame" >> $O/chain_latency.txt
+# ---- LocalBA batches without the profiler
+for g in "" 1; do for cfg in "het 64" "hom 64" "het 32" "hom 32"; do set -- $cfg; echo "AOS2_LBA_GROUPS=${g:-default} $(env ${g:+AOS2_LBA_GROUPS=$g} LBA_MIX=$1 LBA_N=$2 python tools/gpu_lba_mix_prof.py 2>&1 | grep windows | tail -1)"; done; done > $O/lba_unprofiled.txt
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
 du -sh $O; ls $O
