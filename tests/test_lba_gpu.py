@@ -104,6 +104,23 @@ def test_pose_optimization_vs_oracle(pkg, oracle, gpu, cfg):
     assert close(got["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16))
 
 
+def test_pose_optimization_slot_count_boundaries(pkg, oracle, gpu):
+    """The edge passes run a wave's edges K at a time, K = the slots the WAVE uses (pose_opt.hip): correspondence counts around every
+    change of a wave's slot count -- 64 w and 256 j + 64 w (+- 1) for the 256-thread kernel that keeps <= 4 edges per thread in
+    registers, and beyond 1024 the kernel that leaves them in memory -- one call with all of them (problems of different sizes share a launch),
+    with mono-only, stereo-only and mixed edges and enough outliers for edges to leave at every round."""
+    ns = sorted(set(n for base in (64, 128, 192, 256, 320, 512, 576, 768, 832, 1024) for n in (base - 1, base, base + 1)) | {9, 10, 11, 33, 1025, 1500})
+    probs = [pkg.synth.synth_pose_problem(8100 + i, n=n, stereo_frac=(0.0, 1.0, 0.6)[i % 3], outlier_frac=(0.05, 0.3)[i % 2], cfg=("tum", "kitti")[i % 2])
+             for i, n in enumerate(ns)]
+    small = [p for p in probs if p["n"] <= 1024]
+    ba = pkg.LocalBA()
+    got = ba.PoseOptimization(small) + [ba.PoseOptimization(p) for p in probs if p["n"] > 1024]
+    for p, g in zip(small + [p for p in probs if p["n"] > 1024], got):
+        want = oracle.pose_optimization(p)
+        assert g["n_inliers"] == want["n_inliers"] and g["n_bad"] == want["n_bad"] and (g["outlier"] == want["outlier"]).all(), p["n"]
+        assert close(g["Tcw"].reshape(1, 16), want["Tcw"].reshape(1, 16), key="po_slots"), p["n"]
+
+
 def test_pose_optimization_fewer_than_three_correspondences(pkg, oracle, gpu):
     """nInitialCorrespondences < 3 (:355-356): pose unchanged, 0 inliers, and mvbOutlier all false -- also right after a
     call on the same handle that left outlier flags in the device arena (found by tools/gpu_fuzz_rest.py)."""
