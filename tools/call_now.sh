@@ -1,5 +1,14 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_frames_gpu.py -m gpu -x -q 2>&1 | tail -3
-for g in 64 16 8 4 2 1 default; do if [ $g = default ]; then python tools/gpu_fill_group_sweep.py 2>&1 | grep FILL; else AOS2_FILL_GROUP=$g python tools/gpu_fill_group_sweep.py 2>&1 | grep FILL; fi; done
-CHAIN_B=256 python tools/gpu_fill_group_sweep.py 2>&1 | grep FILL
-CHAIN_B=256 AOS2_FILL_GROUP=64 python tools/gpu_fill_group_sweep.py 2>&1 | grep FILL
+mkdir -p gpurun_out/c8
+run() {
+  echo "Q=$1 $2"
+  env GPU_MAX_HW_QUEUES=$1 $2 python bench.py --no-extra --no-cpu-baseline --no-verify 2> gpurun_out/c8/hwq.err | tail -1 > gpurun_out/c8/r.json
+  python -c "
+import json; d=json.loads(open('gpurun_out/c8/r.json').read()); print('   value %.0f ms_per_step %.3f' % (d['value'], d['ms_per_step']))" || tail -3 gpurun_out/c8/hwq.err
+}
+run 4 A=1
+run 2 A=1
+run 3 A=1
+run 1 A=1
+run 4 AOS2_LBA_STREAM_PRIORITY=normal
+run 2 AOS2_LBA_STREAM_PRIORITY=normal
