@@ -218,6 +218,36 @@ def device_count():
     return lib().aos2_device_count()
 
 
+def device_local_cpus(device=0):
+    """set of host CPUs on the device's NUMA node (aos2_device_local_cpus; empty when the platform does not say)"""
+    L = lib()
+    L.aos2_device_local_cpus.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(8192)
+    _check(L.aos2_device_local_cpus(int(device), buf, len(buf)))
+    cpus = set()
+    for part in buf.value.decode().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_to_device_node(device=0):
+    """sched_setaffinity of the calling thread (and the threads it creates from now on) to the device's local CPUs, intersected with
+    the CPUs the process may use; returns the CPU count bound to, 0 when nothing was changed"""
+    import os
+    try:
+        cpus = device_local_cpus(device) & os.sched_getaffinity(0)
+    except (AosError, OSError):
+        return 0
+    if not cpus:
+        return 0
+    os.sched_setaffinity(0, cpus)
+    return len(cpus)
+
+
 class Extractor:
     """Mirror of ORBextractor (include/ORBextractor.h:45-111): ctor args, operator(), getters."""
 

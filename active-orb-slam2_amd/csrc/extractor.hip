@@ -5,7 +5,11 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -850,6 +854,35 @@ int aos2_device_count(void)
         return 0;
     }
     return n;
+}
+
+int aos2_device_local_cpus(int device, char *buf, int cap)
+{
+    if (!buf || cap < 1) return AOS2_ERR_ARG;
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        (void)hipGetLastError();
+        return AOS2_ERR_NO_DEVICE;
+    }
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return AOS2_OK;   // unknown: the empty list
+    }
+    for (char *c = bus; *c; ++c) *c = (char)tolower(*c);   // sysfs names are lower case
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return AOS2_OK;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return AOS2_OK;
+    size_t len = strlen(line);
+    while (len && (line[len - 1] == '\n' || line[len - 1] == ' ')) line[--len] = 0;
+    if ((int)len + 1 > cap) return AOS2_ERR_CAPACITY;
+    memcpy(buf, line, len + 1);
+    return AOS2_OK;
 }
 
 int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,

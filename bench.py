@@ -34,10 +34,8 @@ import sys
 import time
 
 # A step keeps ~12 HIP streams busy (2 pipelines x (extractor + Frame stream + keyframe legs) + 2 LocalBA handles x 2 streams).  The ROCm runtime
-# maps the streams of a priority class onto GPU_MAX_HW_QUEUES hardware queues (default 4) by creation order and serialises those that share
-# one.  Measured (tools/bench_hwq_sweep.sh, three boxes): the default is the best setting now that a LocalBA handle creates two streams
-# (four handles' worth of high-priority streams used to land two on a queue in some processes: 50 k against 60 k frames/s from run to run);
-# 8 queues 52 k, 16 queues 42 k (10 ms stalls in the synchronous passes), 32 queues 23 k.  Left to the runtime unless the caller sets it.
+# maps the streams of a priority class onto GPU_MAX_HW_QUEUES hardware queues (default 4) by creation order.  Over ~60 runs the queue count
+# (4 / 8 / 16) has no effect beyond the line's run-to-run spread, so it is left to the runtime / the caller.
 
 import numpy as np
 
@@ -226,6 +224,18 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Host placement.  AOS2_BENCH_NUMA=1 binds the process to the CPUs of the GPU's NUMA node (aos2_device_local_cpus) before any handle exists,
+    # =setup releases the threads again after the warm-up (handles and page-locked buffers stay on the node), =cores takes one logical CPU per core.
+    # Default 0 (the scheduler decides): on the pool's SHARED hosts no mode was consistently better -- pinned to the OTHER socket the step ran at
+    # 51-52 k frames/s four times out of four (against 59-63 k), but pinned to the local node it also did so twice on one box where the
+    # unpinned runs of the same minutes gave 60 k.  On a dedicated host bind.
+    numa_mode = os.environ.get("AOS2_BENCH_NUMA", "0")
+    affinity0 = os.sched_getaffinity(0)
+    numa_cpus = pkg.bind_to_device_node(local_rank) if numa_mode != "0" else 0
+    if numa_mode == "cores" and numa_cpus:   # one logical CPU per core: the lower half of the node's list
+        cl = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, cl[: len(cl) // 2])
+        numa_cpus = len(cl) // 2
     # the exchange step and the collectives run with more than one rank -- or with ONE rank when AOS2_BENCH_FORCE_DIST=1 (a test
     # hook: the RCCL code path -- process group on the device, gather of device slots on the step's stream, all-reduce, barrier
     # -- on a box with a single GPU; the line then still reports n_gpus = 1)
@@ -240,7 +250,6 @@ def main():
         else:
             dist.init_process_group(backend)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
-    pkg = g.load_package()
     if args.workload == "euroc8":
         run_euroc8(args, pkg, torch, dist, rank, world, local_rank, dev, cdev, backend, dist_on)
         if dist_on:
@@ -413,6 +422,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
+    if numa_mode == "setup":   # handles, page-locked buffers and threads were created on the node; the threads may roam again
+        for t_ in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(t_), affinity0)
+            except OSError:
+                pass
     import gc
     gc.collect()
     gc.disable()   # (a collection inside a short timed region is a multi-millisecond host pause)
@@ -843,6 +858,7 @@ def main():
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
                        "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "local_ba_window_groups_per_handle": LBA_GROUPS,
+                       "host_cpus_bound_to_the_gpus_numa_node": numa_cpus,
                        "frames_per_s_per_rank": [B * args.steps / d_ for d_ in dt_ranks],
                        "host_threads_per_rank": {"enqueue": 1, "local_ba_handles": NLBA, "local_ba_workers_per_handle": lba_threads,
                                                  "keyframe_legs": NPIPE, "host_cores": os.cpu_count()},

@@ -36,6 +36,12 @@ const char *aos2_last_error(void);
 /* number of HIP devices visible (0 when none; never fails) */
 int aos2_device_count(void);
 const char *aos2_version(void);
+/* The host CPUs local to the device (the NUMA node its PCIe root hangs off), as the kernel's list string ("0-63,128-191": sysfs
+ * local_cpulist of the device's PCI function); "" when the platform does not say.  For callers that place their threads: bench.py's
+ * composite ran at 51-52 k frames/s when pinned to the other socket's CPUs and at 59-63 k on the local ones (AOS2_BENCH_NUMA; on the
+ * shared hosts of the test pool the unpinned default was as good as the local node).  Returns AOS2_ERR_CAPACITY
+ * when `cap` is too small, AOS2_ERR_NO_DEVICE without that device.  No reference equivalent (the reference never leaves the CPU). */
+int aos2_device_local_cpus(int device, char *buf, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * ORBextractor  (include/ORBextractor.h:45-111, src/ORBextractor.cc)

@@ -85,7 +85,17 @@ def test_bad_arguments_and_missing_device(pkg):
     assert len(k) == 0 and d.shape == (0, 32)
     with pytest.raises(AssertionError):
         ex(np.zeros((480, 640), np.float32))
+    # aos2_device_local_cpus: argument checks need no device; without one the call says so and bind_to_device_node changes nothing
+    L = capi.lib()
+    L.aos2_device_local_cpus.argtypes = [capi.C.c_int, capi.C.c_char_p, capi.C.c_int]
+    assert L.aos2_device_local_cpus(0, None, 16) == capi.AOS2_ERR_ARG
     if pkg.device_count() == 0:
+        import os
+        before = os.sched_getaffinity(0)
+        with pytest.raises(capi.AosError) as e:
+            pkg.device_local_cpus(0)
+        assert e.value.code == capi.AOS2_ERR_NO_DEVICE
+        assert pkg.bind_to_device_node(0) == 0 and os.sched_getaffinity(0) == before
         with pytest.raises(capi.AosError) as e:
             ex(np.zeros((480, 640), np.uint8))
         assert e.value.code == capi.AOS2_ERR_NO_DEVICE  # loud failure, no CPU fallback

@@ -402,3 +402,23 @@ def test_first_large_batch_on_a_fresh_handle(pkg, oracle, gpu):
     nh, dh = n.cpu().numpy(), desc.cpu().numpy()
     bad = [b for b in range(B) if nh[b] != len(want[b % 8][0]) or not (dh[b, :nh[b]] == want[b % 8][1]).all()]
     assert bad == []
+
+
+def test_device_local_cpus_and_binding(pkg, gpu):
+    """aos2_device_local_cpus: the CPUs of the device's NUMA node (or the empty set when the platform does not say);
+    bind_to_device_node restricts the calling thread to them (intersected with what the process may use) -- and back"""
+    import os
+    before = os.sched_getaffinity(0)
+    cpus = pkg.device_local_cpus(0)
+    assert all(0 <= c < 4096 for c in cpus)
+    try:
+        n = pkg.bind_to_device_node(0)
+        now = os.sched_getaffinity(0)
+        if cpus & before:
+            assert n == len(cpus & before) and now == (cpus & before)
+        else:
+            assert n == 0 and now == before
+    finally:
+        os.sched_setaffinity(0, before)
+    with pytest.raises(pkg.AosError):
+        pkg.device_local_cpus(99)
