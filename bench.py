@@ -229,6 +229,7 @@ def main():
     # Default 0 (the scheduler decides): on the pool's SHARED hosts no mode was consistently better -- pinned to the OTHER socket the step ran at
     # 51-52 k frames/s four times out of four (against 59-63 k), but pinned to the local node it also did so twice on one box where the
     # unpinned runs of the same minutes gave 60 k.  On a dedicated host bind.
+    pkg = g.load_package()
     numa_mode = os.environ.get("AOS2_BENCH_NUMA", "0")
     affinity0 = os.sched_getaffinity(0)
     numa_cpus = pkg.bind_to_device_node(local_rank) if numa_mode != "0" else 0
@@ -319,10 +320,12 @@ def main():
     bow_jobs = [None] * NPIPE
 
     def keyframe_job(j):
+        t_ = time.perf_counter()
         if bows:
             bows[j].run()
         if kfws:
             kfws[j].run()
+        kf_walls.append(time.perf_counter() - t_)
     d_img, d_kps, d_desc, d_n = pipes[0].d_cur, pipes[0].d_kps, pipes[0].d_desc, pipes[0].d_n
     # ---- LocalBA windows of the step: one per frames_per_keyframe frames, every one a DIFFERENT problem drawn over the sizes
     # LocalMapping meets (synth.lba_window_mix: 10-40 local keyframes, 2-6 k points, 4-8 observations per point, 5-20 % gross
@@ -377,17 +380,34 @@ def main():
             else:   # gloo (tests): host tensors
                 gather["work"][j] = dist.gather(gather["slot"][j].cpu(), gather["bufs"][j], dst=0, async_op=True)
 
+    # where the host thread of the timed steps waits (seconds, summed per kind) and how long the LocalBA calls and keyframe jobs took: the
+    # diagnostics behind extra.timed_steps (a few perf_counter reads per step)
+    waits = {"local_ba": 0.0, "keyframe_legs": 0.0, "tracking": 0.0}
+    lba_walls, kf_walls, step_marks = [], [], []
+
+    def lba_call(jl):
+        t_ = time.perf_counter()
+        r_ = lbas[jl].solve_prepared(lba_prep[jl])
+        lba_walls.append(time.perf_counter() - t_)
+        return r_
+
     def step(s):
         # pipeline s % NPIPE: its previous step (s - NPIPE) is complete before its buffers are reused
         j = s % NPIPE
         p = pipes[j]
         jl = s % NLBA
+        t_a = time.perf_counter()
         if lba_jobs[jl] is not None:
             lba_jobs[jl].result()
+        t_b = time.perf_counter()
         if bow_jobs[j] is not None:
             bow_jobs[j].result()
             bow_jobs[j] = None
+        t_c = time.perf_counter()
         p.wait()
+        t_d = time.perf_counter()
+        waits["local_ba"] += t_b - t_a; waits["keyframe_legs"] += t_c - t_b; waits["tracking"] += t_d - t_c
+        step_marks.append(t_d)
         p.step()
         if bows:
             bows[j].order()   # the transform's stream waits for this step's extraction (device side)
@@ -396,7 +416,7 @@ def main():
         if gather is not None:
             gather_step(j)
         if not NO_LBA:
-            lba_jobs[jl] = pool.submit(lbas[jl].solve_prepared, lba_prep[jl])
+            lba_jobs[jl] = pool.submit(lba_call, jl)
 
     def sync():
         for jl in range(NLBA):
@@ -431,12 +451,21 @@ def main():
     import gc
     gc.collect()
     gc.disable()   # (a collection inside a short timed region is a multi-millisecond host pause)
+    for k_ in waits:
+        waits[k_] = 0.0
+    del lba_walls[:], kf_walls[:], step_marks[:]
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    mmm = lambda v: [round(float(x) * 1e3, 3) for x in (min(v), np.median(v), max(v))] if len(v) else None   # noqa: E731
+    timed_steps = {"host_thread_waits_ms_per_step": {k_: round(v_ * 1e3 / max(1, args.steps), 3) for k_, v_ in waits.items()},
+                   "step_to_step_ms_min_median_max": mmm(np.diff(step_marks)) if len(step_marks) > 2 else None,
+                   "local_ba_call_wall_ms_min_median_max": mmm(lba_walls), "keyframe_job_wall_ms_min_median_max": mmm(kf_walls),
+                   "note": "the enqueueing thread waits, per step, for the LocalBA call / keyframe job / tracking chain submitted NPIPE steps before; "
+                           "a step cannot be shorter than (LocalBA call wall) / (handles in flight)"}
     dt_ranks = [dt]
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -595,7 +624,7 @@ def main():
         assert gather_ok, "gathered slot headers corrupt"
 
     # secondary measurements of the other hot-path rows (reported, not part of `value`)
-    extra = {"local_ba_lock_step": lock_step,
+    extra = {"local_ba_lock_step": lock_step, "timed_steps": timed_steps,
              "composite_with_homogeneous_local_ba_windows": None if dt_hom is None else {
                  "note": "the timed steps with round 3's LocalBA batch instead: %d windows of the SURVEY 8(d) size (%d keyframes, %d points, "
                          "%d edges), 4 distinct problems tiled" % (n_win, lba_hom[0]["n_poses"], lba_hom[0]["n_points"], lba_hom[0]["n_edges"]),
