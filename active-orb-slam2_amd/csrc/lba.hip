@@ -106,6 +106,7 @@ struct LbaWin {
     // keyframe's rotation at the linearisation point, Rl) and is applied in that form.  w < 0 marks a stereo edge (|w| is
     // the weight); a masked edge holds zeros: every product it takes part in is +-0.
     double *lrec;
+    double *lomr;                    // 3 per free-keyframe edge (position like lrec): omr = -rho' Omega e of the linearisation (k_schur forms b_p from it)
     double *Rl;                      // 9 per free keyframe (hidx): rotation the system was linearised at (k_lin)
     double *Hpp, *Hll, *b, *x, *Hs, *bs;
     double *tmp;                     // scale terms of the poses (6 np)
@@ -487,16 +488,20 @@ __device__ __forceinline__ void jac_point(const Cam &cam, const double R[9], con
 // so the edge's Hpl block is  J_pose^T w J_point = -E^T C R,  C = w iz Pt^T Pt  (symmetric 3 x 3, C01 = 0): six numbers
 // formed from the record in ~20 operations, and the products with E are cross products with (a, b, 1).
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void lrec_store(const LbaWin &W, int pos, const double p[3], double wo, int stereo)
+__device__ __forceinline__ void lrec_store(const LbaWin &W, int pos, const double p[3], double wo, int stereo, const double omr[3])
 {
     const double iz = 1.0 / p[2];
     const dbl4_t v = {p[0] * iz, p[1] * iz, iz, stereo ? -wo : wo};
     *reinterpret_cast<dbl4_t *>(W.lrec + 4 * (size_t)pos) = v;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) W.lomr[3 * (size_t)pos + i] = omr[i];
 }
 __device__ __forceinline__ void lrec_mask(const LbaWin &W, int pos)
 {
     const dbl4_t v = {0.0, 0.0, 0.0, 0.0};
     *reinterpret_cast<dbl4_t *>(W.lrec + 4 * (size_t)pos) = v;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) W.lomr[3 * (size_t)pos + i] = 0.0;
 }
 __device__ __forceinline__ dbl4_t lrec_load(const LbaWin &W, int pos) { return *reinterpret_cast<const dbl4_t *>(W.lrec + 4 * (size_t)pos); }
 struct EdgeLin {
@@ -525,6 +530,21 @@ __device__ __forceinline__ void lrec_C(const EdgeLin &L, const double t[3], doub
     h[0] = L.C00 * t[0] + L.C02 * t[2];
     h[1] = L.C11 * t[1] + L.C12 * t[2];
     h[2] = L.C02 * t[0] + L.C12 * t[1] + L.C22 * t[2];
+}
+// J_pose^T omr = E^T (Pt^T omr) of a free-keyframe edge: its share of b_p (constructQuadraticForm, base_binary_edge.hpp:95-110), from the record
+// and the omr the landmark side left (lomr): E^T g = (-(a, b, 1) x g, -iz g)
+__device__ __forceinline__ void lrec_bp(const Cam &cam, const dbl4_t rec, const double o[3], double (&acc)[6])
+{
+    const double a = rec.x, b = rec.y, iz = rec.z;
+    const bool stereo = rec.w < 0.0;
+    const double fs = stereo ? cam.fx : 0.0, c = stereo ? cam.bf * iz - a * cam.fx : 0.0;
+    const double g0 = cam.fx * o[0] + fs * o[2], g1 = cam.fy * o[1], g2 = c * o[2] - a * cam.fx * o[0] - b * cam.fy * o[1];
+    acc[0] += g1 - b * g2;
+    acc[1] += a * g2 - g0;
+    acc[2] += b * g0 - a * g1;
+    acc[3] += -(iz * g0);
+    acc[4] += -(iz * g1);
+    acc[5] += -(iz * g2);
 }
 // B^T xp of a free-keyframe edge (block_solver.hpp:455-480 multiplies by the stored Hpl block B):
 // B^T xp = -R^T C E xp,  E xp = (a, b, 1) x omega - iz upsilon  for xp = (omega, upsilon)
@@ -848,7 +868,7 @@ __device__ __forceinline__ void lin_points_body(const LbaWin &W, int blk)
                 for (int c = 0; c < 3; ++c) cH[r * 3 + c] = Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
             }
             const int pp = W.pl_pos[k];
-            if (pp >= 0) lrec_store(W, pp, p, wo, stereo);
+            if (pp >= 0) lrec_store(W, pp, p, wo, stereo, omr);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) s_c[ll][j][i] = cH[i];
@@ -922,7 +942,7 @@ __device__ __forceinline__ void lin_points_walk(const LbaWin &W, int l)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) H[r * 3 + c] += Ja[r] * wo * Ja[c] + Ja[3 + r] * wo * Ja[3 + c] + Ja[6 + r] * wo * Ja[6 + c];
             }
-            if (ph[u] >= 0) lrec_store(W, ph[u], p, wo, stereo);
+            if (ph[u] >= 0) lrec_store(W, ph[u], p, wo, stereo, omr);
         }
     }
     for (int i = 0; i < 9; ++i) W.Hll[9 * (size_t)l + i] = H[i];
@@ -977,7 +997,7 @@ __device__ __forceinline__ double workgroup_sum_k256(double (&acc)[K], double *r
 // thread j takes the pose's edges j, j + 256, ... (the Jacobian is recomputed from the estimates: no per-edge arrays;
 // few edges per thread keep the chain of dependent gathers short), then workgroup_sum_k256 (fixed order).
 // (The former 256 x 43 tree in LDS held 88 KB per pose -- one workgroup per compute unit.)
-__device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
+__device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph, int init)
 {
     __shared__ double red[16 * 43];
     if (ph >= W.np) return;
@@ -993,6 +1013,9 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph)
 #pragma unroll
         for (int i = 0; i < 9; ++i) W.Rl[9 * (size_t)ph + i] = R[i];
     }
+    // Hpp and b_p themselves are formed by k_schur's diagonal units from the landmark side's records (schur_item<true>, lrec_bp); only the
+    // first linearisation of an optimisation needs them here: k_lm_init takes lambda from the diagonal of Hpp before any Schur launch
+    if (!init) return;
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; ++i) acc[i] = 0;
@@ -1039,7 +1062,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (!keyframe) return;
 #endif
     if (keyframe)
-        lin_poses_body(W, blk);
+        lin_poses_body(W, blk, init);
     else if (kWalk)
         lin_points_walk(W, blk * 256 + threadIdx.x);
     else
@@ -1187,6 +1210,16 @@ __device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda
             Q[r * 3 + 2] = sf(CG[r * 3 + 2], Lb.C22, sf(CG[r * 3 + 1], Lb.C12, CG[r * 3] * Lb.C02));
         }
     }
+    if (kDiag) {   // the edge's own Hpp term J_pose^T w J_pose = E^T (w Pt^T Pt) E = E^T (C / iz) E enters with the other sign: the
+                   // diagonal block is Hpp - sum B D^-1 B^T = -sum E^T (Q - w Pt^T Pt) E, so the keyframe side of the linearisation
+                   // (a second pass over every free-keyframe edge: map, Jacobian, 126 products) is not needed after the first one
+        const double w = fabs(ra.w), fx2 = W.cam.fx * W.cam.fx, fy2 = W.cam.fy * W.cam.fy;
+        const bool st = ra.w < 0.0;
+        const double fs = st ? W.cam.fx : 0.0, c = st ? W.cam.bf * La.iz - La.a * W.cam.fx : 0.0;
+        const double P00 = (fx2 + fs * fs) * w, P02 = (fs * c - La.a * fx2) * w, P11 = fy2 * w, P12 = -(La.b * fy2) * w;
+        const double P22 = (La.a * La.a * fx2 + La.b * La.b * fy2 + c * c) * w;
+        Q[0] -= P00; Q[2] -= P02; Q[4] -= P11; Q[5] -= P12; Q[6] -= P02; Q[7] -= P12; Q[8] -= P22;
+    }
     // U = Q E_b (3 x 6), then E_a^T U: rows 0-2 = [a b 1]x^T U, rows 3-5 = -iz_a U
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -1212,14 +1245,11 @@ __device__ __forceinline__ void schur_store(const LbaWin &W, int i1, int i2, int
     if (e < 36) {
         double v = -sum;
         const int r = e / 6, c = e - 6 * r;
-        if (diag) {
-            v += W.Hpp[36 * (size_t)i1 + e];
-            if (r == c) v += lambda;
-        }
+        if (diag && r == c) v += lambda;   // (Hpp is inside the diagonal unit's sum: schur_item<true>)
         W.Hs[(size_t)(6 * i1 + r) * W.hs_ld + 6 * i2 + c] = v;
         if (!diag) W.Hs[(size_t)(6 * i2 + c) * W.hs_ld + 6 * i1 + r] = v;
-    } else if (e < 42 && diag)
-        W.bs[6 * i1 + (e - 36)] = W.b[6 * i1 + (e - 36)] - sum;
+    }
+    // (bschur of a diagonal unit: k_schur, after its b_p pass)
 }
 
 #ifndef AOS2_SCHUR_WPE
@@ -1297,6 +1327,24 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
         for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, W.Rl + 9 * (size_t)i1, W.Rl + 9 * (size_t)i2, acc);
     const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
     schur_store(W, i1, i2, tid, sum, lambda);
+    if (kind == kSchurDiag) {
+        // b_p of the keyframe = sum of J_pose^T omr over its edges, from record + omr (lrec_bp); bschur = b_p - sum B D^-1 b_l
+        __shared__ double s_bsum[6];
+        __syncthreads();   // (red is reused)
+        if (tid >= 36 && tid < 42) s_bsum[tid - 36] = sum;
+        double accb[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = tid; j < n; j += NT) {
+            const int kb = W.it_kb[o0 + j];
+            const dbl4_t rec = lrec_load(W, kb);
+            const double o[3] = {W.lomr[3 * (size_t)kb], W.lomr[3 * (size_t)kb + 1], W.lomr[3 * (size_t)kb + 2]};
+            lrec_bp(W.cam, rec, o, accb);
+        }
+        const double sb = workgroup_sum_k256<6, NT>(accb, red, n);
+        if (tid < 6) {
+            W.b[6 * i1 + tid] = sb;
+            W.bs[6 * i1 + tid] = sb - s_bsum[tid];
+        }
+    }
 }
 
 // Dense LDL^T (no pivoting; fails on a zero pivot like Eigen::SimplicialLDLT) + solve of the reduced
@@ -2158,7 +2206,7 @@ struct WinLayout {
     size_t in_Tcw, in_xyz, in_obs, in_w, e_pose, e_point, e_stereo, pl_pos, hpose, hpoint, pt_off, pt_k, ps_off, ps_k,
         pl_off, pl_k, it_ka, it_kb, it_l, blk_off, sr_o0, sr_info, sr_ij;
     // device only
-    size_t est, bk, robust, level1, err, lrec, Rl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
+    size_t est, bk, robust, level1, err, lrec, lomr, Rl, Hpp, Hll, b, x, Hs, bs, tmp, scal, part, ldlt;
     // results (downloaded)
     size_t out_Tcw, out_xyz, out_outlier, out_chi2, st;
     int n_part, npad, ldlt_lds;
@@ -2555,7 +2603,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         l.est = B.take(8 * (7 * NP + 3 * NL)); l.bk = B.take(8 * (7 * NP + 3 * NL));
         l.robust = B.take(E); l.level1 = B.take(E);
         l.err = B.take(24 * E);
-        l.lrec = B.take(32 * (S.pl_k.size() + 1)); l.Rl = B.take(72 * (size_t)S.np + 8);
+        l.lrec = B.take(32 * (S.pl_k.size() + 1)); l.lomr = B.take(24 * (S.pl_k.size() + 1)); l.Rl = B.take(72 * (size_t)S.np + 8);
         l.Hpp = B.take(288 * (size_t)S.np + 8); l.Hll = B.take(72 * (size_t)S.nl + 8);
         l.b = B.take(8 * dim + 8); l.x = B.take(8 * dim + 8);
         l.npad = (int)((n6 + 15) & ~(size_t)15);
@@ -2663,7 +2711,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.it_l = (const int32_t *)(base + l.it_l); W.blk_off = (const int32_t *)(base + l.blk_off);
         W.sr_o0 = (const int32_t *)(base + l.sr_o0); W.sr_info = (const int32_t *)(base + l.sr_info); W.sr_ij = (const int32_t *)(base + l.sr_ij);
         W.n_srows = (int)S.sr_o0.size();
-        W.lrec = (double *)(base + l.lrec); W.Rl = (double *)(base + l.Rl); W.Hpp = (double *)(base + l.Hpp);
+        W.lrec = (double *)(base + l.lrec); W.lomr = (double *)(base + l.lomr); W.Rl = (double *)(base + l.Rl); W.Hpp = (double *)(base + l.Hpp);
         W.Hll = (double *)(base + l.Hll); W.b = (double *)(base + l.b); W.x = (double *)(base + l.x);
         W.Hs = (double *)(base + l.Hs); W.bs = (double *)(base + l.bs);
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
