@@ -1,8 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_lba_gpu.py -m gpu -x -q 2>&1 | tail -5
-for g in "" 1; do
-  for cfg in "het 64" "hom 64" "hom 32"; do
-    set -- $cfg
-    echo "AOS2_LBA_GROUPS=${g:-default} $(env ${g:+AOS2_LBA_GROUPS=$g} LBA_MIX=$1 LBA_N=$2 python tools/gpu_lba_mix_prof.py 2>&1 | grep windows | tail -1)"
-  done
-done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/fuzz_r04; mkdir -p $O
+python tools/gpu_lba_determinism.py 3000 2>&1 | tail -4 > $O/lba_determinism.txt; cat $O/lba_determinism.txt
+FUZZ_S=150
+python tools/gpu_fuzz_rest.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/rest.txt
+python tools/gpu_fuzz_keyframes.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/keyframes.txt
+python tools/gpu_fuzz_extractor.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/extractor.txt
+python tools/gpu_fuzz_matcher.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/matcher.txt
+python tools/gpu_fuzz_more.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/more.txt
+tail -n 3 $O/*.txt
