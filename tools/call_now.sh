@@ -1,10 +1,6 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/fuzz_r04; mkdir -p $O
-python tools/gpu_lba_determinism.py 3000 2>&1 | tail -4 > $O/lba_determinism.txt; cat $O/lba_determinism.txt
-FUZZ_S=150
-python tools/gpu_fuzz_rest.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/rest.txt
-python tools/gpu_fuzz_keyframes.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/keyframes.txt
-python tools/gpu_fuzz_extractor.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/extractor.txt
-python tools/gpu_fuzz_matcher.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/matcher.txt
-python tools/gpu_fuzz_more.py 100000 $FUZZ_S 2>&1 | tail -3 > $O/more.txt
-tail -n 3 $O/*.txt
+run() {
+  for cfg in "het 64" "hom 64" "hom 32"; do set -- $cfg; echo "$V G=${G:-default} $(env ${G:+AOS2_LBA_GROUPS=$G} LBA_MIX=$1 LBA_N=$2 python tools/gpu_lba_mix_prof.py 2>&1 | grep windows | tail -1)"; done
+}
+V=base; G=; run; G=1; run
+for v in wpe2 fma; do export AOS2_LIB=$GRAFT_REPO_ROOT/active-orb-slam2_amd/lib/libaos2_$v.so; V=$v; G=; run; G=1; run; done
