@@ -48,6 +48,8 @@ def test_bench_contract_single_gpu(gpu):
     ls = d["extra"]["local_ba_lock_step"]
     assert ls["trial_slots_enqueued_per_window"] >= 17 and ls["slots_over_trials"] >= 1.0 and d["config"]["local_ba_mix"] == "heterogeneous"
     assert len(d["config"]["frames_per_s_per_rank"]) == 1 and d["config"]["host_threads_per_rank"]["local_ba_workers_per_handle"] >= 1
+    ts = d["extra"]["timed_steps"]   # where the enqueueing thread waited during the timed steps, how long the LocalBA calls took
+    assert set(ts["host_thread_waits_ms_per_step"]) == {"local_ba", "keyframe_legs", "tracking"} and ts["local_ba_call_wall_ms_min_median_max"][1] > 0
     # host placement is left to the scheduler by default (AOS2_BENCH_NUMA=1 binds to the GPU's NUMA node), one LocalBA program per handle
     assert d["config"]["host_cpus_bound_to_the_gpus_numa_node"] == 0 and d["config"]["local_ba_window_groups_per_handle"] == 1
     # ... and the keyframe legs: the BoW searches and LocalMapping's (keyframe, neighbour) searches
