@@ -1229,12 +1229,20 @@ __device__ __forceinline__ void schur_item(const LbaWin &W, int j, double lambda
             const double q0 = Q[r * 3], q1 = Q[r * 3 + 1], q2 = Q[r * 3 + 2];
             u[r] = c == 0 ? q1 - Lb.b * q2 : c == 1 ? Lb.a * q2 - q0 : c == 2 ? Lb.b * q0 - Lb.a * q1 : -(Lb.iz * Q[r * 3 + (c - 3)]);
         }
+        // (a diagonal block is symmetric -- E^T (Q - w Pt^T Pt) E with a symmetric middle --: its unit forms the upper triangle only and
+        // stores both; the six slots that frees, (1,0) (2,0) (2,1) (3,0) (3,1) (3,2), carry b_p below)
         acc[c] += u[1] - La.b * u[2];
-        acc[6 + c] += La.a * u[2] - u[0];
-        acc[12 + c] += La.b * u[0] - La.a * u[1];
-        acc[18 + c] += -(La.iz * u[0]);
-        acc[24 + c] += -(La.iz * u[1]);
-        acc[30 + c] += -(La.iz * u[2]);
+        if (!kDiag || c >= 1) acc[6 + c] += La.a * u[2] - u[0];
+        if (!kDiag || c >= 2) acc[12 + c] += La.b * u[0] - La.a * u[1];
+        if (!kDiag || c >= 3) acc[18 + c] += -(La.iz * u[0]);
+        if (!kDiag || c >= 4) acc[24 + c] += -(La.iz * u[1]);
+        if (!kDiag || c >= 5) acc[30 + c] += -(La.iz * u[2]);
+    }
+    if (kDiag) {   // b_p += J_pose^T omr = E^T (Pt^T omr) (lrec_bp), omr as the landmark side left it
+        const double o[3] = {W.lomr[3 * (size_t)kb], W.lomr[3 * (size_t)kb + 1], W.lomr[3 * (size_t)kb + 2]};
+        double bp[6] = {0, 0, 0, 0, 0, 0};
+        lrec_bp(W.cam, ra, o, bp);
+        acc[6] += bp[0]; acc[12] += bp[1]; acc[13] += bp[2]; acc[18] += bp[3]; acc[19] += bp[4]; acc[20] += bp[5];
     }
 }
 
@@ -1326,23 +1334,27 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
     else
         for (int j = tid; j < n; j += NT) schur_item<false>(W, o0 + j, lambda, n6, W.Rl + 9 * (size_t)i1, W.Rl + 9 * (size_t)i2, acc);
     const double sum = workgroup_sum_k256<42, NT>(acc, red, n);
-    schur_store(W, i1, i2, tid, sum, lambda);
-    if (kind == kSchurDiag) {
-        // b_p of the keyframe = sum of J_pose^T omr over its edges, from record + omr (lrec_bp); bschur = b_p - sum B D^-1 b_l
-        __shared__ double s_bsum[6];
-        __syncthreads();   // (red is reused)
-        if (tid >= 36 && tid < 42) s_bsum[tid - 36] = sum;
-        double accb[6] = {0, 0, 0, 0, 0, 0};
-        for (int j = tid; j < n; j += NT) {
-            const int kb = W.it_kb[o0 + j];
-            const dbl4_t rec = lrec_load(W, kb);
-            const double o[3] = {W.lomr[3 * (size_t)kb], W.lomr[3 * (size_t)kb + 1], W.lomr[3 * (size_t)kb + 2]};
-            lrec_bp(W.cam, rec, o, accb);
-        }
-        const double sb = workgroup_sum_k256<6, NT>(accb, red, n);
-        if (tid < 6) {
-            W.b[6 * i1 + tid] = sb;
-            W.bs[6 * i1 + tid] = sb - s_bsum[tid];
+    if (kind != kSchurDiag) {
+        schur_store(W, i1, i2, tid, sum, lambda);
+        return;
+    }
+    // diagonal unit: Hschur_ii = lambda I - (upper-triangle sums, mirrored); b_p from its six slots; bschur = b_p - sum B D^-1 b_l
+    __shared__ double s_bsum[6];
+    if (tid >= 36 && tid < 42) s_bsum[tid - 36] = sum;
+    __syncthreads();
+    if (tid < 36) {
+        const int r = tid / 6, c = tid - 6 * r;
+        if (r <= c) {
+            double v = -sum;
+            if (r == c) v += lambda;
+            W.Hs[(size_t)(6 * i1 + r) * W.hs_ld + 6 * i1 + c] = v;
+            if (r != c) W.Hs[(size_t)(6 * i1 + c) * W.hs_ld + 6 * i1 + r] = v;
+        } else {
+            const int j = tid == 6 ? 0 : tid == 12 ? 1 : tid == 13 ? 2 : tid == 18 ? 3 : tid == 19 ? 4 : tid == 20 ? 5 : -1;
+            if (j >= 0) {
+                W.b[6 * i1 + j] = sum;
+                W.bs[6 * i1 + j] = sum - s_bsum[j];
+            }
         }
     }
 }
