@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_lba_gpu.py -m gpu -x -q 2>&1 | tail -4
-for g in "" 1; do
-  for cfg in "het 64" "hom 64" "hom 32"; do
-    set -- $cfg
-    echo "AOS2_LBA_GROUPS=${g:-default} $(env ${g:+AOS2_LBA_GROUPS=$g} LBA_MIX=$1 LBA_N=$2 python tools/gpu_lba_mix_prof.py 2>&1 | grep windows | tail -1)"
-  done
-done
+mkdir -p gpurun_out/c20
+for i in 2 3; do python bench.py > gpurun_out/c20/bench_$i.json 2> gpurun_out/c20/err_$i; python -c "
+import json; d=json.loads(open('gpurun_out/c20/bench_$i.json').read().strip().splitlines()[-1]); print(round(d['value']), round(d['ms_per_step'],3), d['parity_checked']['ok'], d['extra']['timed_steps']['host_thread_waits_ms_per_step'])"; done
