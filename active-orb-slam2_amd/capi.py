@@ -1149,6 +1149,11 @@ class Frames:
     def SearchLocalPoints(self, table, d_local, n_local, th, nnratio, d_nmatches=0):
         _check(self.L.aos2_frames_search_local_points(self.h, C.byref(table), d_local, n_local, th, nnratio, d_nmatches or None))
 
+    def set_async_keyframe_calls(self, on=True):
+        """SearchForTriangulation / Fuse of this handle return after enqueueing (include/aos2.h); wait() completes them"""
+        self.L.aos2_frames_set_async_keyframe_calls.argtypes = [C.c_void_p, C.c_int]
+        _check(self.L.aos2_frames_set_async_keyframe_calls(self.h, 1 if on else 0))
+
     def wait(self):
         _check(self.L.aos2_frames_wait(self.h))
 

@@ -266,7 +266,8 @@ class KeyFrameWork:
     results come back for the host-side map bookkeeping."""
 
     def __init__(self, tc: TrackingChain, voc: dict, n_kf: int, n_nb: int = 20, levelsup: int = 4, fuse_th: float = 3.0,
-                 only_stereo: bool = False, check_orientation: bool = False, epipole=None, nb_cap: int | None = None, n_second: int = 0):
+                 only_stereo: bool = False, check_orientation: bool = False, epipole=None, nb_cap: int | None = None, n_second: int = 0,
+                 async_calls: bool = True):
         t, scen = tc.torch, tc.scen
         # n_nb first-order neighbours (CreateNewMapPoints triangulates against them, SearchInNeighbors fuses into them) and, per
         # first-order neighbour, n_second second-order ones that are fuse targets only (src/LocalMapping.cc:475-485: up to 5 each,
@@ -352,10 +353,18 @@ class KeyFrameWork:
         self.h_out = [t.empty((PT, cap1), dtype=t.int32).pin_memory()] + [t.empty((P, cap1), dtype=t.int32).pin_memory() for _ in range(2)] + \
                      [t.empty((PT,), dtype=t.int32).pin_memory()]
         self.copy_stream = t.cuda.Stream(device=tc.dev)
+        # the three calls of a keyframe are enqueued back to back and waited for ONCE (aos2_frames_set_async_keyframe_calls): on a device that
+        # is busy with the tracking kernels every host round trip of the job costs a scheduling delay
+        self.async_calls = async_calls
+        tc.last.set_async_keyframe_calls(async_calls)
+        self.kfs.set_async_keyframe_calls(async_calls)
+        if async_calls:
+            self._ext = [t.cuda.ExternalStream(tc.last.stream(), device=tc.dev), t.cuda.ExternalStream(self.kfs.stream(), device=tc.dev)]
         t.cuda.synchronize()
         self.last_ms = (0.0, 0.0)
 
-    def run(self):
+    def run(self, timed: bool = False):
+        """timed: every call waited for (last_ms = the calls' own times; bench.py's synchronous stage pass)"""
         import time
         tc = self.tc
         t0 = time.perf_counter()
@@ -363,12 +372,21 @@ class KeyFrameWork:
                                        [self.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [self.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
                                        self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=self.only_stereo,
                                        check_orientation=self.check_orientation)
+        if timed and self.async_calls:
+            tc.last.wait()
         t1 = time.perf_counter()
         self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
         tc.last.Fuse(tc.table, self.rev_target, self.d_rev_rows.data_ptr(), self.rev_rows.shape[1], self.fuse_th, self.d_rev_idx.data_ptr(),
                      self.d_rev_dist.data_ptr())
+        if timed and self.async_calls:
+            self.kfs.wait()
+            tc.last.wait()
         t2 = time.perf_counter()
-        # (the calls return with their results complete; the copies run on a stream of this object)
+        # (synchronous calls return with their results complete; asynchronous ones are ordered before the copies on the device;
+        # the copies run on a stream of this object)
+        if self.async_calls:
+            for e_ in self._ext:
+                self.copy_stream.wait_event(e_.record_event())
         with tc.torch.cuda.stream(self.copy_stream):
             for h, d in zip(self.h_out + self.h_rev, (self.d_match12, self.d_best_idx, self.d_best_dist, self.d_nm, self.d_rev_idx, self.d_rev_dist)):
                 h.copy_(d, non_blocking=True)

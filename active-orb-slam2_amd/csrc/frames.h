@@ -93,6 +93,10 @@ struct aos2_frames {
     aos2::PinnedBuf<uint8_t> h_io;   // small page-locked staging (poses, counts)
     aos2::PinnedBuf<uint8_t> kf_host;   // keyframe work (triangulation pairs, fuse targets): staging ...
     aos2::DevBuf<uint8_t> kf_dev;       // ... and its device copy
+    aos2::PinnedBuf<uint8_t> kf_host2;  // the same for aos2_frames_fuse (SearchForTriangulation and Fuse of one handle may both be in flight)
+    aos2::DevBuf<uint8_t> kf_dev2;
+    bool kf_async = false;              // aos2_frames_set_async_keyframe_calls: the keyframe entry points return after enqueueing
+    hipEvent_t kf_ev_tri = nullptr, kf_ev_fuse = nullptr;   // behind the upload of the staging buffer of the last call of each kind
     float dist[5] = {0, 0, 0, 0, 0};   // mDistCoef for the next aos2_frames_build (aos2_frames_set_distortion)
     float last_ms[4] = {};
 };

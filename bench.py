@@ -570,7 +570,7 @@ def main():
         composite_stage["reference_keyframe_bow_wall"] = timed(_bow)
         composite_stage["reference_keyframe_bow_device"] = {"transform": bows[0].last_ms[0], "search_by_bow": bows[0].last_ms[1], "frames": n_bow}
     if kfws:
-        composite_stage["keyframe_work_wall"] = timed(kfws[0].run)
+        composite_stage["keyframe_work_wall"] = timed(lambda: kfws[0].run(timed=True))
         composite_stage["keyframe_work_calls"] = {"search_for_triangulation": kfws[0].last_ms[0], "fuse": kfws[0].last_ms[1],
                                                   "fuse_pairs": len(kfws[0].kf1), "triangulation_pairs": len(kfws[0].tri_pairs), "keyframes": n_bow,
                                                   "neighbours": N_NB, "second_order_fuse_targets_per_neighbour": N_SECOND}

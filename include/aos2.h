@@ -825,6 +825,12 @@ int aos2_frames_search_for_triangulation(aos2_frames_t *a, aos2_frames_t *b, con
 int aos2_frames_fuse(aos2_frames_t *kfs, const aos2_map_points_dev_t *mps, int n_problems, int n_pts,
                      const int32_t *target, const int32_t *d_rows, float th, int32_t *d_best_idx,
                      int32_t *d_best_dist);
+/* on != 0: aos2_frames_search_for_triangulation (handle = its `a`) and aos2_frames_fuse (handle = `kfs`) return after ENQUEUEING on the
+ * handle's stream -- LocalMapping's three calls for a keyframe then cost one wait instead of three round trips through a device that
+ * is busy with the tracking kernels; aos2_frames_wait(handle) (or ordering another stream behind aos2_frames_stream(handle))
+ * completes them.  The host arrays of a call (kf1, kf2, F12, epipole, target) are copied before it returns.  Default off: the calls
+ * return with their results complete. */
+int aos2_frames_set_async_keyframe_calls(aos2_frames_t *f, int on);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset helper (host code; the reference reads its datasets with cv::imread, Examples/RGB-D/rgbd_tum.cc:77-78): the PNG

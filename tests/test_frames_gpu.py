@@ -327,7 +327,8 @@ def test_keyframe_work_vs_oracle(pkg, oracle, gpu):
     assert ((kw.best_idx >= 0).sum(1) > 50).all()
     # with second-order neighbours (SearchInNeighbors, src/LocalMapping.cc:475-485): Fuse targets only -- 3 first-order neighbours are
     # triangulated against, 3 + 3 x 2 = 9 keyframes per keyframe are fused into
-    kw2 = pkg.chain.KeyFrameWork(tc, voc, n_kf=4, n_nb=3, n_second=2)
+    # (and with the calls returning complete, the default of the C ABI: kw above enqueues its three calls and waits once)
+    kw2 = pkg.chain.KeyFrameWork(tc, voc, n_kf=4, n_nb=3, n_second=2, async_calls=False)
     assert len(kw2.kf1) == 4 * 9 and len(kw2.tri_pairs) == 4 * 3 and (kw2.tri_of >= 0).sum() == 12
     kw2.run()
     co2 = parity.ChainOracle(scen, tc)   # (its cache of the neighbours' oracle extraction is keyed by neighbour index)
