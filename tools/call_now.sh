@@ -1,9 +1,7 @@
+# scratch: the command of the last gpurun call of the round (gpu suite + smoke + three default bench lines at the final commit)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c21
-timeout 900 python -m pytest tests/test_frames_gpu.py tests/test_fuzz_gpu.py -m gpu -x -q 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_bench_gpu.py -m gpu -x -q -k "contract or two_ranks" 2>&1 | tail -3
-for i in 1 2 3 4 5 6; do
-  python bench.py --no-extra --no-cpu-baseline --no-verify 2> gpurun_out/c21/err | tail -1 > gpurun_out/c21/r_$i.json
-  python -c "
-import json; d=json.loads(open('gpurun_out/c21/r_$i.json').read()); t=d['extra']['timed_steps']; print('value %.0f ms_per_step %.3f' % (d['value'], d['ms_per_step']), t['host_thread_waits_ms_per_step'], 'kf', t['keyframe_job_wall_ms_min_median_max'])" || tail -3 gpurun_out/c21/err
-done
+mkdir -p gpurun_out/final
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/final/pytest_gpu.log 2>&1; tail -2 gpurun_out/final/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for i in 1 2 3; do python bench.py > gpurun_out/final/bench_$i.json 2> gpurun_out/final/err_$i; python -c "
+import json; d=json.loads(open('gpurun_out/final/bench_$i.json').read().strip().splitlines()[-1]); print(round(d['value']), round(d['ms_per_step'],3), d['parity_checked']['ok'], d['extra']['timed_steps']['host_thread_waits_ms_per_step'])"; done
