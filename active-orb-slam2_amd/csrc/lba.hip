@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "lba_math.h"
+#include "ldlt_reg.h"
 
 namespace aos2 {
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
         W.e_robust[i] = 1;
         W.e_level1[i] = 0;
     }
-    if (blockIdx.x == 0 && !W.ldlt_lds) {   // reduced system factorised in place: the identity tail of the padded matrix, once
+    if (blockIdx.x == 0 && W.hs_ld == W.npad) {   // reduced system stored padded (k_ldlt_reg, k_ldlt_dev): the identity tail of the matrix, once
         const int n = 6 * W.np, npad = W.npad;
         for (int q = threadIdx.x; q < (npad - n) * npad; q += 256) {
             const int r = n + q / npad, c = q % npad;
@@ -1371,15 +1372,6 @@ void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ task
 // poses).  Otherwise (any size): in a global scratch, 16 waves, the vector in LDS, k_update_poses follows.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// value of `v` in lane `src` (wave-uniform index), uniform result
-__device__ __forceinline__ double readlane_f64(double v, int src)
-{
-    const long long bits = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
-    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // ---- LDS variant (npad <= 128): 8 waves, per 16-column panel k
 //   D_k  the 16x16 diagonal block by wave 0: unblocked LDL^T with row i of the block in the registers of lane i (pivot
 //        and column entries travel through v_readlane; no predication: the upper halves of the rows are scratch), the
@@ -1807,7 +1799,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
-    if (!Wn.st->run || Wn.np == 0 || !Wn.ldlt_lds) return;
+    if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 1) return;
     ldlt_body<false>(Wn, sm);
 }
 // (a kernel of its own: both forms in one kernel cost the LDS form 25 spilled registers)
@@ -1815,8 +1807,47 @@ __global__ __launch_bounds__(512) void k_ldlt_dev(const LbaWin *__restrict__ win
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
-    if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds) return;
+    if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 0) return;
     ldlt_body<true>(Wn, sm);
+}
+
+// The form every window of <= 40 free keyframes takes (ldlt_reg.h): the trailing matrix as MFMA accumulator tiles in the registers of
+// seven waves, the diagonal tiles / panel / T_k / vectors in LDS, no device-memory traffic between the load and the solution; the
+// epilogue is ldlt_body's (solution, pose update with the push() backup, the poses' scale terms).
+__global__ __launch_bounds__(kLrThreads) void k_ldlt_reg(const LbaWin *__restrict__ wins)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const LbaWin &Wn = wins[blockIdx.x];
+    if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 2) return;
+    const int tid = threadIdx.x, n = 6 * Wn.np;
+    const double lambda = Wn.st->lambda;
+    double *xs = nullptr;
+#ifdef AOS2_LDLT_TIMING
+    const bool ok = ldlt_reg_solve<true>(Wn.Hs, Wn.hs_ld, n, Wn.npad, Wn.bs, sm, xs, Wn.st->dbg);
+#else
+    const bool ok = ldlt_reg_solve<false>(Wn.Hs, Wn.hs_ld, n, Wn.npad, Wn.bs, sm, xs, nullptr);
+#endif
+    if (!ok) {
+        if (tid == 0) Wn.scal[3] = 0.0;
+        if (tid < Wn.np) {   // the trial is rejected (lm_decide): its pop() must find the estimates it started from
+            const double *Tp = Wn.pose + 7 * (size_t)Wn.hpose[tid];
+            double *Tbk = Wn.bk + 7 * (size_t)Wn.hpose[tid];
+            for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];
+        }
+        return;
+    }
+    for (int i = tid; i < n; i += kLrThreads) Wn.x[i] = xs[i];
+    if (tid == 0) Wn.scal[3] = 1.0;
+    if (tid < Wn.np) {   // VertexSE3Expmap::oplusImpl + the poses' scale terms
+        double upd[6];
+        for (int i = 0; i < 6; ++i) {
+            upd[i] = xs[6 * tid + i];
+            Wn.tmp[6 * tid + i] = upd[i] * (lambda * upd[i] + Wn.b[6 * tid + i]);
+        }
+        double *Tp = Wn.pose + 7 * (size_t)Wn.hpose[tid], *Tbk = Wn.bk + 7 * (size_t)Wn.hpose[tid];
+        for (int i = 0; i < 7; ++i) Tbk[i] = Tp[i];   // push()
+        se3_oplus_fast(upd, Tp);
+    }
 }
 
 // Between the two optimisations (Optimizer.cc:667-710), one launch (the bDoMore check of :663-666 was made where the first
@@ -1938,6 +1969,7 @@ int lba_handle_init(aos2_lba *s)
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -2478,6 +2510,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     if (const char *e = getenv("AOS2_LBA_LAYOUT")) walk = !strcmp(e, "walk");
     const int lm_per_block = walk ? 128 : kLmBlock;
     const bool prof = getenv("AOS2_LBA_PROF") != nullptr;
+    const bool ldlt_old = getenv("AOS2_LDLT") && !strcmp(getenv("AOS2_LDLT"), "old");
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!prof) return;
@@ -2622,9 +2655,12 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         {
             const size_t ldlt_bytes = ((size_t)l.npad * (l.npad + 1) + (size_t)l.npad * 17 + 4 * (size_t)l.npad + 2 * 16 * 17 + 16) * 8;
             l.ldlt_lds = ldlt_bytes <= 159 * 1024 ? 1 : 0;
+            // the register-resident form (k_ldlt_reg) serves every window of up to 40 free keyframes; AOS2_LDLT=old keeps the two
+            // earlier forms (LDS-resident up to 21 free keyframes, in place in device memory beyond) for comparison
+            if (l.npad <= 16 * kLrMaxNb && !ldlt_old) l.ldlt_lds = 2;
         }
         // (beyond LDS the reduced system is factorised in place: k_schur writes it with leading dimension npad)
-        l.Hs = B.take(l.ldlt_lds ? 8 * n6 * n6 + 8 : 8 * (size_t)l.npad * l.npad + 8, 256); l.bs = B.take(8 * n6 + 8);
+        l.Hs = B.take(l.ldlt_lds == 1 ? 8 * n6 * n6 + 8 : 8 * (size_t)l.npad * l.npad + 8, 256); l.bs = B.take(8 * n6 + 8);
         l.tmp = B.take(8 * n6 + 8);
         l.n_part = std::max(1, (int)((S.nl + lm_per_block - 1) / lm_per_block));
         l.scal = B.take(64); l.part = B.take(16 * (size_t)std::max(S.nl, 1) + 8);
@@ -2657,8 +2693,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // ---- staging (parallel) + descriptors
     LbaWin *hw = reinterpret_cast<LbaWin *>(hin + o_wins);
     struct GroupDims {
-        bool any_lds = false, any_glob = false;
-        int mx_E = 0, mx_pts = 0, mx_npad_glob = 0, mx_npad_lds = 0;
+        bool any_lds = false, any_glob = false, any_reg = false;
+        int mx_E = 0, mx_pts = 0, mx_npad_glob = 0, mx_npad_lds = 0, mx_npad_reg = 0;
     } gd[2];
     std::vector<uint8_t> up_fail(nw, 0);
     for_windows([&](int i) {
@@ -2729,7 +2765,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.tmp = (double *)(base + l.tmp); W.scal = (double *)(base + l.scal); W.part = (double *)(base + l.part);
         W.n_part = l.n_part;
         W.ldlt = (double *)(base + l.ldlt); W.npad = l.npad; W.ldlt_lds = l.ldlt_lds;
-        W.hs_ld = l.ldlt_lds ? 6 * S.np : l.npad;
+        W.hs_ld = l.ldlt_lds == 1 ? 6 * S.np : l.npad;
         W.st = (LmState *)(base + l.st);
         W.abort_word = d_abort + i;
         W.out_Tcw = (float *)(base + l.out_Tcw); W.out_xyz = (float *)(base + l.out_xyz);
@@ -2737,7 +2773,10 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         W.out_chi2 = want_chi2 ? (double *)(base + l.out_chi2) : nullptr;
         GroupDims &D = gd[i >= goff[1] ? 1 : 0];
         if (S.np > 0) {
-            if (l.ldlt_lds) {
+            if (l.ldlt_lds == 2) {
+                D.any_reg = true;
+                D.mx_npad_reg = std::max(D.mx_npad_reg, l.npad);
+            } else if (l.ldlt_lds) {
                 D.any_lds = true;
                 D.mx_npad_lds = std::max(D.mx_npad_lds, l.npad);
             } else {
@@ -2803,7 +2842,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             stagger_pending = false;
         }
         // the two forms of the reduced-system kernel work on different windows: side by side (the LDS form on a stream of its own)
-        const bool both = D.any_glob && D.any_lds;
+        // (k_ldlt_reg and k_ldlt_lds never meet in one call: AOS2_LDLT chooses for the whole call)
+        const bool both = D.any_glob && (D.any_lds || D.any_reg);
         if (both) {
             (void)hipEventRecord(gfork[g], gq[g]);
             (void)hipStreamWaitEvent(gq2[g], gfork[g], 0);
@@ -2812,6 +2852,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
             const size_t need = ((size_t)D.mx_npad_lds * (D.mx_npad_lds + 1) + (size_t)D.mx_npad_lds * 17 + 4 * (size_t)D.mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
             hipLaunchKernelGGL(k_ldlt_lds, dim3(nwg(g)), dim3(512), need, both ? gq2[g] : gq[g], dw + goff[g]);
         }
+        if (D.any_reg)
+            hipLaunchKernelGGL(k_ldlt_reg, dim3(nwg(g)), dim3(kLrThreads), ldlt_reg_lds_doubles(D.mx_npad_reg) * sizeof(double), both ? gq2[g] : gq[g], dw + goff[g]);
         if (D.any_glob)
             hipLaunchKernelGGL(k_ldlt_dev, dim3(nwg(g)), dim3(512), ((size_t)D.mx_npad_glob * 17 + 4 * (size_t)D.mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), gq[g],
                                dw + goff[g]);
