@@ -203,6 +203,11 @@ __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins
             const int r = n + q / npad, c = q % npad;
             W.Hs[(size_t)r * npad + c] = r == c ? 1.0 : 0.0;
         }
+        // ... and the columns beyond n of the rows above it (k_ldlt_reg loads its tiles from the upper block triangle)
+        for (int q = threadIdx.x; q < n * (npad - n); q += 256) {
+            const int r = q / (npad - n), c = n + q % (npad - n);
+            W.Hs[(size_t)r * npad + c] = 0.0;
+        }
     }
     if (blockIdx.x == 0) {   // the state record (1.8 KB): zeroed by the workgroup, not by one thread
         LmState *st = W.st;
@@ -1823,9 +1828,9 @@ __global__ __launch_bounds__(kLrThreads) void k_ldlt_reg(const LbaWin *__restric
     const double lambda = Wn.st->lambda;
     double *xs = nullptr;
 #ifdef AOS2_LDLT_TIMING
-    const bool ok = ldlt_reg_solve<true>(Wn.Hs, Wn.hs_ld, n, Wn.npad, Wn.bs, sm, xs, Wn.st->dbg);
+    const bool ok = ldlt_reg_solve<true>(Wn.Hs, n, Wn.npad, Wn.bs, sm, xs, Wn.st->dbg);
 #else
-    const bool ok = ldlt_reg_solve<false>(Wn.Hs, Wn.hs_ld, n, Wn.npad, Wn.bs, sm, xs, nullptr);
+    const bool ok = ldlt_reg_solve<false>(Wn.Hs, n, Wn.npad, Wn.bs, sm, xs, nullptr);
 #endif
     if (!ok) {
         if (tid == 0) Wn.scal[3] = 0.0;
@@ -1969,7 +1974,7 @@ int lba_handle_init(aos2_lba *s)
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     s->dev_ready = true;
     return AOS2_OK;
 }

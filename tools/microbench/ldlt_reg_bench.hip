@@ -8,7 +8,11 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef AOS2_LR_TRACE
+#define AOS2_LR_TRACE 0
+#endif
 #include "ldlt_reg.h"
+constexpr int kDbg = 16 + AOS2_LR_TRACE * (aos2::kLrWorkers + 1);
 
 using namespace aos2;
 
@@ -18,7 +22,7 @@ __global__ __launch_bounds__(kLrThreads) void k_test(const double *Hs, int ld, i
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const size_t m = blockIdx.x;
     double *xs = nullptr;
-    const bool good = ldlt_reg_solve<kTiming>(Hs + m * (size_t)ld * ld, ld, n, npad, bs + m * (size_t)npad, sm, xs, dbg + 16 * m);
+    const bool good = ldlt_reg_solve<kTiming>(Hs + m * (size_t)ld * ld, n, npad, bs + m * (size_t)npad, sm, xs, dbg + (size_t)kDbg * m);
     if (threadIdx.x == 0) ok[m] = good ? 1 : 0;
     if (good)
         for (int i = threadIdx.x; i < n; i += kLrThreads) x[m * (size_t)npad + i] = xs[i];
@@ -59,11 +63,11 @@ static bool host_ldlt(std::vector<double> A, int n, std::vector<double> b, std::
 int main(int argc, char **argv)
 {
     const int NM = argc > 1 ? atoi(argv[1]) : 38;
-    CK(hipFuncSetAttribute((const void *)k_test<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    CK(hipFuncSetAttribute((const void *)k_test<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void *)k_test<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    CK(hipFuncSetAttribute((const void *)k_test<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     const int nps[] = {1, 2, 3, 5, 8, 11, 16, 20, 21, 22, 27, 28, 33, 38, 40};
     int worst_fail = 0;
-    for (int padded = 0; padded < 2; ++padded)
+    for (int padded = 1; padded < 2; ++padded)   // (the solve takes the padded layout only)
         for (int np : nps) {
             const int n = 6 * np, npad = (n + 15) & ~15, ld = padded ? npad : n;
             std::vector<double> H((size_t)NM * ld * ld, 0.0), B((size_t)NM * npad, 0.0);
@@ -90,18 +94,18 @@ int main(int argc, char **argv)
             CK(hipMalloc(&dH, H.size() * 8));
             CK(hipMalloc(&dB, B.size() * 8));
             CK(hipMalloc(&dX, B.size() * 8));
-            CK(hipMalloc(&dD, 16 * 8 * NM));
+            CK(hipMalloc(&dD, (size_t)kDbg * 8 * NM));
             CK(hipMalloc(&dOk, 4 * NM));
             CK(hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice));
             CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
             CK(hipMemset(dX, 0, B.size() * 8));
-            CK(hipMemset(dD, 0, 16 * 8 * NM));
+            CK(hipMemset(dD, 0, (size_t)kDbg * 8 * NM));
             const size_t lds = ldlt_reg_lds_doubles(npad) * 8;
             for (int rep = 0; rep < 4; ++rep)   // (the counters of the LAST launch: instruction cache warm)
                 hipLaunchKernelGGL(k_test<true>, dim3(NM), dim3(kLrThreads), lds, 0, dH, ld, n, npad, dB, dX, dD, dOk);
             CK(hipDeviceSynchronize());
             std::vector<double> X(B.size());
-            std::vector<long long> D(16 * NM);
+            std::vector<long long> D((size_t)kDbg * NM);
             std::vector<int> ok(NM);
             CK(hipMemcpy(X.data(), dX, X.size() * 8, hipMemcpyDeviceToHost));
             CK(hipMemcpy(D.data(), dD, D.size() * 8, hipMemcpyDeviceToHost));
@@ -140,6 +144,18 @@ int main(int argc, char **argv)
             printf("np %2d n %3d npad %3d ld %3d: %d systems, worst rel err %.2e, failures %d | %.1f us per launch | cycles: load %lld D0 %lld P %lld U %lld (D inside %lld) wait %lld factor %lld backward %lld\n",
                    np, n, npad, ld, NM, worst, nfail, ms * 1e3 / reps, D[0], D[1], D[2], D[3], D[4], D[7], D[5], D[6]);
             printf("      worker 0: load %lld | P own %lld wait %lld | U own %lld wait %lld | backward own %lld wait %lld\n", D[8], D[9], D[10], D[11], D[12], D[13], D[14]);
+            if (AOS2_LR_TRACE && getenv("LR_TRACE_NP") && atoi(getenv("LR_TRACE_NP")) == np) {   // timeline of block 0: per wave, (event, cycles since the first event)
+                long long t0 = D[16] >> 12;
+                for (int w = 0; w <= kLrWorkers; ++w) {
+                    printf("  wave %d:", w);
+                    for (int e = 0; e < AOS2_LR_TRACE; ++e) {
+                        const long long v = D[16 + (size_t)w * AOS2_LR_TRACE + e];
+                        if (!v) break;
+                        printf(" %lld.%lld@%lld", (v & 4095) >> 4, v & 15, (v >> 12) - t0);
+                    }
+                    printf("\n");
+                }
+            }
             worst_fail += nfail;
             CK(hipFree(dH)); CK(hipFree(dB)); CK(hipFree(dX)); CK(hipFree(dD)); CK(hipFree(dOk));
         }
@@ -151,7 +167,7 @@ int main(int argc, char **argv)
         double *dH, *dB, *dX;
         long long *dD;
         int *dOk;
-        CK(hipMalloc(&dH, H.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dX, B.size() * 8)); CK(hipMalloc(&dD, 128)); CK(hipMalloc(&dOk, 4));
+        CK(hipMalloc(&dH, H.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dX, B.size() * 8)); CK(hipMalloc(&dD, (size_t)kDbg * 8)); CK(hipMalloc(&dOk, 4));
         CK(hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_test<false>, dim3(1), dim3(kLrThreads), ldlt_reg_lds_doubles(npad) * 8, 0, dH, ld, n, npad, dB, dX, dD, dOk);
