@@ -116,6 +116,10 @@ struct aos2_extractor {
     int n_streams = 0;
     hipEvent_t ev[8] = {};
     hipEvent_t order_ev[kMaxStreams] = {};   // aos2_extractor_stream_wait
+    // ComputeStereoMatches reads BOTH extractors' pyramid blocks on the left one's first stream: each extractor keeps an event behind
+    // those kernels, and its next batch waits for it on every chunk stream before it rewrites the pyramids (stereo_guard_armed)
+    hipEvent_t stereo_guard = nullptr, stereo_t0 = nullptr, stereo_t1 = nullptr;
+    bool stereo_guard_armed = false;
     int streams_used = 0;                    // streams the batches since the last wait ran on (<= chunks)
     Plan plan;
     int batch_cap = 0;
@@ -687,6 +691,10 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
     e->streams_used = std::max(e->streams_used, chunks);
+    if (e->stereo_guard_armed) {   // stereo kernels enqueued since the last batch still read this extractor's pyramids
+        for (int c = 0; c < chunks; ++c) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[c], e->stereo_guard, 0));
+        e->stereo_guard_armed = false;
+    }
     auto enqueue = [&](int b0, int nb, hipStream_t s, bool timed) -> int {
         const uint8_t *img = d_imgs + (size_t)b0 * image_stride;
         uint8_t *pyr = e->d_pyr.p + (size_t)b0 * P.pyr_bytes;
@@ -937,7 +945,7 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
     const unsigned hc = std::thread::hardware_concurrency();
     e->host_threads = (int)std::min(32u, std::max(1u, hc));
     if (const char *v = getenv("AOS2_HOST_THREADS")) e->host_threads = std::max(1, atoi(v));
-    if (const char *v = getenv("AOS2_DESC_BLUR")) e->blur_level = strcmp(v, "level") == 0;
+    if (const char *v = getenv("AOS2_DESC_BLUR")) e->blur_level = strcmp(v, "level") == 0 && e->nlevels <= 8;   // (the blur plan holds 8 levels; beyond, the per-keypoint form)
     if (const char *v = getenv("AOS2_CHUNKS")) e->chunks = std::max(0, std::min(kMaxStreams, atoi(v)));
     *out = e;
     return AOS2_OK;
@@ -961,6 +969,8 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         for (int i = 0; i < e->n_streams; ++i) (void)hipStreamDestroy(e->streams[i]);
         for (auto &oe : e->order_ev)
             if (oe) (void)hipEventDestroy(oe);
+        for (hipEvent_t x : {e->stereo_guard, e->stereo_t0, e->stereo_t1})
+            if (x) (void)hipEventDestroy(x);
     }
     delete e;
 }
@@ -1193,13 +1203,24 @@ static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int
     if ((st = l->st_rows.alloc((size_t)batch * ((size_t)a.rows + 1 + (size_t)a.row_cap)))) return st;
     a.row_off = l->st_rows.p;
     a.row_idx = l->st_rows.p + (size_t)batch * ((size_t)a.rows + 1);
-    AOS2_HIP_CHECK(hipEventRecord(l->ev[0], l->stream));
+    // (events of its own: ev[0..5] are the stage timings of the extraction, which finish_device() reads)
+    if (!l->stereo_t0) {
+        AOS2_HIP_CHECK(hipEventCreate(&l->stereo_t0));
+        AOS2_HIP_CHECK(hipEventCreate(&l->stereo_t1));
+    }
+    for (aos2_extractor *x : {l, r})
+        if (!x->stereo_guard) AOS2_HIP_CHECK(hipEventCreateWithFlags(&x->stereo_guard, hipEventDisableTiming));
+    AOS2_HIP_CHECK(hipEventRecord(l->stereo_t0, l->stream));
     if ((st = launch_stereo(a, max_n_left, l->stream))) return st;
-    AOS2_HIP_CHECK(hipEventRecord(l->ev[1], l->stream));
+    AOS2_HIP_CHECK(hipEventRecord(l->stereo_t1, l->stream));
+    for (aos2_extractor *x : {l, r}) {   // the next extraction of either eye is ordered behind these kernels on all its streams
+        AOS2_HIP_CHECK(hipEventRecord(x->stereo_guard, l->stream));
+        x->stereo_guard_armed = true;
+    }
     if (!sync) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamSynchronize(l->stream));
     float ms = 0;
-    AOS2_HIP_CHECK(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
+    AOS2_HIP_CHECK(hipEventElapsedTime(&ms, l->stereo_t0, l->stereo_t1));
     l->stereo_ms = ms;
     return AOS2_OK;
 }

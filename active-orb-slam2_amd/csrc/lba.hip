@@ -2027,8 +2027,9 @@ struct WindowPool {
             std::lock_guard<std::mutex> lk(m);
             born = generation;   // a thread added later starts with the jobs after its creation, not with a finished one
         }
+        active = n;
         for (int t = (int)th.size(); t < n; ++t)
-            th.emplace_back([this, born] {
+            th.emplace_back([this, born, idx = t] {
                 int seen = born;
                 for (;;) {
                     {
@@ -2037,12 +2038,14 @@ struct WindowPool {
                         if (quit) return;
                         seen = generation;
                     }
-                    for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
+                    if (idx < active)
+                        for (int i; (i = next.fetch_add(1)) < n_items;) fn(i);
                     std::lock_guard<std::mutex> lk(m);
                     if (--running == 0) cv_done.notify_one();
                 }
             });
     }
+    int active = 0;   // workers that take items of the current job (a lowered host_threads setting: the others just check in)
     void run(int n, std::function<void(int)> f)
     {
         if (n <= 1 || th.empty()) {
@@ -2358,21 +2361,30 @@ void aos2_lba_destroy(aos2_lba_t *s)
 
 int aos2_lba_set_host_threads(aos2_lba_t *s, int n)
 {
-    if (!s || n < 0) return AOS2_ERR_ARG;
+    if (!s || n < 0) {
+        set_error("aos2_lba_set_host_threads: bad argument");
+        return AOS2_ERR_ARG;
+    }
     s->host_threads = n;
     return AOS2_OK;
 }
 
 int aos2_lba_set_window_groups(aos2_lba_t *s, int n)
 {
-    if (!s || n < 0 || n > 2) return AOS2_ERR_ARG;
+    if (!s || n < 0 || n > 2) {
+        set_error("aos2_lba_set_window_groups: 0 (default), 1 or 2");
+        return AOS2_ERR_ARG;
+    }
     s->window_groups = n;
     return AOS2_OK;
 }
 
 int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *host_rounds)
 {
-    if (!s) return AOS2_ERR_ARG;
+    if (!s) {
+        set_error("aos2_lba_last_program: no handle");
+        return AOS2_ERR_ARG;
+    }
     if (trial_slots) *trial_slots = s->last_trial_slots;
     if (host_rounds) *host_rounds = s->last_host_rounds;
     return AOS2_OK;
@@ -2383,7 +2395,10 @@ int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *ho
 // several ranks share a node's cores (tests/test_sharding_cpu.py); returns the wall time of the two phases.
 int aos2_lba_debug_host_phase(const aos2_lba_problem_t *problems, int n_problems, int threads, double *build_ms, double *stage_ms)
 {
-    if (!problems || n_problems <= 0 || threads <= 0) return AOS2_ERR_ARG;
+    if (!problems || n_problems <= 0 || threads <= 0) {
+        set_error("aos2_lba_debug_host_phase: bad argument");
+        return AOS2_ERR_ARG;
+    }
     std::vector<Pass> passes(n_problems);
     WindowPool pool;
     if (n_problems > 1 && threads > 1) pool.start(std::min(threads, n_problems));

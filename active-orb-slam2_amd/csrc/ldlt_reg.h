@@ -118,7 +118,7 @@ template <bool kTiming>
 __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, int n, int npad, const double *__restrict__ bs, double *sm, double *&xs_out,
                                                long long *dbg)
 {
-    constexpr int KW = kLrWorkers, NS = kLrSlots, NT = kLrThreads;
+    constexpr int KW = kLrWorkers, NS = kLrSlots;
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

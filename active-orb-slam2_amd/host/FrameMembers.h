@@ -21,6 +21,9 @@ inline void Frame::ComputeStereoMatches()
 {
     mvuRight = std::vector<float>(N, -1.0f);  // src/Frame.cc:497-498
     mvDepth = std::vector<float>(N, -1.0f);
+    // (this body is the reader of mvImagePyramid that the reference's was: from here on the extractors keep the levels on the device only)
+    mpORBextractorLeft->SetExposePyramid(false);
+    mpORBextractorRight->SetExposePyramid(false);
     if (N == 0) return;
     auto rows32 = [](const cv::Mat &m, int n, std::vector<uint8_t> &tmp) -> const uint8_t * {
         if (n == 0 || m.step == 32) return m.ptr<uint8_t>();
@@ -34,7 +37,7 @@ inline void Frame::ComputeStereoMatches()
         mpORBextractorLeft->handle(), mpORBextractorRight->handle(), 0, reinterpret_cast<const aos2_keypoint_t *>(mvKeys.data()),
         rows32(mDescriptors, N, tl), N, reinterpret_cast<const aos2_keypoint_t *>(mvKeysRight.data()), rows32(mDescriptorsRight, Nr, tr), Nr,
         mb, mbf, mvuRight.data(), mvDepth.data());
-    if (st != AOS2_OK) throw std::runtime_error(std::string("ComputeStereoMatches: ") + aos2_last_error());
+    if (st != AOS2_OK) aos2::fail("ComputeStereoMatches");
 }
 
 // mBowVec / mFeatVec from the descriptor matrix (levelsup = 4).  The reference first splits mDescriptors into one cv::Mat

@@ -18,7 +18,7 @@ class ORBVocabulary {
 public:
     ORBVocabulary()   // (the GPU is the calling thread's: aos2::set_thread_device, default 0)
     {
-        if (aos2_vocabulary_create(aos2::thread_device(), &h_) != AOS2_OK) throw std::runtime_error(aos2_last_error());
+        if (aos2_vocabulary_create(aos2::thread_device(), &h_) != AOS2_OK) aos2::fail("ORBVocabulary");
     }
     ~ORBVocabulary() { aos2_vocabulary_destroy(h_); }
     ORBVocabulary(const ORBVocabulary &) = delete;
@@ -28,7 +28,7 @@ public:
     bool loadFromBinaryFile(const std::string &filename) { return aos2_vocabulary_load_binary(h_, filename.c_str()) == AOS2_OK; }
     void saveToBinaryFile(const std::string &filename) const
     {
-        if (aos2_vocabulary_save_binary(h_, filename.c_str()) != AOS2_OK) throw std::runtime_error(aos2_last_error());
+        if (aos2_vocabulary_save_binary(h_, filename.c_str()) != AOS2_OK) aos2::fail("ORBVocabulary");
     }
     unsigned int size() const { return aos2_vocabulary_size(h_); }
     bool empty() const { return aos2_vocabulary_empty(h_) != 0; }
@@ -56,7 +56,7 @@ public:
         int nb = 0, nf = 0;
         if (aos2_vocabulary_transform(h_, desc, n, levelsup, bw.data(), bv.data(), &nb, fn.data(), fo.data(), fi.data(), &nf,
                                       nullptr, nullptr) != AOS2_OK)
-            throw std::runtime_error(std::string("ORBVocabulary::transform: ") + aos2_last_error());
+            aos2::fail("ORBVocabulary::transform");
         for (int j = 0; j < nb; ++j) v.insert(v.end(), DBoW2::BowVector::value_type(bw[j], bv[j]));
         for (int s = 0; s < nf; ++s) {
             std::vector<unsigned int> idx(fi.begin() + fo[s], fi.begin() + fo[s + 1]);
@@ -72,7 +72,7 @@ public:
         for (const auto &e : b) { w2.push_back(e.first); v2.push_back(e.second); }
         double s = 0;
         if (aos2_vocabulary_score(h_, w1.data(), v1.data(), (int)w1.size(), w2.data(), v2.data(), (int)w2.size(), &s) != AOS2_OK)
-            throw std::runtime_error(std::string("ORBVocabulary::score: ") + aos2_last_error());
+            aos2::fail("ORBVocabulary::score");
         return s;
     }
 

@@ -5,7 +5,7 @@
 // Include AFTER <opencv2/core/core.hpp> (or tests/cpp/refstub/opencv_stub.h in this image, which has no OpenCV).
 #pragma once
 #include <cassert>
-#include <stdexcept>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -20,14 +20,15 @@ public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };  // include/ORBextractor.h:49 (unused by the reference too)
 
     // The reference's five arguments; the GPU is the calling thread's (aos2::set_thread_device, default 0).
-    // mvImagePyramid: the reference's is always there after operator().  Its only reader, Frame::ComputeStereoMatches, runs on
-    // the pyramids the two extractors already hold on the device (FrameMembers.h), so by default the levels are NOT copied back
-    // after every frame (8 levels, ~1.4 MB for 640x480); a caller that does read mvImagePyramid calls FillImagePyramid() after
-    // operator(), or switches the copy on for every frame with SetExposePyramid(true).
+    // mvImagePyramid is filled by every operator() call, like the reference's (src/ORBextractor.cc:1107-1132): an unchanged
+    // Frame::ComputeStereoMatches (src/Frame.cc:502, 592, 609) reads it.  The copy is 8 levels, ~1.4 MB for 640x480, per frame;
+    // a tree whose only reader is the ComputeStereoMatches of FrameMembers.h (which runs on the pyramids the two extractors hold on
+    // the device) switches it off with SetExposePyramid(false) -- FrameMembers.h does so itself on its first call -- and a caller
+    // that wants one frame's levels afterwards calls FillImagePyramid().
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) : nlevels_(nlevels)
     {
         if (aos2_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, aos2::thread_device(), &h_) != AOS2_OK)
-            throw std::invalid_argument(std::string("ORBextractor: ") + aos2_last_error());
+            aos2::fail("ORBextractor");
         const float *a = aos2_extractor_scale_factors(h_), *b = aos2_extractor_inv_scale_factors(h_);
         const float *c = aos2_extractor_sigma2(h_), *d = aos2_extractor_inv_sigma2(h_);
         mvScaleFactor.assign(a, a + nlevels);
@@ -52,7 +53,7 @@ public:
         int n = 0;
         const int st = aos2_extractor_extract(h_, image.data, image.cols, image.rows, (int)image.step,
                                               reinterpret_cast<aos2_keypoint_t *>(_keypoints.data()), scratch_.data(), cap, &n);
-        if (st != AOS2_OK) throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
+        if (st != AOS2_OK) aos2::fail("ORBextractor");
         _keypoints.resize(n);
         if (n == 0)
             _descriptors.release();  // :1065
@@ -75,7 +76,7 @@ public:
             aos2_extractor_pyramid_level_size(h_, l, &w, &h);
             cv::Mat full(h + 38, w + 38, CV_8UC1);
             if (aos2_extractor_pyramid_level(h_, 0, l, 19, full.data, (int)full.step) != AOS2_OK)
-                throw std::runtime_error(std::string("ORBextractor: ") + aos2_last_error());
+                aos2::fail("ORBextractor");
             mvImagePyramid[l] = full(cv::Rect(19, 19, w, h));
         }
     }
@@ -94,7 +95,7 @@ public:
 protected:
     aos2_extractor_t *h_ = nullptr;
     int nlevels_;
-    bool exposePyramid_ = false;
+    bool exposePyramid_ = true;
     std::vector<uint8_t> scratch_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };

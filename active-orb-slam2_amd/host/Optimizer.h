@@ -161,7 +161,7 @@ inline void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Ma
     const int st = aos2_lba_solve(aos2::optimizer_handle(), &P, &R);
     T.call_us = clk.lap();
     if (st == AOS2_ERR_STOPPED) return;
-    if (st != AOS2_OK) throw std::runtime_error(std::string("LocalBundleAdjustment: ") + aos2_last_error());
+    if (st != AOS2_OK) aos2::fail("LocalBundleAdjustment");
     // Check inlier observations (:712-744), erase under the map mutex (:746-757)
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
     for (size_t e = 0; e < outlier.size(); ++e) {
@@ -223,7 +223,7 @@ inline int Optimizer::PoseOptimization(Frame *pFrame)
     aos2::ShimTiming &T = aos2::last_shim_timing();
     T.gather_us = clk.lap();
     if (aos2_pose_optimization(aos2::optimizer_handle(), &P, &R, 1) != AOS2_OK)
-        throw std::runtime_error(std::string("PoseOptimization: ") + aos2_last_error());
+        aos2::fail("PoseOptimization");
     T.call_us = clk.lap();
     if (n < 3) {   // :355-356: return 0 before the pose is touched
         T.scatter_us = clk.lap();

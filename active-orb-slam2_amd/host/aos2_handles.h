@@ -10,6 +10,8 @@
 // of the new device instead of silently staying on the first one.
 #pragma once
 #include <chrono>
+#include <cstdlib>
+#include <iostream>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -19,6 +21,22 @@
 #include "../../include/aos2.h"
 
 namespace aos2 {
+
+// Error convention of the classes in this directory.  The reference's classes have no failure path of their own and the code around
+// their call sites has no exception handling; what the reference does when its environment fails it is `cerr << ...; exit(-1)`
+// (src/System.cc:78-79, 95-97, 111-112).  A failed C-ABI call here is of that kind (no device, out of device memory, a bad
+// argument that the reference's own data cannot produce): by default the message (aos2_last_error) goes to std::cerr and the process
+// exits with -1.  A tree that does handle exceptions compiles with -DAOS2_HOST_EXCEPTIONS and gets std::runtime_error instead
+// (tests/cpp/ref_signature_test.cpp does).
+[[noreturn]] inline void fail(const char *what)
+{
+#ifdef AOS2_HOST_EXCEPTIONS
+    throw std::runtime_error(std::string(what) + ": " + aos2_last_error());
+#else
+    std::cerr << what << ": " << aos2_last_error() << std::endl;
+    std::exit(-1);
+#endif
+}
 
 inline int &thread_device()
 {
@@ -42,7 +60,7 @@ inline aos2_matcher_t *matcher_handle(float nnratio, bool checkOri)
     if (it != cache.m.end()) return it->second;
     aos2_matcher_t *h = nullptr;
     if (aos2_matcher_create(nnratio, checkOri ? 1 : 0, thread_device(), &h) != AOS2_OK)
-        throw std::runtime_error(std::string("ORBmatcher: ") + aos2_last_error());
+        fail("ORBmatcher");
     cache.m[key] = h;
     return h;
 }
@@ -60,7 +78,7 @@ inline aos2_lba_t *optimizer_handle()
     auto it = cache.m.find(thread_device());
     if (it != cache.m.end()) return it->second;
     aos2_lba_t *h = nullptr;
-    if (aos2_lba_create(thread_device(), &h) != AOS2_OK) throw std::runtime_error(std::string("Optimizer: ") + aos2_last_error());
+    if (aos2_lba_create(thread_device(), &h) != AOS2_OK) fail("Optimizer");
     cache.m[thread_device()] = h;
     return h;
 }
@@ -89,7 +107,7 @@ struct ShimClock {
 
 inline void check(int st, const char *what)
 {
-    if (st != AOS2_OK) throw std::runtime_error(std::string(what) + ": " + aos2_last_error());
+    if (st != AOS2_OK) fail(what);
 }
 
 }  // namespace aos2

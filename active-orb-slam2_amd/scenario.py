@@ -33,9 +33,12 @@ def pmap(fn, items, workers=None):
     workers = int(os.environ.get("AOS2_SYNTH_WORKERS", workers))
     try:
         import multiprocessing as mp
+        # (forked from a process that may already hold the HIP runtime's threads: a child that inherits a held lock would hang, not
+        # fail -- the children only run numpy, and the wait is bounded: past it the pool is dropped and the serial loop runs)
         with mp.get_context("fork").Pool(workers) as pool:
-            return pool.map(fn, items, chunksize=max(1, len(items) // (4 * workers)))
-    except Exception:   # noqa: BLE001  (no fork, no semaphores, ...): the serial loop gives the same arrays
+            job = pool.map_async(fn, items, chunksize=max(1, len(items) // (4 * workers)))
+            return job.get(timeout=float(os.environ.get("AOS2_SYNTH_TIMEOUT", max(180.0, 6.0 * len(items)))))
+    except Exception:   # noqa: BLE001  (no fork, no semaphores, a hung child, ...): the serial loop gives the same arrays
         return [fn(x) for x in items]
 
 

@@ -173,7 +173,10 @@ int aos2_compute_stereo_matches_device(aos2_extractor_t *left, aos2_extractor_t 
 /* The same without a host wait: left's first stream waits on the device for both extractors' batches in flight
  * (aos2_extractor_extract_batch_device_async -- the two ExtractORB threads of src/Frame.cc:103-109 joined), the kernels
  * are enqueued behind; what orders itself behind `left` afterwards (aos2_extractor_stream_wait, aos2_frames_build_stereo,
- * aos2_extractor_wait) runs behind them.  No device time is recorded. */
+ * aos2_extractor_wait) runs behind them.  The kernels read BOTH extractors' pyramid blocks: the next extraction of either
+ * extractor waits for them on the device, on every stream it uses, before it rewrites the pyramids -- the calls can be
+ * pipelined without a host wait in between.  The keypoint / descriptor / count / output buffers of the call are the
+ * caller's to keep untouched until left's stream has drained.  No device time is recorded. */
 int aos2_compute_stereo_matches_device_async(aos2_extractor_t *left, aos2_extractor_t *right, int batch,
                                              const aos2_keypoint_t *d_kp_left, const uint8_t *d_desc_left,
                                              const int32_t *d_n_left, const aos2_keypoint_t *d_kp_right,
@@ -828,8 +831,11 @@ int aos2_frames_fuse(aos2_frames_t *kfs, const aos2_map_points_dev_t *mps, int n
 /* on != 0: aos2_frames_search_for_triangulation (handle = its `a`) and aos2_frames_fuse (handle = `kfs`) return after ENQUEUEING on the
  * handle's stream -- LocalMapping's three calls for a keyframe then cost one wait instead of three round trips through a device that
  * is busy with the tracking kernels; aos2_frames_wait(handle) (or ordering another stream behind aos2_frames_stream(handle))
- * completes them.  The host arrays of a call (kf1, kf2, F12, epipole, target) are copied before it returns.  Default off: the calls
- * return with their results complete. */
+ * completes them.  The host arrays of a call (kf1, kf2, F12, epipole, target) are copied before it returns; the OTHER handle of a call
+ * (`b` of SearchForTriangulation, the keyframes a Fuse call reads) and every device input (the FeatureVector CSRs, d_node_of1, the map
+ * point table) must stay untouched -- no rebuild, no set_pose, no reuse of the buffers -- until aos2_frames_wait(handle) of the handle
+ * the call was made on has returned: its kernels read them from that handle's stream.  Default off: the calls return with their results
+ * complete. */
 int aos2_frames_set_async_keyframe_calls(aos2_frames_t *f, int on);
 
 /* ------------------------------------------------------------------------------------------

@@ -951,8 +951,28 @@ static void run_new_call_sites(const Bundle &B, Bundle &O, std::vector<double> &
         cv::Mat dnone;
         left(cv::Mat(), cv::Mat(), none, dnone);
         if (none.size() != 3 || !dnone.empty()) throw std::runtime_error("empty image: outputs were touched");
-        // mvImagePyramid on demand: the ROI exposes the 19-pixel REFLECT_101 frame like the reference's
+        // mvImagePyramid as an UNCHANGED Frame::ComputeStereoMatches reads it (src/Frame.cc:592-593, 609): filled by operator() itself
+        // on a fresh extractor -- no call of this repository's own methods --, patches cut with rowRange / colRange
+        {
+            ORBextractor fresh(nf, 1.2f, 8, 20, 7);
+            std::vector<cv::KeyPoint> kk;
+            cv::Mat dd;
+            fresh(imLeft, cv::Mat(), kk, dd);
+            if (kk.empty()) throw std::runtime_error("fresh extractor: no keypoints");
+            const cv::KeyPoint &kpL = kk[kk.size() / 2];
+            const float scaleFactor = fresh.GetInverseScaleFactors()[kpL.octave];
+            const int scaleduL = (int)lroundf(kpL.pt.x * scaleFactor), scaledvL = (int)lroundf(kpL.pt.y * scaleFactor), wdw = 5;
+            const cv::Mat &lvl = fresh.mvImagePyramid[kpL.octave];
+            if (lvl.empty() || scaledvL - wdw < 0 || scaledvL + wdw + 1 > lvl.rows || scaleduL - wdw < 0 || scaleduL + wdw + 1 > lvl.cols)
+                throw std::runtime_error("mvImagePyramid is not filled by operator() (the reference's default)");
+            cv::Mat IL = lvl.rowRange(scaledvL - wdw, scaledvL + wdw + 1).colRange(scaleduL - wdw, scaleduL + wdw + 1);
+            if (IL.rows != 2 * wdw + 1 || IL.cols != 2 * wdw + 1) throw std::runtime_error("mvImagePyramid patch");
+            if (kpL.octave == 0 && IL.at<uint8_t>(wdw, wdw) != imLeft.data[(size_t)scaledvL * w + scaleduL]) throw std::runtime_error("mvImagePyramid[0] content");
+        }
+        // ... and on demand after SetExposePyramid(false) (what F.ComputeStereoMatches() above switched `left` to): the ROI exposes the
+        // 19-pixel REFLECT_101 frame like the reference's
         left(imLeft, cv::Mat(), none, dnone);
+        if (!left.mvImagePyramid[0].empty() && left.mvImagePyramid[0].data[0] != imLeft.data[0]) throw std::runtime_error("stale mvImagePyramid");
         left.FillImagePyramid();
         const cv::Mat &p0 = left.mvImagePyramid[0];
         if (p0.cols != w || p0.rows != h || *(p0.data - p0.step - 1) != p0.data[p0.step + 1] || p0.data[5 * p0.step + 7] != imLeft.data[5 * (size_t)w + 7])

@@ -22,7 +22,7 @@ KHELD = 1000000
 def build(tmp_path, pkg):
     exe = str(tmp_path / "ref_signature_test")
     libdir = os.path.dirname(pkg.lib_path())
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "ref_signature_test.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-DAOS2_HOST_EXCEPTIONS", os.path.join(ROOT, "tests", "cpp", "ref_signature_test.cpp"),
                            "-o", exe, "-L" + libdir, "-laos2", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
