@@ -175,8 +175,201 @@ def lib():
             L.aos2_frames_search_local_points.argtypes = [vp, vp, vp, ci, cf, cf, vp]
             L.aos2_extractor_stream_wait.argtypes = [vp, vp]
             L.aos2_extractor_pack_slots.argtypes = [vp, ci, vp, vp, vp, ci, vp, C.c_size_t, vp]
-        _LIB = L
+        _LIB = _RecLib(L)
     return _LIB
+
+
+# ---- recording (bench harness): the calls of a job captured instead of executed, for the native step runner (csrc/host_runner.cpp)
+class _Call(C.Structure):
+    _fields_ = [("fn", C.c_void_p), ("n_int", C.c_int32), ("n_fp", C.c_int32), ("iargs", C.c_int64 * 24), ("fargs", C.c_uint64 * 8)]
+
+
+# the functions a recorded job may consist of: work that is enqueued / solved / waited for.  Everything else (getters, stream handles,
+# setters) executes at once even while a recording is open
+_RECORDABLE = {
+    "aos2_frames_set_pose", "aos2_extractor_extract_batch_device_async", "aos2_frames_build", "aos2_frames_build_stereo",
+    "aos2_compute_stereo_matches_device_async", "aos2_frames_search_by_projection_last", "aos2_frames_pose_optimization",
+    "aos2_frames_discard_outliers", "aos2_frames_search_local_points", "aos2_frames_wait", "aos2_extractor_wait",
+    "aos2_extractor_stream_wait", "aos2_vocabulary_transform_device", "aos2_matcher_search_by_bow_frames",
+    "aos2_frames_search_for_triangulation", "aos2_frames_fuse", "aos2_lba_solve_batch", "aos2_extractor_pack_slots",
+    "hipMemcpyAsync", "hipStreamSynchronize", "hipStreamWaitEvent", "hipEventRecord", "hipMemcpy",
+}
+_REC = None   # the open recording (a list), or None
+
+
+class recording:
+    """with capi.recording() as calls: ...   -- the recordable C calls made inside are appended to `calls` (not executed; they
+    "return" AOS2_OK); calls.keep holds every argument object alive; calls.array() is the aos2_call_t array for the runner"""
+
+    class _List(list):
+        def __init__(self):
+            super().__init__()
+            self.keep = []
+
+        def array(self):
+            a = (_Call * max(1, len(self)))()
+            for i, c in enumerate(self):
+                a[i] = c
+            return a
+
+    def __enter__(self):
+        global _REC
+        assert _REC is None, "recordings do not nest"
+        _REC = recording._List()
+        return _REC
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        return False
+
+
+def _record(fn, name, args):
+    import struct
+    at = fn.argtypes
+    if at is None or len(at) != len(args):
+        raise TypeError(f"recording {name}: the function needs argtypes for every argument")
+    c = _Call()
+    c.fn = C.cast(fn, C.c_void_p).value
+    ni = nf = 0
+    for a, t in zip(args, at):
+        if t is C.c_float or t is C.c_double:
+            v = float(a.value if isinstance(a, C._SimpleCData) else a)
+            bits = struct.unpack("<I", struct.pack("<f", v))[0] if t is C.c_float else struct.unpack("<Q", struct.pack("<d", v))[0]
+            if nf >= 8:
+                raise TypeError(f"recording {name}: more than 8 floating-point arguments")
+            c.fargs[nf] = bits
+            nf += 1
+            continue
+        if a is None:
+            v = 0
+        elif isinstance(a, (int, np.integer)):
+            v = int(a)
+        elif isinstance(a, C._SimpleCData):
+            v = a.value or 0
+        else:
+            v = C.cast(a, C.c_void_p).value or 0   # pointers, arrays, byref()
+        if ni >= 24:
+            raise TypeError(f"recording {name}: more than 24 integer arguments")
+        if v >= 1 << 63:
+            v -= 1 << 64
+        c.iargs[ni] = v
+        ni += 1
+    c.n_int, c.n_fp = ni, nf
+    _REC.append(c)
+    _REC.keep.append(args)
+    return AOS2_OK
+
+
+class _RecLib:
+    """the loaded library; a recordable function called while a recording is open is captured instead of executed"""
+
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+        object.__setattr__(self, "_w", {})
+        object.__setattr__(self, "_names", frozenset(_RECORDABLE))   # (kept here: module globals are gone when handles close at exit)
+
+    def __getattr__(self, name):
+        w = self._w.get(name)
+        if w is None:
+            fn = getattr(self._L, name)
+            if name in self._names:
+                def w(*args, _fn=fn, _name=name):
+                    if _REC is None:
+                        return _fn(*args)
+                    return _record(_fn, _name, args)
+                w.argtypes_of = fn
+            else:
+                w = fn
+            self._w[name] = w
+        return w
+
+
+_HIP = None
+
+
+def hip_runtime():
+    """libamdhip64 (the runtime the library itself links) for the harness's own copies: hipMemcpyAsync & co, recordable"""
+    global _HIP
+    if _HIP is None:
+        H = C.CDLL("libamdhip64.so")
+        vp = C.c_void_p
+        H.hipMemcpyAsync.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+        H.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
+        H.hipStreamSynchronize.argtypes = [vp]
+        H.hipStreamWaitEvent.argtypes = [vp, vp, C.c_uint]
+        H.hipEventRecord.argtypes = [vp, vp]
+        H.hipStreamCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+        H.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+        H.hipHostMalloc.argtypes = [C.POINTER(vp), C.c_size_t, C.c_uint]
+        _HIP = _RecLib(H)
+    return _HIP
+
+
+HIP_D2H, HIP_H2D = 2, 1
+
+
+class Runner:
+    """csrc/host_runner.cpp: the step schedule of bench.py on native threads over recorded call lists"""
+    PIPE_WAIT, PIPE_STEP, KF_JOB, LBA_JOB = 0, 1, 2, 3
+
+    def __init__(self, n_pipes, n_lba):
+        p = os.path.join(os.path.dirname(lib_path()), "libaos2_runner.so")
+        if not os.path.exists(p):
+            raise LibraryMissing(f"{p} not found: build it with `make -C {_HERE}/csrc`")
+        R = C.CDLL(p)
+        vp = C.c_void_p
+        R.aos2_runner_create.restype = vp
+        R.aos2_runner_create.argtypes = [C.c_int, C.c_int]
+        R.aos2_runner_destroy.argtypes = [vp]
+        R.aos2_runner_set_list.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        R.aos2_runner_step.argtypes = [vp, C.c_int]
+        R.aos2_runner_run.argtypes = [vp, C.c_int, C.c_int]
+        R.aos2_runner_sync.argtypes = [vp]
+        R.aos2_runner_error.argtypes = [vp]
+        R.aos2_runner_error.restype = C.c_char_p
+        R.aos2_runner_reset_stats.argtypes = [vp]
+        R.aos2_runner_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+        self.R = R
+        self.h = R.aos2_runner_create(int(n_pipes), int(n_lba))
+        if not self.h:
+            raise ValueError("aos2_runner_create")
+        self._keep = {}
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.R.aos2_runner_destroy(self.h)
+            self.h = None
+
+    def set_list(self, kind, index, calls):
+        """calls: a recording (or None / empty: the job is skipped)"""
+        n = len(calls) if calls else 0
+        arr = calls.array() if n else None
+        if self.R.aos2_runner_set_list(self.h, kind, index, C.cast(arr, C.c_void_p) if n else None, n) != 0:
+            raise ValueError("aos2_runner_set_list")
+        self._keep[(kind, index)] = (calls, arr)
+
+    def _st(self, st):
+        if st != 0:
+            raise AosError(st, self.R.aos2_runner_error(self.h).decode() + ": " + lib().aos2_last_error().decode(errors="replace"))
+
+    def step(self, s):
+        self._st(self.R.aos2_runner_step(self.h, int(s)))
+
+    def run(self, s0, n):
+        self._st(self.R.aos2_runner_run(self.h, int(s0), int(n)))
+
+    def sync(self):
+        self._st(self.R.aos2_runner_sync(self.h))
+
+    def reset_stats(self):
+        self.R.aos2_runner_reset_stats(self.h)
+
+    def stats(self, which):
+        n = self.R.aos2_runner_stats(self.h, which, None, 0)
+        a = np.zeros(max(n, 1), np.float64)
+        self.R.aos2_runner_stats(self.h, which, _p(a), n)
+        return a[:n]
 
 
 def _check(st, ok=(AOS2_OK,)):

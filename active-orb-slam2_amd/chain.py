@@ -244,6 +244,20 @@ class ReferenceKeyFrameBoW:
         self.results = None
         return self
 
+    def run_calls(self):
+        """the C calls of run() and nothing else (what capi.recording() captures for the native step runner)"""
+        tc, k = self.tc, self.kf
+        o = [self.bw, self.bv, self.nb, self.fn, self.fo, self.fi, self.nf]
+        V = capi.C.c_void_p
+        capi._check(self.voc.L.aos2_vocabulary_transform_device(self.voc.h, self.n, V(tc.d_desc.data_ptr()), V(tc.d_n.data_ptr()), tc.cap, self.levelsup,
+                                                                *(V(x.data_ptr()) for x in o), V(None), V(None)))
+        self.m.SearchByBoWFrames(self.n, tc.cap, self.kf_has_mp, self.match, self.nmatches,
+                                 d_desc_kf=tc.dl_desc.data_ptr(), d_kps_kf=tc.dl_kps.data_ptr(), d_n_kf=tc.dl_n.data_ptr(),
+                                 d_desc_f=tc.d_desc.data_ptr(), d_kps_f=tc.d_kps.data_ptr(), d_n_f=tc.d_n.data_ptr(),
+                                 d_kf_fv_node=k[3].data_ptr(), d_kf_fv_off=k[4].data_ptr(), d_kf_fv_idx=k[5].data_ptr(), d_kf_n_fv=k[6].data_ptr(),
+                                 d_f_fv_node=self.fn.data_ptr(), d_f_fv_off=self.fo.data_ptr(), d_f_fv_idx=self.fi.data_ptr(), d_f_n_fv=self.nf.data_ptr())
+        self.results = None
+
     def get_results(self):
         """[(nmatches, match_f[:N])] of the last run (host copies)"""
         n_f = self.tc.d_n[: self.n].cpu().numpy()
@@ -395,6 +409,26 @@ class KeyFrameWork:
         self.rev_idx, self.rev_dist = (h.numpy() for h in self.h_rev)
         self.last_ms = ((t1 - t0) * 1e3, (t2 - t1) * 1e3)
         return self
+
+    def run_calls(self):
+        """the C calls of run() and nothing else (capi.recording() / the native step runner): the three searches, the results to the
+        page-locked host arrays on the streams that produce them, both batches waited for"""
+        tc, H = self.tc, capi.hip_runtime()
+        tc.last.SearchForTriangulation(self.kfs, self.t_kf1, self.t_kf2, self.t_F12, self.t_epipole, self.fv1[8].data_ptr(),
+                                       [self.fv1[k].data_ptr() for k in (3, 4, 5, 6)], [self.fv2[k].data_ptr() for k in (3, 4, 5, 6)],
+                                       self.d_match12.data_ptr(), self.d_nm.data_ptr(), only_stereo=self.only_stereo,
+                                       check_orientation=self.check_orientation)
+        self.kfs.Fuse(tc.table, self.kf2, self.d_rows.data_ptr(), tc.cap, self.fuse_th, self.d_best_idx.data_ptr(), self.d_best_dist.data_ptr())
+        tc.last.Fuse(tc.table, self.rev_target, self.d_rev_rows.data_ptr(), self.rev_rows.shape[1], self.fuse_th, self.d_rev_idx.data_ptr(),
+                     self.d_rev_dist.data_ptr())
+        s_last, s_kfs = tc.last.stream(), self.kfs.stream()
+        for h, d, q in zip(self.h_out + self.h_rev, (self.d_match12, self.d_best_idx, self.d_best_dist, self.d_nm, self.d_rev_idx, self.d_rev_dist),
+                           (s_last, s_kfs, s_kfs, s_last, s_last, s_last)):
+            capi._check(H.hipMemcpyAsync(h.data_ptr(), d.data_ptr(), h.numel() * h.element_size(), capi.HIP_D2H, q))
+        self.kfs.wait()
+        tc.last.wait()
+        self.match12, self.best_idx, self.best_dist, self.nm = (h.numpy() for h in self.h_out)   # (views of the page-locked arrays)
+        self.rev_idx, self.rev_dist = (h.numpy() for h in self.h_rev)
 
     def snapshot(self):
         """the inputs (by reference) and the last results (copies), for oracle/parity.py"""

@@ -343,7 +343,10 @@ def main():
         lba_probs = lba_unique
     else:
         lba_mix, lba_unique, lba_probs = None, lba_hom_unique, lba_hom
-    NLBA = max(1, int(os.environ.get("AOS2_BENCH_LBA_HANDLES", str(NPIPE))))   # LocalBA batches in flight (own handle + host thread each)
+    # LocalBA batches in flight (own handle + host thread each): one more than steps in flight -- a call is ~4 ms of host work (structure
+    # build, staging) and ~8 ms of device program beside everything else, i.e. two steps long; with two handles the stepping thread
+    # waited 6-7 ms of every 8 ms step for it (62.7 k frames/s; three handles 66.7-69.7 k, four 65.9 k, one 51.8 k in one session)
+    NLBA = max(1, int(os.environ.get("AOS2_BENCH_LBA_HANDLES", str(NPIPE + 1))))
     lbas = [pkg.LocalBA(device=local_rank) for _ in range(NLBA)]
     # host threads of a handle's per-window work: the node's cores shared among ranks and handles (8 ranks x 2 handles x 32 threads
     # would be 512 threads on 256 cores)
@@ -355,8 +358,15 @@ def main():
         h.set_host_threads(lba_threads)
         h.set_window_groups(LBA_GROUPS)
     lba_prep = [h.prepare_batch(lba_probs) for h in lbas]
-    pool = ThreadPoolExecutor(NLBA)   # LocalMapping-side threads: one per LocalBA handle
+    pool = ThreadPoolExecutor(NLBA)   # LocalMapping-side threads: one per LocalBA handle (AOS2_BENCH_RUNNER=python)
     lba_jobs = [None] * NLBA
+    # The step schedule runs on NATIVE threads by default (csrc/host_runner.cpp): the calls of every job are recorded once
+    # (capi.recording()) and replayed -- the Tracking thread's chain on the stepping thread, the keyframe legs and LocalBA on a thread
+    # each, like the reference's own std::threads (src/System.cc:136-155).  The five Python threads of earlier rounds handed the
+    # interpreter lock to each other between every two C calls: the same steps measured 51.9 / 58.3 / 65.2 k frames/s in three
+    # consecutive runs.  AOS2_BENCH_RUNNER=python keeps that form (tests compare the two).
+    NATIVE = os.environ.get("AOS2_BENCH_RUNNER", "native") != "python"
+    runner = pkg.capi.Runner(NPIPE, NLBA) if NATIVE else None
     NO_LBA = os.environ.get("AOS2_BENCH_NO_LBA") == "1"   # diagnostics only: the tracking chains alone (the JSON line is then not the metric)
     # N > 1: the one exchange step of the path -- every step's keypoint / descriptor slots go to
     # rank 0 in one gather (RCCL over xGMI), enqueued behind the step on the step's own stream and left in flight while
@@ -391,7 +401,36 @@ def main():
         lba_walls.append(time.perf_counter() - t_)
         return r_
 
+    def record_lists():
+        """(re-)record the jobs of the native runner from the harness objects as they are now"""
+        rec = pkg.capi.recording
+        for j_, pp in enumerate(pipes):
+            with rec() as c_:
+                pp.wait()
+            runner.set_list(runner.PIPE_WAIT, j_, c_)
+            with rec() as c_:
+                pp.step()
+                if bows:
+                    bows[j_].order()
+            runner.set_list(runner.PIPE_STEP, j_, c_)
+            with rec() as c_:
+                if bows:
+                    bows[j_].run_calls()
+                if kfws:
+                    kfws[j_].run_calls()
+            runner.set_list(runner.KF_JOB, j_, c_)
+        for jl_ in range(NLBA):
+            with rec() as c_:
+                if not NO_LBA:
+                    lbas[jl_].solve_prepared(lba_prep[jl_])
+            runner.set_list(runner.LBA_JOB, jl_, c_)
+
     def step(s):
+        if NATIVE:
+            runner.step(s)
+            if gather is not None:
+                gather_step(s % NPIPE)
+            return
         # pipeline s % NPIPE: its previous step (s - NPIPE) is complete before its buffers are reused
         j = s % NPIPE
         p = pipes[j]
@@ -419,6 +458,17 @@ def main():
             lba_jobs[jl] = pool.submit(lba_call, jl)
 
     def sync():
+        if NATIVE:
+            runner.sync()
+            for j in range(NPIPE):
+                if gather is not None and gather["work"][j] is not None:
+                    gather["work"][j].wait()
+                    gather["work"][j] = None
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            return
         for jl in range(NLBA):
             if lba_jobs[jl] is not None:
                 lba_jobs[jl].result()
@@ -439,6 +489,8 @@ def main():
     if os.environ.get("AOS2_BENCH_FAULT"):   # test hook (tests/test_bench_gpu.py): the device table moves, the oracle's inputs do not
         for pp in pipes:
             pp.d_table["pos"][pp.map["mp_last"][0][pp.map["mp_last"][0] >= 0][:40].tolist()] += 0.05
+    if NATIVE:
+        record_lists()
     for i in range(args.warmup):
         step(i)
     sync()
@@ -454,12 +506,21 @@ def main():
     for k_ in waits:
         waits[k_] = 0.0
     del lba_walls[:], kf_walls[:], step_marks[:]
+    if NATIVE:
+        runner.reset_stats()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    if NATIVE and gather is None:
+        runner.run(0, args.steps)   # the K steps without a return to the interpreter
+    else:
+        for i in range(args.steps):
+            step(i)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    if NATIVE:
+        w3 = runner.stats(0)
+        waits.update(local_ba=float(w3[0]), keyframe_legs=float(w3[1]), tracking=float(w3[2]))
+        lba_walls[:], kf_walls[:], step_marks[:] = list(runner.stats(1)), list(runner.stats(2)), list(runner.stats(3))
     mmm = lambda v: [round(float(x) * 1e3, 3) for x in (min(v), np.median(v), max(v))] if len(v) else None   # noqa: E731
     timed_steps = {"host_thread_waits_ms_per_step": {k_: round(v_ * 1e3 / max(1, args.steps), 3) for k_, v_ in waits.items()},
                    "step_to_step_ms_min_median_max": mmm(np.diff(step_marks)) if len(step_marks) > 2 else None,
@@ -508,6 +569,8 @@ def main():
     dt_nobow = dt_bowonly = dt_hom = None
     if bows and os.environ.get("AOS2_BENCH_SKIP_R02_FORM") != "1":
         def short_run(n2):
+            if NATIVE:
+                record_lists()   # (the harness objects changed: the jobs are recorded again)
             for i in range(2):
                 step(i)
             sync()
@@ -529,6 +592,8 @@ def main():
         dt_nobow = short_run(n2)
         bows.extend(saved)
         kfws.extend(saved_kfw)
+        if NATIVE:
+            record_lists()
     nm_host = pipes[0].d_nm.cpu().numpy()
     lba_res = lba_prep[0]["R"]
     # ---- stage times of one synchronous pass (every stage waited for: wall clock incl. launch latency)
