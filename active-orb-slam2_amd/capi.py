@@ -174,6 +174,7 @@ def lib():
             L.aos2_frames_discard_outliers.argtypes = [vp]
             L.aos2_frames_search_local_points.argtypes = [vp, vp, vp, ci, cf, cf, vp]
             L.aos2_extractor_stream_wait.argtypes = [vp, vp]
+            L.aos2_extractor_wait_for_stream.argtypes = [vp, vp]
             L.aos2_extractor_pack_slots.argtypes = [vp, ci, vp, vp, vp, ci, vp, C.c_size_t, vp]
         _LIB = _RecLib(L)
     return _LIB
@@ -190,7 +191,7 @@ _RECORDABLE = {
     "aos2_frames_set_pose", "aos2_extractor_extract_batch_device_async", "aos2_frames_build", "aos2_frames_build_stereo",
     "aos2_compute_stereo_matches_device_async", "aos2_frames_search_by_projection_last", "aos2_frames_pose_optimization",
     "aos2_frames_discard_outliers", "aos2_frames_search_local_points", "aos2_frames_wait", "aos2_extractor_wait",
-    "aos2_extractor_stream_wait", "aos2_vocabulary_transform_device", "aos2_matcher_search_by_bow_frames",
+    "aos2_extractor_stream_wait", "aos2_extractor_wait_for_stream", "aos2_vocabulary_transform_device", "aos2_matcher_search_by_bow_frames",
     "aos2_frames_search_for_triangulation", "aos2_frames_fuse", "aos2_lba_solve_batch", "aos2_extractor_pack_slots",
     "hipMemcpyAsync", "hipStreamSynchronize", "hipStreamWaitEvent", "hipEventRecord", "hipMemcpy",
 }
@@ -546,6 +547,10 @@ class Extractor:
 
     def stream_wait(self, stream):
         _check(self.L.aos2_extractor_stream_wait(self.h, stream))
+
+    def wait_for_stream(self, stream):
+        """the batches enqueued from now on run behind what `stream` holds so far (device-side)"""
+        _check(self.L.aos2_extractor_wait_for_stream(self.h, stream))
 
     def wait(self):
         """complete every batch enqueued with extract_batch_device_async"""

@@ -100,6 +100,8 @@ class TrackingChain:
         """enqueue the chain for the batch"""
         c = self.cur
         c.set_pose(self.d_guess.data_ptr())   # mVelocity * mLastFrame.mTcw is known before the image: its copy runs beside the extraction
+        if self.hb is not None:
+            self._images_from_host()
         self.enqueue_extract()
         self.enqueue_build()
         c.SearchByProjectionLast(self.last, self.table, self.th_last, mono=False, check_orientation=True, d_nmatches=self.d_nm[0].data_ptr())
@@ -107,6 +109,56 @@ class TrackingChain:
         c.discard_outliers()
         c.SearchLocalPoints(self.table, self.d_local.data_ptr(), self.n_local, self.th_local, self.nnratio_local, self.d_nm[2].data_ptr())
         c.PoseOptimization(self.table, self.d_nm[3].data_ptr())
+        if self.hb is not None:
+            self._results_to_host()
+
+    # ---- the reference's host boundary (bench.py --host-images): the images of a step come from page-locked HOST memory (the
+    # reference's operator() takes a host cv::Mat, src/Frame.cc:276-282) and what Tracking reads of the Frame afterwards -- mvKeys,
+    # mDescriptors, N, mvuRight, mvDepth, mvpMapPoints, mvbOutlier, mTcw, the match counts -- lands in page-locked host arrays:
+    # one copy up on a stream of the harness (the extraction waits for it on the device), the copies down on the Frame batch's
+    # stream behind the second PoseOptimization (wait() covers them).
+    hb = None
+
+    def enable_host_boundary(self, on=True):
+        t, F = self.torch, capi.Frames
+        if not on:
+            self.hb = None
+            return
+        H = capi.hip_runtime()
+        s_io = capi.C.c_void_p()
+        capi._check(H.hipStreamCreateWithFlags(capi.C.byref(s_io), 1))   # hipStreamNonBlocking
+        B, cap = self.B, self.cap
+        imgs = [("cur", self.d_cur, t.from_numpy(self.scen["cur"][self.scen["index"]]).pin_memory())]
+        if hasattr(self, "d_right"):
+            imgs.append(("right", self.d_right, t.from_numpy(self.scen["right_cur"][self.scen["index"]]).pin_memory()))
+        pin = lambda shape, dt: t.zeros(shape, dtype=dt).pin_memory()   # noqa: E731
+        c = self.cur
+        down = [("kps", self.d_kps.data_ptr(), pin((B, cap, 7), t.float32)), ("desc", self.d_desc.data_ptr(), pin((B, cap, 32), t.uint8)),
+                ("n", self.d_n.data_ptr(), pin((B,), t.int32)), ("nm", self.d_nm.data_ptr(), pin((4, B), t.int32))]
+        self.hb = dict(s_io=s_io, imgs=imgs, down=down, members=None,
+                       pins=dict(mp=pin((B, cap), t.int32), outlier=pin((B, cap), t.uint8), Tcw=pin((B, 16), t.float32),
+                                 u_right=pin((B, cap), t.float32), depth=pin((B, cap), t.float32)))
+        self.hb["up_bytes"] = sum(h.numel() * h.element_size() for _, _, h in imgs)
+
+    def _images_from_host(self):
+        H, hb = capi.hip_runtime(), self.hb
+        for name, d, h in hb["imgs"]:
+            capi._check(H.hipMemcpyAsync(d.data_ptr(), h.data_ptr(), h.numel() * h.element_size(), capi.HIP_H2D, hb["s_io"]))
+        self.ex.wait_for_stream(hb["s_io"])
+        if hasattr(self, "ex_r"):
+            self.ex_r.wait_for_stream(hb["s_io"])
+
+    def _results_to_host(self):
+        H, hb, F, c = capi.hip_runtime(), self.hb, capi.Frames, self.cur
+        if hb["members"] is None:   # (the member arrays exist once the batch was built: their device addresses do not change afterwards)
+            ids = dict(mp=F.MAP_POINTS, outlier=F.OUTLIER, Tcw=F.TCW, u_right=F.U_RIGHT, depth=F.DEPTH)
+            hb["members"] = [(k, c.device_ptr(v), hb["pins"][k]) for k, v in ids.items()]
+            if not all(p for _, p, _ in hb["members"]):
+                raise RuntimeError("host boundary: run one step() before enabling it (the Frame batch has no members yet)")
+            hb["down_bytes"] = sum(h.numel() * h.element_size() for _, _, h in hb["down"] + hb["members"])
+        q = c.stream()
+        for _, d, h in hb["down"] + hb["members"]:
+            capi._check(H.hipMemcpyAsync(h.data_ptr(), d, h.numel() * h.element_size(), capi.HIP_D2H, q))
 
     def wait(self):
         self.cur.wait()

@@ -119,6 +119,7 @@ struct aos2_extractor {
     // ComputeStereoMatches reads BOTH extractors' pyramid blocks on the left one's first stream: each extractor keeps an event behind
     // those kernels, and its next batch waits for it on every chunk stream before it rewrites the pyramids (stereo_guard_armed)
     hipEvent_t stereo_guard = nullptr, stereo_t0 = nullptr, stereo_t1 = nullptr;
+    hipEvent_t input_ev = nullptr;   // aos2_extractor_wait_for_stream
     bool stereo_guard_armed = false;
     int streams_used = 0;                    // streams the batches since the last wait ran on (<= chunks)
     Plan plan;
@@ -969,7 +970,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         for (int i = 0; i < e->n_streams; ++i) (void)hipStreamDestroy(e->streams[i]);
         for (auto &oe : e->order_ev)
             if (oe) (void)hipEventDestroy(oe);
-        for (hipEvent_t x : {e->stereo_guard, e->stereo_t0, e->stereo_t1})
+        for (hipEvent_t x : {e->stereo_guard, e->stereo_t0, e->stereo_t1, e->input_ev})
             if (x) (void)hipEventDestroy(x);
     }
     delete e;
@@ -1056,6 +1057,21 @@ int aos2_extractor_pack_slots(aos2_extractor_t *e, int batch, const aos2_keypoin
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     hipLaunchKernelGGL(pack_slots_kernel, dim3(16, batch), dim3(256), 0, s, d_kps, d_desc, d_n, cap, d_slots, slot_bytes);
     AOS2_HIP_CHECK(hipGetLastError());
+    return AOS2_OK;
+}
+
+int aos2_extractor_wait_for_stream(aos2_extractor_t *e, void *hip_stream)
+{
+    if (!e) {
+        set_error("bad argument");
+        return AOS2_ERR_ARG;
+    }
+    int st = init_device(e);
+    if (st) return st;
+    hipStream_t src = static_cast<hipStream_t>(hip_stream);
+    if (!e->input_ev) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->input_ev, hipEventDisableTiming));
+    AOS2_HIP_CHECK(hipEventRecord(e->input_ev, src));
+    for (int i = 0; i < std::max(1, e->n_streams); ++i) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[i], e->input_ev, 0));
     return AOS2_OK;
 }
 

@@ -185,6 +185,11 @@ def main():
     ap.add_argument("--lba-mix", default="heterogeneous", choices=["heterogeneous", "homogeneous"],
                     help="LocalBA windows of the timed step: heterogeneous = every window a different problem (10-40 local keyframes, "
                          "2-6 k points, 5-20 %% outliers); homogeneous = round 3's SURVEY 8(d)-size windows (4 distinct, tiled)")
+    ap.add_argument("--host-images", action="store_true",
+                    help="the reference's host boundary inside the timed step: the images of every step come from page-locked HOST memory "
+                         "(ORBextractor::operator() takes a host cv::Mat, src/Frame.cc:276-282) and keypoints / descriptors / mvuRight / mvDepth / "
+                         "map point matches / outlier flags / mTcw land in page-locked host arrays, which the parity check then reads; the default "
+                         "line reports this form as extra.composite_host_boundary (value stays the HBM-resident form, as BASELINE's contract asks)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed `extra` rows (matcher / BA / stereo / vocabulary): used for the rocprofv3 summaries, whose per-kernel averages should cover the timed workload only")
@@ -294,6 +299,11 @@ def main():
             pp.ex.set_chunks(1)
             if KITTI:
                 pp.ex_r.set_chunks(1)
+    if args.host_images:
+        for pp in pipes:   # (one step first: the Frame batch's member arrays exist from its first build on)
+            pp.step()
+            pp.wait()
+            pp.enable_host_boundary()
     ex = pipes[0].ex
     cap = pipes[0].cap
     # ---- per keyframe (every `frames_per_keyframe` frames) the front part of Tracking::TrackReferenceKeyFrame (Tracking.cc:858-866):
@@ -562,7 +572,7 @@ def main():
         import parity
         lp, ll = pipes[jv], lba_prep[(args.steps - 1) % NLBA]
         lb = bows[jv] if bows else None
-        snap = dict(chain=parity.chain_snapshot(pkg, lp), pipe=lp, bow=None if lb is None else lb.get_results(),
+        snap = dict(chain=parity.chain_snapshot_host(pkg, lp) if args.host_images else parity.chain_snapshot(pkg, lp), pipe=lp, bow=None if lb is None else lb.get_results(),
                     kfw=kfws[jv].snapshot() if kfws else None,
                     lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win)])
     # ---- the same steps without the keyframe legs: the composite as round 2 measured it, and with the BoW leg only (comparability)
@@ -592,6 +602,32 @@ def main():
         dt_nobow = short_run(n2)
         bows.extend(saved)
         kfws.extend(saved_kfw)
+        if NATIVE:
+            record_lists()
+    # ---- the same steps with the reference's HOST boundary (--host-images): images up from page-locked memory, the Frame's members
+    # down into page-locked arrays, every step; checked against the oracle from those host arrays (below)
+    hb_run = None
+    if not args.host_images and not args.no_extra and not NO_LBA and os.environ.get("AOS2_BENCH_SKIP_HOST_BOUNDARY") != "1":
+        for pp in pipes:
+            pp.enable_host_boundary()
+        if NATIVE:
+            record_lists()
+        n2 = max(10, min(args.steps, 50))
+        while (n2 - 1) % NPIPE != jv:   # (its last step on the pipeline whose oracle results the check below holds)
+            n2 += 1
+        for i in range(2):
+            step(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n2):
+            step(i)
+        sync()
+        dt_hb = (time.perf_counter() - t0) / n2
+        jh = (n2 - 1) % NPIPE
+        hb_run = dict(dt=dt_hb, scen=scens[jh], up=pipes[jh].hb["up_bytes"], down=pipes[jh].hb["down_bytes"],
+                      snap=parity.chain_snapshot_host(pkg, pipes[jh]) if snap is not None else None)
+        for pp in pipes:
+            pp.enable_host_boundary(False)
         if NATIVE:
             record_lists()
     nm_host = pipes[0].d_nm.cpu().numpy()
@@ -694,6 +730,15 @@ def main():
                  "note": "the timed steps with round 3's LocalBA batch instead: %d windows of the SURVEY 8(d) size (%d keyframes, %d points, "
                          "%d edges), 4 distinct problems tiled" % (n_win, lba_hom[0]["n_poses"], lba_hom[0]["n_points"], lba_hom[0]["n_edges"]),
                  "frames_per_s": world * B / dt_hom, "ms_per_step": dt_hom * 1e3},
+             "composite_host_boundary": None if hb_run is None else {
+                 "note": "the timed steps with the reference's HOST boundary (bench.py --host-images makes it the timed form): every step's %d images "
+                         "arrive from page-locked host memory (ORBextractor::operator() takes a host cv::Mat, src/Frame.cc:276-282) and mvKeys / "
+                         "mDescriptors / N / mvuRight / mvDepth / mvpMapPoints / mvbOutlier / mTcw / the match counts of every frame land in page-locked "
+                         "host arrays; `value` above is the HBM-resident form BASELINE's contract asks for" % B,
+                 "frames_per_s": world * B / hb_run["dt"], "ms_per_step": hb_run["dt"] * 1e3,
+                 "host_to_device_MB_per_step": hb_run["up"] / 1e6, "device_to_host_MB_per_step": hb_run["down"] / 1e6,
+                 "pcie_GB_per_s": (hb_run["up"] + hb_run["down"]) / hb_run["dt"] / 1e9,
+                 "parity_checked_from_host_arrays": None},
              "composite_without_reference_keyframe_bow": None if dt_nobow is None else {
                  "note": "the timed steps without the per-keyframe legs (ComputeBoW + SearchByBoW, SearchForTriangulation + Fuse) = the "
                          "composite of round 2's bench line",
@@ -951,6 +996,9 @@ def main():
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
+                       "local_ba_handles_in_flight": NLBA, "step_runner": "native threads (csrc/host_runner.cpp)" if NATIVE else "python threads",
+                       "images": "page-locked host memory every step, results to page-locked host arrays (--host-images)" if args.host_images
+                                 else "resident in HBM (the host-boundary form: extra.composite_host_boundary)",
                        "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "local_ba_window_groups_per_handle": LBA_GROUPS,
                        "host_cpus_bound_to_the_gpus_numa_node": numa_cpus,
                        "frames_per_s_per_rank": [B * args.steps / d_ for d_ in dt_ranks],
@@ -1121,6 +1169,11 @@ def main():
                 kp_ = list(range(len(kq.kf1)))
                 bad += parity.keyframe_work_mismatches(kq, co, voc_nodes, kp_)
                 n_kfw_checked = len(kp_)
+            if hb_run is not None and hb_run["snap"] is not None:   # the host-boundary run's last step (same pipeline), from its HOST arrays
+                hb_run["bad"] = parity.chain_mismatches(hb_run["snap"], co, pos)
+                if isinstance(out.get("extra"), dict) and out["extra"].get("composite_host_boundary"):
+                    out["extra"]["composite_host_boundary"]["parity_checked_from_host_arrays"] = {
+                        "ok": not hb_run["bad"], "frames": len(pos), "n_mismatches": len(hb_run["bad"]), "first": hb_run["bad"][:3]}
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
             for w in wins:
                 bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")

@@ -132,6 +132,10 @@ int aos2_extractor_wait(aos2_extractor_t *e);
  * the stream of an aos2_frames_t, or 0 for the null stream) after this call runs after everything enqueued on the
  * extractor's streams before it.  Errors of the batches in flight are still reported by aos2_extractor_wait(). */
 int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream);
+/* The other direction: every batch enqueued on the extractor after this call runs after everything enqueued on `hip_stream` before
+ * it -- e.g. the caller's own hipMemcpyAsync of the images from page-locked host memory (the reference's images arrive as host
+ * cv::Mat, src/Frame.cc:276-282; bench.py --host-images).  Device-side, no host wait. */
+int aos2_extractor_wait_for_stream(aos2_extractor_t *e, void *hip_stream);
 /* The exchange step of the frame-sharded path: packs the device outputs of a batch into fixed-size
  * per-frame slots {int32 n; int32 pad[3]; KeyPoint[cap]; uint8 desc[cap][32]} (slot_bytes each, a multiple of 16, unused
  * tail zeroed) that one collective (RCCL gather over xGMI) moves to rank 0.  Enqueued on `hip_stream` behind the

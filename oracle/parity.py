@@ -123,6 +123,15 @@ def chain_snapshot(pkg, tc):
                 u_right=tc.cur.get(F.U_RIGHT), depth=tc.cur.get(F.DEPTH), nm=tc.d_nm.cpu().numpy())
 
 
+def chain_snapshot_host(pkg, tc):
+    """the same members from the page-locked HOST arrays a TrackingChain with enable_host_boundary() fills every step"""
+    hb, B, cap = tc.hb, tc.B, tc.cap
+    d = {k: h.numpy().copy() for k, _, h in hb["down"] + hb["members"]}
+    d["kps"] = d["kps"].view(np.uint8).reshape(B, cap, 28).copy().view(pkg.capi.KP_DTYPE).reshape(B, cap)
+    d.update(B=B, cap=cap)
+    return d
+
+
 def chain_mismatches(snap, co: ChainOracle, positions):
     """The device-resident chain's members (chain_snapshot) against the oracle chain, for the batch positions given
     (position b holds unique pair scen["index"][b])."""

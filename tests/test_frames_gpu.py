@@ -363,3 +363,88 @@ def test_stereo_frame_chain_vs_oracle(pkg, oracle, gpu):
     pkg.capi.compute_stereo_matches_device(tc.ex, tc.ex_r, tc.B, tc.d_kps.data_ptr(), tc.d_desc.data_ptr(), tc.d_n.data_ptr(), tc.r_kps.data_ptr(),
                                            tc.r_desc.data_ptr(), tc.r_n.data_ptr(), tc.cap, tc.mb, tc.mbf, ur.data_ptr(), dp.data_ptr())
     assert torch.equal(ur, tc.d_ur) and torch.equal(dp, tc.d_dp)
+
+
+def test_native_step_runner_replays_the_recorded_jobs(pkg, oracle, gpu):
+    """bench.py's step schedule on native threads (csrc/host_runner.cpp): the C calls of the tracking chain, the keyframe legs and a
+    LocalBA batch are recorded once (capi.recording: addresses + arguments, nothing executes) and replayed by the runner -- the chain
+    on the stepping thread, the other two on a thread each.  What the replays leave behind equals the oracle's results like the
+    directly called forms do, step after step, with two pipelines in flight; a failing call stops the runner with its status."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    capi = pkg.capi
+    scen = pkg.scenario.tracking_scenario(41, 12, n_unique=4)
+    voc = pkg.synth.synth_vocabulary(403, 10, 4)
+    pipes = [pkg.chain.TrackingChain(scen, n_local=800) for _ in range(2)]
+    bows = [pkg.chain.ReferenceKeyFrameBoW(p, voc, 6) for p in pipes]
+    kfws = [pkg.chain.KeyFrameWork(p, voc, n_kf=3, n_nb=3) for p in pipes]
+    probs = [pkg.synth.synth_lba_problem(90 + i, n_local=5 + 3 * i, n_fixed=3, n_points=300) for i in range(3)]
+    lba = pkg.LocalBA()
+    prep = lba.prepare_batch(probs)
+    r = capi.Runner(2, 1)
+    for j, p in enumerate(pipes):
+        with capi.recording() as c:
+            p.wait()
+        assert len(c) == 2
+        r.set_list(r.PIPE_WAIT, j, c)
+        with capi.recording() as c:
+            p.step()
+            bows[j].order()
+        assert len(c) == 9   # nothing ran: the batch has no members yet
+        assert p.cur.device_ptr(capi.Frames.TCW) == 0
+        r.set_list(r.PIPE_STEP, j, c)
+        with capi.recording() as c:
+            bows[j].run_calls()
+            kfws[j].run_calls()
+        r.set_list(r.KF_JOB, j, c)
+    with capi.recording() as c:
+        lba.solve_prepared(prep)
+    assert len(c) == 1
+    r.set_list(r.LBA_JOB, 0, c)
+    co = [parity.ChainOracle(scen, p) for p in pipes]
+    want = [oracle.lba_solve(q) for q in probs]
+    r.run(0, 5)
+    r.sync()
+    for j, p in enumerate(pipes):
+        assert parity.chain_mismatches(parity.chain_snapshot(pkg, p), co[j], range(12)) == []
+        assert parity.bow_leg_mismatches(bows[j].get_results(), co[j], voc, range(6)) == []
+        assert parity.keyframe_work_mismatches(kfws[j].snapshot(), co[j], voc, range(len(kfws[j].kf1))) == []
+    for w, q in enumerate(probs):
+        got = pkg.LocalBA._result(prep["R"][w], prep["arrs"][w])
+        assert parity.lba_mismatches(got, want[w], tag=f"window {w}") == []
+    assert len(r.stats(3)) == 5 and len(r.stats(1)) == 5 and len(r.stats(2)) == 5
+    # a call that fails stops the schedule and names itself
+    with capi.recording() as c:
+        capi.lib().aos2_frames_wait(None)
+    r.set_list(r.PIPE_STEP, 0, c)
+    with pytest.raises(pkg.AosError) as ei:
+        r.step(6)
+    assert "kind 1 index 0 call 0" in str(ei.value)
+
+
+def test_host_boundary_of_the_chain(pkg, oracle, gpu):
+    """bench.py --host-images: the images of every step come from page-locked host memory (one copy up on a stream of the harness, the
+    extraction ordered behind it on the device: aos2_extractor_wait_for_stream) and the Frame's members land in page-locked host
+    arrays behind the second PoseOptimization.  The host arrays hold what the device holds, and what the oracle computes -- also
+    after the device copy of the images was scribbled over between the steps (the chain really reads the host images)."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    for stereo in (False, True):
+        scen = pkg.scenario.tracking_scenario(43, 6, cfg="kitti" if stereo else "tum", n_unique=3, stereo=stereo)
+        tc = (pkg.chain.StereoTrackingChain if stereo else pkg.chain.TrackingChain)(scen, n_local=800)
+        tc.step()
+        tc.wait()
+        tc.enable_host_boundary()
+        co = parity.ChainOracle(scen, tc)
+        for _ in range(2):
+            tc.d_cur.zero_()
+            if stereo:
+                tc.d_right.zero_()
+            tc.torch.cuda.synchronize()
+            tc.step()
+            tc.wait()
+            host, dev = parity.chain_snapshot_host(pkg, tc), parity.chain_snapshot(pkg, tc)
+            for k in ("n", "kps", "desc", "mp", "outlier", "Tcw", "u_right", "depth", "nm"):
+                assert host[k].tobytes() == dev[k].tobytes(), k
+            assert parity.chain_mismatches(host, co, range(6)) == []
+        assert tc.hb["up_bytes"] == (2 if stereo else 1) * 6 * scen["w"] * scen["h"] and tc.hb["down_bytes"] > 6 * tc.cap * 60
