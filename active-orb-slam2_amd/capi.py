@@ -175,6 +175,7 @@ def lib():
             L.aos2_frames_search_local_points.argtypes = [vp, vp, vp, ci, cf, cf, vp]
             L.aos2_extractor_stream_wait.argtypes = [vp, vp]
             L.aos2_extractor_wait_for_stream.argtypes = [vp, vp]
+            L.aos2_lba_last_window_slots.argtypes = [vp, C.POINTER(C.c_int64)]
             L.aos2_extractor_pack_slots.argtypes = [vp, ci, vp, vp, vp, ci, vp, C.c_size_t, vp]
         _LIB = _RecLib(L)
     return _LIB
@@ -1223,6 +1224,12 @@ class LocalBA:
         a, b = C.c_int32(), C.c_int32()
         _check(self.L.aos2_lba_last_program(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def last_window_slots(self):
+        """trial slots of the last solve summed over the windows each round covered (include/aos2.h)"""
+        a = C.c_int64()
+        _check(self.L.aos2_lba_last_window_slots(self.h, C.byref(a)))
+        return int(a.value)
 
     def debug_stop_at_poll(self, poll):
         _check(self.L.aos2_lba_debug_stop_at_poll(self.h, int(poll)))

@@ -2450,6 +2450,16 @@ int aos2_lba_debug_host_phase(const aos2_lba_problem_t *problems, int n_problems
     return AOS2_OK;
 }
 
+int aos2_lba_last_window_slots(const aos2_lba_t *s, int64_t *window_slots)
+{
+    if (!s || !window_slots) {
+        set_error("aos2_lba_last_window_slots: bad argument");
+        return AOS2_ERR_ARG;
+    }
+    *window_slots = s->last_window_slots;
+    return AOS2_OK;
+}
+
 int aos2_lba_debug_stop_at_poll(aos2_lba_t *s, int poll)
 {
     if (!s || poll < 0) return AOS2_ERR_ARG;
@@ -2600,29 +2610,37 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     // each with an L2 of its own -- 4 MB, about one window's working set: the Hpl blocks a window's items share are then served by
     // one L2), the windows dealt to the XCDs largest first (every XCD gets about the same number of units), two windows of an XCD
     // at a time, unit by unit -- their DIAG units first.  Padding entries (w = -1) keep the 8 queues in step.
-    std::vector<SchurTask> tasks_g[2], pts_tasks_g[2], lin_tasks_g[2];
-    for (int g = 0; g < G; ++g) {
-        std::vector<SchurTask> &tasks = tasks_g[g];
-        const int w0 = goff[g], nwg = goff[g + 1] - goff[g];
+    // The task lists of a set of windows `ids` (indices into passes / L), the windows addressed as wmap(position): the Schur units
+    // (see above), then the landmark kernels' lists: block b of every window before block b + 1 of any (the windows advance side by
+    // side); k_lin: every landmark block first (the long dependent chains of the launch), then one task per free keyframe
+    struct TaskLists {
+        std::vector<SchurTask> schur, pts, lin;
+    };
+    const int lin_block = walk ? 256 : kLmBlock;
+    auto build_tasks = [&](const std::vector<int> &ids, auto &&wmap, TaskLists &T) {
+        std::vector<SchurTask> &tasks = T.schur;
+        const int nwg = (int)ids.size();
         std::vector<int> order(nwg);
-        std::iota(order.begin(), order.end(), w0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return passes[a].units.size() > passes[b].units.size(); });
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return passes[ids[a]].units.size() > passes[ids[b]].units.size(); });
         const int NX = nwg >= 8 ? 8 : 1;
         std::vector<std::vector<int>> xw(NX);
         std::vector<size_t> load(NX, 0);
-        for (int w : order) {
+        for (int k : order) {
             const int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            xw[x].push_back(w);
-            load[x] += passes[w].units.size();
+            xw[x].push_back(k);
+            load[x] += passes[ids[k]].units.size();
         }
         std::vector<std::vector<SchurTask>> qx(NX);
         for (int x = 0; x < NX; ++x)
             for (size_t k = 0; k < xw[x].size(); k += 2) {
                 const int a = xw[x][k], b = k + 1 < xw[x].size() ? xw[x][k + 1] : -1;
-                const size_t na = passes[a].units.size(), nb2 = b >= 0 ? passes[b].units.size() : 0;
-                for (size_t u = 0; u < std::max(na, nb2); ++u) {
-                    if (u < na) qx[x].push_back(SchurTask{a, passes[a].units[u]});
-                    if (u < nb2) qx[x].push_back(SchurTask{b, passes[b].units[u]});
+                const std::vector<int32_t> &ua = passes[ids[a]].units;
+                static const std::vector<int32_t> none;
+                const std::vector<int32_t> &ub = b >= 0 ? passes[ids[b]].units : none;
+                for (size_t u = 0; u < std::max(ua.size(), ub.size()); ++u) {
+                    if (u < ua.size()) qx[x].push_back(SchurTask{wmap(a), ua[u]});
+                    if (u < ub.size()) qx[x].push_back(SchurTask{wmap(b), ub[u]});
                 }
             }
         size_t mxq = 0;
@@ -2630,35 +2648,41 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         tasks.assign(mxq * NX, SchurTask{-1, 0});
         for (int x = 0; x < NX; ++x)
             for (size_t k = 0; k < qx[x].size(); ++k) tasks[k * NX + x] = qx[x][k];
-    }
-    // ... and the landmark kernels' lists: block b of every window before block b + 1 of any (the windows advance side by side);
-    // k_lin: every landmark block first (the long dependent chains of the launch), then one task per free keyframe
+        int mx_pb = 0, mx_lb = 0, mx_k = 0;
+        std::vector<int> npb(nwg), nlb(nwg);
+        for (int k = 0; k < nwg; ++k) {
+            const Pass &S = passes[ids[k]];
+            npb[k] = std::max(1, (S.nl + lm_per_block - 1) / lm_per_block);   // = WinLayout::n_part
+            nlb[k] = (S.nl + lin_block - 1) / lin_block;
+            mx_pb = std::max(mx_pb, npb[k]); mx_lb = std::max(mx_lb, nlb[k]); mx_k = std::max(mx_k, S.np);
+        }
+        T.pts.clear();
+        T.lin.clear();
+        for (int b = 0; b < mx_pb; ++b)
+            for (int k = 0; k < nwg; ++k)
+                if (b < npb[k]) T.pts.push_back(SchurTask{wmap(k), b});
+        for (int b = 0; b < mx_lb; ++b)
+            for (int k = 0; k < nwg; ++k)
+                if (b < nlb[k]) T.lin.push_back(SchurTask{wmap(k), b});
+        for (int kf = 0; kf < mx_k; ++kf)
+            for (int k = 0; k < nwg; ++k)
+                if (kf < passes[ids[k]].np) T.lin.push_back(SchurTask{wmap(k), (1 << 28) | kf});
+    };
+    TaskLists TL[2];
+    std::vector<SchurTask> *tasks_g[2] = {&TL[0].schur, &TL[1].schur}, *pts_tasks_g[2] = {&TL[0].pts, &TL[1].pts}, *lin_tasks_g[2] = {&TL[0].lin, &TL[1].lin};
     size_t n_all_tasks = 0;
     for (int g = 0; g < G; ++g) {
-        std::vector<SchurTask> &pts_tasks = pts_tasks_g[g], &lin_tasks = lin_tasks_g[g];
-        const int w0 = goff[g], w1 = goff[g + 1];
-        const int lin_block = walk ? 256 : kLmBlock;
-        int mx_pb = 0, mx_lb = 0, mx_k = 0;
-        std::vector<int> npb(nw), nlb(nw);
-        for (int i = w0; i < w1; ++i) {
-            npb[i] = std::max(1, (passes[i].nl + lm_per_block - 1) / lm_per_block);   // = WinLayout::n_part
-            nlb[i] = (passes[i].nl + lin_block - 1) / lin_block;
-            mx_pb = std::max(mx_pb, npb[i]); mx_lb = std::max(mx_lb, nlb[i]); mx_k = std::max(mx_k, passes[i].np);
-        }
-        for (int b = 0; b < mx_pb; ++b)
-            for (int i = w0; i < w1; ++i)
-                if (b < npb[i]) pts_tasks.push_back(SchurTask{i, b});
-        for (int b = 0; b < mx_lb; ++b)
-            for (int i = w0; i < w1; ++i)
-                if (b < nlb[i]) lin_tasks.push_back(SchurTask{i, b});
-        for (int k = 0; k < mx_k; ++k)
-            for (int i = w0; i < w1; ++i)
-                if (k < passes[i].np) lin_tasks.push_back(SchurTask{i, (1 << 28) | k});
-        n_all_tasks += tasks_g[g].size() + pts_tasks.size() + lin_tasks.size();
+        std::vector<int> ids(goff[g + 1] - goff[g]);
+        std::iota(ids.begin(), ids.end(), goff[g]);
+        build_tasks(ids, [&](int k) { return ids[k]; }, TL[g]);   // (the groups' kernels index the whole descriptor array)
+        n_all_tasks += TL[g].schur.size() + TL[g].pts.size() + TL[g].lin.size();
     }
     const size_t o_tasks = B.take(sizeof(SchurTask) * n_all_tasks + 8);
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
+    // (a continuation round runs on the windows that are not finished, compacted: their descriptors and task lists go here)
+    const size_t cont_bytes = sizeof(LbaWin) * (size_t)nw + sizeof(SchurTask) * n_all_tasks + 64;
+    const size_t o_cont = B.take(cont_bytes);
     for (int i = 0; i < nw; ++i) {
         const aos2_lba_problem_t *p = problems + act[i];
         const Pass &S = passes[i];
@@ -2697,7 +2721,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     }
     const size_t res_bytes = B.size - o_res;
     if ((st = s->arena.alloc(B.size + 256))) return st;
-    if ((st = s->h_in.alloc(staged_bytes + 256))) return st;
+    if ((st = s->h_in.alloc(o_cont + cont_bytes + 256))) return st;
     if ((st = s->h_stage.alloc(res_bytes + 256))) return st;
     if ((st = s->h_abort.alloc((size_t)nw + 1))) return st;
     uint8_t *base = s->arena.p, *hin = s->h_in.p;
@@ -2815,7 +2839,7 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         size_t o = o_tasks;
         for (int g = 0; g < G; ++g)
             for (int k = 0; k < 3; ++k) {
-                const std::vector<SchurTask> &v = k == 0 ? tasks_g[g] : k == 1 ? pts_tasks_g[g] : lin_tasks_g[g];
+                const std::vector<SchurTask> &v = k == 0 ? *tasks_g[g] : k == 1 ? *pts_tasks_g[g] : *lin_tasks_g[g];
                 (k == 0 ? d_schur_tasks : k == 1 ? d_pts_tasks : d_lin_tasks)[g] = (const SchurTask *)(base + o);
                 if (!v.empty()) memcpy(hin + o, v.data(), sizeof(SchurTask) * v.size());
                 o += sizeof(SchurTask) * v.size();
@@ -2832,66 +2856,82 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         AOS2_HIP_CHECK(hipEventRecord(s->ev_up, q));
         AOS2_HIP_CHECK(hipStreamWaitEvent(gq[1], s->ev_up, 0));
     }
-    auto enqueue_points = [&](int g, int solve) {
+    // What a launch sequence runs on: the descriptor array its task lists index (`wins`), the first descriptor and the number of
+    // windows of the kernels that take one workgroup row per window (`blk`, nw), the lists, the largest dimensions, the streams
+    struct Prog {
+        const LbaWin *wins, *blk;
+        int nw;
+        const SchurTask *schur, *pts, *lin;
+        size_t n_schur, n_pts, n_lin;
+        GroupDims D;
+        hipStream_t q, q2;
+        hipEvent_t fork, join;
+    };
+    auto enqueue_points = [&](const Prog &P, int solve) {
         if (walk)
-            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)pts_tasks_g[g].size()), dim3(128), 0, gq[g], dw, d_pts_tasks[g], solve);
+            hipLaunchKernelGGL(k_points_walk, dim3((unsigned)P.n_pts), dim3(128), 0, P.q, P.wins, P.pts, solve);
         else
-            hipLaunchKernelGGL(k_points, dim3((unsigned)pts_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_pts_tasks[g], solve);
+            hipLaunchKernelGGL(k_points, dim3((unsigned)P.n_pts), dim3(256), 0, P.q, P.wins, P.pts, solve);
     };
-    auto enqueue_lin = [&](int g, int init) {
-        if (lin_tasks_g[g].empty()) return;
+    auto enqueue_lin = [&](const Prog &P, int init) {
+        if (!P.n_lin) return;
         if (walk)
-            hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)lin_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_lin_tasks[g], init);
+            hipLaunchKernelGGL(k_lin<true>, dim3((unsigned)P.n_lin), dim3(256), 0, P.q, P.wins, P.lin, init);
         else
-            hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)lin_tasks_g[g].size()), dim3(256), 0, gq[g], dw, d_lin_tasks[g], init);
+            hipLaunchKernelGGL(k_lin<false>, dim3((unsigned)P.n_lin), dim3(256), 0, P.q, P.wins, P.lin, init);
     };
-    auto nwg = [&](int g) { return goff[g + 1] - goff[g]; };
-    auto enqueue_init = [&](int g) {
-        enqueue_points(g, 0);
-        enqueue_lin(g, 1);
-        hipLaunchKernelGGL(k_lm_init, dim3(nwg(g)), dim3(1024), 0, gq[g], dw + goff[g]);
+    auto enqueue_init = [&](const Prog &P) {
+        enqueue_points(P, 0);
+        enqueue_lin(P, 1);
+        hipLaunchKernelGGL(k_lm_init, dim3(P.nw), dim3(1024), 0, P.q, P.blk);
     };
-    // one Levenberg-Marquardt trial: 4 launches (5 with a reduced system beyond LDS)
+    // one Levenberg-Marquardt trial: 4 launches (5 with reduced systems of two kinds)
     bool stagger_pending = G == 2 && !getenv("AOS2_LBA_NO_STAGGER");
-    auto enqueue_trial = [&](int g) {
-        const GroupDims &D = gd[g];
-        if (!tasks_g[g].empty()) hipLaunchKernelGGL(k_schur, dim3((unsigned)tasks_g[g].size()), dim3(kSchurThreads), 0, gq[g], dw, d_schur_tasks[g]);
-        if (g == 0 && stagger_pending) {   // the other group starts here: half a trial behind
+    auto enqueue_trial = [&](const Prog &P, bool first_group) {
+        const GroupDims &D = P.D;
+        if (P.n_schur) hipLaunchKernelGGL(k_schur, dim3((unsigned)P.n_schur), dim3(kSchurThreads), 0, P.q, P.wins, P.schur);
+        if (first_group && stagger_pending) {   // the other group starts here: half a trial behind
             (void)hipEventRecord(s->ev_stag, gq[0]);
             (void)hipStreamWaitEvent(gq[1], s->ev_stag, 0);
             stagger_pending = false;
         }
-        // the two forms of the reduced-system kernel work on different windows: side by side (the LDS form on a stream of its own)
+        // the forms of the reduced-system kernel work on different windows: side by side (one of them on a stream of its own)
         // (k_ldlt_reg and k_ldlt_lds never meet in one call: AOS2_LDLT chooses for the whole call)
         const bool both = D.any_glob && (D.any_lds || D.any_reg);
         if (both) {
-            (void)hipEventRecord(gfork[g], gq[g]);
-            (void)hipStreamWaitEvent(gq2[g], gfork[g], 0);
+            (void)hipEventRecord(P.fork, P.q);
+            (void)hipStreamWaitEvent(P.q2, P.fork, 0);
         }
         if (D.any_lds) {
             const size_t need = ((size_t)D.mx_npad_lds * (D.mx_npad_lds + 1) + (size_t)D.mx_npad_lds * 17 + 4 * (size_t)D.mx_npad_lds + 2 * 16 * 17 + 16) * sizeof(double);
-            hipLaunchKernelGGL(k_ldlt_lds, dim3(nwg(g)), dim3(512), need, both ? gq2[g] : gq[g], dw + goff[g]);
+            hipLaunchKernelGGL(k_ldlt_lds, dim3(P.nw), dim3(512), need, both ? P.q2 : P.q, P.blk);
         }
         if (D.any_reg)
-            hipLaunchKernelGGL(k_ldlt_reg, dim3(nwg(g)), dim3(kLrThreads), ldlt_reg_lds_doubles(D.mx_npad_reg) * sizeof(double), both ? gq2[g] : gq[g], dw + goff[g]);
+            hipLaunchKernelGGL(k_ldlt_reg, dim3(P.nw), dim3(kLrThreads), ldlt_reg_lds_doubles(D.mx_npad_reg) * sizeof(double), both ? P.q2 : P.q, P.blk);
         if (D.any_glob)
-            hipLaunchKernelGGL(k_ldlt_dev, dim3(nwg(g)), dim3(512), ((size_t)D.mx_npad_glob * 17 + 4 * (size_t)D.mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), gq[g],
-                               dw + goff[g]);
+            hipLaunchKernelGGL(k_ldlt_dev, dim3(P.nw), dim3(512), ((size_t)D.mx_npad_glob * 17 + 4 * (size_t)D.mx_npad_glob + 3 * 16 * 17 + 16) * sizeof(double), P.q,
+                               P.blk);
         if (both) {
-            (void)hipEventRecord(gjoin[g], gq2[g]);
-            (void)hipStreamWaitEvent(gq[g], gjoin[g], 0);
+            (void)hipEventRecord(P.join, P.q2);
+            (void)hipStreamWaitEvent(P.q, P.join, 0);
         }
-        enqueue_points(g, 1);   // + the LM decision in its last workgroup
-        enqueue_lin(g, 0);
+        enqueue_points(P, 1);   // + the LM decision in its last workgroup
+        enqueue_lin(P, 0);
     };
-    auto enqueue_transition = [&](int g) {
-        hipLaunchKernelGGL(k_transition, dim3(blocks(gd[g].mx_E, 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g]);
+    auto enqueue_transition = [&](const Prog &P) {
+        hipLaunchKernelGGL(k_transition, dim3(blocks(P.D.mx_E, 256), P.nw), dim3(256), 0, P.q, P.blk);
     };
+    Prog PG[2];
+    for (int g = 0; g < G; ++g)
+        PG[g] = Prog{dw, dw + goff[g], goff[g + 1] - goff[g], d_schur_tasks[g], d_pts_tasks[g], d_lin_tasks[g], tasks_g[g]->size(), pts_tasks_g[g]->size(),
+                     lin_tasks_g[g]->size(), gd[g], gq[g], gq2[g], gfork[g], gjoin[g]};
     // results (and states) come back as one copy; the host forwards pbStopFlag into the mapped abort words meanwhile
-    auto finish = [&]() -> int {
-        for (int g = 0; g < G; ++g)
-            hipLaunchKernelGGL(k_final, dim3(blocks(std::max(gd[g].mx_E, gd[g].mx_pts), 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g]);
-        if (G == 2) {
+    auto finish = [&](const Prog *progs, int n_progs) -> int {
+        for (int g = 0; g < n_progs; ++g) {
+            const Prog &P = progs[g];
+            hipLaunchKernelGGL(k_final, dim3(blocks(std::max(P.D.mx_E, P.D.mx_pts), 256), P.nw), dim3(256), 0, P.q, P.blk);
+        }
+        if (n_progs == 2) {
             AOS2_HIP_CHECK(hipEventRecord(s->ev_done_b, gq[1]));
             AOS2_HIP_CHECK(hipStreamWaitEvent(q, s->ev_done_b, 0));
         }
@@ -2913,40 +2953,105 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         max_i2 = std::max(max_i2, problems[act[i]].iters_second);
     }
     rg = std::make_unique<RoctxRange>("LocalBA::optimize(5) + outlier pass + optimize(10) + inlier check (one device program)");
-    // the program: one more trial than iterations per optimisation (room for one rejected step without a second round)
-    s->last_trial_slots = (max_i1 > 0 ? max_i1 + 1 : 0) + (max_i2 > 0 ? max_i2 + 1 : 0);
+    // The program: as many trials as iterations per optimisation -- what every window needs whose steps are all accepted.  A window
+    // with rejected steps is not finished when the program ends: it leaves with the others' results and gets a continuation round
+    // sized for what it still needs, together with the (few) windows like it, compacted (below).  Rounds 2-4 enqueued one spare
+    // trial per optimisation for EVERY window instead (AOS2_LBA_SPARE_SLOTS=1): 13 % of the launches of a batch whose windows need none.
+    const int spare = getenv("AOS2_LBA_SPARE_SLOTS") ? atoi(getenv("AOS2_LBA_SPARE_SLOTS")) : 0;
+    const int slots1 = max_i1 > 0 ? max_i1 + spare : 0, slots2 = max_i2 > 0 ? max_i2 + spare : 0;
+    s->last_trial_slots = slots1 + slots2;
+    s->last_window_slots = (long long)(slots1 + slots2) * nw;
     s->last_host_rounds = 1;
     for (int g = 0; g < G; ++g) {
-        hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(gd[g].mx_E, gd[g].mx_pts), 256), nwg(g)), dim3(256), 0, gq[g], dw + goff[g], s->debug_stop_at_poll);
+        const Prog &P = PG[g];
+        hipLaunchKernelGGL(k_prepare, dim3(blocks(std::max(P.D.mx_E, P.D.mx_pts), 256), P.nw), dim3(256), 0, P.q, P.blk, s->debug_stop_at_poll);
         if (max_i1 > 0) {
-            enqueue_init(g);
-            for (int t = 0; t < max_i1 + 1; ++t) enqueue_trial(g);
+            enqueue_init(P);
+            for (int t = 0; t < slots1; ++t) enqueue_trial(P, g == 0);
         }
-        enqueue_transition(g);
+        enqueue_transition(P);
         if (max_i2 > 0) {
-            enqueue_init(g);
-            for (int t = 0; t < max_i2 + 1; ++t) enqueue_trial(g);
+            enqueue_init(P);
+            for (int t = 0; t < slots2; ++t) enqueue_trial(P, g == 0);
         }
     }
-    if ((st = finish())) return st;
+    if ((st = finish(PG, G))) return st;
     lap("program");
     auto state_of = [&](int i) { return reinterpret_cast<const LmState *>(s->h_stage.p + (L[i].st - o_res)); };
     for (int round = 0;; ++round) {
-        bool all = true;
-        for (int i = 0; i < nw; ++i) all &= state_of(i)->phase == 3;
-        if (all) break;
+        // the windows that are not finished, what they still need at most if no further step is rejected
+        std::vector<int> todo;
+        int need1 = 0, need2 = 0;
+        bool before_second = false;
+        for (int i = 0; i < nw; ++i) {
+            const LmState *ls = state_of(i);
+            if (ls->phase == 3) continue;
+            todo.push_back(i);
+            if (ls->phase == 0) need1 = std::max(need1, std::max(1, ls->iters_max[0] - ls->it));
+            if (ls->phase <= 1) before_second = true;
+            if (ls->phase == 2) need2 = std::max(need2, std::max(1, ls->iters_max[1] - ls->it));
+        }
+        if (todo.empty()) break;
         if (round > 64) {   // 2 x 10 iterations x 10 trials at most: cannot happen
             set_error("internal: LocalBA program did not finish");
             return AOS2_ERR_ARG;
         }
-        for (int g = 0; g < G; ++g) {
-            enqueue_transition(g);
-            enqueue_init(g);
-            for (int t = 0; t < 4; ++t) enqueue_trial(g);
+        if (before_second) need2 = std::max(need2, max_i2);
+        // their descriptors, compacted, and task lists that address them by position
+        TaskLists TC;
+        build_tasks(todo, [](int k) { return k; }, TC);
+        const size_t tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
+        if (sizeof(LbaWin) * todo.size() + tc_bytes > cont_bytes) {
+            set_error("internal: continuation region");
+            return AOS2_ERR_ARG;
         }
-        s->last_trial_slots += 4;
+        uint8_t *hc = hin + o_cont;
+        Prog PC;
+        PC.D = GroupDims();
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const int i = todo[k];
+            reinterpret_cast<LbaWin *>(hc)[k] = hw[i];
+            const WinLayout &l = L[i];
+            const Pass &S = passes[i];
+            if (S.np > 0) {
+                if (l.ldlt_lds == 2) {
+                    PC.D.any_reg = true;
+                    PC.D.mx_npad_reg = std::max(PC.D.mx_npad_reg, l.npad);
+                } else if (l.ldlt_lds) {
+                    PC.D.any_lds = true;
+                    PC.D.mx_npad_lds = std::max(PC.D.mx_npad_lds, l.npad);
+                } else {
+                    PC.D.any_glob = true;
+                    PC.D.mx_npad_glob = std::max(PC.D.mx_npad_glob, l.npad);
+                }
+            }
+            PC.D.mx_E = std::max(PC.D.mx_E, problems[act[i]].n_edges);
+            PC.D.mx_pts = std::max(PC.D.mx_pts, std::max(problems[act[i]].n_points, problems[act[i]].n_poses));
+        }
+        size_t o = sizeof(LbaWin) * todo.size();
+        const SchurTask *dt[3];
+        const std::vector<SchurTask> *tv[3] = {&TC.schur, &TC.pts, &TC.lin};
+        for (int k = 0; k < 3; ++k) {
+            dt[k] = (const SchurTask *)(base + o_cont + o);
+            if (!tv[k]->empty()) memcpy(hc + o, tv[k]->data(), sizeof(SchurTask) * tv[k]->size());
+            o += sizeof(SchurTask) * tv[k]->size();
+        }
+        AOS2_HIP_CHECK(hipMemcpyAsync(base + o_cont, hc, o, hipMemcpyHostToDevice, q));
+        PC.wins = PC.blk = (const LbaWin *)(base + o_cont);
+        PC.nw = (int)todo.size();
+        PC.schur = dt[0]; PC.pts = dt[1]; PC.lin = dt[2];
+        PC.n_schur = TC.schur.size(); PC.n_pts = TC.pts.size(); PC.n_lin = TC.lin.size();
+        PC.q = gq[0]; PC.q2 = gq2[0]; PC.fork = gfork[0]; PC.join = gjoin[0];
+        for (int t = 0; t < need1; ++t) enqueue_trial(PC, false);
+        if (before_second) {
+            enqueue_transition(PC);
+            enqueue_init(PC);
+        }
+        for (int t = 0; t < need2; ++t) enqueue_trial(PC, false);
+        s->last_trial_slots += need1 + need2;
+        s->last_window_slots += (long long)(need1 + need2) * (long long)todo.size();
         s->last_host_rounds++;
-        if ((st = finish())) return st;
+        if ((st = finish(&PC, 1))) return st;
     }
     lap("continuation");
     rg = std::make_unique<RoctxRange>("LocalBA::write-back");

@@ -384,6 +384,7 @@ struct aos2_lba {
     void *lba_cache = nullptr;          // LocalBA: host-side structure buffers kept between calls (lba.hip: LbaCache)
     int host_threads = 0;               // LocalBA: worker threads of the per-window host work (0 = default, aos2_lba_set_host_threads)
     int last_trial_slots = 0, last_host_rounds = 0;   // the device program of the last solve (aos2_lba_last_program)
+    long long last_window_slots = 0;                  // ... and its trial slots summed over the windows each round covered
 };
 
 namespace aos2 {

@@ -711,11 +711,12 @@ def synth_lba_problem(seed: int, n_local: int = 20, n_fixed: int = 30, n_points:
                 fx=fx, fy=fy, cx=cx, cy=cy, bf=bf)
 
 
-def lba_window_mix(seed: int, n_windows: int):
+def lba_window_mix(seed: int, n_windows: int, hard_every: int = 0, hard=(0.5, 3.0, 2.0)):
     """Parameters of `n_windows` DIFFERENT LocalBundleAdjustment windows like LocalMapping meets them (src/Optimizer.cc:457-505:
     the local keyframes are the covisibility neighbourhood of the new keyframe, the fixed ones whatever else sees its points):
     10-40 local keyframes, 0.5-1.5 times as many fixed ones, 3 000-9 000 candidate points (about 70 % of them end up in the
-    window: 2-6 k), 4-8 observations per point, 5-20 % gross outliers.  Keyword dicts for synth_lba_problem()."""
+    window: 2-6 k), 4-8 observations per point, 5-20 % gross outliers.  hard_every = k: every k-th window starts far from the optimum
+    (perturb_lba_problem: steps get rejected, some optimisations stop early).  Keyword dicts for synth_lba_problem() / _lba_from_kwargs()."""
     rng = np.random.default_rng(31000 + seed)
     mix = []
     for i in range(n_windows):
@@ -723,11 +724,36 @@ def lba_window_mix(seed: int, n_windows: int):
         n_fixed = int(np.clip(round(n_local * rng.uniform(0.5, 1.5)), 2, 45))
         mix.append(dict(seed=100000 + 1000 * seed + i, n_local=n_local, n_fixed=n_fixed, n_points=int(rng.integers(3000, 9001)),
                         obs_per_point=int(rng.integers(4, 9)), outlier_frac=float(rng.uniform(0.05, 0.20))))
+        if hard_every and i % hard_every == hard_every - 1:   # a window that starts off the optimum: rejected steps (perturb_lba_problem)
+            mix[-1]["hard"] = tuple(hard)
+            mix[-1]["stereo_frac"] = 0.3   # (mostly monocular observations: depth is what a bad start gets wrong)
     return mix
 
 
+def perturb_lba_problem(prob, seed, rot_sigma, trans_sigma, point_sigma):
+    """the free keyframes and the points of a window moved away from the optimum (a rotation of rot_sigma rad about a random axis,
+    Gaussian offsets): Levenberg-Marquardt then rejects steps (lambda grows, the estimates are restored) and may give up"""
+    def rot(axis, a):
+        axis = axis / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    rng = np.random.default_rng(seed)
+    T = prob["pose_Tcw"].copy().reshape(-1, 4, 4)
+    for i in range(len(T)):
+        if not prob["pose_fixed"][i]:
+            R = rot(rng.normal(size=3), rot_sigma * rng.normal())
+            T[i, :3, :3] = (R @ T[i, :3, :3]).astype(np.float32)
+            T[i, :3, 3] += rng.normal(size=3).astype(np.float32) * trans_sigma
+    prob["pose_Tcw"] = T.reshape(prob["pose_Tcw"].shape).astype(np.float32)
+    prob["point_xyz"] = (prob["point_xyz"] + rng.normal(size=prob["point_xyz"].shape) * point_sigma).astype(np.float32)
+    return prob
+
+
 def _lba_from_kwargs(kw):
-    return synth_lba_problem(**kw)
+    kw = dict(kw)
+    hard = kw.pop("hard", None)
+    prob = synth_lba_problem(**kw)
+    return perturb_lba_problem(prob, kw["seed"], *hard) if hard else prob
 
 
 def synth_lba_problems(mix):

@@ -348,7 +348,10 @@ def main():
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)
         lba_probs = lba_unique
     elif args.lba_mix == "heterogeneous":
-        lba_mix = pkg.synth.lba_window_mix(rank, n_win)
+        # (AOS2_BENCH_LBA_HARD_EVERY=k: every k-th window starts far from the optimum -- rejected steps, early ends.  Not in the timed,
+        # parity-checked step: 15 trials from a bad start do not converge, and two trajectories that agree in every decision still end
+        # 1e-4..1e-2 apart in some points; such a batch is measured and checked on its own: extra.local_ba_batch_with_rejected_steps)
+        lba_mix = pkg.synth.lba_window_mix(rank, n_win, hard_every=int(os.environ.get("AOS2_BENCH_LBA_HARD_EVERY", "0")))
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)
         lba_probs = lba_unique
     else:
@@ -551,16 +554,19 @@ def main():
     if not NO_LBA:
         jl_ = (args.steps - 1) % NLBA
         slots, rounds = lbas[jl_].last_program()
+        wslots = lbas[jl_].last_window_slots()
         need = [int(r_.trials_first) + int(r_.trials_second) for r_ in lba_prep[jl_]["R"]]
         edges = [int(q_["n_edges"]) for q_ in lba_probs]
-        lock_step = {"trial_slots_enqueued_per_window": slots, "host_rounds": rounds, "windows": n_win,
+        lock_step = {"trial_slots_enqueued": slots, "host_rounds": rounds, "windows": n_win, "window_slots": wslots,
                      "trials_needed_min_mean_max": [min(need), float(np.mean(need)), max(need)],
-                     "slots_over_trials": slots * n_win / max(1, sum(need)),
-                     "edge_weighted_slots_over_trials": slots * sum(edges) / max(1, sum(n_ * e_ for n_, e_ in zip(need, edges))),
+                     "windows_with_rejected_or_skipped_trials": int(sum(1 for n_ in need if n_ != 15)),
+                     "slots_over_trials": wslots / max(1, sum(need)),
                      "largest_window_edges_over_mean": max(edges) / (sum(edges) / len(edges)),
-                     "note": "every launch of the program covers every window of the batch with a grid sized for the largest one: "
-                             "slots_over_trials = trial slots x windows / sum of trials needed (1.0 = no window waits for another's "
-                             "rejected steps), largest_window_edges_over_mean = the idle share of the grid's blocks"}
+                     "note": "the first round of the program holds as many trials as there are iterations (5 + 10) for every window; a window "
+                             "that is not finished then (rejected steps) gets a continuation round with the other unfinished windows only, "
+                             "compacted, sized for what it still needs.  slots_over_trials = trial slots summed over the windows each round "
+                             "covered / trials the windows needed (1.0 = no launch covered a window with nothing left to do; a window whose "
+                             "optimisation ends early leaves its remaining slots of the round empty)"}
     jv = (args.steps - 1) % NPIPE   # the pipeline of the last timed step: the one the oracle checks (and the cpu_baseline sample runs)
     scen_v = scens[jv]
     # ---- what the LAST timed step left behind, copied before anything else reuses the buffers: checked against the oracle
@@ -630,6 +636,30 @@ def main():
             pp.enable_host_boundary(False)
         if NATIVE:
             record_lists()
+    # ---- a LocalBA batch whose windows need DIFFERENT numbers of trials (every 8th window starts far from the optimum: rejected steps,
+    # optimisations that end early), alone on the device: the program's rounds, the lock-step ratio, the decisions against the oracle
+    lba_hard = None
+    if rank == 0 and world == 1 and not args.no_extra and not NO_LBA and not KITTI and args.lba_mix == "heterogeneous":
+        hm = pkg.synth.lba_window_mix(rank, n_win, hard_every=8)
+        hp = pkg.synth.synth_lba_problems(hm)
+        hprep = lbas[0].prepare_batch(hp)
+        lbas[0].set_window_groups(0)
+        lbas[0].solve_prepared(hprep)
+        tms = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            lbas[0].solve_prepared(hprep)
+            tms.append((time.perf_counter() - ta) * 1e3)
+        lbas[0].set_window_groups(LBA_GROUPS)
+        hneed = [int(r_.trials_first) + int(r_.trials_second) for r_ in hprep["R"]]
+        lba_hard = dict(mix=hm, probs=hp, res=[pkg.LocalBA._result(hprep["R"][w], tuple(a.copy() for a in hprep["arrs"][w])) for w in range(n_win)],
+                        row={"windows": n_win, "windows_started_off_the_optimum": sum(1 for m_ in hm if "hard" in m_),
+                             "call_wall_ms_median": float(np.median(tms)), "device_ms": float(hprep["R"][0].ms_device),
+                             "trial_slots_enqueued": lbas[0].last_program()[0], "host_rounds": lbas[0].last_program()[1],
+                             "trials_needed_min_mean_max": [min(hneed), float(np.mean(hneed)), max(hneed)],
+                             "windows_not_needing_15_trials": int(sum(1 for n_ in hneed if n_ != 15)),
+                             "slots_over_trials": lbas[0].last_window_slots() / max(1, sum(hneed))})
     nm_host = pipes[0].d_nm.cpu().numpy()
     lba_res = lba_prep[0]["R"]
     # ---- stage times of one synchronous pass (every stage waited for: wall clock incl. launch latency)
@@ -730,6 +760,7 @@ def main():
                  "note": "the timed steps with round 3's LocalBA batch instead: %d windows of the SURVEY 8(d) size (%d keyframes, %d points, "
                          "%d edges), 4 distinct problems tiled" % (n_win, lba_hom[0]["n_poses"], lba_hom[0]["n_points"], lba_hom[0]["n_edges"]),
                  "frames_per_s": world * B / dt_hom, "ms_per_step": dt_hom * 1e3},
+             "local_ba_batch_with_rejected_steps": None if lba_hard is None else lba_hard["row"],
              "composite_host_boundary": None if hb_run is None else {
                  "note": "the timed steps with the reference's HOST boundary (bench.py --host-images makes it the timed form): every step's %d images "
                          "arrive from page-locked host memory (ORBextractor::operator() takes a host cv::Mat, src/Frame.cc:276-282) and mvKeys / "
@@ -1174,6 +1205,28 @@ def main():
                 if isinstance(out.get("extra"), dict) and out["extra"].get("composite_host_boundary"):
                     out["extra"]["composite_host_boundary"]["parity_checked_from_host_arrays"] = {
                         "ok": not hb_run["bad"], "frames": len(pos), "n_mismatches": len(hb_run["bad"]), "first": hb_run["bad"][:3]}
+            if lba_hard is not None and isinstance(out.get("extra"), dict) and out["extra"].get("local_ba_batch_with_rejected_steps"):
+                # every decision (iterations, trials, outlier sets) equals the oracle's; the end points of the windows that started off the
+                # optimum are reported, not gated: 15 trials do not converge from there, and equal decisions still end 1e-4..1e-2 apart
+                from concurrent.futures import ThreadPoolExecutor as _TPE3
+                with _TPE3(n_thr) as pool4:
+                    hw_ = list(pool4.map(O.lba_solve, lba_hard["probs"]))
+                dec_bad, wp, wx, wp_h, wx_h = 0, 0.0, 0.0, 0.0, 0.0
+                for m_, r_, w_ in zip(lba_hard["mix"], lba_hard["res"], hw_):
+                    if r_["iters"] != w_["iters"] or sum(r_["trials"]) != w_["trials"] or not (r_["edge_outlier"] == w_["edge_outlier"]).all():
+                        dec_bad += 1
+                    dp_, dx_ = float(np.abs(r_["pose_Tcw"] - w_["pose_Tcw"]).max()), float(np.abs(r_["point_xyz"] - w_["point_xyz"]).max())
+                    if "hard" in m_:
+                        wp_h, wx_h = max(wp_h, dp_), max(wx_h, dx_)
+                    else:
+                        wp, wx = max(wp, dp_), max(wx, dx_)
+                out["extra"]["local_ba_batch_with_rejected_steps"]["against_the_oracle"] = {
+                    "windows_with_a_different_decision": dec_bad, "worst_abs_diff_ordinary_windows": {"pose": wp, "point": wx},
+                    "worst_abs_diff_windows_started_off_the_optimum": {"pose": wp_h, "point": wx_h},
+                    "note": "iterations, trials and outlier sets of every window equal the oracle's; ordinary windows within the line's 1e-5; a window "
+                            "that starts far off does not converge in 15 trials, and two runs that take the same decisions still end apart"}
+                if dec_bad or wp > 1e-5 or wx > 1.6e-5:
+                    bad.append("LocalBA batch with rejected steps: %d windows decide differently, ordinary windows differ by %g / %g" % (dec_bad, wp, wx))
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
             for w in wins:
                 bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")

@@ -645,10 +645,14 @@ int aos2_lba_set_host_threads(aos2_lba_t *s, int n);
  * faster form when other work shares the device (two handles solving side by side beside the tracking kernels: 61 k against 54 k
  * frames/s of bench.py's composite); 0 = default: 2 for calls of >= 16 windows.  Results do not depend on it.  No reference equivalent. */
 int aos2_lba_set_window_groups(aos2_lba_t *s, int n);
-/* The device program of the last solve of this handle: `trial_slots` = Levenberg-Marquardt trials enqueued for EVERY window of
- * the call (iterations + 1 per optimisation, + 4 per continuation round; a window that needs fewer leaves its slots empty --
- * the lock-step cost of a heterogeneous batch), `host_rounds` = times the host waited for the device (1 = no continuation). */
+/* The device program of the last solve of this handle: `trial_slots` = Levenberg-Marquardt trials enqueued in all (the first round
+ * holds as many as there are iterations, for every window of the call; a window whose steps were not all accepted is not finished
+ * then and gets a continuation round, sized for what it still needs, with the other unfinished windows only), `host_rounds` = times
+ * the host waited for the device (1 = no continuation).  aos2_lba_last_window_slots: the trial slots summed over the windows each
+ * round covered -- divided by the trials the windows needed, the lock-step cost of the batch (1.0 = no launch covered a window that
+ * had nothing left to do). */
 int aos2_lba_last_program(const aos2_lba_t *s, int32_t *trial_slots, int32_t *host_rounds);
+int aos2_lba_last_window_slots(const aos2_lba_t *s, int64_t *window_slots);
 /* Measurement hook (no device, no reference equivalent): the HOST part of aos2_lba_solve_batch for `n_problems` windows -- the
  * per-window index structures and the staging copies -- on `threads` worker threads; wall milliseconds of the two phases. */
 int aos2_lba_debug_host_phase(const aos2_lba_problem_t *problems, int n_problems, int threads, double *build_ms,
