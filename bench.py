@@ -388,18 +388,31 @@ def main():
     sb = sh.slot_bytes(cap)
     gather = None
     if dist_on:
+        # the exchange has a stream of its own per pipeline (not the pipeline's: rank 0's next step must not queue behind world - 1
+        # incoming slot buffers): the pack kernel is ordered behind the step's extraction on the device (aos2_extractor_pack_slots),
+        # the collective behind the pack; the host only makes sure the pack has read the keypoint buffers before the pipeline's
+        # next extraction overwrites them (an event two steps old)
         gather = dict(slot=[torch.zeros((B, sb), dtype=torch.uint8, device=dev) for _ in range(NPIPE)], work=[None] * NPIPE,
-                      ext=[torch.cuda.ExternalStream(pp.cur.stream()) for pp in pipes],
+                      ext=[torch.cuda.Stream(device=dev) for _ in pipes], packed=[None] * NPIPE, t_ev=[None] * NPIPE, us=[],
                       bufs=[[torch.empty((B, sb), dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(NPIPE)])
 
     def gather_step(j):
         p = pipes[j]
-        with torch.cuda.stream(gather["ext"][j]):   # = the pipeline's own stream
+        if gather["t_ev"][j] is not None and gather["t_ev"][j][1].query():   # the previous exchange of this pipeline: pack + collective, device time
+            gather["us"].append(gather["t_ev"][j][0].elapsed_time(gather["t_ev"][j][1]) * 1e3)
+        with torch.cuda.stream(gather["ext"][j]):
             if gather["work"][j] is not None:
                 gather["work"][j].wait()   # the STREAM waits for the previous gather of this slot buffer before it is packed again
-            p.ex.pack_slots(B, p.d_kps.data_ptr(), p.d_desc.data_ptr(), p.d_n.data_ptr(), cap, gather["slot"][j].data_ptr(), sb, p.cur.stream())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p.ex.pack_slots(B, p.d_kps.data_ptr(), p.d_desc.data_ptr(), p.d_n.data_ptr(), cap, gather["slot"][j].data_ptr(), sb, gather["ext"][j].cuda_stream)
+            e0.record()   # (behind the pack's wait for the extraction: what follows is the exchange's own work)
+            gather["packed"][j] = torch.cuda.Event()
+            gather["packed"][j].record()
             if backend == "nccl":
                 gather["work"][j] = dist.gather(gather["slot"][j], gather["bufs"][j], dst=0, async_op=True)
+                gather["work"][j].wait()   # (stream-level: orders e1 behind the collective)
+                e1.record()
+                gather["t_ev"][j] = (e0, e1)
             else:   # gloo (tests): host tensors
                 gather["work"][j] = dist.gather(gather["slot"][j].cpu(), gather["bufs"][j], dst=0, async_op=True)
 
@@ -439,6 +452,8 @@ def main():
             runner.set_list(runner.LBA_JOB, jl_, c_)
 
     def step(s):
+        if gather is not None and gather["packed"][s % NPIPE] is not None:
+            gather["packed"][s % NPIPE].synchronize()   # the last exchange of this pipeline has read its keypoint buffers
         if NATIVE:
             runner.step(s)
             if gather is not None:
@@ -1116,7 +1131,26 @@ def main():
         if dist_on:
             out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
                                            "timed region, in flight while the next step runs" % (B, sb),
-                               "bytes_to_rank0_per_step": (world - 1) * B * sb, "backend": backend, "headers_ok": gather_ok}
+                               "bytes_to_rank0_per_step": (world - 1) * B * sb, "backend": backend, "headers_ok": gather_ok,
+                               "stream": "one of its own per pipeline, behind the step's extraction by an event",
+                               "pack_plus_collective_device_us_median": float(np.median(gather["us"])) if gather["us"] else None}
+        else:   # what the exchange would move at 8 ranks, and the pack kernel's own time (one launch, measured here)
+            gs = torch.cuda.Stream(device=dev)
+            slot_ = torch.zeros((B, sb), dtype=torch.uint8, device=dev)
+            ev_ = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(gs):
+                pipes[0].ex.pack_slots(B, pipes[0].d_kps.data_ptr(), pipes[0].d_desc.data_ptr(), pipes[0].d_n.data_ptr(), cap, slot_.data_ptr(), sb, gs.cuda_stream)
+                ev_[0].record()
+                pipes[0].ex.pack_slots(B, pipes[0].d_kps.data_ptr(), pipes[0].d_desc.data_ptr(), pipes[0].d_n.data_ptr(), cap, slot_.data_ptr(), sb, gs.cuda_stream)
+                ev_[1].record()
+            gs.synchronize()
+            out["exchange"] = {"per_step": "none at N = 1; at N ranks every rank's %d slots x %d B go to rank 0 in one gather per step (RCCL), on a stream of its "
+                                           "own per pipeline behind the step's extraction" % (B, sb),
+                               "slot_bytes": sb, "bytes_to_rank0_per_step_at_8_ranks": 7 * B * sb,
+                               "per_xgmi_link_ms_at_8_ranks_153_GB_per_s": B * sb / 153e9 * 1e3,
+                               "pack_kernel_us": ev_[0].elapsed_time(ev_[1]) * 1e3,
+                               "collective_us": "measured by the one-rank RCCL path (AOS2_BENCH_FORCE_DIST=1: exchange.pack_plus_collective_device_us_median) and at N > 1"}
         co, lba_want = None, {}
         if snap is not None or (world == 1 and not args.no_cpu_baseline):
             O = g.load_oracle()

@@ -46,7 +46,9 @@ def test_bench_contract_single_gpu(gpu):
     assert pc["local_ba_windows"] == 4 and pc["distinct_local_ba_problems"] == 4   # every window a different problem
     assert max(pc["worst_abs_diff"][k] for k in ("mTcw", "lba_pose", "lba_point")) <= 1e-5   # the worst difference is reported
     ls = d["extra"]["local_ba_lock_step"]
-    assert ls["trial_slots_enqueued_per_window"] >= 17 and ls["slots_over_trials"] >= 1.0 and d["config"]["local_ba_mix"] == "heterogeneous"
+    assert ls["trial_slots_enqueued"] >= 15 and 1.0 <= ls["slots_over_trials"] <= 1.03 and d["config"]["local_ba_mix"] == "heterogeneous"
+    assert d["config"]["step_runner"].startswith("native") and d["config"]["local_ba_handles_in_flight"] == 3 and d["config"]["images"].startswith("resident")
+    assert d["exchange"]["bytes_to_rank0_per_step_at_8_ranks"] == 7 * 32 * d["exchange"]["slot_bytes"] and d["exchange"]["pack_kernel_us"] > 0
     assert len(d["config"]["frames_per_s_per_rank"]) == 1 and d["config"]["host_threads_per_rank"]["local_ba_workers_per_handle"] >= 1
     ts = d["extra"]["timed_steps"]   # where the enqueueing thread waited during the timed steps, how long the LocalBA calls took
     assert set(ts["host_thread_waits_ms_per_step"]) == {"local_ba", "keyframe_legs", "tracking"} and ts["local_ba_call_wall_ms_min_median_max"][1] > 0
