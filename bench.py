@@ -1100,10 +1100,13 @@ def main():
         try:
             if KITTI:
                 raise LookupError("the committed PMC passes are of the TUM workload")
-            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
+            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_extractor_counters.json", "r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
             pc = json.load(open(cpath))
             fc, cal = pc["fast_cells_kernel"], pc["calibration"]
             per_frame = (fc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + fc["WRITE_SIZE_KB"] * cal["WRITE_SIZE_factor"]) * 1024.0 / pc["batch"]
+            # `traffic`: HBM bytes per launch of THIS kernel on frames of THIS generator at this batch, from the committed counter passes at
+            # HEAD (FETCH_SIZE / WRITE_SIZE in passes of their own, corrected as calibrated); a property of the kernel, not re-measured per run
+            out["roofline"]["traffic"] = per_frame * B
             out["roofline"]["traffic_profiled"] = {
                 "bytes_per_launch": per_frame * B, "over_algorithmic": per_frame * B / fast_bytes,
                 "source": pc["source"], "correction": "FETCH_SIZE x %.3f (unaligned 32-bit reads), WRITE_SIZE x 1.0" % cal["FETCH_SIZE_factor_unaligned_32bit"]}
@@ -1128,6 +1131,28 @@ def main():
                         "4-cycle pricing, not an independent measurement" % (clock_ghz, cyc, 100.0 * mix["two_cycle_share"])}
         except Exception as exc:
             out["roofline"]["traffic_profiled"] = {"error": repr(exc)}
+        try:   # the LocalBA kernels: SURVEY 8(d)'s bytes per LM iteration for the batch of this run, times and counters of the committed passes
+            lpath = os.path.join(ROOT, "profiles", "r05_lba_counters.json")
+            if not NO_LBA and not KITTI and args.lba_mix == "heterogeneous" and os.path.exists(lpath):
+                lc = json.load(open(lpath))
+                Np = sum(int((q_["pose_fixed"] == 0).sum()) for q_ in lba_probs); Nf = sum(int((q_["pose_fixed"] != 0).sum()) for q_ in lba_probs)
+                M_ = sum(int(q_["n_points"]) for q_ in lba_probs); E_ = sum(int(q_["n_edges"]) for q_ in lba_probs)
+                Ef = sum(int((q_["pose_fixed"][q_["edge_pose"]] == 0).sum()) for q_ in lba_probs)
+                alg = {"k_points_walk": 56.0 * (Np + Nf) + 24.0 * M_ + 48.0 * E_ + 8.0 * (6 * Np + 3 * M_),   # residual pass + update (reads estimates / observations, writes the update)
+                       "k_lin<true>": 56.0 * (Np + Nf) + 24.0 * M_ + 48.0 * E_ + 144.0 * Ef + 288.0 * Np + 72.0 * M_,   # linearisation: Hpl, Hpp, Hll
+                       "k_schur": 144.0 * Ef + 72.0 * M_ + 288.0 * sum(int((q_["pose_fixed"] == 0).sum()) ** 2 for q_ in lba_probs)}   # R Hpl + Hll, W dense Hschur
+                for kn, ab in alg.items():
+                    kc = lc["kernels"].get(kn)
+                    if kc and kc.get("kernel_us"):
+                        out["roofline_other"].append({
+                            "kernel": kn, "bound": "hbm", "kernel_ms": kc["kernel_us"] * 1e-3, "algorithmic_bytes_per_launch": ab,
+                            "achieved": ab / (kc["kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab / (kc["kernel_us"] * 1e-6) / 1e9 / 8000.0,
+                            "traffic": kc.get("hbm_bytes_per_launch"),
+                            "note": "SURVEY 8(d)'s bytes per LM iteration with the stored-block layout it assumed, summed over the %d windows of this run's batch "
+                                    "(the kernels keep a 32-byte record per edge instead of the 144-byte block, so the counters' traffic is below it); "
+                                    "kernel time and counters: %s -- the batch alone on the device; latency / request-rate bound, not bandwidth bound" % (n_win, lc["source"][:60])})
+        except Exception as exc:
+            out.setdefault("roofline_notes", []).append("LocalBA rows: " + repr(exc))
         if dist_on:
             out["exchange"] = {"per_step": "gather of %d slots x %d B per rank to rank 0 (aos2_extractor_pack_slots + one collective), inside the "
                                            "timed region, in flight while the next step runs" % (B, sb),

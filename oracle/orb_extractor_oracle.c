@@ -445,10 +445,16 @@ static void divide_node(olist_t *L, int id, int c[4], const float *xs, const flo
 }
 
 typedef struct { int size, node; } spair_t;
+/* orc_set_tiebreak_mode(1): nodes of equal size in the OPPOSITE order (the reference's order among them is that of their heap
+ * addresses, i.e. unspecified: the two extremes bracket what a reference binary can do) -- for measuring the convention's effect
+ * (tools/convention_effects.py); the parity tests never set it */
+static int g_tiebreak_reverse = 0;
+void orc_set_tiebreak_mode(int reverse) { g_tiebreak_reverse = reverse; }
 static int spair_cmp(const void *a, const void *b)
 {
     const spair_t *x = (const spair_t *)a, *y = (const spair_t *)b;
     if (x->size != y->size) return x->size < y->size ? -1 : 1;
+    if (g_tiebreak_reverse) return x->node > y->node ? -1 : x->node < y->node ? 1 : 0;
     return x->node < y->node ? -1 : x->node > y->node ? 1 : 0;
 }
 

@@ -654,10 +654,14 @@ static float norm3(const float *v)
     return (float)sqrt(s);
 }
 /* MapPoint::PredictScale(currentDist, pKF / pF) src/MapPoint.cc:427-459 */
+/* orc_set_log_mode(1): libm logf instead of the correctly rounded float logarithm -- for measuring the convention's effect
+ * (tools/convention_effects.py); the parity tests never set it */
+static int g_log_libm = 0;
+void orc_set_log_mode(int use_libm) { g_log_libm = use_libm; }
 static int predict_scale(float max_dist, float dist, float log_scale_factor, int n_levels)
 {
     const float ratio = max_dist / dist;
-    const float lg = (float)log((double)ratio);
+    const float lg = g_log_libm ? logf(ratio) : (float)log((double)ratio);
     int nScale = (int)ceilf(lg / log_scale_factor);
     if (nScale < 0) nScale = 0;
     else if (nScale >= n_levels) nScale = n_levels - 1;

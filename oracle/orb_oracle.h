@@ -67,6 +67,8 @@ int orc_fast_corner_score(const uint8_t *center, int stride, int threshold);
 float orc_fast_atan2(float y, float x);
 /* rBRIEF steering trig: 0 = correctly rounded (default, parity convention 3), 1 = libm cosf/sinf */
 void orc_set_trig_mode(int use_libm);
+void orc_set_tiebreak_mode(int reverse);   /* octree: equal-size nodes in the opposite order (measurement only) */
+void orc_set_log_mode(int use_libm);        /* PredictScale: libm logf (measurement only) */
 void orc_sincos_exact(float angle_rad, float *s_out, float *c_out);
 int orc_cv_round_f(float v);
 /* cv::resize INTER_LINEAR 8UC1 */

@@ -1,10 +1,11 @@
-"""profiles/r02_extractor_counters.json from the PMC summary (tools/pmc_summary2.py output) and the kernel stats of
+"""profiles/rNN_extractor_counters.json (round tag: argv[3], default r05) from the PMC summary (tools/pmc_summary2.py output) and the kernel stats of
 tools/prof_extract.py 512: python tools/pmc_extract_digest.py <pmc txt> <kernel_stats.csv>"""
 import csv, json, re, sys
 txt = open(sys.argv[1]).read()
 stats = {r["Name"].split("(")[0].split("::")[-1]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[2]))}
-out = {"source": "profiles/r02_pmc_extract_b512.txt (rocprofv3 --pmc passes of tools/prof_extract.py 512, tools/prof_r02_pmc_extract.sh) + "
-                 "profiles/r02_hbm_counter_calibration.txt", "batch": 512}
+tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
+out = {"source": "profiles/%s_pmc_extract_b512.txt (rocprofv3 --pmc passes of tools/prof_extract.py 512, tools/prof_%s.sh) + "
+                 "profiles/r02_hbm_counter_calibration.txt" % (tag, tag), "batch": 512}
 for k in ("fast_cells_kernel", "describe_kernel"):
     d = {}
     for line in txt.splitlines():
