@@ -2,13 +2,12 @@
 // LinearSolverEigen, solvers/linear_solver_eigen.h:94-124; a dense LDL^T stands in for the sparse Cholesky):
 // blocked right-looking LDL^T + both substitutions by ONE workgroup with the trailing matrix RESIDENT IN REGISTERS.
 //
-//   * the 16x16 tiles below the first sub-diagonal (91 of them at npad = 240) live in the vector registers of kLrWorkers waves as MFMA
+//   * the strictly lower 16x16 tiles (105 of them at npad = 240) live in the vector registers of kLrWorkers waves as MFMA
 //     accumulator tiles for the whole factorisation (tile t -> worker t % kLrWorkers, slot t / kLrWorkers; tiles are ranked from the
 //     bottom-right corner so that the tiles a panel still touches are always a PREFIX of the ranking: every worker has the same
 //     share of every panel's update, and a slot is a compile-time register index);
-//   * the diagonal tiles, the tiles right below them (wave 0 forms their panel product itself, right behind the diagonal block:
-//     the chain D_k -> W_k+1,k -> next diagonal tile -> D_k+1 never waits for a worker), the panel's L D (W), every panel's
-//     T_k = L_kk^-1 and the vectors live in LDS; nothing but the initial load and the solution touches device memory (the in-place global-memory form this
+//   * the diagonal tiles, the panel's L D (W), every panel's T_k = L_kk^-1, the tiles right below the diagonal (as L) and the
+//     vectors live in LDS; nothing but the initial load and the solution touches device memory (the in-place global-memory form this
 //     replaces paid a device-memory round trip per panel phase and per backward block: 113 us at 40 free keyframes);
 //   * wave 0 factorises the diagonal blocks, the block spread over all 64 lanes (row i, columns 4q..4q+3 in lane i + 16 q; T the
 //     same way by columns), so a pivot is 4 + 4 multiply-adds per lane and three LDS reads;
@@ -45,7 +44,7 @@ constexpr bool kLrSpare0 = AOS2_LR_SPARE0 != 0;
 constexpr int kLrWorkers = kLrSpare0 ? kLrWaves - kLrWaves / 4 : kLrWaves - 1;
 constexpr int kLrThreads = 64 * kLrWaves;
 constexpr int kLrMaxNb = 15;                       // npad <= 240: 40 free keyframes
-constexpr int kLrSlots = ((kLrMaxNb - 1) * (kLrMaxNb - 2) / 2 + kLrWorkers - 1) / kLrWorkers;   // (the tiles right below the diagonal live in LDS)
+constexpr int kLrSlots = (kLrMaxNb * (kLrMaxNb - 1) / 2 + kLrWorkers - 1) / kLrWorkers;
 static_assert(kLrSlots <= 16, "the jump tables below list 16 slots");
 
 // doubles of dynamic LDS the solve needs
@@ -112,9 +111,9 @@ __device__ __forceinline__ void lr_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // tail (k_schur / k_prepare write exactly this).  Called by all kLrThreads threads of the workgroup.  Returns false on a zero / NaN
 // pivot; otherwise the solution is left in LDS at `xs_out` (npad doubles, the tail zero).  dbg (kTiming): phase cycle counters.
 //
-// Barriers (every wave runs the same sequence): [wave 0: D_0 | workers: load] B { [wave 0: the panel product of the tile below the diagonal
-// block, forward substitution of the next block's rows | workers: their panel tiles] B [wave 0: next diagonal tile's update, D_k+1 |
-// workers: U_k] B } [clear] B { [wave 0: x_k | workers: L_IJ^T x_I of the row above] B } B
+// Barriers (every wave runs the same sequence): [wave 0: D_0 | workers: load] B { [first panel tile of every worker, the tile below the
+// diagonal block before any other] B [wave 0: forward substitution of the next block's rows | workers: their other panel tiles] B
+// [wave 0: next diagonal tile's update, D_k+1 | workers: U_k] B } [clear] B { [wave 0: x_k | workers: L_IJ^T x_I of the row above] B } B
 template <bool kTiming>
 __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, int n, int npad, const double *__restrict__ bs, double *sm, double *&xs_out,
                                                long long *dbg)
@@ -127,7 +126,7 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
     const int nb = npad >> 4, ld = npad;
     double *Dg = sm;                        // nb x (16 x 17): the diagonal tiles
     double *Tt = Dg + nb * 272;             // nb x (16 x 17): T_k^T (Tt_k[c * 17 + i] = T_k[i][c])
-    double *Ls = Tt + nb * 272;             // nb x (16 x 17): the tile below diagonal block k -- transposed A until its panel product, L afterwards
+    double *Ls = Tt + nb * 272;             // nb x (16 x 17): L of the tile below diagonal block k (the backward pass's critical term)
     double *Wb = Ls + nb * 272;             // npad x 17: L D of the current panel
     double *rv = Wb + (size_t)npad * 17;    // right-hand side under the forward substitution
     double *rdv = rv + npad;                // 1 / D
@@ -137,7 +136,7 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
     double *sbuf = cbuf + 256;              // 64 + 16 + 64: wave 0's cross-lane sums
     double *wred = sbuf + 160;              // KW x 64: a worker's cross-lane sums (backward pass)
     double *part = Wb;                      // backward pass: KW x npad, worker w's share of sum_I L_IJ^T x_I (W is dead by then)
-    const int ntot = (nb - 1) * (nb - 2) / 2;   // register tiles: (I, J) with I >= J + 2
+    const int ntot = nb * (nb - 1) / 2;
     const bool worker = wave > 0 && !(kLrSpare0 && (wave & 3) == 0);
     const int widx = kLrSpare0 ? (wave >> 2) * 3 + (wave & 3) - 1 : wave - 1;   // dense index of a worker
     const int wt = widx * 64 + lane;                                            // ... and of its threads
@@ -195,26 +194,16 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
             const int k0 = kb << 4;
             if (kb >= 0) {
                 rhs_block(kb);
-                // the panel product of the tile right below the diagonal block, by this wave: W = A T_k^T (the transposed tile in LDS is the A
-                // operand as it lies), W to the panel buffer, L = W D^-1 back into the tile's place (the backward pass reads it there)
-                const double *wr = Wb + (size_t)(k0 + 16 + col) * 17;
-                {
-                    double *Sk = Ls + kb * 272;
-                    const double *Tk = Tt + kb * 272;
-                    lr_double4_t pacc = {0, 0, 0, 0};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Sk[(rq + 4 * kk) * 17 + col], Tk[(rq + 4 * kk) * 17 + col], pacc, 0, 0, 0);
-                    const double rdc = rdv[k0 + col];
-                    lr_wave_sync();   // (every lane has read its operands: the tile's place takes L)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Wb[(size_t)(k0 + 16 + rq + 4 * r) * 17 + col] = pacc[r];
-                        Sk[(rq + 4 * r) * 17 + col] = pacc[r] * rdc;
-                    }
-                    lr_wave_sync();
+                LR_EV(16 * (kb + 1) + 4);
+                lr_barrier();   // (every worker's first panel tile: W of the next block's rows is there)
+                LR_EV(16 * (kb + 1) + 5);
+                if (kTiming) {
+                    const long long tn = __builtin_amdgcn_s_memtime();
+                    c_p += tn - t_mark;
+                    t_mark = tn;
                 }
                 // forward substitution of the next block's rows: lane (i, q) sums its four columns, the groups are added through LDS
+                const double *wr = Wb + (size_t)(k0 + 16 + col) * 17;
                 {
                     double f = 0;
 #pragma unroll
@@ -234,13 +223,8 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
                 lr_wave_sync();
                 rv[k0 + 16 + col] = rv[k0 + 16 + col] - ((sbuf[col] + sbuf[16 + col]) + (sbuf[32 + col] + sbuf[48 + col]));
                 LR_EV(16 * (kb + 1) + 6);
-                lr_barrier();   // (the workers' panel tiles)
+                lr_barrier();   // (the workers' other panel tiles)
                 LR_EV(16 * (kb + 1) + 7);
-                if (kTiming) {
-                    const long long tn = __builtin_amdgcn_s_memtime();
-                    c_p += tn - t_mark;
-                    t_mark = tn;
-                }
                 // the next diagonal tile's update, then straight on to its factorisation while the workers update the rest
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-(wv[kk] * rdk[kk]), wv[kk], acc, 0, 0, 0);
@@ -362,23 +346,25 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
         for (int kb = 0; kb < nb - 1; ++kb) {
             lr_barrier();
             lr_barrier();
+            lr_barrier();
         }
         lr_barrier();
         for (int kb = nb - 1; kb >= 0; --kb) lr_barrier();
     } else {
         // ================= the workers: the tiles =================
-        // slot s of this worker holds the tile of rank s KW + widx (below).  Loaded transposed: register r of lane (col, rq) = A[I0 + col][J0 + rq + 4 r]
+        // rank t = a (a - 1) / 2 + b over 0 <= b < a < nb stands for the tile (I, J) = (nb - 1 - b, nb - 1 - a); slot s of this
+        // worker holds rank s KW + widx.  Loaded transposed: register r of lane (col, rq) = A[I0 + col][J0 + rq + 4 r]
         // = Hs[J0 + rq + 4 r][I0 + col] (the matrix is symmetric and both triangles are stored: coalesced rows).
         // tab: lane s holds I0 | J0 << 8 of slot s (read with v_readlane: the table costs one register, not 15 scalar ones)
         lr_double4_t tile[NS];
         int tab;
-        {   // rank t = a (a - 1) / 2 + b over 0 <= b < a <= nb - 2 stands for the tile (I, J) = (nb - 1 - b, nb - 2 - a): I >= J + 2
+        {
             const int t = lane * KW + widx;
             int a = (int)((1.0f + __fsqrt_rn(1.0f + 8.0f * (float)t)) * 0.5f);
             if (a * (a - 1) / 2 > t) --a;
             if (a * (a + 1) / 2 <= t) ++a;
             const int b = t - a * (a - 1) / 2;
-            tab = (lane < NS && t < ntot) ? ((nb - 1 - b) << 4) | ((nb - 2 - a) << 12) : 0;
+            tab = (lane < NS && t < ntot) ? ((nb - 1 - b) << 4) | ((nb - 1 - a) << 12) : 0;
         }
         auto slot_ij = [&](int s) { return __builtin_amdgcn_readlane(tab, s); };
         {
@@ -391,13 +377,6 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
                 dv[u] = Hs[(16 * min(I, nb - 1) + a) * ld + 16 * min(I, nb - 1) + b];
             }
             if (16 + wt < npad) bv = 16 + wt < n ? bs[16 + wt] : 0.0;
-            // the tiles right below the diagonal, transposed like the register tiles: place [j][i] of tile k = Hs[16 k + j][16 (k + 1) + i]
-            double sv_[ND];
-#pragma unroll
-            for (int u = 0; u < ND; ++u) {
-                const int idx = min(wt + u * WT, (nb - 1) * 256 - 1 + (nb == 1)), k = min(idx >> 8, max(nb - 2, 0)), j = (idx >> 4) & 15, i = idx & 15;
-                sv_[u] = Hs[(16 * k + j) * ld + min(16 * (k + 1) + i, npad - 1)];
-            }
             const double *hl = Hs + rq * ld + col;
 #pragma unroll
             for (int s = NS - 1; s >= 0; --s) {   // (no branch: every load in flight at once; a slot beyond the last tile reads tile (0, 0), unused)
@@ -411,40 +390,46 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
                 if (idx < (nb - 1) * 256) Dg[I * 272 + a * 17 + b] = dv[u];
             }
             if (16 + wt < npad) rv[16 + wt] = bv;
-#pragma unroll
-            for (int u = 0; u < ND; ++u) {
-                const int idx = wt + u * WT, k = idx >> 8, j = (idx >> 4) & 15, i = idx & 15;
-                if (idx < (nb - 1) * 256) Ls[k * 272 + j * 17 + i] = sv_[u];
-            }
         }
         LR_EV(9);
         lr_barrier();   // (D_0: wave 0)
         LR_EV(10);
         for (int kb = 0; kb < nb - 1; ++kb) {
             const int k0 = kb << 4, m = nb - 1 - kb;
-            const int lo = (m - 1) * (m - 2) / 2, hi = lo + m - 1;   // ranks of the trailing tiles: [0, lo); of this panel's register tiles: [lo, hi)
-            // ---- P_k: W_I = A_Ik T_k^T -- the transposed tile is the A operand as it stands --, L_Ik = W_I D^-1 stays in the tile
-            // (the tile right below the diagonal block is wave 0's, in LDS)
-            {
-                const double *Tk = Tt + kb * 272;
-                double tb[4];
+            const int lo = m * (m - 1) / 2, hi = lo + m;   // ranks of the trailing tiles: [0, lo); of this panel's tiles: [lo, hi)
+            // ---- P_k: W_I = A_Ik T_k^T -- the transposed tile is the A operand as it stands --, L_Ik = W_I D^-1 stays in the tile.
+            // Every worker's HIGHEST panel tile first (rank hi - 1 = the tile right below the diagonal block: wave 0 waits for it alone)
+            const double *Tk = Tt + kb * 272;
+            double tb[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) tb[kk] = Tk[(rq + 4 * kk) * 17 + col];
-                const double rdc = rdv[k0 + col];
-                auto panel_tile = [&](lr_double4_t &tl, int I0) {
-                    lr_double4_t acc = {0, 0, 0, 0};
+            for (int kk = 0; kk < 4; ++kk) tb[kk] = Tk[(rq + 4 * kk) * 17 + col];
+            const double rdc = rdv[k0 + col];
+            int sp = hi - 1 >= widx ? (hi - 1 - widx) / KW : -1;   // the worker's highest slot with a rank < hi (it may still be below lo)
+            auto panel_tile = [&](lr_double4_t &tl, int I0, bool below_diag) {
+                lr_double4_t acc = {0, 0, 0, 0};
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk], tb[kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk], tb[kk], acc, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Wb[(size_t)(I0 + rq + 4 * r) * 17 + col] = acc[r];
-                        tl[r] = acc[r] * rdc;
-                    }
-                };
-#define LR_PANEL(S) panel_tile(tile[S], slot_ij(S) & 255)
-                for (int sp = hi - 1 >= widx ? (hi - 1 - widx) / KW : -1; sp >= 0 && sp * KW + widx >= lo; --sp) { LR_SLOT_SWITCH(sp, LR_PANEL) }
+                for (int r = 0; r < 4; ++r) {
+                    Wb[(size_t)(I0 + rq + 4 * r) * 17 + col] = acc[r];
+                    tl[r] = acc[r] * rdc;
+                }
+                if (below_diag) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ls[kb * 272 + (rq + 4 * r) * 17 + col] = tl[r];
+                }
+            };
+#define LR_PANEL(S) panel_tile(tile[S], slot_ij(S) & 255, (S) * KW + widx == hi - 1)
+            if (sp >= 0 && sp * KW + widx >= lo) {
+                LR_SLOT_SWITCH(sp, LR_PANEL)
+                --sp;
+            } else
+                sp = -1;
+            LR_EV(16 * (kb + 1) + 4);
+            lr_barrier();
+            LR_EV(16 * (kb + 1) + 5);
+            for (; sp >= 0 && sp * KW + widx >= lo; --sp) { LR_SLOT_SWITCH(sp, LR_PANEL) }
 #undef LR_PANEL
-            }
             LR_EV(16 * (kb + 1) + 6);
             lr_barrier();
             LR_EV(16 * (kb + 1) + 7);
@@ -505,22 +490,6 @@ __device__ __forceinline__ bool ldlt_reg_solve(const double *__restrict__ Hs, in
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Dn[(rq + 4 * r) * 17 + col] = acc[r];
-                }
-            }
-            {   // ... and the tiles right below them, (I, I - 1) for I >= kb + 2 (in LDS, transposed): place [j][i] -= sum_k L[J0 + j][k] W[I0 + i][k]
-                int I = kb + 2 + (widx + KW / 2 + KW * 4 - (kb + 2) % KW) % KW;
-                for (; I < nb; I += KW) {
-                    double *Sn = Ls + (I - 1) * 272;
-                    lr_double4_t acc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = Sn[(rq + 4 * r) * 17 + col];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double wjv = Wb[(size_t)(((I - 1) << 4) + col) * 17 + rq + 4 * kk], wiv = Wb[(size_t)((I << 4) + col) * 17 + rq + 4 * kk];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wjv * nr[kk], wiv, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Sn[(rq + 4 * r) * 17 + col] = acc[r];
                 }
             }
             {   // forward substitution of the rows below the next block: r_i -= sum_c W[i][c] z_c (four partial sums)
