@@ -935,9 +935,9 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     const uint8_t *img_pyr = pyr + (size_t)b * pyr_stride;
     const uint8_t *img_l0 = img0 + (size_t)b * img0_stride;
     uint8_t *patch = reinterpret_cast<uint8_t *>(patch32);
-    // per-lane constants of the three lane grids (each split done once)
+    // per-lane constants of the lane grids (each split done once)
     const int st_rs = (lane * 373) >> 12, st_c = lane - 11 * st_rs;   // staging: 5 rows x 11 dwords
-    const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1; // IC_Angle: 7 rows x 9 dwords
+    const int ic_rs = (lane * 57) >> 9, ic_dj = lane - 9 * ic_rs + 1; // IC_Angle: 7 rows x 9 dwords (lane 63: none)
     // Gaussian weights (8 fractional bits, sum 257): bytes for the h-pass dot4, u16 pairs for the v-pass dot2
     const uint32_t g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
     // h-pass: the 4 outputs of a quad read the same 3 dwords; the taps are shifted in the WEIGHTS (10 dot4, no
@@ -957,9 +957,24 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     const int hrounds = c_hrounds;
     const uint32_t WE0 = g0 | (g1 << 16), WE1 = g2 | (g3 << 16), WE2 = g2 | (g1 << 16), WE3 = g0;   // even output row
     const uint32_t WO0 = g0 << 16, WO1 = g1 | (g2 << 16), WO2 = g3 | (g2 << 16), WO3 = g1 | (g0 << 16);   // odd
-    uint32_t pats[4];
+    // v-pass: item id = lane + 64 t = (column x, 8 output rows seg); its source (h-pass tile, bytes) and destination
+    // (blurred tile, bytes) offsets, fixed for the whole wave: low / high half of one register per round
+    uint32_t vitem[3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pats[r] = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * (r * 64 + lane)]);
+    for (int t = 0; t < 3; ++t) {
+        const int id = lane + 64 * t, seg = (int)(__umul24((uint32_t)id, 1772u) >> 16), x = id - BW * seg;   // id / 37
+        vitem[t] = id < BW * 5 ? (uint32_t)(4 * (x * HTP + 4 * seg)) | ((uint32_t)(x * VBP + 8 * seg) << 16) : 0xffffffffu;
+    }
+    // rBRIEF: this lane's test pair of each of the four 64-bit words, the two points of a pair side by side for the
+    // packed float instructions (x of both, y of both)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 patx[4], paty[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pat = *reinterpret_cast<const uint32_t *>(&c_pattern[4 * (r * 64 + lane)]);
+        patx[r] = f32x2{(float)(int8_t)pat, (float)(int8_t)(pat >> 16)};
+        paty[r] = f32x2{(float)(int8_t)(pat >> 8), (float)(int8_t)(pat >> 24)};
+    }
 
     struct Slot {
         int level, kx, ky, score, w, h, pitch;
@@ -994,6 +1009,78 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     };
     Slot cur = locate(0);
     prefetch(cur);
+
+    // ---- IC_Angle (:75-105) of the wave's DK keypoints together, then their orientations and steering pairs in DK
+    // lane groups at once: the arctangent and the double-precision sine / cosine are the same instructions for every
+    // lane, so one pass serves all the keypoints of the wave instead of one pass each.
+    // The moments come straight from the level (a keypoint is >= 19 px from every edge, :45, so the 31-row disc and
+    // the dwords around it are inside the plane; the patch staged below is only for the blur): lane (rs, dj) reads
+    // rows rs, rs + 7, .. of the disc, dword dj = columns u = 4 dj - 21 .. 4 dj - 18.  With the precomputed byte mask,
+    // S = sum of the kept bytes, T = sum of k * byte_k:   m10 = sum((4 dj - 21) S + T),   m01 = sum(v S).
+    static_assert(DK <= 4, "the moments of at most 4 keypoints are reduced together");
+    int mom[8];
+    {
+        uint32_t icm[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int vr = ic_rs + 7 * t;
+            icm[t] = ic_rs < 7 && vr < 31 ? c_icmask[vr * 9 + ic_dj - 1] : 0u;
+        }
+        const int vr4 = min(ic_rs + 28, 30);   // (rows of lanes without a fifth row: any row of the disc, mask 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mom[2 * i] = mom[2 * i + 1] = 0;
+            if (i < DK && i < nk) {   // wave-uniform
+                const Slot s = i == 0 ? cur : locate(i);
+                const uint8_t *base = s.plane + (size_t)(s.ky - 15) * s.pitch + (s.kx - PR);
+                const uint32_t loff = __umul24((uint32_t)ic_rs, (uint32_t)s.pitch) + 4u * (uint32_t)ic_dj;
+                const uint32_t step = 7u * (uint32_t)s.pitch;
+                uint32_t d[5];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[t] = load_u32_unaligned(base + (loff + (uint32_t)t * step));
+                d[4] = load_u32_unaligned(base + (__umul24((uint32_t)vr4, (uint32_t)s.pitch) + 4u * (uint32_t)ic_dj));
+                uint32_t S = 0, T = 0, TS = 0;   // TS = sum of t * S_t: the row of S_t is v = rs - 15 + 7 t
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const uint32_t dm = d[t] & icm[t];
+                    S = __builtin_amdgcn_udot4(dm, 0x01010101u, S, false);
+                    T = __builtin_amdgcn_udot4(dm, 0x03020100u, T, false);
+                    if (t) TS = __builtin_amdgcn_udot4(dm, 0x01010101u * (uint32_t)t, TS, false);
+                }
+                mom[2 * i] = __mul24(4 * ic_dj - PR, (int)S) + (int)T;
+                mom[2 * i + 1] = __mul24(ic_rs - 15, (int)S) + 7 * (int)TS;
+            }
+        }
+    }
+    // sums over the wave, each landing in its own lanes (no scalar round trips): halves, then rows are exchanged between
+    // two registers (v_permlane32_swap / v_permlane16_swap) and added, then bit 3 of the lane selects; after that
+    // lanes 0-31 hold m10, lanes 32-63 m01, of keypoint (lane bit 4) + 2 (lane bit 3)
+    float kp_angle, kp_sin, kp_cos;
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        auto swap_add32 = [](int a, int b) {   // lanes < 32: a over both halves; lanes >= 32: b
+            const u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+            return (int)(r.x + r.y);
+        };
+        auto swap_add16 = [](int a, int b) {   // even rows: a over the row pair; odd rows: b
+            const u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+            return (int)(r.x + r.y);
+        };
+        const int w0 = swap_add32(mom[0], mom[1]), w1 = swap_add32(mom[2], mom[3]);
+        const int w2 = swap_add32(mom[4], mom[5]), w3 = swap_add32(mom[6], mom[7]);
+        const int x0 = swap_add16(w0, w1), x1 = swap_add16(w2, w3);
+        const bool hi8 = (lane & 8) != 0;
+        const int keep = hi8 ? x1 : x0, give = hi8 ? x0 : x1;
+        int y = keep + __builtin_amdgcn_update_dpp(0, give, 0x128, 0xf, 0xf, false);   // row_ror:8 = lane ^ 8
+        y += __builtin_amdgcn_update_dpp(0, y, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+        y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+        y += __builtin_amdgcn_update_dpp(0, y, 0x141, 0xf, 0xf, false);   // row_half_mirror
+        const u32x2 mm = __builtin_amdgcn_permlane32_swap((unsigned)y, (unsigned)y, false, false);   // x: m10, y: m01, in all lanes
+        kp_angle = fast_atan2_deg((float)(int)mm.y, (float)(int)mm.x);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        sincos_exact(__fmul_rn(kp_angle, factorPI), &kp_sin, &kp_cos);
+    }
+
     for (int i = 0; i < nk; ++i) {
         const int k = k0 + i;
         // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
@@ -1018,37 +1105,12 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
             prefetch(nxt);
         }
         wave_lds_phase();
-        // ---- IC_Angle: integer moments over the circular patch, 4 pixels per LDS dword
-        int m10 = 0, m01 = 0;
-#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 1
-        m10 = cur.kx; m01 = cur.ky;
-        if (false) {
-#else
-        if (ic_rs < 7) {
-#endif
-            // patch dwords 1..9 cover columns 4..39.  With the precomputed byte mask: sum(u*I) over the dword
-            // = (4*dj - 21) * S + T, S = sum of the kept bytes, T = sum of k * byte_k
-            const int c0 = 4 * ic_dj - PR;
-            for (int vr = ic_rs; vr < 31; vr += 7) {
-                const uint32_t d = patch32[(PR - 15 + vr) * PD + ic_dj] & c_icmask[vr * 9 + ic_dj - 1];
-                const int S = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
-                const int T = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
-                m10 += c0 * S + T;
-                m01 += (vr - 15) * S;
-            }
-        }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
         // ---- horizontal 7-tap pass (exact 16-bit sums): item = (row pair m, output quad j) from c_hitems; output
         // column cc (0..36) <-> patch column cc+3.  Stored transposed, rows 2m / 2m+1 packed in one dword, for the
         // v-pass dot2.
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t >= hrounds) continue;   // uniform
-#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 2
-            continue;
-#endif
             // (the per-round addresses are loop-invariant and stay in registers: 76 VGPRs = 6 waves/SIMD measured
             // faster, 0.313 ms, than recomputing them per slot at 7 waves, 0.328 ms -- the kernel is VALU-bound)
             const uint32_t it = (hit2[t >> 1] >> (16 * (t & 1))) & 0xffffu;
@@ -1073,58 +1135,55 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         // ---- vertical 7-tap pass over the whole 37x37 tile: item = (column x, 8 output rows); two taps per dot2
         {
             uint8_t *vb = patch;   // the raw patch is dead
-#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 3
-            for (int id = lane; id < 0; id += 64) {
-#else
-            for (int id = lane; id < BW * 5; id += 64) {
-#endif
-                const int seg = (int)(__umul24((uint32_t)id, 1772u) >> 16), x = id - BW * seg;   // id / 37
-                const uint32_t *src = hbT + __umul24((uint32_t)x, (uint32_t)HTP) + 4 * seg;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (vitem[t] == 0xffffffffu) continue;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(hbT) + (vitem[t] & 0xffffu));
                 uint32_t P[7];
 #pragma unroll
-                for (int t = 0; t < 7; ++t) P[t] = src[t];
+                for (int u = 0; u < 7; ++u) P[u] = src[u];
                 uint32_t w[2] = {0u, 0u};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint32_t e = udot2_u16(P[t], WE0, 1u << 15), od = udot2_u16(P[t], WO0, 1u << 15);
-                    e = udot2_u16(P[t + 1], WE1, e); od = udot2_u16(P[t + 1], WO1, od);
-                    e = udot2_u16(P[t + 2], WE2, e); od = udot2_u16(P[t + 2], WO2, od);
-                    e = udot2_u16(P[t + 3], WE3, e); od = udot2_u16(P[t + 3], WO3, od);
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t e = udot2_u16(P[u], WE0, 1u << 15), od = udot2_u16(P[u], WO0, 1u << 15);
+                    e = udot2_u16(P[u + 1], WE1, e); od = udot2_u16(P[u + 1], WO1, od);
+                    e = udot2_u16(P[u + 2], WE2, e); od = udot2_u16(P[u + 2], WO2, od);
+                    e = udot2_u16(P[u + 3], WE3, e); od = udot2_u16(P[u + 3], WO3, od);
                     e = min(e >> 16, 255u); od = min(od >> 16, 255u);
-                    w[t >> 1] |= (e | (od << 8)) << (16 * (t & 1));
+                    w[u >> 1] |= (e | (od << 8)) << (16 * (u & 1));
                 }
-                uint32_t *dst = reinterpret_cast<uint32_t *>(vb + __umul24((uint32_t)x, (uint32_t)VBP)) + 2 * seg;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(vb + (vitem[t] >> 16));
                 dst[0] = w[0]; dst[1] = w[1];
             }
         }
         wave_lds_phase();
         // ---- steered rBRIEF on the blurred tile: one LDS byte per sample
-        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-        const float ang = __fmul_rn(angle, factorPI);
-        float a, bb;
-        sincos_exact(ang, &bb, &a);
+        const int src_lane = 16 * (i & 1) + 8 * (i >> 1);   // where this keypoint's orientation was computed
+        const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_angle), src_lane));
+        const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_cos), src_lane));
+        const float bb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_sin), src_lane));
         unsigned long long words[4];
         // cvRound by the 1.5 * 2^23 trick: the low bits of (f + MAGIC) are 0x4B400000 + rint(f) for |f| < 2^22, with the
         // FPU's round-to-nearest-even = cvRound's rounding; the constant parts of both coordinates fold into K.
+        // Products and sums are separately rounded (:118-121 in float, no contraction), two points per instruction.
         const float MAGIC = 12582912.f;
         const uint32_t K = 0x400000u * (uint32_t)VBP + 0x4B400000u - (uint32_t)(HR * VBP + HR);
+        const f32x2 va = f32x2{a, a}, vb2 = f32x2{bb, bb}, vmagic = f32x2{MAGIC, MAGIC};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#if defined(AOS2_DESC_ABL) && AOS2_DESC_ABL == 4
-            words[r] = __ballot(patch[lane + r] < patch[lane + 7]);
-            continue;
-#endif
-            const uint32_t pat = pats[r];
-            int val[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float px = (float)(int8_t)(pat >> (16 * q)), py = (float)(int8_t)(pat >> (16 * q + 8));
-                const float fy = __fadd_rn(__fadd_rn(__fmul_rn(px, bb), __fmul_rn(py, a)), MAGIC);
-                const float fx = __fadd_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, bb)), MAGIC);
-                const uint32_t off = (uint32_t)(__mul24(__builtin_bit_cast(int, fx), VBP) + __builtin_bit_cast(int, fy)) - K;
-                val[q] = patch[off];
+            f32x2 fy, fx;
+            {
+#pragma clang fp contract(off)
+                const f32x2 t0 = patx[r] * vb2, t1 = paty[r] * va, t2 = patx[r] * va, t3 = paty[r] * vb2;
+                const f32x2 sy = t0 + t1, sx = t2 - t3;
+                fy = sy + vmagic;
+                fx = sx + vmagic;
             }
-            words[r] = __ballot(val[0] < val[1]);
+            // (__builtin_bit_cast of a vector element folds to nothing with this compiler: __float_as_int)
+            const uint32_t off0 = (uint32_t)(__mul24(__float_as_int(fx.x), VBP) + __float_as_int(fy.x)) - K;
+            const uint32_t off1 = (uint32_t)(__mul24(__float_as_int(fx.y), VBP) + __float_as_int(fy.y)) - K;
+            const int v0 = patch[off0], v1 = patch[off1];
+            words[r] = __ballot(v0 < v1);
         }
         wave_lds_phase();
         if (lane == 0) {
