@@ -863,9 +863,11 @@ constexpr int HTC = 40;           // columns of the h-blur tile (10 quads, 37 us
 constexpr int VBP = 44;           // byte pitch of the blurred tile, stored transposed ([x][y]); 11 dwords (odd)
 
 #ifndef AOS2_DESC_KPW
-#define AOS2_DESC_KPW 4
+#define AOS2_DESC_KPW 8
 #endif
-constexpr int DK = AOS2_DESC_KPW;   // keypoints per wave
+constexpr int DK_BATCH = AOS2_DESC_KPW;   // keypoints per wave of describe_kernel: large batches (the per-wave work is shared by 8)
+constexpr int DK_FEW = 2;                 // ... a few images (the launch is as long as one wave: short waves)
+constexpr int DKB = 4;              // keypoints per wave (describe_blur_kernel)
 
 // LDS traffic of ONE wave is processed in issue order, so a write by one lane is visible to a later read by
 // another lane of the same wave; this only stops the compiler from moving LDS accesses across the phase boundary
@@ -880,6 +882,7 @@ __device__ __forceinline__ void wave_lds_phase() { asm volatile("" ::: "memory")
 #else
 #define DESC_ATTR
 #endif
+template <int DK>
 __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *__restrict__ img0,
                                                       size_t img0_stride, int pitch0,
                                                       const uint8_t *__restrict__ pyr,
@@ -892,17 +895,21 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
                                                       uint8_t *__restrict__ desc, int cap,
                                                       int32_t *__restrict__ n_out,
                                                       unsigned long long umax_nibbles,
-                                                      int32_t *__restrict__ status, int batch)
+                                                      int32_t *__restrict__ status, int batch, int groups)
 {
     // raw patch, 43 rows (+1 so that the last row pair can be read); once the h-pass is done the same bytes hold the
     // blurred tile (37 x VBP = 1628 B)
     __shared__ __attribute__((aligned(16))) uint32_t patch32[(PW + 1) * PD];
     __shared__ __attribute__((aligned(16))) uint32_t hbT[HTC * HTP];   // h-pass sums, [column][row pair] u16x2
-    // image = blockIdx.x (padded to a multiple of 8): image b -> XCD b % 8, whose L2 then holds that image's pyramid
-    const int b = blockIdx.x;
+    // Workgroups go to the XCDs round robin in the order of their linear index, and they start in that order.  Index
+    // L = 8 (i * groups + y) + x is wave y of image b = 8 i + x: an image's waves all run on XCD b % 8 and right after each
+    // other, so that XCD's L2 (4 MB) holds the pyramids of the ~3 images it is working on (1.3 MB each at 640x480) and
+    // the overlapping patches of an image's keypoints are fetched from HBM once.  (With the image as the fast index all
+    // the batch's images were in flight at once, 64 per L2: 2.8 x the pyramids' bytes came from HBM.)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bi = slot / groups;
+    const int b = 8 * bi + xcd;
     if (b >= batch) return;
     const int lane = threadIdx.x;
-    const int k0 = blockIdx.y * DK;  // first output slot of this wave
     // lane l < n_levels keeps level l's geometry; lane i < DK locates slot k0 + i (levels are concatenated
     // level-major, :1060-1104).  Both loads are independent of each other.
     int lv_w = 0, lv_h = 0, lv_pitch = 0, lv_sp = 0;
@@ -914,22 +921,26 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         lv_sp = L.scaled_patch; lv_scale = L.scale;
     }
     const int32_t *cnt = sel_level_cnt + (size_t)b * n_levels;
-    int my_level = -1, my_kin = k0 + lane, total = 0, worst = 0;
+    int total = 0, worst = 0;
     for (int l = 0; l < n_levels; ++l) {
-        const int c = cnt[l] > 0 ? cnt[l] : 0;
+        total += cnt[l] > 0 ? cnt[l] : 0;
         worst = min(worst, cnt[l]);   // negative = the octree stage's failure code for this (image, level)
-        if (my_level < 0 && my_kin < c) my_level = l;
-        if (my_level < 0) my_kin -= c;
-        total += c;
     }
-    if (k0 == 0 && lane == 0) {
+    const int y = slot - bi * groups, k0 = y * DK;   // first output slot of this wave
+    const int nk = min(DK, min(total, cap) - k0);
+    if (y == 0 && lane == 0) {
         n_out[b] = total;
         // sticky per-handle status, read by aos2_extractor_wait(): [0] = lowest failure code, [1] = largest n_out
         if (worst < 0) atomicMin(status, worst);
         if (total > cap) atomicMax(status + 1, total);
     }
-    const int nk = min(DK, min(total, cap) - k0);
     if (nk <= 0) return;  // wave-uniform
+    int my_level = -1, my_kin = k0 + lane;
+    for (int l = 0; l < n_levels; ++l) {
+        const int c = cnt[l] > 0 ? cnt[l] : 0;
+        if (my_level < 0 && my_kin < c) my_level = l;
+        if (my_level < 0) my_kin -= c;
+    }
     uint32_t my_sel = 0;
     if (lane < nk) my_sel = sel[(size_t)b * sel_stride + (size_t)my_level * cap_level + my_kin];
     const uint8_t *img_pyr = pyr + (size_t)b * pyr_stride;
@@ -1017,8 +1028,8 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
     // the dwords around it are inside the plane; the patch staged below is only for the blur): lane (rs, dj) reads
     // rows rs, rs + 7, .. of the disc, dword dj = columns u = 4 dj - 21 .. 4 dj - 18.  With the precomputed byte mask,
     // S = sum of the kept bytes, T = sum of k * byte_k:   m10 = sum((4 dj - 21) S + T),   m01 = sum(v S).
-    static_assert(DK <= 4, "the moments of at most 4 keypoints are reduced together");
-    int mom[8];
+    static_assert(DK <= 8, "the moments of at most 8 keypoints are reduced together");
+    int mom[16];
     {
         uint32_t icm[5];
 #pragma unroll
@@ -1028,7 +1039,7 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         }
         const int vr4 = min(ic_rs + 28, 30);   // (rows of lanes without a fifth row: any row of the disc, mask 0)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             mom[2 * i] = mom[2 * i + 1] = 0;
             if (i < DK && i < nk) {   // wave-uniform
                 const Slot s = i == 0 ? cur : locate(i);
@@ -1052,9 +1063,10 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
             }
         }
     }
-    // sums over the wave, each landing in its own lanes (no scalar round trips): halves, then rows are exchanged between
-    // two registers (v_permlane32_swap / v_permlane16_swap) and added, then bit 3 of the lane selects; after that
-    // lanes 0-31 hold m10, lanes 32-63 m01, of keypoint (lane bit 4) + 2 (lane bit 3)
+    // sums over the wave, each landing in its own lanes (no scalar round trips): a pair of registers exchanges halves
+    // (v_permlane32_swap), then rows (v_permlane16_swap), and the two are added; bits 3 and 2 of the lane then select
+    // which register a lane keeps while the other one travels (row_ror:8, row_shl / shr:4).  After that lanes 0-31 hold
+    // m10, lanes 32-63 m01, of keypoint (lane bit 4) + 2 (lane bit 3) + 4 (lane bit 2).
     float kp_angle, kp_sin, kp_cos;
     {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1066,23 +1078,30 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
             const u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
             return (int)(r.x + r.y);
         };
-        const int w0 = swap_add32(mom[0], mom[1]), w1 = swap_add32(mom[2], mom[3]);
-        const int w2 = swap_add32(mom[4], mom[5]), w3 = swap_add32(mom[6], mom[7]);
-        const int x0 = swap_add16(w0, w1), x1 = swap_add16(w2, w3);
-        const bool hi8 = (lane & 8) != 0;
-        const int keep = hi8 ? x1 : x0, give = hi8 ? x0 : x1;
-        int y = keep + __builtin_amdgcn_update_dpp(0, give, 0x128, 0xf, 0xf, false);   // row_ror:8 = lane ^ 8
-        y += __builtin_amdgcn_update_dpp(0, y, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-        y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-        y += __builtin_amdgcn_update_dpp(0, y, 0x141, 0xf, 0xf, false);   // row_half_mirror
-        const u32x2 mm = __builtin_amdgcn_permlane32_swap((unsigned)y, (unsigned)y, false, false);   // x: m10, y: m01, in all lanes
+        int w[8], x[4], y[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = swap_add32(mom[2 * i], mom[2 * i + 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = swap_add16(w[2 * j], w[2 * j + 1]);
+        const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int keep = b3 ? x[2 * m + 1] : x[2 * m], give = b3 ? x[2 * m] : x[2 * m + 1];
+            y[m] = keep + __builtin_amdgcn_update_dpp(0, give, 0x128, 0xf, 0xf, false);   // row_ror:8 = lane ^ 8
+        }
+        const int keep = b2 ? y[1] : y[0], give = b2 ? y[0] : y[1];
+        int z = keep + __builtin_amdgcn_update_dpp(0, give, 0x104, 0xf, 0x5, false)    // row_shl:4 into lanes with bit 2 = 0
+                     + __builtin_amdgcn_update_dpp(0, give, 0x114, 0xf, 0xa, false);   // row_shr:4 into lanes with bit 2 = 1
+        z += __builtin_amdgcn_update_dpp(0, z, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+        const u32x2 mm = __builtin_amdgcn_permlane32_swap((unsigned)z, (unsigned)z, false, false);   // x: m10, y: m01, in all lanes
         kp_angle = fast_atan2_deg((float)(int)mm.y, (float)(int)mm.x);
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         sincos_exact(__fmul_rn(kp_angle, factorPI), &kp_sin, &kp_cos);
     }
+    auto angle_lane = [](int i) { return 16 * (i & 1) + 8 * ((i >> 1) & 1) + 4 * (i >> 2); };   // where keypoint i's orientation is
 
     for (int i = 0; i < nk; ++i) {
-        const int k = k0 + i;
         // ---- stage the 43x43 patch (BORDER_REFLECT_101 at the level's edges)
         if (cur.interior) {
             if (st_rs < 5) {
@@ -1158,17 +1177,16 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
         }
         wave_lds_phase();
         // ---- steered rBRIEF on the blurred tile: one LDS byte per sample
-        const int src_lane = 16 * (i & 1) + 8 * (i >> 1);   // where this keypoint's orientation was computed
-        const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_angle), src_lane));
+        const int src_lane = angle_lane(i);
         const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_cos), src_lane));
         const float bb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kp_sin), src_lane));
-        unsigned long long words[4];
         // cvRound by the 1.5 * 2^23 trick: the low bits of (f + MAGIC) are 0x4B400000 + rint(f) for |f| < 2^22, with the
         // FPU's round-to-nearest-even = cvRound's rounding; the constant parts of both coordinates fold into K.
         // Products and sums are separately rounded (:118-121 in float, no contraction), two points per instruction.
         const float MAGIC = 12582912.f;
         const uint32_t K = 0x400000u * (uint32_t)VBP + 0x4B400000u - (uint32_t)(HR * VBP + HR);
         const f32x2 va = f32x2{a, a}, vb2 = f32x2{bb, bb}, vmagic = f32x2{MAGIC, MAGIC};
+        uint32_t dsc = 0;   // lanes 0-7: the eight dwords of the descriptor
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             f32x2 fy, fx;
@@ -1183,25 +1201,37 @@ __global__ __launch_bounds__(64) DESC_ATTR void describe_kernel(const uint8_t *_
             const uint32_t off0 = (uint32_t)(__mul24(__float_as_int(fx.x), VBP) + __float_as_int(fy.x)) - K;
             const uint32_t off1 = (uint32_t)(__mul24(__float_as_int(fx.y), VBP) + __float_as_int(fy.y)) - K;
             const int v0 = patch[off0], v1 = patch[off1];
-            words[r] = __ballot(v0 < v1);
+            const unsigned long long word = __ballot(v0 < v1);
+            // lanes 2r, 2r + 1 of one register collect the word: v_writelane_b32 with the lane as a constant (no builtin
+            // for it here; the s_nop covers the wait states between the compare that writes the scalar pair and its
+            // use by v_writelane, which the compiler cannot see inside the asm)
+            asm("s_nop 3\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+                : "+v"(dsc)
+                : "s"((uint32_t)word), "s"((uint32_t)(word >> 32)), "n"(2 * r), "n"(2 * r + 1));
         }
         wave_lds_phase();
-        if (lane == 0) {
-            unsigned long long *d = reinterpret_cast<unsigned long long *>(desc + ((size_t)b * cap + k) * 32);
-            d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+        if (lane < 8) reinterpret_cast<uint32_t *>(desc + ((size_t)b * cap + (k0 + i)) * 32)[lane] = dsc;
+        cur = nxt;
+    }
+    // ---- lane i writes the record of keypoint i (:1060-1104: coordinates scaled to level 0)
+    {
+        const int level = max(my_level, 0);
+        const float scale = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * level, __builtin_bit_cast(int, lv_scale)));
+        const int sp = __builtin_amdgcn_ds_bpermute(4 * level, lv_sp);
+        const float angle = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * angle_lane(lane & 7), __builtin_bit_cast(int, kp_angle)));
+        if (lane < nk) {
+            const int k = k0 + lane;
+            const int kx = (int)(my_sel & 0xfff) + 16, ky = (int)((my_sel >> 12) & 0xfff) + 16;
             aos2_keypoint_t kp;
-            const int level = cur.level;
-            const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lv_scale), level));
-            kp.x = level != 0 ? __fmul_rn((float)cur.kx, scale) : (float)cur.kx;
-            kp.y = level != 0 ? __fmul_rn((float)cur.ky, scale) : (float)cur.ky;
-            kp.size = (float)__builtin_amdgcn_readlane(lv_sp, level);
+            kp.x = level != 0 ? __fmul_rn((float)kx, scale) : (float)kx;
+            kp.y = level != 0 ? __fmul_rn((float)ky, scale) : (float)ky;
+            kp.size = (float)sp;
             kp.angle = angle;
-            kp.response = (float)cur.score;
+            kp.response = (float)(int)(my_sel >> 24);
             kp.octave = level;
             kp.class_id = -1;
             kps[(size_t)b * cap + k] = kp;
         }
-        cur = nxt;
     }
 }
 
@@ -1328,7 +1358,7 @@ __global__ __launch_bounds__(64) void describe_blur_kernel(const uint8_t *__rest
     const int b = blockIdx.x;
     if (b >= batch) return;
     const int lane = threadIdx.x;
-    const int k0 = blockIdx.y * DK;
+    const int k0 = blockIdx.y * DKB;
     int lv_pitch = 0, lv_sp = 0, lv_bpitch = 0;
     uint32_t lv_off = 0, lv_boff = 0;
     float lv_scale = 0.f;
@@ -1352,7 +1382,7 @@ __global__ __launch_bounds__(64) void describe_blur_kernel(const uint8_t *__rest
         if (worst < 0) atomicMin(status, worst);
         if (total > cap) atomicMax(status + 1, total);
     }
-    const int nk = min(DK, min(total, cap) - k0);
+    const int nk = min(DKB, min(total, cap) - k0);
     if (nk <= 0) return;
     uint32_t my_sel = 0;
     if (lane < nk) my_sel = sel[(size_t)b * sel_stride + (size_t)my_level * cap_level + my_kin];
@@ -1663,7 +1693,7 @@ void launch_describe_blur(const uint8_t *img0, size_t img0_stride, int pitch0, c
                           const uint32_t *sel, size_t sel_stride, int cap_level, const int32_t *sel_level_cnt,
                           aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch, int32_t *status, hipStream_t st)
 {
-    dim3 blk(64), grd((batch + 7) & ~7, (cap + DK - 1) / DK);
+    dim3 blk(64), grd((batch + 7) & ~7, (cap + DKB - 1) / DKB);
     hipLaunchKernelGGL(describe_blur_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, blur, blur_stride, to_dev(plan),
                        levels, n_levels, sel, sel_stride, cap_level, sel_level_cnt, kps, desc, cap, n_out, status, batch);
 }
@@ -1674,9 +1704,16 @@ void launch_describe(const uint8_t *img0, size_t img0_stride, int pitch0, const 
                      aos2_keypoint_t *kps, uint8_t *desc, int cap, int32_t *n_out, int batch,
                      unsigned long long umax_nibbles, int32_t *status, hipStream_t st)
 {
-    dim3 blk(64), grd((batch + 7) & ~7, (cap + DK - 1) / DK);
-    hipLaunchKernelGGL(describe_kernel, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel, sel_stride,
-                       cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status, batch);
+    // waves of DK_FEW keypoints while they all fit on the chip at once (256 CUs x 28 waves), of DK_BATCH beyond
+    const bool few = (long long)batch * ((cap + DK_FEW - 1) / DK_FEW) <= 2 * 7168;
+    const int dk = few ? DK_FEW : DK_BATCH, groups = (cap + dk - 1) / dk;
+    dim3 blk(64), grd((unsigned)(((batch + 7) & ~7) * groups));
+    if (few)
+        hipLaunchKernelGGL(describe_kernel<DK_FEW>, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel,
+                           sel_stride, cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status, batch, groups);
+    else
+        hipLaunchKernelGGL(describe_kernel<DK_BATCH>, grd, blk, 0, st, img0, img0_stride, pitch0, pyr, pyr_stride, levels, n_levels, sel,
+                           sel_stride, cap_level, sel_level_cnt, kps, desc, cap, n_out, umax_nibbles, status, batch, groups);
 }
 
 }  // namespace aos2
