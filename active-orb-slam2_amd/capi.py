@@ -177,6 +177,12 @@ def lib():
             L.aos2_extractor_wait_for_stream.argtypes = [vp, vp]
             L.aos2_lba_last_window_slots.argtypes = [vp, C.POINTER(C.c_int64)]
             L.aos2_extractor_pack_slots.argtypes = [vp, ci, vp, vp, vp, ci, vp, C.c_size_t, vp]
+            L.aos2_capture_begin.argtypes = [vp]
+            L.aos2_capture_end.argtypes = [vp, C.POINTER(vp)]
+            L.aos2_graph_launch.argtypes = [vp, vp]
+            L.aos2_graph_nodes.argtypes = [vp]
+            L.aos2_graph_destroy.argtypes = [vp]
+            L.aos2_graph_destroy.restype = None
         _LIB = _RecLib(L)
     return _LIB
 
@@ -285,6 +291,49 @@ class _RecLib:
                 w = fn
             self._w[name] = w
         return w
+
+
+class Graph:
+    """include/aos2.h "Replay of a fixed call sequence": the calls made inside `with Graph.capture(stream) as g:` are recorded
+    (nothing runs); g.launch() enqueues them all with one call"""
+
+    def __init__(self, stream):
+        self.L, self.stream, self.h = lib(), stream, None
+
+    @classmethod
+    def capture(cls, stream):
+        return cls(stream)
+
+    def __enter__(self):
+        _check(self.L.aos2_capture_begin(self.stream))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        st = self.L.aos2_capture_end(self.stream, C.byref(h))
+        if et is None:
+            _check(st)
+            self.h = h
+        elif st == AOS2_OK and h:
+            self.L.aos2_graph_destroy(h)   # (the body failed: what was recorded until then is dropped)
+        return False
+
+    def nodes(self):
+        return int(self.L.aos2_graph_nodes(self.h))
+
+    def launch(self, stream=None):
+        _check(self.L.aos2_graph_launch(self.h, self.stream if stream is None else stream))
+
+    def close(self):
+        if self.h:
+            self.L.aos2_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _HIP = None

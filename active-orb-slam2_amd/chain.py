@@ -164,6 +164,25 @@ class TrackingChain:
         self.cur.wait()
         self.ex.wait()
 
+    # ---- the step as ONE launch (include/aos2.h "Replay of a fixed call sequence"): the calls of step() recorded once, replayed per
+    # frame.  The buffers the recording names (image, pose guess, local-map rows, outputs) are the chain's own: new contents, same places.
+    def capture_step(self):
+        if self.hb is not None:
+            raise RuntimeError("capture_step: the host-boundary copies are not part of the recorded step")
+        self.step()
+        self.wait()   # (every handle has allocated for this shape)
+        q = self.cur.stream()
+        with capi.Graph.capture(q) as gr:
+            for ex in (self.ex, getattr(self, "ex_r", None)):   # the extractors' streams join the recording; Frame::build's device-side
+                if ex is not None:                               # wait on the extraction ends their part
+                    ex.wait_for_stream(q)
+            self.step()
+        self.graph = gr
+        return gr
+
+    def step_graph(self):
+        self.graph.launch()
+
     # ---- ONE sequence, frame after frame, with the NEXT image's ExtractORB already running: the extraction of frame t + 1 depends on
     # nothing of frame t (Tracking::GrabImageRGBD builds the Frame from the image alone, src/Tracking.cc:207-235), so it is enqueued
     # on the extractor's stream as soon as frame t's Frame::Frame has taken its own extraction, beside frame t's searches and

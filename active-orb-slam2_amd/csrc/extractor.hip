@@ -119,8 +119,12 @@ struct aos2_extractor {
     // ComputeStereoMatches reads BOTH extractors' pyramid blocks on the left one's first stream: each extractor keeps an event behind
     // those kernels, and its next batch waits for it on every chunk stream before it rewrites the pyramids (stereo_guard_armed)
     hipEvent_t stereo_guard = nullptr, stereo_t0 = nullptr, stereo_t1 = nullptr;
-    hipEvent_t input_ev = nullptr;   // aos2_extractor_wait_for_stream
+    hipEvent_t input_ev = nullptr, input_fan_ev = nullptr;   // aos2_extractor_wait_for_stream
+    int input_waited = 0;   // streams that wait for the inputs announced since the last batch (0 = none announced)
+    int last_chunks = 1;    // chunk streams of the last batch
     bool stereo_guard_armed = false;
+    bool stereo_guard_captured = false;       // the guard was recorded while its stream was being captured (aos2_capture_begin)
+    hipStream_t stereo_guard_stream = nullptr;   // ... on this stream
     int streams_used = 0;                    // streams the batches since the last wait ran on (<= chunks)
     Plan plan;
     int batch_cap = 0;
@@ -655,6 +659,13 @@ struct HostIO {
     uint8_t *desc;
 };
 
+// true while `s` records for aos2_capture_begin / _end (csrc/replay.hip)
+static bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+
 static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, int w, int h, int stride,
                           size_t image_stride, aos2_keypoint_t *d_kps, uint8_t *d_desc, int cap, int32_t *d_nout,
                           const HostIO *io = nullptr)
@@ -692,8 +703,24 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
     if (e->host_octree) chunks = 1;
     chunks = std::min(chunks, std::min(batch, kMaxStreams));
     e->streams_used = std::max(e->streams_used, chunks);
+    if (e->input_waited > 0 && chunks > e->input_waited) {   // (aos2_extractor_wait_for_stream: stream 0 waits for the inputs already)
+        if (!e->input_fan_ev) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->input_fan_ev, hipEventDisableTiming));
+        AOS2_HIP_CHECK(hipEventRecord(e->input_fan_ev, e->streams[0]));
+        for (int c = e->input_waited; c < chunks; ++c) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[c], e->input_fan_ev, 0));
+    }
+    e->input_waited = 0;
+    e->last_chunks = chunks;
     if (e->stereo_guard_armed) {   // stereo kernels enqueued since the last batch still read this extractor's pyramids
-        for (int c = 0; c < chunks; ++c) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[c], e->stereo_guard, 0));
+        // An event of a recording (aos2_capture_begin) and one of executed work cannot wait for each other.  Executed batch behind a
+        // replayed recording: the guard is recorded again, now, on the stream the recording ran on (behind every launched replay).
+        // Recording behind executed work: no wait (a sequence is run, and waited for, before it is recorded: include/aos2.h).
+        const bool rec = stream_is_capturing(e->streams[0]);
+        if (!rec && e->stereo_guard_captured) {
+            AOS2_HIP_CHECK(hipEventRecord(e->stereo_guard, e->stereo_guard_stream));
+            e->stereo_guard_captured = false;
+        }
+        if (rec == e->stereo_guard_captured)
+            for (int c = 0; c < chunks; ++c) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[c], e->stereo_guard, 0));
         e->stereo_guard_armed = false;
     }
     auto enqueue = [&](int b0, int nb, hipStream_t s, bool timed) -> int {
@@ -792,6 +819,11 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
 static int finish_device(aos2_extractor *e)
 {
     if (e->in_flight == 0) return AOS2_OK;
+    if (stream_is_capturing(e->streams[0])) {   // (refused before the runtime sees the wait: it would invalidate the recording)
+        set_error("the extractor's stream is recording (aos2_capture_begin): a host wait -- aos2_extractor_wait, a synchronous call, a "
+                  "change of batch size or geometry -- cannot be recorded");
+        return AOS2_ERR_ARG;
+    }
     const int L = e->nlevels, batch = e->last_batch, cap = e->flight_cap;
     int32_t status[2] = {0, 0};
     for (int c = 1; c < kMaxStreams; ++c) AOS2_HIP_CHECK(hipStreamSynchronize(e->streams[c]));
@@ -970,7 +1002,7 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
         for (int i = 0; i < e->n_streams; ++i) (void)hipStreamDestroy(e->streams[i]);
         for (auto &oe : e->order_ev)
             if (oe) (void)hipEventDestroy(oe);
-        for (hipEvent_t x : {e->stereo_guard, e->stereo_t0, e->stereo_t1, e->input_ev})
+        for (hipEvent_t x : {e->stereo_guard, e->stereo_t0, e->stereo_t1, e->input_ev, e->input_fan_ev})
             if (x) (void)hipEventDestroy(x);
     }
     delete e;
@@ -1071,7 +1103,12 @@ int aos2_extractor_wait_for_stream(aos2_extractor_t *e, void *hip_stream)
     hipStream_t src = static_cast<hipStream_t>(hip_stream);
     if (!e->input_ev) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->input_ev, hipEventDisableTiming));
     AOS2_HIP_CHECK(hipEventRecord(e->input_ev, src));
-    for (int i = 0; i < std::max(1, e->n_streams); ++i) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[i], e->input_ev, 0));
+    // the streams the last batch's chunks ran on wait now; a next batch cut into more chunks orders the others behind stream 0
+    // (enqueue_device).  Streams that get no work are left alone: a recording (aos2_capture_begin) must not be joined by
+    // streams that never return to it.
+    const int k = std::max(1, std::min(e->n_streams, e->last_chunks));
+    for (int i = 0; i < k; ++i) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[i], e->input_ev, 0));
+    e->input_waited = std::max(e->input_waited, k);
     return AOS2_OK;
 }
 
@@ -1088,6 +1125,7 @@ int aos2_extractor_stream_wait(aos2_extractor_t *e, void *hip_stream)
     const int used = std::max(1, std::min(e->n_streams, e->streams_used));
     for (int i = 0; i < used; ++i) {
         if (!e->order_ev[i]) AOS2_HIP_CHECK(hipEventCreateWithFlags(&e->order_ev[i], hipEventDisableTiming));
+        if (e->streams[i] == waiter) continue;   // (in order behind its own work already)
         AOS2_HIP_CHECK(hipEventRecord(e->order_ev[i], e->streams[i]));
         AOS2_HIP_CHECK(hipStreamWaitEvent(waiter, e->order_ev[i], 0));
     }
@@ -1232,6 +1270,8 @@ static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int
     for (aos2_extractor *x : {l, r}) {   // the next extraction of either eye is ordered behind these kernels on all its streams
         AOS2_HIP_CHECK(hipEventRecord(x->stereo_guard, l->stream));
         x->stereo_guard_armed = true;
+        x->stereo_guard_captured = stream_is_capturing(l->stream);
+        x->stereo_guard_stream = l->stream;
     }
     if (!sync) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamSynchronize(l->stream));

@@ -857,6 +857,29 @@ def main():
                 tc1.wait()
                 lat.append(time.perf_counter() - ta_)
             ms1 = float(np.median(lat[5:])) * 1e3
+            # ... the same calls recorded once and replayed with ONE launch per frame (include/aos2.h "Replay of a fixed call sequence"):
+            # the members the replay leaves are compared with the plain calls' (bytes)
+            tc1.wait()
+            F1 = pkg.capi.Frames
+            plain_members = [tc1.cur.get(F1.TCW).tobytes(), tc1.cur.get(F1.MAP_POINTS).tobytes(), tc1.cur.get(F1.OUTLIER).tobytes(),
+                             tc1.d_nm.cpu().numpy().tobytes(), tc1.d_desc.cpu().numpy().tobytes()]
+            gr1 = tc1.capture_step()
+            tc1.d_nm.zero_(); tc1.d_desc.zero_()
+            lat = []
+            for it_ in range(45):
+                torch.cuda.synchronize()
+                ta_ = time.perf_counter()
+                tc1.step_graph()
+                tc1.cur.wait()
+                lat.append(time.perf_counter() - ta_)
+            ms1g = float(np.median(lat[5:])) * 1e3
+            replay_members = [tc1.cur.get(F1.TCW).tobytes(), tc1.cur.get(F1.MAP_POINTS).tobytes(), tc1.cur.get(F1.OUTLIER).tobytes(),
+                              tc1.d_nm.cpu().numpy().tobytes(), tc1.d_desc.cpu().numpy().tobytes()]
+            replay = {"ms_per_frame": ms1g, "frames_per_s": 1e3 / ms1g, "launches_recorded": gr1.nodes(),
+                      "same_members_as_the_plain_calls": replay_members == plain_members,
+                      "note": "aos2_capture_begin / the calls of the frame / aos2_capture_end once, then aos2_graph_launch + aos2_frames_wait per "
+                              "frame: the kernels run back to back instead of ~6 us apart"}
+            gr1.close()
             # ... and with the next image's ExtractORB enqueued beside the frame's tracking (chain.step_pipelined): wall clock of 200 frames
             tc1.wait()
             for it_ in range(10):
@@ -866,7 +889,7 @@ def main():
                 tc1.step_pipelined(); tc1.wait_frame()
             ms1p = (time.perf_counter() - ta_) * 1e3 / 200
             tc1.wait()
-            extra["single_sequence"] = {"ms_per_frame": ms1, "frames_per_s": 1e3 / ms1,
+            extra["single_sequence"] = {"ms_per_frame": ms1, "frames_per_s": 1e3 / ms1, "recorded_sequence_replayed": replay,
                                         "next_image_extracted_beside_tracking": {"ms_per_frame": ms1p, "frames_per_s": 1e3 / ms1p,
                                             "note": "the same chain, every frame waited for before the next one's Frame::Frame, but the NEXT image's "
                                                     "operator() is enqueued on the extractor's stream while this frame is tracked (it depends on the image "

@@ -847,6 +847,38 @@ int aos2_frames_fuse(aos2_frames_t *kfs, const aos2_map_points_dev_t *mps, int n
 int aos2_frames_set_async_keyframe_calls(aos2_frames_t *f, int on);
 
 /* ------------------------------------------------------------------------------------------
+ * Replay of a fixed call sequence (csrc/replay.hip).  No single reference function: the per-frame body of Tracking::Track on its
+ * usual path -- Frame::Frame (src/Frame.cc:116-172), TrackWithMotionModel (src/Tracking.cc:860-1039: SearchByProjection,
+ * PoseOptimization, the outlier discard), TrackLocalMap (:1041-1100: SearchLocalPoints, PoseOptimization) -- is the same ~20
+ * dependent launches for every frame.  For one sequence (batch 1) the launches' own latency is a sixth of the frame time; a
+ * recorded sequence is enqueued with one call and its kernels run back to back.
+ *
+ *   run the sequence once (the handles allocate on their first call with a shape), then
+ *   aos2_capture_begin(aos2_frames_stream(cur));
+ *   aos2_extractor_wait_for_stream(e, aos2_frames_stream(cur));      -- the extractor's stream joins the recording
+ *   ... aos2_frames_set_pose, aos2_extractor_extract_batch_device_async, aos2_frames_build (orders the batch behind the
+ *       extraction: the extractor's stream leaves the recording), aos2_frames_search_by_projection_last,
+ *       aos2_frames_pose_optimization, ... -- NOTHING runs, the launches are recorded with their arguments
+ *   aos2_capture_end(aos2_frames_stream(cur), &g);
+ *   per frame: write the image / the pose guess / the local-map rows into the SAME device buffers, aos2_graph_launch(g, stream),
+ *   aos2_frames_wait(cur).
+ *
+ * What is fixed at recording time: every argument passed by value (sizes, thresholds, device addresses).  A count that changes from
+ * frame to frame goes through device memory the kernels already read (the frames' keypoint counts d_n, the MapPoint table) or is
+ * padded to a capacity: d_local rows of -1 are "no point" (aos2_frames_search_local_points), so n_local can be the capacity of the
+ * local map.  Calls that wait on the host (aos2_*_wait, the synchronous forms) cannot be recorded.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct aos2_graph aos2_graph_t;
+/* starts recording on `hip_stream` (a handle's stream, not NULL): the calls that follow enqueue nothing */
+int aos2_capture_begin(void *hip_stream);
+/* ends the recording (every other stream that joined must have been waited for by `hip_stream`) and builds the replayable graph */
+int aos2_capture_end(void *hip_stream, aos2_graph_t **out);
+/* enqueues the recorded sequence on `hip_stream` (normally the stream it was recorded on); returns at once */
+int aos2_graph_launch(aos2_graph_t *g, void *hip_stream);
+int aos2_graph_nodes(const aos2_graph_t *g);   /* kernels + copies of the recording */
+void aos2_graph_destroy(aos2_graph_t *g);
+
+/* ------------------------------------------------------------------------------------------
  * Dataset helper (host code; the reference reads its datasets with cv::imread, Examples/RGB-D/rgbd_tum.cc:77-78): the PNG
  * scanline filters undone in place -- rows = h rows of 1 filter byte + stride data bytes as inflated, bpp = bytes per pixel.
  * ------------------------------------------------------------------------------------------ */

@@ -448,3 +448,48 @@ def test_host_boundary_of_the_chain(pkg, oracle, gpu):
                 assert host[k].tobytes() == dev[k].tobytes(), k
             assert parity.chain_mismatches(host, co, range(6)) == []
         assert tc.hb["up_bytes"] == (2 if stereo else 1) * 6 * scen["w"] * scen["h"] and tc.hb["down_bytes"] > 6 * tc.cap * 60
+
+
+def test_recorded_step_replays_as_one_launch(pkg, oracle, gpu):
+    """include/aos2.h "Replay of a fixed call sequence": the calls of the chain's step recorded once (aos2_capture_begin / _end on the
+    Frame batch's stream, the extractors' streams joining through aos2_extractor_wait_for_stream), then one aos2_graph_launch per
+    frame.  After the outputs were scribbled over and the images replaced, the replay leaves what the plain calls leave, and what
+    the oracle computes; a call that waits on the host inside a recording is reported, not recorded."""
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    keys = ("n", "kps", "desc", "mp", "outlier", "Tcw", "u_right", "depth", "nm")
+    for stereo, nf in ((False, 1), (False, 6), (True, 3)):
+        scen = pkg.scenario.tracking_scenario(47, nf, cfg="kitti" if stereo else "tum", n_unique=min(nf, 3), stereo=stereo)
+        tc = (pkg.chain.StereoTrackingChain if stereo else pkg.chain.TrackingChain)(scen, n_local=800)
+        tc.step()
+        tc.wait()
+        want = parity.chain_snapshot(pkg, tc)
+        co = parity.ChainOracle(scen, tc)
+        gr = tc.capture_step()
+        assert gr.nodes() >= 15
+        img = tc.d_cur.clone()
+        for rep in range(3):
+            tc.d_kps.zero_(); tc.d_desc.zero_(); tc.d_n.zero_(); tc.d_nm.zero_()
+            tc.d_cur.zero_()
+            tc.torch.cuda.synchronize()
+            tc.d_cur.copy_(img)   # "the next image" arrives in the same buffer
+            tc.torch.cuda.synchronize()
+            tc.step_graph()
+            tc.cur.wait()
+            got = parity.chain_snapshot(pkg, tc)
+            for k in keys:
+                assert got[k].tobytes() == want[k].tobytes(), (stereo, nf, rep, k)
+            assert parity.chain_mismatches(got, co, range(nf)) == []
+        tc.wait()   # the extractor's own wait reports the replayed extraction's status
+        tc.step(); tc.wait()   # the plain calls still work on the same handles
+        got = parity.chain_snapshot(pkg, tc)
+        assert all(got[k].tobytes() == want[k].tobytes() for k in keys)
+        gr.close()
+    # a host wait inside a recording is refused (before the runtime sees it), the handles stay usable
+    with pytest.raises(RuntimeError) as ei:
+        with pkg.capi.Graph.capture(tc.cur.stream()):
+            tc.cur.wait()
+    assert "recording" in str(ei.value)
+    tc.step(); tc.wait()
+    got = parity.chain_snapshot(pkg, tc)
+    assert all(got[k].tobytes() == want[k].tobytes() for k in keys)
