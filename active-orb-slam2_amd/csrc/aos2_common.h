@@ -17,6 +17,9 @@ void set_error(const char *fmt, ...);
 // Binds `device` for the calling thread; AOS2_ERR_NO_DEVICE if it does not exist.
 int bind_device(int device);
 
+// Every stream of the library is created here (csrc/replay.hip): non-blocking, of the highest priority class when asked for.
+int stream_create(hipStream_t *q, bool high_priority);
+
 #define AOS2_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
         hipError_t err__ = (expr);                                                        \

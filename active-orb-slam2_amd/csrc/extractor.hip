@@ -496,9 +496,9 @@ static int init_device(aos2_extractor *e)
         const char *v = getenv("AOS2_NSTREAMS");
         const int ns = v ? std::max(1, std::min(kMaxStreams, atoi(v))) : kMaxStreams;
         for (int i = 0; i < kMaxStreams; ++i) {
-            if (i < ns)
-                AOS2_HIP_CHECK(hipStreamCreateWithFlags(&e->streams[i], hipStreamNonBlocking));
-            else
+            if (i < ns) {
+                if ((st = stream_create(&e->streams[i], false))) return st;
+            } else
                 e->streams[i] = e->streams[i % ns];
         }
         e->n_streams = ns;

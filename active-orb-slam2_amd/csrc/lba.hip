@@ -1954,20 +1954,12 @@ int lba_handle_init(aos2_lba *s)
     // running system (extraction, searches) are wide and throughput-bound.  On a high-priority stream the optimiser's
     // workgroups are dispatched ahead of the waiting ones of those kernels (AOS2_LBA_STREAM_PRIORITY=normal switches it off).
     {
-        int least = 0, greatest = 0;
         const char *e = getenv("AOS2_LBA_STREAM_PRIORITY");
-        if ((!e || strcmp(e, "normal")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-            AOS2_HIP_CHECK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
-        else
-            AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        if ((st = stream_create(&s->stream, !e || strcmp(e, "normal")))) return st;
     }
     for (auto &e : s->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-            AOS2_HIP_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, greatest));
-        else
-            AOS2_HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+        if ((st = stream_create(&s->stream2, true))) return st;
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AOS2_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     }
@@ -1986,15 +1978,10 @@ int lba_handle_init(aos2_lba *s)
 static int lba_group_streams(aos2_lba *s)
 {
     if (s->stream_b) return AOS2_OK;
-    int least = 0, greatest = 0;
     const char *e = getenv("AOS2_LBA_STREAM_PRIORITY");
-    const bool prio = (!e || strcmp(e, "normal")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least;
-    for (hipStream_t *q : {&s->stream_b, &s->stream2_b}) {
-        if (prio)
-            AOS2_HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
-        else
-            AOS2_HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
-    }
+    const bool prio = !e || strcmp(e, "normal");
+    if (int st_ = stream_create(&s->stream_b, prio)) return st_;
+    if (int st_ = stream_create(&s->stream2_b, prio)) return st_;
     for (hipEvent_t *ev : {&s->ev_fork_b, &s->ev_join_b, &s->ev_up, &s->ev_stag, &s->ev_done_b}) AOS2_HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return AOS2_OK;
 }

@@ -7,6 +7,24 @@
 // with one call and the device runs the kernels back to back.
 #include "aos2_common.h"
 
+namespace aos2 {
+
+// Every stream of the library is created here.  (Measured and dropped, round 5: compute units set aside for LocalBundleAdjustment's
+// reduced-system kernel with hipExtStreamCreateWithCUMask, every other stream masked off them -- the kernel's workgroup needs a
+// whole CU and waits for one while wide tracking kernels keep placing workgroups -- made the composite step 6 x longer, 7.5 ->
+// 46 ms with 32 or 64 of the 256 CUs set aside: streams with a CU mask do not run beside each other the way plain ones do.)
+int stream_create(hipStream_t *q, bool high_priority)
+{
+    int least = 0, greatest = 0;
+    if (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        AOS2_HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, greatest));
+    else
+        AOS2_HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+    return AOS2_OK;
+}
+
+}  // namespace aos2
+
 struct aos2_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;

@@ -76,6 +76,7 @@ fi
 if has chain; then
   python tools/gpu_chain_latency.py 2>&1 | grep -v "amdgpu.ids" > $O/chain_latency.txt
   python tools/gpu_pipelined_trace.py 2>&1 | grep "per frame" >> $O/chain_latency.txt
+  python tools/gpu_graph_chain.py 2>&1 | grep "per frame\|nodes\|matches" >> $O/chain_latency.txt
   tail -5 $O/chain_latency.txt
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*counter_collection.csv" -delete
