@@ -91,6 +91,7 @@ struct aos2_frames {
     aos2::DevBuf<uint64_t> pool;     // candidate entries (8 B each)
     aos2::DevBuf<uint8_t> pose_mem;  // PoseOptimization problem arrays
     aos2::PinnedBuf<uint8_t> h_io;   // small page-locked staging (poses, counts)
+    aos2::PinnedBuf<int32_t> h_overflow;   // d_overflow: written by the kernels, read by aos2_frames_wait
     aos2::PinnedBuf<uint8_t> kf_host;   // keyframe work (triangulation pairs, fuse targets): staging ...
     aos2::DevBuf<uint8_t> kf_dev;       // ... and its device copy
     aos2::PinnedBuf<uint8_t> kf_host2;  // the same for aos2_frames_fuse (SearchForTriangulation and Fuse of one handle may both be in flight)

@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
                 // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
                 const int stride = phase == 2 ? pop : pool_cap / max(P.n_mp, 1);
                 int off = phase == 2 ? slots[i].ent_off - pool_base : i * stride;
-                if (pop > stride && lane == 0) atomicMax(pool_used, pop);   // overflow flag for the host (batched form)
+                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // overflow flag for the host (batched form)
                 if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                     const int lvl = P.pred_level[i];
                     off += pool_base;
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const 
                 } else if (pop > 0) {
                     const int stride = phase == 2 ? pop : pool_cap / max(P.n_last, 1);
                     const int off = phase == 2 ? slots[i].ent_off : pool_base + i * stride;
-                    if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                    if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                         const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
                         window_entries(F, w, load_desc(P.desc + (size_t)row * 32), u, v, radius, minL, maxL, ur, radius, lane,
@@ -1860,7 +1860,7 @@ __global__ __launch_bounds__(64) void projgen_entries_kernel(FrameDev F, ProjGen
             if (pop > 0) {
                 const int stride = pool_cap / max(P.n_pts, 1);   // query i owns pool[i * stride ..): no shared counter
                 const int off = i * stride;
-                if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (pop <= stride) {
                     // mode 2: levels [pred-1, pred] tested per candidate (:379-382) == the level filter of the
                     // Frame version; mode 4: GetFeaturesInArea(u, v, radius, pred-1, pred+1) (:1537).  A level
@@ -2014,7 +2014,7 @@ __global__ __launch_bounds__(64) void init_entries_kernel(FrameDev F2, InitDev P
             if (pop > 0) {
                 const int stride = pool_cap / max(P.n1, 1);
                 const int off = i * stride;
-                if (pop > stride && lane == 0) atomicMax(pool_used, pop);
+                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (pop <= stride) {
                     const int lvl = P.octave1[i];
                     window_entries(F2, w, load_desc(P.desc1 + (size_t)i * 32), x, y, P.window, lvl, lvl, 0.0f,

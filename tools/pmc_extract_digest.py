@@ -2,7 +2,7 @@
 tools/prof_extract.py 512: python tools/pmc_extract_digest.py <pmc txt> <kernel_stats.csv>"""
 import csv, json, re, sys
 txt = open(sys.argv[1]).read()
-stats = {r["Name"].split("(")[0].split("::")[-1]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[2]))}
+stats = {r["Name"].split("(")[0].split("::")[-1].split("<")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[2]))}   # (templates: name<..>)
 tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
 out = {"source": "profiles/%s_pmc_extract_b512.txt (rocprofv3 --pmc passes of tools/prof_extract.py 512, tools/prof_%s.sh) + "
                  "profiles/r02_hbm_counter_calibration.txt" % (tag, tag), "batch": 512}
