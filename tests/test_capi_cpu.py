@@ -275,3 +275,16 @@ def test_host_alloc_needs_the_gpu_runtime(pkg):
     assert L.aos2_host_free(None) == 0
     with pytest.raises(pkg.AosError):
         pkg.host_empty((4, 4))
+
+
+def test_replay_entry_points_validate_their_arguments(pkg):
+    """include/aos2.h "Replay of a fixed call sequence": the argument checks that need no device -- a recording needs a handle's
+    stream (not the null stream), a launch needs a graph; destroying nothing is allowed."""
+    L = pkg.capi.lib()
+    assert L.aos2_capture_begin(None) == pkg.capi.AOS2_ERR_ARG
+    assert b"stream" in L.aos2_last_error()
+    h = C.c_void_p()
+    assert L.aos2_capture_end(None, C.byref(h)) == pkg.capi.AOS2_ERR_ARG and not h.value
+    assert L.aos2_graph_launch(None, None) == pkg.capi.AOS2_ERR_ARG
+    assert L.aos2_graph_nodes(None) == 0
+    L.aos2_graph_destroy(None)
