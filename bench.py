@@ -1261,16 +1261,23 @@ def main():
             # through the oracle's solver); the oracle runs on a few host threads (its C functions hold no state)
             parity.reset_worst()
             t_or = time.perf_counter()
-            n_thr = max(1, min(16, (os.cpu_count() or 1) // 2))
+            n_thr = max(1, min(int(os.environ.get("AOS2_BENCH_ORACLE_THREADS", "64")), (os.cpu_count() or 1) // 2))
+            t_mt = {"chain": time.perf_counter()}
+            n_cached0 = len(co.cache)
             co.precompute(range(n_unique), threads=n_thr)
+            t_mt["chain"] = time.perf_counter() - t_mt["chain"]
+            t_mt["chain_frames"] = len(co.cache) - n_cached0
             pos = [b for b in range(B) if int(scen_v["index"][b]) in co.cache]
             bad = parity.chain_mismatches(snap["chain"], co, pos)
             if snap["lba"]:
                 from concurrent.futures import ThreadPoolExecutor as _TPE2
                 todo = [k for k in range(len(lba_unique)) if k not in lba_want]
+                t_mt["lba"] = time.perf_counter()
                 with _TPE2(n_thr) as pool3:
                     for k, w_ in zip(todo, pool3.map(lambda k_: O.lba_solve(lba_unique[k_]), todo)):
                         lba_want[k] = w_
+                t_mt["lba"] = time.perf_counter() - t_mt["lba"]
+                t_mt["lba_windows"] = len(todo)
             n_bow_checked = 0
             if snap["bow"] is not None:
                 bpos = [b for b in range(n_bow) if int(scen_v["index"][b]) in co.cache]
@@ -1312,6 +1319,20 @@ def main():
             wins = [w for w in range(len(snap["lba"])) if w % len(lba_unique) in lba_want]
             for w in wins:
                 bad += parity.lba_mismatches(snap["lba"][w], lba_want[w % len(lba_unique)], tag=f"LocalBA window {w} (problem {w % len(lba_unique)})")
+            # BASELINE.md section 3 asks for an all-cores CPU figure beside the one-core one: the oracle's passes of this check ARE the
+            # composite's per-frame chains and LocalBA windows on `n_thr` host threads (the C functions hold no state and release the
+            # interpreter lock; the numpy glue between them does not, which is what limits the scaling)
+            if isinstance(out.get("cpu_baseline"), dict) and t_mt.get("chain_frames", 0) > 0 and t_mt.get("lba_windows", 0) > 0:
+                per_frame = t_mt["chain"] / t_mt["chain_frames"]
+                per_window = t_mt["lba"] / t_mt["lba_windows"]
+                one = out["cpu_baseline"].get("ms_per_frame", {})
+                legs = sum(one.get(k_, 0.0) for k_ in ("compute_bow", "search_by_bow", "search_for_triangulation", "fuse")) * 1e-3   # (one thread)
+                out["cpu_baseline"]["composite_frame_parallel"] = {
+                    "value": 1.0 / (per_frame + per_window / fpk + legs), "unit": "frames/s", "cores": n_thr,
+                    "sample": "%d distinct frame pairs through the oracle's tracking chain and %d LocalBA windows through its solver on %d threads "
+                              "(the oracle passes of parity_checked), one window per %d frames; the keyframe legs at their one-thread cost" %
+                              (t_mt["chain_frames"], t_mt["lba_windows"], n_thr, fpk),
+                    "ms_per_frame": {"tracking_chain": per_frame * 1e3, "local_ba": per_window / fpk * 1e3, "keyframe_legs_one_thread": legs * 1e3}}
             out["parity_checked"] = {
                 "ok": not bad, "step": "the last timed step (results copied right after the timed region)",
                 "frames": len(pos), "distinct_frame_pairs": len(co.cache), "reference_keyframe_bow_frames": n_bow_checked,
