@@ -12,8 +12,8 @@ if has suite; then
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 fi
 if has bench; then
-  # the default line five times in a row (the spread), the median run is the committed line; then the other forms once each
-  for i in 1 2 3 4 5; do python bench.py > $O/bench_default_$i.json 2> $O/bench_default_$i.err; tail -c 200 $O/bench_default_$i.json; done
+  # the default line ten times in a row (the spread), the median run is the committed line; then the other forms once each
+  for i in 01 02 03 04 05 06 07 08 09 10; do python bench.py > $O/bench_default_$i.json 2> $O/bench_default_$i.err; tail -c 200 $O/bench_default_$i.json; done
   python bench.py --host-images --no-extra > $O/bench_host_images.json 2> $O/bench_host_images.err
   python bench.py --lba-mix homogeneous --no-extra > $O/bench_homogeneous.json 2> $O/bench_homogeneous.err
   AOS2_BENCH_RUNNER=python AOS2_BENCH_LBA_HANDLES=2 python bench.py --no-extra --no-cpu-baseline > $O/bench_python_threads.json 2> $O/bench_python_threads.err
