@@ -13,6 +13,9 @@ import numpy as np
 from . import capi, scenario
 
 
+HIP_D2D = 3   # hipMemcpyDeviceToDevice
+
+
 class TrackingChain:
     def __init__(self, scen: dict, device: int = 0, n_local: int = 1500, th_last: float = 15.0, th_local: float = 3.0,
                  nnratio_local: float = 0.8):
@@ -119,7 +122,10 @@ class TrackingChain:
     # stream behind the second PoseOptimization (wait() covers them).
     hb = None
 
-    def enable_host_boundary(self, on=True):
+    def enable_host_boundary(self, on=True, prefetch=False):
+        """prefetch: the images of a step were copied up during the step BEFORE (into a staging buffer on the device, the way a frame
+        grabber double-buffers); the step starts with a device-to-device copy staging -> image buffer and then starts the next
+        upload, so that the 157 MB of a 512-frame step travel beside the previous step's kernels instead of in front of this step's"""
         t, F = self.torch, capi.Frames
         if not on:
             self.hb = None
@@ -139,14 +145,27 @@ class TrackingChain:
                        pins=dict(mp=pin((B, cap), t.int32), outlier=pin((B, cap), t.uint8), Tcw=pin((B, 16), t.float32),
                                  u_right=pin((B, cap), t.float32), depth=pin((B, cap), t.float32)))
         self.hb["up_bytes"] = sum(h.numel() * h.element_size() for _, _, h in imgs)
+        self.hb["stage"] = None
+        if prefetch:
+            self.hb["stage"] = [t.empty_like(d) for _, d, _ in imgs]
+            t.cuda.synchronize()
+            for st_, (_, _, h) in zip(self.hb["stage"], imgs):   # the first step's images
+                capi._check(H.hipMemcpyAsync(st_.data_ptr(), h.data_ptr(), h.numel() * h.element_size(), capi.HIP_H2D, s_io))
 
     def _images_from_host(self):
         H, hb = capi.hip_runtime(), self.hb
-        for name, d, h in hb["imgs"]:
-            capi._check(H.hipMemcpyAsync(d.data_ptr(), h.data_ptr(), h.numel() * h.element_size(), capi.HIP_H2D, hb["s_io"]))
+        if hb["stage"] is None:
+            for name, d, h in hb["imgs"]:
+                capi._check(H.hipMemcpyAsync(d.data_ptr(), h.data_ptr(), h.numel() * h.element_size(), capi.HIP_H2D, hb["s_io"]))
+        else:   # (all on the one stream: staging -> images, [the extraction waits for this point], next images -> staging)
+            for st_, (name, d, h) in zip(hb["stage"], hb["imgs"]):
+                capi._check(H.hipMemcpyAsync(d.data_ptr(), st_.data_ptr(), h.numel() * h.element_size(), HIP_D2D, hb["s_io"]))
         self.ex.wait_for_stream(hb["s_io"])
         if hasattr(self, "ex_r"):
             self.ex_r.wait_for_stream(hb["s_io"])
+        if hb["stage"] is not None:
+            for st_, (name, d, h) in zip(hb["stage"], hb["imgs"]):
+                capi._check(H.hipMemcpyAsync(st_.data_ptr(), h.data_ptr(), h.numel() * h.element_size(), capi.HIP_H2D, hb["s_io"]))
 
     def _results_to_host(self):
         H, hb, F, c = capi.hip_runtime(), self.hb, capi.Frames, self.cur

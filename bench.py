@@ -299,11 +299,13 @@ def main():
             pp.ex.set_chunks(1)
             if KITTI:
                 pp.ex_r.set_chunks(1)
+    # the host boundary's uploads run one step ahead (chain.enable_host_boundary(prefetch=True)); AOS2_BENCH_HB_PREFETCH=0: in front of the step
+    HB_PREFETCH = os.environ.get("AOS2_BENCH_HB_PREFETCH", "1") != "0"
     if args.host_images:
         for pp in pipes:   # (one step first: the Frame batch's member arrays exist from its first build on)
             pp.step()
             pp.wait()
-            pp.enable_host_boundary()
+            pp.enable_host_boundary(prefetch=HB_PREFETCH)
     ex = pipes[0].ex
     cap = pipes[0].cap
     # ---- per keyframe (every `frames_per_keyframe` frames) the front part of Tracking::TrackReferenceKeyFrame (Tracking.cc:858-866):
@@ -630,7 +632,7 @@ def main():
     hb_run = None
     if not args.host_images and not args.no_extra and not NO_LBA and os.environ.get("AOS2_BENCH_SKIP_HOST_BOUNDARY") != "1":
         for pp in pipes:
-            pp.enable_host_boundary()
+            pp.enable_host_boundary(prefetch=HB_PREFETCH)
         if NATIVE:
             record_lists()
         n2 = max(10, min(args.steps, 50))
@@ -780,7 +782,11 @@ def main():
                  "note": "the timed steps with the reference's HOST boundary (bench.py --host-images makes it the timed form): every step's %d images "
                          "arrive from page-locked host memory (ORBextractor::operator() takes a host cv::Mat, src/Frame.cc:276-282) and mvKeys / "
                          "mDescriptors / N / mvuRight / mvDepth / mvpMapPoints / mvbOutlier / mTcw / the match counts of every frame land in page-locked "
-                         "host arrays; `value` above is the HBM-resident form BASELINE's contract asks for" % B,
+                         "host arrays; `value` above is the HBM-resident form BASELINE's contract asks for.  " % B +
+                         ("The images of a step are copied up during the pipeline's previous step into a staging buffer on the device (a frame "
+                          "grabber's double buffer) and moved into place by a device-to-device copy when the step starts; AOS2_BENCH_HB_PREFETCH=0 "
+                          "puts the upload in front of the step: 44-52 k frames/s" if HB_PREFETCH else "uploads in front of every step (AOS2_BENCH_HB_PREFETCH=0)"),
+                 "uploads_one_step_ahead": HB_PREFETCH,
                  "frames_per_s": world * B / hb_run["dt"], "ms_per_step": hb_run["dt"] * 1e3,
                  "host_to_device_MB_per_step": hb_run["up"] / 1e6, "device_to_host_MB_per_step": hb_run["down"] / 1e6,
                  "pcie_GB_per_s": (hb_run["up"] + hb_run["down"]) / hb_run["dt"] / 1e9,
@@ -1066,7 +1072,7 @@ def main():
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
                        "local_ba_handles_in_flight": NLBA, "step_runner": "native threads (csrc/host_runner.cpp)" if NATIVE else "python threads",
-                       "images": "page-locked host memory every step, results to page-locked host arrays (--host-images)" if args.host_images
+                       "images": ("page-locked host memory every step%s, results to page-locked host arrays (--host-images)" % (", uploaded one step ahead" if HB_PREFETCH else "")) if args.host_images
                                  else "resident in HBM (the host-boundary form: extra.composite_host_boundary)",
                        "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "local_ba_window_groups_per_handle": LBA_GROUPS,
                        "host_cpus_bound_to_the_gpus_numa_node": numa_cpus,

@@ -429,12 +429,12 @@ def test_host_boundary_of_the_chain(pkg, oracle, gpu):
     after the device copy of the images was scribbled over between the steps (the chain really reads the host images)."""
     sys.path.insert(0, os.path.dirname(oracle.__file__))
     import parity
-    for stereo in (False, True):
+    for stereo, prefetch in ((False, False), (True, False), (False, True), (True, True)):   # prefetch: uploads one step ahead, via a staging buffer
         scen = pkg.scenario.tracking_scenario(43, 6, cfg="kitti" if stereo else "tum", n_unique=3, stereo=stereo)
         tc = (pkg.chain.StereoTrackingChain if stereo else pkg.chain.TrackingChain)(scen, n_local=800)
         tc.step()
         tc.wait()
-        tc.enable_host_boundary()
+        tc.enable_host_boundary(prefetch=prefetch)
         co = parity.ChainOracle(scen, tc)
         for _ in range(2):
             tc.d_cur.zero_()
