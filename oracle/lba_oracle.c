@@ -21,6 +21,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Measurement switches (tools/convention_effects.py; never set by a parity test's reference run): how far do the results move
+ * when the arithmetic is re-associated at rounding level?  bit 0: the reduced system is eliminated in the opposite order (last
+ * unknown first: another admissible ordering of linear_solver_eigen.h:94-124's factorisation); bit 1: every accumulation across
+ * edges / landmarks / pivots (H blocks and b in buildSystem, the Schur products, the factorisation's dot products) is carried in
+ * long double and rounded once.  0 = the oracle as tested. */
+static int g_lba_variant = 0;
+void orc_set_lba_variant(int bits) { g_lba_variant = bits; }
+#define LBA_REVERSE_ELIMINATION 1
+#define LBA_EXTENDED_SUMS 2
+
 /* ------------------------------------------------------------------ small linear algebra */
 void orc_quat_from_rot(const double m[9], double q[4]) /* q = x y z w ; Eigen Quaternion(Matrix3) */
 {
@@ -436,6 +446,13 @@ static void build_system(lba_t *S)
     memset(S->Hll, 0, sizeof(double) * 9 * nl);
     memset(S->Hpl, 0, sizeof(double) * 18 * S->n_act_e);
     memset(S->b, 0, sizeof(double) * (6 * (size_t)np + 3 * (size_t)nl));
+    const int ext = (g_lba_variant & LBA_EXTENDED_SUMS) != 0;
+    long double *xHpp = NULL, *xHll = NULL, *xb = NULL;
+    if (ext) {
+        xHpp = (long double *)calloc(36 * (size_t)np + 1, sizeof(long double));
+        xHll = (long double *)calloc(9 * (size_t)nl + 1, sizeof(long double));
+        xb = (long double *)calloc(6 * (size_t)np + 3 * (size_t)nl + 1, sizeof(long double));
+    }
     for (int k = 0; k < S->n_act_e; ++k) {
         int e = S->act_e[k];
         int stereo = p->edge_stereo[e];
@@ -461,11 +478,11 @@ static void build_system(lba_t *S)
         for (int r = 0; r < 3; ++r) {
             double s = 0;
             for (int d = 0; d < D; ++d) s += A[d * 3 + r] * omega_r[d];
-            bl[r] += s;
+            if (ext) xb[6 * (size_t)np + 3 * (size_t)hl + r] += s; else bl[r] += s;
             for (int c = 0; c < 3; ++c) {
                 double t = 0;
                 for (int d = 0; d < D; ++d) t += A[d * 3 + r] * wo * A[d * 3 + c];
-                Hll[r * 3 + c] += t;
+                if (ext) xHll[9 * (size_t)hl + r * 3 + c] += t; else Hll[r * 3 + c] += t;
             }
         }
         if (hp >= 0) {
@@ -475,11 +492,11 @@ static void build_system(lba_t *S)
             for (int r = 0; r < 6; ++r) {
                 double s = 0;
                 for (int d = 0; d < D; ++d) s += B[d * 6 + r] * omega_r[d];
-                bp[r] += s;
+                if (ext) xb[6 * (size_t)hp + r] += s; else bp[r] += s;
                 for (int c = 0; c < 6; ++c) {
                     double t = 0;
                     for (int d = 0; d < D; ++d) t += B[d * 6 + r] * wo * B[d * 6 + c];
-                    Hpp[r * 6 + c] += t;
+                    if (ext) xHpp[36 * (size_t)hp + r * 6 + c] += t; else Hpp[r * 6 + c] += t;
                 }
                 for (int c = 0; c < 3; ++c) {
                     double t = 0;
@@ -489,11 +506,64 @@ static void build_system(lba_t *S)
             }
         }
     }
+    if (ext) {
+        for (size_t i = 0; i < 36 * (size_t)np; ++i) S->Hpp[i] = (double)xHpp[i];
+        for (size_t i = 0; i < 9 * (size_t)nl; ++i) S->Hll[i] = (double)xHll[i];
+        for (size_t i = 0; i < 6 * (size_t)np + 3 * (size_t)nl; ++i) S->b[i] = (double)xb[i];
+        free(xHpp); free(xHll); free(xb);
+    }
 }
 
 /* dense LDL^T (no pivoting) of the symmetric n x n matrix A (full storage, row-major), solve
  * A x = rhs.  Fails on an exactly-zero pivot like Eigen::SimplicialLDLT. */
+static int ldlt_solve_ext(double *A, int n, const double *rhs, double *x) /* LBA_EXTENDED_SUMS: the same recurrences, sums in long double */
+{
+    double *d = (double *)malloc(sizeof(double) * (n ? n : 1));
+    for (int j = 0; j < n; ++j) {
+        long double dj = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) dj -= (long double)A[(size_t)j * n + k] * A[(size_t)j * n + k] * d[k];
+        if ((double)dj == 0.0 || dj != dj) { free(d); return 0; }
+        d[j] = (double)dj;
+        for (int i = j + 1; i < n; ++i) {
+            long double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= (long double)A[(size_t)i * n + k] * A[(size_t)j * n + k] * d[k];
+            A[(size_t)i * n + j] = (double)(s / d[j]);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        long double s = rhs[i];
+        for (int k = 0; k < i; ++k) s -= (long double)A[(size_t)i * n + k] * x[k];
+        x[i] = (double)s;
+    }
+    for (int i = 0; i < n; ++i) x[i] /= d[i];
+    for (int i = n - 1; i >= 0; --i) {
+        long double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= (long double)A[(size_t)k * n + i] * x[k];
+        x[i] = (double)s;
+    }
+    free(d);
+    return 1;
+}
+
+static int ldlt_solve_plain(double *A, int n, const double *rhs, double *x);
 static int ldlt_solve(double *A, int n, const double *rhs, double *x)
+{
+    int (*f)(double *, int, const double *, double *) = (g_lba_variant & LBA_EXTENDED_SUMS) ? ldlt_solve_ext : ldlt_solve_plain;
+    if (!(g_lba_variant & LBA_REVERSE_ELIMINATION)) return f(A, n, rhs, x);
+    /* P A P^T (P y) = P rhs with P the reversal: the last unknown is eliminated first */
+    double *Ar = (double *)malloc(sizeof(double) * ((size_t)n * n + 1)), *br = (double *)malloc(sizeof(double) * (n + 1)),
+           *xr = (double *)malloc(sizeof(double) * (n + 1));
+    for (int i = 0; i < n; ++i) {
+        br[i] = rhs[n - 1 - i];
+        for (int j = 0; j < n; ++j) Ar[(size_t)i * n + j] = A[(size_t)(n - 1 - i) * n + (n - 1 - j)];
+    }
+    int ok = f(Ar, n, br, xr);
+    for (int i = 0; i < n; ++i) x[i] = xr[n - 1 - i];
+    free(Ar); free(br); free(xr);
+    return ok;
+}
+
+static int ldlt_solve_plain(double *A, int n, const double *rhs, double *x)
 {
     double *d = (double *)malloc(sizeof(double) * (n ? n : 1));
     /* in place: lower triangle becomes L (unit diag) */
@@ -534,6 +604,13 @@ static int solve_schur(lba_t *S)
         for (int r = 0; r < 6; ++r)
             for (int c = 0; c < 6; ++c) S->Hs[(size_t)(6 * i + r) * n6 + 6 * i + c] = S->Hpp[36 * (size_t)i + r * 6 + c];
     memset(S->coeff, 0, sizeof(double) * n6);
+    const int ext = (g_lba_variant & LBA_EXTENDED_SUMS) != 0;
+    long double *xHs = NULL, *xco = NULL;
+    if (ext) {
+        xHs = (long double *)malloc(sizeof(long double) * ((size_t)n6 * n6 + 1));
+        xco = (long double *)calloc((size_t)n6 + 1, sizeof(long double));
+        for (size_t i = 0; i < (size_t)n6 * n6; ++i) xHs[i] = S->Hs[i];
+    }
     for (int l = 0; l < nl; ++l) {
         double *Dinv = S->Dinv + 9 * (size_t)l;
         mat3_inverse(S->Hll + 9 * (size_t)l, Dinv);
@@ -548,17 +625,26 @@ static int solve_schur(lba_t *S)
             for (int r = 0; r < 6; ++r)
                 for (int c = 0; c < 3; ++c)
                     BDinv[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
-            for (int r = 0; r < 6; ++r) S->coeff[6 * i1 + r] += Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+            for (int r = 0; r < 6; ++r) {
+                double t = Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+                if (ext) xco[6 * i1 + r] += t; else S->coeff[6 * i1 + r] += t;
+            }
             for (int bq = a; bq < S->pl_off[l + 1]; ++bq) {
                 int kb = S->pl_edge[bq];
                 int i2 = S->pose_hidx[S->p->edge_pose[S->act_e[kb]]];
                 const double *Bj = S->Hpl + 18 * (size_t)kb;
                 for (int r = 0; r < 6; ++r)
-                    for (int c = 0; c < 6; ++c)
-                        S->Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] -=
-                            BDinv[r * 3] * Bj[c * 3] + BDinv[r * 3 + 1] * Bj[c * 3 + 1] + BDinv[r * 3 + 2] * Bj[c * 3 + 2];
+                    for (int c = 0; c < 6; ++c) {
+                        double t = BDinv[r * 3] * Bj[c * 3] + BDinv[r * 3 + 1] * Bj[c * 3 + 1] + BDinv[r * 3 + 2] * Bj[c * 3 + 2];
+                        if (ext) xHs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] -= t; else S->Hs[(size_t)(6 * i1 + r) * n6 + 6 * i2 + c] -= t;
+                    }
             }
         }
+    }
+    if (ext) {
+        for (size_t i = 0; i < (size_t)n6 * n6; ++i) S->Hs[i] = (double)xHs[i];
+        for (int i = 0; i < n6; ++i) S->coeff[i] = (double)xco[i];
+        free(xHs); free(xco);
     }
     for (int i = 0; i < n6; ++i) S->bs[i] = S->b[i] - S->coeff[i];
     /* symmetrise from the upper block triangle (the solver only reads the upper part) */

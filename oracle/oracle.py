@@ -657,9 +657,27 @@ def pose_to_Tcw(qt):
     return T
 
 
-def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None, stop_at_poll=0):
+_CONTRACTED = None
+
+
+def contracted_lib():
+    """liborb_oracle_contracted.so: the same sources with the reference's own g2o flags (oracle/Makefile "contracted": fused
+    multiply-adds).  Measurement of the restatement's numerical resolution only (parity.lba_resolution); a test's expected value
+    always comes from lib()."""
+    global _CONTRACTED
+    if _CONTRACTED is None:
+        path = os.path.join(_HERE, "liborb_oracle_contracted.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "contracted"])
+        _CONTRACTED = C.CDLL(path)
+    return _CONTRACTED
+
+
+def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None, stop_at_poll=0, variant=0, contracted=False):
     """Runs the LocalBA numerical core on a synth_lba_problem()-style dict with float32 inputs.
-    Returns dict with float32 write-back poses/points like Optimizer.cc:763-778."""
+    Returns dict with float32 write-back poses/points like Optimizer.cc:763-778.
+    variant / contracted (measurement only, lba_oracle.c orc_set_lba_variant / contracted_lib()): the same algorithm with its
+    arithmetic re-associated at rounding level."""
     n_poses, n_points, n_edges = prob["n_poses"], prob["n_points"], prob["n_edges"]
     qt = np.stack([pose_from_Tcw(prob["pose_Tcw"][i]) for i in range(n_poses)]).astype(np.float64)
     pts = np.ascontiguousarray(prob["point_xyz"], np.float32).astype(np.float64)  # Converter::toVector3d
@@ -689,7 +707,12 @@ def lba_solve(prob: dict, iters1=5, iters2=10, stop_flag=None, stop_at_poll=0):
     outl = np.zeros(n_edges, np.uint8)
     lvl1 = np.zeros(n_edges, np.uint8)
     r.edge_chi2, r.edge_depth_pos, r.edge_outlier, r.edge_level1 = (a.ctypes.data for a in (chi2, dpos, outl, lvl1))
-    st = lib().orc_lba_solve(C.byref(s), C.byref(r))
+    L = contracted_lib() if contracted else lib()
+    L.orc_set_lba_variant(int(variant))
+    try:
+        st = L.orc_lba_solve(C.byref(s), C.byref(r))
+    finally:
+        L.orc_set_lba_variant(0)
     Tout = np.stack([pose_to_Tcw(qt[i]) for i in range(n_poses)])
     return dict(status=st, pose_qt=qt, pose_Tcw=Tout, point_xyz=pts.astype(np.float32), point_xyz64=pts,
                 edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier=outl, edge_level1=lvl1,

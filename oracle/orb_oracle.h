@@ -69,6 +69,7 @@ float orc_fast_atan2(float y, float x);
 void orc_set_trig_mode(int use_libm);
 void orc_set_tiebreak_mode(int reverse);   /* octree: equal-size nodes in the opposite order (measurement only) */
 void orc_set_log_mode(int use_libm);        /* PredictScale: libm logf (measurement only) */
+void orc_set_lba_variant(int bits);         /* LocalBA: 1 = reduced system eliminated last-unknown-first, 2 = long double accumulations (measurement only) */
 void orc_sincos_exact(float angle_rad, float *s_out, float *c_out);
 int orc_cv_round_f(float v);
 /* cv::resize INTER_LINEAR 8UC1 */

@@ -538,6 +538,9 @@ def test_lba_unfinished_windows_continue_compacted(pkg, oracle, gpu):
     sized for what they still need), while the others' results already stand.  A batch with such windows among ordinary ones of
     different sizes: every window equals the oracle (iterations, trials, lambda path through the outlier sets, poses), gives the bits
     it gives alone, and the program reports what it enqueued (aos2_lba_last_program / _window_slots)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
     mix = pkg.synth.lba_window_mix(11, 12, hard_every=3)
     for m in mix:
         m["n_points"] = 900 + m["n_points"] // 8
@@ -549,8 +552,14 @@ def test_lba_unfinished_windows_continue_compacted(pkg, oracle, gpu):
     for p, got, m_ in zip(probs, batch, mix + [dict(hard=1), dict(hard=1)]):
         want = oracle.lba_solve(p)
         assert got["status"] == 0 and got["iters"] == want["iters"] and sum(got["trials"]) == want["trials"], (got["iters"], got["trials"], want["iters"], want["trials"])
-        if "hard" in m_:   # (15 trials from a bad start do not converge: the two trajectories agree in every decision, their end points only loosely)
-            assert np.abs(got["pose_Tcw"] - want["pose_Tcw"]).max() < 1e-3 and np.abs(got["point_xyz"] - want["point_xyz"]).max() < 0.2
+        if "hard" in m_:
+            # 15 trials from a bad start do not converge; landmarks left with two inlier observations are held by lambda alone, and
+            # rounding-level differences grow ~10 x per iteration.  The bar is the resolution the ORACLE has on this very window: its
+            # spread against its own re-associated runs (parity.lba_resolution; profiles/r06_lba_sensitivity.txt), times
+            # parity.LBA_RESOLUTION_FACTOR, never below 1e-5 -- and every decision has to be the oracle's
+            res = parity.lba_resolution(p, want=want)
+            assert res["decisions_equal"]
+            assert parity.lba_mismatches(got, want, tag="window off the optimum", resolution=res) == []
         else:
             assert close(got["pose_Tcw"], want["pose_Tcw"], key="cont_pose") and close(got["point_xyz"], want["point_xyz"], key="cont_point")
         assert (got["edge_outlier"] == want["edge_outlier"]).all()

@@ -495,3 +495,33 @@ def test_is_in_frustum_hand_computed_levels(oracle, pkg):
     r = oracle.is_in_frustum(f, p, 0.5)
     assert (r["track_in_view"] == want_in).all()
     assert (r["pred_level"][want_in > 0] == want_lvl[want_in > 0]).all()
+
+
+def test_lba_resolution_of_the_oracle_against_itself(oracle, pkg):
+    """parity.lba_resolution: the oracle re-associated at rounding level (edges reversed, the reduced system eliminated in reverse,
+    long double accumulation, the build with g2o's own flags = fused multiply-adds) against the oracle as tested.  On a window that
+    starts near the optimum every run ends on the same float32 values (differences exist in double, far below float32) and takes the
+    same decisions; on one that starts far off the runs still decide alike and their spread is what bounds a comparison there
+    (tests/test_lba_gpu.py test_lba_unfinished_windows_continue_compacted, bench.py's window off the optimum)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import parity
+    easy = pkg.synth.synth_lba_problem(2, n_local=6, n_fixed=4, n_points=400, stereo_frac=0.3)
+    res = parity.lba_resolution(easy)
+    assert len(res["rows"]) == len(parity.LBA_REASSOCIATIONS) == 6
+    assert res["decisions_equal"] and res["pose"] < 1e-7 and res["point"] < 1e-6
+    assert all(0 < r["point64"] < 1e-8 for r in res["rows"])          # every variant really computes differently ...
+    mix = pkg.synth.lba_window_mix(0, 48, hard_every=8)[47]              # (bench window 47: one landmark moves by 1.7e-3 under fused multiply-adds)
+    mix["n_points"] = 900 + mix["n_points"] // 8
+    hard = pkg.synth._lba_from_kwargs(mix)
+    want = oracle.lba_solve(hard)
+    rh = parity.lba_resolution(hard, want=want)
+    assert rh["decisions_equal"]
+    assert rh["pose"] < 1e-3 and rh["point"] < 0.05                    # ... and an unconverged window amplifies it, boundedly
+    # the comparison rule: the oracle's own contracted run passes as a "device result" at the window's resolution
+    con = oracle.lba_solve(hard, contracted=True)
+    got = dict(status=0, iters=con["iters"], trials=(con["trials"], 0), pose_Tcw=con["pose_Tcw"], point_xyz=con["point_xyz"],
+               edge_outlier=con["edge_outlier"], final_chi2=con["chi2_trace"][-1])
+    assert parity.lba_mismatches(got, want, resolution=rh) == []
+    got["point_xyz"] = got["point_xyz"] + np.float32(4.1 * max(parity.TOL, rh["point"]))
+    assert parity.lba_mismatches(got, want, resolution=rh) != []
