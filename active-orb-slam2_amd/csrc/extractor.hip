@@ -124,7 +124,8 @@ struct aos2_extractor {
     int last_chunks = 1;    // chunk streams of the last batch
     bool stereo_guard_armed = false;
     bool stereo_guard_captured = false;       // the guard was recorded while its stream was being captured (aos2_capture_begin)
-    hipStream_t stereo_guard_stream = nullptr;   // ... on this stream
+    hipStream_t stereo_guard_stream = nullptr;   // ... on this stream (the LEFT extractor's: see stereo_peer)
+    aos2_extractor *stereo_peer = nullptr;       // the other eye of the last ComputeStereoMatches: told when this handle goes away
     int streams_used = 0;                    // streams the batches since the last wait ran on (<= chunks)
     Plan plan;
     int batch_cap = 0;
@@ -990,6 +991,14 @@ void aos2_extractor_destroy(aos2_extractor_t *e)
     if (e->dev_ready) {
         (void)hipSetDevice(e->device);
         for (auto &sx : e->streams) (void)hipStreamSynchronize(sx);
+        if (aos2_extractor *peer = e->stereo_peer) {   // the other eye's guard may name a stream of this handle: drained above, so the
+            if (peer->stereo_peer == e) peer->stereo_peer = nullptr;   // guard has nothing left to order -- forget it before the stream dies
+            for (int i = 0; i < e->n_streams; ++i)
+                if (peer->stereo_guard_stream == e->streams[i]) {
+                    peer->stereo_guard_armed = peer->stereo_guard_captured = false;
+                    peer->stereo_guard_stream = nullptr;
+                }
+        }
         e->plan.release_device();
         e->d_pyr.release(); e->d_blur.release(); e->d_in.release(); e->d_desc.release(); e->d_slots.release(); e->d_dense.release();
         e->d_sel.release(); e->d_cell_cnt.release(); e->d_level_off.release(); e->d_level_cnt.release(); e->d_sel_cnt.release();
@@ -1106,7 +1115,9 @@ int aos2_extractor_wait_for_stream(aos2_extractor_t *e, void *hip_stream)
     // the streams the last batch's chunks ran on wait now; a next batch cut into more chunks orders the others behind stream 0
     // (enqueue_device).  Streams that get no work are left alone: a recording (aos2_capture_begin) must not be joined by
     // streams that never return to it.
-    const int k = std::max(1, std::min(e->n_streams, e->last_chunks));
+    // While `src` is being recorded only stream 0 joins: the batch behind this call may be cut into fewer chunks than the last one,
+    // and a stream that joined a recording without getting work never returns to it (hipStreamEndCapture would fail).
+    const int k = stream_is_capturing(src) ? 1 : std::max(1, std::min(e->n_streams, e->last_chunks));
     for (int i = 0; i < k; ++i) AOS2_HIP_CHECK(hipStreamWaitEvent(e->streams[i], e->input_ev, 0));
     e->input_waited = std::max(e->input_waited, k);
     return AOS2_OK;
@@ -1272,6 +1283,10 @@ static int stereo_run(aos2_extractor *l, aos2_extractor *r, int first_image, int
         x->stereo_guard_armed = true;
         x->stereo_guard_captured = stream_is_capturing(l->stream);
         x->stereo_guard_stream = l->stream;
+    }
+    if (l != r) {
+        l->stereo_peer = r;
+        r->stereo_peer = l;
     }
     if (!sync) return AOS2_OK;
     AOS2_HIP_CHECK(hipStreamSynchronize(l->stream));

@@ -1966,7 +1966,7 @@ int lba_handle_init(aos2_lba *s)
     // the reduced-system factorisation keeps up to 128x128 doubles + panel in LDS (<= 150 KB)
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_dev, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    AOS2_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLrMaxDynLds));
     s->dev_ready = true;
     return AOS2_OK;
 }
@@ -2668,7 +2668,18 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
     // (a continuation round runs on the windows that are not finished, compacted: their descriptors and task lists go here)
-    const size_t cont_bytes = sizeof(LbaWin) * (size_t)nw + sizeof(SchurTask) * n_all_tasks + 64;
+    // Sized for ANY subset of the windows, not for the first round's lists: a subset is dealt to the 8 queues anew (largest first:
+    // the longest queue is at most mean + the largest window, so the padded list holds at most sum + 8 x max units -- a first round of
+    // fewer than 8 windows per group is not padded at all, and the dealing is not monotone on subsets); the landmark / linearisation
+    // lists of a subset are parts of the full ones.
+    size_t cont_tasks = 0, cont_max_units = 0;
+    for (int i = 0; i < nw; ++i) {
+        const Pass &S = passes[i];
+        cont_max_units = std::max(cont_max_units, S.units.size());
+        cont_tasks += S.units.size() + (size_t)std::max(1, (S.nl + lm_per_block - 1) / lm_per_block) + (size_t)(S.nl + lin_block - 1) / lin_block + (size_t)S.np;
+    }
+    cont_tasks += 8 * cont_max_units;
+    const size_t cont_bytes = sizeof(LbaWin) * (size_t)nw + sizeof(SchurTask) * std::max(cont_tasks, n_all_tasks) + 64;
     const size_t o_cont = B.take(cont_bytes);
     for (int i = 0; i < nw; ++i) {
         const aos2_lba_problem_t *p = problems + act[i];

@@ -48,11 +48,12 @@ constexpr int kLrSlots = (kLrMaxNb * (kLrMaxNb - 1) / 2 + kLrWorkers - 1) / kLrW
 static_assert(kLrSlots <= 16, "the jump tables below list 16 slots");
 
 // doubles of dynamic LDS the solve needs
-__host__ __device__ inline size_t ldlt_reg_lds_doubles(int npad)
+__host__ __device__ constexpr size_t ldlt_reg_lds_doubles(int npad)
 {
-    const size_t nb = (size_t)(npad >> 4);
-    return nb * 272 * 3 + (size_t)npad * 17 + 4 * (size_t)npad + 256 + 160 + (size_t)kLrWorkers * 64;
+    return (size_t)(npad >> 4) * 272 * 3 + (size_t)npad * 17 + 4 * (size_t)npad + 256 + 160 + (size_t)kLrWorkers * 64;
 }
+constexpr size_t kLrMaxDynLds = ldlt_reg_lds_doubles(16 * kLrMaxNb) * sizeof(double);   // 149 248 B at 40 free keyframes
+static_assert(kLrMaxDynLds + 64 <= 160 * 1024, "k_ldlt_reg: dynamic + static LDS beyond a CU's 160 KB");
 
 // value of `v` in lane `src` (wave-uniform index), uniform result
 __device__ __forceinline__ double readlane_f64(double v, int src)

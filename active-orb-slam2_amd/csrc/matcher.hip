@@ -836,6 +836,14 @@ struct FrameDev {
     const uint8_t *f_mp_state;
 };
 
+// The sticky "did not fit" word of a search (read by the host after the stream drained; may live in page-locked HOST memory:
+// frames_impl.inc).  A plain system-scope store: any non-zero value raises the capacity error, the value (one of the window
+// populations that did not fit) only feeds its message -- an integer max is not a PCIe AtomicOp, and nothing here needs one.
+__device__ __forceinline__ void overflow_note(int32_t *word, int need)
+{
+    __hip_atomic_store(word, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct Window {
     int x0, x1, y0, y1;  // cell range, valid iff ok
     bool ok;
@@ -1100,7 +1108,7 @@ __device__ __forceinline__ void proj_mp_entries_body(const FrameDev &F, const Pr
                 // query i owns a fixed slice of the pool (no shared counter: same-address atomics serialise in L2)
                 const int stride = phase == 2 ? pop : pool_cap / max(P.n_mp, 1);
                 int off = phase == 2 ? slots[i].ent_off - pool_base : i * stride;
-                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // overflow flag for the host (batched form)
+                if (pop > stride && lane == 0) overflow_note(pool_used, pop);   // overflow flag for the host (batched form)
                 if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                     const int lvl = P.pred_level[i];
                     off += pool_base;
@@ -1346,7 +1354,7 @@ __device__ __forceinline__ void proj_last_entries_body(const FrameDev &F, const 
                 } else if (pop > 0) {
                     const int stride = phase == 2 ? pop : pool_cap / max(P.n_last, 1);
                     const int off = phase == 2 ? slots[i].ent_off : pool_base + i * stride;
-                    if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (pop > stride && lane == 0) overflow_note(pool_used, pop);
                     if (pop <= stride && (phase != 2 || slots[i].cnt == pop)) {
                         const float ur = __fsub_rn(u, __fmul_rn(P.mbf, invzc));
                         window_entries(F, w, load_desc(P.desc + (size_t)row * 32), u, v, radius, minL, maxL, ur, radius, lane,
@@ -1860,7 +1868,7 @@ __global__ __launch_bounds__(64) void projgen_entries_kernel(FrameDev F, ProjGen
             if (pop > 0) {
                 const int stride = pool_cap / max(P.n_pts, 1);   // query i owns pool[i * stride ..): no shared counter
                 const int off = i * stride;
-                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (pop > stride && lane == 0) overflow_note(pool_used, pop);
                 if (pop <= stride) {
                     // mode 2: levels [pred-1, pred] tested per candidate (:379-382) == the level filter of the
                     // Frame version; mode 4: GetFeaturesInArea(u, v, radius, pred-1, pred+1) (:1537).  A level
@@ -2014,7 +2022,7 @@ __global__ __launch_bounds__(64) void init_entries_kernel(FrameDev F2, InitDev P
             if (pop > 0) {
                 const int stride = pool_cap / max(P.n1, 1);
                 const int off = i * stride;
-                if (pop > stride && lane == 0) __hip_atomic_fetch_max(pool_used, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (pop > stride && lane == 0) overflow_note(pool_used, pop);
                 if (pop <= stride) {
                     const int lvl = P.octave1[i];
                     window_entries(F2, w, load_desc(P.desc1 + (size_t)i * 32), x, y, P.window, lvl, lvl, 0.0f,
@@ -3057,7 +3065,7 @@ int aos2_matcher_search_by_projection_batch(aos2_matcher_t *m, const aos2_frame_
     if ((st = A.finish())) return st;
     (void)hipEventElapsedTime(&m->last_ms, m->ev[0], m->ev[1]);
     for (int i = 0; i < n_problems; ++i)
-        if (used[(size_t)i * 64] > 0) {   // overflow flag = largest window population that did not fit its slice
+        if (used[(size_t)i * 64] > 0) {   // overflow flag = a window population that did not fit its slice
             set_error("batched projection search: a search window of problem %d holds %d features, more than the %d "
                       "budgeted per map point; use aos2_matcher_search_by_projection per frame", i, used[(size_t)i * 64],
                       std::min(frames[i].n_f, 512));

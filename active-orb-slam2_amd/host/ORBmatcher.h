@@ -6,10 +6,10 @@
 // pointer graph.  The map bookkeeping at the end of Fuse (Replace / AddObservation / AddMapPoint) stays host code on the
 // pointer graph, as in the reference.
 // Include AFTER the headers that declare Frame, KeyFrame, MapPoint (the reference's, or tests/cpp/refstub/slam_stub.h),
-// i.e. where the reference's own ORBmatcher.h is included.  One change to the reference's data model is needed: two
-// one-line accessors `float MapPoint::GetMinDistance()` / `GetMaxDistance()` returning the raw mfMinDistance /
-// mfMaxDistance (protected members; the searches gate on 0.8f / 1.2f of them and MapPoint::PredictScale divides the raw
-// maximum, src/MapPoint.cc:413-459, so both factors are applied on the device from the raw values).
+// i.e. where the reference's own ORBmatcher.h is included.  NOTHING of the reference's data model changes: the raw
+// mfMinDistance / mfMaxDistance (protected; the searches gate on 0.8f / 1.2f of them and MapPoint::PredictScale divides the raw
+// maximum, src/MapPoint.cc:413-459, so both factors are applied on the device from the raw values) are read through
+// aos2::MapPointDistances (aos2_handles.h: a member pointer formed through a derived class, under mMutexPos).
 #pragma once
 #include <climits>
 #include <cmath>
@@ -165,8 +165,7 @@ protected:
             valid[i] = 1;
             const cv::Mat X = pMP->GetWorldPos();
             for (int k = 0; k < 3; ++k) pos[i * 3 + k] = X.at<float>(k);
-            max_dist[i] = pMP->GetMaxDistance();   // raw mfMaxDistance / mfMinDistance (see the header comment)
-            min_dist[i] = pMP->GetMinDistance();
+            aos2::MapPointDistances<MapPoint>::get(pMP, min_dist[i], max_dist[i]);   // raw mfMinDistance / mfMaxDistance (header comment)
             if (with_normal) {
                 const cv::Mat n = pMP->GetNormal();
                 for (int k = 0; k < 3; ++k) normal[i * 3 + k] = n.at<float>(k);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -26,7 +27,8 @@ namespace aos2 {
 // their call sites has no exception handling; what the reference does when its environment fails it is `cerr << ...; exit(-1)`
 // (src/System.cc:78-79, 95-97, 111-112).  A failed C-ABI call here is of that kind (no device, out of device memory, a bad
 // argument that the reference's own data cannot produce): by default the message (aos2_last_error) goes to std::cerr and the process
-// exits with -1.  A tree that does handle exceptions compiles with -DAOS2_HOST_EXCEPTIONS and gets std::runtime_error instead
+// exits with -1.  Only those: a LocalBundleAdjustment / PoseOptimization call that fails at run time is reported and survived
+// (report() below) -- a SLAM process with three running threads is not torn down for one window.  A tree that does handle exceptions compiles with -DAOS2_HOST_EXCEPTIONS and gets std::runtime_error instead
 // (tests/cpp/ref_signature_test.cpp does).
 [[noreturn]] inline void fail(const char *what)
 {
@@ -35,6 +37,17 @@ namespace aos2 {
 #else
     std::cerr << what << ": " << aos2_last_error() << std::endl;
     std::exit(-1);
+#endif
+}
+
+// A per-call failure that the caller can survive (a solve that did not go through): the message, no exit -- the reference's own
+// optimiser failures print to cerr and go on.  -DAOS2_HOST_EXCEPTIONS: std::runtime_error like fail().
+inline void report(const char *what)
+{
+#ifdef AOS2_HOST_EXCEPTIONS
+    throw std::runtime_error(std::string(what) + ": " + aos2_last_error());
+#else
+    std::cerr << what << ": " << aos2_last_error() << std::endl;
 #endif
 }
 
@@ -102,6 +115,22 @@ struct ShimClock {
         const double us = std::chrono::duration<double, std::micro>(t1 - t0).count();
         t0 = t1;
         return us;
+    }
+};
+
+// MapPoint::mfMinDistance / mfMaxDistance of an UNCHANGED reference MapPoint.  They are protected (include/MapPoint.h:149-150) and the
+// public getters return 0.8f / 1.2f of them (src/MapPoint.cc:413-425) while MapPoint::PredictScale divides the RAW maximum (:432);
+// the device applies both itself and dividing the factor out again is not exact in float.  A class derived from MapPoint may name
+// its base's protected members, and `&Derived::member` has the type `float MapPoint::*` -- well-formed C++ ([class.protected]
+// restricts access through a base OBJECT expression, not forming the member pointer through the derived class): no friend, no new
+// accessor, no edit of MapPoint.h.  Read under mMutexPos like the getters.
+template <class MP>
+struct MapPointDistances : MP {
+    static void get(MP *p, float &min_dist, float &max_dist)
+    {
+        std::unique_lock<std::mutex> lock(p->*(&MapPointDistances::mMutexPos));
+        min_dist = p->*(&MapPointDistances::mfMinDistance);
+        max_dist = p->*(&MapPointDistances::mfMaxDistance);
     }
 };
 

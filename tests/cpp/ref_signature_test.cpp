@@ -203,8 +203,7 @@ static std::vector<std::unique_ptr<MapPoint>> make_points(const Bundle &B, const
         m->mWorldPos = pos_mat(B[p + "pos"].as<float>() + (size_t)i * 3);
         m->mNormalVector = pos_mat(B[p + "normal"].as<float>() + (size_t)i * 3);
         m->mDescriptor = row_desc(B[p + "desc"].as<uint8_t>() + (size_t)i * 32);
-        m->mfMaxDistance = B[p + "max_dist"].as<float>()[i];
-        m->mfMinDistance = B[p + "min_dist"].as<float>()[i];
+        m->stub_set_distances(B[p + "min_dist"].as<float>()[i], B[p + "max_dist"].as<float>()[i]);
         m->nObs = 1 + i % 3;
     }
     return pts;

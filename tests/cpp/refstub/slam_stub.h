@@ -58,9 +58,7 @@ public:
     bool isBad() { return mbBad; }
     float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }   // src/MapPoint.cc:413-423
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
-    // THE ONE ADDITION to the reference's data model: the raw distances (protected members there)
-    float GetMinDistance() { return mfMinDistance; }
-    float GetMaxDistance() { return mfMaxDistance; }
+    void stub_set_distances(float min_dist, float max_dist) { mfMinDistance = min_dist; mfMaxDistance = max_dist; }   // (UpdateNormalAndDepth sets them there)
     bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
     int GetIndexInKeyFrame(KeyFrame *pKF)
     {
@@ -85,11 +83,14 @@ public:
 
     cv::Mat mWorldPos, mNormalVector, mDescriptor;
     std::map<KeyFrame *, size_t> mObservations;
-    float mfMinDistance = 0, mfMaxDistance = 0;
     std::mutex mMutexFeatures;
     int nObs = 0;
     bool mbBad = false;
     int nErased = 0, nNormalUpdates = 0;   // bookkeeping of the tests
+
+protected:   // like include/MapPoint.h:123, 149-154: the shim reads them without an accessor (aos2::MapPointDistances)
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    std::mutex mMutexPos;
 };
 
 class KeyFrame {

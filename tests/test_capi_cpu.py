@@ -288,3 +288,19 @@ def test_replay_entry_points_validate_their_arguments(pkg):
     assert L.aos2_graph_launch(None, None) == pkg.capi.AOS2_ERR_ARG
     assert L.aos2_graph_nodes(None) == 0
     L.aos2_graph_destroy(None)
+
+
+@pytest.mark.parametrize("flags", [["-DAOS2_HOST_EXCEPTIONS"], []])
+def test_reference_signature_classes_compile_and_link(pkg, tmp_path, flags):
+    """host/*.h at the reference's signatures compile (-Wall -Werror, both error conventions) against the stand-in declarations of
+    tests/cpp/refstub -- whose MapPoint keeps mfMinDistance / mfMaxDistance / mMutexPos PROTECTED like include/MapPoint.h:123-154: the
+    shim reads them through aos2::MapPointDistances, no accessor added to the reference's class -- and link against libaos2 (the run
+    needs the GPU: tests/test_ref_signature_gpu.py)."""
+    import subprocess
+    libdir = os.path.dirname(pkg.lib_path())
+    exe = str(tmp_path / "ref_signature_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror"] + flags + [os.path.join(ROOT, "tests", "cpp", "ref_signature_test.cpp"),
+                           "-o", exe, "-L" + libdir, "-laos2", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    stub = open(os.path.join(ROOT, "tests", "cpp", "refstub", "slam_stub.h")).read()
+    assert "GetMaxDistance()" not in stub and "GetMinDistance()" not in stub
+    assert re.search(r"protected:[^}]*mfMinDistance[^}]*mMutexPos", stub, flags=re.S)

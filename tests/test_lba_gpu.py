@@ -578,3 +578,26 @@ def test_lba_unfinished_windows_continue_compacted(pkg, oracle, gpu):
         assert ba2.last_window_slots() >= 17 * len(probs)
     finally:
         del os.environ["AOS2_LBA_SPARE_SLOTS"]
+
+
+@pytest.mark.parametrize("groups", [2, 1])
+def test_lba_continuation_lists_larger_than_the_first_rounds(pkg, gpu, groups):
+    """with two window groups and 8-15 windows a group has fewer than 8 windows, so the first round's Schur list is NOT
+    padded to 8 queues -- the continuation round on >= 8 unfinished windows is (NX = 8, each queue as long as the longest: one
+    40-keyframe window among 10-keyframe ones), i.e. LONGER than anything the first round built.  The continuation region is sized
+    for any subset (lba.hip "Sized for ANY subset"): the batch solves, every window gives the bits it gives alone.  (Seeds whose
+    oracle runs reject steps: more trials than iterations.)"""
+    S = pkg.synth
+    small = lambda seed, pert: S.perturb_lba_problem(S.synth_lba_problem(seed, n_local=10, n_fixed=4, n_points=260, obs_per_point=4, stereo_frac=0.3), seed, *pert)  # noqa: E731
+    probs = [S.perturb_lba_problem(S.synth_lba_problem(880, n_local=40, n_fixed=4, n_points=700, obs_per_point=6, stereo_frac=0.3), 880, 2.0, 3.0, 2.0)]
+    probs += [small(sd, (2.0, 3.0, 2.0)) for sd in (900, 906, 907, 913, 915, 919)] + [small(sd, (1.0, 6.0, 4.0)) for sd in (903, 910, 919, 926)]
+    probs += [S.synth_lba_problem(950, n_local=8, n_fixed=3, n_points=200)]
+    assert len(probs) == 12
+    ba = pkg.LocalBA()
+    ba.set_window_groups(groups)
+    batch = ba.LocalBundleAdjustmentBatch(probs)
+    slots, rounds = ba.last_program()
+    rejected = [sum(r["trials"]) > sum(r["iters"]) for r in batch]
+    assert rounds >= 2 and rejected[0] and sum(rejected) >= 9, (rounds, [(r["iters"], r["trials"]) for r in batch])
+    for p, got in zip(probs, batch):
+        assert got["status"] == 0 and _same(got, pkg.LocalBA().LocalBundleAdjustment(p))

@@ -63,8 +63,8 @@ static bool host_ldlt(std::vector<double> A, int n, std::vector<double> b, std::
 int main(int argc, char **argv)
 {
     const int NM = argc > 1 ? atoi(argv[1]) : 38;
-    CK(hipFuncSetAttribute((const void *)k_test<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    CK(hipFuncSetAttribute((const void *)k_test<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    CK(hipFuncSetAttribute((const void *)k_test<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLrMaxDynLds));
+    CK(hipFuncSetAttribute((const void *)k_test<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLrMaxDynLds));
     const int nps[] = {1, 2, 3, 5, 8, 11, 16, 20, 21, 22, 27, 28, 33, 38, 40};
     int worst_fail = 0;
     for (int padded = 1; padded < 2; ++padded)   // (the solve takes the padded layout only)
