@@ -569,7 +569,6 @@ def test_lba_unfinished_windows_continue_compacted(pkg, oracle, gpu):
     wslots = ba.last_window_slots()
     assert 15 * len(probs) < wslots < slots * len(probs)           # ... and the continuation rounds did not cover the finished ones
     # the form of rounds 2-4 (a spare trial per optimisation for every window) gives the same results
-    import os
     os.environ["AOS2_LBA_SPARE_SLOTS"] = "1"
     try:
         ba2 = pkg.LocalBA()
