@@ -213,6 +213,7 @@ class recording:
         def __init__(self):
             super().__init__()
             self.keep = []
+            self.names = []   # function name per call (diagnostics)
 
         def array(self):
             a = (_Call * max(1, len(self)))()
@@ -266,6 +267,7 @@ def _record(fn, name, args):
     c.n_int, c.n_fp = ni, nf
     _REC.append(c)
     _REC.keep.append(args)
+    _REC.names.append(name)
     return AOS2_OK
 
 

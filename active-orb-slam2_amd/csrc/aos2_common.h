@@ -1,5 +1,6 @@
 // Shared host-side helpers of the aos2 HIP library (error handling, device binding).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -19,6 +20,12 @@ int bind_device(int device);
 
 // Every stream of the library is created here (csrc/replay.hip): non-blocking, of the highest priority class when asked for.
 int stream_create(hipStream_t *q, bool high_priority);
+// (measurement switch: AOS2_PRIO_MATCHER / _VOCABULARY / _FRAMES = 1 puts that handle kind's stream into the high priority class)
+inline bool stream_priority_env(const char *name)
+{
+    const char *e = getenv(name);
+    return e && e[0] == '1';
+}
 
 #define AOS2_HIP_CHECK(expr)                                                              \
     do {                                                                                  \

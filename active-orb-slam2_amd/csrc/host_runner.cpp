@@ -68,6 +68,8 @@ struct Job {   // a worker thread that replays one list when told to
     int status = 0, bad_call = -1;
     std::vector<double> *walls = nullptr;
     std::mutex *walls_m = nullptr;
+    std::vector<double> call_sum;   // wall seconds per call index, summed over the runs since reset (diagnostics: which call of a job waits)
+    long runs = 0;
     void loop()
     {
         for (;;) {
@@ -81,12 +83,27 @@ struct Job {   // a worker thread that replays one list when told to
             }
             const double t0 = now_s();
             int st = 0, bad = -1;
-            for (size_t i = 0; i < l->size() && !st; ++i)
+            double per_call[64];
+            double tp = t0;
+            for (size_t i = 0; i < l->size() && !st; ++i) {
                 if ((st = invoke((*l)[i]))) bad = (int)i;
-            const double dt = now_s() - t0;
+                const double tn = now_s();
+                if (i < 64) per_call[i] = tn - tp;
+                tp = tn;
+            }
+            const double dt = tp - t0;
             if (walls) {
                 std::lock_guard<std::mutex> g(*walls_m);
                 walls->push_back(dt);
+                if (!st) {
+                    const size_t n = l->size() < 64 ? l->size() : 64;
+                    if (call_sum.size() != n) {
+                        call_sum.assign(n, 0.0);
+                        runs = 0;
+                    }
+                    for (size_t i = 0; i < n; ++i) call_sum[i] += per_call[i];
+                    ++runs;
+                }
             }
             std::lock_guard<std::mutex> lk(m);
             if (st && !status) {
@@ -276,14 +293,29 @@ void aos2_runner_reset_stats(aos2_runner *r)
     r->lba_walls.clear();
     r->kf_walls.clear();
     r->step_marks.clear();
+    for (auto *v : {&r->kf, &r->lba})
+        for (Job *j : *v) {
+            j->call_sum.clear();
+            j->runs = 0;
+        }
 }
 
-// which: 0 = the three wait sums (seconds), 1 = LocalBA job walls, 2 = keyframe job walls, 3 = step marks; returns the count, copies <= cap
+// which: 0 = the three wait sums (seconds), 1 = LocalBA job walls, 2 = keyframe job walls, 3 = step marks, 100 + j = mean wall per call of
+// keyframe job j's list, 200 + l = of LocalBA job l's list; returns the count, copies <= cap
 int aos2_runner_stats(aos2_runner *r, int which, double *out, int cap)
 {
     std::lock_guard<std::mutex> g(r->stats_m);
     const double *src = nullptr;
     int n = 0;
+    if (which >= 100) {
+        const std::vector<Job *> &v = which >= 200 ? r->lba : r->kf;
+        const int i = which >= 200 ? which - 200 : which - 100;
+        if (i < 0 || i >= (int)v.size()) return 0;
+        const Job *j = v[i];
+        n = (int)j->call_sum.size();
+        for (int k = 0; k < n && k < cap; ++k) out[k] = j->call_sum[k] / (double)(j->runs > 0 ? j->runs : 1);
+        return n;
+    }
     if (which == 0) {
         src = r->waits;
         n = 3;

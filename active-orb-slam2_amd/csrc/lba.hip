@@ -135,6 +135,20 @@ struct SchurTask {
 // bool SparseOptimizer::terminate(): counts the evaluation, latches the flag
 // `seen` >= 0: the value of the flag read by the caller shortly before (the word lives in host memory: a read is a PCIe
 // round trip, which the decision starts ahead of its other loads)
+// (measurement switch, off: a raised wave priority for LocalBA's kernels -- chains of dependent memory and f64 operations at low
+// occupancy -- so that they issue ahead of another stream's VALU-bound waves on the same SIMD, like octree_kernel's.  The composite
+// did not move: 72.5 / 72.5 k frames/s without, 70.8 / 72.2 k with priority 2, 71.9 k with 3; the batch alone 4.10 ms either way
+// (profiles/r06_composite_decomposition.txt).  What LocalBA costs the step is not issue order.)
+#ifndef AOS2_LBA_WAVE_PRIO
+#define AOS2_LBA_WAVE_PRIO 0
+#endif
+__device__ __forceinline__ void lba_wave_prio()
+{
+#if AOS2_LBA_WAVE_PRIO > 0
+    __builtin_amdgcn_s_setprio(AOS2_LBA_WAVE_PRIO);
+#endif
+}
+
 __device__ inline bool lm_poll(LmState *st, const int32_t *abort_word, int seen = -1)
 {
     st->polls++;
@@ -187,6 +201,7 @@ __device__ __forceinline__ void workgroup_sum2(double v0, double v1, double *out
 // Converter::toSE3Quat / toVector3d and the float -> double copies of Optimizer.cc:523-525, 552-553, 597-606
 __global__ __launch_bounds__(256) void k_prepare(const LbaWin *__restrict__ wins, int stop_at_poll)
 {
+    lba_wave_prio();
     const LbaWin &W = wins[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < W.n_poses) pose_from_Tcw(W.in_Tcw + 16 * (size_t)i, W.pose + 7 * (size_t)i);
@@ -594,6 +609,7 @@ constexpr int kWalkChunkLin = 4;   // all edges (linearisation)
 // Landmark l leaves its chi2 terms in part[l] and its scale terms in part[nl + l] (canonical_sums adds them).
 __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
 {
+    lba_wave_prio();
     __shared__ double s_v[kLmBlock][kLmSlots][3];
     __shared__ double s_X[kLmBlock][3];
     const SchurTask tk = tasks[blockIdx.x];
@@ -699,6 +715,7 @@ __global__ __launch_bounds__(256) void k_points(const LbaWin *__restrict__ wins,
 // leave the same bits.
 __global__ __launch_bounds__(128) void k_points_walk(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int solve)
 {
+    lba_wave_prio();
     const SchurTask tk = tasks[blockIdx.x];
     const LbaWin &W = wins[tk.w];
     if (!(solve ? W.st->run : W.st->initp)) return;
@@ -1057,6 +1074,7 @@ __device__ __forceinline__ void lin_poses_body(const LbaWin &W, int ph, int init
 template <bool kWalk>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_lin(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks, int init)
 {
+    lba_wave_prio();
     const SchurTask tk = tasks[blockIdx.x];
     const LbaWin &W = wins[tk.w];
     if (!(init ? W.st->initp : W.st->lin)) return;
@@ -1079,6 +1097,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // (computeLambdaInit :166-180), ni = 2; the first trial's push() (the backup of the estimates)
 __global__ __launch_bounds__(1024) void k_lm_init(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     __shared__ double sh[1024];
     const LbaWin &W = wins[blockIdx.x];
     LmState *st = W.st;
@@ -1272,6 +1291,7 @@ __device__ __forceinline__ void schur_store(const LbaWin &W, int i1, int i2, int
 __global__ __launch_bounds__(kSchurThreads) __attribute__((amdgpu_waves_per_eu(AOS2_SCHUR_WPE, AOS2_SCHUR_WPE)))
 void k_schur(const LbaWin *__restrict__ wins, const SchurTask *__restrict__ tasks)
 {
+    lba_wave_prio();
     constexpr int NT = kSchurThreads;
     __shared__ double red[(NT / 16) * 43];
     __shared__ int32_t s_info[16], s_ij[16];
@@ -1802,6 +1822,7 @@ __device__ __forceinline__ void ldlt_body(const LbaWin &Wn, double *sm)
 
 __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
     if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 1) return;
@@ -1810,6 +1831,7 @@ __global__ __launch_bounds__(512) void k_ldlt_lds(const LbaWin *__restrict__ win
 // (a kernel of its own: both forms in one kernel cost the LDS form 25 spilled registers)
 __global__ __launch_bounds__(512) void k_ldlt_dev(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
     if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 0) return;
@@ -1821,6 +1843,7 @@ __global__ __launch_bounds__(512) void k_ldlt_dev(const LbaWin *__restrict__ win
 // epilogue is ldlt_body's (solution, pose update with the push() backup, the poses' scale terms).
 __global__ __launch_bounds__(kLrThreads) void k_ldlt_reg(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const LbaWin &Wn = wins[blockIdx.x];
     if (!Wn.st->run || Wn.np == 0 || Wn.ldlt_lds != 2) return;
@@ -1880,6 +1903,7 @@ __device__ __forceinline__ void edge_last_error(const LbaWin &W, int e, int at, 
 
 __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     __shared__ int s_last;
     const LbaWin &W = wins[blockIdx.y];
     LmState *st = W.st;
@@ -1927,6 +1951,7 @@ __global__ __launch_bounds__(256) void k_transition(const LbaWin *__restrict__ w
 // final inlier check (:712-744) and the write-back conversions (:763-778)
 __global__ __launch_bounds__(256) void k_final(const LbaWin *__restrict__ wins)
 {
+    lba_wave_prio();
     const LbaWin &W = wins[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < W.n_edges) {
@@ -2604,19 +2629,22 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         std::vector<SchurTask> schur, pts, lin;
     };
     const int lin_block = walk ? 256 : kLmBlock;
-    auto build_tasks = [&](const std::vector<int> &ids, auto &&wmap, TaskLists &T) {
+    auto build_tasks = [&](const std::vector<int> &ids, auto &&wmap, TaskLists &T, bool one_queue = false) {
         std::vector<SchurTask> &tasks = T.schur;
         const int nwg = (int)ids.size();
         std::vector<int> order(nwg);
         std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return passes[ids[a]].units.size() > passes[ids[b]].units.size(); });
-        const int NX = nwg >= 8 ? 8 : 1;
+        // (dealt by unit count.  By estimated cost instead -- a DIAG / BIG unit = 2 + ceil(items / 256) workgroup rounds, a PACK unit one --
+        // the mixed 64-window batch took 4.15 / 4.17 / 4.14 ms against 4.14 / 4.13 / 4.12: the XCD queues are not what k_schur's tail waits for)
+        auto weight = [&](int k) { return passes[ids[k]].units.size(); };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(a) > weight(b); });
+        const int NX = nwg >= 8 && !one_queue ? 8 : 1;
         std::vector<std::vector<int>> xw(NX);
         std::vector<size_t> load(NX, 0);
         for (int k : order) {
             const int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
             xw[x].push_back(k);
-            load[x] += passes[ids[k]].units.size();
+            load[x] += weight(k);
         }
         std::vector<std::vector<SchurTask>> qx(NX);
         for (int x = 0; x < NX; ++x)
@@ -2668,10 +2696,10 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
     const size_t o_wins = B.take(sizeof(LbaWin) * (size_t)nw);
     const size_t staged_bytes = B.size;
     // (a continuation round runs on the windows that are not finished, compacted: their descriptors and task lists go here)
-    // Sized for ANY subset of the windows, not for the first round's lists: a subset is dealt to the 8 queues anew (largest first:
-    // the longest queue is at most mean + the largest window, so the padded list holds at most sum + 8 x max units -- a first round of
-    // fewer than 8 windows per group is not padded at all, and the dealing is not monotone on subsets); the landmark / linearisation
-    // lists of a subset are parts of the full ones.
+    // Sized for ANY subset of the windows, not for the first round's lists: a subset is dealt to the 8 queues anew (largest first; with
+    // queues of about equal length the padded list holds about sum + 8 x max units -- a first round of fewer than 8 windows per group
+    // is not padded at all, and the dealing is not monotone on subsets); the landmark / linearisation lists of a subset are parts of
+    // the full ones.  A subset whose padded list is longer still falls back to one unpadded queue (below), which always fits.
     size_t cont_tasks = 0, cont_max_units = 0;
     for (int i = 0; i < nw; ++i) {
         const Pass &S = passes[i];
@@ -2998,7 +3026,11 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         // their descriptors, compacted, and task lists that address them by position
         TaskLists TC;
         build_tasks(todo, [](int k) { return k; }, TC);
-        const size_t tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
+        size_t tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
+        if (sizeof(LbaWin) * todo.size() + tc_bytes > cont_bytes) {   // (the dealing is not monotone on subsets: should one pad past the bound,
+            build_tasks(todo, [](int k) { return k; }, TC, true);      //  one unpadded queue always fits -- its length is the subset's sum)
+            tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
+        }
         if (sizeof(LbaWin) * todo.size() + tc_bytes > cont_bytes) {
             set_error("internal: continuation region");
             return AOS2_ERR_ARG;

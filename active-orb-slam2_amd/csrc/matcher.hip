@@ -2154,7 +2154,7 @@ static int matcher_init(aos2_matcher *m)
     int st = bind_device(m->device);
     if (st) return st;
     if (m->dev_ready) return AOS2_OK;
-    if (int st_ = stream_create(&m->stream, false)) return st_;
+    if (int st_ = stream_create(&m->stream, stream_priority_env("AOS2_PRIO_MATCHER"))) return st_;
     for (auto &e : m->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     {
         const char *v = getenv("AOS2_SERIAL_RESOLVE");

@@ -318,7 +318,7 @@ static int voc_init_device(aos2_vocabulary *v)
     int st = bind_device(v->device);
     if (st) return st;
     if (v->dev_ready) return AOS2_OK;
-    if (int st_ = stream_create(&v->stream, false)) return st_;
+    if (int st_ = stream_create(&v->stream, stream_priority_env("AOS2_PRIO_VOCABULARY"))) return st_;
     for (auto &e : v->ev) AOS2_HIP_CHECK(hipEventCreate(&e));
     v->dev_ready = true;
     return AOS2_OK;

@@ -430,6 +430,8 @@ def main():
         lba_walls.append(time.perf_counter() - t_)
         return r_
 
+    job_call_names = {}
+
     def record_lists():
         """(re-)record the jobs of the native runner from the harness objects as they are now"""
         rec = pkg.capi.recording
@@ -448,6 +450,7 @@ def main():
                 if kfws:
                     kfws[j_].run_calls()
             runner.set_list(runner.KF_JOB, j_, c_)
+            job_call_names["kf"] = list(c_.names)
         for jl_ in range(NLBA):
             with rec() as c_:
                 if not NO_LBA:
@@ -556,6 +559,8 @@ def main():
     timed_steps = {"host_thread_waits_ms_per_step": {k_: round(v_ * 1e3 / max(1, args.steps), 3) for k_, v_ in waits.items()},
                    "step_to_step_ms_min_median_max": mmm(np.diff(step_marks)) if len(step_marks) > 2 else None,
                    "local_ba_call_wall_ms_min_median_max": mmm(lba_walls), "keyframe_job_wall_ms_min_median_max": mmm(kf_walls),
+                   "keyframe_job_calls_mean_ms": ([[n_, round(float(v_) * 1e3, 3)] for n_, v_ in zip(job_call_names.get("kf", []), runner.stats(100))]
+                                                  if NATIVE else None),
                    "note": "the enqueueing thread waits, per step, for the LocalBA call / keyframe job / tracking chain submitted NPIPE steps before; "
                            "a step cannot be shorter than (LocalBA call wall) / (handles in flight)"}
     dt_ranks = [dt]
