@@ -383,6 +383,8 @@ class Runner:
         R.aos2_runner_error.restype = C.c_char_p
         R.aos2_runner_reset_stats.argtypes = [vp]
         R.aos2_runner_stats.argtypes = [vp, C.c_int, vp, C.c_int]
+        R.aos2_runner_set_lba_every.argtypes = [vp, C.c_int]
+        R.aos2_runner_last_lba.argtypes = [vp]
         self.R = R
         self.h = R.aos2_runner_create(int(n_pipes), int(n_lba))
         if not self.h:
@@ -405,6 +407,14 @@ class Runner:
     def _st(self, st):
         if st != 0:
             raise AosError(st, self.R.aos2_runner_error(self.h).decode() + ": " + lib().aos2_last_error().decode(errors="replace"))
+
+    def set_lba_every(self, n):
+        """a LocalBA job every n steps (its list then solves the windows of n steps in one call)"""
+        if self.R.aos2_runner_set_lba_every(self.h, int(n)) != 0:
+            raise ValueError("aos2_runner_set_lba_every")
+
+    def last_lba(self):
+        return int(self.R.aos2_runner_last_lba(self.h))
 
     def step(self, s):
         self._st(self.R.aos2_runner_step(self.h, int(s)))

@@ -4,10 +4,10 @@
 // these as std::threads, too).  Python records the calls of every job once (capi.recording(): function address + arguments, all of
 // them constants of the run: handles, device pointers, sizes); this library replays the lists:
 //
-//   step s (pipeline j = s % n_pipes, LocalBA handle l = s % n_lba):
-//       wait for LocalBA job l and keyframe job j of the step that used them last, replay PIPE_WAIT[j]        (main thread)
+//   step s (pipeline j = s % n_pipes; LocalBA handles take turns, one job per `lba_every` steps -- the windows of that many steps in one call):
+//       wait for keyframe job j of the step that used it last (and for the LocalBA job whose handle is due), replay PIPE_WAIT[j]   (main thread)
 //       replay PIPE_STEP[j]: the tracking chain of the batch, enqueued                                        (main thread)
-//       start KF_JOB[j] on keyframe thread j, LBA_JOB[l] on LocalBA thread l                                  (return at once)
+//       start KF_JOB[j] on keyframe thread j, every lba_every-th step LBA_JOB[l] on LocalBA thread l          (return at once)
 //
 // A recorded call is replayed through one function type of 6 + 18 integer and 8 floating-point parameters: on the System V x86-64
 // ABI the k-th integer-class argument travels in the k-th integer register (then on the stack, in order) and the k-th
@@ -140,6 +140,10 @@ struct aos2_runner {
     double waits[3] = {0, 0, 0};   // LocalBA, keyframe legs, tracking: where the stepping thread waited
     std::vector<double> lba_walls, kf_walls, step_marks;
     std::mutex stats_m;
+    int lba_every = 1;     // a LocalBA job is started every `lba_every` steps (it then solves the windows of that many steps in one call)
+    int lba_pending = 0;   // steps whose windows wait for the next job
+    int lba_next = 0;      // the handle that takes it
+    int lba_last = -1;     // the handle of the last job started
     int status = 0;
     char err[256] = {0};
 };
@@ -220,12 +224,42 @@ static void collect(aos2_runner *r, Job *j, const char *what, int index)
     }
 }
 
+// the windows of the last `lba_every` steps go to the next LocalBA handle (its previous job waited for first)
+static void start_lba(aos2_runner *r)
+{
+    const int l = r->lba_next;
+    if (r->lba_busy[l]) {
+        r->lba[l]->wait();
+        collect(r, r->lba[l], "LocalBA", l);
+        r->lba_busy[l] = 0;
+    }
+    if (!r->lists[AOS2_RUN_LBA_JOB][l].empty()) {
+        r->lba[l]->start(&r->lists[AOS2_RUN_LBA_JOB][l]);
+        r->lba_busy[l] = 1;
+    }
+    r->lba_last = l;
+    r->lba_next = (l + 1) % r->n_lba;
+    r->lba_pending = 0;
+}
+
+// the handle whose LocalBA job was started last (-1: none yet)
+int aos2_runner_last_lba(const aos2_runner *r) { return r ? r->lba_last : -1; }
+
+int aos2_runner_set_lba_every(aos2_runner *r, int n)
+{
+    if (!r || n < 1) return -1;
+    r->lba_every = n;
+    return 0;
+}
+
 int aos2_runner_step(aos2_runner *r, int s)
 {
     if (!r || s < 0) return -1;
-    const int j = s % r->n_pipes, l = s % r->n_lba;
+    const int j = s % r->n_pipes;
+    const bool lba_now = r->lba_pending + 1 >= r->lba_every;
+    const int l = r->lba_next;
     const double ta = now_s();
-    if (r->lba_busy[l]) {
+    if (lba_now && r->lba_busy[l]) {
         r->lba[l]->wait();
         collect(r, r->lba[l], "LocalBA", l);
         r->lba_busy[l] = 0;
@@ -249,10 +283,8 @@ int aos2_runner_step(aos2_runner *r, int s)
         r->kf[j]->start(&r->lists[AOS2_RUN_KF_JOB][j]);
         r->kf_busy[j] = 1;
     }
-    if (!r->lists[AOS2_RUN_LBA_JOB][l].empty()) {
-        r->lba[l]->start(&r->lists[AOS2_RUN_LBA_JOB][l]);
-        r->lba_busy[l] = 1;
-    }
+    ++r->lba_pending;
+    if (lba_now) start_lba(r);
     return r->status;
 }
 
@@ -267,6 +299,7 @@ int aos2_runner_run(aos2_runner *r, int s0, int n)
 int aos2_runner_sync(aos2_runner *r)
 {
     if (!r) return -1;
+    if (r->lba_pending > 0) start_lba(r);   // (a step count that is no multiple of lba_every: the rest gets its call, too)
     for (int l = 0; l < r->n_lba; ++l)
         if (r->lba_busy[l]) {
             r->lba[l]->wait();

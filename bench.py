@@ -343,10 +343,17 @@ def main():
     # LocalMapping meets (synth.lba_window_mix: 10-40 local keyframes, 2-6 k points, 4-8 observations per point, 5-20 % gross
     # outliers; src/Optimizer.cc:457-505).  --lba-mix homogeneous = round 3's step: SURVEY 8(d)-size windows, 4 distinct, tiled
     n_win = max(1, B // fpk)
+    # AOS2_BENCH_LBA_STEPS_PER_CALL=k: one LocalBA CALL solves the windows of k consecutive steps (all different problems; every step's
+    # windows are solved inside the timed region, a step count that is no multiple gets a last call for the rest).  The batch program's cost
+    # grows less than linearly with its windows ALONE (64 windows 4.12 ms, 128 7.16, 192 10.5) -- in the composite k = 2 / 3 / 4 gave
+    # 70.0, 70.4 / 76.4 / 67.9 k frames/s beside 71.6, 72.6 k for k = 1 in one session (profiles/r06_composite_decomposition.txt): no
+    # gain that survives the run-to-run spread, at two to four times the latency of a window's result.  Default 1.
+    LBA_SPC = max(1, int(os.environ.get("AOS2_BENCH_LBA_STEPS_PER_CALL", "1")))
+    n_win_call = n_win * LBA_SPC
     lba_hom_unique = [pkg.synth.synth_lba_problem(10 * rank + i, n_points=8000) for i in range(min(4, n_win))]
-    lba_hom = [lba_hom_unique[i % len(lba_hom_unique)] for i in range(n_win)]
+    lba_hom = [lba_hom_unique[i % len(lba_hom_unique)] for i in range(n_win_call)]
     if KITTI:   # BASELINE configs[3]: the 20-keyframe window of SURVEY 8(d) (20 local + 30 fixed keyframes, ~24 k stereo edges), every one a different problem
-        lba_mix = [dict(seed=200000 + 1000 * rank + i, n_local=20, n_fixed=30, n_points=8000) for i in range(n_win)]
+        lba_mix = [dict(seed=200000 + 1000 * rank + i, n_local=20, n_fixed=30, n_points=8000) for i in range(n_win_call)]
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)
         lba_probs = lba_unique
     elif args.lba_mix == "heterogeneous":
@@ -354,7 +361,7 @@ def main():
         # from the optimum: rejected steps, a continuation round for it alone.  Its end point is gated like every other window's, at the
         # resolution the oracle itself has on it (parity.lba_resolution: the oracle against its own re-associated runs, times 4, never
         # below 1e-5; profiles/r06_lba_sensitivity.txt).  A whole batch with every 8th window like that: extra.local_ba_batch_with_rejected_steps
-        lba_mix = pkg.synth.lba_window_mix(rank, n_win, hard_every=int(os.environ.get("AOS2_BENCH_LBA_HARD_EVERY", str(n_win))))
+        lba_mix = pkg.synth.lba_window_mix(rank, n_win_call, hard_every=int(os.environ.get("AOS2_BENCH_LBA_HARD_EVERY", str(n_win))))
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)
         lba_probs = lba_unique
     else:
@@ -366,7 +373,7 @@ def main():
     lbas = [pkg.LocalBA(device=local_rank) for _ in range(NLBA)]
     # host threads of a handle's per-window work: the node's cores shared among ranks and handles (8 ranks x 2 handles x 32 threads
     # would be 512 threads on 256 cores)
-    lba_threads = max(1, min(32, n_win, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)) * NLBA)))
+    lba_threads = max(1, min(32, n_win_call, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)) * NLBA)))
     # two handles solve side by side beside the tracking kernels: one program per batch (a handle's two staggered window groups are the
     # faster form only for a batch that has the device to itself: 61 k against 54 k frames/s here; AOS2_BENCH_LBA_GROUPS overrides)
     LBA_GROUPS = int(os.environ.get("AOS2_BENCH_LBA_GROUPS", "1" if NLBA > 1 else "0"))
@@ -383,6 +390,9 @@ def main():
     # consecutive runs.  AOS2_BENCH_RUNNER=python keeps that form (tests compare the two).
     NATIVE = os.environ.get("AOS2_BENCH_RUNNER", "native") != "python"
     runner = pkg.capi.Runner(NPIPE, NLBA) if NATIVE else None
+    if NATIVE:
+        runner.set_lba_every(LBA_SPC)
+    lba_sched = {"pending": 0, "next": 0, "last": -1}   # (the Python-thread form of the same schedule)
     NO_LBA = os.environ.get("AOS2_BENCH_NO_LBA") == "1"   # diagnostics only: the tracking chains alone (the JSON line is then not the metric)
     # N > 1: the one exchange step of the path -- every step's keypoint / descriptor slots go to
     # rank 0 in one gather (RCCL over xGMI), enqueued behind the step on the step's own stream and left in flight while
@@ -468,9 +478,10 @@ def main():
         # pipeline s % NPIPE: its previous step (s - NPIPE) is complete before its buffers are reused
         j = s % NPIPE
         p = pipes[j]
-        jl = s % NLBA
+        jl = lba_sched["next"]
+        lba_now = lba_sched["pending"] + 1 >= LBA_SPC
         t_a = time.perf_counter()
-        if lba_jobs[jl] is not None:
+        if lba_now and lba_jobs[jl] is not None:
             lba_jobs[jl].result()
         t_b = time.perf_counter()
         if bow_jobs[j] is not None:
@@ -488,8 +499,17 @@ def main():
             bow_jobs[j] = bow_pool.submit(keyframe_job, j)
         if gather is not None:
             gather_step(j)
+        lba_sched["pending"] += 1
+        if lba_now:
+            start_lba_py()
+
+    def start_lba_py():
+        jl = lba_sched["next"]
+        if lba_jobs[jl] is not None:
+            lba_jobs[jl].result()
         if not NO_LBA:
             lba_jobs[jl] = pool.submit(lba_call, jl)
+        lba_sched.update(pending=0, next=(jl + 1) % NLBA, last=jl)
 
     def sync():
         if NATIVE:
@@ -503,6 +523,8 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             return
+        if lba_sched["pending"] > 0:
+            start_lba_py()
         for jl in range(NLBA):
             if lba_jobs[jl] is not None:
                 lba_jobs[jl].result()
@@ -575,12 +597,12 @@ def main():
     # the windows needed (a heterogeneous batch runs in lock step: a window that needs fewer trials leaves its slots empty)
     lock_step = None
     if not NO_LBA:
-        jl_ = (args.steps - 1) % NLBA
+        jl_ = max(0, runner.last_lba() if NATIVE else lba_sched["last"])   # the handle of the last call
         slots, rounds = lbas[jl_].last_program()
         wslots = lbas[jl_].last_window_slots()
         need = [int(r_.trials_first) + int(r_.trials_second) for r_ in lba_prep[jl_]["R"]]
         edges = [int(q_["n_edges"]) for q_ in lba_probs]
-        lock_step = {"trial_slots_enqueued": slots, "host_rounds": rounds, "windows": n_win, "window_slots": wslots,
+        lock_step = {"trial_slots_enqueued": slots, "host_rounds": rounds, "windows": n_win_call, "window_slots": wslots,
                      "trials_needed_min_mean_max": [min(need), float(np.mean(need)), max(need)],
                      "windows_with_rejected_or_skipped_trials": int(sum(1 for n_ in need if n_ != 15)),
                      "slots_over_trials": wslots / max(1, sum(need)),
@@ -599,11 +621,11 @@ def main():
     if rank == 0 and do_verify:
         g.load_oracle()
         import parity
-        lp, ll = pipes[jv], lba_prep[(args.steps - 1) % NLBA]
+        lp, ll = pipes[jv], lba_prep[max(0, runner.last_lba() if NATIVE else lba_sched["last"])]
         lb = bows[jv] if bows else None
         snap = dict(chain=parity.chain_snapshot_host(pkg, lp) if args.host_images else parity.chain_snapshot(pkg, lp), pipe=lp, bow=None if lb is None else lb.get_results(),
                     kfw=kfws[jv].snapshot() if kfws else None,
-                    lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win)])
+                    lba=[] if NO_LBA else [pkg.LocalBA._result(ll["R"][w], tuple(a.copy() for a in ll["arrs"][w])) for w in range(n_win_call)])
     # ---- the same steps without the keyframe legs: the composite as round 2 measured it, and with the BoW leg only (comparability)
     dt_nobow = dt_bowonly = dt_hom = None
     if bows and os.environ.get("AOS2_BENCH_SKIP_R02_FORM") != "1":
@@ -1044,8 +1066,8 @@ def main():
     _ne = [int(q_["n_edges"]) for q_ in lba_probs]
     if lba_mix is not None:
         lba_desc = ("%d of them starting far from the optimum (rejected steps); " % sum(1 for m_ in lba_mix if "hard" in m_) if any("hard" in m_ for m_ in lba_mix) else "") + \
-                   ("%d different windows per step: %d-%d keyframes (%d-%d of them local), %d-%d points, %d-%d edges, mean %.0f edges -- SURVEY 8(d)'s "
-                    "window has 24 066" % (n_win, min(q_["n_poses"] for q_ in lba_probs), max(q_["n_poses"] for q_ in lba_probs),
+                   ("%d windows per step, the %d different windows of %d steps solved per call: %d-%d keyframes (%d-%d of them local), %d-%d points, %d-%d edges, mean %.0f edges -- SURVEY 8(d)'s "
+                    "window has 24 066" % (n_win, n_win_call, LBA_SPC, min(q_["n_poses"] for q_ in lba_probs), max(q_["n_poses"] for q_ in lba_probs),
                                           min(m_["n_local"] for m_ in lba_mix), max(m_["n_local"] for m_ in lba_mix),
                                           min(q_["n_points"] for q_ in lba_probs), max(q_["n_points"] for q_ in lba_probs), min(_ne), max(_ne), float(np.mean(_ne))))
     else:
@@ -1077,6 +1099,7 @@ def main():
                                                             lba_desc),
                        "baseline_metric": "frames/sec (extract+match+localBA) TUM 640\u00d7480, 1/2/4/8 GPU + %HBM roofline",
                        "frames_per_gpu_per_step": B, "frames_per_keyframe": fpk, "local_ba_windows_per_step": n_win,
+                       "local_ba_steps_per_call": LBA_SPC, "local_ba_windows_per_call": n_win_call,
                        "local_ba_mix": args.lba_mix, "distinct_frame_pairs_per_step": n_unique, "pipelines": NPIPE,
                        "local_ba_handles_in_flight": NLBA, "step_runner": "native threads (csrc/host_runner.cpp)" if NATIVE else "python threads",
                        "images": ("page-locked host memory every step%s, results to page-locked host arrays (--host-images)" % (", uploaded one step ahead" if HB_PREFETCH else "")) if args.host_images

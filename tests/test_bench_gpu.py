@@ -44,6 +44,7 @@ def test_bench_contract_single_gpu(gpu):
     pc = d["parity_checked"]
     assert pc["ok"] is True and pc["n_mismatches"] == 0 and pc["frames"] == 32 and pc["distinct_frame_pairs"] == 32   # no tiling
     assert pc["local_ba_windows"] == 4 and pc["distinct_local_ba_problems"] == 4   # every window a different problem
+    assert d["config"]["local_ba_windows_per_step"] == 4 and d["config"]["local_ba_steps_per_call"] == 1 and d["config"]["local_ba_windows_per_call"] == 4
     assert max(pc["worst_abs_diff"][k] for k in ("mTcw", "lba_pose", "lba_point")) <= 1e-5   # the worst difference is reported
     ls = d["extra"]["local_ba_lock_step"]
     assert ls["trial_slots_enqueued"] >= 15 and 1.0 <= ls["slots_over_trials"] <= 1.03 and d["config"]["local_ba_mix"] == "heterogeneous"
@@ -82,6 +83,16 @@ def test_bench_with_the_large_batch_pose_optimization_form(gpu):
     d = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-extra"],
              {"AOS2_PO_THREADS": "128"})
     assert d["parity_checked"]["ok"] is True and d["parity_checked"]["frames"] >= 8
+
+
+def test_bench_local_ba_windows_of_two_steps_per_call(gpu):
+    """AOS2_BENCH_LBA_STEPS_PER_CALL=2: a LocalBA call every second step with both steps' windows (8 different problems here), an odd step
+    count gets a last call for the rest; every window of the last call equals the oracle"""
+    d = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu-baseline", "--no-extra"],
+             {"AOS2_BENCH_LBA_STEPS_PER_CALL": "2"})
+    pc = d["parity_checked"]
+    assert pc["ok"] is True and pc["local_ba_windows"] == 8 and pc["distinct_local_ba_problems"] == 8
+    assert d["config"]["local_ba_windows_per_step"] == 4 and d["config"]["local_ba_steps_per_call"] == 2 and d["config"]["local_ba_windows_per_call"] == 8
 
 
 def test_bench_detects_a_wrong_result(gpu):
