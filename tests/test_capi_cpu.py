@@ -304,3 +304,30 @@ def test_reference_signature_classes_compile_and_link(pkg, tmp_path, flags):
     stub = open(os.path.join(ROOT, "tests", "cpp", "refstub", "slam_stub.h")).read()
     assert "GetMaxDistance()" not in stub and "GetMinDistance()" not in stub
     assert re.search(r"protected:[^}]*mfMinDistance[^}]*mMutexPos", stub, flags=re.S)
+
+
+def test_refcheck_project_configures_and_says_what_it_cannot_build(tmp_path):
+    """tools/refcheck (the reference's own g2o + ORBextractor.cc + ORBmatcher.cc compiled untouched next to the oracle: the route to a
+    PINNED oracle) is a one-command affair on a machine that has OpenCV and Eigen3.  Here it must configure
+    cleanly and say what is missing -- this image has neither library (/root/reference/CMakeLists.txt:33-41 asks for both), so no
+    target is generated and nothing of the reference is built or stood in for."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None:
+        pytest.skip("no cmake on this box")
+    r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "tools", "refcheck"), "-B", str(tmp_path / "b"), "-DAOS2_REFERENCE_DIR=" + str(tmp_path / "no_checkout")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = r.stdout + r.stderr
+    have_cv = "OpenCV not found" not in out
+    have_eigen = "refcheck_lba is not built" not in out
+    assert "Configuring done" in out
+    if not have_cv:
+        assert "refcheck: OpenCV not found" in out
+    if not have_eigen:
+        assert "refcheck: Eigen3 or" in out
+    # the sources the project would compile exist and name the switches a pinned run reports per convention
+    src = open(os.path.join(ROOT, "tools", "refcheck", "refcheck_extractor.cpp")).read()
+    assert "orc_set_tiebreak_mode" in src and "orc_set_trig_mode" in src
+    assert "resolution" in open(os.path.join(ROOT, "tools", "refcheck", "refcheck_lba.cpp")).read()
+    assert "lba_resolution" in open(os.path.join(ROOT, "tools", "refcheck", "dump_cases.py")).read()

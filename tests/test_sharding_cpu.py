@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo run of the frame sharding + slot gather used by bench.py."""
+"""N>1 path on CPU: world_size-2 and world_size-8 gloo runs of the frame sharding + slot gather used by bench.py."""
 import os
 import socket
 import sys
@@ -59,18 +59,31 @@ def _worker(rank, world, port, n_frames, cap, q):
     q.put((rank, bool(ok)))
 
 
-@pytest.mark.parametrize("n_frames", [8, 5])
-def test_world2_gather(n_frames):
+def _run_world(world, n_frames, cap=50):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, 50, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, cap, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in procs)
+    res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == {0: True, 1: True}
+    return res
+
+
+@pytest.mark.parametrize("n_frames", [8, 5])
+def test_world2_gather(n_frames):
+    assert _run_world(2, n_frames) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("n_frames", [5, 8, 13])
+def test_world8_gather_with_ragged_frame_counts(n_frames):
+    """BASELINE configs[4] at its full rank count (8 processes, gloo): 8 frames = one per rank; 5 frames leave three ranks with an
+    empty shard (their padded, zero-count slot still takes part in the collective); 13 frames give five ranks two frames and three
+    ranks one.  Rank 0 reassembles every frame's keypoints and descriptors bit for bit in frame order, and the max-over-ranks
+    reduction bench.py times with sees every rank."""
+    assert _run_world(8, n_frames) == {r: True for r in range(8)}
 
 
 def test_shard_range_partitions(pkg):

@@ -20,12 +20,14 @@ import bundle_io               # noqa: E402
 def main(out):
     os.makedirs(out, exist_ok=True)
     pkg, O = g.load_package(), g.load_oracle()
+    import parity   # oracle/parity.py
     S = pkg.synth
     cases = [dict(seed=1, n_local=3, n_fixed=2, n_points=60, stereo_frac=0.5), dict(seed=2, n_local=6, n_fixed=4, n_points=400, stereo_frac=0.0),
              dict(seed=4, n_local=5, n_fixed=0, n_points=300, include_kf0=True), dict(seed=0), dict(seed=3, include_kf0=True, outlier_frac=0.15)]
     cases += S.lba_window_mix(0, 4)
+    cases += [m for m in S.lba_window_mix(0, 16, hard_every=8) if "hard" in m]   # two windows that start far off the optimum (rejected steps)
     for i, kw in enumerate(cases):
-        p = S.synth_lba_problem(**kw)
+        p = S._lba_from_kwargs(kw)
         w = O.lba_solve(p)
         arrs = {k: p[k] for k in ("pose_Tcw", "pose_fixed", "pose_id", "point_xyz", "point_id", "edge_pose", "edge_point", "edge_obs", "edge_stereo", "edge_inv_sigma2")}
         arrs["pose_id"] = np.asarray(p["pose_id"], np.int64)
@@ -33,8 +35,13 @@ def main(out):
         arrs["cam"] = np.array([p["fx"], p["fy"], p["cx"], p["cy"], p["bf"]], np.float32)
         arrs["out_pose_Tcw"], arrs["out_point_xyz"], arrs["out_outlier"] = w["pose_Tcw"], w["point_xyz"], w["edge_outlier"].astype(np.uint8)
         arrs["out_iters"] = np.asarray(w["iters"], np.int32)
+        # the oracle's own resolution on this window (parity.lba_resolution: its re-associated runs against itself) -- a pinned run's
+        # difference from out_* is a disagreement only beyond this
+        res = parity.lba_resolution(p, want=w)
+        arrs["resolution"] = np.array([res["pose"], res["point"], 1.0 if res["decisions_equal"] else 0.0], np.float64)
         bundle_io.save(os.path.join(out, f"lba_{i}.bundle"), arrs)
-        print(f"lba_{i}: {p['n_poses']} keyframes, {p['n_points']} points, {p['n_edges']} edges, oracle iterations {w['iters']}")
+        print(f"lba_{i}: {p['n_poses']} keyframes, {p['n_points']} points, {p['n_edges']} edges, oracle iterations {w['iters']}, "
+              f"oracle against its re-associated runs: poses {res['pose']:.2e} points {res['point']:.2e}")
     rng = np.random.default_rng(5)
     a, b = S.synth_descriptors(rng, 4096), S.synth_descriptors(rng, 4096)
     bundle_io.save(os.path.join(out, "dist.bundle"), dict(a=a, b=b, dist=np.array([O.descriptor_distance(x, y) for x, y in zip(a, b)], np.int32)))

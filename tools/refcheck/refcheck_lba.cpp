@@ -134,9 +134,17 @@ static int run_case(const char *path)
         for (int d = 0; d < 3; ++d) worstX = std::max(worstX, std::fabs((double)(float)X(d) - (double)oX[3 * j + d]));
     }
     for (int k = 0; k < n_edges; ++k) dout += outlier[k] != oO[k];
-    const bool ok = worstT <= 1e-5 && worstX <= 1e-5 && dout == 0;
-    printf("%s: %d keyframes, %d points, %d edges: poses off by %.3g, points by %.3g, %d outlier flags differ -> %s\n", path, n_poses,
-           n_points, n_edges, worstT, worstX, dout, ok ? "ok" : "DIFFERENT");
+    // the bar: 1e-5, or 4 x the spread of the oracle against its own re-associated runs on THIS window where that is larger (a window that
+    // starts far from the optimum; dump_cases.py stores it as "resolution": oracle/parity.py lba_resolution) -- the rule of the tests
+    double tolT = 1e-5, tolX = 1e-5;
+    if (B.has("resolution")) {
+        const double *res = B["resolution"].as<double>();
+        tolT = std::max(tolT, 4.0 * res[0]);
+        tolX = std::max(tolX, 4.0 * res[1]);
+    }
+    const bool ok = worstT <= tolT && worstX <= tolX && dout == 0;
+    printf("%s: %d keyframes, %d points, %d edges: poses off by %.3g (bar %.3g), points by %.3g (bar %.3g), %d outlier flags differ -> %s\n", path,
+           n_poses, n_points, n_edges, worstT, tolT, worstX, tolX, dout, ok ? "ok" : "DIFFERENT");
     return ok ? 0 : 1;
 }
 
