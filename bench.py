@@ -1159,7 +1159,7 @@ def main():
         try:
             if KITTI:
                 raise LookupError("the committed PMC passes are of the TUM workload")
-            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_extractor_counters.json", "r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
+            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_extractor_counters.json", "r05_extractor_counters.json", "r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
             pc = json.load(open(cpath))
             fc, cal = pc["fast_cells_kernel"], pc["calibration"]
             per_frame = (fc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + fc["WRITE_SIZE_KB"] * cal["WRITE_SIZE_factor"]) * 1024.0 / pc["batch"]
@@ -1169,6 +1169,16 @@ def main():
             out["roofline"]["traffic_profiled"] = {
                 "bytes_per_launch": per_frame * B, "over_algorithmic": per_frame * B / fast_bytes,
                 "source": pc["source"], "correction": "FETCH_SIZE x %.3f (unaligned 32-bit reads), WRITE_SIZE x 1.0" % cal["FETCH_SIZE_factor_unaligned_32bit"]}
+            dc = pc.get("describe_kernel")
+            if dc and dc.get("FETCH_SIZE_KB"):   # describe_kernel's counter traffic beside its algorithmic bytes (1.7-1.9 x)
+                d_lo = (dc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + dc["WRITE_SIZE_KB"]) * 1024.0 / pc["batch"] * B
+                d_hi = (dc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_aligned"] + dc["WRITE_SIZE_KB"]) * 1024.0 / pc["batch"] * B
+                row = out["roofline_other"][0]
+                row["traffic"] = d_hi
+                row["traffic_profiled"] = {"bytes_per_launch_low_high": [d_lo, d_hi], "over_algorithmic": [d_lo / row["algorithmic_bytes_per_launch"], d_hi / row["algorithmic_bytes_per_launch"]],
+                                           "source": pc["source"], "note": "FETCH_SIZE x 1.78 (all reads unaligned 4-byte) .. x 2.0 (all aligned) + WRITE_SIZE; the kernel stages a 43 x 43 patch "
+                                                                           "(1849 B) per keypoint where SURVEY 8(d) counts 749 + 512 B of it: 1.40 x by construction, the rest is sector granularity "
+                                                                           "(a 43-byte patch row touches two or three 32-byte sectors)"}
             insts = fc["SQ_INSTS_VALU"] / pc["batch"] * B
             clock_ghz = 2.4   # the engine clock the kernels run at (GRBM_GUI_ACTIVE / 8 / kernel time of the profiled pass gives 2.25-2.4)
             # issue cost of the kernel's instruction mix: add / sub / logic / mov / right shifts / bitop3 issue in 2 cycles per wave64
@@ -1191,7 +1201,7 @@ def main():
         except Exception as exc:
             out["roofline"]["traffic_profiled"] = {"error": repr(exc)}
         try:   # the LocalBA kernels: SURVEY 8(d)'s bytes per LM iteration for the batch of this run, times and counters of the committed passes
-            lpath = os.path.join(ROOT, "profiles", "r05_lba_counters.json")
+            lpath = next((q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_lba_counters.json", "r05_lba_counters.json")) if os.path.exists(q)), "")
             if not NO_LBA and not KITTI and args.lba_mix == "heterogeneous" and os.path.exists(lpath):
                 lc = json.load(open(lpath))
                 Np = sum(int((q_["pose_fixed"] == 0).sum()) for q_ in lba_probs); Nf = sum(int((q_["pose_fixed"] != 0).sum()) for q_ in lba_probs)
@@ -1203,10 +1213,13 @@ def main():
                 for kn, ab in alg.items():
                     kc = lc["kernels"].get(kn)
                     if kc and kc.get("kernel_us"):
+                        tb = kc.get("hbm_bytes_per_launch")
+                        moved = float(tb) if tb else ab   # the fraction is what the kernel MOVES (counters) over its time; SURVEY's stored-block bytes beside it
                         out["roofline_other"].append({
                             "kernel": kn, "bound": "hbm", "kernel_ms": kc["kernel_us"] * 1e-3, "algorithmic_bytes_per_launch": ab,
-                            "achieved": ab / (kc["kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": ab / (kc["kernel_us"] * 1e-6) / 1e9 / 8000.0,
-                            "traffic": kc.get("hbm_bytes_per_launch"),
+                            "achieved": moved / (kc["kernel_us"] * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": moved / (kc["kernel_us"] * 1e-6) / 1e9 / 8000.0,
+                            "frac_on_survey_stored_block_bytes": ab / (kc["kernel_us"] * 1e-6) / 1e9 / 8000.0,
+                            "traffic": tb,
                             "note": "SURVEY 8(d)'s bytes per LM iteration with the stored-block layout it assumed, summed over the %d windows of this run's batch "
                                     "(the kernels keep a 32-byte record per edge instead of the 144-byte block, so the counters' traffic is below it); "
                                     "kernel time and counters: %s -- the batch alone on the device; latency / request-rate bound, not bandwidth bound" % (n_win, lc["source"][:60])})
