@@ -1157,9 +1157,10 @@ def main():
         # counters of the same kernel from the committed rocprofv3 --pmc passes (B = 512 > Infinity Cache; calibrated against
         # 1 GiB copies): NOT measured in this run -- `roofline.traffic` stays null; the profiled figures are given beside it
         try:
-            if KITTI:
-                raise LookupError("the committed PMC passes are of the TUM workload")
-            cpath = next(q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_extractor_counters.json", "r05_extractor_counters.json", "r03_extractor_counters.json", "r02_extractor_counters.json")) if os.path.exists(q))
+            cnames = ("r06_extractor_counters_kitti.json",) if KITTI else ("r06_extractor_counters.json", "r05_extractor_counters.json", "r03_extractor_counters.json", "r02_extractor_counters.json")
+            cpath = next((q for q in (os.path.join(ROOT, "profiles", n_) for n_ in cnames) if os.path.exists(q)), None)
+            if cpath is None:
+                raise LookupError("no committed PMC passes of this workload's extraction")
             pc = json.load(open(cpath))
             fc, cal = pc["fast_cells_kernel"], pc["calibration"]
             per_frame = (fc["FETCH_SIZE_KB"] * cal["FETCH_SIZE_factor_unaligned_32bit"] + fc["WRITE_SIZE_KB"] * cal["WRITE_SIZE_factor"]) * 1024.0 / pc["batch"]

@@ -1,11 +1,11 @@
-"""profiles/r05_lba_counters.json from the PMC summary of the mixed 64-window LocalBA batch (tools/pmc_summary2.py output: FETCH_SIZE /
+"""profiles/r06_lba_counters.json from the PMC summary of the mixed 64-window LocalBA batch (tools/pmc_summary2.py output: FETCH_SIZE /
 WRITE_SIZE in KB per launch, the MFMA counters) and the kernel stats of the same command:
     python tools/pmc_lba_digest.py <pmc_lba.txt> <lba_het64_kernel_stats.csv>"""
 import csv, json, re, sys
 txt = open(sys.argv[1]).read()
 stats = {r["Name"].split("(")[0].split("::")[-1].replace("void ", ""): (float(r["AverageNs"]) / 1e3, int(r["Calls"])) for r in csv.DictReader(open(sys.argv[2]))}
-out = {"source": "profiles/r05_pmc_lba.txt + profiles/r05_lba_het64_kernel_stats.csv (rocprofv3 passes of LBA_MIX=het LBA_N=64 tools/gpu_lba_mix_prof.py, "
-                 "tools/prof_r05.sh); FETCH_SIZE / WRITE_SIZE in KB per launch, corrected like the extractor's (profiles/r02_hbm_counter_calibration.txt: "
+out = {"source": "profiles/r06_pmc_lba.txt + profiles/r06_lba_het64_kernel_stats.csv (rocprofv3 passes of LBA_MIX=het LBA_N=64 tools/gpu_lba_mix_prof.py, "
+                 "tools/prof_r06.sh); FETCH_SIZE / WRITE_SIZE in KB per launch, corrected like the extractor's (profiles/r02_hbm_counter_calibration.txt: "
                  "FETCH_SIZE reports half the bytes of aligned reads)", "windows": 64, "kernels": {}}
 for k in ("k_schur", "k_points_walk", "k_lin<true>", "k_ldlt_reg", "k_ldlt_dev", "k_lm_init", "k_transition", "k_prepare", "k_final"):
     d = {}

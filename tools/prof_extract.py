@@ -1,5 +1,5 @@
-"""ORBextractor::operator() alone over B resident 640x480 frames, one stream (AOS2_CHUNKS=1), for rocprofv3 passes:
-    rocprofv3 --kernel-trace --stats ... -- python tools/prof_extract.py 512
+"""ORBextractor::operator() alone over B resident frames (640x480; `kitti` as second argument: 1241x376, 2000 features), one stream (AOS2_CHUNKS=1), for rocprofv3 passes:
+    rocprofv3 --kernel-trace --stats ... -- python tools/prof_extract.py 512 [kitti]
     rocprofv3 --kernel-trace --pmc FETCH_SIZE ... (WRITE_SIZE, SQ_* in passes of their own)
 B = 512: pyramids + candidate slots of a batch = 2 x the 256 MiB Infinity Cache."""
 import os, sys
@@ -9,10 +9,11 @@ import numpy as np, torch
 import __graft_entry__ as g
 pkg = g.load_package()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-W, H = 640, 480
+CFG = pkg.synth.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "tum"]   # "kitti": 1241 x 376, 2000 features (one eye per image)
+W, H = CFG["w"], CFG["h"]
 base = pkg.synth.synth_batch(10_000, 32, W, H)
 d = torch.from_numpy(np.concatenate([base] * (B // 32 + 1))[:B]).cuda()
-ex = pkg.Extractor(nfeatures=1000)
+ex = pkg.Extractor(nfeatures=CFG["nfeatures"])
 cap = ex.max_keypoints
 k = torch.empty((B, cap, 7), dtype=torch.float32, device="cuda")
 ds = torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda")
