@@ -107,6 +107,7 @@ struct aos2_extractor {
     bool host_octree = false;
     int oct_lds = 0;                     // LDS bytes per octree job (0 = global-scratch path only)
     OctImageLayout oct_image = {};       // total > 0: one workgroup per image with per-level LDS slices
+    OctImageLayout oct_pair = {};        // total > 0: two levels per workgroup for batches of >= 8 images (extractor_kernels.h)
     int host_threads = 8;
 
     bool dev_ready = false;
@@ -510,6 +511,10 @@ static int init_device(aos2_extractor *e)
         (void)hipGetLastError();
         e->oct_image.total = 0;  // the runtime refuses that much LDS: keep the per-job kernel
     }
+    if (e->oct_pair.total > 0 && prepare_octree_pair_kernel(e->oct_pair.total) != 0) {
+        (void)hipGetLastError();
+        e->oct_pair.total = 0;
+    }
     int r = upload_constants(k_pattern, e->umax, e->gauss7, e->stream);
     if (r != 0) {
         set_error("constant upload failed: %s", hipGetErrorString((hipError_t)r));
@@ -778,6 +783,9 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
             if (e->oct_image.total > 0)
                 launch_octree_image(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
                                     sel_cnt, e->cap_level, e->oct_image, s);
+            else if (e->oct_pair.total > 0 && nb >= 8 && !getenv("AOS2_OCT_GROUP_LEVELS"))   // (fewer images: the helper-wave form of the per-job kernel)
+                launch_octree_pairs(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
+                                    sel_cnt, e->cap_level, e->oct_pair, s);
             else
                 launch_octree(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level, sel_cnt,
                               e->cap_level, e->oct_lds, s);
@@ -974,6 +982,28 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
                 off += bytes;
             }
             e->oct_image.total = off <= 160 * 1024 ? off : 0;
+        }
+        // Default for batches: level g paired with level nlevels - 1 - g in one workgroup, each job in a slice of its own size
+        // (AOS2_OCT_PAIR=0: one job per workgroup with the level-0 reservation, the form of rounds 1-5 and of calls of < 8 images).
+        const char *vp = getenv("AOS2_OCT_PAIR");
+        if (e->oct_lds > 0 && nlevels >= 2 && nlevels <= 16 && !(vp && atoi(vp) == 0)) {
+            int bytes[16], total = 0;
+            for (int l = 0; l < nlevels; ++l) {
+                const int nl = e->mnFeaturesPerLevel[l];
+                bytes[l] = (int)((oct_lds_bytes(8 * nl + (l == 0 ? 256 : 128), nl) + 255) & ~(size_t)255);
+                if (bytes[l] > e->oct_lds) bytes[l] = (e->oct_lds + 255) & ~255;   // (never more than the per-job form takes: larger jobs use the global scratch either way)
+            }
+            for (int g2 = 0; g2 < (nlevels + 1) / 2; ++g2) {
+                const int la = g2, lb = nlevels - 1 - g2;
+                e->oct_pair.off[la] = 0; e->oct_pair.bytes[la] = bytes[la];
+                int sum = bytes[la];
+                if (lb != la) {
+                    e->oct_pair.off[lb] = bytes[la]; e->oct_pair.bytes[lb] = bytes[lb];
+                    sum += bytes[lb];
+                }
+                total = std::max(total, sum);
+            }
+            e->oct_pair.total = total <= 160 * 1024 ? total : 0;
         }
     }
     const unsigned hc = std::thread::hardware_concurrency();

@@ -86,6 +86,13 @@ struct OctImageLayout {
     int total;
 };
 int prepare_octree_image_kernel(int total_lds);
+// Two levels per workgroup (level g and level n_levels - 1 - g: the largest with the smallest), a wave and an LDS slice of its own size
+// each: OctImageLayout::off[l] is level l's offset INSIDE its workgroup, total the largest pair.  The per-job kernel reserves the
+// level-0 size for every level; the pairs hold 1.3-1.6 x as many jobs per compute unit in workgroups no larger than two level-0 jobs.
+int prepare_octree_pair_kernel(int total_lds);
+void launch_octree_pairs(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
+                         int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                         int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st);
 void launch_octree_image(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
                          int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
                          int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st);

@@ -808,6 +808,22 @@ __global__ __launch_bounds__(1024) void octree_image_kernel(uint32_t *__restrict
                       oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
 }
 
+// two levels per workgroup: wave 0 = level g, wave 1 = level n_levels - 1 - g (extractor_kernels.h); jobs stay independent
+__global__ __launch_bounds__(128) void octree_pair_kernel(uint32_t *__restrict__ dense, size_t dense_stride,
+                              OctGather gather, const LevelDev *__restrict__ levels,
+                              int n_levels, int batch, OctDevScratch scr, uint32_t *__restrict__ sel, size_t sel_stride,
+                              int32_t *__restrict__ sel_level_cnt, int cap_level, OctImageLayout lay)
+{
+    extern __shared__ uint32_t oct_lds[];
+    __builtin_amdgcn_s_setprio(3);   // (like octree_kernel: few long serial jobs beside other streams' VALU-bound waves)
+    const int g = blockIdx.x / batch, b = blockIdx.x - g * batch;   // group-major: the pairs with the long level-0 jobs start first
+    const int wave = threadIdx.x >> 6;
+    const int l = wave == 0 ? g : n_levels - 1 - g;
+    if (wave == 1 && l == g) return;   // (odd level count: the middle level is alone)
+    octree_job<false>(b, l, dense, dense_stride, gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level,
+                      oct_lds + (lay.off[l] >> 2), lay.bytes[l]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Orientation (IC_Angle, :77-104) + 7x7 Gaussian blur (cv::GaussianBlur sigma 2, :1085-1086)
 // + steered rBRIEF (computeOrbDescriptor, :108-147), one wave per DK consecutive keypoints.
@@ -1649,6 +1665,19 @@ void launch_octree_image(uint32_t *dense, size_t dense_stride, const OctGather &
 {
     hipLaunchKernelGGL(octree_image_kernel, dim3(batch), dim3(64 * n_levels), (size_t)lay.total, st, dense, dense_stride,
                        gather, levels, n_levels, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
+}
+
+int prepare_octree_pair_kernel(int total_lds)
+{
+    return (int)hipFuncSetAttribute((const void *)octree_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, total_lds);
+}
+
+void launch_octree_pairs(uint32_t *dense, size_t dense_stride, const OctGather &gather, const LevelDev *levels,
+                         int n_levels, int batch, const OctDevScratch &scr, uint32_t *sel, size_t sel_stride,
+                         int32_t *sel_level_cnt, int cap_level, const OctImageLayout &lay, hipStream_t st)
+{
+    hipLaunchKernelGGL(octree_pair_kernel, dim3(batch * ((n_levels + 1) / 2)), dim3(128), (size_t)lay.total, st, dense, dense_stride,
+                       gather, levels, n_levels, batch, scr, sel, sel_stride, sel_level_cnt, cap_level, lay);
 }
 
 // blurred planes of one image: level 0 first (pitch = width rounded up to 16), then the levels >= 1 at their pyramid offsets

@@ -3027,7 +3027,8 @@ int aos2_lba_solve_batch(aos2_lba_t *s, const aos2_lba_problem_t *problems, aos2
         TaskLists TC;
         build_tasks(todo, [](int k) { return k; }, TC);
         size_t tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
-        if (sizeof(LbaWin) * todo.size() + tc_bytes > cont_bytes) {   // (the dealing is not monotone on subsets: should one pad past the bound,
+        static const bool force_one_queue = getenv("AOS2_LBA_CONT_ONE_QUEUE") != nullptr;   // (test hook: the fallback below on every continuation)
+        if (force_one_queue || sizeof(LbaWin) * todo.size() + tc_bytes > cont_bytes) {   // (the dealing is not monotone on subsets: should one pad past the bound,
             build_tasks(todo, [](int k) { return k; }, TC, true);      //  one unpadded queue always fits -- its length is the subset's sum)
             tc_bytes = sizeof(SchurTask) * (TC.schur.size() + TC.pts.size() + TC.lin.size());
         }

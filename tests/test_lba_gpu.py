@@ -600,3 +600,18 @@ def test_lba_continuation_lists_larger_than_the_first_rounds(pkg, gpu, groups):
     assert rounds >= 2 and rejected[0] and sum(rejected) >= 9, (rounds, [(r["iters"], r["trials"]) for r in batch])
     for p, got in zip(probs, batch):
         assert got["status"] == 0 and _same(got, pkg.LocalBA().LocalBundleAdjustment(p))
+    if groups == 2:
+        # a continuation whose padded list would not fit falls back to ONE unpadded queue (AOS2_LBA_CONT_ONE_QUEUE forces that path: the
+        # static is read at the first continuation of the process, so this runs in a child): the same bits
+        import subprocess, sys, pickle, tempfile
+        with tempfile.TemporaryDirectory() as d:
+            pickle.dump(probs, open(os.path.join(d, "p.pkl"), "wb"))
+            code = ("import sys, pickle; sys.path.insert(0, %r); import __graft_entry__ as g; pkg = g.load_package(); "
+                    "probs = pickle.load(open(%r, 'rb')); ba = pkg.LocalBA(); ba.set_window_groups(2); r = ba.LocalBundleAdjustmentBatch(probs); "
+                    "pickle.dump([(x['pose_Tcw'], x['point_xyz'], x['edge_outlier'], x['iters'], x['trials']) for x in r], open(%r, 'wb'))"
+                    % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(d, "p.pkl"), os.path.join(d, "r.pkl")))
+            subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, AOS2_LBA_CONT_ONE_QUEUE="1"))
+            forced = pickle.load(open(os.path.join(d, "r.pkl"), "rb"))
+        for got, f in zip(batch, forced):
+            assert got["pose_Tcw"].tobytes() == f[0].tobytes() and got["point_xyz"].tobytes() == f[1].tobytes() and (got["edge_outlier"] == f[2]).all()
+            assert tuple(got["iters"]) == tuple(f[3]) and tuple(got["trials"]) == tuple(f[4])
