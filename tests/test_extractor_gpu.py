@@ -147,6 +147,29 @@ def test_octree_jobs_with_helper_waves_equal_one_wave_jobs(pkg, oracle, gpu, mon
     monkeypatch.delenv("AOS2_OCT_GROUP_LEVELS")
 
 
+@pytest.mark.parametrize("cfg", [dict(nfeatures=1000, nlevels=8), dict(nfeatures=2000, nlevels=8, w=1241, h=376), dict(nfeatures=700, nlevels=5),
+                                 dict(nfeatures=300, nlevels=2), dict(nfeatures=3000, nlevels=7, scale_factor=1.35), dict(nfeatures=500, nlevels=1)])
+def test_octree_pairs_equal_one_job_per_workgroup(pkg, oracle, gpu, monkeypatch, cfg):
+    """Batches of >= 8 images run the octree with TWO levels per workgroup (level g with level n - 1 - g, each job in an LDS slice of its
+    own size; an odd level count leaves the middle level alone, one level keeps the per-job kernel): the same keypoints and descriptors
+    bit for bit as the per-job kernel (AOS2_OCT_PAIR=0) and the oracle -- textured frames, a saturated-noise frame whose level-0 job
+    exceeds its slice (global-scratch rerun), a low-contrast one -- and with a small LDS budget that sends most jobs to the global path."""
+    cfg = dict(cfg)
+    w, h = cfg.pop("w", 640), cfg.pop("h", 480)
+    rng = np.random.default_rng(3)
+    imgs = [pkg.synth.synth_image(500 + i, w, h) for i in range(7)]
+    imgs += [(rng.integers(0, 2, (h, w)) * 255).astype(np.uint8), (pkg.synth.synth_image(520, w, h) // 6 + 100).astype(np.uint8)]
+    batch = np.stack(imgs)
+    want = [oracle.Extractor(**cfg).extract(im) for im in imgs]
+    got = pkg.Extractor(**cfg).extract_batch(batch)
+    assert all(same(a, b) for a, b in zip(got, want))
+    monkeypatch.setenv("AOS2_OCT_PAIR", "0")
+    assert all(same(a, b) for a, b in zip(pkg.Extractor(**cfg).extract_batch(batch), want))
+    monkeypatch.delenv("AOS2_OCT_PAIR")
+    monkeypatch.setenv("AOS2_OCT_LDS", "6000")
+    assert all(same(a, b) for a, b in zip(pkg.Extractor(**cfg).extract_batch(batch), want))
+
+
 def test_both_pyramid_forms_give_the_same_planes(pkg, oracle, gpu, monkeypatch):
     """A few frames per call build the whole pyramid in ONE launch (tiles walk the levels through LDS), batches use one
     launch per level: same planes bit for bit (and equal to the oracle's), for several geometries incl. ragged tile edges;

@@ -50,9 +50,10 @@ for c in range(n_cases):
     if not (same and pyr_ok):
         bad += 1
         print("MISMATCH case", c, (w, h, nf, sf, nl, ini, mn), "n", len(k), len(ok_), "pyr_ok", pyr_ok)
-    # a small batch of the same geometry through the batched path
+    # a batch of the same geometry through the batched path: three images (the per-job octree kernel with helper waves) or nine (two levels
+    # per workgroup: octree_pair_kernel), alternately
     if c % 4 == 0:
-        imgs = np.stack([img, img[::-1].copy(), np.roll(img, 7, axis=1)])
+        imgs = np.stack([img, img[::-1].copy(), np.roll(img, 7, axis=1)] + ([] if c % 8 else [np.roll(img, k, axis=(k & 1)) for k in (3, 8, 13, 18, 23, 28)]))
         res = ex.extract_batch(imgs)
         for im, (kb, db) in zip(imgs, res):
             k1, d1 = oe.extract(im)
