@@ -299,6 +299,29 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
     return as_u32(bright) | as_u32(dark);
 }
 
+// The same test on operands that are at most 255 (the even pixels, masked): hi - v > t or v - lo > t in SIGNED 16-bit lanes -- three packed
+// operations (two differences, their maximum) instead of the four saturating subtractions and the OR; a lane of the result is > t
+// exactly where compass2's lane is non-zero.
+typedef short ss2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t compass2_margin(us2_t v, us2_t a, us2_t b, us2_t c, us2_t d)
+{
+    const us2_t h1 = __builtin_elementwise_max(a, b), l1 = __builtin_elementwise_min(a, b);
+    const us2_t h2 = __builtin_elementwise_max(c, d), l2 = __builtin_elementwise_min(c, d);
+    const ss2_t hi = __builtin_bit_cast(ss2_t, __builtin_elementwise_min(h1, h2)), lo = __builtin_bit_cast(ss2_t, __builtin_elementwise_max(l1, l2));
+    const ss2_t sv = __builtin_bit_cast(ss2_t, v);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hi - sv, sv - lo));
+}
+
+// at + (bit `lane` of mask): v_addc_co_u32 takes its carry-in per lane from an SGPR pair -- one instruction where `at += p` is a
+// v_cndmask and an add
+__device__ __forceinline__ int add_lane_bit(int at, unsigned long long mask)
+{
+    int r;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(at), "s"(mask));
+    return r;
+}
+
 // (AOS2_FAST_ABL = 1..4, AOS2_DESC_ABL = 1..4: timing-only ablation builds of tools/build_abl_libs.sh -- the kernel stops after /
 // skips one phase, results are wrong by construction; DESIGN.md section 0, item 6 has the phase shares they gave.)
 // Phases per wave (one grid cell of one image, 64-thread workgroup = one wave, so list counters are
@@ -491,7 +514,11 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
                 const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
                 const uint32_t M = 0x00ff00ffu, MH = 0xff00ff00u;
+#ifdef AOS2_FAST_MARGIN
+                f_lo = compass2_margin(as_us2(C & M), as_us2(S & M), as_us2(N & M), as_us2(Eq & M), as_us2(Wq & M));
+#else
                 f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(N & M), as_us2(Eq & M), as_us2(Wq & M), T);
+#endif
                 // the odd pixels in the high byte of each 16-bit lane, the even pixels' bytes left below them as "fraction": a maximum / minimum of
                 // such lanes has the exact high byte, and with H, L, V the high bytes and t the threshold `(H - t) * 256 + g > V * 256 + g'` can
                 // differ from `H - t > V` only for H - t == V (the fractions g, g' < 256): a pixel exactly AT the threshold may survive to the
@@ -501,8 +528,14 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             }
             // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
+#ifdef AOS2_FAST_MARGIN
+            // (lanes of the margin are signed: > t where the pixel survives; a lane without an item holds 0)
+            const bool p0 = (int)(short)(f_lo & 0xffffu) > th, p2 = (int)f_lo > ((th << 16) | 0xffff);
+            const bool p1 = (f_hi & 0xffffu) != 0, p3 = (f_hi >> 16) != 0;
+#else
             const bool p0 = (f_lo & 0xffffu) != 0, p1 = (f_hi & 0xffffu) != 0;
             const bool p2 = (f_lo >> 16) != 0, p3 = (f_hi >> 16) != 0;
+#endif
             const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
             if ((b0 | b1 | b2 | b3) == 0ull) continue;
             // row-major list order (= cv::FAST's emission order, kept through scoring and NMS, so nothing is sorted
@@ -512,6 +545,15 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, (uint32_t)at));
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, (uint32_t)at));
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, (uint32_t)at));
+#ifdef AOS2_FAST_ADDC
+            if (p0) list1[at] = (uint16_t)pos0;
+            at = add_lane_bit(at, b0);
+            if (p1) list1[at] = (uint16_t)(pos0 + 1);
+            at = add_lane_bit(at, b1);
+            if (p2) list1[at] = (uint16_t)(pos0 + 2);
+            at = add_lane_bit(at, b2);
+            if (p3) list1[at] = (uint16_t)(pos0 + 3);
+#else
             if (p0) list1[at] = (uint16_t)pos0;
             at += p0;
             if (p1) list1[at] = (uint16_t)(pos0 + 1);
@@ -519,6 +561,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             if (p2) list1[at] = (uint16_t)(pos0 + 2);
             at += p2;
             if (p3) list1[at] = (uint16_t)(pos0 + 3);
+#endif
             n1 += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         }
         __syncthreads();
