@@ -301,7 +301,8 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
 
 // The same test on operands that are at most 255 (the even pixels, masked): hi - v > t or v - lo > t in SIGNED 16-bit lanes -- three packed
 // operations (two differences, their maximum) instead of the four saturating subtractions and the OR; a lane of the result is > t
-// exactly where compass2's lane is non-zero.
+// exactly where compass2's lane is non-zero.  (Round 6: 0.489 -> 0.478 ms per 512 frames of the profiling batch, same candidates;
+// -DAOS2_FAST_NO_MARGIN keeps the unsigned form for the even pixels too.)
 typedef short ss2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t compass2_margin(us2_t v, us2_t a, us2_t b, us2_t c, us2_t d)
 {
@@ -310,16 +311,6 @@ __device__ __forceinline__ uint32_t compass2_margin(us2_t v, us2_t a, us2_t b, u
     const ss2_t hi = __builtin_bit_cast(ss2_t, __builtin_elementwise_min(h1, h2)), lo = __builtin_bit_cast(ss2_t, __builtin_elementwise_max(l1, l2));
     const ss2_t sv = __builtin_bit_cast(ss2_t, v);
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hi - sv, sv - lo));
-}
-
-// at + (bit `lane` of mask): v_addc_co_u32 takes its carry-in per lane from an SGPR pair -- one instruction where `at += p` is a
-// v_cndmask and an add
-__device__ __forceinline__ int add_lane_bit(int at, unsigned long long mask)
-{
-    int r;
-    unsigned long long carry_out;
-    asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(at), "s"(mask));
-    return r;
 }
 
 // (AOS2_FAST_ABL = 1..4, AOS2_DESC_ABL = 1..4: timing-only ablation builds of tools/build_abl_libs.sh -- the kernel stops after /
@@ -489,6 +480,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         int n1 = 0;
         bool overflowed = false;   // the survivor list was emptied at least once: NMS walks the score map instead
         const us2_t T = {(unsigned short)th, (unsigned short)th};
+        (void)T;   // (the margin form of the even pixels compares with th directly)
         const us2_t TH = {(unsigned short)(th << 8), (unsigned short)(th << 8)};   // for operands scaled by 256 (th <= 255)
         const int nitems = nq * ch;
         for (int g0 = 0; g0 < nitems; g0 += 64) {
@@ -514,7 +506,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 const uint32_t Wq = __builtin_amdgcn_alignbyte(C, Wd, 1);               // columns x-3
                 const uint32_t Eq = __builtin_amdgcn_alignbyte(Ed, C, 3);               // columns x+3
                 const uint32_t M = 0x00ff00ffu, MH = 0xff00ff00u;
-#ifdef AOS2_FAST_MARGIN
+#ifndef AOS2_FAST_NO_MARGIN
                 f_lo = compass2_margin(as_us2(C & M), as_us2(S & M), as_us2(N & M), as_us2(Eq & M), as_us2(Wq & M));
 #else
                 f_lo = compass2(as_us2(C & M), as_us2(S & M), as_us2(N & M), as_us2(Eq & M), as_us2(Wq & M), T);
@@ -528,7 +520,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             }
             // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
-#ifdef AOS2_FAST_MARGIN
+#ifndef AOS2_FAST_NO_MARGIN
             // (lanes of the margin are signed: > t where the pixel survives; a lane without an item holds 0)
             const bool p0 = (int)(short)(f_lo & 0xffffu) > th, p2 = (int)f_lo > ((th << 16) | 0xffff);
             const bool p1 = (f_hi & 0xffffu) != 0, p3 = (f_hi >> 16) != 0;
@@ -545,15 +537,8 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, (uint32_t)at));
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, (uint32_t)at));
             at = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, (uint32_t)at));
-#ifdef AOS2_FAST_ADDC
-            if (p0) list1[at] = (uint16_t)pos0;
-            at = add_lane_bit(at, b0);
-            if (p1) list1[at] = (uint16_t)(pos0 + 1);
-            at = add_lane_bit(at, b1);
-            if (p2) list1[at] = (uint16_t)(pos0 + 2);
-            at = add_lane_bit(at, b2);
-            if (p3) list1[at] = (uint16_t)(pos0 + 3);
-#else
+            // (`at += p` through v_addc_co_u32 with the ballot as per-lane carry-in -- one instruction instead of v_cndmask + add -- was
+            // measured in round 6: -4 static instructions, 0.481 against 0.489 ms alone and nothing on top of the margin form: not kept)
             if (p0) list1[at] = (uint16_t)pos0;
             at += p0;
             if (p1) list1[at] = (uint16_t)(pos0 + 1);
@@ -561,7 +546,6 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
             if (p2) list1[at] = (uint16_t)(pos0 + 2);
             at += p2;
             if (p3) list1[at] = (uint16_t)(pos0 + 3);
-#endif
             n1 += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         }
         __syncthreads();
