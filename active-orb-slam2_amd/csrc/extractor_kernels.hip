@@ -299,18 +299,17 @@ __device__ __forceinline__ uint32_t compass2(us2_t v, us2_t a, us2_t b, us2_t c,
     return as_u32(bright) | as_u32(dark);
 }
 
-// The same test on operands that are at most 255 (the even pixels, masked): hi - v > t or v - lo > t in SIGNED 16-bit lanes -- three packed
-// operations (two differences, their maximum) instead of the four saturating subtractions and the OR; a lane of the result is > t
-// exactly where compass2's lane is non-zero.  (Round 6: 0.489 -> 0.478 ms per 512 frames of the profiling batch, same candidates;
-// -DAOS2_FAST_NO_MARGIN keeps the unsigned form for the even pixels too.)
-typedef short ss2_t __attribute__((ext_vector_type(2)));
+// The same test as a MARGIN: max(hi -sat v, v -sat lo) per 16-bit lane -- three packed operations (two saturating differences and their
+// maximum) instead of four saturating subtractions and an OR; a lane of the result is > T exactly where compass2's lane is non-zero
+// (hi - T > v <=> hi - v > T in integers; a difference that saturates to 0 is false on both sides), also for operands scaled by 256
+// with a fraction below them (T scaled alike).  Round 6: 0.489 -> 0.478 ms per 512 frames of the profiling batch with the even pixels
+// alone in this form, same candidates; -DAOS2_FAST_NO_MARGIN keeps compass2.
 __device__ __forceinline__ uint32_t compass2_margin(us2_t v, us2_t a, us2_t b, us2_t c, us2_t d)
 {
     const us2_t h1 = __builtin_elementwise_max(a, b), l1 = __builtin_elementwise_min(a, b);
     const us2_t h2 = __builtin_elementwise_max(c, d), l2 = __builtin_elementwise_min(c, d);
-    const ss2_t hi = __builtin_bit_cast(ss2_t, __builtin_elementwise_min(h1, h2)), lo = __builtin_bit_cast(ss2_t, __builtin_elementwise_max(l1, l2));
-    const ss2_t sv = __builtin_bit_cast(ss2_t, v);
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hi - sv, sv - lo));
+    const us2_t hi = __builtin_elementwise_min(h1, h2), lo = __builtin_elementwise_max(l1, l2);
+    return as_u32(__builtin_elementwise_max(__builtin_elementwise_sub_sat(hi, v), __builtin_elementwise_sub_sat(v, lo)));
 }
 
 // (AOS2_FAST_ABL = 1..4, AOS2_DESC_ABL = 1..4: timing-only ablation builds of tools/build_abl_libs.sh -- the kernel stops after /
@@ -480,8 +479,9 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
         int n1 = 0;
         bool overflowed = false;   // the survivor list was emptied at least once: NMS walks the score map instead
         const us2_t T = {(unsigned short)th, (unsigned short)th};
-        (void)T;   // (the margin form of the even pixels compares with th directly)
+        (void)T; (void)TH;   // (the margin form compares with th directly)
         const us2_t TH = {(unsigned short)(th << 8), (unsigned short)(th << 8)};   // for operands scaled by 256 (th <= 255)
+        (void)T; (void)TH;   // (the margin form compares with th / th << 8 directly)
         const int nitems = nq * ch;
         for (int g0 = 0; g0 < nitems; g0 += 64) {
             if (n1 > 0 && n1 + 256 > list_cap) {  // one iteration appends <= 256 entries (wave-uniform test)
@@ -516,14 +516,20 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(const uint8_t *__restric
                 // differ from `H - t > V` only for H - t == V (the fractions g, g' < 256): a pixel exactly AT the threshold may survive to the
                 // exact score, none above it is lost -- five mask instructions less
                 (void)MH;
+#ifndef AOS2_FAST_NO_MARGIN
+                f_hi = compass2_margin(as_us2(C), as_us2(S), as_us2(N), as_us2(Eq), as_us2(Wq));
+#else
                 f_hi = compass2(as_us2(C), as_us2(S), as_us2(N), as_us2(Eq), as_us2(Wq), TH);
+#endif
             }
             // (columns >= cw of the last quad are dropped in phase 2)
             const int x0 = 4 * qd;
 #ifndef AOS2_FAST_NO_MARGIN
-            // (lanes of the margin are signed: > t where the pixel survives; a lane without an item holds 0)
-            const bool p0 = (int)(short)(f_lo & 0xffffu) > th, p2 = (int)f_lo > ((th << 16) | 0xffff);
-            const bool p1 = (f_hi & 0xffffu) != 0, p3 = (f_hi >> 16) != 0;
+            // (a lane of the margin is > t -- t << 8 for the odd pixels, whose operands are scaled by 256 -- where the pixel survives; a lane
+            // without an item holds 0.  High lane: m.hi > t <=> m > (t << 16 | 0xffff) as unsigned 32-bit numbers)
+            const uint32_t th8 = (uint32_t)th << 8;
+            const bool p0 = (f_lo & 0xffffu) > (uint32_t)th, p2 = f_lo > (((uint32_t)th << 16) | 0xffffu);
+            const bool p1 = (f_hi & 0xffffu) > th8, p3 = f_hi > ((th8 << 16) | 0xffffu);
 #else
             const bool p0 = (f_lo & 0xffffu) != 0, p1 = (f_hi & 0xffffu) != 0;
             const bool p2 = (f_lo >> 16) != 0, p3 = (f_hi >> 16) != 0;
