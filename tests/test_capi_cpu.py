@@ -331,3 +331,17 @@ def test_refcheck_project_configures_and_says_what_it_cannot_build(tmp_path):
     assert "orc_set_tiebreak_mode" in src and "orc_set_trig_mode" in src
     assert "resolution" in open(os.path.join(ROOT, "tools", "refcheck", "refcheck_lba.cpp")).read()
     assert "lba_resolution" in open(os.path.join(ROOT, "tools", "refcheck", "dump_cases.py")).read()
+
+
+def test_lba_window_builder_on_a_hand_made_graph(tmp_path):
+    """aos2::LbaWindow (host/LbaWindow.h) without a GPU: optimised keyframes / map points / constant cameras / edges of a hand-made pointer
+    graph with bad keyframes, a bad point, the map's first keyframe, a stereo observation and observers outside the window come out as
+    src/Optimizer.cc:457-654 prescribes (edges by ascending KeyFrame::mnId: parity convention 2), and the reference's mnBA...ForKF
+    stamps are not touched (tests/cpp/lba_window_test.cpp)."""
+    import subprocess
+    exe = str(tmp_path / "lba_window_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "lba_window_test.cpp"),
+                           "-I", os.path.join(ROOT, "tests", "cpp", "refstub"), "-I", os.path.join(ROOT, "active-orb-slam2_amd", "host"),
+                           "-I", os.path.join(ROOT, "include"), "-o", exe])
+    out = subprocess.check_output([exe], text=True)
+    assert "lba_window_test ok: 5 keyframes (3 optimised), 3 points, 8 edges" in out
