@@ -359,7 +359,7 @@ def main():
     elif args.lba_mix == "heterogeneous":
         # One window of the timed, parity-checked step (the last of the batch; AOS2_BENCH_LBA_HARD_EVERY=k: every k-th, 0: none) starts far
         # from the optimum: rejected steps, a continuation round for it alone.  Its end point is gated like every other window's, at the
-        # resolution the oracle itself has on it (parity.lba_resolution: the oracle against its own re-associated runs, times 4, never
+        # resolution the oracle itself has on it (parity.lba_resolution: the oracle against its own re-associated runs, times parity.LBA_RESOLUTION_FACTOR = 4, never
         # below 1e-5; profiles/r06_lba_sensitivity.txt).  A whole batch with every 8th window like that: extra.local_ba_batch_with_rejected_steps
         lba_mix = pkg.synth.lba_window_mix(rank, n_win_call, hard_every=int(os.environ.get("AOS2_BENCH_LBA_HARD_EVERY", str(n_win))))
         lba_unique = pkg.synth.synth_lba_problems(lba_mix)

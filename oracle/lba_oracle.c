@@ -26,7 +26,8 @@
  * unknown first: another admissible ordering of linear_solver_eigen.h:94-124's factorisation); bit 1: every accumulation across
  * edges / landmarks / pivots (H blocks and b in buildSystem, the Schur products, the factorisation's dot products) is carried in
  * long double and rounded once.  0 = the oracle as tested. */
-static int g_lba_variant = 0;
+static _Thread_local int g_lba_variant = 0;   /* per THREAD: the checkers run oracle solves of different variants side by side (thread pools of
+                                                 * bench.py / tools), and a setter call and the solve it configures happen on one thread */
 void orc_set_lba_variant(int bits) { g_lba_variant = bits; }
 #define LBA_REVERSE_ELIMINATION 1
 #define LBA_EXTENDED_SUMS 2

@@ -523,5 +523,5 @@ def test_lba_resolution_of_the_oracle_against_itself(oracle, pkg):
     got = dict(status=0, iters=con["iters"], trials=(con["trials"], 0), pose_Tcw=con["pose_Tcw"], point_xyz=con["point_xyz"],
                edge_outlier=con["edge_outlier"], final_chi2=con["chi2_trace"][-1])
     assert parity.lba_mismatches(got, want, resolution=rh) == []
-    got["point_xyz"] = got["point_xyz"] + np.float32(4.1 * max(parity.TOL, rh["point"]))
+    got["point_xyz"] = got["point_xyz"] + np.float32((parity.LBA_RESOLUTION_FACTOR + 0.1) * max(parity.TOL, rh["point"]))
     assert parity.lba_mismatches(got, want, resolution=rh) != []
