@@ -783,7 +783,7 @@ static int enqueue_device(aos2_extractor *e, const uint8_t *d_imgs, int batch, i
             if (e->oct_image.total > 0)
                 launch_octree_image(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
                                     sel_cnt, e->cap_level, e->oct_image, s);
-            else if (e->oct_pair.total > 0 && nb >= 8 && !getenv("AOS2_OCT_GROUP_LEVELS"))   // (fewer images: the helper-wave form of the per-job kernel)
+            else if (e->oct_pair.total > 0 && nb >= 8)   // (fewer images: the helper-wave form of the per-job kernel)
                 launch_octree_pairs(dense, P.slot_total, gather, P.d_levels.p, L, nb, scr, sel, (size_t)L * e->cap_level,
                                     sel_cnt, e->cap_level, e->oct_pair, s);
             else
@@ -986,7 +986,7 @@ int aos2_extractor_create(int nfeatures, float scale_factor, int nlevels, int in
         // Default for batches: level g paired with level nlevels - 1 - g in one workgroup, each job in a slice of its own size
         // (AOS2_OCT_PAIR=0: one job per workgroup with the level-0 reservation, the form of rounds 1-5 and of calls of < 8 images).
         const char *vp = getenv("AOS2_OCT_PAIR");
-        if (e->oct_lds > 0 && nlevels >= 2 && nlevels <= 16 && !(vp && atoi(vp) == 0)) {
+        if (e->oct_lds > 0 && nlevels >= 2 && nlevels <= 16 && !(vp && atoi(vp) == 0) && !getenv("AOS2_OCT_GROUP_LEVELS")) {   // (that switch tests the per-job kernel's helper waves)
             int bytes[16], total = 0;
             for (int l = 0; l < nlevels; ++l) {
                 const int nl = e->mnFeaturesPerLevel[l];
